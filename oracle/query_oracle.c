@@ -1,0 +1,306 @@
+/*
+ * oracle/query_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Plain-C, single-threaded restatement of the reference's world-coordinate
+ * neural-point query (voxel table build -> ray march occupancy mask -> first-SR
+ * compaction -> layered k-NN -> empty-ray compaction).  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.
+ *
+ * PARITY UNPINNED: the reference's query stage is CUDA-C inside a Python string
+ * JIT-compiled by pycuda (needs nvcc + an NVIDIA device), it cannot be run in
+ * this image, and the reference ships no golden vector or test for it.  This
+ * restatement therefore follows the reference *source* line by line under one
+ * stated serial linearisation of its atomics (threads run in index order), and
+ * is cross-checked by independent brute-force properties in
+ * tests/test_query_oracle.py -- not by reference outputs.
+ *
+ * Reference: /root/reference/models/neural_points/query_point_indices_worldcoords.py
+ *   claim_occ                        :237-297   -> oq_build() pass 1
+ *   map_coor2occ                     :299-334   -> oq_build() pass 2
+ *   fill_occ2pnts                    :336-381   -> oq_build() pass 3
+ *   mask_raypos                      :384-408   -> oq_query() march
+ *   torch compaction                 :645-655   -> oq_query() first-SR rule
+ *   get_shadingloc                   :411-433   -> oq_query() sample_loc scatter
+ *   query_neigh_along_ray_layered    :436-522   -> knn_one_sample()
+ *   tail compaction                  :705-711   -> oq_query() second compaction
+ * Sample positions: /root/reference/models/rendering/diff_ray_marching.py:386
+ *   raypos = campos + raydir * t_mid  (fp32 multiply, then fp32 add; the t_mid
+ *   table is an INPUT, produced by the same torch ops as :369-385).
+ *
+ * Linearisation of the reference's races:
+ *   - voxel slots are handed out in point-index order of first appearance;
+ *   - a voxel's point list is in point-index order, truncated to the first P
+ *     (the reference replaces at random beyond P, seeded by wall-clock time);
+ *   - voxels beyond max_o (in first-appearance order) are dropped (same remark);
+ *   - the voxel that owns slot 0 never receives points (`voxel_idx > 0`, :366)
+ *     but still counts as occupied for the dilated march mask.
+ *
+ * Arithmetic is fp32 exactly as written in the source: no FMA contraction
+ * (build with -ffp-contract=off), IEEE divide, floorf.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct {
+    int     dims[3];
+    float   origin[3];
+    float   cell[3];
+    int     P, max_o;
+    int64_t vol;
+    uint8_t *coor_occ;      /* [X*Y*Z]  dilated occupancy (reference: int32 0/1)   */
+    int32_t *coor_2_occ;    /* [X*Y*Z]  cell -> slot, -1 empty                     */
+    int32_t *occ_2_coor;    /* [max_o*3]                                           */
+    int32_t *occ_2_pnts;    /* [max_o*P] -1 padded                                 */
+    int32_t *occ_numpnts;   /* [max_o]  (keeps counting past P, like the reference)*/
+    int32_t  occ_idx;       /* voxels claimed (may exceed max_o)                   */
+    /* diagnostics */
+    int64_t n_inbounds, n_dropped_voxels, n_points_over_P, n_cells_over_P;
+} oq_grid;
+
+static inline int cell_of(const oq_grid *g, const float *p, int c[3])
+{
+    /* :259-263  (int) floor((p - shift) / voxel_size), bounds test */
+    for (int a = 0; a < 3; ++a) {
+        float d = p[a] - g->origin[a];
+        float q = d / g->cell[a];
+        c[a] = (int)floorf(q);
+    }
+    return !(c[0] < 0 || c[0] >= g->dims[0] || c[1] < 0 || c[1] >= g->dims[1] ||
+             c[2] < 0 || c[2] >= g->dims[2]);
+}
+
+static inline int64_t lin(const oq_grid *g, int x, int y, int z)
+{
+    return (int64_t)x * ((int64_t)g->dims[1] * g->dims[2]) + (int64_t)y * g->dims[2] + z;
+}
+
+void oq_free(oq_grid *g)
+{
+    if (!g) return;
+    free(g->coor_occ); free(g->coor_2_occ); free(g->occ_2_coor);
+    free(g->occ_2_pnts); free(g->occ_numpnts); free(g);
+}
+
+/* build_occ_vox  (:540-602) */
+oq_grid *oq_build(const float *xyz, int n, const float origin[3], const float cell[3],
+                  const int dims[3], const int query_size[3], int P, int max_o)
+{
+    if (n < 0 || P <= 0 || max_o <= 0 || dims[0] <= 0 || dims[1] <= 0 || dims[2] <= 0) return NULL;
+    oq_grid *g = (oq_grid *)calloc(1, sizeof(oq_grid));
+    if (!g) return NULL;
+    memcpy(g->dims, dims, sizeof(int) * 3);
+    memcpy(g->origin, origin, sizeof(float) * 3);
+    memcpy(g->cell, cell, sizeof(float) * 3);
+    g->P = P; g->max_o = max_o;
+    g->vol = (int64_t)dims[0] * dims[1] * dims[2];
+    g->coor_occ    = (uint8_t *)calloc((size_t)g->vol, 1);
+    g->coor_2_occ  = (int32_t *)malloc((size_t)g->vol * 4);
+    g->occ_2_coor  = (int32_t *)malloc((size_t)max_o * 3 * 4);
+    g->occ_2_pnts  = (int32_t *)malloc((size_t)max_o * P * 4);
+    g->occ_numpnts = (int32_t *)calloc((size_t)max_o, 4);
+    if (!g->coor_occ || !g->coor_2_occ || !g->occ_2_coor || !g->occ_2_pnts || !g->occ_numpnts) {
+        oq_free(g); return NULL;
+    }
+    memset(g->coor_2_occ, 0xff, (size_t)g->vol * 4);
+    memset(g->occ_2_coor, 0xff, (size_t)max_o * 3 * 4);
+    memset(g->occ_2_pnts, 0xff, (size_t)max_o * P * 4);
+
+    /* pass 1: claim_occ (:237-297), threads in index order */
+    int c[3];
+    for (int i = 0; i < n; ++i) {
+        if (!cell_of(g, xyz + 3 * (size_t)i, c)) continue;
+        g->n_inbounds++;
+        int64_t ci = lin(g, c[0], c[1], c[2]);
+        if (g->coor_2_occ[ci] == -1) {
+            g->coor_2_occ[ci] = 0;                 /* atomicCAS(-1 -> 0) winner */
+            int tmp = g->occ_idx++;                /* atomicAdd(occ_idx, 1)     */
+            if (tmp < max_o) {
+                g->occ_2_coor[3 * tmp + 0] = c[0];
+                g->occ_2_coor[3 * tmp + 1] = c[1];
+                g->occ_2_coor[3 * tmp + 2] = c[2];
+            } else {
+                g->n_dropped_voxels++;             /* reference: random replace */
+            }
+        }
+    }
+    /* :566 fresh -1 grid, then pass 2: map_coor2occ (:299-334) */
+    memset(g->coor_2_occ, 0xff, (size_t)g->vol * 4);
+    int nslots = g->occ_idx < max_o ? g->occ_idx : max_o;
+    for (int s = 0; s < nslots; ++s) {
+        int cx = g->occ_2_coor[3 * s], cy = g->occ_2_coor[3 * s + 1], cz = g->occ_2_coor[3 * s + 2];
+        if (cx < 0) continue;
+        g->coor_2_occ[lin(g, cx, cy, cz)] = s;
+        int x0 = cx - query_size[0] / 2, x1 = cx + (query_size[0] + 1) / 2;
+        int y0 = cy - query_size[1] / 2, y1 = cy + (query_size[1] + 1) / 2;
+        int z0 = cz - query_size[2] / 2, z1 = cz + (query_size[2] + 1) / 2;
+        if (x0 < 0) x0 = 0; if (x1 > dims[0]) x1 = dims[0];
+        if (y0 < 0) y0 = 0; if (y1 > dims[1]) y1 = dims[1];
+        if (z0 < 0) z0 = 0; if (z1 > dims[2]) z1 = dims[2];
+        for (int x = x0; x < x1; ++x)
+            for (int y = y0; y < y1; ++y)
+                for (int z = z0; z < z1; ++z)
+                    g->coor_occ[lin(g, x, y, z)] = 1;
+    }
+    /* pass 3: fill_occ2pnts (:336-381) */
+    for (int i = 0; i < n; ++i) {
+        if (!cell_of(g, xyz + 3 * (size_t)i, c)) continue;
+        int v = g->coor_2_occ[lin(g, c[0], c[1], c[2])];
+        if (v > 0) {                                /* sic: slot 0 never filled */
+            int tmp = g->occ_numpnts[v]++;
+            if (tmp < P) g->occ_2_pnts[(size_t)v * P + tmp] = i;
+            else { g->n_points_over_P++; if (tmp == P) g->n_cells_over_P++; }
+        }
+    }
+    return g;
+}
+
+void oq_grid_info(const oq_grid *g, int64_t out[8])
+{
+    out[0] = g->occ_idx < g->max_o ? g->occ_idx : g->max_o;  /* occupied voxels kept */
+    out[1] = g->n_inbounds;
+    out[2] = g->n_dropped_voxels;
+    out[3] = g->n_points_over_P;
+    out[4] = g->n_cells_over_P;
+    out[5] = g->vol;
+    int64_t nd = 0;
+    for (int64_t i = 0; i < g->vol; ++i) nd += g->coor_occ[i];
+    out[6] = nd;                                              /* dilated cells */
+    out[7] = g->occ_idx;
+}
+
+/* raw tables, for tests that cross-check the device grid */
+const uint8_t *oq_coor_occ(const oq_grid *g)    { return g->coor_occ; }
+const int32_t *oq_coor_2_occ(const oq_grid *g)  { return g->coor_2_occ; }
+const int32_t *oq_occ_2_pnts(const oq_grid *g)  { return g->occ_2_pnts; }
+const int32_t *oq_occ_numpnts(const oq_grid *g) { return g->occ_numpnts; }
+
+/* query_neigh_along_ray_layered (:436-522) for one shading sample.
+ * pidx_out[K] must be pre-filled with -1.  Returns kid (in-radius candidates seen).
+ * stat[0] += occupied cells visited, stat[1] += candidates distance-tested. */
+static int knn_one_sample(const oq_grid *g, const float *xyz, const float ctr[3], int K,
+                          float radius2, const int kernel_size[3], int32_t *pidx_out,
+                          int64_t stat[2])
+{
+    float cx = ctr[0], cy = ctr[1], cz = ctr[2];
+    int fx = (int)floorf((cx - g->origin[0]) / g->cell[0]);
+    int fy = (int)floorf((cy - g->origin[1]) / g->cell[1]);
+    int fz = (int)floorf((cz - g->origin[2]) / g->cell[2]);
+    int kid = 0, far_ind = 0;
+    float far2 = 0.0f;
+    float buf[64];
+    const int P = g->P;
+    for (int layer = 0; layer < (kernel_size[0] + 1) / 2; ++layer) {
+        int xlo = -fx > -layer ? -fx : -layer, xhi = g->dims[0] - fx < layer + 1 ? g->dims[0] - fx : layer + 1;
+        for (int x = xlo; x < xhi; ++x) {
+            int ylo = -fy > -layer ? -fy : -layer, yhi = g->dims[1] - fy < layer + 1 ? g->dims[1] - fy : layer + 1;
+            for (int y = ylo; y < yhi; ++y) {
+                int zlo = -fz > -layer ? -fz : -layer, zhi = g->dims[2] - fz < layer + 1 ? g->dims[2] - fz : layer + 1;
+                for (int z = zlo; z < zhi; ++z) {
+                    int m = abs(x) > abs(y) ? abs(x) : abs(y);
+                    if (abs(z) > m) m = abs(z);
+                    if (m != layer) continue;
+                    int occ = g->coor_2_occ[lin(g, fx + x, fy + y, fz + z)];
+                    if (occ < 0) continue;
+                    int cnt = g->occ_numpnts[occ] < P ? g->occ_numpnts[occ] : P;
+                    stat[0] += 1;
+                    for (int gi = 0; gi < cnt; ++gi) {
+                        int pidx = g->occ_2_pnts[(size_t)occ * P + gi];
+                        float xv = xyz[3 * (size_t)pidx] - cx;
+                        float yv = xyz[3 * (size_t)pidx + 1] - cy;
+                        float zv = xyz[3 * (size_t)pidx + 2] - cz;
+                        float xx = xv * xv, yy = yv * yv, zz = zv * zv;
+                        float d2 = (xx + yy) + zz;
+                        stat[1] += 1;
+                        if (radius2 == 0.0f || d2 <= radius2) {
+                            if (kid++ < K) {
+                                pidx_out[kid - 1] = pidx;
+                                buf[kid - 1] = d2;
+                                if (d2 > far2) { far2 = d2; far_ind = kid - 1; }
+                            } else if (d2 < far2) {
+                                pidx_out[far_ind] = pidx;
+                                buf[far_ind] = d2;
+                                far2 = d2;
+                                for (int i = 0; i < K; ++i)
+                                    if (buf[i] > far2) { far2 = buf[i]; far_ind = i; }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (kid >= K) break;
+    }
+    return kid;
+}
+
+/*
+ * Full query for R rays.
+ *   tmid: [D] if tmid_stride == 0, else [R, tmid_stride] (per-ray jittered depths)
+ * Outputs (caller-allocated, worst-case sized; compact rows are in ray order):
+ *   sample_pidx  [R, SR, K]  first n_valid rows meaningful (-1 padded)
+ *   sample_loc_w [R, SR, 3]  first n_valid rows meaningful (0 padded)
+ *   ray_mask     [R]         1 iff the ray survived both compactions
+ *   counts[0] = n_valid rays (R' after :705-709), counts[1] = rays hit by march (:645-646),
+ *   counts[2] = shading samples kept over march-hit rays, counts[3] = valid neighbours (pidx>=0),
+ *   counts[4] = occupied cells visited by k-NN, counts[5] = candidates distance-tested,
+ *   counts[6] = shading samples with >=1 neighbour.
+ * Also (optional, may be NULL) the un-compacted per-ray view used to test the device kernels:
+ *   full_pidx [R,SR,K], full_loc [R,SR,3], full_nsamp [R].
+ */
+int oq_query(const oq_grid *g, const float *xyz, const float campos[3], const float *raydir,
+             int R, const float *tmid, int D, int tmid_stride, int SR, int K, float radius2,
+             const int kernel_size[3],
+             int32_t *sample_pidx, float *sample_loc_w, int8_t *ray_mask, int64_t counts[8],
+             int32_t *full_pidx, float *full_loc, int32_t *full_nsamp)
+{
+    if (K > 64 || K <= 0 || SR <= 0 || D <= 0) return -1;
+    memset(counts, 0, sizeof(int64_t) * 8);
+    int32_t *pidx_row = (int32_t *)malloc((size_t)SR * K * 4);
+    float   *loc_row  = (float *)malloc((size_t)SR * 3 * 4);
+    if (!pidx_row || !loc_row) { free(pidx_row); free(loc_row); return -2; }
+    int nvalid = 0;
+    int64_t stat[2] = {0, 0};
+    for (int r = 0; r < R; ++r) {
+        const float *dir = raydir + 3 * (size_t)r;
+        const float *tt = tmid + (size_t)r * tmid_stride;
+        int ns = 0;
+        memset(loc_row, 0, (size_t)SR * 3 * 4);
+        for (int i = 0; i < SR * K; ++i) pidx_row[i] = -1;
+        for (int d = 0; d < D && ns < SR; ++d) {
+            float p[3];
+            for (int a = 0; a < 3; ++a) {
+                float m = dir[a] * tt[d];        /* torch mul */
+                p[a] = campos[a] + m;            /* torch add */
+            }
+            int c[3];
+            if (!cell_of(g, p, c)) continue;     /* :404 */
+            if (!g->coor_occ[lin(g, c[0], c[1], c[2])]) continue;
+            loc_row[3 * ns] = p[0]; loc_row[3 * ns + 1] = p[1]; loc_row[3 * ns + 2] = p[2];
+            ns++;
+        }
+        if (full_nsamp) full_nsamp[r] = ns;
+        int any = 0;
+        if (ns > 0) {
+            counts[1]++; counts[2] += ns;
+            for (int s = 0; s < ns; ++s) {
+                knn_one_sample(g, xyz, loc_row + 3 * s, K, radius2, kernel_size, pidx_row + (size_t)s * K, stat);
+                int has = 0;
+                for (int k = 0; k < K; ++k) if (pidx_row[(size_t)s * K + k] >= 0) { counts[3]++; has = 1; }
+                counts[6] += has; any |= has;
+            }
+        }
+        if (full_pidx) memcpy(full_pidx + (size_t)r * SR * K, pidx_row, (size_t)SR * K * 4);
+        if (full_loc)  memcpy(full_loc + (size_t)r * SR * 3, loc_row, (size_t)SR * 3 * 4);
+        ray_mask[r] = (int8_t)any;
+        if (any) {
+            memcpy(sample_pidx + (size_t)nvalid * SR * K, pidx_row, (size_t)SR * K * 4);
+            memcpy(sample_loc_w + (size_t)nvalid * SR * 3, loc_row, (size_t)SR * 3 * 4);
+            nvalid++;
+        }
+    }
+    counts[0] = nvalid; counts[4] = stat[0]; counts[5] = stat[1];
+    free(pidx_row); free(loc_row);
+    return 0;
+}
