@@ -1,0 +1,108 @@
+"""ctypes binding of libhnr_hip.so (the C ABI declared in include/hnr.h).
+
+There is NO fallback: if the HIP library is missing or a call fails, this raises.  PyTorch only
+supplies device memory (`tensor.data_ptr()`) and the current HIP stream.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhnr_hip.so")
+NCOUNTS = 8
+CNT = dict(RAYS_HIT=0, SAMPLES=1, RAYS_VALID=2, NEIGHBOURS=3, CELLS_VISITED=4, CANDIDATES=5, SAMPLES_VALID=6)
+
+
+class HnrError(RuntimeError):
+    pass
+
+
+class GridParams(ctypes.Structure):
+    _fields_ = [("origin", ctypes.c_float * 3), ("cell", ctypes.c_float * 3), ("dims", ctypes.c_int * 3),
+                ("query_size", ctypes.c_int * 3), ("P", ctypes.c_int), ("max_o", ctypes.c_int)]
+
+
+class GridStats(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int64) for n in ("n_points", "n_inbounds", "n_occ", "n_dropped_voxels",
+                                              "n_cells_over_P", "n_dilated", "n_words", "bytes")]
+
+
+class QueryParams(ctypes.Structure):
+    _fields_ = [("R", ctypes.c_int), ("D", ctypes.c_int), ("SR", ctypes.c_int), ("K", ctypes.c_int),
+                ("kernel_size", ctypes.c_int * 3), ("radius2", ctypes.c_float), ("tmid_stride", ctypes.c_int)]
+
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_F = ctypes.c_float
+
+# name -> (restype, argtypes); must list every symbol include/hnr.h declares (tests check this)
+SIGNATURES = {
+    "hnr_version": (ctypes.c_char_p, []),
+    "hnr_last_error": (ctypes.c_char_p, []),
+    "hnr_points_bounds": (_I, [_P, _I, _P, _P]),
+    "hnr_grid_build": (_I, [_P, _I, ctypes.POINTER(GridParams), _P, ctypes.POINTER(_P)]),
+    "hnr_grid_free": (_I, [_P]),
+    "hnr_grid_get_stats": (_I, [_P, ctypes.POINTER(GridStats)]),
+    "hnr_grid_get_params": (_I, [_P, ctypes.POINTER(GridParams)]),
+    "hnr_grid_export_dense": (_I, [_P, _P, _P, _P, _P]),
+    "hnr_march_query": (_I, [_P, _P, _P, _P, ctypes.POINTER(QueryParams), _P, _P, _P, _P, _P, _P, _P]),
+    "hnr_ray_compact_plan": (_I, [_P, _I, _P, _P, _P, _P]),
+    "hnr_ray_compact": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libhnr_hip.so once.  Raises HnrError (never falls back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HnrError(
+            "libhnr_hip.so is missing (%s). Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C hybridneuralrendering_amd/csrc`; there is no CPU or PyTorch fallback." % LIB_PATH)
+    try:
+        L = ctypes.CDLL(LIB_PATH)
+    except OSError as e:
+        raise HnrError("cannot load %s: %s" % (LIB_PATH, e))
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(L, name)
+        except AttributeError:
+            raise HnrError("libhnr_hip.so does not export %s (stale build?)" % name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().hnr_last_error().decode("utf-8", "replace")
+        raise HnrError("%s failed (code %d): %s" % (what, rc, msg))
+
+
+def ptr(t):
+    """Device pointer of a contiguous CUDA(HIP) tensor as void*."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise HnrError("expected a tensor on the GPU, got device=%s" % t.device)
+    if not t.is_contiguous():
+        raise HnrError("expected a contiguous tensor")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu(t, name, dtype=None):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise HnrError("%s must be a tensor on the GPU (the HIP path has no CPU fallback)" % name)
+    if dtype is not None and t.dtype != dtype:
+        raise HnrError("%s must have dtype %s, got %s" % (name, dtype, t.dtype))
+    return t.contiguous()

@@ -1,0 +1,93 @@
+// Shared device/host helpers for libhnr_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/hnr.h"
+
+namespace hnr {
+
+void set_error(const char *fmt, ...);
+
+#define HNR_HIP_CHECK(expr)                                                             \
+    do {                                                                                \
+        hipError_t _e = (expr);                                                         \
+        if (_e != hipSuccess) {                                                         \
+            ::hnr::set_error("%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            return HNR_ERR_HIP;                                                         \
+        }                                                                               \
+    } while (0)
+
+#define HNR_LAUNCH_CHECK()  HNR_HIP_CHECK(hipGetLastError())
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// Device view of the voxel grid (plain struct, passed by value to kernels).
+//
+// Cells are grouped in 4x4x4 bricks; one 64-bit word per brick, bit = (x&3)<<4 | (y&3)<<2 | (z&3).
+//   occ_rec[w] = {bits_lo, bits_hi, prefix, 0}: which cells of brick w hold points, and how many
+//                occupied cells precede brick w, so slot(cell) = prefix + popc(bits below the cell's bit);
+//   dil[w]     = dilated occupancy (the reference's coor_occ) for the ray march: one bit per cell;
+//   cell_rng[slot] = {first index into pts, min(P, points in the cell)};
+//   pts[i]     = {x, y, z, bit-cast point id}, sorted by slot, point-id order inside a cell.
+struct GridView {
+    float ox, oy, oz;      // origin (d_coord_shift)
+    float cx, cy, cz;      // cell size (d_voxel_size)
+    int   dx, dy, dz;      // dims in cells
+    int   by, bz;          // brick dims along y, z
+    const uint4 *occ_rec;
+    const unsigned long long *dil;
+    const int2 *cell_rng;
+    const float4 *pts;
+};
+
+// floor((p - shift) / size) with fp32 subtract and IEEE fp32 divide, exactly as the reference
+// kernels write it (query_point_indices_worldcoords.py:259-261, :400-402, :465-467).
+// Returns INT_MIN for values that do not fit an int (C leaves that cast undefined).
+__device__ __forceinline__ int cell_coord(float p, float o, float c)
+{
+    float d = __fsub_rn(p, o);
+    float q = __fdiv_rn(d, c);
+    if (!(q > -2.0e9f && q < 2.0e9f)) return INT32_MIN;
+    return (int)floorf(q);
+}
+
+__device__ __forceinline__ bool in_bounds(const GridView &g, int x, int y, int z)
+{
+    return x >= 0 && x < g.dx && y >= 0 && y < g.dy && z >= 0 && z < g.dz;
+}
+
+__device__ __forceinline__ uint32_t brick_word(const GridView &g, int x, int y, int z)
+{
+    return (uint32_t)(((x >> 2) * g.by + (y >> 2)) * g.bz + (z >> 2));
+}
+
+__device__ __forceinline__ int brick_bit(int x, int y, int z)
+{
+    return ((x & 3) << 4) | ((y & 3) << 2) | (z & 3);
+}
+
+}  // namespace hnr
+
+struct hnr_grid {
+    hnr_grid_params p;
+    hnr_grid_stats st;
+    int bd[3];
+    uint32_t n_words;
+    uint4 *occ_rec;
+    unsigned long long *dil;
+    int2 *cell_rng;
+    float4 *pts;
+    hnr::GridView view() const
+    {
+        hnr::GridView v;
+        v.ox = p.origin[0]; v.oy = p.origin[1]; v.oz = p.origin[2];
+        v.cx = p.cell[0]; v.cy = p.cell[1]; v.cz = p.cell[2];
+        v.dx = p.dims[0]; v.dy = p.dims[1]; v.dz = p.dims[2];
+        v.by = bd[1]; v.bz = bd[2];
+        v.occ_rec = occ_rec; v.dil = dil; v.cell_rng = cell_rng; v.pts = pts;
+        return v;
+    }
+};

@@ -1,0 +1,354 @@
+// Ray march + first-SR compaction + layered k-NN over the brick/CSR voxel grid.
+//
+// Replaces, for one launch of R rays (reference: models/neural_points/query_point_indices_worldcoords.py):
+//   near_far_linear_ray_generation's raypos tensor (models/rendering/diff_ray_marching.py:386) -- never
+//     materialised: each lane recomputes campos + raydir * t_mid[d] (fp32 mul, then fp32 add);
+//   mask_raypos (:384-408)            -> one bit test per marched sample in `dil`;
+//   torch max/sum/masked_select/cumsum (:645-655) + get_shadingloc (:411-433)
+//                                     -> wavefront ballot + popcount prefix, one wave per ray, no host sync;
+//   query_neigh_along_ray_layered (:436-522) -> knn kernel over a device-side work list of kept samples.
+//
+// Results are bit-identical to oracle/query_oracle.c (same visiting order, same strict-< replacement
+// and first-max scan), so sample_pidx matches slot for slot.
+#include "hnr_common.h"
+
+namespace hnr {
+
+// ------------------------------------------------------------------------------------------------
+// March: one wavefront per ray.  64 lanes test 64 consecutive depth samples per step; the ballot of
+// occupied samples gives every hit its output slot; stops as soon as SR samples are kept.
+__global__ __launch_bounds__(256) void march_kernel(GridView g, const float *__restrict__ campos,
+                                                    const float *__restrict__ raydir,
+                                                    const float *__restrict__ tmid, int R, int D, int SR, int K,
+                                                    int tmid_stride, int32_t *__restrict__ pidx,
+                                                    float *__restrict__ loc, int32_t *__restrict__ ray_nsamp,
+                                                    int8_t *__restrict__ ray_mask, int32_t *__restrict__ work,
+                                                    unsigned long long *__restrict__ counts)
+{
+    const int lane = threadIdx.x & 63;
+    const int r = (int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6);
+    if (r >= R) return;
+    const float px = campos[0], py = campos[1], pz = campos[2];
+    const float dx = raydir[3 * (size_t)r], dy = raydir[3 * (size_t)r + 1], dz = raydir[3 * (size_t)r + 2];
+    const float *tt = tmid + (size_t)r * tmid_stride;
+    float *loc_r = loc + (size_t)r * SR * 3;
+
+    int base = 0;
+    for (int d0 = 0; d0 < D; d0 += 64) {
+        const int d = d0 + lane;
+        bool occ = false;
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        if (d < D) {
+            const float t = tt[d];
+            sx = __fadd_rn(px, __fmul_rn(dx, t));
+            sy = __fadd_rn(py, __fmul_rn(dy, t));
+            sz = __fadd_rn(pz, __fmul_rn(dz, t));
+            const int cx = cell_coord(sx, g.ox, g.cx), cy = cell_coord(sy, g.oy, g.cy), cz = cell_coord(sz, g.oz, g.cz);
+            if (in_bounds(g, cx, cy, cz))
+                occ = (g.dil[brick_word(g, cx, cy, cz)] >> brick_bit(cx, cy, cz)) & 1ull;
+        }
+        const unsigned long long b = __ballot(occ);
+        if (occ) {
+            const int slot = base + __popcll(b & ((1ull << lane) - 1ull));
+            if (slot < SR) {
+                loc_r[3 * slot] = sx; loc_r[3 * slot + 1] = sy; loc_r[3 * slot + 2] = sz;
+            }
+        }
+        base += __popcll(b);
+        if (base >= SR) break;
+    }
+    const int ns = base < SR ? base : SR;
+    // pad: sample_loc zeros (torch.zeros, :647), sample_pidx -1 (torch.full, :648)
+    for (int i = ns * 3 + lane; i < SR * 3; i += 64) loc_r[i] = 0.f;
+    int32_t *pidx_r = pidx + (size_t)r * SR * K;
+    const int nk = SR * K;
+    if ((nk & 3) == 0) {
+        int4 *p4 = reinterpret_cast<int4 *>(pidx_r);
+        for (int i = lane; i < (nk >> 2); i += 64) p4[i] = make_int4(-1, -1, -1, -1);
+    } else {
+        for (int i = lane; i < nk; i += 64) pidx_r[i] = -1;
+    }
+    int w0 = 0;
+    if (lane == 0) {
+        ray_nsamp[r] = ns;
+        ray_mask[r] = 0;
+        if (ns > 0) {
+            w0 = (int)atomicAdd(&counts[HNR_CNT_SAMPLES], (unsigned long long)ns);
+            atomicAdd(&counts[HNR_CNT_RAYS_HIT], 1ull);
+        }
+    }
+    w0 = __shfl(w0, 0);
+    for (int i = lane; i < ns; i += 64) work[w0 + i] = r * SR + i;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k-NN: one lane per kept shading sample, grid-stride over the work list.
+// The K-entry buffer lives in registers (K is a template parameter; all indexing is unrolled).
+template <int K>
+struct KBuf {
+    float d2[K];
+    int id[K];
+    int kid, far_ind;
+    float far2;
+    __device__ __forceinline__ void init()
+    {
+#pragma unroll
+        for (int i = 0; i < K; ++i) { d2[i] = 0.f; id[i] = -1; }
+        kid = 0; far_ind = 0; far2 = 0.f;
+    }
+    // reference :494-513
+    __device__ __forceinline__ void offer(float v, int p)
+    {
+        if (kid < K) {
+#pragma unroll
+            for (int i = 0; i < K; ++i) if (i == kid) { d2[i] = v; id[i] = p; }
+            if (v > far2) { far2 = v; far_ind = kid; }
+            ++kid;
+        } else {
+            ++kid;
+            if (v < far2) {
+#pragma unroll
+                for (int i = 0; i < K; ++i) if (i == far_ind) { d2[i] = v; id[i] = p; }
+                far2 = v;
+#pragma unroll
+                for (int i = 0; i < K; ++i) if (d2[i] > far2) { far2 = d2[i]; far_ind = i; }
+            }
+        }
+    }
+};
+
+template <int K>
+__global__ __launch_bounds__(256) void knn_kernel(GridView g, const int32_t *__restrict__ work,
+                                                  const float *__restrict__ loc, int SR, float radius2, int layers,
+                                                  int32_t *__restrict__ pidx, int8_t *__restrict__ ray_mask,
+                                                  unsigned long long *__restrict__ counts)
+{
+    const int n = (int)counts[HNR_CNT_SAMPLES];
+    unsigned long long n_cells = 0, n_cand = 0, n_nb = 0, n_sv = 0;
+    for (int w = blockIdx.x * blockDim.x + threadIdx.x; w < n; w += gridDim.x * blockDim.x) {
+        const int item = work[w];
+        const float cx = loc[3 * (size_t)item], cy = loc[3 * (size_t)item + 1], cz = loc[3 * (size_t)item + 2];
+        const int fx = cell_coord(cx, g.ox, g.cx), fy = cell_coord(cy, g.oy, g.cy), fz = cell_coord(cz, g.oz, g.cz);
+        KBuf<K> kb;
+        kb.init();
+        for (int layer = 0; layer < layers; ++layer) {
+            const int xlo = max(-fx, -layer), xhi = min(g.dx - fx, layer + 1);
+            const int ylo = max(-fy, -layer), yhi = min(g.dy - fy, layer + 1);
+            const int zlo = max(-fz, -layer), zhi = min(g.dz - fz, layer + 1);
+            for (int x = xlo; x < xhi; ++x)
+                for (int y = ylo; y < yhi; ++y)
+                    for (int z = zlo; z < zhi; ++z) {
+                        if (max(abs(z), max(abs(x), abs(y))) != layer) continue;
+                        const int vx = fx + x, vy = fy + y, vz = fz + z;
+                        const uint4 rec = g.occ_rec[brick_word(g, vx, vy, vz)];
+                        const unsigned long long bb = (unsigned long long)rec.x | ((unsigned long long)rec.y << 32);
+                        const int b = brick_bit(vx, vy, vz);
+                        if (!((bb >> b) & 1ull)) continue;
+                        const int2 rg = g.cell_rng[rec.z + (uint32_t)__popcll(bb & ((1ull << b) - 1ull))];
+                        ++n_cells;
+                        n_cand += (unsigned)rg.y;
+                        for (int j = 0; j < rg.y; ++j) {
+                            const float4 p = g.pts[rg.x + j];
+                            const float xv = __fsub_rn(p.x, cx), yv = __fsub_rn(p.y, cy), zv = __fsub_rn(p.z, cz);
+                            const float v = __fadd_rn(__fadd_rn(__fmul_rn(xv, xv), __fmul_rn(yv, yv)), __fmul_rn(zv, zv));
+                            if (radius2 == 0.f || v <= radius2) kb.offer(v, __float_as_int(p.w));
+                        }
+                    }
+            if (kb.kid >= K) break;
+        }
+        if (kb.kid > 0) {
+            int32_t *o = pidx + (size_t)item * K;
+            if constexpr ((K & 3) == 0) {
+#pragma unroll
+                for (int i = 0; i < K; i += 4)
+                    reinterpret_cast<int4 *>(o)[i >> 2] = make_int4(kb.id[i], kb.id[i + 1], kb.id[i + 2], kb.id[i + 3]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < K; ++i) o[i] = kb.id[i];
+            }
+            ray_mask[item / SR] = 1;
+            n_nb += (unsigned)(kb.kid < K ? kb.kid : K);
+            ++n_sv;
+        }
+    }
+    // one atomic per wave and counter
+    for (int o = 32; o > 0; o >>= 1) {
+        n_cells += __shfl_xor(n_cells, o);
+        n_cand += __shfl_xor(n_cand, o);
+        n_nb += __shfl_xor(n_nb, o);
+        n_sv += __shfl_xor(n_sv, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (n_cells) atomicAdd(&counts[HNR_CNT_CELLS_VISITED], n_cells);
+        if (n_cand) atomicAdd(&counts[HNR_CNT_CANDIDATES], n_cand);
+        if (n_nb) atomicAdd(&counts[HNR_CNT_NEIGHBOURS], n_nb);
+        if (n_sv) atomicAdd(&counts[HNR_CNT_SAMPLES_VALID], n_sv);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Second compaction (:705-709): two small kernels, deterministic, no host sync inside.
+__global__ __launch_bounds__(1024) void compact_count_kernel(const int8_t *__restrict__ mask, int R, int32_t *block_sums)
+{
+    __shared__ int s_w[16];
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    const bool m = i < R && mask[i] != 0;
+    const unsigned long long b = __ballot(m);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = __popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int k = 0; k < 16; ++k) t += s_w[k];
+        block_sums[blockIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(1024) void compact_plan_kernel(const int8_t *__restrict__ mask, int R,
+                                                            const int32_t *__restrict__ block_sums, int nblocks,
+                                                            int32_t *__restrict__ ray_row, unsigned long long *counts)
+{
+    __shared__ int s_w[16];
+    __shared__ int s_base;
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    // block offset: sum of the preceding block sums (R/1024 is small: a frame has ~280 blocks)
+    int part = 0;
+    for (int k = threadIdx.x; k < (int)blockIdx.x; k += 1024) part += block_sums[k];
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+    const bool m = i < R && mask[i] != 0;
+    const unsigned long long b = __ballot(m);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int k = 0; k < 16; ++k) t += s_w[k];
+        s_base = t;
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = __popcll(b);
+    __syncthreads();
+    int off = s_base;
+    for (int k = 0; k < (int)(threadIdx.x >> 6); ++k) off += s_w[k];
+    if (i < R) ray_row[i] = m ? off + __popcll(b & ((1ull << (threadIdx.x & 63)) - 1ull)) : -1;
+    if (blockIdx.x == (unsigned)nblocks - 1 && threadIdx.x == 0) {
+        int t = s_base;
+        for (int k = 0; k < 16; ++k) t += s_w[k];
+        counts[HNR_CNT_RAYS_VALID] = (unsigned long long)t;
+    }
+}
+
+// one wave per input ray: copy its rows to the compact position, expand the ray direction over SR (:91)
+__global__ __launch_bounds__(256) void compact_rows_kernel(const int32_t *__restrict__ ray_row, int R, int SR, int K,
+                                                           const int32_t *__restrict__ pidx, const float *__restrict__ loc,
+                                                           const float *__restrict__ raydir,
+                                                           const float *__restrict__ campos, const float *__restrict__ camrot,
+                                                           int32_t *__restrict__ o_pidx, float *__restrict__ o_loc,
+                                                           float *__restrict__ o_pers, float *__restrict__ o_dir)
+{
+    const int lane = threadIdx.x & 63;
+    const int r = (int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6);
+    if (r >= R) return;
+    const int row = ray_row[r];
+    if (row < 0) return;
+    const int nk = SR * K;
+    for (int i = lane; i < nk; i += 64) o_pidx[(size_t)row * nk + i] = pidx[(size_t)r * nk + i];
+    for (int i = lane; i < SR * 3; i += 64) {
+        o_loc[(size_t)row * SR * 3 + i] = loc[(size_t)r * SR * 3 + i];
+        o_dir[(size_t)row * SR * 3 + i] = raydir[3 * (size_t)r + (i % 3)];
+    }
+    // w2pers (:96-103): xyz_c[j] = sum_i (p[i] - campos[i]) * camrot[i][j]; padded slots included, like the reference
+    for (int s = lane; s < SR; s += 64) {
+        const float *p = loc + ((size_t)r * SR + s) * 3;
+        const float s0 = __fsub_rn(p[0], campos[0]), s1 = __fsub_rn(p[1], campos[1]), s2 = __fsub_rn(p[2], campos[2]);
+        float c[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            c[j] = __fadd_rn(__fadd_rn(__fmul_rn(s0, camrot[j]), __fmul_rn(s1, camrot[3 + j])), __fmul_rn(s2, camrot[6 + j]));
+        float *o = o_pers + ((size_t)row * SR + s) * 3;
+        o[0] = __fdiv_rn(c[0], c[2]); o[1] = __fdiv_rn(c[1], c[2]); o[2] = c[2];
+    }
+}
+
+}  // namespace hnr
+
+using namespace hnr;
+
+template <int K>
+static void launch_knn(const GridView &v, const int32_t *work, const float *loc, int SR, float r2, int layers,
+                       int32_t *pidx, int8_t *mask, unsigned long long *counts, int max_items, hipStream_t st)
+{
+    int blocks = cdiv(max_items, 256);
+    const int cap = 256 * 8;   // 256 CUs x 8 blocks of 256 threads: grid-stride beyond that
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    knn_kernel<K><<<blocks, 256, 0, st>>>(v, work, loc, SR, r2, layers, pidx, mask, counts);
+}
+
+extern "C" int hnr_march_query(const hnr_grid *g, const float *d_campos, const float *d_raydir, const float *d_tmid,
+                               const hnr_query_params *q, int32_t *d_sample_pidx, float *d_sample_loc_w,
+                               int32_t *d_ray_nsamp, int8_t *d_ray_mask, int32_t *d_work, int64_t *d_counts,
+                               void *stream)
+{
+    if (!g || !q || !d_campos || !d_raydir || !d_tmid || !d_sample_pidx || !d_sample_loc_w || !d_ray_nsamp ||
+        !d_ray_mask || !d_work || !d_counts) {
+        set_error("hnr_march_query: NULL argument"); return HNR_ERR_BADARG;
+    }
+    if (q->R < 0 || q->D <= 0 || q->SR <= 0 || q->K <= 0 || q->K > HNR_MAX_K ||
+        (q->tmid_stride != 0 && q->tmid_stride != q->D) || q->kernel_size[0] <= 0) {
+        set_error("hnr_march_query: bad sizes (R=%d D=%d SR=%d K=%d tmid_stride=%d)", q->R, q->D, q->SR, q->K, q->tmid_stride);
+        return HNR_ERR_BADARG;
+    }
+    if ((int64_t)q->R * q->SR * q->K >= (1ll << 31)) { set_error("hnr_march_query: R*SR*K overflows int32"); return HNR_ERR_TOOBIG; }
+    hipStream_t st = (hipStream_t)stream;
+    HNR_HIP_CHECK(hipMemsetAsync(d_counts, 0, sizeof(int64_t) * HNR_NCOUNTS, st));
+    if (q->R == 0) return HNR_OK;
+    const GridView v = g->view();
+    unsigned long long *cnt = reinterpret_cast<unsigned long long *>(d_counts);
+    march_kernel<<<cdiv((int64_t)q->R * 64, 256), 256, 0, st>>>(v, d_campos, d_raydir, d_tmid, q->R, q->D, q->SR, q->K,
+                                                                q->tmid_stride, d_sample_pidx, d_sample_loc_w,
+                                                                d_ray_nsamp, d_ray_mask, d_work, cnt);
+    HNR_LAUNCH_CHECK();
+    const int layers = (q->kernel_size[0] + 1) / 2;
+    const int max_items = q->R * q->SR;
+    switch (q->K) {
+#define HNR_KCASE(KK) case KK: launch_knn<KK>(v, d_work, d_sample_loc_w, q->SR, q->radius2, layers, d_sample_pidx, d_ray_mask, cnt, max_items, st); break;
+        HNR_KCASE(1) HNR_KCASE(2) HNR_KCASE(3) HNR_KCASE(4) HNR_KCASE(5) HNR_KCASE(6) HNR_KCASE(7) HNR_KCASE(8)
+        HNR_KCASE(12) HNR_KCASE(16) HNR_KCASE(24) HNR_KCASE(32)
+#undef HNR_KCASE
+        default:
+            set_error("hnr_march_query: K=%d is not instantiated (1-8, 12, 16, 24, 32)", q->K);
+            return HNR_ERR_BADARG;
+    }
+    HNR_LAUNCH_CHECK();
+    return HNR_OK;
+}
+
+extern "C" int hnr_ray_compact_plan(const int8_t *d_ray_mask, int R, int32_t *d_ray_row, int32_t *d_scratch,
+                                    int64_t *d_counts, void *stream)
+{
+    if (!d_ray_mask || !d_ray_row || !d_scratch || !d_counts || R < 0) { set_error("hnr_ray_compact_plan: bad argument"); return HNR_ERR_BADARG; }
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long *cnt = reinterpret_cast<unsigned long long *>(d_counts);
+    if (R == 0) { HNR_HIP_CHECK(hipMemsetAsync(d_counts + HNR_CNT_RAYS_VALID, 0, 8, st)); return HNR_OK; }
+    const int nb = cdiv(R, 1024);
+    compact_count_kernel<<<nb, 1024, 0, st>>>(d_ray_mask, R, d_scratch);
+    compact_plan_kernel<<<nb, 1024, 0, st>>>(d_ray_mask, R, d_scratch, nb, d_ray_row, cnt);
+    HNR_LAUNCH_CHECK();
+    return HNR_OK;
+}
+
+extern "C" int hnr_ray_compact(const int32_t *d_ray_row, int R, int SR, int K, const int32_t *d_sample_pidx,
+                               const float *d_sample_loc_w, const float *d_raydir, const float *d_campos,
+                               const float *d_camrotc2w, int32_t *d_out_pidx, float *d_out_loc_w,
+                               float *d_out_loc_pers, float *d_out_raydir, void *stream)
+{
+    if (!d_ray_row || !d_sample_pidx || !d_sample_loc_w || !d_raydir || !d_campos || !d_camrotc2w || R < 0 || SR <= 0 || K <= 0) {
+        set_error("hnr_ray_compact: bad argument"); return HNR_ERR_BADARG;
+    }
+    if (R == 0) return HNR_OK;
+    if (!d_out_pidx || !d_out_loc_w || !d_out_loc_pers || !d_out_raydir) { set_error("hnr_ray_compact: NULL output"); return HNR_ERR_BADARG; }
+    compact_rows_kernel<<<cdiv((int64_t)R * 64, 256), 256, 0, (hipStream_t)stream>>>(
+        d_ray_row, R, SR, K, d_sample_pidx, d_sample_loc_w, d_raydir, d_campos, d_camrotc2w, d_out_pidx, d_out_loc_w,
+        d_out_loc_pers, d_out_raydir);
+    HNR_LAUNCH_CHECK();
+    return HNR_OK;
+}

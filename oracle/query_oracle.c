@@ -65,7 +65,9 @@ static inline int cell_of(const oq_grid *g, const float *p, int c[3])
     for (int a = 0; a < 3; ++a) {
         float d = p[a] - g->origin[a];
         float q = d / g->cell[a];
-        c[a] = (int)floorf(q);
+        /* the int cast of a non-finite / huge float is undefined in C (CUDA saturates); such a
+         * sample can only be out of bounds, so say so explicitly (the HIP path does the same) */
+        c[a] = (q > -2.0e9f && q < 2.0e9f) ? (int)floorf(q) : INT32_MIN;
     }
     return !(c[0] < 0 || c[0] >= g->dims[0] || c[1] < 0 || c[1] >= g->dims[1] ||
              c[2] < 0 || c[2] >= g->dims[2]);
