@@ -288,8 +288,9 @@ extern "C" int hnr_march_query(const hnr_grid *g, const float *d_campos, const f
                                int32_t *d_ray_nsamp, int8_t *d_ray_mask, int32_t *d_work, int64_t *d_counts,
                                void *stream)
 {
-    if (!g || !q || !d_campos || !d_raydir || !d_tmid || !d_sample_pidx || !d_sample_loc_w || !d_ray_nsamp ||
-        !d_ray_mask || !d_work || !d_counts) {
+    if (!g || !q || !d_counts) { set_error("hnr_march_query: NULL argument"); return HNR_ERR_BADARG; }
+    if (q->R > 0 && (!d_campos || !d_raydir || !d_tmid || !d_sample_pidx || !d_sample_loc_w || !d_ray_nsamp ||
+                     !d_ray_mask || !d_work)) {
         set_error("hnr_march_query: NULL argument"); return HNR_ERR_BADARG;
     }
     if (q->R < 0 || q->D <= 0 || q->SR <= 0 || q->K <= 0 || q->K > HNR_MAX_K ||
@@ -325,7 +326,9 @@ extern "C" int hnr_march_query(const hnr_grid *g, const float *d_campos, const f
 extern "C" int hnr_ray_compact_plan(const int8_t *d_ray_mask, int R, int32_t *d_ray_row, int32_t *d_scratch,
                                     int64_t *d_counts, void *stream)
 {
-    if (!d_ray_mask || !d_ray_row || !d_scratch || !d_counts || R < 0) { set_error("hnr_ray_compact_plan: bad argument"); return HNR_ERR_BADARG; }
+    if (!d_counts || R < 0 || (R > 0 && (!d_ray_mask || !d_ray_row || !d_scratch))) {
+        set_error("hnr_ray_compact_plan: bad argument"); return HNR_ERR_BADARG;
+    }
     hipStream_t st = (hipStream_t)stream;
     unsigned long long *cnt = reinterpret_cast<unsigned long long *>(d_counts);
     if (R == 0) { HNR_HIP_CHECK(hipMemsetAsync(d_counts + HNR_CNT_RAYS_VALID, 0, 8, st)); return HNR_OK; }
@@ -341,10 +344,11 @@ extern "C" int hnr_ray_compact(const int32_t *d_ray_row, int R, int SR, int K, c
                                const float *d_camrotc2w, int32_t *d_out_pidx, float *d_out_loc_w,
                                float *d_out_loc_pers, float *d_out_raydir, void *stream)
 {
-    if (!d_ray_row || !d_sample_pidx || !d_sample_loc_w || !d_raydir || !d_campos || !d_camrotc2w || R < 0 || SR <= 0 || K <= 0) {
-        set_error("hnr_ray_compact: bad argument"); return HNR_ERR_BADARG;
-    }
+    if (R < 0 || SR <= 0 || K <= 0) { set_error("hnr_ray_compact: bad argument"); return HNR_ERR_BADARG; }
     if (R == 0) return HNR_OK;
+    if (!d_ray_row || !d_sample_pidx || !d_sample_loc_w || !d_raydir || !d_campos || !d_camrotc2w) {
+        set_error("hnr_ray_compact: NULL argument"); return HNR_ERR_BADARG;
+    }
     if (!d_out_pidx || !d_out_loc_w || !d_out_loc_pers || !d_out_raydir) { set_error("hnr_ray_compact: NULL output"); return HNR_ERR_BADARG; }
     compact_rows_kernel<<<cdiv((int64_t)R * 64, 256), 256, 0, (hipStream_t)stream>>>(
         d_ray_row, R, SR, K, d_sample_pidx, d_sample_loc_w, d_raydir, d_campos, d_camrotc2w, d_out_pidx, d_out_loc_w,
