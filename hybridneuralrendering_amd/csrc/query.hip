@@ -22,8 +22,7 @@ __global__ __launch_bounds__(256) void march_kernel(GridView g, const float *__r
                                                     const float *__restrict__ tmid, int R, int D, int SR, int K,
                                                     int tmid_stride, int32_t *__restrict__ pidx,
                                                     float *__restrict__ loc, int32_t *__restrict__ ray_nsamp,
-                                                    int8_t *__restrict__ ray_mask, int32_t *__restrict__ work,
-                                                    unsigned long long *__restrict__ counts)
+                                                    int8_t *__restrict__ ray_mask)
 {
     const int lane = threadIdx.x & 63;
     const int r = (int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6);
@@ -68,17 +67,69 @@ __global__ __launch_bounds__(256) void march_kernel(GridView g, const float *__r
     } else {
         for (int i = lane; i < nk; i += 64) pidx_r[i] = -1;
     }
-    int w0 = 0;
     if (lane == 0) {
         ray_nsamp[r] = ns;
         ray_mask[r] = 0;
-        if (ns > 0) {
-            w0 = (int)atomicAdd(&counts[HNR_CNT_SAMPLES], (unsigned long long)ns);
-            atomicAdd(&counts[HNR_CNT_RAYS_HIT], 1ull);
-        }
     }
-    w0 = __shfl(w0, 0);
-    for (int i = lane; i < ns; i += 64) work[w0 + i] = r * SR + i;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Work list of kept samples in (ray, slot) order, by a two-level exclusive scan of ray_nsamp.
+// No atomics: 285k same-address atomics cost ~6.5 ms on MI355X (measured, profiles/r01_query_v1).
+__global__ __launch_bounds__(1024) void nsamp_block_sum_kernel(const int32_t *__restrict__ ray_nsamp, int R,
+                                                               int32_t *__restrict__ block_sums)
+{
+    __shared__ int s_a[16], s_b[16];
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    int ns = i < R ? ray_nsamp[i] : 0;
+    int hit = ns > 0;
+    for (int o = 32; o > 0; o >>= 1) { ns += __shfl_xor(ns, o); hit += __shfl_xor(hit, o); }
+    if ((threadIdx.x & 63) == 0) { s_a[threadIdx.x >> 6] = ns; s_b[threadIdx.x >> 6] = hit; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int a = 0, b = 0;
+        for (int k = 0; k < 16; ++k) { a += s_a[k]; b += s_b[k]; }
+        block_sums[2 * blockIdx.x] = a;
+        block_sums[2 * blockIdx.x + 1] = b;
+    }
+}
+
+__global__ __launch_bounds__(1024) void worklist_kernel(const int32_t *__restrict__ ray_nsamp, int R, int SR,
+                                                        const int32_t *__restrict__ block_sums, int nblocks,
+                                                        int32_t *__restrict__ work, unsigned long long *__restrict__ counts)
+{
+    __shared__ int s_w[16];
+    __shared__ int s_base;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    int part = 0;
+    for (int k = threadIdx.x; k < (int)blockIdx.x; k += 1024) part += block_sums[2 * k];
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+    if (lane == 0) s_w[wid] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int k = 0; k < 16; ++k) t += s_w[k];
+        s_base = t;
+    }
+    __syncthreads();
+    const int ns = i < R ? ray_nsamp[i] : 0;
+    int inc = ns;                                   // inclusive scan inside the wave
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(inc, o);
+        if (lane >= o) inc += v;
+    }
+    if (lane == 63) s_w[wid] = inc;
+    __syncthreads();
+    int off = s_base + inc - ns;
+    for (int k = 0; k < wid; ++k) off += s_w[k];
+    for (int j = 0; j < ns; ++j) work[off + j] = i * SR + j;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        unsigned long long a = 0, b = 0;
+        for (int k = 0; k < nblocks; ++k) { a += (unsigned)block_sums[2 * k]; b += (unsigned)block_sums[2 * k + 1]; }
+        counts[HNR_CNT_SAMPLES] = a;
+        counts[HNR_CNT_RAYS_HIT] = b;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -121,8 +172,10 @@ template <int K>
 __global__ __launch_bounds__(256) void knn_kernel(GridView g, const int32_t *__restrict__ work,
                                                   const float *__restrict__ loc, int SR, float radius2, int layers,
                                                   int32_t *__restrict__ pidx, int8_t *__restrict__ ray_mask,
-                                                  unsigned long long *__restrict__ counts)
+                                                  const unsigned long long *__restrict__ counts,
+                                                  unsigned long long *__restrict__ block_stats)
 {
+    __shared__ unsigned long long s_st[4][4];
     const int n = (int)counts[HNR_CNT_SAMPLES];
     unsigned long long n_cells = 0, n_cand = 0, n_nb = 0, n_sv = 0;
     for (int w = blockIdx.x * blockDim.x + threadIdx.x; w < n; w += gridDim.x * blockDim.x) {
@@ -178,11 +231,37 @@ __global__ __launch_bounds__(256) void knn_kernel(GridView g, const int32_t *__r
         n_nb += __shfl_xor(n_nb, o);
         n_sv += __shfl_xor(n_sv, o);
     }
+    // per-block partial sums (plain stores); knn_finalize_kernel adds them up -- no same-address atomics
     if ((threadIdx.x & 63) == 0) {
-        if (n_cells) atomicAdd(&counts[HNR_CNT_CELLS_VISITED], n_cells);
-        if (n_cand) atomicAdd(&counts[HNR_CNT_CANDIDATES], n_cand);
-        if (n_nb) atomicAdd(&counts[HNR_CNT_NEIGHBOURS], n_nb);
-        if (n_sv) atomicAdd(&counts[HNR_CNT_SAMPLES_VALID], n_sv);
+        const int wv = threadIdx.x >> 6;
+        s_st[wv][0] = n_cells; s_st[wv][1] = n_cand; s_st[wv][2] = n_nb; s_st[wv][3] = n_sv;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4)
+        block_stats[4 * (size_t)blockIdx.x + threadIdx.x] =
+            s_st[0][threadIdx.x] + s_st[1][threadIdx.x] + s_st[2][threadIdx.x] + s_st[3][threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void knn_finalize_kernel(const unsigned long long *__restrict__ block_stats, int nblocks,
+                                                           unsigned long long *__restrict__ counts)
+{
+    __shared__ unsigned long long s_st[4][4];
+    unsigned long long v[4] = {0, 0, 0, 0};
+    for (int b = threadIdx.x; b < nblocks; b += 256)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] += block_stats[4 * (size_t)b + k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o);
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s_st[threadIdx.x >> 6][k] = v[k];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        counts[HNR_CNT_CELLS_VISITED] = s_st[0][0] + s_st[1][0] + s_st[2][0] + s_st[3][0];
+        counts[HNR_CNT_CANDIDATES] = s_st[0][1] + s_st[1][1] + s_st[2][1] + s_st[3][1];
+        counts[HNR_CNT_NEIGHBOURS] = s_st[0][2] + s_st[1][2] + s_st[2][2] + s_st[3][2];
+        counts[HNR_CNT_SAMPLES_VALID] = s_st[0][3] + s_st[1][3] + s_st[2][3] + s_st[3][3];
     }
 }
 
@@ -272,15 +351,22 @@ __global__ __launch_bounds__(256) void compact_rows_kernel(const int32_t *__rest
 
 using namespace hnr;
 
-template <int K>
-static void launch_knn(const GridView &v, const int32_t *work, const float *loc, int SR, float r2, int layers,
-                       int32_t *pidx, int8_t *mask, unsigned long long *counts, int max_items, hipStream_t st)
+static int knn_blocks(int max_items)
 {
     int blocks = cdiv(max_items, 256);
     const int cap = 256 * 8;   // 256 CUs x 8 blocks of 256 threads: grid-stride beyond that
     if (blocks > cap) blocks = cap;
-    if (blocks < 1) blocks = 1;
-    knn_kernel<K><<<blocks, 256, 0, st>>>(v, work, loc, SR, r2, layers, pidx, mask, counts);
+    return blocks < 1 ? 1 : blocks;
+}
+
+template <int K>
+static void launch_knn(const GridView &v, const int32_t *work, const float *loc, int SR, float r2, int layers,
+                       int32_t *pidx, int8_t *mask, unsigned long long *counts, unsigned long long *block_stats,
+                       int max_items, hipStream_t st)
+{
+    const int blocks = knn_blocks(max_items);
+    knn_kernel<K><<<blocks, 256, 0, st>>>(v, work, loc, SR, r2, layers, pidx, mask, counts, block_stats);
+    knn_finalize_kernel<<<1, 256, 0, st>>>(block_stats, blocks, counts);
 }
 
 extern "C" int hnr_march_query(const hnr_grid *g, const float *d_campos, const float *d_raydir, const float *d_tmid,
@@ -306,12 +392,20 @@ extern "C" int hnr_march_query(const hnr_grid *g, const float *d_campos, const f
     unsigned long long *cnt = reinterpret_cast<unsigned long long *>(d_counts);
     march_kernel<<<cdiv((int64_t)q->R * 64, 256), 256, 0, st>>>(v, d_campos, d_raydir, d_tmid, q->R, q->D, q->SR, q->K,
                                                                 q->tmid_stride, d_sample_pidx, d_sample_loc_w,
-                                                                d_ray_nsamp, d_ray_mask, d_work, cnt);
+                                                                d_ray_nsamp, d_ray_mask);
     HNR_LAUNCH_CHECK();
     const int layers = (q->kernel_size[0] + 1) / 2;
     const int max_items = q->R * q->SR;
+    // scratch layout inside d_work: [R*SR work items | 2*nb block sums | pad to 8 B | 4*knn_blocks u64 stats]
+    const int nb = cdiv(q->R, 1024);
+    int32_t *block_sums = d_work + (size_t)max_items;
+    size_t stats_off = ((size_t)max_items + 2 * (size_t)nb + 1) & ~(size_t)1;
+    unsigned long long *block_stats = reinterpret_cast<unsigned long long *>(d_work + stats_off);
+    nsamp_block_sum_kernel<<<nb, 1024, 0, st>>>(d_ray_nsamp, q->R, block_sums);
+    worklist_kernel<<<nb, 1024, 0, st>>>(d_ray_nsamp, q->R, q->SR, block_sums, nb, d_work, cnt);
+    HNR_LAUNCH_CHECK();
     switch (q->K) {
-#define HNR_KCASE(KK) case KK: launch_knn<KK>(v, d_work, d_sample_loc_w, q->SR, q->radius2, layers, d_sample_pidx, d_ray_mask, cnt, max_items, st); break;
+#define HNR_KCASE(KK) case KK: launch_knn<KK>(v, d_work, d_sample_loc_w, q->SR, q->radius2, layers, d_sample_pidx, d_ray_mask, cnt, block_stats, max_items, st); break;
         HNR_KCASE(1) HNR_KCASE(2) HNR_KCASE(3) HNR_KCASE(4) HNR_KCASE(5) HNR_KCASE(6) HNR_KCASE(7) HNR_KCASE(8)
         HNR_KCASE(12) HNR_KCASE(16) HNR_KCASE(24) HNR_KCASE(32)
 #undef HNR_KCASE
@@ -321,6 +415,14 @@ extern "C" int hnr_march_query(const hnr_grid *g, const float *d_campos, const f
     }
     HNR_LAUNCH_CHECK();
     return HNR_OK;
+}
+
+extern "C" int64_t hnr_query_work_elems(int R, int SR)
+{
+    if (R < 0 || SR <= 0) return 0;
+    const int64_t items = (int64_t)R * SR;
+    const int64_t nb = (R + 1023) / 1024;
+    return ((items + 2 * nb + 1) & ~(int64_t)1) + 2 * 4 * (int64_t)knn_blocks((int)(items < (1ll << 30) ? items : (1ll << 30))) + 2;
 }
 
 extern "C" int hnr_ray_compact_plan(const int8_t *d_ray_mask, int R, int32_t *d_ray_row, int32_t *d_scratch,

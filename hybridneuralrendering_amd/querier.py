@@ -156,7 +156,7 @@ def march_query(grid, campos, raydir, tmid, SR, K, radius2, kernel_size):
     loc = torch.empty((R, SR, 3), dtype=torch.float32, device=dev)
     nsamp = torch.empty((R,), dtype=torch.int32, device=dev)
     mask = torch.empty((R,), dtype=torch.int8, device=dev)
-    work = torch.empty((max(R * SR, 1),), dtype=torch.int32, device=dev)
+    work = torch.empty((max(int(L.hnr_query_work_elems(R, int(SR))), 2),), dtype=torch.int32, device=dev)
     counts = torch.empty((NCOUNTS,), dtype=torch.int64, device=dev)
     with torch.cuda.device(dev):
         _lib.check(L.hnr_march_query(grid.handle, _lib.ptr(campos), _lib.ptr(raydir), _lib.ptr(tmid), ctypes.byref(q),

@@ -120,10 +120,12 @@ enum {
  *   d_sample_loc_w [R,SR,3] f32, 0 padded          (reference: sample_loc before :709)
  *   d_ray_nsamp    [R]      i32  shading samples kept on the ray
  *   d_ray_mask     [R]      i8   1 iff the ray has >= 1 neighbour (reference: ray_mask, :707,:711)
- *   d_work         [R*SR]   i32  scratch: packed (ray*SR+slot) list of kept samples
+ *   d_work         i32[hnr_query_work_elems(R,SR)]  scratch; its first counts[HNR_CNT_SAMPLES] entries are the
+ *                  packed (ray*SR+slot) list of kept samples in (ray, slot) order
  *   d_counts       [HNR_NCOUNTS] i64
  * d_campos [3], d_raydir [R,3], d_tmid see tmid_stride.  No host synchronisation.
  */
+int64_t hnr_query_work_elems(int R, int SR);
 int hnr_march_query(const hnr_grid *g, const float *d_campos, const float *d_raydir, const float *d_tmid,
                     const hnr_query_params *q,
                     int32_t *d_sample_pidx, float *d_sample_loc_w, int32_t *d_ray_nsamp, int8_t *d_ray_mask,
