@@ -66,6 +66,9 @@ SCENE_OPTS = {
 }
 
 
+ROOM_SIZE = {"scene0241": (5.4, 4.1, 2.5), "scene0101": (8.0, 6.0, 3.0)}
+
+
 def scene_opt(name, **kw):
     d = dict(SCENE_OPTS[name])
     d.update(kw)
@@ -199,11 +202,11 @@ def reference_images(n_views, h, w, seed):
                 ph = rng.uniform(0, 2 * np.pi, size=2)
                 acc += rng.uniform(0.3, 1.0) * np.sin(2 * np.pi * fx * xx + ph[0]) * np.cos(2 * np.pi * fy * yy + ph[1])
             acc = (acc - acc.min()) / (acc.max() - acc.min() + 1e-9)
-            imgs[v, :, :, c] = acc
+            imgs[v, :, :, c] = np.round(acc * 255) / 255          # 8-bit images, like the decoded JPEG frames
     return imgs
 
 
-def make_scene(name, n_points, seed, w=None, h=None, n_views=4):
+def make_scene(name, n_points, seed, w=None, h=None, n_views=4, size=None):
     """Bundle: opt, cloud + attributes, a camera inside/around the scene, 4 neighbouring reference
     cameras and images.  name in SCENE_OPTS."""
     opt = scene_opt(name)
@@ -220,11 +223,15 @@ def make_scene(name, n_points, seed, w=None, h=None, n_views=4):
             rot = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]])
             cams.append(look_at(ctr + rot @ (eye - ctr), ctr))
     else:
-        xyz, nrm = room_cloud(n_points, seed)
+        # Room sized so that the occupied-voxel count of a 2 M (4 M) point cloud stays below the scene's
+        # max_o, as it does for the real scans (scene0241: ~0.55 M of 0.61 M; scene0101: ~1.0 M of 2.0 M).
+        size = size or ROOM_SIZE[name]
+        xyz, nrm = room_cloud(n_points, seed, size=size, clutter_frac=0.2, thickness=0.003)
         w, h = w or 640, h or 480
         focal = 577.87 * w / 640.0                                # ScanNet colour intrinsics, scaled
-        eye = np.array([-2.6, -1.7, 0.1])
-        tgt = np.array([2.5, 1.6, -0.6])
+        sz = np.asarray(size)
+        eye = sz * np.array([-0.33, -0.28, 0.03])
+        tgt = sz * np.array([0.31, 0.27, -0.2])
         cams = [look_at(eye, tgt)]
         for k in range(n_views):
             off = np.array([0.06, -0.05, 0.01]) * (k - (n_views - 1) / 2 + 0.5) * 2

@@ -1,0 +1,28 @@
+"""Loads the committed golden fixtures (tests/golden/*.npz|json) -- data only."""
+import json
+import os
+
+import numpy as np
+import torch
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_render(tag):
+    z = np.load(os.path.join(GOLD, "render_%s.npz" % tag), allow_pickle=False)
+    d = {k: z[k] for k in z.files}
+    d["opt"] = json.loads(str(d.pop("opt_json")))
+    d["images_nearest"] = d["images_nearest"].astype(np.float32) / np.float32(255)
+    d["sd"] = {k[3:]: torch.from_numpy(v) for k, v in d.items() if k.startswith("sd.")}
+    return d
+
+
+def torch_inputs(d, device="cpu"):
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    c2w = d["c2w"]
+    return dict(
+        xyz=t(d["xyz"]), emb=t(d["emb"]), conf=t(d["conf"]), pdir=t(d["pdir"]), color=t(d["color"]),
+        campos=t(c2w[:3, 3])[None], camrotc2w=t(c2w[:3, :3])[None], raydir=t(d["raydir"])[None],
+        bg_color=t(d["bg_color"])[None], c2w_nearest=t(d["c2w_nearest"])[None],
+        campos_nearest=t(d["c2w_nearest"][:, :3, 3])[None], intrinsic_nearest=t(d["intrinsic"])[None],
+        images_nearest=t(d["images_nearest"])[None])
