@@ -51,6 +51,18 @@ SIGNATURES = {
     "hnr_march_query": (_I, [_P, _P, _P, _P, ctypes.POINTER(QueryParams), _P, _P, _P, _P, _P, _P, _P]),
     "hnr_ray_compact_plan": (_I, [_P, _I, _P, _P, _P, _P]),
     "hnr_ray_compact": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "hnr_linear_packed_dims": (_I, [_I, _I, ctypes.POINTER(_I), ctypes.POINTER(_I)]),
+    "hnr_linear_pack": (_I, [_P, _P, _I, _I, _P, _P, _P]),
+    "hnr_linear_f32": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
+    "hnr_sample_plan": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _P, _P, _P]),
+    "hnr_gather_rows": (_I, [_P] * 5 + [_I] + [_P] * 9 + [_I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P]),
+    "hnr_ksum": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P, _P]),
+    "hnr_image_features_scratch_elems": (ctypes.c_int64, [_I, _I, _I]),
+    "hnr_image_features": (_I, [_P, _I, _I, _I, ctypes.POINTER(_P), ctypes.POINTER(_P), _F, _P, _P, _P]),
+    "hnr_proj_rows": (_I, [_P] * 8 + [_I, _I, _I, _P, _I, _I, _P, _I, _P, _P]),
+    "hnr_merge": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _P, _I, _P]),
+    "hnr_final_color": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P]),
+    "hnr_composite": (_I, [_P] * 7 + [_I, _I, _I, _F, _I, _P, _P, _P, _P, _P]),
 }
 
 _lib = None

@@ -1,0 +1,152 @@
+"""Host-side mirror of the reference's PointAggregator (viewmlp, order-2 hybrid path) over libhnr_hip.so.
+
+Same parameter names and shapes as /root/reference/models/aggregators/point_aggregators.py:484-754
+(`block1.{0,2}`, `block3.{0,2}`, `alpha_branch.0`, `color_branch.{0,2,4,6}` (constructed, never used --
+:542-553 vs :1001-1037), `color_feature_branch.{0,2,4}`, `aux_merge_weight_block.{0,2,4,6}`,
+`aux_block_s{1,2,3}.{0,2}`, `color_mixup_block.{0,2,4}`, `color_final_block.0`), so a reference
+`*_net_ray_marching.pth` loads with `load_state_dict` unchanged.
+
+Only the configuration family the 19 shipped launch scripts use is implemented; anything else raises
+ instead of silently computing something different.
+"""
+import ctypes
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import HnrError
+from .linear import PackedLinear
+
+_REQUIRED = dict(which_agg_model="viewmlp", agg_distance_kernel="linear", agg_intrp_order=2, agg_dist_pers=20,
+                 apply_pnt_mask=1, num_feat_freqs=3, dist_xyz_freq=5, num_viewdir_freqs=4, view_ori=0,
+                 point_features_dim=32, shading_feature_num=256, shading_feature_mlp_layer1=2,
+                 shading_feature_mlp_layer2=0, shading_feature_mlp_layer3=2, shading_alpha_mlp_layer=1,
+                 shading_color_mlp_layer=4, act_type="LeakyReLU", act_super=1, agg_feat_xyz_mode="None",
+                 agg_alpha_xyz_mode="None", agg_color_xyz_mode="None", feature_guidance=1, mixup_mode="partial",
+                 learn_residuals=1, use_delta_view=1, tradition_attention=0, refine_blend=0, dynamic_weight=0, add_idx=0,
+                 separate_color_decoder=0, large_color_final_block=0, use_2D_CNN=0, learnable_blur_kernel=0,
+                 disable_viewdirs=0, disable_color_feature=0, point_conf_mode="1", point_dir_mode="1", point_color_mode="1")
+
+
+def check_opt(opt):
+    bad = []
+    for k, v in _REQUIRED.items():
+        got = getattr(opt, k, v)
+        if got != v:
+            bad.append("%s=%r (supported: %r)" % (k, got, v))
+    if float(getattr(opt, "dist_xyz_deno", 0.0)) != 0.0:
+        bad.append("dist_xyz_deno=%r (supported: 0)" % opt.dist_xyz_deno)
+    if getattr(opt, "agg_weight_norm", 1) <= 0:
+        bad.append("agg_weight_norm<=0")
+    aw = getattr(opt, "agg_axis_weight", None)
+    if aw is not None and not (float(aw[0]) == 1.0 and float(aw[2]) == 1.0):
+        bad.append("agg_axis_weight=%r (supported: None or 1 1 1)" % (aw,))
+    if bad:
+        raise HnrError("PointAggregator: unsupported option(s) for the HIP path: " + "; ".join(bad))
+
+
+def _xavier_uniform_(m, gain):
+    # models/helpers/networks.py:83-122
+    if isinstance(m, nn.Conv2d):
+        ks = m.kernel_size[0] * m.kernel_size[1]
+        std = gain * np.sqrt(2.0 / ((m.in_channels + m.out_channels) * ks))
+    else:
+        std = gain * np.sqrt(2.0 / (m.in_features + m.out_features))
+    m.weight.data.uniform_(-std * np.sqrt(3.0), std * np.sqrt(3.0))
+
+
+def _init_seq(s):
+    # models/helpers/networks.py:163-172
+    mods = list(s)
+    for a, b in zip(mods[:-1], mods[1:]):
+        if isinstance(a, (nn.Linear, nn.Conv2d)):
+            gain = nn.init.calculate_gain("leaky_relu", b.negative_slope) if isinstance(b, nn.LeakyReLU) else 1
+            _xavier_uniform_(a, gain)
+    if isinstance(mods[-1], (nn.Linear, nn.Conv2d)):
+        _xavier_uniform_(mods[-1], 1)
+
+
+def _mlp(dims, act_last=True, final=None):
+    layers = []
+    for i in range(len(dims) - 1):
+        layers.append(nn.Linear(dims[i], dims[i + 1]))
+        if act_last or i < len(dims) - 2:
+            layers.append(nn.LeakyReLU(inplace=True))
+    if final is not None:
+        layers.append(final)
+    return nn.Sequential(*layers)
+
+
+def _cnn(cin, cout):
+    return nn.Sequential(nn.Conv2d(cin, cout, 3, stride=2, padding=1), nn.LeakyReLU(inplace=True),
+                         nn.Conv2d(cout, cout, 3, stride=1, padding=1), nn.LeakyReLU(inplace=True))
+
+
+class PointAggregator(nn.Module):
+    def __init__(self, opt):
+        super().__init__()
+        check_opt(opt)
+        self.opt = opt
+        self.block1 = _mlp([284, 256, 256])
+        self.block3 = _mlp([263, 256, 256])
+        self.alpha_branch = nn.Sequential(nn.Linear(256, 1))
+        self.color_branch = _mlp([280, 128, 128, 128, 3], act_last=False)          # checkpointed, unused (:542-553)
+        self.color_feature_branch = _mlp([280, 128, 128, 128])
+        self.aux_merge_weight_block = _mlp([176, 64, 64, 64, 1], act_last=False, final=nn.Sigmoid())
+        self.aux_block_s1 = _cnn(3, 6)
+        self.aux_block_s2 = _cnn(6, 12)
+        self.aux_block_s3 = _cnn(12, 24)
+        self.color_mixup_block = _mlp([90, 45, 45, 45], act_last=False)
+        self.color_final_block = nn.Sequential(nn.Linear(128, 3))
+        for m in (self.block1, self.block3, self.alpha_branch, self.color_branch, self.color_feature_branch,
+                  self.aux_merge_weight_block, self.aux_block_s1, self.aux_block_s2, self.aux_block_s3,
+                  self.color_mixup_block, self.color_final_block):
+            _init_seq(m)
+        self._packed = None
+        self._packed_key = None
+
+    # ------------------------------------------------------------------------------------------
+    def packed(self):
+        """Weights in the kernels' layouts, re-packed only when a parameter changed."""
+        key = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if self._packed is not None and key == self._packed_key:
+            return self._packed
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise HnrError("PointAggregator weights must be on the GPU (there is no CPU path)")
+        lin = lambda seq, i: PackedLinear(seq[i].weight, seq[i].bias)
+        f32 = lambda t: t.detach().to(torch.float32).contiguous()
+        pk = dict(
+            b1=[lin(self.block1, 0), lin(self.block1, 2)], b3=[lin(self.block3, 0), lin(self.block3, 2)],
+            cf=[lin(self.color_feature_branch, i) for i in (0, 2, 4)],
+            mw=[lin(self.aux_merge_weight_block, i) for i in (0, 2, 4)],
+            mx=[lin(self.color_mixup_block, i) for i in (0, 2, 4)],
+            alpha_w=f32(self.alpha_branch[0].weight).reshape(256), alpha_b=f32(self.alpha_branch[0].bias).reshape(1),
+            mw_last_w=f32(self.aux_merge_weight_block[6].weight).reshape(64), mw_last_b=f32(self.aux_merge_weight_block[6].bias).reshape(1),
+            fin_w=f32(self.color_final_block[0].weight).reshape(3 * 128), fin_b=f32(self.color_final_block[0].bias).reshape(3),
+            conv_w=[f32(m[i].weight) for m in (self.aux_block_s1, self.aux_block_s2, self.aux_block_s3) for i in (0, 2)],
+            conv_b=[f32(m[i].bias) for m in (self.aux_block_s1, self.aux_block_s2, self.aux_block_s3) for i in (0, 2)],
+            slope=float(self.block1[1].negative_slope),
+        )
+        self._packed, self._packed_key = pk, key
+        return pk
+
+    def image_features(self, images_nearest):
+        """[1,V,H,W,3] -> channels-last feature map [V,H,W,48] (hnr_image_features); once per frame."""
+        L = _lib.lib()
+        pk = self.packed()
+        img = _lib.require_gpu(images_nearest, "images_nearest", torch.float32)
+        if img.dim() == 5:
+            img = img[0]
+        V, H, W, _ = img.shape
+        dev = img.device
+        fm = torch.empty((V, H, W, 48), dtype=torch.float32, device=dev)
+        scratch = torch.empty((max(int(L.hnr_image_features_scratch_elems(V, H, W)), 1),), dtype=torch.float32, device=dev)
+        wp = (ctypes.c_void_p * 6)(*[t.data_ptr() for t in pk["conv_w"]])
+        bp = (ctypes.c_void_p * 6)(*[t.data_ptr() for t in pk["conv_b"]])
+        with torch.cuda.device(dev):
+            _lib.check(L.hnr_image_features(_lib.ptr(img), V, H, W, wp, bp, pk["slope"], _lib.ptr(scratch), _lib.ptr(fm),
+                                            _lib.stream()), "hnr_image_features")
+        return fm

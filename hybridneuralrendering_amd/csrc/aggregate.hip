@@ -1,0 +1,749 @@
+// Gather + row assembly + K-sum + image-feature merge + final colour: everything of
+// PointAggregator.forward / viewmlp (models/aggregators/point_aggregators.py:1427-1522, :892-1338)
+// and NeuralPoints' gather (models/neural_points/neural_points.py:709-720) that is not a dense layer
+// (those run in linear.hip).  Restated for the shipped configuration only:
+// viewmlp, agg_intrp_order=2, linear kernel, agg_dist_pers=20, 3/5/4 PE freqs, hybrid image branch.
+//
+// Row order everywhere is the reference's boolean-mask order: (ray, slot, k) ascending.
+#include "hnr_common.h"
+
+namespace hnr {
+
+// ------------------------------------------------------------------------------------------------
+// Plan: exclusive scans over the work list of kept samples -> compact lists of VALID samples (>= 1
+// neighbour) and of neighbour rows.  Two-level scan, no atomics, deterministic.
+__device__ __forceinline__ int count_neighbours(const int32_t *__restrict__ p, int K)
+{
+    int n = 0;                                        // valid ids are a prefix (reference :494-496)
+    while (n < K && p[n] >= 0) ++n;
+    return n;
+}
+
+__global__ __launch_bounds__(1024) void plan_block_sum_kernel(const int32_t *__restrict__ work, const int32_t *__restrict__ pidx,
+                                                              const unsigned long long *__restrict__ counts, int K,
+                                                              int32_t *__restrict__ block_sums)
+{
+    __shared__ int s_a[16], s_b[16];
+    const int n_items = (int)counts[HNR_CNT_SAMPLES];
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    int nb = i < n_items ? count_neighbours(pidx + (size_t)work[i] * K, K) : 0;
+    int v = nb > 0;
+    for (int o = 32; o > 0; o >>= 1) { nb += __shfl_xor(nb, o); v += __shfl_xor(v, o); }
+    if ((threadIdx.x & 63) == 0) { s_a[threadIdx.x >> 6] = v; s_b[threadIdx.x >> 6] = nb; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int a = 0, b = 0;
+        for (int k = 0; k < 16; ++k) { a += s_a[k]; b += s_b[k]; }
+        block_sums[2 * blockIdx.x] = a;
+        block_sums[2 * blockIdx.x + 1] = b;
+    }
+}
+
+// vs_item[s] = ray*SR+slot of valid sample s; vs_off[s] = first neighbour row; vs_cnt[s] = #neighbours
+__global__ __launch_bounds__(1024) void plan_scan_kernel(const int32_t *__restrict__ work, const int32_t *__restrict__ pidx,
+                                                         const unsigned long long *__restrict__ counts, int K,
+                                                         const int32_t *__restrict__ block_sums,
+                                                         int32_t *__restrict__ vs_item, int32_t *__restrict__ vs_off,
+                                                         int32_t *__restrict__ vs_cnt, int cap_samples, int cap_rows,
+                                                         int32_t *__restrict__ overflow)
+{
+    __shared__ int s_a[16], s_b[16];
+    __shared__ int s_base[2];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int n_items = (int)counts[HNR_CNT_SAMPLES];
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    int pa = 0, pb = 0;
+    for (int k = threadIdx.x; k < (int)blockIdx.x; k += 1024) { pa += block_sums[2 * k]; pb += block_sums[2 * k + 1]; }
+    for (int o = 32; o > 0; o >>= 1) { pa += __shfl_xor(pa, o); pb += __shfl_xor(pb, o); }
+    if (lane == 0) { s_a[wid] = pa; s_b[wid] = pb; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int a = 0, b = 0;
+        for (int k = 0; k < 16; ++k) { a += s_a[k]; b += s_b[k]; }
+        s_base[0] = a; s_base[1] = b;
+    }
+    __syncthreads();
+    int item = 0, nb = 0;
+    if (i < n_items) { item = work[i]; nb = count_neighbours(pidx + (size_t)item * K, K); }
+    const int v = nb > 0;
+    int ia = v, ib = nb;
+    for (int o = 1; o < 64; o <<= 1) {
+        const int ta = __shfl_up(ia, o), tb = __shfl_up(ib, o);
+        if (lane >= o) { ia += ta; ib += tb; }
+    }
+    __syncthreads();
+    if (lane == 63) { s_a[wid] = ia; s_b[wid] = ib; }
+    __syncthreads();
+    int oa = s_base[0] + ia - v, ob = s_base[1] + ib - nb;
+    for (int k = 0; k < wid; ++k) { oa += s_a[k]; ob += s_b[k]; }
+    if (v) {
+        if (oa < cap_samples && ob + nb <= cap_rows) {
+            vs_item[oa] = item; vs_off[oa] = ob; vs_cnt[oa] = nb;
+        } else {
+            *overflow = 1;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Gather + geometry + row assembly.  One 256-thread block handles 32 valid samples (up to 32*K rows):
+//  phase 1: one lane per (sample, k): fetch the point record, w2pers, dists6, inverse-distance weight;
+//  phase 2: the block writes the 284-wide block1 rows and the 7 extra block3 columns, one lane per
+//           column so that every row is stored as contiguous 16-B-aligned bursts.
+// K <= 8 (lanes 8 per sample); larger K loops.
+struct GatherArgs {
+    const float *xyz, *emb, *conf, *pdir, *color;       // point buffers [N,3] [N,F] [N] [N,3] [N,3]
+    int F;                                               // embedding width (32)
+    const int32_t *pidx;                                 // [R,SR,K]
+    const float *loc_w;                                  // [R,SR,3]
+    const float *raydir;                                 // [R,3]
+    const float *campos, *camrot;                        // [3], [3,3]
+    const int32_t *vs_item, *vs_off, *vs_cnt;
+    const unsigned long long *counts;
+    int SR, K;
+    float *X1; int ld1;                                  // [rows, ld1]  block1 input (F + 6F + 60)
+    float *X3; int ld3;                                  // [rows, ld3]  block3 input; cols 256..262 written here
+    float *wagg;                                         // [rows] normalised weight * clamp(conf)
+    float *weight_out, *conf_out;                        // optional [R,SR,K] (reference outputs), may be NULL
+};
+
+constexpr int G_SAMPLES = 32;      // valid samples per block
+constexpr int G_RAW = 40;          // emb32 + dists6 (+2 pad)
+
+__device__ __forceinline__ void w2pers(const float *p, const float *campos, const float *camrot, float out[3])
+{
+    // neural_points.py:607-613 / query_point_indices_worldcoords.py:96-103: c[j] = sum_i shift[i] * camrot[i][j]
+    const float s0 = __fsub_rn(p[0], campos[0]), s1 = __fsub_rn(p[1], campos[1]), s2 = __fsub_rn(p[2], campos[2]);
+    float c[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+        c[j] = __fadd_rn(__fadd_rn(__fmul_rn(camrot[j], s0), __fmul_rn(camrot[3 + j], s1)), __fmul_rn(camrot[6 + j], s2));
+    out[0] = __fdiv_rn(c[0], c[2]); out[1] = __fdiv_rn(c[1], c[2]); out[2] = c[2];
+}
+
+template <int F>
+__global__ __launch_bounds__(256) void gather_rows_kernel(GatherArgs a)
+{
+    __shared__ float s_raw[G_SAMPLES * 8][G_RAW];     // per row: emb[F], dists[6]
+    __shared__ float s_ext[G_SAMPLES * 8][8];         // per row: color3, dir-view3, dir.view, (pad)
+    __shared__ int s_row[G_SAMPLES * 8];              // global row or -1
+    const int n_valid = (int)a.counts[HNR_CNT_SAMPLES_VALID];
+    const int s0 = blockIdx.x * G_SAMPLES;
+    if (s0 >= n_valid) return;
+    const int tid = threadIdx.x;
+    const int K = a.K;
+    const float cp[3] = {a.campos[0], a.campos[1], a.campos[2]};
+    float cr[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) cr[i] = a.camrot[i];
+
+    for (int kbase = 0; kbase < K; kbase += 8) {
+        // ---- phase 1: lane (ls, kk) ----
+        const int ls = tid >> 3, kk = kbase + (tid & 7);
+        const int s = s0 + ls;
+        int row = -1;
+        float wraw = 0.f, confc = 0.f;
+        int item = 0;
+        if (s < n_valid) {
+            item = a.vs_item[s];
+            const int cnt = a.vs_cnt[s];
+            if (kk < K && kk < cnt) row = a.vs_off[s] + kk;
+        }
+        if (row >= 0) {
+            const int pid = a.pidx[(size_t)item * K + kk];
+            const float *lw = a.loc_w + (size_t)item * 3;
+            float sp[3], pp[3];
+            w2pers(lw, cp, cr, sp);
+            const float px = a.xyz[3 * (size_t)pid], py = a.xyz[3 * (size_t)pid + 1], pz = a.xyz[3 * (size_t)pid + 2];
+            const float pw[3] = {px, py, pz};
+            w2pers(pw, cp, cr, pp);
+            float *raw = s_raw[tid];
+            const float4 *e4 = reinterpret_cast<const float4 *>(a.emb + (size_t)pid * F);
+#pragma unroll
+            for (int i = 0; i < F / 4; ++i) {
+                const float4 v = e4[i];
+                raw[4 * i] = v.x; raw[4 * i + 1] = v.y; raw[4 * i + 2] = v.z; raw[4 * i + 3] = v.w;
+            }
+            // dists (point_aggregators.py:1472-1480)
+            const float dx = __fsub_rn(px, lw[0]), dy = __fsub_rn(py, lw[1]), dz = __fsub_rn(pz, lw[2]);
+            raw[F + 0] = dx; raw[F + 1] = dy; raw[F + 2] = dz;
+            raw[F + 3] = __fsub_rn(__fmul_rn(pp[0], pp[2]), __fmul_rn(sp[0], sp[2]));
+            raw[F + 4] = __fsub_rn(__fmul_rn(pp[1], pp[2]), __fmul_rn(sp[1], sp[2]));
+            raw[F + 5] = __fsub_rn(pp[2], sp[2]);
+            // linear kernel (:825-833)
+            const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
+            wraw = __fdiv_rn(1.0f, fmaxf(nrm, 1e-6f));
+            const float cf = a.conf[pid];
+            confc = fminf(fmaxf(cf, 0.0001f), 1.0f);                 // gradiant_clamp forward value (:1422-1424)
+            // block3 extras (:957-971): colour, dir - viewdir, dir . viewdir (viewdir = raw ray direction)
+            const int ray = item / a.SR;
+            const float vx = a.raydir[3 * (size_t)ray], vy = a.raydir[3 * (size_t)ray + 1], vz = a.raydir[3 * (size_t)ray + 2];
+            const float ddx = a.pdir[3 * (size_t)pid], ddy = a.pdir[3 * (size_t)pid + 1], ddz = a.pdir[3 * (size_t)pid + 2];
+            float *ext = s_ext[tid];
+            ext[0] = a.color[3 * (size_t)pid]; ext[1] = a.color[3 * (size_t)pid + 1]; ext[2] = a.color[3 * (size_t)pid + 2];
+            ext[3] = __fsub_rn(ddx, vx); ext[4] = __fsub_rn(ddy, vy); ext[5] = __fsub_rn(ddz, vz);
+            ext[6] = __fadd_rn(__fadd_rn(__fmul_rn(ddx, vx), __fmul_rn(ddy, vy)), __fmul_rn(ddz, vz));
+        }
+        s_row[tid] = row;
+        // normalise over the sample's K neighbours (:1500-1501).  With K <= 8 the 8 lanes of a sample hold all
+        // of them; for K > 8 the sum is carried across kbase passes below.
+        float sum = wraw;
+        sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4);
+        if (K > 8) {
+            // second pass over the other chunks to complete the sum (rare configuration)
+            float extra = 0.f;
+            if (s < n_valid) {
+                const int cnt = a.vs_cnt[s];
+                for (int k2 = 0; k2 < cnt; ++k2) {
+                    if (k2 >= kbase && k2 < kbase + 8) continue;
+                    const int pid2 = a.pidx[(size_t)item * K + k2];
+                    const float *lw = a.loc_w + (size_t)item * 3;
+                    const float ex = __fsub_rn(a.xyz[3 * (size_t)pid2], lw[0]), ey = __fsub_rn(a.xyz[3 * (size_t)pid2 + 1], lw[1]),
+                                ez = __fsub_rn(a.xyz[3 * (size_t)pid2 + 2], lw[2]);
+                    const float n2 = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)), __fmul_rn(ez, ez)));
+                    extra += __fdiv_rn(1.0f, fmaxf(n2, 1e-6f));
+                }
+            }
+            sum += extra;
+        }
+        if (row >= 0) {
+            const float w = __fdiv_rn(wraw, fmaxf(sum, 1e-8f));
+            a.wagg[row] = __fmul_rn(w, confc);
+            if (a.weight_out) { a.weight_out[(size_t)item * K + kk] = w; a.conf_out[(size_t)item * K + kk] = confc; }
+        }
+        __syncthreads();
+        // ---- phase 2: block-wide row assembly; lane = column ----
+        constexpr int NCOL1 = F + 6 * F + 60;
+        for (int r = 0; r < G_SAMPLES * 8; ++r) {
+            const int grow = s_row[r];
+            if (grow < 0) continue;
+            const float *raw = s_raw[r];
+            float *o1 = a.X1 + (size_t)grow * a.ld1;
+            for (int c = tid; c < NCOL1; c += 256) {
+                float v;
+                if (c < F) {
+                    v = raw[c];
+                } else if (c < 7 * F) {
+                    const int cc = c - F, d = cc / 6, rem = cc - 6 * d, f = rem >> 1;
+                    const float x = __fmul_rn(raw[d], (float)(1 << f));       // positional_encoding (networks.py:182-189)
+                    v = (rem & 1) ? cosf(x) : sinf(x);
+                } else {
+                    const int cc = c - 7 * F, d = cc / 10, rem = cc - 10 * d, f = rem >> 1;
+                    const float x = __fmul_rn(raw[F + d], (float)(1 << f));
+                    v = (rem & 1) ? cosf(x) : sinf(x);
+                }
+                o1[c] = v;
+            }
+            if (tid < 7) a.X3[(size_t)grow * a.ld3 + 256 + tid] = s_ext[r][tid];
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K-weighted sum (:1005-1026) + alpha branch + colour-feature-branch input (:1028-1036).
+// One wave per valid sample; 64 lanes x float4 = one 256-wide row per load.
+struct KsumArgs {
+    const float *H4; int ldh;                         // [rows, ldh] block3 output (256 wide)
+    const float *wagg;                                // [rows]
+    const float *alpha_w, *alpha_b;                   // alpha_branch.0: [256], [1]
+    const int32_t *vs_item, *vs_off, *vs_cnt;
+    const float *raydir;                              // [R,3]
+    const unsigned long long *counts;
+    int SR;
+    float *X5; int ld5;                               // [S_v, ld5]: feat256 | sin(viewdir 2^f) 12 | cos 12
+    float *sigma;                                     // [S_v]
+};
+
+__device__ __forceinline__ float softplus_m1(float x)
+{
+    const float y = __fsub_rn(x, 1.0f);                // raw2out_density: softplus(x - 1), beta=1, threshold=20
+    return y > 20.f ? y : log1pf(expf(y));
+}
+
+__global__ __launch_bounds__(256) void ksum_kernel(KsumArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int s = (int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6);
+    const int n_valid = (int)a.counts[HNR_CNT_SAMPLES_VALID];
+    if (s >= n_valid) return;
+    const int off = a.vs_off[s], cnt = a.vs_cnt[s];
+    const float4 aw = reinterpret_cast<const float4 *>(a.alpha_w)[lane];
+    const float ab = a.alpha_b[0];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float sig = 0.f;
+    for (int k = 0; k < cnt; ++k) {
+        const float4 h = reinterpret_cast<const float4 *>(a.H4 + (size_t)(off + k) * a.ldh)[lane];
+        const float w = a.wagg[off + k];
+        float d = h.x * aw.x + h.y * aw.y + h.z * aw.z + h.w * aw.w;
+        for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
+        sig += softplus_m1(d + ab) * w;
+        acc.x += h.x * w; acc.y += h.y * w; acc.z += h.z * w; acc.w += h.w * w;
+    }
+    float *o = a.X5 + (size_t)s * a.ld5;
+    reinterpret_cast<float4 *>(o)[lane] = acc;
+    if (lane < 24) {
+        // positional_encoding(viewdirs, 4, ori=True)[3:] = [sin(d*F+f) x12 | cos x12] (:909-913)
+        const int ray = a.vs_item[s] / a.SR;
+        const int j = lane % 12, d = j >> 2, f = j & 3;
+        const float x = __fmul_rn(a.raydir[3 * (size_t)ray + d], (float)(1 << f));
+        o[256 + lane] = lane < 12 ? sinf(x) : cosf(x);
+    }
+    if (lane == 0) a.sigma[s] = sig;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Reference-view image features: 3x3 conv pyramid (:1047-1063), bilinear upsample + concat (:1064-1067)
+// into a channels-last [V,H,W,48] map (45 used), pixel (0,0) zeroed (:1089).  Once per frame.
+__global__ void conv3x3_lrelu_kernel(const float *__restrict__ in, int Cin, int Hin, int Win, int in_cl, int in_cstride,
+                                     const float *__restrict__ w, const float *__restrict__ b, int Cout, int stride,
+                                     int Hout, int Wout, float slope, float *__restrict__ out, int V)
+{
+    // in: NCHW planar [V,Cin,Hin,Win] (in_cl = 0) or channels-last [V,Hin,Win,in_cstride] (in_cl = 1); out: NCHW planar
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)V * Cout * Hout * Wout;
+    if (idx >= total) return;
+    const int ox = (int)(idx % Wout), oy = (int)((idx / Wout) % Hout), co = (int)((idx / ((int64_t)Wout * Hout)) % Cout),
+              v = (int)(idx / ((int64_t)Wout * Hout * Cout));
+    float acc = b[co];
+    for (int ci = 0; ci < Cin; ++ci)
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy * stride - 1 + ky;
+            if (iy < 0 || iy >= Hin) continue;
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = ox * stride - 1 + kx;
+                if (ix < 0 || ix >= Win) continue;
+                const float x = in_cl ? in[(((size_t)v * Hin + iy) * Win + ix) * in_cstride + ci]
+                                      : in[(((size_t)v * Cin + ci) * Hin + iy) * Win + ix];
+                acc = fmaf(x, w[((co * Cin + ci) * 3 + ky) * 3 + kx], acc);
+            }
+        }
+    out[idx] = acc > 0.f ? acc : acc * slope;
+}
+
+__device__ __forceinline__ float bilinear_at(const float *__restrict__ p, int Hs, int Ws, int H, int W, int y, int x)
+{
+    // F.interpolate(mode='bilinear', align_corners=False): src = (dst + 0.5) * (in/out) - 0.5, clamped at 0
+    const float sy = (float)Hs / (float)H, sx = (float)Ws / (float)W;
+    float fy = ((float)y + 0.5f) * sy - 0.5f, fx = ((float)x + 0.5f) * sx - 0.5f;
+    if (fy < 0.f) fy = 0.f;
+    if (fx < 0.f) fx = 0.f;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < Hs - 1 ? 1 : 0), x1 = x0 + (x0 < Ws - 1 ? 1 : 0);
+    const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+    return hy * (hx * p[(size_t)y0 * Ws + x0] + lx * p[(size_t)y0 * Ws + x1]) + ly * (hx * p[(size_t)y1 * Ws + x0] + lx * p[(size_t)y1 * Ws + x1]);
+}
+
+__global__ void featmap_kernel(const float *__restrict__ img /*[V,H,W,3]*/, const float *__restrict__ s1, const float *__restrict__ s2,
+                               const float *__restrict__ s3, int V, int H, int W, int H1, int W1, int H2, int W2, int H3, int W3,
+                               float *__restrict__ fm /*[V,H,W,48]*/)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)V * H * W * 48;
+    if (idx >= total) return;
+    const int c = (int)(idx % 48);
+    const int64_t pix = idx / 48;
+    const int x = (int)(pix % W), y = (int)((pix / W) % H), v = (int)(pix / ((int64_t)W * H));
+    float val = 0.f;
+    if (!(x == 0 && y == 0)) {                     // aux_feature_output[:, :, 0, 0] *= 0  (:1089)
+        if (c < 3) val = img[pix * 3 + c];
+        else if (c < 9) val = bilinear_at(s1 + ((size_t)v * 6 + (c - 3)) * H1 * W1, H1, W1, H, W, y, x);
+        else if (c < 21) val = bilinear_at(s2 + ((size_t)v * 12 + (c - 9)) * H2 * W2, H2, W2, H, W, y, x);
+        else if (c < 45) val = bilinear_at(s3 + ((size_t)v * 24 + (c - 21)) * H3 * W3, H3, W3, H, W, y, x);
+    }
+    fm[idx] = val;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Merge-weight rows (:1074-1096, :1188-1199): one wave per (view, valid sample): reprojection (w2iproject,
+// neural_points_volumetric_model.py:248-255), truncation to a pixel, 45-float gather, delta view direction
+// (:296-310), colour feature copy.  Row = [imgfeat45 | colfeat128 | delta_dir3] (176), lda = 176.
+struct ProjArgs {
+    const float *loc_w;                                 // [R,SR,3]
+    const int32_t *vs_item;
+    const unsigned long long *counts;
+    const float *w2c;                                   // [V,4,4] = inverse(c2w_nearest[v]) row-major
+    const float *Kmat;                                  // [3,3] intrinsic_nearest
+    const float *campos, *campos_n;                     // [3], [V,3]
+    const float *fm; int H, W;                          // [V,H,W,48]
+    const float *CF; int ldcf;                          // [S_v, ldcf] colour feature (128)
+    int V, cap;                                         // cap = row capacity per view (rows are v*cap + s)
+    float *X6; int ld6;                                 // [V*cap, ld6]
+    float *vmask;                                       // [V*cap]
+};
+
+__global__ __launch_bounds__(256) void proj_rows_kernel(ProjArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wv = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int n_valid = (int)a.counts[HNR_CNT_SAMPLES_VALID];
+    if (n_valid == 0) return;
+    const int v = (int)(wv / n_valid);
+    if (v >= a.V) return;
+    const int s = (int)(wv - (int64_t)v * n_valid);
+    const float *p = a.loc_w + (size_t)a.vs_item[s] * 3;
+    const float x = p[0], y = p[1], z = p[2];
+    const float *m = a.w2c + 16 * v;
+    float c[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) c[j] = x * m[4 * j] + y * m[4 * j + 1] + z * m[4 * j + 2] + m[4 * j + 3];
+    float i3[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) i3[j] = c[0] * a.Kmat[3 * j] + c[1] * a.Kmat[3 * j + 1] + c[2] * a.Kmat[3 * j + 2];
+    const float den = i3[2] + 1e-10f;
+    const float fx = i3[0] / den, fy = i3[1] / den;
+    // .to(torch.int32): truncation toward zero; out-of-range / NaN -> invalid
+    int px = (fx > -2.0e9f && fx < 2.0e9f) ? (int)fx : -1;
+    int py = (fy > -2.0e9f && fy < 2.0e9f) ? (int)fy : -1;
+    const bool inval = px < 0 || px >= a.W || py < 0 || py >= a.H;
+    if (inval) { px = 0; py = 0; }
+    const size_t row = (size_t)v * a.cap + s;
+    float *o = a.X6 + row * a.ld6;
+    const float *f = a.fm + (((size_t)v * a.H + py) * a.W + px) * 48;
+    if (lane < 45) o[lane] = f[lane];
+    // colour feature: 128 floats, 2 per lane
+    const float2 cf = reinterpret_cast<const float2 *>(a.CF + (size_t)s * a.ldcf)[lane];
+    o[45 + 2 * lane] = cf.x; o[45 + 2 * lane + 1] = cf.y;
+    if (lane < 3) {
+        // delta view direction (:298-305)
+        const float cx = x - a.campos[0], cy = y - a.campos[1], cz = z - a.campos[2];
+        const float cn = sqrtf(cx * cx + cy * cy + cz * cz) + 1e-6f;
+        const float nx = x - a.campos_n[3 * v], ny = y - a.campos_n[3 * v + 1], nz = z - a.campos_n[3 * v + 2];
+        const float nn = sqrtf(nx * nx + ny * ny + nz * nz) + 1e-6f;
+        const float cur = (lane == 0 ? cx : lane == 1 ? cy : cz) / cn;
+        const float nea = (lane == 0 ? nx : lane == 1 ? ny : nz) / nn;
+        o[173 + lane] = nea - cur;
+    }
+    if (lane == 0) a.vmask[row] = inval ? 0.f : 1.f;
+}
+
+// Merge (:1199-1217) + mix-up input (:1286-1292): one wave per valid sample.
+struct MergeArgs {
+    const float *X6; int ld6;                            // rows v*cap+s: [imgfeat45 | ...]
+    const float *Hm; int ldh;                            // [V*cap, ldh] last hidden layer of aux_merge_weight_block (64)
+    const float *w_last, *b_last;                        // aux_merge_weight_block.6: [64], [1]
+    const float *vmask; const float *frame_w;            // [V*cap]; optional [V] (downweight_blurry_feats) or NULL
+    const float *CF; int ldcf;
+    const unsigned long long *counts;
+    int V, cap;
+    float *X7; int ld7;                                  // [S_v, ld7]: colfeat[:45] | merged45
+};
+
+__global__ __launch_bounds__(256) void merge_kernel(MergeArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int s = (int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6);
+    const int n_valid = (int)a.counts[HNR_CNT_SAMPLES_VALID];
+    if (s >= n_valid) return;
+    const float wl = a.w_last[lane];
+    float fsum = 0.f, wsum = 0.f;
+    for (int v = 0; v < a.V; ++v) {
+        const size_t row = (size_t)v * a.cap + s;
+        float d = a.Hm[row * a.ldh + lane] * wl;
+        for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
+        float wv = 1.f / (1.f + expf(-(d + a.b_last[0])));
+        wv *= a.vmask[row];
+        if (a.frame_w) wv *= a.frame_w[v];
+        const float f = lane < 45 ? a.X6[row * a.ld6 + lane] : 0.f;
+        fsum += f * wv;
+        wsum += wv;
+    }
+    float *o = a.X7 + (size_t)s * a.ld7;
+    if (lane < 45) {
+        o[lane] = a.CF[(size_t)s * a.ldcf + lane];
+        o[45 + lane] = fsum / (wsum + 1e-6f);
+    }
+}
+
+// Final colour (:1293-1295, :1334, :478-482) and scatter into decoded [R,SR,4] (:1337-1338). One wave per sample.
+struct FinalArgs {
+    const float *Y; int ldy;                             // [S_v, ldy] color_mixup_block output (45)
+    const float *CF; int ldcf;
+    const float *w_fin, *b_fin;                          // color_final_block.0: [3,128], [3]
+    const float *sigma;
+    const int32_t *vs_item;
+    const unsigned long long *counts;
+    float *decoded;                                      // [R*SR, 4], pre-zeroed
+};
+
+__global__ __launch_bounds__(256) void final_color_kernel(FinalArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int s = (int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6);
+    const int n_valid = (int)a.counts[HNR_CNT_SAMPLES_VALID];
+    if (s >= n_valid) return;
+    float r[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int c = lane + 64 * h;
+        const float cf = a.CF[(size_t)s * a.ldcf + c];
+        const float x = c < 45 ? a.Y[(size_t)s * a.ldy + c] + cf : cf;      // learn_residuals (:1294)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) r[j] += x * a.w_fin[j * 128 + c];
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+        for (int o = 32; o > 0; o >>= 1) r[j] += __shfl_xor(r[j], o);
+    if (lane == 0) {
+        float4 out;
+        out.x = a.sigma[s];
+        float rgb[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float sg = 1.f / (1.f + expf(-(r[j] + a.b_fin[j])));
+            rgb[j] = sg * (1.f + 2.f * 0.001f) - 0.001f;
+        }
+        out.y = rgb[0]; out.z = rgb[1]; out.w = rgb[2];
+        reinterpret_cast<float4 *>(a.decoded)[a.vs_item[s]] = out;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Composite: ray_dist (neural_points_volumetric_model.py:331-339) + ray_march (diff_ray_marching.py:508-557)
+// + fill_invalid (:87-126).  One lane per ray, serial over SR (front to back).
+struct CompositeArgs {
+    const float *decoded;                                // [R,SR,4]
+    const float *loc_w;                                  // [R,SR,3] (zero padded)
+    const int32_t *pidx;                                 // [R,SR,K]
+    const int8_t *ray_mask;                              // [R]
+    const float *campos, *camrot, *bg;                   // [3], [3,3], [3]
+    int R, SR, K;
+    float vsize_z;
+    int unit_mode;
+    float *raycolor;                                     // [R,3]   (background colour where ray_mask == 0)
+    float *opacity;                                      // [R,SR]  (0 where ray_mask == 0)
+    float *is_bg;                                        // [R]     (1 where ray_mask == 0)
+    float *blend_w;                                      // [R,SR] optional
+};
+
+__global__ __launch_bounds__(256) void composite_kernel(CompositeArgs a)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.R) return;
+    const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
+    float *op = a.opacity + (size_t)r * a.SR;
+    if (!a.ray_mask[r]) {
+        a.raycolor[3 * (size_t)r] = bg0; a.raycolor[3 * (size_t)r + 1] = bg1; a.raycolor[3 * (size_t)r + 2] = bg2;
+        a.is_bg[r] = 1.f;
+        for (int s = 0; s < a.SR; ++s) { op[s] = 0.f; if (a.blend_w) a.blend_w[(size_t)r * a.SR + s] = 0.f; }
+        return;
+    }
+    float cr[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) cr[i] = a.camrot[i];
+    const float cp[3] = {a.campos[0], a.campos[1], a.campos[2]};
+    auto zc = [&](int s) {
+        const float *p = a.loc_w + ((size_t)r * a.SR + s) * 3;
+        const float s0 = __fsub_rn(p[0], cp[0]), s1 = __fsub_rn(p[1], cp[1]), s2 = __fsub_rn(p[2], cp[2]);
+        return __fadd_rn(__fadd_rn(__fmul_rn(cr[2], s0), __fmul_rn(cr[5], s1)), __fmul_rn(cr[8], s2));
+    };
+    float T = 1.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
+    float zmax = zc(0);
+    for (int s = 0; s < a.SR; ++s) {
+        float dist;
+        if (s + 1 < a.SR) {
+            const float zn = fmaxf(zmax, zc(s + 1));       // cummax
+            dist = __fsub_rn(zn, zmax);
+            zmax = zn;
+        } else {
+            dist = a.vsize_z;
+        }
+        if (dist < 1e-8f || (a.unit_mode && dist > 2.f * a.vsize_z)) dist = a.vsize_z;
+        const bool valid = a.pidx[((size_t)r * a.SR + s) * a.K] >= 0;      // ray_valid = any(mask over K); ids are a prefix
+        const float4 d = reinterpret_cast<const float4 *>(a.decoded)[(size_t)r * a.SR + s];
+        const float sigma = valid ? d.x : 0.f;
+        const float rd = valid ? dist : 0.f;
+        const float o = 1.f - expf(-sigma * rd);
+        const float bw = o * T;
+        c0 += d.y * bw; c1 += d.z * bw; c2 += d.w * bw;
+        op[s] = o;
+        if (a.blend_w) a.blend_w[(size_t)r * a.SR + s] = bw;
+        T *= (1.f - o + 1e-10f);
+    }
+    a.raycolor[3 * (size_t)r] = c0 + bg0 * T;
+    a.raycolor[3 * (size_t)r + 1] = c1 + bg1 * T;
+    a.raycolor[3 * (size_t)r + 2] = c2 + bg2 * T;
+    a.is_bg[r] = T;
+}
+
+}  // namespace hnr
+
+using namespace hnr;
+
+// ================================================================================== C ABI
+extern "C" int hnr_sample_plan(const int32_t *d_work, const int32_t *d_sample_pidx, const int64_t *d_counts, int K,
+                               int max_items, int32_t *d_vs_item, int32_t *d_vs_off, int32_t *d_vs_cnt,
+                               int cap_samples, int cap_rows, int32_t *d_scratch, int32_t *d_overflow, void *stream)
+{
+    if (!d_work || !d_sample_pidx || !d_counts || !d_vs_item || !d_vs_off || !d_vs_cnt || !d_scratch || !d_overflow ||
+        K <= 0 || max_items < 0) {
+        set_error("hnr_sample_plan: bad argument"); return HNR_ERR_BADARG;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    HNR_HIP_CHECK(hipMemsetAsync(d_overflow, 0, 4, st));
+    if (max_items == 0) return HNR_OK;
+    const int nb = cdiv(max_items, 1024);
+    const unsigned long long *cnt = reinterpret_cast<const unsigned long long *>(d_counts);
+    plan_block_sum_kernel<<<nb, 1024, 0, st>>>(d_work, d_sample_pidx, cnt, K, d_scratch);
+    plan_scan_kernel<<<nb, 1024, 0, st>>>(d_work, d_sample_pidx, cnt, K, d_scratch, d_vs_item, d_vs_off, d_vs_cnt,
+                                          cap_samples, cap_rows, d_overflow);
+    HNR_LAUNCH_CHECK();
+    return HNR_OK;
+}
+
+extern "C" int hnr_gather_rows(const float *d_xyz, const float *d_emb, const float *d_conf, const float *d_dir,
+                               const float *d_color, int F, const int32_t *d_sample_pidx, const float *d_sample_loc_w,
+                               const float *d_raydir, const float *d_campos, const float *d_camrot,
+                               const int32_t *d_vs_item, const int32_t *d_vs_off, const int32_t *d_vs_cnt,
+                               const int64_t *d_counts, int SR, int K, int cap_samples,
+                               float *d_X1, int ld1, float *d_X3, int ld3, float *d_wagg,
+                               float *d_weight_out, float *d_conf_out, void *stream)
+{
+    if (!d_xyz || !d_emb || !d_conf || !d_dir || !d_color || !d_sample_pidx || !d_sample_loc_w || !d_raydir || !d_campos ||
+        !d_camrot || !d_vs_item || !d_vs_off || !d_vs_cnt || !d_counts || !d_X1 || !d_X3 || !d_wagg) {
+        set_error("hnr_gather_rows: NULL argument"); return HNR_ERR_BADARG;
+    }
+    if (F != 32) { set_error("hnr_gather_rows: point_features_dim=%d unsupported (32 in every shipped config)", F); return HNR_ERR_BADARG; }
+    if (ld1 < 7 * F + 60 || (ld1 & 3) || ld3 < 263 || (ld3 & 3) || K <= 0 || K > HNR_MAX_K || SR <= 0) {
+        set_error("hnr_gather_rows: bad leading dimensions / sizes"); return HNR_ERR_BADARG;
+    }
+    if (cap_samples <= 0) return HNR_OK;
+    GatherArgs a;
+    a.xyz = d_xyz; a.emb = d_emb; a.conf = d_conf; a.pdir = d_dir; a.color = d_color; a.F = F;
+    a.pidx = d_sample_pidx; a.loc_w = d_sample_loc_w; a.raydir = d_raydir; a.campos = d_campos; a.camrot = d_camrot;
+    a.vs_item = d_vs_item; a.vs_off = d_vs_off; a.vs_cnt = d_vs_cnt;
+    a.counts = reinterpret_cast<const unsigned long long *>(d_counts);
+    a.SR = SR; a.K = K; a.X1 = d_X1; a.ld1 = ld1; a.X3 = d_X3; a.ld3 = ld3; a.wagg = d_wagg;
+    a.weight_out = d_weight_out; a.conf_out = d_weight_out ? d_conf_out : nullptr;
+    if (d_weight_out && !d_conf_out) { set_error("hnr_gather_rows: weight_out needs conf_out"); return HNR_ERR_BADARG; }
+    gather_rows_kernel<32><<<cdiv(cap_samples, G_SAMPLES), 256, 0, (hipStream_t)stream>>>(a);
+    HNR_LAUNCH_CHECK();
+    return HNR_OK;
+}
+
+extern "C" int hnr_ksum(const float *d_H4, int ldh, const float *d_wagg, const float *d_alpha_w, const float *d_alpha_b,
+                        const int32_t *d_vs_item, const int32_t *d_vs_off, const int32_t *d_vs_cnt, const float *d_raydir,
+                        const int64_t *d_counts, int SR, int cap_samples, float *d_X5, int ld5, float *d_sigma, void *stream)
+{
+    if (!d_H4 || !d_wagg || !d_alpha_w || !d_alpha_b || !d_vs_item || !d_vs_off || !d_vs_cnt || !d_raydir || !d_counts ||
+        !d_X5 || !d_sigma || ldh < 256 || (ldh & 3) || ld5 < 280 || (ld5 & 3)) {
+        set_error("hnr_ksum: bad argument"); return HNR_ERR_BADARG;
+    }
+    if (cap_samples <= 0) return HNR_OK;
+    KsumArgs a;
+    a.H4 = d_H4; a.ldh = ldh; a.wagg = d_wagg; a.alpha_w = d_alpha_w; a.alpha_b = d_alpha_b;
+    a.vs_item = d_vs_item; a.vs_off = d_vs_off; a.vs_cnt = d_vs_cnt; a.raydir = d_raydir;
+    a.counts = reinterpret_cast<const unsigned long long *>(d_counts); a.SR = SR; a.X5 = d_X5; a.ld5 = ld5; a.sigma = d_sigma;
+    ksum_kernel<<<cdiv((int64_t)cap_samples * 64, 256), 256, 0, (hipStream_t)stream>>>(a);
+    HNR_LAUNCH_CHECK();
+    return HNR_OK;
+}
+
+extern "C" int hnr_image_features(const float *d_img, int V, int H, int W, const float *const *d_conv_w,
+                                  const float *const *d_conv_b, float slope, float *d_scratch, float *d_featmap, void *stream)
+{
+    if (!d_img || !d_conv_w || !d_conv_b || !d_scratch || !d_featmap || V <= 0 || H <= 1 || W <= 1) {
+        set_error("hnr_image_features: bad argument"); return HNR_ERR_BADARG;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    auto o = [](int n) { return (n + 2 - 3) / 2 + 1; };      // conv 3x3, stride 2, padding 1
+    const int H1 = o(H), W1 = o(W), H2 = o(H1), W2 = o(W1), H3 = o(H2), W3 = o(W2);
+    // scratch layout: s1a s1 s2a s2 s3a s3 (planar NCHW)
+    float *s1a = d_scratch, *s1 = s1a + (size_t)V * 6 * H1 * W1;
+    float *s2a = s1 + (size_t)V * 6 * H1 * W1, *s2 = s2a + (size_t)V * 12 * H2 * W2;
+    float *s3a = s2 + (size_t)V * 12 * H2 * W2, *s3 = s3a + (size_t)V * 24 * H3 * W3;
+    auto conv = [&](const float *in, int Cin, int Hin, int Win, int cl, int cstride, int li, int Cout, int stride, int Hout, int Wout, float *out) {
+        const int64_t total = (int64_t)V * Cout * Hout * Wout;
+        conv3x3_lrelu_kernel<<<cdiv(total, 256), 256, 0, st>>>(in, Cin, Hin, Win, cl, cstride, d_conv_w[li], d_conv_b[li], Cout, stride,
+                                                                Hout, Wout, slope, out, V);
+    };
+    conv(d_img, 3, H, W, 1, 3, 0, 6, 2, H1, W1, s1a);
+    conv(s1a, 6, H1, W1, 0, 0, 1, 6, 1, H1, W1, s1);
+    conv(s1, 6, H1, W1, 0, 0, 2, 12, 2, H2, W2, s2a);
+    conv(s2a, 12, H2, W2, 0, 0, 3, 12, 1, H2, W2, s2);
+    conv(s2, 12, H2, W2, 0, 0, 4, 24, 2, H3, W3, s3a);
+    conv(s3a, 24, H3, W3, 0, 0, 5, 24, 1, H3, W3, s3);
+    const int64_t total = (int64_t)V * H * W * 48;
+    featmap_kernel<<<cdiv(total, 256), 256, 0, st>>>(d_img, s1, s2, s3, V, H, W, H1, W1, H2, W2, H3, W3, d_featmap);
+    HNR_LAUNCH_CHECK();
+    return HNR_OK;
+}
+
+extern "C" int64_t hnr_image_features_scratch_elems(int V, int H, int W)
+{
+    auto o = [](int n) { return (n + 2 - 3) / 2 + 1; };
+    const int64_t H1 = o(H), W1 = o(W), H2 = o((int)H1), W2 = o((int)W1), H3 = o((int)H2), W3 = o((int)W2);
+    return 2 * (int64_t)V * (6 * H1 * W1 + 12 * H2 * W2 + 24 * H3 * W3);
+}
+
+extern "C" int hnr_proj_rows(const float *d_sample_loc_w, const int32_t *d_vs_item, const int64_t *d_counts, const float *d_w2c,
+                             const float *d_intrinsic, const float *d_campos, const float *d_campos_nearest, const float *d_featmap,
+                             int V, int H, int W, const float *d_CF, int ldcf, int cap_samples, float *d_X6, int ld6,
+                             float *d_vmask, void *stream)
+{
+    if (!d_sample_loc_w || !d_vs_item || !d_counts || !d_w2c || !d_intrinsic || !d_campos || !d_campos_nearest || !d_featmap ||
+        !d_CF || !d_X6 || !d_vmask || V <= 0 || ld6 < 176 || (ld6 & 3) || ldcf < 128 || (ldcf & 1)) {
+        set_error("hnr_proj_rows: bad argument"); return HNR_ERR_BADARG;
+    }
+    if (cap_samples <= 0) return HNR_OK;
+    ProjArgs a;
+    a.loc_w = d_sample_loc_w; a.vs_item = d_vs_item; a.counts = reinterpret_cast<const unsigned long long *>(d_counts);
+    a.w2c = d_w2c; a.Kmat = d_intrinsic; a.campos = d_campos; a.campos_n = d_campos_nearest; a.fm = d_featmap; a.H = H; a.W = W;
+    a.CF = d_CF; a.ldcf = ldcf; a.V = V; a.cap = cap_samples; a.X6 = d_X6; a.ld6 = ld6; a.vmask = d_vmask;
+    proj_rows_kernel<<<cdiv((int64_t)V * cap_samples * 64, 256), 256, 0, (hipStream_t)stream>>>(a);
+    HNR_LAUNCH_CHECK();
+    return HNR_OK;
+}
+
+extern "C" int hnr_merge(const float *d_X6, int ld6, const float *d_Hm, int ldh, const float *d_w_last, const float *d_b_last,
+                         const float *d_vmask, const float *d_frame_w, const float *d_CF, int ldcf, const int64_t *d_counts,
+                         int V, int cap_samples, float *d_X7, int ld7, void *stream)
+{
+    if (!d_X6 || !d_Hm || !d_w_last || !d_b_last || !d_vmask || !d_CF || !d_counts || !d_X7 || ldh < 64 || ld7 < 90) {
+        set_error("hnr_merge: bad argument"); return HNR_ERR_BADARG;
+    }
+    if (cap_samples <= 0) return HNR_OK;
+    MergeArgs a;
+    a.X6 = d_X6; a.ld6 = ld6; a.Hm = d_Hm; a.ldh = ldh; a.w_last = d_w_last; a.b_last = d_b_last; a.vmask = d_vmask;
+    a.frame_w = d_frame_w; a.CF = d_CF; a.ldcf = ldcf; a.counts = reinterpret_cast<const unsigned long long *>(d_counts);
+    a.V = V; a.cap = cap_samples; a.X7 = d_X7; a.ld7 = ld7;
+    merge_kernel<<<cdiv((int64_t)cap_samples * 64, 256), 256, 0, (hipStream_t)stream>>>(a);
+    HNR_LAUNCH_CHECK();
+    return HNR_OK;
+}
+
+extern "C" int hnr_final_color(const float *d_Y, int ldy, const float *d_CF, int ldcf, const float *d_w_fin, const float *d_b_fin,
+                               const float *d_sigma, const int32_t *d_vs_item, const int64_t *d_counts, int cap_samples,
+                               float *d_decoded, void *stream)
+{
+    if (!d_Y || !d_CF || !d_w_fin || !d_b_fin || !d_sigma || !d_vs_item || !d_counts || !d_decoded || ldy < 45 || ldcf < 128) {
+        set_error("hnr_final_color: bad argument"); return HNR_ERR_BADARG;
+    }
+    if (cap_samples <= 0) return HNR_OK;
+    FinalArgs a;
+    a.Y = d_Y; a.ldy = ldy; a.CF = d_CF; a.ldcf = ldcf; a.w_fin = d_w_fin; a.b_fin = d_b_fin; a.sigma = d_sigma;
+    a.vs_item = d_vs_item; a.counts = reinterpret_cast<const unsigned long long *>(d_counts); a.decoded = d_decoded;
+    final_color_kernel<<<cdiv((int64_t)cap_samples * 64, 256), 256, 0, (hipStream_t)stream>>>(a);
+    HNR_LAUNCH_CHECK();
+    return HNR_OK;
+}
+
+extern "C" int hnr_composite(const float *d_decoded, const float *d_sample_loc_w, const int32_t *d_sample_pidx,
+                             const int8_t *d_ray_mask, const float *d_campos, const float *d_camrot, const float *d_bg_color,
+                             int R, int SR, int K, float vsize_z, int raydist_mode_unit, float *d_raycolor, float *d_opacity,
+                             float *d_is_background, float *d_blend_weight, void *stream)
+{
+    if (R < 0 || SR <= 0 || K <= 0) { set_error("hnr_composite: bad sizes"); return HNR_ERR_BADARG; }
+    if (R == 0) return HNR_OK;
+    if (!d_decoded || !d_sample_loc_w || !d_sample_pidx || !d_ray_mask || !d_campos || !d_camrot || !d_bg_color || !d_raycolor ||
+        !d_opacity || !d_is_background) {
+        set_error("hnr_composite: NULL argument"); return HNR_ERR_BADARG;
+    }
+    CompositeArgs a;
+    a.decoded = d_decoded; a.loc_w = d_sample_loc_w; a.pidx = d_sample_pidx; a.ray_mask = d_ray_mask; a.campos = d_campos;
+    a.camrot = d_camrot; a.bg = d_bg_color; a.R = R; a.SR = SR; a.K = K; a.vsize_z = vsize_z; a.unit_mode = raydist_mode_unit;
+    a.raycolor = d_raycolor; a.opacity = d_opacity; a.is_bg = d_is_background; a.blend_w = d_blend_weight;
+    composite_kernel<<<cdiv(R, 256), 256, 0, (hipStream_t)stream>>>(a);
+    HNR_LAUNCH_CHECK();
+    return HNR_OK;
+}

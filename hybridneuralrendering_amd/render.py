@@ -1,0 +1,188 @@
+"""The fused forward render path: query -> gather/aggregate -> composite, all in libhnr_hip.so.
+
+`HybridRenderer.render_rays` is the MI355X counterpart of one pass of
+`NeuralPointsRayMarching.forward` + `fill_invalid`
+(/root/reference/models/neural_points_volumetric_model.py:257-391, :87-126) over R rays, without the
+reference's per-chunk grid rebuild, raypos tensor, boolean-mask copies or host syncs (one host read of
+three counters per launch sizes the MLP workspaces).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import HnrError, CNT
+from . import querier as Q
+
+
+def _i32(n, dev):
+    return torch.empty((max(int(n), 1),), dtype=torch.int32, device=dev)
+
+
+def _f32(shape, dev):
+    return torch.empty(shape, dtype=torch.float32, device=dev)
+
+
+class PointCloud:
+    """The neural point buffers in the kernels' layouts (views of the NeuralPoints parameters)."""
+
+    def __init__(self, xyz, emb, conf, pdir, color):
+        g = _lib.require_gpu
+        self.xyz = g(xyz.detach(), "xyz", torch.float32).reshape(-1, 3)
+        n = self.xyz.shape[0]
+        self.emb = g(emb.detach(), "points_embeding", torch.float32).reshape(n, -1)
+        self.conf = g(conf.detach(), "points_conf", torch.float32).reshape(n)
+        self.dir = g(pdir.detach(), "points_dir", torch.float32).reshape(n, 3)
+        self.color = g(color.detach(), "points_color", torch.float32).reshape(n, 3)
+        self.F = self.emb.shape[1]
+
+
+class HybridRenderer:
+    def __init__(self, opt, aggregator, device):
+        self.opt = opt
+        self.agg = aggregator
+        self.device = torch.device(device)
+        self.querier = Q.lighting_fast_querier(self.device, opt)
+        self._fm_key, self._fm = None, None
+        self.last_counts = None
+        if getattr(opt, "which_render_func", "radiance") != "radiance" or getattr(opt, "which_blend_func", "alpha") != "alpha" \
+                or getattr(opt, "which_tonemap_func", "off") != "off":
+            raise HnrError("only radiance render / alpha blend / no tone map are implemented (all shipped configs)")
+
+    # -- per-frame reference-view features, cached -------------------------------------------------
+    def feature_map(self, images_nearest):
+        key = (images_nearest.data_ptr(), tuple(images_nearest.shape), images_nearest._version,
+               tuple((p.data_ptr(), p._version) for p in self.agg.parameters()))
+        if key != self._fm_key:
+            self._fm = self.agg.image_features(images_nearest)
+            self._fm_key = key
+        return self._fm
+
+    # -- stage 3: gather + aggregate ----------------------------------------------------------------
+    def aggregate(self, cloud, qres, raydir, campos, camrot, w2c_nearest, intrinsic_nearest, campos_nearest, featmap,
+                  frame_weight=None, want_weights=False):
+        """Returns decoded [R,SR,4] (sigma, r, g, b; zeros where the sample has no neighbour)."""
+        L = _lib.lib()
+        pk = self.agg.packed()
+        dev = raydir.device
+        pidx, loc_w, counts, work = qres["sample_pidx"], qres["sample_loc_w"], qres["counts"], qres["work"]
+        R, SR, K = pidx.shape
+        decoded = torch.zeros((R, SR, 4), dtype=torch.float32, device=dev)
+        out = dict(decoded=decoded)
+        if R == 0:
+            return out
+        st = _lib.stream
+        # the one host read: sizes of the packed row buffers
+        c = counts.cpu()
+        self.last_counts = c
+        n_valid, n_rows = int(c[CNT["SAMPLES_VALID"]]), int(c[CNT["NEIGHBOURS"]])
+        if n_valid == 0:
+            return out
+        vs_item, vs_off, vs_cnt = _i32(n_valid, dev), _i32(n_valid, dev), _i32(n_valid, dev)
+        scratch = _i32(2 * ((R * SR + 1023) // 1024) + 2, dev)
+        overflow = torch.zeros(1, dtype=torch.int32, device=dev)
+        p = _lib.ptr
+        with torch.cuda.device(dev):
+            _lib.check(L.hnr_sample_plan(p(work), p(pidx), p(counts), K, R * SR, p(vs_item), p(vs_off), p(vs_cnt), n_valid, n_rows,
+                                         p(scratch), p(overflow), st()), "hnr_sample_plan")
+            A = _f32((n_rows, 284), dev)       # X1, later H3
+            B = _f32((n_rows, 256), dev)       # H1, later H4
+            C = _f32((n_rows, 264), dev)       # X3 = [H2 | extras]
+            wagg = _f32((n_rows,), dev)
+            w_out = c_out = None
+            if want_weights:
+                w_out = torch.zeros((R, SR, K), dtype=torch.float32, device=dev)
+                # empty slots read point 0 in the reference (index clamp, neural_points.py:711): same value here
+                c_out = cloud.conf[0].clamp(0.0001, 1.0).expand(R, SR, K).contiguous()
+            _lib.check(L.hnr_gather_rows(p(cloud.xyz), p(cloud.emb), p(cloud.conf), p(cloud.dir), p(cloud.color), cloud.F,
+                                         p(pidx), p(loc_w), p(raydir), p(campos), p(camrot), p(vs_item), p(vs_off), p(vs_cnt),
+                                         p(counts), SR, K, n_valid, p(A), 284, p(C), 264, p(wagg),
+                                         p(w_out) if want_weights else None, p(c_out) if want_weights else None, st()),
+                       "hnr_gather_rows")
+            sl = pk["slope"]
+            pk["b1"][0](A, out=B, act=True, slope=sl)                       # 284 -> 256
+            pk["b1"][1](B, out=C, act=True, slope=sl)                       # 256 -> 256 into X3[:, :256]
+            H3 = A[:, :256]
+            pk["b3"][0](C, out=H3, act=True, slope=sl, K=263)               # 263 -> 256
+            pk["b3"][1](H3, out=B, act=True, slope=sl)                      # 256 -> 256  (H4)
+            X5 = _f32((n_valid, 280), dev)
+            sigma = _f32((n_valid,), dev)
+            _lib.check(L.hnr_ksum(p(B), 256, p(wagg), p(pk["alpha_w"]), p(pk["alpha_b"]), p(vs_item), p(vs_off), p(vs_cnt),
+                                  p(raydir), p(counts), SR, n_valid, p(X5), 280, p(sigma), st()), "hnr_ksum")
+            del A, B, C
+            T1, T2 = _f32((n_valid, 128), dev), _f32((n_valid, 128), dev)
+            pk["cf"][0](X5, out=T1, act=True, slope=sl)
+            pk["cf"][1](T1, out=T2, act=True, slope=sl)
+            CF = pk["cf"][2](T2, out=T1, act=True, slope=sl)
+            V, H, W = featmap.shape[0], featmap.shape[1], featmap.shape[2]
+            X6 = _f32((V * n_valid, 176), dev)
+            vmask = _f32((V * n_valid,), dev)
+            _lib.check(L.hnr_proj_rows(p(loc_w), p(vs_item), p(counts), p(w2c_nearest), p(intrinsic_nearest), p(campos),
+                                       p(campos_nearest), p(featmap), V, H, W, p(CF), 128, n_valid, p(X6), 176, p(vmask), st()),
+                       "hnr_proj_rows")
+            M1, M2 = _f32((V * n_valid, 64), dev), _f32((V * n_valid, 64), dev)
+            pk["mw"][0](X6, out=M1, act=True, slope=sl)
+            pk["mw"][1](M1, out=M2, act=True, slope=sl)
+            pk["mw"][2](M2, out=M1, act=True, slope=sl)
+            X7 = _f32((n_valid, 92), dev)
+            fw = None if frame_weight is None else _lib.require_gpu(frame_weight, "frame_weight", torch.float32).reshape(-1)
+            _lib.check(L.hnr_merge(p(X6), 176, p(M1), 64, p(pk["mw_last_w"]), p(pk["mw_last_b"]), p(vmask),
+                                   p(fw) if fw is not None else None, p(CF), 128, p(counts), V, n_valid, p(X7), 92, st()), "hnr_merge")
+            Y1, Y2 = _f32((n_valid, 48), dev), _f32((n_valid, 48), dev)
+            pk["mx"][0](X7, out=Y1, act=True, slope=sl, K=90)
+            pk["mx"][1](Y1, out=Y2, act=True, slope=sl, K=45)
+            pk["mx"][2](Y2, out=Y1, act=False, K=45)
+            _lib.check(L.hnr_final_color(p(Y1), 48, p(CF), 128, p(pk["fin_w"]), p(pk["fin_b"]), p(sigma), p(vs_item), p(counts),
+                                         n_valid, p(decoded), st()), "hnr_final_color")
+        if int(overflow.item()) != 0:
+            raise HnrError("hnr_sample_plan: row buffers too small (internal sizing error)")
+        if want_weights:
+            out.update(weight=w_out, conf_coefficient=c_out)
+        return out
+
+    # -- stage 4 ------------------------------------------------------------------------------------
+    def composite(self, decoded, qres, campos, camrot, bg_color, want_blend=False):
+        L = _lib.lib()
+        pidx, loc_w, mask = qres["sample_pidx"], qres["sample_loc_w"], qres["ray_mask"]
+        R, SR, K = pidx.shape
+        dev = pidx.device
+        col, opa, isbg = _f32((R, 3), dev), _f32((R, SR), dev), _f32((R,), dev)
+        bw = _f32((R, SR), dev) if want_blend else None
+        p = _lib.ptr
+        with torch.cuda.device(dev):
+            _lib.check(L.hnr_composite(p(decoded), p(loc_w), p(pidx), p(mask), p(campos), p(camrot), p(bg_color), R, SR, K,
+                                       float(np.float32(self.opt.vsize[2])), int(getattr(self.opt, "raydist_mode_unit", 0) > 0),
+                                       p(col), p(opa), p(isbg), p(bw) if want_blend else None, _lib.stream()), "hnr_composite")
+        return dict(coarse_raycolor=col, coarse_point_opacity=opa, coarse_is_background=isbg, blend_weight=bw)
+
+    # -- the whole path -------------------------------------------------------------------------------
+    def render_rays(self, cloud, raydir, campos, camrot, bg_color, near, far, c2w_nearest, campos_nearest, intrinsic_nearest,
+                    images_nearest, frame_weight=None, want_weights=False, w2c_nearest=None):
+        """raydir [R,3]; campos [3]; camrot [3,3]; c2w_nearest [V,4,4]; images_nearest [V,H,W,3] (or with a leading 1).
+        Returns full-R outputs (fill_invalid applied): coarse_raycolor [R,3], coarse_point_opacity [R,SR],
+        coarse_is_background [R], ray_mask [R] i8, decoded [R,SR,4] + the query tensors."""
+        g = _lib.require_gpu
+        raydir = g(raydir, "raydir", torch.float32).reshape(-1, 3)
+        campos = g(campos, "campos", torch.float32).reshape(3)
+        camrot = g(camrot, "camrotc2w", torch.float32).reshape(3, 3)
+        bg_color = g(bg_color, "bg_color", torch.float32).reshape(3)
+        c2w_nearest = g(c2w_nearest, "c2w_nearest", torch.float32).reshape(-1, 4, 4)
+        campos_nearest = g(campos_nearest, "campos_nearest", torch.float32).reshape(-1, 3)
+        intrinsic_nearest = g(intrinsic_nearest, "intrinsic_nearest", torch.float32).reshape(3, 3)
+        if w2c_nearest is None:
+            w2c_nearest = torch.inverse(c2w_nearest)          # 4x4 plumbing op (:250); V matrices per frame
+        w2c_nearest = w2c_nearest.contiguous()
+        q = self.querier
+        grid, hp = q._grid_for(cloud.xyz[None])
+        tmid = q._tmid_for(float(near), float(far), self.opt.z_depth_dim, raydir.shape[0], raydir.device)
+        qres = Q.march_query(grid, campos, raydir, tmid, self.opt.SR, self.opt.K, np.float32(hp[0] ** 2), self.opt.kernel_size)
+        fm = self.feature_map(images_nearest)
+        a = self.aggregate(cloud, qres, raydir, campos, camrot, w2c_nearest, intrinsic_nearest, campos_nearest, fm,
+                           frame_weight=frame_weight, want_weights=want_weights)
+        out = self.composite(a["decoded"], qres, campos, camrot, bg_color, want_blend=want_weights)
+        out.update(ray_mask=qres["ray_mask"], decoded=a["decoded"], sample_pidx=qres["sample_pidx"],
+                   sample_loc_w=qres["sample_loc_w"], ray_nsamp=qres["ray_nsamp"], counts=qres["counts"])
+        if want_weights:
+            out.update(weight=a.get("weight"), conf_coefficient=a.get("conf_coefficient"))
+        return out

@@ -148,6 +148,99 @@ int hnr_ray_compact(const int32_t *d_ray_row, int R, int SR, int K,
                     float *d_out_loc_pers /*[R',SR,3] = w2pers(loc_w), :96-103*/,
                     float *d_out_raydir /*[R',SR,3]*/, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Stage 3a: dense layers of the aggregation MLP on the matrix cores (fp32 in, fp32 accumulate).
+ * Replaces the nn.Linear(+LeakyReLU) layers of PointAggregator.viewmlp
+ * (models/aggregators/point_aggregators.py:948 block1, :972 block3, :1037 color_feature_branch,
+ *  :1199 aux_merge_weight_block, :1292 color_mixup_block).
+ *   C[M,N] = act(A[M,K] * W[N,K]^T + bias[N]),  act: 0 = none, 1 = LeakyReLU(slope)
+ * W is the torch nn.Linear weight ([out,in], row-major).  It is packed ONCE per checkpoint into a
+ * zero-padded [N_pad,K_pad] image (+ bias[N_pad]) by hnr_linear_pack; sizes from hnr_linear_packed_dims.
+ * lda must be a multiple of 4 floats and A 16-byte aligned; ldc >= N.
+ */
+int hnr_linear_packed_dims(int N, int K, int *N_pad, int *K_pad);
+int hnr_linear_pack(const float *d_W, const float *d_bias /*may be NULL*/, int N, int K,
+                    float *d_Wp /*[N_pad*K_pad]*/, float *d_bias_p /*[N_pad]*/, void *stream);
+int hnr_linear_f32(const float *d_A, int lda, const float *d_Wp, const float *d_bias_p, float *d_C, int ldc,
+                   int M, int N, int K, int act, float slope, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Stage 3b: everything of the gather / aggregate / composite path that is not a dense layer.
+ * Row order is the reference's boolean-mask order, (ray, slot, k) ascending, so packed rows line up
+ * with `feat[pnt_mask_flat]` / `[ray_valid]` of point_aggregators.py:924-935, :1014-1026.
+ * Every function reads its work sizes from d_counts on the device (no host sync); `cap_*` arguments
+ * are the capacities of the caller's buffers (grid sizes); hnr_sample_plan raises *d_overflow when a
+ * capacity is too small.
+ */
+
+/* Compact lists over the kept samples of hnr_march_query (d_work, d_counts[HNR_CNT_SAMPLES]):
+ *   d_vs_item[s] = ray*SR+slot of the s-th VALID sample (>= 1 neighbour; `ray_valid`, :1441),
+ *   d_vs_off[s]  = index of its first neighbour row, d_vs_cnt[s] = its neighbour count.
+ * d_scratch: int32[2*ceil(max_items/1024)].  max_items = R*SR. */
+int hnr_sample_plan(const int32_t *d_work, const int32_t *d_sample_pidx, const int64_t *d_counts, int K, int max_items,
+                    int32_t *d_vs_item, int32_t *d_vs_off, int32_t *d_vs_cnt, int cap_samples, int cap_rows,
+                    int32_t *d_scratch, int32_t *d_overflow, void *stream);
+
+/* NeuralPoints gather (neural_points.py:709-720) + w2pers (:607-613) + dists (point_aggregators.py:1472-1480)
+ * + inverse-distance weights (:825-833, :1500-1501, x clamp(conf) :1508-1512) + positional encodings
+ * (:930, :938) written straight into the packed MLP inputs:
+ *   d_X1[row, 0:284]     = [emb32 | PE3(emb) 192 | PE5(dists6) 60]            (block1 input)
+ *   d_X3[row, 256:263]   = [color3 | dir - viewdir | dir . viewdir]            (block3 extras, :957-971)
+ *   d_wagg[row]          = normalised weight * clamp(conf, 1e-4, 1)
+ *   optional d_weight_out / d_conf_out [R,SR,K]: the reference's `weight` and `conf_coefficient` outputs.
+ * Point buffers: xyz [N,3], emb [N,32], conf [N], dir [N,3], color [N,3]. */
+int hnr_gather_rows(const float *d_xyz, const float *d_emb, const float *d_conf, const float *d_dir, const float *d_color,
+                    int F, const int32_t *d_sample_pidx, const float *d_sample_loc_w, const float *d_raydir,
+                    const float *d_campos, const float *d_camrot, const int32_t *d_vs_item, const int32_t *d_vs_off,
+                    const int32_t *d_vs_cnt, const int64_t *d_counts, int SR, int K, int cap_samples,
+                    float *d_X1, int ld1, float *d_X3, int ld3, float *d_wagg, float *d_weight_out, float *d_conf_out,
+                    void *stream);
+
+/* alpha branch + softplus(x-1) (:1005, :471-476) + K-weighted sums (:1008-1026) + view-direction encoding:
+ *   d_X5[s, 0:280] = [sum_k w feat_k (256) | sin(viewdir 2^f) 12 | cos 12]   (color_feature_branch input, :1028-1036)
+ *   d_sigma[s]     = sum_k w softplus(alpha_k - 1) */
+int hnr_ksum(const float *d_H4, int ldh, const float *d_wagg, const float *d_alpha_w, const float *d_alpha_b,
+             const int32_t *d_vs_item, const int32_t *d_vs_off, const int32_t *d_vs_cnt, const float *d_raydir,
+             const int64_t *d_counts, int SR, int cap_samples, float *d_X5, int ld5, float *d_sigma, void *stream);
+
+/* Reference-view feature pyramid, once per frame (:1047-1067, :1089): conv_w/conv_b are HOST arrays of 6 device
+ * pointers (aux_block_s1.{0,2}, s2.{0,2}, s3.{0,2}); d_img [V,H,W,3]; d_featmap [V,H,W,48] channels-last
+ * (45 used: RGB | up(s1) 6 | up(s2) 12 | up(s3) 24), pixel (0,0) zeroed.
+ * d_scratch: float[hnr_image_features_scratch_elems(V,H,W)]. */
+int64_t hnr_image_features_scratch_elems(int V, int H, int W);
+int hnr_image_features(const float *d_img, int V, int H, int W, const float *const *conv_w, const float *const *conv_b,
+                       float slope, float *d_scratch, float *d_featmap, void *stream);
+
+/* Merge-weight rows: reprojection into the V reference views (neural_points_volumetric_model.py:248-255,
+ * d_w2c[v] = inverse(c2w_nearest[v]) row-major), truncation to a pixel + bounds rule (:1077-1088), feature
+ * gather, delta view directions (:296-310):  d_X6[v*cap+s, 0:176] = [imgfeat45 | colfeat128 | ddir3], d_vmask. */
+int hnr_proj_rows(const float *d_sample_loc_w, const int32_t *d_vs_item, const int64_t *d_counts, const float *d_w2c,
+                  const float *d_intrinsic, const float *d_campos, const float *d_campos_nearest, const float *d_featmap,
+                  int V, int H, int W, const float *d_CF, int ldcf, int cap_samples, float *d_X6, int ld6, float *d_vmask,
+                  void *stream);
+
+/* Last layer + sigmoid of aux_merge_weight_block, weighted merge (:1199-1217) and the mix-up input (:1286-1292):
+ *   d_X7[s, 0:90] = [colfeat[:45] | sum_v w_v f_v / (sum_v w_v + 1e-6)].  d_frame_w: optional [V]. */
+int hnr_merge(const float *d_X6, int ld6, const float *d_Hm, int ldh, const float *d_w_last, const float *d_b_last,
+              const float *d_vmask, const float *d_frame_w, const float *d_CF, int ldcf, const int64_t *d_counts, int V,
+              int cap_samples, float *d_X7, int ld7, void *stream);
+
+/* Residual + color_final_block + sigmoid*1.002-0.001 (:1294-1295, :1334, :478-482), scattered with sigma into
+ * d_decoded [R*SR,4] (pre-zeroed by the caller; :1337-1338). */
+int hnr_final_color(const float *d_Y, int ldy, const float *d_CF, int ldcf, const float *d_w_fin, const float *d_b_fin,
+                    const float *d_sigma, const int32_t *d_vs_item, const int64_t *d_counts, int cap_samples,
+                    float *d_decoded, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Stage 4: ray_dist (neural_points_volumetric_model.py:331-339) + ray_march with radiance render / alpha
+ * blend (models/rendering/diff_ray_marching.py:508-557) + fill_invalid (:87-126), in input-ray order:
+ *   d_raycolor [R,3] (bg colour where ray_mask = 0), d_opacity [R,SR], d_is_background [R] (T_end; 1 where
+ *   ray_mask = 0), optional d_blend_weight [R,SR]. */
+int hnr_composite(const float *d_decoded, const float *d_sample_loc_w, const int32_t *d_sample_pidx, const int8_t *d_ray_mask,
+                  const float *d_campos, const float *d_camrot, const float *d_bg_color, int R, int SR, int K, float vsize_z,
+                  int raydist_mode_unit, float *d_raycolor, float *d_opacity, float *d_is_background, float *d_blend_weight,
+                  void *stream);
+
 #ifdef __cplusplus
 }
 #endif
