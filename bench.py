@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""Headline benchmark: rays/s of the forward hybrid render (query -> gather/aggregate -> composite)
+on the scene0241_01-like synthetic config (BASELINE.json configs[2] / SURVEY.md section 8d C3).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = every rank renders one full 620x460 = 285 200-ray frame (its own camera pose; cloud, grid,
+weights and reference-view features replicated and already resident in HBM) and the colours are gathered to
+rank 0 with ONE RCCL gather.  Rank 0 prints ONE JSON line.  value = rays of all ranks / max-over-ranks time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+F32_MFMA_PEAK_TF = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--points", type=float, default=2.0e6)
+    ap.add_argument("--chunk", type=int, default=0, help="rays per launch (0 = the whole frame in one launch)")
+    ap.add_argument("--scene", default="scene0241")
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--margin", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-rays", type=int, default=2304)
+    return ap.parse_args()
+
+
+def build_world(args, dev, rank):
+    from hybridneuralrendering_amd import scenes
+    from hybridneuralrendering_amd.aggregator import PointAggregator
+    from hybridneuralrendering_amd.render import HybridRenderer, PointCloud
+    sc = scenes.make_scene(args.scene, int(args.points), 2, w=args.width, h=args.height)
+    opt = sc.opt
+    torch.manual_seed(0)
+    agg = PointAggregator(opt)
+    with torch.no_grad():          # random-init weights; scale the density head so opacities are spread over (0,1)
+        agg.alpha_branch[0].weight.mul_(30.0)
+        agg.alpha_branch[0].bias.fill_(30.0)
+    agg = agg.to(dev)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    cloud = PointCloud(t(sc.xyz), t(sc.emb), t(sc.conf), t(sc.dir), t(sc.color))
+    rnd = HybridRenderer(opt, agg, dev)
+    # rank-specific camera: same scene, slightly different pose (weak scaling: every GPU renders a whole frame)
+    eye = sc.c2w[:3, 3] + np.array([0.05, -0.04, 0.01], np.float32) * rank
+    tgt = sc.c2w[:3, 3] + sc.c2w[:3, 2] * 3.0
+    c2w = scenes.look_at(eye, tgt)
+    pix = scenes.pixel_grid(sc.w, sc.h, args.margin)
+    rays = scenes.camera_rays(pix, sc.intrinsic, c2w)
+    cam = dict(raydir=t(rays), campos=t(c2w[:3, 3]), camrot=t(c2w[:3, :3]), bg=t(sc.bg_color),
+               c2w_nearest=t(sc.c2w_nearest), campos_nearest=t(sc.c2w_nearest[:, :3, 3]), intrinsic=t(sc.intrinsic),
+               images=t(sc.images_nearest), w2c_nearest=torch.inverse(t(sc.c2w_nearest)), c2w=c2w, pix=pix, rays_np=rays)
+    return sc, opt, agg, cloud, rnd, cam
+
+
+def render_frame(rnd, cloud, cam, sc, chunk, timers=None):
+    R = cam["raydir"].shape[0]
+    chunk = R if chunk <= 0 else chunk
+    cols = []
+    for lo in range(0, R, chunk):
+        out = rnd.render_rays(cloud, cam["raydir"][lo:lo + chunk], cam["campos"], cam["camrot"], cam["bg"], sc.near, sc.far,
+                              cam["c2w_nearest"], cam["campos_nearest"], cam["intrinsic"], cam["images"],
+                              w2c_nearest=cam["w2c_nearest"], timers=timers)
+        cols.append(out["coarse_raycolor"])
+    return cols[0] if len(cols) == 1 else torch.cat(cols, dim=0), out
+
+
+def cpu_baseline(args, sc, opt, agg, cam, gpu_colors):
+    """The CPU oracle (C query restatement + torch-CPU aggregate/composite) on one 48x48-ray chunk of the same
+    frame, grid build included (the reference rebuilds its grid for every chunk)."""
+    from oracle import query_oracle as qo, render_oracle as ro
+    n = args.cpu_sample_rays
+    side = int(np.sqrt(n))
+    W = sc.w - 2 * args.margin
+    H = sc.h - 2 * args.margin
+    x0, y0 = (W - side) // 2, (H - side) // 2
+    idx = ((y0 + np.arange(side))[:, None] * W + (x0 + np.arange(side))[None, :]).reshape(-1)
+    rays = cam["rays_np"][idx]
+    c2w = cam["c2w"]
+    sd = {k: v.detach().cpu() for k, v in agg.state_dict().items()}
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    cores = torch.get_num_threads()
+    t0 = time.time()
+    hp = qo.hyperparameters(sc.xyz, opt.vsize, opt.vscale, opt.kernel_size, opt.ranges, opt.radius_limit_scale)
+    g = qo.OracleGrid(sc.xyz, hp["origin"], hp["cell"], hp["dims"], opt.query_size, opt.P, opt.max_o)
+    q = g.query(c2w[:3, 3], rays, qo.tmid_table(sc.near, sc.far, opt.z_depth_dim), opt.SR, opt.K, hp["radius2"], opt.kernel_size)
+    t_query = time.time() - t0
+    with torch.no_grad():
+        ref = ro.render(t(sc.xyz), t(sc.emb), t(sc.conf), t(sc.dir), t(sc.color), sd, q, t(c2w[:3, 3])[None], t(c2w[:3, :3])[None],
+                        t(rays)[None], t(sc.bg_color)[None], t(sc.c2w_nearest)[None], t(sc.c2w_nearest[:, :3, 3])[None],
+                        t(sc.intrinsic)[None], t(sc.images_nearest)[None], opt.vsize)
+    dt = time.time() - t0
+    refc = ref["full_coarse_raycolor"][0].numpy()
+    got = gpu_colors[idx]
+    mse = float(np.mean((refc.astype(np.float64) - got.astype(np.float64)) ** 2))
+    psnr = 99.0 if mse == 0 else -10.0 * np.log10(mse)
+    return dict(value=len(idx) / dt, unit="rays/s", cores=cores, kind="port",
+                sample="one %dx%d-ray chunk of the same frame: C oracle grid build over %d points + query (%.2f s, 1 thread) + torch-CPU "
+                       "aggregate/composite with 4 reference views (%d threads); %.2f s total" % (side, side, sc.xyz.shape[0], t_query, cores, dt),
+                psnr_gpu_vs_oracle_db=round(psnr, 2), max_abs_gpu_vs_oracle=float(np.abs(refc - got).max()))
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    from hybridneuralrendering_amd import parallel
+    from hybridneuralrendering_amd._lib import CNT
+
+    sc, opt, agg, cloud, rnd, cam = build_world(args, dev, rank)
+    R = cam["raydir"].shape[0]
+
+    def step(timers=None):
+        col, out = render_frame(rnd, cloud, cam, sc, args.chunk, timers)
+        if world > 1:
+            # reassemble the N frames on rank 0: ONE gather over xGMI (every rank sends R x 3 floats)
+            outs = [torch.empty_like(col) for _ in range(world)] if rank == 0 else None
+            dist.gather(col, outs, dst=0)
+        return col, out
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    timers = {}
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        col, out = step(timers)
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    if rank == 0:
+        counts = out["counts"].cpu().numpy() if args.chunk <= 0 or args.chunk >= R else None
+        stage_ms = {k: sum(e0.elapsed_time(e1) for e0, e1 in v) / args.steps for k, v in timers.items()}
+        # --- roofline of the dominant kernel (fp32 MFMA dense layer) and of the query stage, from HIP events
+        # recorded on the launch stream inside the timed region
+        roof, roof_q = None, None
+        if counts is not None:
+            n_rows, n_valid = int(counts[CNT["NEIGHBOURS"]]), int(counts[CNT["SAMPLES_VALID"]])
+            s_all, cells, cand = int(counts[CNT["SAMPLES"]]), int(counts[CNT["CELLS_VISITED"]]), int(counts[CNT["CANDIDATES"]])
+            # per-neighbour MLP: block1 (284->256->256) + block3 (263->256->256): 4 launches of linear_f32_kernel<2,2,1>
+            flops_nb = 2.0 * n_rows * 256 * (284 + 256 + 263 + 256)
+            ms_nb = stage_ms.get("mlp_neighbour", 0.0)
+            if ms_nb > 0:
+                ach = flops_nb / (ms_nb * 1e-3) / 1e12
+                roof = dict(kernel="linear_f32_kernel<2,2,1> (block1+block3, 4 launches, M=%d rows)" % n_rows, bound="mfma",
+                            achieved=round(ach, 2), peak=F32_MFMA_PEAK_TF, unit="TFLOP/s", frac=round(ach / F32_MFMA_PEAK_TF, 4),
+                            traffic=None, flops_per_launch=flops_nb / 4, avg_launch_ms=round(ms_nb / 4, 4))
+            D, K = opt.z_depth_dim, opt.K
+            alg = R * (12 + (D + 7) // 8 + 1) + s_all * (12 + 27 * 4 + 4 * K) + 4 * cells + 16 * cand
+            ms_q = stage_ms.get("query", 0.0)
+            if ms_q > 0:
+                ach = alg / (ms_q * 1e-3) / 1e9
+                roof_q = dict(kernel="hnr_march_query: march_kernel + worklist scans + knn_kernel<8>", bound="hbm", achieved=round(ach, 1),
+                              peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), traffic=None,
+                              algorithmic_bytes=int(alg), avg_launch_ms=round(ms_q, 4),
+                              per_ray=dict(samples=round(s_all / R, 2), cells_per_sample=round(cells / max(s_all, 1), 2),
+                                           candidates_per_sample=round(cand / max(s_all, 1), 2)))
+        cpu = None
+        if not args.no_cpu_baseline:
+            cpu = cpu_baseline(args, sc, opt, agg, cam, col.cpu().numpy())
+        res = {
+            "metric": "rays/sec (fwd render) scene0241_01 at 1/2/4/8 GPU; PSNR delta vs ref",
+            "value": world * R * args.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "scene0241_01-like synthetic room (SURVEY 8d C3): %d points, %dx%d frame margin %d = %d rays per GPU per step, "
+                                   "SR=%d K=%d P=%d max_o=%d D=%d, 4 reference views %dx%d, hybrid viewmlp forward (query+gather+aggregate+composite)"
+                                   % (sc.xyz.shape[0], sc.w, sc.h, args.margin, R, opt.SR, opt.K, opt.P, opt.max_o, opt.z_depth_dim, sc.h, sc.w),
+                       "rays_per_gpu": R, "points": int(sc.xyz.shape[0]), "chunk_rays": args.chunk if args.chunk > 0 else R,
+                       "parallelism": "ray-sharded x%d, one RCCL gather" % world},
+            "roofline": roof, "roofline_query": roof_q, "cpu_baseline": cpu,
+            "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
+            "grid": rnd.querier.last_grid_stats,
+        }
+        if counts is not None:
+            res["counts"] = {k: int(counts[v]) for k, v in CNT.items()}
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -24,6 +24,26 @@ def _f32(shape, dev):
     return torch.empty(shape, dtype=torch.float32, device=dev)
 
 
+class _Stage:
+    """Optional HIP-event bracket around a stage (events are recorded on the launch stream)."""
+
+    def __init__(self, timers, name):
+        self.timers, self.name = timers, name
+
+    def __enter__(self):
+        if self.timers is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.timers is not None:
+            self.e1.record()
+            self.timers.setdefault(self.name, []).append((self.e0, self.e1))
+        return False
+
+
 class PointCloud:
     """The neural point buffers in the kernels' layouts (views of the NeuralPoints parameters)."""
 
@@ -61,7 +81,7 @@ class HybridRenderer:
 
     # -- stage 3: gather + aggregate ----------------------------------------------------------------
     def aggregate(self, cloud, qres, raydir, campos, camrot, w2c_nearest, intrinsic_nearest, campos_nearest, featmap,
-                  frame_weight=None, want_weights=False):
+                  frame_weight=None, want_weights=False, timers=None):
         """Returns decoded [R,SR,4] (sigma, r, g, b; zeros where the sample has no neighbour)."""
         L = _lib.lib()
         pk = self.agg.packed()
@@ -83,7 +103,9 @@ class HybridRenderer:
         scratch = _i32(2 * ((R * SR + 1023) // 1024) + 2, dev)
         overflow = torch.zeros(1, dtype=torch.int32, device=dev)
         p = _lib.ptr
+        T = lambda name: _Stage(timers, name)
         with torch.cuda.device(dev):
+          with T("plan_gather"):
             _lib.check(L.hnr_sample_plan(p(work), p(pidx), p(counts), K, R * SR, p(vs_item), p(vs_off), p(vs_cnt), n_valid, n_rows,
                                          p(scratch), p(overflow), st()), "hnr_sample_plan")
             A = _f32((n_rows, 284), dev)       # X1, later H3
@@ -100,39 +122,47 @@ class HybridRenderer:
                                          p(counts), SR, K, n_valid, p(A), 284, p(C), 264, p(wagg),
                                          p(w_out) if want_weights else None, p(c_out) if want_weights else None, st()),
                        "hnr_gather_rows")
-            sl = pk["slope"]
+          sl = pk["slope"]
+          with T("mlp_neighbour"):
             pk["b1"][0](A, out=B, act=True, slope=sl)                       # 284 -> 256
             pk["b1"][1](B, out=C, act=True, slope=sl)                       # 256 -> 256 into X3[:, :256]
             H3 = A[:, :256]
             pk["b3"][0](C, out=H3, act=True, slope=sl, K=263)               # 263 -> 256
             pk["b3"][1](H3, out=B, act=True, slope=sl)                      # 256 -> 256  (H4)
+          with T("ksum"):
             X5 = _f32((n_valid, 280), dev)
             sigma = _f32((n_valid,), dev)
             _lib.check(L.hnr_ksum(p(B), 256, p(wagg), p(pk["alpha_w"]), p(pk["alpha_b"]), p(vs_item), p(vs_off), p(vs_cnt),
                                   p(raydir), p(counts), SR, n_valid, p(X5), 280, p(sigma), st()), "hnr_ksum")
-            del A, B, C
+          del A, B, C
+          with T("mlp_colorfeat"):
             T1, T2 = _f32((n_valid, 128), dev), _f32((n_valid, 128), dev)
             pk["cf"][0](X5, out=T1, act=True, slope=sl)
             pk["cf"][1](T1, out=T2, act=True, slope=sl)
             CF = pk["cf"][2](T2, out=T1, act=True, slope=sl)
+          with T("proj_rows"):
             V, H, W = featmap.shape[0], featmap.shape[1], featmap.shape[2]
             X6 = _f32((V * n_valid, 176), dev)
             vmask = _f32((V * n_valid,), dev)
             _lib.check(L.hnr_proj_rows(p(loc_w), p(vs_item), p(counts), p(w2c_nearest), p(intrinsic_nearest), p(campos),
                                        p(campos_nearest), p(featmap), V, H, W, p(CF), 128, n_valid, p(X6), 176, p(vmask), st()),
                        "hnr_proj_rows")
+          with T("mlp_merge"):
             M1, M2 = _f32((V * n_valid, 64), dev), _f32((V * n_valid, 64), dev)
             pk["mw"][0](X6, out=M1, act=True, slope=sl)
             pk["mw"][1](M1, out=M2, act=True, slope=sl)
             pk["mw"][2](M2, out=M1, act=True, slope=sl)
+          with T("merge"):
             X7 = _f32((n_valid, 92), dev)
             fw = None if frame_weight is None else _lib.require_gpu(frame_weight, "frame_weight", torch.float32).reshape(-1)
             _lib.check(L.hnr_merge(p(X6), 176, p(M1), 64, p(pk["mw_last_w"]), p(pk["mw_last_b"]), p(vmask),
                                    p(fw) if fw is not None else None, p(CF), 128, p(counts), V, n_valid, p(X7), 92, st()), "hnr_merge")
+          with T("mlp_mixup"):
             Y1, Y2 = _f32((n_valid, 48), dev), _f32((n_valid, 48), dev)
             pk["mx"][0](X7, out=Y1, act=True, slope=sl, K=90)
             pk["mx"][1](Y1, out=Y2, act=True, slope=sl, K=45)
             pk["mx"][2](Y2, out=Y1, act=False, K=45)
+          with T("final_color"):
             _lib.check(L.hnr_final_color(p(Y1), 48, p(CF), 128, p(pk["fin_w"]), p(pk["fin_b"]), p(sigma), p(vs_item), p(counts),
                                          n_valid, p(decoded), st()), "hnr_final_color")
         if int(overflow.item()) != 0:
@@ -158,7 +188,7 @@ class HybridRenderer:
 
     # -- the whole path -------------------------------------------------------------------------------
     def render_rays(self, cloud, raydir, campos, camrot, bg_color, near, far, c2w_nearest, campos_nearest, intrinsic_nearest,
-                    images_nearest, frame_weight=None, want_weights=False, w2c_nearest=None):
+                    images_nearest, frame_weight=None, want_weights=False, w2c_nearest=None, timers=None):
         """raydir [R,3]; campos [3]; camrot [3,3]; c2w_nearest [V,4,4]; images_nearest [V,H,W,3] (or with a leading 1).
         Returns full-R outputs (fill_invalid applied): coarse_raycolor [R,3], coarse_point_opacity [R,SR],
         coarse_is_background [R], ray_mask [R] i8, decoded [R,SR,4] + the query tensors."""
@@ -176,11 +206,14 @@ class HybridRenderer:
         q = self.querier
         grid, hp = q._grid_for(cloud.xyz[None])
         tmid = q._tmid_for(float(near), float(far), self.opt.z_depth_dim, raydir.shape[0], raydir.device)
-        qres = Q.march_query(grid, campos, raydir, tmid, self.opt.SR, self.opt.K, np.float32(hp[0] ** 2), self.opt.kernel_size)
-        fm = self.feature_map(images_nearest)
+        with _Stage(timers, "query"):
+            qres = Q.march_query(grid, campos, raydir, tmid, self.opt.SR, self.opt.K, np.float32(hp[0] ** 2), self.opt.kernel_size)
+        with _Stage(timers, "featmap"):
+            fm = self.feature_map(images_nearest)
         a = self.aggregate(cloud, qres, raydir, campos, camrot, w2c_nearest, intrinsic_nearest, campos_nearest, fm,
-                           frame_weight=frame_weight, want_weights=want_weights)
-        out = self.composite(a["decoded"], qres, campos, camrot, bg_color, want_blend=want_weights)
+                           frame_weight=frame_weight, want_weights=want_weights, timers=timers)
+        with _Stage(timers, "composite"):
+            out = self.composite(a["decoded"], qres, campos, camrot, bg_color, want_blend=want_weights)
         out.update(ray_mask=qres["ray_mask"], decoded=a["decoded"], sample_pidx=qres["sample_pidx"],
                    sample_loc_w=qres["sample_loc_w"], ray_nsamp=qres["ray_nsamp"], counts=qres["counts"])
         if want_weights:
