@@ -56,6 +56,7 @@ SIGNATURES = {
     "hnr_linear_f32": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "hnr_sample_plan": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _P, _P, _P]),
     "hnr_gather_rows": (_I, [_P] * 5 + [_I] + [_P] * 9 + [_I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P]),
+    "hnr_gather_points": (_I, [_P, ctypes.c_int64] + [_P] * 5 + [_I] + [_P] * 9 + [_P]),
     "hnr_ksum": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P, _P]),
     "hnr_image_features_scratch_elems": (ctypes.c_int64, [_I, _I, _I]),
     "hnr_image_features": (_I, [_P, _I, _I, _I, ctypes.POINTER(_P), ctypes.POINTER(_P), _F, _P, _P, _P]),

@@ -566,11 +566,61 @@ __global__ __launch_bounds__(256) void composite_kernel(CompositeArgs a)
     a.is_bg[r] = T;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The materialised gather of NeuralPoints.forward (neural_points.py:709-720) for the drop-in 14-tuple API
+// only (the fused path never materialises it).  One 8-lane group per (ray, slot, k) entry; empty entries
+// read point 0 like the reference's clamp(min=0).
+__global__ __launch_bounds__(256) void gather_points_kernel(const int32_t *__restrict__ pidx, int64_t n, const float *__restrict__ xyz,
+                                                            const float *__restrict__ emb, const float *__restrict__ conf,
+                                                            const float *__restrict__ pdir, const float *__restrict__ color, int F,
+                                                            const float *__restrict__ campos, const float *__restrict__ camrot,
+                                                            float *__restrict__ o_color, float *__restrict__ o_dir,
+                                                            float *__restrict__ o_conf, float *__restrict__ o_emb,
+                                                            float *__restrict__ o_pers, float *__restrict__ o_xyz, uint8_t *__restrict__ o_mask)
+{
+    const int64_t e = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+    const int sub = threadIdx.x & 7;
+    if (e >= n) return;
+    const int raw = pidx[e];
+    const int pid = raw < 0 ? 0 : raw;
+    for (int c = sub; c < F; c += 8) o_emb[e * F + c] = emb[(size_t)pid * F + c];
+    if (sub < 3) {
+        o_color[e * 3 + sub] = color[3 * (size_t)pid + sub];
+        o_dir[e * 3 + sub] = pdir[3 * (size_t)pid + sub];
+        o_xyz[e * 3 + sub] = xyz[3 * (size_t)pid + sub];
+    }
+    if (sub == 3) {
+        const float p[3] = {xyz[3 * (size_t)pid], xyz[3 * (size_t)pid + 1], xyz[3 * (size_t)pid + 2]};
+        float pp[3];
+        w2pers(p, campos, camrot, pp);
+        o_pers[e * 3] = pp[0]; o_pers[e * 3 + 1] = pp[1]; o_pers[e * 3 + 2] = pp[2];
+    }
+    if (sub == 4) { o_conf[e] = conf[pid]; o_mask[e] = raw >= 0 ? 1 : 0; }
+}
+
 }  // namespace hnr
 
 using namespace hnr;
 
 // ================================================================================== C ABI
+extern "C" int hnr_gather_points(const int32_t *d_sample_pidx, int64_t n_entries, const float *d_xyz, const float *d_emb,
+                                 const float *d_conf, const float *d_dir, const float *d_color, int F, const float *d_campos,
+                                 const float *d_camrot, float *d_o_color, float *d_o_dir, float *d_o_conf, float *d_o_emb,
+                                 float *d_o_xyz_pers, float *d_o_xyz, uint8_t *d_o_mask, void *stream)
+{
+    if (n_entries < 0 || F <= 0) { set_error("hnr_gather_points: bad sizes"); return HNR_ERR_BADARG; }
+    if (n_entries == 0) return HNR_OK;
+    if (!d_sample_pidx || !d_xyz || !d_emb || !d_conf || !d_dir || !d_color || !d_campos || !d_camrot || !d_o_color || !d_o_dir ||
+        !d_o_conf || !d_o_emb || !d_o_xyz_pers || !d_o_xyz || !d_o_mask) {
+        set_error("hnr_gather_points: NULL argument"); return HNR_ERR_BADARG;
+    }
+    gather_points_kernel<<<cdiv(n_entries * 8, 256), 256, 0, (hipStream_t)stream>>>(d_sample_pidx, n_entries, d_xyz, d_emb, d_conf, d_dir,
+                                                                                   d_color, F, d_campos, d_camrot, d_o_color, d_o_dir,
+                                                                                   d_o_conf, d_o_emb, d_o_xyz_pers, d_o_xyz, d_o_mask);
+    HNR_LAUNCH_CHECK();
+    return HNR_OK;
+}
+
 extern "C" int hnr_sample_plan(const int32_t *d_work, const int32_t *d_sample_pidx, const int64_t *d_counts, int K,
                                int max_items, int32_t *d_vs_item, int32_t *d_vs_off, int32_t *d_vs_cnt,
                                int cap_samples, int cap_rows, int32_t *d_scratch, int32_t *d_overflow, void *stream)

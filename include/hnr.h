@@ -196,6 +196,14 @@ int hnr_gather_rows(const float *d_xyz, const float *d_emb, const float *d_conf,
                     float *d_X1, int ld1, float *d_X3, int ld3, float *d_wagg, float *d_weight_out, float *d_conf_out,
                     void *stream);
 
+/* The materialised gather of NeuralPoints.forward (neural_points.py:709-720) for the drop-in 14-tuple only:
+ * n_entries = R'*SR*K entries of d_sample_pidx; empty entries (-1) read point 0 (the reference clamps the index);
+ * outputs [n,3] [n,3] [n] [n,F] [n,3] [n,3] and d_o_mask [n] u8 = (pidx >= 0). */
+int hnr_gather_points(const int32_t *d_sample_pidx, int64_t n_entries, const float *d_xyz, const float *d_emb,
+                      const float *d_conf, const float *d_dir, const float *d_color, int F, const float *d_campos,
+                      const float *d_camrot, float *d_o_color, float *d_o_dir, float *d_o_conf, float *d_o_emb,
+                      float *d_o_xyz_pers, float *d_o_xyz, uint8_t *d_o_mask, void *stream);
+
 /* alpha branch + softplus(x-1) (:1005, :471-476) + K-weighted sums (:1008-1026) + view-direction encoding:
  *   d_X5[s, 0:280] = [sum_k w feat_k (256) | sin(viewdir 2^f) 12 | cos 12]   (color_feature_branch input, :1028-1036)
  *   d_sigma[s]     = sum_k w softplus(alpha_k - 1) */

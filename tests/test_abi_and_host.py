@@ -1,0 +1,136 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/hnr.h declares (no compute
+calls -- there is no GPU here), host logic, and the product never routes through the oracle."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    src = open(os.path.join(ROOT, "include", "hnr.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(hnr_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from hybridneuralrendering_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    syms = _header_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(L, s), "libhnr_hip.so does not export %s" % s
+    # ... and the ctypes table covers the same set, so no declared entry point is unbound in Python
+    assert sorted(_lib.SIGNATURES) == syms
+    assert _lib.lib().hnr_version().startswith(b"hnr-hip")
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from hybridneuralrendering_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libhnr_hip.so")
+    with pytest.raises(_lib.HnrError):
+        _lib.lib()
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "hybridneuralrendering_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
+                assert "liboracle" not in txt and "oracle/_build" not in txt, f       # never loads the oracle library either
+
+
+def test_cpu_tensors_are_rejected_not_silently_computed():
+    from hybridneuralrendering_amd import _lib
+    with pytest.raises(_lib.HnrError):
+        _lib.require_gpu(torch.zeros(3), "x")
+    from hybridneuralrendering_amd.querier import lighting_fast_querier
+    from hybridneuralrendering_amd import scenes
+    with pytest.raises(_lib.HnrError):
+        lighting_fast_querier(torch.device("cpu"), scenes.default_opt())
+
+
+def test_unsupported_options_raise():
+    from hybridneuralrendering_amd import scenes
+    from hybridneuralrendering_amd.aggregator import PointAggregator, check_opt
+    from hybridneuralrendering_amd._lib import HnrError
+    check_opt(scenes.default_opt())
+    for k, v in (("agg_intrp_order", 1), ("agg_distance_kernel", "quadric"), ("which_agg_model", "nsvfmlp"), ("agg_dist_pers", 10),
+                 ("num_feat_freqs", 0), ("mixup_mode", "full"), ("act_type", "ReLU"), ("tradition_attention", 1)):
+        with pytest.raises(HnrError):
+            check_opt(scenes.default_opt(**{k: v}))
+    agg = PointAggregator(scenes.default_opt())
+    names = {k: tuple(v.shape) for k, v in agg.state_dict().items()}
+    # checkpoint compatibility: names and shapes of the reference's aggregator
+    assert names["block1.0.weight"] == (256, 284) and names["block3.0.weight"] == (256, 263)
+    assert names["alpha_branch.0.weight"] == (1, 256) and names["color_branch.6.weight"] == (3, 128)
+    assert names["aux_merge_weight_block.0.weight"] == (64, 176) and names["aux_merge_weight_block.6.weight"] == (1, 64)
+    assert names["aux_block_s3.2.weight"] == (24, 24, 3, 3) and names["color_mixup_block.4.weight"] == (45, 45)
+    assert names["color_final_block.0.weight"] == (3, 128)
+    assert sum(v.numel() for v in agg.state_dict().values()) == 449381
+
+
+def test_aggregator_state_dict_matches_reference_fixture_keys():
+    from tests.golden_io import load_render
+    from hybridneuralrendering_amd import scenes
+    from hybridneuralrendering_amd.aggregator import PointAggregator
+    d = load_render("scannet_small")
+    agg = PointAggregator(scenes.default_opt())
+    assert sorted(agg.state_dict().keys()) == sorted(d["sd"].keys())
+    agg.load_state_dict(d["sd"], strict=True)
+
+
+def test_shard_bounds_cover_all_rays():
+    from hybridneuralrendering_amd.parallel import shard_bounds
+    for n in (0, 1, 7, 285200, 1000003):
+        for w in (1, 2, 3, 8):
+            b = [shard_bounds(n, w, r) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 1
+
+
+_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from hybridneuralrendering_amd import parallel
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+R = 1001
+rays = torch.arange(R * 3, dtype=torch.float32).reshape(R, 3)
+# stand-in render: a per-ray function, so the assembled image is checkable exactly
+img = parallel.render_sharded(lambda r: r * 2.0 + 1.0, rays)
+if rank == 0:
+    assert img.shape == (R, 3) and torch.equal(img, rays * 2.0 + 1.0)
+    print("SHARD_OK")
+else:
+    assert img is None
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_ray_sharding_world_size_2_gloo(tmp_path):
+    script = tmp_path / "w.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29613", WORLD_SIZE="2")
+    procs = []
+    for r in range(2):
+        e = dict(env, RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=180)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "SHARD_OK" in outs[0]
