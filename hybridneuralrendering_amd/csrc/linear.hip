@@ -10,11 +10,13 @@
 //
 // Tiling (wave64): 256-thread workgroup = 2x2 waves; each wave owns TM x TN MFMA tiles of 32x32.
 //   <2,2>: 128x128 block tile (N >= 128)      <2,1>: 128x64 block tile (N <= 64)
-// BK = 32.  A and W tiles are staged through LDS in row-major [row][BK+1] (the +1 pad makes the
-// MFMA fragment reads -- 32 lanes x 32 rows, same k -- conflict-free); the next tile's global loads are
-// issued into registers before the current tile's MFMAs (register double buffering).
+// BK = 32.  A and W tiles are staged through LDS as [row][36] with the k-values of a row de-interleaved (evens, then
+// odds) so every MFMA fragment is read with ds_read_b128; the next tile's global loads are issued into registers
+// before the current tile's MFMAs (register double buffering).
 // Weights are pre-packed once per checkpoint into a zero-padded [N_pad][K_pad] image, so the W loads
 // are unguarded 16-B loads; A rows are guarded (zero-filled) for m >= M and k >= K.
+#include <stdlib.h>
+
 #include "hnr_common.h"
 
 namespace hnr {
@@ -22,10 +24,14 @@ namespace hnr {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BK = 32;
-constexpr int LDS_LD = BK + 1;
+constexpr int LDS_LD = BK + 4;     // 36 floats = 144 B rows: 16-B aligned, and 9*row mod 16 spreads ds_read_b128 over all banks
 
-template <int TM, int TN, int ACT>   // ACT: 0 none, 1 LeakyReLU(slope)
-__global__ __launch_bounds__(256) void linear_f32_kernel(const float *__restrict__ A, int lda,
+// LDS tile layout.  Row r of a tile holds its 32 k-values DE-INTERLEAVED: position p < 16 holds k = 2p, position
+// 16 + p holds k = 2p + 1.  The 32x32x2 MFMA takes k = 0 from lanes 0-31 and k = 1 from lanes 32-63, so lane-half h
+// needs k = 2j + h at step j = position 16h + j: sixteen CONSECUTIVE floats -> four ds_read_b128 per 32-row block per
+// tile (instead of sixteen ds_read_b32), and a partial last tile only costs ceil(k_valid / 2) MFMA steps.
+template <int TM, int TN, int ACT, int DBG = 0>   // ACT: 0 none, 1 LeakyReLU(slope); DBG: ablation switches (probe only)
+__global__ __launch_bounds__(256, 2) void linear_f32_kernel(const float *__restrict__ A, int lda,
                                                          const float *__restrict__ Wp, int K_pad,
                                                          const float *__restrict__ bias_p, float *__restrict__ C, int ldc,
                                                          int M, int N, int K, float slope)
@@ -33,12 +39,14 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(const float *__restrict
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int A_F4 = BM * BK / 4 / 256;     // float4 per thread for the A tile
     constexpr int W_F4 = BN * BK / 4 / 256;
-    __shared__ float As[BM * LDS_LD];
-    __shared__ float Ws[BN * LDS_LD];
+    __shared__ __attribute__((aligned(16))) float As[2 * BM * LDS_LD];     // double-buffered: one barrier per K tile
+    __shared__ __attribute__((aligned(16))) float Ws[2 * BN * LDS_LD];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int n0 = blockIdx.y * BN;
+    const int n_mtiles = (M + BM - 1) / BM;
+    const int nk = (K + BK - 1) / BK;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -48,88 +56,165 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(const float *__restrict
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // Staging registers.  A loads are UNCONDITIONAL (row and column clamped into the buffer) and masked afterwards with
+    // selects, so no branch consumes a loaded value early: the loads stay in flight across the tile's MFMAs.
     float4 ra[A_F4], rw[W_F4];
-    auto load_tiles = [&](int k0) {
+    const int c4 = (tid & 7) << 2;
+    const int trow = tid >> 3;                  // row of this thread's first float4 inside a tile (+32 per extra float4)
+    auto load_tiles = [&](int mt, int k0) {
+        const int gk = k0 + c4;
+        const int gk_safe = gk + 4 <= lda ? gk : lda - 4;
 #pragma unroll
         for (int i = 0; i < A_F4; ++i) {
-            const int idx = tid + i * 256;
-            const int row = idx >> 3, c4 = (idx & 7) << 2;
-            const int gm = m0 + row, gk = k0 + c4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gm < M && gk < K) {
-                v = *reinterpret_cast<const float4 *>(A + (size_t)gm * lda + gk);
-                if (gk + 3 >= K) {
-                    if (gk + 1 >= K) v.y = 0.f;
-                    if (gk + 2 >= K) v.z = 0.f;
-                    v.w = 0.f;
+            const int gm = mt * BM + trow + 32 * i;
+            ra[i] = *reinterpret_cast<const float4 *>(A + (size_t)(gm < M ? gm : M - 1) * lda + gk_safe);
+        }
+#pragma unroll
+        for (int i = 0; i < W_F4; ++i)
+            rw[i] = *reinterpret_cast<const float4 *>(Wp + (size_t)(n0 + trow + 32 * i) * K_pad + gk);
+    };
+    auto mask_k = [&](int k0) {                 // only the last K tile can hold k >= K (rows >= M are never stored)
+        const int gk = k0 + c4;
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) {
+            ra[i].x = gk < K ? ra[i].x : 0.f;
+            ra[i].y = gk + 1 < K ? ra[i].y : 0.f;
+            ra[i].z = gk + 2 < K ? ra[i].z : 0.f;
+            ra[i].w = gk + 3 < K ? ra[i].w : 0.f;
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) {
+            float *d = As + buf * BM * LDS_LD + (trow + 32 * i) * LDS_LD + (c4 >> 1);   // k0..k0+3 -> evens at k0/2, odds at 16 + k0/2
+            *reinterpret_cast<float2 *>(d) = make_float2(ra[i].x, ra[i].z);
+            *reinterpret_cast<float2 *>(d + 16) = make_float2(ra[i].y, ra[i].w);
+        }
+#pragma unroll
+        for (int i = 0; i < W_F4; ++i) {
+            float *d = Ws + buf * BN * LDS_LD + (trow + 32 * i) * LDS_LD + (c4 >> 1);
+            *reinterpret_cast<float2 *>(d) = make_float2(rw[i].x, rw[i].z);
+            *reinterpret_cast<float2 *>(d + 16) = make_float2(rw[i].y, rw[i].w);
+        }
+    };
+    const int frag_a = (wr * 32 * TM + (lane & 31)) * LDS_LD + 16 * (lane >> 5);
+    const int frag_w = (wc * 32 * TN + (lane & 31)) * LDS_LD + 16 * (lane >> 5);
+    auto frag_load = [&](float4 (&a)[TM], float4 (&b)[TN], const float *ab, const float *wb, int qt) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const float4 *>(ab + i * 32 * LDS_LD + qt * 4);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const float4 *>(wb + j * 32 * LDS_LD + qt * 4);
+    };
+    auto mfma16 = [&](const float4 (&a)[TM], const float4 (&b)[TN]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const float av = e == 0 ? a[i].x : e == 1 ? a[i].y : e == 2 ? a[i].z : a[i].w;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const float bv = e == 0 ? b[j].x : e == 1 ? b[j].y : e == 2 ? b[j].z : b[j].w;
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
                 }
             }
-            ra[i] = v;
-        }
-#pragma unroll
-        for (int i = 0; i < W_F4; ++i) {
-            const int idx = tid + i * 256;
-            const int row = idx >> 3, c4 = (idx & 7) << 2;
-            rw[i] = *reinterpret_cast<const float4 *>(Wp + (size_t)(n0 + row) * K_pad + k0 + c4);
         }
     };
-    auto store_tiles = [&]() {
+    float bias_v[TN];
 #pragma unroll
-        for (int i = 0; i < A_F4; ++i) {
-            const int idx = tid + i * 256;
-            float *d = As + (idx >> 3) * LDS_LD + ((idx & 7) << 2);
-            d[0] = ra[i].x; d[1] = ra[i].y; d[2] = ra[i].z; d[3] = ra[i].w;
-        }
+    for (int j = 0; j < TN; ++j) bias_v[j] = bias_p[n0 + wc * 32 * TN + j * 32 + (lane & 31)];
+    // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    auto epilogue = [&](int mt) {
 #pragma unroll
-        for (int i = 0; i < W_F4; ++i) {
-            const int idx = tid + i * 256;
-            float *d = Ws + (idx >> 3) * LDS_LD + ((idx & 7) << 2);
-            d[0] = rw[i].x; d[1] = rw[i].y; d[2] = rw[i].z; d[3] = rw[i].w;
+        for (int j = 0; j < TN; ++j) {
+            const int gn = n0 + wc * 32 * TN + j * 32 + (lane & 31);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int gm = mt * BM + wr * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    float v = acc[i][j][r] + bias_v[j];
+                    if (ACT == 1) v = v > 0.f ? v : v * slope;
+                    if (gm < M && gn < N) C[(size_t)gm * ldc + gn] = v;
+                    acc[i][j][r] = 0.f;
+                }
+            }
         }
     };
 
-    const int nk = K_pad / BK;
-    load_tiles(0);
-    store_tiles();
-    __syncthreads();
-    const float *a_base = As + (wr * 32 * TM + (lane & 31)) * LDS_LD + (lane >> 5);
-    const float *w_base = Ws + (wc * 32 * TN + (lane & 31)) * LDS_LD + (lane >> 5);
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) load_tiles((kt + 1) * BK);
-#pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            float a[TM], b[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = a_base[i * 32 * LDS_LD + kk];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = w_base[j * 32 * LDS_LD + kk];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    // PERSISTENT over M tiles: the (M tile, K tile) pairs of this workgroup form one flat software pipeline, so the first
+    // K tile of the next M tile is already in flight while the current one finishes and its results are stored.  With
+    // K = 256..284 an M tile is only 8-9 K tiles long; a prologue/epilogue bubble per M tile would cost ~25 %.
+    // Pipeline per K tile t:  [regs hold tile t+1, loaded during t-1]  ds_write(t+1) -> other LDS buffer ; issue global loads
+    // (t+2) -> regs ; MFMAs of tile t ; ONE barrier.  Both the LDS stores and the global loads sit in the shadow of the MFMAs.
+    int mt = blockIdx.x;
+    if (mt >= n_mtiles) return;
+    auto compute_full = [&](int cur) {                        // 4 software-pipelined quarters of 4 MFMA steps
+        const float *ab = As + cur * BM * LDS_LD + frag_a;
+        const float *wb = Ws + cur * BN * LDS_LD + frag_w;
+        float4 a0[TM], b0[TN], a1[TM], b1[TN];
+        frag_load(a0, b0, ab, wb, 0);
+        frag_load(a1, b1, ab, wb, 1);
+        mfma16(a0, b0);
+        frag_load(a0, b0, ab, wb, 2);
+        mfma16(a1, b1);
+        frag_load(a1, b1, ab, wb, 3);
+        mfma16(a0, b0);
+        mfma16(a1, b1);
+    };
+    auto compute_partial = [&](int cur, int kvalid) {         // ceil(k_valid / 8) quarters
+        const float *ab = As + cur * BM * LDS_LD + frag_a;
+        const float *wb = Ws + cur * BN * LDS_LD + frag_w;
+        const int nquart = (kvalid + 7) >> 3;
+#pragma unroll 1
+        for (int qt = 0; qt < nquart; ++qt) {
+            float4 a0[TM], b0[TN];
+            frag_load(a0, b0, ab, wb, qt);
+            mfma16(a0, b0);
         }
-        __syncthreads();
-        if (kt + 1 < nk) {
-            store_tiles();
+    };
+    // flat position of "the tile after (m, k)"
+    auto next_tile = [&](int &m, int &k) { if (++k == nk) { k = 0; m += (int)gridDim.x; } };
+    const int kvalid_last = K - (nk - 1) * BK;
+
+    int pm = mt, pk = 0;                                       // (M tile, K tile) of the data currently in the staging registers
+    load_tiles(pm, 0);
+    if (nk == 1) mask_k(0);
+    store_tiles(0);
+    next_tile(pm, pk);
+    if (pm < n_mtiles) load_tiles(pm, pk * BK);                // tile 1 -> regs
+    __syncthreads();
+    int it = 0;
+    auto stage_next = [&](int cur) {
+        if (pm < n_mtiles) {                                      // regs hold the next tile (pm, pk): park it in the other buffer
+            if (pk + 1 == nk) mask_k(pk * BK);
+            if (DBG < 2) store_tiles(cur ^ 1);                    // that buffer was last read one iteration ago (barrier passed)
+            next_tile(pm, pk);
+            if (pm < n_mtiles && DBG == 0) load_tiles(pm, pk * BK);   // tile after next -> regs, in flight during the MFMAs
+        }
+    };
+#pragma unroll 1
+    for (; mt < n_mtiles; mt += gridDim.x) {
+#pragma unroll 1
+        for (int kt = 0; kt + 1 < nk; ++kt, ++it) {              // full tiles
+            const int cur = it & 1;
+            stage_next(cur);
+            // keep the stores/prefetch ABOVE the MFMAs: without this fence hipcc sinks the global loads below the last MFMA
+            // and waits for them at once (vmcnt(0)), exposing the whole HBM/L2 latency every tile
+            __builtin_amdgcn_sched_barrier(0);
+            compute_full(cur);
+            __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
         }
-    }
-
-    // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int gn = n0 + wc * 32 * TN + j * 32 + (lane & 31);
-        const float bv = bias_p[gn];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int gm = m0 + wr * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                float v = acc[i][j][r] + bv;
-                if (ACT == 1) v = v > 0.f ? v : v * slope;
-                if (gm < M && gn < N) C[(size_t)gm * ldc + gn] = v;
-            }
+        {                                                         // last K tile of this M tile, then its results
+            const int cur = it & 1;
+            stage_next(cur);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kvalid_last >= 25) compute_full(cur);
+            else compute_partial(cur, kvalid_last);
+            __builtin_amdgcn_sched_barrier(0);
+            epilogue(mt);
+            __syncthreads();
+            ++it;
         }
     }
 }
@@ -183,12 +268,33 @@ extern "C" int hnr_linear_f32(const float *d_A, int lda, const float *d_Wp, cons
     int Np, Kp;
     hnr_linear_packed_dims(N, K, &Np, &Kp);
     hipStream_t st = (hipStream_t)stream;
+    // persistent workgroups: 2 per CU fit (registers + 2 x LDS double buffers); they stride over the M tiles
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+        if (n_cu <= 0) n_cu = 256;
+    }
+    const int n_mtiles = cdiv(M, 128);
     if (N >= 128) {
-        dim3 grid(cdiv(M, 128), Np / 128);
-        if (act) linear_f32_kernel<2, 2, 1><<<grid, 256, 0, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope);
+        const int ny = Np / 128;
+        int gx = (2 * n_cu) / ny;
+        if (gx < 1) gx = 1;
+        if (gx > n_mtiles) gx = n_mtiles;
+        dim3 grid(gx, ny);
+        static int dbg = -1;
+        if (dbg < 0) { const char *e = getenv("HNR_LINEAR_DBG"); dbg = e ? atoi(e) : 0; }
+        if (dbg == 1) linear_f32_kernel<2, 2, 1, 1><<<grid, 256, 0, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope);
+        else if (dbg == 2) linear_f32_kernel<2, 2, 1, 2><<<grid, 256, 0, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope);
+        else if (act) linear_f32_kernel<2, 2, 1><<<grid, 256, 0, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope);
         else linear_f32_kernel<2, 2, 0><<<grid, 256, 0, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope);
     } else {
-        dim3 grid(cdiv(M, 128), Np / 64);
+        const int ny = Np / 64;
+        int gx = (2 * n_cu) / ny;
+        if (gx < 1) gx = 1;
+        if (gx > n_mtiles) gx = n_mtiles;
+        dim3 grid(gx, ny);
         if (act) linear_f32_kernel<2, 1, 1><<<grid, 256, 0, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope);
         else linear_f32_kernel<2, 1, 0><<<grid, 256, 0, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope);
     }
