@@ -212,29 +212,41 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(GatherArgs a)
             if (a.weight_out) { a.weight_out[(size_t)item * K + kk] = w; a.conf_out[(size_t)item * K + kk] = confc; }
         }
         __syncthreads();
-        // ---- phase 2: block-wide row assembly; lane = column ----
-        constexpr int NCOL1 = F + 6 * F + 60;
-        for (int r = 0; r < G_SAMPLES * 8; ++r) {
+        // ---- phase 2: block-wide row assembly.  Work item = one 16-B chunk of the raw embedding, or one
+        // (input, frequency) pair whose sin AND cos come from one sincosf and are stored as one 8-B pair
+        // (positional_encoding interleaves [sin, cos] per (dim, freq), networks.py:182-189). ----
+        constexpr int NPAIR = 3 * F + 30;                     // 96 embedding pairs + 30 distance pairs
+        constexpr int NITEM = F / 4 + NPAIR;                  // per row
+        for (int it = tid; it < G_SAMPLES * 8 * NITEM; it += 256) {
+            const int r = it / NITEM, w = it - r * NITEM;
             const int grow = s_row[r];
             if (grow < 0) continue;
             const float *raw = s_raw[r];
             float *o1 = a.X1 + (size_t)grow * a.ld1;
-            for (int c = tid; c < NCOL1; c += 256) {
-                float v;
-                if (c < F) {
-                    v = raw[c];
-                } else if (c < 7 * F) {
-                    const int cc = c - F, d = cc / 6, rem = cc - 6 * d, f = rem >> 1;
-                    const float x = __fmul_rn(raw[d], (float)(1 << f));       // positional_encoding (networks.py:182-189)
-                    v = (rem & 1) ? cosf(x) : sinf(x);
+            if (w < F / 4) {
+                reinterpret_cast<float4 *>(o1)[w] = make_float4(raw[4 * w], raw[4 * w + 1], raw[4 * w + 2], raw[4 * w + 3]);
+            } else {
+                const int p = w - F / 4;
+                float x;
+                int col;
+                if (p < 3 * F) {
+                    const int d = p / 3, f = p - 3 * d;
+                    x = __fmul_rn(raw[d], (float)(1 << f));
+                    col = F + 2 * p;
                 } else {
-                    const int cc = c - 7 * F, d = cc / 10, rem = cc - 10 * d, f = rem >> 1;
-                    const float x = __fmul_rn(raw[F + d], (float)(1 << f));
-                    v = (rem & 1) ? cosf(x) : sinf(x);
+                    const int q = p - 3 * F, d = q / 5, f = q - 5 * d;
+                    x = __fmul_rn(raw[F + d], (float)(1 << f));
+                    col = 7 * F + 2 * q;
                 }
-                o1[c] = v;
+                float sv, cv;
+                sincosf(x, &sv, &cv);
+                *reinterpret_cast<float2 *>(o1 + col) = make_float2(sv, cv);
             }
-            if (tid < 7) a.X3[(size_t)grow * a.ld3 + 256 + tid] = s_ext[r][tid];
+        }
+        for (int r = tid >> 3; r < G_SAMPLES * 8; r += 32) {
+            const int grow = s_row[r];
+            const int e = tid & 7;
+            if (grow >= 0 && e < 7) a.X3[(size_t)grow * a.ld3 + 256 + e] = s_ext[r][e];
         }
         __syncthreads();
     }
