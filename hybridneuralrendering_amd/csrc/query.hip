@@ -10,6 +10,8 @@
 //
 // Results are bit-identical to oracle/query_oracle.c (same visiting order, same strict-< replacement
 // and first-max scan), so sample_pidx matches slot for slot.
+#include <stdlib.h>
+
 #include "hnr_common.h"
 
 namespace hnr {
@@ -242,6 +244,113 @@ __global__ __launch_bounds__(256) void knn_kernel(GridView g, const int32_t *__r
             s_st[0][threadIdx.x] + s_st[1][threadIdx.x] + s_st[2][threadIdx.x] + s_st[3][threadIdx.x];
 }
 
+// ------------------------------------------------------------------------------------------------
+// k-NN, two passes per lane (one lane per shading sample), for the 3x3x3 neighbourhood:
+//  pass 1: all 27 brick records are fetched in a branch-free unrolled loop (the loads are independent, so they are
+//          in flight together instead of forming a 27-long dependent chain); the lane keeps a 27-bit occupancy
+//          mask and parks the CSR slot of every occupied cell in LDS;
+//  pass 2: only the occupied cells are walked (9 of 27 on the bench scene), in the reference's order; the next cell's
+//          {start,count} is requested before the current cell's candidates are scanned, and candidates are fetched
+//          two at a time.
+// Same visiting order and insertion rule as knn_kernel / the oracle: results are bit-identical.
+// Measured alternatives (profiles/README.md): 8 lanes per sample with coalesced candidate reads 2.2x slower (per-cell
+// control paid by 8 lanes); wave = 8x8 pixel tile x one slot 1.4-1.5x slower (idle lanes where ray_nsamp differs).
+template <int K>
+__global__ __launch_bounds__(256) void knn2_kernel(GridView g, const int32_t *__restrict__ work, const float *__restrict__ loc,
+                                                   int SR, float radius2, int layers, int32_t *__restrict__ pidx,
+                                                   int8_t *__restrict__ ray_mask, const unsigned long long *__restrict__ counts,
+                                                   unsigned long long *__restrict__ block_stats)
+{
+    __shared__ unsigned long long s_st[4][4];
+    __shared__ uint32_t s_slot[27][256];                      // [cell][thread]: conflict-free (consecutive lanes, consecutive banks)
+    const int n = (int)counts[HNR_CNT_SAMPLES];
+    unsigned long long n_cells = 0, n_cand = 0, n_nb = 0, n_sv = 0;
+    for (int w = blockIdx.x * blockDim.x + threadIdx.x; w < n; w += gridDim.x * blockDim.x) {
+        const int item = work[w];
+        const float cx = loc[3 * (size_t)item], cy = loc[3 * (size_t)item + 1], cz = loc[3 * (size_t)item + 2];
+        const int fx = cell_coord(cx, g.ox, g.cx), fy = cell_coord(cy, g.oy, g.cy), fz = cell_coord(cz, g.oz, g.cz);
+        // ---- pass 1 ----
+        uint32_t occ = 0;
+#pragma unroll
+        for (int c = 0; c < 27; ++c) {
+            const int x = c / 9 - 1, y = (c / 3) % 3 - 1, z = c % 3 - 1;
+            const int vx = fx + x, vy = fy + y, vz = fz + z;
+            const bool inb = in_bounds(g, vx, vy, vz);
+            const int qx = inb ? vx : fx, qy = inb ? vy : fy, qz = inb ? vz : fz;     // clamp: the load is unconditional
+            const uint4 rec = g.occ_rec[brick_word(g, qx, qy, qz)];
+            const unsigned long long bb = (unsigned long long)rec.x | ((unsigned long long)rec.y << 32);
+            const int b = brick_bit(qx, qy, qz);
+            const bool o = inb && ((bb >> b) & 1ull);
+            occ |= (o ? 1u : 0u) << c;
+            s_slot[c][threadIdx.x] = rec.z + (uint32_t)__popcll(bb & ((1ull << b) - 1ull));
+        }
+        // ---- pass 2 ----
+        KBuf<K> kb;
+        kb.init();
+        for (int layer = 0; layer < layers && layer < 2; ++layer) {
+            uint32_t m = layer == 0 ? (occ & (1u << 13)) : (occ & ~(1u << 13));   // shell 0 = the sample's own cell
+            int2 rg_next = make_int2(0, 0);
+            if (m) rg_next = g.cell_rng[s_slot[__ffs((int)m) - 1][threadIdx.x]];
+            while (m) {
+                m &= m - 1;
+                const int2 rg = rg_next;
+                if (m) rg_next = g.cell_rng[s_slot[__ffs((int)m) - 1][threadIdx.x]];   // request the next cell early
+                ++n_cells;
+                n_cand += (unsigned)rg.y;
+                int j = 0;
+                for (; j + 1 < rg.y; j += 2) {
+                    const float4 p0 = g.pts[rg.x + j], p1 = g.pts[rg.x + j + 1];
+                    {
+                        const float xv = __fsub_rn(p0.x, cx), yv = __fsub_rn(p0.y, cy), zv = __fsub_rn(p0.z, cz);
+                        const float v = __fadd_rn(__fadd_rn(__fmul_rn(xv, xv), __fmul_rn(yv, yv)), __fmul_rn(zv, zv));
+                        if (radius2 == 0.f || v <= radius2) kb.offer(v, __float_as_int(p0.w));
+                    }
+                    {
+                        const float xv = __fsub_rn(p1.x, cx), yv = __fsub_rn(p1.y, cy), zv = __fsub_rn(p1.z, cz);
+                        const float v = __fadd_rn(__fadd_rn(__fmul_rn(xv, xv), __fmul_rn(yv, yv)), __fmul_rn(zv, zv));
+                        if (radius2 == 0.f || v <= radius2) kb.offer(v, __float_as_int(p1.w));
+                    }
+                }
+                if (j < rg.y) {
+                    const float4 p0 = g.pts[rg.x + j];
+                    const float xv = __fsub_rn(p0.x, cx), yv = __fsub_rn(p0.y, cy), zv = __fsub_rn(p0.z, cz);
+                    const float v = __fadd_rn(__fadd_rn(__fmul_rn(xv, xv), __fmul_rn(yv, yv)), __fmul_rn(zv, zv));
+                    if (radius2 == 0.f || v <= radius2) kb.offer(v, __float_as_int(p0.w));
+                }
+            }
+            if (kb.kid >= K) break;
+        }
+        if (kb.kid > 0) {
+            int32_t *o = pidx + (size_t)item * K;
+            if constexpr ((K & 3) == 0) {
+#pragma unroll
+                for (int i = 0; i < K; i += 4)
+                    reinterpret_cast<int4 *>(o)[i >> 2] = make_int4(kb.id[i], kb.id[i + 1], kb.id[i + 2], kb.id[i + 3]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < K; ++i) o[i] = kb.id[i];
+            }
+            ray_mask[item / SR] = 1;
+            n_nb += (unsigned)(kb.kid < K ? kb.kid : K);
+            ++n_sv;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        n_cells += __shfl_xor(n_cells, o);
+        n_cand += __shfl_xor(n_cand, o);
+        n_nb += __shfl_xor(n_nb, o);
+        n_sv += __shfl_xor(n_sv, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        const int wv = threadIdx.x >> 6;
+        s_st[wv][0] = n_cells; s_st[wv][1] = n_cand; s_st[wv][2] = n_nb; s_st[wv][3] = n_sv;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4)
+        block_stats[4 * (size_t)blockIdx.x + threadIdx.x] =
+            s_st[0][threadIdx.x] + s_st[1][threadIdx.x] + s_st[2][threadIdx.x] + s_st[3][threadIdx.x];
+}
+
 __global__ __launch_bounds__(256) void knn_finalize_kernel(const unsigned long long *__restrict__ block_stats, int nblocks,
                                                            unsigned long long *__restrict__ counts)
 {
@@ -404,6 +513,14 @@ extern "C" int hnr_march_query(const hnr_grid *g, const float *d_campos, const f
     nsamp_block_sum_kernel<<<nb, 1024, 0, st>>>(d_ray_nsamp, q->R, block_sums);
     worklist_kernel<<<nb, 1024, 0, st>>>(d_ray_nsamp, q->R, q->SR, block_sums, nb, d_work, cnt);
     HNR_LAUNCH_CHECK();
+    // K = 8 with a 3x3x3 neighbourhood (every shipped config): the two-pass kernel
+    if (q->K == 8 && layers <= 2 && !getenv("HNR_KNN_SINGLE_PASS")) {
+        const int blocks = knn_blocks(max_items);
+        knn2_kernel<8><<<blocks, 256, 0, st>>>(v, d_work, d_sample_loc_w, q->SR, q->radius2, layers, d_sample_pidx, d_ray_mask, cnt, block_stats);
+        knn_finalize_kernel<<<1, 256, 0, st>>>(block_stats, blocks, cnt);
+        HNR_LAUNCH_CHECK();
+        return HNR_OK;
+    }
     switch (q->K) {
 #define HNR_KCASE(KK) case KK: launch_knn<KK>(v, d_work, d_sample_loc_w, q->SR, q->radius2, layers, d_sample_pidx, d_ray_mask, cnt, block_stats, max_items, st); break;
         HNR_KCASE(1) HNR_KCASE(2) HNR_KCASE(3) HNR_KCASE(4) HNR_KCASE(5) HNR_KCASE(6) HNR_KCASE(7) HNR_KCASE(8)
