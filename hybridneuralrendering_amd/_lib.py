@@ -30,7 +30,8 @@ class GridStats(ctypes.Structure):
 
 class QueryParams(ctypes.Structure):
     _fields_ = [("R", ctypes.c_int), ("D", ctypes.c_int), ("SR", ctypes.c_int), ("K", ctypes.c_int),
-                ("kernel_size", ctypes.c_int * 3), ("radius2", ctypes.c_float), ("tmid_stride", ctypes.c_int)]
+                ("kernel_size", ctypes.c_int * 3), ("radius2", ctypes.c_float), ("tmid_stride", ctypes.c_int),
+                ("pad_outputs", ctypes.c_int)]
 
 
 _P = ctypes.c_void_p
@@ -63,7 +64,7 @@ SIGNATURES = {
     "hnr_proj_rows": (_I, [_P] * 8 + [_I, _I, _I, _P, _I, _I, _P, _I, _P, _P]),
     "hnr_merge": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _P, _I, _P]),
     "hnr_final_color": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P]),
-    "hnr_composite": (_I, [_P] * 7 + [_I, _I, _I, _F, _I, _P, _P, _P, _P, _P]),
+    "hnr_composite": (_I, [_P] * 8 + [_I, _I, _I, _F, _I, _P, _P, _P, _P, _P]),
 }
 
 _lib = None

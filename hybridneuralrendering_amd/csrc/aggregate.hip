@@ -518,6 +518,7 @@ struct CompositeArgs {
     const float *loc_w;                                  // [R,SR,3] (zero padded)
     const int32_t *pidx;                                 // [R,SR,K]
     const int8_t *ray_mask;                              // [R]
+    const int32_t *nsamp;                                // [R] or NULL (padded inputs)
     const float *campos, *camrot, *bg;                   // [3], [3,3], [3]
     int R, SR, K;
     float vsize_z;
@@ -544,9 +545,11 @@ __global__ __launch_bounds__(256) void composite_kernel(CompositeArgs a)
 #pragma unroll
     for (int i = 0; i < 9; ++i) cr[i] = a.camrot[i];
     const float cp[3] = {a.campos[0], a.campos[1], a.campos[2]};
+    const int ns = a.nsamp ? a.nsamp[r] : a.SR;          // slots >= ns hold the padding values (position 0, no neighbour)
     auto zc = [&](int s) {
         const float *p = a.loc_w + ((size_t)r * a.SR + s) * 3;
-        const float s0 = __fsub_rn(p[0], cp[0]), s1 = __fsub_rn(p[1], cp[1]), s2 = __fsub_rn(p[2], cp[2]);
+        const float q0 = s < ns ? p[0] : 0.f, q1 = s < ns ? p[1] : 0.f, q2 = s < ns ? p[2] : 0.f;
+        const float s0 = __fsub_rn(q0, cp[0]), s1 = __fsub_rn(q1, cp[1]), s2 = __fsub_rn(q2, cp[2]);
         return __fadd_rn(__fadd_rn(__fmul_rn(cr[2], s0), __fmul_rn(cr[5], s1)), __fmul_rn(cr[8], s2));
     };
     float T = 1.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
@@ -561,7 +564,7 @@ __global__ __launch_bounds__(256) void composite_kernel(CompositeArgs a)
             dist = a.vsize_z;
         }
         if (dist < 1e-8f || (a.unit_mode && dist > 2.f * a.vsize_z)) dist = a.vsize_z;
-        const bool valid = a.pidx[((size_t)r * a.SR + s) * a.K] >= 0;      // ray_valid = any(mask over K); ids are a prefix
+        const bool valid = s < ns && a.pidx[((size_t)r * a.SR + s) * a.K] >= 0;   // ray_valid = any(mask over K); ids are a prefix
         const float4 d = reinterpret_cast<const float4 *>(a.decoded)[(size_t)r * a.SR + s];
         const float sigma = valid ? d.x : 0.f;
         const float rd = valid ? dist : 0.f;
@@ -791,7 +794,7 @@ extern "C" int hnr_final_color(const float *d_Y, int ldy, const float *d_CF, int
 }
 
 extern "C" int hnr_composite(const float *d_decoded, const float *d_sample_loc_w, const int32_t *d_sample_pidx,
-                             const int8_t *d_ray_mask, const float *d_campos, const float *d_camrot, const float *d_bg_color,
+                             const int8_t *d_ray_mask, const int32_t *d_ray_nsamp, const float *d_campos, const float *d_camrot, const float *d_bg_color,
                              int R, int SR, int K, float vsize_z, int raydist_mode_unit, float *d_raycolor, float *d_opacity,
                              float *d_is_background, float *d_blend_weight, void *stream)
 {
@@ -802,7 +805,7 @@ extern "C" int hnr_composite(const float *d_decoded, const float *d_sample_loc_w
         set_error("hnr_composite: NULL argument"); return HNR_ERR_BADARG;
     }
     CompositeArgs a;
-    a.decoded = d_decoded; a.loc_w = d_sample_loc_w; a.pidx = d_sample_pidx; a.ray_mask = d_ray_mask; a.campos = d_campos;
+    a.decoded = d_decoded; a.loc_w = d_sample_loc_w; a.pidx = d_sample_pidx; a.ray_mask = d_ray_mask; a.nsamp = d_ray_nsamp; a.campos = d_campos;
     a.camrot = d_camrot; a.bg = d_bg_color; a.R = R; a.SR = SR; a.K = K; a.vsize_z = vsize_z; a.unit_mode = raydist_mode_unit;
     a.raycolor = d_raycolor; a.opacity = d_opacity; a.is_bg = d_is_background; a.blend_w = d_blend_weight;
     composite_kernel<<<cdiv(R, 256), 256, 0, (hipStream_t)stream>>>(a);

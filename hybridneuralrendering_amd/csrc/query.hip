@@ -22,7 +22,7 @@ namespace hnr {
 __global__ __launch_bounds__(256) void march_kernel(GridView g, const float *__restrict__ campos,
                                                     const float *__restrict__ raydir,
                                                     const float *__restrict__ tmid, int R, int D, int SR, int K,
-                                                    int tmid_stride, int32_t *__restrict__ pidx,
+                                                    int tmid_stride, int pad, int32_t *__restrict__ pidx,
                                                     float *__restrict__ loc, int32_t *__restrict__ ray_nsamp,
                                                     int8_t *__restrict__ ray_mask)
 {
@@ -59,15 +59,11 @@ __global__ __launch_bounds__(256) void march_kernel(GridView g, const float *__r
         if (base >= SR) break;
     }
     const int ns = base < SR ? base : SR;
-    // pad: sample_loc zeros (torch.zeros, :647), sample_pidx -1 (torch.full, :648)
-    for (int i = ns * 3 + lane; i < SR * 3; i += 64) loc_r[i] = 0.f;
-    int32_t *pidx_r = pidx + (size_t)r * SR * K;
-    const int nk = SR * K;
-    if ((nk & 3) == 0) {
-        int4 *p4 = reinterpret_cast<int4 *>(pidx_r);
-        for (int i = lane; i < (nk >> 2); i += 64) p4[i] = make_int4(-1, -1, -1, -1);
-    } else {
-        for (int i = lane; i < nk; i += 64) pidx_r[i] = -1;
+    if (pad) {
+        // pad: sample_loc zeros (torch.zeros, :647), sample_pidx -1 (torch.full, :648); kept slots are written by the k-NN
+        for (int i = ns * 3 + lane; i < SR * 3; i += 64) loc_r[i] = 0.f;
+        int32_t *pidx_r = pidx + (size_t)r * SR * K;
+        for (int i = ns * K + lane; i < SR * K; i += 64) pidx_r[i] = -1;
     }
     if (lane == 0) {
         ray_nsamp[r] = ns;
@@ -211,7 +207,7 @@ __global__ __launch_bounds__(256) void knn_kernel(GridView g, const int32_t *__r
                     }
             if (kb.kid >= K) break;
         }
-        if (kb.kid > 0) {
+        {   // every kept sample gets its K ids (-1 where empty): the march kernel pads only the unused slots
             int32_t *o = pidx + (size_t)item * K;
             if constexpr ((K & 3) == 0) {
 #pragma unroll
@@ -221,6 +217,8 @@ __global__ __launch_bounds__(256) void knn_kernel(GridView g, const int32_t *__r
 #pragma unroll
                 for (int i = 0; i < K; ++i) o[i] = kb.id[i];
             }
+        }
+        if (kb.kid > 0) {
             ray_mask[item / SR] = 1;
             n_nb += (unsigned)(kb.kid < K ? kb.kid : K);
             ++n_sv;
@@ -320,7 +318,7 @@ __global__ __launch_bounds__(256) void knn2_kernel(GridView g, const int32_t *__
             }
             if (kb.kid >= K) break;
         }
-        if (kb.kid > 0) {
+        {   // every kept sample gets its K ids (-1 where empty): the march kernel pads only the unused slots
             int32_t *o = pidx + (size_t)item * K;
             if constexpr ((K & 3) == 0) {
 #pragma unroll
@@ -330,6 +328,8 @@ __global__ __launch_bounds__(256) void knn2_kernel(GridView g, const int32_t *__
 #pragma unroll
                 for (int i = 0; i < K; ++i) o[i] = kb.id[i];
             }
+        }
+        if (kb.kid > 0) {
             ray_mask[item / SR] = 1;
             n_nb += (unsigned)(kb.kid < K ? kb.kid : K);
             ++n_sv;
@@ -500,7 +500,7 @@ extern "C" int hnr_march_query(const hnr_grid *g, const float *d_campos, const f
     const GridView v = g->view();
     unsigned long long *cnt = reinterpret_cast<unsigned long long *>(d_counts);
     march_kernel<<<cdiv((int64_t)q->R * 64, 256), 256, 0, st>>>(v, d_campos, d_raydir, d_tmid, q->R, q->D, q->SR, q->K,
-                                                                q->tmid_stride, d_sample_pidx, d_sample_loc_w,
+                                                                q->tmid_stride, q->pad_outputs, d_sample_pidx, d_sample_loc_w,
                                                                 d_ray_nsamp, d_ray_mask);
     HNR_LAUNCH_CHECK();
     const int layers = (q->kernel_size[0] + 1) / 2;

@@ -226,7 +226,7 @@ class NeuralPointsRayMarching(nn.Module):
         nearv, farv = torch.min(near).item(), torch.max(far).item()
         fw = frame_weight_nearest[0] if getattr(self.opt, "downweight_blurry_feats", 0) else None
         full = rnd.render_rays(cloud, raydir[0], campos[0], camrotc2w[0], bg_color[0], nearv, farv, c2w_nearest[0], campos_nearest[0],
-                               intrinsic_nearest[0], images_nearest[0], frame_weight=fw, want_weights=True)
+                               intrinsic_nearest[0], images_nearest[0], frame_weight=fw, want_weights=True, pad=True)
         mask = full["ray_mask"]
         rows = torch.nonzero(mask)[:, 0]                                  # valid rays, in ray order (:705-709)
         sel = lambda t: t.index_select(0, rows)[None]

@@ -131,7 +131,7 @@ def points_bounds(xyz):
     return o[:3].copy(), o[3:].copy()
 
 
-def march_query(grid, campos, raydir, tmid, SR, K, radius2, kernel_size):
+def march_query(grid, campos, raydir, tmid, SR, K, radius2, kernel_size, pad=True):
     """hnr_march_query on R rays.  Un-compacted outputs (row r = input ray r), no host sync:
     dict(sample_pidx [R,SR,K] i32, sample_loc_w [R,SR,3] f32, ray_nsamp [R] i32, ray_mask [R] i8,
     counts [8] i64 (device))."""
@@ -152,6 +152,7 @@ def march_query(grid, campos, raydir, tmid, SR, K, radius2, kernel_size):
     for a in range(3):
         q.kernel_size[a] = int(kernel_size[a])
     q.radius2 = float(radius2)
+    q.pad_outputs = 1 if pad else 0
     pidx = torch.empty((R, SR, K), dtype=torch.int32, device=dev)
     loc = torch.empty((R, SR, 3), dtype=torch.float32, device=dev)
     nsamp = torch.empty((R,), dtype=torch.int32, device=dev)
@@ -162,7 +163,7 @@ def march_query(grid, campos, raydir, tmid, SR, K, radius2, kernel_size):
         _lib.check(L.hnr_march_query(grid.handle, _lib.ptr(campos), _lib.ptr(raydir), _lib.ptr(tmid), ctypes.byref(q),
                                      _lib.ptr(pidx), _lib.ptr(loc), _lib.ptr(nsamp), _lib.ptr(mask), _lib.ptr(work),
                                      _lib.ptr(counts), _lib.stream()), "hnr_march_query")
-    return dict(sample_pidx=pidx, sample_loc_w=loc, ray_nsamp=nsamp, ray_mask=mask, counts=counts, work=work)
+    return dict(sample_pidx=pidx, sample_loc_w=loc, ray_nsamp=nsamp, ray_mask=mask, counts=counts, work=work, padded=bool(pad))
 
 
 def compact_rays(res, raydir, campos, camrot):

@@ -181,14 +181,15 @@ class HybridRenderer:
         bw = _f32((R, SR), dev) if want_blend else None
         p = _lib.ptr
         with torch.cuda.device(dev):
-            _lib.check(L.hnr_composite(p(decoded), p(loc_w), p(pidx), p(mask), p(campos), p(camrot), p(bg_color), R, SR, K,
+            _lib.check(L.hnr_composite(p(decoded), p(loc_w), p(pidx), p(mask), None if qres.get("padded", True) else p(qres["ray_nsamp"]),
+                                       p(campos), p(camrot), p(bg_color), R, SR, K,
                                        float(np.float32(self.opt.vsize[2])), int(getattr(self.opt, "raydist_mode_unit", 0) > 0),
                                        p(col), p(opa), p(isbg), p(bw) if want_blend else None, _lib.stream()), "hnr_composite")
         return dict(coarse_raycolor=col, coarse_point_opacity=opa, coarse_is_background=isbg, blend_weight=bw)
 
     # -- the whole path -------------------------------------------------------------------------------
     def render_rays(self, cloud, raydir, campos, camrot, bg_color, near, far, c2w_nearest, campos_nearest, intrinsic_nearest,
-                    images_nearest, frame_weight=None, want_weights=False, w2c_nearest=None, timers=None):
+                    images_nearest, frame_weight=None, want_weights=False, w2c_nearest=None, timers=None, pad=False):
         """raydir [R,3]; campos [3]; camrot [3,3]; c2w_nearest [V,4,4]; images_nearest [V,H,W,3] (or with a leading 1).
         Returns full-R outputs (fill_invalid applied): coarse_raycolor [R,3], coarse_point_opacity [R,SR],
         coarse_is_background [R], ray_mask [R] i8, decoded [R,SR,4] + the query tensors."""
@@ -207,7 +208,8 @@ class HybridRenderer:
         grid, hp = q._grid_for(cloud.xyz[None])
         tmid = q._tmid_for(float(near), float(far), self.opt.z_depth_dim, raydir.shape[0], raydir.device)
         with _Stage(timers, "query"):
-            qres = Q.march_query(grid, campos, raydir, tmid, self.opt.SR, self.opt.K, np.float32(hp[0] ** 2), self.opt.kernel_size)
+            # pad=False: only kept slots are written (no -1 / 0 padding stores); everything downstream takes ray_nsamp
+            qres = Q.march_query(grid, campos, raydir, tmid, self.opt.SR, self.opt.K, np.float32(hp[0] ** 2), self.opt.kernel_size, pad=pad)
         with _Stage(timers, "featmap"):
             fm = self.feature_map(images_nearest)
         a = self.aggregate(cloud, qres, raydir, campos, camrot, w2c_nearest, intrinsic_nearest, campos_nearest, fm,

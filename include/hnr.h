@@ -100,6 +100,10 @@ typedef struct {
     float radius2;        /* radius_limit^2, 0 = unlimited (:493, :685)                         */
     int   tmid_stride;    /* 0: d_tmid is one [D] table shared by all rays (jitter = 0);
                              D: d_tmid is [R,D], one depth table per ray (train-time jitter)    */
+    int   pad_outputs;    /* 1: d_sample_pidx / d_sample_loc_w are fully written, -1 / 0 in the unused slots
+                             (the reference's torch.full / torch.zeros tensors, :647-648);
+                             0: only the first d_ray_nsamp[r] slots of a ray are written (fused path: consumers
+                             take d_ray_nsamp; saves 1 kB of padding stores per ray)                */
 } hnr_query_params;
 
 /* counters written by hnr_march_query (device, int64[HNR_NCOUNTS]) */
@@ -243,8 +247,11 @@ int hnr_final_color(const float *d_Y, int ldy, const float *d_CF, int ldcf, cons
  * Stage 4: ray_dist (neural_points_volumetric_model.py:331-339) + ray_march with radiance render / alpha
  * blend (models/rendering/diff_ray_marching.py:508-557) + fill_invalid (:87-126), in input-ray order:
  *   d_raycolor [R,3] (bg colour where ray_mask = 0), d_opacity [R,SR], d_is_background [R] (T_end; 1 where
- *   ray_mask = 0), optional d_blend_weight [R,SR]. */
+ *   ray_mask = 0), optional d_blend_weight [R,SR].
+ * d_ray_nsamp: NULL when the query outputs are padded (pad_outputs = 1); else slots >= d_ray_nsamp[r] are taken as
+ * the padding values (position 0, no neighbour) without being read. */
 int hnr_composite(const float *d_decoded, const float *d_sample_loc_w, const int32_t *d_sample_pidx, const int8_t *d_ray_mask,
+                  const int32_t *d_ray_nsamp,
                   const float *d_campos, const float *d_camrot, const float *d_bg_color, int R, int SR, int K, float vsize_z,
                   int raydist_mode_unit, float *d_raycolor, float *d_opacity, float *d_is_background, float *d_blend_weight,
                   void *stream);

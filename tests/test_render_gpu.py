@@ -45,8 +45,14 @@ def test_full_path_matches_reference_golden(tag):
     w2c = torch.inverse(ti["c2w_nearest"][0].cpu()).to(ti["raydir"].device)      # same LU as the reference's CPU run
     out = rnd.render_rays(cloud, ti["raydir"][0], ti["campos"][0], ti["camrotc2w"][0], ti["bg_color"][0], near, far,
                           ti["c2w_nearest"][0], ti["campos_nearest"][0], ti["intrinsic_nearest"][0], ti["images_nearest"][0],
-                          want_weights=True, w2c_nearest=w2c)
+                          want_weights=True, w2c_nearest=w2c, pad=True)
     torch.cuda.synchronize()
+    # the un-padded fused mode (only kept slots written) must give the same image, bit for bit
+    out_np = rnd.render_rays(cloud, ti["raydir"][0], ti["campos"][0], ti["camrotc2w"][0], ti["bg_color"][0], near, far,
+                             ti["c2w_nearest"][0], ti["campos_nearest"][0], ti["intrinsic_nearest"][0], ti["images_nearest"][0],
+                             w2c_nearest=w2c, pad=False)
+    assert torch.equal(out_np["coarse_raycolor"], out["coarse_raycolor"])
+    assert torch.equal(out_np["coarse_point_opacity"], out["coarse_point_opacity"])
     # query stage: bit-exact against the fixture's (oracle-produced) indices
     rows = np.nonzero(d["q_ray_mask"])[0]
     np.testing.assert_array_equal(out["ray_mask"].cpu().numpy(), d["q_ray_mask"])
