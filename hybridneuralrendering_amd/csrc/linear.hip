@@ -30,20 +30,23 @@ constexpr int LDS_LD = BK + 4;     // 36 floats = 144 B rows: 16-B aligned, and 
 // 16 + p holds k = 2p + 1.  The 32x32x2 MFMA takes k = 0 from lanes 0-31 and k = 1 from lanes 32-63, so lane-half h
 // needs k = 2j + h at step j = position 16h + j: sixteen CONSECUTIVE floats -> four ds_read_b128 per 32-row block per
 // tile (instead of sixteen ds_read_b32), and a partial last tile only costs ceil(k_valid / 2) MFMA steps.
-template <int TM, int TN, int ACT, int DBG = 0>   // ACT: 0 none, 1 LeakyReLU(slope); DBG: ablation switches (probe only)
-__global__ __launch_bounds__(256, 2) void linear_f32_kernel(const float *__restrict__ A, int lda,
+template <int TM, int TN, int ACT, int DBG = 0, int WN = 2>   // ACT: 0 none, 1 LeakyReLU(slope); DBG: ablation switches (probe only)
+__global__ __launch_bounds__(128 * WN, 2) void linear_f32_kernel(const float *__restrict__ A, int lda,
                                                          const float *__restrict__ Wp, int K_pad,
                                                          const float *__restrict__ bias_p, float *__restrict__ C, int ldc,
                                                          int M, int N, int K, float slope)
 {
-    constexpr int BM = 64 * TM, BN = 64 * TN;
-    constexpr int A_F4 = BM * BK / 4 / 256;     // float4 per thread for the A tile
-    constexpr int W_F4 = BN * BK / 4 / 256;
+    // workgroup = 2 x WN waves; each wave owns TM x TN MFMA tiles of 32x32
+    constexpr int NT = 128 * WN;                // threads
+    constexpr int RPP = NT / 8;                 // tile rows covered by one pass of the loader (8 float4 per 32-float row)
+    constexpr int BM = 64 * TM, BN = 32 * TN * WN;
+    constexpr int A_F4 = BM * BK / 4 / NT;      // float4 per thread for the A tile
+    constexpr int W_F4 = BN * BK / 4 / NT;
     __shared__ __attribute__((aligned(16))) float As[2 * BM * LDS_LD];     // double-buffered: one barrier per K tile
     __shared__ __attribute__((aligned(16))) float Ws[2 * BN * LDS_LD];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / WN, wc = wave % WN;
     const int n0 = blockIdx.y * BN;
     const int n_mtiles = (M + BM - 1) / BM;
     const int nk = (K + BK - 1) / BK;
@@ -60,18 +63,18 @@ __global__ __launch_bounds__(256, 2) void linear_f32_kernel(const float *__restr
     // selects, so no branch consumes a loaded value early: the loads stay in flight across the tile's MFMAs.
     float4 ra[A_F4], rw[W_F4];
     const int c4 = (tid & 7) << 2;
-    const int trow = tid >> 3;                  // row of this thread's first float4 inside a tile (+32 per extra float4)
+    const int trow = tid >> 3;                  // row of this thread's first float4 inside a tile (+RPP per extra float4)
     auto load_tiles = [&](int mt, int k0) {
         const int gk = k0 + c4;
         const int gk_safe = gk + 4 <= lda ? gk : lda - 4;
 #pragma unroll
         for (int i = 0; i < A_F4; ++i) {
-            const int gm = mt * BM + trow + 32 * i;
+            const int gm = mt * BM + trow + RPP * i;
             ra[i] = *reinterpret_cast<const float4 *>(A + (size_t)(gm < M ? gm : M - 1) * lda + gk_safe);
         }
 #pragma unroll
         for (int i = 0; i < W_F4; ++i)
-            rw[i] = *reinterpret_cast<const float4 *>(Wp + (size_t)(n0 + trow + 32 * i) * K_pad + gk);
+            rw[i] = *reinterpret_cast<const float4 *>(Wp + (size_t)(n0 + trow + RPP * i) * K_pad + gk);
     };
     auto mask_k = [&](int k0) {                 // only the last K tile can hold k >= K (rows >= M are never stored)
         const int gk = k0 + c4;
@@ -86,13 +89,13 @@ __global__ __launch_bounds__(256, 2) void linear_f32_kernel(const float *__restr
     auto store_tiles = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < A_F4; ++i) {
-            float *d = As + buf * BM * LDS_LD + (trow + 32 * i) * LDS_LD + (c4 >> 1);   // k0..k0+3 -> evens at k0/2, odds at 16 + k0/2
+            float *d = As + buf * BM * LDS_LD + (trow + RPP * i) * LDS_LD + (c4 >> 1);   // k0..k0+3 -> evens at k0/2, odds at 16 + k0/2
             *reinterpret_cast<float2 *>(d) = make_float2(ra[i].x, ra[i].z);
             *reinterpret_cast<float2 *>(d + 16) = make_float2(ra[i].y, ra[i].w);
         }
 #pragma unroll
         for (int i = 0; i < W_F4; ++i) {
-            float *d = Ws + buf * BN * LDS_LD + (trow + 32 * i) * LDS_LD + (c4 >> 1);
+            float *d = Ws + buf * BN * LDS_LD + (trow + RPP * i) * LDS_LD + (c4 >> 1);
             *reinterpret_cast<float2 *>(d) = make_float2(rw[i].x, rw[i].z);
             *reinterpret_cast<float2 *>(d + 16) = make_float2(rw[i].y, rw[i].w);
         }
@@ -277,14 +280,24 @@ extern "C" int hnr_linear_f32(const float *d_A, int lda, const float *d_Wp, cons
         if (n_cu <= 0) n_cu = 256;
     }
     const int n_mtiles = cdiv(M, 128);
-    if (N >= 128) {
+    static int dbg = -1;
+    if (dbg < 0) { const char *e = getenv("HNR_LINEAR_DBG"); dbg = e ? atoi(e) : 0; }
+    if (N > 128 && Np % 256 == 0 && dbg != 3) {
+        // 128 x 256 block tile, 8 waves (2 x 4): the A tile is fetched ONCE for all 256 output columns.  (With two 128-column
+        // workgroups per M tile the PMC counters show A coming from HBM twice: 56.7 GB fetched per 24.3 GB of A.)
+        const int ny = Np / 256;
+        int gx = n_cu / ny;                                       // one 512-thread workgroup per CU (110 KB of LDS)
+        if (gx < 1) gx = 1;
+        if (gx > n_mtiles) gx = n_mtiles;
+        dim3 grid(gx, ny);
+        if (act) linear_f32_kernel<2, 2, 1, 0, 4><<<grid, 512, 0, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope);
+        else linear_f32_kernel<2, 2, 0, 0, 4><<<grid, 512, 0, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope);
+    } else if (N >= 128) {
         const int ny = Np / 128;
         int gx = (2 * n_cu) / ny;
         if (gx < 1) gx = 1;
         if (gx > n_mtiles) gx = n_mtiles;
         dim3 grid(gx, ny);
-        static int dbg = -1;
-        if (dbg < 0) { const char *e = getenv("HNR_LINEAR_DBG"); dbg = e ? atoi(e) : 0; }
         if (dbg == 1) linear_f32_kernel<2, 2, 1, 1><<<grid, 256, 0, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope);
         else if (dbg == 2) linear_f32_kernel<2, 2, 1, 2><<<grid, 256, 0, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope);
         else if (act) linear_f32_kernel<2, 2, 1><<<grid, 256, 0, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope);
