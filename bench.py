@@ -81,6 +81,16 @@ def render_frame(rnd, cloud, cam, sc, chunk, timers=None):
     return cols[0] if len(cols) == 1 else torch.cat(cols, dim=0), out
 
 
+def pmc_traffic():
+    """HBM bytes per launch from the rocprofv3 PMC passes kept under profiles/ (FETCH_SIZE / WRITE_SIZE cannot be read
+    from inside the process; the passes are re-collected with tools/collect_traffic.py whenever the kernels change)."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["kernels"]
+    except Exception:
+        return {}
+    return d
+
+
 def cpu_baseline(args, sc, opt, agg, cam, gpu_colors):
     """The CPU oracle (C query restatement + torch-CPU aggregate/composite) on one 48x48-ray chunk of the same
     frame, grid build included (the reference rebuilds its grid for every chunk)."""
@@ -169,6 +179,9 @@ def main():
         # --- roofline of the dominant kernel (fp32 MFMA dense layer) and of the query stage, from HIP events
         # recorded on the launch stream inside the timed region
         roof, roof_q = None, None
+        pmc = pmc_traffic() if (int(args.points) == 2000000 and args.scene == "scene0241" and args.chunk <= 0) else {}
+        t_lin = next((v for k, v in pmc.items() if "linear_f32_kernel<2, 2, 1, 0, 4>" in k), None)
+        t_q = [v for k, v in pmc.items() if "march_kernel" in k or "knn2_kernel" in k]
         if counts is not None:
             n_rows, n_valid = int(counts[CNT["NEIGHBOURS"]]), int(counts[CNT["SAMPLES_VALID"]])
             s_all, cells, cand = int(counts[CNT["SAMPLES"]]), int(counts[CNT["CELLS_VISITED"]]), int(counts[CNT["CANDIDATES"]])
@@ -177,16 +190,20 @@ def main():
             ms_nb = stage_ms.get("mlp_neighbour", 0.0)
             if ms_nb > 0:
                 ach = flops_nb / (ms_nb * 1e-3) / 1e12
-                roof = dict(kernel="linear_f32_kernel<2,2,1> (block1+block3, 4 launches, M=%d rows)" % n_rows, bound="mfma",
+                roof = dict(kernel="linear_f32_kernel<2,2,1,0,4> (block1+block3, 4 launches, M=%d rows)" % n_rows, bound="mfma",
                             achieved=round(ach, 2), peak=F32_MFMA_PEAK_TF, unit="TFLOP/s", frac=round(ach / F32_MFMA_PEAK_TF, 4),
-                            traffic=None, flops_per_launch=flops_nb / 4, avg_launch_ms=round(ms_nb / 4, 4))
+                            traffic=int(t_lin["hbm_bytes"]) if t_lin else None,
+                            traffic_source="profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)" if t_lin else None,
+                            flops_per_launch=flops_nb / 4, avg_launch_ms=round(ms_nb / 4, 4))
             D, K = opt.z_depth_dim, opt.K
             alg = R * (12 + (D + 7) // 8 + 1) + s_all * (12 + 27 * 4 + 4 * K) + 4 * cells + 16 * cand
             ms_q = stage_ms.get("query", 0.0)
             if ms_q > 0:
                 ach = alg / (ms_q * 1e-3) / 1e9
-                roof_q = dict(kernel="hnr_march_query: march_kernel + worklist scans + knn_kernel<8>", bound="hbm", achieved=round(ach, 1),
-                              peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), traffic=None,
+                roof_q = dict(kernel="hnr_march_query: march_kernel + worklist scans + knn2_kernel<8>", bound="hbm", achieved=round(ach, 1),
+                              peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
+                              traffic=int(sum(v["hbm_bytes"] for v in t_q)) if len(t_q) == 2 else None,
+                              traffic_source="profiles/r01_traffic.json (march_kernel + knn2_kernel, bytes per launch)" if len(t_q) == 2 else None,
                               algorithmic_bytes=int(alg), avg_launch_ms=round(ms_q, 4),
                               per_ray=dict(samples=round(s_all / R, 2), cells_per_sample=round(cells / max(s_all, 1), 2),
                                            candidates_per_sample=round(cand / max(s_all, 1), 2)))
