@@ -10,9 +10,8 @@
 //
 // Tiling (wave64): 256-thread workgroup = 2x2 waves; each wave owns TM x TN MFMA tiles of 32x32.
 //   <2,2>: 128x128 block tile (N >= 128)      <2,1>: 128x64 block tile (N <= 64)
-// BK = 32.  A and W tiles are staged through LDS as [row][36] with the k-values of a row de-interleaved (evens, then
-// odds) so every MFMA fragment is read with ds_read_b128; the next tile's global loads are issued into registers
-// before the current tile's MFMAs (register double buffering).
+// BK = 32.  Every MFMA fragment is one ds_read_b128 (see the K-assignment note below); the A tile is staged through
+// registers one tile ahead, the W tile goes global -> LDS by DMA (global_load_lds_dwordx4).
 // Weights are pre-packed once per checkpoint into a zero-padded [N_pad][K_pad] image, so the W loads
 // are unguarded 16-B loads; A rows are guarded (zero-filled) for m >= M and k >= K.
 #include <stdlib.h>
@@ -24,12 +23,15 @@ namespace hnr {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BK = 32;
-constexpr int LDS_LD = BK + 4;     // 36 floats = 144 B rows: 16-B aligned, and 9*row mod 16 spreads ds_read_b128 over all banks
+constexpr int LDS_LD = BK + 4;     // A rows: 36 floats = 144 B (16-B aligned; 9*row mod 16 spreads ds_read_b128 over all banks)
 
-// LDS tile layout.  Row r of a tile holds its 32 k-values DE-INTERLEAVED: position p < 16 holds k = 2p, position
-// 16 + p holds k = 2p + 1.  The 32x32x2 MFMA takes k = 0 from lanes 0-31 and k = 1 from lanes 32-63, so lane-half h
-// needs k = 2j + h at step j = position 16h + j: sixteen CONSECUTIVE floats -> four ds_read_b128 per 32-row block per
-// tile (instead of sixteen ds_read_b32), and a partial last tile only costs ceil(k_valid / 2) MFMA steps.
+// K-assignment of the 32x32x2 MFMA inside a 32-wide K tile: the instruction takes k = 0 from lanes 0-31 and k = 1 from
+// lanes 32-63; any pairing of k values works as long as A and W agree, so in quarter q (8 k values) lane-half h reads
+// the 16-B chunk 2q+h of its row ONCE (ds_read_b128) and feeds its 4 floats to 4 consecutive MFMAs.
+//   A tile: staged through registers (rows clamped, K tail masked), stored as [row][36] in natural k order;
+//   W tile: copied global -> LDS by the DMA path (global_load_lds_dwordx4, no VGPRs, no ds_write); the LDS image must be
+//           lane-linear, so rows are [32] un-padded and the 16-B chunks of a row are XOR-swizzled by (row & 7) through the
+//           per-lane SOURCE address; the fragment read applies the same XOR (2-way conflict instead of 8-way).
 template <int TM, int TN, int ACT, int DBG = 0, int WN = 2>   // ACT: 0 none, 1 LeakyReLU(slope); DBG: ablation switches (probe only)
 __global__ __launch_bounds__(128 * WN, 2) void linear_f32_kernel(const float *__restrict__ A, int lda,
                                                          const float *__restrict__ Wp, int K_pad,
@@ -38,12 +40,14 @@ __global__ __launch_bounds__(128 * WN, 2) void linear_f32_kernel(const float *__
 {
     // workgroup = 2 x WN waves; each wave owns TM x TN MFMA tiles of 32x32
     constexpr int NT = 128 * WN;                // threads
-    constexpr int RPP = NT / 8;                 // tile rows covered by one pass of the loader (8 float4 per 32-float row)
+    constexpr int NW = NT / 64;                 // waves
+    constexpr int RPP = NT / 8;                 // tile rows covered by one pass of the A loader (8 float4 per 32-float row)
     constexpr int BM = 64 * TM, BN = 32 * TN * WN;
     constexpr int A_F4 = BM * BK / 4 / NT;      // float4 per thread for the A tile
-    constexpr int W_F4 = BN * BK / 4 / NT;
+    constexpr int W_DMA = (BN / 8) / NW;        // 1-KiB DMA pieces (8 rows x 128 B) per wave for the W tile
+    static_assert((BN / 8) % NW == 0, "W tile must split evenly over the waves");
     __shared__ __attribute__((aligned(16))) float As[2 * BM * LDS_LD];     // double-buffered: one barrier per K tile
-    __shared__ __attribute__((aligned(16))) float Ws[2 * BN * LDS_LD];
+    __shared__ __attribute__((aligned(16))) float Ws[2 * BN * BK];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave / WN, wc = wave % WN;
@@ -59,12 +63,12 @@ __global__ __launch_bounds__(128 * WN, 2) void linear_f32_kernel(const float *__
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // Staging registers.  A loads are UNCONDITIONAL (row and column clamped into the buffer) and masked afterwards with
+    // A staging registers.  Loads are UNCONDITIONAL (row and column clamped into the buffer) and masked afterwards with
     // selects, so no branch consumes a loaded value early: the loads stay in flight across the tile's MFMAs.
-    float4 ra[A_F4], rw[W_F4];
+    float4 ra[A_F4];
     const int c4 = (tid & 7) << 2;
     const int trow = tid >> 3;                  // row of this thread's first float4 inside a tile (+RPP per extra float4)
-    auto load_tiles = [&](int mt, int k0) {
+    auto load_a = [&](int mt, int k0) {
         const int gk = k0 + c4;
         const int gk_safe = gk + 4 <= lda ? gk : lda - 4;
 #pragma unroll
@@ -72,9 +76,6 @@ __global__ __launch_bounds__(128 * WN, 2) void linear_f32_kernel(const float *__
             const int gm = mt * BM + trow + RPP * i;
             ra[i] = *reinterpret_cast<const float4 *>(A + (size_t)(gm < M ? gm : M - 1) * lda + gk_safe);
         }
-#pragma unroll
-        for (int i = 0; i < W_F4; ++i)
-            rw[i] = *reinterpret_cast<const float4 *>(Wp + (size_t)(n0 + trow + RPP * i) * K_pad + gk);
     };
     auto mask_k = [&](int k0) {                 // only the last K tile can hold k >= K (rows >= M are never stored)
         const int gk = k0 + c4;
@@ -86,27 +87,33 @@ __global__ __launch_bounds__(128 * WN, 2) void linear_f32_kernel(const float *__
             ra[i].w = gk + 3 < K ? ra[i].w : 0.f;
         }
     };
-    auto store_tiles = [&](int buf) {
+    auto store_a = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < A_F4; ++i) {
-            float *d = As + buf * BM * LDS_LD + (trow + RPP * i) * LDS_LD + (c4 >> 1);   // k0..k0+3 -> evens at k0/2, odds at 16 + k0/2
-            *reinterpret_cast<float2 *>(d) = make_float2(ra[i].x, ra[i].z);
-            *reinterpret_cast<float2 *>(d + 16) = make_float2(ra[i].y, ra[i].w);
-        }
+        for (int i = 0; i < A_F4; ++i)
+            *reinterpret_cast<float4 *>(As + buf * BM * LDS_LD + (trow + RPP * i) * LDS_LD + c4) = ra[i];
+    };
+    // W tile kt -> LDS buffer `buf`: piece p = wave + NW*i covers rows 8p..8p+7; lane l lands at byte 16*l of the piece,
+    // i.e. (row 8p + l/8, chunk position l%8), and fetches the global chunk (l%8) ^ (l/8) of that row.
+    const int w_src = ((lane >> 3) * K_pad) + (((lane & 7) ^ (lane >> 3)) << 2);
+    auto dma_w = [&](int buf, int kt) {
 #pragma unroll
-        for (int i = 0; i < W_F4; ++i) {
-            float *d = Ws + buf * BN * LDS_LD + (trow + RPP * i) * LDS_LD + (c4 >> 1);
-            *reinterpret_cast<float2 *>(d) = make_float2(rw[i].x, rw[i].z);
-            *reinterpret_cast<float2 *>(d + 16) = make_float2(rw[i].y, rw[i].w);
+        for (int i = 0; i < W_DMA; ++i) {
+            const int piece = wave + NW * i;
+            const float *src = Wp + (size_t)(n0 + 8 * piece) * K_pad + kt * BK + w_src;
+            float *dst = Ws + buf * BN * BK + piece * 256;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
         }
     };
-    const int frag_a = (wr * 32 * TM + (lane & 31)) * LDS_LD + 16 * (lane >> 5);
-    const int frag_w = (wc * 32 * TN + (lane & 31)) * LDS_LD + 16 * (lane >> 5);
+    const int frag_a = (wr * 32 * TM + (lane & 31)) * LDS_LD + 4 * (lane >> 5);
+    const int frag_w_row = (wc * 32 * TN + (lane & 31)) * BK;
+    const int frag_w_h = lane >> 5, frag_w_x = lane & 7;
     auto frag_load = [&](float4 (&a)[TM], float4 (&b)[TN], const float *ab, const float *wb, int qt) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const float4 *>(ab + i * 32 * LDS_LD + qt * 4);
+        for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const float4 *>(ab + i * 32 * LDS_LD + qt * 8);
+        const int pos = ((2 * qt + frag_w_h) ^ frag_w_x) << 2;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const float4 *>(wb + j * 32 * LDS_LD + qt * 4);
+        for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const float4 *>(wb + j * 32 * BK + pos);
     };
     auto mfma16 = [&](const float4 (&a)[TM], const float4 (&b)[TN]) {
 #pragma unroll
@@ -147,13 +154,13 @@ __global__ __launch_bounds__(128 * WN, 2) void linear_f32_kernel(const float *__
     // PERSISTENT over M tiles: the (M tile, K tile) pairs of this workgroup form one flat software pipeline, so the first
     // K tile of the next M tile is already in flight while the current one finishes and its results are stored.  With
     // K = 256..284 an M tile is only 8-9 K tiles long; a prologue/epilogue bubble per M tile would cost ~25 %.
-    // Pipeline per K tile t:  [regs hold tile t+1, loaded during t-1]  ds_write(t+1) -> other LDS buffer ; issue global loads
-    // (t+2) -> regs ; MFMAs of tile t ; ONE barrier.  Both the LDS stores and the global loads sit in the shadow of the MFMAs.
+    // Pipeline per K tile t:  [regs hold A(t+1), loaded during t-1]  ds_write A(t+1) + DMA W(t+1) -> other LDS buffer ; issue
+    // global loads A(t+2) -> regs ; MFMAs of tile t ; ONE barrier.  Stores, DMA and loads sit in the shadow of the MFMAs.
     int mt = blockIdx.x;
     if (mt >= n_mtiles) return;
     auto compute_full = [&](int cur) {                        // 4 software-pipelined quarters of 4 MFMA steps
         const float *ab = As + cur * BM * LDS_LD + frag_a;
-        const float *wb = Ws + cur * BN * LDS_LD + frag_w;
+        const float *wb = Ws + cur * BN * BK + frag_w_row;
         float4 a0[TM], b0[TN], a1[TM], b1[TN];
         frag_load(a0, b0, ab, wb, 0);
         frag_load(a1, b1, ab, wb, 1);
@@ -166,7 +173,7 @@ __global__ __launch_bounds__(128 * WN, 2) void linear_f32_kernel(const float *__
     };
     auto compute_partial = [&](int cur, int kvalid) {         // ceil(k_valid / 8) quarters
         const float *ab = As + cur * BM * LDS_LD + frag_a;
-        const float *wb = Ws + cur * BN * LDS_LD + frag_w;
+        const float *wb = Ws + cur * BN * BK + frag_w_row;
         const int nquart = (kvalid + 7) >> 3;
 #pragma unroll 1
         for (int qt = 0; qt < nquart; ++qt) {
@@ -179,20 +186,21 @@ __global__ __launch_bounds__(128 * WN, 2) void linear_f32_kernel(const float *__
     auto next_tile = [&](int &m, int &k) { if (++k == nk) { k = 0; m += (int)gridDim.x; } };
     const int kvalid_last = K - (nk - 1) * BK;
 
-    int pm = mt, pk = 0;                                       // (M tile, K tile) of the data currently in the staging registers
-    load_tiles(pm, 0);
+    int pm = mt, pk = 0;                                       // (M tile, K tile) of the A data currently in the staging registers
+    load_a(pm, 0);
+    dma_w(0, 0);
     if (nk == 1) mask_k(0);
-    store_tiles(0);
+    store_a(0);
     next_tile(pm, pk);
-    if (pm < n_mtiles) load_tiles(pm, pk * BK);                // tile 1 -> regs
-    __syncthreads();
+    if (pm < n_mtiles) load_a(pm, pk * BK);                    // tile 1 -> regs
+    __syncthreads();                                           // (drains the DMA: vmcnt(0) precedes the barrier)
     int it = 0;
     auto stage_next = [&](int cur) {
-        if (pm < n_mtiles) {                                      // regs hold the next tile (pm, pk): park it in the other buffer
+        if (pm < n_mtiles) {                                      // regs hold A of the next tile (pm, pk): park it in the other buffer
             if (pk + 1 == nk) mask_k(pk * BK);
-            if (DBG < 2) store_tiles(cur ^ 1);                    // that buffer was last read one iteration ago (barrier passed)
+            if (DBG < 2) { store_a(cur ^ 1); dma_w(cur ^ 1, pk); }   // that buffer was last read one iteration ago (barrier passed)
             next_tile(pm, pk);
-            if (pm < n_mtiles && DBG == 0) load_tiles(pm, pk * BK);   // tile after next -> regs, in flight during the MFMAs
+            if (pm < n_mtiles && DBG == 0) load_a(pm, pk * BK);   // tile after next -> regs, in flight during the MFMAs
         }
     };
 #pragma unroll 1
