@@ -23,15 +23,31 @@ namespace hnr {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BK = 32;
-constexpr int LDS_LD = BK + 4;     // A rows: 36 floats = 144 B (16-B aligned; 9*row mod 16 spreads ds_read_b128 over all banks)
 
 // K-assignment of the 32x32x2 MFMA inside a 32-wide K tile: the instruction takes k = 0 from lanes 0-31 and k = 1 from
 // lanes 32-63; any pairing of k values works as long as A and W agree, so in quarter q (8 k values) lane-half h reads
 // the 16-B chunk 2q+h of its row ONCE (ds_read_b128) and feeds its 4 floats to 4 consecutive MFMAs.
-//   A tile: staged through registers (rows clamped, K tail masked), stored as [row][36] in natural k order;
-//   W tile: copied global -> LDS by the DMA path (global_load_lds_dwordx4, no VGPRs, no ds_write); the LDS image must be
-//           lane-linear, so rows are [32] un-padded and the 16-B chunks of a row are XOR-swizzled by (row & 7) through the
-//           per-lane SOURCE address; the fragment read applies the same XOR (2-way conflict instead of 8-way).
+//
+// Both tiles are copied global -> LDS by the DMA path (global_load_lds_dwordx4: no VGPRs, no ds_write).  The LDS image must
+// be lane-linear, so rows are [32] un-padded and the 16-B chunks of a row are XOR-swizzled by (row & 7) through the per-lane
+// SOURCE address; the fragment read applies the same XOR (2-way conflict instead of 8-way).  W (L2-resident) runs one
+// tile ahead in 2 LDS buffers; A (streamed from HBM once) runs TWO tiles ahead in 3 LDS buffers, kept in flight across the
+// barrier by a counted `s_waitcnt vmcnt(N)` + raw `s_barrier` (a plain __syncthreads() would drain the DMA queue).
+// A partial last K tile (K % 32 != 0) is copied like the others; its k >= K values are zeroed in the fragment registers.
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// One LDS-DMA piece: 64 lanes x 16 B from per-lane global addresses to the 1 KiB at LDS byte address `lds_base`
+// (wave-uniform, goes through M0).  Written in inline asm ON PURPOSE: hipcc (ROCm 7.2) tracks a builtin LDS-DMA as a pending
+// LDS write and puts `s_waitcnt vmcnt(0)` in front of the next ds_read, which drains the copy queue every K tile; through asm
+// the copies are invisible to that pass and are ordered by the counted waits + barriers of the pipeline below.
+// (M0 is otherwise unused in this kernel: gfx950 LDS instructions do not read it.)
+__device__ __forceinline__ void lds_dma16(const float *src, unsigned lds_base)
+{
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                 :: "v"(src), "s"(__builtin_amdgcn_readfirstlane(lds_base)) : "memory");
+}
+
 template <int TM, int TN, int ACT, int DBG = 0, int WN = 2>   // ACT: 0 none, 1 LeakyReLU(slope); DBG: ablation switches (probe only)
 __global__ __launch_bounds__(128 * WN, 2) void linear_f32_kernel(const float *__restrict__ A, int lda,
                                                          const float *__restrict__ Wp, int K_pad,
@@ -41,13 +57,15 @@ __global__ __launch_bounds__(128 * WN, 2) void linear_f32_kernel(const float *__
     // workgroup = 2 x WN waves; each wave owns TM x TN MFMA tiles of 32x32
     constexpr int NT = 128 * WN;                // threads
     constexpr int NW = NT / 64;                 // waves
-    constexpr int RPP = NT / 8;                 // tile rows covered by one pass of the A loader (8 float4 per 32-float row)
     constexpr int BM = 64 * TM, BN = 32 * TN * WN;
-    constexpr int A_F4 = BM * BK / 4 / NT;      // float4 per thread for the A tile
     constexpr int W_DMA = (BN / 8) / NW;        // 1-KiB DMA pieces (8 rows x 128 B) per wave for the W tile
-    static_assert((BN / 8) % NW == 0, "W tile must split evenly over the waves");
-    __shared__ __attribute__((aligned(16))) float As[2 * BM * LDS_LD];     // double-buffered: one barrier per K tile
-    __shared__ __attribute__((aligned(16))) float Ws[2 * BN * BK];
+    constexpr int A_DMA = (BM / 8) / NW;        // ... and for the A tile
+    static_assert((BN / 8) % NW == 0 && (BM / 8) % NW == 0, "tiles must split evenly over the waves");
+    // dynamic LDS, one object (sized by the launcher: (3*BM + 2*BN) * BK floats)
+    extern __shared__ __attribute__((aligned(16))) float lds_all[];
+    float *const As = lds_all;                                             // A: two tiles ahead (3 buffers)
+    float *const Ws = lds_all + 3 * BM * BK;                               // W: one tile ahead (2 buffers)
+    const unsigned lds_a0 = (unsigned)(uintptr_t)As, lds_w0 = (unsigned)(uintptr_t)Ws;   // LDS byte addresses
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave / WN, wc = wave % WN;
@@ -63,55 +81,37 @@ __global__ __launch_bounds__(128 * WN, 2) void linear_f32_kernel(const float *__
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // A staging registers.  Loads are UNCONDITIONAL (row and column clamped into the buffer) and masked afterwards with
-    // selects, so no branch consumes a loaded value early: the loads stay in flight across the tile's MFMAs.
-    float4 ra[A_F4];
-    const int c4 = (tid & 7) << 2;
-    const int trow = tid >> 3;                  // row of this thread's first float4 inside a tile (+RPP per extra float4)
-    auto load_a = [&](int mt, int k0) {
-        const int gk = k0 + c4;
-        const int gk_safe = gk + 4 <= lda ? gk : lda - 4;
+    // DMA: piece p = wave + NW*i covers rows 8p..8p+7 of a tile; lane l lands at byte 16*l of the piece, i.e. (row 8p + l/8,
+    // chunk position l%8), and fetches the global chunk (l%8) ^ (l/8) of that row.
+    const int swz = ((lane & 7) ^ (lane >> 3)) << 2;
+    // rows past M are clamped to the last row (never stored); chunks past lda (partial last K tile) are clamped into the
+    // row -- their values are zeroed in the fragment registers by compute_partial, they never enter a product
+    auto dma_a = [&](int buf, int mt, int kt) {
+        int kk = kt * BK + swz;
+        kk = kk + 4 <= lda ? kk : lda - 4;
 #pragma unroll
-        for (int i = 0; i < A_F4; ++i) {
-            const int gm = mt * BM + trow + RPP * i;
-            ra[i] = *reinterpret_cast<const float4 *>(A + (size_t)(gm < M ? gm : M - 1) * lda + gk_safe);
+        for (int i = 0; i < A_DMA; ++i) {
+            const int piece = wave + NW * i;
+            const int gm = mt * BM + 8 * piece + (lane >> 3);
+            const float *src = A + (size_t)(gm < M ? gm : M - 1) * lda + kk;
+            lds_dma16(src, lds_a0 + (unsigned)((buf * BM * BK + piece * 256) * 4));
         }
     };
-    auto mask_k = [&](int k0) {                 // only the last K tile can hold k >= K (rows >= M are never stored)
-        const int gk = k0 + c4;
-#pragma unroll
-        for (int i = 0; i < A_F4; ++i) {
-            ra[i].x = gk < K ? ra[i].x : 0.f;
-            ra[i].y = gk + 1 < K ? ra[i].y : 0.f;
-            ra[i].z = gk + 2 < K ? ra[i].z : 0.f;
-            ra[i].w = gk + 3 < K ? ra[i].w : 0.f;
-        }
-    };
-    auto store_a = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < A_F4; ++i)
-            *reinterpret_cast<float4 *>(As + buf * BM * LDS_LD + (trow + RPP * i) * LDS_LD + c4) = ra[i];
-    };
-    // W tile kt -> LDS buffer `buf`: piece p = wave + NW*i covers rows 8p..8p+7; lane l lands at byte 16*l of the piece,
-    // i.e. (row 8p + l/8, chunk position l%8), and fetches the global chunk (l%8) ^ (l/8) of that row.
-    const int w_src = ((lane >> 3) * K_pad) + (((lane & 7) ^ (lane >> 3)) << 2);
     auto dma_w = [&](int buf, int kt) {
 #pragma unroll
         for (int i = 0; i < W_DMA; ++i) {
             const int piece = wave + NW * i;
-            const float *src = Wp + (size_t)(n0 + 8 * piece) * K_pad + kt * BK + w_src;
-            float *dst = Ws + buf * BN * BK + piece * 256;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+            const float *src = Wp + (size_t)(n0 + 8 * piece + (lane >> 3)) * K_pad + kt * BK + swz;
+            lds_dma16(src, lds_w0 + (unsigned)((buf * BN * BK + piece * 256) * 4));
         }
     };
-    const int frag_a = (wr * 32 * TM + (lane & 31)) * LDS_LD + 4 * (lane >> 5);
-    const int frag_w_row = (wc * 32 * TN + (lane & 31)) * BK;
-    const int frag_w_h = lane >> 5, frag_w_x = lane & 7;
+    const int frag_a = (wr * 32 * TM + (lane & 31)) * BK;
+    const int frag_w = (wc * 32 * TN + (lane & 31)) * BK;
+    const int frag_h = lane >> 5, frag_x = lane & 7;
     auto frag_load = [&](float4 (&a)[TM], float4 (&b)[TN], const float *ab, const float *wb, int qt) {
+        const int pos = ((2 * qt + frag_h) ^ frag_x) << 2;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const float4 *>(ab + i * 32 * LDS_LD + qt * 8);
-        const int pos = ((2 * qt + frag_w_h) ^ frag_w_x) << 2;
+        for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const float4 *>(ab + i * 32 * BK + pos);
 #pragma unroll
         for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const float4 *>(wb + j * 32 * BK + pos);
     };
@@ -150,17 +150,9 @@ __global__ __launch_bounds__(128 * WN, 2) void linear_f32_kernel(const float *__
             }
         }
     };
-
-    // PERSISTENT over M tiles: the (M tile, K tile) pairs of this workgroup form one flat software pipeline, so the first
-    // K tile of the next M tile is already in flight while the current one finishes and its results are stored.  With
-    // K = 256..284 an M tile is only 8-9 K tiles long; a prologue/epilogue bubble per M tile would cost ~25 %.
-    // Pipeline per K tile t:  [regs hold A(t+1), loaded during t-1]  ds_write A(t+1) + DMA W(t+1) -> other LDS buffer ; issue
-    // global loads A(t+2) -> regs ; MFMAs of tile t ; ONE barrier.  Stores, DMA and loads sit in the shadow of the MFMAs.
-    int mt = blockIdx.x;
-    if (mt >= n_mtiles) return;
-    auto compute_full = [&](int cur) {                        // 4 software-pipelined quarters of 4 MFMA steps
-        const float *ab = As + cur * BM * LDS_LD + frag_a;
-        const float *wb = Ws + cur * BN * BK + frag_w_row;
+    auto compute_full = [&](int abuf, int wbuf) {              // 4 software-pipelined quarters of 4 MFMA steps
+        const float *ab = As + abuf * BM * BK + frag_a;
+        const float *wb = Ws + wbuf * BN * BK + frag_w;
         float4 a0[TM], b0[TN], a1[TM], b1[TN];
         frag_load(a0, b0, ab, wb, 0);
         frag_load(a1, b1, ab, wb, 1);
@@ -171,61 +163,89 @@ __global__ __launch_bounds__(128 * WN, 2) void linear_f32_kernel(const float *__
         mfma16(a0, b0);
         mfma16(a1, b1);
     };
-    auto compute_partial = [&](int cur, int kvalid) {         // ceil(k_valid / 8) quarters
-        const float *ab = As + cur * BM * LDS_LD + frag_a;
-        const float *wb = Ws + cur * BN * BK + frag_w_row;
+    auto compute_partial = [&](int abuf, int wbuf, int kvalid) {   // ceil(k_valid / 8) quarters; A values with k >= K zeroed
+        const float *ab = As + abuf * BM * BK + frag_a;
+        const float *wb = Ws + wbuf * BN * BK + frag_w;
         const int nquart = (kvalid + 7) >> 3;
 #pragma unroll 1
         for (int qt = 0; qt < nquart; ++qt) {
             float4 a0[TM], b0[TN];
             frag_load(a0, b0, ab, wb, qt);
+            const int kb = 8 * qt + 4 * frag_h;                    // this lane's chunk holds k = kb .. kb+3 of the tile
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                a0[i].x = kb < kvalid ? a0[i].x : 0.f;
+                a0[i].y = kb + 1 < kvalid ? a0[i].y : 0.f;
+                a0[i].z = kb + 2 < kvalid ? a0[i].z : 0.f;
+                a0[i].w = kb + 3 < kvalid ? a0[i].w : 0.f;
+            }
             mfma16(a0, b0);
         }
     };
-    // flat position of "the tile after (m, k)"
-    auto next_tile = [&](int &m, int &k) { if (++k == nk) { k = 0; m += (int)gridDim.x; } };
-    const int kvalid_last = K - (nk - 1) * BK;
 
-    int pm = mt, pk = 0;                                       // (M tile, K tile) of the A data currently in the staging registers
-    load_a(pm, 0);
+    // PERSISTENT over M tiles: the (M tile, K tile) pairs of this workgroup form one flat software pipeline f = 0, 1, 2, ...
+    //   iteration f:  [partial A(f+1) parked from registers, if any]  DMA W(f+1) ; DMA A(f+2) (or its register loads) ;
+    //                 MFMAs of tile f ; [epilogue] ; s_waitcnt vmcnt(#ops issued for A(f+2)) ; s_barrier
+    // so that A(f+1) and W(f+1) have landed for everyone while A(f+2) stays in flight across the barrier.
+    const int mt0 = blockIdx.x;
+    if (mt0 >= n_mtiles) return;
+    const int kvalid_last = K - (nk - 1) * BK;
+    auto next_tile = [&](int &m, int &k) { if (++k == nk) { k = 0; m += (int)gridDim.x; } };
+    auto barrier_keep_a = [&]() {                               // the A_DMA youngest copies (tile f+2) stay in flight
+        wait_vmcnt<A_DMA>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    auto barrier_drain = [&]() {
+        wait_vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+
+    int m1 = mt0, k1 = 0;                                      // cursor: tile f+1
+    next_tile(m1, k1);
+    int m2 = m1, k2 = k1;                                      // cursor: tile f+2
+    if (m2 < n_mtiles) next_tile(m2, k2);
+    // prologue: W(0), A(0), A(1); everything lands before the first barrier
     dma_w(0, 0);
-    if (nk == 1) mask_k(0);
-    store_a(0);
-    next_tile(pm, pk);
-    if (pm < n_mtiles) load_a(pm, pk * BK);                    // tile 1 -> regs
-    __syncthreads();                                           // (drains the DMA: vmcnt(0) precedes the barrier)
-    int it = 0;
-    auto stage_next = [&](int cur) {
-        if (pm < n_mtiles) {                                      // regs hold A of the next tile (pm, pk): park it in the other buffer
-            if (pk + 1 == nk) mask_k(pk * BK);
-            if (DBG < 2) { store_a(cur ^ 1); dma_w(cur ^ 1, pk); }   // that buffer was last read one iteration ago (barrier passed)
-            next_tile(pm, pk);
-            if (pm < n_mtiles && DBG == 0) load_a(pm, pk * BK);   // tile after next -> regs, in flight during the MFMAs
+    dma_a(0, mt0, 0);
+    if (m1 < n_mtiles) dma_a(1, m1, k1);
+    barrier_drain();
+
+    int f = 0;
+    auto stage = [&]() -> bool {                                  // issue the copies for tiles f+1 (W) and f+2 (A), in that order
+        bool a_issued = false;
+        if (DBG == 0) {
+            if (m1 < n_mtiles) dma_w((f + 1) & 1, k1);                // buffer last read in iteration f-1 (barrier passed)
+            if (m2 < n_mtiles) { dma_a((f + 2) % 3, m2, k2); a_issued = true; }   // buffer (f+2)%3 = (f-1)%3: same argument
         }
+        return a_issued;
+    };
+    auto advance = [&]() {
+        m1 = m2; k1 = k2;
+        if (m2 < n_mtiles) next_tile(m2, k2);
+        ++f;
     };
 #pragma unroll 1
-    for (; mt < n_mtiles; mt += gridDim.x) {
+    for (int mt = mt0; mt < n_mtiles; mt += gridDim.x) {
 #pragma unroll 1
-        for (int kt = 0; kt + 1 < nk; ++kt, ++it) {              // full tiles
-            const int cur = it & 1;
-            stage_next(cur);
-            // keep the stores/prefetch ABOVE the MFMAs: without this fence hipcc sinks the global loads below the last MFMA
-            // and waits for them at once (vmcnt(0)), exposing the whole HBM/L2 latency every tile
+        for (int kt = 0; kt + 1 < nk; ++kt) {                     // full tiles
+            const bool a_issued = stage();
+            __builtin_amdgcn_sched_barrier(0);                    // keep the DMA issue ABOVE the MFMAs
+            compute_full(f % 3, f & 1);
             __builtin_amdgcn_sched_barrier(0);
-            compute_full(cur);
-            __builtin_amdgcn_sched_barrier(0);
-            __syncthreads();
+            advance();
+            if (a_issued) barrier_keep_a(); else barrier_drain();
         }
         {                                                         // last K tile of this M tile, then its results
-            const int cur = it & 1;
-            stage_next(cur);
+            stage();
             __builtin_amdgcn_sched_barrier(0);
-            if (kvalid_last >= 25) compute_full(cur);
-            else compute_partial(cur, kvalid_last);
+            if (kvalid_last == BK) compute_full(f % 3, f & 1);
+            else compute_partial(f % 3, f & 1, kvalid_last);     // also zeroes the k >= K values of the copied tile
             __builtin_amdgcn_sched_barrier(0);
-            epilogue(mt);
-            __syncthreads();
-            ++it;
+            epilogue(mt);                                         // its stores are younger than the DMA: drain here
+            advance();
+            barrier_drain();
         }
     }
 }
@@ -298,26 +318,26 @@ extern "C" int hnr_linear_f32(const float *d_A, int lda, const float *d_Wp, cons
         if (gx < 1) gx = 1;
         if (gx > n_mtiles) gx = n_mtiles;
         dim3 grid(gx, ny);
-        if (act) linear_f32_kernel<2, 2, 1, 0, 4><<<grid, 512, 0, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope);
-        else linear_f32_kernel<2, 2, 0, 0, 4><<<grid, 512, 0, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope);
+        if (act) linear_f32_kernel<2, 2, 1, 0, 4><<<grid, 512, 114688, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope);
+        else linear_f32_kernel<2, 2, 0, 0, 4><<<grid, 512, 114688, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope);
     } else if (N >= 128) {
         const int ny = Np / 128;
         int gx = (2 * n_cu) / ny;
         if (gx < 1) gx = 1;
         if (gx > n_mtiles) gx = n_mtiles;
         dim3 grid(gx, ny);
-        if (dbg == 1) linear_f32_kernel<2, 2, 1, 1><<<grid, 256, 0, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope);
-        else if (dbg == 2) linear_f32_kernel<2, 2, 1, 2><<<grid, 256, 0, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope);
-        else if (act) linear_f32_kernel<2, 2, 1><<<grid, 256, 0, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope);
-        else linear_f32_kernel<2, 2, 0><<<grid, 256, 0, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope);
+        if (dbg == 1) linear_f32_kernel<2, 2, 1, 1><<<grid, 256, 81920, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope);
+        else if (dbg == 2) linear_f32_kernel<2, 2, 1, 2><<<grid, 256, 81920, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope);
+        else if (act) linear_f32_kernel<2, 2, 1><<<grid, 256, 81920, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope);
+        else linear_f32_kernel<2, 2, 0><<<grid, 256, 81920, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope);
     } else {
         const int ny = Np / 64;
         int gx = (2 * n_cu) / ny;
         if (gx < 1) gx = 1;
         if (gx > n_mtiles) gx = n_mtiles;
         dim3 grid(gx, ny);
-        if (act) linear_f32_kernel<2, 1, 1><<<grid, 256, 0, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope);
-        else linear_f32_kernel<2, 1, 0><<<grid, 256, 0, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope);
+        if (act) linear_f32_kernel<2, 1, 1><<<grid, 256, 65536, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope);
+        else linear_f32_kernel<2, 1, 0><<<grid, 256, 65536, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope);
     }
     HNR_LAUNCH_CHECK();
     return HNR_OK;
