@@ -55,8 +55,10 @@ SIGNATURES = {
     "hnr_linear_packed_dims": (_I, [_I, _I, ctypes.POINTER(_I), ctypes.POINTER(_I)]),
     "hnr_linear_pack": (_I, [_P, _P, _I, _I, _P, _P, _P]),
     "hnr_linear_f32": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
+    "hnr_linear_f32_gather_add": (_I, [_P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P]),
     "hnr_sample_plan": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _P, _P, _P]),
-    "hnr_gather_rows": (_I, [_P] * 5 + [_I] + [_P] * 9 + [_I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P]),
+    "hnr_gather_rows": (_I, [_P] * 5 + [_I] + [_P] * 9 + [_I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P]),
+    "hnr_point_rows": (_I, [_P, _I, _I, _P, _I, _P]),
     "hnr_gather_points": (_I, [_P, ctypes.c_int64] + [_P] * 5 + [_I] + [_P] * 9 + [_P]),
     "hnr_ksum": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P, _P]),
     "hnr_image_features_scratch_elems": (ctypes.c_int64, [_I, _I, _I]),

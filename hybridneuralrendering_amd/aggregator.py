@@ -120,6 +120,9 @@ class PointAggregator(nn.Module):
         f32 = lambda t: t.detach().to(torch.float32).contiguous()
         pk = dict(
             b1=[lin(self.block1, 0), lin(self.block1, 2)], b3=[lin(self.block3, 0), lin(self.block3, 2)],
+            # block1.0 split by input columns: [emb32 | PE(emb) 192] depend on the point only, [PE(dists) 60] on the pair
+            b1_point=PackedLinear(self.block1[0].weight[:, :224].contiguous(), None),
+            b1_dist=PackedLinear(self.block1[0].weight[:, 224:].contiguous(), self.block1[0].bias),
             cf=[lin(self.color_feature_branch, i) for i in (0, 2, 4)],
             mw=[lin(self.aux_merge_weight_block, i) for i in (0, 2, 4)],
             mx=[lin(self.color_mixup_block, i) for i in (0, 2, 4)],
@@ -132,6 +135,18 @@ class PointAggregator(nn.Module):
         )
         self._packed, self._packed_key = pk, key
         return pk
+
+    def point_table(self, emb):
+        """[N,256] = [emb | PE3(emb)] @ block1.0.weight[:, :224]^T -- the point-only part of block1's first layer
+        (exact split of the dot product; the bias and the 60 distance columns are added per (sample, neighbour) row)."""
+        L = _lib.lib()
+        pk = self.packed()
+        emb = _lib.require_gpu(emb, "points_embeding", torch.float32)
+        n, F = emb.shape
+        E = torch.empty((n, 224), dtype=torch.float32, device=emb.device)
+        with torch.cuda.device(emb.device):
+            _lib.check(L.hnr_point_rows(_lib.ptr(emb), n, F, _lib.ptr(E), 224, _lib.stream()), "hnr_point_rows")
+        return pk["b1_point"](E, act=False)
 
     def image_features(self, images_nearest):
         """[1,V,H,W,3] -> channels-last feature map [V,H,W,48] (hnr_image_features); once per frame."""

@@ -105,6 +105,7 @@ struct GatherArgs {
     float *X3; int ld3;                                  // [rows, ld3]  block3 input; cols 256..262 written here
     float *wagg;                                         // [rows] normalised weight * clamp(conf)
     float *weight_out, *conf_out;                        // optional [R,SR,K] (reference outputs), may be NULL
+    int32_t *row_pid;                                    // SPLIT only: point id of every neighbour row
 };
 
 constexpr int G_SAMPLES = 32;      // valid samples per block
@@ -121,7 +122,9 @@ __device__ __forceinline__ void w2pers(const float *p, const float *campos, cons
     out[0] = __fdiv_rn(c[0], c[2]); out[1] = __fdiv_rn(c[1], c[2]); out[2] = c[2];
 }
 
-template <int F>
+// SPLIT = 1: X1 rows hold only the 60 distance-encoding columns (the point-only 224 columns of block1's input are folded
+// into a per-point table, see hnr_linear_f32_gather_add) and row_pid[row] names the point.
+template <int F, int SPLIT>
 __global__ __launch_bounds__(256) void gather_rows_kernel(GatherArgs a)
 {
     __shared__ float s_raw[G_SAMPLES * 8][G_RAW];     // per row: emb[F], dists[6]
@@ -209,21 +212,28 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(GatherArgs a)
         if (row >= 0) {
             const float w = __fdiv_rn(wraw, fmaxf(sum, 1e-8f));
             a.wagg[row] = __fmul_rn(w, confc);
+            if (SPLIT) a.row_pid[row] = a.pidx[(size_t)item * K + kk];
             if (a.weight_out) { a.weight_out[(size_t)item * K + kk] = w; a.conf_out[(size_t)item * K + kk] = confc; }
         }
         __syncthreads();
         // ---- phase 2: block-wide row assembly.  Work item = one 16-B chunk of the raw embedding, or one
         // (input, frequency) pair whose sin AND cos come from one sincosf and are stored as one 8-B pair
         // (positional_encoding interleaves [sin, cos] per (dim, freq), networks.py:182-189). ----
-        constexpr int NPAIR = 3 * F + 30;                     // 96 embedding pairs + 30 distance pairs
-        constexpr int NITEM = F / 4 + NPAIR;                  // per row
+        constexpr int NPAIR = SPLIT ? 30 : 3 * F + 30;        // (96 embedding pairs +) 30 distance pairs
+        constexpr int NITEM = SPLIT ? NPAIR : F / 4 + NPAIR;  // per row
         for (int it = tid; it < G_SAMPLES * 8 * NITEM; it += 256) {
             const int r = it / NITEM, w = it - r * NITEM;
             const int grow = s_row[r];
             if (grow < 0) continue;
             const float *raw = s_raw[r];
             float *o1 = a.X1 + (size_t)grow * a.ld1;
-            if (w < F / 4) {
+            if (SPLIT) {
+                const int d = w / 5, f = w - 5 * d;
+                const float x = __fmul_rn(raw[F + d], (float)(1 << f));
+                float sv, cv;
+                sincosf(x, &sv, &cv);
+                *reinterpret_cast<float2 *>(o1 + 2 * w) = make_float2(sv, cv);
+            } else if (w < F / 4) {
                 reinterpret_cast<float4 *>(o1)[w] = make_float4(raw[4 * w], raw[4 * w + 1], raw[4 * w + 2], raw[4 * w + 3]);
             } else {
                 const int p = w - F / 4;
@@ -249,6 +259,28 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(GatherArgs a)
             if (grow >= 0 && e < 7) a.X3[(size_t)grow * a.ld3 + 256 + e] = s_ext[r][e];
         }
         __syncthreads();
+    }
+}
+
+// Per-point half of block1's input row: E[p, 0:224] = [emb32 | PE3(emb) 192] (point_aggregators.py:931-938), one 8-lane group
+// of work items per point; E feeds one dense layer that yields the per-point addend table of hnr_linear_f32_gather_add.
+template <int F>
+__global__ __launch_bounds__(256) void point_rows_kernel(const float *__restrict__ emb, int n, float *__restrict__ E, int lde)
+{
+    constexpr int NITEM = F / 4 + 3 * F;
+    const int64_t total = (int64_t)n * NITEM;
+    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (int64_t)gridDim.x * blockDim.x) {
+        const int p = (int)(it / NITEM), w = (int)(it - (int64_t)p * NITEM);
+        const float *e = emb + (size_t)p * F;
+        float *o = E + (size_t)p * lde;
+        if (w < F / 4) {
+            reinterpret_cast<float4 *>(o)[w] = reinterpret_cast<const float4 *>(e)[w];
+        } else {
+            const int q = w - F / 4, d = q / 3, f = q - 3 * d;
+            float sv, cv;
+            sincosf(__fmul_rn(e[d], (float)(1 << f)), &sv, &cv);
+            *reinterpret_cast<float2 *>(o + F + 2 * q) = make_float2(sv, cv);
+        }
     }
 }
 
@@ -662,14 +694,15 @@ extern "C" int hnr_gather_rows(const float *d_xyz, const float *d_emb, const flo
                                const int32_t *d_vs_item, const int32_t *d_vs_off, const int32_t *d_vs_cnt,
                                const int64_t *d_counts, int SR, int K, int cap_samples,
                                float *d_X1, int ld1, float *d_X3, int ld3, float *d_wagg,
-                               float *d_weight_out, float *d_conf_out, void *stream)
+                               float *d_weight_out, float *d_conf_out, int32_t *d_row_pid, void *stream)
 {
+    const bool split = d_row_pid != nullptr;
     if (!d_xyz || !d_emb || !d_conf || !d_dir || !d_color || !d_sample_pidx || !d_sample_loc_w || !d_raydir || !d_campos ||
         !d_camrot || !d_vs_item || !d_vs_off || !d_vs_cnt || !d_counts || !d_X1 || !d_X3 || !d_wagg) {
         set_error("hnr_gather_rows: NULL argument"); return HNR_ERR_BADARG;
     }
     if (F != 32) { set_error("hnr_gather_rows: point_features_dim=%d unsupported (32 in every shipped config)", F); return HNR_ERR_BADARG; }
-    if (ld1 < 7 * F + 60 || (ld1 & 3) || ld3 < 263 || (ld3 & 3) || K <= 0 || K > HNR_MAX_K || SR <= 0) {
+    if (ld1 < (split ? 60 : 7 * F + 60) || (ld1 & 3) || ld3 < 263 || (ld3 & 3) || K <= 0 || K > HNR_MAX_K || SR <= 0) {
         set_error("hnr_gather_rows: bad leading dimensions / sizes"); return HNR_ERR_BADARG;
     }
     if (cap_samples <= 0) return HNR_OK;
@@ -681,7 +714,22 @@ extern "C" int hnr_gather_rows(const float *d_xyz, const float *d_emb, const flo
     a.SR = SR; a.K = K; a.X1 = d_X1; a.ld1 = ld1; a.X3 = d_X3; a.ld3 = ld3; a.wagg = d_wagg;
     a.weight_out = d_weight_out; a.conf_out = d_weight_out ? d_conf_out : nullptr;
     if (d_weight_out && !d_conf_out) { set_error("hnr_gather_rows: weight_out needs conf_out"); return HNR_ERR_BADARG; }
-    gather_rows_kernel<32><<<cdiv(cap_samples, G_SAMPLES), 256, 0, (hipStream_t)stream>>>(a);
+    a.row_pid = d_row_pid;
+    if (split) gather_rows_kernel<32, 1><<<cdiv(cap_samples, G_SAMPLES), 256, 0, (hipStream_t)stream>>>(a);
+    else gather_rows_kernel<32, 0><<<cdiv(cap_samples, G_SAMPLES), 256, 0, (hipStream_t)stream>>>(a);
+    HNR_LAUNCH_CHECK();
+    return HNR_OK;
+}
+
+extern "C" int hnr_point_rows(const float *d_emb, int n_points, int F, float *d_E, int lde, void *stream)
+{
+    if (n_points < 0 || F != 32 || lde < 7 * F || (lde & 3)) { set_error("hnr_point_rows: bad argument (F must be 32, lde >= 224 and a multiple of 4)"); return HNR_ERR_BADARG; }
+    if (n_points == 0) return HNR_OK;
+    if (!d_emb || !d_E) { set_error("hnr_point_rows: NULL argument"); return HNR_ERR_BADARG; }
+    const int64_t total = (int64_t)n_points * (F / 4 + 3 * F);
+    int blocks = cdiv(total, 256);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    point_rows_kernel<32><<<blocks, 256, 0, (hipStream_t)stream>>>(d_emb, n_points, d_E, lde);
     HNR_LAUNCH_CHECK();
     return HNR_OK;
 }

@@ -52,7 +52,8 @@ template <int TM, int TN, int ACT, int DBG = 0, int WN = 2>   // ACT: 0 none, 1 
 __global__ __launch_bounds__(128 * WN, 2) void linear_f32_kernel(const float *__restrict__ A, int lda,
                                                          const float *__restrict__ Wp, int K_pad,
                                                          const float *__restrict__ bias_p, float *__restrict__ C, int ldc,
-                                                         int M, int N, int K, float slope)
+                                                         int M, int N, int K, float slope,
+                                                         const float *__restrict__ R, const int32_t *__restrict__ ridx, int ldr)
 {
     // workgroup = 2 x WN waves; each wave owns TM x TN MFMA tiles of 32x32
     constexpr int NT = 128 * WN;                // threads
@@ -134,6 +135,40 @@ __global__ __launch_bounds__(128 * WN, 2) void linear_f32_kernel(const float *__
     for (int j = 0; j < TN; ++j) bias_v[j] = bias_p[n0 + wc * 32 * TN + j * 32 + (lane & 31)];
     // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     auto epilogue = [&](int mt) {
+        const int row0 = mt * BM + wr * 32 * TM + 4 * (lane >> 5);
+        if (R != nullptr) {
+            // gathered addend: fetch this lane's 16*TM row indices, then all addend values of one column block at once (the
+            // loads are independent, so they overlap instead of forming index -> value -> store chains)
+            int rid[TM][16];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int gm = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                    rid[i][r] = ridx[gm < M ? gm : M - 1];
+                }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int gn = n0 + wc * 32 * TN + j * 32 + (lane & 31);
+                const int gn_safe = gn < N ? gn : N - 1;
+                float add[TM][16];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) add[i][r] = R[(size_t)rid[i][r] * ldr + gn_safe];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int gm = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                        float v = acc[i][j][r] + bias_v[j] + add[i][r];
+                        if (ACT == 1) v = v > 0.f ? v : v * slope;
+                        if (gm < M && gn < N) C[(size_t)gm * ldc + gn] = v;
+                        acc[i][j][r] = 0.f;
+                    }
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int gn = n0 + wc * 32 * TN + j * 32 + (lane & 31);
@@ -141,7 +176,7 @@ __global__ __launch_bounds__(128 * WN, 2) void linear_f32_kernel(const float *__
             for (int i = 0; i < TM; ++i) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int gm = mt * BM + wr * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const int gm = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
                     float v = acc[i][j][r] + bias_v[j];
                     if (ACT == 1) v = v > 0.f ? v : v * slope;
                     if (gm < M && gn < N) C[(size_t)gm * ldc + gn] = v;
@@ -287,8 +322,25 @@ extern "C" int hnr_linear_pack(const float *d_W, const float *d_bias, int N, int
     return HNR_OK;
 }
 
+static int linear_launch(const float *d_A, int lda, const float *d_Wp, const float *d_bias_p, float *d_C, int ldc, int M, int N, int K,
+                         int act, float slope, const float *d_R, const int32_t *d_ridx, int ldr, void *stream);
+
 extern "C" int hnr_linear_f32(const float *d_A, int lda, const float *d_Wp, const float *d_bias_p, float *d_C, int ldc,
                               int M, int N, int K, int act, float slope, void *stream)
+{
+    return linear_launch(d_A, lda, d_Wp, d_bias_p, d_C, ldc, M, N, K, act, slope, nullptr, nullptr, 0, stream);
+}
+
+extern "C" int hnr_linear_f32_gather_add(const float *d_A, int lda, const float *d_Wp, const float *d_bias_p, const float *d_R,
+                                         const int32_t *d_ridx, int ldr, float *d_C, int ldc, int M, int N, int K, int act,
+                                         float slope, void *stream)
+{
+    if (M > 0 && (!d_R || !d_ridx || ldr < N)) { set_error("hnr_linear_f32_gather_add: bad addend arguments"); return HNR_ERR_BADARG; }
+    return linear_launch(d_A, lda, d_Wp, d_bias_p, d_C, ldc, M, N, K, act, slope, d_R, d_ridx, ldr, stream);
+}
+
+static int linear_launch(const float *d_A, int lda, const float *d_Wp, const float *d_bias_p, float *d_C, int ldc, int M, int N, int K,
+                         int act, float slope, const float *d_R, const int32_t *d_ridx, int ldr, void *stream)
 {
     if (M < 0 || N <= 0 || K <= 0 || lda < K || (lda & 3) || ldc < N || (act != 0 && act != 1)) {
         set_error("hnr_linear_f32: bad sizes (M=%d N=%d K=%d lda=%d ldc=%d act=%d; lda must be a multiple of 4 and >= K)", M, N, K, lda, ldc, act);
@@ -318,26 +370,26 @@ extern "C" int hnr_linear_f32(const float *d_A, int lda, const float *d_Wp, cons
         if (gx < 1) gx = 1;
         if (gx > n_mtiles) gx = n_mtiles;
         dim3 grid(gx, ny);
-        if (act) linear_f32_kernel<2, 2, 1, 0, 4><<<grid, 512, 114688, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope);
-        else linear_f32_kernel<2, 2, 0, 0, 4><<<grid, 512, 114688, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope);
+        if (act) linear_f32_kernel<2, 2, 1, 0, 4><<<grid, 512, 114688, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope, d_R, d_ridx, ldr);
+        else linear_f32_kernel<2, 2, 0, 0, 4><<<grid, 512, 114688, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope, d_R, d_ridx, ldr);
     } else if (N >= 128) {
         const int ny = Np / 128;
         int gx = (2 * n_cu) / ny;
         if (gx < 1) gx = 1;
         if (gx > n_mtiles) gx = n_mtiles;
         dim3 grid(gx, ny);
-        if (dbg == 1) linear_f32_kernel<2, 2, 1, 1><<<grid, 256, 81920, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope);
-        else if (dbg == 2) linear_f32_kernel<2, 2, 1, 2><<<grid, 256, 81920, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope);
-        else if (act) linear_f32_kernel<2, 2, 1><<<grid, 256, 81920, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope);
-        else linear_f32_kernel<2, 2, 0><<<grid, 256, 81920, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope);
+        if (dbg == 1) linear_f32_kernel<2, 2, 1, 1><<<grid, 256, 81920, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope, d_R, d_ridx, ldr);
+        else if (dbg == 2) linear_f32_kernel<2, 2, 1, 2><<<grid, 256, 81920, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope, d_R, d_ridx, ldr);
+        else if (act) linear_f32_kernel<2, 2, 1><<<grid, 256, 81920, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope, d_R, d_ridx, ldr);
+        else linear_f32_kernel<2, 2, 0><<<grid, 256, 81920, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope, d_R, d_ridx, ldr);
     } else {
         const int ny = Np / 64;
         int gx = (2 * n_cu) / ny;
         if (gx < 1) gx = 1;
         if (gx > n_mtiles) gx = n_mtiles;
         dim3 grid(gx, ny);
-        if (act) linear_f32_kernel<2, 1, 1><<<grid, 256, 65536, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope);
-        else linear_f32_kernel<2, 1, 0><<<grid, 256, 65536, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope);
+        if (act) linear_f32_kernel<2, 1, 1><<<grid, 256, 65536, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope, d_R, d_ridx, ldr);
+        else linear_f32_kernel<2, 1, 0><<<grid, 256, 65536, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope, d_R, d_ridx, ldr);
     }
     HNR_LAUNCH_CHECK();
     return HNR_OK;

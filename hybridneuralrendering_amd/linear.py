@@ -25,6 +25,20 @@ class PackedLinear:
             _lib.check(L.hnr_linear_pack(_lib.ptr(weight), _lib.ptr(b) if b is not None else None, self.N, self.K,
                                          _lib.ptr(self.wp), _lib.ptr(self.bp), _lib.stream()), "hnr_linear_pack")
 
+    def gather_add(self, a, R, ridx, out=None, act=False, slope=0.01, K=None):
+        """out[m] = act(a[m] W^T + b + R[ridx[m]])  (hnr_linear_f32_gather_add)."""
+        L = _lib.lib()
+        M, lda = a.shape[0], a.stride(0) if a.shape[0] > 1 else a.shape[1]
+        if out is None:
+            out = torch.empty((M, self.N), dtype=torch.float32, device=a.device)
+        ldc = out.stride(0) if M > 1 else out.shape[1]
+        with torch.cuda.device(a.device):
+            _lib.check(L.hnr_linear_f32_gather_add(ctypes.c_void_p(a.data_ptr()), int(lda), _lib.ptr(self.wp), _lib.ptr(self.bp),
+                                                   _lib.ptr(R), _lib.ptr(ridx), int(R.stride(0)), ctypes.c_void_p(out.data_ptr()),
+                                                   int(ldc), M, self.N, self.K if K is None else K, 1 if act else 0, float(slope),
+                                                   _lib.stream()), "hnr_linear_f32_gather_add")
+        return out
+
     def __call__(self, a, out=None, act=False, slope=0.01, K=None):
         """a: [M, lda] fp32 (lda % 4 == 0, lda >= K); out: optional [M, ldc] buffer (ldc >= N). Returns out."""
         L = _lib.lib()

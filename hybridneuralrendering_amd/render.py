@@ -65,6 +65,8 @@ class HybridRenderer:
         self.device = torch.device(device)
         self.querier = Q.lighting_fast_querier(self.device, opt)
         self._fm_key, self._fm = None, None
+        self._pt_key, self._pt = None, None
+        self.split_block1 = True          # fold the point-only 224 columns of block1.0 into a per-point table
         self.last_counts = None
         if getattr(opt, "which_render_func", "radiance") != "radiance" or getattr(opt, "which_blend_func", "alpha") != "alpha" \
                 or getattr(opt, "which_tonemap_func", "off") != "off":
@@ -78,6 +80,15 @@ class HybridRenderer:
             self._fm = self.agg.image_features(images_nearest)
             self._fm_key = key
         return self._fm
+
+    def point_table(self, cloud):
+        """Per-point addend of block1's first layer, rebuilt when the embeddings or the weights change."""
+        key = (cloud.emb.data_ptr(), tuple(cloud.emb.shape), cloud.emb._version,
+               tuple((p.data_ptr(), p._version) for p in self.agg.block1.parameters()))
+        if key != self._pt_key:
+            self._pt = self.agg.point_table(cloud.emb)
+            self._pt_key = key
+        return self._pt
 
     # -- stage 3: gather + aggregate ----------------------------------------------------------------
     def aggregate(self, cloud, qres, raydir, campos, camrot, w2c_nearest, intrinsic_nearest, campos_nearest, featmap,
@@ -108,10 +119,14 @@ class HybridRenderer:
           with T("plan_gather"):
             _lib.check(L.hnr_sample_plan(p(work), p(pidx), p(counts), K, R * SR, p(vs_item), p(vs_off), p(vs_cnt), n_valid, n_rows,
                                          p(scratch), p(overflow), st()), "hnr_sample_plan")
-            A = _f32((n_rows, 284), dev)       # X1, later H3
+            split = self.split_block1
+            A = _f32((n_rows, 256 if split else 284), dev)       # (X1,) later H3
             B = _f32((n_rows, 256), dev)       # H1, later H4
             C = _f32((n_rows, 264), dev)       # X3 = [H2 | extras]
             wagg = _f32((n_rows,), dev)
+            Xd = _f32((n_rows, 64), dev) if split else None      # PE5(dists6), 60 columns used
+            row_pid = _i32(n_rows, dev) if split else None
+            ptab = self.point_table(cloud) if split else None
             w_out = c_out = None
             if want_weights:
                 w_out = torch.zeros((R, SR, K), dtype=torch.float32, device=dev)
@@ -119,12 +134,16 @@ class HybridRenderer:
                 c_out = cloud.conf[0].clamp(0.0001, 1.0).expand(R, SR, K).contiguous()
             _lib.check(L.hnr_gather_rows(p(cloud.xyz), p(cloud.emb), p(cloud.conf), p(cloud.dir), p(cloud.color), cloud.F,
                                          p(pidx), p(loc_w), p(raydir), p(campos), p(camrot), p(vs_item), p(vs_off), p(vs_cnt),
-                                         p(counts), SR, K, n_valid, p(A), 284, p(C), 264, p(wagg),
-                                         p(w_out) if want_weights else None, p(c_out) if want_weights else None, st()),
+                                         p(counts), SR, K, n_valid, p(Xd) if split else p(A), 64 if split else 284, p(C), 264, p(wagg),
+                                         p(w_out) if want_weights else None, p(c_out) if want_weights else None,
+                                         p(row_pid) if split else None, st()),
                        "hnr_gather_rows")
           sl = pk["slope"]
           with T("mlp_neighbour"):
-            pk["b1"][0](A, out=B, act=True, slope=sl)                       # 284 -> 256
+            if split:
+                pk["b1_dist"].gather_add(Xd, ptab, row_pid, out=B, act=True, slope=sl, K=60)   # 60 -> 256 (+ per-point addend)
+            else:
+                pk["b1"][0](A, out=B, act=True, slope=sl)                   # 284 -> 256
             pk["b1"][1](B, out=C, act=True, slope=sl)                       # 256 -> 256 into X3[:, :256]
             H3 = A[:, :256]
             pk["b3"][0](C, out=H3, act=True, slope=sl, K=263)               # 263 -> 256
@@ -134,7 +153,7 @@ class HybridRenderer:
             sigma = _f32((n_valid,), dev)
             _lib.check(L.hnr_ksum(p(B), 256, p(wagg), p(pk["alpha_w"]), p(pk["alpha_b"]), p(vs_item), p(vs_off), p(vs_cnt),
                                   p(raydir), p(counts), SR, n_valid, p(X5), 280, p(sigma), st()), "hnr_ksum")
-          del A, B, C
+          del A, B, C, Xd
           with T("mlp_colorfeat"):
             T1, T2 = _f32((n_valid, 128), dev), _f32((n_valid, 128), dev)
             pk["cf"][0](X5, out=T1, act=True, slope=sl)

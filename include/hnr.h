@@ -167,6 +167,13 @@ int hnr_linear_pack(const float *d_W, const float *d_bias /*may be NULL*/, int N
                     float *d_Wp /*[N_pad*K_pad]*/, float *d_bias_p /*[N_pad]*/, void *stream);
 int hnr_linear_f32(const float *d_A, int lda, const float *d_Wp, const float *d_bias_p, float *d_C, int ldc,
                    int M, int N, int K, int act, float slope, void *stream);
+/* Same, with a gathered per-row addend:  C[m,:] = act(A[m,:] W^T + bias + R[ridx[m], :])  (R row stride ldr >= N).
+ * Used to split block1.0 (point_aggregators.py:948): its input row is [emb | PE(emb) | PE(dists)] (:931-939) and the first
+ * 224 columns depend on the POINT only, so R = [emb | PE(emb)] W[:, :224]^T is computed once per point (hnr_point_rows +
+ * hnr_linear_f32) and each (sample, neighbour) row only multiplies its 60 distance-encoding columns. */
+int hnr_linear_f32_gather_add(const float *d_A, int lda, const float *d_Wp, const float *d_bias_p, const float *d_R,
+                              const int32_t *d_ridx, int ldr, float *d_C, int ldc, int M, int N, int K, int act, float slope,
+                              void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Stage 3b: everything of the gather / aggregate / composite path that is not a dense layer.
@@ -192,13 +199,19 @@ int hnr_sample_plan(const int32_t *d_work, const int32_t *d_sample_pidx, const i
  *   d_X3[row, 256:263]   = [color3 | dir - viewdir | dir . viewdir]            (block3 extras, :957-971)
  *   d_wagg[row]          = normalised weight * clamp(conf, 1e-4, 1)
  *   optional d_weight_out / d_conf_out [R,SR,K]: the reference's `weight` and `conf_coefficient` outputs.
- * Point buffers: xyz [N,3], emb [N,32], conf [N], dir [N,3], color [N,3]. */
+ * Point buffers: xyz [N,3], emb [N,32], conf [N], dir [N,3], color [N,3].
+ * d_row_pid != NULL selects the SPLIT layout: d_X1[row, 0:60] = PE5(dists6) only (ld1 >= 60) and d_row_pid[row] = point id;
+ * the point-only columns [emb32 | PE3(emb)] come from hnr_point_rows through hnr_linear_f32_gather_add. */
 int hnr_gather_rows(const float *d_xyz, const float *d_emb, const float *d_conf, const float *d_dir, const float *d_color,
                     int F, const int32_t *d_sample_pidx, const float *d_sample_loc_w, const float *d_raydir,
                     const float *d_campos, const float *d_camrot, const int32_t *d_vs_item, const int32_t *d_vs_off,
                     const int32_t *d_vs_cnt, const int64_t *d_counts, int SR, int K, int cap_samples,
                     float *d_X1, int ld1, float *d_X3, int ld3, float *d_wagg, float *d_weight_out, float *d_conf_out,
-                    void *stream);
+                    int32_t *d_row_pid, void *stream);
+
+/* d_E[p, 0:224] = [emb32 | PE3(emb) 192] for every point (point_aggregators.py:931-938): the point-only columns of
+ * block1's input row.  lde >= 224, multiple of 4. */
+int hnr_point_rows(const float *d_emb, int n_points, int F, float *d_E, int lde, void *stream);
 
 /* The materialised gather of NeuralPoints.forward (neural_points.py:709-720) for the drop-in 14-tuple only:
  * n_entries = R'*SR*K entries of d_sample_pidx; empty entries (-1) read point 0 (the reference clamps the index);
