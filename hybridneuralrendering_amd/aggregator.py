@@ -124,6 +124,11 @@ class PointAggregator(nn.Module):
             b1_point=PackedLinear(self.block1[0].weight[:, :224].contiguous(), None),
             b1_dist=PackedLinear(self.block1[0].weight[:, 224:].contiguous(), self.block1[0].bias),
             cf=[lin(self.color_feature_branch, i) for i in (0, 2, 4)],
+            # aux_merge_weight_block.0 split by input columns [imgfeat45 | colfeat128 | ddir3]: the colour-feature part is the
+            # same for the V views of a sample
+            mw0_cf=PackedLinear(self.aux_merge_weight_block[0].weight[:, 45:173].contiguous(), self.aux_merge_weight_block[0].bias),
+            mw0_fd=PackedLinear(torch.cat([self.aux_merge_weight_block[0].weight[:, :45],
+                                           self.aux_merge_weight_block[0].weight[:, 173:176]], dim=1).contiguous(), None),
             mw=[lin(self.aux_merge_weight_block, i) for i in (0, 2, 4)],
             mx=[lin(self.color_mixup_block, i) for i in (0, 2, 4)],
             alpha_w=f32(self.alpha_branch[0].weight).reshape(256), alpha_b=f32(self.alpha_branch[0].bias).reshape(1),

@@ -414,6 +414,7 @@ struct ProjArgs {
     int V, cap;                                         // cap = row capacity per view (rows are v*cap + s)
     float *X6; int ld6;                                 // [V*cap, ld6]
     float *vmask;                                       // [V*cap]
+    int32_t *row_sample;                                // SPLIT: [V*cap] sample index of the row (CF is then not copied)
 };
 
 __global__ __launch_bounds__(256) void proj_rows_kernel(ProjArgs a)
@@ -445,9 +446,14 @@ __global__ __launch_bounds__(256) void proj_rows_kernel(ProjArgs a)
     float *o = a.X6 + row * a.ld6;
     const float *f = a.fm + (((size_t)v * a.H + py) * a.W + px) * 48;
     if (lane < 45) o[lane] = f[lane];
-    // colour feature: 128 floats, 2 per lane
-    const float2 cf = reinterpret_cast<const float2 *>(a.CF + (size_t)s * a.ldcf)[lane];
-    o[45 + 2 * lane] = cf.x; o[45 + 2 * lane + 1] = cf.y;
+    const int dcol = a.row_sample ? 45 : 173;          // SPLIT rows are [imgfeat45 | ddir3]
+    if (!a.row_sample) {
+        // colour feature: 128 floats, 2 per lane
+        const float2 cf = reinterpret_cast<const float2 *>(a.CF + (size_t)s * a.ldcf)[lane];
+        o[45 + 2 * lane] = cf.x; o[45 + 2 * lane + 1] = cf.y;
+    } else if (lane == 63) {
+        a.row_sample[row] = s;
+    }
     if (lane < 3) {
         // delta view direction (:298-305)
         const float cx = x - a.campos[0], cy = y - a.campos[1], cz = z - a.campos[2];
@@ -456,7 +462,7 @@ __global__ __launch_bounds__(256) void proj_rows_kernel(ProjArgs a)
         const float nn = sqrtf(nx * nx + ny * ny + nz * nz) + 1e-6f;
         const float cur = (lane == 0 ? cx : lane == 1 ? cy : cz) / cn;
         const float nea = (lane == 0 ? nx : lane == 1 ? ny : nz) / nn;
-        o[173 + lane] = nea - cur;
+        o[dcol + lane] = nea - cur;
     }
     if (lane == 0) a.vmask[row] = inval ? 0.f : 1.f;
 }
@@ -792,17 +798,18 @@ extern "C" int64_t hnr_image_features_scratch_elems(int V, int H, int W)
 extern "C" int hnr_proj_rows(const float *d_sample_loc_w, const int32_t *d_vs_item, const int64_t *d_counts, const float *d_w2c,
                              const float *d_intrinsic, const float *d_campos, const float *d_campos_nearest, const float *d_featmap,
                              int V, int H, int W, const float *d_CF, int ldcf, int cap_samples, float *d_X6, int ld6,
-                             float *d_vmask, void *stream)
+                             float *d_vmask, int32_t *d_row_sample, void *stream)
 {
+    const bool split = d_row_sample != nullptr;
     if (!d_sample_loc_w || !d_vs_item || !d_counts || !d_w2c || !d_intrinsic || !d_campos || !d_campos_nearest || !d_featmap ||
-        !d_CF || !d_X6 || !d_vmask || V <= 0 || ld6 < 176 || (ld6 & 3) || ldcf < 128 || (ldcf & 1)) {
+        (!split && !d_CF) || !d_X6 || !d_vmask || V <= 0 || ld6 < (split ? 48 : 176) || (ld6 & 3) || (!split && (ldcf < 128 || (ldcf & 1)))) {
         set_error("hnr_proj_rows: bad argument"); return HNR_ERR_BADARG;
     }
     if (cap_samples <= 0) return HNR_OK;
     ProjArgs a;
     a.loc_w = d_sample_loc_w; a.vs_item = d_vs_item; a.counts = reinterpret_cast<const unsigned long long *>(d_counts);
     a.w2c = d_w2c; a.Kmat = d_intrinsic; a.campos = d_campos; a.campos_n = d_campos_nearest; a.fm = d_featmap; a.H = H; a.W = W;
-    a.CF = d_CF; a.ldcf = ldcf; a.V = V; a.cap = cap_samples; a.X6 = d_X6; a.ld6 = ld6; a.vmask = d_vmask;
+    a.CF = d_CF; a.ldcf = ldcf; a.V = V; a.cap = cap_samples; a.X6 = d_X6; a.ld6 = ld6; a.vmask = d_vmask; a.row_sample = d_row_sample;
     proj_rows_kernel<<<cdiv((int64_t)V * cap_samples * 64, 256), 256, 0, (hipStream_t)stream>>>(a);
     HNR_LAUNCH_CHECK();
     return HNR_OK;

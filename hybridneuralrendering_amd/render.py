@@ -67,6 +67,7 @@ class HybridRenderer:
         self._fm_key, self._fm = None, None
         self._pt_key, self._pt = None, None
         self.split_block1 = True          # fold the point-only 224 columns of block1.0 into a per-point table
+        self.split_merge = True           # multiply the colour-feature columns of aux_merge_weight_block.0 once per sample
         self.last_counts = None
         if getattr(opt, "which_render_func", "radiance") != "radiance" or getattr(opt, "which_blend_func", "alpha") != "alpha" \
                 or getattr(opt, "which_tonemap_func", "off") != "off":
@@ -161,20 +162,26 @@ class HybridRenderer:
             CF = pk["cf"][2](T2, out=T1, act=True, slope=sl)
           with T("proj_rows"):
             V, H, W = featmap.shape[0], featmap.shape[1], featmap.shape[2]
-            X6 = _f32((V * n_valid, 176), dev)
+            ld6 = 48 if self.split_merge else 176
+            X6 = _f32((V * n_valid, ld6), dev)
             vmask = _f32((V * n_valid,), dev)
+            row_s = _i32(V * n_valid, dev) if self.split_merge else None
             _lib.check(L.hnr_proj_rows(p(loc_w), p(vs_item), p(counts), p(w2c_nearest), p(intrinsic_nearest), p(campos),
-                                       p(campos_nearest), p(featmap), V, H, W, p(CF), 128, n_valid, p(X6), 176, p(vmask), st()),
-                       "hnr_proj_rows")
+                                       p(campos_nearest), p(featmap), V, H, W, p(CF), 128, n_valid, p(X6), ld6, p(vmask),
+                                       p(row_s) if self.split_merge else None, st()), "hnr_proj_rows")
           with T("mlp_merge"):
             M1, M2 = _f32((V * n_valid, 64), dev), _f32((V * n_valid, 64), dev)
-            pk["mw"][0](X6, out=M1, act=True, slope=sl)
+            if self.split_merge:
+                pre = pk["mw0_cf"](CF, act=False)                                     # [S,64] once per sample (bias included)
+                pk["mw0_fd"].gather_add(X6, pre, row_s, out=M1, act=True, slope=sl)   # 48 -> 64 per (view, sample) + addend
+            else:
+                pk["mw"][0](X6, out=M1, act=True, slope=sl)
             pk["mw"][1](M1, out=M2, act=True, slope=sl)
             pk["mw"][2](M2, out=M1, act=True, slope=sl)
           with T("merge"):
             X7 = _f32((n_valid, 92), dev)
             fw = None if frame_weight is None else _lib.require_gpu(frame_weight, "frame_weight", torch.float32).reshape(-1)
-            _lib.check(L.hnr_merge(p(X6), 176, p(M1), 64, p(pk["mw_last_w"]), p(pk["mw_last_b"]), p(vmask),
+            _lib.check(L.hnr_merge(p(X6), ld6, p(M1), 64, p(pk["mw_last_w"]), p(pk["mw_last_b"]), p(vmask),
                                    p(fw) if fw is not None else None, p(CF), 128, p(counts), V, n_valid, p(X7), 92, st()), "hnr_merge")
           with T("mlp_mixup"):
             Y1, Y2 = _f32((n_valid, 48), dev), _f32((n_valid, 48), dev)

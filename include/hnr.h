@@ -238,11 +238,14 @@ int hnr_image_features(const float *d_img, int V, int H, int W, const float *con
 
 /* Merge-weight rows: reprojection into the V reference views (neural_points_volumetric_model.py:248-255,
  * d_w2c[v] = inverse(c2w_nearest[v]) row-major), truncation to a pixel + bounds rule (:1077-1088), feature
- * gather, delta view directions (:296-310):  d_X6[v*cap+s, 0:176] = [imgfeat45 | colfeat128 | ddir3], d_vmask. */
+ * gather, delta view directions (:296-310):  d_X6[v*cap+s, 0:176] = [imgfeat45 | colfeat128 | ddir3], d_vmask.
+ * d_row_sample != NULL selects the SPLIT layout: rows are [imgfeat45 | ddir3] (ld6 >= 48), d_row_sample[row] = s and the
+ * colour feature is not copied -- its 128 columns of aux_merge_weight_block.0 are shared by the V views of a sample, so they
+ * are multiplied once per sample and added per row by hnr_linear_f32_gather_add. */
 int hnr_proj_rows(const float *d_sample_loc_w, const int32_t *d_vs_item, const int64_t *d_counts, const float *d_w2c,
                   const float *d_intrinsic, const float *d_campos, const float *d_campos_nearest, const float *d_featmap,
                   int V, int H, int W, const float *d_CF, int ldcf, int cap_samples, float *d_X6, int ld6, float *d_vmask,
-                  void *stream);
+                  int32_t *d_row_sample, void *stream);
 
 /* Last layer + sigmoid of aux_merge_weight_block, weighted merge (:1199-1217) and the mix-up input (:1286-1292):
  *   d_X7[s, 0:90] = [colfeat[:45] | sum_v w_v f_v / (sum_v w_v + 1e-6)].  d_frame_w: optional [V]. */
