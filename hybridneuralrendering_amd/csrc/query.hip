@@ -267,56 +267,56 @@ __global__ __launch_bounds__(256) void knn2_kernel(GridView g, const int32_t *__
         const int item = work[w];
         const float cx = loc[3 * (size_t)item], cy = loc[3 * (size_t)item + 1], cz = loc[3 * (size_t)item + 2];
         const int fx = cell_coord(cx, g.ox, g.cx), fy = cell_coord(cy, g.oy, g.cy), fz = cell_coord(cz, g.oz, g.cz);
-        // ---- pass 1 ----
+        // ---- pass 1 (three x-planes of 9 cells: 9 brick records in flight at a time keeps the VGPR count, hence the
+        // number of resident waves, reasonable) ----
         uint32_t occ = 0;
+#pragma unroll 1
+        for (int xp = 0; xp < 3; ++xp) {
 #pragma unroll
-        for (int c = 0; c < 27; ++c) {
-            const int x = c / 9 - 1, y = (c / 3) % 3 - 1, z = c % 3 - 1;
-            const int vx = fx + x, vy = fy + y, vz = fz + z;
-            const bool inb = in_bounds(g, vx, vy, vz);
-            const int qx = inb ? vx : fx, qy = inb ? vy : fy, qz = inb ? vz : fz;     // clamp: the load is unconditional
-            const uint4 rec = g.occ_rec[brick_word(g, qx, qy, qz)];
-            const unsigned long long bb = (unsigned long long)rec.x | ((unsigned long long)rec.y << 32);
-            const int b = brick_bit(qx, qy, qz);
-            const bool o = inb && ((bb >> b) & 1ull);
-            occ |= (o ? 1u : 0u) << c;
-            s_slot[c][threadIdx.x] = rec.z + (uint32_t)__popcll(bb & ((1ull << b) - 1ull));
+            for (int yz = 0; yz < 9; ++yz) {
+                const int c = xp * 9 + yz;
+                const int x = xp - 1, y = yz / 3 - 1, z = yz % 3 - 1;
+                const int vx = fx + x, vy = fy + y, vz = fz + z;
+                const bool inb = in_bounds(g, vx, vy, vz);
+                const int qx = inb ? vx : fx, qy = inb ? vy : fy, qz = inb ? vz : fz;     // clamp: the load is unconditional
+                const uint4 rec = g.occ_rec[brick_word(g, qx, qy, qz)];
+                const unsigned long long bb = (unsigned long long)rec.x | ((unsigned long long)rec.y << 32);
+                const int b = brick_bit(qx, qy, qz);
+                const bool o = inb && ((bb >> b) & 1ull);
+                occ |= (o ? 1u : 0u) << c;
+                s_slot[c][threadIdx.x] = rec.z + (uint32_t)__popcll(bb & ((1ull << b) - 1ull));
+            }
         }
-        // ---- pass 2 ----
+        // ---- pass 2: one flat candidate stream per lane.  Every loop trip either tests ONE candidate or steps to the next
+        // occupied cell, so lanes with many small cells and lanes with few large cells stay busy together (nested per-cell
+        // loops ran at ~20 % lane utilisation: each trip waited for the longest list in the wave). ----
         KBuf<K> kb;
         kb.init();
-        for (int layer = 0; layer < layers && layer < 2; ++layer) {
-            uint32_t m = layer == 0 ? (occ & (1u << 13)) : (occ & ~(1u << 13));   // shell 0 = the sample's own cell
-            int2 rg_next = make_int2(0, 0);
-            if (m) rg_next = g.cell_rng[s_slot[__ffs((int)m) - 1][threadIdx.x]];
-            while (m) {
-                m &= m - 1;
-                const int2 rg = rg_next;
-                if (m) rg_next = g.cell_rng[s_slot[__ffs((int)m) - 1][threadIdx.x]];   // request the next cell early
-                ++n_cells;
-                n_cand += (unsigned)rg.y;
-                int j = 0;
-                for (; j + 1 < rg.y; j += 2) {
-                    const float4 p0 = g.pts[rg.x + j], p1 = g.pts[rg.x + j + 1];
-                    {
-                        const float xv = __fsub_rn(p0.x, cx), yv = __fsub_rn(p0.y, cy), zv = __fsub_rn(p0.z, cz);
-                        const float v = __fadd_rn(__fadd_rn(__fmul_rn(xv, xv), __fmul_rn(yv, yv)), __fmul_rn(zv, zv));
-                        if (radius2 == 0.f || v <= radius2) kb.offer(v, __float_as_int(p0.w));
-                    }
-                    {
-                        const float xv = __fsub_rn(p1.x, cx), yv = __fsub_rn(p1.y, cy), zv = __fsub_rn(p1.z, cz);
-                        const float v = __fadd_rn(__fadd_rn(__fmul_rn(xv, xv), __fmul_rn(yv, yv)), __fmul_rn(zv, zv));
-                        if (radius2 == 0.f || v <= radius2) kb.offer(v, __float_as_int(p1.w));
-                    }
+        int layer = 0;
+        uint32_t m = occ & (1u << 13);                         // shell 0 = the sample's own cell
+        int start = 0, cnt = 0, j = 0;
+        bool done = false;
+        while (!done) {
+            if (j < cnt) {
+                const float4 p0 = g.pts[start + j];
+                ++j;
+                const float xv = __fsub_rn(p0.x, cx), yv = __fsub_rn(p0.y, cy), zv = __fsub_rn(p0.z, cz);
+                const float v = __fadd_rn(__fadd_rn(__fmul_rn(xv, xv), __fmul_rn(yv, yv)), __fmul_rn(zv, zv));
+                if (radius2 == 0.f || v <= radius2) kb.offer(v, __float_as_int(p0.w));
+            } else {
+                if (m == 0) {                                   // shell finished (reference: `if (kid >= K) break;` after a layer)
+                    if (layer == 0 && layers > 1 && kb.kid < K) { layer = 1; m = occ & ~(1u << 13); }
+                    else done = true;
                 }
-                if (j < rg.y) {
-                    const float4 p0 = g.pts[rg.x + j];
-                    const float xv = __fsub_rn(p0.x, cx), yv = __fsub_rn(p0.y, cy), zv = __fsub_rn(p0.z, cz);
-                    const float v = __fadd_rn(__fadd_rn(__fmul_rn(xv, xv), __fmul_rn(yv, yv)), __fmul_rn(zv, zv));
-                    if (radius2 == 0.f || v <= radius2) kb.offer(v, __float_as_int(p0.w));
+                if (!done && m) {
+                    const int c = __ffs((int)m) - 1;
+                    m &= m - 1;
+                    const int2 rg = g.cell_rng[s_slot[c][threadIdx.x]];
+                    start = rg.x; cnt = rg.y; j = 0;
+                    ++n_cells;
+                    n_cand += (unsigned)rg.y;
                 }
             }
-            if (kb.kid >= K) break;
         }
         {   // every kept sample gets its K ids (-1 where empty): the march kernel pads only the unused slots
             int32_t *o = pidx + (size_t)item * K;
