@@ -139,7 +139,8 @@ def aggregate(g, sample_loc, sample_loc_w, sample_ray_dirs, sd, loc_i_n, delta_v
     # linear kernel (:825-833) + normalisation (:1500-1501)
     weight = mask * (1. / torch.clamp(torch.norm(dists[..., :3], dim=-1), min=1e-6))
     weight = weight / torch.clamp(torch.sum(weight, dim=-1, keepdim=True), min=1e-8)
-    conf_c = torch.clamp(g["sampled_conf"][..., 0], min=0.0001, max=1)          # gradiant_clamp forward value (:1422-1424)
+    sc0 = g["sampled_conf"][..., 0]                                              # gradiant_clamp (:1422-1424): clamp forward,
+    conf_c = sc0 - (sc0 - torch.clamp(sc0, min=0.0001, max=1)).detach()          # identity backward
     w_agg = (weight * conf_c).view(B * R * SR, K, 1)
 
     pm = mask.view(-1)
@@ -233,7 +234,7 @@ def ray_march(rd, ray_valid, feats, bg_color):
 
 
 def render(xyz, emb, conf, pdir, color, sd, q, campos, camrotc2w, raydir_all, bg_color, c2w_nearest, campos_nearest,
-           intrinsic_nearest, images_nearest, vsize, raydist_mode_unit=1):
+           intrinsic_nearest, images_nearest, vsize, raydist_mode_unit=1, is_train=False, drop_ray_rows=None):
     """NeuralPointsRayMarching.forward (:257-391) after the query, + fill_invalid (:87-126).
 
     q: dict(sample_pidx [R',SR,K], sample_loc_w [R',SR,3], ray_mask [R]) numpy or tensors (the query 7-tuple core).
@@ -245,7 +246,7 @@ def render(xyz, emb, conf, pdir, color, sd, q, campos, camrotc2w, raydir_all, bg
     dirs = torch.masked_select(raydir_all, ray_mask[..., None] > 0).reshape(1, -1, 3)[..., None, :].expand(-1, -1, SR, -1).contiguous()
     g = gather_points(xyz, emb, conf, pdir, color, pidx, camrotc2w, campos)
     loc_i, dvd = project_nearest(loc_w, campos, c2w_nearest, campos_nearest, intrinsic_nearest)
-    a = aggregate(g, sample_loc, loc_w, dirs, sd, loc_i, dvd, images_nearest)
+    a = aggregate(g, sample_loc, loc_w, dirs, sd, loc_i, dvd, images_nearest, is_train=is_train, drop_ray_rows=drop_ray_rows)
     rd = ray_dist(sample_loc, a["ray_valid"], vsize[2], raydist_mode_unit)
     m = ray_march(rd, a["ray_valid"], a["decoded"], bg_color)
     out = dict(coarse_raycolor=m["ray_color"], coarse_point_opacity=m["opacity"], coarse_is_background=m["background_transmission"],
@@ -263,3 +264,47 @@ def render(xyz, emb, conf, pdir, color, sd, q, campos, camrotc2w, raydir_all, bg
     opa[inds[..., 0], inds[..., 1], :] = out["coarse_point_opacity"]
     out.update(full_coarse_raycolor=col, full_coarse_is_background=isbg, full_coarse_mask=1 - isbg, full_coarse_point_opacity=opa)
     return out
+
+
+
+def drop_patch_rays(patch_size, patch_num, drop_ratio):
+    """point_aggregators.py:14-23: ray rows (of the patch_num*patch_size square batch) whose image feature is dropped."""
+    flag = np.zeros((patch_size * patch_num, patch_size * patch_num))
+    n = int(patch_num * patch_num * drop_ratio)
+    row, col = n // patch_num, n % patch_num
+    flag[0:row * patch_size, :] = 1
+    flag[row * patch_size:row * patch_size + patch_size, 0:col * patch_size] = 1
+    return np.where(flag.flatten() == 1)[0]
+
+
+def shipped_loss(full_raycolor, ray_mask, conf_coefficient, gt, zero_epsilon, w_color=1.0, w_zero_one=1e-4):
+    """The two loss terms the shipped ScanNet scripts enable (dev_scripts/w_scannet_etf/scene241.sh:146-151):
+    `ray_masked_coarse_raycolor` MSE (models/base_rendering_model.py:1113-1118) and the zero-one regulariser on
+    conf_coefficient (:1228-1240).  Returns (total, color, zero_one)."""
+    m3 = (ray_mask > 0)[..., None].expand(-1, -1, 3)
+    mo = torch.masked_select(full_raycolor, m3).reshape(1, -1, 3)
+    mg = torch.masked_select(gt, m3).reshape(1, -1, 3)
+    lc = F.mse_loss(mo, mg)
+    val = torch.clamp(conf_coefficient, zero_epsilon, 1 - zero_epsilon)
+    lz = torch.mean(torch.log(val) + torch.log(1 - val))
+    return lc * w_color + lz * w_zero_one, lc, lz
+
+
+def train_step(xyz, emb, conf, pdir, color, sd, q, campos, camrotc2w, raydir_all, bg_color, c2w_nearest, campos_nearest,
+               intrinsic_nearest, images_nearest, vsize, gt, zero_epsilon, drop_ray_rows, raydist_mode_unit=1):
+    """Forward in train mode + autograd of shipped_loss.  Returns (outputs, loss triple, grads dict) with grads keyed
+    `neural_points.points_*` and `aggregator.<param>` like the reference's named parameters."""
+    leaves = dict(emb=emb.clone().requires_grad_(True), conf=conf.clone().requires_grad_(True),
+                  pdir=pdir.clone().requires_grad_(True), color=color.clone().requires_grad_(True))
+    sdl = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    out = render(xyz, leaves["emb"], leaves["conf"], leaves["pdir"], leaves["color"], sdl, q, campos, camrotc2w, raydir_all,
+                 bg_color, c2w_nearest, campos_nearest, intrinsic_nearest, images_nearest, vsize, raydist_mode_unit,
+                 is_train=True, drop_ray_rows=drop_ray_rows)
+    loss, lc, lz = shipped_loss(out["full_coarse_raycolor"], out["ray_mask"], out["conf_coefficient"], gt, zero_epsilon)
+    loss.backward()
+    grads = {"neural_points.points_embeding": leaves["emb"].grad, "neural_points.points_conf": leaves["conf"].grad,
+             "neural_points.points_dir": leaves["pdir"].grad, "neural_points.points_color": leaves["color"].grad}
+    for k, v in sdl.items():
+        if v.grad is not None:
+            grads["aggregator." + k] = v.grad
+    return out, (loss.item(), lc.item(), lz.item()), grads

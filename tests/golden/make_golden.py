@@ -7,6 +7,8 @@ What is pinned by the reference itself (runs on CPU with torch):
                            (models/neural_points/query_point_indices_worldcoords.py:46-77)
   * tmid.npz            <- near_far_linear_ray_generation (models/rendering/diff_ray_marching.py:349-392)
   * posenc.npz          <- positional_encoding (models/helpers/networks.py:175-189)
+  * train_*.npz         <- the same forward in train mode (jittered depths, patch drop) + torch autograd of the
+                           shipped loss terms: gradients w.r.t. every aggregator parameter and the point buffers
   * render_*.npz        <- NeuralPointsRayMarching.forward (models/neural_points_volumetric_model.py:257-427)
                            = NeuralPoints gather + PointAggregator + ray_march, + fill_invalid (:87-126)
 The reference's query kernels cannot run here (pycuda/nvcc), so inside render_* the 7-tuple of
@@ -115,11 +117,15 @@ def make_oracle_querier(ref):
             near_depth, far_depth = np.asarray(near_depth).item(), np.asarray(far_depth).item()
             hp = self._ref.get_hyperparameters(self.opt.vsize, point_xyz_w_tensor, ranges=self.opt.ranges)
             radius_limit_np, _, ranges_np, _, _, scaled_vsize_np, scaled_vdim_np = hp[:7]
+            # same call as :87 (torch.rand jitter at train time; the drawn depths are kept as a fixture input)
             raypos, _, _, ts = ref.drm.near_far_linear_ray_generation(cam_pos_tensor, ray_dirs_tensor, self.opt.z_depth_dim,
-                                                                     near=near_depth, far=far_depth, jitter=0.)
+                                                                     near=near_depth, far=far_depth,
+                                                                     jitter=0.3 if self.opt.is_train > 0 else 0.)
+            OracleQuerier.last_ts = ts[0].numpy()
             g = qo.OracleGrid(point_xyz_w_tensor[0].detach().numpy(), ranges_np[:3], scaled_vsize_np, scaled_vdim_np,
                               self.opt.query_size, self.opt.P, self.opt.max_o)
-            res = g.query(cam_pos_tensor[0].numpy(), ray_dirs_tensor[0].numpy(), ts[0, 0].numpy(), self.opt.SR, self.opt.K,
+            res = g.query(cam_pos_tensor[0].numpy(), ray_dirs_tensor[0].numpy(),
+                          ts[0].numpy() if self.opt.is_train > 0 else ts[0, 0].numpy(), self.opt.SR, self.opt.K,
                           np.float32(radius_limit_np ** 2), self.opt.kernel_size)
             sample_pidx_tensor = torch.from_numpy(res["sample_pidx"])[None]
             sample_loc_w_tensor = torch.from_numpy(res["sample_loc_w"])[None]
@@ -215,6 +221,108 @@ def gen_render(ref, tag, scene_name, n_points, seed, w, h, n_rays, opt_over=None
     return net, inputs, out
 
 
+def gen_train(ref, tag, scene_name, n_points, seed, w, h, patch, opt_over=None, margin=2, size=None):
+    """One training step of the reference on CPU (forward in train mode + autograd): the C3 fixture.
+
+    Loss = the two terms the shipped ScanNet scripts switch on (dev_scripts/w_scannet_etf/scene241.sh:146-151):
+    MSE over rays with ray_mask>0 (`ray_masked_coarse_raycolor`, models/base_rendering_model.py:1113-1118) and
+    1e-4 * mean(log v + log(1-v)), v = clamp(conf_coefficient, eps, 1-eps) (:1228-1240)."""
+    torch.manual_seed(seed)
+    sc = scenes.make_scene(scene_name, n_points, seed, w=w, h=h, size=size)
+    opt = sc.opt
+    for k, v in (opt_over or {}).items():
+        setattr(opt, k, v)
+    opt.is_train = 1
+    opt.checkpoints_dir, opt.name, opt.resume_iter = "/nonexistent", "golden", "latest"
+    ref.npts.lighting_fast_querier_w = make_oracle_querier(ref)
+    ckpt = {"neural_points.xyz": torch.from_numpy(sc.xyz), "neural_points.points_embeding": torch.from_numpy(sc.emb),
+            "neural_points.points_conf": torch.from_numpy(sc.conf), "neural_points.points_dir": torch.from_numpy(sc.dir),
+            "neural_points.points_color": torch.from_numpy(sc.color)}
+    with tempfile.NamedTemporaryFile(suffix=".pth", delete=False) as f:
+        torch.save(ckpt, f.name)
+        ckpt_path = f.name
+    dev = torch.device("cpu")
+    neural_points = ref.npts.NeuralPoints(opt.point_features_dim, n_points, opt, dev, checkpoint=ckpt_path,
+                                          feature_init_method="rand", reg_weight=0.)
+    os.unlink(ckpt_path)
+    aggregator = ref.agg.PointAggregator(opt)
+    with torch.no_grad():
+        aggregator.alpha_branch[0].weight.mul_(30.0)
+        aggregator.alpha_branch[0].bias.fill_(30.0)
+    net = ref.vol.NeuralPointsRayMarching(
+        tonemap_func=ref.drf.find_tone_map(opt.which_tonemap_func), render_func=ref.drf.find_render_function(opt.which_render_func),
+        blend_func=ref.drf.find_blend_function(opt.which_blend_func), aggregator=aggregator, is_compute_depth=False,
+        neural_points=neural_points, opt=opt, num_pos_freqs=opt.num_pos_freqs, num_viewdir_freqs=opt.num_viewdir_freqs)
+    net.train()
+    rng = np.random.default_rng(seed + 7)
+    # a patch x patch block of pixels (random_sample='random' picks a random window, data/scannet_ft_dataset.py:899-912)
+    x0 = int(rng.integers(margin, sc.w - margin - patch + 1))
+    y0 = int(rng.integers(margin, sc.h - margin - patch + 1))
+    px, py = np.meshgrid(np.arange(x0, x0 + patch), np.arange(y0, y0 + patch), indexing="ij")
+    pix = np.stack([px, py], axis=-1).reshape(-1, 2).astype(np.int32)
+    raydir = scenes.camera_rays(pix, sc.intrinsic, sc.c2w)
+    gt = rng.uniform(0, 1, size=(1, pix.shape[0], 3)).astype(np.float32)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    inputs = dict(
+        campos=t(sc.c2w[:3, 3])[None], raydir=t(raydir)[None], bg_color=t(sc.bg_color)[None],
+        camrotc2w=t(sc.c2w[:3, :3])[None], pixel_idx=t(pix.astype(np.float32))[None],
+        near=torch.tensor([[[sc.near]]]), far=torch.tensor([[[sc.far]]]), h=torch.tensor([sc.h]), w=torch.tensor([sc.w]),
+        intrinsic=t(sc.intrinsic)[None], c2w=t(sc.c2w)[None], c2w_nearest=t(sc.c2w_nearest)[None],
+        images_nearest=t(sc.images_nearest)[None], campos_nearest=t(sc.c2w_nearest[:, :3, 3])[None],
+        intrinsic_nearest=t(sc.intrinsic)[None], vid_angle_nearest=torch.zeros(1, 4), frame_weight_nearest=torch.ones(1, 4))
+    out = net(**inputs)
+    Q = ref.npts.lighting_fast_querier_w
+    q, ts = Q.last, Q.last_ts
+    # fill_invalid (:87-126) through the reference method, as run_network_models does (:84-86)
+    shell = SimpleNamespace(input={}, opt=opt, tonemap_func=ref.drf.find_tone_map(opt.which_tonemap_func))
+    out_full = ref.vol.NeuralPointsVolumetricModel.fill_invalid(shell, dict(out), inputs)
+    # losses (restated from the shell, see the docstring)
+    mask3 = (out["ray_mask"] > 0)[..., None].expand(-1, -1, 3)
+    mo = torch.masked_select(out_full["coarse_raycolor"], mask3).reshape(1, -1, 3)
+    mg = torch.masked_select(t(gt), mask3).reshape(1, -1, 3)
+    loss_color = torch.nn.functional.mse_loss(mo, mg)
+    eps = float(getattr(opt, "zero_epsilon", 1e-3))
+    val = torch.clamp(out["conf_coefficient"], eps, 1 - eps)
+    loss_zo = torch.mean(torch.log(val) + torch.log(1 - val))
+    loss = loss_color * 1.0 + loss_zo * 1e-4
+    loss.backward()
+    save = dict(
+        scene=np.array([scene_name, str(n_points), str(seed), str(w), str(h), json.dumps(size)]),
+        opt_json=np.array(json.dumps({k: v for k, v in vars(opt).items() if isinstance(v, (int, float, str, list, tuple, type(None)))})),
+        xyz=sc.xyz, emb=sc.emb, conf=sc.conf, pdir=sc.dir, color=sc.color,
+        pix=pix, raydir=raydir, c2w=sc.c2w, c2w_nearest=sc.c2w_nearest, intrinsic=sc.intrinsic,
+        images_nearest=(sc.images_nearest * 255).round().astype(np.uint8),
+        bg_color=sc.bg_color, near_far=np.array([sc.near, sc.far], np.float64), tmid=ts.astype(np.float32), gt=gt,
+        zero_epsilon=np.float64(eps),
+        q_sample_pidx=q["sample_pidx"], q_sample_loc_w=q["sample_loc_w"], q_ray_mask=q["ray_mask"],
+        coarse_raycolor=out["coarse_raycolor"].detach().numpy(), conf_coefficient=out["conf_coefficient"].detach().numpy(),
+        full_coarse_raycolor=out_full["coarse_raycolor"].detach().numpy(),
+        loss=np.array([loss.item(), loss_color.item(), loss_zo.item()], np.float64),
+    )
+    # same seed and scene as render_<tag>.npz: the weights are that fixture's `sd.*` entries (checked, not stored twice)
+    twin = np.load(os.path.join(HERE, "render_%s.npz" % tag))
+    for k, v in aggregator.state_dict().items():
+        assert np.array_equal(twin["sd." + k], v.detach().numpy()), k
+    for k in ("xyz", "emb", "conf", "pdir", "color", "c2w_nearest", "images_nearest"):
+        assert np.array_equal(twin[k], save[k]), k
+        del save[k]
+    n_grad = 0
+    for k, prm in aggregator.named_parameters():
+        if prm.grad is not None:
+            save["grad.aggregator." + k] = prm.grad.numpy()
+            n_grad += 1
+    for k in ("points_embeding", "points_conf", "points_dir", "points_color"):
+        g = getattr(neural_points, k).grad
+        save["grad.neural_points." + k] = g.numpy()
+    path = os.path.join(HERE, "train_%s.npz" % tag)
+    np.savez_compressed(path, **save)
+    ge = save["grad.neural_points.points_embeding"]
+    print("%s: %d rays, %d valid, loss %.6f (color %.6f, zero-one %.4f), %d aggregator grads, |d emb| max %.3e, touched points %d, %.1f MB" % (
+        os.path.basename(path), raydir.shape[0], int(q["ray_mask"].sum()), loss.item(), loss_color.item(), loss_zo.item(), n_grad,
+        float(np.abs(ge).max()), int((np.abs(ge).sum(-1) > 0).sum()), os.path.getsize(path) / 1e6))
+    opt.is_train = 0
+
+
 def main():
     ref = import_reference()
     gen_hparams(ref)
@@ -222,6 +330,8 @@ def main():
     gen_posenc(ref)
     gen_render(ref, "scannet_small", "scene0241", 12000, 11, 64, 48, 600, opt_over=dict(agg_axis_weight=None), size=(1.0, 0.8, 0.6))
     gen_render(ref, "synth_small", "lego", 9000, 12, 40, 40, 500, opt_over=dict(agg_axis_weight=None, SR=40))
+    gen_train(ref, "scannet_small", "scene0241", 12000, 11, 64, 48, 28,
+              opt_over=dict(agg_axis_weight=None, dilation_setup="7_4_1_8"), size=(1.0, 0.8, 0.6))
 
 
 if __name__ == "__main__":

@@ -17,6 +17,21 @@ def load_render(tag):
     return d
 
 
+def load_train(tag):
+    """train_<tag>.npz shares its scene and weights with render_<tag>.npz (asserted by make_golden.py)."""
+    d = load_render(tag)
+    z = np.load(os.path.join(GOLD, "train_%s.npz" % tag), allow_pickle=False)
+    for k in ("coarse_raycolor", "conf_coefficient", "full_coarse_raycolor", "q_sample_pidx", "q_sample_loc_w", "q_ray_mask",
+              "pix", "raydir", "c2w", "intrinsic", "bg_color", "near_far", "tmid", "gt", "loss", "zero_epsilon"):
+        d[k] = z[k]
+    d["opt"] = json.loads(str(z["opt_json"]))
+    d["grad"] = {k[5:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("grad.")}
+    for k in ("coarse_point_opacity", "coarse_is_background", "queried_shading", "ray_mask", "weight", "blend_weight",
+              "decoded_features", "ray_valid", "full_coarse_point_opacity", "full_coarse_is_background", "full_coarse_mask"):
+        d.pop(k, None)
+    return d
+
+
 def torch_inputs(d, device="cpu"):
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
     c2w = d["c2w"]

@@ -9,7 +9,7 @@ import torch
 
 from oracle import render_oracle as ro
 from oracle import query_oracle as qo
-from tests.golden_io import GOLD, load_render, torch_inputs
+from tests.golden_io import GOLD, load_render, load_train, torch_inputs
 
 
 def test_hyperparameters_match_reference():
@@ -95,6 +95,44 @@ def test_query_fixture_is_reproduced_by_the_query_oracle():
     near, far = d["near_far"]
     res = g.query(d["c2w"][:3, 3], d["raydir"], qo.tmid_table(float(near), float(far), o["z_depth_dim"]), o["SR"], o["K"],
                   hp["radius2"], o["kernel_size"])
+    np.testing.assert_array_equal(res["sample_pidx"], d["q_sample_pidx"])
+    np.testing.assert_array_equal(res["sample_loc_w"], d["q_sample_loc_w"])
+    np.testing.assert_array_equal(res["ray_mask"], d["q_ray_mask"])
+
+
+def _drop_rows(opt):
+    pn, ps = int(opt["dilation_setup"].split("_")[0]), int(opt["dilation_setup"].split("_")[1])
+    return ro.drop_patch_rays(ps, pn, opt["drop_ratio"])
+
+
+def test_train_step_oracle_matches_reference_gradients():
+    """Forward in train mode (jittered depths, patch drop, straight-through conf clamp) + autograd of the shipped loss:
+    loss value and every gradient the reference produced (tests/golden/train_scannet_small.npz)."""
+    d = load_train("scannet_small")
+    ti = torch_inputs(d)
+    q = dict(sample_pidx=d["q_sample_pidx"], sample_loc_w=d["q_sample_loc_w"], ray_mask=d["q_ray_mask"])
+    assert 0 < int(d["q_ray_mask"].sum()) < d["q_ray_mask"].size          # R' != R: the valid-row indexing of the drop pattern matters
+    out, losses, grads = ro.train_step(ti["xyz"], ti["emb"], ti["conf"], ti["pdir"], ti["color"], d["sd"], q, ti["campos"],
+                                       ti["camrotc2w"], ti["raydir"], ti["bg_color"], ti["c2w_nearest"], ti["campos_nearest"],
+                                       ti["intrinsic_nearest"], ti["images_nearest"], d["opt"]["vsize"],
+                                       torch.from_numpy(d["gt"]), float(d["zero_epsilon"]), _drop_rows(d["opt"]))
+    np.testing.assert_allclose(out["coarse_raycolor"].detach().numpy(), d["coarse_raycolor"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(out["conf_coefficient"].detach().numpy(), d["conf_coefficient"], rtol=0, atol=0)
+    np.testing.assert_allclose(np.array(losses), d["loss"], rtol=1e-6)
+    assert set(grads) == set(d["grad"]), set(grads) ^ set(d["grad"])
+    for k, g in d["grad"].items():
+        ref = g.numpy()
+        scale = np.abs(ref).max()
+        assert scale > 0, k
+        np.testing.assert_allclose(grads[k].numpy(), ref, rtol=1e-4, atol=2e-5 * scale, err_msg=k)
+
+
+def test_train_fixture_query_is_reproduced_with_per_ray_depths():
+    d = load_train("scannet_small")
+    o = d["opt"]
+    hp = qo.hyperparameters(d["xyz"], o["vsize"], o["vscale"], o["kernel_size"], o["ranges"], o["radius_limit_scale"])
+    g = qo.OracleGrid(d["xyz"], hp["origin"], hp["cell"], hp["dims"], o["query_size"], o["P"], o["max_o"])
+    res = g.query(d["c2w"][:3, 3], d["raydir"], d["tmid"], o["SR"], o["K"], hp["radius2"], o["kernel_size"])
     np.testing.assert_array_equal(res["sample_pidx"], d["q_sample_pidx"])
     np.testing.assert_array_equal(res["sample_loc_w"], d["q_sample_loc_w"])
     np.testing.assert_array_equal(res["ray_mask"], d["q_ray_mask"])
