@@ -56,17 +56,33 @@ SIGNATURES = {
     "hnr_linear_pack": (_I, [_P, _P, _I, _I, _P, _P, _P]),
     "hnr_linear_f32": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "hnr_linear_f32_gather_add": (_I, [_P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P]),
+    "hnr_linear_f32_side": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _P, _I, _I, _I, _I, _I, _F, _P]),
+    "hnr_linear_wgrad_scratch_elems": (ctypes.c_int64, [_I, _I, _I]),
+    "hnr_linear_f32_wgrad": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P]),
     "hnr_sample_plan": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _P, _P, _P]),
     "hnr_gather_rows": (_I, [_P] * 5 + [_I] + [_P] * 9 + [_I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P]),
-    "hnr_point_rows": (_I, [_P, _I, _I, _P, _I, _P]),
+    "hnr_point_rows": (_I, [_P, _P, _I, _I, _P, _I, _P]),
     "hnr_gather_points": (_I, [_P, ctypes.c_int64] + [_P] * 5 + [_I] + [_P] * 9 + [_P]),
     "hnr_ksum": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P, _P]),
     "hnr_image_features_scratch_elems": (ctypes.c_int64, [_I, _I, _I]),
     "hnr_image_features": (_I, [_P, _I, _I, _I, ctypes.POINTER(_P), ctypes.POINTER(_P), _F, _P, _P, _P]),
     "hnr_proj_rows": (_I, [_P] * 8 + [_I, _I, _I, _P, _I, _I, _P, _I, _P, _P, _P]),
-    "hnr_merge": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _P, _I, _P]),
+    "hnr_merge": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _P, _I, _P, _P, _I, _P]),
     "hnr_final_color": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P]),
     "hnr_composite": (_I, [_P] * 8 + [_I, _I, _I, _F, _I, _P, _P, _P, _P, _P]),
+    # backward
+    "hnr_composite_bwd": (_I, [_P] * 8 + [_I, _I, _I, _F, _I, _P, _P, _P]),
+    "hnr_final_color_bwd": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _I, _P, _I, _P, _P, _P, _P]),
+    "hnr_merge_bwd": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _I, _F, _P, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P]),
+    "hnr_proj_rows_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P]),
+    "hnr_image_features_bwd": (_I, [_P, _I, _I, _I, ctypes.POINTER(_P), _F, _P, _P, ctypes.POINTER(_P), ctypes.POINTER(_P), _P]),
+    "hnr_ksum_bwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _F, _P, _I, _P, _P, _P, _P]),
+    "hnr_gather_rows_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "hnr_unique_points": (_I, [_P, ctypes.c_int64, _I, _P, _P, _I, _P, _P, _P, _P]),
+    "hnr_scatter_add_rows": (_I, [_P, _I, _P, ctypes.c_int64, _I, _P, _I, _P]),
+    "hnr_point_rows_bwd": (_I, [_P, _I, _P, _I, _P, _I, _I, _P, _P]),
+    "hnr_dleaky": (_I, [_P, _I, _P, _I, ctypes.c_int64, _I, _F, _P]),
+    "hnr_sum_views": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P]),
 }
 
 _lib = None

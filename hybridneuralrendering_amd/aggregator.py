@@ -141,17 +141,22 @@ class PointAggregator(nn.Module):
         self._packed, self._packed_key = pk, key
         return pk
 
-    def point_table(self, emb):
+    def point_table(self, emb, ids=None, n_ids=None, want_rows=False):
         """[N,256] = [emb | PE3(emb)] @ block1.0.weight[:, :224]^T -- the point-only part of block1's first layer
-        (exact split of the dot product; the bias and the 60 distance columns are added per (sample, neighbour) row)."""
+        (exact split of the dot product; the bias and the 60 distance columns are added per (sample, neighbour) row).
+        ids: int32 list of point ids -> only those rows (training: the points a batch touches)."""
         L = _lib.lib()
         pk = self.packed()
         emb = _lib.require_gpu(emb, "points_embeding", torch.float32)
         n, F = emb.shape
+        if ids is not None:
+            n = int(n_ids)
         E = torch.empty((n, 224), dtype=torch.float32, device=emb.device)
         with torch.cuda.device(emb.device):
-            _lib.check(L.hnr_point_rows(_lib.ptr(emb), n, F, _lib.ptr(E), 224, _lib.stream()), "hnr_point_rows")
-        return pk["b1_point"](E, act=False)
+            _lib.check(L.hnr_point_rows(_lib.ptr(emb), _lib.ptr(ids) if ids is not None else None, n, F, _lib.ptr(E), 224,
+                                        _lib.stream()), "hnr_point_rows")
+        T = pk["b1_point"](E, act=False)
+        return (T, E) if want_rows else T
 
     def image_features(self, images_nearest):
         """[1,V,H,W,3] -> channels-last feature map [V,H,W,48] (hnr_image_features); once per frame."""

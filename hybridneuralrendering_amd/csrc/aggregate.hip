@@ -265,13 +265,14 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(GatherArgs a)
 // Per-point half of block1's input row: E[p, 0:224] = [emb32 | PE3(emb) 192] (point_aggregators.py:931-938), one 8-lane group
 // of work items per point; E feeds one dense layer that yields the per-point addend table of hnr_linear_f32_gather_add.
 template <int F>
-__global__ __launch_bounds__(256) void point_rows_kernel(const float *__restrict__ emb, int n, float *__restrict__ E, int lde)
+__global__ __launch_bounds__(256) void point_rows_kernel(const float *__restrict__ emb, const int32_t *__restrict__ ids, int n,
+                                                         float *__restrict__ E, int lde)
 {
     constexpr int NITEM = F / 4 + 3 * F;
     const int64_t total = (int64_t)n * NITEM;
     for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (int64_t)gridDim.x * blockDim.x) {
         const int p = (int)(it / NITEM), w = (int)(it - (int64_t)p * NITEM);
-        const float *e = emb + (size_t)p * F;
+        const float *e = emb + (size_t)(ids ? ids[p] : p) * F;      // ids: rows for a list of points (train: the touched ones)
         float *o = E + (size_t)p * lde;
         if (w < F / 4) {
             reinterpret_cast<float4 *>(o)[w] = reinterpret_cast<const float4 *>(e)[w];
@@ -477,6 +478,7 @@ struct MergeArgs {
     const unsigned long long *counts;
     int V, cap;
     float *X7; int ld7;                                  // [S_v, ld7]: colfeat[:45] | merged45
+    const uint8_t *ray_drop; const int32_t *vs_item; int SR;   // train-time patch drop (:1222-1237): merged = 0 on flagged rays
 };
 
 __global__ __launch_bounds__(256) void merge_kernel(MergeArgs a)
@@ -501,7 +503,8 @@ __global__ __launch_bounds__(256) void merge_kernel(MergeArgs a)
     float *o = a.X7 + (size_t)s * a.ld7;
     if (lane < 45) {
         o[lane] = a.CF[(size_t)s * a.ldcf + lane];
-        o[45 + lane] = fsum / (wsum + 1e-6f);
+        const bool drop = a.ray_drop && a.ray_drop[a.vs_item[s] / a.SR];
+        o[45 + lane] = drop ? 0.f : fsum / (wsum + 1e-6f);
     }
 }
 
@@ -727,7 +730,7 @@ extern "C" int hnr_gather_rows(const float *d_xyz, const float *d_emb, const flo
     return HNR_OK;
 }
 
-extern "C" int hnr_point_rows(const float *d_emb, int n_points, int F, float *d_E, int lde, void *stream)
+extern "C" int hnr_point_rows(const float *d_emb, const int32_t *d_ids, int n_points, int F, float *d_E, int lde, void *stream)
 {
     if (n_points < 0 || F != 32 || lde < 7 * F || (lde & 3)) { set_error("hnr_point_rows: bad argument (F must be 32, lde >= 224 and a multiple of 4)"); return HNR_ERR_BADARG; }
     if (n_points == 0) return HNR_OK;
@@ -735,7 +738,7 @@ extern "C" int hnr_point_rows(const float *d_emb, int n_points, int F, float *d_
     const int64_t total = (int64_t)n_points * (F / 4 + 3 * F);
     int blocks = cdiv(total, 256);
     if (blocks > 256 * 16) blocks = 256 * 16;
-    point_rows_kernel<32><<<blocks, 256, 0, (hipStream_t)stream>>>(d_emb, n_points, d_E, lde);
+    point_rows_kernel<32><<<blocks, 256, 0, (hipStream_t)stream>>>(d_emb, d_ids, n_points, d_E, lde);
     HNR_LAUNCH_CHECK();
     return HNR_OK;
 }
@@ -817,16 +820,18 @@ extern "C" int hnr_proj_rows(const float *d_sample_loc_w, const int32_t *d_vs_it
 
 extern "C" int hnr_merge(const float *d_X6, int ld6, const float *d_Hm, int ldh, const float *d_w_last, const float *d_b_last,
                          const float *d_vmask, const float *d_frame_w, const float *d_CF, int ldcf, const int64_t *d_counts,
-                         int V, int cap_samples, float *d_X7, int ld7, void *stream)
+                         int V, int cap_samples, float *d_X7, int ld7, const uint8_t *d_ray_drop, const int32_t *d_vs_item, int SR,
+                         void *stream)
 {
-    if (!d_X6 || !d_Hm || !d_w_last || !d_b_last || !d_vmask || !d_CF || !d_counts || !d_X7 || ldh < 64 || ld7 < 90) {
+    if (!d_X6 || !d_Hm || !d_w_last || !d_b_last || !d_vmask || !d_CF || !d_counts || !d_X7 || ldh < 64 || ld7 < 90 ||
+        (d_ray_drop && (!d_vs_item || SR <= 0))) {
         set_error("hnr_merge: bad argument"); return HNR_ERR_BADARG;
     }
     if (cap_samples <= 0) return HNR_OK;
     MergeArgs a;
     a.X6 = d_X6; a.ld6 = ld6; a.Hm = d_Hm; a.ldh = ldh; a.w_last = d_w_last; a.b_last = d_b_last; a.vmask = d_vmask;
     a.frame_w = d_frame_w; a.CF = d_CF; a.ldcf = ldcf; a.counts = reinterpret_cast<const unsigned long long *>(d_counts);
-    a.V = V; a.cap = cap_samples; a.X7 = d_X7; a.ld7 = ld7;
+    a.V = V; a.cap = cap_samples; a.X7 = d_X7; a.ld7 = ld7; a.ray_drop = d_ray_drop; a.vs_item = d_vs_item; a.SR = SR;
     merge_kernel<<<cdiv((int64_t)cap_samples * 64, 256), 256, 0, (hipStream_t)stream>>>(a);
     HNR_LAUNCH_CHECK();
     return HNR_OK;

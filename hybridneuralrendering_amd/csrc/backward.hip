@@ -1,0 +1,811 @@
+// Backward of the gather / aggregate / composite path (everything that is not a dense layer; those are in linear.hip
+// (input gradient = another forward GEMM with the LeakyReLU derivative as its side operand) and linear_bwd.hip (weights)).
+//
+// The reference gets these from torch autograd over its eager ops; the formulas below are the analytic derivatives of the
+// forward kernels in aggregate.hip, one backward kernel per forward kernel, in the same row order:
+//   composite_bwd      <- ray_march / alpha blend         models/rendering/diff_ray_marching.py:508-557
+//   final_color_bwd    <- color_final_block + sigmoid      models/aggregators/point_aggregators.py:1294-1295, :1334, :478-482
+//   merge_bwd          <- weighted merge + last layer      :1199-1217, :1222-1237 (train-time patch drop), :1286-1292
+//   proj_rows_bwd      <- pixel gather + F.interpolate     :1064-1067, :1077-1089, :1193
+//   conv3x3_bwd_*      <- aux_block_s1..3                  :1047-1063
+//   ksum_bwd           <- alpha branch + K-weighted sums   :1005-1026, :471-476
+//   gather_rows_bwd    <- NeuralPoints gather, block3 extras, conf straight-through clamp
+//                                                          models/neural_points/neural_points.py:709-720, :957-971, :1422-1424, :1508-1512
+//   point_rows_bwd     <- positional encoding of the embedding (:931-938)
+// Gradients flow to points_embeding / points_conf / points_dir / points_color and to every aggregator weight; positions
+// (xyz, sample locations, view directions) carry no gradient (xyz_grad = 0 in every shipped script).
+#include "hnr_common.h"
+
+namespace hnr {
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------ composite
+struct CompositeBwdArgs {
+    const float *decoded, *loc_w;
+    const int32_t *pidx;
+    const int8_t *ray_mask;
+    const int32_t *nsamp;
+    const float *campos, *camrot, *bg;
+    int R, SR, K;
+    float vsize_z;
+    int unit_mode;
+    const float *g_raycolor;                             // [R,3] gradient of the (fill_invalid'ed) ray colour
+    float *g_decoded;                                    // [R,SR,4] out: (d sigma, d rgb); doubles as the per-ray scratch
+};
+
+__global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.R) return;
+    float4 *dd = reinterpret_cast<float4 *>(a.g_decoded) + (size_t)r * a.SR;
+    if (!a.ray_mask[r]) {
+        for (int s = 0; s < a.SR; ++s) dd[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    float cr[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) cr[i] = a.camrot[i];
+    const float cp[3] = {a.campos[0], a.campos[1], a.campos[2]};
+    const int ns = a.nsamp ? a.nsamp[r] : a.SR;
+    auto zc = [&](int s) {
+        const float *p = a.loc_w + ((size_t)r * a.SR + s) * 3;
+        const float q0 = s < ns ? p[0] : 0.f, q1 = s < ns ? p[1] : 0.f, q2 = s < ns ? p[2] : 0.f;
+        const float s0 = __fsub_rn(q0, cp[0]), s1 = __fsub_rn(q1, cp[1]), s2 = __fsub_rn(q2, cp[2]);
+        return __fadd_rn(__fadd_rn(__fmul_rn(cr[2], s0), __fmul_rn(cr[5], s1)), __fmul_rn(cr[8], s2));
+    };
+    // pass 1 (front to back, identical to composite_kernel): park (opacity, ray_dist * valid, T before the sample)
+    float T = 1.f;
+    float zmax = zc(0);
+    for (int s = 0; s < a.SR; ++s) {
+        float dist;
+        if (s + 1 < a.SR) {
+            const float zn = fmaxf(zmax, zc(s + 1));
+            dist = __fsub_rn(zn, zmax);
+            zmax = zn;
+        } else {
+            dist = a.vsize_z;
+        }
+        if (dist < 1e-8f || (a.unit_mode && dist > 2.f * a.vsize_z)) dist = a.vsize_z;
+        const bool valid = s < ns && a.pidx[((size_t)r * a.SR + s) * a.K] >= 0;
+        const float4 d = reinterpret_cast<const float4 *>(a.decoded)[(size_t)r * a.SR + s];
+        const float sigma = valid ? d.x : 0.f;
+        const float rd = valid ? dist : 0.f;
+        const float o = 1.f - expf(-sigma * rd);
+        dd[s] = make_float4(o, rd, T, 0.f);
+        T *= (1.f - o + 1e-10f);
+    }
+    // pass 2 (back to front).  colour = sum_s w_s rgb_s + bg T_end,  w_s = o_s T_s,  T_s = prod_{j<s} q_j,  q = 1 - o + 1e-10:
+    //   d/d o_s = T_s (rgb_s . g) - (sum_{j>s} w_j (rgb_j . g) + (bg . g) T_end) / q_s
+    const float g0 = a.g_raycolor[3 * (size_t)r], g1 = a.g_raycolor[3 * (size_t)r + 1], g2 = a.g_raycolor[3 * (size_t)r + 2];
+    float S = (a.bg[0] * g0 + a.bg[1] * g1 + a.bg[2] * g2) * T;
+    for (int s = a.SR - 1; s >= 0; --s) {
+        const float4 t = dd[s];
+        const float o = t.x, rd = t.y, Ts = t.z;
+        const float4 d = reinterpret_cast<const float4 *>(a.decoded)[(size_t)r * a.SR + s];
+        const float gs = d.y * g0 + d.z * g1 + d.w * g2;
+        const float q = 1.f - o + 1e-10f;
+        const float d_o = Ts * gs - S / q;
+        const float w = o * Ts;
+        S += gs * w;
+        const float sigma = rd > 0.f ? d.x : 0.f;
+        const float d_sigma = d_o * rd * expf(-sigma * rd);
+        dd[s] = make_float4(d_sigma, w * g0, w * g1, w * g2);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ final colour
+struct FinalBwdArgs {
+    const float *Y; int ldy;
+    const float *CF; int ldcf;
+    const float *w_fin, *b_fin;
+    const int32_t *vs_item;
+    const unsigned long long *counts;
+    const float *g_decoded;                              // [R*SR,4]
+    float *gY; int ldgy;                                 // [S, ldgy] d color_mixup_block output (45 columns)
+    float *gCF; int ldgcf;                               // [S, ldgcf] d colour feature (128 columns, OVERWRITTEN)
+    float *g_sigma;                                      // [S]
+    float *g_w_fin, *g_b_fin;                            // [3*128], [3]  accumulated with atomics
+};
+
+__global__ __launch_bounds__(256) void final_color_bwd_kernel(FinalBwdArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = (int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6);
+    const int n_waves = (int)((gridDim.x * (unsigned)blockDim.x) >> 6);
+    const int n_valid = (int)a.counts[HNR_CNT_SAMPLES_VALID];
+    float aw[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}}, ab[3] = {0.f, 0.f, 0.f};
+    for (int s = wave; s < n_valid; s += n_waves) {
+        float x[2], r[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int c = lane + 64 * h;
+            const float cf = a.CF[(size_t)s * a.ldcf + c];
+            x[h] = c < 45 ? a.Y[(size_t)s * a.ldy + c] + cf : cf;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) r[j] += x[h] * a.w_fin[j * 128 + c];
+        }
+        const float4 g = reinterpret_cast<const float4 *>(a.g_decoded)[a.vs_item[s]];
+        const float gc[3] = {g.y, g.z, g.w};
+        float dz[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            r[j] = wave_sum(r[j]);
+            const float sg = 1.f / (1.f + expf(-(r[j] + a.b_fin[j])));
+            dz[j] = gc[j] * (1.f + 2.f * 0.001f) * sg * (1.f - sg);
+            ab[j] += dz[j];
+        }
+        if (lane == 0) a.g_sigma[s] = g.x;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int c = lane + 64 * h;
+            float dx = 0.f;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { dx += dz[j] * a.w_fin[j * 128 + c]; aw[h][j] += dz[j] * x[h]; }
+            a.gCF[(size_t)s * a.ldgcf + c] = dx;
+            if (c < 45) a.gY[(size_t)s * a.ldgy + c] = dx;
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) atomicAdd(a.g_w_fin + j * 128 + lane + 64 * h, aw[h][j]);
+    if (lane == 0)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) atomicAdd(a.g_b_fin + j, ab[j]);
+}
+
+// ------------------------------------------------------------------------------------------------ merge
+struct MergeBwdArgs {
+    const float *X6; int ld6;
+    const float *Hm; int ldh;
+    const float *w_last, *b_last;
+    const float *vmask, *frame_w;
+    const unsigned long long *counts;
+    int V, cap;
+    float slope;
+    const uint8_t *ray_drop; const int32_t *vs_item; int SR;   // train-time patch drop (ray_drop may be NULL)
+    const float *gX7; int ldg7;                          // [S, ldg7] d mix-up input: [d colfeat[:45] | d merged45]
+    float *gF; int ldgf;                                 // [V*cap, ldgf] out: d image feature rows (48 columns, 45..47 = 0)
+    float *gZ3; int ldgz;                                // [V*cap, ldgz] out: d PRE-activation of the last hidden layer (64)
+    float *gCF; int ldgcf;                               // [S, ldgcf] += d colfeat[:45]
+    float *g_w_last, *g_b_last;                          // [64], [1] atomics
+};
+
+constexpr int MAXV = 8;
+
+__global__ __launch_bounds__(256) void merge_bwd_kernel(MergeBwdArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = (int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6);
+    const int n_waves = (int)((gridDim.x * (unsigned)blockDim.x) >> 6);
+    const int n_valid = (int)a.counts[HNR_CNT_SAMPLES_VALID];
+    const float wl = a.w_last[lane], bl = a.b_last[0];
+    float acc_w = 0.f, acc_b = 0.f;
+    for (int s = wave; s < n_valid; s += n_waves) {
+        float sg[MAXV], wv[MAXV], f[MAXV], hm[MAXV], scale[MAXV];
+        float fsum = 0.f, wsum = 0.f;
+#pragma unroll
+        for (int v = 0; v < MAXV; ++v) {
+            if (v >= a.V) break;
+            const size_t row = (size_t)v * a.cap + s;
+            hm[v] = a.Hm[row * a.ldh + lane];
+            const float d = wave_sum(hm[v] * wl);
+            sg[v] = 1.f / (1.f + expf(-(d + bl)));
+            scale[v] = a.vmask[row] * (a.frame_w ? a.frame_w[v] : 1.f);
+            wv[v] = sg[v] * a.vmask[row];
+            if (a.frame_w) wv[v] *= a.frame_w[v];
+            f[v] = lane < 45 ? a.X6[row * a.ld6 + lane] : 0.f;
+            fsum += f[v] * wv[v];
+            wsum += wv[v];
+        }
+        const float den = wsum + 1e-6f;
+        const float merged = fsum / den;
+        const bool drop = a.ray_drop && a.ray_drop[a.vs_item[s] / a.SR];
+        const float dm = (lane < 45 && !drop) ? a.gX7[(size_t)s * a.ldg7 + 45 + lane] : 0.f;
+#pragma unroll
+        for (int v = 0; v < MAXV; ++v) {
+            if (v >= a.V) break;
+            const size_t row = (size_t)v * a.cap + s;
+            if (lane < 48) a.gF[row * a.ldgf + lane] = dm * wv[v] / den;
+            const float d_wv = wave_sum(dm * (f[v] - merged) / den);
+            const float d_pre = d_wv * scale[v] * sg[v] * (1.f - sg[v]);
+            a.gZ3[row * a.ldgz + lane] = d_pre * wl * (hm[v] > 0.f ? 1.f : a.slope);
+            acc_w += d_pre * hm[v];
+            acc_b += d_pre;
+        }
+        if (lane < 45) a.gCF[(size_t)s * a.ldgcf + lane] += a.gX7[(size_t)s * a.ldg7 + lane];
+    }
+    atomicAdd(a.g_w_last + lane, acc_w);
+    if (lane == 0) atomicAdd(a.g_b_last, acc_b);
+}
+
+// ------------------------------------------------------------------------------------------------ pixel gather + upsample
+struct ProjBwdArgs {
+    const float *loc_w;
+    const int32_t *vs_item;
+    const unsigned long long *counts;
+    const float *w2c, *Kmat;
+    int V, H, W, cap;
+    const float *gFa; int lda;                           // [V*cap, lda] d image-feature columns (45)
+    const float *gFb; int ldb;                           // second source (d rows of the merge-weight MLP), may be NULL
+    float *g1, *g2, *g3;                                 // planar grads of the pyramid levels [V,6,H1,W1] [V,12,H2,W2] [V,24,H3,W3]
+    int H1, W1, H2, W2, H3, W3;
+};
+
+__global__ __launch_bounds__(256) void proj_rows_bwd_kernel(ProjBwdArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wv = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int n_valid = (int)a.counts[HNR_CNT_SAMPLES_VALID];
+    if (n_valid == 0) return;
+    const int v = (int)(wv / n_valid);
+    if (v >= a.V) return;
+    const int s = (int)(wv - (int64_t)v * n_valid);
+    const float *p = a.loc_w + (size_t)a.vs_item[s] * 3;
+    const float x = p[0], y = p[1], z = p[2];
+    const float *m = a.w2c + 16 * v;
+    float c[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) c[j] = x * m[4 * j] + y * m[4 * j + 1] + z * m[4 * j + 2] + m[4 * j + 3];
+    float i3[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) i3[j] = c[0] * a.Kmat[3 * j] + c[1] * a.Kmat[3 * j + 1] + c[2] * a.Kmat[3 * j + 2];
+    const float den = i3[2] + 1e-10f;
+    const float fx = i3[0] / den, fy = i3[1] / den;
+    const int px = (fx > -2.0e9f && fx < 2.0e9f) ? (int)fx : -1;
+    const int py = (fy > -2.0e9f && fy < 2.0e9f) ? (int)fy : -1;
+    if (px < 0 || px >= a.W || py < 0 || py >= a.H) return;      // masked row: reads the zeroed pixel (0,0), no gradient
+    if (px == 0 && py == 0) return;                              // feature at (0,0) is the constant 0 (:1089)
+    if (lane < 3 || lane >= 45) return;                          // RGB channels are inputs
+    const size_t row = (size_t)v * a.cap + s;
+    float g = a.gFa[row * a.lda + lane];
+    if (a.gFb) g += a.gFb[row * a.ldb + lane];
+    float *gp;
+    int Hs, Ws;
+    if (lane < 9) { Hs = a.H1; Ws = a.W1; gp = a.g1 + ((size_t)v * 6 + (lane - 3)) * Hs * Ws; }
+    else if (lane < 21) { Hs = a.H2; Ws = a.W2; gp = a.g2 + ((size_t)v * 12 + (lane - 9)) * Hs * Ws; }
+    else { Hs = a.H3; Ws = a.W3; gp = a.g3 + ((size_t)v * 24 + (lane - 21)) * Hs * Ws; }
+    // transpose of bilinear_at (aggregate.hip): same source coordinates and weights
+    const float sy = (float)Hs / (float)a.H, sx = (float)Ws / (float)a.W;
+    float qy = ((float)py + 0.5f) * sy - 0.5f, qx = ((float)px + 0.5f) * sx - 0.5f;
+    if (qy < 0.f) qy = 0.f;
+    if (qx < 0.f) qx = 0.f;
+    const int y0 = (int)qy, x0 = (int)qx;
+    const int y1 = y0 + (y0 < Hs - 1 ? 1 : 0), x1 = x0 + (x0 < Ws - 1 ? 1 : 0);
+    const float ly = qy - (float)y0, lx = qx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+    atomicAdd(gp + (size_t)y0 * Ws + x0, g * hy * hx);
+    atomicAdd(gp + (size_t)y0 * Ws + x1, g * hy * lx);
+    atomicAdd(gp + (size_t)y1 * Ws + x0, g * ly * hx);
+    atomicAdd(gp + (size_t)y1 * Ws + x1, g * ly * lx);
+}
+
+// ------------------------------------------------------------------------------------------------ 3x3 convolutions
+// g_out is the gradient w.r.t. the POST-activation output `out`; d pre-activation = g_out * (out > 0 ? 1 : slope).
+// data gradient: one lane per input element, gather form (no atomics), ACCUMULATES into g_in
+__global__ void conv3x3_bwd_data_kernel(const float *__restrict__ g_out, const float *__restrict__ out, const float *__restrict__ w,
+                                        int Cin, int Hin, int Win, int Cout, int stride, int Hout, int Wout, float slope,
+                                        float *__restrict__ g_in, int V)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)V * Cin * Hin * Win;
+    if (idx >= total) return;
+    const int ix = (int)(idx % Win), iy = (int)((idx / Win) % Hin), ci = (int)((idx / ((int64_t)Win * Hin)) % Cin),
+              v = (int)(idx / ((int64_t)Win * Hin * Cin));
+    float acc = 0.f;
+    for (int ky = 0; ky < 3; ++ky) {
+        const int ty = iy + 1 - ky;
+        if (ty < 0 || ty % stride) continue;
+        const int oy = ty / stride;
+        if (oy >= Hout) continue;
+        for (int kx = 0; kx < 3; ++kx) {
+            const int tx = ix + 1 - kx;
+            if (tx < 0 || tx % stride) continue;
+            const int ox = tx / stride;
+            if (ox >= Wout) continue;
+            for (int co = 0; co < Cout; ++co) {
+                const size_t o = (((size_t)v * Cout + co) * Hout + oy) * Wout + ox;
+                const float dz = g_out[o] * (out[o] > 0.f ? 1.f : slope);
+                acc = fmaf(dz, w[((co * Cin + ci) * 3 + ky) * 3 + kx], acc);
+            }
+        }
+    }
+    g_in[idx] += acc;
+}
+
+// weight + bias gradient: blockIdx.x = co * Cin + ci, blockIdx.y = pixel chunk; block reduction, then 9 (+1) atomics
+__global__ __launch_bounds__(256) void conv3x3_bwd_weight_kernel(const float *__restrict__ g_out, const float *__restrict__ out,
+                                                                 const float *__restrict__ in, int in_cl, int in_cstride,
+                                                                 int Cin, int Hin, int Win, int Cout, int stride, int Hout, int Wout,
+                                                                 float slope, float *__restrict__ g_w, float *__restrict__ g_b, int V)
+{
+    __shared__ float s_red[4][10];
+    const int co = blockIdx.x / Cin, ci = blockIdx.x % Cin;
+    const int64_t npix = (int64_t)V * Hout * Wout;
+    float acc[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) acc[i] = 0.f;
+    for (int64_t pix = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; pix < npix; pix += (int64_t)gridDim.y * blockDim.x) {
+        const int ox = (int)(pix % Wout), oy = (int)((pix / Wout) % Hout), v = (int)(pix / ((int64_t)Wout * Hout));
+        const size_t o = (((size_t)v * Cout + co) * Hout + oy) * Wout + ox;
+        const float dz = g_out[o] * (out[o] > 0.f ? 1.f : slope);
+        if (dz == 0.f) continue;
+        acc[9] += dz;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy * stride - 1 + ky;
+            if (iy < 0 || iy >= Hin) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = ox * stride - 1 + kx;
+                if (ix < 0 || ix >= Win) continue;
+                const float xv = in_cl ? in[(((size_t)v * Hin + iy) * Win + ix) * in_cstride + ci]
+                                       : in[(((size_t)v * Cin + ci) * Hin + iy) * Win + ix];
+                acc[ky * 3 + kx] = fmaf(dz, xv, acc[ky * 3 + kx]);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 10; ++i) acc[i] = wave_sum(acc[i]);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0)
+#pragma unroll
+        for (int i = 0; i < 10; ++i) s_red[wid][i] = acc[i];
+    __syncthreads();
+    if (threadIdx.x < 10) {
+        const float t = s_red[0][threadIdx.x] + s_red[1][threadIdx.x] + s_red[2][threadIdx.x] + s_red[3][threadIdx.x];
+        if (threadIdx.x < 9) atomicAdd(g_w + (size_t)(co * Cin + ci) * 9 + threadIdx.x, t);
+        else if (ci == 0) atomicAdd(g_b + co, t);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ K-sum + alpha branch
+struct KsumBwdArgs {
+    const float *H4; int ldh;
+    const float *wagg, *alpha_w, *alpha_b;
+    const int32_t *vs_off, *vs_cnt;
+    const unsigned long long *counts;
+    const float *gX5; int ldg5;                          // [S, ldg5] d colour-feature-branch input; columns 0..255 = d sum_k w feat_k
+    const float *g_sigma;                                // [S]
+    float slope;
+    float *gZ4; int ldgz;                                // [rows, ldgz] out: d PRE-activation of block3's last layer (256)
+    float *g_wagg;                                       // [rows] out
+    float *g_alpha_w, *g_alpha_b;                        // [256], [1] atomics
+};
+
+__global__ __launch_bounds__(256) void ksum_bwd_kernel(KsumBwdArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = (int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6);
+    const int n_waves = (int)((gridDim.x * (unsigned)blockDim.x) >> 6);
+    const int n_valid = (int)a.counts[HNR_CNT_SAMPLES_VALID];
+    const float4 aw = reinterpret_cast<const float4 *>(a.alpha_w)[lane];
+    const float ab = a.alpha_b[0];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float acc_b = 0.f;
+    for (int s = wave; s < n_valid; s += n_waves) {
+        const int off = a.vs_off[s], cnt = a.vs_cnt[s];
+        const float4 gf = reinterpret_cast<const float4 *>(a.gX5 + (size_t)s * a.ldg5)[lane];
+        const float gs = a.g_sigma[s];
+        for (int k = 0; k < cnt; ++k) {
+            const size_t row = (size_t)(off + k);
+            const float4 h = reinterpret_cast<const float4 *>(a.H4 + row * a.ldh)[lane];
+            const float w = a.wagg[row];
+            const float d = wave_sum(h.x * aw.x + h.y * aw.y + h.z * aw.z + h.w * aw.w);
+            const float yv = __fsub_rn(d + ab, 1.0f);
+            // softplus(beta = 1, threshold = 20) and its derivative (torch: z / (z + 1), z = exp(y), identity above the threshold)
+            const float ez = expf(yv);
+            const float sp = yv > 20.f ? yv : log1pf(ez);
+            const float spd = yv > 20.f ? 1.f : ez / (ez + 1.f);
+            const float da = w * gs * spd;
+            float4 o;
+            o.x = (w * gf.x + da * aw.x) * (h.x > 0.f ? 1.f : a.slope);
+            o.y = (w * gf.y + da * aw.y) * (h.y > 0.f ? 1.f : a.slope);
+            o.z = (w * gf.z + da * aw.z) * (h.z > 0.f ? 1.f : a.slope);
+            o.w = (w * gf.w + da * aw.w) * (h.w > 0.f ? 1.f : a.slope);
+            reinterpret_cast<float4 *>(a.gZ4 + row * a.ldgz)[lane] = o;
+            const float hf = wave_sum(h.x * gf.x + h.y * gf.y + h.z * gf.z + h.w * gf.w);
+            if (lane == 0) a.g_wagg[row] = sp * gs + hf;
+            acc.x += da * h.x; acc.y += da * h.y; acc.z += da * h.z; acc.w += da * h.w;
+            acc_b += da;
+        }
+    }
+    atomicAdd(a.g_alpha_w + 4 * lane, acc.x); atomicAdd(a.g_alpha_w + 4 * lane + 1, acc.y);
+    atomicAdd(a.g_alpha_w + 4 * lane + 2, acc.z); atomicAdd(a.g_alpha_w + 4 * lane + 3, acc.w);
+    if (lane == 0) atomicAdd(a.g_alpha_b, acc_b);
+}
+
+// ------------------------------------------------------------------------------------------------ gather
+struct GatherBwdArgs {
+    const int32_t *pidx;
+    const float *raydir;
+    const int32_t *vs_item, *vs_off, *vs_cnt;
+    const unsigned long long *counts;
+    int SR, K;
+    const float *gX3; int ldg3;                          // [rows, ldg3] d block3 input; columns 256..262 = d [colour3 | dir - view | dir . view]
+    const float *g_wagg;                                 // [rows] d (normalised weight * clamp(conf))
+    const float *weight;                                 // [R,SR,K] normalised weights (forward output)
+    const float *g_conf_out;                             // [R,SR,K] d conf_coefficient output, may be NULL
+    float *g_conf, *g_dir, *g_color;                     // [N], [N,3], [N,3] atomics
+};
+
+__global__ __launch_bounds__(256) void gather_rows_bwd_kernel(GatherBwdArgs a)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int n_valid = (int)a.counts[HNR_CNT_SAMPLES_VALID];
+    const int s = (int)(t / a.K), kk = (int)(t - (int64_t)s * a.K);
+    if (s >= n_valid || kk >= a.vs_cnt[s]) return;
+    const int item = a.vs_item[s];
+    const size_t row = (size_t)a.vs_off[s] + kk, e = (size_t)item * a.K + kk;
+    const int pid = a.pidx[e];
+    const int ray = item / a.SR;
+    const float *g = a.gX3 + row * a.ldg3 + 256;
+    const float gd = g[6];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        atomicAdd(a.g_color + 3 * (size_t)pid + j, g[j]);
+        atomicAdd(a.g_dir + 3 * (size_t)pid + j, g[3 + j] + gd * a.raydir[3 * (size_t)ray + j]);
+    }
+    // w_agg = w_norm * clamp_ST(conf): the clamp passes the gradient through unchanged (gradiant_clamp, :1422-1424)
+    float gc = a.g_wagg[row] * a.weight[e];
+    if (a.g_conf_out) gc += a.g_conf_out[e];
+    atomicAdd(a.g_conf + pid, gc);
+}
+
+// dst[idx[m], :] += src[m, :]  (n_cols a multiple of 4): the per-point accumulation of block1's first-layer gradient
+__global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float *__restrict__ src, int lds, const int32_t *__restrict__ idx,
+                                                               int64_t M, int n_cols, float *__restrict__ dst, int ldd)
+{
+    const int per_row = n_cols >> 2;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t m = t / per_row;
+    if (m >= M) return;
+    const int c4 = (int)(t - m * per_row);
+    const float4 v = reinterpret_cast<const float4 *>(src + (size_t)m * lds)[c4];
+    float *d = dst + (size_t)idx[m] * ldd + 4 * c4;
+    atomicAdd(d, v.x); atomicAdd(d + 1, v.y); atomicAdd(d + 2, v.z); atomicAdd(d + 3, v.w);
+}
+
+// d emb from d [emb | PE3(emb)] rows of the touched points; E holds the forward sin/cos values
+template <int F>
+__global__ __launch_bounds__(256) void point_rows_bwd_kernel(const float *__restrict__ gE, int ldg, const float *__restrict__ E, int lde,
+                                                             const int32_t *__restrict__ ids, int n, float *__restrict__ g_emb)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int u = (int)(t / F), d = (int)(t - (int64_t)u * F);
+    if (u >= n) return;
+    const float *g = gE + (size_t)u * ldg, *e = E + (size_t)u * lde;
+    float acc = g[d];
+#pragma unroll
+    for (int f = 0; f < 3; ++f) {
+        const int col = F + 2 * (3 * d + f);
+        // d sin(x 2^f) = cos(x 2^f) 2^f dx,  d cos(x 2^f) = -sin(x 2^f) 2^f dx
+        acc += (float)(1 << f) * (e[col + 1] * g[col] - e[col] * g[col + 1]);
+    }
+    const int p = ids ? ids[u] : u;
+    g_emb[(size_t)p * F + d] += acc;
+}
+
+// ------------------------------------------------------------------------------------------------ small helpers
+// g[m, n] *= (y[m, n] > 0 ? 1 : slope)
+__global__ void dleaky_kernel(float *__restrict__ g, int ldg, const float *__restrict__ y, int ldy, int64_t M, int N, float slope)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t m = t / N;
+    if (m >= M) return;
+    const int n = (int)(t - m * N);
+    if (!(y[(size_t)m * ldy + n] > 0.f)) g[(size_t)m * ldg + n] *= slope;
+}
+
+// out[s, :] = sum_v in[v * cap + s, :]
+__global__ void sum_views_kernel(const float *__restrict__ in, int ldi, int V, int cap, int n_samples, int N, float *__restrict__ out, int ldo)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t s = t / N;
+    if (s >= n_samples) return;
+    const int n = (int)(t - s * N);
+    float acc = 0.f;
+    for (int v = 0; v < V; ++v) acc += in[((size_t)v * cap + s) * ldi + n];
+    out[(size_t)s * ldo + n] = acc;
+}
+
+// Unique touched points: flags -> exclusive scan (two-level, deterministic) -> compact list + per-row compact index.
+__global__ void mark_points_kernel(const int32_t *__restrict__ row_pid, int64_t M, int32_t *__restrict__ flags)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < M) flags[row_pid[t]] = 1;
+}
+
+__global__ __launch_bounds__(1024) void flag_block_sum_kernel(const int32_t *__restrict__ flags, int n, int32_t *__restrict__ block_sums)
+{
+    __shared__ int s_a[16];
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    int v = i < n ? flags[i] : 0;
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0) s_a[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int a = 0;
+        for (int k = 0; k < 16; ++k) a += s_a[k];
+        block_sums[blockIdx.x] = a;
+    }
+}
+
+__global__ __launch_bounds__(1024) void flag_scan_kernel(int32_t *__restrict__ flags /* in: 0/1, out: compact index or -1 */, int n,
+                                                         const int32_t *__restrict__ block_sums, int32_t *__restrict__ ulist, int cap,
+                                                         int32_t *__restrict__ count)
+{
+    __shared__ int s_a[16];
+    __shared__ int s_base;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    int pa = 0;
+    for (int k = threadIdx.x; k < (int)blockIdx.x; k += 1024) pa += block_sums[k];
+    for (int o = 32; o > 0; o >>= 1) pa += __shfl_xor(pa, o);
+    if (lane == 0) s_a[wid] = pa;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int a = 0;
+        for (int k = 0; k < 16; ++k) a += s_a[k];
+        s_base = a;
+    }
+    __syncthreads();
+    const int v = i < n ? flags[i] : 0;
+    int ia = v;
+    for (int o = 1; o < 64; o <<= 1) {
+        const int ta = __shfl_up(ia, o);
+        if (lane >= o) ia += ta;
+    }
+    __syncthreads();
+    if (lane == 63) s_a[wid] = ia;
+    __syncthreads();
+    int oa = s_base + ia - v;
+    for (int k = 0; k < wid; ++k) oa += s_a[k];
+    if (i < n) {
+        flags[i] = v ? oa : -1;
+        if (v && oa < cap) ulist[oa] = i;
+        if (i == n - 1) *count = oa + v;
+    }
+}
+
+__global__ void map_rows_kernel(const int32_t *__restrict__ row_pid, int64_t M, const int32_t *__restrict__ uidx, int32_t *__restrict__ row_u)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < M) row_u[t] = uidx[row_pid[t]];
+}
+
+}  // namespace hnr
+
+using namespace hnr;
+
+static int persistent_blocks(int64_t n_waves_wanted)
+{
+    int64_t b = (n_waves_wanted + 3) / 4;
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+// ================================================================================== C ABI
+extern "C" int hnr_composite_bwd(const float *d_decoded, const float *d_sample_loc_w, const int32_t *d_sample_pidx, const int8_t *d_ray_mask,
+                                 const int32_t *d_ray_nsamp, const float *d_campos, const float *d_camrot, const float *d_bg_color,
+                                 int R, int SR, int K, float vsize_z, int raydist_mode_unit, const float *d_g_raycolor,
+                                 float *d_g_decoded, void *stream)
+{
+    if (R < 0 || SR <= 0 || K <= 0) { set_error("hnr_composite_bwd: bad sizes"); return HNR_ERR_BADARG; }
+    if (R == 0) return HNR_OK;
+    if (!d_decoded || !d_sample_loc_w || !d_sample_pidx || !d_ray_mask || !d_campos || !d_camrot || !d_bg_color || !d_g_raycolor || !d_g_decoded) {
+        set_error("hnr_composite_bwd: NULL argument"); return HNR_ERR_BADARG;
+    }
+    CompositeBwdArgs a;
+    a.decoded = d_decoded; a.loc_w = d_sample_loc_w; a.pidx = d_sample_pidx; a.ray_mask = d_ray_mask; a.nsamp = d_ray_nsamp;
+    a.campos = d_campos; a.camrot = d_camrot; a.bg = d_bg_color; a.R = R; a.SR = SR; a.K = K; a.vsize_z = vsize_z;
+    a.unit_mode = raydist_mode_unit; a.g_raycolor = d_g_raycolor; a.g_decoded = d_g_decoded;
+    composite_bwd_kernel<<<cdiv(R, 256), 256, 0, (hipStream_t)stream>>>(a);
+    HNR_LAUNCH_CHECK();
+    return HNR_OK;
+}
+
+extern "C" int hnr_final_color_bwd(const float *d_Y, int ldy, const float *d_CF, int ldcf, const float *d_w_fin, const float *d_b_fin,
+                                   const int32_t *d_vs_item, const int64_t *d_counts, int cap_samples, const float *d_g_decoded,
+                                   float *d_gY, int ldgy, float *d_gCF, int ldgcf, float *d_g_sigma, float *d_g_w_fin, float *d_g_b_fin,
+                                   void *stream)
+{
+    if (!d_Y || !d_CF || !d_w_fin || !d_b_fin || !d_vs_item || !d_counts || !d_g_decoded || !d_gY || !d_gCF || !d_g_sigma || !d_g_w_fin ||
+        !d_g_b_fin || ldy < 45 || ldcf < 128 || ldgy < 45 || ldgcf < 128) {
+        set_error("hnr_final_color_bwd: bad argument"); return HNR_ERR_BADARG;
+    }
+    if (cap_samples <= 0) return HNR_OK;
+    FinalBwdArgs a;
+    a.Y = d_Y; a.ldy = ldy; a.CF = d_CF; a.ldcf = ldcf; a.w_fin = d_w_fin; a.b_fin = d_b_fin; a.vs_item = d_vs_item;
+    a.counts = reinterpret_cast<const unsigned long long *>(d_counts); a.g_decoded = d_g_decoded; a.gY = d_gY; a.ldgy = ldgy;
+    a.gCF = d_gCF; a.ldgcf = ldgcf; a.g_sigma = d_g_sigma; a.g_w_fin = d_g_w_fin; a.g_b_fin = d_g_b_fin;
+    final_color_bwd_kernel<<<persistent_blocks(cap_samples), 256, 0, (hipStream_t)stream>>>(a);
+    HNR_LAUNCH_CHECK();
+    return HNR_OK;
+}
+
+extern "C" int hnr_merge_bwd(const float *d_X6, int ld6, const float *d_Hm, int ldh, const float *d_w_last, const float *d_b_last,
+                             const float *d_vmask, const float *d_frame_w, const int64_t *d_counts, int V, int cap_samples, float slope,
+                             const uint8_t *d_ray_drop, const int32_t *d_vs_item, int SR, const float *d_gX7, int ldg7,
+                             float *d_gF, int ldgf, float *d_gZ3, int ldgz, float *d_gCF, int ldgcf, float *d_g_w_last, float *d_g_b_last,
+                             void *stream)
+{
+    if (!d_X6 || !d_Hm || !d_w_last || !d_b_last || !d_vmask || !d_counts || !d_vs_item || !d_gX7 || !d_gF || !d_gZ3 || !d_gCF ||
+        !d_g_w_last || !d_g_b_last || V <= 0 || V > MAXV || ldh < 64 || ldg7 < 90 || ldgf < 48 || ldgz < 64 || ldgcf < 45 || SR <= 0) {
+        set_error("hnr_merge_bwd: bad argument (V <= %d)", MAXV); return HNR_ERR_BADARG;
+    }
+    if (cap_samples <= 0) return HNR_OK;
+    MergeBwdArgs a;
+    a.X6 = d_X6; a.ld6 = ld6; a.Hm = d_Hm; a.ldh = ldh; a.w_last = d_w_last; a.b_last = d_b_last; a.vmask = d_vmask; a.frame_w = d_frame_w;
+    a.counts = reinterpret_cast<const unsigned long long *>(d_counts); a.V = V; a.cap = cap_samples; a.slope = slope;
+    a.ray_drop = d_ray_drop; a.vs_item = d_vs_item; a.SR = SR; a.gX7 = d_gX7; a.ldg7 = ldg7; a.gF = d_gF; a.ldgf = ldgf;
+    a.gZ3 = d_gZ3; a.ldgz = ldgz; a.gCF = d_gCF; a.ldgcf = ldgcf; a.g_w_last = d_g_w_last; a.g_b_last = d_g_b_last;
+    merge_bwd_kernel<<<persistent_blocks(cap_samples), 256, 0, (hipStream_t)stream>>>(a);
+    HNR_LAUNCH_CHECK();
+    return HNR_OK;
+}
+
+static inline int conv_out(int n) { return (n + 2 - 3) / 2 + 1; }
+
+extern "C" int hnr_proj_rows_bwd(const float *d_sample_loc_w, const int32_t *d_vs_item, const int64_t *d_counts, const float *d_w2c,
+                                 const float *d_intrinsic, int V, int H, int W, int cap_samples, const float *d_gFa, int lda,
+                                 const float *d_gFb, int ldb, float *d_g_pyramid, void *stream)
+{
+    if (!d_sample_loc_w || !d_vs_item || !d_counts || !d_w2c || !d_intrinsic || !d_gFa || !d_g_pyramid || V <= 0 || H <= 1 || W <= 1 ||
+        lda < 45 || (d_gFb && ldb < 45)) {
+        set_error("hnr_proj_rows_bwd: bad argument"); return HNR_ERR_BADARG;
+    }
+    if (cap_samples <= 0) return HNR_OK;
+    ProjBwdArgs a;
+    a.loc_w = d_sample_loc_w; a.vs_item = d_vs_item; a.counts = reinterpret_cast<const unsigned long long *>(d_counts);
+    a.w2c = d_w2c; a.Kmat = d_intrinsic; a.V = V; a.H = H; a.W = W; a.cap = cap_samples; a.gFa = d_gFa; a.lda = lda; a.gFb = d_gFb; a.ldb = ldb;
+    a.H1 = conv_out(H); a.W1 = conv_out(W); a.H2 = conv_out(a.H1); a.W2 = conv_out(a.W1); a.H3 = conv_out(a.H2); a.W3 = conv_out(a.W2);
+    // same layout as the forward scratch of hnr_image_features: s1a s1 s2a s2 s3a s3
+    const size_t n1 = (size_t)V * 6 * a.H1 * a.W1, n2 = (size_t)V * 12 * a.H2 * a.W2, n3 = (size_t)V * 24 * a.H3 * a.W3;
+    a.g1 = d_g_pyramid + n1; a.g2 = d_g_pyramid + 2 * n1 + n2; a.g3 = d_g_pyramid + 2 * n1 + 2 * n2 + n3;
+    proj_rows_bwd_kernel<<<cdiv((int64_t)V * cap_samples * 64, 256), 256, 0, (hipStream_t)stream>>>(a);
+    HNR_LAUNCH_CHECK();
+    return HNR_OK;
+}
+
+extern "C" int hnr_image_features_bwd(const float *d_img, int V, int H, int W, const float *const *conv_w, float slope,
+                                      const float *d_scratch, float *d_g_pyramid, float *const *g_conv_w, float *const *g_conv_b,
+                                      void *stream)
+{
+    if (!d_img || !conv_w || !d_scratch || !d_g_pyramid || !g_conv_w || !g_conv_b || V <= 0 || H <= 1 || W <= 1) {
+        set_error("hnr_image_features_bwd: bad argument"); return HNR_ERR_BADARG;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int H1 = conv_out(H), W1 = conv_out(W), H2 = conv_out(H1), W2 = conv_out(W1), H3 = conv_out(H2), W3 = conv_out(W2);
+    const size_t n1 = (size_t)V * 6 * H1 * W1, n2 = (size_t)V * 12 * H2 * W2, n3 = (size_t)V * 24 * H3 * W3;
+    const float *s1a = d_scratch, *s1 = s1a + n1, *s2a = s1 + n1, *s2 = s2a + n2, *s3a = s2 + n2, *s3 = s3a + n3;
+    float *g1a = d_g_pyramid, *g1 = g1a + n1, *g2a = g1 + n1, *g2 = g2a + n2, *g3a = g2 + n2, *g3 = g3a + n3;
+    auto wgrad = [&](const float *g_out, const float *out, const float *in, int cl, int cstride, int Cin, int Hin, int Win, int Cout,
+                     int stride, int Hout, int Wout, int li) {
+        const int64_t npix = (int64_t)V * Hout * Wout;
+        int chunks = cdiv(npix, 256 * 8);
+        if (chunks > 64) chunks = 64;
+        conv3x3_bwd_weight_kernel<<<dim3(Cout * Cin, chunks), 256, 0, st>>>(g_out, out, in, cl, cstride, Cin, Hin, Win, Cout, stride, Hout,
+                                                                             Wout, slope, g_conv_w[li], g_conv_b[li], V);
+    };
+    auto dgrad = [&](const float *g_out, const float *out, int li, int Cin, int Hin, int Win, int Cout, int stride, int Hout, int Wout,
+                     float *g_in) {
+        const int64_t total = (int64_t)V * Cin * Hin * Win;
+        conv3x3_bwd_data_kernel<<<cdiv(total, 256), 256, 0, st>>>(g_out, out, conv_w[li], Cin, Hin, Win, Cout, stride, Hout, Wout, slope, g_in, V);
+    };
+    // conv5: s3a -> s3 ; conv4: s2 -> s3a (stride 2) ; conv3: s2a -> s2 ; conv2: s1 -> s2a (stride 2) ; conv1: s1a -> s1 ; conv0: img -> s1a
+    wgrad(g3, s3, s3a, 0, 0, 24, H3, W3, 24, 1, H3, W3, 5);
+    dgrad(g3, s3, 5, 24, H3, W3, 24, 1, H3, W3, g3a);
+    wgrad(g3a, s3a, s2, 0, 0, 12, H2, W2, 24, 2, H3, W3, 4);
+    dgrad(g3a, s3a, 4, 12, H2, W2, 24, 2, H3, W3, g2);
+    wgrad(g2, s2, s2a, 0, 0, 12, H2, W2, 12, 1, H2, W2, 3);
+    dgrad(g2, s2, 3, 12, H2, W2, 12, 1, H2, W2, g2a);
+    wgrad(g2a, s2a, s1, 0, 0, 6, H1, W1, 12, 2, H2, W2, 2);
+    dgrad(g2a, s2a, 2, 6, H1, W1, 12, 2, H2, W2, g1);
+    wgrad(g1, s1, s1a, 0, 0, 6, H1, W1, 6, 1, H1, W1, 1);
+    dgrad(g1, s1, 1, 6, H1, W1, 6, 1, H1, W1, g1a);
+    wgrad(g1a, s1a, d_img, 1, 3, 3, H, W, 6, 2, H1, W1, 0);
+    HNR_LAUNCH_CHECK();
+    return HNR_OK;
+}
+
+extern "C" int hnr_ksum_bwd(const float *d_H4, int ldh, const float *d_wagg, const float *d_alpha_w, const float *d_alpha_b,
+                            const int32_t *d_vs_off, const int32_t *d_vs_cnt, const int64_t *d_counts, int cap_samples,
+                            const float *d_gX5, int ldg5, const float *d_g_sigma, float slope, float *d_gZ4, int ldgz, float *d_g_wagg,
+                            float *d_g_alpha_w, float *d_g_alpha_b, void *stream)
+{
+    if (!d_H4 || !d_wagg || !d_alpha_w || !d_alpha_b || !d_vs_off || !d_vs_cnt || !d_counts || !d_gX5 || !d_g_sigma || !d_gZ4 || !d_g_wagg ||
+        !d_g_alpha_w || !d_g_alpha_b || ldh < 256 || (ldh & 3) || ldg5 < 256 || (ldg5 & 3) || ldgz < 256 || (ldgz & 3)) {
+        set_error("hnr_ksum_bwd: bad argument"); return HNR_ERR_BADARG;
+    }
+    if (cap_samples <= 0) return HNR_OK;
+    KsumBwdArgs a;
+    a.H4 = d_H4; a.ldh = ldh; a.wagg = d_wagg; a.alpha_w = d_alpha_w; a.alpha_b = d_alpha_b; a.vs_off = d_vs_off; a.vs_cnt = d_vs_cnt;
+    a.counts = reinterpret_cast<const unsigned long long *>(d_counts); a.gX5 = d_gX5; a.ldg5 = ldg5; a.g_sigma = d_g_sigma; a.slope = slope;
+    a.gZ4 = d_gZ4; a.ldgz = ldgz; a.g_wagg = d_g_wagg; a.g_alpha_w = d_g_alpha_w; a.g_alpha_b = d_g_alpha_b;
+    ksum_bwd_kernel<<<persistent_blocks(cap_samples), 256, 0, (hipStream_t)stream>>>(a);
+    HNR_LAUNCH_CHECK();
+    return HNR_OK;
+}
+
+extern "C" int hnr_gather_rows_bwd(const int32_t *d_sample_pidx, const float *d_raydir, const int32_t *d_vs_item, const int32_t *d_vs_off,
+                                   const int32_t *d_vs_cnt, const int64_t *d_counts, int SR, int K, int cap_samples, const float *d_gX3,
+                                   int ldg3, const float *d_g_wagg, const float *d_weight, const float *d_g_conf_out, float *d_g_conf,
+                                   float *d_g_dir, float *d_g_color, void *stream)
+{
+    if (!d_sample_pidx || !d_raydir || !d_vs_item || !d_vs_off || !d_vs_cnt || !d_counts || !d_gX3 || !d_g_wagg || !d_weight || !d_g_conf ||
+        !d_g_dir || !d_g_color || ldg3 < 263 || SR <= 0 || K <= 0) {
+        set_error("hnr_gather_rows_bwd: bad argument"); return HNR_ERR_BADARG;
+    }
+    if (cap_samples <= 0) return HNR_OK;
+    GatherBwdArgs a;
+    a.pidx = d_sample_pidx; a.raydir = d_raydir; a.vs_item = d_vs_item; a.vs_off = d_vs_off; a.vs_cnt = d_vs_cnt;
+    a.counts = reinterpret_cast<const unsigned long long *>(d_counts); a.SR = SR; a.K = K; a.gX3 = d_gX3; a.ldg3 = ldg3; a.g_wagg = d_g_wagg;
+    a.weight = d_weight; a.g_conf_out = d_g_conf_out; a.g_conf = d_g_conf; a.g_dir = d_g_dir; a.g_color = d_g_color;
+    gather_rows_bwd_kernel<<<cdiv((int64_t)cap_samples * K, 256), 256, 0, (hipStream_t)stream>>>(a);
+    HNR_LAUNCH_CHECK();
+    return HNR_OK;
+}
+
+extern "C" int hnr_scatter_add_rows(const float *d_src, int lds, const int32_t *d_idx, int64_t M, int n_cols, float *d_dst, int ldd,
+                                    void *stream)
+{
+    if (M < 0 || n_cols <= 0 || (n_cols & 3) || lds < n_cols || (lds & 3) || ldd < n_cols) { set_error("hnr_scatter_add_rows: bad sizes"); return HNR_ERR_BADARG; }
+    if (M == 0) return HNR_OK;
+    if (!d_src || !d_idx || !d_dst) { set_error("hnr_scatter_add_rows: NULL argument"); return HNR_ERR_BADARG; }
+    scatter_add_rows_kernel<<<cdiv(M * (n_cols >> 2), 256), 256, 0, (hipStream_t)stream>>>(d_src, lds, d_idx, M, n_cols, d_dst, ldd);
+    HNR_LAUNCH_CHECK();
+    return HNR_OK;
+}
+
+extern "C" int hnr_point_rows_bwd(const float *d_gE, int ldg, const float *d_E, int lde, const int32_t *d_ids, int n, int F, float *d_g_emb,
+                                  void *stream)
+{
+    if (n < 0 || F != 32 || ldg < 7 * F || lde < 7 * F) { set_error("hnr_point_rows_bwd: bad argument"); return HNR_ERR_BADARG; }
+    if (n == 0) return HNR_OK;
+    if (!d_gE || !d_E || !d_g_emb) { set_error("hnr_point_rows_bwd: NULL argument"); return HNR_ERR_BADARG; }
+    point_rows_bwd_kernel<32><<<cdiv((int64_t)n * F, 256), 256, 0, (hipStream_t)stream>>>(d_gE, ldg, d_E, lde, d_ids, n, d_g_emb);
+    HNR_LAUNCH_CHECK();
+    return HNR_OK;
+}
+
+extern "C" int hnr_dleaky(float *d_g, int ldg, const float *d_y, int ldy, int64_t M, int N, float slope, void *stream)
+{
+    if (M < 0 || N <= 0 || ldg < N || ldy < N) { set_error("hnr_dleaky: bad sizes"); return HNR_ERR_BADARG; }
+    if (M == 0) return HNR_OK;
+    if (!d_g || !d_y) { set_error("hnr_dleaky: NULL argument"); return HNR_ERR_BADARG; }
+    dleaky_kernel<<<cdiv(M * N, 256), 256, 0, (hipStream_t)stream>>>(d_g, ldg, d_y, ldy, M, N, slope);
+    HNR_LAUNCH_CHECK();
+    return HNR_OK;
+}
+
+extern "C" int hnr_sum_views(const float *d_in, int ldi, int V, int cap, int n_samples, int N, float *d_out, int ldo, void *stream)
+{
+    if (V <= 0 || cap < n_samples || n_samples < 0 || N <= 0 || ldi < N || ldo < N) { set_error("hnr_sum_views: bad sizes"); return HNR_ERR_BADARG; }
+    if (n_samples == 0) return HNR_OK;
+    if (!d_in || !d_out) { set_error("hnr_sum_views: NULL argument"); return HNR_ERR_BADARG; }
+    sum_views_kernel<<<cdiv((int64_t)n_samples * N, 256), 256, 0, (hipStream_t)stream>>>(d_in, ldi, V, cap, n_samples, N, d_out, ldo);
+    HNR_LAUNCH_CHECK();
+    return HNR_OK;
+}
+
+extern "C" int hnr_unique_points(const int32_t *d_row_pid, int64_t M, int n_points, int32_t *d_uidx, int32_t *d_ulist, int cap,
+                                 int32_t *d_row_u, int32_t *d_count, int32_t *d_scratch, void *stream)
+{
+    if (M < 0 || n_points <= 0 || cap < 0) { set_error("hnr_unique_points: bad sizes"); return HNR_ERR_BADARG; }
+    if (!d_uidx || !d_ulist || !d_count || !d_scratch || (M > 0 && (!d_row_pid || !d_row_u))) { set_error("hnr_unique_points: NULL argument"); return HNR_ERR_BADARG; }
+    hipStream_t st = (hipStream_t)stream;
+    HNR_HIP_CHECK(hipMemsetAsync(d_uidx, 0, (size_t)n_points * 4, st));
+    if (M > 0) mark_points_kernel<<<cdiv(M, 256), 256, 0, st>>>(d_row_pid, M, d_uidx);
+    const int nb = cdiv(n_points, 1024);
+    flag_block_sum_kernel<<<nb, 1024, 0, st>>>(d_uidx, n_points, d_scratch);
+    flag_scan_kernel<<<nb, 1024, 0, st>>>(d_uidx, n_points, d_scratch, d_ulist, cap, d_count);
+    if (M > 0) map_rows_kernel<<<cdiv(M, 256), 256, 0, st>>>(d_row_pid, M, d_uidx, d_row_u);
+    HNR_LAUNCH_CHECK();
+    return HNR_OK;
+}

@@ -53,7 +53,8 @@ __global__ __launch_bounds__(128 * WN, 2) void linear_f32_kernel(const float *__
                                                          const float *__restrict__ Wp, int K_pad,
                                                          const float *__restrict__ bias_p, float *__restrict__ C, int ldc,
                                                          int M, int N, int K, float slope,
-                                                         const float *__restrict__ R, const int32_t *__restrict__ ridx, int ldr)
+                                                         const float *R, const int32_t *__restrict__ ridx, int ldr,
+                                                         int r_cols, int r_mode)
 {
     // workgroup = 2 x WN waves; each wave owns TM x TN MFMA tiles of 32x32
     constexpr int NT = 128 * WN;                // threads
@@ -137,20 +138,25 @@ __global__ __launch_bounds__(128 * WN, 2) void linear_f32_kernel(const float *__
     auto epilogue = [&](int mt) {
         const int row0 = mt * BM + wr * 32 * TM + 4 * (lane >> 5);
         if (R != nullptr) {
-            // gathered addend: fetch this lane's 16*TM row indices, then all addend values of one column block at once (the
-            // loads are independent, so they overlap instead of forming index -> value -> store chains)
+            // side operand R (row stride ldr), applied to the columns < r_cols:
+            //   r_mode 0: gathered addend, v = act(acc + bias + R[ridx[m], n])   (ridx == NULL: row m itself, e.g. R == C for "+=")
+            //   r_mode 1: LeakyReLU derivative of a stored activation, v = (acc + bias) * (R[m, n] > 0 ? 1 : slope)  (backward)
+            // This lane's 16*TM row indices are fetched first, then all side values of one column block at once (the loads
+            // are independent, so they overlap instead of forming index -> value -> store chains).
             int rid[TM][16];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int gm = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
-                    rid[i][r] = ridx[gm < M ? gm : M - 1];
+                    const int gmc = gm < M ? gm : M - 1;
+                    rid[i][r] = ridx ? ridx[gmc] : gmc;
                 }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int gn = n0 + wc * 32 * TN + j * 32 + (lane & 31);
-                const int gn_safe = gn < N ? gn : N - 1;
+                const bool use = gn < r_cols;
+                const int gn_safe = use ? gn : r_cols - 1;
                 float add[TM][16];
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
@@ -161,8 +167,13 @@ __global__ __launch_bounds__(128 * WN, 2) void linear_f32_kernel(const float *__
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int gm = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
-                        float v = acc[i][j][r] + bias_v[j] + add[i][r];
-                        if (ACT == 1) v = v > 0.f ? v : v * slope;
+                        float v = acc[i][j][r] + bias_v[j];
+                        if (r_mode == 0) {
+                            v += use ? add[i][r] : 0.f;
+                            if (ACT == 1) v = v > 0.f ? v : v * slope;
+                        } else {
+                            v *= (use && !(add[i][r] > 0.f)) ? slope : 1.f;
+                        }
                         if (gm < M && gn < N) C[(size_t)gm * ldc + gn] = v;
                         acc[i][j][r] = 0.f;
                     }
@@ -323,12 +334,12 @@ extern "C" int hnr_linear_pack(const float *d_W, const float *d_bias, int N, int
 }
 
 static int linear_launch(const float *d_A, int lda, const float *d_Wp, const float *d_bias_p, float *d_C, int ldc, int M, int N, int K,
-                         int act, float slope, const float *d_R, const int32_t *d_ridx, int ldr, void *stream);
+                         int act, float slope, const float *d_R, const int32_t *d_ridx, int ldr, int r_cols, int r_mode, void *stream);
 
 extern "C" int hnr_linear_f32(const float *d_A, int lda, const float *d_Wp, const float *d_bias_p, float *d_C, int ldc,
                               int M, int N, int K, int act, float slope, void *stream)
 {
-    return linear_launch(d_A, lda, d_Wp, d_bias_p, d_C, ldc, M, N, K, act, slope, nullptr, nullptr, 0, stream);
+    return linear_launch(d_A, lda, d_Wp, d_bias_p, d_C, ldc, M, N, K, act, slope, nullptr, nullptr, 0, 0, 0, stream);
 }
 
 extern "C" int hnr_linear_f32_gather_add(const float *d_A, int lda, const float *d_Wp, const float *d_bias_p, const float *d_R,
@@ -336,11 +347,21 @@ extern "C" int hnr_linear_f32_gather_add(const float *d_A, int lda, const float 
                                          float slope, void *stream)
 {
     if (M > 0 && (!d_R || !d_ridx || ldr < N)) { set_error("hnr_linear_f32_gather_add: bad addend arguments"); return HNR_ERR_BADARG; }
-    return linear_launch(d_A, lda, d_Wp, d_bias_p, d_C, ldc, M, N, K, act, slope, d_R, d_ridx, ldr, stream);
+    return linear_launch(d_A, lda, d_Wp, d_bias_p, d_C, ldc, M, N, K, act, slope, d_R, d_ridx, ldr, N, 0, stream);
+}
+
+extern "C" int hnr_linear_f32_side(const float *d_A, int lda, const float *d_Wp, const float *d_bias_p, const float *d_R,
+                                   const int32_t *d_ridx, int ldr, int r_cols, int r_mode, float *d_C, int ldc, int M, int N, int K,
+                                   int act, float slope, void *stream)
+{
+    if (M > 0 && (!d_R || r_cols <= 0 || r_cols > N || ldr < r_cols || (r_mode != 0 && r_mode != 1) || (r_mode == 1 && (act != 0 || d_ridx)))) {
+        set_error("hnr_linear_f32_side: bad side-operand arguments"); return HNR_ERR_BADARG;
+    }
+    return linear_launch(d_A, lda, d_Wp, d_bias_p, d_C, ldc, M, N, K, act, slope, d_R, d_ridx, ldr, r_cols, r_mode, stream);
 }
 
 static int linear_launch(const float *d_A, int lda, const float *d_Wp, const float *d_bias_p, float *d_C, int ldc, int M, int N, int K,
-                         int act, float slope, const float *d_R, const int32_t *d_ridx, int ldr, void *stream)
+                         int act, float slope, const float *d_R, const int32_t *d_ridx, int ldr, int r_cols, int r_mode, void *stream)
 {
     if (M < 0 || N <= 0 || K <= 0 || lda < K || (lda & 3) || ldc < N || (act != 0 && act != 1)) {
         set_error("hnr_linear_f32: bad sizes (M=%d N=%d K=%d lda=%d ldc=%d act=%d; lda must be a multiple of 4 and >= K)", M, N, K, lda, ldc, act);
@@ -370,26 +391,26 @@ static int linear_launch(const float *d_A, int lda, const float *d_Wp, const flo
         if (gx < 1) gx = 1;
         if (gx > n_mtiles) gx = n_mtiles;
         dim3 grid(gx, ny);
-        if (act) linear_f32_kernel<2, 2, 1, 0, 4><<<grid, 512, 114688, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope, d_R, d_ridx, ldr);
-        else linear_f32_kernel<2, 2, 0, 0, 4><<<grid, 512, 114688, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope, d_R, d_ridx, ldr);
+        if (act) linear_f32_kernel<2, 2, 1, 0, 4><<<grid, 512, 114688, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope, d_R, d_ridx, ldr, r_cols, r_mode);
+        else linear_f32_kernel<2, 2, 0, 0, 4><<<grid, 512, 114688, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope, d_R, d_ridx, ldr, r_cols, r_mode);
     } else if (N >= 128) {
         const int ny = Np / 128;
         int gx = (2 * n_cu) / ny;
         if (gx < 1) gx = 1;
         if (gx > n_mtiles) gx = n_mtiles;
         dim3 grid(gx, ny);
-        if (dbg == 1) linear_f32_kernel<2, 2, 1, 1><<<grid, 256, 81920, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope, d_R, d_ridx, ldr);
-        else if (dbg == 2) linear_f32_kernel<2, 2, 1, 2><<<grid, 256, 81920, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope, d_R, d_ridx, ldr);
-        else if (act) linear_f32_kernel<2, 2, 1><<<grid, 256, 81920, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope, d_R, d_ridx, ldr);
-        else linear_f32_kernel<2, 2, 0><<<grid, 256, 81920, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope, d_R, d_ridx, ldr);
+        if (dbg == 1) linear_f32_kernel<2, 2, 1, 1><<<grid, 256, 81920, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope, d_R, d_ridx, ldr, r_cols, r_mode);
+        else if (dbg == 2) linear_f32_kernel<2, 2, 1, 2><<<grid, 256, 81920, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope, d_R, d_ridx, ldr, r_cols, r_mode);
+        else if (act) linear_f32_kernel<2, 2, 1><<<grid, 256, 81920, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope, d_R, d_ridx, ldr, r_cols, r_mode);
+        else linear_f32_kernel<2, 2, 0><<<grid, 256, 81920, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope, d_R, d_ridx, ldr, r_cols, r_mode);
     } else {
         const int ny = Np / 64;
         int gx = (2 * n_cu) / ny;
         if (gx < 1) gx = 1;
         if (gx > n_mtiles) gx = n_mtiles;
         dim3 grid(gx, ny);
-        if (act) linear_f32_kernel<2, 1, 1><<<grid, 256, 65536, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope, d_R, d_ridx, ldr);
-        else linear_f32_kernel<2, 1, 0><<<grid, 256, 65536, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope, d_R, d_ridx, ldr);
+        if (act) linear_f32_kernel<2, 1, 1><<<grid, 256, 65536, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope, d_R, d_ridx, ldr, r_cols, r_mode);
+        else linear_f32_kernel<2, 1, 0><<<grid, 256, 65536, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope, d_R, d_ridx, ldr, r_cols, r_mode);
     }
     HNR_LAUNCH_CHECK();
     return HNR_OK;

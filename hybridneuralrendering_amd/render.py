@@ -182,7 +182,8 @@ class HybridRenderer:
             X7 = _f32((n_valid, 92), dev)
             fw = None if frame_weight is None else _lib.require_gpu(frame_weight, "frame_weight", torch.float32).reshape(-1)
             _lib.check(L.hnr_merge(p(X6), ld6, p(M1), 64, p(pk["mw_last_w"]), p(pk["mw_last_b"]), p(vmask),
-                                   p(fw) if fw is not None else None, p(CF), 128, p(counts), V, n_valid, p(X7), 92, st()), "hnr_merge")
+                                   p(fw) if fw is not None else None, p(CF), 128, p(counts), V, n_valid, p(X7), 92,
+                                   None, None, 0, st()), "hnr_merge")
           with T("mlp_mixup"):
             Y1, Y2 = _f32((n_valid, 48), dev), _f32((n_valid, 48), dev)
             pk["mx"][0](X7, out=Y1, act=True, slope=sl, K=90)

@@ -174,6 +174,20 @@ int hnr_linear_f32(const float *d_A, int lda, const float *d_Wp, const float *d_
 int hnr_linear_f32_gather_add(const float *d_A, int lda, const float *d_Wp, const float *d_bias_p, const float *d_R,
                               const int32_t *d_ridx, int ldr, float *d_C, int ldc, int M, int N, int K, int act, float slope,
                               void *stream);
+/* General form of the side operand, applied to the output columns < r_cols only (d_ridx may be NULL = row m itself):
+ *   r_mode 0: C = act(A W^T + bias + R[ridx[m], :])          (d_R == d_C gives an accumulating "+=" layer)
+ *   r_mode 1: C = (A W^T + bias) * (R[m, :] > 0 ? 1 : slope)  LeakyReLU derivative of the stored activation R; act must be 0.
+ * r_mode 1 is the input-gradient GEMM of the backward pass (torch autograd of nn.Linear + LeakyReLU in the reference):
+ * with W^T packed as the weight, dZ_prev = (dZ W) * LeakyReLU'(Y_prev). */
+int hnr_linear_f32_side(const float *d_A, int lda, const float *d_Wp, const float *d_bias_p, const float *d_R,
+                        const int32_t *d_ridx, int ldr, int r_cols, int r_mode, float *d_C, int ldc, int M, int N, int K,
+                        int act, float slope, void *stream);
+/* Weight and bias gradient of a dense layer:  dW[N,K] (row stride lddw) = dZ[M,N]^T X[M,K],  db[N] = column sums of dZ
+ * (d_db may be NULL); accumulate != 0 adds to the existing values.  ldz, ldx multiples of 4; d_scratch:
+ * float[hnr_linear_wgrad_scratch_elems(M,N,K)].  Deterministic (fixed-order two-stage reduction, no atomics). */
+int64_t hnr_linear_wgrad_scratch_elems(int M, int N, int K);
+int hnr_linear_f32_wgrad(const float *d_dZ, int ldz, const float *d_X, int ldx, int M, int N, int K, float *d_dW, int lddw,
+                         float *d_db, int accumulate, float *d_scratch, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Stage 3b: everything of the gather / aggregate / composite path that is not a dense layer.
@@ -210,8 +224,10 @@ int hnr_gather_rows(const float *d_xyz, const float *d_emb, const float *d_conf,
                     int32_t *d_row_pid, void *stream);
 
 /* d_E[p, 0:224] = [emb32 | PE3(emb) 192] for every point (point_aggregators.py:931-938): the point-only columns of
- * block1's input row.  lde >= 224, multiple of 4. */
-int hnr_point_rows(const float *d_emb, int n_points, int F, float *d_E, int lde, void *stream);
+ * block1's input row.  lde >= 224, multiple of 4.  With d_ids the rows are those of the listed points only (training:
+ * the points a batch touches, hnr_unique_points). */
+int hnr_point_rows(const float *d_emb, const int32_t *d_ids /*NULL or [n_points] point ids*/, int n_points, int F, float *d_E, int lde,
+                   void *stream);
 
 /* The materialised gather of NeuralPoints.forward (neural_points.py:709-720) for the drop-in 14-tuple only:
  * n_entries = R'*SR*K entries of d_sample_pidx; empty entries (-1) read point 0 (the reference clamps the index);
@@ -248,10 +264,12 @@ int hnr_proj_rows(const float *d_sample_loc_w, const int32_t *d_vs_item, const i
                   int32_t *d_row_sample, void *stream);
 
 /* Last layer + sigmoid of aux_merge_weight_block, weighted merge (:1199-1217) and the mix-up input (:1286-1292):
- *   d_X7[s, 0:90] = [colfeat[:45] | sum_v w_v f_v / (sum_v w_v + 1e-6)].  d_frame_w: optional [V]. */
+ *   d_X7[s, 0:90] = [colfeat[:45] | sum_v w_v f_v / (sum_v w_v + 1e-6)].  d_frame_w: optional [V].
+ * d_ray_drop: optional [R] u8; samples on flagged rays get merged = 0 (train-time patch drop, :1222-1237; the caller
+ * builds the flags from drop_patch_rays :14-23 over the valid-ray rows). */
 int hnr_merge(const float *d_X6, int ld6, const float *d_Hm, int ldh, const float *d_w_last, const float *d_b_last,
               const float *d_vmask, const float *d_frame_w, const float *d_CF, int ldcf, const int64_t *d_counts, int V,
-              int cap_samples, float *d_X7, int ld7, void *stream);
+              int cap_samples, float *d_X7, int ld7, const uint8_t *d_ray_drop, const int32_t *d_vs_item, int SR, void *stream);
 
 /* Residual + color_final_block + sigmoid*1.002-0.001 (:1294-1295, :1334, :478-482), scattered with sigma into
  * d_decoded [R*SR,4] (pre-zeroed by the caller; :1337-1338). */
@@ -271,6 +289,77 @@ int hnr_composite(const float *d_decoded, const float *d_sample_loc_w, const int
                   const float *d_campos, const float *d_camrot, const float *d_bg_color, int R, int SR, int K, float vsize_z,
                   int raydist_mode_unit, float *d_raycolor, float *d_opacity, float *d_is_background, float *d_blend_weight,
                   void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Stage 5: backward of stages 3b and 4 (hnr_gather_aggregate_bwd / hnr_composite_bwd), one entry point per
+ * forward kernel.  The reference obtains all of these from torch autograd over its eager ops; file:line below name the
+ * forward code whose derivative each one is.  g_* / d_g* are gradients; weight gradients marked "atomics" are ADDED to
+ * the caller's (zero-initialised or accumulating) buffers.
+ */
+
+/* ray_march + alpha blend (models/rendering/diff_ray_marching.py:508-557) and fill_invalid (:87-126):
+ * d_g_raycolor [R,3] -> d_g_decoded [R,SR,4] = (d sigma, d rgb), zeros for invalid samples / rays. */
+int hnr_composite_bwd(const float *d_decoded, const float *d_sample_loc_w, const int32_t *d_sample_pidx, const int8_t *d_ray_mask,
+                      const int32_t *d_ray_nsamp, const float *d_campos, const float *d_camrot, const float *d_bg_color,
+                      int R, int SR, int K, float vsize_z, int raydist_mode_unit, const float *d_g_raycolor,
+                      float *d_g_decoded, void *stream);
+
+/* color_final_block + sigmoid*1.002-0.001 + residual (point_aggregators.py:1294-1295, :1334, :478-482):
+ * d_g_decoded -> d_gY [S,45] (mix-up output), d_gCF [S,128] (OVERWRITTEN), d_g_sigma [S]; weights: atomics. */
+int hnr_final_color_bwd(const float *d_Y, int ldy, const float *d_CF, int ldcf, const float *d_w_fin, const float *d_b_fin,
+                        const int32_t *d_vs_item, const int64_t *d_counts, int cap_samples, const float *d_g_decoded,
+                        float *d_gY, int ldgy, float *d_gCF, int ldgcf, float *d_g_sigma, float *d_g_w_fin, float *d_g_b_fin,
+                        void *stream);
+
+/* weighted merge + last layer of aux_merge_weight_block (:1199-1217, patch drop :1222-1237, mix-up input :1286-1292):
+ * d_gX7 [S,90] -> d_gF [V*cap,48] (d image-feature columns), d_gZ3 [V*cap,64] (d pre-activation of the last hidden layer),
+ * d_gCF[:, :45] += ; last-layer weights: atomics. */
+int hnr_merge_bwd(const float *d_X6, int ld6, const float *d_Hm, int ldh, const float *d_w_last, const float *d_b_last,
+                  const float *d_vmask, const float *d_frame_w, const int64_t *d_counts, int V, int cap_samples, float slope,
+                  const uint8_t *d_ray_drop, const int32_t *d_vs_item, int SR, const float *d_gX7, int ldg7,
+                  float *d_gF, int ldgf, float *d_gZ3, int ldgz, float *d_gCF, int ldgcf, float *d_g_w_last, float *d_g_b_last,
+                  void *stream);
+
+/* pixel gather (:1077-1089, :1193) + F.interpolate (:1064-1067) transposed: the rows' image-feature gradients (two sources
+ * added: d_gFa from hnr_merge_bwd, optional d_gFb from the merge-weight MLP's first layer) are scattered with the bilinear
+ * weights into d_g_pyramid, a ZERO-INITIALISED buffer laid out like the forward scratch of hnr_image_features. */
+int hnr_proj_rows_bwd(const float *d_sample_loc_w, const int32_t *d_vs_item, const int64_t *d_counts, const float *d_w2c,
+                      const float *d_intrinsic, int V, int H, int W, int cap_samples, const float *d_gFa, int lda,
+                      const float *d_gFb, int ldb, float *d_g_pyramid, void *stream);
+
+/* aux_block_s1..3 (:1047-1063): d_scratch is the forward scratch (activations), d_g_pyramid as above (used as workspace);
+ * g_conv_w / g_conv_b: HOST arrays of 6 device pointers, atomics. */
+int hnr_image_features_bwd(const float *d_img, int V, int H, int W, const float *const *conv_w, float slope,
+                           const float *d_scratch, float *d_g_pyramid, float *const *g_conv_w, float *const *g_conv_b,
+                           void *stream);
+
+/* alpha branch + softplus(x-1) + K-weighted sums (:1005-1026, :471-476): d_gX5[:, :256], d_g_sigma ->
+ * d_gZ4 [rows,256] (d pre-activation of block3's last layer), d_g_wagg [rows]; alpha weights: atomics. */
+int hnr_ksum_bwd(const float *d_H4, int ldh, const float *d_wagg, const float *d_alpha_w, const float *d_alpha_b,
+                 const int32_t *d_vs_off, const int32_t *d_vs_cnt, const int64_t *d_counts, int cap_samples,
+                 const float *d_gX5, int ldg5, const float *d_g_sigma, float slope, float *d_gZ4, int ldgz, float *d_g_wagg,
+                 float *d_g_alpha_w, float *d_g_alpha_b, void *stream);
+
+/* NeuralPoints gather (neural_points.py:709-720), block3 extras (:957-971), conf straight-through clamp (:1422-1424, :1508-1512):
+ * d_gX3[:, 256:263], d_g_wagg, optional d_g_conf_out [R,SR,K] (gradient of the conf_coefficient output) ->
+ * points_conf / points_dir / points_color gradients (atomics into [N], [N,3], [N,3]). */
+int hnr_gather_rows_bwd(const int32_t *d_sample_pidx, const float *d_raydir, const int32_t *d_vs_item, const int32_t *d_vs_off,
+                        const int32_t *d_vs_cnt, const int64_t *d_counts, int SR, int K, int cap_samples, const float *d_gX3,
+                        int ldg3, const float *d_g_wagg, const float *d_weight, const float *d_g_conf_out, float *d_g_conf,
+                        float *d_g_dir, float *d_g_color, void *stream);
+
+/* The set of points a batch touches: d_uidx [n_points] = compact index or -1, d_ulist [<= cap] = their ids (ascending),
+ * d_row_u [M] = compact index of every neighbour row, *d_count = how many.  d_scratch: int32[ceil(n_points/1024)]. */
+int hnr_unique_points(const int32_t *d_row_pid, int64_t M, int n_points, int32_t *d_uidx, int32_t *d_ulist, int cap,
+                      int32_t *d_row_u, int32_t *d_count, int32_t *d_scratch, void *stream);
+/* d_dst[d_idx[m], :] += d_src[m, :] (atomics; n_cols a multiple of 4): per-point sum of block1's first-layer gradient. */
+int hnr_scatter_add_rows(const float *d_src, int lds, const int32_t *d_idx, int64_t M, int n_cols, float *d_dst, int ldd, void *stream);
+/* positional encoding of the embedding (:931-938) transposed: d_gE [n,224] (+ forward rows d_E) -> d_g_emb[ids[u], :] +=. */
+int hnr_point_rows_bwd(const float *d_gE, int ldg, const float *d_E, int lde, const int32_t *d_ids, int n, int F, float *d_g_emb,
+                       void *stream);
+/* g *= LeakyReLU'(y) in place;  out[s,:] = sum over the V view rows of a sample. */
+int hnr_dleaky(float *d_g, int ldg, const float *d_y, int ldy, int64_t M, int N, float slope, void *stream);
+int hnr_sum_views(const float *d_in, int ldi, int V, int cap, int n_samples, int N, float *d_out, int ldo, void *stream);
 
 #ifdef __cplusplus
 }

@@ -291,9 +291,22 @@ def shipped_loss(full_raycolor, ray_mask, conf_coefficient, gt, zero_epsilon, w_
 
 
 def train_step(xyz, emb, conf, pdir, color, sd, q, campos, camrotc2w, raydir_all, bg_color, c2w_nearest, campos_nearest,
-               intrinsic_nearest, images_nearest, vsize, gt, zero_epsilon, drop_ray_rows, raydist_mode_unit=1):
+               intrinsic_nearest, images_nearest, vsize, gt, zero_epsilon, drop_ray_rows, raydist_mode_unit=1, dtype=None):
     """Forward in train mode + autograd of shipped_loss.  Returns (outputs, loss triple, grads dict) with grads keyed
-    `neural_points.points_*` and `aggregator.<param>` like the reference's named parameters."""
+    `neural_points.points_*` and `aggregator.<param>` like the reference's named parameters.
+    dtype=torch.float64 re-runs the same graph in double precision (the query result q is kept): the yardstick for how much
+    of a gradient difference is fp32 rounding noise."""
+    if dtype is not None and dtype != torch.float32:
+        c = lambda t: t.to(dtype) if isinstance(t, torch.Tensor) and t.is_floating_point() else t
+        q = dict(q, sample_loc_w=torch.as_tensor(np.ascontiguousarray(q["sample_loc_w"])).to(dtype))
+        old = torch.get_default_dtype()
+        torch.set_default_dtype(dtype)
+        try:
+            return train_step(c(xyz), c(emb), c(conf), c(pdir), c(color), {k: c(v) for k, v in sd.items()}, q, c(campos), c(camrotc2w),
+                              c(raydir_all), c(bg_color), c(c2w_nearest), c(campos_nearest), c(intrinsic_nearest), c(images_nearest),
+                              vsize, c(gt), zero_epsilon, drop_ray_rows, raydist_mode_unit)
+        finally:
+            torch.set_default_dtype(old)
     leaves = dict(emb=emb.clone().requires_grad_(True), conf=conf.clone().requires_grad_(True),
                   pdir=pdir.clone().requires_grad_(True), color=color.clone().requires_grad_(True))
     sdl = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
