@@ -208,6 +208,7 @@ class NeuralPointsRayMarching(nn.Module):
         if getattr(opt, "prob", 0) == 1:
             raise HnrError("prob==1 (hole probing) is a 'next' row (SURVEY 8f) and is not implemented")
         self._renderer = None
+        self._train_path = None
 
     def renderer(self):
         if self._renderer is None:
@@ -221,12 +222,24 @@ class NeuralPointsRayMarching(nn.Module):
                 campos_nearest=None, intrinsic_nearest=None, vid_angle_nearest=None, frame_weight_nearest=None, **kargs):
         if "bg_ray" in kargs:
             raise HnrError("per-ray backgrounds (bg_ray) are unsupported")
+        # kargs["tmid"] (optional, [R, z_depth_dim]): explicit marched depths instead of freshly drawn jitter (tests)
         rnd = self.renderer()
-        cloud = self.neural_points.cloud()
         nearv, farv = torch.min(near).item(), torch.max(far).item()
         fw = frame_weight_nearest[0] if getattr(self.opt, "downweight_blurry_feats", 0) else None
-        full = rnd.render_rays(cloud, raydir[0], campos[0], camrotc2w[0], bg_color[0], nearv, farv, c2w_nearest[0], campos_nearest[0],
-                               intrinsic_nearest[0], images_nearest[0], frame_weight=fw, want_weights=True, pad=True)
+        if getattr(self.opt, "is_train", 0) and torch.is_grad_enabled():
+            # training: same HIP forward with the activations kept + the hand-written backward (train.py); coarse_raycolor and
+            # conf_coefficient stay attached to the autograd graph of the point buffers and the aggregator parameters
+            from .train import TrainPath, render_train
+            if self._train_path is None:
+                self._train_path = TrainPath(rnd)
+            npnt = self.neural_points
+            full = render_train(self._train_path, self.aggregator, npnt.xyz, npnt.points_embeding, npnt.points_conf, npnt.points_dir,
+                                npnt.points_color, raydir[0], campos[0], camrotc2w[0], bg_color[0], nearv, farv, c2w_nearest[0],
+                                campos_nearest[0], intrinsic_nearest[0], images_nearest[0], frame_weight=fw, tmid=kargs.get("tmid"))
+        else:
+            cloud = self.neural_points.cloud()
+            full = rnd.render_rays(cloud, raydir[0], campos[0], camrotc2w[0], bg_color[0], nearv, farv, c2w_nearest[0], campos_nearest[0],
+                                   intrinsic_nearest[0], images_nearest[0], frame_weight=fw, want_weights=True, pad=True)
         mask = full["ray_mask"]
         rows = torch.nonzero(mask)[:, 0]                                  # valid rays, in ray order (:705-709)
         sel = lambda t: t.index_select(0, rows)[None]

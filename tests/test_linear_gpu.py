@@ -79,7 +79,7 @@ def test_point_rows_and_split_equal_unsplit_layer():
     emb = (torch.randn(700, 32) * 0.3)
     E_ref = torch.cat([emb, ro.positional_encoding(emb, 3)], dim=-1)            # reference row layout (networks.py:175-189)
     E = torch.empty((700, 224), device=d)
-    _lib.check(_lib.lib().hnr_point_rows(_lib.ptr(emb.to(d)), 700, 32, _lib.ptr(E), 224, _lib.stream()), "hnr_point_rows")
+    _lib.check(_lib.lib().hnr_point_rows(_lib.ptr(emb.to(d)), None, 700, 32, _lib.ptr(E), 224, _lib.stream()), "hnr_point_rows")
     np.testing.assert_allclose(E.cpu().numpy(), E_ref.numpy(), rtol=0, atol=3e-7)
     T = agg.point_table(emb.to(d))
     W = agg.block1[0].weight.detach().cpu().double()

@@ -96,3 +96,41 @@ def test_install_rebinds_reference_globals():
     assert sys.modules["models.neural_points.neural_points"].lighting_fast_querier_w is modules.Q.lighting_fast_querier
     for name in ("models", "models.neural_points", "models.neural_points.neural_points", "models.neural_points_volumetric_model"):
         sys.modules.pop(name, None)
+
+
+def test_train_mode_module_gives_reference_gradients_on_its_parameters():
+    """Drop-in surface in train mode: loss.backward() through NeuralPointsRayMarching fills .grad of the reference-named
+    nn.Parameters (neural_points.points_*, aggregator.*) with the values torch autograd produced on the reference."""
+    from tests.golden_io import load_train
+    import tests.test_modules_gpu as me
+    d = load_train("scannet_small")
+    orig = me.load_render
+    me.load_render = lambda tag: d                      # same scene + weights, train-mode options and ray batch
+    try:
+        d, ti, opt, npts, net, dev = _build("scannet_small")
+    finally:
+        me.load_render = orig
+    assert opt.is_train == 1
+    net.train()
+    inp = _inputs(d, ti, dev)
+    out = net(**inp, tmid=torch.from_numpy(d["tmid"]).to(dev))
+    rows = np.nonzero(d["q_ray_mask"])[0]
+    assert out["coarse_raycolor"].shape == (1, len(rows), 3) and out["coarse_raycolor"].requires_grad
+    np.testing.assert_allclose(out["coarse_raycolor"].detach().cpu().numpy(), d["coarse_raycolor"], rtol=0, atol=2e-4)
+    gt = torch.from_numpy(d["gt"]).to(dev)[:, rows]
+    eps = float(d["zero_epsilon"])
+    val = torch.clamp(out["conf_coefficient"], eps, 1 - eps)
+    loss = torch.nn.functional.mse_loss(out["coarse_raycolor"], gt) + 1e-4 * torch.mean(torch.log(val) + torch.log(1 - val))
+    np.testing.assert_allclose(loss.item(), d["loss"][0], rtol=2e-5)
+    loss.backward()
+    got = {"neural_points." + k: getattr(npts, k).grad for k in ("points_embeding", "points_conf", "points_dir", "points_color")}
+    for k, prm in net.aggregator.named_parameters():
+        if prm.grad is not None:
+            got["aggregator." + k] = prm.grad
+    assert set(got) == set(d["grad"])
+    for k, ref in d["grad"].items():
+        r = ref.numpy().astype(np.float64)
+        x = got[k].detach().cpu().numpy().astype(np.float64).reshape(r.shape)
+        tol = 1.5e-3 if k.startswith("neural_points.") else 3e-4        # see tests/test_train_gpu.py for the fp32-noise yardstick
+        assert np.abs(x - r).max() <= tol * np.abs(r).max(), k
+    assert npts.xyz.grad is None
