@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--margin", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train-leg", action="store_true")
     ap.add_argument("--cpu-sample-rays", type=int, default=2304)
     return ap.parse_args()
 
@@ -124,6 +125,59 @@ def cpu_baseline(args, sc, opt, agg, cam, gpu_colors):
                 sample="one %dx%d-ray chunk of the same frame: C oracle grid build over %d points + query (%.2f s, 1 thread) + torch-CPU "
                        "aggregate/composite with 4 reference views (%d threads); %.2f s total" % (side, side, sc.xyz.shape[0], t_query, cores, dt),
                 psnr_gpu_vs_oracle_db=round(psnr, 2), max_abs_gpu_vs_oracle=float(np.abs(refc - got).max()))
+
+
+def train_leg(args, sc, opt, agg, cloud, rnd, cam, dev, steps=5, warmup=2):
+    """SURVEY 8d config C3 (fwd+bwd): one 56x56 = 3136-ray training batch (random window, jittered depths, patch drop) through
+    the HIP forward + backward with the shipped loss terms.  Reported beside the headline metric, never part of `value`."""
+    from hybridneuralrendering_amd import scenes
+    from hybridneuralrendering_amd.train import TrainPath, render_train
+    old = opt.is_train
+    opt.is_train = 1
+    try:
+        path = TrainPath(rnd)
+        rng = np.random.default_rng(17)
+        x0 = int(rng.integers(args.margin, sc.w - args.margin - 56)); y0 = int(rng.integers(args.margin, sc.h - args.margin - 56))
+        px, py = np.meshgrid(np.arange(x0, x0 + 56), np.arange(y0, y0 + 56), indexing="ij")
+        pix = np.stack([px, py], axis=-1).reshape(-1, 2).astype(np.int32)
+        raydir = torch.from_numpy(scenes.camera_rays(pix, sc.intrinsic, sc.c2w)).to(dev)
+        gt = torch.rand((raydir.shape[0], 3), device=dev)
+        leaves = [t.clone().requires_grad_(True) for t in (cloud.emb, cloud.conf, cloud.dir, cloud.color)]
+        for prm in agg.parameters():
+            prm.requires_grad_(True)
+        def one(ev=None):
+            for t in leaves:
+                t.grad = None
+            agg.zero_grad(set_to_none=True)
+            if ev: ev[0].record()
+            out = render_train(path, agg, cloud.xyz, leaves[0], leaves[1], leaves[2], leaves[3], raydir, cam["campos"], cam["camrot"],
+                               cam["bg"], sc.near, sc.far, cam["c2w_nearest"], cam["campos_nearest"], cam["intrinsic"], cam["images"])
+            if ev: ev[1].record()
+            m = out["ray_mask"] > 0
+            val = torch.clamp(out["conf_coefficient"][m], 1e-3, 1 - 1e-3)
+            loss = torch.nn.functional.mse_loss(out["coarse_raycolor"][m], gt[m]) + 1e-4 * torch.mean(torch.log(val) + torch.log(1 - val))
+            loss.backward()
+            if ev: ev[2].record()
+            return out
+        for _ in range(warmup):
+            out = one()
+        torch.cuda.synchronize()
+        evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
+        t0 = time.perf_counter()
+        for i in range(steps):
+            out = one(evs[i])
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        fwd = sum(e[0].elapsed_time(e[1]) for e in evs) / steps
+        bwd = sum(e[1].elapsed_time(e[2]) for e in evs) / steps
+        c = out["counts"].cpu().numpy()
+        return dict(workload="C3: 56x56 = %d rays, fwd (train mode) + bwd, shipped loss" % raydir.shape[0], ms_per_step=round(dt * 1e3, 3),
+                    rays_per_s=round(raydir.shape[0] / dt, 1), fwd_ms=round(fwd, 3), loss_bwd_ms=round(bwd, 3),
+                    neighbour_rows=int(c[3]), valid_samples=int(c[6]), steps=steps)
+    finally:
+        opt.is_train = old
+        for prm in agg.parameters():
+            prm.requires_grad_(False)
 
 
 def main():
@@ -226,6 +280,9 @@ def main():
         cpu = None
         if not args.no_cpu_baseline:
             cpu = cpu_baseline(args, sc, opt, agg, cam, col.cpu().numpy())
+        train = None
+        if world == 1 and not args.no_train_leg:
+            train = train_leg(args, sc, opt, agg, cloud, rnd, cam, dev)
         res = {
             "metric": "rays/sec (fwd render) scene0241_01 at 1/2/4/8 GPU; PSNR delta vs ref",
             "value": world * R * args.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -238,7 +295,7 @@ def main():
                        "parallelism": "ray-sharded x%d, one RCCL gather" % world},
             "roofline": roof, "roofline_query": roof_q, "cpu_baseline": cpu,
             "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
-            "amortised_ms": amort, "grid": rnd.querier.last_grid_stats,
+            "amortised_ms": amort, "train_step": train, "grid": rnd.querier.last_grid_stats,
         }
         if counts is not None:
             res["counts"] = {k: int(counts[v]) for k, v in CNT.items()}

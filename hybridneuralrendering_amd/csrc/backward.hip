@@ -150,13 +150,27 @@ __global__ __launch_bounds__(256) void final_color_bwd_kernel(FinalBwdArgs a)
             if (c < 45) a.gY[(size_t)s * a.ldgy + c] = dx;
         }
     }
+    // the 4 waves of the block add up in LDS first: one atomic per block and address
+    __shared__ float s_w[4][6][64];
+    __shared__ float s_b[4][3];
+    const int wid = threadIdx.x >> 6;
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) atomicAdd(a.g_w_fin + j * 128 + lane + 64 * h, aw[h][j]);
+        for (int j = 0; j < 3; ++j) s_w[wid][h * 3 + j][lane] = aw[h][j];
     if (lane == 0)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) atomicAdd(a.g_b_fin + j, ab[j]);
+        for (int j = 0; j < 3; ++j) s_b[wid][j] = ab[j];
+    __syncthreads();
+    if (wid == 0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                atomicAdd(a.g_w_fin + j * 128 + lane + 64 * h,
+                          s_w[0][h * 3 + j][lane] + s_w[1][h * 3 + j][lane] + s_w[2][h * 3 + j][lane] + s_w[3][h * 3 + j][lane]);
+        if (lane < 3) atomicAdd(a.g_b_fin + lane, s_b[0][lane] + s_b[1][lane] + s_b[2][lane] + s_b[3][lane]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ merge
@@ -220,11 +234,23 @@ __global__ __launch_bounds__(256) void merge_bwd_kernel(MergeBwdArgs a)
         }
         if (lane < 45) a.gCF[(size_t)s * a.ldgcf + lane] += a.gX7[(size_t)s * a.ldg7 + lane];
     }
-    atomicAdd(a.g_w_last + lane, acc_w);
-    if (lane == 0) atomicAdd(a.g_b_last, acc_b);
+    __shared__ float s_w[4][64];
+    __shared__ float s_b[4];
+    const int wid = threadIdx.x >> 6;
+    s_w[wid][lane] = acc_w;
+    if (lane == 0) s_b[wid] = acc_b;
+    __syncthreads();
+    if (wid == 0) {
+        atomicAdd(a.g_w_last + lane, s_w[0][lane] + s_w[1][lane] + s_w[2][lane] + s_w[3][lane]);
+        if (lane == 0) atomicAdd(a.g_b_last, s_b[0] + s_b[1] + s_b[2] + s_b[3]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ pixel gather + upsample
+// Two steps, so that the many samples of a training batch that reproject into the same few pyramid cells do not serialise on
+// atomics: (1) every (view, sample) row adds its 42 feature-gradient columns to ITS full-resolution pixel of g_featmap and
+// widens the per-view bounding box of touched pixels; (2) per pyramid level a gather kernel applies the transpose of
+// F.interpolate(bilinear, align_corners=False) over the destination pixels inside the bounding box -- no atomics, fixed order.
 struct ProjBwdArgs {
     const float *loc_w;
     const int32_t *vs_item;
@@ -233,8 +259,8 @@ struct ProjBwdArgs {
     int V, H, W, cap;
     const float *gFa; int lda;                           // [V*cap, lda] d image-feature columns (45)
     const float *gFb; int ldb;                           // second source (d rows of the merge-weight MLP), may be NULL
-    float *g1, *g2, *g3;                                 // planar grads of the pyramid levels [V,6,H1,W1] [V,12,H2,W2] [V,24,H3,W3]
-    int H1, W1, H2, W2, H3, W3;
+    float *g_fm;                                         // [V,H,W,48] zero-initialised
+    int32_t *bbox;                                       // [V,4] = min x, min y, max x, max y; initialised {W, H, -1, -1}
 };
 
 __global__ __launch_bounds__(256) void proj_rows_bwd_kernel(ProjBwdArgs a)
@@ -261,27 +287,54 @@ __global__ __launch_bounds__(256) void proj_rows_bwd_kernel(ProjBwdArgs a)
     const int py = (fy > -2.0e9f && fy < 2.0e9f) ? (int)fy : -1;
     if (px < 0 || px >= a.W || py < 0 || py >= a.H) return;      // masked row: reads the zeroed pixel (0,0), no gradient
     if (px == 0 && py == 0) return;                              // feature at (0,0) is the constant 0 (:1089)
+    if (lane == 0) {
+        int32_t *bb = a.bbox + 4 * v;
+        if (px < bb[0]) atomicMin(bb, px);
+        if (py < bb[1]) atomicMin(bb + 1, py);
+        if (px > bb[2]) atomicMax(bb + 2, px);
+        if (py > bb[3]) atomicMax(bb + 3, py);
+    }
     if (lane < 3 || lane >= 45) return;                          // RGB channels are inputs
     const size_t row = (size_t)v * a.cap + s;
     float g = a.gFa[row * a.lda + lane];
     if (a.gFb) g += a.gFb[row * a.ldb + lane];
-    float *gp;
-    int Hs, Ws;
-    if (lane < 9) { Hs = a.H1; Ws = a.W1; gp = a.g1 + ((size_t)v * 6 + (lane - 3)) * Hs * Ws; }
-    else if (lane < 21) { Hs = a.H2; Ws = a.W2; gp = a.g2 + ((size_t)v * 12 + (lane - 9)) * Hs * Ws; }
-    else { Hs = a.H3; Ws = a.W3; gp = a.g3 + ((size_t)v * 24 + (lane - 21)) * Hs * Ws; }
-    // transpose of bilinear_at (aggregate.hip): same source coordinates and weights
-    const float sy = (float)Hs / (float)a.H, sx = (float)Ws / (float)a.W;
-    float qy = ((float)py + 0.5f) * sy - 0.5f, qx = ((float)px + 0.5f) * sx - 0.5f;
-    if (qy < 0.f) qy = 0.f;
-    if (qx < 0.f) qx = 0.f;
-    const int y0 = (int)qy, x0 = (int)qx;
-    const int y1 = y0 + (y0 < Hs - 1 ? 1 : 0), x1 = x0 + (x0 < Ws - 1 ? 1 : 0);
-    const float ly = qy - (float)y0, lx = qx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
-    atomicAdd(gp + (size_t)y0 * Ws + x0, g * hy * hx);
-    atomicAdd(gp + (size_t)y0 * Ws + x1, g * hy * lx);
-    atomicAdd(gp + (size_t)y1 * Ws + x0, g * ly * hx);
-    atomicAdd(gp + (size_t)y1 * Ws + x1, g * ly * lx);
+    atomicAdd(a.g_fm + (((size_t)v * a.H + py) * a.W + px) * 48 + lane, g);
+}
+
+// transpose of bilinear_at (aggregate.hip): one lane per (view, source cell, channel of the level), channel fastest
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const float *__restrict__ g_fm, const int32_t *__restrict__ bbox, int V, int H, int W,
+                                                           int Hs, int Ws, int C, int c0, float *__restrict__ g_level /*[V,C,Hs,Ws]*/)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)V * Hs * Ws * C) return;
+    const int cl = (int)(idx % C), xs = (int)((idx / C) % Ws), ys = (int)((idx / ((int64_t)C * Ws)) % Hs), v = (int)(idx / ((int64_t)C * Ws * Hs));
+    const int bx0 = bbox[4 * v], by0 = bbox[4 * v + 1], bx1 = bbox[4 * v + 2], by1 = bbox[4 * v + 3];
+    if (bx1 < bx0) return;
+    const float sy = (float)Hs / (float)H, sx = (float)Ws / (float)W;
+    // destination pixels that can touch this source cell: source coordinate within (ys - 1, ys + 1)
+    const int ry = (H + Hs - 1) / Hs, rx = (W + Ws - 1) / Ws;
+    int ylo = (ys - 1) * ry - 1, yhi = (ys + 2) * ry + 1, xlo = (xs - 1) * rx - 1, xhi = (xs + 2) * rx + 1;
+    ylo = ylo < by0 ? by0 : ylo; yhi = yhi > by1 + 1 ? by1 + 1 : yhi;
+    xlo = xlo < bx0 ? bx0 : xlo; xhi = xhi > bx1 + 1 ? bx1 + 1 : xhi;
+    float acc = 0.f;
+    for (int y = ylo; y < yhi; ++y) {
+        float qy = ((float)y + 0.5f) * sy - 0.5f;
+        if (qy < 0.f) qy = 0.f;
+        const int y0 = (int)qy, y1 = y0 + (y0 < Hs - 1 ? 1 : 0);
+        const float ly = qy - (float)y0;
+        const float wy = (y0 == ys ? 1.f - ly : 0.f) + (y1 == ys ? ly : 0.f);
+        if (wy == 0.f) continue;
+        for (int x = xlo; x < xhi; ++x) {
+            float qx = ((float)x + 0.5f) * sx - 0.5f;
+            if (qx < 0.f) qx = 0.f;
+            const int x0 = (int)qx, x1 = x0 + (x0 < Ws - 1 ? 1 : 0);
+            const float lx = qx - (float)x0;
+            const float wx = (x0 == xs ? 1.f - lx : 0.f) + (x1 == xs ? lx : 0.f);
+            if (wx == 0.f) continue;
+            acc += wy * wx * g_fm[(((size_t)v * H + y) * W + x) * 48 + c0 + cl];
+        }
+    }
+    g_level[(((size_t)v * C + cl) * Hs + ys) * Ws + xs] = acc;
 }
 
 // ------------------------------------------------------------------------------------------------ 3x3 convolutions
@@ -414,9 +467,18 @@ __global__ __launch_bounds__(256) void ksum_bwd_kernel(KsumBwdArgs a)
             acc_b += da;
         }
     }
-    atomicAdd(a.g_alpha_w + 4 * lane, acc.x); atomicAdd(a.g_alpha_w + 4 * lane + 1, acc.y);
-    atomicAdd(a.g_alpha_w + 4 * lane + 2, acc.z); atomicAdd(a.g_alpha_w + 4 * lane + 3, acc.w);
-    if (lane == 0) atomicAdd(a.g_alpha_b, acc_b);
+    __shared__ float4 s_w[4][64];
+    __shared__ float s_b[4];
+    const int wid = threadIdx.x >> 6;
+    s_w[wid][lane] = acc;
+    if (lane == 0) s_b[wid] = acc_b;
+    __syncthreads();
+    if (wid == 0) {
+        const float4 p0 = s_w[0][lane], p1 = s_w[1][lane], p2 = s_w[2][lane], p3 = s_w[3][lane];
+        atomicAdd(a.g_alpha_w + 4 * lane, p0.x + p1.x + p2.x + p3.x); atomicAdd(a.g_alpha_w + 4 * lane + 1, p0.y + p1.y + p2.y + p3.y);
+        atomicAdd(a.g_alpha_w + 4 * lane + 2, p0.z + p1.z + p2.z + p3.z); atomicAdd(a.g_alpha_w + 4 * lane + 3, p0.w + p1.w + p2.w + p3.w);
+        if (lane == 0) atomicAdd(a.g_alpha_b, s_b[0] + s_b[1] + s_b[2] + s_b[3]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ gather
@@ -585,7 +647,7 @@ using namespace hnr;
 static int persistent_blocks(int64_t n_waves_wanted)
 {
     int64_t b = (n_waves_wanted + 3) / 4;
-    if (b > 2048) b = 2048;
+    if (b > 512) b = 512;                           // 2 blocks per CU; every block ends with one atomic per weight
     if (b < 1) b = 1;
     return (int)b;
 }
@@ -654,21 +716,26 @@ static inline int conv_out(int n) { return (n + 2 - 3) / 2 + 1; }
 
 extern "C" int hnr_proj_rows_bwd(const float *d_sample_loc_w, const int32_t *d_vs_item, const int64_t *d_counts, const float *d_w2c,
                                  const float *d_intrinsic, int V, int H, int W, int cap_samples, const float *d_gFa, int lda,
-                                 const float *d_gFb, int ldb, float *d_g_pyramid, void *stream)
+                                 const float *d_gFb, int ldb, float *d_g_featmap, int32_t *d_bbox, float *d_g_pyramid, void *stream)
 {
-    if (!d_sample_loc_w || !d_vs_item || !d_counts || !d_w2c || !d_intrinsic || !d_gFa || !d_g_pyramid || V <= 0 || H <= 1 || W <= 1 ||
-        lda < 45 || (d_gFb && ldb < 45)) {
+    if (!d_sample_loc_w || !d_vs_item || !d_counts || !d_w2c || !d_intrinsic || !d_gFa || !d_g_featmap || !d_bbox || !d_g_pyramid || V <= 0 ||
+        H <= 1 || W <= 1 || lda < 45 || (d_gFb && ldb < 45)) {
         set_error("hnr_proj_rows_bwd: bad argument"); return HNR_ERR_BADARG;
     }
     if (cap_samples <= 0) return HNR_OK;
+    hipStream_t st = (hipStream_t)stream;
     ProjBwdArgs a;
     a.loc_w = d_sample_loc_w; a.vs_item = d_vs_item; a.counts = reinterpret_cast<const unsigned long long *>(d_counts);
     a.w2c = d_w2c; a.Kmat = d_intrinsic; a.V = V; a.H = H; a.W = W; a.cap = cap_samples; a.gFa = d_gFa; a.lda = lda; a.gFb = d_gFb; a.ldb = ldb;
-    a.H1 = conv_out(H); a.W1 = conv_out(W); a.H2 = conv_out(a.H1); a.W2 = conv_out(a.W1); a.H3 = conv_out(a.H2); a.W3 = conv_out(a.W2);
+    a.g_fm = d_g_featmap; a.bbox = d_bbox;
+    proj_rows_bwd_kernel<<<cdiv((int64_t)V * cap_samples * 64, 256), 256, 0, st>>>(a);
+    const int H1 = conv_out(H), W1 = conv_out(W), H2 = conv_out(H1), W2 = conv_out(W1), H3 = conv_out(H2), W3 = conv_out(W2);
     // same layout as the forward scratch of hnr_image_features: s1a s1 s2a s2 s3a s3
-    const size_t n1 = (size_t)V * 6 * a.H1 * a.W1, n2 = (size_t)V * 12 * a.H2 * a.W2, n3 = (size_t)V * 24 * a.H3 * a.W3;
-    a.g1 = d_g_pyramid + n1; a.g2 = d_g_pyramid + 2 * n1 + n2; a.g3 = d_g_pyramid + 2 * n1 + 2 * n2 + n3;
-    proj_rows_bwd_kernel<<<cdiv((int64_t)V * cap_samples * 64, 256), 256, 0, (hipStream_t)stream>>>(a);
+    const size_t n1 = (size_t)V * 6 * H1 * W1, n2 = (size_t)V * 12 * H2 * W2, n3 = (size_t)V * 24 * H3 * W3;
+    float *g1 = d_g_pyramid + n1, *g2 = d_g_pyramid + 2 * n1 + n2, *g3 = d_g_pyramid + 2 * n1 + 2 * n2 + n3;
+    upsample_bwd_kernel<<<cdiv((int64_t)n1, 256), 256, 0, st>>>(d_g_featmap, d_bbox, V, H, W, H1, W1, 6, 3, g1);
+    upsample_bwd_kernel<<<cdiv((int64_t)n2, 256), 256, 0, st>>>(d_g_featmap, d_bbox, V, H, W, H2, W2, 12, 9, g2);
+    upsample_bwd_kernel<<<cdiv((int64_t)n3, 256), 256, 0, st>>>(d_g_featmap, d_bbox, V, H, W, H3, W3, 24, 21, g3);
     HNR_LAUNCH_CHECK();
     return HNR_OK;
 }

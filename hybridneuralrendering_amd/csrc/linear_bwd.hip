@@ -91,22 +91,27 @@ __global__ __launch_bounds__(64) void linear_wgrad_kernel(const float *__restric
     }
 }
 
-__global__ void linear_wgrad_reduce_kernel(const float *__restrict__ partial, const float *__restrict__ bias_partial, int P, int Np, int Kp,
-                                           int N, int K, float *__restrict__ dW, int lddw, float *__restrict__ db, int accumulate)
+// 8 lanes per output element, each adding every 8th partition, then an xor-shuffle tree: fixed order, deterministic
+__global__ __launch_bounds__(256) void linear_wgrad_reduce_kernel(const float *__restrict__ partial, const float *__restrict__ bias_partial,
+                                                                  int P, int Np, int Kp, int N, int K, float *__restrict__ dW, int lddw,
+                                                                  float *__restrict__ db, int accumulate)
 {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int idx = t >> 3, sub = t & 7;
+    float s = 0.f;
+    float *o = nullptr;
     if (idx < N * K) {
         const int n = idx / K, k = idx - n * K;
-        float s = 0.f;
-        for (int p = 0; p < P; ++p) s += partial[((size_t)p * Np + n) * Kp + k];
-        float *o = dW + (size_t)n * lddw + k;
-        *o = accumulate ? *o + s : s;
+        const float *src = partial + (size_t)n * Kp + k;
+        for (int p = sub; p < P; p += 8) s += src[(size_t)p * Np * Kp];
+        o = dW + (size_t)n * lddw + k;
     } else if (db && idx < N * K + N) {
         const int n = idx - N * K;
-        float s = 0.f;
-        for (int p = 0; p < P; ++p) s += bias_partial[(size_t)p * Np + n];
-        db[n] = accumulate ? db[n] + s : s;
+        for (int p = sub; p < P; p += 8) s += bias_partial[(size_t)p * Np + n];
+        o = db + n;
     }
+    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+    if (o && sub == 0) *o = accumulate ? *o + s : s;
 }
 
 static void wgrad_plan(int M, int N, int K, int *P, int *rows, int *Np, int *Kp)
@@ -151,7 +156,7 @@ extern "C" int hnr_linear_f32_wgrad(const float *d_dZ, int ldz, const float *d_X
     float *partial = d_scratch, *bias_partial = d_scratch + (size_t)P * Np * Kp;
     dim3 grid(P, Np / 128, Kp / 128);
     linear_wgrad_kernel<<<grid, 64, 0, st>>>(d_dZ, ldz, d_X, ldx, M, rows, Np, Kp, partial, d_db ? bias_partial : nullptr);
-    linear_wgrad_reduce_kernel<<<cdiv((int64_t)N * K + N, 256), 256, 0, st>>>(partial, bias_partial, P, Np, Kp, N, K, d_dW, lddw, d_db, accumulate);
+    linear_wgrad_reduce_kernel<<<cdiv(((int64_t)N * K + N) * 8, 256), 256, 0, st>>>(partial, bias_partial, P, Np, Kp, N, K, d_dW, lddw, d_db, accumulate);
     HNR_LAUNCH_CHECK();
     return HNR_OK;
 }

@@ -63,6 +63,7 @@ class TrainPath:
         self.agg = renderer.agg
         self.opt = renderer.opt
         self._pt_key, self._pt = None, None
+        self._bbox0, self._bbox_key = None, None
 
     # transposed weights for the input-gradient GEMMs, cached with the forward pack
     def packed_t(self):
@@ -271,8 +272,14 @@ class TrainPath:
             del dZ, dZ1, gZ3
             # 6. pixel gather + upsample + conv pyramid
             g_pyr = torch.zeros_like(S.fm_scratch)
+            g_fm = z(V, S.H, S.W, 48)
+            if self._bbox0 is None or self._bbox_key != (V, S.H, S.W, dev):
+                self._bbox0 = torch.tensor([[S.W, S.H, -1, -1]] * V, dtype=torch.int32, device=dev)
+                self._bbox_key = (V, S.H, S.W, dev)
+            bbox = self._bbox0.clone()
             _lib.check(L.hnr_proj_rows_bwd(p(loc_w), p(S.vs_item), p(counts), p(S.w2c), p(S.Kn), V, S.H, S.W, nS, p(gF), 48, p(gX6), 48,
-                                           p(g_pyr), st()), "hnr_proj_rows_bwd")
+                                           p(g_fm), p(bbox), p(g_pyr), st()), "hnr_proj_rows_bwd")
+            del g_fm
             conv_names = [("aux_block_s%d.%d" % (lvl, i)) for lvl in (1, 2, 3) for i in (0, 2)]
             wp = (ctypes.c_void_p * 6)(*[tt.data_ptr() for tt in pk["conv_w"]])
             gw = (ctypes.c_void_p * 6)(*[ag[n + ".weight"].data_ptr() for n in conv_names])

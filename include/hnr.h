@@ -321,11 +321,13 @@ int hnr_merge_bwd(const float *d_X6, int ld6, const float *d_Hm, int ldh, const 
                   void *stream);
 
 /* pixel gather (:1077-1089, :1193) + F.interpolate (:1064-1067) transposed: the rows' image-feature gradients (two sources
- * added: d_gFa from hnr_merge_bwd, optional d_gFb from the merge-weight MLP's first layer) are scattered with the bilinear
- * weights into d_g_pyramid, a ZERO-INITIALISED buffer laid out like the forward scratch of hnr_image_features. */
+ * added: d_gFa from hnr_merge_bwd, optional d_gFb from the merge-weight MLP's first layer) are first added to their pixel
+ * of d_g_featmap ([V,H,W,48], ZERO-INITIALISED; d_bbox int32[V,4] initialised to {W,H,-1,-1} receives the touched
+ * rectangle), then gathered with the bilinear weights into the s1/s2/s3 slots of d_g_pyramid, a ZERO-INITIALISED buffer
+ * laid out like the forward scratch of hnr_image_features. */
 int hnr_proj_rows_bwd(const float *d_sample_loc_w, const int32_t *d_vs_item, const int64_t *d_counts, const float *d_w2c,
                       const float *d_intrinsic, int V, int H, int W, int cap_samples, const float *d_gFa, int lda,
-                      const float *d_gFb, int ldb, float *d_g_pyramid, void *stream);
+                      const float *d_gFb, int ldb, float *d_g_featmap, int32_t *d_bbox, float *d_g_pyramid, void *stream);
 
 /* aux_block_s1..3 (:1047-1063): d_scratch is the forward scratch (activations), d_g_pyramid as above (used as workspace);
  * g_conv_w / g_conv_b: HOST arrays of 6 device pointers, atomics. */
