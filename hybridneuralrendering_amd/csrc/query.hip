@@ -145,6 +145,38 @@ struct KBuf {
         for (int i = 0; i < K; ++i) { d2[i] = 0.f; id[i] = -1; }
         kid = 0; far_ind = 0; far2 = 0.f;
     }
+    // The same rule without divergent branches (selects only; the re-scan for the new farthest entry runs when any lane of
+    // the wave replaced one): `ok` = this lane really has a candidate inside the radius.
+    __device__ __forceinline__ void offer_sel(float v, int p, bool ok)
+    {
+        const bool full = kid >= K;
+        const bool ins = ok && (!full || v < far2);
+        const int wp = full ? far_ind : kid;
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            const bool sel = ins && i == wp;
+            d2[i] = sel ? v : d2[i];
+            id[i] = sel ? p : id[i];
+        }
+        const bool grow = ok && !full && v > far2;             // filling phase: track the farthest entry (:497-500)
+        far2 = grow ? v : far2;
+        far_ind = grow ? kid : far_ind;
+        const bool repl = ins && full;
+        if (__builtin_amdgcn_ballot_w64(repl) != 0ull) {        // wave-uniform
+            // (:506-511) far2 = v, then the first strictly larger entry wins, progressively: the result is the FIRST position of
+            // the maximum if the maximum exceeds v, else the replaced slot itself (the entries include v at far_ind)
+            float mx = d2[0];
+#pragma unroll
+            for (int i = 1; i < K; ++i) mx = fmaxf(mx, d2[i]);
+            int ni = K - 1;
+#pragma unroll
+            for (int i = K - 2; i >= 0; --i) ni = d2[i] == mx ? i : ni;
+            ni = mx > v ? ni : far_ind;
+            far2 = repl ? mx : far2;
+            far_ind = repl ? ni : far_ind;
+        }
+        kid += ok ? 1 : 0;
+    }
     // reference :494-513
     __device__ __forceinline__ void offer(float v, int p)
     {
@@ -351,6 +383,140 @@ __global__ __launch_bounds__(256) void knn2_kernel(GridView g, const int32_t *__
             s_st[0][threadIdx.x] + s_st[1][threadIdx.x] + s_st[2][threadIdx.x] + s_st[3][threadIdx.x];
 }
 
+// ------------------------------------------------------------------------------------------------
+// k-NN, pipelined (K = 8, 3x3x3, the shipped configuration).  Same visiting order and insertion rule as knn_kernel /
+// knn2_kernel / the oracle -- results are bit-identical -- but the candidate records are no longer fetched one dependent
+// load per loop trip (rocprofv3: ~1 us per trip and wave slot = one exposed L2/HBM round trip, 0.9 ms per frame):
+//  pass 1: per x-plane, 9 brick records in flight, then the 9 {start,count} records of the occupied cells in flight; each
+//          cell's list is parked in LDS as one word (start << 6 | count; P <= 63, N < 2^26 checked by the launcher);
+//  pass 2: per shell, an address generator walks the occupied cells and a 4-deep register ring keeps four candidate
+//          loads in flight ahead of the insertion; stepping to the next cell costs no loop trip; the insertion is select-only.
+// After this the kernel is VALU-bound on the insertion rule (rocprofv3 --pmc: 303 M VALU wave-instructions per frame = 0.56 ms of
+// issue time on 1024 SIMDs, SQ_WAIT_INST_ANY 17 % of the wave cycles).  Measured and dropped on top of it (profiles/README.md):
+// re-dealing a block's samples to lanes by candidate count + one stream over both shells (lane slots 215 M -> 132 M, same
+// time: the extra bookkeeping costs what the idle lanes did); 4-record chunks per trip (1.2x slower: more slots, more loads).
+template <int K>
+__global__ __launch_bounds__(256) void knn3_kernel(GridView g, const int32_t *__restrict__ work, const float *__restrict__ loc,
+                                                   int SR, float radius2, int layers, int32_t *__restrict__ pidx,
+                                                   int8_t *__restrict__ ray_mask, const unsigned long long *__restrict__ counts,
+                                                   unsigned long long *__restrict__ block_stats)
+{
+    __shared__ unsigned long long s_st[4][4];
+    __shared__ uint32_t s_cell[27][256];                      // [cell][thread]: conflict-free (consecutive lanes, consecutive banks)
+    const int n = (int)counts[HNR_CNT_SAMPLES];
+    unsigned n_cells = 0, n_cand = 0, n_nb = 0, n_sv = 0;
+    for (int w = blockIdx.x * blockDim.x + threadIdx.x; w < n; w += gridDim.x * blockDim.x) {
+        const int item = work[w];
+        const float cx = loc[3 * (size_t)item], cy = loc[3 * (size_t)item + 1], cz = loc[3 * (size_t)item + 2];
+        const int fx = cell_coord(cx, g.ox, g.cx), fy = cell_coord(cy, g.oy, g.cy), fz = cell_coord(cz, g.oz, g.cz);
+        uint32_t occ = 0, occ_nz = 0;                          // occupied cells / those that list at least one point
+        unsigned cand0 = 0, cand1 = 0;
+#pragma unroll 1
+        for (int xp = 0; xp < 3; ++xp) {
+            uint32_t slot[9];
+            uint32_t ob = 0, onz = 0;
+#pragma unroll
+            for (int yz = 0; yz < 9; ++yz) {
+                const int x = xp - 1, y = yz / 3 - 1, z = yz % 3 - 1;
+                const int vx = fx + x, vy = fy + y, vz = fz + z;
+                const bool inb = in_bounds(g, vx, vy, vz);
+                const int qx = inb ? vx : fx, qy = inb ? vy : fy, qz = inb ? vz : fz;     // clamp: the load is unconditional
+                const uint4 rec = g.occ_rec[brick_word(g, qx, qy, qz)];
+                const unsigned long long bb = (unsigned long long)rec.x | ((unsigned long long)rec.y << 32);
+                const int b = brick_bit(qx, qy, qz);
+                const bool o = inb && ((bb >> b) & 1ull);
+                ob |= (o ? 1u : 0u) << yz;
+                slot[yz] = o ? rec.z + (uint32_t)__popcll(bb & ((1ull << b) - 1ull)) : 0u;
+            }
+#pragma unroll
+            for (int yz = 0; yz < 9; ++yz) {
+                const int c = xp * 9 + yz;
+                const int2 rg = g.cell_rng[slot[yz]];                                     // slot 0 for empty cells: a valid record, unused
+                const bool o = (ob >> yz) & 1u;
+                s_cell[c][threadIdx.x] = o ? ((uint32_t)rg.x << 6) | (uint32_t)rg.y : 0u;
+                onz |= (o && rg.y > 0 ? 1u : 0u) << yz;         // (the slot-0 voxel is occupied but lists nothing, :366)
+                if (c == 13) cand0 = o ? (unsigned)rg.y : 0u; else cand1 += o ? (unsigned)rg.y : 0u;
+            }
+            occ |= ob << (xp * 9);
+            occ_nz |= onz << (xp * 9);
+        }
+        KBuf<K> kb;
+        kb.init();
+        auto run_shell = [&](uint32_t mg) {
+            int st = 0, cn = 0, jg = 0;
+            auto gen = [&]() -> int {                            // next candidate index of this lane, -1 when the shell is exhausted
+                const bool need = jg >= cn;
+                if (__builtin_amdgcn_ballot_w64(need) != 0ull) { // wave-uniform; every cell in the mask lists >= 1 point
+                    const int c = mg ? __ffs((int)mg) - 1 : 0;
+                    const uint32_t u = s_cell[c][threadIdx.x];
+                    st = need ? (int)(u >> 6) : st;
+                    cn = need ? (mg ? (int)(u & 63u) : 0) : cn;
+                    jg = need ? 0 : jg;
+                    mg = need ? (mg & (mg - 1)) : mg;
+                }
+                const int a = jg < cn ? st + jg : -1;
+                ++jg;
+                return a;
+            };
+            auto consume = [&](const float4 &p, bool have) {
+                const float xv = __fsub_rn(p.x, cx), yv = __fsub_rn(p.y, cy), zv = __fsub_rn(p.z, cz);
+                const float v = __fadd_rn(__fadd_rn(__fmul_rn(xv, xv), __fmul_rn(yv, yv)), __fmul_rn(zv, zv));
+                kb.offer_sel(v, __float_as_int(p.w), have && (radius2 == 0.f || v <= radius2));
+            };
+            // loads are UNCONDITIONAL (an exhausted lane re-reads record 0): no branch around them, so the four requests stay
+            // in flight across the insertion code instead of being waited for one by one
+            int a0 = gen(), a1 = gen(), a2 = gen(), a3 = gen();
+            float4 p0 = g.pts[a0 < 0 ? 0 : a0], p1 = g.pts[a1 < 0 ? 0 : a1], p2 = g.pts[a2 < 0 ? 0 : a2], p3 = g.pts[a3 < 0 ? 0 : a3];
+            while (__builtin_amdgcn_ballot_w64(a0 >= 0) != 0ull) {
+                consume(p0, a0 >= 0); a0 = gen(); p0 = g.pts[a0 < 0 ? 0 : a0];
+                consume(p1, a1 >= 0); a1 = gen(); p1 = g.pts[a1 < 0 ? 0 : a1];
+                consume(p2, a2 >= 0); a2 = gen(); p2 = g.pts[a2 < 0 ? 0 : a2];
+                consume(p3, a3 >= 0); a3 = gen(); p3 = g.pts[a3 < 0 ? 0 : a3];
+            }
+        };
+        const uint32_t m0 = occ & (1u << 13), m1 = occ & ~(1u << 13);
+        run_shell(occ_nz & (1u << 13));                         // shell 0 = the sample's own cell
+        n_cells += m0 ? 1u : 0u;
+        n_cand += cand0;
+        if (layers > 1 && kb.kid < K) {                         // reference: `if (kid >= K) break;` after a layer
+            run_shell(occ_nz & ~(1u << 13));
+            n_cells += (unsigned)__popc(m1);
+            n_cand += cand1;
+        }
+        {
+            int32_t *o = pidx + (size_t)item * K;
+            if constexpr ((K & 3) == 0) {
+#pragma unroll
+                for (int i = 0; i < K; i += 4)
+                    reinterpret_cast<int4 *>(o)[i >> 2] = make_int4(kb.id[i], kb.id[i + 1], kb.id[i + 2], kb.id[i + 3]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < K; ++i) o[i] = kb.id[i];
+            }
+        }
+        if (kb.kid > 0) {
+            ray_mask[item / SR] = 1;
+            n_nb += (unsigned)(kb.kid < K ? kb.kid : K);
+            ++n_sv;
+        }
+    }
+    unsigned long long t_cells = n_cells, t_cand = n_cand, t_nb = n_nb, t_sv = n_sv;
+    for (int o = 32; o > 0; o >>= 1) {
+        t_cells += __shfl_xor(t_cells, o);
+        t_cand += __shfl_xor(t_cand, o);
+        t_nb += __shfl_xor(t_nb, o);
+        t_sv += __shfl_xor(t_sv, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        const int wv = threadIdx.x >> 6;
+        s_st[wv][0] = t_cells; s_st[wv][1] = t_cand; s_st[wv][2] = t_nb; s_st[wv][3] = t_sv;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4)
+        block_stats[4 * (size_t)blockIdx.x + threadIdx.x] =
+            s_st[0][threadIdx.x] + s_st[1][threadIdx.x] + s_st[2][threadIdx.x] + s_st[3][threadIdx.x];
+}
+
 __global__ __launch_bounds__(256) void knn_finalize_kernel(const unsigned long long *__restrict__ block_stats, int nblocks,
                                                            unsigned long long *__restrict__ counts)
 {
@@ -513,10 +679,19 @@ extern "C" int hnr_march_query(const hnr_grid *g, const float *d_campos, const f
     nsamp_block_sum_kernel<<<nb, 1024, 0, st>>>(d_ray_nsamp, q->R, block_sums);
     worklist_kernel<<<nb, 1024, 0, st>>>(d_ray_nsamp, q->R, q->SR, block_sums, nb, d_work, cnt);
     HNR_LAUNCH_CHECK();
-    // K = 8 with a 3x3x3 neighbourhood (every shipped config): the two-pass kernel
-    if (q->K == 8 && layers <= 2 && !getenv("HNR_KNN_SINGLE_PASS")) {
+    // K = 8 with a 3x3x3 neighbourhood (every shipped config): the pipelined kernel (HNR_KNN=2 / =1 select the older ones)
+    static int knn_sel = -1;
+    if (knn_sel < 0) { const char *e = getenv("HNR_KNN"); knn_sel = e ? atoi(e) : 3; }
+    if (q->K == 8 && layers <= 2 && knn_sel != 1) {
         const int blocks = knn_blocks(max_items);
-        knn2_kernel<8><<<blocks, 256, 0, st>>>(v, d_work, d_sample_loc_w, q->SR, q->radius2, layers, d_sample_pidx, d_ray_mask, cnt, block_stats);
+        hnr_grid_params gp;
+        hnr_grid_stats gs;
+        hnr_grid_get_params(g, &gp);
+        hnr_grid_get_stats(g, &gs);
+        if (knn_sel == 3 && gp.P <= 63 && gs.n_points < (1ll << 26))
+            knn3_kernel<8><<<blocks, 256, 0, st>>>(v, d_work, d_sample_loc_w, q->SR, q->radius2, layers, d_sample_pidx, d_ray_mask, cnt, block_stats);
+        else
+            knn2_kernel<8><<<blocks, 256, 0, st>>>(v, d_work, d_sample_loc_w, q->SR, q->radius2, layers, d_sample_pidx, d_ray_mask, cnt, block_stats);
         knn_finalize_kernel<<<1, 256, 0, st>>>(block_stats, blocks, cnt);
         HNR_LAUNCH_CHECK();
         return HNR_OK;
