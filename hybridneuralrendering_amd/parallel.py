@@ -50,3 +50,81 @@ def render_sharded(render_fn, raydir, n_total=None, group=None):
     rays, (lo, hi) = shard_rays(raydir, world, rank)
     local = render_fn(rays)
     return gather_rows(local, raydir.shape[0] if n_total is None else n_total, group=group)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Training: the batch is sharded by WHOLE dilated patches, every rank runs forward +
+# backward on its rays with the replicated cloud and weights, and the gradients are summed so that both optimisers
+# (models/mvs_points_volumetric_model.py:94-104 in the reference) step identically on every rank.  The reference has no
+# counterpart: its DataParallel wrapper always runs on gpu_ids[0] only.
+
+def shard_patches(n_patches, patch_rays, world_size, rank):
+    """Ray range [lo, hi) of rank `rank` when `n_patches` patches of `patch_rays` rays each are dealt out as whole
+    patches (49 patches on 8 ranks -> 7,6,6,6,6,6,6,6), so the per-patch blur/argmin of the shell needs no halo."""
+    lo, hi = shard_bounds(n_patches, world_size, rank)
+    return lo * patch_rays, hi * patch_rays
+
+
+def loss_scale(n_local, n_total):
+    """A loss that is a MEAN over rays: each rank back-propagates mean_local * n_local / n_total and the summed gradients
+    equal those of the global mean."""
+    return float(n_local) / float(max(n_total, 1))
+
+
+def allreduce_gradients(tensors, group=None, bucket_bytes=64 << 20):
+    """In-place SUM over ranks of a list of gradient tensors, packed into a few large flat buckets: the network's 449 381
+    parameters are one 1.8 MB message (latency-bound); the dense point-buffer gradients (N x 39 floats) go as 64 MB ring
+    segments, which is what the point-to-point xGMI links like (per-link bound)."""
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    tensors = [t for t in tensors if t is not None]
+    i = 0
+    while i < len(tensors):
+        j, size = i, 0
+        while j < len(tensors) and (j == i or size + tensors[j].numel() * 4 <= bucket_bytes) and tensors[j].dtype == tensors[i].dtype:
+            size += tensors[j].numel() * 4
+            j += 1
+        if j == i + 1:
+            t = tensors[i]
+            if t.is_contiguous():
+                dist.all_reduce(t, group=group)
+            else:
+                c = t.contiguous()
+                dist.all_reduce(c, group=group)
+                t.copy_(c)
+        else:
+            flat = torch.cat([t.reshape(-1) for t in tensors[i:j]])
+            dist.all_reduce(flat, group=group)
+            off = 0
+            for t in tensors[i:j]:
+                t.copy_(flat[off:off + t.numel()].view_as(t))
+                off += t.numel()
+        i = j
+
+
+def allreduce_point_gradients_sparse(grad, touched, group=None):
+    """SUM over ranks of a point-buffer gradient [N, C] that is non-zero only on the rows `touched` (int64 ids, the points
+    this rank's batch referenced -- at most ~600 k of N = 2-4 M): all-gather (id, row) pairs and scatter-add locally instead
+    of moving N x C floats around the ring.  Returns the summed dense gradient (new tensor)."""
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return grad
+    world = dist.get_world_size(group)
+    n_local = torch.tensor([touched.numel()], dtype=torch.int64, device=grad.device)
+    counts = [torch.zeros_like(n_local) for _ in range(world)]
+    dist.all_gather(counts, n_local, group=group)
+    cap = int(max(int(c.item()) for c in counts))
+    C = grad.shape[1]
+    ids = torch.full((cap,), -1, dtype=torch.int64, device=grad.device)
+    rows = torch.zeros((cap, C), dtype=grad.dtype, device=grad.device)
+    ids[:touched.numel()] = touched
+    rows[:touched.numel()] = grad.index_select(0, touched)
+    all_ids = [torch.empty_like(ids) for _ in range(world)]
+    all_rows = [torch.empty_like(rows) for _ in range(world)]
+    dist.all_gather(all_ids, ids, group=group)
+    dist.all_gather(all_rows, rows, group=group)
+    out = torch.zeros_like(grad)
+    for i, r, c in zip(all_ids, all_rows, counts):
+        k = int(c.item())
+        if k:
+            out.index_add_(0, i[:k], r[:k])
+    return out

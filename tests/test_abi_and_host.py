@@ -134,3 +134,51 @@ def test_ray_sharding_world_size_2_gloo(tmp_path):
     outs = [p.communicate(timeout=180)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "SHARD_OK" in outs[0]
+
+
+_GRAD_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from hybridneuralrendering_amd import parallel
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+# whole patches per rank: 49 patches of 64 rays on 2 ranks -> 25 + 24
+lo, hi = parallel.shard_patches(49, 64, world, rank)
+assert (lo, hi) == ((0, 25 * 64) if rank == 0 else (25 * 64, 49 * 64))
+def grads(r):
+    g = torch.Generator().manual_seed(100 + r)
+    return [torch.randn(256, 284, generator=g), torch.randn(256, generator=g), torch.randn(3, 128, generator=g)[:, ::2], torch.randn(45, 90, generator=g)]
+mine = grads(rank)
+want = [a + b for a, b in zip(grads(0), grads(1))]
+parallel.allreduce_gradients(mine, bucket_bytes=300000)      # forces several buckets + a lone non-contiguous tensor
+for a, b in zip(mine, want):
+    assert torch.allclose(a, b, rtol=0, atol=1e-6)
+# sparse point-gradient exchange == dense sum
+N = 5000
+def pg(r):
+    g = torch.Generator().manual_seed(7 + r)
+    ids = torch.randperm(N, generator=g)[:300 + 100 * r].sort().values
+    d = torch.zeros(N, 32); d[ids] = torch.randn(ids.numel(), 32, generator=g)
+    return d, ids
+d, ids = pg(rank)
+s = parallel.allreduce_point_gradients_sparse(d, ids)
+assert torch.allclose(s, pg(0)[0] + pg(1)[0], rtol=0, atol=1e-6)
+assert abs(parallel.loss_scale(hi - lo, 49 * 64) - (hi - lo) / 3136.0) < 1e-12
+if rank == 0:
+    print("GRAD_OK")
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_gradient_allreduce_world_size_2_gloo(tmp_path):
+    script = tmp_path / "g.py"
+    script.write_text(_GRAD_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29614", WORLD_SIZE="2")
+    procs = []
+    for r in range(2):
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=180)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "GRAD_OK" in outs[0]
