@@ -74,7 +74,10 @@ SIGNATURES = {
     "hnr_composite_bwd": (_I, [_P] * 8 + [_I, _I, _I, _F, _I, _P, _P, _P]),
     "hnr_final_color_bwd": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _I, _P, _I, _P, _P, _P, _P]),
     "hnr_merge_bwd": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _I, _F, _P, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P]),
-    "hnr_proj_rows_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P]),
+    "hnr_proj_rows_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, ctypes.c_int64, _P]),
+    "hnr_sort_rows_scratch_bytes": (ctypes.c_int64, [ctypes.c_int64]),
+    "hnr_sort_rows_by_key": (_I, [_P, ctypes.c_int64, _P, _P, _P, ctypes.c_int64, _P]),
+    "hnr_segment_sum_rows": (_I, [_P, _I, _P, _I, _P, _P, ctypes.c_int64, _I, _P, ctypes.c_int64, _P]),
     "hnr_image_features_bwd": (_I, [_P, _I, _I, _I, ctypes.POINTER(_P), _F, _P, _P, ctypes.POINTER(_P), ctypes.POINTER(_P), _P]),
     "hnr_ksum_bwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _F, _P, _I, _P, _P, _P, _P]),
     "hnr_gather_rows_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P]),

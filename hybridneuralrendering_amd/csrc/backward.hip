@@ -247,58 +247,66 @@ __global__ __launch_bounds__(256) void merge_bwd_kernel(MergeBwdArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------ pixel gather + upsample
-// Two steps, so that the many samples of a training batch that reproject into the same few pyramid cells do not serialise on
-// atomics: (1) every (view, sample) row adds its 42 feature-gradient columns to ITS full-resolution pixel of g_featmap and
-// widens the per-view bounding box of touched pixels; (2) per pyramid level a gather kernel applies the transpose of
-// F.interpolate(bilinear, align_corners=False) over the destination pixels inside the bounding box -- no atomics, fixed order.
+// Three steps, so that the many samples of a training batch that reproject into the same few pixels / pyramid cells do not
+// serialise on atomics: (1) every (view, sample) row gets its full-resolution pixel index as a key and widens the per-view
+// bounding box of touched pixels; (2) the rows are summed per pixel into g_featmap (sort by key + running sums,
+// segment.hip); (3) per pyramid level a gather kernel applies the transpose of F.interpolate(bilinear,
+// align_corners=False) over the destination pixels inside the bounding box -- no atomics, fixed order.
 struct ProjBwdArgs {
     const float *loc_w;
     const int32_t *vs_item;
     const unsigned long long *counts;
     const float *w2c, *Kmat;
     int V, H, W, cap;
-    const float *gFa; int lda;                           // [V*cap, lda] d image-feature columns (45)
-    const float *gFb; int ldb;                           // second source (d rows of the merge-weight MLP), may be NULL
-    float *g_fm;                                         // [V,H,W,48] zero-initialised
+    int32_t *keys;                                       // [V*cap] out: pixel index (v*H + y)*W + x of the row, -1 = no gradient
     int32_t *bbox;                                       // [V,4] = min x, min y, max x, max y; initialised {W, H, -1, -1}
 };
 
 __global__ __launch_bounds__(256) void proj_rows_bwd_kernel(ProjBwdArgs a)
 {
-    const int lane = threadIdx.x & 63;
-    const int64_t wv = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    // one lane per (view, sample) row: pixel key; per-wave min/max of the touched pixels -> one atomic per wave and bound
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int n_valid = (int)a.counts[HNR_CNT_SAMPLES_VALID];
-    if (n_valid == 0) return;
-    const int v = (int)(wv / n_valid);
-    if (v >= a.V) return;
-    const int s = (int)(wv - (int64_t)v * n_valid);
-    const float *p = a.loc_w + (size_t)a.vs_item[s] * 3;
-    const float x = p[0], y = p[1], z = p[2];
-    const float *m = a.w2c + 16 * v;
-    float c[3];
+    const int v = n_valid > 0 ? (int)(t / n_valid) : a.V;
+    const bool live = v < a.V;
+    int px = -1, py = -1;
+    bool none = true;
+    if (live) {
+        const int s = (int)(t - (int64_t)v * n_valid);
+        const float *p = a.loc_w + (size_t)a.vs_item[s] * 3;
+        const float x = p[0], y = p[1], z = p[2];
+        const float *m = a.w2c + 16 * v;
+        float c[3];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) c[j] = x * m[4 * j] + y * m[4 * j + 1] + z * m[4 * j + 2] + m[4 * j + 3];
-    float i3[3];
+        for (int j = 0; j < 3; ++j) c[j] = x * m[4 * j] + y * m[4 * j + 1] + z * m[4 * j + 2] + m[4 * j + 3];
+        float i3[3];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) i3[j] = c[0] * a.Kmat[3 * j] + c[1] * a.Kmat[3 * j + 1] + c[2] * a.Kmat[3 * j + 2];
-    const float den = i3[2] + 1e-10f;
-    const float fx = i3[0] / den, fy = i3[1] / den;
-    const int px = (fx > -2.0e9f && fx < 2.0e9f) ? (int)fx : -1;
-    const int py = (fy > -2.0e9f && fy < 2.0e9f) ? (int)fy : -1;
-    if (px < 0 || px >= a.W || py < 0 || py >= a.H) return;      // masked row: reads the zeroed pixel (0,0), no gradient
-    if (px == 0 && py == 0) return;                              // feature at (0,0) is the constant 0 (:1089)
-    if (lane == 0) {
-        int32_t *bb = a.bbox + 4 * v;
-        if (px < bb[0]) atomicMin(bb, px);
-        if (py < bb[1]) atomicMin(bb + 1, py);
-        if (px > bb[2]) atomicMax(bb + 2, px);
-        if (py > bb[3]) atomicMax(bb + 3, py);
+        for (int j = 0; j < 3; ++j) i3[j] = c[0] * a.Kmat[3 * j] + c[1] * a.Kmat[3 * j + 1] + c[2] * a.Kmat[3 * j + 2];
+        const float den = i3[2] + 1e-10f;
+        const float fx = i3[0] / den, fy = i3[1] / den;
+        px = (fx > -2.0e9f && fx < 2.0e9f) ? (int)fx : -1;
+        py = (fy > -2.0e9f && fy < 2.0e9f) ? (int)fy : -1;
+        // masked row: reads the zeroed pixel (0,0), no gradient; the feature at (0,0) is the constant 0 (:1089)
+        none = px < 0 || px >= a.W || py < 0 || py >= a.H || (px == 0 && py == 0);
+        a.keys[(size_t)v * a.cap + s] = none ? -1 : (v * a.H + py) * a.W + px;
     }
-    if (lane < 3 || lane >= 45) return;                          // RGB channels are inputs
-    const size_t row = (size_t)v * a.cap + s;
-    float g = a.gFa[row * a.lda + lane];
-    if (a.gFb) g += a.gFb[row * a.ldb + lane];
-    atomicAdd(a.g_fm + (((size_t)v * a.H + py) * a.W + px) * 48 + lane, g);
+    // the lanes of a wave almost always belong to one view (rows are view-major): reduce for the first lane's view, the
+    // few lanes of another view fall back to their own atomics
+    const int v0 = __shfl(v, 0);
+    const bool mine = !none && v == v0;
+    int x0 = mine ? px : 0x7fffffff, y0 = mine ? py : 0x7fffffff, x1 = mine ? px : -1, y1 = mine ? py : -1;
+    for (int o = 32; o > 0; o >>= 1) {
+        x0 = min(x0, __shfl_xor(x0, o)); y0 = min(y0, __shfl_xor(y0, o));
+        x1 = max(x1, __shfl_xor(x1, o)); y1 = max(y1, __shfl_xor(y1, o));
+    }
+    if ((threadIdx.x & 63) == 0 && x1 >= 0) {
+        int32_t *bb = a.bbox + 4 * v0;
+        atomicMin(bb, x0); atomicMin(bb + 1, y0); atomicMax(bb + 2, x1); atomicMax(bb + 3, y1);
+    }
+    if (!none && v != v0) {
+        int32_t *bb = a.bbox + 4 * v;
+        atomicMin(bb, px); atomicMin(bb + 1, py); atomicMax(bb + 2, px); atomicMax(bb + 3, py);
+    }
 }
 
 // transpose of bilinear_at (aggregate.hip): one lane per (view, source cell, channel of the level), channel fastest
@@ -714,21 +722,37 @@ extern "C" int hnr_merge_bwd(const float *d_X6, int ld6, const float *d_Hm, int 
 
 static inline int conv_out(int n) { return (n + 2 - 3) / 2 + 1; }
 
+extern "C" int64_t hnr_sort_rows_scratch_bytes(int64_t M);
+extern "C" int hnr_sort_rows_by_key(const int32_t *d_keys, int64_t M, int32_t *d_keys_sorted, int32_t *d_perm, void *d_scratch,
+                                    int64_t scratch_bytes, void *stream);
+extern "C" int hnr_segment_sum_rows(const float *d_A, int lda, const float *d_B, int ldb, const int32_t *d_keys_sorted,
+                                    const int32_t *d_perm, int64_t M, int n_cols, float *d_dst, int64_t dst_stride, void *stream);
+
 extern "C" int hnr_proj_rows_bwd(const float *d_sample_loc_w, const int32_t *d_vs_item, const int64_t *d_counts, const float *d_w2c,
                                  const float *d_intrinsic, int V, int H, int W, int cap_samples, const float *d_gFa, int lda,
-                                 const float *d_gFb, int ldb, float *d_g_featmap, int32_t *d_bbox, float *d_g_pyramid, void *stream)
+                                 const float *d_gFb, int ldb, float *d_g_featmap, int32_t *d_bbox, float *d_g_pyramid,
+                                 int32_t *d_key_scratch, void *d_sort_scratch, int64_t sort_scratch_bytes, void *stream)
 {
-    if (!d_sample_loc_w || !d_vs_item || !d_counts || !d_w2c || !d_intrinsic || !d_gFa || !d_g_featmap || !d_bbox || !d_g_pyramid || V <= 0 ||
-        H <= 1 || W <= 1 || lda < 45 || (d_gFb && ldb < 45)) {
-        set_error("hnr_proj_rows_bwd: bad argument"); return HNR_ERR_BADARG;
+    if (!d_sample_loc_w || !d_vs_item || !d_counts || !d_w2c || !d_intrinsic || !d_gFa || !d_g_featmap || !d_bbox || !d_g_pyramid ||
+        !d_key_scratch || !d_sort_scratch || V <= 0 || H <= 1 || W <= 1 || lda < 48 || (lda & 3) || (d_gFb && (ldb < 48 || (ldb & 3))) ||
+        (int64_t)V * H * W >= (1ll << 31)) {
+        set_error("hnr_proj_rows_bwd: bad argument (row strides >= 48, multiples of 4)"); return HNR_ERR_BADARG;
     }
     if (cap_samples <= 0) return HNR_OK;
     hipStream_t st = (hipStream_t)stream;
+    const int64_t rows = (int64_t)V * cap_samples;
+    int32_t *keys = d_key_scratch, *keys_sorted = keys + rows, *perm = keys_sorted + rows;
     ProjBwdArgs a;
     a.loc_w = d_sample_loc_w; a.vs_item = d_vs_item; a.counts = reinterpret_cast<const unsigned long long *>(d_counts);
-    a.w2c = d_w2c; a.Kmat = d_intrinsic; a.V = V; a.H = H; a.W = W; a.cap = cap_samples; a.gFa = d_gFa; a.lda = lda; a.gFb = d_gFb; a.ldb = ldb;
-    a.g_fm = d_g_featmap; a.bbox = d_bbox;
-    proj_rows_bwd_kernel<<<cdiv((int64_t)V * cap_samples * 64, 256), 256, 0, st>>>(a);
+    a.w2c = d_w2c; a.Kmat = d_intrinsic; a.V = V; a.H = H; a.W = W; a.cap = cap_samples; a.keys = keys; a.bbox = d_bbox;
+    // rows past counts[SAMPLES_VALID] (none when cap_samples is exact) must not carry stale keys
+    HNR_HIP_CHECK(hipMemsetAsync(keys, 0xff, (size_t)rows * 4, st));
+    proj_rows_bwd_kernel<<<cdiv(rows, 256), 256, 0, st>>>(a);
+    HNR_LAUNCH_CHECK();
+    int rc = hnr_sort_rows_by_key(keys, rows, keys_sorted, perm, d_sort_scratch, sort_scratch_bytes, stream);
+    if (rc != HNR_OK) return rc;
+    rc = hnr_segment_sum_rows(d_gFa, lda, d_gFb, ldb, keys_sorted, perm, rows, 48, d_g_featmap, 48, stream);
+    if (rc != HNR_OK) return rc;
     const int H1 = conv_out(H), W1 = conv_out(W), H2 = conv_out(H1), W2 = conv_out(W1), H3 = conv_out(H2), W3 = conv_out(W2);
     // same layout as the forward scratch of hnr_image_features: s1a s1 s2a s2 s3a s3
     const size_t n1 = (size_t)V * 6 * H1 * W1, n2 = (size_t)V * 12 * H2 * W2, n3 = (size_t)V * 24 * H3 * W3;

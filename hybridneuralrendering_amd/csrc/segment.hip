@@ -1,0 +1,99 @@
+// Sum-by-key of gradient rows without per-element atomics: rows are ordered by key with a stable radix sort (rocprim), then
+// every wave walks a short run of the sorted order with a running sum and writes one result per key.
+//
+// Used by the backward pass for the two "many rows -> few destinations" reductions that torch autograd performs with
+// index_add / scatter kernels in the reference:
+//   * d(per-point table) = sum of block1's first-layer gradient rows over the rows that reference the point
+//     (gather of neural_points.py:709-720 transposed; 272 k rows of 256 floats -> ~10^5 points in a training batch);
+//   * d(feature map pixel) = sum of the image-feature gradient rows over the samples that reproject to the pixel
+//     (point_aggregators.py:1077-1089, :1193 transposed).
+// A direct atomicAdd scatter costs 1.06 ms / 1.15 ms per step for these two (rocprofv3, profiles/r01_train_kernel_stats.csv).
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+
+#include "hnr_common.h"
+
+namespace hnr {
+
+constexpr int SEG_CHUNK = 16;       // sorted entries per wave
+
+// dst[key * dst_stride + c] += sum over the rows with that key of (A[row, c] + B[row, c]),  c < n_cols (multiple of 4, <= 256).
+// Keys < 0 are skipped.  A key's rows may straddle two waves' runs, so the (few) results are added with atomics.
+__global__ __launch_bounds__(256) void segment_sum_rows_kernel(const float *__restrict__ A, int lda, const float *__restrict__ B, int ldb,
+                                                               const int32_t *__restrict__ keys_sorted, const int32_t *__restrict__ perm,
+                                                               int64_t M, int n_cols, float *__restrict__ dst, int64_t dst_stride)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t e0 = wave * SEG_CHUNK;
+    if (e0 >= M) return;
+    const int64_t e1 = e0 + SEG_CHUNK < M ? e0 + SEG_CHUNK : M;
+    const bool active = 4 * lane < n_cols;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int cur = keys_sorted[e0];
+    auto flush = [&](int key) {
+        if (key >= 0 && active) {
+            float *d = dst + (size_t)key * dst_stride + 4 * lane;
+            atomicAdd(d, acc.x); atomicAdd(d + 1, acc.y); atomicAdd(d + 2, acc.z); atomicAdd(d + 3, acc.w);
+        }
+        acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    for (int64_t e = e0; e < e1; ++e) {
+        const int key = keys_sorted[e];
+        if (key != cur) { flush(cur); cur = key; }
+        if (key >= 0 && active) {
+            const int row = perm[e];
+            float4 v = reinterpret_cast<const float4 *>(A + (size_t)row * lda)[lane];
+            if (B) {
+                const float4 w = reinterpret_cast<const float4 *>(B + (size_t)row * ldb)[lane];
+                v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+            }
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    }
+    flush(cur);
+}
+
+}  // namespace hnr
+
+using namespace hnr;
+
+extern "C" int64_t hnr_sort_rows_scratch_bytes(int64_t M)
+{
+    if (M <= 0) return 16;
+    size_t sz = 0;
+    rocprim::counting_iterator<int32_t> iota(0);
+    if (rocprim::radix_sort_pairs(nullptr, sz, (const int32_t *)nullptr, (int32_t *)nullptr, iota, (int32_t *)nullptr, (size_t)M, 0, 32,
+                                  (hipStream_t) nullptr) != hipSuccess)
+        return -1;
+    return (int64_t)sz + 16;
+}
+
+extern "C" int hnr_sort_rows_by_key(const int32_t *d_keys, int64_t M, int32_t *d_keys_sorted, int32_t *d_perm, void *d_scratch,
+                                    int64_t scratch_bytes, void *stream)
+{
+    if (M < 0) { set_error("hnr_sort_rows_by_key: bad size"); return HNR_ERR_BADARG; }
+    if (M == 0) return HNR_OK;
+    if (!d_keys || !d_keys_sorted || !d_perm || !d_scratch) { set_error("hnr_sort_rows_by_key: NULL argument"); return HNR_ERR_BADARG; }
+    size_t sz = (size_t)scratch_bytes;
+    rocprim::counting_iterator<int32_t> iota(0);
+    // signed keys: negative (= skipped) keys sort first
+    HNR_HIP_CHECK(rocprim::radix_sort_pairs(d_scratch, sz, d_keys, d_keys_sorted, iota, d_perm, (size_t)M, 0, 32, (hipStream_t)stream));
+    return HNR_OK;
+}
+
+extern "C" int hnr_segment_sum_rows(const float *d_A, int lda, const float *d_B, int ldb, const int32_t *d_keys_sorted,
+                                    const int32_t *d_perm, int64_t M, int n_cols, float *d_dst, int64_t dst_stride, void *stream)
+{
+    if (M < 0 || n_cols <= 0 || n_cols > 256 || (n_cols & 3) || lda < n_cols || (lda & 3) || (d_B && (ldb < n_cols || (ldb & 3))) ||
+        dst_stride < n_cols) {
+        set_error("hnr_segment_sum_rows: bad sizes (n_cols a multiple of 4, <= 256; row strides multiples of 4)"); return HNR_ERR_BADARG;
+    }
+    if (M == 0) return HNR_OK;
+    if (!d_A || !d_keys_sorted || !d_perm || !d_dst) { set_error("hnr_segment_sum_rows: NULL argument"); return HNR_ERR_BADARG; }
+    const int64_t waves = (M + SEG_CHUNK - 1) / SEG_CHUNK;
+    segment_sum_rows_kernel<<<cdiv(waves * 64, 256), 256, 0, (hipStream_t)stream>>>(d_A, lda, d_B, ldb, d_keys_sorted, d_perm, M, n_cols, d_dst,
+                                                                                    dst_stride);
+    HNR_LAUNCH_CHECK();
+    return HNR_OK;
+}

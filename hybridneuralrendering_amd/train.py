@@ -151,8 +151,9 @@ class TrainPath:
                 cap_u = min(n_rows, N)
                 S.uidx, S.ulist, S.row_u = _i32(N, dev), _i32(cap_u, dev), _i32(n_rows, dev)
                 ucount = torch.zeros(1, dtype=torch.int32, device=dev)
+                scan_scratch = _i32((N + 1023) // 1024 + 1, dev)
                 _lib.check(L.hnr_unique_points(p(S.row_pid), n_rows, N, p(S.uidx), p(S.ulist), cap_u, p(S.row_u), p(ucount),
-                                               p(_i32((N + 1023) // 1024 + 1, dev)), st()), "hnr_unique_points")
+                                               p(scan_scratch), st()), "hnr_unique_points")
                 S.U = int(ucount.item())
                 Tu, S.E = self.agg.point_table(cloud.emb, ids=S.ulist, n_ids=S.U, want_rows=True)
                 S.H1 = pk["b1_dist"].gather_add(S.Xd, Tu, S.row_u, act=True, slope=sl, K=60)
@@ -277,8 +278,10 @@ class TrainPath:
                 self._bbox0 = torch.tensor([[S.W, S.H, -1, -1]] * V, dtype=torch.int32, device=dev)
                 self._bbox_key = (V, S.H, S.W, dev)
             bbox = self._bbox0.clone()
+            sb = int(L.hnr_sort_rows_scratch_bytes(V * nS))
+            key_scratch, sort_scratch = _i32(3 * V * nS, dev), torch.empty((sb,), dtype=torch.uint8, device=dev)   # named: both must stay alive
             _lib.check(L.hnr_proj_rows_bwd(p(loc_w), p(S.vs_item), p(counts), p(S.w2c), p(S.Kn), V, S.H, S.W, nS, p(gF), 48, p(gX6), 48,
-                                           p(g_fm), p(bbox), p(g_pyr), st()), "hnr_proj_rows_bwd")
+                                           p(g_fm), p(bbox), p(g_pyr), p(key_scratch), p(sort_scratch), sb, st()), "hnr_proj_rows_bwd")
             del g_fm
             conv_names = [("aux_block_s%d.%d" % (lvl, i)) for lvl in (1, 2, 3) for i in (0, 2)]
             wp = (ctypes.c_void_p * 6)(*[tt.data_ptr() for tt in pk["conv_w"]])
@@ -315,7 +318,11 @@ class TrainPath:
             G1 = ag["block1.0.weight"]                                                # [256,284]
             weight_grad(dZ1, S.Xd, 256, 60, dW=G1[:, 224:284], db=ag["block1.0.bias"])
             gTu = z(max(S.U, 1), 256)
-            _lib.check(L.hnr_scatter_add_rows(p(dZ1), 256, p(S.row_u), M, 256, p(gTu), 256, st()), "hnr_scatter_add_rows")
+            # rows -> touched point: sort the rows by point once, then running sums (no per-element atomics)
+            sb = int(L.hnr_sort_rows_scratch_bytes(M))
+            ks, perm, sort_scratch = _i32(M, dev), _i32(M, dev), torch.empty((sb,), dtype=torch.uint8, device=dev)
+            _lib.check(L.hnr_sort_rows_by_key(p(S.row_u), M, p(ks), p(perm), p(sort_scratch), sb, st()), "hnr_sort_rows_by_key")
+            _lib.check(L.hnr_segment_sum_rows(p(dZ1), 256, None, 0, p(ks), p(perm), M, 256, p(gTu), 256, st()), "hnr_segment_sum_rows")
             if S.U > 0:
                 gTu = gTu[:S.U]
                 weight_grad(gTu, S.E, 256, 224, dW=G1[:, :224], want_bias=False)

@@ -323,11 +323,24 @@ int hnr_merge_bwd(const float *d_X6, int ld6, const float *d_Hm, int ldh, const 
 /* pixel gather (:1077-1089, :1193) + F.interpolate (:1064-1067) transposed: the rows' image-feature gradients (two sources
  * added: d_gFa from hnr_merge_bwd, optional d_gFb from the merge-weight MLP's first layer) are first added to their pixel
  * of d_g_featmap ([V,H,W,48], ZERO-INITIALISED; d_bbox int32[V,4] initialised to {W,H,-1,-1} receives the touched
- * rectangle), then gathered with the bilinear weights into the s1/s2/s3 slots of d_g_pyramid, a ZERO-INITIALISED buffer
+ * rectangle; rows are summed per pixel by sort + segment sum, row strides lda/ldb >= 48), then gathered with the bilinear weights into the s1/s2/s3 slots of d_g_pyramid, a ZERO-INITIALISED buffer
  * laid out like the forward scratch of hnr_image_features. */
 int hnr_proj_rows_bwd(const float *d_sample_loc_w, const int32_t *d_vs_item, const int64_t *d_counts, const float *d_w2c,
                       const float *d_intrinsic, int V, int H, int W, int cap_samples, const float *d_gFa, int lda,
-                      const float *d_gFb, int ldb, float *d_g_featmap, int32_t *d_bbox, float *d_g_pyramid, void *stream);
+                      const float *d_gFb, int ldb, float *d_g_featmap, int32_t *d_bbox, float *d_g_pyramid,
+                      int32_t *d_key_scratch /* int32[3*V*cap_samples] */, void *d_sort_scratch,
+                      int64_t sort_scratch_bytes /* hnr_sort_rows_scratch_bytes(V*cap_samples) */, void *stream);
+
+/* Sum-by-key of gradient rows (torch autograd's index_add / scatter in the reference) without per-element atomics:
+ *   hnr_sort_rows_by_key : stable radix sort of (key, row index); keys < 0 sort first and are skipped later;
+ *   hnr_segment_sum_rows : d_dst[key * dst_stride + c] += sum over the rows with that key of (A[row,c] + B[row,c]),
+ *                          c < n_cols (multiple of 4, <= 256; d_B may be NULL).
+ * Used for d(per-point table) (rows -> touched point) and d(feature map) (rows -> pixel). */
+int64_t hnr_sort_rows_scratch_bytes(int64_t M);
+int hnr_sort_rows_by_key(const int32_t *d_keys, int64_t M, int32_t *d_keys_sorted, int32_t *d_perm, void *d_scratch,
+                         int64_t scratch_bytes, void *stream);
+int hnr_segment_sum_rows(const float *d_A, int lda, const float *d_B, int ldb, const int32_t *d_keys_sorted,
+                         const int32_t *d_perm, int64_t M, int n_cols, float *d_dst, int64_t dst_stride, void *stream);
 
 /* aux_block_s1..3 (:1047-1063): d_scratch is the forward scratch (activations), d_g_pyramid as above (used as workspace);
  * g_conv_w / g_conv_b: HOST arrays of 6 device pointers, atomics. */

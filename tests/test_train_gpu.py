@@ -196,3 +196,29 @@ def test_input_grad_gemm_with_leaky_derivative(M, N, K):
     tw.side(dZp, acc, r_mode=0, out=acc, K=K)
     ref2 = dZ.double() @ W.double() + 2.0
     assert (acc[:, :N].double() - ref2).abs().max().item() < 5e-5 * max(1.0, ref2.abs().max().item())
+
+
+@pytest.mark.parametrize("M,n_cols,n_keys,two", [(5000, 256, 300, False), (20000, 48, 1500, True), (17, 48, 5, True), (100000, 256, 40000, False)])
+def test_sort_and_segment_sum_equal_index_add(M, n_cols, n_keys, two):
+    """hnr_sort_rows_by_key + hnr_segment_sum_rows == torch index_add over the rows with key >= 0."""
+    import ctypes
+    from hybridneuralrendering_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator(device="cpu").manual_seed(M + n_cols)
+    keys = torch.randint(-1, n_keys, (M,), generator=g, dtype=torch.int32).cuda()
+    A = torch.randn((M, n_cols), generator=g).cuda()
+    B = torch.randn((M, n_cols), generator=g).cuda() if two else None
+    ks, perm = torch.empty_like(keys), torch.empty_like(keys)
+    sb = int(L.hnr_sort_rows_scratch_bytes(M))
+    scratch = torch.empty((sb,), dtype=torch.uint8, device="cuda")
+    _lib.check(L.hnr_sort_rows_by_key(_lib.ptr(keys), M, _lib.ptr(ks), _lib.ptr(perm), _lib.ptr(scratch), sb, _lib.stream()), "sort")
+    order = torch.sort(keys.cpu().to(torch.int64), stable=True)
+    assert torch.equal(ks.cpu().to(torch.int64), order.values) and torch.equal(perm.cpu().to(torch.int64), order.indices)
+    dst = torch.zeros((n_keys, n_cols + 4), device="cuda")
+    _lib.check(L.hnr_segment_sum_rows(_lib.ptr(A), n_cols, _lib.ptr(B) if two else None, n_cols if two else 0, _lib.ptr(ks), _lib.ptr(perm), M,
+                                      n_cols, _lib.ptr(dst), n_cols + 4, _lib.stream()), "segment sum")
+    src = (A + B) if two else A
+    m = keys >= 0
+    ref = torch.zeros((n_keys, n_cols), dtype=torch.float64, device="cuda").index_add_(0, keys[m].long(), src[m].double())
+    assert (dst[:, :n_cols].double() - ref).abs().max().item() < 1e-4
+    assert torch.all(dst[:, n_cols:] == 0)
