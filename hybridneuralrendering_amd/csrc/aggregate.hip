@@ -623,6 +623,32 @@ __global__ __launch_bounds__(256) void composite_kernel(CompositeArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------
+// ray_march as a stand-alone operator (diff_ray_marching.py:508-557) for callers that already hold ray_dist / ray_valid /
+// decoded features (the drop-in `ray_march` function); the fused path uses composite_kernel.  One lane per ray.
+__global__ __launch_bounds__(256) void ray_march_kernel(const float *__restrict__ ray_dist, const uint8_t *__restrict__ ray_valid,
+                                                        const float *__restrict__ feat /*[R,SR,4]*/, const float *__restrict__ bg /*[3] or NULL*/,
+                                                        int R, int SR, float *__restrict__ ray_color, float *__restrict__ opacity,
+                                                        float *__restrict__ acc_t, float *__restrict__ blend_w, float *__restrict__ bg_t)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    float T = 1.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
+    for (int s = 0; s < SR; ++s) {
+        const size_t i = (size_t)r * SR + s;
+        const float4 d = reinterpret_cast<const float4 *>(feat)[i];
+        const float sigma = ray_valid[i] ? d.x : 0.f;
+        const float o = 1.f - expf(-sigma * ray_dist[i]);
+        const float w = o * T;
+        opacity[i] = o; acc_t[i] = T; blend_w[i] = w;
+        c0 += d.y * w; c1 += d.z * w; c2 += d.w * w;
+        T *= (1.f - o + 1e-10f);
+    }
+    if (bg) { c0 += bg[0] * T; c1 += bg[1] * T; c2 += bg[2] * T; }
+    ray_color[3 * (size_t)r] = c0; ray_color[3 * (size_t)r + 1] = c1; ray_color[3 * (size_t)r + 2] = c2;
+    bg_t[r] = T;
+}
+
+// ------------------------------------------------------------------------------------------------
 // The materialised gather of NeuralPoints.forward (neural_points.py:709-720) for the drop-in 14-tuple API
 // only (the fused path never materialises it).  One 8-lane group per (ray, slot, k) entry; empty entries
 // read point 0 like the reference's clamp(min=0).
@@ -869,6 +895,21 @@ extern "C" int hnr_composite(const float *d_decoded, const float *d_sample_loc_w
     a.camrot = d_camrot; a.bg = d_bg_color; a.R = R; a.SR = SR; a.K = K; a.vsize_z = vsize_z; a.unit_mode = raydist_mode_unit;
     a.raycolor = d_raycolor; a.opacity = d_opacity; a.is_bg = d_is_background; a.blend_w = d_blend_weight;
     composite_kernel<<<cdiv(R, 256), 256, 0, (hipStream_t)stream>>>(a);
+    HNR_LAUNCH_CHECK();
+    return HNR_OK;
+}
+
+extern "C" int hnr_ray_march(const float *d_ray_dist, const uint8_t *d_ray_valid, const float *d_features, const float *d_bg_color, int R,
+                             int SR, float *d_ray_color, float *d_opacity, float *d_acc_transmission, float *d_blend_weight,
+                             float *d_bg_transmission, void *stream)
+{
+    if (R < 0 || SR <= 0) { set_error("hnr_ray_march: bad sizes"); return HNR_ERR_BADARG; }
+    if (R == 0) return HNR_OK;
+    if (!d_ray_dist || !d_ray_valid || !d_features || !d_ray_color || !d_opacity || !d_acc_transmission || !d_blend_weight || !d_bg_transmission) {
+        set_error("hnr_ray_march: NULL argument"); return HNR_ERR_BADARG;
+    }
+    ray_march_kernel<<<cdiv(R, 256), 256, 0, (hipStream_t)stream>>>(d_ray_dist, d_ray_valid, d_features, d_bg_color, R, SR, d_ray_color, d_opacity,
+                                                                    d_acc_transmission, d_blend_weight, d_bg_transmission);
     HNR_LAUNCH_CHECK();
     return HNR_OK;
 }

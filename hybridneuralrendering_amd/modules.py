@@ -53,19 +53,34 @@ def find_tone_map(name):
 
 
 def ray_march(ray_dist, ray_valid, ray_features, render_func, blend_func, bg_color=None):
-    """diff_ray_marching.py:508-557 for tensors that already exist (drop-in for callers that hold decoded
-    features); the fused path uses hnr_composite instead.  Thin tensor algebra, kept for API completeness."""
-    point_color = render_func(ray_features)
-    sigma = ray_features[..., 0] * ray_valid.float()
-    opacity = 1 - torch.exp(-sigma * ray_dist)
-    acc = torch.cumprod(1. - opacity + 1e-10, dim=-1)
-    bg_t = acc[:, :, [-1]]
-    acc = torch.cat([torch.ones(opacity.shape[0:2] + (1,), device=opacity.device), acc[:, :, :-1]], dim=-1)
-    blend_weight = blend_func(opacity, acc)[..., None]
-    ray_color = torch.sum(point_color * blend_weight, dim=-2)
-    if bg_color is not None:
-        ray_color = ray_color + bg_color.to(opacity.device).float().view(bg_t.shape[0], 1, 3) * bg_t
-    return ray_color, point_color, opacity, acc, blend_weight, bg_t, blend_func(1, bg_t)
+    """diff_ray_marching.py:508-557 for tensors that already exist (drop-in for callers that hold decoded features);
+    runs hnr_ray_march.  The fused NeuralPointsRayMarching path composites inside hnr_composite and differentiates through
+    hnr_composite_bwd; this stand-alone operator is forward-only."""
+    if render_func is not radiance_render or blend_func is not alpha_blend:
+        raise HnrError("ray_march: only radiance render / alpha blend are implemented (all shipped configs)")
+    if torch.is_grad_enabled() and (ray_features.requires_grad or ray_dist.requires_grad):
+        raise HnrError("ray_march: the stand-alone operator is forward-only; train through NeuralPointsRayMarching (HIP backward)")
+    feats = _lib.require_gpu(ray_features, "ray_features", torch.float32)
+    if feats.dim() != 4 or feats.shape[-1] != 4:
+        raise HnrError("ray_march: ray_features must be [N, R, SR, 4] (sigma, rgb)")
+    N, R, SR, _ = feats.shape
+    dist = _lib.require_gpu(ray_dist.to(torch.float32), "ray_dist", torch.float32).reshape(N * R, SR)
+    valid = _lib.require_gpu(ray_valid.to(torch.uint8), "ray_valid", torch.uint8).reshape(N * R, SR)
+    dev = feats.device
+    f = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)
+    out = []
+    for n in range(N):                                           # N (batch) is 1 everywhere; bg_color is per batch entry
+        col, opa, acc, bw, bgt = f(R, 3), f(R, SR), f(R, SR), f(R, SR), f(R)
+        bg = None if bg_color is None else _lib.require_gpu(bg_color.to(dev).float().reshape(-1, 3)[n if bg_color.numel() > 3 else 0],
+                                                            "bg_color", torch.float32)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().hnr_ray_march(_lib.ptr(dist[n * R:(n + 1) * R]), _lib.ptr(valid[n * R:(n + 1) * R]), _lib.ptr(feats[n]),
+                                                _lib.ptr(bg) if bg is not None else None, R, SR, _lib.ptr(col), _lib.ptr(opa), _lib.ptr(acc),
+                                                _lib.ptr(bw), _lib.ptr(bgt), _lib.stream()), "hnr_ray_march")
+        out.append((col, opa, acc, bw, bgt))
+    cat = lambda i: torch.stack([o[i] for o in out], dim=0)
+    bg_t = cat(4)[..., None]
+    return cat(0), feats[..., 1:], cat(1), cat(2), cat(3)[..., None], bg_t, bg_t
 
 
 # ------------------------------------------------------------------------------------------------ NeuralPoints

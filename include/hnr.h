@@ -290,6 +290,13 @@ int hnr_composite(const float *d_decoded, const float *d_sample_loc_w, const int
                   int raydist_mode_unit, float *d_raycolor, float *d_opacity, float *d_is_background, float *d_blend_weight,
                   void *stream);
 
+/* ray_march alone (models/rendering/diff_ray_marching.py:508-557; radiance render + alpha blend) on existing tensors:
+ * d_ray_dist [R,SR], d_ray_valid [R,SR] u8, d_features [R,SR,4] = (sigma, rgb), d_bg_color [3] or NULL ->
+ * d_ray_color [R,3], d_opacity / d_acc_transmission / d_blend_weight [R,SR], d_bg_transmission [R]. */
+int hnr_ray_march(const float *d_ray_dist, const uint8_t *d_ray_valid, const float *d_features, const float *d_bg_color, int R,
+                  int SR, float *d_ray_color, float *d_opacity, float *d_acc_transmission, float *d_blend_weight,
+                  float *d_bg_transmission, void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Stage 5: backward of stages 3b and 4 (hnr_gather_aggregate_bwd / hnr_composite_bwd), one entry point per
  * forward kernel.  The reference obtains all of these from torch autograd over its eager ops; file:line below name the

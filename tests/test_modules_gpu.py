@@ -134,3 +134,23 @@ def test_train_mode_module_gives_reference_gradients_on_its_parameters():
         tol = 1.5e-3 if k.startswith("neural_points.") else 3e-4        # see tests/test_train_gpu.py for the fp32-noise yardstick
         assert np.abs(x - r).max() <= tol * np.abs(r).max(), k
     assert npts.xyz.grad is None
+
+
+def test_standalone_ray_march_matches_reference_formula():
+    """modules.ray_march (hnr_ray_march) vs the torch restatement of diff_ray_marching.py:508-557."""
+    from hybridneuralrendering_amd.modules import ray_march, radiance_render, alpha_blend
+    from oracle import render_oracle as ro
+    g = torch.Generator(device="cpu").manual_seed(2)
+    R, SR = 777, 24
+    feats = torch.cat([torch.nn.functional.softplus(torch.randn((1, R, SR, 1), generator=g)) * 30, torch.rand((1, R, SR, 3), generator=g)], -1)
+    rd = torch.rand((1, R, SR), generator=g) * 0.02
+    rv = torch.rand((1, R, SR), generator=g) > 0.3
+    bg = torch.tensor([[0.2, 0.5, 1.0]])
+    ref = ro.ray_march(rd, rv, feats, bg)
+    out = ray_march(rd.cuda(), rv.cuda(), feats.cuda(), radiance_render, alpha_blend, bg.cuda())
+    assert len(out) == 7
+    for got, want in ((out[0], ref["ray_color"]), (out[2], ref["opacity"]), (out[3], ref["acc_transmission"]), (out[4], ref["blend_weight"]),
+                      (out[5], ref["background_transmission"])):
+        assert got.shape == want.shape
+        np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=0, atol=2e-6)
+    assert torch.equal(out[1].cpu(), feats[..., 1:])
