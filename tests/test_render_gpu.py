@@ -129,3 +129,30 @@ def test_image_feature_map_matches_oracle():
     assert torch.all(fm[..., 45:] == 0)
     np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=0, atol=2e-6)
     assert torch.all(got[:, :, 0, 0] == 0)
+
+
+def test_whole_frame_equals_chunked_render():
+    """driver.render_image: one launch over the frame vs the reference's 2304-ray chunk loop (run/test_ft.py:165-198) --
+    the query is bit-identical and the colours agree to fp32 summation-order noise; the image is assembled by pixel index."""
+    from hybridneuralrendering_amd import scenes
+    from hybridneuralrendering_amd.driver import render_image
+    d, ti, opt, cloud, rnd = _setup("scannet_small")
+    sc_w, sc_h = int(d["scene"][3]), int(d["scene"][4])
+    pix = scenes.pixel_grid(sc_w, sc_h, 2)
+    rays = scenes.camera_rays(pix, d["intrinsic"], d["c2w"])
+    dev = ti["raydir"].device
+    near, far = d["near_far"]
+    frame = dict(raydir=torch.from_numpy(rays).to(dev)[None], pixel_idx=torch.from_numpy(pix.astype(np.float32)).to(dev)[None], campos=ti["campos"],
+                 camrotc2w=ti["camrotc2w"], bg_color=ti["bg_color"], near=torch.tensor([[[near]]]), far=torch.tensor([[[far]]]), h=sc_h, w=sc_w,
+                 c2w_nearest=ti["c2w_nearest"], campos_nearest=ti["campos_nearest"], intrinsic_nearest=ti["intrinsic_nearest"],
+                 images_nearest=ti["images_nearest"])
+    whole = render_image(rnd, cloud, frame)
+    chunked = render_image(rnd, cloud, frame, chunk_rays=48 * 48 // 9)
+    assert whole["image"].shape == (sc_h, sc_w, 3)
+    assert torch.equal(whole["ray_mask"], chunked["ray_mask"])
+    assert float((whole["image"] - chunked["image"]).abs().max()) < 2e-5
+    # margin pixels were never cast: background colour
+    assert bool((whole["image"][0, 0] == ti["bg_color"][0]).all())
+    img = whole["image"].cpu().numpy()
+    np.testing.assert_array_equal(img[pix[:, 1], pix[:, 0]], whole["coarse_raycolor"].cpu().numpy())
+    assert int(whole["ray_mask"].sum()) > 100 and img.std() > 0.01
