@@ -321,3 +321,22 @@ def train_step(xyz, emb, conf, pdir, color, sd, q, campos, camrotc2w, raydir_all
         if v.grad is not None:
             grads["aggregator." + k] = v.grad
     return out, (loss.item(), lc.item(), lz.item()), grads
+
+
+def blur_update_output(color, gt, kernels, patch_num, patch_size):
+    """models/base_rendering_model.py:677-745 (faster_version).  color, gt [1, S*S, 3]; kernels [N, ks, ks].
+    Returns (new colours [1, S*S, 3], selected candidate per patch [patch_num^2], N = un-blurred)."""
+    pn, ps = patch_num, patch_size
+    S = pn * ps
+    N, ks = kernels.shape[0], kernels.shape[-1]
+    to_patches = lambda t: t.reshape(1, S, S, 3).permute(0, 3, 1, 2)[0].reshape(3, pn, ps, pn, ps).permute(1, 3, 0, 2, 4).reshape(pn * pn, 3, ps, ps)
+    cp, gp = to_patches(color), to_patches(gt)
+    w = kernels[:, None]                                               # [N,1,ks,ks]: F.conv2d = cross-correlation
+    x = cp.reshape(pn * pn * 3, 1, ps, ps)
+    m = F.conv2d(torch.ones_like(x), w, padding=ks // 2)
+    b = torch.cat((F.conv2d(x, w, padding=ks // 2) / m, x), dim=1).reshape(pn * pn, 3, N + 1, ps, ps)
+    diff = torch.sum(torch.abs(b - gp[:, :, None]), dim=(1, 3, 4))
+    sel = torch.argmin(diff, dim=1)
+    best = b[torch.arange(pn * pn), :, sel]                            # [P,3,ps,ps]
+    out = best.reshape(pn, pn, 3, ps, ps).permute(2, 0, 3, 1, 4).reshape(3, S, S).permute(1, 2, 0).reshape(1, S * S, 3)
+    return out, sel

@@ -9,6 +9,7 @@ What is pinned by the reference itself (runs on CPU with torch):
   * posenc.npz          <- positional_encoding (models/helpers/networks.py:175-189)
   * train_*.npz         <- the same forward in train mode (jittered depths, patch drop) + torch autograd of the
                            shipped loss terms: gradients w.r.t. every aggregator parameter and the point buffers
+  * blur_select.npz     <- BaseRenderingModel.blur_update_output (models/base_rendering_model.py:677-745) + autograd
   * render_*.npz        <- NeuralPointsRayMarching.forward (models/neural_points_volumetric_model.py:257-427)
                            = NeuralPoints gather + PointAggregator + ray_march, + fill_invalid (:87-126)
 The reference's query kernels cannot run here (pycuda/nvcc), so inside render_* the 7-tuple of
@@ -323,6 +324,53 @@ def gen_train(ref, tag, scene_name, n_points, seed, w, h, patch, opt_over=None, 
     opt.is_train = 0
 
 
+def gen_blur(ref):
+    """BaseRenderingModel.blur_update_output (models/base_rendering_model.py:677-745) on a 7x7 grid of 8x8 patches with 12
+    normalised 9x9 kernels: new colours, per-patch choice and the gradient of a random linear functional of the output."""
+    import models.base_rendering_model as brm
+    rng = np.random.default_rng(31)
+    pn, ps, N, ks = 7, 8, 12, 9
+    S = pn * ps
+    kernels = np.zeros((N, ks, ks), np.float32)
+    c = ks // 2
+    for i, dist in enumerate((1, 2, 4)):                     # line kernels in 4 directions x 3 lengths (symmetrical family, :214-242)
+        for j, (dy, dx) in enumerate(((1, 0), (0, 1), (1, 1), (1, -1))):
+            for t in range(-dist, dist + 1):
+                kernels[i * 4 + j, c + t * dy, c + t * dx] = 1.0
+    kernels /= kernels.sum(axis=(1, 2), keepdims=True)
+    color = rng.uniform(0, 1, size=(1, S * S, 3)).astype(np.float32)
+    # ground truth: per patch, a blurred or un-blurred copy of the render + noise, so that several candidates win
+    ct = torch.from_numpy(color).reshape(1, S, S, 3).permute(0, 3, 1, 2)
+    gt = ct.clone()
+    for p in range(pn * pn):
+        i, j = divmod(p, pn)
+        pick = int(rng.integers(0, N + 1))
+        patch = ct[0, :, i * ps:(i + 1) * ps, j * ps:(j + 1) * ps]
+        if pick < N:
+            k = torch.from_numpy(kernels[pick])[None, None]
+            m = torch.nn.functional.conv2d(torch.ones(3, 1, ps, ps), k, padding=c)
+            patch = torch.nn.functional.conv2d(patch[:, None], k, padding=c)[:, 0] / m[:, 0]
+        gt[0, :, i * ps:(i + 1) * ps, j * ps:(j + 1) * ps] = patch
+    gt = (gt + 0.02 * torch.from_numpy(rng.normal(size=gt.shape).astype(np.float32))).permute(0, 2, 3, 1).reshape(1, S * S, 3).contiguous()
+    col = torch.from_numpy(color).clone().requires_grad_(True)
+    shell = SimpleNamespace(dilation_PatchNum=pn, dilation_PatchSize=ps, gt_image=gt, output={"coarse_raycolor": col},
+                            blur_kernels=torch.from_numpy(kernels)[None], xv_patches=[], yv_patches=[])
+    orig_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self             # the method moves the kernels with .cuda(); this container has no GPU
+    try:
+        brm.BaseRenderingModel.blur_update_output(shell)
+    finally:
+        torch.Tensor.cuda = orig_cuda
+    out = shell.output["coarse_raycolor"]
+    wgt = torch.from_numpy(rng.normal(size=out.shape).astype(np.float32))
+    (out * wgt).sum().backward()
+    # the choice per patch, recovered from the output (which candidate reproduces the patch)
+    np.savez_compressed(os.path.join(HERE, "blur_select.npz"), color=color, gt=gt.numpy(), kernels=kernels, dims=np.array([pn, ps, N, ks]),
+                        out=out.detach().numpy(), upstream=wgt.numpy(), grad_color=col.grad.numpy())
+    changed = int((np.abs(out.detach().numpy() - color).reshape(pn, ps, pn, ps, 3).max(axis=(1, 3, 4)) > 0).sum())
+    print("blur_select.npz: %d of %d patches replaced by a blurred candidate" % (changed, pn * pn))
+
+
 def main():
     ref = import_reference()
     gen_hparams(ref)
@@ -330,6 +378,7 @@ def main():
     gen_posenc(ref)
     gen_render(ref, "scannet_small", "scene0241", 12000, 11, 64, 48, 600, opt_over=dict(agg_axis_weight=None), size=(1.0, 0.8, 0.6))
     gen_render(ref, "synth_small", "lego", 9000, 12, 40, 40, 500, opt_over=dict(agg_axis_weight=None, SR=40))
+    gen_blur(ref)
     gen_train(ref, "scannet_small", "scene0241", 12000, 11, 64, 48, 28,
               opt_over=dict(agg_axis_weight=None, dilation_setup="7_4_1_8"), size=(1.0, 0.8, 0.6))
 

@@ -157,3 +157,14 @@ def test_fp32_gradient_noise_of_the_reference_is_what_the_gpu_tolerances_assume(
             worst_w = max(worst_w, e)
     assert 5e-5 < worst_p < 6e-4, worst_p          # measured 2.4e-4
     assert worst_w < 1e-4, worst_w                 # measured 3.6e-5
+
+
+def test_blur_select_oracle_matches_reference():
+    z = np.load(os.path.join(GOLD, "blur_select.npz"))
+    pn, ps, N, ks = (int(v) for v in z["dims"])
+    col = torch.from_numpy(z["color"]).clone().requires_grad_(True)
+    out, sel = ro.blur_update_output(col, torch.from_numpy(z["gt"]), torch.from_numpy(z["kernels"]), pn, ps)
+    np.testing.assert_allclose(out.detach().numpy(), z["out"], rtol=0, atol=1e-6)
+    (out * torch.from_numpy(z["upstream"])).sum().backward()
+    np.testing.assert_allclose(col.grad.numpy(), z["grad_color"], rtol=0, atol=1e-6)
+    assert len(set(sel.tolist())) >= 6                                # several different candidates win in the fixture
