@@ -400,7 +400,7 @@ __global__ void featmap_kernel(const float *__restrict__ img /*[V,H,W,3]*/, cons
 }
 
 // ------------------------------------------------------------------------------------------------
-// Merge-weight rows (:1074-1096, :1188-1199): one wave per (view, valid sample): reprojection (w2iproject,
+// Merge-weight rows (:1074-1096, :1188-1199): 16 lanes per (view, valid sample): reprojection (w2iproject,
 // neural_points_volumetric_model.py:248-255), truncation to a pixel, 45-float gather, delta view direction
 // (:296-310), colour feature copy.  Row = [imgfeat45 | colfeat128 | delta_dir3] (176), lda = 176.
 struct ProjArgs {
@@ -420,13 +420,15 @@ struct ProjArgs {
 
 __global__ __launch_bounds__(256) void proj_rows_kernel(ProjArgs a)
 {
-    const int lane = threadIdx.x & 63;
-    const int64_t wv = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    // 16 lanes per (view, sample) row, 3 feature channels per lane: 4 rows per wave keep four dependent
+    // index -> position -> pixel -> feature load chains in flight (one row per wave was latency-bound: 5.0 ms per frame)
+    const int sub = threadIdx.x & 15;
+    const int64_t rowi = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const int n_valid = (int)a.counts[HNR_CNT_SAMPLES_VALID];
     if (n_valid == 0) return;
-    const int v = (int)(wv / n_valid);
+    const int v = (int)(rowi / n_valid);
     if (v >= a.V) return;
-    const int s = (int)(wv - (int64_t)v * n_valid);
+    const int s = (int)(rowi - (int64_t)v * n_valid);
     const float *p = a.loc_w + (size_t)a.vs_item[s] * 3;
     const float x = p[0], y = p[1], z = p[2];
     const float *m = a.w2c + 16 * v;
@@ -446,26 +448,32 @@ __global__ __launch_bounds__(256) void proj_rows_kernel(ProjArgs a)
     const size_t row = (size_t)v * a.cap + s;
     float *o = a.X6 + row * a.ld6;
     const float *f = a.fm + (((size_t)v * a.H + py) * a.W + px) * 48;
-    if (lane < 45) o[lane] = f[lane];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int ch = sub + 16 * q;
+        if (ch < 45) o[ch] = f[ch];
+    }
     const int dcol = a.row_sample ? 45 : 173;          // SPLIT rows are [imgfeat45 | ddir3]
     if (!a.row_sample) {
-        // colour feature: 128 floats, 2 per lane
-        const float2 cf = reinterpret_cast<const float2 *>(a.CF + (size_t)s * a.ldcf)[lane];
-        o[45 + 2 * lane] = cf.x; o[45 + 2 * lane + 1] = cf.y;
-    } else if (lane == 63) {
+        // colour feature: 128 floats, 8 per lane
+        const float4 *cf = reinterpret_cast<const float4 *>(a.CF + (size_t)s * a.ldcf);
+        const float4 c0 = cf[2 * sub], c1 = cf[2 * sub + 1];
+        float *oc = o + 45 + 8 * sub;
+        oc[0] = c0.x; oc[1] = c0.y; oc[2] = c0.z; oc[3] = c0.w; oc[4] = c1.x; oc[5] = c1.y; oc[6] = c1.z; oc[7] = c1.w;
+    } else if (sub == 15) {
         a.row_sample[row] = s;
     }
-    if (lane < 3) {
+    if (sub < 3) {
         // delta view direction (:298-305)
         const float cx = x - a.campos[0], cy = y - a.campos[1], cz = z - a.campos[2];
         const float cn = sqrtf(cx * cx + cy * cy + cz * cz) + 1e-6f;
         const float nx = x - a.campos_n[3 * v], ny = y - a.campos_n[3 * v + 1], nz = z - a.campos_n[3 * v + 2];
         const float nn = sqrtf(nx * nx + ny * ny + nz * nz) + 1e-6f;
-        const float cur = (lane == 0 ? cx : lane == 1 ? cy : cz) / cn;
-        const float nea = (lane == 0 ? nx : lane == 1 ? ny : nz) / nn;
-        o[dcol + lane] = nea - cur;
+        const float cur = (sub == 0 ? cx : sub == 1 ? cy : cz) / cn;
+        const float nea = (sub == 0 ? nx : sub == 1 ? ny : nz) / nn;
+        o[dcol + sub] = nea - cur;
     }
-    if (lane == 0) a.vmask[row] = inval ? 0.f : 1.f;
+    if (sub == 0) a.vmask[row] = inval ? 0.f : 1.f;
 }
 
 // Merge (:1199-1217) + mix-up input (:1286-1292): one wave per valid sample.
@@ -489,16 +497,28 @@ __global__ __launch_bounds__(256) void merge_kernel(MergeArgs a)
     if (s >= n_valid) return;
     const float wl = a.w_last[lane];
     float fsum = 0.f, wsum = 0.f;
-    for (int v = 0; v < a.V; ++v) {
-        const size_t row = (size_t)v * a.cap + s;
-        float d = a.Hm[row * a.ldh + lane] * wl;
-        for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
-        float wv = 1.f / (1.f + expf(-(d + a.b_last[0])));
-        wv *= a.vmask[row];
-        if (a.frame_w) wv *= a.frame_w[v];
-        const float f = lane < 45 ? a.X6[row * a.ld6 + lane] : 0.f;
-        fsum += f * wv;
-        wsum += wv;
+    constexpr int VB = 4;                                  // views fetched together (independent loads in flight)
+    for (int v0 = 0; v0 < a.V; v0 += VB) {
+        float hm[VB], f[VB], vm[VB];
+#pragma unroll
+        for (int u = 0; u < VB; ++u) {
+            const int v = v0 + u < a.V ? v0 + u : a.V - 1;
+            const size_t row = (size_t)v * a.cap + s;
+            hm[u] = a.Hm[row * a.ldh + lane];
+            f[u] = lane < 45 ? a.X6[row * a.ld6 + lane] : 0.f;
+            vm[u] = a.vmask[row];
+        }
+#pragma unroll
+        for (int u = 0; u < VB; ++u) {
+            if (v0 + u >= a.V) break;
+            float d = hm[u] * wl;
+            for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
+            float wv = 1.f / (1.f + expf(-(d + a.b_last[0])));
+            wv *= vm[u];
+            if (a.frame_w) wv *= a.frame_w[v0 + u];
+            fsum += f[u] * wv;
+            wsum += wv;
+        }
     }
     float *o = a.X7 + (size_t)s * a.ld7;
     if (lane < 45) {
@@ -831,7 +851,7 @@ extern "C" int hnr_proj_rows(const float *d_sample_loc_w, const int32_t *d_vs_it
 {
     const bool split = d_row_sample != nullptr;
     if (!d_sample_loc_w || !d_vs_item || !d_counts || !d_w2c || !d_intrinsic || !d_campos || !d_campos_nearest || !d_featmap ||
-        (!split && !d_CF) || !d_X6 || !d_vmask || V <= 0 || ld6 < (split ? 48 : 176) || (ld6 & 3) || (!split && (ldcf < 128 || (ldcf & 1)))) {
+        (!split && !d_CF) || !d_X6 || !d_vmask || V <= 0 || ld6 < (split ? 48 : 176) || (ld6 & 3) || (!split && (ldcf < 128 || (ldcf & 3)))) {
         set_error("hnr_proj_rows: bad argument"); return HNR_ERR_BADARG;
     }
     if (cap_samples <= 0) return HNR_OK;
@@ -839,7 +859,7 @@ extern "C" int hnr_proj_rows(const float *d_sample_loc_w, const int32_t *d_vs_it
     a.loc_w = d_sample_loc_w; a.vs_item = d_vs_item; a.counts = reinterpret_cast<const unsigned long long *>(d_counts);
     a.w2c = d_w2c; a.Kmat = d_intrinsic; a.campos = d_campos; a.campos_n = d_campos_nearest; a.fm = d_featmap; a.H = H; a.W = W;
     a.CF = d_CF; a.ldcf = ldcf; a.V = V; a.cap = cap_samples; a.X6 = d_X6; a.ld6 = ld6; a.vmask = d_vmask; a.row_sample = d_row_sample;
-    proj_rows_kernel<<<cdiv((int64_t)V * cap_samples * 64, 256), 256, 0, (hipStream_t)stream>>>(a);
+    proj_rows_kernel<<<cdiv((int64_t)V * cap_samples * 16, 256), 256, 0, (hipStream_t)stream>>>(a);
     HNR_LAUNCH_CHECK();
     return HNR_OK;
 }
