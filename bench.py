@@ -236,7 +236,7 @@ def main():
         roof, roof_q = None, None
         pmc = pmc_traffic() if (int(args.points) == 2000000 and args.scene == "scene0241" and args.chunk <= 0) else {}
         t_lin = next((v for k, v in pmc.items() if "linear_f32_kernel<2, 2, 1, 0, 4>" in k), None)
-        t_q = [v for k, v in pmc.items() if "march_kernel" in k or "knn2_kernel" in k]
+        t_q = [v for k, v in pmc.items() if "march_kernel" in k or "knn3_kernel" in k]
         if counts is not None:
             n_rows, n_valid = int(counts[CNT["NEIGHBOURS"]]), int(counts[CNT["SAMPLES_VALID"]])
             s_all, cells, cand = int(counts[CNT["SAMPLES"]]), int(counts[CNT["CELLS_VISITED"]]), int(counts[CNT["CANDIDATES"]])
@@ -260,10 +260,10 @@ def main():
             ms_q = stage_ms.get("query", 0.0)
             if ms_q > 0:
                 ach = alg / (ms_q * 1e-3) / 1e9
-                roof_q = dict(kernel="hnr_march_query: march_kernel + worklist scans + knn2_kernel<8>", bound="hbm", achieved=round(ach, 1),
+                roof_q = dict(kernel="hnr_march_query: march_kernel + worklist scans + knn3_kernel<8>", bound="hbm", achieved=round(ach, 1),
                               peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
                               traffic=int(sum(v["hbm_bytes"] for v in t_q)) if len(t_q) == 2 else None,
-                              traffic_source="profiles/r01_traffic.json (march_kernel + knn2_kernel, bytes per launch)" if len(t_q) == 2 else None,
+                              traffic_source="profiles/r01_traffic.json (march_kernel + knn3_kernel, bytes per launch)" if len(t_q) == 2 else None,
                               algorithmic_bytes=int(alg), avg_launch_ms=round(ms_q, 4),
                               per_ray=dict(samples=round(s_all / R, 2), cells_per_sample=round(cells / max(s_all, 1), 2),
                                            candidates_per_sample=round(cand / max(s_all, 1), 2)))

@@ -48,7 +48,9 @@ __device__ __forceinline__ void lds_dma16(const float *src, unsigned lds_base)
                  :: "v"(src), "s"(__builtin_amdgcn_readfirstlane(lds_base)) : "memory");
 }
 
-template <int TM, int TN, int ACT, int DBG = 0, int WN = 2>   // ACT: 0 none, 1 LeakyReLU(slope); DBG: ablation switches (probe only)
+// SIDE = 1 compiles the side-operand epilogue in (its index / value arrays cost registers: with it in the plain kernel the
+// 128x256 variant spilled 68 B per lane and the big layers ran 4 % slower).
+template <int TM, int TN, int ACT, int DBG = 0, int WN = 2, int SIDE = 0>   // ACT: 0 none, 1 LeakyReLU(slope); DBG: ablation switches (probe only)
 __global__ __launch_bounds__(128 * WN, 2) void linear_f32_kernel(const float *__restrict__ A, int lda,
                                                          const float *__restrict__ Wp, int K_pad,
                                                          const float *__restrict__ bias_p, float *__restrict__ C, int ldc,
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(128 * WN, 2) void linear_f32_kernel(const float *__
     // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     auto epilogue = [&](int mt) {
         const int row0 = mt * BM + wr * 32 * TM + 4 * (lane >> 5);
-        if (R != nullptr) {
+        if (SIDE && R != nullptr) {
             // side operand R (row stride ldr), applied to the columns < r_cols:
             //   r_mode 0: gathered addend, v = act(acc + bias + R[ridx[m], n])   (ridx == NULL: row m itself, e.g. R == C for "+=")
             //   r_mode 1: LeakyReLU derivative of a stored activation, v = (acc + bias) * (R[m, n] > 0 ? 1 : slope)  (backward)
@@ -157,26 +159,25 @@ __global__ __launch_bounds__(128 * WN, 2) void linear_f32_kernel(const float *__
                 const int gn = n0 + wc * 32 * TN + j * 32 + (lane & 31);
                 const bool use = gn < r_cols;
                 const int gn_safe = use ? gn : r_cols - 1;
-                float add[TM][16];
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i) {
+                    float add[16];                               // 16 independent loads in flight per (i, j) block
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) add[i][r] = R[(size_t)rid[i][r] * ldr + gn_safe];
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
+                    for (int r = 0; r < 16; ++r) add[r] = R[(size_t)rid[i][r] * ldr + gn_safe];
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int gm = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
                         float v = acc[i][j][r] + bias_v[j];
                         if (r_mode == 0) {
-                            v += use ? add[i][r] : 0.f;
+                            v += use ? add[r] : 0.f;
                             if (ACT == 1) v = v > 0.f ? v : v * slope;
                         } else {
-                            v *= (use && !(add[i][r] > 0.f)) ? slope : 1.f;
+                            v *= (use && !(add[r] > 0.f)) ? slope : 1.f;
                         }
                         if (gm < M && gn < N) C[(size_t)gm * ldc + gn] = v;
                         acc[i][j][r] = 0.f;
                     }
+                }
             }
             return;
         }
@@ -360,6 +361,14 @@ extern "C" int hnr_linear_f32_side(const float *d_A, int lda, const float *d_Wp,
     return linear_launch(d_A, lda, d_Wp, d_bias_p, d_C, ldc, M, N, K, act, slope, d_R, d_ridx, ldr, r_cols, r_mode, stream);
 }
 
+#define HNR_LINEAR_LAUNCH(TM_, TN_, ACT_, DBG_, WN_, THREADS_, LDS_)                                                                  \
+    do {                                                                                                                             \
+        if (d_R) linear_f32_kernel<TM_, TN_, ACT_, DBG_, WN_, 1><<<grid, THREADS_, LDS_, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, \
+                                                                                                slope, d_R, d_ridx, ldr, r_cols, r_mode);   \
+        else linear_f32_kernel<TM_, TN_, ACT_, DBG_, WN_, 0><<<grid, THREADS_, LDS_, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K,     \
+                                                                                            slope, d_R, d_ridx, ldr, r_cols, r_mode);       \
+    } while (0)
+
 static int linear_launch(const float *d_A, int lda, const float *d_Wp, const float *d_bias_p, float *d_C, int ldc, int M, int N, int K,
                          int act, float slope, const float *d_R, const int32_t *d_ridx, int ldr, int r_cols, int r_mode, void *stream)
 {
@@ -391,26 +400,26 @@ static int linear_launch(const float *d_A, int lda, const float *d_Wp, const flo
         if (gx < 1) gx = 1;
         if (gx > n_mtiles) gx = n_mtiles;
         dim3 grid(gx, ny);
-        if (act) linear_f32_kernel<2, 2, 1, 0, 4><<<grid, 512, 114688, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope, d_R, d_ridx, ldr, r_cols, r_mode);
-        else linear_f32_kernel<2, 2, 0, 0, 4><<<grid, 512, 114688, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope, d_R, d_ridx, ldr, r_cols, r_mode);
+        if (act) HNR_LINEAR_LAUNCH(2, 2, 1, 0, 4, 512, 114688);
+        else HNR_LINEAR_LAUNCH(2, 2, 0, 0, 4, 512, 114688);
     } else if (N >= 128) {
         const int ny = Np / 128;
         int gx = (2 * n_cu) / ny;
         if (gx < 1) gx = 1;
         if (gx > n_mtiles) gx = n_mtiles;
         dim3 grid(gx, ny);
-        if (dbg == 1) linear_f32_kernel<2, 2, 1, 1><<<grid, 256, 81920, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope, d_R, d_ridx, ldr, r_cols, r_mode);
-        else if (dbg == 2) linear_f32_kernel<2, 2, 1, 2><<<grid, 256, 81920, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope, d_R, d_ridx, ldr, r_cols, r_mode);
-        else if (act) linear_f32_kernel<2, 2, 1><<<grid, 256, 81920, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope, d_R, d_ridx, ldr, r_cols, r_mode);
-        else linear_f32_kernel<2, 2, 0><<<grid, 256, 81920, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope, d_R, d_ridx, ldr, r_cols, r_mode);
+        if (dbg == 1) HNR_LINEAR_LAUNCH(2, 2, 1, 1, 2, 256, 81920);
+        else if (dbg == 2) HNR_LINEAR_LAUNCH(2, 2, 1, 2, 2, 256, 81920);
+        else if (act) HNR_LINEAR_LAUNCH(2, 2, 1, 0, 2, 256, 81920);
+        else HNR_LINEAR_LAUNCH(2, 2, 0, 0, 2, 256, 81920);
     } else {
         const int ny = Np / 64;
         int gx = (2 * n_cu) / ny;
         if (gx < 1) gx = 1;
         if (gx > n_mtiles) gx = n_mtiles;
         dim3 grid(gx, ny);
-        if (act) linear_f32_kernel<2, 1, 1><<<grid, 256, 65536, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope, d_R, d_ridx, ldr, r_cols, r_mode);
-        else linear_f32_kernel<2, 1, 0><<<grid, 256, 65536, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope, d_R, d_ridx, ldr, r_cols, r_mode);
+        if (act) HNR_LINEAR_LAUNCH(2, 1, 1, 0, 2, 256, 65536);
+        else HNR_LINEAR_LAUNCH(2, 1, 0, 0, 2, 256, 65536);
     }
     HNR_LAUNCH_CHECK();
     return HNR_OK;
