@@ -187,13 +187,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # Rehearsal of the multi-rank control flow on a box with fewer GPUs than ranks (HNR_BENCH_REHEARSAL=1 only: ranks share
+    # devices and the collectives run over gloo on host copies -- numbers from such a run mean nothing and say so).
+    rehearsal = world > 1 and os.environ.get("HNR_BENCH_REHEARSAL") == "1" and torch.cuda.device_count() < world
+    if rehearsal:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    coll = (lambda t: t.cpu()) if rehearsal else (lambda t: t)
     from hybridneuralrendering_amd import parallel
     from hybridneuralrendering_amd._lib import CNT
 
@@ -205,8 +214,9 @@ def main():
         col, out = render_frame(rnd, cloud, cam, sc, args.chunk, timers)
         if world > 1:
             # reassemble the N frames on rank 0: ONE gather over xGMI (every rank sends R x 3 floats)
-            outs = [torch.empty_like(col) for _ in range(world)] if rank == 0 else None
-            dist.gather(col, outs, dst=0)
+            c = coll(col)
+            outs = [torch.empty_like(c) for _ in range(world)] if rank == 0 else None
+            dist.gather(c, outs, dst=0)
         return col, out
 
     def barrier():
@@ -223,7 +233,7 @@ def main():
         col, out = step(timers)
     barrier()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tmax = coll(torch.tensor([dt], dtype=torch.float64, device=dev))
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
@@ -283,7 +293,7 @@ def main():
         amort["grid_build_ms"] = _timed(lambda: Q.VoxelGrid(cloud.xyz, hp[2][:3], hp[5], hp[6], opt.query_size, opt.P, opt.max_o))
         amort["point_table_ms"] = _timed(lambda: agg.point_table(cloud.emb))
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # reported at N=1 only (rank 0)
             cpu = cpu_baseline(args, sc, opt, agg, cam, col.cpu().numpy())
         train = None
         if world == 1 and not args.no_train_leg:
@@ -292,7 +302,7 @@ def main():
             "metric": "rays/sec (fwd render) scene0241_01 at 1/2/4/8 GPU; PSNR delta vs ref",
             "value": world * R * args.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32", "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: ranks share GPUs, gloo collectives -- not a measurement)",
             "config": {"workload": "scene0241_01-like synthetic room (SURVEY 8d C3): %d points, %dx%d frame margin %d = %d rays per GPU per step, "
                                    "SR=%d K=%d P=%d max_o=%d D=%d, 4 reference views %dx%d, hybrid viewmlp forward (query+gather+aggregate+composite)"
                                    % (sc.xyz.shape[0], sc.w, sc.h, args.margin, R, opt.SR, opt.K, opt.P, opt.max_o, opt.z_depth_dim, sc.h, sc.w),
