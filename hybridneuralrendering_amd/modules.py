@@ -120,6 +120,15 @@ class NeuralPoints(nn.Module):
 
     def _set(self, name, tensor, grad_flag):
         setattr(self, name, None if tensor is None else nn.Parameter(tensor, requires_grad=grad_flag > 0))
+        if name == "xyz":
+            self._points_changed()
+
+    def _points_changed(self):
+        """The voxel grid is cached per cloud (the reference rebuilds it per chunk, so it never has this problem): any change
+        of the point set drops it; the next query rebuilds it (3.5 ms for 2 M points -- cheap enough that an incremental CSR
+        update, SURVEY 8f-3, buys nothing)."""
+        if getattr(self, "querier", None) is not None:
+            self.querier.clean_up()
 
     def prune(self, thresh):                                           # :350-373
         mask = self.points_conf[0, ..., 0] >= thresh
@@ -154,6 +163,7 @@ class NeuralPoints(nn.Module):
         self.points_color = None if points_color is None else wrap(points_color, self.opt.color_grad)
         self.points_embeding = wrap(points_embeding, self.opt.feat_grad)
         self.Rw2c = torch.eye(3, device=points_xyz.device, dtype=points_xyz.dtype)
+        self._points_changed()
 
     def editing_set_points(self, points_xyz, points_embeding, points_color=None, points_dir=None, points_conf=None,
                            parameter=False, Rw2c=None, eulers=None):   # :473-487
@@ -162,6 +172,7 @@ class NeuralPoints(nn.Module):
         self.xyz, self.points_embeding, self.points_dir = points_xyz, points_embeding, points_dir
         self.points_conf, self.points_color = points_conf, points_color
         self.Rw2c = torch.eye(3, device=points_xyz.device, dtype=points_xyz.dtype)
+        self._points_changed()
 
     def null_grad(self):
         self.points_embeding.grad = None
