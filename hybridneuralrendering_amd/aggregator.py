@@ -26,7 +26,7 @@ _REQUIRED = dict(which_agg_model="viewmlp", agg_distance_kernel="linear", agg_in
                  shading_color_mlp_layer=4, act_type="LeakyReLU", act_super=1, agg_feat_xyz_mode="None",
                  agg_alpha_xyz_mode="None", agg_color_xyz_mode="None", feature_guidance=1, mixup_mode="partial",
                  learn_residuals=1, use_delta_view=1, tradition_attention=0, refine_blend=0, dynamic_weight=0, add_idx=0,
-                 separate_color_decoder=0, large_color_final_block=0, use_2D_CNN=0, learnable_blur_kernel=0,
+                 separate_color_decoder=0, large_color_final_block=0, use_2D_CNN=0,
                  disable_viewdirs=0, disable_color_feature=0, point_conf_mode="1", point_dir_mode="1", point_color_mode="1")
 
 
@@ -100,12 +100,39 @@ class PointAggregator(nn.Module):
         self.aux_block_s3 = _cnn(12, 24)
         self.color_mixup_block = _mlp([90, 45, 45, 45], act_last=False)
         self.color_final_block = nn.Sequential(nn.Linear(128, 3))
+        # blur-kernel predictor of the *_learnable.sh configs (point_aggregators.py:715-750): the aggregator only OWNS these
+        # parameters (checkpoint names `learn_blur_kernel_block.*`, `learn_blur_kernel_conv_block.*`) and hands the modules to
+        # the training shell as `blur_predictor` (:1339-1344); the shell's learnable_blur_update_output applies them
+        # (models/base_rendering_model.py:827-1020, out of scope) -- the hot path itself does not change.
+        blur_blocks = []
+        self.learn_blur_kernel_block = None
+        if getattr(opt, "learnable_blur_kernel", 0):
+            ps, ks = int(getattr(opt, "learnable_blur_patch_size", 8)), int(getattr(opt, "learnable_blur_kernel_size", 9))
+            n_in, n_out = 2 * ps * ps, ks * ks + (1 if getattr(opt, "learnable_blur_kernel_mode", 4) in (2, 4) else 0)
+            if getattr(opt, "learnable_blur_kernel_conv", 0):
+                act = lambda: nn.LeakyReLU(inplace=True)
+                self.learn_blur_kernel_conv_block = nn.Sequential(nn.Conv2d(2, 4, 3), act(), nn.Conv2d(4, 4, 1), act(), nn.Conv2d(4, 8, 3), act(),
+                                                                  nn.Conv2d(8, 8, 1), act())
+                blur_blocks.append(self.learn_blur_kernel_conv_block)
+                n_in = 8 * (ps - 4) * (ps - 4)
+            self.learn_blur_kernel_block = _mlp([n_in, 128, 128, 128, n_out], act_last=False, final=nn.Sigmoid())
+            blur_blocks.append(self.learn_blur_kernel_block)
+        for m in blur_blocks:
+            _init_seq(m)
         for m in (self.block1, self.block3, self.alpha_branch, self.color_branch, self.color_feature_branch,
                   self.aux_merge_weight_block, self.aux_block_s1, self.aux_block_s2, self.aux_block_s3,
                   self.color_mixup_block, self.color_final_block):
             _init_seq(m)
         self._packed = None
         self._packed_key = None
+
+    def blur_predictor(self):
+        """What viewmlp returns next to the decoded features (:1339-1344): None, the MLP, or [conv block, MLP]."""
+        if self.learn_blur_kernel_block is None:
+            return None
+        if getattr(self.opt, "learnable_blur_kernel_conv", 0):
+            return [self.learn_blur_kernel_conv_block, self.learn_blur_kernel_block]
+        return self.learn_blur_kernel_block
 
     # ------------------------------------------------------------------------------------------
     def packed(self):

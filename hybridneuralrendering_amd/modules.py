@@ -269,7 +269,8 @@ class NeuralPointsRayMarching(nn.Module):
         mask = full["ray_mask"]
         rows = torch.nonzero(mask)[:, 0]                                  # valid rays, in ray order (:705-709)
         sel = lambda t: t.index_select(0, rows)[None]
-        out = {"blur_predictor": None}
+        # the blur-kernel predictor modules go to the training shell untouched (:312-330: only in train mode)
+        out = {"blur_predictor": self.aggregator.blur_predictor() if getattr(self.opt, "is_train", 0) else None}
         ray_valid = (full["sample_pidx"][..., 0] >= 0)
         out["queried_shading"] = torch.logical_not(torch.any(sel(ray_valid), dim=-1, keepdims=True)).repeat(1, 1, 3).to(torch.float32)
         col = sel(full["coarse_raycolor"])

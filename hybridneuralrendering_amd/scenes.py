@@ -39,7 +39,8 @@ def default_opt(**kw):
         drop_ratio=0.5, drop_patch=1, ray_points=1, random_position=1, drop_disturb_range=0,
         dilation_setup="7_8_1_8", downweight_blurry_feats=0, disable_viewdirs=0, disable_color_feature=0,
         separate_color_decoder=0, large_color_final_block=0, use_2D_CNN=0, learnable_blur_kernel=0,
-        learnable_blur_kernel_conv=0, search_size=0, search_dilation=0, exp_aggregation=0,
+        learnable_blur_kernel_conv=0, learnable_blur_kernel_size=9, learnable_blur_patch_size=8,
+        learnable_blur_kernel_mode=4, learnable_blur_kernel_norm=0, search_size=0, search_dilation=0, exp_aggregation=0,
         sparse_loss_weight=0, zero_one_loss_items=["conf_coefficient"], prob=0,
         # render shell (models/neural_points_volumetric_model.py:47-70)
         raydist_mode_unit=1, which_render_func="radiance", which_blend_func="alpha",

@@ -38,11 +38,20 @@ def ray_drop_flags(opt, ray_mask):
     VALID-ray row (`drop_ray_flag[ray_drop_positions, :]` over the R' compacted rays, :1225-1233), reproduced here."""
     if not (getattr(opt, "is_train", 0) and getattr(opt, "drop_ratio", 0) > 0 and getattr(opt, "random_position", 0) == 1):
         return None
-    if not (getattr(opt, "ray_points", 0) and getattr(opt, "drop_patch", 0)) or getattr(opt, "drop_disturb_range", 0) != 0:
-        raise HnrError("only the deterministic patch drop (ray_points=1, drop_patch=1, drop_disturb_range=0) is implemented")
+    if not getattr(opt, "ray_points", 0) or getattr(opt, "drop_disturb_range", 0) != 0:
+        raise HnrError("only ray-based image-feature drop with drop_disturb_range=0 is implemented (all 19 shipped scripts)")
+    R = ray_mask.shape[0]
+    m = ray_mask > 0
+    if not getattr(opt, "drop_patch", 0):
+        # `random.sample(range(R'), int(R' * drop_ratio))` over the valid-ray rows (:1231-1232; Python's RNG there, torch's here):
+        # an exact-size uniform subset, chosen on the device without reading R' back
+        keys = torch.rand(R, device=ray_mask.device).masked_fill(~m, 2.0)
+        rank = torch.empty(R, dtype=torch.long, device=ray_mask.device)
+        rank[torch.argsort(keys)] = torch.arange(R, device=ray_mask.device)
+        n_drop = (m.sum() * float(opt.drop_ratio)).to(torch.long)           # int() truncation, like the reference
+        return (m & (rank < n_drop)).to(torch.uint8).contiguous()
     ps, pn = int(opt.dilation_setup.split("_")[1]), int(opt.dilation_setup.split("_")[0])
     pos = drop_patch_rays(ps, pn, opt.drop_ratio)
-    R = ray_mask.shape[0]
     lut = torch.zeros(R + 1, dtype=torch.bool, device=ray_mask.device)
     pos = pos[pos < R]
     lut[torch.from_numpy(pos).to(ray_mask.device)] = True
@@ -210,7 +219,7 @@ class TrainPath:
         ag = {}
         names = dict(a.named_parameters())
         for k, prm in names.items():
-            if not k.startswith("color_branch."):
+            if not k.startswith(("color_branch.", "learn_blur_kernel")):   # unused head / modules the training shell runs itself
                 ag[k] = torch.zeros_like(prm, dtype=torch.float32)
         if g_conf_out is not None:
             g_conf_out = _lib.require_gpu(g_conf_out, "grad conf_coefficient", torch.float32).reshape(R, SR, K)

@@ -9,6 +9,7 @@ What is pinned by the reference itself (runs on CPU with torch):
   * posenc.npz          <- positional_encoding (models/helpers/networks.py:175-189)
   * train_*.npz         <- the same forward in train mode (jittered depths, patch drop) + torch autograd of the
                            shipped loss terms: gradients w.r.t. every aggregator parameter and the point buffers
+  * aggregator_param_keys.json <- PointAggregator(opt).state_dict() names/shapes for the shipped option sets
   * blur_select.npz     <- BaseRenderingModel.blur_update_output (models/base_rendering_model.py:677-745) + autograd
   * render_*.npz        <- NeuralPointsRayMarching.forward (models/neural_points_volumetric_model.py:257-427)
                            = NeuralPoints gather + PointAggregator + ray_march, + fill_invalid (:87-126)
@@ -324,6 +325,20 @@ def gen_train(ref, tag, scene_name, n_points, seed, w, h, patch, opt_over=None, 
     opt.is_train = 0
 
 
+def gen_param_keys(ref):
+    """Parameter names and shapes of the reference's PointAggregator for the option sets of the shipped scripts
+    (default hybrid; *_learnable.sh: learnable_blur_kernel=1; plus the conv front-end switch)."""
+    out = {}
+    for tag, over in (("hybrid", {}), ("learnable", dict(learnable_blur_kernel=1)),
+                      ("learnable_conv", dict(learnable_blur_kernel=1, learnable_blur_kernel_conv=1))):
+        opt = scenes.scene_opt("scene0241", agg_axis_weight=None, **over)
+        agg = ref.agg.PointAggregator(opt)
+        out[tag] = {k: list(v.shape) for k, v in agg.state_dict().items()}
+    with open(os.path.join(HERE, "aggregator_param_keys.json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+    print("aggregator_param_keys.json:", {k: len(v) for k, v in out.items()})
+
+
 def gen_blur(ref):
     """BaseRenderingModel.blur_update_output (models/base_rendering_model.py:677-745) on a 7x7 grid of 8x8 patches with 12
     normalised 9x9 kernels: new colours, per-patch choice and the gradient of a random linear functional of the output."""
@@ -378,6 +393,7 @@ def main():
     gen_posenc(ref)
     gen_render(ref, "scannet_small", "scene0241", 12000, 11, 64, 48, 600, opt_over=dict(agg_axis_weight=None), size=(1.0, 0.8, 0.6))
     gen_render(ref, "synth_small", "lego", 9000, 12, 40, 40, 500, opt_over=dict(agg_axis_weight=None, SR=40))
+    gen_param_keys(ref)
     gen_blur(ref)
     gen_train(ref, "scannet_small", "scene0241", 12000, 11, 64, 48, 28,
               opt_over=dict(agg_axis_weight=None, dilation_setup="7_4_1_8"), size=(1.0, 0.8, 0.6))
