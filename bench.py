@@ -303,9 +303,10 @@ def main():
             "value": world * R * args.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: ranks share GPUs, gloo collectives -- not a measurement)",
-            "config": {"workload": "scene0241_01-like synthetic room (SURVEY 8d C3): %d points, %dx%d frame margin %d = %d rays per GPU per step, "
+            "config": {"workload": "%s synthetic scene (SURVEY 8d): %d points, %dx%d frame margin %d = %d rays per GPU per step, "
                                    "SR=%d K=%d P=%d max_o=%d D=%d, 4 reference views %dx%d, hybrid viewmlp forward (query+gather+aggregate+composite)"
-                                   % (sc.xyz.shape[0], sc.w, sc.h, args.margin, R, opt.SR, opt.K, opt.P, opt.max_o, opt.z_depth_dim, sc.h, sc.w),
+                                   % ({"scene0241": "scene0241_01-like room", "scene0101": "scene0101_04-like room"}.get(args.scene, args.scene + "-like object"),
+                                      sc.xyz.shape[0], sc.w, sc.h, args.margin, R, opt.SR, opt.K, opt.P, opt.max_o, opt.z_depth_dim, sc.h, sc.w),
                        "rays_per_gpu": R, "points": int(sc.xyz.shape[0]), "chunk_rays": args.chunk if args.chunk > 0 else R,
                        "parallelism": "ray-sharded x%d, one RCCL gather" % world},
             "roofline": roof, "roofline_query": roof_q, "cpu_baseline": cpu,
