@@ -224,3 +224,42 @@ def test_image_feature_drop_flags():
     f0 = ray_drop_flags(SimpleNamespace(drop_patch=0, **base), mask).numpy().astype(bool)
     assert f0.sum() == int(int(mask.sum()) * 0.5) and not (f0 & (mask.numpy() == 0)).any()
     assert ray_drop_flags(SimpleNamespace(drop_patch=1, **dict(base, is_train=0)), mask) is None
+
+
+def test_c_abi_rejects_bad_arguments_without_touching_the_gpu():
+    """Error convention of include/hnr.h: negative status + hnr_last_error() text, never an abort (the reference validates
+    nothing).  Argument checks run before any HIP call, so this needs no GPU."""
+    import ctypes
+    from hybridneuralrendering_amd import _lib
+    L = _lib.lib()
+    null = None
+    one = ctypes.c_void_p(16)                                   # a non-NULL, 16-byte aligned fake pointer; never dereferenced
+    bad = -1                                                    # HNR_ERR_BADARG
+    assert L.hnr_version().decode().startswith("hnr-hip")
+    np_, kp_ = ctypes.c_int(), ctypes.c_int()
+    assert L.hnr_linear_packed_dims(0, 5, ctypes.byref(np_), ctypes.byref(kp_)) == bad
+    assert L.hnr_linear_packed_dims(263, 256, ctypes.byref(np_), ctypes.byref(kp_)) == 0 and (np_.value, kp_.value) == (384, 256)
+    # lda not a multiple of 4 / smaller than K
+    assert L.hnr_linear_f32(one, 30, one, one, one, 256, 10, 256, 60, 1, 0.01, null) == bad
+    assert b"lda" in L.hnr_last_error()
+    assert L.hnr_linear_f32(one, 64, one, one, one, 100, 10, 256, 60, 1, 0.01, null) == bad        # ldc < N
+    assert L.hnr_linear_f32(null, 64, one, one, one, 256, 10, 256, 60, 1, 0.01, null) == bad       # NULL A with M > 0
+    assert L.hnr_linear_f32(null, 64, one, one, one, 256, 0, 256, 60, 1, 0.01, null) == 0          # M == 0: nothing to do
+    assert L.hnr_linear_f32_side(one, 64, one, one, null, null, 256, 256, 0, one, 256, 10, 256, 60, 0, 0.01, null) == bad   # side operand missing
+    assert L.hnr_linear_f32_side(one, 64, one, one, one, null, 256, 256, 1, one, 256, 10, 256, 60, 1, 0.01, null) == bad    # r_mode 1 with act
+    assert L.hnr_linear_f32_wgrad(one, 255, one, 64, 10, 256, 60, one, 60, null, 0, one, null) == bad                        # ldz % 4
+    assert L.hnr_linear_wgrad_scratch_elems(1000, 256, 256) >= 256 * 256
+    q = _lib.QueryParams(R=10, D=400, SR=24, K=40, kernel_size=(3, 3, 3), radius2=1.0, tmid_stride=0, pad_outputs=1)
+    assert L.hnr_march_query(one, one, one, one, ctypes.byref(q), one, one, one, one, one, one, null) == bad                # K > HNR_MAX_K
+    assert b"K=40" in L.hnr_last_error()
+    q.K, q.tmid_stride = 8, 7
+    assert L.hnr_march_query(one, one, one, one, ctypes.byref(q), one, one, one, one, one, one, null) == bad                # stride must be 0 or D
+    assert L.hnr_gather_rows(one, one, one, one, one, 16, one, one, one, one, one, one, one, one, one, 24, 8, 10, one, 64, one, 264, one, null, null,
+                             one, null) == bad                  # F != 32
+    assert L.hnr_composite(one, one, one, one, null, one, one, one, -1, 24, 8, 0.008, 1, one, one, one, null, null) == bad
+    assert L.hnr_composite_bwd(one, one, one, one, null, one, one, one, 5, 24, 8, 0.008, 1, null, one, null) == bad          # NULL upstream gradient
+    assert L.hnr_blur_select(one, one, one, 40, 9, 7, 8, one, one, null) == bad                                               # too many kernels
+    assert L.hnr_blur_select(one, one, one, 12, 8, 7, 8, one, one, null) == bad                                               # even kernel size
+    assert L.hnr_segment_sum_rows(one, 48, null, 0, one, one, 10, 46, one, 48, null) == bad                                   # n_cols % 4
+    assert L.hnr_query_work_elems(285200, 24) > 285200 * 24
+    assert L.hnr_image_features_scratch_elems(4, 480, 640) == 2 * 4 * (6 * 240 * 320 + 12 * 120 * 160 + 24 * 60 * 80)
