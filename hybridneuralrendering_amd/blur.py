@@ -21,11 +21,11 @@ class _BlurSelect(torch.autograd.Function):
         k = k.reshape(-1, k.shape[-2], k.shape[-1])
         if k.shape[-1] != k.shape[-2]:
             raise HnrError("blur kernels must be square")
-        S = patch_num * patch_size
-        if c.shape[0] != S * S or g.shape[0] != S * S:
-            raise HnrError("blur_update_output: the batch must be a %dx%d grid of rays (dilated patches), got %d rays" % (S, S, c.shape[0]))
+        n_patches = -patch_num if patch_num < 0 else patch_num * patch_num          # patch_num < 0: patch-major list of whole patches
+        if c.shape[0] != n_patches * patch_size * patch_size or g.shape[0] != c.shape[0]:
+            raise HnrError("blur_update_output: expected %d patches of %dx%d rays, got %d rays" % (n_patches, patch_size, patch_size, c.shape[0]))
         out = torch.empty_like(c)
-        sel = torch.empty((patch_num * patch_num,), dtype=torch.int32, device=c.device)
+        sel = torch.empty((n_patches,), dtype=torch.int32, device=c.device)
         with torch.cuda.device(c.device):
             _lib.check(L.hnr_blur_select(_lib.ptr(c), _lib.ptr(g), _lib.ptr(k), k.shape[0], k.shape[-1], patch_num, patch_size, _lib.ptr(out),
                                          _lib.ptr(sel), _lib.stream()), "hnr_blur_select")
@@ -47,9 +47,13 @@ class _BlurSelect(torch.autograd.Function):
         return g_in.reshape(shape), None, None, None, None
 
 
-def blur_update_output(coarse_raycolor, gt_image, blur_kernels, patch_num, patch_size, return_select=False):
+def blur_update_output(coarse_raycolor, gt_image, blur_kernels, patch_num, patch_size, return_select=False, layout="grid"):
     """coarse_raycolor, gt_image: [1, S*S, 3] (S = patch_num * patch_size, dilated-patch ray layout); blur_kernels [1, N, ks, ks]
     (the dataset item's `blur_kernels`, data/scannet_ft_dataset.py:974).  Returns the new coarse_raycolor (same shape,
-    differentiable w.r.t. the input colours)."""
-    out, sel = _BlurSelect.apply(coarse_raycolor, gt_image, blur_kernels, int(patch_num), int(patch_size))
+    differentiable w.r.t. the input colours).  layout="patch_major": the tensors hold `patch_num` whole patches packed
+    (patch, y, x) -- a rank's share when the batch is sharded by patches (parallel.shard_patches)."""
+    if layout not in ("grid", "patch_major"):
+        raise HnrError("blur_update_output: layout must be 'grid' or 'patch_major'")
+    out, sel = _BlurSelect.apply(coarse_raycolor, gt_image, blur_kernels, -int(patch_num) if layout == "patch_major" else int(patch_num),
+                                 int(patch_size))
     return (out, sel) if return_select else out

@@ -19,21 +19,28 @@ struct BlurArgs {
     const float *color, *gt;          // [S*S,3] ray layout: ray = row * S + col, S = patch_num * patch_size
     const float *kernels;             // [N, ks, ks]
     int N, ks, pn, ps;
+    int n_patches, patch_major;       // patch_major: ray = (patch * ps + y) * ps + x (a rank's whole patches); else the pn x pn grid
     float *out;                       // [S*S,3]
-    int32_t *select;                  // [pn*pn] chosen candidate (N = un-blurred)
+    int32_t *select;                  // [n_patches] chosen candidate (N = un-blurred)
 };
+
+__device__ __forceinline__ size_t blur_ray(int p, int y, int x, int pn, int ps, int patch_major)
+{
+    if (patch_major) return ((size_t)p * ps + y) * ps + x;
+    return (size_t)((p / pn) * ps + y) * (pn * ps) + ((p % pn) * ps + x);
+}
 
 __global__ __launch_bounds__(256) void blur_select_kernel(BlurArgs a)
 {
     __shared__ float s_in[3][BLUR_MAX_PS][BLUR_MAX_PS], s_gt[3][BLUR_MAX_PS][BLUR_MAX_PS];
     __shared__ float s_diff[BLUR_MAX_N + 1];
     __shared__ int s_sel;
-    const int p = blockIdx.x, pi = p / a.pn, pj = p % a.pn;
-    const int ps = a.ps, S = a.pn * a.ps, half = a.ks / 2;
+    const int p = blockIdx.x;
+    const int ps = a.ps, half = a.ks / 2;
     const int npos = 3 * ps * ps;
     for (int t = threadIdx.x; t < npos; t += blockDim.x) {
         const int c = t / (ps * ps), y = (t / ps) % ps, x = t % ps;
-        const size_t ray = (size_t)(pi * ps + y) * S + (pj * ps + x);
+        const size_t ray = blur_ray(p, y, x, a.pn, ps, a.patch_major);
         s_in[c][y][x] = a.color[3 * ray + c];
         s_gt[c][y][x] = a.gt[3 * ray + c];
     }
@@ -77,7 +84,7 @@ __global__ __launch_bounds__(256) void blur_select_kernel(BlurArgs a)
     const int sel = s_sel;
     for (int t = threadIdx.x; t < npos; t += blockDim.x) {
         const int c = t / (ps * ps), y = (t / ps) % ps, x = t % ps;
-        const size_t ray = (size_t)(pi * ps + y) * S + (pj * ps + x);
+        const size_t ray = blur_ray(p, y, x, a.pn, ps, a.patch_major);
         a.out[3 * ray + c] = blurred(sel, c, y, x);
     }
 }
@@ -87,20 +94,21 @@ struct BlurBwdArgs {
     const float *kernels;
     const int32_t *select;
     int N, ks, pn, ps;
+    int n_patches, patch_major;
     float *g_in;                      // [S*S,3]
 };
 
 __global__ __launch_bounds__(256) void blur_select_bwd_kernel(BlurBwdArgs a)
 {
     __shared__ float s_g[3][BLUR_MAX_PS][BLUR_MAX_PS];     // g_out / mask_out of the selected kernel
-    const int p = blockIdx.x, pi = p / a.pn, pj = p % a.pn;
-    const int ps = a.ps, S = a.pn * a.ps, half = a.ks / 2;
+    const int p = blockIdx.x;
+    const int ps = a.ps, half = a.ks / 2;
     const int npos = 3 * ps * ps;
     const int sel = a.select[p];
     const float *k = a.kernels + (size_t)(sel < a.N ? sel : 0) * a.ks * a.ks;
     for (int t = threadIdx.x; t < npos; t += blockDim.x) {
         const int c = t / (ps * ps), y = (t / ps) % ps, x = t % ps;
-        const size_t ray = (size_t)(pi * ps + y) * S + (pj * ps + x);
+        const size_t ray = blur_ray(p, y, x, a.pn, ps, a.patch_major);
         float g = a.g_out[3 * ray + c];
         if (sel < a.N) {
             float msk = 0.f;
@@ -119,7 +127,7 @@ __global__ __launch_bounds__(256) void blur_select_bwd_kernel(BlurBwdArgs a)
     __syncthreads();
     for (int t = threadIdx.x; t < npos; t += blockDim.x) {
         const int c = t / (ps * ps), y = (t / ps) % ps, x = t % ps;
-        const size_t ray = (size_t)(pi * ps + y) * S + (pj * ps + x);
+        const size_t ray = blur_ray(p, y, x, a.pn, ps, a.patch_major);
         float acc;
         if (sel >= a.N) {
             acc = s_g[c][y][x];
@@ -146,7 +154,7 @@ using namespace hnr;
 
 static int blur_check(int N, int ks, int pn, int ps, const char *who)
 {
-    if (N < 0 || N > BLUR_MAX_N || ks <= 0 || (ks & 1) == 0 || pn <= 0 || ps <= 0 || ps > BLUR_MAX_PS) {
+    if (N < 0 || N > BLUR_MAX_N || ks <= 0 || (ks & 1) == 0 || pn == 0 || ps <= 0 || ps > BLUR_MAX_PS) {
         set_error("%s: unsupported sizes (N <= %d kernels, odd kernel size, patch size <= %d)", who, BLUR_MAX_N, BLUR_MAX_PS);
         return HNR_ERR_BADARG;
     }
@@ -159,9 +167,10 @@ extern "C" int hnr_blur_select(const float *d_color, const float *d_gt, const fl
     if (blur_check(n_kernels, kernel_size, patch_num, patch_size, "hnr_blur_select") != HNR_OK) return HNR_ERR_BADARG;
     if (!d_color || !d_gt || (n_kernels > 0 && !d_kernels) || !d_out || !d_select) { set_error("hnr_blur_select: NULL argument"); return HNR_ERR_BADARG; }
     BlurArgs a;
-    a.color = d_color; a.gt = d_gt; a.kernels = d_kernels; a.N = n_kernels; a.ks = kernel_size; a.pn = patch_num; a.ps = patch_size;
+    a.color = d_color; a.gt = d_gt; a.kernels = d_kernels; a.N = n_kernels; a.ks = kernel_size; a.ps = patch_size;
+    a.patch_major = patch_num < 0; a.pn = patch_num < 0 ? 1 : patch_num; a.n_patches = patch_num < 0 ? -patch_num : patch_num * patch_num;
     a.out = d_out; a.select = d_select;
-    blur_select_kernel<<<patch_num * patch_num, 256, 0, (hipStream_t)stream>>>(a);
+    blur_select_kernel<<<a.n_patches, 256, 0, (hipStream_t)stream>>>(a);
     HNR_LAUNCH_CHECK();
     return HNR_OK;
 }
@@ -172,9 +181,10 @@ extern "C" int hnr_blur_select_bwd(const float *d_g_out, const float *d_kernels,
     if (blur_check(n_kernels, kernel_size, patch_num, patch_size, "hnr_blur_select_bwd") != HNR_OK) return HNR_ERR_BADARG;
     if (!d_g_out || (n_kernels > 0 && !d_kernels) || !d_select || !d_g_in) { set_error("hnr_blur_select_bwd: NULL argument"); return HNR_ERR_BADARG; }
     BlurBwdArgs a;
-    a.g_out = d_g_out; a.kernels = d_kernels; a.select = d_select; a.N = n_kernels; a.ks = kernel_size; a.pn = patch_num; a.ps = patch_size;
+    a.g_out = d_g_out; a.kernels = d_kernels; a.select = d_select; a.N = n_kernels; a.ks = kernel_size; a.ps = patch_size;
+    a.patch_major = patch_num < 0; a.pn = patch_num < 0 ? 1 : patch_num; a.n_patches = patch_num < 0 ? -patch_num : patch_num * patch_num;
     a.g_in = d_g_in;
-    blur_select_bwd_kernel<<<patch_num * patch_num, 256, 0, (hipStream_t)stream>>>(a);
+    blur_select_bwd_kernel<<<a.n_patches, 256, 0, (hipStream_t)stream>>>(a);
     HNR_LAUNCH_CHECK();
     return HNR_OK;
 }

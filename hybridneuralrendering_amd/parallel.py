@@ -58,11 +58,31 @@ def render_sharded(render_fn, raydir, n_total=None, group=None):
 # (models/mvs_points_volumetric_model.py:94-104 in the reference) step identically on every rank.  The reference has no
 # counterpart: its DataParallel wrapper always runs on gpu_ids[0] only.
 
-def shard_patches(n_patches, patch_rays, world_size, rank):
-    """Ray range [lo, hi) of rank `rank` when `n_patches` patches of `patch_rays` rays each are dealt out as whole
-    patches (49 patches on 8 ranks -> 7,6,6,6,6,6,6,6), so the per-patch blur/argmin of the shell needs no halo."""
-    lo, hi = shard_bounds(n_patches, world_size, rank)
-    return lo * patch_rays, hi * patch_rays
+def shard_patches(patch_num, patch_size, world_size, rank):
+    """Whole dilated patches per rank (49 patches on 8 ranks -> 7,6,6,6,6,6,6,6), so the per-patch blur / argmin of the shell needs
+    no halo.  The batch is a (patch_num*patch_size)^2 grid of rays in row-major order (data/scannet_ft_dataset.py:899-949), so a
+    patch is NOT a contiguous ray range.  Returns (patch ids [n_local], ray indices [n_local * patch_size^2]) with the rays
+    packed patch-major (patch, y, x) -- the layout blur.blur_update_output(..., layout="patch_major") expects."""
+    lo, hi = shard_bounds(patch_num * patch_num, world_size, rank)
+    ids = torch.arange(lo, hi)
+    S = patch_num * patch_size
+    pi, pj = ids // patch_num, ids % patch_num
+    y = torch.arange(patch_size)
+    rows = (pi[:, None, None] * patch_size + y[None, :, None]) * S + (pj[:, None, None] * patch_size + y[None, None, :])
+    return ids, rows.reshape(-1)
+
+
+def global_drop_flags(patch_num, patch_size, drop_ratio):
+    """[S*S] uint8: the batch-wide image-feature drop pattern of the reference (drop_patch_rays, point_aggregators.py:14-23) by
+    GLOBAL ray index; a rank passes its slice to render_train(ray_drop=...).  (Single-GPU training indexes the pattern by
+    valid-ray row like the reference; the two agree whenever every ray of the batch finds neighbours.)"""
+    S = patch_num * patch_size
+    flag = torch.zeros((S, S), dtype=torch.uint8)
+    n = int(patch_num * patch_num * drop_ratio)
+    row, col = n // patch_num, n % patch_num
+    flag[0:row * patch_size, :] = 1
+    flag[row * patch_size:row * patch_size + patch_size, 0:col * patch_size] = 1
+    return flag.reshape(-1)
 
 
 def loss_scale(n_local, n_total):

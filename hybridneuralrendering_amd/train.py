@@ -95,7 +95,7 @@ class TrainPath:
 
     # ---------------------------------------------------------------------------------------------- forward
     def forward(self, cloud, raydir, campos, camrot, bg_color, near, far, c2w_nearest, campos_nearest, intrinsic_nearest,
-                images_nearest, frame_weight=None, tmid=None):
+                images_nearest, frame_weight=None, tmid=None, ray_drop=None):
         L = _lib.lib()
         r, opt = self.r, self.opt
         g = _lib.require_gpu
@@ -129,7 +129,9 @@ class TrainPath:
         c = counts.cpu()
         n_valid, n_rows = int(c[CNT["SAMPLES_VALID"]]), int(c[CNT["NEIGHBOURS"]])
         S.n_valid, S.n_rows = n_valid, n_rows
-        S.ray_drop = ray_drop_flags(opt, qres["ray_mask"])
+        # ray_drop: explicit [R] flags (a rank's slice of the batch-wide drop pattern when the batch is sharded over GPUs)
+        S.ray_drop = ray_drop_flags(opt, qres["ray_mask"]) if ray_drop is None else \
+            (_lib.require_gpu(ray_drop, "ray_drop", torch.uint8).reshape(-1) & (qres["ray_mask"] > 0).to(torch.uint8)).contiguous()
         img = g(images_nearest, "images_nearest", torch.float32)
         if img.dim() == 5:
             img = img[0]
@@ -350,7 +352,8 @@ class _RenderFn(torch.autograd.Function):
         cloud = PointCloud(static["xyz"], emb, conf, pdir, color)
         out, S = path.forward(cloud, static["raydir"], static["campos"], static["camrot"], static["bg_color"], static["near"],
                               static["far"], static["c2w_nearest"], static["campos_nearest"], static["intrinsic_nearest"],
-                              static["images_nearest"], frame_weight=static.get("frame_weight"), tmid=static.get("tmid"))
+                              static["images_nearest"], frame_weight=static.get("frame_weight"), tmid=static.get("tmid"),
+                              ray_drop=static.get("ray_drop"))
         ctx.path, ctx.S = path, S
         ctx.shapes = (emb.shape, conf.shape, pdir.shape, color.shape)
         ctx.param_names = static["param_names"]
@@ -374,7 +377,7 @@ class _RenderFn(torch.autograd.Function):
 
 
 def render_train(path, aggregator, xyz, emb, conf, pdir, color, raydir, campos, camrot, bg_color, near, far, c2w_nearest,
-                 campos_nearest, intrinsic_nearest, images_nearest, frame_weight=None, tmid=None):
+                 campos_nearest, intrinsic_nearest, images_nearest, frame_weight=None, tmid=None, ray_drop=None):
     """Differentiable render of one ray batch.  emb/conf/pdir/color may be nn.Parameters (reference shapes [1,N,32], [1,N,1],
     [1,N,3], [1,N,3]); aggregator parameters receive gradients through the returned tensors.  Returns the output dict of
     TrainPath.forward with `coarse_raycolor` and `conf_coefficient` attached to the autograd graph."""
@@ -382,7 +385,7 @@ def render_train(path, aggregator, xyz, emb, conf, pdir, color, raydir, campos, 
     params = [q for _, q in aggregator.named_parameters()]
     static = dict(xyz=xyz, raydir=raydir, campos=campos, camrot=camrot, bg_color=bg_color, near=near, far=far,
                   c2w_nearest=c2w_nearest, campos_nearest=campos_nearest, intrinsic_nearest=intrinsic_nearest,
-                  images_nearest=images_nearest, frame_weight=frame_weight, tmid=tmid, param_names=names)
+                  images_nearest=images_nearest, frame_weight=frame_weight, tmid=tmid, ray_drop=ray_drop, param_names=names)
     col, cc = _RenderFn.apply(path, static, emb, conf, pdir, color, *params)
     out = dict(static.pop("_out"))
     out["coarse_raycolor"], out["conf_coefficient"] = col, cc

@@ -388,7 +388,9 @@ int hnr_sum_views(const float *d_in, int ldi, int V, int cap, int n_samples, int
  * (`blur_update_output`, called at mvs_points_volumetric_model.py:145-146).  d_color / d_gt / d_out: [S*S,3] with
  * S = patch_num * patch_size in the dilated-patch ray layout; d_kernels [n_kernels, ks, ks]; per patch the candidate
  * (n_kernels blurred versions, normalised at the borders, + the un-blurred patch as candidate n_kernels) closest in L1 to
- * the ground truth replaces the patch; d_select [patch_num^2] records the choice for the backward. */
+ * the ground truth replaces the patch; d_select [patch_num^2] records the choice for the backward.
+ * patch_num < 0: the buffers hold -patch_num whole patches packed patch-major (patch, y, x) -- a rank's share of a batch
+ * that is sharded over GPUs by whole patches (parallel.shard_patches); d_select then has -patch_num entries. */
 int hnr_blur_select(const float *d_color, const float *d_gt, const float *d_kernels, int n_kernels, int kernel_size,
                     int patch_num, int patch_size, float *d_out, int32_t *d_select, void *stream);
 int hnr_blur_select_bwd(const float *d_g_out, const float *d_kernels, const int32_t *d_select, int n_kernels, int kernel_size,

@@ -46,3 +46,21 @@ def test_blur_select_matches_oracle(pn, ps, N, ks):
     assert torch.equal(sel.cpu().long(), rsel)
     np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=0, atol=2e-6)
     np.testing.assert_allclose(c1.grad.cpu().numpy(), c0.grad.numpy(), rtol=0, atol=2e-6)
+
+
+def test_blur_select_patch_major_layout_equals_grid_layout():
+    """A rank's whole patches packed (patch, y, x) give the same per-patch results as the grid layout of the full batch."""
+    from hybridneuralrendering_amd.blur import blur_update_output
+    from hybridneuralrendering_amd.parallel import shard_patches
+    z = np.load(os.path.join(GOLD, "blur_select.npz"))
+    pn, ps, N, ks = (int(v) for v in z["dims"])
+    col, gt, k = torch.from_numpy(z["color"]).cuda(), torch.from_numpy(z["gt"]).cuda(), torch.from_numpy(z["kernels"]).cuda()[None]
+    full, sel_full = blur_update_output(col, gt, k, pn, ps, return_select=True)
+    for rank in range(3):
+        ids, rays = shard_patches(pn, ps, 3, rank)
+        rays = rays.cuda()
+        c = col[:, rays].clone().requires_grad_(True)
+        part, sel = blur_update_output(c, gt[:, rays], k, ids.numel(), ps, return_select=True, layout="patch_major")
+        assert torch.equal(part.detach(), full[:, rays]) and torch.equal(sel, sel_full[ids.cuda()])
+        part.sum().backward()
+        assert torch.isfinite(c.grad).all()
