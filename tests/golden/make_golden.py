@@ -18,6 +18,9 @@ query_points comes from oracle/query_oracle.c wrapped in the reference's own tai
 everything downstream of it is the reference's code and weights (seeded init).
 
 Only data (inputs + expected outputs) is written; no reference source travels.
+Re-running reproduces every array bit for bit except the gradients of the three conv blocks in train_*.npz (torch's
+multi-threaded CPU conv backward sums in a run-dependent order; differences ~1e-9) and `opt_json` when option defaults
+were added since.
 """
 import json
 import os
