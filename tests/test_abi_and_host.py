@@ -266,3 +266,30 @@ def test_c_abi_rejects_bad_arguments_without_touching_the_gpu():
     assert L.hnr_segment_sum_rows(one, 48, null, 0, one, one, 10, 46, one, 48, null) == bad                                   # n_cols % 4
     assert L.hnr_query_work_elems(285200, 24) > 285200 * 24
     assert L.hnr_image_features_scratch_elems(4, 480, 640) == 2 * 4 * (6 * 240 * 320 + 12 * 120 * 160 + 24 * 60 * 80)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/models"), reason="the reference checkout only exists in the build container")
+def test_install_rebinds_the_reference_globals():
+    """hnr.install() swaps the five names the reference's shell resolves by module global."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from _ref_import import import_reference
+    ref = import_reference()
+    import hybridneuralrendering_amd.modules as hnr
+    from hybridneuralrendering_amd.aggregator import PointAggregator
+    from hybridneuralrendering_amd import querier
+    saved = (ref.vol.NeuralPoints, ref.vol.PointAggregator, ref.vol.NeuralPointsRayMarching, ref.vol.ray_march, ref.npts.lighting_fast_querier_w)
+    try:
+        vol = hnr.install()
+        assert vol is ref.vol
+        assert ref.vol.NeuralPoints is hnr.NeuralPoints and ref.vol.PointAggregator is PointAggregator
+        assert ref.vol.NeuralPointsRayMarching is hnr.NeuralPointsRayMarching and ref.vol.ray_march is hnr.ray_march
+        assert ref.npts.lighting_fast_querier_w is querier.lighting_fast_querier
+        # same constructor / forward parameter names as the classes they replace
+        import inspect
+        for ours, theirs in ((hnr.NeuralPointsRayMarching.forward, saved[2].forward), (hnr.NeuralPoints.__init__, saved[0].__init__),
+                             (querier.lighting_fast_querier.query_points, ref.qw.lighting_fast_querier.query_points)):
+            po = [p for p in inspect.signature(ours).parameters]
+            pt = [p for p in inspect.signature(theirs).parameters]
+            assert po[:len(pt)] == pt or set(pt) <= set(po), (po, pt)
+    finally:
+        (ref.vol.NeuralPoints, ref.vol.PointAggregator, ref.vol.NeuralPointsRayMarching, ref.vol.ray_march, ref.npts.lighting_fast_querier_w) = saved
