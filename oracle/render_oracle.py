@@ -280,7 +280,8 @@ def drop_patch_rays(patch_size, patch_num, drop_ratio):
 def shipped_loss(full_raycolor, ray_mask, conf_coefficient, gt, zero_epsilon, w_color=1.0, w_zero_one=1e-4):
     """The two loss terms the shipped ScanNet scripts enable (dev_scripts/w_scannet_etf/scene241.sh:146-151):
     `ray_masked_coarse_raycolor` MSE (models/base_rendering_model.py:1113-1118) and the zero-one regulariser on
-    conf_coefficient (:1228-1240).  Returns (total, color, zero_one)."""
+    conf_coefficient (:1228-1240).  Returns (total, color, zero_one).  The shell's compute_losses adds a constant 1e-6 per colour
+    loss item on top (:1198; no gradient) -- tests/golden/train_*.npz keeps its value as `loss_compute_losses`."""
     m3 = (ray_mask > 0)[..., None].expand(-1, -1, 3)
     mo = torch.masked_select(full_raycolor, m3).reshape(1, -1, 3)
     mg = torch.masked_select(gt, m3).reshape(1, -1, 3)

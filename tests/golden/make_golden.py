@@ -290,6 +290,19 @@ def gen_train(ref, tag, scene_name, n_points, seed, w, h, patch, opt_over=None, 
     val = torch.clamp(out["conf_coefficient"], eps, 1 - eps)
     loss_zo = torch.mean(torch.log(val) + torch.log(1 - val))
     loss = loss_color * 1.0 + loss_zo * 1e-4
+    # pin the restated terms against the shell's own compute_losses (models/base_rendering_model.py:1022-1262) on a stand-in
+    # `self`: same items / weights as scene241.sh:146-151.  It adds a constant 1e-6 per colour item (:1198), nothing else differs.
+    import models.base_rendering_model as brm
+    lopt = SimpleNamespace(color_loss_items=["ray_masked_coarse_raycolor", "ray_miss_coarse_raycolor", "coarse_raycolor"],
+                           color_loss_weights=[1.0, 0.0, 0.0], depth_loss_items=[], depth_loss_weights=[], bg_loss_items=[], bg_loss_weights=[],
+                           zero_one_loss_items=["conf_coefficient"], zero_one_loss_weights=[1e-4], zero_epsilon=eps, l2_size_loss_items=[],
+                           l2_size_loss_weights=[], sparse_loss_weight=0, use_frame_weight=0)
+    lshell = SimpleNamespace(opt=lopt, output=dict(coarse_raycolor=out_full["coarse_raycolor"].detach(), ray_mask=out["ray_mask"],
+                                                   conf_coefficient=out["conf_coefficient"].detach()),
+                             gt_image=t(gt), l2loss=torch.nn.MSELoss(), is_train=True, dilation_PatchSize=None, input={}, frame_weight=None)
+    brm.BaseRenderingModel.compute_losses(lshell)
+    loss_shell = float(lshell.loss_total)
+    assert abs(loss_shell - (loss.item() + 3e-6)) < 2e-7, (loss_shell, loss.item())
     loss.backward()
     save = dict(
         scene=np.array([scene_name, str(n_points), str(seed), str(w), str(h), json.dumps(size)]),
@@ -302,7 +315,7 @@ def gen_train(ref, tag, scene_name, n_points, seed, w, h, patch, opt_over=None, 
         q_sample_pidx=q["sample_pidx"], q_sample_loc_w=q["sample_loc_w"], q_ray_mask=q["ray_mask"],
         coarse_raycolor=out["coarse_raycolor"].detach().numpy(), conf_coefficient=out["conf_coefficient"].detach().numpy(),
         full_coarse_raycolor=out_full["coarse_raycolor"].detach().numpy(),
-        loss=np.array([loss.item(), loss_color.item(), loss_zo.item()], np.float64),
+        loss=np.array([loss.item(), loss_color.item(), loss_zo.item()], np.float64), loss_compute_losses=np.float64(loss_shell),
     )
     # same seed and scene as render_<tag>.npz: the weights are that fixture's `sd.*` entries (checked, not stored twice)
     twin = np.load(os.path.join(HERE, "render_%s.npz" % tag))

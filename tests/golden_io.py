@@ -22,7 +22,7 @@ def load_train(tag):
     d = load_render(tag)
     z = np.load(os.path.join(GOLD, "train_%s.npz" % tag), allow_pickle=False)
     for k in ("coarse_raycolor", "conf_coefficient", "full_coarse_raycolor", "q_sample_pidx", "q_sample_loc_w", "q_ray_mask",
-              "pix", "raydir", "c2w", "intrinsic", "bg_color", "near_far", "tmid", "gt", "loss", "zero_epsilon"):
+              "pix", "raydir", "c2w", "intrinsic", "bg_color", "near_far", "tmid", "gt", "loss", "zero_epsilon", "loss_compute_losses"):
         d[k] = z[k]
     d["opt"] = json.loads(str(z["opt_json"]))
     d["grad"] = {k[5:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("grad.")}

@@ -119,6 +119,8 @@ def test_train_step_oracle_matches_reference_gradients():
     np.testing.assert_allclose(out["coarse_raycolor"].detach().numpy(), d["coarse_raycolor"], rtol=0, atol=2e-6)
     np.testing.assert_allclose(out["conf_coefficient"].detach().numpy(), d["conf_coefficient"], rtol=0, atol=0)
     np.testing.assert_allclose(np.array(losses), d["loss"], rtol=1e-6)
+    # the shell's own compute_losses on the same outputs = the restated terms + its constant 1e-6 per colour item (:1198)
+    assert abs(float(d["loss_compute_losses"]) - (losses[0] + 3e-6)) < 3e-7
     assert set(grads) == set(d["grad"]), set(grads) ^ set(d["grad"])
     for k, g in d["grad"].items():
         ref = g.numpy()
