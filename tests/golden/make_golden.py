@@ -413,6 +413,8 @@ def main():
     gen_blur(ref)
     gen_train(ref, "scannet_small", "scene0241", 12000, 11, 64, 48, 28,
               opt_over=dict(agg_axis_weight=None, dilation_setup="7_4_1_8"), size=(1.0, 0.8, 0.6))
+    # object scene: most rays miss (R' << R), SR = 40
+    gen_train(ref, "synth_small", "lego", 9000, 12, 40, 40, 20, opt_over=dict(agg_axis_weight=None, SR=40, dilation_setup="5_4_1_8"), margin=8)
 
 
 if __name__ == "__main__":

@@ -105,10 +105,11 @@ def _drop_rows(opt):
     return ro.drop_patch_rays(ps, pn, opt["drop_ratio"])
 
 
-def test_train_step_oracle_matches_reference_gradients():
+@pytest.mark.parametrize("tag", ["scannet_small", "synth_small"])
+def test_train_step_oracle_matches_reference_gradients(tag):
     """Forward in train mode (jittered depths, patch drop, straight-through conf clamp) + autograd of the shipped loss:
-    loss value and every gradient the reference produced (tests/golden/train_scannet_small.npz)."""
-    d = load_train("scannet_small")
+    loss value and every gradient the reference produced (tests/golden/train_<tag>.npz)."""
+    d = load_train(tag)
     ti = torch_inputs(d)
     q = dict(sample_pidx=d["q_sample_pidx"], sample_loc_w=d["q_sample_loc_w"], ray_mask=d["q_ray_mask"])
     assert 0 < int(d["q_ray_mask"].sum()) < d["q_ray_mask"].size          # R' != R: the valid-row indexing of the drop pattern matters
