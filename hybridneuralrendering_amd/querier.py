@@ -211,6 +211,7 @@ class lighting_fast_querier:
         self.count = 0
         self._grid = None
         self._grid_key = None
+        self._grid_src = None
         self._hp = None
         self._tmid = {}
         self.last_counts = None
@@ -220,7 +221,7 @@ class lighting_fast_querier:
     def clean_up(self):
         if self._grid is not None:
             self._grid.free()
-        self._grid, self._grid_key, self._hp = None, None, None
+        self._grid, self._grid_key, self._hp, self._grid_src = None, None, None, None
 
     # -- hyper-parameters (:46-77) -------------------------------------------------------------
     def get_hyperparameters(self, vsize_np, point_xyz_w_tensor, ranges=None):
@@ -248,6 +249,7 @@ class lighting_fast_querier:
         self._grid = VoxelGrid(xyz.reshape(-1, 3), ranges_np[:3], scaled_vsize_np, scaled_vdim_np, self.opt.query_size,
                                self.opt.P, self.opt.max_o)
         self._grid_key, self._hp = key, hp
+        self._grid_src = xyz                                     # keeps the keyed buffer alive (its address must not be recycled)
         self.last_grid_stats = self._grid.stats
         return self._grid, hp
 

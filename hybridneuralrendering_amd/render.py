@@ -64,8 +64,8 @@ class HybridRenderer:
         self.agg = aggregator
         self.device = torch.device(device)
         self.querier = Q.lighting_fast_querier(self.device, opt)
-        self._fm_key, self._fm = None, None
-        self._pt_key, self._pt = None, None
+        self._fm_key, self._fm, self._fm_src = None, None, None
+        self._pt_key, self._pt, self._pt_src = None, None, None
         self.split_block1 = True          # fold the point-only 224 columns of block1.0 into a per-point table
         self.split_merge = True           # multiply the colour-feature columns of aux_merge_weight_block.0 once per sample
         self.last_counts = None
@@ -80,6 +80,9 @@ class HybridRenderer:
         if key != self._fm_key:
             self._fm = self.agg.image_features(images_nearest)
             self._fm_key = key
+            # keep the keyed tensor alive: a freed buffer's address (and version 0) can be handed to the NEXT frame's images by the
+            # caching allocator, which would look like a cache hit
+            self._fm_src = images_nearest
         return self._fm
 
     def point_table(self, cloud):
@@ -89,6 +92,7 @@ class HybridRenderer:
         if key != self._pt_key:
             self._pt = self.agg.point_table(cloud.emb)
             self._pt_key = key
+            self._pt_src = cloud.emb                             # same reason as in feature_map
         return self._pt
 
     # -- stage 3: gather + aggregate ----------------------------------------------------------------

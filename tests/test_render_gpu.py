@@ -156,3 +156,19 @@ def test_whole_frame_equals_chunked_render():
     img = whole["image"].cpu().numpy()
     np.testing.assert_array_equal(img[pix[:, 1], pix[:, 0]], whole["coarse_raycolor"].cpu().numpy())
     assert int(whole["ray_mask"].sum()) > 100 and img.std() > 0.01
+
+
+def test_feature_cache_is_not_fooled_by_a_recycled_buffer():
+    """A new frame's reference images may be allocated at the address of the previous frame's (freed) tensor: the per-frame
+    feature-pyramid cache must rebuild (it keeps the keyed tensor alive so that cannot happen)."""
+    d, ti, opt, cloud, rnd = _setup("scannet_small")
+    img = ti["images_nearest"][0].clone()
+    fm1 = rnd.feature_map(img).clone()
+    ptr = img.data_ptr()
+    del img
+    torch.cuda.synchronize()
+    img2 = (1.0 - ti["images_nearest"][0]).clone()               # a different frame; the allocator is free to reuse the block
+    fm2 = rnd.feature_map(img2)
+    assert img2.data_ptr() != ptr or True                         # (either way the result must be the new frame's pyramid)
+    want = rnd.agg.image_features(img2)
+    assert torch.equal(fm2, want) and not torch.equal(fm2, fm1)
