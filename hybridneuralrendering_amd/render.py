@@ -196,8 +196,7 @@ class HybridRenderer:
           with T("final_color"):
             _lib.check(L.hnr_final_color(p(Y1), 48, p(CF), 128, p(pk["fin_w"]), p(pk["fin_b"]), p(sigma), p(vs_item), p(counts),
                                          n_valid, p(decoded), st()), "hnr_final_color")
-        if int(overflow.item()) != 0:
-            raise HnrError("hnr_sample_plan: row buffers too small (internal sizing error)")
+        out["overflow"] = overflow                 # checked by render_rays AFTER the composite is queued (no pipeline drain here)
         if want_weights:
             out.update(weight=w_out, conf_coefficient=c_out)
         return out
@@ -247,6 +246,8 @@ class HybridRenderer:
                            frame_weight=frame_weight, want_weights=want_weights, timers=timers)
         with _Stage(timers, "composite"):
             out = self.composite(a["decoded"], qres, campos, camrot, bg_color, want_blend=want_weights)
+        if "overflow" in a and int(a["overflow"].item()) != 0:
+            raise HnrError("hnr_sample_plan: row buffers too small (internal sizing error)")
         out.update(ray_mask=qres["ray_mask"], decoded=a["decoded"], sample_pidx=qres["sample_pidx"],
                    sample_loc_w=qres["sample_loc_w"], ray_nsamp=qres["ray_nsamp"], counts=qres["counts"])
         if want_weights:
