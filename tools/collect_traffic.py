@@ -1,28 +1,41 @@
-"""Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py into profiles/r01_traffic.json.
-Run on the GPU box after the two PMC passes (see profiles/README.md)."""
-import collections, csv, glob, json, sys
+"""Summarise the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py (tools/run_traffic.sh) into profiles/r01_traffic.json.
 
+    bash tools/run_traffic.sh                      # on the GPU box: writes gpurun_out/traffic4/{pmc_FETCH_SIZE,pmc_WRITE_SIZE,stats}
+    python tools/collect_traffic.py gpurun_out/traffic4
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+root = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "traffic4")
+KERNELS = ("linear_f32_kernel<2, 2, 1, 0, 4", "knn3_kernel", "march_kernel", "gather_rows", "ksum_kernel", "proj_rows_kernel", "merge_kernel")
 out = {}
-root = sys.argv[1]
 for name in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob("%s/pmc_%s/*/*counter_collection.csv" % (root, name))[0]
     per = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if r["Counter_Name"] != name:
-            continue
-        per[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
-    out[name] = {k: v for k, v in per.items()}
-res = {}
-for k in out["FETCH_SIZE"]:
-    if not any(s in k for s in ("linear_f32_kernel<2, 2, 1", "knn2_kernel", "march_kernel", "gather_rows", "ksum", "proj_rows")):
+        if r["Counter_Name"] == name:
+            per[r["Kernel_Name"].split("(")[0].strip()].append(float(r["Counter_Value"]))
+    out[name] = per
+kern = {}
+for k, fs in out["FETCH_SIZE"].items():
+    if not any(s in k for s in KERNELS):
         continue
-    fs, ws = out["FETCH_SIZE"][k], out["WRITE_SIZE"].get(k, [])
-    if "linear_f32_kernel<2, 2, 1" in k:
-        # the 4 per-neighbour launches of a frame are the big ones (M = 23.8 M rows); 3 colour-feature launches are ~7x smaller
-        thr = 0.5 * max(fs)
-        big = [i for i, v in enumerate(fs) if v > thr]
-        fs = [fs[i] for i in big]
-        ws = [ws[i] for i in big] if len(ws) >= len(out["FETCH_SIZE"][k]) else ws
-    res[k] = dict(launches=len(fs), fetch_kib_avg=sum(fs) / len(fs), write_kib_avg=(sum(ws) / len(ws)) if ws else None)
-json.dump(res, open("%s/traffic_summary.json" % root, "w"), indent=1)
-print(json.dumps(res, indent=1))
+    ws = out["WRITE_SIZE"].get(k, [])
+    big = [i for i, v in enumerate(fs) if v > 0.5 * max(fs)]            # the large launches of the name (per-neighbour layers, full frames)
+    f2 = [fs[i] for i in big]
+    w2 = [ws[i] for i in big] if len(ws) == len(fs) else ws
+    raw = sum(f2) / len(f2) * 1024                                       # the counters are in KiB
+    wr = sum(w2) / len(w2) * 1024 if w2 else 0.0
+    kern[k] = dict(launches=len(f2), fetch_bytes_raw=raw, fetch_bytes_corrected=2 * raw, write_bytes=wr, hbm_bytes=2 * raw + wr)
+    print("%-55s n=%2d fetch x2 %9.1f MB  write %9.1f MB" % (k[:55], len(f2), 2 * raw / 1e6, wr / 1e6))
+note = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-train-leg` on MI355X "
+        "(tools/run_traffic.sh); per-launch averages over the LARGE launches of each kernel name (linear_f32_kernel<2,2,1,0,4,0>: the three plain "
+        "per-neighbour layers, M = 23.8 M rows; <...,1>: the K=60 layer with its gathered 1 KB/row addend); FETCH_SIZE doubled per MI355X_MICROARCH.md "
+        "(gfx950 tallies 128-B requests as 64 B on wide coalesced reads; calibrated on ksum_kernel: 12.4 GB raw vs 24.3 GB of rows actually read). "
+        "Run-to-run: the plain 256x256 layer read 24.4 GB in an earlier collection and 27-32 GB in later ones on other boxes.")
+json.dump(dict(note=note, kernels=kern), open(os.path.join(ROOT, "profiles", "r01_traffic.json"), "w"), indent=1)
