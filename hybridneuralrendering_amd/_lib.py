@@ -70,6 +70,7 @@ SIGNATURES = {
     "hnr_merge": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _P, _I, _P, _P, _I, _P]),
     "hnr_final_color": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P]),
     "hnr_composite": (_I, [_P] * 8 + [_I, _I, _I, _F, _I, _P, _P, _P, _P, _P]),
+    "hnr_probe_outputs": (_I, [_P] * 10 + [_I, _I, _I, _I] + [_P] * 7 + [_P]),
     "hnr_ray_march": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P]),
     "hnr_blur_select": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "hnr_blur_select_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),

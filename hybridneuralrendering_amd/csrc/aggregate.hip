@@ -669,6 +669,66 @@ __global__ __launch_bounds__(256) void ray_march_kernel(const float *__restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
+// Hole-probing outputs (opt.prob == 1; models/neural_points_volumetric_model.py:392-416), read by the shell's point-growing
+// step (run/train_ft.py:450-569): per ray the shading sample of maximum opacity, its position, the distance to its nearest
+// listed neighbour and the weight * confidence averages of its neighbours' attributes.  8 lanes per ray.
+struct ProbeArgs {
+    const float *opacity, *loc_w;                        // [R,SR], [R,SR,3]
+    const int32_t *pidx;                                 // [R,SR,K]
+    const float *weight, *conf_c;                        // [R,SR,K] normalised weights, clamped confidences
+    const float *xyz, *emb, *conf, *pdir, *color;        // point buffers
+    int F, R, SR, K;
+    float *o_opacity, *o_loc, *o_far, *o_color, *o_dir, *o_conf, *o_emb;   // [R], [R,3], [R], [R,3], [R,3], [R], [R,F]
+};
+
+__global__ __launch_bounds__(256) void probe_kernel(ProbeArgs a)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = (int)(t >> 3), sub = (int)(t & 7);
+    if (r >= a.R) return;
+    // argmax over the ray's samples (first maximum, like torch.max on CPU)
+    int best = 0;
+    float bo = a.opacity[(size_t)r * a.SR];
+    for (int s = 1; s < a.SR; ++s) {
+        const float o = a.opacity[(size_t)r * a.SR + s];
+        if (o > bo) { bo = o; best = s; }
+    }
+    const size_t item = (size_t)r * a.SR + best;
+    const float lx = a.loc_w[3 * item], ly = a.loc_w[3 * item + 1], lz = a.loc_w[3 * item + 2];
+    float far = INFINITY, acc_c[3] = {0.f, 0.f, 0.f}, acc_d[3] = {0.f, 0.f, 0.f}, acc_f = 0.f;
+    float acc_e[4] = {0.f, 0.f, 0.f, 0.f};              // this lane's embedding columns sub, sub+8, sub+16, sub+24 (F <= 32)
+    for (int k = 0; k < a.K; ++k) {
+        const int raw = a.pidx[item * a.K + k];
+        const int pid = raw < 0 ? 0 : raw;                // empty slots read point 0 (index clamp, neural_points.py:711); their weight is 0
+        const float w = a.weight[item * a.K + k] * a.conf_c[item * a.K + k];
+        const float dx = a.xyz[3 * (size_t)pid] - lx, dy = a.xyz[3 * (size_t)pid + 1] - ly, dz = a.xyz[3 * (size_t)pid + 2] - lz;
+        far = fminf(far, sqrtf(dx * dx + dy * dy + dz * dz));
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            acc_c[j] += a.color[3 * (size_t)pid + j] * w;
+            acc_d[j] += a.pdir[3 * (size_t)pid + j] * w;
+        }
+        acc_f += a.conf[pid] * w;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = sub + 8 * q;
+            if (c < a.F) acc_e[q] += a.emb[(size_t)pid * a.F + c] * w;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c = sub + 8 * q;
+        if (c < a.F) a.o_emb[(size_t)r * a.F + c] = acc_e[q];
+    }
+    if (sub == 0) {
+        a.o_opacity[r] = bo; a.o_far[r] = far; a.o_conf[r] = acc_f;
+        a.o_loc[3 * (size_t)r] = lx; a.o_loc[3 * (size_t)r + 1] = ly; a.o_loc[3 * (size_t)r + 2] = lz;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { a.o_color[3 * (size_t)r + j] = acc_c[j]; a.o_dir[3 * (size_t)r + j] = acc_d[j]; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // The materialised gather of NeuralPoints.forward (neural_points.py:709-720) for the drop-in 14-tuple API
 // only (the fused path never materialises it).  One 8-lane group per (ray, slot, k) entry; empty entries
 // read point 0 like the reference's clamp(min=0).
@@ -930,6 +990,26 @@ extern "C" int hnr_ray_march(const float *d_ray_dist, const uint8_t *d_ray_valid
     }
     ray_march_kernel<<<cdiv(R, 256), 256, 0, (hipStream_t)stream>>>(d_ray_dist, d_ray_valid, d_features, d_bg_color, R, SR, d_ray_color, d_opacity,
                                                                     d_acc_transmission, d_blend_weight, d_bg_transmission);
+    HNR_LAUNCH_CHECK();
+    return HNR_OK;
+}
+
+extern "C" int hnr_probe_outputs(const float *d_opacity, const float *d_sample_loc_w, const int32_t *d_sample_pidx, const float *d_weight,
+                                 const float *d_conf_coefficient, const float *d_xyz, const float *d_emb, const float *d_conf, const float *d_dir,
+                                 const float *d_color, int F, int R, int SR, int K, float *d_max_opacity, float *d_max_loc_w, float *d_far_dist,
+                                 float *d_avg_color, float *d_avg_dir, float *d_avg_conf, float *d_avg_emb, void *stream)
+{
+    if (R < 0 || SR <= 0 || K <= 0 || F <= 0 || F > 32) { set_error("hnr_probe_outputs: bad sizes (F <= 32)"); return HNR_ERR_BADARG; }
+    if (R == 0) return HNR_OK;
+    if (!d_opacity || !d_sample_loc_w || !d_sample_pidx || !d_weight || !d_conf_coefficient || !d_xyz || !d_emb || !d_conf || !d_dir || !d_color ||
+        !d_max_opacity || !d_max_loc_w || !d_far_dist || !d_avg_color || !d_avg_dir || !d_avg_conf || !d_avg_emb) {
+        set_error("hnr_probe_outputs: NULL argument"); return HNR_ERR_BADARG;
+    }
+    ProbeArgs a;
+    a.opacity = d_opacity; a.loc_w = d_sample_loc_w; a.pidx = d_sample_pidx; a.weight = d_weight; a.conf_c = d_conf_coefficient; a.xyz = d_xyz;
+    a.emb = d_emb; a.conf = d_conf; a.pdir = d_dir; a.color = d_color; a.F = F; a.R = R; a.SR = SR; a.K = K; a.o_opacity = d_max_opacity;
+    a.o_loc = d_max_loc_w; a.o_far = d_far_dist; a.o_color = d_avg_color; a.o_dir = d_avg_dir; a.o_conf = d_avg_conf; a.o_emb = d_avg_emb;
+    probe_kernel<<<cdiv((int64_t)R * 8, 256), 256, 0, (hipStream_t)stream>>>(a);
     HNR_LAUNCH_CHECK();
     return HNR_OK;
 }

@@ -231,8 +231,6 @@ class NeuralPointsRayMarching(nn.Module):
         self.neural_points = neural_points
         if is_compute_depth:
             raise HnrError("compute_depth is unsupported (no shipped config sets it; the reference path itself references an undefined ray_ts)")
-        if getattr(opt, "prob", 0) == 1:
-            raise HnrError("prob==1 (hole probing) is a 'next' row (SURVEY 8f) and is not implemented")
         self._renderer = None
         self._train_path = None
 
@@ -282,7 +280,28 @@ class NeuralPointsRayMarching(nn.Module):
         out["weight"] = sel(full["weight"])
         out["blend_weight"] = sel(full["blend_weight"])[..., None]
         out["conf_coefficient"] = sel(full["conf_coefficient"])
+        if getattr(self.opt, "prob", 0) == 1 and rows.numel() > 0:
+            out.update(self._probe_outputs(full, rows))
         return out
+
+    def _probe_outputs(self, full, rows):
+        """opt.prob == 1 (:392-416): per valid ray the max-opacity sample and the weighted averages of its neighbours' attributes."""
+        npnt = self.neural_points
+        cloud = npnt.cloud()
+        R, SR, K = full["sample_pidx"].shape
+        dev = full["sample_pidx"].device
+        f = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)
+        mo, loc, far, col, dr, cf, em = f(R), f(R, 3), f(R), f(R, 3), f(R, 3), f(R), f(R, cloud.F)
+        p = _lib.ptr
+        g = lambda t: _lib.require_gpu(t.detach(), "probe input", torch.float32)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().hnr_probe_outputs(p(g(full["coarse_point_opacity"])), p(full["sample_loc_w"]), p(full["sample_pidx"]), p(g(full["weight"])),
+                                                    p(g(full["conf_coefficient"])), p(cloud.xyz), p(cloud.emb), p(cloud.conf), p(cloud.dir), p(cloud.color),
+                                                    cloud.F, R, SR, K, p(mo), p(loc), p(far), p(col), p(dr), p(cf), p(em), _lib.stream()),
+                       "hnr_probe_outputs")
+        sel = lambda t: t.index_select(0, rows)[None]
+        return dict(ray_max_shading_opacity=sel(mo)[..., None], ray_max_sample_loc_w=sel(loc), ray_max_far_dist=sel(far)[..., None],
+                    shading_avg_color=sel(col), shading_avg_dir=sel(dr), shading_avg_conf=sel(cf)[..., None], shading_avg_embedding=sel(em))
 
 
 def install():

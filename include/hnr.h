@@ -290,6 +290,15 @@ int hnr_composite(const float *d_decoded, const float *d_sample_loc_w, const int
                   int raydist_mode_unit, float *d_raycolor, float *d_opacity, float *d_is_background, float *d_blend_weight,
                   void *stream);
 
+/* Hole-probing outputs of opt.prob == 1 (models/neural_points_volumetric_model.py:392-416; consumed by the point-growing step
+ * of run/train_ft.py:450-569): per ray the sample of maximum opacity -> d_max_opacity [R], its position d_max_loc_w [R,3],
+ * the distance to the nearest of its K listed points d_far_dist [R] (empty slots read point 0, like the reference's clamped
+ * gather), and sum_k (weight * conf_coefficient) x {color, dir, conf, embedding} of those points.  Rows = input rays. */
+int hnr_probe_outputs(const float *d_opacity, const float *d_sample_loc_w, const int32_t *d_sample_pidx, const float *d_weight,
+                      const float *d_conf_coefficient, const float *d_xyz, const float *d_emb, const float *d_conf, const float *d_dir,
+                      const float *d_color, int F, int R, int SR, int K, float *d_max_opacity, float *d_max_loc_w, float *d_far_dist,
+                      float *d_avg_color, float *d_avg_dir, float *d_avg_conf, float *d_avg_emb, void *stream);
+
 /* ray_march alone (models/rendering/diff_ray_marching.py:508-557; radiance render + alpha blend) on existing tensors:
  * d_ray_dist [R,SR], d_ray_valid [R,SR] u8, d_features [R,SR,4] = (sigma, rgb), d_bg_color [3] or NULL ->
  * d_ray_color [R,3], d_opacity / d_acc_transmission / d_blend_weight [R,SR], d_bg_transmission [R]. */

@@ -11,6 +11,7 @@ What is pinned by the reference itself (runs on CPU with torch):
                            shipped loss terms: gradients w.r.t. every aggregator parameter and the point buffers
   * aggregator_param_keys.json <- PointAggregator(opt).state_dict() names/shapes for the shipped option sets
   * blur_select.npz     <- BaseRenderingModel.blur_update_output (models/base_rendering_model.py:677-745) + autograd
+  * render_scannet_small_prob.npz <- the same forward with opt.prob = 1: the hole-probing outputs (:392-416)
   * render_*.npz        <- NeuralPointsRayMarching.forward (models/neural_points_volumetric_model.py:257-427)
                            = NeuralPoints gather + PointAggregator + ray_march, + fill_invalid (:87-126)
 The reference's query kernels cannot run here (pycuda/nvcc), so inside render_* the 7-tuple of
@@ -194,6 +195,13 @@ def gen_render(ref, tag, scene_name, n_points, seed, w, h, n_rays, opt_over=None
     with torch.no_grad():
         out = net(**inputs)
     q = ref.npts.lighting_fast_querier_w.last
+    if getattr(opt, "prob", 0) == 1:
+        # hole-probing outputs (:392-416) only: the scene and weights are those of render_<base tag>.npz
+        save = {k: out[k].numpy() for k in ("ray_max_shading_opacity", "ray_max_sample_loc_w", "ray_max_far_dist", "shading_avg_color",
+                                            "shading_avg_dir", "shading_avg_conf", "shading_avg_embedding", "coarse_raycolor")}
+        np.savez_compressed(os.path.join(HERE, "render_%s.npz" % tag), **save)
+        print("render_%s.npz: probing outputs of %d valid rays" % (tag, save["ray_max_far_dist"].shape[1]))
+        return net, inputs, out
     # fill_invalid (:87-126) through the reference method, on a minimal stand-in `self`
     shell = SimpleNamespace(input={}, opt=opt, tonemap_func=ref.drf.find_tone_map(opt.which_tonemap_func))
     out_full = ref.vol.NeuralPointsVolumetricModel.fill_invalid(shell, dict(out), inputs)
@@ -409,6 +417,7 @@ def main():
     gen_posenc(ref)
     gen_render(ref, "scannet_small", "scene0241", 12000, 11, 64, 48, 600, opt_over=dict(agg_axis_weight=None), size=(1.0, 0.8, 0.6))
     gen_render(ref, "synth_small", "lego", 9000, 12, 40, 40, 500, opt_over=dict(agg_axis_weight=None, SR=40))
+    gen_render(ref, "scannet_small_prob", "scene0241", 12000, 11, 64, 48, 600, opt_over=dict(agg_axis_weight=None, prob=1), size=(1.0, 0.8, 0.6))
     gen_param_keys(ref)
     gen_blur(ref)
     gen_train(ref, "scannet_small", "scene0241", 12000, 11, 64, 48, 28,
