@@ -164,30 +164,36 @@ class HybridRenderer:
             pk["cf"][0](X5, out=T1, act=True, slope=sl)
             pk["cf"][1](T1, out=T2, act=True, slope=sl)
             CF = pk["cf"][2](T2, out=T1, act=True, slope=sl)
-          with T("proj_rows"):
-            V, H, W = featmap.shape[0], featmap.shape[1], featmap.shape[2]
-            ld6 = 48 if self.split_merge else 176
-            X6 = _f32((V * n_valid, ld6), dev)
-            vmask = _f32((V * n_valid,), dev)
-            row_s = _i32(V * n_valid, dev) if self.split_merge else None
-            _lib.check(L.hnr_proj_rows(p(loc_w), p(vs_item), p(counts), p(w2c_nearest), p(intrinsic_nearest), p(campos),
-                                       p(campos_nearest), p(featmap), V, H, W, p(CF), 128, n_valid, p(X6), ld6, p(vmask),
-                                       p(row_s) if self.split_merge else None, st()), "hnr_proj_rows")
-          with T("mlp_merge"):
-            M1, M2 = _f32((V * n_valid, 64), dev), _f32((V * n_valid, 64), dev)
-            if self.split_merge:
-                pre = pk["mw0_cf"](CF, act=False)                                     # [S,64] once per sample (bias included)
-                pk["mw0_fd"].gather_add(X6, pre, row_s, out=M1, act=True, slope=sl)   # 48 -> 64 per (view, sample) + addend
-            else:
-                pk["mw"][0](X6, out=M1, act=True, slope=sl)
-            pk["mw"][1](M1, out=M2, act=True, slope=sl)
-            pk["mw"][2](M2, out=M1, act=True, slope=sl)
-          with T("merge"):
-            X7 = _f32((n_valid, 92), dev)
-            fw = None if frame_weight is None else _lib.require_gpu(frame_weight, "frame_weight", torch.float32).reshape(-1)
-            _lib.check(L.hnr_merge(p(X6), ld6, p(M1), 64, p(pk["mw_last_w"]), p(pk["mw_last_b"]), p(vmask),
-                                   p(fw) if fw is not None else None, p(CF), 128, p(counts), V, n_valid, p(X7), 92,
-                                   None, None, 0, st()), "hnr_merge")
+          no_views = getattr(self.opt, "use_nearest", 4) == 0
+          if no_views:
+            # use_nearest = 0 (scene241.sh): the image branch is off, merged = 0 (point_aggregators.py:1257-1258)
+            X7 = torch.zeros((n_valid, 92), dtype=torch.float32, device=dev)
+            X7[:, :45] = CF[:, :45]
+          else:
+            with T("proj_rows"):
+              V, H, W = featmap.shape[0], featmap.shape[1], featmap.shape[2]
+              ld6 = 48 if self.split_merge else 176
+              X6 = _f32((V * n_valid, ld6), dev)
+              vmask = _f32((V * n_valid,), dev)
+              row_s = _i32(V * n_valid, dev) if self.split_merge else None
+              _lib.check(L.hnr_proj_rows(p(loc_w), p(vs_item), p(counts), p(w2c_nearest), p(intrinsic_nearest), p(campos),
+                                         p(campos_nearest), p(featmap), V, H, W, p(CF), 128, n_valid, p(X6), ld6, p(vmask),
+                                         p(row_s) if self.split_merge else None, st()), "hnr_proj_rows")
+            with T("mlp_merge"):
+              M1, M2 = _f32((V * n_valid, 64), dev), _f32((V * n_valid, 64), dev)
+              if self.split_merge:
+                  pre = pk["mw0_cf"](CF, act=False)                                     # [S,64] once per sample (bias included)
+                  pk["mw0_fd"].gather_add(X6, pre, row_s, out=M1, act=True, slope=sl)   # 48 -> 64 per (view, sample) + addend
+              else:
+                  pk["mw"][0](X6, out=M1, act=True, slope=sl)
+              pk["mw"][1](M1, out=M2, act=True, slope=sl)
+              pk["mw"][2](M2, out=M1, act=True, slope=sl)
+            with T("merge"):
+              X7 = _f32((n_valid, 92), dev)
+              fw = None if frame_weight is None else _lib.require_gpu(frame_weight, "frame_weight", torch.float32).reshape(-1)
+              _lib.check(L.hnr_merge(p(X6), ld6, p(M1), 64, p(pk["mw_last_w"]), p(pk["mw_last_b"]), p(vmask),
+                                     p(fw) if fw is not None else None, p(CF), 128, p(counts), V, n_valid, p(X7), 92,
+                                     None, None, 0, st()), "hnr_merge")
           with T("mlp_mixup"):
             Y1, Y2 = _f32((n_valid, 48), dev), _f32((n_valid, 48), dev)
             pk["mx"][0](X7, out=Y1, act=True, slope=sl, K=90)
@@ -241,7 +247,7 @@ class HybridRenderer:
             # pad=False: only kept slots are written (no -1 / 0 padding stores); everything downstream takes ray_nsamp
             qres = Q.march_query(grid, campos, raydir, tmid, self.opt.SR, self.opt.K, np.float32(hp[0] ** 2), self.opt.kernel_size, pad=pad)
         with _Stage(timers, "featmap"):
-            fm = self.feature_map(images_nearest)
+            fm = None if getattr(self.opt, "use_nearest", 4) == 0 else self.feature_map(images_nearest)
         a = self.aggregate(cloud, qres, raydir, campos, camrot, w2c_nearest, intrinsic_nearest, campos_nearest, fm,
                            frame_weight=frame_weight, want_weights=want_weights, timers=timers)
         with _Stage(timers, "composite"):

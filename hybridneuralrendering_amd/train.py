@@ -138,14 +138,16 @@ class TrainPath:
         S.img = img
         V, H, W = img.shape[0], img.shape[1], img.shape[2]
         S.V, S.H, S.W = V, H, W
+        S.no_views = getattr(opt, "use_nearest", 4) == 0        # scene241.sh: image branch off, merged = 0 (point_aggregators.py:1257-1258)
         with torch.cuda.device(dev):
-            if n_valid > 0:
+            if n_valid > 0 and not S.no_views:
                 # reference-view pyramid (activations kept for the conv backward)
                 fm = torch.empty((V, H, W, 48), dtype=torch.float32, device=dev)
                 S.fm_scratch = torch.empty((max(int(L.hnr_image_features_scratch_elems(V, H, W)), 1),), dtype=torch.float32, device=dev)
                 wp = (ctypes.c_void_p * 6)(*[t.data_ptr() for t in pk["conv_w"]])
                 bp = (ctypes.c_void_p * 6)(*[t.data_ptr() for t in pk["conv_b"]])
                 _lib.check(L.hnr_image_features(p(img), V, H, W, wp, bp, sl, p(S.fm_scratch), p(fm), st()), "hnr_image_features")
+            if n_valid > 0:
                 S.vs_item, S.vs_off, S.vs_cnt = _i32(n_valid, dev), _i32(n_valid, dev), _i32(n_valid, dev)
                 scratch = _i32(2 * ((R * SR + 1023) // 1024) + 2, dev)
                 overflow = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -177,20 +179,25 @@ class TrainPath:
                 S.T1 = pk["cf"][0](S.X5, act=True, slope=sl)
                 S.T2 = pk["cf"][1](S.T1, act=True, slope=sl)
                 S.CF = pk["cf"][2](S.T2, act=True, slope=sl)
-                S.X6, S.vmask, S.row_s = _f32((V * n_valid, 48), dev), _f32((V * n_valid,), dev), _i32(V * n_valid, dev)
-                _lib.check(L.hnr_proj_rows(p(loc_w), p(S.vs_item), p(counts), p(w2c_nearest), p(intrinsic_nearest), p(campos),
-                                           p(campos_nearest), p(fm), V, H, W, p(S.CF), 128, n_valid, p(S.X6), 48, p(S.vmask),
-                                           p(S.row_s), st()), "hnr_proj_rows")
-                del fm
-                pre = pk["mw0_cf"](S.CF, act=False)
-                S.M1 = pk["mw0_fd"].gather_add(S.X6, pre, S.row_s, act=True, slope=sl)
-                S.M2 = pk["mw"][1](S.M1, act=True, slope=sl)
-                S.M3 = pk["mw"][2](S.M2, act=True, slope=sl)
-                S.X7 = _f32((n_valid, 92), dev)
-                S.fw = None if frame_weight is None else g(frame_weight, "frame_weight", torch.float32).reshape(-1)
-                _lib.check(L.hnr_merge(p(S.X6), 48, p(S.M3), 64, p(pk["mw_last_w"]), p(pk["mw_last_b"]), p(S.vmask),
-                                       p(S.fw) if S.fw is not None else None, p(S.CF), 128, p(counts), V, n_valid, p(S.X7), 92,
-                                       p(S.ray_drop) if S.ray_drop is not None else None, p(S.vs_item), SR, st()), "hnr_merge")
+                if S.no_views:
+                    S.X7 = torch.zeros((n_valid, 92), dtype=torch.float32, device=dev)
+                    S.X7[:, :45] = S.CF[:, :45]
+                    S.fw = None
+                else:
+                    S.X6, S.vmask, S.row_s = _f32((V * n_valid, 48), dev), _f32((V * n_valid,), dev), _i32(V * n_valid, dev)
+                    _lib.check(L.hnr_proj_rows(p(loc_w), p(S.vs_item), p(counts), p(w2c_nearest), p(intrinsic_nearest), p(campos),
+                                               p(campos_nearest), p(fm), V, H, W, p(S.CF), 128, n_valid, p(S.X6), 48, p(S.vmask),
+                                               p(S.row_s), st()), "hnr_proj_rows")
+                    del fm
+                    pre = pk["mw0_cf"](S.CF, act=False)
+                    S.M1 = pk["mw0_fd"].gather_add(S.X6, pre, S.row_s, act=True, slope=sl)
+                    S.M2 = pk["mw"][1](S.M1, act=True, slope=sl)
+                    S.M3 = pk["mw"][2](S.M2, act=True, slope=sl)
+                    S.X7 = _f32((n_valid, 92), dev)
+                    S.fw = None if frame_weight is None else g(frame_weight, "frame_weight", torch.float32).reshape(-1)
+                    _lib.check(L.hnr_merge(p(S.X6), 48, p(S.M3), 64, p(pk["mw_last_w"]), p(pk["mw_last_b"]), p(S.vmask),
+                                           p(S.fw) if S.fw is not None else None, p(S.CF), 128, p(counts), V, n_valid, p(S.X7), 92,
+                                           p(S.ray_drop) if S.ray_drop is not None else None, p(S.vs_item), SR, st()), "hnr_merge")
                 S.Y1 = pk["mx"][0](S.X7, out=_f32((n_valid, 48), dev), act=True, slope=sl, K=90)
                 S.Y2 = pk["mx"][1](S.Y1, out=_f32((n_valid, 48), dev), act=True, slope=sl, K=45)
                 S.Y3 = pk["mx"][2](S.Y2, out=_f32((n_valid, 48), dev), act=False, K=45)
@@ -221,7 +228,10 @@ class TrainPath:
         ag = {}
         names = dict(a.named_parameters())
         for k, prm in names.items():
-            if not k.startswith(("color_branch.", "learn_blur_kernel")):   # unused head / modules the training shell runs itself
+            skip = ("color_branch.", "learn_blur_kernel")         # unused head / modules the training shell runs itself
+            if S.no_views:
+                skip += ("aux_block_", "aux_merge_weight_block.")    # image branch off: like unused parameters in the reference, no gradient
+            if not k.startswith(skip):
                 ag[k] = torch.zeros_like(prm, dtype=torch.float32)
         if g_conf_out is not None:
             g_conf_out = _lib.require_gpu(g_conf_out, "grad conf_coefficient", torch.float32).reshape(R, SR, K)
@@ -260,47 +270,50 @@ class TrainPath:
             dZ = lin_bwd(dZ, S.Y1, "color_mixup_block.2.weight", "color_mixup_block.2.bias", 45, 45, t["mx"][1], prev=S.Y1,
                          out=_f32((nS, 48), dev))
             gX7 = lin_bwd(dZ, S.X7, "color_mixup_block.0.weight", "color_mixup_block.0.bias", 45, 90, t["mx"][0], out=_f32((nS, 92), dev))
-            # 4. merge
-            gF, gZ3 = _f32((V * nS, 48), dev), _f32((V * nS, 64), dev)
-            g_wl, g_bl = z(64), z(1)
-            _lib.check(L.hnr_merge_bwd(p(S.X6), 48, p(S.M3), 64, p(pk["mw_last_w"]), p(pk["mw_last_b"]), p(S.vmask),
-                                       p(S.fw) if S.fw is not None else None, p(counts), V, nS, sl,
-                                       p(S.ray_drop) if S.ray_drop is not None else None, p(S.vs_item), SR, p(gX7), 92, p(gF), 48,
-                                       p(gZ3), 64, p(gCF), 128, p(g_wl), p(g_bl), st()), "hnr_merge_bwd")
-            ag["aux_merge_weight_block.6.weight"].copy_(g_wl.view(1, 64))
-            ag["aux_merge_weight_block.6.bias"].copy_(g_bl)
-            # 5. merge-weight MLP (first layer split: [imgfeat45 | ddir3] per row, colour feature once per sample)
-            dZ = lin_bwd(gZ3, S.M2, "aux_merge_weight_block.4.weight", "aux_merge_weight_block.4.bias", 64, 64, t["mw"][2], prev=S.M2)
-            dZ1 = lin_bwd(dZ, S.M1, "aux_merge_weight_block.2.weight", "aux_merge_weight_block.2.bias", 64, 64, t["mw"][1], prev=S.M1)
-            G0 = ag["aux_merge_weight_block.0.weight"]                                # [64,176]
-            gWfd, _ = weight_grad(dZ1, S.X6, 64, 48, want_bias=False)
-            G0[:, :45].copy_(gWfd[:, :45])
-            G0[:, 173:176].copy_(gWfd[:, 45:48])
-            gpre = _f32((nS, 64), dev)
-            _lib.check(L.hnr_sum_views(p(dZ1), 64, V, nS, nS, 64, p(gpre), 64, st()), "hnr_sum_views")
-            weight_grad(gpre, S.CF, 64, 128, dW=G0[:, 45:173], db=ag["aux_merge_weight_block.0.bias"])
-            gX6 = t["mw0_fd"](dZ1, act=False, K=64)                                   # [V*S,48]
-            t["mw0_cf"].side(gpre, gCF, r_mode=0, out=gCF, act=False, K=64)           # gCF += gpre Wcf
-            del dZ, dZ1, gZ3
-            # 6. pixel gather + upsample + conv pyramid
-            g_pyr = torch.zeros_like(S.fm_scratch)
-            g_fm = z(V, S.H, S.W, 48)
-            if self._bbox0 is None or self._bbox_key != (V, S.H, S.W, dev):
-                self._bbox0 = torch.tensor([[S.W, S.H, -1, -1]] * V, dtype=torch.int32, device=dev)
-                self._bbox_key = (V, S.H, S.W, dev)
-            bbox = self._bbox0.clone()
-            sb = int(L.hnr_sort_rows_scratch_bytes(V * nS))
-            key_scratch, sort_scratch = _i32(3 * V * nS, dev), torch.empty((sb,), dtype=torch.uint8, device=dev)   # named: both must stay alive
-            _lib.check(L.hnr_proj_rows_bwd(p(loc_w), p(S.vs_item), p(counts), p(S.w2c), p(S.Kn), V, S.H, S.W, nS, p(gF), 48, p(gX6), 48,
-                                           p(g_fm), p(bbox), p(g_pyr), p(key_scratch), p(sort_scratch), sb, st()), "hnr_proj_rows_bwd")
-            del g_fm
-            conv_names = [("aux_block_s%d.%d" % (lvl, i)) for lvl in (1, 2, 3) for i in (0, 2)]
-            wp = (ctypes.c_void_p * 6)(*[tt.data_ptr() for tt in pk["conv_w"]])
-            gw = (ctypes.c_void_p * 6)(*[ag[n + ".weight"].data_ptr() for n in conv_names])
-            gb = (ctypes.c_void_p * 6)(*[ag[n + ".bias"].data_ptr() for n in conv_names])
-            _lib.check(L.hnr_image_features_bwd(p(S.img), V, S.H, S.W, wp, sl, p(S.fm_scratch), p(g_pyr), gw, gb, st()),
-                       "hnr_image_features_bwd")
-            del g_pyr, gF, gX6
+            if S.no_views:
+                gCF[:, :45] += gX7[:, :45]                               # X7 = [colfeat[:45] | 0]
+            else:
+                # 4. merge
+                gF, gZ3 = _f32((V * nS, 48), dev), _f32((V * nS, 64), dev)
+                g_wl, g_bl = z(64), z(1)
+                _lib.check(L.hnr_merge_bwd(p(S.X6), 48, p(S.M3), 64, p(pk["mw_last_w"]), p(pk["mw_last_b"]), p(S.vmask),
+                                           p(S.fw) if S.fw is not None else None, p(counts), V, nS, sl,
+                                           p(S.ray_drop) if S.ray_drop is not None else None, p(S.vs_item), SR, p(gX7), 92, p(gF), 48,
+                                           p(gZ3), 64, p(gCF), 128, p(g_wl), p(g_bl), st()), "hnr_merge_bwd")
+                ag["aux_merge_weight_block.6.weight"].copy_(g_wl.view(1, 64))
+                ag["aux_merge_weight_block.6.bias"].copy_(g_bl)
+                # 5. merge-weight MLP (first layer split: [imgfeat45 | ddir3] per row, colour feature once per sample)
+                dZ = lin_bwd(gZ3, S.M2, "aux_merge_weight_block.4.weight", "aux_merge_weight_block.4.bias", 64, 64, t["mw"][2], prev=S.M2)
+                dZ1 = lin_bwd(dZ, S.M1, "aux_merge_weight_block.2.weight", "aux_merge_weight_block.2.bias", 64, 64, t["mw"][1], prev=S.M1)
+                G0 = ag["aux_merge_weight_block.0.weight"]                                # [64,176]
+                gWfd, _ = weight_grad(dZ1, S.X6, 64, 48, want_bias=False)
+                G0[:, :45].copy_(gWfd[:, :45])
+                G0[:, 173:176].copy_(gWfd[:, 45:48])
+                gpre = _f32((nS, 64), dev)
+                _lib.check(L.hnr_sum_views(p(dZ1), 64, V, nS, nS, 64, p(gpre), 64, st()), "hnr_sum_views")
+                weight_grad(gpre, S.CF, 64, 128, dW=G0[:, 45:173], db=ag["aux_merge_weight_block.0.bias"])
+                gX6 = t["mw0_fd"](dZ1, act=False, K=64)                                   # [V*S,48]
+                t["mw0_cf"].side(gpre, gCF, r_mode=0, out=gCF, act=False, K=64)           # gCF += gpre Wcf
+                del dZ, dZ1, gZ3
+                # 6. pixel gather + upsample + conv pyramid
+                g_pyr = torch.zeros_like(S.fm_scratch)
+                g_fm = z(V, S.H, S.W, 48)
+                if self._bbox0 is None or self._bbox_key != (V, S.H, S.W, dev):
+                    self._bbox0 = torch.tensor([[S.W, S.H, -1, -1]] * V, dtype=torch.int32, device=dev)
+                    self._bbox_key = (V, S.H, S.W, dev)
+                bbox = self._bbox0.clone()
+                sb = int(L.hnr_sort_rows_scratch_bytes(V * nS))
+                key_scratch, sort_scratch = _i32(3 * V * nS, dev), torch.empty((sb,), dtype=torch.uint8, device=dev)   # named: both must stay alive
+                _lib.check(L.hnr_proj_rows_bwd(p(loc_w), p(S.vs_item), p(counts), p(S.w2c), p(S.Kn), V, S.H, S.W, nS, p(gF), 48, p(gX6), 48,
+                                               p(g_fm), p(bbox), p(g_pyr), p(key_scratch), p(sort_scratch), sb, st()), "hnr_proj_rows_bwd")
+                del g_fm
+                conv_names = [("aux_block_s%d.%d" % (lvl, i)) for lvl in (1, 2, 3) for i in (0, 2)]
+                wp = (ctypes.c_void_p * 6)(*[tt.data_ptr() for tt in pk["conv_w"]])
+                gw = (ctypes.c_void_p * 6)(*[ag[n + ".weight"].data_ptr() for n in conv_names])
+                gb = (ctypes.c_void_p * 6)(*[ag[n + ".bias"].data_ptr() for n in conv_names])
+                _lib.check(L.hnr_image_features_bwd(p(S.img), V, S.H, S.W, wp, sl, p(S.fm_scratch), p(g_pyr), gw, gb, st()),
+                           "hnr_image_features_bwd")
+                del g_pyr, gF, gX6
             # 7. colour-feature branch
             _lib.check(L.hnr_dleaky(p(gCF), 128, p(S.CF), 128, nS, 128, sl, st()), "hnr_dleaky")
             dZ = lin_bwd(gCF, S.T2, "color_feature_branch.4.weight", "color_feature_branch.4.bias", 128, 128, t["cf"][2], prev=S.T2)

@@ -118,7 +118,7 @@ def image_features(images_nearest, sd, slope=0.01):
 
 
 def aggregate(g, sample_loc, sample_loc_w, sample_ray_dirs, sd, loc_i_n, delta_viewdir_n, images_nearest,
-              is_train=False, drop_ray_rows=None, frame_weight_n=None):
+              is_train=False, drop_ray_rows=None, frame_weight_n=None, use_nearest=4):
     """PointAggregator.forward (:1427-1522) + viewmlp (:892-1338), order-2 hybrid path.
 
     g = gather_points(...) dict.  Returns dict(decoded [1,R,SR,4], ray_valid [1,R,SR] bool, weight [1,R,SR,K],
@@ -171,7 +171,17 @@ def aggregate(g, sample_loc, sample_loc_w, sample_ray_dirs, sd, loc_i_n, delta_v
     feat = torch.sum(fh.view(B * R * SR, K, -1) * w_agg, dim=-2).view(-1, fh.shape[-1])[ray_valid, :]
     # colour-feature branch (:1028-1037)
     cf = _seq(torch.cat([feat, vd], dim=-1), sd, "color_feature_branch", (0, 2, 4))
-    # image branch (:1047-1217)
+    # image branch (:1047-1217); use_nearest == 0 switches it off: merged = 0 (:1257-1258)
+    if use_nearest == 0:
+        C = 45
+        merged = torch.zeros_like(cf)[:, :C]
+        ci, cv = cf[:, :C], cf[:, C:]
+        mix = _seq(torch.cat((ci, merged), dim=-1), sd, "color_mixup_block", (0, 2, 4), act_last=False) + ci
+        rgb = torch.sigmoid(F.linear(torch.cat([mix, cv], dim=-1), sd["color_final_block.0.weight"], sd["color_final_block.0.bias"]))
+        rgb = rgb * (1 + 2 * 0.001) - 0.001
+        out = torch.zeros([total, 4])
+        out[ray_valid] = torch.cat([alpha, rgb], dim=-1)
+        return dict(decoded=out.view(B, R, SR, 4), ray_valid=ray_valid.view(B, R, SR), weight=weight, conf_coefficient=conf_c)
     aux = image_features(images_nearest, sd)
     V, C, H1, W1 = aux.shape
     li = loc_i_n.view(V, -1, 2)[:, ray_valid, :].reshape(-1, 2)
@@ -234,7 +244,7 @@ def ray_march(rd, ray_valid, feats, bg_color):
 
 
 def render(xyz, emb, conf, pdir, color, sd, q, campos, camrotc2w, raydir_all, bg_color, c2w_nearest, campos_nearest,
-           intrinsic_nearest, images_nearest, vsize, raydist_mode_unit=1, is_train=False, drop_ray_rows=None):
+           intrinsic_nearest, images_nearest, vsize, raydist_mode_unit=1, is_train=False, drop_ray_rows=None, use_nearest=4):
     """NeuralPointsRayMarching.forward (:257-391) after the query, + fill_invalid (:87-126).
 
     q: dict(sample_pidx [R',SR,K], sample_loc_w [R',SR,3], ray_mask [R]) numpy or tensors (the query 7-tuple core).
@@ -246,7 +256,8 @@ def render(xyz, emb, conf, pdir, color, sd, q, campos, camrotc2w, raydir_all, bg
     dirs = torch.masked_select(raydir_all, ray_mask[..., None] > 0).reshape(1, -1, 3)[..., None, :].expand(-1, -1, SR, -1).contiguous()
     g = gather_points(xyz, emb, conf, pdir, color, pidx, camrotc2w, campos)
     loc_i, dvd = project_nearest(loc_w, campos, c2w_nearest, campos_nearest, intrinsic_nearest)
-    a = aggregate(g, sample_loc, loc_w, dirs, sd, loc_i, dvd, images_nearest, is_train=is_train, drop_ray_rows=drop_ray_rows)
+    a = aggregate(g, sample_loc, loc_w, dirs, sd, loc_i, dvd, images_nearest, is_train=is_train, drop_ray_rows=drop_ray_rows,
+                  use_nearest=use_nearest)
     rd = ray_dist(sample_loc, a["ray_valid"], vsize[2], raydist_mode_unit)
     m = ray_march(rd, a["ray_valid"], a["decoded"], bg_color)
     out = dict(coarse_raycolor=m["ray_color"], coarse_point_opacity=m["opacity"], coarse_is_background=m["background_transmission"],
@@ -292,7 +303,7 @@ def shipped_loss(full_raycolor, ray_mask, conf_coefficient, gt, zero_epsilon, w_
 
 
 def train_step(xyz, emb, conf, pdir, color, sd, q, campos, camrotc2w, raydir_all, bg_color, c2w_nearest, campos_nearest,
-               intrinsic_nearest, images_nearest, vsize, gt, zero_epsilon, drop_ray_rows, raydist_mode_unit=1, dtype=None):
+               intrinsic_nearest, images_nearest, vsize, gt, zero_epsilon, drop_ray_rows, raydist_mode_unit=1, dtype=None, use_nearest=4):
     """Forward in train mode + autograd of shipped_loss.  Returns (outputs, loss triple, grads dict) with grads keyed
     `neural_points.points_*` and `aggregator.<param>` like the reference's named parameters.
     dtype=torch.float64 re-runs the same graph in double precision (the query result q is kept): the yardstick for how much
@@ -305,7 +316,7 @@ def train_step(xyz, emb, conf, pdir, color, sd, q, campos, camrotc2w, raydir_all
         try:
             return train_step(c(xyz), c(emb), c(conf), c(pdir), c(color), {k: c(v) for k, v in sd.items()}, q, c(campos), c(camrotc2w),
                               c(raydir_all), c(bg_color), c(c2w_nearest), c(campos_nearest), c(intrinsic_nearest), c(images_nearest),
-                              vsize, c(gt), zero_epsilon, drop_ray_rows, raydist_mode_unit)
+                              vsize, c(gt), zero_epsilon, drop_ray_rows, raydist_mode_unit, use_nearest=use_nearest)
         finally:
             torch.set_default_dtype(old)
     leaves = dict(emb=emb.clone().requires_grad_(True), conf=conf.clone().requires_grad_(True),
@@ -313,7 +324,7 @@ def train_step(xyz, emb, conf, pdir, color, sd, q, campos, camrotc2w, raydir_all
     sdl = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     out = render(xyz, leaves["emb"], leaves["conf"], leaves["pdir"], leaves["color"], sdl, q, campos, camrotc2w, raydir_all,
                  bg_color, c2w_nearest, campos_nearest, intrinsic_nearest, images_nearest, vsize, raydist_mode_unit,
-                 is_train=True, drop_ray_rows=drop_ray_rows)
+                 is_train=True, drop_ray_rows=drop_ray_rows, use_nearest=use_nearest)
     loss, lc, lz = shipped_loss(out["full_coarse_raycolor"], out["ray_mask"], out["conf_coefficient"], gt, zero_epsilon)
     loss.backward()
     grads = {"neural_points.points_embeding": leaves["emb"].grad, "neural_points.points_conf": leaves["conf"].grad,

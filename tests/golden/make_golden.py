@@ -234,7 +234,7 @@ def gen_render(ref, tag, scene_name, n_points, seed, w, h, n_rays, opt_over=None
     return net, inputs, out
 
 
-def gen_train(ref, tag, scene_name, n_points, seed, w, h, patch, opt_over=None, margin=2, size=None):
+def gen_train(ref, tag, scene_name, n_points, seed, w, h, patch, opt_over=None, margin=2, size=None, keep=None, twin=None):
     """One training step of the reference on CPU (forward in train mode + autograd): the C3 fixture.
 
     Loss = the two terms the shipped ScanNet scripts switch on (dev_scripts/w_scannet_etf/scene241.sh:146-151):
@@ -326,20 +326,28 @@ def gen_train(ref, tag, scene_name, n_points, seed, w, h, patch, opt_over=None, 
         loss=np.array([loss.item(), loss_color.item(), loss_zo.item()], np.float64), loss_compute_losses=np.float64(loss_shell),
     )
     # same seed and scene as render_<tag>.npz: the weights are that fixture's `sd.*` entries (checked, not stored twice)
-    twin = np.load(os.path.join(HERE, "render_%s.npz" % tag))
+    twin = np.load(os.path.join(HERE, "render_%s.npz" % (twin or tag)))
     for k, v in aggregator.state_dict().items():
         assert np.array_equal(twin["sd." + k], v.detach().numpy()), k
     for k in ("xyz", "emb", "conf", "pdir", "color", "c2w_nearest", "images_nearest"):
         assert np.array_equal(twin[k], save[k]), k
         del save[k]
     n_grad = 0
+    save["grad_names"] = np.array(sorted("aggregator." + k for k, prm in aggregator.named_parameters() if prm.grad is not None))
     for k, prm in aggregator.named_parameters():
-        if prm.grad is not None:
+        if prm.grad is not None and (keep is None or any(k.startswith(p) for p in keep)):      # keep: store a subset (small fixture)
             save["grad.aggregator." + k] = prm.grad.numpy()
             n_grad += 1
     for k in ("points_embeding", "points_conf", "points_dir", "points_color"):
         g = getattr(neural_points, k).grad
         save["grad.neural_points." + k] = g.numpy()
+    if twin is not None:
+        # inputs identical to train_<twin>.npz (same seed): stored once
+        tw = np.load(os.path.join(HERE, "train_%s.npz" % twin))
+        for k in ("pix", "raydir", "c2w", "intrinsic", "bg_color", "near_far", "tmid", "gt", "q_sample_pidx", "q_sample_loc_w", "q_ray_mask"):
+            assert np.array_equal(tw[k], save[k]), k
+            del save[k]
+        save["shares_inputs_with"] = np.array("train_%s" % twin)
     path = os.path.join(HERE, "train_%s.npz" % tag)
     np.savez_compressed(path, **save)
     ge = save["grad.neural_points.points_embeding"]
@@ -422,6 +430,10 @@ def main():
     gen_blur(ref)
     gen_train(ref, "scannet_small", "scene0241", 12000, 11, 64, 48, 28,
               opt_over=dict(agg_axis_weight=None, dilation_setup="7_4_1_8"), size=(1.0, 0.8, 0.6))
+    # use_nearest = 0 (scene241.sh): image branch off; a small fixture (subset of the weight gradients, names of all)
+    gen_train(ref, "scannet_small_nearest0", "scene0241", 12000, 11, 64, 48, 28, twin="scannet_small",
+              opt_over=dict(agg_axis_weight=None, dilation_setup="7_4_1_8", use_nearest=0), size=(1.0, 0.8, 0.6),
+              keep=("alpha_branch", "color_final_block", "color_mixup_block", "block3.2.bias", "block1.0.bias"))
     # object scene: most rays miss (R' << R), SR = 40
     gen_train(ref, "synth_small", "lego", 9000, 12, 40, 40, 20, opt_over=dict(agg_axis_weight=None, SR=40, dilation_setup="5_4_1_8"), margin=8)
 

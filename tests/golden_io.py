@@ -18,14 +18,25 @@ def load_render(tag):
 
 
 def load_train(tag):
-    """train_<tag>.npz shares its scene and weights with render_<tag>.npz (asserted by make_golden.py)."""
-    d = load_render(tag)
+    """train_<tag>.npz shares its scene and weights with render_<tag>.npz (asserted by make_golden.py); a fixture with
+    `shares_inputs_with` (e.g. the use_nearest=0 variant) also takes its ray batch from that training fixture."""
     z = np.load(os.path.join(GOLD, "train_%s.npz" % tag), allow_pickle=False)
+    if "shares_inputs_with" in z.files:
+        d = load_train(str(z["shares_inputs_with"])[len("train_"):])
+        for k in z.files:
+            if not k.startswith("grad.") and k not in ("opt_json", "shares_inputs_with", "grad_names", "scene"):
+                d[k] = z[k]
+        d["opt"] = json.loads(str(z["opt_json"]))
+        d["grad"] = {k[5:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("grad.")}
+        d["grad_names"] = [str(n) for n in z["grad_names"]]
+        return d
+    d = load_render(tag)
     for k in ("coarse_raycolor", "conf_coefficient", "full_coarse_raycolor", "q_sample_pidx", "q_sample_loc_w", "q_ray_mask",
               "pix", "raydir", "c2w", "intrinsic", "bg_color", "near_far", "tmid", "gt", "loss", "zero_epsilon", "loss_compute_losses"):
         d[k] = z[k]
     d["opt"] = json.loads(str(z["opt_json"]))
     d["grad"] = {k[5:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("grad.")}
+    d["grad_names"] = sorted(k for k in d["grad"] if k.startswith("aggregator."))
     for k in ("coarse_point_opacity", "coarse_is_background", "queried_shading", "ray_mask", "weight", "blend_weight",
               "decoded_features", "ray_valid", "full_coarse_point_opacity", "full_coarse_is_background", "full_coarse_mask"):
         d.pop(k, None)

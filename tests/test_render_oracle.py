@@ -105,7 +105,7 @@ def _drop_rows(opt):
     return ro.drop_patch_rays(ps, pn, opt["drop_ratio"])
 
 
-@pytest.mark.parametrize("tag", ["scannet_small", "synth_small"])
+@pytest.mark.parametrize("tag", ["scannet_small", "synth_small", "scannet_small_nearest0"])
 def test_train_step_oracle_matches_reference_gradients(tag):
     """Forward in train mode (jittered depths, patch drop, straight-through conf clamp) + autograd of the shipped loss:
     loss value and every gradient the reference produced (tests/golden/train_<tag>.npz)."""
@@ -116,13 +116,16 @@ def test_train_step_oracle_matches_reference_gradients(tag):
     out, losses, grads = ro.train_step(ti["xyz"], ti["emb"], ti["conf"], ti["pdir"], ti["color"], d["sd"], q, ti["campos"],
                                        ti["camrotc2w"], ti["raydir"], ti["bg_color"], ti["c2w_nearest"], ti["campos_nearest"],
                                        ti["intrinsic_nearest"], ti["images_nearest"], d["opt"]["vsize"],
-                                       torch.from_numpy(d["gt"]), float(d["zero_epsilon"]), _drop_rows(d["opt"]))
+                                       torch.from_numpy(d["gt"]), float(d["zero_epsilon"]), _drop_rows(d["opt"]),
+                                       use_nearest=d["opt"].get("use_nearest", 4))
     np.testing.assert_allclose(out["coarse_raycolor"].detach().numpy(), d["coarse_raycolor"], rtol=0, atol=2e-6)
     np.testing.assert_allclose(out["conf_coefficient"].detach().numpy(), d["conf_coefficient"], rtol=0, atol=0)
     np.testing.assert_allclose(np.array(losses), d["loss"], rtol=1e-6)
     # the shell's own compute_losses on the same outputs = the restated terms + its constant 1e-6 per colour item (:1198)
-    assert abs(float(d["loss_compute_losses"]) - (losses[0] + 3e-6)) < 3e-7
-    assert set(grads) == set(d["grad"]), set(grads) ^ set(d["grad"])
+    if "loss_compute_losses" in d and tag == "scannet_small":
+        assert abs(float(d["loss_compute_losses"]) - (losses[0] + 3e-6)) < 3e-7
+    # the set of parameters that receive a gradient (use_nearest = 0: none for the image branch) + the stored subset of values
+    assert sorted(k for k in grads if k.startswith("aggregator.")) == d["grad_names"]
     for k, g in d["grad"].items():
         ref = g.numpy()
         scale = np.abs(ref).max()
