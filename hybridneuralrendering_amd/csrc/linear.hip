@@ -50,7 +50,12 @@ __device__ __forceinline__ void lds_dma16(const float *src, unsigned lds_base)
 
 // SIDE = 1 compiles the side-operand epilogue in (its index / value arrays cost registers: with it in the plain kernel the
 // 128x256 variant spilled 68 B per lane and the big layers ran 4 % slower).
-template <int TM, int TN, int ACT, int DBG = 0, int WN = 2, int SIDE = 0>   // ACT: 0 none, 1 LeakyReLU(slope); DBG: ablation switches (probe only)
+//
+// PAIR = 1 (TN == 2 only) deals the output columns of a wave's 64-column strip to its two MFMA tiles as {2c + j} instead of
+// {32j + c}: the W rows are permuted through the DMA source address (free), and lane c then owns the ADJACENT columns 2c, 2c+1
+// of every row it holds, so the epilogue issues one 8-B store (and one 8-B side-operand load) where it issued two 4-B ones.
+// The store tail of a tile is bound by the number of store INSTRUCTIONS, not by bytes.
+template <int TM, int TN, int ACT, int DBG = 0, int WN = 2, int SIDE = 0, int PAIR = 0>   // ACT: 0 none, 1 LeakyReLU(slope); DBG: ablation switches (probe only)
 __global__ __launch_bounds__(128 * WN, 2) void linear_f32_kernel(const float *__restrict__ A, int lda,
                                                          const float *__restrict__ Wp, int K_pad,
                                                          const float *__restrict__ bias_p, float *__restrict__ C, int ldc,
@@ -105,7 +110,9 @@ __global__ __launch_bounds__(128 * WN, 2) void linear_f32_kernel(const float *__
 #pragma unroll
         for (int i = 0; i < W_DMA; ++i) {
             const int piece = wave + NW * i;
-            const float *src = Wp + (size_t)(n0 + 8 * piece + (lane >> 3)) * K_pad + kt * BK + swz;
+            int rl = 8 * piece + (lane >> 3);                         // LDS row = (strip, tile j, lane c)
+            if (PAIR) rl = (rl & ~63) + 2 * (rl & 31) + ((rl >> 5) & 1);   // ... holds the W row of output column strip + 2c + j
+            const float *src = Wp + (size_t)(n0 + rl) * K_pad + kt * BK + swz;
             lds_dma16(src, lds_w0 + (unsigned)((buf * BN * BK + piece * 256) * 4));
         }
     };
@@ -133,9 +140,11 @@ __global__ __launch_bounds__(128 * WN, 2) void linear_f32_kernel(const float *__
             }
         }
     };
+    static_assert(!PAIR || TN == 2, "PAIR needs two MFMA tiles per wave along N");
+    auto col_of = [&](int j) { return n0 + wc * 32 * TN + (PAIR ? 2 * (lane & 31) + j : j * 32 + (lane & 31)); };
     float bias_v[TN];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) bias_v[j] = bias_p[n0 + wc * 32 * TN + j * 32 + (lane & 31)];
+    for (int j = 0; j < TN; ++j) bias_v[j] = bias_p[col_of(j)];
     // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     auto epilogue = [&](int mt) {
         const int row0 = mt * BM + wr * 32 * TM + 4 * (lane >> 5);
@@ -145,6 +154,46 @@ __global__ __launch_bounds__(128 * WN, 2) void linear_f32_kernel(const float *__
             //   r_mode 1: LeakyReLU derivative of a stored activation, v = (acc + bias) * (R[m, n] > 0 ? 1 : slope)  (backward)
             // This lane's 16*TM row indices are fetched first, then all side values of one column block at once (the loads
             // are independent, so they overlap instead of forming index -> value -> store chains).
+            if (PAIR) {
+                // launcher guarantees: r_cols, ldr, ldc, N even; R and C 8-B aligned
+                const int gn = col_of(0);
+                const bool use = gn < r_cols;
+                const int gn_safe = use ? gn : r_cols - 2;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    int rid[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int gm = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                        const int gmc = gm < M ? gm : M - 1;
+                        rid[r] = ridx ? ridx[gmc] : gmc;
+                    }
+#pragma unroll
+                    for (int rb = 0; rb < 16; rb += 8) {
+                        float2 add[8];                             // 8 independent 8-B loads in flight
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) add[r] = *reinterpret_cast<const float2 *>(R + (size_t)rid[rb + r] * ldr + gn_safe);
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) {
+                            const int rr = rb + r;
+                            const int gm = row0 + i * 32 + (rr & 3) + 8 * (rr >> 2);
+                            float v0 = acc[i][0][rr] + bias_v[0], v1 = acc[i][1][rr] + bias_v[1];
+                            if (r_mode == 0) {
+                                v0 += use ? add[r].x : 0.f;
+                                v1 += use ? add[r].y : 0.f;
+                                if (ACT == 1) { v0 = v0 > 0.f ? v0 : v0 * slope; v1 = v1 > 0.f ? v1 : v1 * slope; }
+                            } else {
+                                v0 *= (use && !(add[r].x > 0.f)) ? slope : 1.f;
+                                v1 *= (use && !(add[r].y > 0.f)) ? slope : 1.f;
+                            }
+                            if (gm < M && gn < N) *reinterpret_cast<float2 *>(C + (size_t)gm * ldc + gn) = make_float2(v0, v1);
+                            acc[i][0][rr] = 0.f;
+                            acc[i][1][rr] = 0.f;
+                        }
+                    }
+                }
+                return;
+            }
             int rid[TM][16];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -156,7 +205,7 @@ __global__ __launch_bounds__(128 * WN, 2) void linear_f32_kernel(const float *__
                 }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const int gn = n0 + wc * 32 * TN + j * 32 + (lane & 31);
+                const int gn = col_of(j);
                 const bool use = gn < r_cols;
                 const int gn_safe = use ? gn : r_cols - 1;
 #pragma unroll
@@ -181,9 +230,25 @@ __global__ __launch_bounds__(128 * WN, 2) void linear_f32_kernel(const float *__
             }
             return;
         }
+        if (PAIR) {
+            const int gn = col_of(0);                              // even; N and ldc even, C 8-B aligned (launcher)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int gm = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                    float v0 = acc[i][0][r] + bias_v[0], v1 = acc[i][1][r] + bias_v[1];
+                    if (ACT == 1) { v0 = v0 > 0.f ? v0 : v0 * slope; v1 = v1 > 0.f ? v1 : v1 * slope; }
+                    if ((DBG != 4 || v0 == -1.2345e30f) && gm < M && gn < N) *reinterpret_cast<float2 *>(C + (size_t)gm * ldc + gn) = make_float2(v0, v1);
+                    acc[i][0][r] = 0.f;
+                    acc[i][1][r] = 0.f;
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int gn = n0 + wc * 32 * TN + j * 32 + (lane & 31);
+            const int gn = col_of(j);
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -191,7 +256,7 @@ __global__ __launch_bounds__(128 * WN, 2) void linear_f32_kernel(const float *__
                     const int gm = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
                     float v = acc[i][j][r] + bias_v[j];
                     if (ACT == 1) v = v > 0.f ? v : v * slope;
-                    if (gm < M && gn < N) C[(size_t)gm * ldc + gn] = v;
+                    if ((DBG != 4 || v == -1.2345e30f) && gm < M && gn < N) C[(size_t)gm * ldc + gn] = v;
                     acc[i][j][r] = 0.f;
                 }
             }
@@ -262,7 +327,7 @@ __global__ __launch_bounds__(128 * WN, 2) void linear_f32_kernel(const float *__
     int f = 0;
     auto stage = [&]() -> bool {                                  // issue the copies for tiles f+1 (W) and f+2 (A), in that order
         bool a_issued = false;
-        if (DBG == 0) {
+        if (DBG == 0 || DBG == 4) {
             if (m1 < n_mtiles) dma_w((f + 1) & 1, k1);                // buffer last read in iteration f-1 (barrier passed)
             if (m2 < n_mtiles) { dma_a((f + 2) % 3, m2, k2); a_issued = true; }   // buffer (f+2)%3 = (f-1)%3: same argument
         }
@@ -361,12 +426,11 @@ extern "C" int hnr_linear_f32_side(const float *d_A, int lda, const float *d_Wp,
     return linear_launch(d_A, lda, d_Wp, d_bias_p, d_C, ldc, M, N, K, act, slope, d_R, d_ridx, ldr, r_cols, r_mode, stream);
 }
 
-#define HNR_LINEAR_LAUNCH(TM_, TN_, ACT_, DBG_, WN_, THREADS_, LDS_)                                                                  \
-    do {                                                                                                                             \
-        if (d_R) linear_f32_kernel<TM_, TN_, ACT_, DBG_, WN_, 1><<<grid, THREADS_, LDS_, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, \
-                                                                                                slope, d_R, d_ridx, ldr, r_cols, r_mode);   \
-        else linear_f32_kernel<TM_, TN_, ACT_, DBG_, WN_, 0><<<grid, THREADS_, LDS_, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K,     \
-                                                                                            slope, d_R, d_ridx, ldr, r_cols, r_mode);       \
+#define HNR_LINEAR_ARGS d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope, d_R, d_ridx, ldr, r_cols, r_mode
+#define HNR_LINEAR_LAUNCH(TM_, TN_, ACT_, DBG_, WN_, PAIR_, THREADS_, LDS_)                                                   \
+    do {                                                                                                                     \
+        if (d_R) linear_f32_kernel<TM_, TN_, ACT_, DBG_, WN_, 1, PAIR_><<<grid, THREADS_, LDS_, st>>>(HNR_LINEAR_ARGS);      \
+        else linear_f32_kernel<TM_, TN_, ACT_, DBG_, WN_, 0, PAIR_><<<grid, THREADS_, LDS_, st>>>(HNR_LINEAR_ARGS);          \
     } while (0)
 
 static int linear_launch(const float *d_A, int lda, const float *d_Wp, const float *d_bias_p, float *d_C, int ldc, int M, int N, int K,
@@ -392,6 +456,11 @@ static int linear_launch(const float *d_A, int lda, const float *d_Wp, const flo
     const int n_mtiles = cdiv(M, 128);
     static int dbg = -1;
     if (dbg < 0) { const char *e = getenv("HNR_LINEAR_DBG"); dbg = e ? atoi(e) : 0; }
+    // column pairing (8-B epilogue accesses) needs even strides / column counts and 8-B aligned bases
+    static int pair_env = -1;
+    if (pair_env < 0) { const char *e = getenv("HNR_LINEAR_PAIR"); pair_env = e ? atoi(e) : 1; }
+    const bool pair = pair_env && N >= 128 && !(N & 1) && !(ldc & 1) && !((uintptr_t)d_C & 7) &&
+                      (!d_R || (!(ldr & 1) && !(r_cols & 1) && !((uintptr_t)d_R & 7)));
     if (N > 128 && Np % 256 == 0 && dbg != 3) {
         // 128 x 256 block tile, 8 waves (2 x 4): the A tile is fetched ONCE for all 256 output columns.  (With two 128-column
         // workgroups per M tile the PMC counters show A coming from HBM twice: 56.7 GB fetched per 24.3 GB of A.)
@@ -400,26 +469,29 @@ static int linear_launch(const float *d_A, int lda, const float *d_Wp, const flo
         if (gx < 1) gx = 1;
         if (gx > n_mtiles) gx = n_mtiles;
         dim3 grid(gx, ny);
-        if (act) HNR_LINEAR_LAUNCH(2, 2, 1, 0, 4, 512, 114688);
-        else HNR_LINEAR_LAUNCH(2, 2, 0, 0, 4, 512, 114688);
+        if (dbg == 4) { if (pair) HNR_LINEAR_LAUNCH(2, 2, 1, 4, 4, 1, 512, 114688); else HNR_LINEAR_LAUNCH(2, 2, 1, 4, 4, 0, 512, 114688); }
+        else if (pair) { if (act) HNR_LINEAR_LAUNCH(2, 2, 1, 0, 4, 1, 512, 114688); else HNR_LINEAR_LAUNCH(2, 2, 0, 0, 4, 1, 512, 114688); }
+        else if (act) HNR_LINEAR_LAUNCH(2, 2, 1, 0, 4, 0, 512, 114688);
+        else HNR_LINEAR_LAUNCH(2, 2, 0, 0, 4, 0, 512, 114688);
     } else if (N >= 128) {
         const int ny = Np / 128;
         int gx = (2 * n_cu) / ny;
         if (gx < 1) gx = 1;
         if (gx > n_mtiles) gx = n_mtiles;
         dim3 grid(gx, ny);
-        if (dbg == 1) HNR_LINEAR_LAUNCH(2, 2, 1, 1, 2, 256, 81920);
-        else if (dbg == 2) HNR_LINEAR_LAUNCH(2, 2, 1, 2, 2, 256, 81920);
-        else if (act) HNR_LINEAR_LAUNCH(2, 2, 1, 0, 2, 256, 81920);
-        else HNR_LINEAR_LAUNCH(2, 2, 0, 0, 2, 256, 81920);
+        if (dbg == 1) HNR_LINEAR_LAUNCH(2, 2, 1, 1, 2, 0, 256, 81920);
+        else if (dbg == 2) HNR_LINEAR_LAUNCH(2, 2, 1, 2, 2, 0, 256, 81920);
+        else if (pair) { if (act) HNR_LINEAR_LAUNCH(2, 2, 1, 0, 2, 1, 256, 81920); else HNR_LINEAR_LAUNCH(2, 2, 0, 0, 2, 1, 256, 81920); }
+        else if (act) HNR_LINEAR_LAUNCH(2, 2, 1, 0, 2, 0, 256, 81920);
+        else HNR_LINEAR_LAUNCH(2, 2, 0, 0, 2, 0, 256, 81920);
     } else {
         const int ny = Np / 64;
         int gx = (2 * n_cu) / ny;
         if (gx < 1) gx = 1;
         if (gx > n_mtiles) gx = n_mtiles;
         dim3 grid(gx, ny);
-        if (act) HNR_LINEAR_LAUNCH(2, 1, 1, 0, 2, 256, 65536);
-        else HNR_LINEAR_LAUNCH(2, 1, 0, 0, 2, 256, 65536);
+        if (act) HNR_LINEAR_LAUNCH(2, 1, 1, 0, 2, 0, 256, 65536);
+        else HNR_LINEAR_LAUNCH(2, 1, 0, 0, 2, 0, 256, 65536);
     }
     HNR_LAUNCH_CHECK();
     return HNR_OK;
