@@ -330,7 +330,6 @@ __global__ __launch_bounds__(128 * WN, 2) void linear_f32_kernel(const float *__
         if (mt0 >= n_mtiles) return;
         const int kvalid_last = K - (nk - 1) * BK;
         const int wave_s = __builtin_amdgcn_readfirstlane(wave);
-        const int g = wave_s / WN;                                 // wave row; rows 0 and 1 share the SIMDs pairwise
         const unsigned lds_a_wave = __builtin_amdgcn_readfirstlane(lds_a0) + (unsigned)wave_s * 1024u;
         const unsigned lds_w_wave = __builtin_amdgcn_readfirstlane(lds_w0) + (unsigned)wave_s * 1024u;
         auto barrier_plain = [&]() {
@@ -339,6 +338,10 @@ __global__ __launch_bounds__(128 * WN, 2) void linear_f32_kernel(const float *__
         };
         const long long t_begin = DBG == 5 ? clock64() : 0;
         long long t_retire = 0, t_barrier = 0, t_mark = 0;      // DBG == 5: cycles in the counted wait / from there to the barrier release
+        long long t_line[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // DBG == 5: issue timeline of tile 100 of workgroup 0
+        int tile_no = 0;
+        long long t_kt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_tile0 = 0;       // DBG == 5: cycles per K-tile position, summed over the M tiles
+        auto stamp = [&](int i) { if (DBG == 5 && tile_no == 100) t_line[i] = clock64(); };
 
         // copy cursor = the tile whose A is copied next; its W copy follows one iteration later
         int cm = mt0, ck = 0;
@@ -418,41 +421,45 @@ __global__ __launch_bounds__(128 * WN, 2) void linear_f32_kernel(const float *__
         auto body = [&](int kv, int kv_next) __attribute__((always_inline)) {   // one K tile (valid k of this tile / of the next one)
             if (!(ABL & 2)) { load_q(sa2, sb2, a_rd, w_rd, 2, kv); load_q(sa3, sb3, a_rd, w_rd, 3, kv); }
             const bool do_w = !(ABL & 1) && has_w, do_a = !(ABL & 1) && cm < n_mtiles;
-            // The matrix pipe of a SIMD is arbitrated by priority, then age: left alone, the older wave (rows 0) takes every
-            // slot it can use, finishes its 64 MFMAs early and idles at the barrier while the younger wave runs the rest of its
-            // tile with nobody to fill the gaps between its MFMAs (measured: rows 0 spend 27 % of the kernel in the barrier,
-            // rows 1 2 %).  The younger row therefore takes priority for the first half of every tile and gives it back for
-            // the second half: both waves reach the barrier together.
-            if (g == 1) __builtin_amdgcn_s_setprio(1);
-            // copy issue between the MFMA groups of quarter 0 (moving it to other slots, spreading the pieces over the tile or
-            // giving the two wave rows different slots measured the same or slower: profiles/README.md)
+            stamp(0);
             mfma4(sa0, sb0, 0);
             __builtin_amdgcn_sched_barrier(0);                     // the copy issue stays between these MFMA groups
+            stamp(1);
             if (do_w) copy_w(k_w, w_wr);
+            stamp(2);
             __builtin_amdgcn_sched_barrier(0);
             mfma4(sa0, sb0, 1);
             mfma4(sa0, sb0, 2);
             __builtin_amdgcn_sched_barrier(0);
+            stamp(3);
             if (do_a) copy_a(a_wr);
+            stamp(4);
             __builtin_amdgcn_sched_barrier(0);
             mfma4(sa0, sb0, 3);
+            __builtin_amdgcn_sched_barrier(0);
+            stamp(5);
             // the first two quarters of tile f+1 go into the sets that have just been consumed
             // (past the last tile the reads hit a stale buffer and are never used)
             const unsigned a_rd1 = (a_rd + A_BUF_B) & (A_RING_B - 1), w_rd1 = w_rd + W_BUF_B == W_RING_B ? 0 : w_rd + W_BUF_B;
             if (!(ABL & 2)) load_q(sa0, sb0, a_rd1, w_rd1, 0, kv_next);
 #pragma unroll
             for (int e = 0; e < 4; ++e) mfma4(sa1, sb1, e);
-            if (g == 1) __builtin_amdgcn_s_setprio(0);
+            if (DBG == 5) __builtin_amdgcn_sched_barrier(0);
+            stamp(6);
             if (!(ABL & 2)) load_q(sa1, sb1, a_rd1, w_rd1, 1, kv_next);
 #pragma unroll
             for (int e = 0; e < 4; ++e) mfma4(sa2, sb2, e);
+            if (DBG == 5) __builtin_amdgcn_sched_barrier(0);
+            stamp(7);
 #pragma unroll
             for (int e = 0; e < 4; ++e) mfma4(sa3, sb3, e);
             __builtin_amdgcn_sched_barrier(0);
+            stamp(8);
             long long tw0 = 0;
             if (DBG == 5) tw0 = clock64();
             if (do_a) wait_vmcnt<A_DMA>(); else wait_vmcnt<0>();   // tile f+2 has landed; only A(f+3) stays in flight
             if (DBG == 5) { const long long t = clock64(); t_retire += t - tw0; t_mark = t; }
+            stamp(9);
             has_w = cm < n_mtiles;                                 // the tile whose A went out now gets its W next iteration
             k_w = ck;
             if (has_w) advance();
@@ -461,6 +468,7 @@ __global__ __launch_bounds__(128 * WN, 2) void linear_f32_kernel(const float *__
             a_wr = (a_wr + A_BUF_B) & (A_RING_B - 1);
             w_wr = w_wr + W_BUF_B == W_RING_B ? 0 : w_wr + W_BUF_B;
         };
+        if (DBG == 5) t_tile0 = clock64();
 #pragma unroll 1
         for (int mc = mt0; mc < n_mtiles; mc += (int)gridDim.x) {
 #pragma unroll 1
@@ -468,14 +476,21 @@ __global__ __launch_bounds__(128 * WN, 2) void linear_f32_kernel(const float *__
                 body(BK, kt + 2 == nk ? kvalid_last : BK);
                 if (!(ABL & 4)) barrier_plain();
                 if (DBG == 5) t_barrier += clock64() - t_mark;
+                stamp(10);
+                ++tile_no;
+                if (DBG == 5) { const long long t = clock64(); t_kt[kt & 7] += t - t_tile0; t_tile0 = t; }
             }
             body(kvalid_last, kv_first);
             epilogue(mc);                                          // stores are younger than the counted wait above
             barrier_plain();
+            if (DBG == 5) { const long long t = clock64(); t_kt[(nk - 1) & 7] += t - t_tile0; t_tile0 = t; ++tile_no; }
         }
         if (DBG == 5 && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) {
             long long *o = reinterpret_cast<long long *>(const_cast<float *>(R)) + 4 * wave;
             o[0] = clock64() - t_begin; o[1] = t_retire; o[2] = t_barrier;
+            long long *tl = reinterpret_cast<long long *>(const_cast<float *>(R)) + 32 + 12 * wave;
+            for (int i = 0; i < 12; ++i) tl[i] = t_line[i];
+            if (wave == 0) for (int i = 0; i < 8; ++i) tl[96 + i] = t_kt[i];
         }
         return;
     }
@@ -665,14 +680,23 @@ static int linear_launch(const float *d_A, int lda, const float *d_Wp, const flo
 #ifdef HNR_LINEAR_PROBE                                            /* ablation / timing instantiations: probe builds only */
         if (dbg == 5 && pair && !d_R) {
             static long long *d_dbg = nullptr;
-            if (!d_dbg && hipMalloc(&d_dbg, 8 * 8 * sizeof(long long)) != hipSuccess) return HNR_ERR_HIP;
+            if (!d_dbg && hipMalloc(&d_dbg, (32 + 8 * 12 + 8) * sizeof(long long)) != hipSuccess) return HNR_ERR_HIP;
             linear_f32_kernel<2, 2, 1, 5, 4, 0, 1><<<grid, 512, 163840, st>>>(d_A, lda, d_Wp, Kp, d_bias_p, d_C, ldc, M, N, K, slope,
                                                                               reinterpret_cast<const float *>(d_dbg), nullptr, 0, 0, 0);
-            long long h[32];
+            long long h[32 + 96 + 8];
             if (hipMemcpy(h, d_dbg, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return HNR_ERR_HIP;
             for (int w = 0; w < 8; ++w)
                 fprintf(stderr, "[linear dbg5] wave %d: %lld cycles (%d M tiles x %d K tiles); in the counted wait %lld, wait end -> barrier release %lld\n", w,
                         h[4 * w], (n_mtiles + gx - 1) / gx, (K + 31) / 32, h[4 * w + 1], h[4 * w + 2]);
+            fprintf(stderr, "[linear dbg5] wave 0, cycles per K-tile position (avg over the M tiles):");
+            for (int i = 0; i < 8; ++i) fprintf(stderr, " %lld", h[32 + 96 + i] / ((n_mtiles + gx - 1) / gx));
+            fprintf(stderr, "\n");
+            const long long t00 = h[32] < h[32 + 48] ? h[32] : h[32 + 48];
+            for (int w = 0; w < 8; w += 4) {
+                fprintf(stderr, "[linear dbg5] wave %d tile 100 timeline (cycles after the earlier wave's start):", w);
+                for (int i = 0; i < 11; ++i) fprintf(stderr, " %lld", h[32 + 12 * w + i] - t00);
+                fprintf(stderr, "\n");
+            }
         }
         else if (dbg >= 16 && pair && !d_R && !(K % 32)) {
 #define HNR_ABL(X_) case X_: linear_f32_kernel<2, 2, 1, 16 + X_, 4, 0, 1, 0><<<grid, 512, 163840, st>>>(HNR_LINEAR_ARGS); break;
