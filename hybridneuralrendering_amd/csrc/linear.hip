@@ -443,16 +443,16 @@ __global__ __launch_bounds__(128 * WN, 2) void linear_f32_kernel(const float *__
             const unsigned a_rd1 = (a_rd + A_BUF_B) & (A_RING_B - 1), w_rd1 = w_rd + W_BUF_B == W_RING_B ? 0 : w_rd + W_BUF_B;
             if (!(ABL & 2)) load_q(sa0, sb0, a_rd1, w_rd1, 0, kv_next);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) mfma4(sa1, sb1, e);
+            for (int e = 0; e < 4; ++e) if (!MASKED || kv > 8) mfma4(sa1, sb1, e);      // a partial last K tile skips its empty quarters
             if (DBG == 5) __builtin_amdgcn_sched_barrier(0);
             stamp(6);
             if (!(ABL & 2)) load_q(sa1, sb1, a_rd1, w_rd1, 1, kv_next);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) mfma4(sa2, sb2, e);
+            for (int e = 0; e < 4; ++e) if (!MASKED || kv > 16) mfma4(sa2, sb2, e);
             if (DBG == 5) __builtin_amdgcn_sched_barrier(0);
             stamp(7);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) mfma4(sa3, sb3, e);
+            for (int e = 0; e < 4; ++e) if (!MASKED || kv > 24) mfma4(sa3, sb3, e);
             __builtin_amdgcn_sched_barrier(0);
             stamp(8);
             long long tw0 = 0;
