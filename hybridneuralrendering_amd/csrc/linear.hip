@@ -480,8 +480,68 @@ __global__ __launch_bounds__(128 * WN, 2) void linear_f32_kernel(const float *__
                 ++tile_no;
                 if (DBG == 5) { const long long t = clock64(); t_kt[kt & 7] += t - t_tile0; t_tile0 = t; }
             }
-            body(kvalid_last, kv_first);
-            epilogue(mc);                                          // stores are younger than the counted wait above
+            if constexpr (SIDE && PAIR) {
+                // Side-operand layers: this lane's 32 row indices are fetched BEFORE the last K tile (its counted wait retires
+                // them), and the side values are gathered in four batches of 8 rows, each batch requested before the previous
+                // one is consumed -- the epilogue pays ~2 memory round trips instead of the 6 of the index -> value -> store chain
+                // per 16 rows (the K=60 layer of the neighbour MLP spends half of its time in this epilogue).
+                const int row0 = mc * BM + wr * 32 * TM + 4 * (lane >> 5);
+                int rid[TM][16];
+                if (R != nullptr) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int gm = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                            const int gmc = gm < M ? gm : M - 1;
+                            rid[i][r] = ridx ? ridx[gmc] : gmc;
+                        }
+                }
+                body(kvalid_last, kv_first);
+                if (R != nullptr) {
+                    const int gn = col_of(0);                      // launcher: r_cols, ldr, ldc, N even; R and C 8-B aligned
+                    const bool use = gn < r_cols;
+                    const int gn_safe = use ? gn : r_cols - 2;
+                    float2 add_a[8], add_b[8];
+                    auto gather8 = [&](float2 (&ad)[8], int i, int rb) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) ad[r] = *reinterpret_cast<const float2 *>(R + (size_t)rid[i][rb + r] * ldr + gn_safe);
+                    };
+                    auto finish8 = [&](const float2 (&ad)[8], int i, int rb) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) {
+                            const int rr = rb + r;
+                            const int gm = row0 + i * 32 + (rr & 3) + 8 * (rr >> 2);
+                            float v0 = acc[i][0][rr] + bias_v[0], v1 = acc[i][1][rr] + bias_v[1];
+                            if (r_mode == 0) {
+                                v0 += use ? ad[r].x : 0.f;
+                                v1 += use ? ad[r].y : 0.f;
+                                if (ACT == 1) { v0 = v0 > 0.f ? v0 : v0 * slope; v1 = v1 > 0.f ? v1 : v1 * slope; }
+                            } else {
+                                v0 *= (use && !(ad[r].x > 0.f)) ? slope : 1.f;
+                                v1 *= (use && !(ad[r].y > 0.f)) ? slope : 1.f;
+                            }
+                            if (gm < M && gn < N) *reinterpret_cast<float2 *>(C + (size_t)gm * ldc + gn) = make_float2(v0, v1);
+                            acc[i][0][rr] = 0.f;
+                            acc[i][1][rr] = 0.f;
+                        }
+                    };
+                    static_assert(TM == 2, "batch plan below is written for two row blocks per wave");
+                    gather8(add_a, 0, 0);
+                    gather8(add_b, 0, 8);
+                    finish8(add_a, 0, 0);
+                    gather8(add_a, 1, 0);
+                    finish8(add_b, 0, 8);
+                    gather8(add_b, 1, 8);
+                    finish8(add_a, 1, 0);
+                    finish8(add_b, 1, 8);
+                } else {
+                    epilogue(mc);
+                }
+            } else {
+                body(kvalid_last, kv_first);
+                epilogue(mc);                                      // stores are younger than the counted wait above
+            }
             barrier_plain();
             if (DBG == 5) { const long long t = clock64(); t_kt[(nk - 1) & 7] += t - t_tile0; t_tile0 = t; ++tile_no; }
         }
