@@ -58,6 +58,9 @@ SIGNATURES = {
     "hnr_linear_f32": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "hnr_linear_f32_gather_add": (_I, [_P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P]),
     "hnr_linear_f32_side": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _P, _I, _I, _I, _I, _I, _F, _P]),
+    "hnr_linear_s3_packed_bytes": (ctypes.c_int64, [_I, _I]),
+    "hnr_linear_s3_pack": (_I, [_P, _P, _I, _I, _P, _P, _P]),
+    "hnr_linear_s3": (_I, [_P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P]),
     "hnr_linear_wgrad_scratch_elems": (ctypes.c_int64, [_I, _I, _I]),
     "hnr_linear_f32_wgrad": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P]),
     "hnr_sample_plan": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _P, _P, _P]),

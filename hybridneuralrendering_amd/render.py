@@ -7,6 +7,7 @@ reference's per-chunk grid rebuild, raypos tensor, boolean-mask copies or host s
 three counters per launch sizes the MLP workspaces).
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -67,6 +68,11 @@ class HybridRenderer:
         self._fm_key, self._fm, self._fm_src = None, None, None
         self._pt_key, self._pt, self._pt_src = None, None, None
         self.split_block1 = True          # fold the point-only 224 columns of block1.0 into a per-point table
+        # dense arithmetic of the three 256-wide per-neighbour layers: "bf16x3" = fp32 operands split exactly into three bf16
+        # terms on the bf16 matrix cores (hnr_linear_s3), "f32" = fp32 MFMA (hnr_linear_f32).  Same fp32-class results.
+        self.dense = os.environ.get("HNR_DENSE", "bf16x3")
+        if self.dense not in ("bf16x3", "f32"):
+            raise HnrError("HNR_DENSE must be bf16x3 or f32, got %r" % self.dense)
         self.split_merge = True           # multiply the colour-feature columns of aux_merge_weight_block.0 once per sample
         self.last_counts = None
         if getattr(opt, "which_render_func", "radiance") != "radiance" or getattr(opt, "which_blend_func", "alpha") != "alpha" \
@@ -149,10 +155,15 @@ class HybridRenderer:
                 pk["b1_dist"].gather_add(Xd, ptab, row_pid, out=B, act=True, slope=sl, K=60)   # 60 -> 256 (+ per-point addend)
             else:
                 pk["b1"][0](A, out=B, act=True, slope=sl)                   # 284 -> 256
-            pk["b1"][1](B, out=C, act=True, slope=sl)                       # 256 -> 256 into X3[:, :256]
+            if self.dense == "bf16x3":
+                ps = self.agg.packed_split()
+                l12, l30, l32 = ps["b1_2"], ps["b3_0"], ps["b3_2"]
+            else:
+                l12, l30, l32 = pk["b1"][1], pk["b3"][0], pk["b3"][1]
+            l12(B, out=C, act=True, slope=sl)                               # 256 -> 256 into X3[:, :256]
             H3 = A[:, :256]
-            pk["b3"][0](C, out=H3, act=True, slope=sl, K=263)               # 263 -> 256
-            pk["b3"][1](H3, out=B, act=True, slope=sl)                      # 256 -> 256  (H4)
+            l30(C, out=H3, act=True, slope=sl, K=263)                       # 263 -> 256
+            l32(H3, out=B, act=True, slope=sl)                              # 256 -> 256  (H4)
           with T("ksum"):
             X5 = _f32((n_valid, 280), dev)
             sigma = _f32((n_valid,), dev)

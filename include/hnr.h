@@ -182,6 +182,16 @@ int hnr_linear_f32_gather_add(const float *d_A, int lda, const float *d_Wp, cons
 int hnr_linear_f32_side(const float *d_A, int lda, const float *d_Wp, const float *d_bias_p, const float *d_R,
                         const int32_t *d_ridx, int ldr, int r_cols, int r_mode, float *d_C, int ldc, int M, int N, int K,
                         int act, float slope, void *stream);
+/* The same dense layer on the bf16 matrix cores by EXACT operand splitting (csrc/linear_s3.hip): every fp32 operand is the
+ * exact sum of three bf16 values (x = h + m + l), the six partial products >= 2^-16 |a w| are issued as
+ * v_mfma_f32_32x32x16_bf16 with fp32 accumulation, the three dropped ones sum to <= 2^-23 |a w| (one fp32 rounding of the
+ * product): fp32-class results at 6/16 of the fp32 matrix-pipe time.  N must be 256 (the per-neighbour layers block1 / block3,
+ * point_aggregators.py:948,:972).  d_W3: hnr_linear_s3_packed_bytes(N,K) bytes, d_bias_p: float[256], packed once per
+ * checkpoint.  d_R / d_ridx (may both be NULL): per-row addend R[ridx[m], 0..N) added before the activation (ldr >= N). */
+int64_t hnr_linear_s3_packed_bytes(int N, int K);
+int hnr_linear_s3_pack(const float *d_W, const float *d_bias /*may be NULL*/, int N, int K, void *d_W3, float *d_bias_p, void *stream);
+int hnr_linear_s3(const float *d_A, int lda, const void *d_W3, const float *d_bias_p, const float *d_R, const int32_t *d_ridx,
+                  int ldr, float *d_C, int ldc, int M, int N, int K, int act, float slope, void *stream);
 /* Weight and bias gradient of a dense layer:  dW[N,K] (row stride lddw) = dZ[M,N]^T X[M,K],  db[N] = column sums of dZ
  * (d_db may be NULL); accumulate != 0 adds to the existing values.  ldz, ldx multiples of 4; d_scratch:
  * float[hnr_linear_wgrad_scratch_elems(M,N,K)].  Deterministic (fixed-order two-stage reduction, no atomics). */

@@ -293,3 +293,30 @@ def test_install_rebinds_the_reference_globals():
             assert po[:len(pt)] == pt or set(pt) <= set(po), (po, pt)
     finally:
         (ref.vol.NeuralPoints, ref.vol.PointAggregator, ref.vol.NeuralPointsRayMarching, ref.vol.ray_march, ref.npts.lighting_fast_querier_w) = saved
+
+
+def test_three_bf16_terms_represent_fp32_exactly():
+    """The arithmetic claim behind hnr_linear_s3 (csrc/linear_s3.hip): x = h + m + l with h = bf16(x), m = bf16(x - h),
+    l = bf16(x - h - m) (round to nearest even) is EXACT for fp32 x, and the three partial products the kernel drops
+    (m*l, l*m, l*l) are <= 2^-23 |a w| together."""
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.standard_normal(200000).astype(np.float32) * np.float32(10.0) ** rng.integers(-6, 6, 200000).astype(np.float32),
+                        np.array([0.0, 1.0, -1.0, 3.0e38, 1.17549435e-38 * 2 ** 20, 0.1, 1 / 3], np.float32)])
+
+    def bf16(v):
+        u = v.astype(np.float32).view(np.uint32).astype(np.uint64)
+        u = (u + 0x7FFF + ((u >> 16) & 1)) >> 16 << 16
+        return u.astype(np.uint32).view(np.float32)
+
+    h = bf16(x)
+    r1 = x - h
+    m = bf16(r1)
+    r2 = r1 - m
+    l = bf16(r2)
+    assert np.array_equal(h.astype(np.float64) + m.astype(np.float64) + l.astype(np.float64), x.astype(np.float64))
+    assert np.all(np.abs(m) <= np.abs(x) * 2.0 ** -8) and np.all(np.abs(l) <= np.abs(x) * 2.0 ** -16)
+    w = rng.standard_normal(x.size).astype(np.float32)
+    wh = bf16(w); wm = bf16(w - wh); wl = bf16(w - wh - wm)
+    f = lambda a: a.astype(np.float64)
+    kept = f(h) * f(wh) + f(h) * f(wm) + f(m) * f(wh) + f(h) * f(wl) + f(m) * f(wm) + f(l) * f(wh)
+    assert np.all(np.abs(f(x) * f(w) - kept) <= np.abs(f(x) * f(w)) * 2.0 ** -23 + 1e-300)
