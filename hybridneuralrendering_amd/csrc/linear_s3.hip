@@ -18,6 +18,7 @@
 // streamed global -> LDS by DMA (24 KiB per k step, ring of three), one ds_read_b128 per (k step, column tile, plane).
 // Persistent workgroups stride the 128-row tiles.
 #include <stdlib.h>
+#include <type_traits>
 
 #include "hnr_common.h"
 
@@ -246,8 +247,211 @@ __global__ __launch_bounds__(256, 2) void linear_s3_kernel(const float *__restri
 #undef S3_STAMP
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Weight-stationary variant (the product path for K = 256 / 257..272 / 49..64).
+//
+// The layer is a skinny GEMM (M = 2.4e7 rows, N = 256, K <= 272): the 384 KiB of split weights are the only operand worth keeping
+// on chip, and a CU has 512 KiB of registers + 160 KiB of LDS.  One 256-thread workgroup per CU (one wave per SIMD, up to 512
+// registers each); wave w OWNS output columns 64 w .. 64 w + 63 and keeps their weight fragments for the whole kernel
+// ([k step][2 column tiles][3 planes] x 16 B per lane: the first S-4 k steps in registers, the last 4 in its private LDS
+// slice).  The activations stream past: the workgroup loads a 32-row x 128-column chunk with fully coalesced 16-B loads
+// (2 rows x 512 B per wave instruction), every thread splits its 16 values ONCE and writes the three bf16 planes into LDS in
+// MFMA fragment order; all four waves then read each fragment (ds_read_b128) for their own 64 columns.  Per output row the
+// kernel moves 1 KiB in + 1 KiB out through the vector-memory path and nothing else (the acc-stationary kernel above also
+// re-streams 3 KiB of weights per row, which is what bounds it).
+// ------------------------------------------------------------------------------------------------------------------------
+template <int S, int ACT, int SIDE, int DBG = 0>
+__global__ __launch_bounds__(256, 1) void linear_s3w_kernel(const float *__restrict__ A, int lda, const char *__restrict__ W3,
+                                                            const float *__restrict__ bias, float *__restrict__ C, int ldc,
+                                                            int M, int K, float slope, const float *__restrict__ R,
+                                                            const int32_t *__restrict__ ridx, int ldr)
+{
+    constexpr int CK = 8;                              // k steps per activation chunk (128 columns)
+    constexpr int NC = (S + CK - 1) / CK;              // chunks per 32-row tile
+    constexpr int SL = S > 4 ? 4 : 0;                  // k steps whose weight fragments live in LDS (the last SL)
+    constexpr int SR = S - SL;                         // k steps whose weight fragments live in registers
+    constexpr int SSTRIDE = 3 * 1024 + 32;             // bytes per k step of the activation planes (+32 spreads the split writes over the banks)
+    constexpr int ABUF = CK * SSTRIDE;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, j = lane & 31;
+    const int n_tiles = (M + 31) / 32;
+    if ((int)blockIdx.x >= n_tiles) return;
+    const int my_tiles = (n_tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1;
+    const int total = my_tiles * NC;
+
+    // ---- resident weights of this wave's 64 columns (column tiles 2 wave, 2 wave + 1)
+    u32x4 wr[SR > 0 ? SR : 1][2][3];
+    char *wl = lds + 2 * ABUF + wave * (SL * 6 * 1024) + lane * 16;
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                const u32x4 v = *reinterpret_cast<const u32x4 *>(W3 + ((size_t)((s * 8 + 2 * wave + c) * 3 + pl)) * 1024 + lane * 16);
+                if (s < SR) wr[s][c][pl] = v;
+                else *reinterpret_cast<u32x4 *>(wl + (((s - SR) * 2 + c) * 3 + pl) * 1024) = v;
+            }
+
+    // ---- activation chunk producer: thread (wave, lane) owns k quad kq = lane & 31 of rows 8 wave + 2 q + (lane >> 5), q = 0..3
+    const int kq = lane & 31;
+    float4 raw[4];
+    auto steps_of = [&](int kc) { return kc == NC - 1 ? S - (NC - 1) * CK : CK; };
+    // Loads are unconditional: rows past M and quads past lda are clamped to valid memory (such rows are never stored, such
+    // quads are >= K and zeroed at the split), chunks past this workgroup's last tile re-read the last tile.
+    const int last_tile = (int)blockIdx.x + (my_tiles - 1) * (int)gridDim.x;
+    auto load_quad = [&](int q, int row0, int k0) {
+        int row = row0 + 2 * q;
+        if (row >= M) row = M - 1;
+        raw[q] = *reinterpret_cast<const float4 *>(A + (size_t)row * lda + k0);
+    };
+    auto chunk_row0 = [&](int t) { return (t > last_tile ? last_tile : t) * 32 + 8 * wave + h; };
+    auto chunk_k0 = [&](int kc) { const int k0 = kc * (CK * 16) + 4 * kq; return k0 + 4 > lda ? lda - 4 : k0; };
+    // k = 16 s + 8 hh + 4 sub + e: quad kq sits in k step kq >> 2, lane half (kq >> 1) & 1, 8-byte half kq & 1 of the fragment
+    const int w_off = (kq >> 2) * SSTRIDE + ((kq >> 1) & 1) * 512 + (kq & 1) * 8 + (8 * wave + h) * 16;
+    f32x16 acc[2];
+    // Producer pieces, one per k step of the chunk being computed, so that their VALU / LDS / VMEM instructions issue in the
+    // shadow of the MFMAs: piece 2 q splits (x, y) of raw[q], piece 2 q + 1 splits (z, w), writes the three 8-B plane entries of
+    // chunk n+1 and re-loads raw[q] with chunk n+2.
+    struct Prod { bool wr; int k0w; char *dst; int row0, k0l; } pr;       // (row0, k0l): first row / column of this thread's quads of chunk n+2
+    unsigned sp[6];
+    auto piece = [&](int i) {
+        const int q = i >> 1;
+        if (!(i & 1)) {
+            float x = raw[q].x, y = raw[q].y;
+            if (pr.k0w + 0 >= K) x = 0.f;
+            if (pr.k0w + 1 >= K) y = 0.f;
+            split2(x, y, sp[0], sp[1], sp[2]);
+        } else {
+            float z = raw[q].z, w = raw[q].w;
+            if (pr.k0w + 2 >= K) z = 0.f;
+            if (pr.k0w + 3 >= K) w = 0.f;
+            split2(z, w, sp[3], sp[4], sp[5]);
+            if (pr.wr) {
+                *reinterpret_cast<uint2 *>(pr.dst + q * 32) = make_uint2(sp[0], sp[3]);
+                *reinterpret_cast<uint2 *>(pr.dst + q * 32 + 1024) = make_uint2(sp[1], sp[4]);
+                *reinterpret_cast<uint2 *>(pr.dst + q * 32 + 2048) = make_uint2(sp[2], sp[5]);
+            }
+            load_quad(q, pr.row0, pr.k0l);
+        }
+    };
+    auto compute = [&](auto KC, int buf) {
+        constexpr int kc = decltype(KC)::value;
+        constexpr int ns = kc == NC - 1 ? S - (NC - 1) * CK : CK;
+        const char *ab = lds + buf * ABUF + lane * 16;
+        u32x4 af[2][3], wf[2][2][3];
+        auto fetch = [&](int slot, int sl) {
+            const int s = kc * CK + sl;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) af[slot][pl] = *reinterpret_cast<const u32x4 *>(ab + sl * SSTRIDE + pl * 1024);
+            if (s >= SR) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) wf[slot][c][pl] = *reinterpret_cast<const u32x4 *>(wl + (((s - SR) * 2 + c) * 3 + pl) * 1024);
+            }
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int sl = 0; sl < ns; ++sl) {
+            const int s = kc * CK + sl, cur = sl & 1;
+            if (sl + 1 < ns) fetch(cur ^ 1, sl + 1);
+            const bf16x8 Ah = __builtin_bit_cast(bf16x8, af[cur][0]), Am = __builtin_bit_cast(bf16x8, af[cur][1]), Al = __builtin_bit_cast(bf16x8, af[cur][2]);
+#define W_(c, pl) __builtin_bit_cast(bf16x8, (s < SR ? wr[s < SR ? s : 0][c][pl] : wf[cur][c][pl]))
+            // smallest terms first; the two column tiles alternate so that no MFMA waits for its predecessor
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, W_(0, 0), acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, W_(1, 0), acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, W_(0, 2), acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, W_(1, 2), acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, W_(0, 1), acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, W_(1, 1), acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, W_(0, 0), acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, W_(1, 0), acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, W_(0, 1), acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, W_(1, 1), acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, W_(0, 0), acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, W_(1, 0), acc[1], 0, 0, 0);
+#undef W_
+            piece(sl);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i = ns; i < 8; ++i) piece(i);                      // short chunk: the pieces that found no k step to hide under
+    };
+    // epilogue: column tile c, lane column j of wave w carries output column 64 w + 2 j + c, so a lane owns two ADJACENT columns
+    // of each of its 16 rows i = (r & 3) + 8 (r >> 2) + 4 h: one 8-B store per row, 256 contiguous bytes per half wave
+    const float2 bj = *reinterpret_cast<const float2 *>(bias + 64 * wave + 2 * j);
+    auto epilogue = [&](int t) {
+        const int row0 = t * 32;
+        int my_ridx = 0;
+        if (SIDE) { const int rr = row0 + j; my_ridx = ridx[rr < M ? rr : M - 1]; }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int row = row0 + i;
+            float2 v = make_float2(acc[0][r] + bj.x, acc[1][r] + bj.y);
+            if (SIDE) {
+                const int src = __shfl(my_ridx, i, 64);
+                const float2 rv = *reinterpret_cast<const float2 *>(R + (size_t)src * ldr + 64 * wave + 2 * j);
+                v.x += rv.x; v.y += rv.y;
+            }
+            if (ACT) { v.x = v.x > 0.f ? v.x : v.x * slope; v.y = v.y > 0.f ? v.y : v.y * slope; }
+            if (row < M && (!(DBG & 8) || v.x == 123.456f)) *reinterpret_cast<float2 *>(C + (size_t)row * ldc + 64 * wave + 2 * j) = v;
+            acc[0][r] = 0.f; acc[1][r] = 0.f;
+        }
+    };
+
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+    // prologue: chunk 0 -> LDS buffer 0, chunk 1 -> registers
+    {
+        pr.wr = kq < 4 * steps_of(0); pr.k0w = 4 * kq; pr.dst = lds + w_off;
+        const int r0 = chunk_row0(blockIdx.x), k00 = chunk_k0(0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) load_quad(q, r0, k00);
+        pr.row0 = NC > 1 ? r0 : chunk_row0((int)blockIdx.x + (int)gridDim.x);
+        pr.k0l = chunk_k0(NC > 1 ? 1 : 0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) piece(i);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    long long tm[6] = {0, 0, 0, 0, 0, 0}, t_prev = 0, t_start = 0, w_start = 0;
+    if (DBG & 32) { t_start = t_prev = clock64(); w_start = wall_clock64(); }
+#define S3_STAMP(i_) do { if (DBG & 32) { const long long t_ = clock64(); tm[i_] += t_ - t_prev; t_prev = t_; } } while (0)
+    int qn = 0;                                                      // chunk counter of this workgroup (buffer = qn & 1)
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        auto one_chunk = [&](auto KC) {
+            constexpr int kc = decltype(KC)::value;
+            constexpr int kn = (kc + 1) % NC, k2 = (kc + 2) % NC;
+            S3_STAMP(0);
+            // chunk qn+1 (k chunk kn): registers -> split -> LDS buffer (qn+1)&1, last read in the previous iteration;
+            // chunk qn+2 (k chunk k2 of tile + ((kc+2)/NC) grid): global -> registers
+            pr.wr = qn + 1 < total && kq < 4 * (kn == NC - 1 ? S - (NC - 1) * CK : CK);
+            pr.k0w = kn * (CK * 16) + 4 * kq;
+            pr.dst = lds + ((qn + 1) & 1) * ABUF + w_off;
+            pr.row0 = chunk_row0(tile + ((kc + 2) / NC) * (int)gridDim.x);
+            pr.k0l = chunk_k0(k2);
+            compute(KC, qn & 1);
+            S3_STAMP(3);
+            if (kc == NC - 1) { epilogue(tile); S3_STAMP(4); }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            S3_STAMP(5);
+            ++qn;
+        };
+        one_chunk(std::integral_constant<int, 0>{});
+        if (NC > 1) one_chunk(std::integral_constant<int, (NC > 1 ? 1 : 0)>{});
+        if (NC > 2) one_chunk(std::integral_constant<int, (NC > 2 ? 2 : 0)>{});
+    }
+    if ((DBG & 32) && blockIdx.x == 0 && lane == 0) {
+        long long *o = reinterpret_cast<long long *>(const_cast<float *>(R)) + wave * 16;
+        for (int i = 0; i < 6; ++i) o[i] = tm[i];
+        o[8] = clock64() - t_start; o[9] = wall_clock64() - w_start; o[10] = total;
+    }
+#undef S3_STAMP
+}
+
 // W[N,K] fp32 -> split bf16 fragments; bias -> padded fp32[256]
-__global__ void pack_s3_kernel(const float *__restrict__ W, const float *__restrict__ bias, int N, int K, int G,
+__global__ void pack_s3_kernel(const float *__restrict__ W, const float *__restrict__ bias, int N, int K, int G, int stationary,
                                unsigned short *__restrict__ W3, float *__restrict__ bias_p)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // one (g, ks, c, lane, e) per thread
@@ -255,7 +459,10 @@ __global__ void pack_s3_kernel(const float *__restrict__ W, const float *__restr
     if (i < 256) bias_p[i] = (i < N && bias) ? bias[i] : 0.f;
     if (i >= total) return;
     const int e = (int)(i & 7), l = (int)((i >> 3) & 63), c = (int)((i >> 9) & 7), ks = (int)((i >> 12) & 1), g = (int)(i >> 13);
-    const int n = 8 * (l & 31) + c, k = 32 * g + 16 * (l >> 5) + 8 * ks + e;     // tile c, lane column j <-> output column 8 j + c
+    // acc-stationary kernel: tile c, lane column j <-> output column 8 j + c, k = 32 g + 16 hh + 8 ks + e
+    // weight-stationary kernel: output column 64 (c >> 1) + 2 j + (c & 1), k = 16 (2 g + ks) + 8 hh + e
+    const int n = stationary ? 64 * (c >> 1) + 2 * (l & 31) + (c & 1) : 8 * (l & 31) + c;
+    const int k = stationary ? 16 * (2 * g + ks) + 8 * (l >> 5) + e : 32 * g + 16 * (l >> 5) + 8 * ks + e;
     const float x = (n < N && k < K) ? W[(size_t)n * K + k] : 0.f;
     auto rne = [](float v) -> unsigned {                 // fp32 -> bf16 bits, round to nearest even (finite inputs)
         unsigned u = __float_as_uint(v);
@@ -277,6 +484,17 @@ __global__ void pack_s3_kernel(const float *__restrict__ W, const float *__restr
 
 using namespace hnr;
 
+// K steps of 16: the weight-stationary kernel is instantiated for the layer shapes of the path (K = 60 -> 4, 256 -> 16, 263 -> 17);
+// any other K runs the acc-stationary kernel.  HNR_S3_KERNEL=acc forces the latter (A/B timing).  Pack and launch must agree.
+static int s3_stationary_steps(int K)
+{
+    static int force_acc = -1;
+    if (force_acc < 0) { const char *e = getenv("HNR_S3_KERNEL"); force_acc = (e && !strcmp(e, "acc")) ? 1 : 0; }
+    if (force_acc) return 0;
+    const int S = (K + 15) / 16;
+    return (S == 4 || S == 16 || S == 17) ? S : 0;
+}
+
 extern "C" int64_t hnr_linear_s3_packed_bytes(int N, int K)
 {
     if (N <= 0 || N > 256 || K <= 0) return -1;
@@ -288,7 +506,7 @@ extern "C" int hnr_linear_s3_pack(const float *d_W, const float *d_bias, int N, 
     if (!d_W || !d_W3 || !d_bias_p || N <= 0 || N > 256 || K <= 0) { set_error("hnr_linear_s3_pack: bad argument (N must be <= 256)"); return HNR_ERR_BADARG; }
     const int G = (K + 31) / 32;
     const int64_t total = (int64_t)G * 2 * 8 * 64 * 8;
-    pack_s3_kernel<<<cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(d_W, d_bias, N, K, G, (unsigned short *)d_W3, d_bias_p);
+    pack_s3_kernel<<<cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(d_W, d_bias, N, K, G, s3_stationary_steps(K) ? 1 : 0, (unsigned short *)d_W3, d_bias_p);
     HNR_LAUNCH_CHECK();
     return HNR_OK;
 }
@@ -310,9 +528,41 @@ extern "C" int hnr_linear_s3(const float *d_A, int lda, const void *d_W3, const 
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
         if (n_cu <= 0) n_cu = 256;
     }
+    hipStream_t st = (hipStream_t)stream;
+    if (const int S = s3_stationary_steps(K)) {
+        const int n_tiles32 = cdiv(M, 32);
+        const int gridw = n_tiles32 < n_cu ? n_tiles32 : n_cu;
+        const size_t ldsw = 2 * 8 * (3 * 1024 + 32) + (S > 4 ? 4 * 4 * 6 * 1024 : 0);
+        const char *w3w = (const char *)d_W3;
+#define HNR_S3W_LAUNCH(S_, ACT_, SIDE_) linear_s3w_kernel<S_, ACT_, SIDE_><<<gridw, 256, ldsw, st>>>(d_A, lda, w3w, d_bias_p, d_C, ldc, M, K, slope, d_R, d_ridx, ldr)
+#define HNR_S3W_LAUNCH_S(S_) do { if (d_R) { if (act) HNR_S3W_LAUNCH(S_, 1, 1); else HNR_S3W_LAUNCH(S_, 0, 1); } else { if (act) HNR_S3W_LAUNCH(S_, 1, 0); else HNR_S3W_LAUNCH(S_, 0, 0); } } while (0)
+#ifdef HNR_LINEAR_PROBE
+        static int dbgw = -1;
+        if (dbgw < 0) { const char *e = getenv("HNR_S3_DBG"); dbgw = e ? atoi(e) : 0; }
+        if (dbgw == 32 && S == 16 && act && !d_R) {
+            static long long *d_dbg = nullptr;
+            if (!d_dbg && hipMalloc(&d_dbg, 4 * 16 * sizeof(long long)) != hipSuccess) return HNR_ERR_HIP;
+            linear_s3w_kernel<16, 1, 0, 32><<<gridw, 256, ldsw, st>>>(d_A, lda, w3w, d_bias_p, d_C, ldc, M, K, slope, reinterpret_cast<const float *>(d_dbg), d_ridx, ldr);
+            long long hh[64];
+            if (hipMemcpy(hh, d_dbg, sizeof(hh), hipMemcpyDeviceToHost) != hipSuccess) return HNR_ERR_HIP;
+            int wall_khz = 0; (void)hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, 0);
+            for (int w = 0; w < 4; ++w) {
+                const long long *o = hh + 16 * w;
+                const double nq = (double)o[10];
+                fprintf(stderr, "[s3w dbg32] wave %d: %lld chunks, %lld cycles at %.3f GHz; per chunk: set-up %.0f, (%.0f, %.0f), 96 MFMAs + producer pieces %.0f, epilogue (per tile) %.0f, barrier %.0f\n", w,
+                        o[10], o[8], (double)o[8] / ((double)o[9] / (wall_khz * 1e3)) / 1e9, o[0] / nq, o[1] / nq, o[2] / nq, o[3] / nq, o[4] / (nq / 2), o[5] / nq);
+            }
+        } else if (dbgw == 8 && S == 16 && act && !d_R) linear_s3w_kernel<16, 1, 0, 8><<<gridw, 256, ldsw, st>>>(d_A, lda, w3w, d_bias_p, d_C, ldc, M, K, slope, d_R, d_ridx, ldr);
+        else
+#endif
+        if (S == 4) HNR_S3W_LAUNCH_S(4); else if (S == 16) HNR_S3W_LAUNCH_S(16); else HNR_S3W_LAUNCH_S(17);
+#undef HNR_S3W_LAUNCH_S
+#undef HNR_S3W_LAUNCH
+        HNR_LAUNCH_CHECK();
+        return HNR_OK;
+    }
     const int n_tiles = cdiv(M, S3_ROWS), G = (K + 31) / 32;
     const int grid = n_tiles < 2 * n_cu ? n_tiles : 2 * n_cu;
-    hipStream_t st = (hipStream_t)stream;
     const size_t lds = 3 * S3_STEP_BYTES;
     const char *w3 = (const char *)d_W3;
 #define HNR_S3_LAUNCH(ACT_, SIDE_) linear_s3_kernel<ACT_, SIDE_><<<grid, 256, lds, st>>>(d_A, lda, w3, d_bias_p, d_C, ldc, M, K, G, slope, d_R, d_ridx, ldr)
