@@ -24,6 +24,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F32_MFMA_PEAK_TF = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+BF16_MFMA_PEAK_TF = 2500.0     # MI355X_MICROARCH.md: bf16 MFMA dense peak (v_mfma_f32_32x32x16_bf16)
 
 
 def parse():
@@ -245,8 +246,11 @@ def main():
         # recorded on the launch stream inside the timed region
         roof, roof_q = None, None
         pmc = pmc_traffic() if (int(args.points) == 2000000 and args.scene == "scene0241" and args.chunk <= 0) else {}
-        # the 4 per-neighbour layers: three plain launches (<2,2,1,0,4,0>) and the K=60 layer with the gathered addend (<...,1>)
-        lin = {k: v for k, v in pmc.items() if "linear_f32_kernel<2, 2, 1, 0, 4" in k}
+        split = getattr(rnd, "dense", "f32") == "bf16x3"
+        # the per-neighbour layers: bf16x3 -> three linear_s3w_kernel launches (block1.2, block3.0, block3.2) + the fp32-MFMA K=60
+        # layer with its gathered addend; f32 -> four linear_f32_kernel launches
+        kname = "linear_s3w_kernel" if split else "linear_f32_kernel<2, 2, 1, 0, 4"
+        lin = {k: v for k, v in pmc.items() if kname in k}
         t_lin = None
         if lin:
             n = sum(v["launches"] for v in lin.values())
@@ -255,13 +259,34 @@ def main():
         if counts is not None:
             n_rows, n_valid = int(counts[CNT["NEIGHBOURS"]]), int(counts[CNT["SAMPLES_VALID"]])
             s_all, cells, cand = int(counts[CNT["SAMPLES"]]), int(counts[CNT["CELLS_VISITED"]]), int(counts[CNT["CANDIDATES"]])
-            # per-neighbour MLP: block1 (284->256->256) + block3 (263->256->256) = 4 launches of linear_f32_kernel<2,2,1,0,4>.
-            # ALGORITHMIC flops (271 104 MAC per valid neighbour for these four layers); the kernels EXECUTE fewer
-            # because block1.0's 224 point-only input columns are folded into a per-point table (60 columns left per row).
-            flops_nb = 2.0 * n_rows * 256 * (284 + 256 + 263 + 256)
-            flops_exec = 2.0 * n_rows * 256 * (60 + 256 + 263 + 256) if rnd.split_block1 else flops_nb
             ms_nb = stage_ms.get("mlp_neighbour", 0.0)
-            if ms_nb > 0:
+            ms_3 = sum(stage_ms.get(k, 0.0) for k in ("dense_b1_2", "dense_b3_0", "dense_b3_2"))
+            # ALGORITHMIC flops (271 104 MAC per valid neighbour for block1 + block3)
+            flops_nb = 2.0 * n_rows * 256 * (284 + 256 + 263 + 256)
+            if split and ms_3 > 0:
+                # dominant kernel: the split-bf16 dense layer.  Algorithmic fp32 flops of the three layers = 2 M N K; the kernel
+                # issues SIX bf16 MFMA products per fp32 product (exact 3-way operand split, csrc/linear_s3.hip), K rounded up to 16.
+                alg = 2.0 * n_rows * 256 * (256 + 263 + 256)
+                issued = 6.0 * 2.0 * n_rows * 256 * (256 + 272 + 256)
+                ach = issued / (ms_3 * 1e-3) / 1e12
+                roof = dict(kernel="linear_s3w_kernel<16|17,1,0> (block1.2, block3.0, block3.2: 3 launches, M=%d rows, N=256)" % n_rows, bound="mfma",
+                            achieved=round(ach, 1), peak=BF16_MFMA_PEAK_TF, unit="TFLOP/s", frac=round(ach / BF16_MFMA_PEAK_TF, 4),
+                            traffic=int(t_lin["hbm_bytes"]) if t_lin else None,
+                            traffic_source="profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)" if t_lin else None,
+                            flops_per_launch=issued / 3, avg_launch_ms=round(ms_3 / 3, 4),
+                            fp32_equivalent_tflops=round(alg / (ms_3 * 1e-3) / 1e12, 2),
+                            algorithmic_bytes_per_launch=int(n_rows * (256 + 256) * 4),
+                            hbm_gbs=round(n_rows * 2048.0 * 3 / (ms_3 * 1e-3) / 1e9, 1),
+                            note="achieved = bf16 MFMA flops issued (6 per fp32 product) / time, against the bf16 dense peak; the matrix pipe is "
+                                 "power-limited with real operand data: tools/mfma_peak_bf16 sustains 1895 TFLOP/s (1.89 GHz) with random and "
+                                 "2470 (2.39 GHz) with constant operands on this chip; fp32_equivalent_tflops = 2 M N K / time "
+                                 "(the fp32-MFMA kernel it replaces: 119-125, peak 157.3)",
+                            neighbour_mlp=dict(ms=round(ms_nb, 3), algorithmic_tflops=round(flops_nb / (ms_nb * 1e-3) / 1e12, 2) if ms_nb > 0 else None,
+                                               k60_layer_ms=round(ms_nb - ms_3, 3)))
+            elif ms_nb > 0:
+                # per-neighbour MLP on fp32 MFMA: 4 launches of linear_f32_kernel<2,2,1,0,4>; the kernels EXECUTE fewer flops than
+                # the algorithmic count because block1.0's 224 point-only input columns are folded into a per-point table
+                flops_exec = 2.0 * n_rows * 256 * (60 + 256 + 263 + 256) if rnd.split_block1 else flops_nb
                 ach = flops_nb / (ms_nb * 1e-3) / 1e12
                 roof = dict(kernel="linear_f32_kernel<2,2,1,0,4,*> (block1+block3, 4 launches, M=%d rows)" % n_rows, bound="mfma",
                             achieved=round(ach, 2), peak=F32_MFMA_PEAK_TF, unit="TFLOP/s", frac=round(ach / F32_MFMA_PEAK_TF, 4),
@@ -302,7 +327,7 @@ def main():
             "metric": "rays/sec (fwd render) scene0241_01 at 1/2/4/8 GPU; PSNR delta vs ref",
             "value": world * R * args.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: ranks share GPUs, gloo collectives -- not a measurement)",
+            "dtype": "f32", "dense_arithmetic": ("fp32 MFMA (v_mfma_f32_32x32x2_f32)" if getattr(rnd, "dense", "f32") == "f32" else "256-wide per-neighbour layers: fp32 operands split EXACTLY into 3 bf16 terms, 6 bf16 MFMAs per product, fp32 accumulate (fp32-class error, tests/test_linear_gpu.py); all other layers fp32 MFMA"), "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: ranks share GPUs, gloo collectives -- not a measurement)",
             "config": {"workload": "%s synthetic scene (SURVEY 8d): %d points, %dx%d frame margin %d = %d rays per GPU per step, "
                                    "SR=%d K=%d P=%d max_o=%d D=%d, 4 reference views %dx%d, hybrid viewmlp forward (query+gather+aggregate+composite)"
                                    % ({"scene0241": "scene0241_01-like room", "scene0101": "scene0101_04-like room"}.get(args.scene, args.scene + "-like object"),

@@ -160,10 +160,13 @@ class HybridRenderer:
                 l12, l30, l32 = ps["b1_2"], ps["b3_0"], ps["b3_2"]
             else:
                 l12, l30, l32 = pk["b1"][1], pk["b3"][0], pk["b3"][1]
-            l12(B, out=C, act=True, slope=sl)                               # 256 -> 256 into X3[:, :256]
+            with T("dense_b1_2"):
+                l12(B, out=C, act=True, slope=sl)                           # 256 -> 256 into X3[:, :256]
             H3 = A[:, :256]
-            l30(C, out=H3, act=True, slope=sl, K=263)                       # 263 -> 256
-            l32(H3, out=B, act=True, slope=sl)                              # 256 -> 256  (H4)
+            with T("dense_b3_0"):
+                l30(C, out=H3, act=True, slope=sl, K=263)                   # 263 -> 256
+            with T("dense_b3_2"):
+                l32(H3, out=B, act=True, slope=sl)                          # 256 -> 256  (H4)
           with T("ksum"):
             X5 = _f32((n_valid, 280), dev)
             sigma = _f32((n_valid,), dev)

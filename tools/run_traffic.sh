@@ -1,6 +1,6 @@
 # HBM traffic per kernel for the bench frame: separate rocprofv3 --pmc passes (kernel-trace only), each under its own timeout
 cd /tmp && export TMPDIR=/tmp
-OUT=$GRAFT_REPO_ROOT/gpurun_out/traffic4; rm -rf $OUT; mkdir -p $OUT
+OUT=$GRAFT_REPO_ROOT/gpurun_out/traffic5; rm -rf $OUT; mkdir -p $OUT
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
   timeout 420 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -o p -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-train-leg --steps 2 --warmup 1 > /tmp/pmc_$c.log 2>&1
