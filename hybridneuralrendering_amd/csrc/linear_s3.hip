@@ -316,6 +316,7 @@ __global__ __launch_bounds__(256, 1) void linear_s3w_kernel(const float *__restr
     struct Prod { bool wr; int k0w; char *dst; int row0, k0l; } pr;       // (row0, k0l): first row / column of this thread's quads of chunk n+2
     unsigned sp[6];
     auto piece = [&](int i) {
+        if (DBG & 64) return;                                       // probe: no producer work at all
         const int q = i >> 1;
         if (!(i & 1)) {
             float x = raw[q].x, y = raw[q].y;
@@ -355,9 +356,9 @@ __global__ __launch_bounds__(256, 1) void linear_s3w_kernel(const float *__restr
 #pragma unroll
         for (int sl = 0; sl < ns; ++sl) {
             const int s = kc * CK + sl, cur = sl & 1;
-            if (sl + 1 < ns) fetch(cur ^ 1, sl + 1);
-            const bf16x8 Ah = __builtin_bit_cast(bf16x8, af[cur][0]), Am = __builtin_bit_cast(bf16x8, af[cur][1]), Al = __builtin_bit_cast(bf16x8, af[cur][2]);
-#define W_(c, pl) __builtin_bit_cast(bf16x8, (s < SR ? wr[s < SR ? s : 0][c][pl] : wf[cur][c][pl]))
+            if (sl + 1 < ns && !(DBG & 128)) fetch(cur ^ 1, sl + 1);
+            const bf16x8 Ah = __builtin_bit_cast(bf16x8, af[(DBG & 128) ? 0 : cur][0]), Am = __builtin_bit_cast(bf16x8, af[(DBG & 128) ? 0 : cur][1]), Al = __builtin_bit_cast(bf16x8, af[(DBG & 128) ? 0 : cur][2]);
+#define W_(c, pl) __builtin_bit_cast(bf16x8, ((s < SR || (DBG & 128)) ? wr[s < SR ? s : 0][c][pl] : wf[cur][c][pl]))
             // smallest terms first; the two column tiles alternate so that no MFMA waits for its predecessor
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, W_(0, 0), acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, W_(1, 0), acc[1], 0, 0, 0);
@@ -553,6 +554,26 @@ extern "C" int hnr_linear_s3(const float *d_A, int lda, const void *d_W3, const 
                         o[10], o[8], (double)o[8] / ((double)o[9] / (wall_khz * 1e3)) / 1e9, o[0] / nq, o[1] / nq, o[2] / nq, o[3] / nq, o[4] / (nq / 2), o[5] / nq);
             }
         } else if (dbgw == 8 && S == 16 && act && !d_R) linear_s3w_kernel<16, 1, 0, 8><<<gridw, 256, ldsw, st>>>(d_A, lda, w3w, d_bias_p, d_C, ldc, M, K, slope, d_R, d_ridx, ldr);
+        else if ((dbgw == 64 || dbgw == 128 || dbgw == 192 || dbgw == 200 || dbgw == 96 || dbgw == 160 || dbgw == 224) && S == 16 && act && !d_R) {
+            static long long *d_dbg2 = nullptr;
+            if (!d_dbg2 && hipMalloc(&d_dbg2, 4 * 16 * sizeof(long long)) != hipSuccess) return HNR_ERR_HIP;
+            const float *dr = reinterpret_cast<const float *>(d_dbg2);
+            switch (dbgw) {
+            case 64: linear_s3w_kernel<16, 1, 0, 64><<<gridw, 256, ldsw, st>>>(d_A, lda, w3w, d_bias_p, d_C, ldc, M, K, slope, d_R, d_ridx, ldr); break;
+            case 128: linear_s3w_kernel<16, 1, 0, 128><<<gridw, 256, ldsw, st>>>(d_A, lda, w3w, d_bias_p, d_C, ldc, M, K, slope, d_R, d_ridx, ldr); break;
+            case 192: linear_s3w_kernel<16, 1, 0, 192><<<gridw, 256, ldsw, st>>>(d_A, lda, w3w, d_bias_p, d_C, ldc, M, K, slope, d_R, d_ridx, ldr); break;
+            case 200: linear_s3w_kernel<16, 1, 0, 200><<<gridw, 256, ldsw, st>>>(d_A, lda, w3w, d_bias_p, d_C, ldc, M, K, slope, d_R, d_ridx, ldr); break;
+            default: {
+                if (dbgw == 96) linear_s3w_kernel<16, 1, 0, 96><<<gridw, 256, ldsw, st>>>(d_A, lda, w3w, d_bias_p, d_C, ldc, M, K, slope, dr, d_ridx, ldr);
+                else if (dbgw == 160) linear_s3w_kernel<16, 1, 0, 160><<<gridw, 256, ldsw, st>>>(d_A, lda, w3w, d_bias_p, d_C, ldc, M, K, slope, dr, d_ridx, ldr);
+                else linear_s3w_kernel<16, 1, 0, 224><<<gridw, 256, ldsw, st>>>(d_A, lda, w3w, d_bias_p, d_C, ldc, M, K, slope, dr, d_ridx, ldr);
+                long long hh[64];
+                if (hipMemcpy(hh, d_dbg2, sizeof(hh), hipMemcpyDeviceToHost) != hipSuccess) return HNR_ERR_HIP;
+                int wall_khz = 0; (void)hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, 0);
+                fprintf(stderr, "[s3w dbg%d] wave 0: %lld chunks, %lld cycles at %.3f GHz, MFMA phase per chunk %.0f\n", dbgw, hh[10], hh[8],
+                        (double)hh[8] / ((double)hh[9] / (wall_khz * 1e3)) / 1e9, (double)hh[3] / (double)hh[10]);
+            } }
+        }
         else
 #endif
         if (S == 4) HNR_S3W_LAUNCH_S(4); else if (S == 16) HNR_S3W_LAUNCH_S(16); else HNR_S3W_LAUNCH_S(17);
