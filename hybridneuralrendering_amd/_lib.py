@@ -78,6 +78,10 @@ SIGNATURES = {
     "hnr_ray_march": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P]),
     "hnr_blur_select": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "hnr_blur_select_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),
+    "hnr_blur_gray_patches": (_I, [_P, _P, _I, _I, _P, _P]),
+    "hnr_blur_gray_patches_bwd": (_I, [_P, _I, _I, _P, _P]),
+    "hnr_blur_apply": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
+    "hnr_blur_apply_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     # backward
     "hnr_composite_bwd": (_I, [_P] * 8 + [_I, _I, _I, _F, _I, _P, _P, _P]),
     "hnr_final_color_bwd": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _I, _P, _I, _P, _P, _P, _P]),

@@ -148,6 +148,147 @@ __global__ __launch_bounds__(256) void blur_select_bwd_kernel(BlurBwdArgs a)
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Learnable blur kernels: /root/reference/models/base_rendering_model.py:827-1020 (`learnable_blur_update_output`,
+// faster_version).  The training shell turns each patch of the rendered batch and of the ground truth into a grey patch
+// (:886-893), a small predictor network (owned by the aggregator, point_aggregators.py:1339-1344) maps the two grey patches
+// to one ks x ks kernel per patch, the kernels are normalised / blended with the identity (:897-911, a few hundred floats:
+// torch), and every patch is convolved with ITS kernel (grouped F.conv2d = cross-correlation, zero padding ks/2) with one of
+// three border rules (:915-923).  Here: one block per patch for the grey patches, for the convolution and for its backward
+// (gradients w.r.t. the rendered colours AND the per-patch kernels, so the predictor trains).
+// ------------------------------------------------------------------------------------------------------------------------
+constexpr int BLUR_MAX_KS = 15;
+
+struct BlurLearnArgs {
+    const float *color, *gt;          // [rays,3]
+    const float *kernels;             // [n_patches, ks, ks]
+    const float *g_out, *g_gray;      // backward inputs
+    int ks, pn, ps, n_patches, patch_major, mode;
+    float *out;                       // [rays,3]
+    float *gray;                      // [n_patches, 2, ps, ps]: channel 0 = ground truth, 1 = render (torch.cat order, :888 / :892)
+    float *g_color, *g_kernels;       // backward outputs
+};
+
+__global__ __launch_bounds__(256) void blur_gray_kernel(BlurLearnArgs a)
+{
+    const int p = blockIdx.x, ps = a.ps;
+    for (int t = threadIdx.x; t < ps * ps; t += blockDim.x) {
+        const int y = t / ps, x = t % ps;
+        const size_t ray = blur_ray(p, y, x, a.pn, ps, a.patch_major);
+        const float *g = a.gt + 3 * ray, *c = a.color + 3 * ray;
+        a.gray[((size_t)p * 2 + 0) * ps * ps + t] = ((g[0] + g[1]) + g[2]) / 3.0f;
+        a.gray[((size_t)p * 2 + 1) * ps * ps + t] = ((c[0] + c[1]) + c[2]) / 3.0f;
+    }
+}
+
+__global__ __launch_bounds__(256) void blur_gray_bwd_kernel(BlurLearnArgs a)
+{
+    const int p = blockIdx.x, ps = a.ps;
+    for (int t = threadIdx.x; t < ps * ps; t += blockDim.x) {
+        const int y = t / ps, x = t % ps;
+        const size_t ray = blur_ray(p, y, x, a.pn, ps, a.patch_major);
+        const float g = a.g_gray[((size_t)p * 2 + 1) * ps * ps + t] / 3.0f;
+        a.g_color[3 * ray + 0] = g; a.g_color[3 * ray + 1] = g; a.g_color[3 * ray + 2] = g;
+    }
+}
+
+// mode 0: out = conv / (mask + 1e-10); mode 1 / 2: out = conv + (1 - mask) * in, mask = the same convolution of a ones patch
+// (mode 2 takes no gradient through the mask)
+template <int BWD>
+__global__ __launch_bounds__(256) void blur_apply_kernel(BlurLearnArgs a)
+{
+    __shared__ float s_in[3][BLUR_MAX_PS][BLUR_MAX_PS], s_g[3][BLUR_MAX_PS][BLUR_MAX_PS], s_conv[3][BLUR_MAX_PS][BLUR_MAX_PS];
+    __shared__ float s_msk[BLUR_MAX_PS][BLUR_MAX_PS], s_dm[BLUR_MAX_PS][BLUR_MAX_PS], s_k[BLUR_MAX_KS * BLUR_MAX_KS];
+    const int p = blockIdx.x, ps = a.ps, ks = a.ks, half = ks / 2;
+    const int npos = 3 * ps * ps;
+    for (int t = threadIdx.x; t < ks * ks; t += blockDim.x) s_k[t] = a.kernels[(size_t)p * ks * ks + t];
+    for (int t = threadIdx.x; t < npos; t += blockDim.x) {
+        const int c = t / (ps * ps), y = (t / ps) % ps, x = t % ps;
+        const size_t ray = blur_ray(p, y, x, a.pn, ps, a.patch_major);
+        s_in[c][y][x] = a.color[3 * ray + c];
+        if (BWD) s_g[c][y][x] = a.g_out[3 * ray + c];
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < npos; t += blockDim.x) {
+        const int c = t / (ps * ps), y = (t / ps) % ps, x = t % ps;
+        float acc = 0.f, msk = 0.f;
+        for (int dy = 0; dy < ks; ++dy) {
+            const int yy = y + dy - half;
+            if (yy < 0 || yy >= ps) continue;
+            for (int dx = 0; dx < ks; ++dx) {
+                const int xx = x + dx - half;
+                if (xx < 0 || xx >= ps) continue;
+                const float w = s_k[dy * ks + dx];
+                acc = fmaf(s_in[c][yy][xx], w, acc);
+                msk += w;
+            }
+        }
+        if (!BWD) {
+            const size_t ray = blur_ray(p, y, x, a.pn, ps, a.patch_major);
+            a.out[3 * ray + c] = a.mode == 0 ? acc / (msk + 1e-10f) : acc + (1.f - msk) * s_in[c][y][x];
+        } else {
+            s_conv[c][y][x] = acc;
+            if (c == 0) s_msk[y][x] = msk;
+        }
+    }
+    if (!BWD) return;
+    __syncthreads();
+    // gradient w.r.t. the convolution result (s_g, in place) and w.r.t. the mask value of every output pixel (s_dm)
+    for (int t = threadIdx.x; t < ps * ps; t += blockDim.x) {
+        const int y = t / ps, x = t % ps;
+        const float m = s_msk[y][x];
+        float dm = 0.f;
+        for (int c = 0; c < 3; ++c) {
+            const float g = s_g[c][y][x];
+            if (a.mode == 0) {
+                const float d = m + 1e-10f;
+                dm -= g * s_conv[c][y][x] / (d * d);
+                s_g[c][y][x] = g / d;
+            } else {
+                dm -= g * s_in[c][y][x];
+            }
+        }
+        s_dm[y][x] = a.mode == 2 ? 0.f : dm;
+    }
+    __syncthreads();
+    // d in[y,x] = sum_{y0,x0} gc[y0,x0] k[y-y0+half, x-x0+half]  (+ (1 - mask[y,x]) g[y,x] for the pass-through term of modes 1 / 2;
+    // s_g still holds g itself in those modes)
+    for (int t = threadIdx.x; t < npos; t += blockDim.x) {
+        const int c = t / (ps * ps), y = (t / ps) % ps, x = t % ps;
+        float acc = 0.f;
+        for (int y0 = 0; y0 < ps; ++y0) {
+            const int dy = y - y0 + half;
+            if (dy < 0 || dy >= ks) continue;
+            for (int x0 = 0; x0 < ps; ++x0) {
+                const int dx = x - x0 + half;
+                if (dx < 0 || dx >= ks) continue;
+                acc = fmaf(s_g[c][y0][x0], s_k[dy * ks + dx], acc);
+            }
+        }
+        if (a.mode != 0) acc += (1.f - s_msk[y][x]) * s_g[c][y][x];
+        const size_t ray = blur_ray(p, y, x, a.pn, ps, a.patch_major);
+        a.g_color[3 * ray + c] = acc;
+    }
+    // d k[dy,dx] = sum over output pixels whose tap (dy,dx) falls inside the patch of (sum_c gc * in[tap] + d mask)
+    for (int t = threadIdx.x; t < ks * ks; t += blockDim.x) {
+        const int dy = t / ks, dx = t % ks;
+        float acc = 0.f;
+        for (int y = 0; y < ps; ++y) {
+            const int yy = y + dy - half;
+            if (yy < 0 || yy >= ps) continue;
+            for (int x = 0; x < ps; ++x) {
+                const int xx = x + dx - half;
+                if (xx < 0 || xx >= ps) continue;
+                float v = s_dm[y][x];
+                for (int c = 0; c < 3; ++c) v = fmaf(s_g[c][y][x], s_in[c][yy][xx], v);
+                acc += v;
+            }
+        }
+        a.g_kernels[(size_t)p * ks * ks + t] = acc;
+    }
+}
+
 }  // namespace hnr
 
 using namespace hnr;
@@ -185,6 +326,65 @@ extern "C" int hnr_blur_select_bwd(const float *d_g_out, const float *d_kernels,
     a.patch_major = patch_num < 0; a.pn = patch_num < 0 ? 1 : patch_num; a.n_patches = patch_num < 0 ? -patch_num : patch_num * patch_num;
     a.g_in = d_g_in;
     blur_select_bwd_kernel<<<a.n_patches, 256, 0, (hipStream_t)stream>>>(a);
+    HNR_LAUNCH_CHECK();
+    return HNR_OK;
+}
+
+static int blur_learn_fill(BlurLearnArgs &a, int kernel_size, int patch_num, int patch_size, int mode, const char *who)
+{
+    if (kernel_size <= 0 || (kernel_size & 1) == 0 || kernel_size > BLUR_MAX_KS || patch_num == 0 || patch_size <= 0 || patch_size > BLUR_MAX_PS ||
+        mode < 0 || mode > 2) {
+        set_error("%s: unsupported sizes (odd kernel size <= %d, patch size <= %d, boundary_mode 0..2)", who, BLUR_MAX_KS, BLUR_MAX_PS);
+        return HNR_ERR_BADARG;
+    }
+    memset(&a, 0, sizeof(a));
+    a.ks = kernel_size; a.ps = patch_size; a.mode = mode;
+    a.patch_major = patch_num < 0; a.pn = patch_num < 0 ? 1 : patch_num; a.n_patches = patch_num < 0 ? -patch_num : patch_num * patch_num;
+    return HNR_OK;
+}
+
+extern "C" int hnr_blur_gray_patches(const float *d_color, const float *d_gt, int patch_num, int patch_size, float *d_gray, void *stream)
+{
+    BlurLearnArgs a;
+    if (blur_learn_fill(a, 1, patch_num, patch_size, 0, "hnr_blur_gray_patches") != HNR_OK) return HNR_ERR_BADARG;
+    if (!d_color || !d_gt || !d_gray) { set_error("hnr_blur_gray_patches: NULL argument"); return HNR_ERR_BADARG; }
+    a.color = d_color; a.gt = d_gt; a.gray = d_gray;
+    blur_gray_kernel<<<a.n_patches, 256, 0, (hipStream_t)stream>>>(a);
+    HNR_LAUNCH_CHECK();
+    return HNR_OK;
+}
+
+extern "C" int hnr_blur_gray_patches_bwd(const float *d_g_gray, int patch_num, int patch_size, float *d_g_color, void *stream)
+{
+    BlurLearnArgs a;
+    if (blur_learn_fill(a, 1, patch_num, patch_size, 0, "hnr_blur_gray_patches_bwd") != HNR_OK) return HNR_ERR_BADARG;
+    if (!d_g_gray || !d_g_color) { set_error("hnr_blur_gray_patches_bwd: NULL argument"); return HNR_ERR_BADARG; }
+    a.g_gray = d_g_gray; a.g_color = d_g_color;
+    blur_gray_bwd_kernel<<<a.n_patches, 256, 0, (hipStream_t)stream>>>(a);
+    HNR_LAUNCH_CHECK();
+    return HNR_OK;
+}
+
+extern "C" int hnr_blur_apply(const float *d_color, const float *d_kernels, int kernel_size, int patch_num, int patch_size,
+                              int boundary_mode, float *d_out, void *stream)
+{
+    BlurLearnArgs a;
+    if (blur_learn_fill(a, kernel_size, patch_num, patch_size, boundary_mode, "hnr_blur_apply") != HNR_OK) return HNR_ERR_BADARG;
+    if (!d_color || !d_kernels || !d_out) { set_error("hnr_blur_apply: NULL argument"); return HNR_ERR_BADARG; }
+    a.color = d_color; a.kernels = d_kernels; a.out = d_out;
+    blur_apply_kernel<0><<<a.n_patches, 256, 0, (hipStream_t)stream>>>(a);
+    HNR_LAUNCH_CHECK();
+    return HNR_OK;
+}
+
+extern "C" int hnr_blur_apply_bwd(const float *d_g_out, const float *d_color, const float *d_kernels, int kernel_size, int patch_num,
+                                  int patch_size, int boundary_mode, float *d_g_color, float *d_g_kernels, void *stream)
+{
+    BlurLearnArgs a;
+    if (blur_learn_fill(a, kernel_size, patch_num, patch_size, boundary_mode, "hnr_blur_apply_bwd") != HNR_OK) return HNR_ERR_BADARG;
+    if (!d_g_out || !d_color || !d_kernels || !d_g_color || !d_g_kernels) { set_error("hnr_blur_apply_bwd: NULL argument"); return HNR_ERR_BADARG; }
+    a.g_out = d_g_out; a.color = d_color; a.kernels = d_kernels; a.g_color = d_g_color; a.g_kernels = d_g_kernels;
+    blur_apply_kernel<1><<<a.n_patches, 256, 0, (hipStream_t)stream>>>(a);
     HNR_LAUNCH_CHECK();
     return HNR_OK;
 }

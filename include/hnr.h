@@ -415,6 +415,20 @@ int hnr_blur_select(const float *d_color, const float *d_gt, const float *d_kern
 int hnr_blur_select_bwd(const float *d_g_out, const float *d_kernels, const int32_t *d_select, int n_kernels, int kernel_size,
                         int patch_num, int patch_size, float *d_g_in, void *stream);
 
+/* "Next" row, learnable blur kernels: models/base_rendering_model.py:827-1020 (`learnable_blur_update_output`,
+ * faster_version; called at mvs_points_volumetric_model.py:143-144 when the aggregator returns a blur predictor).
+ *   hnr_blur_gray_patches      d_gray [n_patches, 2, ps, ps]: channel 0 = grey ground-truth patch, 1 = grey rendered patch (:886-893),
+ *                              the predictor's input; _bwd returns the gradient w.r.t. the rendered colours.
+ *   hnr_blur_apply             every patch convolved with ITS kernel d_kernels[patch] (grouped F.conv2d, zero padding ks/2) under
+ *                              opt.boundary_mode 0 / 1 / 2 (:915-923); _bwd gives the gradients w.r.t. the colours and the kernels.
+ * Ray layout and the patch_num < 0 (patch-major) convention as for hnr_blur_select.  kernel_size odd, <= 15; patch_size <= 16. */
+int hnr_blur_gray_patches(const float *d_color, const float *d_gt, int patch_num, int patch_size, float *d_gray, void *stream);
+int hnr_blur_gray_patches_bwd(const float *d_g_gray, int patch_num, int patch_size, float *d_g_color, void *stream);
+int hnr_blur_apply(const float *d_color, const float *d_kernels, int kernel_size, int patch_num, int patch_size, int boundary_mode,
+                   float *d_out, void *stream);
+int hnr_blur_apply_bwd(const float *d_g_out, const float *d_color, const float *d_kernels, int kernel_size, int patch_num, int patch_size,
+                       int boundary_mode, float *d_g_color, float *d_g_kernels, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

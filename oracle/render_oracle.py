@@ -352,3 +352,37 @@ def blur_update_output(color, gt, kernels, patch_num, patch_size):
     best = b[torch.arange(pn * pn), :, sel]                            # [P,3,ps,ps]
     out = best.reshape(pn, pn, 3, ps, ps).permute(2, 0, 3, 1, 4).reshape(3, S, S).permute(1, 2, 0).reshape(1, S * S, 3)
     return out, sel
+
+
+def learnable_blur_update_output(color, gt, blur_predictor, patch_num, patch_size, kernel_size, kernel_norm, kernel_mode, boundary_mode, kernel_conv):
+    """models/base_rendering_model.py:827-1020 (faster_version).  color, gt [1, S*S, 3]; returns (new colours, kernels [N,1,ks,ks])."""
+    pn, ps, ks = patch_num, patch_size, kernel_size
+    S, N = pn * ps, pn * pn
+    to_patches = lambda t: t.reshape(1, S, S, 3).permute(0, 3, 1, 2)[0].reshape(3, pn, ps, pn, ps).permute(1, 3, 0, 2, 4).reshape(N, 3, ps, ps)
+    cp, gp = to_patches(color), to_patches(gt)
+    if kernel_conv:                                                                    # :886-889
+        pred = blur_predictor[1](blur_predictor[0](torch.cat((gp.mean(dim=1, keepdim=True), cp.mean(dim=1, keepdim=True)), dim=1)).view(N, -1))
+    else:                                                                              # :891-893
+        pred = blur_predictor(torch.cat((gp.mean(dim=1).view(N, -1), cp.mean(dim=1).view(N, -1)), dim=-1))
+    if kernel_norm == 0:                                                               # :897-901
+        k = pred[:, 0:ks * ks].view(N, 1, ks, ks)
+        k = k / k.sum(dim=(2, 3), keepdim=True)
+    else:
+        k = F.softmax(pred[:, 0:ks * ks], dim=-1).view(N, 1, ks, ks)
+    if kernel_mode == 4:                                                               # :906-910
+        w = pred[:, -1][..., None, None, None]
+        ident = torch.zeros_like(k)
+        ident[:, :, ks // 2, ks // 2] = 1.0
+        k = w * k + (1 - w) * ident
+        k = k / k.sum(dim=(2, 3), keepdim=True)
+    x = cp.permute(1, 0, 2, 3)                                                         # [3, N, ps, ps], groups = N
+    ones = torch.ones_like(x)
+    if boundary_mode == 0:                                                             # :915-923
+        b = F.conv2d(x, k, padding=ks // 2, groups=N) / (F.conv2d(ones, k, padding=ks // 2, groups=N) + 1e-10)
+    elif boundary_mode == 1:
+        b = F.conv2d(x, k, padding=ks // 2, groups=N) + (1 - F.conv2d(ones, k, padding=ks // 2, groups=N)) * x
+    else:
+        b = F.conv2d(x, k, padding=ks // 2, groups=N) + (1 - F.conv2d(ones, k.clone().detach(), padding=ks // 2, groups=N)) * x
+    b = b.permute(1, 0, 2, 3)                                                          # [N, 3, ps, ps]
+    out = b.reshape(pn, pn, 3, ps, ps).permute(2, 0, 3, 1, 4).reshape(3, S, S).permute(1, 2, 0).reshape(1, S * S, 3)
+    return out, k

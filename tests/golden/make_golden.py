@@ -418,6 +418,52 @@ def gen_blur(ref):
     print("blur_select.npz: %d of %d patches replaced by a blurred candidate" % (changed, pn * pn))
 
 
+
+def gen_blur_learn(ref):
+    """BaseRenderingModel.learnable_blur_update_output (models/base_rendering_model.py:827-1020, faster_version) on a 7x7 grid of
+    8x8 patches: the shipped *_learnable.sh setting (MLP predictor, kernel size 9, mode 4, boundary_mode 1) and a second case
+    (conv predictor, softmax norm, mode 0, boundary_mode 0).  Stored: inputs, the predictor's state_dict, the new colours and the
+    gradients of a random linear functional w.r.t. the colours and every predictor parameter."""
+    import models.base_rendering_model as brm
+    import torch.nn as nn
+    rng = np.random.default_rng(47)
+    pn, ps, ks = 7, 8, 9
+    S, N = pn * ps, pn * pn
+    out = {}
+    for tag, conv, norm, mode, bmode in (("a", 0, 0, 4, 1), ("b", 1, 1, 0, 0), ("c", 0, 0, 4, 2)):
+        torch.manual_seed(100 + ord(tag))
+        act = lambda: nn.LeakyReLU(inplace=True)
+        n_in, n_out = 2 * ps * ps, ks * ks + (1 if mode in (2, 4) else 0)
+        blocks = []
+        if conv:                                               # point_aggregators.py:721-733
+            blocks.append(nn.Sequential(nn.Conv2d(2, 4, 3), act(), nn.Conv2d(4, 4, 1), act(), nn.Conv2d(4, 8, 3), act(), nn.Conv2d(8, 8, 1), act()))
+            n_in = 8 * (ps - 4) * (ps - 4)
+        blocks.append(nn.Sequential(nn.Linear(n_in, 128), act(), nn.Linear(128, 128), act(), nn.Linear(128, 128), act(), nn.Linear(128, n_out),
+                                    nn.Sigmoid()))                # :738-747
+        predictor = blocks if conv else blocks[0]
+        color = rng.uniform(0, 1, size=(1, S * S, 3)).astype(np.float32)
+        gt = np.clip(color + 0.1 * rng.normal(size=color.shape), 0, 1).astype(np.float32)
+        col = torch.from_numpy(color).clone().requires_grad_(True)
+        opt = SimpleNamespace(learnable_blur_kernel_size=ks, learnable_blur_kernel_conv=conv, learnable_blur_kernel_norm=norm,
+                              learnable_blur_kernel_mode=mode, boundary_mode=bmode)
+        shell = SimpleNamespace(dilation_PatchNum=pn, dilation_PatchSize=ps, gt_image=torch.from_numpy(gt), output={"coarse_raycolor": col},
+                                opt=opt, xv_patches=[], yv_patches=[])
+        brm.BaseRenderingModel.learnable_blur_update_output(shell, predictor)
+        res = shell.output["coarse_raycolor"]
+        wgt = torch.from_numpy(rng.normal(size=res.shape).astype(np.float32))
+        (res * wgt).sum().backward()
+        out[tag + "_cfg"] = np.array([pn, ps, ks, conv, norm, mode, bmode])
+        out[tag + "_color"], out[tag + "_gt"], out[tag + "_out"] = color, gt, res.detach().numpy()
+        out[tag + "_upstream"], out[tag + "_grad_color"] = wgt.numpy(), col.grad.numpy()
+        for bi, blk in enumerate(blocks):
+            for k, v in blk.state_dict().items():
+                out["%s_w%d.%s" % (tag, bi, k)] = v.numpy()
+            for k, v in blk.named_parameters():
+                out["%s_g%d.%s" % (tag, bi, k)] = v.grad.numpy()
+        print("blur_learn case %s: max |out - color| %.3f" % (tag, float(np.abs(res.detach().numpy() - color).max())))
+    np.savez_compressed(os.path.join(HERE, "blur_learn.npz"), **out)
+
+
 def main():
     ref = import_reference()
     gen_hparams(ref)
@@ -428,6 +474,7 @@ def main():
     gen_render(ref, "scannet_small_prob", "scene0241", 12000, 11, 64, 48, 600, opt_over=dict(agg_axis_weight=None, prob=1), size=(1.0, 0.8, 0.6))
     gen_param_keys(ref)
     gen_blur(ref)
+    gen_blur_learn(ref)
     gen_train(ref, "scannet_small", "scene0241", 12000, 11, 64, 48, 28,
               opt_over=dict(agg_axis_weight=None, dilation_setup="7_4_1_8"), size=(1.0, 0.8, 0.6))
     # use_nearest = 0 (scene241.sh): image branch off; a small fixture (subset of the weight gradients, names of all)

@@ -52,3 +52,26 @@ def torch_inputs(d, device="cpu"):
         bg_color=t(d["bg_color"])[None], c2w_nearest=t(d["c2w_nearest"])[None],
         campos_nearest=t(d["c2w_nearest"][:, :3, 3])[None], intrinsic_nearest=t(d["intrinsic"])[None],
         images_nearest=t(d["images_nearest"])[None])
+
+
+def blur_learn_case(tag, device="cpu"):
+    """One case of tests/golden/blur_learn.npz: (cfg dict, color, gt, upstream, predictor [module or [conv, mlp]], expected dict)."""
+    import numpy as np
+    import torch
+    import torch.nn as nn
+    z = np.load(os.path.join(GOLD, "blur_learn.npz"))
+    pn, ps, ks, conv, norm, mode, bmode = (int(v) for v in z[tag + "_cfg"])
+    act = lambda: nn.LeakyReLU(inplace=True)
+    n_in, n_out = 2 * ps * ps, ks * ks + (1 if mode in (2, 4) else 0)
+    blocks = []
+    if conv:
+        blocks.append(nn.Sequential(nn.Conv2d(2, 4, 3), act(), nn.Conv2d(4, 4, 1), act(), nn.Conv2d(4, 8, 3), act(), nn.Conv2d(8, 8, 1), act()))
+        n_in = 8 * (ps - 4) * (ps - 4)
+    blocks.append(nn.Sequential(nn.Linear(n_in, 128), act(), nn.Linear(128, 128), act(), nn.Linear(128, 128), act(), nn.Linear(128, n_out), nn.Sigmoid()))
+    for bi, blk in enumerate(blocks):
+        blk.load_state_dict({k: torch.from_numpy(z["%s_w%d.%s" % (tag, bi, k)]) for k in blk.state_dict()})
+        blk.to(device)
+    t = lambda k: torch.from_numpy(z[tag + "_" + k]).to(device)
+    cfg = dict(pn=pn, ps=ps, ks=ks, conv=conv, norm=norm, mode=mode, bmode=bmode)
+    grads = {"%d.%s" % (bi, k): z["%s_g%d.%s" % (tag, bi, k)] for bi, blk in enumerate(blocks) for k, _ in blk.named_parameters()}
+    return cfg, t("color"), t("gt"), t("upstream"), (blocks if conv else blocks[0]), blocks, dict(out=z[tag + "_out"], grad_color=z[tag + "_grad_color"], grads=grads)

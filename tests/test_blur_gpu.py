@@ -64,3 +64,47 @@ def test_blur_select_patch_major_layout_equals_grid_layout():
         assert torch.equal(part.detach(), full[:, rays]) and torch.equal(sel, sel_full[ids.cuda()])
         part.sum().backward()
         assert torch.isfinite(c.grad).all()
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_learnable_blur_matches_reference_golden(tag):
+    """learnable_blur_update_output (HIP grey patches + grouped per-patch convolution with its border rule, forward and backward)
+    vs the imported reference method: new colours to 2e-6, gradients w.r.t. the colours and every predictor parameter."""
+    from types import SimpleNamespace
+    from tests.golden_io import blur_learn_case
+    from hybridneuralrendering_amd.blur import learnable_blur_update_output
+    cfg, color, gt, up, predictor, blocks, exp = blur_learn_case(tag, device="cuda")
+    opt = SimpleNamespace(learnable_blur_kernel_size=cfg["ks"], learnable_blur_kernel_conv=cfg["conv"], learnable_blur_kernel_norm=cfg["norm"],
+                          learnable_blur_kernel_mode=cfg["mode"], boundary_mode=cfg["bmode"])
+    col = color.clone().requires_grad_(True)
+    out = learnable_blur_update_output(col, gt, predictor, opt, cfg["pn"], cfg["ps"])
+    (out * up).sum().backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), exp["out"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(col.grad.cpu().numpy(), exp["grad_color"], rtol=0, atol=5e-6)
+    for bi, blk in enumerate(blocks):
+        for k, v in blk.named_parameters():
+            g = exp["grads"]["%d.%s" % (bi, k)]
+            np.testing.assert_allclose(v.grad.cpu().numpy(), g, rtol=0, atol=2e-5 * max(1.0, float(np.abs(g).max())))
+
+
+def test_learnable_blur_patch_major_equals_grid_and_checks_arguments():
+    from types import SimpleNamespace
+    from tests.golden_io import blur_learn_case
+    from hybridneuralrendering_amd.blur import learnable_blur_update_output
+    from hybridneuralrendering_amd.parallel import shard_patches
+    from hybridneuralrendering_amd._lib import HnrError
+    cfg, color, gt, up, predictor, blocks, exp = blur_learn_case("a", device="cuda")
+    opt = SimpleNamespace(learnable_blur_kernel_size=cfg["ks"], learnable_blur_kernel_conv=0, learnable_blur_kernel_norm=0,
+                          learnable_blur_kernel_mode=4, boundary_mode=1)
+    full = learnable_blur_update_output(color, gt, predictor, opt, cfg["pn"], cfg["ps"])
+    for rank in range(2):
+        ids, rays = shard_patches(cfg["pn"], cfg["ps"], 2, rank)
+        rays = rays.cuda()
+        part = learnable_blur_update_output(color[:, rays], gt[:, rays], predictor, opt, ids.numel(), cfg["ps"], layout="patch_major")
+        assert torch.allclose(part, full[:, rays], rtol=0, atol=1e-6)
+    opt.boundary_mode = 3
+    with pytest.raises(HnrError):
+        learnable_blur_update_output(color, gt, predictor, opt, cfg["pn"], cfg["ps"])
+    opt.boundary_mode, opt.learnable_blur_kernel_mode = 1, 2
+    with pytest.raises(HnrError):
+        learnable_blur_update_output(color, gt, predictor, opt, cfg["pn"], cfg["ps"])

@@ -174,3 +174,21 @@ def test_blur_select_oracle_matches_reference():
     (out * torch.from_numpy(z["upstream"])).sum().backward()
     np.testing.assert_allclose(col.grad.numpy(), z["grad_color"], rtol=0, atol=1e-6)
     assert len(set(sel.tolist())) >= 6                                # several different candidates win in the fixture
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_oracle_learnable_blur_matches_reference_golden(tag):
+    """oracle.render_oracle.learnable_blur_update_output vs the imported reference method (tests/golden/blur_learn.npz):
+    new colours, gradient w.r.t. the colours and w.r.t. every predictor parameter."""
+    from tests.golden_io import blur_learn_case
+    from oracle import render_oracle as ro
+    cfg, color, gt, up, predictor, blocks, exp = blur_learn_case(tag)
+    col = color.clone().requires_grad_(True)
+    out, _ = ro.learnable_blur_update_output(col, gt, predictor, cfg["pn"], cfg["ps"], cfg["ks"], cfg["norm"], cfg["mode"], cfg["bmode"], cfg["conv"])
+    (out * up).sum().backward()
+    np.testing.assert_allclose(out.detach().numpy(), exp["out"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(col.grad.numpy(), exp["grad_color"], rtol=0, atol=5e-6)
+    for bi, blk in enumerate(blocks):
+        for k, v in blk.named_parameters():
+            g = exp["grads"]["%d.%s" % (bi, k)]
+            np.testing.assert_allclose(v.grad.numpy(), g, rtol=0, atol=2e-5 * max(1.0, float(np.abs(g).max())))
