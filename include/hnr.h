@@ -429,6 +429,17 @@ int hnr_blur_apply(const float *d_color, const float *d_kernels, int kernel_size
 int hnr_blur_apply_bwd(const float *d_g_out, const float *d_color, const float *d_kernels, int kernel_size, int patch_num, int patch_size,
                        int boundary_mode, float *d_g_color, float *d_g_kernels, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * "Next" row: voxel down-sampling of the initial point cloud, models/mvs/mvs_utils.py:537-563
+ * (`construct_vox_points_closest`, called at run/train_ft.py:164 and :725; needs torch_scatter in the reference).
+ *   cell = floor((xyz - space_min) / vox_size)  (fp32 subtract, fp32 divide);  voxels in the lexicographic order of torch.unique(dim=0);
+ *   d_centroid [V,3] per-voxel mean (sequential fp32 sum in point-id order), d_grid_idx [V,3] the cells, d_min_idx [V] the point
+ *   closest to its voxel's centroid (first one on ties), d_inverse [n] voxel of every point (may be NULL), d_count[0] = V.
+ * Output arrays are sized for n voxels.  space_min: 3 host floats.  Synchronises the stream (it reports out-of-range points). */
+int64_t hnr_voxel_downsample_scratch_bytes(int64_t n);
+int hnr_voxel_downsample(const float *d_xyz, int n, const float *space_min, float vox_size, float *d_centroid, int32_t *d_grid_idx,
+                         int32_t *d_min_idx, int32_t *d_inverse, int64_t *d_count, void *d_scratch, int64_t scratch_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

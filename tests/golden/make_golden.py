@@ -464,6 +464,52 @@ def gen_blur_learn(ref):
     np.savez_compressed(os.path.join(HERE, "blur_learn.npz"), **out)
 
 
+
+def gen_voxel(ref):
+    """models/mvs/mvs_utils.py:537-563 construct_vox_points_closest on two seeded clouds.  torch_scatter is absent from this image:
+    its two calls get stand-ins (scatter_mean = index_add_ / count in point order, scatter_min = first minimum per voxel); bounds,
+    cell arithmetic, torch.unique order and the residual norm are the reference's own code."""
+    import sys, types
+    def scatter_mean(src, index, dim=0):
+        n = int(index.max()) + 1
+        out = torch.zeros((n,) + src.shape[1:], dtype=src.dtype).index_add_(0, index, src)
+        cnt = torch.zeros((n,), dtype=src.dtype).index_add_(0, index, torch.ones_like(index, dtype=src.dtype))
+        return out / cnt[:, None]
+    def scatter_min(src, index, dim=0):
+        n = int(index.max()) + 1
+        best = torch.full((n,), float("inf"), dtype=src.dtype)
+        arg = torch.full((n,), -1, dtype=torch.long)
+        for i in range(src.shape[0]):
+            v = int(index[i])
+            if src[i] < best[v]:
+                best[v], arg[v] = src[i], i
+        return best, arg
+    sys.modules["torch_scatter"] = types.ModuleType("torch_scatter")
+    sys.modules["torch_scatter"].__dict__.update(scatter_mean=scatter_mean, scatter_min=scatter_min, segment_coo=None)
+    for name in ("matplotlib", "matplotlib.pyplot"):
+        if name not in sys.modules:
+            try:
+                __import__(name)
+            except Exception:
+                sys.modules[name] = types.ModuleType(name)
+    import importlib
+    ku = types.ModuleType("kornia.utils"); ku.create_meshgrid = None
+    ws = types.ModuleType("warmup_scheduler"); ws.GradualWarmupScheduler = None; sys.modules["warmup_scheduler"] = ws
+    sys.modules["kornia"].utils = ku; sys.modules["kornia.utils"] = ku; sys.modules["kornia"].__path__ = []
+    sys.modules["cv2"].__dict__.setdefault("COLORMAP_JET", 2)          # a default argument of an unrelated helper (mvs_utils.py:29)
+    mu = importlib.import_module("models.mvs.mvs_utils")
+    rng = np.random.default_rng(53)
+    out = {}
+    for tag, n, res in (("a", 20000, 40), ("b", 5000, 100.0 / 1.5)):
+        base = rng.uniform(-1, 1, size=(n // 4, 3)) * np.array([2.0, 1.5, 0.7])
+        xyz = (np.repeat(base, 4, axis=0) + 0.01 * rng.normal(size=(n, 3))).astype(np.float32)       # clusters: several points per voxel
+        cen, grid, midx = mu.construct_vox_points_closest(torch.from_numpy(xyz), res)
+        out[tag + "_xyz"], out[tag + "_res"] = xyz, np.array([res], np.float64)
+        out[tag + "_centroid"], out[tag + "_grid"], out[tag + "_min_idx"] = cen.numpy(), grid.numpy(), midx.numpy()
+        print("voxel_down case %s: %d points -> %d voxels" % (tag, n, grid.shape[0]))
+    np.savez_compressed(os.path.join(HERE, "voxel_down.npz"), **out)
+
+
 def main():
     ref = import_reference()
     gen_hparams(ref)
@@ -475,6 +521,7 @@ def main():
     gen_param_keys(ref)
     gen_blur(ref)
     gen_blur_learn(ref)
+    gen_voxel(ref)
     gen_train(ref, "scannet_small", "scene0241", 12000, 11, 64, 48, 28,
               opt_over=dict(agg_axis_weight=None, dilation_setup="7_4_1_8"), size=(1.0, 0.8, 0.6))
     # use_nearest = 0 (scene241.sh): image branch off; a small fixture (subset of the weight gradients, names of all)
