@@ -264,6 +264,23 @@ def test_c_abi_rejects_bad_arguments_without_touching_the_gpu():
     assert L.hnr_blur_select(one, one, one, 40, 9, 7, 8, one, one, null) == bad                                               # too many kernels
     assert L.hnr_blur_select(one, one, one, 12, 8, 7, 8, one, one, null) == bad                                               # even kernel size
     assert L.hnr_segment_sum_rows(one, 48, null, 0, one, one, 10, 46, one, 48, null) == bad                                   # n_cols % 4
+    # split-bf16 dense layer: N must be 256, strides multiples of 4, addend needs its index
+    assert L.hnr_linear_s3_packed_bytes(128, 256) == 8 * 49152 and L.hnr_linear_s3_packed_bytes(300, 256) == -1
+    assert L.hnr_linear_s3_pack(one, null, 300, 256, one, one, null) == bad
+    assert L.hnr_linear_s3(one, 256, one, one, null, null, 0, one, 256, 10, 128, 256, 1, 0.01, null) == bad                    # N != 256
+    assert b"N must be 256" in L.hnr_last_error()
+    assert L.hnr_linear_s3(one, 254, one, one, null, null, 0, one, 256, 10, 256, 250, 1, 0.01, null) == bad                    # lda % 4
+    assert L.hnr_linear_s3(one, 256, one, one, one, null, 256, one, 256, 10, 256, 256, 1, 0.01, null) == bad                   # addend without index
+    assert L.hnr_linear_s3(one, 256, one, one, null, null, 0, one, 258, 10, 256, 256, 1, 0.01, null) == bad                    # ldc % 4
+    assert L.hnr_linear_s3(null, 256, one, one, null, null, 0, one, 256, 0, 256, 256, 1, 0.01, null) == 0                      # M == 0
+    # learnable blur / voxel down-sampling
+    assert L.hnr_blur_apply(one, one, 8, 7, 8, 1, one, null) == bad                                                           # even kernel size
+    assert L.hnr_blur_apply(one, one, 9, 7, 8, 3, one, null) == bad                                                           # boundary_mode 3
+    assert L.hnr_blur_apply_bwd(one, one, one, 9, 7, 32, 1, one, one, null) == bad                                            # patch size > 16
+    assert L.hnr_blur_gray_patches(one, null, 7, 8, one, null) == bad
+    assert L.hnr_voxel_downsample_scratch_bytes(0) == 256
+    assert L.hnr_voxel_downsample(one, 10, None, ctypes.c_float(0.1), one, one, one, null, one, one, 1 << 20, null) == bad     # no space_min
+    assert L.hnr_voxel_downsample(one, 10, (ctypes.c_float * 3)(0, 0, 0), ctypes.c_float(0.0), one, one, one, null, one, one, 1 << 20, null) == bad
     assert L.hnr_query_work_elems(285200, 24) > 285200 * 24
     assert L.hnr_image_features_scratch_elems(4, 480, 640) == 2 * 4 * (6 * 240 * 320 + 12 * 120 * 160 + 24 * 60 * 80)
 
