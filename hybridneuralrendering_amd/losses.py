@@ -1,0 +1,49 @@
+"""The loss terms of the shipped training configurations on the device (SURVEY 8f "next" row 2, second half).
+
+Mirror of the enabled part of BaseRenderingModel.compute_losses (models/base_rendering_model.py:1060-1245; items from
+dev_scripts/w_scannet_etf/scene241.sh:146-151): masked colour MSE on `coarse_raycolor` + zero-one regulariser on
+`conf_coefficient`, value and both gradients from two small HIP kernels instead of masked_select copies and an autograd graph.
+"""
+import torch
+
+from . import _lib
+from ._lib import HnrError
+
+
+class _ShippedLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, color, conf, gt, ray_mask, zero_epsilon, w_color, w_zero_one, frame_weight):
+        L = _lib.lib()
+        c = _lib.require_gpu(color.detach(), "coarse_raycolor", torch.float32).reshape(-1, 3)
+        g = _lib.require_gpu(gt, "gt_image", torch.float32).reshape(-1, 3)
+        m = _lib.require_gpu(ray_mask, "ray_mask").reshape(-1)
+        if m.dtype != torch.int8:
+            m = m.to(torch.int8)
+        x = _lib.require_gpu(conf.detach(), "conf_coefficient", torch.float32).reshape(-1)
+        if g.shape[0] != c.shape[0] or m.shape[0] != c.shape[0]:
+            raise HnrError("shipped_loss: coarse_raycolor, gt_image and ray_mask disagree on the number of rays")
+        dev = c.device
+        out = torch.empty((4,), dtype=torch.float32, device=dev)
+        g_c, g_x = torch.empty_like(c), torch.empty_like(x)
+        scratch = torch.empty((int(L.hnr_shipped_loss_scratch_bytes()),), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.hnr_shipped_loss(_lib.ptr(c), _lib.ptr(g), _lib.ptr(m), c.shape[0], _lib.ptr(x), x.shape[0], float(zero_epsilon),
+                                          float(w_color), float(w_zero_one), float(frame_weight), _lib.ptr(out), _lib.ptr(g_c), _lib.ptr(g_x),
+                                          _lib.ptr(scratch), _lib.stream()), "hnr_shipped_loss")
+        ctx.save_for_backward(g_c, g_x)
+        ctx.shapes = (color.shape, conf.shape)
+        ctx.mark_non_differentiable(out)
+        return out[0].clone(), out
+
+    @staticmethod
+    def backward(ctx, g_total, _g_out):
+        g_c, g_x = ctx.saved_tensors
+        cs, xs = ctx.shapes
+        return (g_c * g_total).reshape(cs), (g_x * g_total).reshape(xs), None, None, None, None, None, None
+
+
+def shipped_loss(coarse_raycolor, conf_coefficient, gt_image, ray_mask, zero_epsilon, w_color=1.0, w_zero_one=1e-4, frame_weight=None):
+    """Returns (loss_total, parts) with parts = tensor {total, colour MSE, zero-one mean, valid rays}; loss_total is differentiable
+    w.r.t. coarse_raycolor [.., R, 3] and conf_coefficient (any shape).  frame_weight: the dataset item's scalar (or None)."""
+    fw = 1.0 if frame_weight is None else float(torch.as_tensor(frame_weight).reshape(-1)[0])
+    return _ShippedLoss.apply(coarse_raycolor, conf_coefficient, gt_image, ray_mask, zero_epsilon, w_color, w_zero_one, fw)

@@ -430,6 +430,18 @@ int hnr_blur_apply_bwd(const float *d_g_out, const float *d_color, const float *
                        int boundary_mode, float *d_g_color, float *d_g_kernels, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * "Next" row (second half): the loss terms of the shipped training configurations, value + gradients.
+ * BaseRenderingModel.compute_losses, models/base_rendering_model.py: colour item `ray_masked_coarse_raycolor` (:1113-1118:
+ * MSE over the rays with ray_mask > 0, 0 when none; `+ 1e-6` per item :1198; `* frame_weight` :1204-1205) and the zero-one
+ * regulariser on conf_coefficient (:1228-1240: mean(log v + log(1 - v)), v = clamp(x, eps, 1 - eps)).
+ *   d_out4 = {total, colour MSE, zero-one mean, number of valid rays};  total = (mse * w_color + 1e-6) * frame_weight + zo * w_zero_one
+ *   d_g_color [R,3], d_g_conf [n_conf]: d total / d input (both NULL = value only).  d_scratch: hnr_shipped_loss_scratch_bytes(). */
+int64_t hnr_shipped_loss_scratch_bytes(void);
+int hnr_shipped_loss(const float *d_color, const float *d_gt, const int8_t *d_ray_mask, int R, const float *d_conf, int64_t n_conf,
+                     float zero_epsilon, float w_color, float w_zero_one, float frame_weight, float *d_out4, float *d_g_color,
+                     float *d_g_conf, void *d_scratch, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
  * "Next" row: voxel down-sampling of the initial point cloud, models/mvs/mvs_utils.py:537-563
  * (`construct_vox_points_closest`, called at run/train_ft.py:164 and :725; needs torch_scatter in the reference).
  *   cell = floor((xyz - space_min) / vox_size)  (fp32 subtract, fp32 divide);  voxels in the lexicographic order of torch.unique(dim=0);

@@ -279,6 +279,8 @@ def test_c_abi_rejects_bad_arguments_without_touching_the_gpu():
     assert L.hnr_blur_apply_bwd(one, one, one, 9, 7, 32, 1, one, one, null) == bad                                            # patch size > 16
     assert L.hnr_blur_gray_patches(one, null, 7, 8, one, null) == bad
     assert L.hnr_voxel_downsample_scratch_bytes(0) == 256
+    assert L.hnr_shipped_loss(one, one, one, 10, one, 5, ctypes.c_float(0.7), 1.0, 1e-4, 1.0, one, one, one, one, null) == bad       # zero_epsilon >= 0.5
+    assert L.hnr_shipped_loss(one, one, one, 10, one, 5, ctypes.c_float(1e-3), 1.0, 1e-4, 1.0, null, one, one, one, null) == bad      # no output
     assert L.hnr_voxel_downsample(one, 10, None, ctypes.c_float(0.1), one, one, one, null, one, one, 1 << 20, null) == bad     # no space_min
     assert L.hnr_voxel_downsample(one, 10, (ctypes.c_float * 3)(0, 0, 0), ctypes.c_float(0.0), one, one, one, null, one, one, 1 << 20, null) == bad
     assert L.hnr_query_work_elems(285200, 24) > 285200 * 24
