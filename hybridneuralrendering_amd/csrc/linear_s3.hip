@@ -360,12 +360,14 @@ __global__ __launch_bounds__(256, 1) void linear_s3w_kernel(const float *__restr
             const bf16x8 Ah = __builtin_bit_cast(bf16x8, af[(DBG & 128) ? 0 : cur][0]), Am = __builtin_bit_cast(bf16x8, af[(DBG & 128) ? 0 : cur][1]), Al = __builtin_bit_cast(bf16x8, af[(DBG & 128) ? 0 : cur][2]);
 #define W_(c, pl) __builtin_bit_cast(bf16x8, ((s < SR || (DBG & 128)) ? wr[s < SR ? s : 0][c][pl] : wf[cur][c][pl]))
             // smallest terms first; the two column tiles alternate so that no MFMA waits for its predecessor
+            if (!(DBG & 256)) {                                     // probe: DBG & 256 drops the three 2^-16-level terms (16-bit operands)
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, W_(0, 0), acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, W_(1, 0), acc[1], 0, 0, 0);
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, W_(0, 2), acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, W_(1, 2), acc[1], 0, 0, 0);
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, W_(0, 1), acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, W_(1, 1), acc[1], 0, 0, 0);
+            }
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, W_(0, 0), acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, W_(1, 0), acc[1], 0, 0, 0);
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, W_(0, 1), acc[0], 0, 0, 0);
@@ -553,7 +555,8 @@ extern "C" int hnr_linear_s3(const float *d_A, int lda, const void *d_W3, const 
                 fprintf(stderr, "[s3w dbg32] wave %d: %lld chunks, %lld cycles at %.3f GHz; per chunk: set-up %.0f, (%.0f, %.0f), 96 MFMAs + producer pieces %.0f, epilogue (per tile) %.0f, barrier %.0f\n", w,
                         o[10], o[8], (double)o[8] / ((double)o[9] / (wall_khz * 1e3)) / 1e9, o[0] / nq, o[1] / nq, o[2] / nq, o[3] / nq, o[4] / (nq / 2), o[5] / nq);
             }
-        } else if (dbgw == 8 && S == 16 && act && !d_R) linear_s3w_kernel<16, 1, 0, 8><<<gridw, 256, ldsw, st>>>(d_A, lda, w3w, d_bias_p, d_C, ldc, M, K, slope, d_R, d_ridx, ldr);
+        } else if (dbgw == 256 && S == 16 && act && !d_R) linear_s3w_kernel<16, 1, 0, 256><<<gridw, 256, ldsw, st>>>(d_A, lda, w3w, d_bias_p, d_C, ldc, M, K, slope, d_R, d_ridx, ldr);
+        else if (dbgw == 8 && S == 16 && act && !d_R) linear_s3w_kernel<16, 1, 0, 8><<<gridw, 256, ldsw, st>>>(d_A, lda, w3w, d_bias_p, d_C, ldc, M, K, slope, d_R, d_ridx, ldr);
         else if ((dbgw == 64 || dbgw == 128 || dbgw == 192 || dbgw == 200 || dbgw == 96 || dbgw == 160 || dbgw == 224) && S == 16 && act && !d_R) {
             static long long *d_dbg2 = nullptr;
             if (!d_dbg2 && hipMalloc(&d_dbg2, 4 * 16 * sizeof(long long)) != hipSuccess) return HNR_ERR_HIP;

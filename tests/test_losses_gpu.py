@@ -36,7 +36,8 @@ def test_shipped_loss_matches_oracle(R, frac_valid, fw):
     total, parts = shipped_loss(c1, x1, gt.cuda(), mask.cuda(), eps, 1.0, 1e-4, frame_weight=None if fw is None else torch.tensor([fw]))
     (total * 1.0).backward()
     p = parts.cpu().numpy()
-    assert abs(p[0] - float(ref_total)) <= 2e-6 * max(1.0, abs(float(ref_total)))
+    rt = float(ref_total.detach())
+    assert abs(p[0] - rt) <= 2e-6 * max(1.0, abs(rt))
     assert abs(p[1] - float(lc)) <= 2e-6 * max(1e-3, float(lc)) and abs(p[2] - float(lz)) <= 2e-6 * abs(float(lz))
     assert int(p[3]) == int(mask.sum())
     gc = c0.grad if c0.grad is not None else torch.zeros_like(col)

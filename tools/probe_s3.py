@@ -56,4 +56,8 @@ for name, layer in (("split-bf16", SplitLinear(W, b)), ("fp32-MFMA", PackedLinea
         layer(A, out=out, act=True)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / a.reps
+    if os.environ.get("HNR_S3_DBG") == "256":
+        ref = torch.nn.functional.leaky_relu(A[:200000].double() @ W.double().t() + b.double(), 0.01)
+        mag = A[:200000].abs().double() @ W.abs().double().t() + b.abs().double()
+        print("3-term variant: max |err| / sum|a||w| = %.3e" % ((out[:200000].double() - ref).abs() / mag).max().item())
     print("%s: M=%d 256x256: %.3f ms  = %.1f fp32-equivalent TFLOP/s, %.2f TB/s of A+C" % (name, M, ms, 2.0 * M * 65536 / ms / 1e9, M * 2048 / ms / 1e9), flush=True)
