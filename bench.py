@@ -133,6 +133,7 @@ def train_leg(args, sc, opt, agg, cloud, rnd, cam, dev, steps=5, warmup=2):
     the HIP forward + backward with the shipped loss terms.  Reported beside the headline metric, never part of `value`."""
     from hybridneuralrendering_amd import scenes
     from hybridneuralrendering_amd.train import TrainPath, render_train
+    from hybridneuralrendering_amd.losses import shipped_loss
     old = opt.is_train
     opt.is_train = 1
     try:
@@ -154,9 +155,9 @@ def train_leg(args, sc, opt, agg, cloud, rnd, cam, dev, steps=5, warmup=2):
             out = render_train(path, agg, cloud.xyz, leaves[0], leaves[1], leaves[2], leaves[3], raydir, cam["campos"], cam["camrot"],
                                cam["bg"], sc.near, sc.far, cam["c2w_nearest"], cam["campos_nearest"], cam["intrinsic"], cam["images"])
             if ev: ev[1].record()
-            m = out["ray_mask"] > 0
-            val = torch.clamp(out["conf_coefficient"][m], 1e-3, 1 - 1e-3)
-            loss = torch.nn.functional.mse_loss(out["coarse_raycolor"][m], gt[m]) + 1e-4 * torch.mean(torch.log(val) + torch.log(1 - val))
+            # the shipped loss terms (masked colour MSE + zero-one regulariser on conf_coefficient of the valid rays), value and
+            # gradients on the device (hnr_shipped_loss)
+            loss, _parts = shipped_loss(out["coarse_raycolor"], out["conf_coefficient"][out["ray_mask"] > 0], gt, out["ray_mask"], 1e-3, 1.0, 1e-4)
             loss.backward()
             if ev: ev[2].record()
             return out

@@ -170,9 +170,14 @@ class TrainPath:
                 S.U = int(ucount.item())
                 Tu, S.E = self.agg.point_table(cloud.emb, ids=S.ulist, n_ids=S.U, want_rows=True)
                 S.H1 = pk["b1_dist"].gather_add(S.Xd, Tu, S.row_u, act=True, slope=sl, K=60)
-                pk["b1"][1](S.H1, out=S.X3, act=True, slope=sl)                      # H2 into X3[:, :256]
-                S.H3 = pk["b3"][0](S.X3, act=True, slope=sl, K=263)
-                S.H4 = pk["b3"][1](S.H3, act=True, slope=sl)
+                if getattr(r, "dense", "f32") == "bf16x3":                           # the forward's 256-wide layers as in inference (exactly split bf16 operands)
+                    ps = self.agg.packed_split()
+                    l12, l30, l32 = ps["b1_2"], ps["b3_0"], ps["b3_2"]
+                else:
+                    l12, l30, l32 = pk["b1"][1], pk["b3"][0], pk["b3"][1]
+                l12(S.H1, out=S.X3, act=True, slope=sl)                              # H2 into X3[:, :256]
+                S.H3 = l30(S.X3, act=True, slope=sl, K=263)
+                S.H4 = l32(S.H3, act=True, slope=sl)
                 S.X5, S.sigma = _f32((n_valid, 280), dev), _f32((n_valid,), dev)
                 _lib.check(L.hnr_ksum(p(S.H4), 256, p(S.wagg), p(pk["alpha_w"]), p(pk["alpha_b"]), p(S.vs_item), p(S.vs_off), p(S.vs_cnt),
                                       p(raydir), p(counts), SR, n_valid, p(S.X5), 280, p(S.sigma), st()), "hnr_ksum")
