@@ -278,8 +278,8 @@ def main():
                             fp32_equivalent_tflops=round(alg / (ms_3 * 1e-3) / 1e12, 2),
                             algorithmic_bytes_per_launch=int(n_rows * (256 + 256) * 4),
                             hbm_gbs=round(n_rows * 2048.0 * 3 / (ms_3 * 1e-3) / 1e9, 1),
-                            note="achieved = bf16 MFMA flops issued (6 per fp32 product) / time, against the bf16 dense peak; the matrix pipe is "
-                                 "power-limited with real operand data: tools/mfma_peak_bf16 sustains 1895 TFLOP/s (1.89 GHz) with random and "
+                            note="achieved = bf16 MFMA flops issued (6 per fp32 product) / time, against the bf16 dense peak; with real operand data the matrix pipe "
+                                 "sustains less than the spec peak: tools/mfma_peak_bf16 reaches 1860-1930 TFLOP/s (1.87-1.92 GHz) with random / split-plane and "
                                  "2470 (2.39 GHz) with constant operands on this chip; fp32_equivalent_tflops = 2 M N K / time "
                                  "(the fp32-MFMA kernel it replaces: 119-125, peak 157.3)",
                             neighbour_mlp=dict(ms=round(ms_nb, 3), algorithmic_tflops=round(flops_nb / (ms_nb * 1e-3) / 1e12, 2) if ms_nb > 0 else None,
