@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256, 1) void probe(int iters, float *out, long long
     float vx = (float)threadIdx.x, vy = 1.0001f;
     const size_t stride = (size_t)gridDim.x * 256;
     size_t gi = (size_t)blockIdx.x * 256 + threadIdx.x;
-    float4 ld = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 ld = make_float4(0.f, 0.f, 0.f, 0.f), ld2 = ld;
     const long long c0 = clock64();
     const long long w0 = wall_clock64();
 #pragma unroll 1
@@ -57,16 +57,22 @@ __global__ __launch_bounds__(256, 1) void probe(int iters, float *out, long long
 #pragma unroll
                 for (int v = 0; v < VALU; ++v) { vx = fmaf(vx, vy, 0.5f); vy = vy * 0.99999f + 1e-6f; }
             }
-            if (MEM && (g & 3) == 0) {
+            if (MEM == 1 && (g & 3) == 0) {
                 dst[gi] = ld;                               // the value loaded one round earlier: no wait on the load just issued
                 ld = src[gi];
                 gi += stride; if (gi >= ((size_t)1 << 26)) gi -= ((size_t)1 << 26);
             }
+            // store-only variants, one store instruction per wave per 12 MFMAs (the kernel: 16 per 192), register data, no load
+            if (MEM == 2) { reinterpret_cast<float2 *>(dst)[gi] = make_float2(vx, vy); gi += stride; if (gi >= ((size_t)1 << 26)) gi -= ((size_t)1 << 26); }
+            if (MEM == 3) { dst[gi] = make_float4(vx, vy, vx, vy); gi += stride; if (gi >= ((size_t)1 << 26)) gi -= ((size_t)1 << 26); }
+            if (MEM == 4) { reinterpret_cast<float *>(dst)[gi] = vx; gi += stride; if (gi >= ((size_t)1 << 26)) gi -= ((size_t)1 << 26); }
+            // load-only: one 16-B load per lane per 24 MFMAs (the kernel: 8 per 192), consumed two rounds later
+            if (MEM == 5 && (g & 1) == 0) { vx += ld.x; ld = ld2; ld2 = src[gi]; gi += stride; if (gi >= ((size_t)1 << 26)) gi -= ((size_t)1 << 26); }
         }
     }
     const long long c1 = clock64();
     const long long w1 = wall_clock64();
-    float s = vx + vy + ld.x;
+    float s = vx + vy + ld.x + ld2.y;
     for (int t = 0; t < 2; ++t) for (int r = 0; r < 16; ++r) s += acc[t][r];
     if (s == 12345.678f) out[0] = s;
     if (threadIdx.x == 0 && blockIdx.x == 0) { cyc[0] = c1 - c0; cyc[1] = w1 - w0; }
@@ -104,7 +110,9 @@ int main(int argc, char **argv)
     run<72, 1, 0, 0>("72 B fragments + A fragments from LDS every 12 MFMAs", iters, out, cyc, src, dst, cus, wall_khz);
     run<72, 1, 12, 0>("  + 24 VALU per 12 MFMAs", iters, out, cyc, src, dst, cus, wall_khz);
     run<72, 1, 12, 1>("  + one 16-B load and store per lane per 48 MFMAs", iters, out, cyc, src, dst, cus, wall_khz);
-    run<72, 1, 0, 1>("72 B frags + LDS A + load/store, no VALU", iters, out, cyc, src, dst, cus, wall_khz);
-    run<72, 0, 0, 1>("72 B frags + load/store only", iters, out, cyc, src, dst, cus, wall_khz);
+    run<72, 1, 0, 2>("72 B frags + LDS A + one 8-B store per lane per 12 MFMAs", iters, out, cyc, src, dst, cus, wall_khz);
+    run<72, 1, 0, 3>("72 B frags + LDS A + one 16-B store per lane per 12 MFMAs", iters, out, cyc, src, dst, cus, wall_khz);
+    run<72, 1, 0, 4>("72 B frags + LDS A + one 4-B store per lane per 12 MFMAs", iters, out, cyc, src, dst, cus, wall_khz);
+    run<72, 1, 0, 5>("72 B frags + LDS A + one 16-B load per lane per 24 MFMAs", iters, out, cyc, src, dst, cus, wall_khz);
     return 0;
 }
