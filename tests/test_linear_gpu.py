@@ -136,3 +136,21 @@ def test_split_bf16_rejects_bad_arguments():
         lin(torch.randn(10, 63, device=d))                          # lda not a multiple of 4
     with pytest.raises(HnrError):
         lin(torch.randn(10, 32, device=d))                          # lda < K
+
+
+@pytest.mark.parametrize("spread", [8, 24])
+def test_split_bf16_layer_keeps_fp32_accuracy_over_a_wide_dynamic_range(spread):
+    """Operands whose exponents spread over 2^(-spread) .. 2^(+spread): the three-term split is exact at every scale, so the
+    error stays that of the fp32-MFMA kernel (both ~1e-6 * sum|a w| at worst)."""
+    from hybridneuralrendering_amd.linear import PackedLinear, SplitLinear
+    d = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(spread)
+    M, K = 20000, 256
+    A = torch.randn((M, K), generator=g) * torch.exp2((torch.rand((M, K), generator=g) - 0.5) * 2 * spread)
+    W = torch.randn((256, K), generator=g) / 16 * torch.exp2((torch.rand((256, K), generator=g) - 0.5) * 16)
+    b = torch.zeros(256)
+    ref = A.double() @ W.double().t()
+    mag = A.abs().double() @ W.abs().double().t()
+    e3 = ((SplitLinear(W.to(d), b.to(d))(A.to(d)).cpu().double() - ref).abs() / mag).max().item()
+    e1 = ((PackedLinear(W.to(d), b.to(d))(A.to(d)).cpu().double() - ref).abs() / mag).max().item()
+    assert e3 < 2e-6 and e3 < 1.5 * e1 + 1e-7, (e3, e1)

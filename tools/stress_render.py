@@ -72,16 +72,20 @@ for i in range(n_cases):
         got = {"neural_points.points_embeding": leaves[0].grad, "neural_points.points_conf": leaves[1].grad, "neural_points.points_dir": leaves[2].grad,
                "neural_points.points_color": leaves[3].grad}
         got.update({"aggregator." + k: v.grad for k, v in agg.named_parameters() if v.grad is not None})
-        ge = 0.0
+        ge, worst_key = 0.0, ""
         for k, r in gref.items():
             r = r.numpy()
             if r.size > 1 and np.abs(r).max() > 0:
-                ge = max(ge, float(np.abs(got[k].detach().cpu().numpy().reshape(r.shape) - r).max() / np.abs(r).max()))
+                d = np.abs(got[k].detach().cpu().numpy().reshape(r.shape) - r) / np.abs(r).max()
+                if float(d.max()) > ge:
+                    ge, worst_key = float(d.max()), "%s (%d of %d entries above 1e-3 of max)" % (k, int((d > 1e-3).sum()), d.size)
         worst_grad = max(worst_grad, ge)
         ok = e < 1e-4 and ge < 5e-3
         opt.is_train = 0
     if not ok:
         bad += 1
+        if train:
+            print("    worst gradient: " + worst_key)
     print("case %2d %-9s SR=%2d valid rays %3d  %s  -> %s" % (i, name, opt.SR, int(q["ray_mask"].sum()),
                                                             ("loss rel %.1e grad %.1e" % (e, ge)) if train else ("max|d colour| %.1e" % e), "ok" if ok else "MISMATCH"))
 print("stress_render: %d cases, %d mismatches; worst forward %.1e, worst gradient %.1e of max" % (n_cases, bad, worst_fwd, worst_grad))
