@@ -5,9 +5,15 @@ on the scene0241_01-like synthetic config (BASELINE.json configs[2] / SURVEY.md 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-One "step" = every rank renders one full 620x460 = 285 200-ray frame (its own camera pose; cloud, grid,
-weights and reference-view features replicated and already resident in HBM) and the colours are gathered to
-rank 0 with ONE RCCL gather.  Rank 0 prints ONE JSON line.  value = rays of all ranks / max-over-ranks time.
+One "step" = one full 620x460 = 285 200-ray frame of the FIXED scene0241_01-like ray batch (north_star): with N ranks the
+frame's rays are split into N contiguous scan-line blocks (parallel.shard_bounds), every rank renders its block (cloud,
+grid, weights and reference-view features replicated and already resident in HBM) and the colours are reassembled on rank 0
+with ONE RCCL gather -- strong scaling, value = 285 200 rays / max-over-ranks step time.  `--scaling weak` instead lets every
+rank render a whole frame of its own (value = N x 285 200 / time).
+
+`python bench.py --gpus N` with WORLD_SIZE unset spawns the N ranks itself (child processes, before anything touches the GPU);
+under torch.distributed.run the launcher's RANK / LOCAL_RANK / WORLD_SIZE are used and must agree with --gpus.
+Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -41,7 +47,32 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-leg", action="store_true")
     ap.add_argument("--cpu-sample-rays", type=int, default=2304)
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
+                    help="strong: the N ranks share ONE fixed frame (north_star); weak: one whole frame per rank")
+    ap.add_argument("--dump-colors", default="", help="rank 0 writes the assembled [R,3] colours of the last step to this .npy file")
     return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N child ranks (fresh processes; this parent never touches the GPU
+    and never exec()s), relay rank 0's output, fail if any rank fails."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0]
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0.decode("utf-8", "replace"))
+    sys.stdout.flush()
+    if any(rcs):
+        raise SystemExit("bench.py: rank exit codes %s" % rcs)
 
 
 def build_world(args, dev, rank):
@@ -184,14 +215,21 @@ def train_leg(args, sc, opt, agg, cloud, rnd, cam, dev, steps=5, warmup=2):
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return spawn_ranks(args)              # the parent has not touched the GPU (device_count() / is_available() not called yet)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher set WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     # Rehearsal of the multi-rank control flow on a box with fewer GPUs than ranks (HNR_BENCH_REHEARSAL=1 only: ranks share
     # devices and the collectives run over gloo on host copies -- numbers from such a run mean nothing and say so).
     rehearsal = world > 1 and os.environ.get("HNR_BENCH_REHEARSAL") == "1" and torch.cuda.device_count() < world
+    if world > torch.cuda.device_count() and not rehearsal:
+        raise SystemExit("bench.py: %d ranks but %d GPUs (set HNR_BENCH_REHEARSAL=1 to rehearse the control flow on shared devices)"
+                         % (world, torch.cuda.device_count()))
     if rehearsal:
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
@@ -208,18 +246,41 @@ def main():
     from hybridneuralrendering_amd import parallel
     from hybridneuralrendering_amd._lib import CNT
 
-    sc, opt, agg, cloud, rnd, cam = build_world(args, dev, rank)
+    strong = args.scaling == "strong"
+    # strong: every rank builds the SAME frame (pose 0) and renders its block of rays; weak: rank-specific pose, whole frame
+    sc, opt, agg, cloud, rnd, cam = build_world(args, dev, 0 if strong else rank)
+    R_frame = cam["raydir"].shape[0]
+    lo, hi = parallel.shard_bounds(R_frame, world, rank) if strong else (0, R_frame)
+    if strong and world > 1:
+        cam = dict(cam, raydir=cam["raydir"][lo:hi].contiguous(), rays_np=cam["rays_np"][lo:hi])
     R = cam["raydir"].shape[0]
+    R_job = R_frame if strong else world * R_frame          # rays the whole job renders per step
+    sizes = [parallel.shard_bounds(R_frame, world, r) for r in range(world)] if strong else [(0, R_frame)] * world
+    pad = max(b - a for a, b in sizes)
+    gather_ev = []
 
-    def step(timers=None):
+    def step(timers=None, time_gather=False):
         rnd._fm_key = None          # a new frame has new reference views: their feature pyramid is rebuilt inside every step
         col, out = render_frame(rnd, cloud, cam, sc, args.chunk, timers)
+        frame = col
         if world > 1:
-            # reassemble the N frames on rank 0: ONE gather over xGMI (every rank sends R x 3 floats)
-            c = coll(col)
+            # reassemble the frame (strong) / the N frames (weak) on rank 0: ONE gather over xGMI, equal-size blocks
+            buf = col
+            if col.shape[0] != pad:
+                buf = torch.zeros((pad, 3), dtype=col.dtype, device=col.device)
+                buf[:col.shape[0]] = col
+            c = coll(buf.contiguous())
             outs = [torch.empty_like(c) for _ in range(world)] if rank == 0 else None
+            if time_gather and not rehearsal:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             dist.gather(c, outs, dst=0)
-        return col, out
+            if time_gather and not rehearsal:
+                e1.record()
+                gather_ev.append((e0, e1))
+            if rank == 0:
+                frame = torch.cat([o[:b - a] for o, (a, b) in zip(outs, sizes)], dim=0) if strong else outs[0]
+        return col, out, frame
 
     def barrier():
         if world > 1:
@@ -232,13 +293,15 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        col, out = step(timers)
+        col, out, frame = step(timers, time_gather=True)
     barrier()
     dt = time.perf_counter() - t0
     tmax = coll(torch.tensor([dt], dtype=torch.float64, device=dev))
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
+    if rank == 0 and args.dump_colors:
+        np.save(args.dump_colors, frame.detach().cpu().numpy())
 
     if rank == 0:
         counts = out["counts"].cpu().numpy() if args.chunk <= 0 or args.chunk >= R else None
@@ -326,15 +389,20 @@ def main():
             train = train_leg(args, sc, opt, agg, cloud, rnd, cam, dev)
         res = {
             "metric": "rays/sec (fwd render) scene0241_01 at 1/2/4/8 GPU; PSNR delta vs ref",
-            "value": world * R * args.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "value": R_job * args.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "dense_arithmetic": ("fp32 MFMA (v_mfma_f32_32x32x2_f32)" if getattr(rnd, "dense", "f32") == "f32" else "256-wide per-neighbour layers: fp32 operands split EXACTLY into 3 bf16 terms, 6 bf16 MFMAs per product, fp32 accumulate (fp32-class error, tests/test_linear_gpu.py); all other layers fp32 MFMA"), "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: ranks share GPUs, gloo collectives -- not a measurement)",
-            "config": {"workload": "%s synthetic scene (SURVEY 8d): %d points, %dx%d frame margin %d = %d rays per GPU per step, "
-                                   "SR=%d K=%d P=%d max_o=%d D=%d, 4 reference views %dx%d, hybrid viewmlp forward (query+gather+aggregate+composite)"
+            "config": {"workload": "%s synthetic scene (SURVEY 8d): %d points, %dx%d frame margin %d = %d rays per step (%s), "
+                                   "SR=%d K=%d P=%d max_o=%d D=%d, 4 reference views %dx%d, hybrid viewmlp forward (query+gather+aggregate+composite); "
+                                   "random-init weights with alpha_branch.0 rescaled (weight x30, bias = 30) so that opacities spread over (0,1)"
                                    % ({"scene0241": "scene0241_01-like room", "scene0101": "scene0101_04-like room"}.get(args.scene, args.scene + "-like object"),
-                                      sc.xyz.shape[0], sc.w, sc.h, args.margin, R, opt.SR, opt.K, opt.P, opt.max_o, opt.z_depth_dim, sc.h, sc.w),
-                       "rays_per_gpu": R, "points": int(sc.xyz.shape[0]), "chunk_rays": args.chunk if args.chunk > 0 else R,
-                       "parallelism": "ray-sharded x%d, one RCCL gather" % world},
+                                      sc.xyz.shape[0], sc.w, sc.h, args.margin, R_frame,
+                                      "ONE fixed frame sharded over the ranks" if strong else "one such frame per rank",
+                                      opt.SR, opt.K, opt.P, opt.max_o, opt.z_depth_dim, sc.h, sc.w),
+                       "rays_per_step": R_job, "rays_per_gpu": R, "points": int(sc.xyz.shape[0]), "chunk_rays": args.chunk if args.chunk > 0 else R,
+                       "parallelism": ("one fixed frame ray-sharded x%d (contiguous scan-line blocks), one RCCL gather" if strong else
+                                       "one frame per rank x%d, one RCCL gather") % world},
+            "gather_ms": (round(sum(a.elapsed_time(b) for a, b in gather_ev) / max(len(gather_ev), 1), 4) if gather_ev else None),
             "roofline": roof, "roofline_query": roof_q, "cpu_baseline": cpu,
             "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
             "amortised_ms": amort, "train_step": train, "grid": rnd.querier.last_grid_stats,

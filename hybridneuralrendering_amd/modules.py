@@ -94,6 +94,10 @@ class NeuralPoints(nn.Module):
         self.device = device
         if getattr(opt, "wcoord_query", 1) <= 0:
             raise HnrError("only the world-coordinate querier (wcoord_query=1) is implemented; no shipped script uses the other")
+        if getattr(opt, "xyz_grad", 0) > 0:
+            # the reference differentiates through sampled_xyz / dists (neural_points.py:132-138); the HIP backward carries no
+            # position gradient, and an optimiser that silently never moves xyz would be a different training run
+            raise HnrError("xyz_grad > 0 is not implemented (no shipped script sets it): the HIP backward has no gradient w.r.t. point positions")
         if getattr(opt, "load_points", 0) == 1:
             saved = torch.load(checkpoint, map_location=device) if checkpoint else None
             if saved is None or "neural_points.xyz" not in saved:

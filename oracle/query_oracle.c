@@ -35,8 +35,20 @@
  *   - the voxel that owns slot 0 never receives points (`voxel_idx > 0`, :366)
  *     but still counts as occupied for the dilated march mask.
  *
- * Arithmetic is fp32 exactly as written in the source: no FMA contraction
- * (build with -ffp-contract=off), IEEE divide, floorf.
+ * Arithmetic is fp32 with every operation of the source rounded separately: no FMA
+ * contraction (build with -ffp-contract=off), IEEE divide, floorf.
+ *
+ * KNOWN, MEASURED DEVIATION from the reference BINARY (not from its source): the
+ * reference compiles its kernels with pycuda's nvcc defaults (-fmad=true), which
+ * contract `x_v * x_v + y_v * y_v + z_v * z_v` (:492) into x*x -> fma(y,y,.) ->
+ * fma(z,z,.).  oq_set_fma_d2(1) switches THIS restatement to that FMA chain
+ * (explicit fmaf, still -ffp-contract=off everywhere else); the HIP kernels and the
+ * default oracle use the separately rounded form.  Measured effect on the bench scene
+ * (scene0241-like, 2 M points): over the whole 285 200-ray frame (3 378 283 shading
+ * samples, 95.4 M distance tests) ONE sample picks a different neighbour set and 3
+ * store the same set in another slot order; on every 15th ray (the subset
+ * tests/test_query_oracle.py::test_fma_contracted_d2_changes_few_neighbour_sets runs)
+ * none does.  A tie-level effect (1 ulp of d2 at the radius / replacement compare).
  */
 #include <math.h>
 #include <stdint.h>
@@ -178,6 +190,10 @@ const int32_t *oq_coor_2_occ(const oq_grid *g)  { return g->coor_2_occ; }
 const int32_t *oq_occ_2_pnts(const oq_grid *g)  { return g->occ_2_pnts; }
 const int32_t *oq_occ_numpnts(const oq_grid *g) { return g->occ_numpnts; }
 
+static int g_fma_d2 = 0;
+/* 0 (default): d2 = (x*x + y*y) + z*z, each op rounded; 1: the chain nvcc -fmad=true emits for :492 */
+void oq_set_fma_d2(int on) { g_fma_d2 = on ? 1 : 0; }
+
 /* query_neigh_along_ray_layered (:436-522) for one shading sample.
  * pidx_out[K] must be pre-filled with -1.  Returns kid (in-radius candidates seen).
  * stat[0] += occupied cells visited, stat[1] += candidates distance-tested. */
@@ -213,7 +229,7 @@ static int knn_one_sample(const oq_grid *g, const float *xyz, const float ctr[3]
                         float yv = xyz[3 * (size_t)pidx + 1] - cy;
                         float zv = xyz[3 * (size_t)pidx + 2] - cz;
                         float xx = xv * xv, yy = yv * yv, zz = zv * zv;
-                        float d2 = (xx + yy) + zz;
+                        float d2 = g_fma_d2 ? fmaf(zv, zv, fmaf(yv, yv, xx)) : (xx + yy) + zz;
                         stat[1] += 1;
                         if (radius2 == 0.0f || d2 <= radius2) {
                             if (kid++ < K) {

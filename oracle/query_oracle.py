@@ -43,6 +43,8 @@ def _load():
                      ("oq_occ_2_pnts", c_ip), ("oq_occ_numpnts", c_ip)):
         getattr(lib, name).restype = rt
         getattr(lib, name).argtypes = [ctypes.c_void_p]
+    lib.oq_set_fma_d2.argtypes = [ctypes.c_int]
+    lib.oq_set_fma_d2.restype = None
     lib.oq_query.restype = ctypes.c_int
     lib.oq_query.argtypes = [ctypes.c_void_p, c_fp, c_fp, c_fp, ctypes.c_int, c_fp, ctypes.c_int,
                              ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, c_ip,
@@ -126,8 +128,9 @@ class OracleGrid:
         onp = np.ctypeslib.as_array(_lib.oq_occ_numpnts(self._h), shape=(self.max_o,)).copy()
         return occ, c2o, o2p, onp
 
-    def query(self, campos, raydir, tmid, SR, K, radius2, kernel_size, want_full=False):
+    def query(self, campos, raydir, tmid, SR, K, radius2, kernel_size, want_full=False, fma_d2=False):
         """Restates query_grid_point_index (:605-711) after build_occ_vox.
+        fma_d2: evaluate the candidate distance (:492) with the FMA chain nvcc -fmad=true emits (see query_oracle.c header).
 
         Returns dict(sample_pidx [R',SR,K] i32, sample_loc_w [R',SR,3] f32, ray_mask [R] i8,
         counts dict[, full_pidx, full_loc, full_nsamp]).
@@ -151,11 +154,13 @@ class OracleGrid:
             fp = np.empty((R, SR, K), dtype=np.int32)
             fl = np.empty((R, SR, 3), dtype=np.float32)
             fn = np.empty((R,), dtype=np.int32)
+        _lib.oq_set_fma_d2(1 if fma_d2 else 0)
         rc = _lib.oq_query(self._h, _fp(self.xyz), _fp(campos), _fp(raydir), R, _fp(tmid), D, stride,
                            int(SR), int(K), ctypes.c_float(float(radius2)), _ip(ks),
                            _ip(pidx), _fp(loc), mask.ctypes.data_as(ctypes.POINTER(ctypes.c_int8)), counts,
                            _ip(fp) if want_full else None, _fp(fl) if want_full else None,
                            _ip(fn) if want_full else None)
+        _lib.oq_set_fma_d2(0)
         if rc != 0:
             raise RuntimeError("oq_query failed rc=%d" % rc)
         keys = ["n_valid_rays", "n_hit_rays", "n_samples", "n_neighbours", "n_cells_visited",

@@ -234,6 +234,66 @@ def gen_render(ref, tag, scene_name, n_points, seed, w, h, n_rays, opt_over=None
     return net, inputs, out
 
 
+def c1_batch(sc):
+    """BASELINE config C1: the 200x200 chair camera, ONE 32x32 = 1024-ray batch (the image centre)."""
+    x0 = y0 = 84
+    px, py = np.meshgrid(np.arange(x0, x0 + 32), np.arange(y0, y0 + 32), indexing="ij")
+    pix = np.stack([px, py], axis=-1).reshape(-1, 2).astype(np.int32)
+    return pix, scenes.camera_rays(pix, sc.intrinsic, sc.c2w)
+
+
+def gen_c1(ref):
+    """render_c1_chair.npz: BASELINE config C1 (dev_scripts/w_n360/chair_hybrid.sh: 200x200, 1024-ray batch, SR 80, P 12,
+    100 k points, seed 0) through the imported reference on CPU.  The scene regenerates from its seed and the weights are those
+    of render_synth_small.npz, so only the expected OUTPUTS are stored."""
+    sc = scenes.make_scene("chair", 100000, 0)
+    opt = sc.opt
+    opt.agg_axis_weight = None
+    opt.checkpoints_dir, opt.name, opt.resume_iter = "/nonexistent", "golden", "latest"
+    ref.npts.lighting_fast_querier_w = make_oracle_querier(ref)
+    ckpt = {"neural_points.xyz": torch.from_numpy(sc.xyz), "neural_points.points_embeding": torch.from_numpy(sc.emb),
+            "neural_points.points_conf": torch.from_numpy(sc.conf), "neural_points.points_dir": torch.from_numpy(sc.dir),
+            "neural_points.points_color": torch.from_numpy(sc.color)}
+    with tempfile.NamedTemporaryFile(suffix=".pth", delete=False) as f:
+        torch.save(ckpt, f.name)
+        ckpt_path = f.name
+    neural_points = ref.npts.NeuralPoints(opt.point_features_dim, sc.xyz.shape[0], opt, torch.device("cpu"), checkpoint=ckpt_path,
+                                          feature_init_method="rand", reg_weight=0.)
+    os.unlink(ckpt_path)
+    aggregator = ref.agg.PointAggregator(opt)
+    z = np.load(os.path.join(HERE, "render_synth_small.npz"))
+    aggregator.load_state_dict({k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd.")})
+    net = ref.vol.NeuralPointsRayMarching(
+        tonemap_func=ref.drf.find_tone_map(opt.which_tonemap_func), render_func=ref.drf.find_render_function(opt.which_render_func),
+        blend_func=ref.drf.find_blend_function(opt.which_blend_func), aggregator=aggregator, is_compute_depth=False,
+        neural_points=neural_points, opt=opt, num_pos_freqs=opt.num_pos_freqs, num_viewdir_freqs=opt.num_viewdir_freqs)
+    net.eval()
+    pix, raydir = c1_batch(sc)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    inputs = dict(
+        campos=t(sc.c2w[:3, 3])[None], raydir=t(raydir)[None], bg_color=t(sc.bg_color)[None],
+        camrotc2w=t(sc.c2w[:3, :3])[None], pixel_idx=t(pix.astype(np.float32))[None],
+        near=torch.tensor([[[sc.near]]]), far=torch.tensor([[[sc.far]]]), h=torch.tensor([sc.h]), w=torch.tensor([sc.w]),
+        intrinsic=t(sc.intrinsic)[None], c2w=t(sc.c2w)[None], c2w_nearest=t(sc.c2w_nearest)[None],
+        images_nearest=t(sc.images_nearest)[None], campos_nearest=t(sc.c2w_nearest[:, :3, 3])[None],
+        intrinsic_nearest=t(sc.intrinsic)[None], vid_angle_nearest=torch.zeros(1, 4), frame_weight_nearest=torch.ones(1, 4))
+    with torch.no_grad():
+        out = net(**inputs)
+    shell = SimpleNamespace(input={}, opt=opt, tonemap_func=ref.drf.find_tone_map(opt.which_tonemap_func))
+    out_full = ref.vol.NeuralPointsVolumetricModel.fill_invalid(shell, dict(out), inputs)
+    q = ref.npts.lighting_fast_querier_w.last
+    np.savez_compressed(os.path.join(HERE, "render_c1_chair.npz"),
+                        scene=np.array(["chair", "100000", "0", "200", "200", "32x32 batch at (84,84)"]),
+                        weights_from=np.array("render_synth_small.npz"),
+                        ray_mask=out["ray_mask"].numpy(), counts=np.array([q["counts"][k] for k in sorted(q["counts"])], np.int64),
+                        count_keys=np.array(sorted(q["counts"])),
+                        full_coarse_raycolor=out_full["coarse_raycolor"].numpy(),
+                        full_coarse_point_opacity=out_full["coarse_point_opacity"].numpy(),
+                        full_coarse_is_background=out_full["coarse_is_background"].numpy())
+    print("render_c1_chair.npz: 1024 rays, %d valid, %d samples, %d neighbours, colour mean %.4f" % (
+        int(q["ray_mask"].sum()), q["counts"]["n_samples"], q["counts"]["n_neighbours"], float(out_full["coarse_raycolor"].mean())))
+
+
 def gen_train(ref, tag, scene_name, n_points, seed, w, h, patch, opt_over=None, margin=2, size=None, keep=None, twin=None):
     """One training step of the reference on CPU (forward in train mode + autograd): the C3 fixture.
 
@@ -512,12 +572,17 @@ def gen_voxel(ref):
 
 def main():
     ref = import_reference()
+    if len(sys.argv) > 1:                     # python make_golden.py gen_c1 gen_voxel ... : only the named fixtures
+        for name in sys.argv[1:]:
+            globals()[name](ref)
+        return
     gen_hparams(ref)
     gen_tmid(ref)
     gen_posenc(ref)
     gen_render(ref, "scannet_small", "scene0241", 12000, 11, 64, 48, 600, opt_over=dict(agg_axis_weight=None), size=(1.0, 0.8, 0.6))
     gen_render(ref, "synth_small", "lego", 9000, 12, 40, 40, 500, opt_over=dict(agg_axis_weight=None, SR=40))
     gen_render(ref, "scannet_small_prob", "scene0241", 12000, 11, 64, 48, 600, opt_over=dict(agg_axis_weight=None, prob=1), size=(1.0, 0.8, 0.6))
+    gen_c1(ref)
     gen_param_keys(ref)
     gen_blur(ref)
     gen_blur_learn(ref)

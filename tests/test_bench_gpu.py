@@ -20,9 +20,10 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
               "config", "roofline", "cpu_baseline"):
         assert k in d, k
-    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["unit"] == "rays/s" and d["scaling"] == "weak" and d["dtype"] == "f32"
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["unit"] == "rays/s" and d["scaling"] == "strong" and d["dtype"] == "f32"
     assert d["vs_baseline"] is None and d["higher_is_better"] is True and "workload" in d["config"] and "model" not in d["config"]
-    assert abs(d["value"] - d["config"]["rays_per_gpu"] * 1000.0 / d["ms_per_step"]) < 1e-3 * d["value"]
+    assert abs(d["value"] - d["config"]["rays_per_step"] * 1000.0 / d["ms_per_step"]) < 1e-3 * d["value"]
+    assert "alpha_branch" in d["config"]["workload"]
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
@@ -32,3 +33,38 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
         assert k in c, k
     assert c["kind"] == "port" and c["value"] > 0 and c["psnr_gpu_vs_oracle_db"] > 60
     assert d["roofline_query"]["bound"] == "hbm" and d["train_step"]["ms_per_step"] > 0
+
+
+def _run(extra, env=None, timeout=1500):
+    e = dict(os.environ)
+    e.update(env or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--points", "2e5", "--no-cpu-baseline",
+                        "--no-train-leg"] + extra, cwd=ROOT, capture_output=True, text=True, timeout=timeout, env=e)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_2_spawns_two_ranks_and_reassembles_the_same_frame(tmp_path):
+    """`python bench.py --gpus 2` with no launcher: the parent spawns the two ranks itself (rehearsal mode here: one GPU, gloo), the
+    fixed frame is split into two scan-line blocks and the gathered image equals the N=1 image (counterpart of the chunk scatter
+    at /root/reference/run/test_ft.py:185-198)."""
+    import numpy as np
+    a, b = str(tmp_path / "n1.npy"), str(tmp_path / "n2.npy")
+    d1 = _run(["--gpus", "1", "--dump-colors", a])
+    d2 = _run(["--gpus", "2", "--dump-colors", b], env={"HNR_BENCH_REHEARSAL": "1"})
+    assert d1["n_gpus"] == 1 and d2["n_gpus"] == 2 and d2["scaling"] == "strong"
+    assert d2["config"]["rays_per_step"] == d1["config"]["rays_per_step"] and d2["config"]["rays_per_gpu"] * 2 == d1["config"]["rays_per_gpu"]
+    assert "REHEARSAL" in d2["data"]
+    c1, c2 = np.load(a), np.load(b)
+    assert c1.shape == c2.shape == (d1["config"]["rays_per_step"], 3)
+    np.testing.assert_array_equal(c1, c2)
+
+
+def test_bench_weak_scaling_flag_and_world_size_mismatch():
+    d = _run(["--gpus", "2", "--scaling", "weak"], env={"HNR_BENCH_REHEARSAL": "1"})
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["rays_per_step"] == 2 * d["config"]["rays_per_gpu"]
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], cwd=ROOT, capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert p.returncode != 0 and "WORLD_SIZE" in (p.stderr + p.stdout)

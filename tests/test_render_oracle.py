@@ -192,3 +192,26 @@ def test_oracle_learnable_blur_matches_reference_golden(tag):
         for k, v in blk.named_parameters():
             g = exp["grads"]["%d.%s" % (bi, k)]
             np.testing.assert_allclose(v.grad.numpy(), g, rtol=0, atol=2e-5 * max(1.0, float(np.abs(g).max())))
+
+
+def test_c1_chair_1k_ray_cpu_plumbing_batch_matches_reference():
+    """BASELINE config C1 (nerf_synthetic/chair 200x200, 1k-ray batch, CPU path; dev_scripts/w_n360/chair_hybrid.sh): the whole
+    CPU oracle path -- C query restatement + torch gather/aggregate/composite -- on make_scene("chair") against the outputs of the
+    imported reference's NeuralPointsRayMarching.forward + fill_invalid on the same batch."""
+    from tests.golden_io import c1_chair
+    sc, pix, raydir, sd, exp = c1_chair()
+    opt = sc.opt
+    assert raydir.shape == (1024, 3) and opt.SR == 80 and opt.P == 12 and opt.max_o == 410000 and sc.xyz.shape[0] == 100000
+    hp = qo.hyperparameters(sc.xyz, opt.vsize, opt.vscale, opt.kernel_size, opt.ranges, opt.radius_limit_scale)
+    g = qo.OracleGrid(sc.xyz, hp["origin"], hp["cell"], hp["dims"], opt.query_size, opt.P, opt.max_o)
+    q = g.query(sc.c2w[:3, 3], raydir, qo.tmid_table(sc.near, sc.far, opt.z_depth_dim), opt.SR, opt.K, hp["radius2"], opt.kernel_size)
+    assert q["counts"] == exp["counts"]
+    np.testing.assert_array_equal(q["ray_mask"], exp["ray_mask"].reshape(-1))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    with torch.no_grad():
+        out = ro.render(t(sc.xyz), t(sc.emb), t(sc.conf), t(sc.dir), t(sc.color), sd, q, t(sc.c2w[:3, 3])[None], t(sc.c2w[:3, :3])[None],
+                        t(raydir)[None], t(sc.bg_color)[None], t(sc.c2w_nearest)[None], t(sc.c2w_nearest[:, :3, 3])[None],
+                        t(sc.intrinsic)[None], t(sc.images_nearest)[None], opt.vsize)
+    np.testing.assert_allclose(out["full_coarse_raycolor"].numpy(), exp["full_coarse_raycolor"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(out["full_coarse_point_opacity"].numpy(), exp["full_coarse_point_opacity"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(out["full_coarse_is_background"].numpy(), exp["full_coarse_is_background"], rtol=0, atol=2e-6)
