@@ -167,6 +167,7 @@ class PointAggregator(nn.Module):
         )
         self._packed, self._packed_key = pk, key
         self._packed_split = None
+        self._packed_chain = None
         return pk
 
     def packed_split(self):
@@ -177,6 +178,24 @@ class PointAggregator(nn.Module):
             sl = lambda seq, i: SplitLinear(seq[i].weight, seq[i].bias)
             self._packed_split = dict(b1_2=sl(self.block1, 2), b3_0=sl(self.block3, 0), b3_2=sl(self.block3, 2))
         return self._packed_split
+
+    def packed_chain(self):
+        """block1 / block3 / alpha_branch in the image of the fused per-neighbour chain (hnr_chain_pack; csrc/chain.hip), packed
+        with the fp32 images and re-packed when a parameter changes."""
+        self.packed()
+        if getattr(self, "_packed_chain", None) is None:
+            L = _lib.lib()
+            dev = next(self.parameters()).device
+            buf = torch.empty((int(L.hnr_chain_packed_bytes()),), dtype=torch.uint8, device=dev)
+            f32 = lambda t: t.detach().to(torch.float32).contiguous()
+            w0 = f32(self.block1[0].weight[:, 224:284])
+            args = [f32(self.block1[0].bias), f32(self.block1[2].weight), f32(self.block1[2].bias), f32(self.block3[0].weight),
+                    f32(self.block3[0].bias), f32(self.block3[2].weight), f32(self.block3[2].bias),
+                    f32(self.alpha_branch[0].weight).reshape(256), f32(self.alpha_branch[0].bias).reshape(1)]
+            with torch.cuda.device(dev):
+                _lib.check(L.hnr_chain_pack(_lib.ptr(w0), 60, *[_lib.ptr(t) for t in args], _lib.ptr(buf), _lib.stream()), "hnr_chain_pack")
+            self._packed_chain = buf
+        return self._packed_chain
 
     def point_table(self, emb, ids=None, n_ids=None, want_rows=False):
         """[N,256] = [emb | PE3(emb)] @ block1.0.weight[:, :224]^T -- the point-only part of block1's first layer

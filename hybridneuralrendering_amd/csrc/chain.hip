@@ -1,0 +1,692 @@
+// The per-neighbour chain of PointAggregator.viewmlp in ONE kernel:
+//   block1 (Linear 284->256, LeakyReLU, Linear 256->256, LeakyReLU)        models/aggregators/point_aggregators.py:948
+//   block3 on [block1_out | colour3 | dir - viewdir 3 | dir.viewdir 1]       :957-972
+//   alpha_branch (Linear 256->1) + softplus(x - 1)                          :1005, :471-476
+//   K-weighted sums of the density and of the 256 features per shading sample :1008-1026
+// Activations never leave the CU: each workgroup carries a tile of 128 neighbour rows (16 shading samples x K = 8 slots)
+// through the four dense layers with the layer outputs staged in LDS, and only the per-sample sums go back to HBM.
+// (The unfused path -- linear_s3.hip / linear.hip + ksum_kernel -- writes and re-reads a [rows, 256] fp32 matrix between all
+// launches: 232 GB of HBM traffic per 285 200-ray frame against 4 GB of algorithmic bytes.)
+//
+// Arithmetic: "f16x2".  gfx950 has no TF32 and runs fp32 MFMA at 1/16 of the 16-bit matrix rate.  Every operand x (an
+// activation or a weight, scaled by a power of two so that the row / layer maximum sits just below 2^15 / 2^14) is split into
+// two fp16 values h = fp16(x), m = fp16(x - h) (x - h is exact), |x - h - m| <= 2^-22 |x|, and a product is issued as the three
+// v_mfma_f32_32x32x16_f16 terms  wm*xh + wh*xm + wh*xh  with fp32 accumulation; the dropped terms are <= 3 * 2^-22 |w x| per
+// product with random sign, which over a K >= 60 dot product stays below the rounding error of the fp32 accumulation itself
+// (tests/test_chain_gpu.py measures the layer against fp64 beside the fp32-MFMA kernel: same error class).  The scaling makes
+// the split exact-to-22-bits for every element down to 2^-18 of its row's maximum and keeps fp16 overflow impossible; the
+// power-of-two scales are removed exactly in the epilogue.  Per-ROW activation scales make a row's result independent of
+// which other rows share its tile, so chunked / sharded renders reproduce the whole-frame pixels bit for bit.
+//
+// Row layout: sample-major, K = 8 slots per valid shading sample (row = 8 s + k; empty slots carry weight 0), so the K-sum
+// is a sum over 8 adjacent MFMA columns.
+//
+// Orientation: the MFMA computes OUT^T = W * X^T: the A operand is a weight fragment (32 output columns x 16 k), the B
+// operand an activation fragment (32 rows x 16 k), so an accumulator lane (j = lane & 31, h = lane >> 5) holds, for
+// activation row j, 16 output columns.  The weight rows are dealt to the MFMA tile so that those 16 columns are CONSECUTIVE
+// (32 ct + 16 h + r): they are exactly one k step (16 k) of the next layer's B fragment for row j, i.e. the epilogue writes
+// the next layer's operand with two 16-B LDS stores per plane and no cross-lane traffic.
+//
+// Tiling: 256 threads = 4 waves, one per SIMD (up to 512 registers); wave w owns output columns 64 w .. 64 w + 63 of all
+// 128 rows (4 row tiles x 2 column tiles = 128 accumulator registers), streams its own weight fragments global -> registers
+// (L2-resident: the 848 KiB weight image is read by every CU), and all four waves read the shared activation fragments from
+// LDS (ds_read_b128, 8 per k step for 24 MFMAs).
+#include <stdlib.h>
+#include <type_traits>
+
+#include "hnr_common.h"
+
+namespace hnr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int CH_ROWS = 128;                       // neighbour rows per tile
+constexpr int CH_SAMPLES = 16;                     // shading samples per tile
+constexpr int CH_SLOT = 8192;                      // LDS bytes per k step of activation planes: [row tile 4][plane 2][64 lanes][16 B]
+constexpr int CH_WSTEP = 16384;                    // weight image bytes per k step: [column tile 8][plane 2][64 lanes][16 B]
+constexpr int CH_S0 = 4, CH_S1 = 16, CH_S2 = 17, CH_S3 = 16;      // k steps of the four layers (K = 60, 256, 263, 256)
+constexpr int CH_W0 = 0, CH_W1 = CH_S0 * CH_WSTEP, CH_W2 = CH_W1 + CH_S1 * CH_WSTEP, CH_W3 = CH_W2 + CH_S2 * CH_WSTEP;
+constexpr int CH_WBYTES = CH_W3 + CH_S3 * CH_WSTEP;               // 53 k steps = 848 KiB
+constexpr int CH_META = CH_WBYTES;                 // floats after the image: bias[4][256], alpha_w[256], alpha_b, descale_w[4], max|W| bits[4], pad
+constexpr int CH_META_DESCALE = 4 * 256 + 256 + 1, CH_META_WMAX = CH_META_DESCALE + 4;
+constexpr int CH_META_FLOATS = CH_META_WMAX + 4 + 3;
+constexpr int CH_XP_TILE = CH_S0 * CH_SLOT;        // bytes of one tile's layer-0 operand image (32 KiB)
+constexpr int CH_AUX_TILE = 128 * 4 + 128 * 4 + 128 * 8 * 4;      // pid[128] i32, wagg[128] f32, ext[128][8] f32 = 5 KiB
+constexpr int CH_LDS_EXCH = 17 * CH_SLOT;          // float[128][4] exchange area behind the 17 plane slots
+constexpr int CH_LDS_BYTES = CH_LDS_EXCH + 128 * 4 * 4;
+constexpr int CH_ACT_EXP = 15;                     // a row's maximum is scaled into [2^14, 2^15)
+constexpr int CH_W_EXP = 14;                       // a layer's largest weight is scaled into [2^13, 2^14)
+
+// (x0, x1) -> packed fp16 pairs h, m with x = h + m + O(2^-22 |x|); round-to-nearest-even
+__device__ __forceinline__ void split2h(float x0, float x1, unsigned &ph, unsigned &pm)
+{
+    float r0, r1;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(ph) : "v"(x0), "v"(x1));
+    asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(ph), "v"(x0));                  // x0 - h.lo (exact)
+    asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(ph), "v"(x1));    // x1 - h.hi
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(pm) : "v"(r0), "v"(r1));
+}
+
+__device__ __forceinline__ float pow2f(int e) { return __uint_as_float((unsigned)(127 + e) << 23); }   // -126 <= e <= 127
+
+// scale exponent k of a row whose largest |value| is m: m * 2^k in [2^(CH_ACT_EXP-1), 2^CH_ACT_EXP)
+__device__ __forceinline__ int row_scale_exp(float m)
+{
+    int ex = (int)((__float_as_uint(m) >> 23) & 0xffu);          // biased exponent; m >= 0
+    ex = ex < 48 ? 48 : (ex > 250 ? 250 : ex);                   // zero / tiny rows: scale 2^93 at most; inf / nan rows: garbage in, garbage out
+    return CH_ACT_EXP + 126 - ex;
+}
+
+struct ChainArgs {
+    const char *xp;                    // [tiles][CH_XP_TILE] layer-0 operand image (chain_gather_kernel)
+    const char *aux;                   // [tiles][CH_AUX_TILE]
+    const float *ptab; int ldt;        // per-point addend of block1.0: [N, ldt >= 256]
+    const char *wimg;                  // packed weights (hnr_chain_pack)
+    const unsigned long long *counts;  // device counters of the query (n_valid samples)
+    float *X5; int ld5;                // [S_v, ld5 >= 256]: weighted feature sums
+    float *sigma;                      // [S_v]
+    float slope;
+    int cap_samples;
+    float *dbg; int dbg_layer;         // probe: post-activation output of layer dbg_layer -> [rows, 256]
+};
+
+// one dense layer of the tile: acc[rt][c] (+)= W[64 wave + 32 c .. +31, :] * X[32 rt .. +31, :]^T over S k steps
+template <int S, int PRELOAD_ALL, class Mid>
+__device__ __forceinline__ void chain_mfma_layer(__amdgpu_buffer_rsrc_t wsrd, int wbase, const char *lds, int wave, int lane, f32x16 (&acc)[4][2], Mid mid)
+{
+    // fragment (s, ct = 2 wave + c, plane p) at s * CH_WSTEP + (c * 2 + p) * 1024 of the layer image; the per-lane part is ONE
+    // 32-bit offset beside the uniform buffer descriptor, so no load needs a 64-bit address register pair
+    const unsigned woff = (unsigned)(2 * wave) * 2048u + (unsigned)lane * 16u;
+    asm volatile("" : "+s"(wbase));                                       // per-tile opaque: the k-step offsets are s_add'ed here, not hoisted out of the tile loop (SGPR spills)
+    const char *bp = lds + lane * 16;                                     // fragment (s, rt, plane p) at s * CH_SLOT + (rt * 2 + p) * 1024
+    constexpr int NW = PRELOAD_ALL ? S : 3;
+    u32x4 wf[NW][2][2], bf[2][4][2];
+    auto load_w = [&](int slot, int s) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) wf[slot][c][p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wsrd, woff + (c * 2 + p) * 1024, wbase + s * CH_WSTEP, 0));
+    };
+    auto load_b = [&](int slot, int s) {
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) bf[slot][rt][p] = *reinterpret_cast<const u32x4 *>(bp + s * CH_SLOT + (rt * 2 + p) * 1024);
+    };
+    if (PRELOAD_ALL) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) load_w(s, s);
+    } else {
+        load_w(0, 0);
+        if (S > 1) load_w(1, 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mid();                                                                // loads the caller wants queued BEHIND the first weight fragments
+    __builtin_amdgcn_sched_barrier(0);
+    load_b(0, 0);
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        if (!PRELOAD_ALL && s + 2 < S) load_w((s + 2) % 3, s + 2);
+        if (s + 1 < S) load_b((s + 1) & 1, s + 1);
+        const int ws = PRELOAD_ALL ? s : s % 3, bs = s & 1;
+#define CH_W(c, p) __builtin_bit_cast(f16x8, wf[ws][c][p])
+#define CH_X(rt, p) __builtin_bit_cast(f16x8, bf[bs][rt][p])
+        // smallest terms first; 8 independent accumulators between two MFMAs on the same one
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) acc[rt][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(CH_W(c, 1), CH_X(rt, 0), acc[rt][c], 0, 0, 0);
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) acc[rt][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(CH_W(c, 0), CH_X(rt, 1), acc[rt][c], 0, 0, 0);
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) acc[rt][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(CH_W(c, 0), CH_X(rt, 0), acc[rt][c], 0, 0, 0);
+#undef CH_W
+#undef CH_X
+        // issue order inside the k step: the 8 fragment reads of step s+1 and the 4 weight loads of step s+2 go out under the
+        // FIRST MFMAs (left alone, hipcc sinks the reads to the end of the step and the next step's first MFMA waits for LDS)
+        if (s + 1 < S) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+        }
+        if (!PRELOAD_ALL && s + 2 < S) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
+        }
+        __builtin_amdgcn_sched_barrier(0);                                // keep the prefetch distance: no load of a later k step is hoisted across
+    }
+}
+
+__device__ __forceinline__ float chain_softplus_m1(float x)
+{
+    const float y = __fsub_rn(x, 1.0f);                // raw2out_density: softplus(x - 1), beta = 1, threshold = 20 (:471-476)
+    return y > 20.f ? y : log1pf(expf(y));
+}
+
+template <int DBG>
+__global__ __launch_bounds__(256, 1) void chain_kernel(ChainArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, j = lane & 31;
+    int n_valid = (int)a.counts[HNR_CNT_SAMPLES_VALID];
+    if (n_valid > a.cap_samples) n_valid = a.cap_samples;
+    const int n_tiles = (n_valid + CH_SAMPLES - 1) / CH_SAMPLES;
+    const float *meta = reinterpret_cast<const float *>(a.wimg + CH_META);
+    const __amdgpu_buffer_rsrc_t wsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(a.wimg), 0, CH_WBYTES, 0x00020000);
+    float *exch = reinterpret_cast<float *>(lds + CH_LDS_EXCH);            // [row 128][wave 4]
+    const int col0 = 64 * wave + 16 * h;                                   // this lane's columns: col0 + 32 c + r
+
+    // the extras k step (slot 16) carries 7 columns: its k = 8..15 half (lanes 32..63 of every fragment) stays zero
+    for (int i = tid; i < 8 * 32; i += 256)
+        *reinterpret_cast<u32x4 *>(lds + 16 * CH_SLOT + (i >> 5) * 1024 + (32 + (i & 31)) * 16) = u32x4{0u, 0u, 0u, 0u};
+
+    // XCD-aware tile order: block b runs on XCD b & 7; every XCD walks one contiguous eighth of the tiles so that
+    // neighbouring samples (which share points, i.e. rows of the per-point table) meet in one L2
+    const int xcd = blockIdx.x & 7, nb = (gridDim.x + 7 - xcd) / 8, bi = blockIdx.x >> 3;
+    const int per = (n_tiles + 7) / 8, t_lo = xcd * per, t_hi = (t_lo + per < n_tiles) ? t_lo + per : n_tiles;
+    const bool xcd_order = gridDim.x >= 8;
+
+    for (int tile = xcd_order ? t_lo + bi : (int)blockIdx.x; tile < (xcd_order ? t_hi : n_tiles); tile += xcd_order ? nb : (int)gridDim.x) {
+        // ---- tile prologue: layer-0 operand image -> LDS slots 0..3; per-row scalars
+        {
+            const char *src = a.xp + (size_t)tile * CH_XP_TILE;
+            u32x4 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const u32x4 *>(src + (i * 256 + tid) * 16);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) *reinterpret_cast<u32x4 *>(lds + (i * 256 + tid) * 16) = v[i];
+        }
+        const char *aux = a.aux + (size_t)tile * CH_AUX_TILE;
+        int pid[4];
+        float wq[4];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+            pid[rt] = reinterpret_cast<const int32_t *>(aux)[32 * rt + j];
+            wq[rt] = reinterpret_cast<const float *>(aux + 512)[32 * rt + j];
+        }
+        // extras of the rows this wave publishes (row tile = wave)
+        const float4 e0 = *reinterpret_cast<const float4 *>(aux + 1024 + (32 * wave + j) * 32);
+        const float4 e1 = *reinterpret_cast<const float4 *>(aux + 1024 + (32 * wave + j) * 32 + 16);
+        __syncthreads();
+
+        f32x16 acc[4][2];
+        float inv[4];                                                      // per row tile: 1 / (row scale * layer weight scale) of the running layer
+        auto zero_acc = [&]() {
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[rt][c][r] = 0.f;
+        };
+        // bias + LeakyReLU in place, per-row maxima; L0 adds the gathered per-point rows
+        float4 tv[4][2][4];                                                // layer 0: gathered rows of the per-point table
+        auto activate = [&](int layer, float (&amax)[4], auto with_table) {
+            constexpr bool TV = decltype(with_table)::value;
+            float bias[2][16];
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 b = *reinterpret_cast<const float4 *>(meta + layer * 256 + col0 + 32 * c + 4 * q);
+                    bias[c][4 * q] = b.x; bias[c][4 * q + 1] = b.y; bias[c][4 * q + 2] = b.z; bias[c][4 * q + 3] = b.w;
+                }
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) {
+                float m = 0.f;
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float add = bias[c][r];
+                        if (TV) { const float4 t4 = tv[rt][c][r >> 2]; add = __fadd_rn(add, (r & 3) == 0 ? t4.x : (r & 3) == 1 ? t4.y : (r & 3) == 2 ? t4.z : t4.w); }
+                        float v = fmaf(acc[rt][c][r], inv[rt], add);
+                        v = fmaxf(v, __fmul_rn(v, a.slope));               // LeakyReLU, 0 < slope < 1
+                        acc[rt][c][r] = v;
+                        m = fmaxf(m, fabsf(v));
+                        if (DBG) { if (a.dbg && a.dbg_layer == layer) a.dbg[((size_t)tile * CH_ROWS + 32 * rt + j) * 256 + col0 + 32 * c + r] = v; }
+                    }
+                amax[rt] = m;
+            }
+        };
+        // per-row scale from the maxima of all four waves, split, publish the next layer's operand planes
+        auto publish = [&](int next_layer, float (&amax)[4], bool with_extras) {
+            float emax = 0.f;
+            if (with_extras) emax = fmaxf(fmaxf(fmaxf(fabsf(e0.x), fabsf(e0.y)), fmaxf(fabsf(e0.z), fabsf(e0.w))), fmaxf(fmaxf(fabsf(e1.x), fabsf(e1.y)), fabsf(e1.z)));
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) {
+                float m = fmaxf(amax[rt], __shfl_xor(amax[rt], 32));
+                if (with_extras && rt == wave) m = fmaxf(m, emax);
+                if (h == 0) exch[(32 * rt + j) * 4 + wave] = m;
+            }
+            __syncthreads();                                               // every wave has finished reading the previous planes
+            const float dw = meta[CH_META_DESCALE + next_layer];         // 2^-sw of the next layer's weights
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) {
+                const float4 m4 = *reinterpret_cast<const float4 *>(exch + (32 * rt + j) * 4);
+                const int k = row_scale_exp(fmaxf(fmaxf(m4.x, m4.y), fmaxf(m4.z, m4.w)));
+                const float sc = pow2f(k);
+                inv[rt] = __fmul_rn(pow2f(-k), dw);
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    unsigned ph[8], pm[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) split2h(__fmul_rn(acc[rt][c][2 * q], sc), __fmul_rn(acc[rt][c][2 * q + 1], sc), ph[q], pm[q]);
+                    char *dst = lds + (2 * (2 * wave + c) + h) * CH_SLOT + (rt * 2) * 1024 + j * 16;
+                    *reinterpret_cast<u32x4 *>(dst) = u32x4{ph[0], ph[1], ph[2], ph[3]};
+                    *reinterpret_cast<u32x4 *>(dst + 512) = u32x4{ph[4], ph[5], ph[6], ph[7]};
+                    *reinterpret_cast<u32x4 *>(dst + 1024) = u32x4{pm[0], pm[1], pm[2], pm[3]};
+                    *reinterpret_cast<u32x4 *>(dst + 1024 + 512) = u32x4{pm[4], pm[5], pm[6], pm[7]};
+                }
+                if (with_extras && rt == wave && h == 0) {
+                    unsigned ph[4], pm[4];
+                    split2h(__fmul_rn(e0.x, sc), __fmul_rn(e0.y, sc), ph[0], pm[0]);
+                    split2h(__fmul_rn(e0.z, sc), __fmul_rn(e0.w, sc), ph[1], pm[1]);
+                    split2h(__fmul_rn(e1.x, sc), __fmul_rn(e1.y, sc), ph[2], pm[2]);
+                    split2h(__fmul_rn(e1.z, sc), 0.f, ph[3], pm[3]);
+                    char *dst = lds + 16 * CH_SLOT + (rt * 2) * 1024 + j * 16;
+                    *reinterpret_cast<u32x4 *>(dst) = u32x4{ph[0], ph[1], ph[2], ph[3]};
+                    *reinterpret_cast<u32x4 *>(dst + 1024) = u32x4{pm[0], pm[1], pm[2], pm[3]};
+                }
+            }
+            __syncthreads();
+        };
+
+        // ---- layer 0: PE5(dists6) (60 columns, scale 2^14 fixed: |sin|, |cos| <= 1) + per-point addend
+        {
+            const float dw0 = meta[CH_META_DESCALE + 0];
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) inv[rt] = __fmul_rn(pow2f(-14), dw0);
+            zero_acc();
+            // all 16 weight fragments first, THEN the gathered table rows: the MFMAs wait for the (older) weight loads only
+            chain_mfma_layer<CH_S0, 1>(wsrd, CH_W0, lds, wave, lane, acc, [&]() {
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt) {
+                    const float *trow = a.ptab + (size_t)(pid[rt] < 0 ? 0 : pid[rt]) * a.ldt + col0;
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) tv[rt][c][q] = *reinterpret_cast<const float4 *>(trow + 32 * c + 4 * q);
+                }
+            });
+            float amax[4];
+            activate(0, amax, std::true_type{});
+            publish(1, amax, false);
+        }
+        // ---- layer 1 (block1.2) -> operand of block3.0 = [H2 | extras]
+        {
+            zero_acc();
+            chain_mfma_layer<CH_S1, 0>(wsrd, CH_W1, lds, wave, lane, acc, []() {});
+            float amax[4];
+            activate(1, amax, std::false_type{});
+            publish(2, amax, true);
+        }
+        // ---- layer 2 (block3.0)
+        {
+            zero_acc();
+            chain_mfma_layer<CH_S2, 0>(wsrd, CH_W2, lds, wave, lane, acc, []() {});
+            float amax[4];
+            activate(2, amax, std::false_type{});
+            publish(3, amax, false);
+        }
+        // ---- layer 3 (block3.2) + alpha branch + K-weighted sums
+        {
+            zero_acc();
+            chain_mfma_layer<CH_S3, 0>(wsrd, CH_W3, lds, wave, lane, acc, []() {});
+            float amax[4];
+            activate(3, amax, std::false_type{});
+            float aw[2][16];
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 b = *reinterpret_cast<const float4 *>(meta + 4 * 256 + col0 + 32 * c + 4 * q);
+                    aw[c][4 * q] = b.x; aw[c][4 * q + 1] = b.y; aw[c][4 * q + 2] = b.z; aw[c][4 * q + 3] = b.w;
+                }
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) {
+                float ap = 0.f;
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ap = fmaf(acc[rt][c][r], aw[c][r], ap);
+                ap = __fadd_rn(ap, __shfl_xor(ap, 32));
+                if (h == 0) exch[(32 * rt + j) * 4 + wave] = ap;
+            }
+            __syncthreads();                                               // also: the planes are free for the next tile
+            const float ab = meta[4 * 256 + 256];
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) {
+                // weighted feature sums over the sample's 8 rows = 8 adjacent lanes
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float f = __fmul_rn(acc[rt][c][r], wq[rt]);
+                        f = __fadd_rn(f, __builtin_amdgcn_update_dpp(0.f, f, 0xB1, 0xf, 0xf, false));       // quad_perm [1,0,3,2]
+                        f = __fadd_rn(f, __builtin_amdgcn_update_dpp(0.f, f, 0x4E, 0xf, 0xf, false));       // quad_perm [2,3,0,1]
+                        f = __fadd_rn(f, __builtin_amdgcn_update_dpp(0.f, f, 0x141, 0xf, 0xf, false));      // row_half_mirror
+                        acc[rt][c][r] = f;
+                    }
+                const int s = tile * CH_SAMPLES + 4 * rt + (j >> 3);
+                if ((j & 7) == 0 && s < n_valid) {
+                    float *o = a.X5 + (size_t)s * a.ld5 + col0;
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            *reinterpret_cast<float4 *>(o + 32 * c + 4 * q) = make_float4(acc[rt][c][4 * q], acc[rt][c][4 * q + 1], acc[rt][c][4 * q + 2], acc[rt][c][4 * q + 3]);
+                }
+                if (rt == wave) {
+                    const float4 d4 = *reinterpret_cast<const float4 *>(exch + (32 * rt + j) * 4);
+                    const float d = __fadd_rn(__fadd_rn(d4.x, d4.y), __fadd_rn(d4.z, d4.w));
+                    float sg = __fmul_rn(chain_softplus_m1(__fadd_rn(d, ab)), wq[rt]);
+                    sg = __fadd_rn(sg, __builtin_amdgcn_update_dpp(0.f, sg, 0xB1, 0xf, 0xf, false));
+                    sg = __fadd_rn(sg, __builtin_amdgcn_update_dpp(0.f, sg, 0x4E, 0xf, 0xf, false));
+                    sg = __fadd_rn(sg, __builtin_amdgcn_update_dpp(0.f, sg, 0x141, 0xf, 0xf, false));
+                    if (h == 0 && (j & 7) == 0 && s < n_valid) a.sigma[s] = sg;
+                }
+            }
+            __syncthreads();                                               // exch is rewritten by the next tile's layer 0
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Gather + geometry for the fused chain (NeuralPoints.forward gather neural_points.py:709-720, w2pers :607-613, dists
+// point_aggregators.py:1472-1480, inverse-distance weights :825-833, :1500-1501, x clamp(conf) :1508-1512, positional
+// encoding of the distances :930): one 256-thread block per tile of 16 valid samples writes
+//   xp[tile]  = layer 0's activation operand PE5(dists6) * 2^14, already split into fp16 (h, m) planes in MFMA fragment order,
+//   aux[tile] = per row: point id (-1: empty slot), aggregation weight, block3's 7 extra inputs (:957-971),
+//   X5[s, 256:280] = view-direction encoding of the sample's ray (:909-913),
+// and optionally the reference's `weight` / `conf_coefficient` outputs [R,SR,K].
+struct ChainGatherArgs {
+    const float *xyz, *conf, *pdir, *color;
+    const int32_t *pidx;                                 // [R,SR,8]
+    const float *loc_w, *raydir, *campos, *camrot;
+    const int32_t *vs_item;
+    const unsigned long long *counts;
+    int SR, cap_samples;
+    char *xp, *aux;
+    float *X5; int ld5;
+    float *weight_out, *conf_out;
+};
+
+__device__ __forceinline__ void chain_w2pers(const float *p, const float *campos, const float *camrot, float out[3])
+{
+    const float s0 = __fsub_rn(p[0], campos[0]), s1 = __fsub_rn(p[1], campos[1]), s2 = __fsub_rn(p[2], campos[2]);
+    float c[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+        c[q] = __fadd_rn(__fadd_rn(__fmul_rn(camrot[q], s0), __fmul_rn(camrot[3 + q], s1)), __fmul_rn(camrot[6 + q], s2));
+    out[0] = __fdiv_rn(c[0], c[2]); out[1] = __fdiv_rn(c[1], c[2]); out[2] = c[2];
+}
+
+__global__ __launch_bounds__(256) void chain_gather_kernel(ChainGatherArgs a)
+{
+    __shared__ float s_d[CH_ROWS][8];                    // dists6 per row
+    int n_valid = (int)a.counts[HNR_CNT_SAMPLES_VALID];
+    if (n_valid > a.cap_samples) n_valid = a.cap_samples;
+    const int tile = blockIdx.x;
+    if (tile * CH_SAMPLES >= n_valid) return;
+    const int tid = threadIdx.x;
+    char *aux = a.aux + (size_t)tile * CH_AUX_TILE;
+    if (tid < CH_ROWS) {
+        const int ls = tid >> 3, kk = tid & 7;
+        const int s = tile * CH_SAMPLES + ls;
+        const float cp[3] = {a.campos[0], a.campos[1], a.campos[2]};
+        float cr[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) cr[i] = a.camrot[i];
+        int pid = -1, item = 0;
+        if (s < n_valid) { item = a.vs_item[s]; pid = a.pidx[(size_t)item * 8 + kk]; }
+        float wraw = 0.f, confc = 0.f, ext[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, d6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (pid >= 0) {
+            const float *lw = a.loc_w + (size_t)item * 3;
+            float sp[3], pp[3];
+            chain_w2pers(lw, cp, cr, sp);
+            const float px = a.xyz[3 * (size_t)pid], py = a.xyz[3 * (size_t)pid + 1], pz = a.xyz[3 * (size_t)pid + 2];
+            const float pw[3] = {px, py, pz};
+            chain_w2pers(pw, cp, cr, pp);
+            const float dx = __fsub_rn(px, lw[0]), dy = __fsub_rn(py, lw[1]), dz = __fsub_rn(pz, lw[2]);
+            d6[0] = dx; d6[1] = dy; d6[2] = dz;
+            d6[3] = __fsub_rn(__fmul_rn(pp[0], pp[2]), __fmul_rn(sp[0], sp[2]));
+            d6[4] = __fsub_rn(__fmul_rn(pp[1], pp[2]), __fmul_rn(sp[1], sp[2]));
+            d6[5] = __fsub_rn(pp[2], sp[2]);
+            const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
+            wraw = __fdiv_rn(1.0f, fmaxf(nrm, 1e-6f));
+            confc = fminf(fmaxf(a.conf[pid], 0.0001f), 1.0f);
+            const int ray = item / a.SR;
+            const float vx = a.raydir[3 * (size_t)ray], vy = a.raydir[3 * (size_t)ray + 1], vz = a.raydir[3 * (size_t)ray + 2];
+            const float ddx = a.pdir[3 * (size_t)pid], ddy = a.pdir[3 * (size_t)pid + 1], ddz = a.pdir[3 * (size_t)pid + 2];
+            ext[0] = a.color[3 * (size_t)pid]; ext[1] = a.color[3 * (size_t)pid + 1]; ext[2] = a.color[3 * (size_t)pid + 2];
+            ext[3] = __fsub_rn(ddx, vx); ext[4] = __fsub_rn(ddy, vy); ext[5] = __fsub_rn(ddz, vz);
+            ext[6] = __fadd_rn(__fadd_rn(__fmul_rn(ddx, vx), __fmul_rn(ddy, vy)), __fmul_rn(ddz, vz));
+        }
+        float sum = wraw;
+        sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4);
+        const float w = pid >= 0 ? __fdiv_rn(wraw, fmaxf(sum, 1e-8f)) : 0.f;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) s_d[tid][i] = d6[i];
+        reinterpret_cast<int32_t *>(aux)[tid] = pid;
+        reinterpret_cast<float *>(aux + 512)[tid] = __fmul_rn(w, confc);
+        *reinterpret_cast<float4 *>(aux + 1024 + tid * 32) = make_float4(ext[0], ext[1], ext[2], ext[3]);
+        *reinterpret_cast<float4 *>(aux + 1024 + tid * 32 + 16) = make_float4(ext[4], ext[5], ext[6], 0.f);
+        if (a.weight_out && pid >= 0) { a.weight_out[(size_t)item * 8 + kk] = w; a.conf_out[(size_t)item * 8 + kk] = confc; }
+    } else if (tid < CH_ROWS + CH_SAMPLES * 4) {
+        // view-direction encoding: positional_encoding(viewdirs, 4, ori=True)[3:] = [sin(d*4+f) x12 | cos x12]; 6 values per thread
+        const int t = tid - CH_ROWS, ls = t >> 2, part = t & 3;
+        const int s = tile * CH_SAMPLES + ls;
+        if (s < n_valid) {
+            const int ray = a.vs_item[s] / a.SR;
+            float *o = a.X5 + (size_t)s * a.ld5 + 256;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const int l = part * 6 + i, jj = l % 12, d = jj >> 2, f = jj & 3;
+                const float x = __fmul_rn(a.raydir[3 * (size_t)ray + d], (float)(1 << f));
+                o[l] = l < 12 ? sinf(x) : cosf(x);
+            }
+        }
+    }
+    __syncthreads();
+    // operand image: fragment (k step s, row tile rt, plane): lane (row = 32 rt + (L & 31), k = 16 s + 8 (L >> 5) + e), e = 0..7
+    // = 4 (dist, freq) pairs [sin, cos]; positional_encoding interleaves [sin, cos] per (dim, freq): column 2 (5 d + f) + {0, 1}
+    char *xp = a.xp + (size_t)tile * CH_XP_TILE;
+#pragma unroll
+    for (int s = 0; s < CH_S0; ++s) {
+        const int L = tid & 63, rt = tid >> 6;
+        const int row = 32 * rt + (L & 31), k0 = 16 * s + 8 * (L >> 5);
+        unsigned ph[4], pm[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int p = (k0 >> 1) + e;
+            float sv = 0.f, cv = 0.f;
+            if (p < 30) {
+                const int d = p / 5, f = p - 5 * d;
+                sincosf(__fmul_rn(s_d[row][d], (float)(1 << f)), &sv, &cv);
+            }
+            split2h(__fmul_rn(sv, 16384.f), __fmul_rn(cv, 16384.f), ph[e], pm[e]);
+        }
+        char *dst = xp + s * CH_SLOT + (rt * 2) * 1024 + L * 16;
+        *reinterpret_cast<u32x4 *>(dst) = u32x4{ph[0], ph[1], ph[2], ph[3]};
+        *reinterpret_cast<u32x4 *>(dst + 1024) = u32x4{pm[0], pm[1], pm[2], pm[3]};
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Weight image.  Layer l, k step s, column tile ct, plane p (0: h, 1: m): lane (i = lane & 31, hh = lane >> 5) holds
+// W[n][16 s + 8 hh + e] * 2^sw, e = 0..7, with n = 32 ct + 16 ((i >> 2) & 1) + (i & 3) + 4 (i >> 3): MFMA row i of the A operand
+// lands in accumulator register r = (i & 3) + 4 (i >> 3) of lane half (i >> 2) & 1, so a lane's 16 registers are 16 consecutive
+// output columns.
+struct ChainPackArgs {
+    const float *W[4]; int ldw[4]; int K[4];
+    const float *b[4];
+    const float *alpha_w, *alpha_b;
+    char *out;
+    unsigned *wmax;                    // [4] bit patterns of max |W| per layer
+};
+
+__global__ void chain_wmax_kernel(ChainPackArgs a)
+{
+    const int l = blockIdx.y;
+    float m = 0.f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 256 * a.K[l]; i += gridDim.x * blockDim.x) {
+        const int n = i / a.K[l], k = i - n * a.K[l];
+        m = fmaxf(m, fabsf(a.W[l][(size_t)n * a.ldw[l] + k]));
+    }
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(a.wmax + l, __float_as_uint(m));     // non-negative floats order like their bit patterns
+}
+
+__device__ __forceinline__ int chain_weight_exp(unsigned maxbits)
+{
+    int ex = (int)((maxbits >> 23) & 0xffu);
+    ex = ex < 110 ? 110 : (ex > 160 ? 160 : ex);                               // sw in [-20, 30]
+    return CH_W_EXP + 126 - ex;
+}
+
+__global__ void chain_pack_kernel(ChainPackArgs a)
+{
+    const int l = blockIdx.y;
+    constexpr int steps[4] = {CH_S0, CH_S1, CH_S2, CH_S3};
+    constexpr int base[4] = {CH_W0, CH_W1, CH_W2, CH_W3};
+    const int sw = chain_weight_exp(a.wmax[l]);
+    const float scale = pow2f(sw);
+    const int total = steps[l] * 8 * 64 * 8;                                   // (s, ct, lane, e)
+    float *meta = reinterpret_cast<float *>(a.out + CH_META);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int e = i & 7, ln = (i >> 3) & 63, ct = (i >> 9) & 7, s = i >> 12;
+        const int ii = ln & 31, hh = ln >> 5;
+        const int n = 32 * ct + 16 * ((ii >> 2) & 1) + (ii & 3) + 4 * (ii >> 3), k = 16 * s + 8 * hh + e;
+        const float x = k < a.K[l] ? __fmul_rn(a.W[l][(size_t)n * a.ldw[l] + k], scale) : 0.f;
+        const _Float16 hv = (_Float16)x;
+        const _Float16 mv = (_Float16)__fsub_rn(x, (float)hv);
+        _Float16 *dst = reinterpret_cast<_Float16 *>(a.out + base[l] + (size_t)s * CH_WSTEP + (ct * 2) * 1024 + ln * 16) + e;
+        dst[0] = hv;
+        dst[512] = mv;
+    }
+    if (blockIdx.x == 0) {
+        for (int i = threadIdx.x; i < 256; i += blockDim.x) {
+            meta[l * 256 + i] = a.b[l] ? a.b[l][i] : 0.f;
+            if (l == 0) meta[4 * 256 + i] = a.alpha_w[i];
+        }
+        if (threadIdx.x == 0) {
+            meta[CH_META_DESCALE + l] = pow2f(-sw);
+            if (l == 0) meta[4 * 256 + 256] = a.alpha_b[0];
+        }
+    }
+}
+
+}  // namespace hnr
+
+using namespace hnr;
+
+static int chain_num_cus()
+{
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+        if (n_cu <= 0) n_cu = 256;
+    }
+    return n_cu;
+}
+
+extern "C" int64_t hnr_chain_packed_bytes(void) { return (int64_t)CH_WBYTES + CH_META_FLOATS * 4; }
+
+extern "C" int64_t hnr_chain_workspace_bytes(int cap_samples)
+{
+    if (cap_samples < 0) return -1;
+    const int64_t tiles = ((int64_t)cap_samples + CH_SAMPLES - 1) / CH_SAMPLES;
+    return tiles * (CH_XP_TILE + CH_AUX_TILE);
+}
+
+extern "C" int hnr_chain_pack(const float *d_w_b1_0_dist, int ldw0, const float *d_b_b1_0, const float *d_w_b1_2, const float *d_b_b1_2,
+                              const float *d_w_b3_0, const float *d_b_b3_0, const float *d_w_b3_2, const float *d_b_b3_2,
+                              const float *d_alpha_w, const float *d_alpha_b, void *d_packed, void *stream)
+{
+    if (!d_w_b1_0_dist || !d_w_b1_2 || !d_w_b3_0 || !d_w_b3_2 || !d_alpha_w || !d_alpha_b || !d_packed || ldw0 < 60 || ((uintptr_t)d_packed & 15)) {
+        set_error("hnr_chain_pack: NULL / unaligned pointer or ldw0 < 60");
+        return HNR_ERR_BADARG;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    ChainPackArgs a;
+    a.W[0] = d_w_b1_0_dist; a.ldw[0] = ldw0; a.K[0] = 60; a.b[0] = d_b_b1_0;
+    a.W[1] = d_w_b1_2; a.ldw[1] = 256; a.K[1] = 256; a.b[1] = d_b_b1_2;
+    a.W[2] = d_w_b3_0; a.ldw[2] = 263; a.K[2] = 263; a.b[2] = d_b_b3_0;
+    a.W[3] = d_w_b3_2; a.ldw[3] = 256; a.K[3] = 256; a.b[3] = d_b_b3_2;
+    a.alpha_w = d_alpha_w; a.alpha_b = d_alpha_b;
+    a.out = (char *)d_packed;
+    a.wmax = reinterpret_cast<unsigned *>(a.out + CH_META) + CH_META_WMAX;      // four words of the meta block the pack kernel only reads
+    HNR_HIP_CHECK(hipMemsetAsync(a.wmax, 0, 16, st));
+    chain_wmax_kernel<<<dim3(64, 4), 256, 0, st>>>(a);
+    HNR_LAUNCH_CHECK();
+    chain_pack_kernel<<<dim3(64, 4), 256, 0, st>>>(a);
+    HNR_LAUNCH_CHECK();
+    return HNR_OK;
+}
+
+extern "C" int hnr_chain_gather(const float *d_xyz, const float *d_conf, const float *d_dir, const float *d_color,
+                                const int32_t *d_sample_pidx, const float *d_sample_loc_w, const float *d_raydir, const float *d_campos,
+                                const float *d_camrot, const int32_t *d_vs_item, const int64_t *d_counts, int SR, int K, int cap_samples,
+                                void *d_workspace, float *d_X5, int ld5, float *d_weight_out, float *d_conf_out, void *stream)
+{
+    if (K != 8) { set_error("hnr_chain_gather: the fused chain is built for K = 8 (got %d); use the per-layer path", K); return HNR_ERR_BADARG; }
+    if (cap_samples < 0 || SR <= 0 || ld5 < 280 || (ld5 & 3)) { set_error("hnr_chain_gather: bad sizes (cap_samples=%d SR=%d ld5=%d)", cap_samples, SR, ld5); return HNR_ERR_BADARG; }
+    if (cap_samples == 0) return HNR_OK;
+    if (!d_xyz || !d_conf || !d_dir || !d_color || !d_sample_pidx || !d_sample_loc_w || !d_raydir || !d_campos || !d_camrot || !d_vs_item ||
+        !d_counts || !d_workspace || !d_X5 || ((uintptr_t)d_workspace & 15) || (!d_weight_out != !d_conf_out)) {
+        set_error("hnr_chain_gather: NULL / unaligned pointer");
+        return HNR_ERR_BADARG;
+    }
+    const int tiles = cdiv(cap_samples, CH_SAMPLES);
+    ChainGatherArgs a;
+    a.xyz = d_xyz; a.conf = d_conf; a.pdir = d_dir; a.color = d_color; a.pidx = d_sample_pidx; a.loc_w = d_sample_loc_w;
+    a.raydir = d_raydir; a.campos = d_campos; a.camrot = d_camrot; a.vs_item = d_vs_item;
+    a.counts = reinterpret_cast<const unsigned long long *>(d_counts); a.SR = SR; a.cap_samples = cap_samples;
+    a.xp = (char *)d_workspace; a.aux = (char *)d_workspace + (size_t)tiles * CH_XP_TILE;
+    a.X5 = d_X5; a.ld5 = ld5; a.weight_out = d_weight_out; a.conf_out = d_conf_out;
+    chain_gather_kernel<<<tiles, 256, 0, (hipStream_t)stream>>>(a);
+    HNR_LAUNCH_CHECK();
+    return HNR_OK;
+}
+
+extern "C" int hnr_chain_forward(const void *d_workspace, const float *d_point_table, int ldt, const void *d_packed, const int64_t *d_counts,
+                                 int cap_samples, float slope, float *d_X5, int ld5, float *d_sigma, float *d_dbg, int dbg_layer, void *stream)
+{
+    if (cap_samples < 0 || ldt < 256 || (ldt & 3) || ld5 < 256 || (ld5 & 3) || !(slope > 0.f && slope < 1.f)) {
+        set_error("hnr_chain_forward: bad sizes (cap_samples=%d ldt=%d ld5=%d slope=%g; LeakyReLU slope must be in (0,1))", cap_samples, ldt, ld5, (double)slope);
+        return HNR_ERR_BADARG;
+    }
+    if (cap_samples == 0) return HNR_OK;
+    if (!d_workspace || !d_point_table || !d_packed || !d_counts || !d_X5 || !d_sigma || ((uintptr_t)d_workspace & 15) || ((uintptr_t)d_packed & 15) ||
+        ((uintptr_t)d_point_table & 15) || ((uintptr_t)d_X5 & 15)) {
+        set_error("hnr_chain_forward: NULL / unaligned pointer");
+        return HNR_ERR_BADARG;
+    }
+    const int tiles = cdiv(cap_samples, CH_SAMPLES);
+    ChainArgs a;
+    a.xp = (const char *)d_workspace; a.aux = (const char *)d_workspace + (size_t)tiles * CH_XP_TILE;
+    a.ptab = d_point_table; a.ldt = ldt; a.wimg = (const char *)d_packed;
+    a.counts = reinterpret_cast<const unsigned long long *>(d_counts);
+    a.X5 = d_X5; a.ld5 = ld5; a.sigma = d_sigma; a.slope = slope; a.cap_samples = cap_samples; a.dbg = d_dbg; a.dbg_layer = dbg_layer;
+    const int n_cu = chain_num_cus();
+    const int grid = tiles < n_cu ? tiles : n_cu;
+    hipStream_t st = (hipStream_t)stream;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chain_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS_BYTES));
+        HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chain_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS_BYTES));
+        attr_set = true;
+    }
+    if (d_dbg) chain_kernel<1><<<grid, 256, CH_LDS_BYTES, st>>>(a);
+    else chain_kernel<0><<<grid, 256, CH_LDS_BYTES, st>>>(a);
+    HNR_LAUNCH_CHECK();
+    return HNR_OK;
+}

@@ -68,11 +68,14 @@ class HybridRenderer:
         self._fm_key, self._fm, self._fm_src = None, None, None
         self._pt_key, self._pt, self._pt_src = None, None, None
         self.split_block1 = True          # fold the point-only 224 columns of block1.0 into a per-point table
-        # dense arithmetic of the three 256-wide per-neighbour layers: "bf16x3" = fp32 operands split exactly into three bf16
-        # terms on the bf16 matrix cores (hnr_linear_s3), "f32" = fp32 MFMA (hnr_linear_f32).  Same fp32-class results.
-        self.dense = os.environ.get("HNR_DENSE", "bf16x3")
-        if self.dense not in ("bf16x3", "f32"):
-            raise HnrError("HNR_DENSE must be bf16x3 or f32, got %r" % self.dense)
+        # dense arithmetic of the per-neighbour layers (fp32 in / out, fp32-class error in every mode):
+        #   "f16x2"  (default) the whole per-neighbour chain in ONE kernel (hnr_chain_forward, K = 8): operands split into two fp16
+        #            terms, three 16-bit MFMAs per product, activations never leave the CU;
+        #   "bf16x3" one launch per layer, fp32 operands split exactly into three bf16 terms (hnr_linear_s3);
+        #   "f32"    one launch per layer on fp32 MFMA (hnr_linear_f32).
+        self.dense = os.environ.get("HNR_DENSE", "f16x2")
+        if self.dense not in ("f16x2", "bf16x3", "f32"):
+            raise HnrError("HNR_DENSE must be f16x2, bf16x3 or f32, got %r" % self.dense)
         self.split_merge = True           # multiply the colour-feature columns of aux_merge_weight_block.0 once per sample
         self.last_counts = None
         if getattr(opt, "which_render_func", "radiance") != "radiance" or getattr(opt, "which_blend_func", "alpha") != "alpha" \
@@ -130,6 +133,27 @@ class HybridRenderer:
           with T("plan_gather"):
             _lib.check(L.hnr_sample_plan(p(work), p(pidx), p(counts), K, R * SR, p(vs_item), p(vs_off), p(vs_cnt), n_valid, n_rows,
                                          p(scratch), p(overflow), st()), "hnr_sample_plan")
+          fused = self.dense == "f16x2" and K == 8
+          if fused:
+            # the fused chain: gather + geometry + PE -> operand image, then block1 -> block3 -> alpha + K-sums in one kernel
+            ws = torch.empty((int(L.hnr_chain_workspace_bytes(n_valid)),), dtype=torch.uint8, device=dev)
+            X5 = _f32((n_valid, 280), dev)
+            sigma = _f32((n_valid,), dev)
+            w_out = c_out = None
+            if want_weights:
+                w_out = torch.zeros((R, SR, K), dtype=torch.float32, device=dev)
+                c_out = cloud.conf[0].clamp(0.0001, 1.0).expand(R, SR, K).contiguous()
+            ptab = self.point_table(cloud)
+            with T("chain_gather"):
+                _lib.check(L.hnr_chain_gather(p(cloud.xyz), p(cloud.conf), p(cloud.dir), p(cloud.color), p(pidx), p(loc_w), p(raydir),
+                                              p(campos), p(camrot), p(vs_item), p(counts), SR, K, n_valid, p(ws), p(X5), 280,
+                                              p(w_out) if want_weights else None, p(c_out) if want_weights else None, st()),
+                           "hnr_chain_gather")
+            with T("chain"):
+                _lib.check(L.hnr_chain_forward(p(ws), p(ptab), int(ptab.stride(0)), p(self.agg.packed_chain()), p(counts), n_valid,
+                                               float(pk["slope"]), p(X5), 280, p(sigma), None, 0, st()), "hnr_chain_forward")
+            del ws
+          else:
             split = self.split_block1
             A = _f32((n_rows, 256 if split else 284), dev)       # (X1,) later H3
             B = _f32((n_rows, 256), dev)       # H1, later H4
@@ -149,30 +173,31 @@ class HybridRenderer:
                                          p(w_out) if want_weights else None, p(c_out) if want_weights else None,
                                          p(row_pid) if split else None, st()),
                        "hnr_gather_rows")
+            sl = pk["slope"]
+            with T("mlp_neighbour"):
+              if split:
+                  pk["b1_dist"].gather_add(Xd, ptab, row_pid, out=B, act=True, slope=sl, K=60)   # 60 -> 256 (+ per-point addend)
+              else:
+                  pk["b1"][0](A, out=B, act=True, slope=sl)                   # 284 -> 256
+              if self.dense == "bf16x3":
+                  ps = self.agg.packed_split()
+                  l12, l30, l32 = ps["b1_2"], ps["b3_0"], ps["b3_2"]
+              else:
+                  l12, l30, l32 = pk["b1"][1], pk["b3"][0], pk["b3"][1]
+              with T("dense_b1_2"):
+                  l12(B, out=C, act=True, slope=sl)                           # 256 -> 256 into X3[:, :256]
+              H3 = A[:, :256]
+              with T("dense_b3_0"):
+                  l30(C, out=H3, act=True, slope=sl, K=263)                   # 263 -> 256
+              with T("dense_b3_2"):
+                  l32(H3, out=B, act=True, slope=sl)                          # 256 -> 256  (H4)
+            with T("ksum"):
+              X5 = _f32((n_valid, 280), dev)
+              sigma = _f32((n_valid,), dev)
+              _lib.check(L.hnr_ksum(p(B), 256, p(wagg), p(pk["alpha_w"]), p(pk["alpha_b"]), p(vs_item), p(vs_off), p(vs_cnt),
+                                    p(raydir), p(counts), SR, n_valid, p(X5), 280, p(sigma), st()), "hnr_ksum")
+            del A, B, C, Xd
           sl = pk["slope"]
-          with T("mlp_neighbour"):
-            if split:
-                pk["b1_dist"].gather_add(Xd, ptab, row_pid, out=B, act=True, slope=sl, K=60)   # 60 -> 256 (+ per-point addend)
-            else:
-                pk["b1"][0](A, out=B, act=True, slope=sl)                   # 284 -> 256
-            if self.dense == "bf16x3":
-                ps = self.agg.packed_split()
-                l12, l30, l32 = ps["b1_2"], ps["b3_0"], ps["b3_2"]
-            else:
-                l12, l30, l32 = pk["b1"][1], pk["b3"][0], pk["b3"][1]
-            with T("dense_b1_2"):
-                l12(B, out=C, act=True, slope=sl)                           # 256 -> 256 into X3[:, :256]
-            H3 = A[:, :256]
-            with T("dense_b3_0"):
-                l30(C, out=H3, act=True, slope=sl, K=263)                   # 263 -> 256
-            with T("dense_b3_2"):
-                l32(H3, out=B, act=True, slope=sl)                          # 256 -> 256  (H4)
-          with T("ksum"):
-            X5 = _f32((n_valid, 280), dev)
-            sigma = _f32((n_valid,), dev)
-            _lib.check(L.hnr_ksum(p(B), 256, p(wagg), p(pk["alpha_w"]), p(pk["alpha_b"]), p(vs_item), p(vs_off), p(vs_cnt),
-                                  p(raydir), p(counts), SR, n_valid, p(X5), 280, p(sigma), st()), "hnr_ksum")
-          del A, B, C, Xd
           with T("mlp_colorfeat"):
             T1, T2 = _f32((n_valid, 128), dev), _f32((n_valid, 128), dev)
             pk["cf"][0](X5, out=T1, act=True, slope=sl)

@@ -281,6 +281,36 @@ int hnr_merge(const float *d_X6, int ld6, const float *d_Hm, int ldh, const floa
               const float *d_vmask, const float *d_frame_w, const float *d_CF, int ldcf, const int64_t *d_counts, int V,
               int cap_samples, float *d_X7, int ld7, const uint8_t *d_ray_drop, const int32_t *d_vs_item, int SR, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * The per-neighbour chain of PointAggregator.viewmlp fused into one kernel (csrc/chain.hip): block1 (:948), block3 on
+ * [block1_out | colour | dir - viewdir | dir.viewdir] (:957-972), alpha_branch + softplus(x - 1) (:1005, :471-476) and the
+ * K-weighted sums per shading sample (:1008-1026).  Replaces hnr_gather_rows + four hnr_linear_* launches + hnr_ksum of the
+ * per-layer path for K = 8: activations stay on chip, only [S_v, 256] feature sums and [S_v] densities are written.
+ * fp32 in / fp32 out; dense arithmetic: every operand split into two fp16 terms (22 bits), three 16-bit MFMAs per product,
+ * fp32 accumulation, exact power-of-two scaling per activation row / per layer (fp32-class error, tests/test_chain_gpu.py).
+ *
+ * hnr_chain_pack: the four nn.Linear weights -> the kernel's image, once per checkpoint.  d_w_b1_0_dist = block1.0.weight[:, 224:284]
+ *   (row stride ldw0; the point-only columns [:, :224] go into the per-point table, hnr_point_rows + hnr_linear_f32), d_w_b1_2
+ *   [256,256], d_w_b3_0 [256,263], d_w_b3_2 [256,256] contiguous, biases [256], alpha_branch.0 weight [256] / bias [1].
+ * hnr_chain_gather: gather + geometry + positional encoding of the distances for the valid samples d_vs_item[0 .. n_valid)
+ *   (n_valid = d_counts[HNR_CNT_SAMPLES_VALID], read on the device; cap_samples bounds it) into d_workspace
+ *   (hnr_chain_workspace_bytes(cap_samples)); also d_X5[s, 256:280] = view-direction encoding (:909-913) and, optionally, the
+ *   reference's `weight` / `conf_coefficient` outputs [R,SR,K] (written for valid neighbour slots only).
+ * hnr_chain_forward: d_X5[s, 0:256] = sum_k w_k block3(...)_k, d_sigma[s] = sum_k w_k softplus(alpha_k - 1).
+ *   d_point_table [N, ldt >= 256] = [emb | PE3(emb)] block1.0.weight[:, :224]^T.  d_dbg (probe, may be NULL): the post-activation
+ *   output of layer dbg_layer (0..3) as [rows = 8 per valid sample, 256]. */
+int64_t hnr_chain_packed_bytes(void);
+int64_t hnr_chain_workspace_bytes(int cap_samples);
+int hnr_chain_pack(const float *d_w_b1_0_dist, int ldw0, const float *d_b_b1_0, const float *d_w_b1_2, const float *d_b_b1_2,
+                   const float *d_w_b3_0, const float *d_b_b3_0, const float *d_w_b3_2, const float *d_b_b3_2,
+                   const float *d_alpha_w, const float *d_alpha_b, void *d_packed, void *stream);
+int hnr_chain_gather(const float *d_xyz, const float *d_conf, const float *d_dir, const float *d_color,
+                     const int32_t *d_sample_pidx, const float *d_sample_loc_w, const float *d_raydir, const float *d_campos,
+                     const float *d_camrot, const int32_t *d_vs_item, const int64_t *d_counts, int SR, int K, int cap_samples,
+                     void *d_workspace, float *d_X5, int ld5, float *d_weight_out, float *d_conf_out, void *stream);
+int hnr_chain_forward(const void *d_workspace, const float *d_point_table, int ldt, const void *d_packed, const int64_t *d_counts,
+                      int cap_samples, float slope, float *d_X5, int ld5, float *d_sigma, float *d_dbg, int dbg_layer, void *stream);
+
 /* Residual + color_final_block + sigmoid*1.002-0.001 (:1294-1295, :1334, :478-482), scattered with sigma into
  * d_decoded [R*SR,4] (pre-zeroed by the caller; :1337-1338). */
 int hnr_final_color(const float *d_Y, int ldy, const float *d_CF, int ldcf, const float *d_w_fin, const float *d_b_fin,
