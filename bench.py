@@ -114,11 +114,14 @@ def render_frame(rnd, cloud, cam, sc, chunk, timers=None):
     return cols[0] if len(cols) == 1 else torch.cat(cols, dim=0), out
 
 
+TRAFFIC_JSON = "r02_traffic.json"
+
+
 def pmc_traffic():
     """HBM bytes per launch from the rocprofv3 PMC passes kept under profiles/ (FETCH_SIZE / WRITE_SIZE cannot be read
     from inside the process; the passes are re-collected with tools/collect_traffic.py whenever the kernels change)."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["kernels"]
+        d = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_JSON)))["kernels"]
     except Exception:
         return {}
     return d
@@ -311,6 +314,7 @@ def main():
         roof, roof_q = None, None
         pmc = pmc_traffic() if (int(args.points) == 2000000 and args.scene == "scene0241" and args.chunk <= 0) else {}
         split = getattr(rnd, "dense", "f32") == "bf16x3"
+        fused = getattr(rnd, "dense", "f32") == "f16x2" and opt.K == 8
         # the per-neighbour layers: bf16x3 -> three linear_s3w_kernel launches (block1.2, block3.0, block3.2) + the fp32-MFMA K=60
         # layer with its gathered addend; f32 -> four linear_f32_kernel launches
         kname = "linear_s3w_kernel" if split else "linear_f32_kernel<2, 2, 1, 0, 4"
@@ -327,7 +331,33 @@ def main():
             ms_3 = sum(stage_ms.get(k, 0.0) for k in ("dense_b1_2", "dense_b3_0", "dense_b3_2"))
             # ALGORITHMIC flops (271 104 MAC per valid neighbour for block1 + block3)
             flops_nb = 2.0 * n_rows * 256 * (284 + 256 + 263 + 256)
-            if split and ms_3 > 0:
+            ms_ch = stage_ms.get("chain", 0.0)
+            if fused and ms_ch > 0:
+                # dominant kernel: the fused per-neighbour chain (csrc/chain.hip), ONE launch per frame.  Rows are padded to K = 8 slots
+                # per valid sample and to whole 128-row tiles; every fp32 product is issued as THREE fp16 MFMA products (two-term
+                # operand split), K rounded up to 16 per layer (60 -> 64, 263 -> 272).
+                rows_pad = 128 * ((n_valid + 15) // 16)
+                issued = 3.0 * 2.0 * rows_pad * 256 * (64 + 256 + 272 + 256)
+                alg = 2.0 * n_rows * 256 * (60 + 256 + 263 + 256) + 2.0 * n_rows * 256          # executed layers + alpha branch (SURVEY 8d counts 284 columns
+                ach = issued / (ms_ch * 1e-3) / 1e12                                             # for block1.0: 224 of them live in the per-point table)
+                t_ch = [v for k, v in pmc.items() if "chain_kernel" in k]
+                roof = dict(kernel="chain_kernel<4,0>: block1 -> block3 -> alpha + K-sums fused (1 launch, %d valid neighbour rows in %d padded rows)" % (n_rows, rows_pad),
+                            bound="mfma", achieved=round(ach, 1), peak=BF16_MFMA_PEAK_TF, unit="TFLOP/s", frac=round(ach / BF16_MFMA_PEAK_TF, 4),
+                            frac_issued=round(ach / BF16_MFMA_PEAK_TF, 4),
+                            frac_algorithmic=round(alg / (ms_ch * 1e-3) / 1e12 / BF16_MFMA_PEAK_TF, 4),
+                            traffic=int(t_ch[0]["hbm_bytes"]) if t_ch else None,
+                            traffic_source=("profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)" % TRAFFIC_JSON) if t_ch else None,
+                            flops_per_launch=issued, avg_launch_ms=round(ms_ch, 4),
+                            fp32_equivalent_tflops=round(alg / (ms_ch * 1e-3) / 1e12, 2),
+                            algorithmic_flops_per_launch=alg,
+                            algorithmic_bytes_per_launch=int(n_rows * 168 + n_valid * 1028),
+                            note="achieved = 16-bit MFMA flops issued (3 per fp32 product: wm*xh + wh*xm + wh*xh, fp16 two-term split with exact power-of-two "
+                                 "row / layer scales, fp32 accumulate) / HIP-event time of the launch, against the 2.5 PFLOP/s dense 16-bit peak; "
+                                 "frac_algorithmic = 2 M N K fp32 flops of the four layers on the VALID rows / time / the same peak; algorithmic bytes = "
+                                 "168 B per valid neighbour (SURVEY 8d) + 1028 B of sums per valid sample; padding to 8 slots per sample costs "
+                                 "%.1f %% extra rows" % (100.0 * (rows_pad / max(n_rows, 1) - 1.0)),
+                            neighbour_stage=dict(chain_ms=round(ms_ch, 3), gather_ms=round(stage_ms.get("chain_gather", 0.0), 3)))
+            elif split and ms_3 > 0:
                 # dominant kernel: the split-bf16 dense layer.  Algorithmic fp32 flops of the three layers = 2 M N K; the kernel
                 # issues SIX bf16 MFMA products per fp32 product (exact 3-way operand split, csrc/linear_s3.hip), K rounded up to 16.
                 alg = 2.0 * n_rows * 256 * (256 + 263 + 256)
@@ -336,7 +366,7 @@ def main():
                 roof = dict(kernel="linear_s3w_kernel<16|17,1,0> (block1.2, block3.0, block3.2: 3 launches, M=%d rows, N=256)" % n_rows, bound="mfma",
                             achieved=round(ach, 1), peak=BF16_MFMA_PEAK_TF, unit="TFLOP/s", frac=round(ach / BF16_MFMA_PEAK_TF, 4),
                             traffic=int(t_lin["hbm_bytes"]) if t_lin else None,
-                            traffic_source="profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)" if t_lin else None,
+                            traffic_source=("profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)" % TRAFFIC_JSON) if t_lin else None,
                             flops_per_launch=issued / 3, avg_launch_ms=round(ms_3 / 3, 4),
                             fp32_equivalent_tflops=round(alg / (ms_3 * 1e-3) / 1e12, 2),
                             algorithmic_bytes_per_launch=int(n_rows * (256 + 256) * 4),
@@ -355,7 +385,7 @@ def main():
                 roof = dict(kernel="linear_f32_kernel<2,2,1,0,4,*> (block1+block3, 4 launches, M=%d rows)" % n_rows, bound="mfma",
                             achieved=round(ach, 2), peak=F32_MFMA_PEAK_TF, unit="TFLOP/s", frac=round(ach / F32_MFMA_PEAK_TF, 4),
                             traffic=int(t_lin["hbm_bytes"]) if t_lin else None,
-                            traffic_source="profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)" if t_lin else None,
+                            traffic_source=("profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)" % TRAFFIC_JSON) if t_lin else None,
                             flops_per_launch=flops_nb / 4, avg_launch_ms=round(ms_nb / 4, 4),
                             executed_tflops=round(flops_exec / (ms_nb * 1e-3) / 1e12, 2),
                             note="achieved = algorithmic flops / time; executed_tflops = MFMA flops actually issued / time")
@@ -367,7 +397,7 @@ def main():
                 roof_q = dict(kernel="hnr_march_query: march_kernel + worklist scans + knn3_kernel<8>", bound="hbm", achieved=round(ach, 1),
                               peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
                               traffic=int(sum(v["hbm_bytes"] for v in t_q)) if len(t_q) == 2 else None,
-                              traffic_source="profiles/r01_traffic.json (march_kernel + knn3_kernel, bytes per launch)" if len(t_q) == 2 else None,
+                              traffic_source=("profiles/%s (march_kernel + knn kernel, bytes per launch)" % TRAFFIC_JSON) if len(t_q) == 2 else None,
                               algorithmic_bytes=int(alg), avg_launch_ms=round(ms_q, 4),
                               per_ray=dict(samples=round(s_all / R, 2), cells_per_sample=round(cells / max(s_all, 1), 2),
                                            candidates_per_sample=round(cand / max(s_all, 1), 2)))
@@ -391,7 +421,7 @@ def main():
             "metric": "rays/sec (fwd render) scene0241_01 at 1/2/4/8 GPU; PSNR delta vs ref",
             "value": R_job * args.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": "f32", "dense_arithmetic": ("fp32 MFMA (v_mfma_f32_32x32x2_f32)" if getattr(rnd, "dense", "f32") == "f32" else "256-wide per-neighbour layers: fp32 operands split EXACTLY into 3 bf16 terms, 6 bf16 MFMAs per product, fp32 accumulate (fp32-class error, tests/test_linear_gpu.py); all other layers fp32 MFMA"), "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: ranks share GPUs, gloo collectives -- not a measurement)",
+            "dtype": "f32", "dense_arithmetic": {"f32": "fp32 MFMA (v_mfma_f32_32x32x2_f32)", "bf16x3": "256-wide per-neighbour layers: fp32 operands split EXACTLY into 3 bf16 terms, 6 bf16 MFMAs per product, fp32 accumulate (fp32-class error, tests/test_linear_gpu.py); all other layers fp32 MFMA", "f16x2": "per-neighbour chain fused in one kernel: fp32 operands split into 2 fp16 terms under exact power-of-two row / layer scales, 3 fp16 MFMAs per product, fp32 accumulate (error vs fp64 at or below the fp32-MFMA path's, tests/test_chain_gpu.py); all other layers fp32 MFMA"}[getattr(rnd, "dense", "f32")], "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: ranks share GPUs, gloo collectives -- not a measurement)",
             "config": {"workload": "%s synthetic scene (SURVEY 8d): %d points, %dx%d frame margin %d = %d rays per step (%s), "
                                    "SR=%d K=%d P=%d max_o=%d D=%d, 4 reference views %dx%d, hybrid viewmlp forward (query+gather+aggregate+composite); "
                                    "random-init weights with alpha_branch.0 rescaled (weight x30, bias = 30) so that opacities spread over (0,1)"

@@ -42,9 +42,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int CH_ROWS = 128;                       // neighbour rows per tile
-constexpr int CH_SAMPLES = 16;                     // shading samples per tile
-constexpr int CH_SLOT = 8192;                      // LDS bytes per k step of activation planes: [row tile 4][plane 2][64 lanes][16 B]
+// a GROUP = 32 rows = one MFMA row tile = 4 shading samples x 8 slots
 constexpr int CH_WSTEP = 16384;                    // weight image bytes per k step: [column tile 8][plane 2][64 lanes][16 B]
 constexpr int CH_S0 = 4, CH_S1 = 16, CH_S2 = 17, CH_S3 = 16;      // k steps of the four layers (K = 60, 256, 263, 256)
 constexpr int CH_W0 = 0, CH_W1 = CH_S0 * CH_WSTEP, CH_W2 = CH_W1 + CH_S1 * CH_WSTEP, CH_W3 = CH_W2 + CH_S2 * CH_WSTEP;
@@ -52,12 +50,14 @@ constexpr int CH_WBYTES = CH_W3 + CH_S3 * CH_WSTEP;               // 53 k steps 
 constexpr int CH_META = CH_WBYTES;                 // floats after the image: bias[4][256], alpha_w[256], alpha_b, descale_w[4], max|W| bits[4], pad
 constexpr int CH_META_DESCALE = 4 * 256 + 256 + 1, CH_META_WMAX = CH_META_DESCALE + 4;
 constexpr int CH_META_FLOATS = CH_META_WMAX + 4 + 3;
-constexpr int CH_XP_TILE = CH_S0 * CH_SLOT;        // bytes of one tile's layer-0 operand image (32 KiB)
-constexpr int CH_AUX_TILE = 128 * 4 + 128 * 4 + 128 * 8 * 4;      // pid[128] i32, wagg[128] f32, ext[128][8] f32 = 5 KiB
-constexpr int CH_LDS_EXCH = 17 * CH_SLOT;          // float[128][4] exchange area behind the 17 plane slots
-constexpr int CH_LDS_BYTES = CH_LDS_EXCH + 128 * 4 * 4;
+constexpr int CH_XP_GROUP = CH_S0 * 2048;          // bytes of one group's layer-0 operand image: [k step 4][plane 2][64 lanes][16 B] = 8 KiB
+constexpr int CH_AUX_GROUP = 32 * 4 + 32 * 4 + 32 * 8 * 4;        // pid[32] i32, wagg[32] f32, ext[32][8] f32 = 1280 B
 constexpr int CH_ACT_EXP = 15;                     // a row's maximum is scaled into [2^14, 2^15)
 constexpr int CH_W_EXP = 14;                       // a layer's largest weight is scaled into [2^13, 2^14)
+// workgroup tile = RT groups; LDS: 17 k-step slots of [row tile RT][plane 2][64 lanes][16 B], then the float[32 RT][4] exchange area
+constexpr int ch_slot(int RT) { return RT * 2048; }
+constexpr int ch_lds_exch(int RT) { return 17 * ch_slot(RT); }
+constexpr int ch_lds_bytes(int RT) { return ch_lds_exch(RT) + 32 * RT * 4 * 4; }
 
 // (x0, x1) -> packed fp16 pairs h, m with x = h + m + O(2^-22 |x|); round-to-nearest-even
 __device__ __forceinline__ void split2h(float x0, float x1, unsigned &ph, unsigned &pm)
@@ -80,8 +80,8 @@ __device__ __forceinline__ int row_scale_exp(float m)
 }
 
 struct ChainArgs {
-    const char *xp;                    // [tiles][CH_XP_TILE] layer-0 operand image (chain_gather_kernel)
-    const char *aux;                   // [tiles][CH_AUX_TILE]
+    const char *xp;                    // [groups][CH_XP_GROUP] layer-0 operand image (chain_gather_kernel)
+    const char *aux;                   // [groups][CH_AUX_GROUP]
     const float *ptab; int ldt;        // per-point addend of block1.0: [N, ldt >= 256]
     const char *wimg;                  // packed weights (hnr_chain_pack)
     const unsigned long long *counts;  // device counters of the query (n_valid samples)
@@ -90,19 +90,25 @@ struct ChainArgs {
     float slope;
     int cap_samples;
     float *dbg; int dbg_layer;         // probe: post-activation output of layer dbg_layer -> [rows, 256]
+    int skew;                          // RT = 2: the second half of the grid (the CUs' second workgroups) starts skew x 64 cycles late
 };
 
-// one dense layer of the tile: acc[rt][c] (+)= W[64 wave + 32 c .. +31, :] * X[32 rt .. +31, :]^T over S k steps
-template <int S, int PRELOAD_ALL, class Mid>
-__device__ __forceinline__ void chain_mfma_layer(__amdgpu_buffer_rsrc_t wsrd, int wbase, const char *lds, int wave, int lane, f32x16 (&acc)[4][2], Mid mid)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// one dense layer of the tile: acc[rt][c] (+)= W[64 wave + 32 c .. +31, :] * X[32 rt .. +31, :]^T over S k steps.
+// PD = prefetch distance of the weight fragments in k steps (ring of PD + 1); PRELOAD_ALL: all S steps up front (layer 0).
+template <int RT, int S, int PRELOAD_ALL, class Mid>
+__device__ __forceinline__ void chain_mfma_layer(__amdgpu_buffer_rsrc_t wsrd, int wbase, const char *lds, int wave, int lane, f32x16 (&acc)[RT][2], Mid mid)
 {
+    constexpr int SLOT = ch_slot(RT);
+    constexpr int PD = RT >= 4 ? 2 : 3;
     // fragment (s, ct = 2 wave + c, plane p) at s * CH_WSTEP + (c * 2 + p) * 1024 of the layer image; the per-lane part is ONE
     // 32-bit offset beside the uniform buffer descriptor, so no load needs a 64-bit address register pair
     const unsigned woff = (unsigned)(2 * wave) * 2048u + (unsigned)lane * 16u;
     asm volatile("" : "+s"(wbase));                                       // per-tile opaque: the k-step offsets are s_add'ed here, not hoisted out of the tile loop (SGPR spills)
-    const char *bp = lds + lane * 16;                                     // fragment (s, rt, plane p) at s * CH_SLOT + (rt * 2 + p) * 1024
-    constexpr int NW = PRELOAD_ALL ? S : 3;
-    u32x4 wf[NW][2][2], bf[2][4][2];
+    const char *bp = lds + lane * 16;                                     // fragment (s, rt, plane p) at s * SLOT + (rt * 2 + p) * 1024
+    constexpr int NW = PRELOAD_ALL ? S : PD + 1;
+    u32x4 wf[NW][2][2], bf[2][RT][2];
     auto load_w = [&](int slot, int s) {
 #pragma unroll
         for (int c = 0; c < 2; ++c)
@@ -111,16 +117,16 @@ __device__ __forceinline__ void chain_mfma_layer(__amdgpu_buffer_rsrc_t wsrd, in
     };
     auto load_b = [&](int slot, int s) {
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt)
+        for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-            for (int p = 0; p < 2; ++p) bf[slot][rt][p] = *reinterpret_cast<const u32x4 *>(bp + s * CH_SLOT + (rt * 2 + p) * 1024);
+            for (int p = 0; p < 2; ++p) bf[slot][rt][p] = *reinterpret_cast<const u32x4 *>(bp + s * SLOT + (rt * 2 + p) * 1024);
     };
     if (PRELOAD_ALL) {
 #pragma unroll
         for (int s = 0; s < S; ++s) load_w(s, s);
     } else {
-        load_w(0, 0);
-        if (S > 1) load_w(1, 1);
+#pragma unroll
+        for (int s = 0; s < PD && s < S; ++s) load_w(s, s);
     }
     __builtin_amdgcn_sched_barrier(0);
     mid();                                                                // loads the caller wants queued BEHIND the first weight fragments
@@ -128,33 +134,33 @@ __device__ __forceinline__ void chain_mfma_layer(__amdgpu_buffer_rsrc_t wsrd, in
     load_b(0, 0);
 #pragma unroll
     for (int s = 0; s < S; ++s) {
-        if (!PRELOAD_ALL && s + 2 < S) load_w((s + 2) % 3, s + 2);
+        if (!PRELOAD_ALL && s + PD < S) load_w((s + PD) % (PD + 1), s + PD);
         if (s + 1 < S) load_b((s + 1) & 1, s + 1);
-        const int ws = PRELOAD_ALL ? s : s % 3, bs = s & 1;
+        const int ws = PRELOAD_ALL ? s : s % (PD + 1), bs = s & 1;
 #define CH_W(c, p) __builtin_bit_cast(f16x8, wf[ws][c][p])
 #define CH_X(rt, p) __builtin_bit_cast(f16x8, bf[bs][rt][p])
-        // smallest terms first; 8 independent accumulators between two MFMAs on the same one
+        // smallest terms first; 2 RT independent accumulators between two MFMAs on the same one
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt)
+        for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int c = 0; c < 2; ++c) acc[rt][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(CH_W(c, 1), CH_X(rt, 0), acc[rt][c], 0, 0, 0);
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt)
+        for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int c = 0; c < 2; ++c) acc[rt][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(CH_W(c, 0), CH_X(rt, 1), acc[rt][c], 0, 0, 0);
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt)
+        for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int c = 0; c < 2; ++c) acc[rt][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(CH_W(c, 0), CH_X(rt, 0), acc[rt][c], 0, 0, 0);
 #undef CH_W
 #undef CH_X
-        // issue order inside the k step: the 8 fragment reads of step s+1 and the 4 weight loads of step s+2 go out under the
+        // issue order inside the k step: the fragment reads of step s+1 and the 4 weight loads of step s+PD go out under the
         // FIRST MFMAs (left alone, hipcc sinks the reads to the end of the step and the next step's first MFMA waits for LDS)
         if (s + 1 < S) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+            for (int i = 0; i < 2 * RT; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
         }
-        if (!PRELOAD_ALL && s + 2 < S) {
+        if (!PRELOAD_ALL && s + PD < S) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
         }
@@ -168,22 +174,27 @@ __device__ __forceinline__ float chain_softplus_m1(float x)
     return y > 20.f ? y : log1pf(expf(y));
 }
 
-template <int DBG>
-__global__ __launch_bounds__(256, 1) void chain_kernel(ChainArgs a)
+// RT = 4: one 128-row workgroup per CU (one wave per SIMD, <= 512 registers).  RT = 2: two 64-row workgroups per CU (<= 256
+// registers each): they drift out of phase, so one's epilogue (VALU + LDS stores + barriers) runs under the other's MFMAs; the
+// price is that each streams the whole weight image for half as many rows.
+template <int RT, int DBG>
+__global__ __launch_bounds__(256, RT >= 4 ? 1 : 2) void chain_kernel(ChainArgs a)
 {
+    constexpr int SLOT = ch_slot(RT), ROWS = 32 * RT, SAMPLES = 4 * RT;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, j = lane & 31;
     int n_valid = (int)a.counts[HNR_CNT_SAMPLES_VALID];
     if (n_valid > a.cap_samples) n_valid = a.cap_samples;
-    const int n_tiles = (n_valid + CH_SAMPLES - 1) / CH_SAMPLES;
+    const int n_tiles = (n_valid + SAMPLES - 1) / SAMPLES;
     const float *meta = reinterpret_cast<const float *>(a.wimg + CH_META);
     const __amdgpu_buffer_rsrc_t wsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(a.wimg), 0, CH_WBYTES, 0x00020000);
-    float *exch = reinterpret_cast<float *>(lds + CH_LDS_EXCH);            // [row 128][wave 4]
+    float *exch = reinterpret_cast<float *>(lds + ch_lds_exch(RT));        // [row][wave 4]
     const int col0 = 64 * wave + 16 * h;                                   // this lane's columns: col0 + 32 c + r
+    const f32x2 slope2 = {a.slope, a.slope};
 
     // the extras k step (slot 16) carries 7 columns: its k = 8..15 half (lanes 32..63 of every fragment) stays zero
-    for (int i = tid; i < 8 * 32; i += 256)
-        *reinterpret_cast<u32x4 *>(lds + 16 * CH_SLOT + (i >> 5) * 1024 + (32 + (i & 31)) * 16) = u32x4{0u, 0u, 0u, 0u};
+    for (int i = tid; i < 2 * RT * 32; i += 256)
+        *reinterpret_cast<u32x4 *>(lds + 16 * SLOT + (i >> 5) * 1024 + (32 + (i & 31)) * 16) = u32x4{0u, 0u, 0u, 0u};
 
     // XCD-aware tile order: block b runs on XCD b & 7; every XCD walks one contiguous eighth of the tiles so that
     // neighbouring samples (which share points, i.e. rows of the per-point table) meet in one L2
@@ -191,93 +202,125 @@ __global__ __launch_bounds__(256, 1) void chain_kernel(ChainArgs a)
     const int per = (n_tiles + 7) / 8, t_lo = xcd * per, t_hi = (t_lo + per < n_tiles) ? t_lo + per : n_tiles;
     const bool xcd_order = gridDim.x >= 8;
 
+    // Two workgroups share a CU (RT = 2) and run the same phase sequence; started together they stay in phase -- both in their
+    // MFMA loops (each at half rate), then both in their epilogues (matrix pipe idle).  The second half of the grid (the second
+    // workgroup of every CU, by dispatch order) starts half a tile late, so one's epilogue runs under the other's MFMAs.
+    if (RT < 4 && a.skew > 0 && blockIdx.x >= gridDim.x / 2) {
+        for (int i = 0; i < a.skew; i += 64) __builtin_amdgcn_s_sleep(64);
+    }
+    // DBG == 2: per-phase cycle counts of block 0 (s_memtime) -> a.dbg as long long [wave][16]
+    long long tm[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0, t_start = 0, w_start = 0;
+    int n_my = 0;
+    if (DBG == 2) { t_start = t_prev = clock64(); w_start = wall_clock64(); }
+#define CH_STAMP(i_) do { if (DBG == 2) { const long long t_ = clock64(); tm[i_] += t_ - t_prev; t_prev = t_; } } while (0)
     for (int tile = xcd_order ? t_lo + bi : (int)blockIdx.x; tile < (xcd_order ? t_hi : n_tiles); tile += xcd_order ? nb : (int)gridDim.x) {
         // ---- tile prologue: layer-0 operand image -> LDS slots 0..3; per-row scalars
         {
-            const char *src = a.xp + (size_t)tile * CH_XP_TILE;
-            u32x4 v[8];
+            // 1-KiB chunk c = (row tile rt = c >> 3, k step s = (c >> 1) & 3, plane p = c & 1); a wave moves one chunk per pass
+            const char *src = a.xp + (size_t)tile * RT * CH_XP_GROUP + lane * 16;
+            u32x4 v[2 * RT];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const u32x4 *>(src + (i * 256 + tid) * 16);
+            for (int i = 0; i < 2 * RT; ++i) v[i] = *reinterpret_cast<const u32x4 *>(src + (i * 4 + wave) * 1024);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) *reinterpret_cast<u32x4 *>(lds + (i * 256 + tid) * 16) = v[i];
+            for (int i = 0; i < 2 * RT; ++i) {
+                const int c = i * 4 + wave, rt = c >> 3, sp = c & 7;
+                *reinterpret_cast<u32x4 *>(lds + (sp >> 1) * SLOT + (rt * 2 + (sp & 1)) * 1024 + lane * 16) = v[i];
+            }
         }
-        const char *aux = a.aux + (size_t)tile * CH_AUX_TILE;
-        int pid[4];
-        float wq[4];
+        const char *aux = a.aux + (size_t)tile * RT * CH_AUX_GROUP;
+        int pid[RT];
+        float wq[RT];
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) {
-            pid[rt] = reinterpret_cast<const int32_t *>(aux)[32 * rt + j];
-            wq[rt] = reinterpret_cast<const float *>(aux + 512)[32 * rt + j];
+        for (int rt = 0; rt < RT; ++rt) {
+            pid[rt] = reinterpret_cast<const int32_t *>(aux + rt * CH_AUX_GROUP)[j];
+            wq[rt] = reinterpret_cast<const float *>(aux + rt * CH_AUX_GROUP + 128)[j];
         }
         // extras of the rows this wave publishes (row tile = wave)
-        const float4 e0 = *reinterpret_cast<const float4 *>(aux + 1024 + (32 * wave + j) * 32);
-        const float4 e1 = *reinterpret_cast<const float4 *>(aux + 1024 + (32 * wave + j) * 32 + 16);
+        float4 e0 = make_float4(0.f, 0.f, 0.f, 0.f), e1 = e0;
+        if (wave < RT) {
+            e0 = *reinterpret_cast<const float4 *>(aux + wave * CH_AUX_GROUP + 256 + j * 32);
+            e1 = *reinterpret_cast<const float4 *>(aux + wave * CH_AUX_GROUP + 256 + j * 32 + 16);
+        }
         __syncthreads();
+        ++n_my;
+        CH_STAMP(0);
 
-        f32x16 acc[4][2];
-        float inv[4];                                                      // per row tile: 1 / (row scale * layer weight scale) of the running layer
+        f32x16 acc[RT][2];
+        float inv[RT];                                                     // per row tile: 1 / (row scale * layer weight scale) of the running layer
         auto zero_acc = [&]() {
 #pragma unroll
-            for (int rt = 0; rt < 4; ++rt)
+            for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[rt][c][r] = 0.f;
         };
-        // bias + LeakyReLU in place, per-row maxima; L0 adds the gathered per-point rows
-        float4 tv[4][2][4];                                                // layer 0: gathered rows of the per-point table
-        auto activate = [&](int layer, float (&amax)[4], auto with_table) {
+        // bias + LeakyReLU in place, per-row maxima; L0 adds the gathered per-point rows.  Packed fp32 math where the ISA has it
+        // (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two values per issue slot) and v_max3_f32 for the running maximum.
+        float4 tv[RT][2][4];                                               // layer 0: gathered rows of the per-point table
+        auto activate = [&](int layer, float (&amax)[RT], auto with_table) {
             constexpr bool TV = decltype(with_table)::value;
-            float bias[2][16];
+            f32x2 bias[2][8];
 #pragma unroll
             for (int c = 0; c < 2; ++c)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float4 b = *reinterpret_cast<const float4 *>(meta + layer * 256 + col0 + 32 * c + 4 * q);
-                    bias[c][4 * q] = b.x; bias[c][4 * q + 1] = b.y; bias[c][4 * q + 2] = b.z; bias[c][4 * q + 3] = b.w;
+                    bias[c][2 * q] = f32x2{b.x, b.y}; bias[c][2 * q + 1] = f32x2{b.z, b.w};
                 }
 #pragma unroll
-            for (int rt = 0; rt < 4; ++rt) {
+            for (int rt = 0; rt < RT; ++rt) {
                 float m = 0.f;
+                const f32x2 inv2 = {inv[rt], inv[rt]};
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        float add = bias[c][r];
-                        if (TV) { const float4 t4 = tv[rt][c][r >> 2]; add = __fadd_rn(add, (r & 3) == 0 ? t4.x : (r & 3) == 1 ? t4.y : (r & 3) == 2 ? t4.z : t4.w); }
-                        float v = fmaf(acc[rt][c][r], inv[rt], add);
-                        v = fmaxf(v, __fmul_rn(v, a.slope));               // LeakyReLU, 0 < slope < 1
-                        acc[rt][c][r] = v;
-                        m = fmaxf(m, fabsf(v));
-                        if (DBG) { if (a.dbg && a.dbg_layer == layer) a.dbg[((size_t)tile * CH_ROWS + 32 * rt + j) * 256 + col0 + 32 * c + r] = v; }
+                    for (int q = 0; q < 8; ++q) {
+                        f32x2 add = bias[c][q];
+                        if (TV) { const float4 t4 = tv[rt][c][q >> 1]; add = add + ((q & 1) ? f32x2{t4.z, t4.w} : f32x2{t4.x, t4.y}); }
+                        f32x2 v = __builtin_elementwise_fma(f32x2{acc[rt][c][2 * q], acc[rt][c][2 * q + 1]}, inv2, add);
+                        const f32x2 sv = v * slope2;
+                        v.x = fmaxf(v.x, sv.x); v.y = fmaxf(v.y, sv.y);       // LeakyReLU, 0 < slope < 1
+                        acc[rt][c][2 * q] = v.x; acc[rt][c][2 * q + 1] = v.y;
+                        m = fmaxf(fmaxf(m, fabsf(v.x)), fabsf(v.y));
+                        if (DBG == 1) {
+                            if (a.dbg && a.dbg_layer == layer) {
+                                float *o = a.dbg + ((size_t)tile * ROWS + 32 * rt + j) * 256 + col0 + 32 * c + 2 * q;
+                                o[0] = v.x; o[1] = v.y;
+                            }
+                        }
                     }
                 amax[rt] = m;
             }
         };
         // per-row scale from the maxima of all four waves, split, publish the next layer's operand planes
-        auto publish = [&](int next_layer, float (&amax)[4], bool with_extras) {
+        auto publish = [&](int next_layer, float (&amax)[RT], bool with_extras) {
             float emax = 0.f;
             if (with_extras) emax = fmaxf(fmaxf(fmaxf(fabsf(e0.x), fabsf(e0.y)), fmaxf(fabsf(e0.z), fabsf(e0.w))), fmaxf(fmaxf(fabsf(e1.x), fabsf(e1.y)), fabsf(e1.z)));
 #pragma unroll
-            for (int rt = 0; rt < 4; ++rt) {
+            for (int rt = 0; rt < RT; ++rt) {
                 float m = fmaxf(amax[rt], __shfl_xor(amax[rt], 32));
                 if (with_extras && rt == wave) m = fmaxf(m, emax);
                 if (h == 0) exch[(32 * rt + j) * 4 + wave] = m;
             }
             __syncthreads();                                               // every wave has finished reading the previous planes
-            const float dw = meta[CH_META_DESCALE + next_layer];         // 2^-sw of the next layer's weights
+            const float dw = meta[CH_META_DESCALE + next_layer];           // 2^-sw of the next layer's weights
 #pragma unroll
-            for (int rt = 0; rt < 4; ++rt) {
+            for (int rt = 0; rt < RT; ++rt) {
                 const float4 m4 = *reinterpret_cast<const float4 *>(exch + (32 * rt + j) * 4);
                 const int k = row_scale_exp(fmaxf(fmaxf(m4.x, m4.y), fmaxf(m4.z, m4.w)));
                 const float sc = pow2f(k);
+                const f32x2 sc2 = {sc, sc};
                 inv[rt] = __fmul_rn(pow2f(-k), dw);
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
                     unsigned ph[8], pm[8];
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) split2h(__fmul_rn(acc[rt][c][2 * q], sc), __fmul_rn(acc[rt][c][2 * q + 1], sc), ph[q], pm[q]);
-                    char *dst = lds + (2 * (2 * wave + c) + h) * CH_SLOT + (rt * 2) * 1024 + j * 16;
+                    for (int q = 0; q < 8; ++q) {
+                        const f32x2 vs = f32x2{acc[rt][c][2 * q], acc[rt][c][2 * q + 1]} * sc2;
+                        split2h(vs.x, vs.y, ph[q], pm[q]);
+                    }
+                    char *dst = lds + (2 * (2 * wave + c) + h) * SLOT + (rt * 2) * 1024 + j * 16;
                     *reinterpret_cast<u32x4 *>(dst) = u32x4{ph[0], ph[1], ph[2], ph[3]};
                     *reinterpret_cast<u32x4 *>(dst + 512) = u32x4{ph[4], ph[5], ph[6], ph[7]};
                     *reinterpret_cast<u32x4 *>(dst + 1024) = u32x4{pm[0], pm[1], pm[2], pm[3]};
@@ -289,7 +332,7 @@ __global__ __launch_bounds__(256, 1) void chain_kernel(ChainArgs a)
                     split2h(__fmul_rn(e0.z, sc), __fmul_rn(e0.w, sc), ph[1], pm[1]);
                     split2h(__fmul_rn(e1.x, sc), __fmul_rn(e1.y, sc), ph[2], pm[2]);
                     split2h(__fmul_rn(e1.z, sc), 0.f, ph[3], pm[3]);
-                    char *dst = lds + 16 * CH_SLOT + (rt * 2) * 1024 + j * 16;
+                    char *dst = lds + 16 * SLOT + (rt * 2) * 1024 + j * 16;
                     *reinterpret_cast<u32x4 *>(dst) = u32x4{ph[0], ph[1], ph[2], ph[3]};
                     *reinterpret_cast<u32x4 *>(dst + 1024) = u32x4{pm[0], pm[1], pm[2], pm[3]};
                 }
@@ -301,12 +344,12 @@ __global__ __launch_bounds__(256, 1) void chain_kernel(ChainArgs a)
         {
             const float dw0 = meta[CH_META_DESCALE + 0];
 #pragma unroll
-            for (int rt = 0; rt < 4; ++rt) inv[rt] = __fmul_rn(pow2f(-14), dw0);
+            for (int rt = 0; rt < RT; ++rt) inv[rt] = __fmul_rn(pow2f(-14), dw0);
             zero_acc();
             // all 16 weight fragments first, THEN the gathered table rows: the MFMAs wait for the (older) weight loads only
-            chain_mfma_layer<CH_S0, 1>(wsrd, CH_W0, lds, wave, lane, acc, [&]() {
+            chain_mfma_layer<RT, CH_S0, 1>(wsrd, CH_W0, lds, wave, lane, acc, [&]() {
 #pragma unroll
-                for (int rt = 0; rt < 4; ++rt) {
+                for (int rt = 0; rt < RT; ++rt) {
                     const float *trow = a.ptab + (size_t)(pid[rt] < 0 ? 0 : pid[rt]) * a.ldt + col0;
 #pragma unroll
                     for (int c = 0; c < 2; ++c)
@@ -314,31 +357,41 @@ __global__ __launch_bounds__(256, 1) void chain_kernel(ChainArgs a)
                         for (int q = 0; q < 4; ++q) tv[rt][c][q] = *reinterpret_cast<const float4 *>(trow + 32 * c + 4 * q);
                 }
             });
-            float amax[4];
+            CH_STAMP(1);
+            float amax[RT];
             activate(0, amax, std::true_type{});
+            CH_STAMP(2);
             publish(1, amax, false);
+            CH_STAMP(3);
         }
         // ---- layer 1 (block1.2) -> operand of block3.0 = [H2 | extras]
         {
             zero_acc();
-            chain_mfma_layer<CH_S1, 0>(wsrd, CH_W1, lds, wave, lane, acc, []() {});
-            float amax[4];
+            chain_mfma_layer<RT, CH_S1, 0>(wsrd, CH_W1, lds, wave, lane, acc, []() {});
+            CH_STAMP(4);
+            float amax[RT];
             activate(1, amax, std::false_type{});
+            CH_STAMP(5);
             publish(2, amax, true);
+            CH_STAMP(6);
         }
         // ---- layer 2 (block3.0)
         {
             zero_acc();
-            chain_mfma_layer<CH_S2, 0>(wsrd, CH_W2, lds, wave, lane, acc, []() {});
-            float amax[4];
+            chain_mfma_layer<RT, CH_S2, 0>(wsrd, CH_W2, lds, wave, lane, acc, []() {});
+            CH_STAMP(7);
+            float amax[RT];
             activate(2, amax, std::false_type{});
+            CH_STAMP(5);
             publish(3, amax, false);
+            CH_STAMP(6);
         }
         // ---- layer 3 (block3.2) + alpha branch + K-weighted sums
         {
             zero_acc();
-            chain_mfma_layer<CH_S3, 0>(wsrd, CH_W3, lds, wave, lane, acc, []() {});
-            float amax[4];
+            chain_mfma_layer<RT, CH_S3, 0>(wsrd, CH_W3, lds, wave, lane, acc, []() {});
+            CH_STAMP(8);
+            float amax[RT];
             activate(3, amax, std::false_type{});
             float aw[2][16];
 #pragma unroll
@@ -349,7 +402,7 @@ __global__ __launch_bounds__(256, 1) void chain_kernel(ChainArgs a)
                     aw[c][4 * q] = b.x; aw[c][4 * q + 1] = b.y; aw[c][4 * q + 2] = b.z; aw[c][4 * q + 3] = b.w;
                 }
 #pragma unroll
-            for (int rt = 0; rt < 4; ++rt) {
+            for (int rt = 0; rt < RT; ++rt) {
                 float ap = 0.f;
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
@@ -361,7 +414,7 @@ __global__ __launch_bounds__(256, 1) void chain_kernel(ChainArgs a)
             __syncthreads();                                               // also: the planes are free for the next tile
             const float ab = meta[4 * 256 + 256];
 #pragma unroll
-            for (int rt = 0; rt < 4; ++rt) {
+            for (int rt = 0; rt < RT; ++rt) {
                 // weighted feature sums over the sample's 8 rows = 8 adjacent lanes
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
@@ -373,7 +426,7 @@ __global__ __launch_bounds__(256, 1) void chain_kernel(ChainArgs a)
                         f = __fadd_rn(f, __builtin_amdgcn_update_dpp(0.f, f, 0x141, 0xf, 0xf, false));      // row_half_mirror
                         acc[rt][c][r] = f;
                     }
-                const int s = tile * CH_SAMPLES + 4 * rt + (j >> 3);
+                const int s = tile * SAMPLES + 4 * rt + (j >> 3);
                 if ((j & 7) == 0 && s < n_valid) {
                     float *o = a.X5 + (size_t)s * a.ld5 + col0;
 #pragma unroll
@@ -393,16 +446,27 @@ __global__ __launch_bounds__(256, 1) void chain_kernel(ChainArgs a)
                 }
             }
             __syncthreads();                                               // exch is rewritten by the next tile's layer 0
+            CH_STAMP(9);
         }
     }
+    if (DBG == 2 && blockIdx.x == 0 && lane == 0 && a.dbg) {
+        long long *o = reinterpret_cast<long long *>(a.dbg) + wave * 16;
+        for (int i = 0; i < 10; ++i) o[i] = tm[i];
+        o[10] = clock64() - t_start; o[11] = wall_clock64() - w_start; o[12] = n_my;
+    }
+    if (DBG == 2 && tid == 0 && a.dbg) {                                   // every block: {cycles, wall ticks, tiles, XCC id}
+        long long *o = reinterpret_cast<long long *>(a.dbg) + 64 + 4 * (size_t)blockIdx.x;
+        o[0] = clock64() - t_start; o[1] = wall_clock64() - w_start; o[2] = n_my; o[3] = (__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 0xf) | ((long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)) << 8);
+    }
+#undef CH_STAMP
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
 // Gather + geometry for the fused chain (NeuralPoints.forward gather neural_points.py:709-720, w2pers :607-613, dists
 // point_aggregators.py:1472-1480, inverse-distance weights :825-833, :1500-1501, x clamp(conf) :1508-1512, positional
-// encoding of the distances :930): one 256-thread block per tile of 16 valid samples writes
-//   xp[tile]  = layer 0's activation operand PE5(dists6) * 2^14, already split into fp16 (h, m) planes in MFMA fragment order,
-//   aux[tile] = per row: point id (-1: empty slot), aggregation weight, block3's 7 extra inputs (:957-971),
+// encoding of the distances :930): one 256-thread block per 4 groups (16 valid samples = 128 rows) writes, per group of 32 rows,
+//   xp[group]  = layer 0's activation operand PE5(dists6) * 2^14, already split into fp16 (h, m) planes in MFMA fragment order,
+//   aux[group] = per row: point id (-1: empty slot), aggregation weight, block3's 7 extra inputs (:957-971),
 //   X5[s, 256:280] = view-direction encoding of the sample's ray (:909-913),
 // and optionally the reference's `weight` / `conf_coefficient` outputs [R,SR,K].
 struct ChainGatherArgs {
@@ -429,16 +493,17 @@ __device__ __forceinline__ void chain_w2pers(const float *p, const float *campos
 
 __global__ __launch_bounds__(256) void chain_gather_kernel(ChainGatherArgs a)
 {
-    __shared__ float s_d[CH_ROWS][8];                    // dists6 per row
+    __shared__ float s_d[128][8];                        // dists6 per row
     int n_valid = (int)a.counts[HNR_CNT_SAMPLES_VALID];
     if (n_valid > a.cap_samples) n_valid = a.cap_samples;
-    const int tile = blockIdx.x;
-    if (tile * CH_SAMPLES >= n_valid) return;
+    const int blk = blockIdx.x;                          // 16 samples = 4 groups
+    if (blk * 16 >= n_valid) return;
     const int tid = threadIdx.x;
-    char *aux = a.aux + (size_t)tile * CH_AUX_TILE;
-    if (tid < CH_ROWS) {
+    if (tid < 128) {
         const int ls = tid >> 3, kk = tid & 7;
-        const int s = tile * CH_SAMPLES + ls;
+        const int s = blk * 16 + ls;
+        char *aux = a.aux + (size_t)(blk * 4 + (tid >> 5)) * CH_AUX_GROUP;
+        const int jr = tid & 31;
         const float cp[3] = {a.campos[0], a.campos[1], a.campos[2]};
         float cr[9];
 #pragma unroll
@@ -473,15 +538,15 @@ __global__ __launch_bounds__(256) void chain_gather_kernel(ChainGatherArgs a)
         const float w = pid >= 0 ? __fdiv_rn(wraw, fmaxf(sum, 1e-8f)) : 0.f;
 #pragma unroll
         for (int i = 0; i < 6; ++i) s_d[tid][i] = d6[i];
-        reinterpret_cast<int32_t *>(aux)[tid] = pid;
-        reinterpret_cast<float *>(aux + 512)[tid] = __fmul_rn(w, confc);
-        *reinterpret_cast<float4 *>(aux + 1024 + tid * 32) = make_float4(ext[0], ext[1], ext[2], ext[3]);
-        *reinterpret_cast<float4 *>(aux + 1024 + tid * 32 + 16) = make_float4(ext[4], ext[5], ext[6], 0.f);
+        reinterpret_cast<int32_t *>(aux)[jr] = pid;
+        reinterpret_cast<float *>(aux + 128)[jr] = __fmul_rn(w, confc);
+        *reinterpret_cast<float4 *>(aux + 256 + jr * 32) = make_float4(ext[0], ext[1], ext[2], ext[3]);
+        *reinterpret_cast<float4 *>(aux + 256 + jr * 32 + 16) = make_float4(ext[4], ext[5], ext[6], 0.f);
         if (a.weight_out && pid >= 0) { a.weight_out[(size_t)item * 8 + kk] = w; a.conf_out[(size_t)item * 8 + kk] = confc; }
-    } else if (tid < CH_ROWS + CH_SAMPLES * 4) {
+    } else if (tid < 128 + 64) {
         // view-direction encoding: positional_encoding(viewdirs, 4, ori=True)[3:] = [sin(d*4+f) x12 | cos x12]; 6 values per thread
-        const int t = tid - CH_ROWS, ls = t >> 2, part = t & 3;
-        const int s = tile * CH_SAMPLES + ls;
+        const int t = tid - 128, ls = t >> 2, part = t & 3;
+        const int s = blk * 16 + ls;
         if (s < n_valid) {
             const int ray = a.vs_item[s] / a.SR;
             float *o = a.X5 + (size_t)s * a.ld5 + 256;
@@ -494,12 +559,12 @@ __global__ __launch_bounds__(256) void chain_gather_kernel(ChainGatherArgs a)
         }
     }
     __syncthreads();
-    // operand image: fragment (k step s, row tile rt, plane): lane (row = 32 rt + (L & 31), k = 16 s + 8 (L >> 5) + e), e = 0..7
+    // operand image of group rt: fragment (k step s, plane): lane (row = L & 31, k = 16 s + 8 (L >> 5) + e), e = 0..7
     // = 4 (dist, freq) pairs [sin, cos]; positional_encoding interleaves [sin, cos] per (dim, freq): column 2 (5 d + f) + {0, 1}
-    char *xp = a.xp + (size_t)tile * CH_XP_TILE;
+    const int L = tid & 63, rt = tid >> 6;
+    char *xp = a.xp + (size_t)(blk * 4 + rt) * CH_XP_GROUP;
 #pragma unroll
     for (int s = 0; s < CH_S0; ++s) {
-        const int L = tid & 63, rt = tid >> 6;
         const int row = 32 * rt + (L & 31), k0 = 16 * s + 8 * (L >> 5);
         unsigned ph[4], pm[4];
 #pragma unroll
@@ -512,7 +577,7 @@ __global__ __launch_bounds__(256) void chain_gather_kernel(ChainGatherArgs a)
             }
             split2h(__fmul_rn(sv, 16384.f), __fmul_rn(cv, 16384.f), ph[e], pm[e]);
         }
-        char *dst = xp + s * CH_SLOT + (rt * 2) * 1024 + L * 16;
+        char *dst = xp + (s * 2) * 1024 + L * 16;
         *reinterpret_cast<u32x4 *>(dst) = u32x4{ph[0], ph[1], ph[2], ph[3]};
         *reinterpret_cast<u32x4 *>(dst + 1024) = u32x4{pm[0], pm[1], pm[2], pm[3]};
     }
@@ -603,8 +668,8 @@ extern "C" int64_t hnr_chain_packed_bytes(void) { return (int64_t)CH_WBYTES + CH
 extern "C" int64_t hnr_chain_workspace_bytes(int cap_samples)
 {
     if (cap_samples < 0) return -1;
-    const int64_t tiles = ((int64_t)cap_samples + CH_SAMPLES - 1) / CH_SAMPLES;
-    return tiles * (CH_XP_TILE + CH_AUX_TILE);
+    const int64_t groups = 4 * (((int64_t)cap_samples + 15) / 16);                // whole 4-group blocks of the gather kernel
+    return groups * (CH_XP_GROUP + CH_AUX_GROUP);
 }
 
 extern "C" int hnr_chain_pack(const float *d_w_b1_0_dist, int ldw0, const float *d_b_b1_0, const float *d_w_b1_2, const float *d_b_b1_2,
@@ -645,14 +710,14 @@ extern "C" int hnr_chain_gather(const float *d_xyz, const float *d_conf, const f
         set_error("hnr_chain_gather: NULL / unaligned pointer");
         return HNR_ERR_BADARG;
     }
-    const int tiles = cdiv(cap_samples, CH_SAMPLES);
+    const int blocks = cdiv(cap_samples, 16);
     ChainGatherArgs a;
     a.xyz = d_xyz; a.conf = d_conf; a.pdir = d_dir; a.color = d_color; a.pidx = d_sample_pidx; a.loc_w = d_sample_loc_w;
     a.raydir = d_raydir; a.campos = d_campos; a.camrot = d_camrot; a.vs_item = d_vs_item;
     a.counts = reinterpret_cast<const unsigned long long *>(d_counts); a.SR = SR; a.cap_samples = cap_samples;
-    a.xp = (char *)d_workspace; a.aux = (char *)d_workspace + (size_t)tiles * CH_XP_TILE;
+    a.xp = (char *)d_workspace; a.aux = (char *)d_workspace + (size_t)blocks * 4 * CH_XP_GROUP;
     a.X5 = d_X5; a.ld5 = ld5; a.weight_out = d_weight_out; a.conf_out = d_conf_out;
-    chain_gather_kernel<<<tiles, 256, 0, (hipStream_t)stream>>>(a);
+    chain_gather_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(a);
     HNR_LAUNCH_CHECK();
     return HNR_OK;
 }
@@ -670,23 +735,44 @@ extern "C" int hnr_chain_forward(const void *d_workspace, const float *d_point_t
         set_error("hnr_chain_forward: NULL / unaligned pointer");
         return HNR_ERR_BADARG;
     }
-    const int tiles = cdiv(cap_samples, CH_SAMPLES);
+    const int blocks = cdiv(cap_samples, 16);
     ChainArgs a;
-    a.xp = (const char *)d_workspace; a.aux = (const char *)d_workspace + (size_t)tiles * CH_XP_TILE;
+    a.xp = (const char *)d_workspace; a.aux = (const char *)d_workspace + (size_t)blocks * 4 * CH_XP_GROUP;
     a.ptab = d_point_table; a.ldt = ldt; a.wimg = (const char *)d_packed;
     a.counts = reinterpret_cast<const unsigned long long *>(d_counts);
     a.X5 = d_X5; a.ld5 = ld5; a.sigma = d_sigma; a.slope = slope; a.cap_samples = cap_samples; a.dbg = d_dbg; a.dbg_layer = dbg_layer;
     const int n_cu = chain_num_cus();
-    const int grid = tiles < n_cu ? tiles : n_cu;
     hipStream_t st = (hipStream_t)stream;
+    // HNR_CHAIN_RT = 4 (default): one 128-row workgroup per CU; 2: two 64-row workgroups per CU.  Measured equal (35.9 vs 36.1 ms on
+    // the 3.5 M-sample probe frame: the pair needs 9 % fewer cycles but the chip clocks 1.80 instead of 2.02 GHz under it), so the
+    // variant that streams the weight image half as often is the default.
+    static int rt_mode = 0, skew = 0;
+    if (rt_mode == 0) {
+        const char *e = getenv("HNR_CHAIN_RT"); rt_mode = (e && atoi(e) == 2) ? 2 : 4;
+        const char *k = getenv("HNR_CHAIN_SKEW"); skew = k ? atoi(k) : 0;            // x 64 cycles (probe; measured: no effect)
+    }
+    a.skew = skew;
     static bool attr_set = false;
     if (!attr_set) {
-        HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chain_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS_BYTES));
-        HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chain_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS_BYTES));
+        HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chain_kernel<4, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, ch_lds_bytes(4)));
+        HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chain_kernel<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, ch_lds_bytes(4)));
+        HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chain_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, ch_lds_bytes(4)));
+        HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chain_kernel<2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, ch_lds_bytes(2)));
+        HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chain_kernel<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, ch_lds_bytes(2)));
+        HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chain_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, ch_lds_bytes(2)));
         attr_set = true;
     }
-    if (d_dbg) chain_kernel<1><<<grid, 256, CH_LDS_BYTES, st>>>(a);
-    else chain_kernel<0><<<grid, 256, CH_LDS_BYTES, st>>>(a);
+    if (rt_mode == 4) {
+        const int tiles = cdiv(cap_samples, 16), grid = tiles < n_cu ? tiles : n_cu;
+        if (d_dbg && dbg_layer < 0) chain_kernel<4, 2><<<grid, 256, ch_lds_bytes(4), st>>>(a);      // probe: per-phase cycle counts of block 0
+        else if (d_dbg) chain_kernel<4, 1><<<grid, 256, ch_lds_bytes(4), st>>>(a);
+        else chain_kernel<4, 0><<<grid, 256, ch_lds_bytes(4), st>>>(a);
+    } else {
+        const int tiles = cdiv(cap_samples, 8), grid = tiles < 2 * n_cu ? tiles : 2 * n_cu;
+        if (d_dbg && dbg_layer < 0) chain_kernel<2, 2><<<grid, 256, ch_lds_bytes(2), st>>>(a);
+        else if (d_dbg) chain_kernel<2, 1><<<grid, 256, ch_lds_bytes(2), st>>>(a);
+        else chain_kernel<2, 0><<<grid, 256, ch_lds_bytes(2), st>>>(a);
+    }
     HNR_LAUNCH_CHECK();
     return HNR_OK;
 }

@@ -223,4 +223,4 @@ def test_chain_capacity_bounds_and_bad_arguments():
                                       None), "hnr_chain_gather")
     with pytest.raises(HnrError):
         _lib.check(L.hnr_chain_forward(None, None, 256, None, None, 16, ctypes.c_float(1.5), None, 280, None, None, 0, None), "hnr_chain_forward")
-    assert L.hnr_chain_workspace_bytes(0) == 0 and L.hnr_chain_workspace_bytes(17) == 2 * (32768 + 5120)
+    assert L.hnr_chain_workspace_bytes(0) == 0 and L.hnr_chain_workspace_bytes(17) == 8 * (8192 + 1280)

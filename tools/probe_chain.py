@@ -1,0 +1,52 @@
+"""Per-phase cycle counts of the fused chain kernel (block 0), bench scene.  python tools/probe_chain.py [points]"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from tests import test_chain_gpu as T
+from hybridneuralrendering_amd import _lib
+
+n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 2000000
+W = T._world(n_points=n, w=640, h=480, seed=2)
+L, p = _lib.lib(), _lib.ptr
+dev = W["dev"]
+nv = W["n_valid"]
+ws = torch.empty((int(L.hnr_chain_workspace_bytes(nv)),), dtype=torch.uint8, device=dev)
+X5 = torch.empty((nv, 280), dtype=torch.float32, device=dev); sg = torch.empty((nv,), dtype=torch.float32, device=dev)
+ptab = W["rnd"].point_table(W["cloud"]); q = W["q"]; c = W["cloud"]
+_lib.check(L.hnr_chain_gather(p(c.xyz), p(c.conf), p(c.dir), p(c.color), p(q["sample_pidx"]), p(q["sample_loc_w"]), p(W["raydir"]), p(W["campos"]),
+                              p(W["camrot"]), p(W["vs_item"]), p(q["counts"]), W["SR"], W["K"], nv, p(ws), p(X5), 280, None, None, _lib.stream()), "g")
+dbg = torch.zeros(((4 * 16 + 4 * 1024) * 2,), dtype=torch.float32, device=dev)
+pk = W["agg"].packed_chain()
+for it in range(3):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    _lib.check(L.hnr_chain_forward(p(ws), p(ptab), 256, p(pk), p(q["counts"]), nv, 0.01, p(X5), 280, p(sg), p(dbg) if it == 2 else None, -1, _lib.stream()), "f")
+    e1.record(); torch.cuda.synchronize()
+    print("chain_forward %.3f ms, %d valid samples, %d tiles" % (e0.elapsed_time(e1), nv, (nv + 15) // 16))
+allv = dbg.view(torch.int64).cpu().numpy()
+t = allv[:64].reshape(4, 16)
+blk = allv[64:].reshape(-1, 4)
+blk = blk[blk[:, 2] > 0]
+ms = blk[:, 1] / 1e5
+print('blocks %d: wall ms per block min %.2f mean %.2f max %.2f; tiles min %d max %d' % (len(blk), ms.min(), ms.mean(), ms.max(), blk[:, 2].min(), blk[:, 2].max()))
+hw = blk[:, 3] >> 8
+xcc = blk[:, 3] & 0xf
+cu = (xcc << 8) | ((hw >> 8) & 0xff)               # (xcc, se_id[15:13], sh_id[12], cu_id[11:8])
+from collections import defaultdict
+by = defaultdict(list)
+for i, c_ in enumerate(cu):
+    by[int(c_)].append(i)
+sizes = sorted(set(len(v) for v in by.values()))
+pairs = [tuple(v) for v in by.values() if len(v) == 2][:6]
+print('  distinct CUs %d, blocks per CU %s, example co-resident pairs %s' % (len(by), sizes, pairs))
+d = [abs(v[1] - v[0]) for v in by.values() if len(v) == 2]
+print('  |b1 - b0| of co-resident pairs: %s' % sorted(set(d))[:10])
+fast = [min(ms[v[0]], ms[v[1]]) for v in by.values() if len(v) == 2]; slow = [max(ms[v[0]], ms[v[1]]) for v in by.values() if len(v) == 2]
+if fast: print('  per CU: first finisher mean %.2f ms, second mean %.2f ms' % (np.mean(fast), np.mean(slow)))
+for x in range(8):
+    m = (np.arange(len(blk)) % 8) == x
+    print('  blocks b%%8==%d: xcc %s, ms mean %.2f max %.2f, GHz %.3f' % (x, sorted(set(xcc[m].tolist())), ms[m].mean(), ms[m].max(), (blk[m, 0] / blk[m, 1]).mean() * 0.1))
+names = ["prologue", "L0 mfma", "L0 act(+T wait)", "L0 publish", "L1 mfma", "L1/L2 act", "L1/L2 publish", "L2 mfma", "L3 mfma", "L3 epilogue"]
+for w in range(4):
+    nt = max(t[w, 12], 1)
+    print("wave %d: %d tiles, %.0f cycles/tile (%.3f GHz): " % (w, nt, t[w, 10] / nt, t[w, 10] / max(t[w, 11], 1) * 0.1) + ", ".join("%s %.0f" % (names[i], t[w, i] / nt) for i in range(10)))
