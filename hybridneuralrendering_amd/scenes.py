@@ -244,3 +244,38 @@ def make_scene(name, n_points, seed, w=None, h=None, n_views=4, size=None):
         w=w, h=h, intrinsic=K, c2w=cams[0], c2w_nearest=np.stack(cams[1:1 + n_views]),
         images_nearest=reference_images(n_views, h, w, seed),
         near=float(opt.near_plane), far=float(opt.far_plane), bg_color=np.ones(3, np.float32))
+
+
+# ----------------------------------------------------------------------------- training batches (configs C3 / C5)
+def dilated_patch_batch(w, h, margin, dilation_setup, seed):
+    """Pixel coordinates [S*S, 2] (x, y) of one `random_sample='dilated'` batch (data/scannet_ft_dataset.py:918-949 in the reference):
+    patch_num x patch_num patches of patch_size x patch_size pixels, each with its own stride in [d_lo, d_hi] and position, laid out as
+    an S x S grid (S = patch_num * patch_size) in row-major ray order.  dilation_setup = "7_8_1_6"."""
+    pn, ps, d_lo, d_hi = (int(v) for v in dilation_setup.split("_"))
+    rng = np.random.default_rng(seed)
+    S = pn * ps
+    px, py = np.zeros((S, S), np.int32), np.zeros((S, S), np.int32)
+    gx, gy = np.meshgrid(np.arange(ps), np.arange(ps))
+    for pi in range(pn):
+        for pj in range(pn):
+            d = int(rng.integers(d_lo, d_hi + 1))
+            x0 = int(rng.integers(margin, w - margin - (ps - 1) * d))
+            y0 = int(rng.integers(margin, h - margin - (ps - 1) * d))
+            px[pi * ps:(pi + 1) * ps, pj * ps:(pj + 1) * ps] = x0 + d * gx
+            py[pi * ps:(pi + 1) * ps, pj * ps:(pj + 1) * ps] = y0 + d * gy
+    return np.stack([px, py], axis=-1).reshape(-1, 2).astype(np.int32), pn, ps
+
+
+def blur_kernels_v2(k_size=9, dists=(1, 2, 4), n_dirs=8):
+    """`blur_kernel_version=2` of the reference (data/scannet_ft_dataset.py:214-242): for every motion length in `dists` and
+    every one of the n_dirs / 2 directions (0, 45, 90, 135 degrees) a normalised symmetric line kernel -> [12, 9, 9]."""
+    c = k_size // 2
+    dirs = [(0, 1), (1, 1), (1, 0), (1, -1)][:n_dirs // 2]
+    out = []
+    for dist in dists:
+        for dy, dx in dirs:
+            k = np.zeros((k_size, k_size), np.float32)
+            for t in range(-dist, dist + 1):
+                k[c + t * dy, c + t * dx] = 1.0
+            out.append(k / k.sum())
+    return np.stack(out)

@@ -208,3 +208,70 @@ def test_c3_scene0241_train_step_full_size():
             tol_e, tol_l2 = (8e-3, 3e-3) if "aux_merge_weight_block" in k else (2e-3, 1.5e-3)
             assert e < tol_e and l2 < tol_l2, (k, e, l2)
     print("C3 full size: %d rows; worst gradient error: weights %.1e, points %.1e of max" % (int(o["counts"][3]), worst_w, worst_p))
+
+
+def test_c4_scene0101_full_forward_render_and_8_way_shards():
+    """BASELINE config C4 (ScanNet scene0101_04 full-res forward render, ray batches sharded across 8 GPUs;
+    dev_scripts/w_scannet_etf/scene101_full.sh, run/test_ft.py:139-198) at its full size: 4.0 M points, P 30, max_o 2 M, the whole
+    620x460 = 285 200-ray frame through query -> gather/aggregate -> composite in one launch.  (a) the colours of a 2304-ray subset
+    against the CPU oracle (C query over all 4 M points + torch aggregate/composite); (b) the 8 scan-line blocks of
+    parallel.shard_bounds -- what the 8 ranks render -- reproduce the whole-frame colours BIT FOR BIT."""
+    from hybridneuralrendering_amd import scenes
+    from hybridneuralrendering_amd.aggregator import PointAggregator
+    from hybridneuralrendering_amd.render import HybridRenderer, PointCloud
+    from hybridneuralrendering_amd.parallel import shard_bounds
+    from oracle import query_oracle as qo, render_oracle as ro
+    sc = scenes.make_scene("scene0101", int(4.0e6), 3)
+    opt = sc.opt
+    assert (opt.P, opt.max_o, opt.SR, opt.K) == (30, 2000000, 24, 8)
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    agg = PointAggregator(opt)
+    with torch.no_grad():
+        agg.alpha_branch[0].weight.mul_(30.0)
+        agg.alpha_branch[0].bias.fill_(30.0)
+    sd = {k: v.detach().clone() for k, v in agg.state_dict().items()}
+    agg = agg.to(dev)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    cloud = PointCloud(t(sc.xyz), t(sc.emb), t(sc.conf), t(sc.dir), t(sc.color))
+    rnd = HybridRenderer(opt, agg, dev)
+    pix = scenes.pixel_grid(sc.w, sc.h, 10)
+    rays_np = scenes.camera_rays(pix, sc.intrinsic, sc.c2w)
+    assert rays_np.shape[0] == 285200
+    rays = t(rays_np)
+    cam = (t(sc.c2w[:3, 3]), t(sc.c2w[:3, :3]), t(sc.bg_color))
+    ref_views = (t(sc.c2w_nearest), t(sc.c2w_nearest[:, :3, 3]), t(sc.intrinsic), t(sc.images_nearest))
+    w2c = torch.inverse(torch.from_numpy(sc.c2w_nearest)).to(dev)
+    render = lambda r: rnd.render_rays(cloud, r, cam[0], cam[1], cam[2], sc.near, sc.far, ref_views[0], ref_views[1], ref_views[2], ref_views[3],
+                                       w2c_nearest=w2c)
+    full = render(rays)
+    col = full["coarse_raycolor"]
+    assert int(full["ray_mask"].sum()) > 0.99 * rays.shape[0] and bool(torch.isfinite(col).all())
+    assert float(col.std()) > 0.02                                      # a real image, not a constant
+    # (b) the 8 ranks' blocks
+    for rank in range(8):
+        lo, hi = shard_bounds(rays.shape[0], 8, rank)
+        assert hi - lo in (35650,)
+        part = render(rays[lo:hi].contiguous())
+        assert torch.equal(part["coarse_raycolor"], col[lo:hi]) and torch.equal(part["ray_mask"], full["ray_mask"][lo:hi])
+        assert torch.equal(part["coarse_point_opacity"], full["coarse_point_opacity"][lo:hi])
+    # (a) oracle on a 48x48-ray block + 1 000 scattered rays
+    W = sc.w - 20
+    blk = ((200 + np.arange(48))[:, None] * W + (300 + np.arange(48))[None, :]).reshape(-1)
+    sel = np.unique(np.concatenate([blk, np.random.default_rng(11).choice(rays_np.shape[0], size=1000, replace=False)]))
+    hp = qo.hyperparameters(sc.xyz, opt.vsize, opt.vscale, opt.kernel_size, opt.ranges, opt.radius_limit_scale)
+    g = qo.OracleGrid(sc.xyz, hp["origin"], hp["cell"], hp["dims"], opt.query_size, opt.P, opt.max_o)
+    q = g.query(sc.c2w[:3, 3], rays_np[sel], qo.tmid_table(sc.near, sc.far, opt.z_depth_dim), opt.SR, opt.K, hp["radius2"], opt.kernel_size)
+    c = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    with torch.no_grad():
+        oref = ro.render(c(sc.xyz), c(sc.emb), c(sc.conf), c(sc.dir), c(sc.color), sd, q, c(sc.c2w[:3, 3])[None], c(sc.c2w[:3, :3])[None],
+                         c(rays_np[sel])[None], c(sc.bg_color)[None], c(sc.c2w_nearest)[None], c(sc.c2w_nearest[:, :3, 3])[None],
+                         c(sc.intrinsic)[None], c(sc.images_nearest)[None], opt.vsize)
+    exp = oref["full_coarse_raycolor"][0].numpy()
+    got = col[torch.from_numpy(sel).to(dev)].cpu().numpy()
+    np.testing.assert_array_equal(full["ray_mask"][torch.from_numpy(sel).to(dev)].cpu().numpy(), q["ray_mask"])
+    err = float(np.abs(got - exp).max())
+    mse = float(np.mean((got.astype(np.float64) - exp.astype(np.float64)) ** 2))
+    assert err < 2e-4 and -10 * np.log10(max(mse, 1e-30)) > 80.0, (err, mse)        # fp32 path, summation order differs from the CPU GEMMs
+    print("C4 full frame: %d rays, %d valid samples, %d neighbours; max |d colour| vs oracle on %d rays %.2e" % (
+        rays.shape[0], int(full["counts"][6]), int(full["counts"][3]), len(sel), err))
