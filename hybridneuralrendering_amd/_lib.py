@@ -77,6 +77,9 @@ SIGNATURES = {
     "hnr_chain_pack": (_I, [_P, _I] + [_P] * 9 + [_P, _P]),
     "hnr_chain_gather": (_I, [_P] * 11 + [_I, _I, _I, _P, _P, _I, _P, _P, _P]),
     "hnr_chain_forward": (_I, [_P, _P, _I, _P, _P, _I, _F, _P, _I, _P, _P, _I, _P]),
+    "hnr_mlp3_packed_bytes": (ctypes.c_int64, [ctypes.POINTER(_I)]),
+    "hnr_mlp3_pack": (_I, [ctypes.POINTER(_P), ctypes.POINTER(_I), ctypes.POINTER(_I), ctypes.POINTER(_I), ctypes.POINTER(_P), _P, _P]),
+    "hnr_mlp3_forward": (_I, [_P, _I, ctypes.c_int64, _P, _I, _I, _P, ctypes.POINTER(_I), ctypes.POINTER(_I), ctypes.POINTER(_I), _F, _P, _P, _I, _P, _I, _P]),
     "hnr_final_color": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P]),
     "hnr_composite": (_I, [_P] * 8 + [_I, _I, _I, _F, _I, _P, _P, _P, _P, _P]),
     "hnr_probe_outputs": (_I, [_P] * 10 + [_I, _I, _I, _I] + [_P] * 7 + [_P]),

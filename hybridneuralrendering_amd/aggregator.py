@@ -17,7 +17,7 @@ import torch.nn as nn
 
 from . import _lib
 from ._lib import HnrError
-from .linear import PackedLinear, SplitLinear
+from .linear import PackedLinear, SplitLinear, FusedMlp3
 
 _REQUIRED = dict(which_agg_model="viewmlp", agg_distance_kernel="linear", agg_intrp_order=2, agg_dist_pers=20,
                  apply_pnt_mask=1, num_feat_freqs=3, dist_xyz_freq=5, num_viewdir_freqs=4, view_ori=0,
@@ -168,6 +168,7 @@ class PointAggregator(nn.Module):
         self._packed, self._packed_key = pk, key
         self._packed_split = None
         self._packed_chain = None
+        self._packed_mlp3 = None
         return pk
 
     def packed_split(self):
@@ -196,6 +197,19 @@ class PointAggregator(nn.Module):
                 _lib.check(L.hnr_chain_pack(_lib.ptr(w0), 60, *[_lib.ptr(t) for t in args], _lib.ptr(buf), _lib.stream()), "hnr_chain_pack")
             self._packed_chain = buf
         return self._packed_chain
+
+    def packed_mlp3(self):
+        """The per-sample MLPs as fused three-layer launches (hnr_mlp3_forward; csrc/mlp.hip): colour feature, merge weights
+        (first layer split: the image-feature / view-direction columns here, the colour-feature columns per sample in `mw0_cf`), mix-up."""
+        self.packed()
+        if getattr(self, "_packed_mlp3", None) is None:
+            cf, mw, mx = self.color_feature_branch, self.aux_merge_weight_block, self.color_mixup_block
+            w_fd = torch.cat([mw[0].weight[:, :45], mw[0].weight[:, 173:176]], dim=1).contiguous()
+            self._packed_mlp3 = dict(
+                cf=FusedMlp3([cf[0].weight, cf[2].weight, cf[4].weight], [cf[0].bias, cf[2].bias, cf[4].bias], [1, 1, 1]),
+                mw=FusedMlp3([w_fd, mw[2].weight, mw[4].weight], [None, mw[2].bias, mw[4].bias], [1, 1, 1]),
+                mx=FusedMlp3([mx[0].weight, mx[2].weight, mx[4].weight], [mx[0].bias, mx[2].bias, mx[4].bias], [1, 1, 0]))
+        return self._packed_mlp3
 
     def point_table(self, emb, ids=None, n_ids=None, want_rows=False):
         """[N,256] = [emb | PE3(emb)] @ block1.0.weight[:, :224]^T -- the point-only part of block1's first layer

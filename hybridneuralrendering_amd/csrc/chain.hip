@@ -32,15 +32,10 @@
 // (L2-resident: the 848 KiB weight image is read by every CU), and all four waves read the shared activation fragments from
 // LDS (ds_read_b128, 8 per k step for 24 MFMAs).
 #include <stdlib.h>
-#include <type_traits>
 
-#include "hnr_common.h"
+#include "hnr_h2.h"
 
 namespace hnr {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // a GROUP = 32 rows = one MFMA row tile = 4 shading samples x 8 slots
 constexpr int CH_WSTEP = 16384;                    // weight image bytes per k step: [column tile 8][plane 2][64 lanes][16 B]
@@ -52,32 +47,10 @@ constexpr int CH_META_DESCALE = 4 * 256 + 256 + 1, CH_META_WMAX = CH_META_DESCAL
 constexpr int CH_META_FLOATS = CH_META_WMAX + 4 + 3;
 constexpr int CH_XP_GROUP = CH_S0 * 2048;          // bytes of one group's layer-0 operand image: [k step 4][plane 2][64 lanes][16 B] = 8 KiB
 constexpr int CH_AUX_GROUP = 32 * 4 + 32 * 4 + 32 * 8 * 4;        // pid[32] i32, wagg[32] f32, ext[32][8] f32 = 1280 B
-constexpr int CH_ACT_EXP = 15;                     // a row's maximum is scaled into [2^14, 2^15)
-constexpr int CH_W_EXP = 14;                       // a layer's largest weight is scaled into [2^13, 2^14)
 // workgroup tile = RT groups; LDS: 17 k-step slots of [row tile RT][plane 2][64 lanes][16 B], then the float[32 RT][4] exchange area
 constexpr int ch_slot(int RT) { return RT * 2048; }
 constexpr int ch_lds_exch(int RT) { return 17 * ch_slot(RT); }
 constexpr int ch_lds_bytes(int RT) { return ch_lds_exch(RT) + 32 * RT * 4 * 4; }
-
-// (x0, x1) -> packed fp16 pairs h, m with x = h + m + O(2^-22 |x|); round-to-nearest-even
-__device__ __forceinline__ void split2h(float x0, float x1, unsigned &ph, unsigned &pm)
-{
-    float r0, r1;
-    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(ph) : "v"(x0), "v"(x1));
-    asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(ph), "v"(x0));                  // x0 - h.lo (exact)
-    asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(ph), "v"(x1));    // x1 - h.hi
-    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(pm) : "v"(r0), "v"(r1));
-}
-
-__device__ __forceinline__ float pow2f(int e) { return __uint_as_float((unsigned)(127 + e) << 23); }   // -126 <= e <= 127
-
-// scale exponent k of a row whose largest |value| is m: m * 2^k in [2^(CH_ACT_EXP-1), 2^CH_ACT_EXP)
-__device__ __forceinline__ int row_scale_exp(float m)
-{
-    int ex = (int)((__float_as_uint(m) >> 23) & 0xffu);          // biased exponent; m >= 0
-    ex = ex < 48 ? 48 : (ex > 250 ? 250 : ex);                   // zero / tiny rows: scale 2^93 at most; inf / nan rows: garbage in, garbage out
-    return CH_ACT_EXP + 126 - ex;
-}
 
 struct ChainArgs {
     const char *xp;                    // [groups][CH_XP_GROUP] layer-0 operand image (chain_gather_kernel)
@@ -92,81 +65,6 @@ struct ChainArgs {
     float *dbg; int dbg_layer;         // probe: post-activation output of layer dbg_layer -> [rows, 256]
     int skew;                          // RT = 2: the second half of the grid (the CUs' second workgroups) starts skew x 64 cycles late
 };
-
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-// one dense layer of the tile: acc[rt][c] (+)= W[64 wave + 32 c .. +31, :] * X[32 rt .. +31, :]^T over S k steps.
-// PD = prefetch distance of the weight fragments in k steps (ring of PD + 1); PRELOAD_ALL: all S steps up front (layer 0).
-template <int RT, int S, int PRELOAD_ALL, class Mid>
-__device__ __forceinline__ void chain_mfma_layer(__amdgpu_buffer_rsrc_t wsrd, int wbase, const char *lds, int wave, int lane, f32x16 (&acc)[RT][2], Mid mid)
-{
-    constexpr int SLOT = ch_slot(RT);
-    constexpr int PD = RT >= 4 ? 2 : 3;
-    // fragment (s, ct = 2 wave + c, plane p) at s * CH_WSTEP + (c * 2 + p) * 1024 of the layer image; the per-lane part is ONE
-    // 32-bit offset beside the uniform buffer descriptor, so no load needs a 64-bit address register pair
-    const unsigned woff = (unsigned)(2 * wave) * 2048u + (unsigned)lane * 16u;
-    asm volatile("" : "+s"(wbase));                                       // per-tile opaque: the k-step offsets are s_add'ed here, not hoisted out of the tile loop (SGPR spills)
-    const char *bp = lds + lane * 16;                                     // fragment (s, rt, plane p) at s * SLOT + (rt * 2 + p) * 1024
-    constexpr int NW = PRELOAD_ALL ? S : PD + 1;
-    u32x4 wf[NW][2][2], bf[2][RT][2];
-    auto load_w = [&](int slot, int s) {
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int p = 0; p < 2; ++p) wf[slot][c][p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wsrd, woff + (c * 2 + p) * 1024, wbase + s * CH_WSTEP, 0));
-    };
-    auto load_b = [&](int slot, int s) {
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int p = 0; p < 2; ++p) bf[slot][rt][p] = *reinterpret_cast<const u32x4 *>(bp + s * SLOT + (rt * 2 + p) * 1024);
-    };
-    if (PRELOAD_ALL) {
-#pragma unroll
-        for (int s = 0; s < S; ++s) load_w(s, s);
-    } else {
-#pragma unroll
-        for (int s = 0; s < PD && s < S; ++s) load_w(s, s);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    mid();                                                                // loads the caller wants queued BEHIND the first weight fragments
-    __builtin_amdgcn_sched_barrier(0);
-    load_b(0, 0);
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-        if (!PRELOAD_ALL && s + PD < S) load_w((s + PD) % (PD + 1), s + PD);
-        if (s + 1 < S) load_b((s + 1) & 1, s + 1);
-        const int ws = PRELOAD_ALL ? s : s % (PD + 1), bs = s & 1;
-#define CH_W(c, p) __builtin_bit_cast(f16x8, wf[ws][c][p])
-#define CH_X(rt, p) __builtin_bit_cast(f16x8, bf[bs][rt][p])
-        // smallest terms first; 2 RT independent accumulators between two MFMAs on the same one
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int c = 0; c < 2; ++c) acc[rt][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(CH_W(c, 1), CH_X(rt, 0), acc[rt][c], 0, 0, 0);
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int c = 0; c < 2; ++c) acc[rt][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(CH_W(c, 0), CH_X(rt, 1), acc[rt][c], 0, 0, 0);
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int c = 0; c < 2; ++c) acc[rt][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(CH_W(c, 0), CH_X(rt, 0), acc[rt][c], 0, 0, 0);
-#undef CH_W
-#undef CH_X
-        // issue order inside the k step: the fragment reads of step s+1 and the 4 weight loads of step s+PD go out under the
-        // FIRST MFMAs (left alone, hipcc sinks the reads to the end of the step and the next step's first MFMA waits for LDS)
-        if (s + 1 < S) {
-#pragma unroll
-            for (int i = 0; i < 2 * RT; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
-        }
-        if (!PRELOAD_ALL && s + PD < S) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
-        }
-        __builtin_amdgcn_sched_barrier(0);                                // keep the prefetch distance: no load of a later k step is hoisted across
-    }
-}
 
 __device__ __forceinline__ float chain_softplus_m1(float x)
 {
@@ -191,6 +89,7 @@ __global__ __launch_bounds__(256, RT >= 4 ? 1 : 2) void chain_kernel(ChainArgs a
     float *exch = reinterpret_cast<float *>(lds + ch_lds_exch(RT));        // [row][wave 4]
     const int col0 = 64 * wave + 16 * h;                                   // this lane's columns: col0 + 32 c + r
     const f32x2 slope2 = {a.slope, a.slope};
+    const unsigned woff = (unsigned)(2 * wave) * 2048u + (unsigned)lane * 16u;       // this wave's column tiles 2 wave, 2 wave + 1 of a weight k step
 
     // the extras k step (slot 16) carries 7 columns: its k = 8..15 half (lanes 32..63 of every fragment) stays zero
     for (int i = tid; i < 2 * RT * 32; i += 256)
@@ -347,7 +246,7 @@ __global__ __launch_bounds__(256, RT >= 4 ? 1 : 2) void chain_kernel(ChainArgs a
             for (int rt = 0; rt < RT; ++rt) inv[rt] = __fmul_rn(pow2f(-14), dw0);
             zero_acc();
             // all 16 weight fragments first, THEN the gathered table rows: the MFMAs wait for the (older) weight loads only
-            chain_mfma_layer<RT, CH_S0, 1>(wsrd, CH_W0, lds, wave, lane, acc, [&]() {
+            h2_mfma_layer<RT, 2, CH_S0, 1, CH_WSTEP, ch_slot(RT)>(wsrd, CH_W0, woff, lds, lane, acc, [&]() {
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) {
                     const float *trow = a.ptab + (size_t)(pid[rt] < 0 ? 0 : pid[rt]) * a.ldt + col0;
@@ -367,7 +266,7 @@ __global__ __launch_bounds__(256, RT >= 4 ? 1 : 2) void chain_kernel(ChainArgs a
         // ---- layer 1 (block1.2) -> operand of block3.0 = [H2 | extras]
         {
             zero_acc();
-            chain_mfma_layer<RT, CH_S1, 0>(wsrd, CH_W1, lds, wave, lane, acc, []() {});
+            h2_mfma_layer<RT, 2, CH_S1, 0, CH_WSTEP, ch_slot(RT)>(wsrd, CH_W1, woff, lds, lane, acc, []() {});
             CH_STAMP(4);
             float amax[RT];
             activate(1, amax, std::false_type{});
@@ -378,7 +277,7 @@ __global__ __launch_bounds__(256, RT >= 4 ? 1 : 2) void chain_kernel(ChainArgs a
         // ---- layer 2 (block3.0)
         {
             zero_acc();
-            chain_mfma_layer<RT, CH_S2, 0>(wsrd, CH_W2, lds, wave, lane, acc, []() {});
+            h2_mfma_layer<RT, 2, CH_S2, 0, CH_WSTEP, ch_slot(RT)>(wsrd, CH_W2, woff, lds, lane, acc, []() {});
             CH_STAMP(7);
             float amax[RT];
             activate(2, amax, std::false_type{});
@@ -389,7 +288,7 @@ __global__ __launch_bounds__(256, RT >= 4 ? 1 : 2) void chain_kernel(ChainArgs a
         // ---- layer 3 (block3.2) + alpha branch + K-weighted sums
         {
             zero_acc();
-            chain_mfma_layer<RT, CH_S3, 0>(wsrd, CH_W3, lds, wave, lane, acc, []() {});
+            h2_mfma_layer<RT, 2, CH_S3, 0, CH_WSTEP, ch_slot(RT)>(wsrd, CH_W3, woff, lds, lane, acc, []() {});
             CH_STAMP(8);
             float amax[RT];
             activate(3, amax, std::false_type{});

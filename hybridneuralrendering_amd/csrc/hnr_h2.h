@@ -1,0 +1,112 @@
+// Shared pieces of the "f16x2" dense arithmetic (csrc/chain.hip, csrc/mlp.hip): fp32 operands split into two fp16 terms under exact
+// power-of-two scales, three v_mfma_f32_32x32x16_f16 per product, fp32 accumulation.  See the header of chain.hip.
+#pragma once
+#include <type_traits>
+
+#include "hnr_common.h"
+
+namespace hnr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int CH_ACT_EXP = 15;                     // a row's maximum is scaled into [2^14, 2^15)
+constexpr int CH_W_EXP = 14;                       // a layer's largest weight is scaled into [2^13, 2^14)
+
+// (x0, x1) -> packed fp16 pairs h, m with x = h + m + O(2^-22 |x|); round-to-nearest-even
+__device__ __forceinline__ void split2h(float x0, float x1, unsigned &ph, unsigned &pm)
+{
+    float r0, r1;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(ph) : "v"(x0), "v"(x1));
+    asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(ph), "v"(x0));                  // x0 - h.lo (exact)
+    asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(ph), "v"(x1));    // x1 - h.hi
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(pm) : "v"(r0), "v"(r1));
+}
+
+__device__ __forceinline__ float pow2f(int e) { return __uint_as_float((unsigned)(127 + e) << 23); }   // -126 <= e <= 127
+
+// scale exponent k of a row whose largest |value| is m: m * 2^k in [2^(CH_ACT_EXP-1), 2^CH_ACT_EXP)
+__device__ __forceinline__ int row_scale_exp(float m)
+{
+    int ex = (int)((__float_as_uint(m) >> 23) & 0xffu);          // biased exponent; m >= 0
+    ex = ex < 48 ? 48 : (ex > 250 ? 250 : ex);                   // zero / tiny rows: scale 2^93 at most; inf / nan rows: garbage in, garbage out
+    return CH_ACT_EXP + 126 - ex;
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// one dense layer of the tile: acc[rt][c] (+)= W[64 wave + 32 c .. +31, :] * X[32 rt .. +31, :]^T over S k steps.
+// PD = prefetch distance of the weight fragments in k steps (ring of PD + 1); PRELOAD_ALL: all S steps up front (layer 0).
+// woff = this lane's byte offset inside a k step of the weight image (first column tile of the wave + lane * 16), WSTEP = bytes per k step
+// of the image ([column tile][plane 2][64 lanes][16 B]), SLOT = LDS bytes per k step of the activation planes ([row tile][plane 2][1 KiB]).
+template <int RT, int CT, int S, int PRELOAD_ALL, int WSTEP, int SLOT, class Mid>
+__device__ __forceinline__ void h2_mfma_layer(__amdgpu_buffer_rsrc_t wsrd, int wbase, unsigned woff, const char *lds, int lane, f32x16 (&acc)[RT][CT], Mid mid)
+{
+    constexpr int PD = RT * CT >= 8 ? 2 : 3;
+    // fragment (s, column tile c of the wave, plane p) at s * WSTEP + (c * 2 + p) * 1024 + woff of the layer image; the per-lane part
+    // is ONE 32-bit offset beside the uniform buffer descriptor, so no load needs a 64-bit address register pair
+    asm volatile("" : "+s"(wbase));                                       // per-tile opaque: the k-step offsets are s_add'ed here, not hoisted out of the tile loop (SGPR spills)
+    const char *bp = lds + lane * 16;                                     // fragment (s, rt, plane p) at s * SLOT + (rt * 2 + p) * 1024
+    constexpr int NW = PRELOAD_ALL ? S : PD + 1;
+    u32x4 wf[NW][CT][2], bf[2][RT][2];
+    auto load_w = [&](int slot, int s) {
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) wf[slot][c][p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wsrd, woff + (c * 2 + p) * 1024, wbase + s * WSTEP, 0));
+    };
+    auto load_b = [&](int slot, int s) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) bf[slot][rt][p] = *reinterpret_cast<const u32x4 *>(bp + s * SLOT + (rt * 2 + p) * 1024);
+    };
+    if (PRELOAD_ALL) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) load_w(s, s);
+    } else {
+#pragma unroll
+        for (int s = 0; s < PD && s < S; ++s) load_w(s, s);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mid();                                                                // loads the caller wants queued BEHIND the first weight fragments
+    __builtin_amdgcn_sched_barrier(0);
+    load_b(0, 0);
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        if (!PRELOAD_ALL && s + PD < S) load_w((s + PD) % (PD + 1), s + PD);
+        if (s + 1 < S) load_b((s + 1) & 1, s + 1);
+        const int ws = PRELOAD_ALL ? s : s % (PD + 1), bs = s & 1;
+#define CH_W(c, p) __builtin_bit_cast(f16x8, wf[ws][c][p])
+#define CH_X(rt, p) __builtin_bit_cast(f16x8, bf[bs][rt][p])
+        // smallest terms first; RT * CT independent accumulators between two MFMAs on the same one
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int c = 0; c < CT; ++c) acc[rt][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(CH_W(c, 1), CH_X(rt, 0), acc[rt][c], 0, 0, 0);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int c = 0; c < CT; ++c) acc[rt][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(CH_W(c, 0), CH_X(rt, 1), acc[rt][c], 0, 0, 0);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int c = 0; c < CT; ++c) acc[rt][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(CH_W(c, 0), CH_X(rt, 0), acc[rt][c], 0, 0, 0);
+#undef CH_W
+#undef CH_X
+        // issue order inside the k step: the fragment reads of step s+1 and the 4 weight loads of step s+PD go out under the
+        // FIRST MFMAs (left alone, hipcc sinks the reads to the end of the step and the next step's first MFMA waits for LDS)
+        if (s + 1 < S) {
+#pragma unroll
+            for (int i = 0; i < 2 * RT; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+        }
+        if (!PRELOAD_ALL && s + PD < S) {
+#pragma unroll
+            for (int i = 0; i < 2 * CT; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
+        }
+        __builtin_amdgcn_sched_barrier(0);                                // keep the prefetch distance: no load of a later k step is hoisted across
+    }
+}
+
+}  // namespace hnr

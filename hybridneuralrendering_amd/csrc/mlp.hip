@@ -1,0 +1,337 @@
+// Three dense layers (nn.Linear + LeakyReLU) of width <= 128 in ONE kernel, fp32 in / fp32 out, "f16x2" arithmetic (hnr_h2.h):
+// the per-SAMPLE MLPs of PointAggregator.viewmlp,
+//   color_feature_branch   280 -> 128 -> 128 -> 128                              models/aggregators/point_aggregators.py:1028-1037
+//   aux_merge_weight_block [imgfeat45 | ddir3] (+ per-sample colour-feature addend) -> 64 -> 64 -> 64    :1199 (first three layers)
+//   color_mixup_block      90 -> 45 -> 45 -> 45 (last layer without activation)  :1285-1292
+// which the per-layer path runs as 3 + 3 + 3 fp32-MFMA launches with every [rows, width] activation written to and re-read from
+// HBM (13.7 ms of the round-1 frame for 0.35 TFLOP).  Here a workgroup carries a tile of 128 rows through the three layers with
+// the activations staged in LDS as fp16 (h, m) planes in MFMA fragment order, exactly like csrc/chain.hip: wave w owns output
+// columns 32 w .. 32 w + 31 (waves whose columns are padding idle through the layer), weights stream L2 -> registers.
+#include <stdlib.h>
+
+#include "hnr_h2.h"
+
+namespace hnr {
+
+constexpr int ML_SLOT = 8192;                      // LDS bytes per k step of the activation planes: [row tile 4][plane 2][64 lanes][16 B]
+constexpr int ML_WSTEP = 8192;                     // weight image bytes per k step: [column tile 4][plane 2][64 lanes][16 B]
+constexpr int ML_META_FLOATS = 3 * 128 + 4 + 4;    // bias[3][128], descale[3] (+pad), max|W| bits[3] (+pad)
+
+struct MlpArgs {
+    const float *A; int lda;           // [M, lda] input rows
+    const float *R; const int32_t *ridx; int ldr;      // optional addend of layer 0: R[ridx[row], 0:N0]
+    const char *wimg;                  // packed weights (hnr_mlp_pack)
+    int wbase[3];                      // byte offset of every layer's image
+    int K0, N[3], act[3];
+    float slope;
+    const unsigned long long *counts; int count_index, count_mult; long long M_cap;     // M = min(M_cap, counts[index] * mult) (counts may be NULL)
+    float *C; int ldc;                 // [M, ldc] output rows (N[2] columns)
+};
+
+template <int S0, int S1, int S2>
+__global__ __launch_bounds__(256, 1) void mlp3_kernel(MlpArgs a)
+{
+    constexpr int SMAX = S0 > S1 ? (S0 > S2 ? S0 : S2) : (S1 > S2 ? S1 : S2);
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, j = lane & 31;
+    long long M = a.M_cap;
+    if (a.counts) { const long long c = (long long)a.counts[a.count_index] * a.count_mult; if (c < M) M = c; }
+    const int n_tiles = (int)((M + 127) / 128);
+    const int total_steps = S0 + S1 + S2;
+    const float *meta = reinterpret_cast<const float *>(a.wimg + (size_t)total_steps * ML_WSTEP);
+    const __amdgpu_buffer_rsrc_t wsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(a.wimg), 0, total_steps * ML_WSTEP, 0x00020000);
+    float *exch = reinterpret_cast<float *>(lds + SMAX * ML_SLOT);         // [row 128][wave 4]
+    float *rowinv = exch + 128 * 4;                                        // [row 128]: 2^-k of the input row's scale
+    const int col0 = 32 * wave + 16 * h;                                   // this lane's columns: col0 + r
+    const unsigned woff = (unsigned)wave * 2048u + (unsigned)lane * 16u;
+    const f32x2 slope2 = {a.slope, a.slope};
+
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const long long row_base = (long long)tile * 128;
+        float inv[4];
+        // ---- prologue: wave w loads rows 32 w + j (lane half hh takes k = 16 s + 8 hh .. + 7 of every k step), scales each row by
+        // a power of two from its own maximum, splits and writes the layer-0 operand planes
+        {
+            long long row = row_base + 32 * wave + j;
+            if (row >= M) row = M - 1;
+            const float *src = a.A + (size_t)row * a.lda + 8 * h;
+            float x[S0][8];
+            float m = 0.f;
+#pragma unroll
+            for (int s = 0; s < S0; ++s) {
+                const int k0 = 16 * s + 8 * h;
+                float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+                if (k0 + 4 <= a.lda) v0 = *reinterpret_cast<const float4 *>(src + 16 * s);
+                if (k0 + 8 <= a.lda) v1 = *reinterpret_cast<const float4 *>(src + 16 * s + 4);
+                const float t[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    x[s][e] = (k0 + e < a.K0) ? t[e] : 0.f;
+                    m = fmaxf(m, fabsf(x[s][e]));
+                }
+            }
+            m = fmaxf(m, __shfl_xor(m, 32));
+            const int k = row_scale_exp(m);
+            const float sc = pow2f(k);
+            if (h == 0) rowinv[32 * wave + j] = pow2f(-k);
+#pragma unroll
+            for (int s = 0; s < S0; ++s) {
+                unsigned ph[4], pm[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) split2h(__fmul_rn(x[s][2 * q], sc), __fmul_rn(x[s][2 * q + 1], sc), ph[q], pm[q]);
+                char *dst = lds + s * ML_SLOT + (wave * 2) * 1024 + lane * 16;
+                *reinterpret_cast<u32x4 *>(dst) = u32x4{ph[0], ph[1], ph[2], ph[3]};
+                *reinterpret_cast<u32x4 *>(dst + 1024) = u32x4{pm[0], pm[1], pm[2], pm[3]};
+            }
+        }
+        __syncthreads();
+        {
+            const float dw0 = meta[3 * 128 + 0];
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) inv[rt] = __fmul_rn(rowinv[32 * rt + j], dw0);
+        }
+
+        f32x16 acc[4][1];
+        auto zero_acc = [&]() {
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[rt][0][r] = 0.f;
+        };
+        // v = acc * inv + bias (+ addend) (+ LeakyReLU); returns the per-row maxima of this wave's columns
+        auto activate = [&](int layer, float (&amax)[4], auto with_addend) {
+            constexpr bool ADD = decltype(with_addend)::value;
+            f32x2 bias[8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 b = *reinterpret_cast<const float4 *>(meta + layer * 128 + col0 + 4 * q);
+                bias[2 * q] = f32x2{b.x, b.y}; bias[2 * q + 1] = f32x2{b.z, b.w};
+            }
+            const bool act = a.act[layer] != 0;
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) {
+                float m = 0.f;
+                const f32x2 inv2 = {inv[rt], inv[rt]};
+                const float *rrow = nullptr;
+                if (ADD) {
+                    long long row = row_base + 32 * rt + j;
+                    if (row >= M) row = M - 1;
+                    rrow = a.R + (size_t)a.ridx[row] * a.ldr + col0;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    f32x2 add = bias[q];
+                    if (ADD) { const float2 t2 = *reinterpret_cast<const float2 *>(rrow + 2 * q); add = add + f32x2{t2.x, t2.y}; }
+                    f32x2 v = __builtin_elementwise_fma(f32x2{acc[rt][0][2 * q], acc[rt][0][2 * q + 1]}, inv2, add);
+                    if (act) { const f32x2 sv = v * slope2; v.x = fmaxf(v.x, sv.x); v.y = fmaxf(v.y, sv.y); }
+                    acc[rt][0][2 * q] = v.x; acc[rt][0][2 * q + 1] = v.y;
+                    m = fmaxf(fmaxf(m, fabsf(v.x)), fabsf(v.y));
+                }
+                amax[rt] = m;
+            }
+        };
+        auto publish = [&](int next_layer, bool active, float (&amax)[4]) {
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) {
+                const float m = active ? fmaxf(amax[rt], __shfl_xor(amax[rt], 32)) : 0.f;
+                if (h == 0) exch[(32 * rt + j) * 4 + wave] = m;
+            }
+            __syncthreads();                                               // every wave has finished reading the previous planes
+            const float dw = meta[3 * 128 + next_layer];
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) {
+                const float4 m4 = *reinterpret_cast<const float4 *>(exch + (32 * rt + j) * 4);
+                const int k = row_scale_exp(fmaxf(fmaxf(m4.x, m4.y), fmaxf(m4.z, m4.w)));
+                const float sc = pow2f(k);
+                const f32x2 sc2 = {sc, sc};
+                inv[rt] = __fmul_rn(pow2f(-k), dw);
+                if (active) {
+                    unsigned ph[8], pm[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const f32x2 vs = f32x2{acc[rt][0][2 * q], acc[rt][0][2 * q + 1]} * sc2;
+                        split2h(vs.x, vs.y, ph[q], pm[q]);
+                    }
+                    char *dst = lds + (2 * wave + h) * ML_SLOT + (rt * 2) * 1024 + j * 16;
+                    *reinterpret_cast<u32x4 *>(dst) = u32x4{ph[0], ph[1], ph[2], ph[3]};
+                    *reinterpret_cast<u32x4 *>(dst + 512) = u32x4{ph[4], ph[5], ph[6], ph[7]};
+                    *reinterpret_cast<u32x4 *>(dst + 1024) = u32x4{pm[0], pm[1], pm[2], pm[3]};
+                    *reinterpret_cast<u32x4 *>(dst + 1024 + 512) = u32x4{pm[4], pm[5], pm[6], pm[7]};
+                }
+            }
+            __syncthreads();
+        };
+        const bool act0 = 32 * wave < a.N[0], act1 = 32 * wave < a.N[1], act2 = 32 * wave < a.N[2];
+        float amax[4];
+        // ---- layer 0
+        zero_acc();
+        if (act0) {
+            h2_mfma_layer<4, 1, S0, 0, ML_WSTEP, ML_SLOT>(wsrd, a.wbase[0], woff, lds, lane, acc, []() {});
+            if (a.R) activate(0, amax, std::true_type{}); else activate(0, amax, std::false_type{});
+        }
+        publish(1, act0, amax);
+        // ---- layer 1
+        zero_acc();
+        if (act1) {
+            h2_mfma_layer<4, 1, S1, 0, ML_WSTEP, ML_SLOT>(wsrd, a.wbase[1], woff, lds, lane, acc, []() {});
+            activate(1, amax, std::false_type{});
+        }
+        publish(2, act1, amax);
+        // ---- layer 2 -> fp32 rows
+        zero_acc();
+        if (act2) {
+            h2_mfma_layer<4, 1, S2, 0, ML_WSTEP, ML_SLOT>(wsrd, a.wbase[2], woff, lds, lane, acc, []() {});
+            activate(2, amax, std::false_type{});
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) {
+                const long long row = row_base + 32 * rt + j;
+                if (row < M) {
+                    float *o = a.C + (size_t)row * a.ldc + col0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int c = col0 + 4 * q;
+                        if (c + 4 <= a.ldc)
+                            *reinterpret_cast<float4 *>(o + 4 * q) = make_float4(acc[rt][0][4 * q], acc[rt][0][4 * q + 1], acc[rt][0][4 * q + 2], acc[rt][0][4 * q + 3]);
+                    }
+                }
+            }
+        }
+        __syncthreads();                                                   // the planes and rowinv are rewritten by the next tile's prologue
+    }
+}
+
+struct MlpPackArgs {
+    const float *W[3]; int ldw[3], N[3], K[3], S[3], base[3];
+    const float *b[3];
+    char *out; int total_steps;
+};
+
+__global__ void mlp_wmax_kernel(MlpPackArgs a)
+{
+    const int l = blockIdx.y;
+    unsigned *wmax = reinterpret_cast<unsigned *>(a.out + (size_t)a.total_steps * ML_WSTEP) + 3 * 128 + 4;
+    float m = 0.f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.N[l] * a.K[l]; i += gridDim.x * blockDim.x) {
+        const int n = i / a.K[l], k = i - n * a.K[l];
+        m = fmaxf(m, fabsf(a.W[l][(size_t)n * a.ldw[l] + k]));
+    }
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(wmax + l, __float_as_uint(m));
+}
+
+__global__ void mlp_pack_kernel(MlpPackArgs a)
+{
+    const int l = blockIdx.y;
+    float *meta = reinterpret_cast<float *>(a.out + (size_t)a.total_steps * ML_WSTEP);
+    const unsigned maxbits = reinterpret_cast<const unsigned *>(meta)[3 * 128 + 4 + l];
+    int ex = (int)((maxbits >> 23) & 0xffu);
+    ex = ex < 110 ? 110 : (ex > 160 ? 160 : ex);
+    const int sw = CH_W_EXP + 126 - ex;
+    const float scale = pow2f(sw);
+    const int total = a.S[l] * 4 * 64 * 8;                                     // (s, ct, lane, e)
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int e = i & 7, ln = (i >> 3) & 63, ct = (i >> 9) & 3, s = i >> 11;
+        const int ii = ln & 31, hh = ln >> 5;
+        const int n = 32 * ct + 16 * ((ii >> 2) & 1) + (ii & 3) + 4 * (ii >> 3), k = 16 * s + 8 * hh + e;
+        const float x = (n < a.N[l] && k < a.K[l]) ? __fmul_rn(a.W[l][(size_t)n * a.ldw[l] + k], scale) : 0.f;
+        const _Float16 hv = (_Float16)x;
+        const _Float16 mv = (_Float16)__fsub_rn(x, (float)hv);
+        _Float16 *dst = reinterpret_cast<_Float16 *>(a.out + a.base[l] + (size_t)s * ML_WSTEP + (ct * 2) * 1024 + ln * 16) + e;
+        dst[0] = hv;
+        dst[512] = mv;
+    }
+    if (blockIdx.x == 0) {
+        for (int i = threadIdx.x; i < 128; i += blockDim.x) meta[l * 128 + i] = (a.b[l] && i < a.N[l]) ? a.b[l][i] : 0.f;
+        if (threadIdx.x == 0) meta[3 * 128 + l] = pow2f(-sw);
+    }
+}
+
+}  // namespace hnr
+
+using namespace hnr;
+
+static int mlp_steps(int K) { return (K + 15) / 16; }
+
+extern "C" int64_t hnr_mlp3_packed_bytes(const int *K)
+{
+    if (!K) return -1;
+    int64_t steps = 0;
+    for (int l = 0; l < 3; ++l) { if (K[l] <= 0 || K[l] > 288) return -1; steps += mlp_steps(K[l]); }
+    return steps * ML_WSTEP + ML_META_FLOATS * 4;
+}
+
+extern "C" int hnr_mlp3_pack(const float *const *d_W, const int *ldw, const int *N, const int *K, const float *const *d_bias, void *d_packed,
+                             void *stream)
+{
+    if (!d_W || !ldw || !N || !K || !d_bias || !d_packed || ((uintptr_t)d_packed & 15)) { set_error("hnr_mlp3_pack: NULL / unaligned pointer"); return HNR_ERR_BADARG; }
+    MlpPackArgs a;
+    int steps = 0;
+    for (int l = 0; l < 3; ++l) {
+        if (!d_W[l] || N[l] <= 0 || N[l] > 128 || K[l] <= 0 || K[l] > 288 || ldw[l] < K[l] || (l > 0 && K[l] != N[l - 1])) {
+            set_error("hnr_mlp3_pack: layer %d: N=%d (1..128) K=%d (1..288, = N of the previous layer) ldw=%d", l, N[l], K[l], ldw[l]);
+            return HNR_ERR_BADARG;
+        }
+        a.W[l] = d_W[l]; a.ldw[l] = ldw[l]; a.N[l] = N[l]; a.K[l] = K[l]; a.S[l] = mlp_steps(K[l]); a.b[l] = d_bias[l];
+        a.base[l] = steps * ML_WSTEP;
+        steps += a.S[l];
+    }
+    a.out = (char *)d_packed; a.total_steps = steps;
+    hipStream_t st = (hipStream_t)stream;
+    HNR_HIP_CHECK(hipMemsetAsync(a.out + (size_t)steps * ML_WSTEP, 0, ML_META_FLOATS * 4, st));
+    mlp_wmax_kernel<<<dim3(16, 3), 256, 0, st>>>(a);
+    HNR_LAUNCH_CHECK();
+    mlp_pack_kernel<<<dim3(32, 3), 256, 0, st>>>(a);
+    HNR_LAUNCH_CHECK();
+    return HNR_OK;
+}
+
+extern "C" int hnr_mlp3_forward(const float *d_A, int lda, int64_t M_cap, const int64_t *d_counts, int count_index, int count_mult,
+                                const void *d_packed, const int *N, const int *K, const int *act, float slope, const float *d_R,
+                                const int32_t *d_ridx, int ldr, float *d_C, int ldc, void *stream)
+{
+    if (!N || !K || !act || M_cap < 0 || lda < K[0] || (lda & 3) || ldc < N[2] || (ldc & 3) || !(slope > 0.f && slope < 1.f) || (d_R && (!d_ridx || ldr < N[0] || (ldr & 1)))) {
+        set_error("hnr_mlp3_forward: bad sizes (lda=%d ldc=%d ldr=%d slope=%g)", lda, ldc, ldr, (double)slope);
+        return HNR_ERR_BADARG;
+    }
+    if (M_cap == 0) return HNR_OK;
+    if (!d_A || !d_packed || !d_C || ((uintptr_t)d_A & 15) || ((uintptr_t)d_C & 15) || ((uintptr_t)d_packed & 15) || ((uintptr_t)d_R & 7)) {
+        set_error("hnr_mlp3_forward: NULL / unaligned pointer");
+        return HNR_ERR_BADARG;
+    }
+    MlpArgs a;
+    a.A = d_A; a.lda = lda; a.R = d_R; a.ridx = d_ridx; a.ldr = ldr; a.wimg = (const char *)d_packed;
+    int steps = 0, S[3];
+    for (int l = 0; l < 3; ++l) {
+        if (N[l] <= 0 || N[l] > 128 || K[l] <= 0 || K[l] > 288 || (l > 0 && K[l] != N[l - 1])) { set_error("hnr_mlp3_forward: bad layer %d (N=%d K=%d)", l, N[l], K[l]); return HNR_ERR_BADARG; }
+        S[l] = mlp_steps(K[l]); a.wbase[l] = steps * ML_WSTEP; steps += S[l]; a.N[l] = N[l]; a.act[l] = act[l];
+    }
+    a.K0 = K[0]; a.slope = slope;
+    a.counts = reinterpret_cast<const unsigned long long *>(d_counts); a.count_index = count_index; a.count_mult = count_mult; a.M_cap = M_cap;
+    a.C = d_C; a.ldc = ldc;
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+        if (n_cu <= 0) n_cu = 256;
+    }
+    const int64_t tiles = (M_cap + 127) / 128;
+    const int grid = (int)(tiles < n_cu ? tiles : n_cu);
+    hipStream_t st = (hipStream_t)stream;
+#define HNR_MLP3_CASE(S0_, S1_, S2_)                                                                                                   \
+    if (S[0] == S0_ && S[1] == S1_ && S[2] == S2_) {                                                                                    \
+        constexpr int smax = S0_ > S1_ ? (S0_ > S2_ ? S0_ : S2_) : (S1_ > S2_ ? S1_ : S2_);                                             \
+        constexpr int ldsb = smax * ML_SLOT + 128 * 4 * 4 + 128 * 4;                                                                    \
+        static bool attr = false;                                                                                                       \
+        if (!attr) { HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(mlp3_kernel<S0_, S1_, S2_>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb)); attr = true; } \
+        mlp3_kernel<S0_, S1_, S2_><<<grid, 256, ldsb, st>>>(a);                                                                         \
+        HNR_LAUNCH_CHECK();                                                                                                             \
+        return HNR_OK;                                                                                                                  \
+    }
+    HNR_MLP3_CASE(18, 8, 8)        // color_feature_branch: 280 -> 128 -> 128 -> 128
+    HNR_MLP3_CASE(3, 4, 4)         // aux_merge_weight_block: 48 -> 64 -> 64 -> 64
+    HNR_MLP3_CASE(6, 3, 3)         // color_mixup_block: 90 -> 45 -> 45 -> 45
+#undef HNR_MLP3_CASE
+    set_error("hnr_mlp3_forward: no kernel for k steps (%d, %d, %d); built: (18,8,8) (3,4,4) (6,3,3)", S[0], S[1], S[2]);
+    return HNR_ERR_BADARG;
+}

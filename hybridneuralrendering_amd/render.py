@@ -198,11 +198,17 @@ class HybridRenderer:
                                     p(raydir), p(counts), SR, n_valid, p(X5), 280, p(sigma), st()), "hnr_ksum")
             del A, B, C, Xd
           sl = pk["slope"]
+          fused_s = self.dense == "f16x2"          # the per-sample MLPs as fused three-layer launches (hnr_mlp3_forward)
+          m3 = self.agg.packed_mlp3() if fused_s else None
+          ci = CNT["SAMPLES_VALID"]
           with T("mlp_colorfeat"):
-            T1, T2 = _f32((n_valid, 128), dev), _f32((n_valid, 128), dev)
-            pk["cf"][0](X5, out=T1, act=True, slope=sl)
-            pk["cf"][1](T1, out=T2, act=True, slope=sl)
-            CF = pk["cf"][2](T2, out=T1, act=True, slope=sl)
+            if fused_s:
+                CF = m3["cf"](X5, _f32((n_valid, 128), dev), n_valid, counts, ci, 1, slope=sl)
+            else:
+                T1, T2 = _f32((n_valid, 128), dev), _f32((n_valid, 128), dev)
+                pk["cf"][0](X5, out=T1, act=True, slope=sl)
+                pk["cf"][1](T1, out=T2, act=True, slope=sl)
+                CF = pk["cf"][2](T2, out=T1, act=True, slope=sl)
           no_views = getattr(self.opt, "use_nearest", 4) == 0
           if no_views:
             # use_nearest = 0 (scene241.sh): the image branch is off, merged = 0 (point_aggregators.py:1257-1258)
@@ -219,14 +225,20 @@ class HybridRenderer:
                                          p(campos_nearest), p(featmap), V, H, W, p(CF), 128, n_valid, p(X6), ld6, p(vmask),
                                          p(row_s) if self.split_merge else None, st()), "hnr_proj_rows")
             with T("mlp_merge"):
-              M1, M2 = _f32((V * n_valid, 64), dev), _f32((V * n_valid, 64), dev)
-              if self.split_merge:
+              M1 = _f32((V * n_valid, 64), dev)
+              if fused_s and self.split_merge:
+                  pre = pk["mw0_cf"](CF, act=False)                                     # [S,64] once per sample (bias included)
+                  m3["mw"](X6, M1, V * n_valid, counts, ci, V, slope=sl, R=pre, ridx=row_s)
+              elif self.split_merge:
+                  M2 = _f32((V * n_valid, 64), dev)
                   pre = pk["mw0_cf"](CF, act=False)                                     # [S,64] once per sample (bias included)
                   pk["mw0_fd"].gather_add(X6, pre, row_s, out=M1, act=True, slope=sl)   # 48 -> 64 per (view, sample) + addend
               else:
+                  M2 = _f32((V * n_valid, 64), dev)
                   pk["mw"][0](X6, out=M1, act=True, slope=sl)
-              pk["mw"][1](M1, out=M2, act=True, slope=sl)
-              pk["mw"][2](M2, out=M1, act=True, slope=sl)
+              if not (fused_s and self.split_merge):
+                  pk["mw"][1](M1, out=M2, act=True, slope=sl)
+                  pk["mw"][2](M2, out=M1, act=True, slope=sl)
             with T("merge"):
               X7 = _f32((n_valid, 92), dev)
               fw = None if frame_weight is None else _lib.require_gpu(frame_weight, "frame_weight", torch.float32).reshape(-1)
@@ -234,10 +246,14 @@ class HybridRenderer:
                                      p(fw) if fw is not None else None, p(CF), 128, p(counts), V, n_valid, p(X7), 92,
                                      None, None, 0, st()), "hnr_merge")
           with T("mlp_mixup"):
-            Y1, Y2 = _f32((n_valid, 48), dev), _f32((n_valid, 48), dev)
-            pk["mx"][0](X7, out=Y1, act=True, slope=sl, K=90)
-            pk["mx"][1](Y1, out=Y2, act=True, slope=sl, K=45)
-            pk["mx"][2](Y2, out=Y1, act=False, K=45)
+            Y1 = _f32((n_valid, 48), dev)
+            if fused_s:
+                m3["mx"](X7, Y1, n_valid, counts, ci, 1, slope=sl)
+            else:
+                Y2 = _f32((n_valid, 48), dev)
+                pk["mx"][0](X7, out=Y1, act=True, slope=sl, K=90)
+                pk["mx"][1](Y1, out=Y2, act=True, slope=sl, K=45)
+                pk["mx"][2](Y2, out=Y1, act=False, K=45)
           with T("final_color"):
             _lib.check(L.hnr_final_color(p(Y1), 48, p(CF), 128, p(pk["fin_w"]), p(pk["fin_b"]), p(sigma), p(vs_item), p(counts),
                                          n_valid, p(decoded), st()), "hnr_final_color")

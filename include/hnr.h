@@ -311,6 +311,20 @@ int hnr_chain_gather(const float *d_xyz, const float *d_conf, const float *d_dir
 int hnr_chain_forward(const void *d_workspace, const float *d_point_table, int ldt, const void *d_packed, const int64_t *d_counts,
                       int cap_samples, float slope, float *d_X5, int ld5, float *d_sigma, float *d_dbg, int dbg_layer, void *stream);
 
+/* Three consecutive nn.Linear (+ LeakyReLU) layers of width <= 128 fused into one kernel (csrc/mlp.hip), fp32 in / fp32 out, the
+ * same two-term fp16 split arithmetic as the chain above: the per-sample MLPs of viewmlp -- color_feature_branch (:1028-1037),
+ * the first three layers of aux_merge_weight_block (:1199) and color_mixup_block (:1285-1292).
+ *   hnr_mlp3_pack: d_W[l] [N[l], K[l]] (row stride ldw[l]), d_bias[l] [N[l]] or NULL; K[l] = N[l-1]; K[0] <= 288, N <= 128.
+ *   hnr_mlp3_forward: d_C[m, 0:N[2]] = L2(L1(L0(d_A[m, 0:K[0]]) )), act[l] != 0 applies LeakyReLU(slope) after layer l; optional addend of
+ *   layer 0 before its activation: d_R[d_ridx[m], 0:N[0]] (the colour-feature part of aux_merge_weight_block.0, shared by a sample's
+ *   views).  Rows: M = min(M_cap, d_counts[count_index] * count_mult) when d_counts != NULL (device-side count), else M_cap.
+ *   Built for the k-step triples of the three uses: K = (280,128,128), (48,64,64), (90,45,45). */
+int64_t hnr_mlp3_packed_bytes(const int *K);
+int hnr_mlp3_pack(const float *const *d_W, const int *ldw, const int *N, const int *K, const float *const *d_bias, void *d_packed, void *stream);
+int hnr_mlp3_forward(const float *d_A, int lda, int64_t M_cap, const int64_t *d_counts, int count_index, int count_mult,
+                     const void *d_packed, const int *N, const int *K, const int *act, float slope, const float *d_R,
+                     const int32_t *d_ridx, int ldr, float *d_C, int ldc, void *stream);
+
 /* Residual + color_final_block + sigmoid*1.002-0.001 (:1294-1295, :1334, :478-482), scattered with sigma into
  * d_decoded [R*SR,4] (pre-zeroed by the caller; :1337-1338). */
 int hnr_final_color(const float *d_Y, int ldy, const float *d_CF, int ldcf, const float *d_w_fin, const float *d_b_fin,
