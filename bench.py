@@ -308,7 +308,12 @@ def main():
 
     if rank == 0:
         counts = out["counts"].cpu().numpy() if args.chunk <= 0 or args.chunk >= R else None
-        stage_ms = {k: sum(e0.elapsed_time(e1) for e0, e1 in v) / args.steps for k, v in timers.items()}
+        # stage times inside the timed region: HIP events recorded on the launch stream -- by torch around the Python-driven stages, by
+        # the library itself at the stage boundaries of the single-call path (hnr_render_forward's stage_events hook)
+        stage_ms = {k: sum(e0.elapsed_time(e1) for e0, e1 in v) / args.steps for k, v in timers.items() if k != "_stage_events"}
+        for ev in timers.get("_stage_events", []):
+            for k, ms in ev.elapsed_ms().items():
+                stage_ms[k] = stage_ms.get(k, 0.0) + ms / args.steps
         # --- roofline of the dominant kernel (fp32 MFMA dense layer) and of the query stage, from HIP events
         # recorded on the launch stream inside the timed region
         roof, roof_q = None, None
@@ -429,6 +434,7 @@ def main():
                                       sc.xyz.shape[0], sc.w, sc.h, args.margin, R_frame,
                                       "ONE fixed frame sharded over the ranks" if strong else "one such frame per rank",
                                       opt.SR, opt.K, opt.P, opt.max_o, opt.z_depth_dim, sc.h, sc.w),
+                       "entry": "hnr_render_forward (one library call per frame, no host read)" if getattr(rnd, "single_call", False) and fused else "per-stage C-ABI calls from Python",
                        "rays_per_step": R_job, "rays_per_gpu": R, "points": int(sc.xyz.shape[0]), "chunk_rays": args.chunk if args.chunk > 0 else R,
                        "parallelism": ("one fixed frame ray-sharded x%d (contiguous scan-line blocks), one RCCL gather" if strong else
                                        "one frame per rank x%d, one RCCL gather") % world},

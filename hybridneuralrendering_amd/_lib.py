@@ -39,6 +39,38 @@ _P = ctypes.c_void_p
 _I = ctypes.c_int
 _F = ctypes.c_float
 
+
+class RenderParams(ctypes.Structure):
+    _fields_ = [("R", _I), ("SR", _I), ("K", _I), ("D", _I), ("tmid_stride", _I), ("kernel_size", _I * 3), ("radius2", _F), ("vsize_z", _F),
+                ("raydist_mode_unit", _I), ("V", _I), ("cap_samples", _I)]
+
+
+class RenderCloud(ctypes.Structure):
+    _fields_ = [("d_xyz", _P), ("d_conf", _P), ("d_dir", _P), ("d_color", _P), ("d_point_table", _P), ("ldt", _I)]
+
+
+class RenderWeights(ctypes.Structure):
+    _fields_ = [("d_chain", _P), ("d_mlp_cf", _P), ("d_mlp_mw", _P), ("d_mlp_mx", _P),
+                ("d_mw_last_w", _P), ("d_mw_last_b", _P), ("d_fin_w", _P), ("d_fin_b", _P), ("slope", _F)]
+
+
+class RenderCamera(ctypes.Structure):
+    _fields_ = [("d_campos", _P), ("d_camrot", _P), ("d_raydir", _P), ("d_tmid", _P), ("d_bg_color", _P)]
+
+
+class RenderViews(ctypes.Structure):
+    _fields_ = [("d_w2c", _P), ("d_intrinsic", _P), ("d_campos_nearest", _P), ("d_featmap", _P), ("H", _I), ("W", _I), ("d_frame_w", _P)]
+
+
+class RenderOutputs(ctypes.Structure):
+    _fields_ = [("d_raycolor", _P), ("d_opacity", _P), ("d_is_background", _P), ("d_blend_weight", _P), ("d_ray_mask", _P), ("d_decoded", _P),
+                ("d_sample_pidx", _P), ("d_sample_loc_w", _P), ("d_ray_nsamp", _P), ("d_counts", _P), ("d_status", _P), ("d_weight", _P),
+                ("d_conf_coefficient", _P), ("stage_events", ctypes.POINTER(_P))]
+
+
+RENDER_STAGES = ("query", "plan_gather", "chain_gather", "chain", "mlp_colorfeat", "proj_rows", "mlp_merge", "merge", "mlp_mixup", "final_color",
+                 "composite")
+
 # name -> (restype, argtypes); must list every symbol include/hnr.h declares (tests check this)
 SIGNATURES = {
     "hnr_version": (ctypes.c_char_p, []),
@@ -77,9 +109,12 @@ SIGNATURES = {
     "hnr_chain_pack": (_I, [_P, _I] + [_P] * 9 + [_P, _P]),
     "hnr_chain_gather": (_I, [_P] * 11 + [_I, _I, _I, _P, _P, _I, _P, _P, _P]),
     "hnr_chain_forward": (_I, [_P, _P, _I, _P, _P, _I, _F, _P, _I, _P, _P, _I, _P]),
-    "hnr_mlp3_packed_bytes": (ctypes.c_int64, [ctypes.POINTER(_I)]),
-    "hnr_mlp3_pack": (_I, [ctypes.POINTER(_P), ctypes.POINTER(_I), ctypes.POINTER(_I), ctypes.POINTER(_I), ctypes.POINTER(_P), _P, _P]),
-    "hnr_mlp3_forward": (_I, [_P, _I, ctypes.c_int64, _P, _I, _I, _P, ctypes.POINTER(_I), ctypes.POINTER(_I), ctypes.POINTER(_I), _F, _P, _P, _I, _P, _I, _P]),
+    "hnr_mlp3_packed_bytes": (ctypes.c_int64, [_I, ctypes.POINTER(_I)]),
+    "hnr_mlp3_pack": (_I, [_I, ctypes.POINTER(_P), ctypes.POINTER(_I), ctypes.POINTER(_I), ctypes.POINTER(_I), ctypes.POINTER(_P), _P, _P]),
+    "hnr_mlp3_forward": (_I, [_P, _I, ctypes.c_int64, _P, _I, _I, _I, _P, _I, ctypes.POINTER(_I), ctypes.POINTER(_I), ctypes.POINTER(_I), _F, _P, _P, _I, _P, _I, _P, _I, _P]),
+    "hnr_render_workspace_bytes": (ctypes.c_int64, [ctypes.POINTER(RenderParams)]),
+    "hnr_render_forward": (_I, [_P, ctypes.POINTER(RenderParams), ctypes.POINTER(RenderCloud), ctypes.POINTER(RenderWeights),
+                                ctypes.POINTER(RenderCamera), ctypes.POINTER(RenderViews), _P, ctypes.c_int64, ctypes.POINTER(RenderOutputs), _P]),
     "hnr_final_color": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P]),
     "hnr_composite": (_I, [_P] * 8 + [_I, _I, _I, _F, _I, _P, _P, _P, _P, _P]),
     "hnr_probe_outputs": (_I, [_P] * 10 + [_I, _I, _I, _I] + [_P] * 7 + [_P]),
@@ -166,3 +201,51 @@ def require_gpu(t, name, dtype=None):
     if dtype is not None and t.dtype != dtype:
         raise HnrError("%s must have dtype %s, got %s" % (name, dtype, t.dtype))
     return t.contiguous()
+
+
+# ---- raw HIP events (profiling hooks of hnr_render_forward: recorded by the library on the launch stream) ------------------
+_hip = None
+
+
+def hip_runtime():
+    global _hip
+    if _hip is None:
+        _hip = ctypes.CDLL("libamdhip64.so")
+        _hip.hipEventCreate.argtypes = [ctypes.POINTER(_P)]
+        _hip.hipEventDestroy.argtypes = [_P]
+        _hip.hipEventSynchronize.argtypes = [_P]
+        _hip.hipEventElapsedTime.argtypes = [ctypes.POINTER(_F), _P, _P]
+    return _hip
+
+
+class StageEvents:
+    """len(RENDER_STAGES) + 1 hipEvent_t handles; elapsed_ms() after the stream has been synchronised."""
+
+    def __init__(self):
+        H = hip_runtime()
+        self.n = len(RENDER_STAGES) + 1
+        self.arr = (_P * self.n)()
+        for i in range(self.n):
+            e = _P()
+            if H.hipEventCreate(ctypes.byref(e)) != 0:
+                raise HnrError("hipEventCreate failed")
+            self.arr[i] = e
+
+    def elapsed_ms(self):
+        H = hip_runtime()
+        out = {}
+        for i, name in enumerate(RENDER_STAGES):
+            ms = _F()
+            if H.hipEventElapsedTime(ctypes.byref(ms), self.arr[i], self.arr[i + 1]) != 0:
+                raise HnrError("hipEventElapsedTime failed (events not recorded / not complete)")
+            out[name] = float(ms.value)
+        return out
+
+    def __del__(self):
+        try:
+            H = hip_runtime()
+            for i in range(self.n):
+                if self.arr[i]:
+                    H.hipEventDestroy(self.arr[i])
+        except Exception:
+            pass

@@ -206,7 +206,9 @@ class PointAggregator(nn.Module):
             cf, mw, mx = self.color_feature_branch, self.aux_merge_weight_block, self.color_mixup_block
             w_fd = torch.cat([mw[0].weight[:, :45], mw[0].weight[:, 173:176]], dim=1).contiguous()
             self._packed_mlp3 = dict(
-                cf=FusedMlp3([cf[0].weight, cf[2].weight, cf[4].weight], [cf[0].bias, cf[2].bias, cf[4].bias], [1, 1, 1]),
+                # colour feature + on its tail the colour-feature columns of aux_merge_weight_block.0 (with that layer's bias), once per sample
+                cf=FusedMlp3([cf[0].weight, cf[2].weight, cf[4].weight, mw[0].weight[:, 45:173].contiguous()],
+                             [cf[0].bias, cf[2].bias, cf[4].bias, mw[0].bias], [1, 1, 1, 0]),
                 mw=FusedMlp3([w_fd, mw[2].weight, mw[4].weight], [None, mw[2].bias, mw[4].bias], [1, 1, 1]),
                 mx=FusedMlp3([mx[0].weight, mx[2].weight, mx[4].weight], [mx[0].bias, mx[2].bias, mx[4].bias], [1, 1, 0]))
         return self._packed_mlp3

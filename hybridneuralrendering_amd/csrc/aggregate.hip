@@ -423,11 +423,11 @@ __global__ __launch_bounds__(256) void proj_rows_kernel(ProjArgs a)
     // 16 lanes per (view, sample) row, 3 feature channels per lane: 4 rows per wave keep four dependent
     // index -> position -> pixel -> feature load chains in flight (one row per wave was latency-bound: 5.0 ms per frame)
     const int sub = threadIdx.x & 15;
-    const int64_t rowi = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const int n_valid = (int)a.counts[HNR_CNT_SAMPLES_VALID];
-    if (n_valid == 0) return;
+    // grid-stride over the V * n_valid rows: the grid is sized from a CAPACITY (the count lives on the device), a fixed number of
+    // blocks walking the real rows costs nothing when the capacity is generous
+    for (int64_t rowi = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4; rowi < (int64_t)a.V * n_valid; rowi += ((int64_t)gridDim.x * blockDim.x) >> 4) {
     const int v = (int)(rowi / n_valid);
-    if (v >= a.V) return;
     const int s = (int)(rowi - (int64_t)v * n_valid);
     const float *p = a.loc_w + (size_t)a.vs_item[s] * 3;
     const float x = p[0], y = p[1], z = p[2];
@@ -474,6 +474,7 @@ __global__ __launch_bounds__(256) void proj_rows_kernel(ProjArgs a)
         o[dcol + sub] = nea - cur;
     }
     if (sub == 0) a.vmask[row] = inval ? 0.f : 1.f;
+    }
 }
 
 // Merge (:1199-1217) + mix-up input (:1286-1292): one wave per valid sample.
@@ -492,10 +493,9 @@ struct MergeArgs {
 __global__ __launch_bounds__(256) void merge_kernel(MergeArgs a)
 {
     const int lane = threadIdx.x & 63;
-    const int s = (int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6);
     const int n_valid = (int)a.counts[HNR_CNT_SAMPLES_VALID];
-    if (s >= n_valid) return;
     const float wl = a.w_last[lane];
+    for (int s = (int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6); s < n_valid; s += (int)((gridDim.x * (unsigned)blockDim.x) >> 6)) {
     float fsum = 0.f, wsum = 0.f;
     constexpr int VB = 4;                                  // views fetched together (independent loads in flight)
     for (int v0 = 0; v0 < a.V; v0 += VB) {
@@ -526,6 +526,7 @@ __global__ __launch_bounds__(256) void merge_kernel(MergeArgs a)
         const bool drop = a.ray_drop && a.ray_drop[a.vs_item[s] / a.SR];
         o[45 + lane] = drop ? 0.f : fsum / (wsum + 1e-6f);
     }
+    }
 }
 
 // Final colour (:1293-1295, :1334, :478-482) and scatter into decoded [R,SR,4] (:1337-1338). One wave per sample.
@@ -542,9 +543,8 @@ struct FinalArgs {
 __global__ __launch_bounds__(256) void final_color_kernel(FinalArgs a)
 {
     const int lane = threadIdx.x & 63;
-    const int s = (int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6);
     const int n_valid = (int)a.counts[HNR_CNT_SAMPLES_VALID];
-    if (s >= n_valid) return;
+    for (int s = (int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6); s < n_valid; s += (int)((gridDim.x * (unsigned)blockDim.x) >> 6)) {
     float r[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -568,6 +568,7 @@ __global__ __launch_bounds__(256) void final_color_kernel(FinalArgs a)
         }
         out.y = rgb[0]; out.z = rgb[1]; out.w = rgb[2];
         reinterpret_cast<float4 *>(a.decoded)[a.vs_item[s]] = out;
+    }
     }
 }
 
@@ -919,7 +920,7 @@ extern "C" int hnr_proj_rows(const float *d_sample_loc_w, const int32_t *d_vs_it
     a.loc_w = d_sample_loc_w; a.vs_item = d_vs_item; a.counts = reinterpret_cast<const unsigned long long *>(d_counts);
     a.w2c = d_w2c; a.Kmat = d_intrinsic; a.campos = d_campos; a.campos_n = d_campos_nearest; a.fm = d_featmap; a.H = H; a.W = W;
     a.CF = d_CF; a.ldcf = ldcf; a.V = V; a.cap = cap_samples; a.X6 = d_X6; a.ld6 = ld6; a.vmask = d_vmask; a.row_sample = d_row_sample;
-    proj_rows_kernel<<<cdiv((int64_t)V * cap_samples * 16, 256), 256, 0, (hipStream_t)stream>>>(a);
+    { const int need = cdiv((int64_t)V * cap_samples * 16, 256); proj_rows_kernel<<<need < 8192 ? need : 8192, 256, 0, (hipStream_t)stream>>>(a); }
     HNR_LAUNCH_CHECK();
     return HNR_OK;
 }
@@ -938,7 +939,7 @@ extern "C" int hnr_merge(const float *d_X6, int ld6, const float *d_Hm, int ldh,
     a.X6 = d_X6; a.ld6 = ld6; a.Hm = d_Hm; a.ldh = ldh; a.w_last = d_w_last; a.b_last = d_b_last; a.vmask = d_vmask;
     a.frame_w = d_frame_w; a.CF = d_CF; a.ldcf = ldcf; a.counts = reinterpret_cast<const unsigned long long *>(d_counts);
     a.V = V; a.cap = cap_samples; a.X7 = d_X7; a.ld7 = ld7; a.ray_drop = d_ray_drop; a.vs_item = d_vs_item; a.SR = SR;
-    merge_kernel<<<cdiv((int64_t)cap_samples * 64, 256), 256, 0, (hipStream_t)stream>>>(a);
+    { const int need = cdiv((int64_t)cap_samples * 64, 256); merge_kernel<<<need < 8192 ? need : 8192, 256, 0, (hipStream_t)stream>>>(a); }
     HNR_LAUNCH_CHECK();
     return HNR_OK;
 }
@@ -954,7 +955,7 @@ extern "C" int hnr_final_color(const float *d_Y, int ldy, const float *d_CF, int
     FinalArgs a;
     a.Y = d_Y; a.ldy = ldy; a.CF = d_CF; a.ldcf = ldcf; a.w_fin = d_w_fin; a.b_fin = d_b_fin; a.sigma = d_sigma;
     a.vs_item = d_vs_item; a.counts = reinterpret_cast<const unsigned long long *>(d_counts); a.decoded = d_decoded;
-    final_color_kernel<<<cdiv((int64_t)cap_samples * 64, 256), 256, 0, (hipStream_t)stream>>>(a);
+    { const int need = cdiv((int64_t)cap_samples * 64, 256); final_color_kernel<<<need < 8192 ? need : 8192, 256, 0, (hipStream_t)stream>>>(a); }
     HNR_LAUNCH_CHECK();
     return HNR_OK;
 }

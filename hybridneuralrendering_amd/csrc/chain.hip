@@ -395,9 +395,8 @@ __global__ __launch_bounds__(256) void chain_gather_kernel(ChainGatherArgs a)
     __shared__ float s_d[128][8];                        // dists6 per row
     int n_valid = (int)a.counts[HNR_CNT_SAMPLES_VALID];
     if (n_valid > a.cap_samples) n_valid = a.cap_samples;
-    const int blk = blockIdx.x;                          // 16 samples = 4 groups
-    if (blk * 16 >= n_valid) return;
     const int tid = threadIdx.x;
+    for (int blk = blockIdx.x; blk * 16 < n_valid; blk += gridDim.x) {       // 16 samples = 4 groups per pass; the grid is sized from the capacity
     if (tid < 128) {
         const int ls = tid >> 3, kk = tid & 7;
         const int s = blk * 16 + ls;
@@ -479,6 +478,8 @@ __global__ __launch_bounds__(256) void chain_gather_kernel(ChainGatherArgs a)
         char *dst = xp + (s * 2) * 1024 + L * 16;
         *reinterpret_cast<u32x4 *>(dst) = u32x4{ph[0], ph[1], ph[2], ph[3]};
         *reinterpret_cast<u32x4 *>(dst + 1024) = u32x4{pm[0], pm[1], pm[2], pm[3]};
+    }
+    __syncthreads();                                     // s_d is rewritten by the next pass
     }
 }
 
@@ -616,7 +617,7 @@ extern "C" int hnr_chain_gather(const float *d_xyz, const float *d_conf, const f
     a.counts = reinterpret_cast<const unsigned long long *>(d_counts); a.SR = SR; a.cap_samples = cap_samples;
     a.xp = (char *)d_workspace; a.aux = (char *)d_workspace + (size_t)blocks * 4 * CH_XP_GROUP;
     a.X5 = d_X5; a.ld5 = ld5; a.weight_out = d_weight_out; a.conf_out = d_conf_out;
-    chain_gather_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(a);
+    chain_gather_kernel<<<blocks < 16384 ? blocks : 16384, 256, 0, (hipStream_t)stream>>>(a);
     HNR_LAUNCH_CHECK();
     return HNR_OK;
 }

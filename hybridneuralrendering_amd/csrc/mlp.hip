@@ -15,29 +15,47 @@ namespace hnr {
 
 constexpr int ML_SLOT = 8192;                      // LDS bytes per k step of the activation planes: [row tile 4][plane 2][64 lanes][16 B]
 constexpr int ML_WSTEP = 8192;                     // weight image bytes per k step: [column tile 4][plane 2][64 lanes][16 B]
-constexpr int ML_META_FLOATS = 3 * 128 + 4 + 4;    // bias[3][128], descale[3] (+pad), max|W| bits[3] (+pad)
+constexpr int ML_META_FLOATS = 4 * 128 + 4 + 4;    // bias[4][128], descale[4], max|W| bits[4]
+constexpr int ML_DESC = 4 * 128, ML_WMAX = 4 * 128 + 4;
 
 struct MlpArgs {
     const float *A; int lda;           // [M, lda] input rows
     const float *R; const int32_t *ridx; int ldr;      // optional addend of layer 0: R[ridx[row], 0:N0]
     const char *wimg;                  // packed weights (hnr_mlp_pack)
-    int wbase[3];                      // byte offset of every layer's image
-    int K0, N[3], act[3];
+    int wbase[4];                      // byte offset of every layer's image
+    int K0, N[4], act[4];
+    float *C2; int ldc2;               // optional TAIL layer (S3 > 0): a fourth layer on layer 2's output, written to C2 [M, ldc2] (N[3] columns)
     float slope;
     const unsigned long long *counts; int count_index, count_mult; long long M_cap;     // M = min(M_cap, counts[index] * mult) (counts may be NULL)
+    int seg_stride;                    // > 0: the rows are count_mult segments of counts[index] rows each, segment v starting at row v * seg_stride
     float *C; int ldc;                 // [M, ldc] output rows (N[2] columns)
 };
 
-template <int S0, int S1, int S2>
+template <int S0, int S1, int S2, int S3>
 __global__ __launch_bounds__(256, 1) void mlp3_kernel(MlpArgs a)
 {
-    constexpr int SMAX = S0 > S1 ? (S0 > S2 ? S0 : S2) : (S1 > S2 ? S1 : S2);
+    constexpr int SMAX3 = S0 > S1 ? (S0 > S2 ? S0 : S2) : (S1 > S2 ? S1 : S2), SMAX = SMAX3 > S3 ? SMAX3 : S3;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, j = lane & 31;
     long long M = a.M_cap;
     if (a.counts) { const long long c = (long long)a.counts[a.count_index] * a.count_mult; if (c < M) M = c; }
+    // logical row m -> physical row of A / ridx / C
+    long long n_unit = 1;
+    if (a.seg_stride > 0) {
+        n_unit = a.counts ? (long long)a.counts[a.count_index] : a.M_cap / (a.count_mult > 0 ? a.count_mult : 1);
+        if (n_unit > a.seg_stride) n_unit = a.seg_stride;
+        if (n_unit < 1) n_unit = 1;
+        if (M > n_unit * a.count_mult) M = n_unit * a.count_mult;
+    }
+    // (no integer division: at most 7 compares -- a 64-bit divide per lane and use cost more than the tile's MFMAs)
+    auto phys = [&](long long m) -> long long {
+        if (a.seg_stride <= 0) return m;
+        int q = 0;
+        for (int v = 1; v < a.count_mult && v < 8; ++v) q += (m >= (long long)v * n_unit) ? 1 : 0;
+        return (long long)q * a.seg_stride + (m - (long long)q * n_unit);
+    };
     const int n_tiles = (int)((M + 127) / 128);
-    const int total_steps = S0 + S1 + S2;
+    const int total_steps = S0 + S1 + S2 + S3;
     const float *meta = reinterpret_cast<const float *>(a.wimg + (size_t)total_steps * ML_WSTEP);
     const __amdgpu_buffer_rsrc_t wsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(a.wimg), 0, total_steps * ML_WSTEP, 0x00020000);
     float *exch = reinterpret_cast<float *>(lds + SMAX * ML_SLOT);         // [row 128][wave 4]
@@ -54,6 +72,7 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(MlpArgs a)
         {
             long long row = row_base + 32 * wave + j;
             if (row >= M) row = M - 1;
+            row = phys(row);
             const float *src = a.A + (size_t)row * a.lda + 8 * h;
             float x[S0][8];
             float m = 0.f;
@@ -86,7 +105,7 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(MlpArgs a)
         }
         __syncthreads();
         {
-            const float dw0 = meta[3 * 128 + 0];
+            const float dw0 = meta[ML_DESC + 0];
 #pragma unroll
             for (int rt = 0; rt < 4; ++rt) inv[rt] = __fmul_rn(rowinv[32 * rt + j], dw0);
         }
@@ -116,7 +135,7 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(MlpArgs a)
                 if (ADD) {
                     long long row = row_base + 32 * rt + j;
                     if (row >= M) row = M - 1;
-                    rrow = a.R + (size_t)a.ridx[row] * a.ldr + col0;
+                    rrow = a.R + (size_t)a.ridx[phys(row)] * a.ldr + col0;
                 }
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
@@ -137,7 +156,7 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(MlpArgs a)
                 if (h == 0) exch[(32 * rt + j) * 4 + wave] = m;
             }
             __syncthreads();                                               // every wave has finished reading the previous planes
-            const float dw = meta[3 * 128 + next_layer];
+            const float dw = meta[ML_DESC + next_layer];
 #pragma unroll
             for (int rt = 0; rt < 4; ++rt) {
                 const float4 m4 = *reinterpret_cast<const float4 *>(exch + (32 * rt + j) * 4);
@@ -161,6 +180,21 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(MlpArgs a)
             }
             __syncthreads();
         };
+        auto store = [&](float *C, int ldc) {
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) {
+                const long long row = row_base + 32 * rt + j;
+                if (row < M) {
+                    float *o = C + (size_t)phys(row) * ldc + col0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int c = col0 + 4 * q;
+                        if (c + 4 <= ldc)
+                            *reinterpret_cast<float4 *>(o + 4 * q) = make_float4(acc[rt][0][4 * q], acc[rt][0][4 * q + 1], acc[rt][0][4 * q + 2], acc[rt][0][4 * q + 3]);
+                    }
+                }
+            }
+        };
         const bool act0 = 32 * wave < a.N[0], act1 = 32 * wave < a.N[1], act2 = 32 * wave < a.N[2];
         float amax[4];
         // ---- layer 0
@@ -182,18 +216,16 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(MlpArgs a)
         if (act2) {
             h2_mfma_layer<4, 1, S2, 0, ML_WSTEP, ML_SLOT>(wsrd, a.wbase[2], woff, lds, lane, acc, []() {});
             activate(2, amax, std::false_type{});
-#pragma unroll
-            for (int rt = 0; rt < 4; ++rt) {
-                const long long row = row_base + 32 * rt + j;
-                if (row < M) {
-                    float *o = a.C + (size_t)row * a.ldc + col0;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int c = col0 + 4 * q;
-                        if (c + 4 <= a.ldc)
-                            *reinterpret_cast<float4 *>(o + 4 * q) = make_float4(acc[rt][0][4 * q], acc[rt][0][4 * q + 1], acc[rt][0][4 * q + 2], acc[rt][0][4 * q + 3]);
-                    }
-                }
+            store(a.C, a.ldc);
+        }
+        if (S3 > 0) {
+            // ---- tail layer on layer 2's output -> second fp32 output
+            publish(3, act2, amax);
+            zero_acc();
+            if (32 * wave < a.N[3]) {
+                h2_mfma_layer<4, 1, (S3 > 0 ? S3 : 1), 0, ML_WSTEP, ML_SLOT>(wsrd, a.wbase[3], woff, lds, lane, acc, []() {});
+                activate(3, amax, std::false_type{});
+                store(a.C2, a.ldc2);
             }
         }
         __syncthreads();                                                   // the planes and rowinv are rewritten by the next tile's prologue
@@ -201,15 +233,15 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(MlpArgs a)
 }
 
 struct MlpPackArgs {
-    const float *W[3]; int ldw[3], N[3], K[3], S[3], base[3];
-    const float *b[3];
+    const float *W[4]; int ldw[4], N[4], K[4], S[4], base[4];
+    const float *b[4];
     char *out; int total_steps;
 };
 
 __global__ void mlp_wmax_kernel(MlpPackArgs a)
 {
     const int l = blockIdx.y;
-    unsigned *wmax = reinterpret_cast<unsigned *>(a.out + (size_t)a.total_steps * ML_WSTEP) + 3 * 128 + 4;
+    unsigned *wmax = reinterpret_cast<unsigned *>(a.out + (size_t)a.total_steps * ML_WSTEP) + ML_WMAX;
     float m = 0.f;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.N[l] * a.K[l]; i += gridDim.x * blockDim.x) {
         const int n = i / a.K[l], k = i - n * a.K[l];
@@ -223,7 +255,7 @@ __global__ void mlp_pack_kernel(MlpPackArgs a)
 {
     const int l = blockIdx.y;
     float *meta = reinterpret_cast<float *>(a.out + (size_t)a.total_steps * ML_WSTEP);
-    const unsigned maxbits = reinterpret_cast<const unsigned *>(meta)[3 * 128 + 4 + l];
+    const unsigned maxbits = reinterpret_cast<const unsigned *>(meta)[ML_WMAX + l];
     int ex = (int)((maxbits >> 23) & 0xffu);
     ex = ex < 110 ? 110 : (ex > 160 ? 160 : ex);
     const int sw = CH_W_EXP + 126 - ex;
@@ -242,7 +274,7 @@ __global__ void mlp_pack_kernel(MlpPackArgs a)
     }
     if (blockIdx.x == 0) {
         for (int i = threadIdx.x; i < 128; i += blockDim.x) meta[l * 128 + i] = (a.b[l] && i < a.N[l]) ? a.b[l][i] : 0.f;
-        if (threadIdx.x == 0) meta[3 * 128 + l] = pow2f(-sw);
+        if (threadIdx.x == 0) meta[ML_DESC + l] = pow2f(-sw);
     }
 }
 
@@ -252,23 +284,24 @@ using namespace hnr;
 
 static int mlp_steps(int K) { return (K + 15) / 16; }
 
-extern "C" int64_t hnr_mlp3_packed_bytes(const int *K)
+extern "C" int64_t hnr_mlp3_packed_bytes(int n_layers, const int *K)
 {
-    if (!K) return -1;
+    if (!K || (n_layers != 3 && n_layers != 4)) return -1;
     int64_t steps = 0;
-    for (int l = 0; l < 3; ++l) { if (K[l] <= 0 || K[l] > 288) return -1; steps += mlp_steps(K[l]); }
+    for (int l = 0; l < n_layers; ++l) { if (K[l] <= 0 || K[l] > 288) return -1; steps += mlp_steps(K[l]); }
     return steps * ML_WSTEP + ML_META_FLOATS * 4;
 }
 
-extern "C" int hnr_mlp3_pack(const float *const *d_W, const int *ldw, const int *N, const int *K, const float *const *d_bias, void *d_packed,
+extern "C" int hnr_mlp3_pack(int n_layers, const float *const *d_W, const int *ldw, const int *N, const int *K, const float *const *d_bias, void *d_packed,
                              void *stream)
 {
-    if (!d_W || !ldw || !N || !K || !d_bias || !d_packed || ((uintptr_t)d_packed & 15)) { set_error("hnr_mlp3_pack: NULL / unaligned pointer"); return HNR_ERR_BADARG; }
+    if ((n_layers != 3 && n_layers != 4) || !d_W || !ldw || !N || !K || !d_bias || !d_packed || ((uintptr_t)d_packed & 15)) { set_error("hnr_mlp3_pack: NULL / unaligned pointer or n_layers not 3 / 4"); return HNR_ERR_BADARG; }
     MlpPackArgs a;
     int steps = 0;
-    for (int l = 0; l < 3; ++l) {
-        if (!d_W[l] || N[l] <= 0 || N[l] > 128 || K[l] <= 0 || K[l] > 288 || ldw[l] < K[l] || (l > 0 && K[l] != N[l - 1])) {
-            set_error("hnr_mlp3_pack: layer %d: N=%d (1..128) K=%d (1..288, = N of the previous layer) ldw=%d", l, N[l], K[l], ldw[l]);
+    for (int l = 0; l < n_layers; ++l) {
+        // layer l > 0 reads layer l-1's output; the tail (l = 3) reads layer 2's
+        if (!d_W[l] || N[l] <= 0 || N[l] > 128 || K[l] <= 0 || K[l] > 288 || ldw[l] < K[l] || (l > 0 && K[l] != N[l == 3 ? 2 : l - 1])) {
+            set_error("hnr_mlp3_pack: layer %d: N=%d (1..128) K=%d (1..288, = N of the layer it reads) ldw=%d", l, N[l], K[l], ldw[l]);
             return HNR_ERR_BADARG;
         }
         a.W[l] = d_W[l]; a.ldw[l] = ldw[l]; a.N[l] = N[l]; a.K[l] = K[l]; a.S[l] = mlp_steps(K[l]); a.b[l] = d_bias[l];
@@ -278,19 +311,20 @@ extern "C" int hnr_mlp3_pack(const float *const *d_W, const int *ldw, const int 
     a.out = (char *)d_packed; a.total_steps = steps;
     hipStream_t st = (hipStream_t)stream;
     HNR_HIP_CHECK(hipMemsetAsync(a.out + (size_t)steps * ML_WSTEP, 0, ML_META_FLOATS * 4, st));
-    mlp_wmax_kernel<<<dim3(16, 3), 256, 0, st>>>(a);
+    mlp_wmax_kernel<<<dim3(16, n_layers), 256, 0, st>>>(a);
     HNR_LAUNCH_CHECK();
-    mlp_pack_kernel<<<dim3(32, 3), 256, 0, st>>>(a);
+    mlp_pack_kernel<<<dim3(32, n_layers), 256, 0, st>>>(a);
     HNR_LAUNCH_CHECK();
     return HNR_OK;
 }
 
-extern "C" int hnr_mlp3_forward(const float *d_A, int lda, int64_t M_cap, const int64_t *d_counts, int count_index, int count_mult,
-                                const void *d_packed, const int *N, const int *K, const int *act, float slope, const float *d_R,
-                                const int32_t *d_ridx, int ldr, float *d_C, int ldc, void *stream)
+extern "C" int hnr_mlp3_forward(const float *d_A, int lda, int64_t M_cap, const int64_t *d_counts, int count_index, int count_mult, int seg_stride,
+                                const void *d_packed, int n_layers, const int *N, const int *K, const int *act, float slope, const float *d_R,
+                                const int32_t *d_ridx, int ldr, float *d_C, int ldc, float *d_C2, int ldc2, void *stream)
 {
-    if (!N || !K || !act || M_cap < 0 || lda < K[0] || (lda & 3) || ldc < N[2] || (ldc & 3) || !(slope > 0.f && slope < 1.f) || (d_R && (!d_ridx || ldr < N[0] || (ldr & 1)))) {
-        set_error("hnr_mlp3_forward: bad sizes (lda=%d ldc=%d ldr=%d slope=%g)", lda, ldc, ldr, (double)slope);
+    if ((n_layers != 3 && n_layers != 4) || !N || !K || !act || M_cap < 0 || seg_stride < 0 || (seg_stride > 0 && (count_mult < 1 || count_mult > 8)) || lda < K[0] || (lda & 3) || ldc < N[2] || (ldc & 3) ||
+        !(slope > 0.f && slope < 1.f) || (d_R && (!d_ridx || ldr < N[0] || (ldr & 1))) || (n_layers == 4 && (!d_C2 || ldc2 < N[3] || (ldc2 & 3) || ((uintptr_t)d_C2 & 15)))) {
+        set_error("hnr_mlp3_forward: bad sizes (n_layers=%d lda=%d ldc=%d ldr=%d ldc2=%d slope=%g)", n_layers, lda, ldc, ldr, ldc2, (double)slope);
         return HNR_ERR_BADARG;
     }
     if (M_cap == 0) return HNR_OK;
@@ -300,14 +334,16 @@ extern "C" int hnr_mlp3_forward(const float *d_A, int lda, int64_t M_cap, const 
     }
     MlpArgs a;
     a.A = d_A; a.lda = lda; a.R = d_R; a.ridx = d_ridx; a.ldr = ldr; a.wimg = (const char *)d_packed;
-    int steps = 0, S[3];
-    for (int l = 0; l < 3; ++l) {
-        if (N[l] <= 0 || N[l] > 128 || K[l] <= 0 || K[l] > 288 || (l > 0 && K[l] != N[l - 1])) { set_error("hnr_mlp3_forward: bad layer %d (N=%d K=%d)", l, N[l], K[l]); return HNR_ERR_BADARG; }
+    int steps = 0, S[4] = {0, 0, 0, 0};
+    a.N[3] = 0; a.act[3] = 0; a.wbase[3] = 0;
+    for (int l = 0; l < n_layers; ++l) {
+        if (N[l] <= 0 || N[l] > 128 || K[l] <= 0 || K[l] > 288 || (l > 0 && K[l] != N[l == 3 ? 2 : l - 1])) { set_error("hnr_mlp3_forward: bad layer %d (N=%d K=%d)", l, N[l], K[l]); return HNR_ERR_BADARG; }
         S[l] = mlp_steps(K[l]); a.wbase[l] = steps * ML_WSTEP; steps += S[l]; a.N[l] = N[l]; a.act[l] = act[l];
     }
     a.K0 = K[0]; a.slope = slope;
     a.counts = reinterpret_cast<const unsigned long long *>(d_counts); a.count_index = count_index; a.count_mult = count_mult; a.M_cap = M_cap;
-    a.C = d_C; a.ldc = ldc;
+    a.seg_stride = seg_stride;
+    a.C = d_C; a.ldc = ldc; a.C2 = d_C2; a.ldc2 = ldc2;
     static int n_cu = 0;
     if (n_cu == 0) {
         int dev = 0;
@@ -318,20 +354,21 @@ extern "C" int hnr_mlp3_forward(const float *d_A, int lda, int64_t M_cap, const 
     const int64_t tiles = (M_cap + 127) / 128;
     const int grid = (int)(tiles < n_cu ? tiles : n_cu);
     hipStream_t st = (hipStream_t)stream;
-#define HNR_MLP3_CASE(S0_, S1_, S2_)                                                                                                   \
-    if (S[0] == S0_ && S[1] == S1_ && S[2] == S2_) {                                                                                    \
-        constexpr int smax = S0_ > S1_ ? (S0_ > S2_ ? S0_ : S2_) : (S1_ > S2_ ? S1_ : S2_);                                             \
+#define HNR_MLP3_CASE(S0_, S1_, S2_, S3_)                                                                                              \
+    if (S[0] == S0_ && S[1] == S1_ && S[2] == S2_ && S[3] == S3_) {                                                                     \
+        constexpr int smax3 = S0_ > S1_ ? (S0_ > S2_ ? S0_ : S2_) : (S1_ > S2_ ? S1_ : S2_), smax = smax3 > S3_ ? smax3 : S3_;          \
         constexpr int ldsb = smax * ML_SLOT + 128 * 4 * 4 + 128 * 4;                                                                    \
         static bool attr = false;                                                                                                       \
-        if (!attr) { HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(mlp3_kernel<S0_, S1_, S2_>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb)); attr = true; } \
-        mlp3_kernel<S0_, S1_, S2_><<<grid, 256, ldsb, st>>>(a);                                                                         \
+        if (!attr) { HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(mlp3_kernel<S0_, S1_, S2_, S3_>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb)); attr = true; } \
+        mlp3_kernel<S0_, S1_, S2_, S3_><<<grid, 256, ldsb, st>>>(a);                                                                    \
         HNR_LAUNCH_CHECK();                                                                                                             \
         return HNR_OK;                                                                                                                  \
     }
-    HNR_MLP3_CASE(18, 8, 8)        // color_feature_branch: 280 -> 128 -> 128 -> 128
-    HNR_MLP3_CASE(3, 4, 4)         // aux_merge_weight_block: 48 -> 64 -> 64 -> 64
-    HNR_MLP3_CASE(6, 3, 3)         // color_mixup_block: 90 -> 45 -> 45 -> 45
+    HNR_MLP3_CASE(18, 8, 8, 0)     // color_feature_branch: 280 -> 128 -> 128 -> 128
+    HNR_MLP3_CASE(18, 8, 8, 8)     // the same + tail 128 -> 64: the colour-feature columns of aux_merge_weight_block.0, once per sample
+    HNR_MLP3_CASE(3, 4, 4, 0)      // aux_merge_weight_block: 48 -> 64 -> 64 -> 64
+    HNR_MLP3_CASE(6, 3, 3, 0)      // color_mixup_block: 90 -> 45 -> 45 -> 45
 #undef HNR_MLP3_CASE
-    set_error("hnr_mlp3_forward: no kernel for k steps (%d, %d, %d); built: (18,8,8) (3,4,4) (6,3,3)", S[0], S[1], S[2]);
+    set_error("hnr_mlp3_forward: no kernel for k steps (%d, %d, %d, %d); built: (18,8,8,0) (18,8,8,8) (3,4,4,0) (6,3,3,0)", S[0], S[1], S[2], S[3]);
     return HNR_ERR_BADARG;
 }

@@ -137,37 +137,45 @@ def weight_grad(dZ, X, N, K, dW=None, db=None, accumulate=False, want_bias=True)
 
 
 class FusedMlp3:
-    """Three nn.Linear (+LeakyReLU) layers of width <= 128 as ONE launch (hnr_mlp3_forward; csrc/mlp.hip), fp32 in / out."""
+    """Three nn.Linear (+LeakyReLU) layers of width <= 128 as ONE launch (hnr_mlp3_forward; csrc/mlp.hip), fp32 in / out.
+    A fourth (weight, bias, act) is a TAIL layer on layer 2's output whose result goes to a second output tensor."""
 
     def __init__(self, weights, biases, acts):
         L = _lib.lib()
         ws = [_lib.require_gpu(w.detach(), "weight", torch.float32) for w in weights]
         bs = [None if b is None else _lib.require_gpu(b.detach(), "bias", torch.float32) for b in biases]
+        self.n = len(ws)
+        if self.n not in (3, 4):
+            raise HnrError("FusedMlp3: 3 layers (+ 1 tail) expected")
         self.N = [int(w.shape[0]) for w in ws]
         self.K = [int(w.shape[1]) for w in ws]
         self.act = [1 if a else 0 for a in acts]
-        I3 = ctypes.c_int * 3
-        self._N, self._K, self._act = I3(*self.N), I3(*self.K), I3(*self.act)
-        nbytes = int(L.hnr_mlp3_packed_bytes(self._K))
+        IN = ctypes.c_int * self.n
+        self._N, self._K, self._act = IN(*self.N), IN(*self.K), IN(*self.act)
+        nbytes = int(L.hnr_mlp3_packed_bytes(self.n, self._K))
         if nbytes <= 0:
             raise HnrError("FusedMlp3: unsupported layer sizes %r" % (list(zip(self.N, self.K)),))
         dev = ws[0].device
         self.packed = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
-        P3 = ctypes.c_void_p * 3
+        PN = ctypes.c_void_p * self.n
         with torch.cuda.device(dev):
-            _lib.check(L.hnr_mlp3_pack(P3(*[w.data_ptr() for w in ws]), I3(*[int(w.stride(0)) for w in ws]), self._N, self._K,
-                                       P3(*[(b.data_ptr() if b is not None else None) for b in bs]), _lib.ptr(self.packed), _lib.stream()),
+            _lib.check(L.hnr_mlp3_pack(self.n, PN(*[w.data_ptr() for w in ws]), IN(*[int(w.stride(0)) for w in ws]), self._N, self._K,
+                                       PN(*[(b.data_ptr() if b is not None else None) for b in bs]), _lib.ptr(self.packed), _lib.stream()),
                        "hnr_mlp3_pack")
         self._keep = (ws, bs)
 
-    def __call__(self, a, out, rows_cap, counts=None, count_index=0, count_mult=1, slope=0.01, R=None, ridx=None):
+    def __call__(self, a, out, rows_cap, counts=None, count_index=0, count_mult=1, slope=0.01, R=None, ridx=None, seg_stride=0, out2=None):
         L = _lib.lib()
         lda = a.stride(0) if a.shape[0] > 1 else a.shape[1]
         ldc = out.stride(0) if out.shape[0] > 1 else out.shape[1]
+        if (self.n == 4) != (out2 is not None):
+            raise HnrError("FusedMlp3: a 4-layer stack needs out2 (and only it)")
+        ldc2 = 0 if out2 is None else (out2.stride(0) if out2.shape[0] > 1 else out2.shape[1])
         with torch.cuda.device(a.device):
             _lib.check(L.hnr_mlp3_forward(ctypes.c_void_p(a.data_ptr()), int(lda), int(rows_cap), _lib.ptr(counts) if counts is not None else None,
-                                          int(count_index), int(count_mult), _lib.ptr(self.packed), self._N, self._K, self._act, float(slope),
-                                          _lib.ptr(R) if R is not None else None, _lib.ptr(ridx) if ridx is not None else None,
-                                          int(R.stride(0)) if R is not None else 0, ctypes.c_void_p(out.data_ptr()), int(ldc), _lib.stream()),
+                                          int(count_index), int(count_mult), int(seg_stride), _lib.ptr(self.packed), self.n, self._N, self._K, self._act,
+                                          float(slope), _lib.ptr(R) if R is not None else None, _lib.ptr(ridx) if ridx is not None else None,
+                                          int(R.stride(0)) if R is not None else 0, ctypes.c_void_p(out.data_ptr()), int(ldc),
+                                          ctypes.c_void_p(out2.data_ptr()) if out2 is not None else None, int(ldc2), _lib.stream()),
                        "hnr_mlp3_forward")
         return out

@@ -77,6 +77,9 @@ class HybridRenderer:
         if self.dense not in ("f16x2", "bf16x3", "f32"):
             raise HnrError("HNR_DENSE must be f16x2, bf16x3 or f32, got %r" % self.dense)
         self.split_merge = True           # multiply the colour-feature columns of aux_merge_weight_block.0 once per sample
+        # the whole frame as ONE library call (hnr_render_forward: no host read between query and composite); HNR_SINGLE_CALL=0 runs the
+        # same kernels stage by stage from Python with exactly sized buffers (one host read of the counters)
+        self.single_call = os.environ.get("HNR_SINGLE_CALL", "1") != "0"
         self.last_counts = None
         if getattr(opt, "which_render_func", "radiance") != "radiance" or getattr(opt, "which_blend_func", "alpha") != "alpha" \
                 or getattr(opt, "which_tonemap_func", "off") != "off":
@@ -203,7 +206,8 @@ class HybridRenderer:
           ci = CNT["SAMPLES_VALID"]
           with T("mlp_colorfeat"):
             if fused_s:
-                CF = m3["cf"](X5, _f32((n_valid, 128), dev), n_valid, counts, ci, 1, slope=sl)
+                pre = _f32((n_valid, 64), dev)            # colour-feature part of aux_merge_weight_block.0 (bias included), once per sample
+                CF = m3["cf"](X5, _f32((n_valid, 128), dev), n_valid, counts, ci, 1, slope=sl, out2=pre)
             else:
                 T1, T2 = _f32((n_valid, 128), dev), _f32((n_valid, 128), dev)
                 pk["cf"][0](X5, out=T1, act=True, slope=sl)
@@ -227,7 +231,6 @@ class HybridRenderer:
             with T("mlp_merge"):
               M1 = _f32((V * n_valid, 64), dev)
               if fused_s and self.split_merge:
-                  pre = pk["mw0_cf"](CF, act=False)                                     # [S,64] once per sample (bias included)
                   m3["mw"](X6, M1, V * n_valid, counts, ci, V, slope=sl, R=pre, ridx=row_s)
               elif self.split_merge:
                   M2 = _f32((V * n_valid, 64), dev)
@@ -278,6 +281,74 @@ class HybridRenderer:
                                        p(col), p(opa), p(isbg), p(bw) if want_blend else None, _lib.stream()), "hnr_composite")
         return dict(coarse_raycolor=col, coarse_point_opacity=opa, coarse_is_background=isbg, blend_weight=bw)
 
+    # -- the whole path as ONE library call (no host read between query and composite) ---------------
+    def _single_call(self, cloud, raydir, campos, camrot, bg_color, tmid, grid, radius2, w2c_nearest, campos_nearest, intrinsic_nearest, fm,
+                     frame_weight, want_weights, timers):
+        """hnr_render_forward: every launch of the frame issued by the library on the current stream; workspaces sized for the worst
+        case R*SR valid samples (or what fits: the status word reports an overflow), no `.cpu()` / `.item()` on the way."""
+        L, p = _lib.lib(), _lib.ptr
+        opt, dev = self.opt, raydir.device
+        R, SR, K = raydir.shape[0], int(opt.SR), int(opt.K)
+        V = 0 if fm is None else int(fm.shape[0])
+        prm = _lib.RenderParams()
+        prm.R, prm.SR, prm.K, prm.D = R, SR, K, int(tmid.shape[-1])
+        prm.tmid_stride = 0 if tmid.dim() == 1 else int(tmid.shape[1])
+        for i in range(3):
+            prm.kernel_size[i] = int(opt.kernel_size[i])
+        prm.radius2, prm.vsize_z = float(radius2), float(np.float32(opt.vsize[2]))
+        prm.raydist_mode_unit, prm.V = int(getattr(opt, "raydist_mode_unit", 0) > 0), V
+        cap = R * SR
+        prm.cap_samples = cap
+        nbytes = int(L.hnr_render_workspace_bytes(ctypes.byref(prm)))
+        free, _total = torch.cuda.mem_get_info(dev)
+        cached = torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+        if nbytes > 0.6 * (free + cached):
+            return None                                   # the worst case does not fit: the staged path sizes its buffers exactly
+        ws = torch.empty((nbytes + 256,), dtype=torch.uint8, device=dev)
+        off = (-ws.data_ptr()) % 256
+        pk, agg = self.agg.packed(), self.agg
+        m3 = agg.packed_mlp3()
+        ptab = self.point_table(cloud)
+        cl = _lib.RenderCloud(p(cloud.xyz), p(cloud.conf), p(cloud.dir), p(cloud.color), p(ptab), int(ptab.stride(0)))
+        wt = _lib.RenderWeights(p(agg.packed_chain()), p(m3["cf"].packed), p(m3["mw"].packed), p(m3["mx"].packed),
+                                p(pk["mw_last_w"]), p(pk["mw_last_b"]), p(pk["fin_w"]), p(pk["fin_b"]), float(pk["slope"]))
+        cam = _lib.RenderCamera(p(campos), p(camrot), p(raydir), p(tmid), p(bg_color))
+        vw = None
+        fw = None if frame_weight is None else _lib.require_gpu(frame_weight, "frame_weight", torch.float32).reshape(-1)
+        if V > 0:
+            vw = _lib.RenderViews(p(w2c_nearest), p(intrinsic_nearest), p(campos_nearest), p(fm), int(fm.shape[1]), int(fm.shape[2]),
+                                  p(fw) if fw is not None else None)
+        col, opa, isbg = _f32((R, 3), dev), _f32((R, SR), dev), _f32((R,), dev)
+        bw = _f32((R, SR), dev) if want_weights else None
+        mask = torch.empty((R,), dtype=torch.int8, device=dev)
+        decoded = _f32((R, SR, 4), dev)
+        pidx = torch.empty((R, SR, K), dtype=torch.int32, device=dev)
+        loc = _f32((R, SR, 3), dev)
+        nsamp = torch.empty((R,), dtype=torch.int32, device=dev)
+        counts = torch.empty((_lib.NCOUNTS,), dtype=torch.int64, device=dev)
+        status = torch.empty((2,), dtype=torch.int32, device=dev)
+        w_out = c_out = None
+        if want_weights:
+            w_out = torch.zeros((R, SR, K), dtype=torch.float32, device=dev)
+            c_out = cloud.conf[0].clamp(0.0001, 1.0).expand(R, SR, K).contiguous()     # empty slots read point 0 in the reference (:711)
+        ev = None
+        if timers is not None:
+            ev = _lib.StageEvents()
+            timers.setdefault("_stage_events", []).append(ev)
+        out = _lib.RenderOutputs(p(col), p(opa), p(isbg), p(bw) if bw is not None else None, p(mask), p(decoded), p(pidx), p(loc), p(nsamp), p(counts),
+                                 p(status), p(w_out) if w_out is not None else None, p(c_out) if c_out is not None else None,
+                                 ev.arr if ev is not None else None)
+        with torch.cuda.device(dev):
+            _lib.check(L.hnr_render_forward(grid.handle, ctypes.byref(prm), ctypes.byref(cl), ctypes.byref(wt), ctypes.byref(cam),
+                                            ctypes.byref(vw) if vw is not None else None, ctypes.c_void_p(ws.data_ptr() + off), nbytes,
+                                            ctypes.byref(out), _lib.stream()), "hnr_render_forward")
+        self._keepalive = (ws, fw)             # the launches are asynchronous: the workspace must outlive them (next call replaces it)
+        res = dict(coarse_raycolor=col, coarse_point_opacity=opa, coarse_is_background=isbg, blend_weight=bw, ray_mask=mask, decoded=decoded,
+                   sample_pidx=pidx, sample_loc_w=loc, ray_nsamp=nsamp, counts=counts, status=status)
+        if want_weights:
+            res.update(weight=w_out, conf_coefficient=c_out)
+        return res
+
     # -- the whole path -------------------------------------------------------------------------------
     def render_rays(self, cloud, raydir, campos, camrot, bg_color, near, far, c2w_nearest, campos_nearest, intrinsic_nearest,
                     images_nearest, frame_weight=None, want_weights=False, w2c_nearest=None, timers=None, pad=False):
@@ -298,6 +369,13 @@ class HybridRenderer:
         q = self.querier
         grid, hp = q._grid_for(cloud.xyz[None])
         tmid = q._tmid_for(float(near), float(far), self.opt.z_depth_dim, raydir.shape[0], raydir.device)
+        if self.dense == "f16x2" and self.opt.K == 8 and self.single_call and not pad and raydir.shape[0] > 0:
+            with _Stage(timers, "featmap"):
+                fm = None if getattr(self.opt, "use_nearest", 4) == 0 else self.feature_map(images_nearest)
+            res = self._single_call(cloud, raydir, campos, camrot, bg_color, tmid, grid, np.float32(hp[0] ** 2), w2c_nearest, campos_nearest,
+                                    intrinsic_nearest, fm, frame_weight, want_weights, timers)
+            if res is not None:
+                return res
         with _Stage(timers, "query"):
             # pad=False: only kept slots are written (no -1 / 0 padding stores); everything downstream takes ray_nsamp
             qres = Q.march_query(grid, campos, raydir, tmid, self.opt.SR, self.opt.K, np.float32(hp[0] ** 2), self.opt.kernel_size, pad=pad)

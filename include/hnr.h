@@ -318,12 +318,17 @@ int hnr_chain_forward(const void *d_workspace, const float *d_point_table, int l
  *   hnr_mlp3_forward: d_C[m, 0:N[2]] = L2(L1(L0(d_A[m, 0:K[0]]) )), act[l] != 0 applies LeakyReLU(slope) after layer l; optional addend of
  *   layer 0 before its activation: d_R[d_ridx[m], 0:N[0]] (the colour-feature part of aux_merge_weight_block.0, shared by a sample's
  *   views).  Rows: M = min(M_cap, d_counts[count_index] * count_mult) when d_counts != NULL (device-side count), else M_cap.
- *   Built for the k-step triples of the three uses: K = (280,128,128), (48,64,64), (90,45,45). */
-int64_t hnr_mlp3_packed_bytes(const int *K);
-int hnr_mlp3_pack(const float *const *d_W, const int *ldw, const int *N, const int *K, const float *const *d_bias, void *d_packed, void *stream);
-int hnr_mlp3_forward(const float *d_A, int lda, int64_t M_cap, const int64_t *d_counts, int count_index, int count_mult,
-                     const void *d_packed, const int *N, const int *K, const int *act, float slope, const float *d_R,
-                     const int32_t *d_ridx, int ldr, float *d_C, int ldc, void *stream);
+ *   seg_stride > 0: the rows are count_mult SEGMENTS of d_counts[count_index] rows each, segment v starting at row v * seg_stride
+ *   (the (view, sample) rows of hnr_proj_rows: row = v * cap_samples + s).
+ *   n_layers = 4 adds a TAIL: a fourth layer reading layer 2's output, written to d_C2[m, 0:N[3]] (K[3] = N[2]) -- the colour-feature
+ *   columns of aux_merge_weight_block.0 (128 -> 64, no activation) ride on the colour-feature launch.
+ *   Built for the k-step tuples of these uses: K = (280,128,128[,128]), (48,64,64), (90,45,45). */
+int64_t hnr_mlp3_packed_bytes(int n_layers, const int *K);
+int hnr_mlp3_pack(int n_layers, const float *const *d_W, const int *ldw, const int *N, const int *K, const float *const *d_bias, void *d_packed,
+                  void *stream);
+int hnr_mlp3_forward(const float *d_A, int lda, int64_t M_cap, const int64_t *d_counts, int count_index, int count_mult, int seg_stride,
+                     const void *d_packed, int n_layers, const int *N, const int *K, const int *act, float slope, const float *d_R,
+                     const int32_t *d_ridx, int ldr, float *d_C, int ldc, float *d_C2, int ldc2, void *stream);
 
 /* Residual + color_final_block + sigmoid*1.002-0.001 (:1294-1295, :1334, :478-482), scattered with sigma into
  * d_decoded [R*SR,4] (pre-zeroed by the caller; :1337-1338). */
@@ -445,6 +450,62 @@ int hnr_point_rows_bwd(const float *d_gE, int ldg, const float *d_E, int lde, co
 /* g *= LeakyReLU'(y) in place;  out[s,:] = sum over the V view rows of a sample. */
 int hnr_dleaky(float *d_g, int ldg, const float *d_y, int ldy, int64_t M, int N, float slope, void *stream);
 int hnr_sum_views(const float *d_in, int ldi, int V, int cap, int n_samples, int N, float *d_out, int ldo, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * The whole forward path in ONE call (csrc/render_forward.hip): one pass of NeuralPointsRayMarching.forward + fill_invalid
+ * (models/neural_points_volumetric_model.py:257-391, :87-126) over R rays -- query, gather / aggregate (fused chain + fused
+ * per-sample MLPs), composite -- with every launch issued here, back to back on the caller's stream.  The reference's three host
+ * synchronisations per chunk (query_point_indices_worldcoords.py:645-646, :705; point_aggregators.py:1092) have no counterpart:
+ * the kernels read their work sizes from the query's device counters, the intermediate buffers live in the caller's workspace
+ * (hnr_render_workspace_bytes) sized for `cap_samples` valid shading samples (R*SR is always enough), and d_status[0] becomes 1 when
+ * that capacity was exceeded (the extra samples are dropped; d_status[1] holds the true count's low 32 bits).  K = 8 only.
+ * All pointers are device pointers; nothing is allocated, nothing is read back. */
+typedef struct {
+    int   R, SR, K, D;            /* rays, opt.SR, opt.K (8), opt.z_depth_dim                                          */
+    int   tmid_stride;            /* 0: cam->d_tmid is one [D] table; D: [R,D] per-ray tables (train-time jitter)       */
+    int   kernel_size[3];
+    float radius2;                /* radius_limit^2                                                                    */
+    float vsize_z;                /* opt.vsize[2] (ray_dist rule, :331-339)                                            */
+    int   raydist_mode_unit;
+    int   V;                      /* reference views (0: use_nearest = 0, image branch off)                            */
+    int   cap_samples;            /* capacity of the workspace in valid shading samples                                */
+} hnr_render_params;
+typedef struct {
+    const float *d_xyz, *d_conf, *d_dir, *d_color;      /* [N,3] [N] [N,3] [N,3]                                       */
+    const float *d_point_table; int ldt;                /* [N, ldt >= 256] per-point addend of block1.0                 */
+} hnr_render_cloud;
+typedef struct {
+    const void  *d_chain;                               /* hnr_chain_pack                                               */
+    const void  *d_mlp_cf, *d_mlp_mw, *d_mlp_mx;        /* hnr_mlp3_pack images: colour feature (4 layers: + the 128 -> 64 colour-feature
+                                                           columns of aux_merge_weight_block.0 with its bias), merge weights, mix-up */
+    const float *d_mw_last_w, *d_mw_last_b;             /* aux_merge_weight_block.6: [64], [1]                           */
+    const float *d_fin_w, *d_fin_b;                     /* color_final_block.0: [3,128], [3]                             */
+    float slope;                                        /* LeakyReLU slope                                               */
+} hnr_render_weights;
+typedef struct { const float *d_campos, *d_camrot, *d_raydir, *d_tmid, *d_bg_color; } hnr_render_camera;
+typedef struct {
+    const float *d_w2c, *d_intrinsic, *d_campos_nearest; /* [V,4,4] inverse(c2w_nearest), [3,3], [V,3]                  */
+    const float *d_featmap; int H, W;                    /* hnr_image_features output [V,H,W,48]                         */
+    const float *d_frame_w;                              /* optional [V]                                                 */
+} hnr_render_views;
+typedef struct {
+    float   *d_raycolor, *d_opacity, *d_is_background;   /* [R,3] [R,SR] [R]  (fill_invalid applied)                     */
+    float   *d_blend_weight;                             /* optional [R,SR]                                              */
+    int8_t  *d_ray_mask;                                 /* [R]                                                          */
+    float   *d_decoded;                                  /* [R,SR,4] (sigma, rgb)                                        */
+    int32_t *d_sample_pidx; float *d_sample_loc_w; int32_t *d_ray_nsamp;    /* the query outputs, un-padded               */
+    int64_t *d_counts;                                   /* [HNR_NCOUNTS]                                                */
+    int32_t *d_status;                                   /* [2]                                                          */
+    float   *d_weight, *d_conf_coefficient;              /* optional [R,SR,K] (both or neither)                          */
+    void   **stage_events;                               /* optional: HNR_RENDER_NSTAGES + 1 hipEvent_t handles recorded at the
+                                                            stage boundaries (query, plan, chain_gather, chain, mlp_colorfeat,
+                                                            proj_rows, mlp_merge, merge, mlp_mixup, final_color, composite) */
+} hnr_render_outputs;
+#define HNR_RENDER_NSTAGES 11
+int64_t hnr_render_workspace_bytes(const hnr_render_params *p);
+int hnr_render_forward(const hnr_grid *grid, const hnr_render_params *p, const hnr_render_cloud *cloud, const hnr_render_weights *weights,
+                       const hnr_render_camera *camera, const hnr_render_views *views, void *d_workspace, int64_t workspace_bytes,
+                       const hnr_render_outputs *out, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * "Next" row: blur-handling module with pre-defined kernels, models/base_rendering_model.py:677-745
