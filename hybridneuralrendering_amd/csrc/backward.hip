@@ -501,6 +501,7 @@ struct GatherBwdArgs {
     const float *weight;                                 // [R,SR,K] normalised weights (forward output)
     const float *g_conf_out;                             // [R,SR,K] d conf_coefficient output, may be NULL
     float *g_conf, *g_dir, *g_color;                     // [N], [N,3], [N,3] atomics
+    float *G8;                                           // deterministic mode: per-row [rows, 8] contributions instead (no atomics)
 };
 
 __global__ __launch_bounds__(256) void gather_rows_bwd_kernel(GatherBwdArgs a)
@@ -515,15 +516,36 @@ __global__ __launch_bounds__(256) void gather_rows_bwd_kernel(GatherBwdArgs a)
     const int ray = item / a.SR;
     const float *g = a.gX3 + row * a.ldg3 + 256;
     const float gd = g[6];
+    // w_agg = w_norm * clamp_ST(conf): the clamp passes the gradient through unchanged (gradiant_clamp, :1422-1424)
+    float gc = a.g_wagg[row] * a.weight[e];
+    if (a.g_conf_out) gc += a.g_conf_out[e];
+    if (a.G8) {
+        // deterministic mode: the row's contribution [d color 3 | d dir 3 | d conf | 0] is parked; hnr_segment_sum_rows_det adds the rows of
+        // every touched point in a fixed order (atomics into the point buffers sum in a run-dependent order)
+        float4 *o = reinterpret_cast<float4 *>(a.G8 + row * 8);
+        o[0] = make_float4(g[0], g[1], g[2], g[3] + gd * a.raydir[3 * (size_t)ray]);
+        o[1] = make_float4(g[4] + gd * a.raydir[3 * (size_t)ray + 1], g[5] + gd * a.raydir[3 * (size_t)ray + 2], gc, 0.f);
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         atomicAdd(a.g_color + 3 * (size_t)pid + j, g[j]);
         atomicAdd(a.g_dir + 3 * (size_t)pid + j, g[3 + j] + gd * a.raydir[3 * (size_t)ray + j]);
     }
-    // w_agg = w_norm * clamp_ST(conf): the clamp passes the gradient through unchanged (gradiant_clamp, :1422-1424)
-    float gc = a.g_wagg[row] * a.weight[e];
-    if (a.g_conf_out) gc += a.g_conf_out[e];
     atomicAdd(a.g_conf + pid, gc);
+}
+
+// [U, 8] per-point sums -> the three point buffers (every touched point once: plain adds)
+__global__ void point_small_grads_kernel(const float *__restrict__ P8, const int32_t *__restrict__ ulist, int U, float *__restrict__ g_conf,
+                                         float *__restrict__ g_dir, float *__restrict__ g_color)
+{
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= U) return;
+    const float4 a0 = reinterpret_cast<const float4 *>(P8 + (size_t)u * 8)[0], a1 = reinterpret_cast<const float4 *>(P8 + (size_t)u * 8)[1];
+    const size_t p = (size_t)ulist[u];
+    g_color[3 * p] += a0.x; g_color[3 * p + 1] += a0.y; g_color[3 * p + 2] += a0.z;
+    g_dir[3 * p] += a0.w; g_dir[3 * p + 1] += a1.x; g_dir[3 * p + 2] += a1.y;
+    g_conf[p] += a1.z;
 }
 
 // dst[idx[m], :] += src[m, :]  (n_cols a multiple of 4): the per-point accumulation of block1's first-layer gradient
@@ -837,8 +859,36 @@ extern "C" int hnr_gather_rows_bwd(const int32_t *d_sample_pidx, const float *d_
     GatherBwdArgs a;
     a.pidx = d_sample_pidx; a.raydir = d_raydir; a.vs_item = d_vs_item; a.vs_off = d_vs_off; a.vs_cnt = d_vs_cnt;
     a.counts = reinterpret_cast<const unsigned long long *>(d_counts); a.SR = SR; a.K = K; a.gX3 = d_gX3; a.ldg3 = ldg3; a.g_wagg = d_g_wagg;
-    a.weight = d_weight; a.g_conf_out = d_g_conf_out; a.g_conf = d_g_conf; a.g_dir = d_g_dir; a.g_color = d_g_color;
+    a.weight = d_weight; a.g_conf_out = d_g_conf_out; a.g_conf = d_g_conf; a.g_dir = d_g_dir; a.g_color = d_g_color; a.G8 = nullptr;
     gather_rows_bwd_kernel<<<cdiv((int64_t)cap_samples * K, 256), 256, 0, (hipStream_t)stream>>>(a);
+    HNR_LAUNCH_CHECK();
+    return HNR_OK;
+}
+
+extern "C" int hnr_gather_rows_bwd_rows(const int32_t *d_sample_pidx, const float *d_raydir, const int32_t *d_vs_item, const int32_t *d_vs_off,
+                                        const int32_t *d_vs_cnt, const int64_t *d_counts, int SR, int K, int cap_samples, const float *d_gX3,
+                                        int ldg3, const float *d_g_wagg, const float *d_weight, const float *d_g_conf_out, float *d_G8, void *stream)
+{
+    if (!d_sample_pidx || !d_raydir || !d_vs_item || !d_vs_off || !d_vs_cnt || !d_counts || !d_gX3 || !d_g_wagg || !d_weight || !d_G8 ||
+        ((uintptr_t)d_G8 & 15) || ldg3 < 263 || SR <= 0 || K <= 0) {
+        set_error("hnr_gather_rows_bwd_rows: bad argument"); return HNR_ERR_BADARG;
+    }
+    if (cap_samples <= 0) return HNR_OK;
+    GatherBwdArgs a;
+    a.pidx = d_sample_pidx; a.raydir = d_raydir; a.vs_item = d_vs_item; a.vs_off = d_vs_off; a.vs_cnt = d_vs_cnt;
+    a.counts = reinterpret_cast<const unsigned long long *>(d_counts); a.SR = SR; a.K = K; a.gX3 = d_gX3; a.ldg3 = ldg3; a.g_wagg = d_g_wagg;
+    a.weight = d_weight; a.g_conf_out = d_g_conf_out; a.g_conf = nullptr; a.g_dir = nullptr; a.g_color = nullptr; a.G8 = d_G8;
+    gather_rows_bwd_kernel<<<cdiv((int64_t)cap_samples * K, 256), 256, 0, (hipStream_t)stream>>>(a);
+    HNR_LAUNCH_CHECK();
+    return HNR_OK;
+}
+
+extern "C" int hnr_point_small_grads(const float *d_P8, const int32_t *d_ulist, int U, float *d_g_conf, float *d_g_dir, float *d_g_color, void *stream)
+{
+    if (U < 0) { set_error("hnr_point_small_grads: bad size"); return HNR_ERR_BADARG; }
+    if (U == 0) return HNR_OK;
+    if (!d_P8 || !d_ulist || !d_g_conf || !d_g_dir || !d_g_color || ((uintptr_t)d_P8 & 15)) { set_error("hnr_point_small_grads: NULL / unaligned argument"); return HNR_ERR_BADARG; }
+    point_small_grads_kernel<<<cdiv(U, 256), 256, 0, (hipStream_t)stream>>>(d_P8, d_ulist, U, d_g_conf, d_g_dir, d_g_color);
     HNR_LAUNCH_CHECK();
     return HNR_OK;
 }

@@ -54,9 +54,47 @@ __global__ __launch_bounds__(256) void segment_sum_rows_kernel(const float *__re
     flush(cur);
 }
 
+// Deterministic variant for DENSE keys 0 .. n_keys-1 (the compact indices of the points a batch touches): one wave per key finds its
+// run in the sorted order by binary search and adds the rows in that (stable = row) order -- no atomics, bit-identical run to run.
+// dst row = dst_index ? dst_index[key] : key;  accumulate != 0: dst += sum (dst rows are unique per key, so a plain read-modify-write).
+__global__ __launch_bounds__(256) void segment_sum_rows_det_kernel(const float *__restrict__ A, int lda, const int32_t *__restrict__ keys_sorted,
+                                                                   const int32_t *__restrict__ perm, int64_t M, int n_cols, int n_keys,
+                                                                   const int32_t *__restrict__ dst_index, float *__restrict__ dst,
+                                                                   int64_t dst_stride, int accumulate)
+{
+    const int lane = threadIdx.x & 63;
+    const int key = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (key >= n_keys) return;
+    int64_t lo = 0, hi = M;                               // first entry with keys_sorted >= key
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (keys_sorted[mid] < key) lo = mid + 1; else hi = mid; }
+    if (4 * lane >= n_cols) return;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t e = lo; e < M && keys_sorted[e] == key; ++e) {
+        const float4 v = reinterpret_cast<const float4 *>(A + (size_t)perm[e] * lda)[lane];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    float4 *d = reinterpret_cast<float4 *>(dst + (size_t)(dst_index ? dst_index[key] : key) * dst_stride) + lane;
+    if (accumulate) { const float4 o = *d; acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w; }
+    *d = acc;
+}
+
 }  // namespace hnr
 
 using namespace hnr;
+
+extern "C" int hnr_segment_sum_rows_det(const float *d_A, int lda, const int32_t *d_keys_sorted, const int32_t *d_perm, int64_t M, int n_cols,
+                                        int n_keys, const int32_t *d_dst_index, float *d_dst, int64_t dst_stride, int accumulate, void *stream)
+{
+    if (M < 0 || n_keys < 0 || n_cols <= 0 || n_cols > 256 || (n_cols & 3) || lda < n_cols || (lda & 3) || dst_stride < n_cols || (dst_stride & 3)) {
+        set_error("hnr_segment_sum_rows_det: bad sizes (n_cols a multiple of 4, <= 256; strides multiples of 4)"); return HNR_ERR_BADARG;
+    }
+    if (n_keys == 0) return HNR_OK;
+    if (!d_A || !d_keys_sorted || !d_perm || !d_dst || ((uintptr_t)d_A & 15) || ((uintptr_t)d_dst & 15)) { set_error("hnr_segment_sum_rows_det: NULL / unaligned argument"); return HNR_ERR_BADARG; }
+    segment_sum_rows_det_kernel<<<cdiv((int64_t)n_keys * 64, 256), 256, 0, (hipStream_t)stream>>>(d_A, lda, d_keys_sorted, d_perm, M, n_cols, n_keys, d_dst_index,
+                                                                                                 d_dst, dst_stride, accumulate);
+    HNR_LAUNCH_CHECK();
+    return HNR_OK;
+}
 
 extern "C" int64_t hnr_sort_rows_scratch_bytes(int64_t M)
 {

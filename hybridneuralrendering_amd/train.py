@@ -337,21 +337,26 @@ class TrainPath:
             gX3 = lin_bwd(dZ3, S.X3, "block3.0.weight", "block3.0.bias", 256, 263, t["b3_0"], prev=S.X3, prev_cols=256,
                           out=_f32((M, 264), dev))
             del dZ3
+            # rows -> touched point: sort the rows by touched-point index ONCE; both per-point reductions below then add a point's rows in
+            # that fixed order (one wave per point, no atomics): gradients are bit-identical run to run
+            sb = int(L.hnr_sort_rows_scratch_bytes(M))
+            ks, perm, sort_scratch = _i32(M, dev), _i32(M, dev), torch.empty((sb,), dtype=torch.uint8, device=dev)
+            _lib.check(L.hnr_sort_rows_by_key(p(S.row_u), M, p(ks), p(perm), p(sort_scratch), sb, st()), "hnr_sort_rows_by_key")
             # 10. point colour / direction / confidence
-            _lib.check(L.hnr_gather_rows_bwd(p(pidx), p(S.raydir), p(S.vs_item), p(S.vs_off), p(S.vs_cnt), p(counts), SR, K, nS, p(gX3), 264,
-                                             p(g_wagg), p(S.w_out), p(g_conf_out) if g_conf_out is not None else None,
-                                             p(pg["points_conf"]), p(pg["points_dir"]), p(pg["points_color"]), st()), "hnr_gather_rows_bwd")
+            G8, P8 = _f32((M, 8), dev), _f32((max(S.U, 1), 8), dev)
+            _lib.check(L.hnr_gather_rows_bwd_rows(p(pidx), p(S.raydir), p(S.vs_item), p(S.vs_off), p(S.vs_cnt), p(counts), SR, K, nS, p(gX3), 264,
+                                                  p(g_wagg), p(S.w_out), p(g_conf_out) if g_conf_out is not None else None, p(G8), st()),
+                       "hnr_gather_rows_bwd_rows")
+            _lib.check(L.hnr_segment_sum_rows_det(p(G8), 8, p(ks), p(perm), M, 8, S.U, None, p(P8), 8, 0, st()), "hnr_segment_sum_rows_det")
+            _lib.check(L.hnr_point_small_grads(p(P8), p(S.ulist), S.U, p(pg["points_conf"]), p(pg["points_dir"]), p(pg["points_color"]), st()),
+                       "hnr_point_small_grads")
             # 11. block1 (first layer split: 60 distance columns per row + per-point table)
             dZ2 = gX3[:, :256]
             dZ1 = lin_bwd(dZ2, S.H1, "block1.2.weight", "block1.2.bias", 256, 256, t["b1_1"], prev=S.H1)
             G1 = ag["block1.0.weight"]                                                # [256,284]
             weight_grad(dZ1, S.Xd, 256, 60, dW=G1[:, 224:284], db=ag["block1.0.bias"])
-            gTu = z(max(S.U, 1), 256)
-            # rows -> touched point: sort the rows by point once, then running sums (no per-element atomics)
-            sb = int(L.hnr_sort_rows_scratch_bytes(M))
-            ks, perm, sort_scratch = _i32(M, dev), _i32(M, dev), torch.empty((sb,), dtype=torch.uint8, device=dev)
-            _lib.check(L.hnr_sort_rows_by_key(p(S.row_u), M, p(ks), p(perm), p(sort_scratch), sb, st()), "hnr_sort_rows_by_key")
-            _lib.check(L.hnr_segment_sum_rows(p(dZ1), 256, None, 0, p(ks), p(perm), M, 256, p(gTu), 256, st()), "hnr_segment_sum_rows")
+            gTu = _f32((max(S.U, 1), 256), dev)
+            _lib.check(L.hnr_segment_sum_rows_det(p(dZ1), 256, p(ks), p(perm), M, 256, S.U, None, p(gTu), 256, 0, st()), "hnr_segment_sum_rows_det")
             if S.U > 0:
                 gTu = gTu[:S.U]
                 weight_grad(gTu, S.E, 256, 224, dW=G1[:, :224], want_bias=False)

@@ -438,6 +438,18 @@ int hnr_gather_rows_bwd(const int32_t *d_sample_pidx, const float *d_raydir, con
                         int ldg3, const float *d_g_wagg, const float *d_weight, const float *d_g_conf_out, float *d_g_conf,
                         float *d_g_dir, float *d_g_color, void *stream);
 
+/* Deterministic form of the same: the per-row contributions [d color 3 | d dir 3 | d conf | 0] are written to d_G8 [rows, 8] instead of
+ * being added with atomics; hnr_segment_sum_rows_det over the rows sorted by touched-point index (hnr_sort_rows_by_key of d_row_u) and
+ * hnr_point_small_grads then add them per point in a fixed order: bit-identical gradients run to run. */
+int hnr_gather_rows_bwd_rows(const int32_t *d_sample_pidx, const float *d_raydir, const int32_t *d_vs_item, const int32_t *d_vs_off,
+                             const int32_t *d_vs_cnt, const int64_t *d_counts, int SR, int K, int cap_samples, const float *d_gX3,
+                             int ldg3, const float *d_g_wagg, const float *d_weight, const float *d_g_conf_out, float *d_G8, void *stream);
+int hnr_point_small_grads(const float *d_P8, const int32_t *d_ulist, int U, float *d_g_conf, float *d_g_dir, float *d_g_color, void *stream);
+/* dst[(dst_index ? dst_index[k] : k), 0:n_cols] (+)= sum of the rows A[perm[e], :] with keys_sorted[e] == k, for the DENSE keys k = 0 .. n_keys-1;
+ * one wave per key, rows added in sorted (= original row) order, no atomics.  n_cols a multiple of 4, <= 256. */
+int hnr_segment_sum_rows_det(const float *d_A, int lda, const int32_t *d_keys_sorted, const int32_t *d_perm, int64_t M, int n_cols,
+                             int n_keys, const int32_t *d_dst_index, float *d_dst, int64_t dst_stride, int accumulate, void *stream);
+
 /* The set of points a batch touches: d_uidx [n_points] = compact index or -1, d_ulist [<= cap] = their ids (ascending),
  * d_row_u [M] = compact index of every neighbour row, *d_count = how many.  d_scratch: int32[ceil(n_points/1024)]. */
 int hnr_unique_points(const int32_t *d_row_pid, int64_t M, int n_points, int32_t *d_uidx, int32_t *d_ulist, int cap,

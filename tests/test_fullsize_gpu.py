@@ -199,7 +199,7 @@ def test_c3_scene0241_train_step_full_size():
         l2 = float(np.linalg.norm(x - r) / np.linalg.norm(r))
         if k.startswith("neural_points."):
             worst_p = max(worst_p, e)
-            assert e < 8e-3 and l2 < 2e-3, (k, e, l2)     # measured 2.9e-3 / 4e-4 (atomics order varies run to run)
+            assert e < 4e-3 and l2 < 1e-3, (k, e, l2)     # deterministic per-point sums (no atomics): the same value every run
         else:
             worst_w = max(worst_w, e)
             # fp32 effects at 272 k rows: a LeakyReLU-kink flip (see test_train_gpu.py) moves a weight gradient by ~1e-3; the

@@ -226,3 +226,27 @@ def test_sort_and_segment_sum_equal_index_add(M, n_cols, n_keys, two):
     ref = torch.zeros((n_keys, n_cols), dtype=torch.float64, device="cuda").index_add_(0, keys[m].long(), src[m].double())
     assert (dst[:, :n_cols].double() - ref).abs().max().item() < 1e-4
     assert torch.all(dst[:, n_cols:] == 0)
+
+
+def test_point_buffer_gradients_are_bit_identical_run_to_run():
+    """The gradients of points_embeding / points_conf / points_dir / points_color (the transposed gather of
+    models/neural_points/neural_points.py:709-720) are summed per touched point in a FIXED order -- rows sorted by point with a
+    stable radix sort, one wave per point (hnr_segment_sum_rows_det) -- not with float atomics: repeated steps give the same bits."""
+    from hybridneuralrendering_amd.train import render_train
+    d, ti, opt, agg, path = _setup("scannet_small")
+    near, far = d["near_far"]
+    tmid = torch.from_numpy(d["tmid"]).to(ti["emb"].device)
+    gt = torch.from_numpy(d["gt"][0]).to(ti["emb"].device)
+    runs = []
+    for _ in range(3):
+        emb, conf, pdir, color = _leaves(ti)
+        agg.zero_grad(set_to_none=True)
+        out = render_train(path, agg, ti["xyz"], emb, conf, pdir, color, ti["raydir"][0], ti["campos"][0], ti["camrotc2w"][0],
+                           ti["bg_color"][0], near, far, ti["c2w_nearest"][0], ti["campos_nearest"][0], ti["intrinsic_nearest"][0],
+                           ti["images_nearest"][0], tmid=tmid)
+        loss, _, _ = _loss(out, gt, float(d["zero_epsilon"]))
+        loss.backward()
+        runs.append([g.grad.clone() for g in (emb, conf, pdir, color)])
+    for other in runs[1:]:
+        for a, b, name in zip(runs[0], other, ("points_embeding", "points_conf", "points_dir", "points_color")):
+            assert torch.equal(a, b), name
