@@ -143,6 +143,7 @@ SIGNATURES = {
     "hnr_gather_rows_bwd_rows": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P]),
     "hnr_point_small_grads": (_I, [_P, _P, _I, _P, _P, _P, _P]),
     "hnr_segment_sum_rows_det": (_I, [_P, _I, _P, _P, ctypes.c_int64, _I, _I, _P, _P, ctypes.c_int64, _I, _P]),
+    "hnr_probe_select": (_I, [_P, _P, _P, _P, ctypes.POINTER(_F), _P, _P, _I, _I, _I, _F, _F, _P, _P, _P]),
     "hnr_unique_points": (_I, [_P, ctypes.c_int64, _I, _P, _P, _I, _P, _P, _P, _P]),
     "hnr_scatter_add_rows": (_I, [_P, _I, _P, ctypes.c_int64, _I, _P, _I, _P]),
     "hnr_point_rows_bwd": (_I, [_P, _I, _P, _I, _P, _I, _I, _P, _P]),

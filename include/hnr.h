@@ -520,6 +520,17 @@ int hnr_render_forward(const hnr_grid *grid, const hnr_render_params *p, const h
                        const hnr_render_outputs *out, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * "Next" row: hole probing, run/train_ft.py:527-549 (`probe_hole`) + :571-581 (`bloat_inds`).  Per probed frame: a cast
+ * ray that found no neighbour although its ground-truth pixel is not background (|gt - bg| > 0.002) marks a hole; every hit ray
+ * whose max-opacity sample exceeds opacity_thresh and that lies in the 3x3 neighbourhood of a hole -- or, when far_thresh > 0, whose
+ * nearest neighbour is farther than far_thresh while its colour is within 0.1 of the ground truth -- becomes a new point.
+ * d_sel [h*w] receives ray id + 1 at the selected pixels (0 elsewhere); the caller compacts it in row-major order.
+ * d_pixel_idx [R,2] (x, y) as floats, d_ray_mask [R] float, bg3_host: 3 HOST floats, d_miss_scratch int32[h*w]. */
+int hnr_probe_select(const float *d_pixel_idx, const float *d_ray_mask, const float *d_gt, const float *d_raycolor, const float *bg3_host,
+                     const float *d_far_dist, const float *d_opacity, int R, int h, int w, float far_thresh, float opacity_thresh,
+                     int32_t *d_miss_scratch, int32_t *d_sel, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
  * "Next" row: blur-handling module with pre-defined kernels, models/base_rendering_model.py:677-745
  * (`blur_update_output`, called at mvs_points_volumetric_model.py:145-146).  d_color / d_gt / d_out: [S*S,3] with
  * S = patch_num * patch_size in the dilated-patch ray layout; d_kernels [n_kernels, ks, ks]; per patch the candidate

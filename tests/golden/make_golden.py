@@ -294,6 +294,122 @@ def gen_c1(ref):
         int(q["ray_mask"].sum()), q["counts"]["n_samples"], q["counts"]["n_neighbours"], float(out_full["coarse_raycolor"].mean())))
 
 
+def _reference_functions(path, names):
+    """The named top-level functions of a reference source file, compiled from the file where it lies (this container only) into a
+    namespace of our choosing -- for drivers like run/train_ft.py whose module-level imports (data loaders, MVS nets, ...) cannot be
+    satisfied here.  Nothing of the source is stored; only the fixture it produces."""
+    import ast
+    tree = ast.parse(open(path).read())
+    keep = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    assert len(keep) == len(names), [n.name for n in keep]
+    return compile(ast.Module(body=keep, type_ignores=[]), path, "exec")
+
+
+def gen_probe_hole(ref):
+    """probe_hole.npz: the reference's hole probing / point growing selection (run/train_ft.py:450-569 `probe_hole` + :571-581 `bloat_inds`)
+    driven on CPU over two synthetic frames: the function's own code, a stand-in model whose test() hands back pre-drawn per-ray probe
+    outputs (the opt.prob == 1 keys of models/neural_points_volumetric_model.py:392-416), a stand-in dataset and visualiser."""
+    import contextlib
+    import random
+    code = _reference_functions("/root/reference/run/train_ft.py", ("probe_hole", "bloat_inds"))
+
+    class TorchCPU:                                    # torch with device="cuda" requests served on the CPU
+        def __getattr__(self, n):
+            return getattr(torch, n)
+
+        @staticmethod
+        def zeros(*a, **k):
+            k.pop("device", None)
+            return torch.zeros(*a, **k)
+
+    class Bar:
+        def __init__(self, it):
+            self.it = it
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+        def __iter__(self):
+            return iter(self.it)
+
+        def set_description(self, *_):
+            pass
+
+    ns = dict(torch=TorchCPU(), np=np, random=random, tqdm=Bar, print=lambda *a, **k: None)
+    old_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        exec(code, ns)
+        rng = np.random.default_rng(21)
+        H, W, m = 20, 28, 2
+        pix = np.stack(np.meshgrid(np.arange(m, W - m), np.arange(m, H - m)), axis=-1).astype(np.float32)      # [H', W', 2] (x, y), row-major
+        R = pix.shape[0] * pix.shape[1]
+        frames = []
+        for f in range(2):
+            ray_mask = (rng.random(R) > 0.22).astype(np.float32)
+            fr = dict(ray_mask=ray_mask, coarse_raycolor=rng.random((R, 3)).astype(np.float32),
+                      ray_max_sample_loc_w=rng.normal(size=(R, 3)).astype(np.float32), ray_max_far_dist=(rng.random((R, 1)) * 0.1).astype(np.float32),
+                      ray_max_shading_opacity=rng.random((R, 1)).astype(np.float32), shading_avg_color=rng.random((R, 3)).astype(np.float32),
+                      shading_avg_dir=rng.normal(size=(R, 3)).astype(np.float32), shading_avg_conf=rng.random((R, 1)).astype(np.float32),
+                      shading_avg_embedding=rng.normal(size=(R, 32)).astype(np.float32))
+            gt = rng.random((R, 3)).astype(np.float32)
+            gt[rng.random(R) < 0.3] = 1.0                                  # background-coloured ground truth: a miss there is no hole
+            near = rng.random(R) < 0.4                                     # rays whose render is close to the ground truth (far_thresh rule)
+            gt[near] = np.clip(fr["coarse_raycolor"][near] + rng.normal(size=(int(near.sum()), 3)).astype(np.float32) * 0.02, 0, 1)
+            frames.append((fr, gt))
+
+        class Model:
+            def __init__(self):
+                self.opt = SimpleNamespace(kernel_size=[3, 3, 3], query_size=[3, 3, 3], prob=0)
+                self.cur = None
+
+            def set_input(self, data):
+                self.cur = data
+
+            def test(self):
+                fr = frames[self.cur["_frame"]][0]
+                px = self.cur["pixel_idx"][0].to(torch.long)
+                idx = (px[:, 1] - m) * (W - 2 * m) + (px[:, 0] - m)
+                out = {k: torch.from_numpy(v)[idx][None] for k, v in fr.items()}
+                return out
+
+        class Dataset:
+            height, width = H, W
+
+            def __len__(self):
+                return len(frames)
+
+            def get_item(self, i):
+                return dict(bg_color=torch.ones(3), raydir=torch.zeros(1, R, 3), pixel_idx=torch.from_numpy(pix)[None],
+                            gt_image=torch.from_numpy(frames[i][1]), _frame=i)
+
+        vis = SimpleNamespace(reset=lambda: None, save_ref_views=lambda *a, **k: None, save_neural_points=lambda *a, **k: None,
+                              print_details=lambda *a, **k: None)
+        save = dict(pix=pix.reshape(-1, 2), hw=np.array([H, W]), bg=np.ones(3, np.float32))
+        for f, (fr, gt) in enumerate(frames):
+            for k, v in fr.items():
+                save["f%d_%s" % (f, k)] = v
+            save["f%d_gt" % f] = gt
+        for tag, far_thresh in (("far0", 0.0), ("far", 0.05)):
+            opt = SimpleNamespace(point_features_dim=32, prob_kernel_size=None, prob_tiers=[], prob_mode=1, prob_num_step=1, prob_top=0,
+                                  random_sample_size=8, far_thresh=far_thresh, prob_mul=0.4, bgmodel="no")
+            random.seed(3)
+            order = list(range(len(frames)))
+            random.shuffle(order)
+            random.seed(3)
+            add = ns["probe_hole"](Model(), Dataset(), vis, opt, None, test_steps=0, opacity_thresh=0.7)
+            save[tag + "_order"] = np.array(order)
+            for name, t in zip(("xyz", "embedding", "color", "dir", "conf"), add):
+                save["%s_%s" % (tag, name)] = t.numpy()
+            print("probe_hole.npz[%s]: %d new points over %d frames (order %s)" % (tag, add[0].shape[0], len(frames), order))
+        np.savez_compressed(os.path.join(HERE, "probe_hole.npz"), **save)
+    finally:
+        torch.Tensor.cuda = old_cuda
+
+
 def gen_train(ref, tag, scene_name, n_points, seed, w, h, patch, opt_over=None, margin=2, size=None, keep=None, twin=None):
     """One training step of the reference on CPU (forward in train mode + autograd): the C3 fixture.
 
@@ -583,6 +699,7 @@ def main():
     gen_render(ref, "synth_small", "lego", 9000, 12, 40, 40, 500, opt_over=dict(agg_axis_weight=None, SR=40))
     gen_render(ref, "scannet_small_prob", "scene0241", 12000, 11, 64, 48, 600, opt_over=dict(agg_axis_weight=None, prob=1), size=(1.0, 0.8, 0.6))
     gen_c1(ref)
+    gen_probe_hole(ref)
     gen_param_keys(ref)
     gen_blur(ref)
     gen_blur_learn(ref)
