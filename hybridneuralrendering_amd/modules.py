@@ -101,8 +101,17 @@ class NeuralPoints(nn.Module):
         if getattr(opt, "load_points", 0) == 1:
             saved = torch.load(checkpoint, map_location=device) if checkpoint else None
             if saved is None or "neural_points.xyz" not in saved:
-                raise HnrError("NeuralPoints: a checkpoint holding neural_points.* is required (cloud files are loaded by the "
-                               "reference's data layer, which is out of scope); use set_points() otherwise")
+                # no cloud in the checkpoint (:248-308): positions from opt.cloud_path, features from feature_init_method, confidence 1
+                from . import cloud_io
+                if getattr(opt, "construct_res", 0) > 0 or len(getattr(opt, "point_noise", "")) > 0:
+                    raise HnrError("NeuralPoints: construct_res / point_noise are not implemented (no shipped script sets them)")
+                xyz = torch.as_tensor(cloud_io.load_cloud(opt), device=device, dtype=torch.float32)
+                emb, conf = cloud_io.init_point_features(xyz, num_channels, feature_init_method, device, int(opt.point_features_dim))
+                saved = dict(saved or {})
+                saved.update({"neural_points.xyz": xyz})
+                saved.setdefault("neural_points.points_embeding", emb)
+                if "neural_points.points_conf" not in saved and not checkpoint:
+                    saved["neural_points.points_conf"] = conf
             par = lambda k, g: nn.Parameter(saved[k], requires_grad=g) if k in saved else None
             self.xyz = nn.Parameter(saved["neural_points.xyz"], requires_grad=opt.xyz_grad > 0)
             self.points_embeding = par("neural_points.points_embeding", opt.feat_grad > 0)

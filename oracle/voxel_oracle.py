@@ -4,7 +4,9 @@ models/mvs/mvs_utils.py:537-563 `construct_vox_points_closest`, for the shipped 
 Pinning: the reference function itself needs torch_scatter, which this image lacks.  tests/golden/make_golden.py::gen_voxel runs the
 reference function with a stand-in for its two torch_scatter calls (scatter_mean = index_add / count, scatter_min = first
 minimum) -- everything else (bounds, fp32 cell arithmetic, torch.unique order, residual norm) is the reference's own code --
-and this file is checked against that fixture (tests/golden/voxel_down.npz).  The two scatter calls are therefore restated,
+and this file is checked against that fixture (tests/golden/voxel_down.npz).  The stand-ins themselves are pinned to the DEFINITION of
+the two operators by brute force in float64 (tests/test_voxel.py::test_golden_scatter_outputs_satisfy_the_definition_of_torch_scatter).
+The two scatter calls are therefore restated,
 not pinned: torch_scatter's CUDA path sums with atomics and resolves argmin ties by race, so no fixture could pin them anyway.
 """
 import numpy as np

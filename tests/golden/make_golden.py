@@ -410,6 +410,39 @@ def gen_probe_hole(ref):
         torch.Tensor.cuda = old_cuda
 
 
+def gen_cloud_io(ref):
+    """cloud_io.npz: the reference's point-cloud file helpers run on small inputs -- `save_points` (utils/visualizer.py:29-39) writes the
+    `.txt` dumps whose bytes are stored, `load_blender_cloud` (data/load_blender.py:116-132) draws a pickled cloud down to num_point with
+    python's `random` (seeded here), and `positional_encoding` (models/helpers/networks.py:175-189) gives the 'pos' feature init."""
+    import pickle
+    import random
+    ns = dict(np=np, os=os, torch=torch)
+    exec(_reference_functions("/root/reference/utils/visualizer.py", ("save_points",)), ns)
+    ns2 = dict(np=np, pickle=pickle, random=random, print=lambda *a, **k: None)
+    exec(_reference_functions("/root/reference/data/load_blender.py", ("load_blender_cloud",)), ns2)
+    rng = np.random.default_rng(31)
+    xyz = rng.normal(size=(7, 3)).astype(np.float32)
+    xyz6 = np.concatenate([xyz, rng.random((7, 3)).astype(np.float32) * 255], axis=1)
+    stack = rng.normal(size=(3, 5, 6)).astype(np.float32)
+    save = dict(xyz=xyz, xyz6=xyz6, stack=stack)
+    with tempfile.TemporaryDirectory() as d:
+        ns["save_points"](xyz, d, 12)
+        ns["save_points"](xyz6, d, "prob0007")
+        ns["save_points"](stack, os.path.join(d, "s"), 3)
+        for rel in ("step-0012-0.txt", "step-prob0007-0.txt", "s/step-0003-0.txt", "s/step-0003-2.txt"):
+            save["file:" + rel] = np.frombuffer(open(os.path.join(d, rel), "rb").read(), dtype=np.uint8)
+        big = dict(point_xyz=rng.normal(size=(50, 3)).astype(np.float32), point_face_normal=rng.normal(size=(50, 3)).astype(np.float32))
+        pk = os.path.join(d, "cloud.pkl")
+        pickle.dump(big, open(pk, "wb"))
+        random.seed(5)
+        sub, nrm = ns2["load_blender_cloud"](pk, 20)
+        allp, _ = ns2["load_blender_cloud"](pk, 80)
+        save.update(pkl_xyz=big["point_xyz"], pkl_nrm=big["point_face_normal"], sub_xyz=sub, sub_nrm=nrm, all_xyz=allp)
+    save["pos_init"] = ref.nets.positional_encoding(torch.from_numpy(xyz).reshape(1, -1, 3), 5).numpy()        # feature_dim 32 -> 5 freqs (30) + 2 random
+    np.savez_compressed(os.path.join(HERE, "cloud_io.npz"), **save)
+    print("cloud_io.npz: %d files, subsample %s" % (sum(k.startswith("file:") for k in save), sub.shape))
+
+
 def gen_train(ref, tag, scene_name, n_points, seed, w, h, patch, opt_over=None, margin=2, size=None, keep=None, twin=None):
     """One training step of the reference on CPU (forward in train mode + autograd): the C3 fixture.
 
@@ -700,6 +733,7 @@ def main():
     gen_render(ref, "scannet_small_prob", "scene0241", 12000, 11, 64, 48, 600, opt_over=dict(agg_axis_weight=None, prob=1), size=(1.0, 0.8, 0.6))
     gen_c1(ref)
     gen_probe_hole(ref)
+    gen_cloud_io(ref)
     gen_param_keys(ref)
     gen_blur(ref)
     gen_blur_learn(ref)

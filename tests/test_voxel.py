@@ -74,3 +74,38 @@ def test_voxel_hip_large_cloud_properties_and_edge_cases():
         construct_vox_points_closest(xyz[:10], 100, space_min=torch.zeros(3))
     with pytest.raises(HnrError):
         construct_vox_points_closest(xyz[:10].cpu(), 100)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_golden_scatter_outputs_satisfy_the_definition_of_torch_scatter(tag):
+    """The image has no torch_scatter, so the golden ran the reference function with stand-ins for its two calls (make_golden.py::gen_voxel).
+    This pins those stand-ins -- and with them the stored `centroid` / `min_idx` -- to the DEFINITION of the two operators
+    (torch_scatter docs: scatter_mean = per-index arithmetic mean; scatter_min = per-index minimum and an index attaining it), evaluated
+    here by brute force in float64 over every voxel: membership from the stored cells, not from any code under test."""
+    z = np.load(os.path.join(GOLD, "voxel_down.npz"))
+    xyz, grid, cen, midx = z[tag + "_xyz"].astype(np.float64), z[tag + "_grid"], z[tag + "_centroid"], z[tag + "_min_idx"]
+    V = grid.shape[0]
+    assert cen.shape == (V, 3) and midx.shape == (V,)
+    # voxel of every point, re-derived from the stored outputs alone: the chosen point of voxel v lies in v, and a point belongs to the
+    # voxel whose cell equals floor((p - space_min) / size); recover (space_min, size) from the data the way :541-551 define them
+    x32 = z[tag + "_xyz"]
+    mn, mx = x32.min(0), x32.max(0)
+    edge = np.float32(np.max(mx - mn) * np.float32(1.05))
+    space_min = ((mx + mn) / np.float32(2) - edge / np.float32(2)).astype(np.float32)
+    size = np.float32(edge / np.float32(float(z[tag + "_res"][0])))
+    cell = np.floor((x32 - space_min[None]) / size).astype(np.int64)
+    key = {tuple(c): v for v, c in enumerate(grid.tolist())}
+    inv = np.array([key[tuple(c)] for c in cell.tolist()])
+    assert len(key) == V and np.array_equal(np.unique(inv), np.arange(V))            # torch.unique(dim=0): every voxel non-empty, no duplicate
+    assert all(grid[i].tolist() < grid[i + 1].tolist() for i in range(V - 1))       # ... in lexicographic order
+    worst_c, ties = 0.0, 0
+    for v in range(V):
+        members = np.nonzero(inv == v)[0]
+        mean = xyz[members].mean(axis=0)                                             # scatter_mean
+        worst_c = max(worst_c, float(np.abs(mean - cen[v]).max()))
+        r = np.linalg.norm(xyz[members] - cen[v].astype(np.float64), axis=1)        # residual to the (stored fp32) centroid, :555-556
+        assert midx[v] in members                                                    # scatter_min's argument index lies in the group ...
+        assert r[list(members).index(midx[v])] <= r.min() * (1 + 1e-6) + 1e-9       # ... and attains the minimum (fp32 rounding of the norm)
+        ties += int((r <= r.min() * (1 + 1e-6) + 1e-9).sum() > 1)
+    assert worst_c < 2e-6, worst_c
+    print("voxel golden %s: %d voxels, centroid max deviation from the float64 mean %.1e, %d voxels with a residual tie" % (tag, V, worst_c, ties))
