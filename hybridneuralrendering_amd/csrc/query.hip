@@ -698,11 +698,14 @@ extern "C" int hnr_march_query(const hnr_grid *g, const float *d_campos, const f
     }
     switch (q->K) {
 #define HNR_KCASE(KK) case KK: launch_knn<KK>(v, d_work, d_sample_loc_w, q->SR, q->radius2, layers, d_sample_pidx, d_ray_mask, cnt, block_stats, max_items, st); break;
+        // every K up to HNR_MAX_K (the reference compiles `#define KN <K>` into its kernel for any value, query_point_indices_worldcoords.py:110)
         HNR_KCASE(1) HNR_KCASE(2) HNR_KCASE(3) HNR_KCASE(4) HNR_KCASE(5) HNR_KCASE(6) HNR_KCASE(7) HNR_KCASE(8)
-        HNR_KCASE(12) HNR_KCASE(16) HNR_KCASE(24) HNR_KCASE(32)
+        HNR_KCASE(9) HNR_KCASE(10) HNR_KCASE(11) HNR_KCASE(12) HNR_KCASE(13) HNR_KCASE(14) HNR_KCASE(15) HNR_KCASE(16)
+        HNR_KCASE(17) HNR_KCASE(18) HNR_KCASE(19) HNR_KCASE(20) HNR_KCASE(21) HNR_KCASE(22) HNR_KCASE(23) HNR_KCASE(24)
+        HNR_KCASE(25) HNR_KCASE(26) HNR_KCASE(27) HNR_KCASE(28) HNR_KCASE(29) HNR_KCASE(30) HNR_KCASE(31) HNR_KCASE(32)
 #undef HNR_KCASE
         default:
-            set_error("hnr_march_query: K=%d is not instantiated (1-8, 12, 16, 24, 32)", q->K);
+            set_error("hnr_march_query: K=%d exceeds HNR_MAX_K = %d", q->K, HNR_MAX_K);
             return HNR_ERR_BADARG;
     }
     HNR_LAUNCH_CHECK();

@@ -44,7 +44,19 @@ def render_image(renderer, cloud, frame, chunk_rays=0, sharded=None, group=None)
             outs.append(torch.cat([o["coarse_raycolor"], o["ray_mask"].to(torch.float32)[:, None]], dim=1))
         return outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
 
-    rows = parallel.render_sharded(render, raydir, group=group) if sharded else render(raydir)
+    def render_auto(rays):
+        """whole block in one launch; when the workspace does not fit (render_rays says so) halve the chunk until it does"""
+        nonlocal chunk_rays
+        for _ in range(8):
+            try:
+                return render(rays)
+            except HnrError as e:
+                if "in chunks" not in str(e):
+                    raise
+                chunk_rays = max((rays.shape[0] if chunk_rays <= 0 else chunk_rays) // 2, 1)
+        return render(rays)
+
+    rows = parallel.render_sharded(render_auto, raydir, group=group) if sharded else render_auto(raydir)
     if rows is None:
         return None
     col, mask = rows[:, :3].contiguous(), rows[:, 3].to(torch.int8)

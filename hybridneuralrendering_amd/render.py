@@ -137,6 +137,14 @@ class HybridRenderer:
             _lib.check(L.hnr_sample_plan(p(work), p(pidx), p(counts), K, R * SR, p(vs_item), p(vs_off), p(vs_cnt), n_valid, n_rows,
                                          p(scratch), p(overflow), st()), "hnr_sample_plan")
           fused = self.dense == "f16x2" and K == 8
+          # memory guard (the per-layer path keeps 3360 B per neighbour row, the fused chain 296 B per neighbour SLOT + ~3 KB per sample):
+          # a frame that cannot fit is refused with the remedy named instead of dying in the allocator
+          need = (n_valid * 8 * 296 + n_valid * 6000) if fused else (n_rows * 3400 + n_valid * 6000)
+          free, _tot = torch.cuda.mem_get_info(dev)
+          cached = torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+          if need > 0.9 * (free + cached):
+              raise HnrError("render_rays: this launch needs ~%.1f GB of workspace for %d valid samples / %d neighbour rows but only %.1f GB are "
+                             "free; render the frame in chunks (driver.render_image(chunk_rays=...), bench.py --chunk)" % (need / 1e9, n_valid, n_rows, (free + cached) / 1e9))
           if fused:
             # the fused chain: gather + geometry + PE -> operand image, then block1 -> block3 -> alpha + K-sums in one kernel
             ws = torch.empty((int(L.hnr_chain_workspace_bytes(n_valid)),), dtype=torch.uint8, device=dev)

@@ -87,6 +87,8 @@ def test_grid_tables_match_oracle(seed, P, max_o):
     (5, 8000, 8, 100000, 1, 3, 300),
     (6, 20000, 12, 100000, 16, 80, 700),     # SR > 64 (synthetic scenes use 80), K = 16
     (7, 20000, 9, 100000, 5, 7, 257),        # odd K / odd SR*K: scalar store path
+    (9, 20000, 12, 100000, 9, 6, 300),       # any K <= HNR_MAX_K is built (the reference compiles `#define KN <K>` for any value, :110)
+    (10, 20000, 30, 100000, 27, 4, 200),
 ])
 def test_march_query_bit_exact(seed, n, P, max_o, K, SR, R):
     cs = _case(seed, n, P, max_o, K, SR, R)
@@ -195,7 +197,7 @@ def test_edge_cases():
     assert int(res["ray_nsamp"][0]) == 0
     # bad arguments are reported, not crashed on
     with pytest.raises(HnrError):
-        Q.march_query(g, campos, away, tm, 6, 9, hp["radius2"], [3, 3, 3])      # K=9 not instantiated
+        Q.march_query(g, campos, away, tm, 6, 33, hp["radius2"], [3, 3, 3])     # K > HNR_MAX_K = 32
     with pytest.raises(HnrError):
         Q.VoxelGrid(xyz, hp["origin"], hp["cell"], [0, 4, 4], [3, 3, 3], 4, 10)
     with pytest.raises(HnrError):
