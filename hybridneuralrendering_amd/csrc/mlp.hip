@@ -25,14 +25,22 @@ struct MlpArgs {
     int wbase[4];                      // byte offset of every layer's image
     int K0, N[4], act[4];
     float *C2; int ldc2;               // optional TAIL layer (S3 > 0): a fourth layer on layer 2's output, written to C2 [M, ldc2] (N[3] columns)
+    // MODE 1 (merge stage: reprojection + image-feature gather -> merge-weight MLP -> weighted merge; rows = 4 views x samples):
+    const float *loc_w; const int32_t *vs_item;         // [R,SR,3], valid-sample list
+    const float *w2c, *Kmat, *campos, *campos_n;        // [4,4,4] inverse(c2w_nearest), [3,3], [3], [4,3]
+    const float *fm; int H, W;                          // reference-view feature map [4,H,W,48]
+    const float *frame_w;                               // optional [4]
+    const float *w_last, *b_last;                       // aux_merge_weight_block.6: [64], [1]
+    const float *CF; int ldcf;                          // colour feature [S,128] (its first 45 columns open the mix-up row)
+    float *X7; int ld7;                                 // out [S, ld7 >= 90]: [colfeat[:45] | merged45]
     float slope;
     const unsigned long long *counts; int count_index, count_mult; long long M_cap;     // M = min(M_cap, counts[index] * mult) (counts may be NULL)
     int seg_stride;                    // > 0: the rows are count_mult segments of counts[index] rows each, segment v starting at row v * seg_stride
     float *C; int ldc;                 // [M, ldc] output rows (N[2] columns)
 };
 
-template <int S0, int S1, int S2, int S3>
-__global__ __launch_bounds__(256, 1) void mlp3_kernel(MlpArgs a)
+template <int S0, int S1, int S2, int S3, int MODE>
+__global__ __launch_bounds__(256, MODE == 1 ? 2 : 1) void mlp3_kernel(MlpArgs a)
 {
     constexpr int SMAX3 = S0 > S1 ? (S0 > S2 ? S0 : S2) : (S1 > S2 ? S1 : S2), SMAX = SMAX3 > S3 ? SMAX3 : S3;
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -60,6 +68,10 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(MlpArgs a)
     const __amdgpu_buffer_rsrc_t wsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(a.wimg), 0, total_steps * ML_WSTEP, 0x00020000);
     float *exch = reinterpret_cast<float *>(lds + SMAX * ML_SLOT);         // [row 128][wave 4]
     float *rowinv = exch + 128 * 4;                                        // [row 128]: 2^-k of the input row's scale
+    // MODE 1 extras: fp32 rows [128][48] = [imgfeat45 | ddir3] of the tile's (sample, view) rows, per-row pixel offset / validity / merge weight
+    float *s_f = rowinv + 128;
+    int *s_pix = reinterpret_cast<int *>(s_f + 128 * 48);
+    float *s_vm = reinterpret_cast<float *>(s_pix + 128), *s_w = s_vm + 128;
     const int col0 = 32 * wave + 16 * h;                                   // this lane's columns: col0 + r
     const unsigned woff = (unsigned)wave * 2048u + (unsigned)lane * 16u;
     const f32x2 slope2 = {a.slope, a.slope};
@@ -67,6 +79,73 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(MlpArgs a)
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const long long row_base = (long long)tile * 128;
         float inv[4];
+        if (MODE == 1) {
+            // ---- merge-stage prologue.  Row t of the tile = (sample ls = t >> 2, view v = t & 3): a sample's four views sit in adjacent rows.
+            // (a) reprojection into the view (w2iproject, neural_points_volumetric_model.py:248-255), truncation to a pixel + bounds rule
+            //     (point_aggregators.py:1077-1088), delta view direction (:296-310) -- the arithmetic of proj_rows_kernel;
+            if (tid < 128) {
+                const int ls = tid >> 2, v = tid & 3;
+                long long sidx = row_base / 4 + ls;
+                if (sidx * 4 >= M) sidx = M / 4 - 1;
+                const float *pw = a.loc_w + (size_t)a.vs_item[sidx] * 3;
+                const float x = pw[0], y = pw[1], z = pw[2];
+                const float *mm = a.w2c + 16 * v;
+                float c[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) c[q] = x * mm[4 * q] + y * mm[4 * q + 1] + z * mm[4 * q + 2] + mm[4 * q + 3];
+                float i3[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) i3[q] = c[0] * a.Kmat[3 * q] + c[1] * a.Kmat[3 * q + 1] + c[2] * a.Kmat[3 * q + 2];
+                const float den = i3[2] + 1e-10f;
+                const float fx = i3[0] / den, fy = i3[1] / den;
+                int px = (fx > -2.0e9f && fx < 2.0e9f) ? (int)fx : -1;
+                int py = (fy > -2.0e9f && fy < 2.0e9f) ? (int)fy : -1;
+                const bool inval = px < 0 || px >= a.W || py < 0 || py >= a.H;
+                if (inval) { px = 0; py = 0; }
+                s_pix[tid] = ((v * a.H + py) * a.W + px) * 48;
+                s_vm[tid] = inval ? 0.f : 1.f;
+                const float cx = x - a.campos[0], cy = y - a.campos[1], cz = z - a.campos[2];
+                const float cn = sqrtf(cx * cx + cy * cy + cz * cz) + 1e-6f;
+                const float nx = x - a.campos_n[3 * v], ny = y - a.campos_n[3 * v + 1], nz = z - a.campos_n[3 * v + 2];
+                const float nn = sqrtf(nx * nx + ny * ny + nz * nz) + 1e-6f;
+                s_f[tid * 48 + 45] = nx / nn - cx / cn; s_f[tid * 48 + 46] = ny / nn - cy / cn; s_f[tid * 48 + 47] = nz / nn - cz / cn;
+            }
+            __syncthreads();
+            // (b) the 45 feature channels of the pixel (192-B contiguous per row; channels 45..47 of the map are padding);
+            for (int idx = tid; idx < 128 * 12; idx += 256) {
+                const int row = idx / 12, q = idx - row * 12;
+                float4 f4 = *reinterpret_cast<const float4 *>(a.fm + (size_t)s_pix[row] + 4 * q);
+                float *d = s_f + row * 48 + 4 * q;
+                if (q < 11) *reinterpret_cast<float4 *>(d) = f4; else d[0] = f4.x;          // column 44; 45..47 hold the direction deltas
+            }
+            __syncthreads();
+            // (c) layer-0 operand planes of the rows 32 wave + j
+            {
+                const float *src = s_f + (32 * wave + j) * 48 + 8 * h;
+                float x[3][8];
+                float m = 0.f;
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    const float4 v0 = *reinterpret_cast<const float4 *>(src + 16 * s), v1 = *reinterpret_cast<const float4 *>(src + 16 * s + 4);
+                    const float t[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { x[s][e] = t[e]; m = fmaxf(m, fabsf(t[e])); }
+                }
+                m = fmaxf(m, __shfl_xor(m, 32));
+                const int k = row_scale_exp(m);
+                const float sc = pow2f(k);
+                if (h == 0) rowinv[32 * wave + j] = pow2f(-k);
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    unsigned ph[4], pm[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) split2h(__fmul_rn(x[s][2 * q], sc), __fmul_rn(x[s][2 * q + 1], sc), ph[q], pm[q]);
+                    char *dst = lds + s * ML_SLOT + (wave * 2) * 1024 + lane * 16;
+                    *reinterpret_cast<u32x4 *>(dst) = u32x4{ph[0], ph[1], ph[2], ph[3]};
+                    *reinterpret_cast<u32x4 *>(dst + 1024) = u32x4{pm[0], pm[1], pm[2], pm[3]};
+                }
+            }
+        } else
         // ---- prologue: wave w loads rows 32 w + j (lane half hh takes k = 16 s + 8 hh .. + 7 of every k step), scales each row by
         // a power of two from its own maximum, splits and writes the layer-0 operand planes
         {
@@ -135,7 +214,7 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(MlpArgs a)
                 if (ADD) {
                     long long row = row_base + 32 * rt + j;
                     if (row >= M) row = M - 1;
-                    rrow = a.R + (size_t)a.ridx[phys(row)] * a.ldr + col0;
+                    rrow = a.R + (size_t)(MODE == 1 ? row / 4 : (long long)a.ridx[phys(row)]) * a.ldr + col0;
                 }
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
@@ -216,7 +295,43 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(MlpArgs a)
         if (act2) {
             h2_mfma_layer<4, 1, S2, 0, ML_WSTEP, ML_SLOT>(wsrd, a.wbase[2], woff, lds, lane, acc, []() {});
             activate(2, amax, std::false_type{});
-            store(a.C, a.ldc);
+            if (MODE != 1) store(a.C, a.ldc);
+        }
+        if (MODE == 1) {
+            // ---- last layer of aux_merge_weight_block (64 -> 1) + sigmoid, validity / frame weights (:1199), weighted merge over the 4 views
+            // (:1217) and the mix-up row (:1286-1292)
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) {
+                float d = 0.f;
+                if (act2) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) d = fmaf(acc[rt][0][r], a.w_last[col0 + r], d);
+                    d = __fadd_rn(d, __shfl_xor(d, 32));
+                }
+                if (h == 0) exch[(32 * rt + j) * 4 + wave] = d;
+            }
+            __syncthreads();
+            if (tid < 128) {
+                const float4 d4 = *reinterpret_cast<const float4 *>(exch + tid * 4);
+                const float d = __fadd_rn(__fadd_rn(d4.x, d4.y), __fadd_rn(d4.z, d4.w));
+                float wv = 1.f / (1.f + expf(-(d + a.b_last[0])));
+                wv *= s_vm[tid];
+                if (a.frame_w) wv *= a.frame_w[tid & 3];
+                s_w[tid] = wv;
+            }
+            __syncthreads();
+            for (int idx = tid; idx < 32 * 45; idx += 256) {
+                const int ls = idx / 45, ch = idx - ls * 45;
+                const long long sidx = row_base / 4 + ls;
+                if (sidx * 4 < M) {
+                    float fsum = 0.f, wsum = 0.f;
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) { const float wv = s_w[4 * ls + v]; fsum += s_f[(4 * ls + v) * 48 + ch] * wv; wsum += wv; }
+                    float *o = a.X7 + (size_t)sidx * a.ld7;
+                    o[ch] = a.CF[(size_t)sidx * a.ldcf + ch];
+                    o[45 + ch] = fsum / (wsum + 1e-6f);
+                }
+            }
         }
         if (S3 > 0) {
             // ---- tail layer on layer 2's output -> second fp32 output
@@ -344,6 +459,8 @@ extern "C" int hnr_mlp3_forward(const float *d_A, int lda, int64_t M_cap, const 
     a.counts = reinterpret_cast<const unsigned long long *>(d_counts); a.count_index = count_index; a.count_mult = count_mult; a.M_cap = M_cap;
     a.seg_stride = seg_stride;
     a.C = d_C; a.ldc = ldc; a.C2 = d_C2; a.ldc2 = ldc2;
+    a.loc_w = nullptr; a.vs_item = nullptr; a.w2c = a.Kmat = a.campos = a.campos_n = a.fm = a.frame_w = a.w_last = a.b_last = a.CF = nullptr;
+    a.H = a.W = a.ldcf = a.ld7 = 0; a.X7 = nullptr;
     static int n_cu = 0;
     if (n_cu == 0) {
         int dev = 0;
@@ -359,8 +476,8 @@ extern "C" int hnr_mlp3_forward(const float *d_A, int lda, int64_t M_cap, const 
         constexpr int smax3 = S0_ > S1_ ? (S0_ > S2_ ? S0_ : S2_) : (S1_ > S2_ ? S1_ : S2_), smax = smax3 > S3_ ? smax3 : S3_;          \
         constexpr int ldsb = smax * ML_SLOT + 128 * 4 * 4 + 128 * 4;                                                                    \
         static bool attr = false;                                                                                                       \
-        if (!attr) { HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(mlp3_kernel<S0_, S1_, S2_, S3_>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb)); attr = true; } \
-        mlp3_kernel<S0_, S1_, S2_, S3_><<<grid, 256, ldsb, st>>>(a);                                                                    \
+        if (!attr) { HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(mlp3_kernel<S0_, S1_, S2_, S3_, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb)); attr = true; } \
+        mlp3_kernel<S0_, S1_, S2_, S3_, 0><<<grid, 256, ldsb, st>>>(a);                                                                    \
         HNR_LAUNCH_CHECK();                                                                                                             \
         return HNR_OK;                                                                                                                  \
     }
@@ -371,4 +488,49 @@ extern "C" int hnr_mlp3_forward(const float *d_A, int lda, int64_t M_cap, const 
 #undef HNR_MLP3_CASE
     set_error("hnr_mlp3_forward: no kernel for k steps (%d, %d, %d, %d); built: (18,8,8,0) (18,8,8,8) (3,4,4,0) (6,3,3,0)", S[0], S[1], S[2], S[3]);
     return HNR_ERR_BADARG;
+}
+
+
+// Merge stage of the image branch in one launch: reprojection of every valid sample into the 4 reference views + feature gather
+// (hnr_proj_rows), the first three layers of aux_merge_weight_block with the per-sample colour-feature addend (hnr_mlp3_forward), the
+// last layer + sigmoid + weighted merge + mix-up row (hnr_merge).  The [4 S, 48] rows, the [4 S, 64] hidden activations and the per-row
+// weights never reach HBM.
+extern "C" int hnr_merge_stage(const float *d_sample_loc_w, const int32_t *d_vs_item, const int64_t *d_counts, const float *d_w2c, const float *d_intrinsic,
+                               const float *d_campos, const float *d_campos_nearest, const float *d_featmap, int V, int H, int W, const float *d_frame_w,
+                               const float *d_pre, int ldpre, const void *d_mlp_mw, const float *d_w_last, const float *d_b_last, const float *d_CF, int ldcf,
+                               int cap_samples, float slope, float *d_X7, int ld7, void *stream)
+{
+    if (V != 4) { set_error("hnr_merge_stage: built for V = 4 reference views (got %d); use hnr_proj_rows + hnr_mlp3_forward + hnr_merge", V); return HNR_ERR_BADARG; }
+    if (cap_samples < 0 || H <= 0 || W <= 0 || ldpre < 64 || (ldpre & 1) || ldcf < 45 || ld7 < 90 || !(slope > 0.f && slope < 1.f)) {
+        set_error("hnr_merge_stage: bad sizes (cap_samples=%d H=%d W=%d ldpre=%d ldcf=%d ld7=%d)", cap_samples, H, W, ldpre, ldcf, ld7); return HNR_ERR_BADARG;
+    }
+    if (cap_samples == 0) return HNR_OK;
+    if (!d_sample_loc_w || !d_vs_item || !d_counts || !d_w2c || !d_intrinsic || !d_campos || !d_campos_nearest || !d_featmap || !d_pre || !d_mlp_mw ||
+        !d_w_last || !d_b_last || !d_CF || !d_X7 || ((uintptr_t)d_featmap & 15) || ((uintptr_t)d_pre & 7) || ((uintptr_t)d_mlp_mw & 15)) {
+        set_error("hnr_merge_stage: NULL / unaligned pointer"); return HNR_ERR_BADARG;
+    }
+    MlpArgs a;
+    a.A = nullptr; a.lda = 48; a.R = d_pre; a.ridx = nullptr; a.ldr = ldpre; a.wimg = (const char *)d_mlp_mw;
+    a.wbase[0] = 0; a.wbase[1] = 3 * ML_WSTEP; a.wbase[2] = 7 * ML_WSTEP; a.wbase[3] = 0;
+    a.K0 = 48; a.N[0] = a.N[1] = a.N[2] = 64; a.N[3] = 0; a.act[0] = a.act[1] = a.act[2] = 1; a.act[3] = 0;
+    a.slope = slope;
+    a.counts = reinterpret_cast<const unsigned long long *>(d_counts); a.count_index = HNR_CNT_SAMPLES_VALID; a.count_mult = 4; a.M_cap = (long long)cap_samples * 4;
+    a.seg_stride = 0; a.C = nullptr; a.ldc = 64; a.C2 = nullptr; a.ldc2 = 0;
+    a.loc_w = d_sample_loc_w; a.vs_item = d_vs_item; a.w2c = d_w2c; a.Kmat = d_intrinsic; a.campos = d_campos; a.campos_n = d_campos_nearest;
+    a.fm = d_featmap; a.H = H; a.W = W; a.frame_w = d_frame_w; a.w_last = d_w_last; a.b_last = d_b_last; a.CF = d_CF; a.ldcf = ldcf; a.X7 = d_X7; a.ld7 = ld7;
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+        if (n_cu <= 0) n_cu = 256;
+    }
+    const int64_t tiles = ((int64_t)cap_samples * 4 + 127) / 128;
+    const int grid = (int)(tiles < 2 * n_cu ? tiles : 2 * n_cu);
+    constexpr int ldsb = 4 * ML_SLOT + 128 * 4 * 4 + 128 * 4 + 128 * 48 * 4 + 3 * 128 * 4;
+    static bool attr = false;
+    if (!attr) { HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(mlp3_kernel<3, 4, 4, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb)); attr = true; }
+    mlp3_kernel<3, 4, 4, 0, 1><<<grid, 256, ldsb, (hipStream_t)stream>>>(a);
+    HNR_LAUNCH_CHECK();
+    return HNR_OK;
 }

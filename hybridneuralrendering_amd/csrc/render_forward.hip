@@ -119,7 +119,14 @@ extern "C" int hnr_render_forward(const hnr_grid *grid, const hnr_render_params 
     if ((rc = hnr_mlp3_forward(L.X5, 280, cap, o->d_counts, HNR_CNT_SAMPLES_VALID, 1, 0, w->d_mlp_cf, V > 0 ? 4 : 3, cfN, cfK, act1110, w->slope, nullptr, nullptr, 0,
                                L.CF, 128, L.pre, 64, stream)) != HNR_OK) return rc;
     HNR_MARK();
-    if (V > 0) {
+    if (V == 4) {
+        // reprojection + feature gather + merge-weight MLP + weighted merge in one launch: nothing per (view, sample) row reaches HBM
+        HNR_MARK();
+        if ((rc = hnr_merge_stage(o->d_sample_loc_w, L.vs_item, o->d_counts, vw->d_w2c, vw->d_intrinsic, cam->d_campos, vw->d_campos_nearest, vw->d_featmap, V,
+                                  vw->H, vw->W, vw->d_frame_w, L.pre, 64, w->d_mlp_mw, w->d_mw_last_w, w->d_mw_last_b, L.CF, 128, cap, w->slope, L.X7, 92,
+                                  stream)) != HNR_OK) return rc;
+        HNR_MARK();
+    } else if (V > 0) {
         if ((rc = hnr_proj_rows(o->d_sample_loc_w, L.vs_item, o->d_counts, vw->d_w2c, vw->d_intrinsic, cam->d_campos, vw->d_campos_nearest, vw->d_featmap,
                                 V, vw->H, vw->W, L.CF, 128, cap, L.X6, 48, L.vmask, L.row_s, stream)) != HNR_OK) return rc;
         HNR_MARK();

@@ -80,6 +80,7 @@ class HybridRenderer:
         # the whole frame as ONE library call (hnr_render_forward: no host read between query and composite); HNR_SINGLE_CALL=0 runs the
         # same kernels stage by stage from Python with exactly sized buffers (one host read of the counters)
         self.single_call = os.environ.get("HNR_SINGLE_CALL", "1") != "0"
+        self.fuse_merge = True            # V = 4: hnr_merge_stage instead of hnr_proj_rows + the merge-weight MLP + hnr_merge (staged path switch)
         self.last_counts = None
         if getattr(opt, "which_render_func", "radiance") != "radiance" or getattr(opt, "which_blend_func", "alpha") != "alpha" \
                 or getattr(opt, "which_tonemap_func", "off") != "off":
@@ -227,35 +228,43 @@ class HybridRenderer:
             X7 = torch.zeros((n_valid, 92), dtype=torch.float32, device=dev)
             X7[:, :45] = CF[:, :45]
           else:
-            with T("proj_rows"):
-              V, H, W = featmap.shape[0], featmap.shape[1], featmap.shape[2]
-              ld6 = 48 if self.split_merge else 176
-              X6 = _f32((V * n_valid, ld6), dev)
-              vmask = _f32((V * n_valid,), dev)
-              row_s = _i32(V * n_valid, dev) if self.split_merge else None
-              _lib.check(L.hnr_proj_rows(p(loc_w), p(vs_item), p(counts), p(w2c_nearest), p(intrinsic_nearest), p(campos),
-                                         p(campos_nearest), p(featmap), V, H, W, p(CF), 128, n_valid, p(X6), ld6, p(vmask),
-                                         p(row_s) if self.split_merge else None, st()), "hnr_proj_rows")
-            with T("mlp_merge"):
-              M1 = _f32((V * n_valid, 64), dev)
-              if fused_s and self.split_merge:
-                  m3["mw"](X6, M1, V * n_valid, counts, ci, V, slope=sl, R=pre, ridx=row_s)
-              elif self.split_merge:
-                  M2 = _f32((V * n_valid, 64), dev)
-                  pre = pk["mw0_cf"](CF, act=False)                                     # [S,64] once per sample (bias included)
-                  pk["mw0_fd"].gather_add(X6, pre, row_s, out=M1, act=True, slope=sl)   # 48 -> 64 per (view, sample) + addend
-              else:
-                  M2 = _f32((V * n_valid, 64), dev)
-                  pk["mw"][0](X6, out=M1, act=True, slope=sl)
-              if not (fused_s and self.split_merge):
-                  pk["mw"][1](M1, out=M2, act=True, slope=sl)
-                  pk["mw"][2](M2, out=M1, act=True, slope=sl)
-            with T("merge"):
-              X7 = _f32((n_valid, 92), dev)
-              fw = None if frame_weight is None else _lib.require_gpu(frame_weight, "frame_weight", torch.float32).reshape(-1)
-              _lib.check(L.hnr_merge(p(X6), ld6, p(M1), 64, p(pk["mw_last_w"]), p(pk["mw_last_b"]), p(vmask),
-                                     p(fw) if fw is not None else None, p(CF), 128, p(counts), V, n_valid, p(X7), 92,
-                                     None, None, 0, st()), "hnr_merge")
+            V, H, W = featmap.shape[0], featmap.shape[1], featmap.shape[2]
+            fw = None if frame_weight is None else _lib.require_gpu(frame_weight, "frame_weight", torch.float32).reshape(-1)
+            if fused_s and self.split_merge and V == 4 and self.fuse_merge:
+              # reprojection + feature gather + merge-weight MLP + weighted merge in one launch (hnr_merge_stage)
+              with T("mlp_merge"):
+                X7 = _f32((n_valid, 92), dev)
+                _lib.check(L.hnr_merge_stage(p(loc_w), p(vs_item), p(counts), p(w2c_nearest), p(intrinsic_nearest), p(campos), p(campos_nearest),
+                                             p(featmap), V, H, W, p(fw) if fw is not None else None, p(pre), 64, p(m3["mw"].packed), p(pk["mw_last_w"]),
+                                             p(pk["mw_last_b"]), p(CF), 128, n_valid, float(sl), p(X7), 92, st()), "hnr_merge_stage")
+            else:
+              with T("proj_rows"):
+                ld6 = 48 if self.split_merge else 176
+                X6 = _f32((V * n_valid, ld6), dev)
+                vmask = _f32((V * n_valid,), dev)
+                row_s = _i32(V * n_valid, dev) if self.split_merge else None
+                _lib.check(L.hnr_proj_rows(p(loc_w), p(vs_item), p(counts), p(w2c_nearest), p(intrinsic_nearest), p(campos),
+                                           p(campos_nearest), p(featmap), V, H, W, p(CF), 128, n_valid, p(X6), ld6, p(vmask),
+                                           p(row_s) if self.split_merge else None, st()), "hnr_proj_rows")
+              with T("mlp_merge"):
+                M1 = _f32((V * n_valid, 64), dev)
+                if fused_s and self.split_merge:
+                    m3["mw"](X6, M1, V * n_valid, counts, ci, V, slope=sl, R=pre, ridx=row_s)
+                elif self.split_merge:
+                    M2 = _f32((V * n_valid, 64), dev)
+                    pre = pk["mw0_cf"](CF, act=False)                                     # [S,64] once per sample (bias included)
+                    pk["mw0_fd"].gather_add(X6, pre, row_s, out=M1, act=True, slope=sl)   # 48 -> 64 per (view, sample) + addend
+                else:
+                    M2 = _f32((V * n_valid, 64), dev)
+                    pk["mw"][0](X6, out=M1, act=True, slope=sl)
+                if not (fused_s and self.split_merge):
+                    pk["mw"][1](M1, out=M2, act=True, slope=sl)
+                    pk["mw"][2](M2, out=M1, act=True, slope=sl)
+              with T("merge"):
+                X7 = _f32((n_valid, 92), dev)
+                _lib.check(L.hnr_merge(p(X6), ld6, p(M1), 64, p(pk["mw_last_w"]), p(pk["mw_last_b"]), p(vmask),
+                                       p(fw) if fw is not None else None, p(CF), 128, p(counts), V, n_valid, p(X7), 92,
+                                       None, None, 0, st()), "hnr_merge")
           with T("mlp_mixup"):
             Y1 = _f32((n_valid, 48), dev)
             if fused_s:

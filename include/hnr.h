@@ -330,6 +330,18 @@ int hnr_mlp3_forward(const float *d_A, int lda, int64_t M_cap, const int64_t *d_
                      const void *d_packed, int n_layers, const int *N, const int *K, const int *act, float slope, const float *d_R,
                      const int32_t *d_ridx, int ldr, float *d_C, int ldc, float *d_C2, int ldc2, void *stream);
 
+/* The merge stage of the image branch in ONE launch (V = 4): reprojection of every valid sample into the reference views + truncation +
+ * feature gather + delta view directions (hnr_proj_rows: neural_points_volumetric_model.py:248-255, :296-310; point_aggregators.py:1077-1088),
+ * aux_merge_weight_block on [imgfeat45 | colfeat128 | ddir3] (:1199; the colour-feature columns enter as the per-sample addend d_pre [S, 64],
+ * bias included -- the tail output of the colour-feature launch), sigmoid, validity / frame weights, the weighted merge over the views
+ * (:1217) and the mix-up row d_X7[s, 0:90] = [colfeat[:45] | merged45] (:1286-1292).  Replaces hnr_proj_rows + hnr_mlp3_forward + hnr_merge:
+ * the [4 S, 48] rows, the [4 S, 64] activations and the per-row weights stay on chip.  d_mlp_mw: hnr_mlp3_pack image of the three layers
+ * 48 -> 64 -> 64 -> 64 (first layer = the image-feature and direction columns, no bias). */
+int hnr_merge_stage(const float *d_sample_loc_w, const int32_t *d_vs_item, const int64_t *d_counts, const float *d_w2c, const float *d_intrinsic,
+                    const float *d_campos, const float *d_campos_nearest, const float *d_featmap, int V, int H, int W, const float *d_frame_w,
+                    const float *d_pre, int ldpre, const void *d_mlp_mw, const float *d_w_last, const float *d_b_last, const float *d_CF, int ldcf,
+                    int cap_samples, float slope, float *d_X7, int ld7, void *stream);
+
 /* Residual + color_final_block + sigmoid*1.002-0.001 (:1294-1295, :1334, :478-482), scattered with sigma into
  * d_decoded [R*SR,4] (pre-zeroed by the caller; :1337-1338). */
 int hnr_final_color(const float *d_Y, int ldy, const float *d_CF, int ldcf, const float *d_w_fin, const float *d_b_fin,

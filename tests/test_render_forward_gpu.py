@@ -109,3 +109,17 @@ def test_workspace_capacity_overflow_is_reported_not_overrun():
     with pytest.raises(_lib.HnrError):
         _lib.check(L.hnr_render_forward(grid.handle, ctypes.byref(prm), ctypes.byref(cl), ctypes.byref(wt), ctypes.byref(cam), ctypes.byref(vw),
                                         ctypes.c_void_p(ws.data_ptr() + off), nbytes // 2, ctypes.byref(out), _lib.stream()), "hnr_render_forward")
+
+
+@pytest.mark.parametrize("tag", ["scannet_small", "synth_small"])
+def test_fused_merge_stage_equals_its_three_kernel_form(tag):
+    """hnr_merge_stage (reprojection + gather + merge-weight MLP + weighted merge in one launch) against hnr_proj_rows + hnr_mlp3_forward +
+    hnr_merge on the same frame: same arithmetic except the order of the 64-term dot product of the last merge-weight layer."""
+    d, ti, opt, cloud, rnd = _setup(tag)
+    rnd.single_call = False
+    a = _render(rnd, cloud, ti, d)
+    rnd.fuse_merge = False
+    b = _render(rnd, cloud, ti, d)
+    assert float((a["decoded"] - b["decoded"]).abs().max()) < 2e-6
+    assert float((a["coarse_raycolor"] - b["coarse_raycolor"]).abs().max()) < 2e-6
+    assert torch.equal(a["decoded"][..., 0], b["decoded"][..., 0])              # densities do not pass through the image branch

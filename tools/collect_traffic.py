@@ -1,4 +1,4 @@
-"""Summarise the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py (tools/run_traffic.sh) into profiles/r01_traffic.json.
+"""Summarise the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py (tools/run_traffic.sh) into profiles/r02_traffic.json.
 
     bash tools/run_traffic.sh                      # on the GPU box: writes gpurun_out/traffic5/{pmc_FETCH_SIZE,pmc_WRITE_SIZE,stats}
     python tools/collect_traffic.py gpurun_out/traffic5
@@ -12,7 +12,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 root = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "traffic5")
-KERNELS = ("linear_s3w_kernel", "linear_f32_kernel<2, 2, 1, 0, 4", "knn3_kernel", "march_kernel", "gather_rows", "ksum_kernel", "proj_rows_kernel", "merge_kernel")
+KERNELS = ("chain_kernel", "chain_gather_kernel", "mlp3_kernel", "knn3_kernel", "knn_set_kernel", "march_kernel", "proj_rows_kernel", "merge_kernel", "final_color_kernel",
+           "composite_kernel", "linear_s3w_kernel", "linear_f32_kernel<2, 2, 1, 0, 4", "gather_rows", "ksum_kernel")
 out = {}
 for name in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob("%s/pmc_%s/*/*counter_collection.csv" % (root, name))[0]
@@ -34,8 +35,8 @@ for k, fs in out["FETCH_SIZE"].items():
     kern[k] = dict(launches=len(f2), fetch_bytes_raw=raw, fetch_bytes_corrected=2 * raw, write_bytes=wr, hbm_bytes=2 * raw + wr)
     print("%-55s n=%2d fetch x2 %9.1f MB  write %9.1f MB" % (k[:55], len(f2), 2 * raw / 1e6, wr / 1e6))
 note = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-train-leg` on MI355X "
-        "(tools/run_traffic.sh); per-launch averages over the LARGE launches of each kernel name (linear_s3w_kernel<16|17,1,0>: the three 256-wide "
-        "per-neighbour layers on split-bf16 operands, M = 23.8 M rows; linear_f32_kernel<2,2,1,0,4,1>: the K=60 layer with its gathered 1 KB/row addend); FETCH_SIZE doubled per MI355X_MICROARCH.md "
-        "(gfx950 tallies 128-B requests as 64 B on wide coalesced reads; calibrated on ksum_kernel: 12.4 GB raw vs 24.3 GB of rows actually read). "
-        "Run-to-run: the plain 256x256 layer read 24.4 GB in an earlier collection and 27-32 GB in later ones on other boxes.")
-json.dump(dict(note=note, kernels=kern), open(os.path.join(ROOT, "profiles", "r01_traffic.json"), "w"), indent=1)
+        "(tools/run_traffic.sh); per-launch averages over the LARGE launches of each kernel name; FETCH_SIZE doubled per MI355X_MICROARCH.md "
+        "(gfx950 tallies 128-B requests as 64 B on wide coalesced reads; calibrated in round 1 on ksum_kernel: 12.4 GB raw vs 24.3 GB of rows actually read). "
+        "chain_kernel<4,0> = the fused per-neighbour chain (one launch per frame); its weight image (848 KiB) is re-read by every workgroup tile from L2, "
+        "which these memory-side counters do not see.")
+json.dump(dict(note=note, kernels=kern), open(os.path.join(ROOT, "profiles", "r02_traffic.json"), "w"), indent=1)
