@@ -40,7 +40,13 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // PD = prefetch distance of the weight fragments in k steps (ring of PD + 1); PRELOAD_ALL: all S steps up front (layer 0).
 // woff = this lane's byte offset inside a k step of the weight image (first column tile of the wave + lane * 16), WSTEP = bytes per k step
 // of the image ([column tile][plane 2][64 lanes][16 B]), SLOT = LDS bytes per k step of the activation planes ([row tile][plane 2][1 KiB]).
-template <int RT, int CT, int S, int PRELOAD_ALL, int WSTEP, int SLOT, class Mid>
+// BAR >= 0: a bare s_barrier (rendezvous only, no memory wait) after k step BAR -- the dual-group chain kernel pairs it with a barrier of the
+// group that runs its epilogue meanwhile.
+// PACE > 0 (dual-group kernel): every MFMA is followed by s_nop PACE - 1 (one less when a load is issued in the same slot).  A wave whose next
+// MFMA waits at the issue stage for the matrix pipe blocks the SIMD's VALU port for every other wave (tools/coissue_probe.hip: the
+// co-resident wave is starved completely); parked in s_nop for the ~24 cycles the pipe is busy anyway, it leaves the port to the other
+// group's epilogue (6.2 instead of 5.0 cycles per VALU instruction there, 34.0 instead of 32.0 cycles per MFMA here).
+template <int RT, int CT, int S, int PRELOAD_ALL, int WSTEP, int SLOT, int BAR = -1, int WSAME = 0, int PACE = 0, class Mid>
 __device__ __forceinline__ void h2_mfma_layer(__amdgpu_buffer_rsrc_t wsrd, int wbase, unsigned woff, const char *lds, int lane, f32x16 (&acc)[RT][CT], Mid mid)
 {
     constexpr int PD = RT * CT >= 8 ? 2 : 3;
@@ -54,7 +60,7 @@ __device__ __forceinline__ void h2_mfma_layer(__amdgpu_buffer_rsrc_t wsrd, int w
 #pragma unroll
         for (int c = 0; c < CT; ++c)
 #pragma unroll
-            for (int p = 0; p < 2; ++p) wf[slot][c][p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wsrd, woff + (c * 2 + p) * 1024, wbase + s * WSTEP, 0));
+            for (int p = 0; p < 2; ++p) wf[slot][c][p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wsrd, woff + (c * 2 + p) * 1024, wbase + (WSAME ? 0 : s) * WSTEP, 0));   // WSAME: probe only (every k step re-reads step 0: L1 hits)
     };
     auto load_b = [&](int slot, int s) {
 #pragma unroll
@@ -75,11 +81,35 @@ __device__ __forceinline__ void h2_mfma_layer(__amdgpu_buffer_rsrc_t wsrd, int w
     load_b(0, 0);
 #pragma unroll
     for (int s = 0; s < S; ++s) {
-        if (!PRELOAD_ALL && s + PD < S) load_w((s + PD) % (PD + 1), s + PD);
-        if (s + 1 < S) load_b((s + 1) & 1, s + 1);
+        if (PACE == 0) {
+            if (!PRELOAD_ALL && s + PD < S) load_w((s + PD) % (PD + 1), s + PD);
+            if (s + 1 < S) load_b((s + 1) & 1, s + 1);
+        }
         const int ws = PRELOAD_ALL ? s : s % (PD + 1), bs = s & 1;
 #define CH_W(c, p) __builtin_bit_cast(f16x8, wf[ws][c][p])
 #define CH_X(rt, p) __builtin_bit_cast(f16x8, bf[bs][rt][p])
+        if (PACE > 0) {
+            // fixed issue order: MFMA, pause, (one load of a later k step), fence
+            const bool has_b = s + 1 < S, has_w = !PRELOAD_ALL && s + PD < S;
+#pragma unroll
+            for (int m = 0; m < 3 * RT * CT; ++m) {
+                const int term = m / (RT * CT), rt = (m % (RT * CT)) / CT, c = m % CT;
+                const int wp = term == 0 ? 1 : 0, xp = term == 1 ? 1 : 0;             // wm*xh, wh*xm, wh*xh
+                acc[rt][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(CH_W(c, wp), CH_X(rt, xp), acc[rt][c], 0, 0, 0);
+                bool load = false;
+                if (has_b && m < 2 * RT) {
+                    const int r2 = m >> 1, p2 = m & 1;
+                    bf[(s + 1) & 1][r2][p2] = *reinterpret_cast<const u32x4 *>(bp + (s + 1) * SLOT + (r2 * 2 + p2) * 1024);
+                    load = true;
+                } else if (has_w && m >= 2 * RT && m < 2 * RT + 2 * CT) {
+                    const int i2 = m - 2 * RT, c2 = i2 >> 1, p2 = i2 & 1;
+                    wf[(s + PD) % (PD + 1)][c2][p2] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wsrd, woff + (c2 * 2 + p2) * 1024, wbase + (WSAME ? 0 : s + PD) * WSTEP, 0));
+                    load = true;
+                }
+                if (load) asm volatile("s_nop %0" :: "n"(PACE > 1 ? PACE - 2 : 0)); else asm volatile("s_nop %0" :: "n"(PACE > 0 ? PACE - 1 : 0));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
         // smallest terms first; RT * CT independent accumulators between two MFMAs on the same one
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
@@ -93,8 +123,6 @@ __device__ __forceinline__ void h2_mfma_layer(__amdgpu_buffer_rsrc_t wsrd, int w
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int c = 0; c < CT; ++c) acc[rt][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(CH_W(c, 0), CH_X(rt, 0), acc[rt][c], 0, 0, 0);
-#undef CH_W
-#undef CH_X
         // issue order inside the k step: the fragment reads of step s+1 and the 4 weight loads of step s+PD go out under the
         // FIRST MFMAs (left alone, hipcc sinks the reads to the end of the step and the next step's first MFMA waits for LDS)
         if (s + 1 < S) {
@@ -105,7 +133,11 @@ __device__ __forceinline__ void h2_mfma_layer(__amdgpu_buffer_rsrc_t wsrd, int w
 #pragma unroll
             for (int i = 0; i < 2 * CT; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
         }
+        }
+#undef CH_W
+#undef CH_X
         __builtin_amdgcn_sched_barrier(0);                                // keep the prefetch distance: no load of a later k step is hoisted across
+        if (s == BAR) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
     }
 }
 

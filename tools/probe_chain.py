@@ -15,17 +15,19 @@ X5 = torch.empty((nv, 280), dtype=torch.float32, device=dev); sg = torch.empty((
 ptab = W["rnd"].point_table(W["cloud"]); q = W["q"]; c = W["cloud"]
 _lib.check(L.hnr_chain_gather(p(c.xyz), p(c.conf), p(c.dir), p(c.color), p(q["sample_pidx"]), p(q["sample_loc_w"]), p(W["raydir"]), p(W["campos"]),
                               p(W["camrot"]), p(W["vs_item"]), p(q["counts"]), W["SR"], W["K"], nv, p(ws), p(X5), 280, None, None, _lib.stream()), "g")
-dbg = torch.zeros(((4 * 16 + 4 * 1024) * 2,), dtype=torch.float32, device=dev)
+NW = 8 if os.environ.get('HNR_CHAIN_RT', '4') == '8' else 4          # waves per workgroup: 8 in the dual-group kernel (default)
+dbg = torch.zeros(((NW * 16 + 4 * 1024) * 2,), dtype=torch.float32, device=dev)
 pk = W["agg"].packed_chain()
+MODE = -int(os.environ.get('PROBE_MODE', '1'))          # -1: phase timing; -3 / -4 / -5 (dual-group kernel only): no epilogue work / same weights / both
 for it in range(3):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    _lib.check(L.hnr_chain_forward(p(ws), p(ptab), 256, p(pk), p(q["counts"]), nv, 0.01, p(X5), 280, p(sg), p(dbg) if it == 2 else None, -1, _lib.stream()), "f")
+    _lib.check(L.hnr_chain_forward(p(ws), p(ptab), 256, p(pk), p(q["counts"]), nv, 0.01, p(X5), 280, p(sg), p(dbg) if it == 2 else None, MODE, _lib.stream()), "f")
     e1.record(); torch.cuda.synchronize()
     print("chain_forward %.3f ms, %d valid samples, %d tiles" % (e0.elapsed_time(e1), nv, (nv + 15) // 16))
 allv = dbg.view(torch.int64).cpu().numpy()
-t = allv[:64].reshape(4, 16)
-blk = allv[64:].reshape(-1, 4)
+t = allv[:NW * 16].reshape(NW, 16)
+blk = allv[NW * 16:].reshape(-1, 4)
 blk = blk[blk[:, 2] > 0]
 ms = blk[:, 1] / 1e5
 print('blocks %d: wall ms per block min %.2f mean %.2f max %.2f; tiles min %d max %d' % (len(blk), ms.min(), ms.mean(), ms.max(), blk[:, 2].min(), blk[:, 2].max()))
@@ -47,6 +49,6 @@ for x in range(8):
     m = (np.arange(len(blk)) % 8) == x
     print('  blocks b%%8==%d: xcc %s, ms mean %.2f max %.2f, GHz %.3f' % (x, sorted(set(xcc[m].tolist())), ms[m].mean(), ms[m].max(), (blk[m, 0] / blk[m, 1]).mean() * 0.1))
 names = ["prologue", "L0 mfma", "L0 act(+T wait)", "L0 publish", "L1 mfma", "L1/L2 act", "L1/L2 publish", "L2 mfma", "L3 mfma", "L3 epilogue"]
-for w in range(4):
+for w in range(NW):
     nt = max(t[w, 12], 1)
     print("wave %d: %d tiles, %.0f cycles/tile (%.3f GHz): " % (w, nt, t[w, 10] / nt, t[w, 10] / max(t[w, 11], 1) * 0.1) + ", ".join("%s %.0f" % (names[i], t[w, i] / nt) for i in range(10)))
