@@ -314,7 +314,17 @@ def main():
 
     def step(timers=None, time_gather=False):
         rnd._fm_key = None          # a new frame has new reference views: their feature pyramid is rebuilt inside every step
-        col, out = render_frame(rnd, cloud, cam, sc, args.chunk, timers)
+        if rehearsal and world > 1:
+            # rehearsal (all ranks on ONE GPU): the ranks take turns on the device.  Processes that share a GPU are time-sliced by wave
+            # preemption, and on this pool a preempted long kernel can resume with a perturbed result (tools/stress_determinism.py,
+            # profiles/README.md: 216 of 285 200 pixels of a block); the rehearsal checks the sharding / gather path, not throughput
+            for r in range(world):
+                if r == rank:
+                    col, out = render_frame(rnd, cloud, cam, sc, args.chunk, timers)
+                    torch.cuda.synchronize()
+                dist.barrier()
+        else:
+            col, out = render_frame(rnd, cloud, cam, sc, args.chunk, timers)
         frame = col
         if world > 1:
             # reassemble the frame (strong) / the N frames (weak) on rank 0: ONE gather over xGMI, equal-size blocks

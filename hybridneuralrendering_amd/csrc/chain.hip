@@ -33,44 +33,9 @@
 // LDS (ds_read_b128, 8 per k step for 24 MFMAs).
 #include <stdlib.h>
 
-#include "hnr_h2.h"
+#include "chain_defs.h"
 
 namespace hnr {
-
-// a GROUP = 32 rows = one MFMA row tile = 4 shading samples x 8 slots
-constexpr int CH_WSTEP = 16384;                    // weight image bytes per k step: [column tile 8][plane 2][64 lanes][16 B]
-constexpr int CH_S0 = 4, CH_S1 = 16, CH_S2 = 17, CH_S3 = 16;      // k steps of the four layers (K = 60, 256, 263, 256)
-constexpr int CH_W0 = 0, CH_W1 = CH_S0 * CH_WSTEP, CH_W2 = CH_W1 + CH_S1 * CH_WSTEP, CH_W3 = CH_W2 + CH_S2 * CH_WSTEP;
-constexpr int CH_WBYTES = CH_W3 + CH_S3 * CH_WSTEP;               // 53 k steps = 848 KiB
-constexpr int CH_META = CH_WBYTES;                 // floats after the image: bias[4][256], alpha_w[256], alpha_b, descale_w[4], max|W| bits[4], pad
-constexpr int CH_META_DESCALE = 4 * 256 + 256 + 1, CH_META_WMAX = CH_META_DESCALE + 4;
-constexpr int CH_META_FLOATS = CH_META_WMAX + 4 + 3;
-constexpr int CH_XP_GROUP = CH_S0 * 2048;          // bytes of one group's layer-0 operand image: [k step 4][plane 2][64 lanes][16 B] = 8 KiB
-constexpr int CH_AUX_GROUP = 32 * 4 + 32 * 4 + 32 * 8 * 4;        // pid[32] i32, wagg[32] f32, ext[32][8] f32 = 1280 B
-// workgroup tile = RT groups; LDS: 17 k-step slots of [row tile RT][plane 2][64 lanes][16 B], then the float[32 RT][4] exchange area
-constexpr int ch_slot(int RT) { return RT * 2048; }
-constexpr int ch_lds_exch(int RT) { return 17 * ch_slot(RT); }
-constexpr int ch_lds_bytes(int RT) { return ch_lds_exch(RT) + 32 * RT * 4 * 4; }
-
-struct ChainArgs {
-    const char *xp;                    // [groups][CH_XP_GROUP] layer-0 operand image (chain_gather_kernel)
-    const char *aux;                   // [groups][CH_AUX_GROUP]
-    const float *ptab; int ldt;        // per-point addend of block1.0: [N, ldt >= 256]
-    const char *wimg;                  // packed weights (hnr_chain_pack)
-    const unsigned long long *counts;  // device counters of the query (n_valid samples)
-    float *X5; int ld5;                // [S_v, ld5 >= 256]: weighted feature sums
-    float *sigma;                      // [S_v]
-    float slope;
-    int cap_samples;
-    float *dbg; int dbg_layer;         // probe: post-activation output of layer dbg_layer -> [rows, 256]
-    int skew;                          // RT = 2: the second half of the grid (the CUs' second workgroups) starts skew x 64 cycles late
-};
-
-__device__ __forceinline__ float chain_softplus_m1(float x)
-{
-    const float y = __fsub_rn(x, 1.0f);                // raw2out_density: softplus(x - 1), beta = 1, threshold = 20 (:471-476)
-    return y > 20.f ? y : log1pf(expf(y));
-}
 
 // RT = 4: one 128-row workgroup per CU (one wave per SIMD, <= 512 registers).  RT = 2: two 64-row workgroups per CU (<= 256
 // registers each): they drift out of phase, so one's epilogue (VALU + LDS stores + barriers) runs under the other's MFMAs; the
@@ -956,7 +921,7 @@ extern "C" int hnr_chain_forward(const void *d_workspace, const float *d_point_t
     // variant that streams the weight image half as often is the default.
     static int rt_mode = 0, skew = 0;
     if (rt_mode == 0) {
-        const char *e = getenv("HNR_CHAIN_RT"); rt_mode = (e && atoi(e) == 2) ? 2 : (e && atoi(e) == 8) ? 8 : 4;   // 8: dual-group kernel (measured slower: 39.8 vs 33.3 ms, profiles/README.md)
+        const char *e = getenv("HNR_CHAIN_RT"); rt_mode = (e && atoi(e) == 2) ? 2 : (e && atoi(e) == 8) ? 8 : (e && atoi(e) == 4) ? 4 : 16;    // default: the weight-stationary pipelined kernel   // 8: dual-group kernel (measured slower: 39.8 vs 33.3 ms, profiles/README.md)
         const char *k = getenv("HNR_CHAIN_SKEW"); skew = k ? atoi(k) : 0;            // x 64 cycles (probe; measured: no effect)
     }
     a.skew = skew;
@@ -974,6 +939,10 @@ extern "C" int hnr_chain_forward(const void *d_workspace, const float *d_point_t
         HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chain_kernel<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, ch_lds_bytes(2)));
         HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chain_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, ch_lds_bytes(2)));
         attr_set = true;
+    }
+    if (rt_mode == 16) {                                                    // weight-stationary pipelined kernel (csrc/chain_ws.hip)
+        const int tiles = cdiv(cap_samples, 16), grid = tiles < n_cu ? tiles : n_cu;
+        return launch_chain_ws(a, grid, st, (d_dbg && dbg_layer <= -3 && dbg_layer >= -7) ? -dbg_layer : (d_dbg && dbg_layer < 0) ? 2 : d_dbg ? 1 : 0);
     }
     if (rt_mode == 8) {
         const int tiles = cdiv(cap_samples, 16), grid = tiles < n_cu ? tiles : n_cu;

@@ -1,0 +1,47 @@
+// Shared definitions of the fused per-neighbour chain kernels (csrc/chain.hip: one-group and dual-group kernels, packing, gather;
+// csrc/chain_ws.hip: the weight-stationary pipelined kernel).  Layouts are described in the header of chain.hip.
+#pragma once
+#include "hnr_h2.h"
+
+namespace hnr {
+
+// a GROUP = 32 rows = one MFMA row tile = 4 shading samples x 8 slots
+constexpr int CH_WSTEP = 16384;                    // weight image bytes per k step: [column tile 8][plane 2][64 lanes][16 B]
+constexpr int CH_S0 = 4, CH_S1 = 16, CH_S2 = 17, CH_S3 = 16;      // k steps of the four layers (K = 60, 256, 263, 256)
+constexpr int CH_W0 = 0, CH_W1 = CH_S0 * CH_WSTEP, CH_W2 = CH_W1 + CH_S1 * CH_WSTEP, CH_W3 = CH_W2 + CH_S2 * CH_WSTEP;
+constexpr int CH_WBYTES = CH_W3 + CH_S3 * CH_WSTEP;               // 53 k steps = 848 KiB
+constexpr int CH_META = CH_WBYTES;                 // floats after the image: bias[4][256], alpha_w[256], alpha_b, descale_w[4], max|W| bits[4], pad
+constexpr int CH_META_DESCALE = 4 * 256 + 256 + 1, CH_META_WMAX = CH_META_DESCALE + 4;
+constexpr int CH_META_FLOATS = CH_META_WMAX + 4 + 3;
+constexpr int CH_XP_GROUP = CH_S0 * 2048;          // bytes of one group's layer-0 operand image: [k step 4][plane 2][64 lanes][16 B] = 8 KiB
+constexpr int CH_AUX_GROUP = 32 * 4 + 32 * 4 + 32 * 8 * 4;        // pid[32] i32, wagg[32] f32, ext[32][8] f32 = 1280 B
+// workgroup tile = RT groups; LDS: 17 k-step slots of [row tile RT][plane 2][64 lanes][16 B], then the float[32 RT][4] exchange area
+constexpr int ch_slot(int RT) { return RT * 2048; }
+constexpr int ch_lds_exch(int RT) { return 17 * ch_slot(RT); }
+constexpr int ch_lds_bytes(int RT) { return ch_lds_exch(RT) + 32 * RT * 4 * 4; }
+
+struct ChainArgs {
+    const char *xp;                    // [groups][CH_XP_GROUP] layer-0 operand image (chain_gather_kernel)
+    const char *aux;                   // [groups][CH_AUX_GROUP]
+    const float *ptab; int ldt;        // per-point addend of block1.0: [N, ldt >= 256]
+    const char *wimg;                  // packed weights (hnr_chain_pack)
+    const unsigned long long *counts;  // device counters of the query (n_valid samples)
+    float *X5; int ld5;                // [S_v, ld5 >= 256]: weighted feature sums
+    float *sigma;                      // [S_v]
+    float slope;
+    int cap_samples;
+    float *dbg; int dbg_layer;         // probe: post-activation output of layer dbg_layer -> [rows, 256]
+    int skew;                          // RT = 2: the second half of the grid (the CUs' second workgroups) starts skew x 64 cycles late
+};
+
+__device__ __forceinline__ float chain_softplus_m1(float x)
+{
+    const float y = __fsub_rn(x, 1.0f);                // raw2out_density: softplus(x - 1), beta = 1, threshold = 20 (:471-476)
+    return y > 20.f ? y : log1pf(expf(y));
+}
+
+// csrc/chain_ws.hip: weight-stationary, software-pipelined form of the chain kernel.  mode 0: product, 1: layer dump (a.dbg, a.dbg_layer),
+// 2: phase timing.
+int launch_chain_ws(const ChainArgs &a, int grid, hipStream_t st, int mode);
+
+}  // namespace hnr
