@@ -405,8 +405,11 @@ def main():
                 issued = 3.0 * 2.0 * rows_pad * 256 * (64 + 256 + 272 + 256)
                 alg = 2.0 * n_rows * 256 * (60 + 256 + 263 + 256) + 2.0 * n_rows * 256          # executed layers + alpha branch (SURVEY 8d counts 284 columns
                 ach = issued / (ms_ch * 1e-3) / 1e12                                             # for block1.0: 224 of them live in the per-point table)
-                t_ch = [v for k, v in pmc.items() if "chain_kernel" in k]
-                roof = dict(kernel="chain_kernel<4,0>: block1 -> block3 -> alpha + K-sums fused (1 launch, %d valid neighbour rows in %d padded rows)" % (n_rows, rows_pad),
+                variant = os.environ.get("HNR_CHAIN_RT", "16")
+                kname = {"16": "chain_ws_kernel", "4": "chain_kernel<4", "2": "chain_kernel<2", "8": "chain2_kernel"}.get(variant, "chain_ws_kernel")
+                t_ch = [v for k, v in pmc.items() if kname in k]
+                roof = dict(kernel="%s: block1 -> block3 -> alpha + K-sums fused (1 launch, %d valid neighbour rows in %d padded rows)" % (
+                                {"chain_ws_kernel": "chain_ws_kernel<0> (weight-stationary, epilogue pieces between the wave's own MFMAs)"}.get(kname, kname), n_rows, rows_pad),
                             bound="mfma", achieved=round(ach, 1), peak=BF16_MFMA_PEAK_TF, unit="TFLOP/s", frac=round(ach / BF16_MFMA_PEAK_TF, 4),
                             frac_issued=round(ach / BF16_MFMA_PEAK_TF, 4),
                             frac_algorithmic=round(alg / (ms_ch * 1e-3) / 1e12 / BF16_MFMA_PEAK_TF, 4),

@@ -72,7 +72,6 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
     const float *meta = reinterpret_cast<const float *>(a.wimg + CH_META);
     const __amdgpu_buffer_rsrc_t wsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(a.wimg), 0, CH_WBYTES, 0x00020000);
     const int col0 = 64 * wave + 16 * h;
-    const f32x2 slope2 = {a.slope, a.slope};
     const unsigned woff = (unsigned)(2 * wave) * 2048u + (unsigned)lane * 16u;
     // LDS addressing: a handful of per-lane byte offsets; every access is `base register + immediate` (a ds offset field holds 16 bits, hence one
     // base per 64 KiB window).  CW_KEEP launders a base where it is used, so that the compiler folds the constant part into the instruction
@@ -410,19 +409,24 @@ int launch_chain_ws(const ChainArgs &a, int grid, hipStream_t st, int mode)
         HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chain_ws_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, cw_lds_bytes()));
         HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chain_ws_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, cw_lds_bytes()));
         HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chain_ws_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, cw_lds_bytes()));
+#ifdef HNR_CHAIN_WS_PROBES
         HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chain_ws_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, cw_lds_bytes()));
         HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chain_ws_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, cw_lds_bytes()));
         HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chain_ws_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, cw_lds_bytes()));
         HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chain_ws_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, cw_lds_bytes()));
         HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chain_ws_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, cw_lds_bytes()));
+#endif
         attr_set = true;
     }
-    if (mode == 5) chain_ws_kernel<5><<<grid, 256, cw_lds_bytes(), st>>>(a);
-    else if (mode == 6) chain_ws_kernel<6><<<grid, 256, cw_lds_bytes(), st>>>(a);
-    else if (mode == 7) chain_ws_kernel<7><<<grid, 256, cw_lds_bytes(), st>>>(a);
-    else if (mode == 3) chain_ws_kernel<3><<<grid, 256, cw_lds_bytes(), st>>>(a);       // probes: no epilogue / no MFMAs (timing only)
-    else if (mode == 4) chain_ws_kernel<4><<<grid, 256, cw_lds_bytes(), st>>>(a);
-    else if (mode == 2) chain_ws_kernel<2><<<grid, 256, cw_lds_bytes(), st>>>(a);
+#ifdef HNR_CHAIN_WS_PROBES                                                       // timing probes (results are garbage): make EXTRA=-DHNR_CHAIN_WS_PROBES
+    if (mode == 5) chain_ws_kernel<5><<<grid, 256, cw_lds_bytes(), st>>>(a);           // epilogue without its LDS reads
+    else if (mode == 6) chain_ws_kernel<6><<<grid, 256, cw_lds_bytes(), st>>>(a);      // epilogue without its LDS writes
+    else if (mode == 7) chain_ws_kernel<7><<<grid, 256, cw_lds_bytes(), st>>>(a);      // neither
+    else if (mode == 3) chain_ws_kernel<3><<<grid, 256, cw_lds_bytes(), st>>>(a);      // no epilogue
+    else if (mode == 4) chain_ws_kernel<4><<<grid, 256, cw_lds_bytes(), st>>>(a);      // no MFMAs
+    else
+#endif
+    if (mode == 2) chain_ws_kernel<2><<<grid, 256, cw_lds_bytes(), st>>>(a);
     else if (mode == 1) chain_ws_kernel<1><<<grid, 256, cw_lds_bytes(), st>>>(a);
     else chain_ws_kernel<0><<<grid, 256, cw_lds_bytes(), st>>>(a);
     HNR_LAUNCH_CHECK();
