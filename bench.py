@@ -469,6 +469,29 @@ def main():
                               algorithmic_bytes=int(alg), avg_launch_ms=round(ms_q, 4),
                               per_ray=dict(samples=round(s_all / R, 2), cells_per_sample=round(cells / max(s_all, 1), 2),
                                            candidates_per_sample=round(cand / max(s_all, 1), 2)))
+            # the query with hnr_query_params.knn_order = 1 (same neighbour sets, ascending-distance order; HybridRenderer.knn_order =
+            # "sorted"), timed beside the timed region on the same frame: an OPTION, not what `value` was measured with
+            if roof_q is not None and opt.K == 8:
+                from hybridneuralrendering_amd import querier as Qm
+                grid_q, hp_q = rnd.querier._grid_for(cloud.xyz[None])
+                tm_q = rnd.querier._tmid_for(float(sc.near), float(sc.far), opt.z_depth_dim, cam["raydir"].shape[0], dev)
+                r2_q = np.float32(hp_q[0] ** 2)
+                if grid_q is not None and r2_q is not None:
+                    ms_o = {}
+                    for order in (0, 1):
+                        for _ in range(2):
+                            Qm.march_query(grid_q, cam["campos"], cam["raydir"], tm_q, opt.SR, opt.K, r2_q, opt.kernel_size, pad=False, knn_order=order)
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        for _ in range(5):
+                            Qm.march_query(grid_q, cam["campos"], cam["raydir"], tm_q, opt.SR, opt.K, r2_q, opt.kernel_size, pad=False, knn_order=order)
+                        e1.record(); torch.cuda.synchronize()
+                        ms_o[order] = e0.elapsed_time(e1) / 5
+                    roof_q["sorted_neighbour_order"] = dict(avg_launch_ms=round(ms_o[1], 4), reference_order_ms_same_loop=round(ms_o[0], 4),
+                                                            achieved=round(alg / (ms_o[1] * 1e-3) / 1e9, 1), frac=round(alg / (ms_o[1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                                            note="hnr_query_params.knn_order = 1: sorted insertion (v_med3 network) instead of the replay of the reference's "
+                                                                 "farthest-first replacement; same sets, canonical order; VALU wave-instructions per launch of the k-NN kernel "
+                                                                 "in profiles/README.md")
         # one-off work that is amortised over frames (rebuilt only when the cloud / the weights change), timed once here
         amort = {}
         def _timed(fn):

@@ -32,7 +32,7 @@ class GridStats(ctypes.Structure):
 class QueryParams(ctypes.Structure):
     _fields_ = [("R", ctypes.c_int), ("D", ctypes.c_int), ("SR", ctypes.c_int), ("K", ctypes.c_int),
                 ("kernel_size", ctypes.c_int * 3), ("radius2", ctypes.c_float), ("tmid_stride", ctypes.c_int),
-                ("pad_outputs", ctypes.c_int)]
+                ("pad_outputs", ctypes.c_int), ("knn_order", ctypes.c_int)]
 
 
 _P = ctypes.c_void_p
@@ -42,7 +42,7 @@ _F = ctypes.c_float
 
 class RenderParams(ctypes.Structure):
     _fields_ = [("R", _I), ("SR", _I), ("K", _I), ("D", _I), ("tmid_stride", _I), ("kernel_size", _I * 3), ("radius2", _F), ("vsize_z", _F),
-                ("raydist_mode_unit", _I), ("V", _I), ("cap_samples", _I)]
+                ("raydist_mode_unit", _I), ("V", _I), ("cap_samples", _I), ("knn_order", _I)]
 
 
 class RenderCloud(ctypes.Structure):

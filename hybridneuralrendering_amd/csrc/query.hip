@@ -12,6 +12,8 @@
 // and first-max scan), so sample_pidx matches slot for slot.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "hnr_common.h"
 
 namespace hnr {
@@ -389,13 +391,47 @@ __global__ __launch_bounds__(256) void knn2_kernel(GridView g, const int32_t *__
 // load per loop trip (rocprofv3: ~1 us per trip and wave slot = one exposed L2/HBM round trip, 0.9 ms per frame):
 //  pass 1: per x-plane, 9 brick records in flight, then the 9 {start,count} records of the occupied cells in flight; each
 //          cell's list is parked in LDS as one word (start << 6 | count; P <= 63, N < 2^26 checked by the launcher);
+// Set-exact mode (hnr_query_params.knn_order = 1): the same neighbour SET as the rule above -- the K smallest candidates by (d^2, enumeration
+// order), because a later candidate replaces the farthest entry only if it is STRICTLY closer -- kept as a sorted list, so the output
+// is in the canonical order ascending (d^2, enumeration order) instead of the reference's insertion-history order (the
+// consumers are order-free: every use is a sum over the K slots).  Sorted insertion of v into d[0] <= ... <= d[K-1]:
+//   d'[i] = median(d[i-1], d[i], v) = v_med3_f32 (one instruction per slot),   id'[i] = v < d[i-1] ? id[i-1] : v < d[i] ? p : id[i]
+// = 4 VALU per slot and no re-scan for the farthest entry, against ~9 per slot for the slot-exact rule.
+template <int K>
+struct KSorted {
+    float d2[K];
+    int id[K];
+    int kid;
+    __device__ __forceinline__ void init()
+    {
+#pragma unroll
+        for (int i = 0; i < K; ++i) { d2[i] = __int_as_float(0x7f800000); id[i] = -1; }
+        kid = 0;
+    }
+    __device__ __forceinline__ void offer_sel(float v, int p, bool ok)
+    {
+        const float vv = ok ? v : __int_as_float(0x7f800000);       // a rejected candidate is +inf: it is never < an entry
+        bool c[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) c[i] = vv < d2[i];              // on the OLD list; monotone in i
+#pragma unroll
+        for (int i = K - 1; i >= 1; --i) {
+            id[i] = c[i - 1] ? id[i - 1] : (c[i] ? p : id[i]);
+            d2[i] = __builtin_amdgcn_fmed3f(d2[i - 1], d2[i], vv);
+        }
+        id[0] = c[0] ? p : id[0];
+        d2[0] = fminf(d2[0], vv);
+        kid += ok ? 1 : 0;
+    }
+};
+
 //  pass 2: per shell, an address generator walks the occupied cells and a 4-deep register ring keeps four candidate
 //          loads in flight ahead of the insertion; stepping to the next cell costs no loop trip; the insertion is select-only.
 // After this the kernel is VALU-bound on the insertion rule (rocprofv3 --pmc: 303 M VALU wave-instructions per frame = 0.56 ms of
 // issue time on 1024 SIMDs, SQ_WAIT_INST_ANY 17 % of the wave cycles).  Measured and dropped on top of it (profiles/README.md):
 // re-dealing a block's samples to lanes by candidate count + one stream over both shells (lane slots 215 M -> 132 M, same
 // time: the extra bookkeeping costs what the idle lanes did); 4-record chunks per trip (1.2x slower: more slots, more loads).
-template <int K>
+template <int K, int SORTED = 0>
 __global__ __launch_bounds__(256) void knn3_kernel(GridView g, const int32_t *__restrict__ work, const float *__restrict__ loc,
                                                    int SR, float radius2, int layers, int32_t *__restrict__ pidx,
                                                    int8_t *__restrict__ ray_mask, const unsigned long long *__restrict__ counts,
@@ -440,7 +476,7 @@ __global__ __launch_bounds__(256) void knn3_kernel(GridView g, const int32_t *__
             occ |= ob << (xp * 9);
             occ_nz |= onz << (xp * 9);
         }
-        KBuf<K> kb;
+        typename std::conditional<SORTED != 0, KSorted<K>, KBuf<K>>::type kb;
         kb.init();
         auto run_shell = [&](uint32_t mg) {
             int st = 0, cn = 0, jg = 0;
@@ -655,7 +691,7 @@ extern "C" int hnr_march_query(const hnr_grid *g, const float *d_campos, const f
         set_error("hnr_march_query: NULL argument"); return HNR_ERR_BADARG;
     }
     if (q->R < 0 || q->D <= 0 || q->SR <= 0 || q->K <= 0 || q->K > HNR_MAX_K ||
-        (q->tmid_stride != 0 && q->tmid_stride != q->D) || q->kernel_size[0] <= 0) {
+        (q->tmid_stride != 0 && q->tmid_stride != q->D) || q->kernel_size[0] <= 0 || (q->knn_order != 0 && q->knn_order != 1)) {
         set_error("hnr_march_query: bad sizes (R=%d D=%d SR=%d K=%d tmid_stride=%d)", q->R, q->D, q->SR, q->K, q->tmid_stride);
         return HNR_ERR_BADARG;
     }
@@ -682,13 +718,23 @@ extern "C" int hnr_march_query(const hnr_grid *g, const float *d_campos, const f
     // K = 8 with a 3x3x3 neighbourhood (every shipped config): the pipelined kernel (HNR_KNN=2 / =1 select the older ones)
     static int knn_sel = -1;
     if (knn_sel < 0) { const char *e = getenv("HNR_KNN"); knn_sel = e ? atoi(e) : 3; }
-    if (q->K == 8 && layers <= 2 && knn_sel != 1) {
+    if (q->knn_order == 1 && !(q->K == 8 && layers <= 2)) {
+        set_error("hnr_march_query: knn_order = 1 (canonical neighbour order) is built for K = 8 with a 3x3x3 neighbourhood (K=%d)", q->K);
+        return HNR_ERR_BADARG;
+    }
+    if (q->K == 8 && layers <= 2 && (knn_sel != 1 || q->knn_order == 1)) {
         const int blocks = knn_blocks(max_items);
         hnr_grid_params gp;
         hnr_grid_stats gs;
         hnr_grid_get_params(g, &gp);
         hnr_grid_get_stats(g, &gs);
-        if (knn_sel == 3 && gp.P <= 63 && gs.n_points < (1ll << 26))
+        if (q->knn_order == 1 && !(gp.P <= 63 && gs.n_points < (1ll << 26))) {
+            set_error("hnr_march_query: knn_order = 1 needs P <= 63 and < 2^26 points (P=%d)", gp.P);
+            return HNR_ERR_BADARG;
+        }
+        if (q->knn_order == 1)
+            knn3_kernel<8, 1><<<blocks, 256, 0, st>>>(v, d_work, d_sample_loc_w, q->SR, q->radius2, layers, d_sample_pidx, d_ray_mask, cnt, block_stats);
+        else if (knn_sel == 3 && gp.P <= 63 && gs.n_points < (1ll << 26))
             knn3_kernel<8><<<blocks, 256, 0, st>>>(v, d_work, d_sample_loc_w, q->SR, q->radius2, layers, d_sample_pidx, d_ray_mask, cnt, block_stats);
         else
             knn2_kernel<8><<<blocks, 256, 0, st>>>(v, d_work, d_sample_loc_w, q->SR, q->radius2, layers, d_sample_pidx, d_ray_mask, cnt, block_stats);

@@ -95,7 +95,7 @@ extern "C" int hnr_render_forward(const hnr_grid *grid, const hnr_render_params 
     HNR_MARK();
     // ---- query (march + first-SR compaction + k-NN), un-padded outputs
     hnr_query_params q;
-    q.R = R; q.D = p->D; q.SR = SR; q.K = K; q.radius2 = p->radius2; q.tmid_stride = p->tmid_stride; q.pad_outputs = 0;
+    q.R = R; q.D = p->D; q.SR = SR; q.K = K; q.radius2 = p->radius2; q.tmid_stride = p->tmid_stride; q.pad_outputs = 0; q.knn_order = p->knn_order;
     for (int i = 0; i < 3; ++i) q.kernel_size[i] = p->kernel_size[i];
     if ((rc = hnr_march_query(grid, cam->d_campos, cam->d_raydir, cam->d_tmid, &q, o->d_sample_pidx, o->d_sample_loc_w, o->d_ray_nsamp, o->d_ray_mask,
                               L.work, o->d_counts, stream)) != HNR_OK) return rc;

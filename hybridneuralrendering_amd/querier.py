@@ -131,10 +131,10 @@ def points_bounds(xyz):
     return o[:3].copy(), o[3:].copy()
 
 
-def march_query(grid, campos, raydir, tmid, SR, K, radius2, kernel_size, pad=True):
+def march_query(grid, campos, raydir, tmid, SR, K, radius2, kernel_size, pad=True, knn_order=0):
     """hnr_march_query on R rays.  Un-compacted outputs (row r = input ray r), no host sync:
     dict(sample_pidx [R,SR,K] i32, sample_loc_w [R,SR,3] f32, ray_nsamp [R] i32, ray_mask [R] i8,
-    counts [8] i64 (device))."""
+    counts [8] i64 (device)).  knn_order = 1: the neighbour SET of the reference rule in canonical order (ascending distance), K = 8 only."""
     L = _lib.lib()
     campos = _lib.require_gpu(campos, "campos", torch.float32).reshape(3)
     raydir = _lib.require_gpu(raydir, "raydir", torch.float32).reshape(-1, 3)
@@ -153,6 +153,7 @@ def march_query(grid, campos, raydir, tmid, SR, K, radius2, kernel_size, pad=Tru
         q.kernel_size[a] = int(kernel_size[a])
     q.radius2 = float(radius2)
     q.pad_outputs = 1 if pad else 0
+    q.knn_order = int(knn_order)
     pidx = torch.empty((R, SR, K), dtype=torch.int32, device=dev)
     loc = torch.empty((R, SR, 3), dtype=torch.float32, device=dev)
     nsamp = torch.empty((R,), dtype=torch.int32, device=dev)

@@ -80,6 +80,11 @@ class HybridRenderer:
         # the whole frame as ONE library call (hnr_render_forward: no host read between query and composite); HNR_SINGLE_CALL=0 runs the
         # same kernels stage by stage from Python with exactly sized buffers (one host read of the counters)
         self.single_call = os.environ.get("HNR_SINGLE_CALL", "1") != "0"
+        # neighbour order inside a sample's K slots: "reference" = exactly the reference kernel's (insertion history), "sorted" = the same
+        # neighbour SET in ascending-distance order (hnr_query_params.knn_order = 1: cheaper insertion; colours agree to fp32 summation order)
+        self.knn_order = os.environ.get("HNR_KNN_ORDER", "reference")
+        if self.knn_order not in ("reference", "sorted"):
+            raise HnrError("HNR_KNN_ORDER must be 'reference' or 'sorted' (got %r)" % (self.knn_order,))
         self.fuse_merge = True            # V = 4: hnr_merge_stage instead of hnr_proj_rows + the merge-weight MLP + hnr_merge (staged path switch)
         self.last_counts = None
         if getattr(opt, "which_render_func", "radiance") != "radiance" or getattr(opt, "which_blend_func", "alpha") != "alpha" \
@@ -316,6 +321,7 @@ class HybridRenderer:
         prm.raydist_mode_unit, prm.V = int(getattr(opt, "raydist_mode_unit", 0) > 0), V
         cap = R * SR
         prm.cap_samples = cap
+        prm.knn_order = 1 if self.knn_order == "sorted" else 0
         nbytes = int(L.hnr_render_workspace_bytes(ctypes.byref(prm)))
         free, _total = torch.cuda.mem_get_info(dev)
         cached = torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
@@ -395,7 +401,8 @@ class HybridRenderer:
                 return res
         with _Stage(timers, "query"):
             # pad=False: only kept slots are written (no -1 / 0 padding stores); everything downstream takes ray_nsamp
-            qres = Q.march_query(grid, campos, raydir, tmid, self.opt.SR, self.opt.K, np.float32(hp[0] ** 2), self.opt.kernel_size, pad=pad)
+            qres = Q.march_query(grid, campos, raydir, tmid, self.opt.SR, self.opt.K, np.float32(hp[0] ** 2), self.opt.kernel_size, pad=pad,
+                                 knn_order=1 if (self.knn_order == "sorted" and self.opt.K == 8) else 0)
         with _Stage(timers, "featmap"):
             fm = None if getattr(self.opt, "use_nearest", 4) == 0 else self.feature_map(images_nearest)
         a = self.aggregate(cloud, qres, raydir, campos, camrot, w2c_nearest, intrinsic_nearest, campos_nearest, fm,

@@ -104,6 +104,11 @@ typedef struct {
                              (the reference's torch.full / torch.zeros tensors, :647-648);
                              0: only the first d_ray_nsamp[r] slots of a ray are written (fused path: consumers
                              take d_ray_nsamp; saves 1 kB of padding stores per ray)                */
+    int   knn_order;      /* 0: the K slots of a sample are filled exactly as the reference kernel fills them (insertion
+                             history, farthest-first replacement: query_point_indices_worldcoords.py:494-513);
+                             1: the same neighbour SET in canonical order, ascending (d^2, enumeration order) -- a sorted
+                             insertion instead of the replay of that rule (K = 8, 3x3x3 neighbourhood); every consumer of
+                             the path sums over the K slots, so only the fp32 summation order of a sample changes       */
 } hnr_query_params;
 
 /* counters written by hnr_march_query (device, int64[HNR_NCOUNTS]) */
@@ -493,6 +498,7 @@ typedef struct {
     int   raydist_mode_unit;
     int   V;                      /* reference views (0: use_nearest = 0, image branch off)                            */
     int   cap_samples;            /* capacity of the workspace in valid shading samples                                */
+    int   knn_order;              /* hnr_query_params.knn_order                                                        */
 } hnr_render_params;
 typedef struct {
     const float *d_xyz, *d_conf, *d_dir, *d_color;      /* [N,3] [N] [N,3] [N,3]                                       */

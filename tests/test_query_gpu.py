@@ -213,3 +213,42 @@ def test_mid_size_scene():
     og, ref, g, res = _run_both(cs)
     _assert_query_equal(ref, res, cs)
     assert ref["counts"]["n_samples"] > 50000
+
+
+@pytest.mark.parametrize("seed,n,P,R", [(0, 8000, 4, 400), (1, 60000, 26, 1500), (5, 60000, 12, 1500)])
+def test_sorted_neighbour_order_is_the_reference_set_in_ascending_distance(seed, n, P, R):
+    """hnr_query_params.knn_order = 1 (the production option for order-free consumers): per kept sample the same neighbour SET as the
+    reference's insertion rule (/root/reference/models/neural_points/query_point_indices_worldcoords.py:494-513, checked against the C
+    oracle), listed by ascending d^2 -- valid ids first, -1 after them -- and every other output of the query unchanged."""
+    from hybridneuralrendering_amd import querier as Q
+    cs = _case(seed, n, P, 100000, 8, 12, R)
+    og, ref, g, res = _run_both(cs)
+    d = _dev()
+    srt = Q.march_query(g, torch.from_numpy(cs["campos"]).to(d), torch.from_numpy(cs["rays"]).to(d), torch.from_numpy(np.ascontiguousarray(cs["tmid"])).to(d),
+                        cs["SR"], cs["K"], cs["hp"]["radius2"], [3, 3, 3], knn_order=1)
+    for k in ("ray_nsamp", "sample_loc_w", "ray_mask", "counts"):
+        assert torch.equal(srt[k], res[k]), k
+    a, b = srt["sample_pidx"].cpu().numpy().reshape(-1, 8), ref["full_pidx"].reshape(-1, 8)
+    loc = ref["full_loc"].reshape(-1, 3)
+    np.testing.assert_array_equal(np.sort(a, axis=1), np.sort(b, axis=1))                 # the same set, slot by slot after sorting
+    full = int((np.sort(b, axis=1)[:, 0] >= 0).sum())
+    assert full > 100 and (b >= 0).any(axis=1).sum() > full                                # both full and partly filled samples occur
+    valid = a >= 0
+    assert (valid[:, :-1] >= valid[:, 1:]).all()                                          # valid ids are a prefix
+    x = cs["xyz"][np.maximum(a, 0)]                                                        # [S, 8, 3]
+    dv = x - loc[:, None, :]
+    d2 = (dv[..., 0] * dv[..., 0] + dv[..., 1] * dv[..., 1]) + dv[..., 2] * dv[..., 2]     # float32, the kernel's operation order
+    d2 = np.where(valid, d2, np.float32(np.inf))
+    assert (d2[:, :-1] <= d2[:, 1:]).all()
+    assert (a != b).any()                                                                  # and it is not the reference's slot order
+
+
+def test_sorted_neighbour_order_bad_arguments():
+    from hybridneuralrendering_amd import querier as Q
+    from hybridneuralrendering_amd._lib import HnrError
+    cs = _case(0, 4000, 4, 100000, 4, 6, 64)
+    og, ref, g, res = _run_both(cs)
+    d = _dev()
+    with pytest.raises(HnrError, match="knn_order"):
+        Q.march_query(g, torch.from_numpy(cs["campos"]).to(d), torch.from_numpy(cs["rays"]).to(d), torch.from_numpy(np.ascontiguousarray(cs["tmid"])).to(d),
+                      cs["SR"], 4, cs["hp"]["radius2"], [3, 3, 3], knn_order=1)
