@@ -39,9 +39,20 @@ struct MlpArgs {
     float *C; int ldc;                 // [M, ldc] output rows (N[2] columns)
 };
 
-template <int S0, int S1, int S2, int S3, int MODE>
-__global__ __launch_bounds__(256, MODE == 1 ? 2 : 1) void mlp3_kernel(MlpArgs a)
+#ifdef HNR_MLP_PROBE
+__device__ long long g_mlp_probe[16];
+#define MLP_STAMP(i_) do { const long long t_ = clock64(); tm_[i_] += t_ - tp_; tp_ = t_; if ((i_) == 0) ++ntile_; } while (0)
+#else
+#define MLP_STAMP(i_) do { } while (0)
+#endif
+// RT = row tiles of 32 rows per workgroup tile.  RT = 4 (128 rows): one workgroup per CU when layer 0 is wide (280 inputs = 144 KiB of operand
+// planes); RT = 2 (64 rows): two workgroups per CU, so that one's prologue (row loads, scaling, fp16 split: latency and VALU) runs under the
+// other's MFMAs -- the phases of a single workgroup are serial.
+template <int S0, int S1, int S2, int S3, int MODE, int RT = 4>
+__global__ __launch_bounds__(256, (MODE == 1 || RT < 4) ? 2 : 1) void mlp3_kernel(MlpArgs a)
 {
+    static_assert(MODE != 1 || RT == 4, "the merge stage is built on 128-row tiles (32 samples x 4 views)");
+    constexpr int SLOT = RT * 2048, ROWS = 32 * RT;                        // LDS bytes per k step of the planes: [row tile RT][plane 2][64 lanes][16 B]
     constexpr int SMAX3 = S0 > S1 ? (S0 > S2 ? S0 : S2) : (S1 > S2 ? S1 : S2), SMAX = SMAX3 > S3 ? SMAX3 : S3;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, j = lane & 31;
@@ -62,23 +73,27 @@ __global__ __launch_bounds__(256, MODE == 1 ? 2 : 1) void mlp3_kernel(MlpArgs a)
         for (int v = 1; v < a.count_mult && v < 8; ++v) q += (m >= (long long)v * n_unit) ? 1 : 0;
         return (long long)q * a.seg_stride + (m - (long long)q * n_unit);
     };
-    const int n_tiles = (int)((M + 127) / 128);
+    const int n_tiles = (int)((M + ROWS - 1) / ROWS);
     const int total_steps = S0 + S1 + S2 + S3;
     const float *meta = reinterpret_cast<const float *>(a.wimg + (size_t)total_steps * ML_WSTEP);
     const __amdgpu_buffer_rsrc_t wsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(a.wimg), 0, total_steps * ML_WSTEP, 0x00020000);
-    float *exch = reinterpret_cast<float *>(lds + SMAX * ML_SLOT);         // [row 128][wave 4]
-    float *rowinv = exch + 128 * 4;                                        // [row 128]: 2^-k of the input row's scale
+    float *exch = reinterpret_cast<float *>(lds + SMAX * SLOT);            // [row ROWS][wave 4]
+    float *rowinv = exch + ROWS * 4;                                       // [row ROWS]: 2^-k of the input row's scale
     // MODE 1 extras: fp32 rows [128][48] = [imgfeat45 | ddir3] of the tile's (sample, view) rows, per-row pixel offset / validity / merge weight
-    float *s_f = rowinv + 128;
+    float *s_f = rowinv + ROWS;
     int *s_pix = reinterpret_cast<int *>(s_f + 128 * 48);
     float *s_vm = reinterpret_cast<float *>(s_pix + 128), *s_w = s_vm + 128;
     const int col0 = 32 * wave + 16 * h;                                   // this lane's columns: col0 + r
     const unsigned woff = (unsigned)wave * 2048u + (unsigned)lane * 16u;
     const f32x2 slope2 = {a.slope, a.slope};
 
+#ifdef HNR_MLP_PROBE
+    long long tm_[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tp_ = clock64(), ntile_ = 0;
+#endif
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const long long row_base = (long long)tile * 128;
-        float inv[4];
+        const long long row_base = (long long)tile * ROWS;
+        MLP_STAMP(0);
+        float inv[RT];
         if (MODE == 1) {
             // ---- merge-stage prologue.  Row t of the tile = (sample ls = t >> 2, view v = t & 3): a sample's four views sit in adjacent rows.
             // (a) reprojection into the view (w2iproject, neural_points_volumetric_model.py:248-255), truncation to a pixel + bounds rule
@@ -140,64 +155,93 @@ __global__ __launch_bounds__(256, MODE == 1 ? 2 : 1) void mlp3_kernel(MlpArgs a)
                     unsigned ph[4], pm[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) split2h(__fmul_rn(x[s][2 * q], sc), __fmul_rn(x[s][2 * q + 1], sc), ph[q], pm[q]);
-                    char *dst = lds + s * ML_SLOT + (wave * 2) * 1024 + lane * 16;
+                    char *dst = lds + s * SLOT + (wave * 2) * 1024 + lane * 16;
                     *reinterpret_cast<u32x4 *>(dst) = u32x4{ph[0], ph[1], ph[2], ph[3]};
                     *reinterpret_cast<u32x4 *>(dst + 1024) = u32x4{pm[0], pm[1], pm[2], pm[3]};
                 }
             }
         } else
-        // ---- prologue: wave w loads rows 32 w + j (lane half hh takes k = 16 s + 8 hh .. + 7 of every k step), scales each row by
-        // a power of two from its own maximum, splits and writes the layer-0 operand planes
+        // ---- prologue: wave w converts rows 8 RT w .. 8 RT (w + 1) - 1.  LPR lanes share a row and read it as ONE contiguous burst (16 B per lane; a
+        // second burst for columns >= 4 LPR): a lane-per-row layout touched 32 cache lines with every load instruction and ran at 5 B/clk.
+        // Row maximum by a butterfly over the LPR lanes, power-of-two scale, fp16 split, and each lane drops its 4 columns (8 B per plane)
+        // into the fragment slot (k step = col >> 4, lane half = (col >> 3) & 1, element = col & 7) of the layer-0 operand planes.
         {
-            long long row = row_base + 32 * wave + j;
-            if (row >= M) row = M - 1;
-            row = phys(row);
-            const float *src = a.A + (size_t)row * a.lda + 8 * h;
-            float x[S0][8];
-            float m = 0.f;
+            constexpr int COLS = 16 * S0, LPR = COLS > 128 ? 64 : (COLS > 64 ? 32 : 16), RPI = 64 / LPR, NB = (COLS + 4 * LPR - 1) / (4 * LPR);
+            const int lr = lane % LPR, sub = lane / LPR;                   // lane within the row, row within the instruction
+            constexpr int RW = 8 * RT;                                     // rows of this wave
+            constexpr int ROWS_B = (NB * RW * 4 <= (RT < 4 ? 128 : 256)) ? RW : RW / 2;       // rows in flight per batch
+            constexpr int BATCH = ROWS_B / RPI;
+#pragma unroll 1
+            for (int r0 = 0; r0 < RW; r0 += ROWS_B) {
+                float4 v[BATCH][NB];
 #pragma unroll
-            for (int s = 0; s < S0; ++s) {
-                const int k0 = 16 * s + 8 * h;
-                float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
-                if (k0 + 4 <= a.lda) v0 = *reinterpret_cast<const float4 *>(src + 16 * s);
-                if (k0 + 8 <= a.lda) v1 = *reinterpret_cast<const float4 *>(src + 16 * s + 4);
-                const float t[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                for (int b = 0; b < BATCH; ++b) {
+                    const int rl = RW * wave + r0 + b * RPI + sub;         // row of the tile
+                    long long row = row_base + rl;
+                    if (row >= M) row = M - 1;
+                    const float *src = a.A + (size_t)phys(row) * a.lda;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    x[s][e] = (k0 + e < a.K0) ? t[e] : 0.f;
-                    m = fmaxf(m, fabsf(x[s][e]));
+                    for (int nb = 0; nb < NB; ++nb) {
+                        const int c = 4 * (nb * LPR + lr);
+                        v[b][nb] = *reinterpret_cast<const float4 *>(src + (c + 4 <= a.lda ? c : 0));      // past the row's end: re-read its start (masked below)
+                    }
+                }
+#pragma unroll
+                for (int b = 0; b < BATCH; ++b) {
+                    const int rl = RW * wave + r0 + b * RPI + sub;
+                    float m = 0.f;
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        const int c = 4 * (nb * LPR + lr);
+                        float *t = reinterpret_cast<float *>(&v[b][nb]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { t[e] = (c + e < a.K0) ? t[e] : 0.f; m = fmaxf(m, fabsf(t[e])); }
+                    }
+                    // maximum over the row's LPR lanes by DPP (no LDS round trips): quads, half rows, rows of 16, then row broadcasts
+                    m = fmaxf(m, __builtin_amdgcn_update_dpp(m, m, 0xB1, 0xf, 0xf, false));      // quad_perm [1,0,3,2]
+                    m = fmaxf(m, __builtin_amdgcn_update_dpp(m, m, 0x4E, 0xf, 0xf, false));      // quad_perm [2,3,0,1]
+                    m = fmaxf(m, __builtin_amdgcn_update_dpp(m, m, 0x141, 0xf, 0xf, false));     // row_half_mirror
+                    m = fmaxf(m, __builtin_amdgcn_update_dpp(m, m, 0x140, 0xf, 0xf, false));     // row_mirror: every lane of a 16-lane row holds its maximum
+                    if (LPR >= 32) m = fmaxf(m, __builtin_amdgcn_update_dpp(m, m, 0x142, 0xa, 0xf, false));     // row_bcast15 -> rows 1, 3
+                    if (LPR >= 64) m = fmaxf(m, __builtin_amdgcn_update_dpp(m, m, 0x143, 0xc, 0xf, false));     // row_bcast31 -> rows 2, 3
+                    if (LPR == 64) m = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 63));
+                    else if (LPR == 32) { const float m0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 31)), m1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 63)); m = sub ? m1 : m0; }
+                    const int k = row_scale_exp(m);
+                    const float sc = pow2f(k);
+                    if (lr == 0) rowinv[rl] = pow2f(-k);
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        const int c = 4 * (nb * LPR + lr);
+                        if (c < COLS) {
+                            unsigned ph0, pm0, ph1, pm1;
+                            split2h(__fmul_rn(v[b][nb].x, sc), __fmul_rn(v[b][nb].y, sc), ph0, pm0);
+                            split2h(__fmul_rn(v[b][nb].z, sc), __fmul_rn(v[b][nb].w, sc), ph1, pm1);
+                            char *dst = lds + (c >> 4) * SLOT + ((rl >> 5) * 2) * 1024 + ((((c >> 3) & 1) * 32 + (rl & 31)) * 16) + (c & 7) * 2;
+                            *reinterpret_cast<uint2 *>(dst) = make_uint2(ph0, ph1);
+                            *reinterpret_cast<uint2 *>(dst + 1024) = make_uint2(pm0, pm1);
+                        }
+                    }
                 }
             }
-            m = fmaxf(m, __shfl_xor(m, 32));
-            const int k = row_scale_exp(m);
-            const float sc = pow2f(k);
-            if (h == 0) rowinv[32 * wave + j] = pow2f(-k);
-#pragma unroll
-            for (int s = 0; s < S0; ++s) {
-                unsigned ph[4], pm[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) split2h(__fmul_rn(x[s][2 * q], sc), __fmul_rn(x[s][2 * q + 1], sc), ph[q], pm[q]);
-                char *dst = lds + s * ML_SLOT + (wave * 2) * 1024 + lane * 16;
-                *reinterpret_cast<u32x4 *>(dst) = u32x4{ph[0], ph[1], ph[2], ph[3]};
-                *reinterpret_cast<u32x4 *>(dst + 1024) = u32x4{pm[0], pm[1], pm[2], pm[3]};
-            }
         }
+        MLP_STAMP(1);
         __syncthreads();
+        MLP_STAMP(2);
         {
             const float dw0 = meta[ML_DESC + 0];
 #pragma unroll
-            for (int rt = 0; rt < 4; ++rt) inv[rt] = __fmul_rn(rowinv[32 * rt + j], dw0);
+            for (int rt = 0; rt < RT; ++rt) inv[rt] = __fmul_rn(rowinv[32 * rt + j], dw0);
         }
 
-        f32x16 acc[4][1];
+        f32x16 acc[RT][1];
         auto zero_acc = [&]() {
 #pragma unroll
-            for (int rt = 0; rt < 4; ++rt)
+            for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[rt][0][r] = 0.f;
         };
         // v = acc * inv + bias (+ addend) (+ LeakyReLU); returns the per-row maxima of this wave's columns
-        auto activate = [&](int layer, float (&amax)[4], auto with_addend) {
+        auto activate = [&](int layer, float (&amax)[RT], auto with_addend) {
             constexpr bool ADD = decltype(with_addend)::value;
             f32x2 bias[8];
 #pragma unroll
@@ -207,7 +251,7 @@ __global__ __launch_bounds__(256, MODE == 1 ? 2 : 1) void mlp3_kernel(MlpArgs a)
             }
             const bool act = a.act[layer] != 0;
 #pragma unroll
-            for (int rt = 0; rt < 4; ++rt) {
+            for (int rt = 0; rt < RT; ++rt) {
                 float m = 0.f;
                 const f32x2 inv2 = {inv[rt], inv[rt]};
                 const float *rrow = nullptr;
@@ -228,16 +272,16 @@ __global__ __launch_bounds__(256, MODE == 1 ? 2 : 1) void mlp3_kernel(MlpArgs a)
                 amax[rt] = m;
             }
         };
-        auto publish = [&](int next_layer, bool active, float (&amax)[4]) {
+        auto publish = [&](int next_layer, bool active, float (&amax)[RT]) {
 #pragma unroll
-            for (int rt = 0; rt < 4; ++rt) {
+            for (int rt = 0; rt < RT; ++rt) {
                 const float m = active ? fmaxf(amax[rt], __shfl_xor(amax[rt], 32)) : 0.f;
                 if (h == 0) exch[(32 * rt + j) * 4 + wave] = m;
             }
             __syncthreads();                                               // every wave has finished reading the previous planes
             const float dw = meta[ML_DESC + next_layer];
 #pragma unroll
-            for (int rt = 0; rt < 4; ++rt) {
+            for (int rt = 0; rt < RT; ++rt) {
                 const float4 m4 = *reinterpret_cast<const float4 *>(exch + (32 * rt + j) * 4);
                 const int k = row_scale_exp(fmaxf(fmaxf(m4.x, m4.y), fmaxf(m4.z, m4.w)));
                 const float sc = pow2f(k);
@@ -250,7 +294,7 @@ __global__ __launch_bounds__(256, MODE == 1 ? 2 : 1) void mlp3_kernel(MlpArgs a)
                         const f32x2 vs = f32x2{acc[rt][0][2 * q], acc[rt][0][2 * q + 1]} * sc2;
                         split2h(vs.x, vs.y, ph[q], pm[q]);
                     }
-                    char *dst = lds + (2 * wave + h) * ML_SLOT + (rt * 2) * 1024 + j * 16;
+                    char *dst = lds + (2 * wave + h) * SLOT + (rt * 2) * 1024 + j * 16;
                     *reinterpret_cast<u32x4 *>(dst) = u32x4{ph[0], ph[1], ph[2], ph[3]};
                     *reinterpret_cast<u32x4 *>(dst + 512) = u32x4{ph[4], ph[5], ph[6], ph[7]};
                     *reinterpret_cast<u32x4 *>(dst + 1024) = u32x4{pm[0], pm[1], pm[2], pm[3]};
@@ -261,7 +305,7 @@ __global__ __launch_bounds__(256, MODE == 1 ? 2 : 1) void mlp3_kernel(MlpArgs a)
         };
         auto store = [&](float *C, int ldc) {
 #pragma unroll
-            for (int rt = 0; rt < 4; ++rt) {
+            for (int rt = 0; rt < RT; ++rt) {
                 const long long row = row_base + 32 * rt + j;
                 if (row < M) {
                     float *o = C + (size_t)phys(row) * ldc + col0;
@@ -275,33 +319,41 @@ __global__ __launch_bounds__(256, MODE == 1 ? 2 : 1) void mlp3_kernel(MlpArgs a)
             }
         };
         const bool act0 = 32 * wave < a.N[0], act1 = 32 * wave < a.N[1], act2 = 32 * wave < a.N[2];
-        float amax[4];
+        float amax[RT];
         // ---- layer 0
         zero_acc();
         if (act0) {
-            h2_mfma_layer<4, 1, S0, 0, ML_WSTEP, ML_SLOT>(wsrd, a.wbase[0], woff, lds, lane, acc, []() {});
+            h2_mfma_layer<RT, 1, S0, 0, ML_WSTEP, SLOT>(wsrd, a.wbase[0], woff, lds, lane, acc, []() {});
+            MLP_STAMP(3);
             if (a.R) activate(0, amax, std::true_type{}); else activate(0, amax, std::false_type{});
+            MLP_STAMP(4);
         }
         publish(1, act0, amax);
+        MLP_STAMP(5);
         // ---- layer 1
         zero_acc();
         if (act1) {
-            h2_mfma_layer<4, 1, S1, 0, ML_WSTEP, ML_SLOT>(wsrd, a.wbase[1], woff, lds, lane, acc, []() {});
+            h2_mfma_layer<RT, 1, S1, 0, ML_WSTEP, SLOT>(wsrd, a.wbase[1], woff, lds, lane, acc, []() {});
+            MLP_STAMP(6);
             activate(1, amax, std::false_type{});
         }
         publish(2, act1, amax);
+        MLP_STAMP(7);
         // ---- layer 2 -> fp32 rows
         zero_acc();
         if (act2) {
-            h2_mfma_layer<4, 1, S2, 0, ML_WSTEP, ML_SLOT>(wsrd, a.wbase[2], woff, lds, lane, acc, []() {});
+            h2_mfma_layer<RT, 1, S2, 0, ML_WSTEP, SLOT>(wsrd, a.wbase[2], woff, lds, lane, acc, []() {});
+            MLP_STAMP(8);
             activate(2, amax, std::false_type{});
+            MLP_STAMP(9);
             if (MODE != 1) store(a.C, a.ldc);
+            MLP_STAMP(10);
         }
         if (MODE == 1) {
             // ---- last layer of aux_merge_weight_block (64 -> 1) + sigmoid, validity / frame weights (:1199), weighted merge over the 4 views
             // (:1217) and the mix-up row (:1286-1292)
 #pragma unroll
-            for (int rt = 0; rt < 4; ++rt) {
+            for (int rt = 0; rt < RT; ++rt) {
                 float d = 0.f;
                 if (act2) {
 #pragma unroll
@@ -338,13 +390,18 @@ __global__ __launch_bounds__(256, MODE == 1 ? 2 : 1) void mlp3_kernel(MlpArgs a)
             publish(3, act2, amax);
             zero_acc();
             if (32 * wave < a.N[3]) {
-                h2_mfma_layer<4, 1, (S3 > 0 ? S3 : 1), 0, ML_WSTEP, ML_SLOT>(wsrd, a.wbase[3], woff, lds, lane, acc, []() {});
+                h2_mfma_layer<RT, 1, (S3 > 0 ? S3 : 1), 0, ML_WSTEP, SLOT>(wsrd, a.wbase[3], woff, lds, lane, acc, []() {});
                 activate(3, amax, std::false_type{});
                 store(a.C2, a.ldc2);
             }
         }
+        MLP_STAMP(11);
         __syncthreads();                                                   // the planes and rowinv are rewritten by the next tile's prologue
+        MLP_STAMP(12);
     }
+#ifdef HNR_MLP_PROBE
+    if (blockIdx.x == 0 && threadIdx.x == 0) { for (int i = 0; i < 14; ++i) g_mlp_probe[i] = tm_[i]; g_mlp_probe[14] = ntile_; }
+#endif
 }
 
 struct MlpPackArgs {
@@ -433,6 +490,24 @@ extern "C" int hnr_mlp3_pack(int n_layers, const float *const *d_W, const int *l
     return HNR_OK;
 }
 
+static void mlp3_probe_print(hipStream_t st, int n_layers, int K0)
+{
+#ifdef HNR_MLP_PROBE
+    if (getenv("HNR_MLP_PROBE_PRINT")) {
+        (void)hipStreamSynchronize(st);
+        long long h[16];
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_mlp_probe), sizeof(h)) == hipSuccess && h[14] > 0) {
+            const char *nm[13] = {"wait/prev", "A load + split", "barrier", "L0 mfma", "L0 act", "L0 publish", "L1 mfma+act", "L1 publish", "L2 mfma", "L2 act", "store", "tail", "end barrier"};
+            fprintf(stderr, "[mlp3 probe] n_layers %d K0 %d tiles %lld:", n_layers, K0, h[14]);
+            for (int i = 0; i < 13; ++i) fprintf(stderr, " %s %lld", nm[i], h[i] / h[14]);
+            fprintf(stderr, "\n");
+        }
+    }
+#else
+    (void)st; (void)n_layers; (void)K0;
+#endif
+}
+
 extern "C" int hnr_mlp3_forward(const float *d_A, int lda, int64_t M_cap, const int64_t *d_counts, int count_index, int count_mult, int seg_stride,
                                 const void *d_packed, int n_layers, const int *N, const int *K, const int *act, float slope, const float *d_R,
                                 const int32_t *d_ridx, int ldr, float *d_C, int ldc, float *d_C2, int ldc2, void *stream)
@@ -468,23 +543,25 @@ extern "C" int hnr_mlp3_forward(const float *d_A, int lda, int64_t M_cap, const 
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
         if (n_cu <= 0) n_cu = 256;
     }
-    const int64_t tiles = (M_cap + 127) / 128;
-    const int grid = (int)(tiles < n_cu ? tiles : n_cu);
     hipStream_t st = (hipStream_t)stream;
-#define HNR_MLP3_CASE(S0_, S1_, S2_, S3_)                                                                                              \
+    // RT_ = row tiles per workgroup tile: 2 (64 rows, two workgroups per CU) where four (128 rows) would leave room for one workgroup only
+#define HNR_MLP3_CASE(S0_, S1_, S2_, S3_, RT_)                                                                                         \
     if (S[0] == S0_ && S[1] == S1_ && S[2] == S2_ && S[3] == S3_) {                                                                     \
         constexpr int smax3 = S0_ > S1_ ? (S0_ > S2_ ? S0_ : S2_) : (S1_ > S2_ ? S1_ : S2_), smax = smax3 > S3_ ? smax3 : S3_;          \
-        constexpr int ldsb = smax * ML_SLOT + 128 * 4 * 4 + 128 * 4;                                                                    \
+        constexpr int ldsb = smax * RT_ * 2048 + 32 * RT_ * 4 * 4 + 32 * RT_ * 4;                                                       \
+        const int64_t tiles = (M_cap + 32 * RT_ - 1) / (32 * RT_);                                                                      \
+        const int wgs = (RT_ < 4 ? 2 : 1) * n_cu, grid = (int)(tiles < wgs ? tiles : wgs);                                              \
         static bool attr = false;                                                                                                       \
-        if (!attr) { HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(mlp3_kernel<S0_, S1_, S2_, S3_, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb)); attr = true; } \
-        mlp3_kernel<S0_, S1_, S2_, S3_, 0><<<grid, 256, ldsb, st>>>(a);                                                                    \
+        if (!attr) { HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(mlp3_kernel<S0_, S1_, S2_, S3_, 0, RT_>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb)); attr = true; } \
+        mlp3_kernel<S0_, S1_, S2_, S3_, 0, RT_><<<grid, 256, ldsb, st>>>(a);                                                             \
+        mlp3_probe_print(st, n_layers, K[0]);                                                                                          \
         HNR_LAUNCH_CHECK();                                                                                                             \
         return HNR_OK;                                                                                                                  \
     }
-    HNR_MLP3_CASE(18, 8, 8, 0)     // color_feature_branch: 280 -> 128 -> 128 -> 128
-    HNR_MLP3_CASE(18, 8, 8, 8)     // the same + tail 128 -> 64: the colour-feature columns of aux_merge_weight_block.0, once per sample
-    HNR_MLP3_CASE(3, 4, 4, 0)      // aux_merge_weight_block: 48 -> 64 -> 64 -> 64
-    HNR_MLP3_CASE(6, 3, 3, 0)      // color_mixup_block: 90 -> 45 -> 45 -> 45
+    HNR_MLP3_CASE(18, 8, 8, 0, 2)     // color_feature_branch: 280 -> 128 -> 128 -> 128
+    HNR_MLP3_CASE(18, 8, 8, 8, 2)     // the same + tail 128 -> 64: the colour-feature columns of aux_merge_weight_block.0, once per sample
+    HNR_MLP3_CASE(3, 4, 4, 0, 4)      // aux_merge_weight_block: 48 -> 64 -> 64 -> 64
+    HNR_MLP3_CASE(6, 3, 3, 0, 2)      // color_mixup_block: 90 -> 45 -> 45 -> 45
 #undef HNR_MLP3_CASE
     set_error("hnr_mlp3_forward: no kernel for k steps (%d, %d, %d, %d); built: (18,8,8,0) (18,8,8,8) (3,4,4,0) (6,3,3,0)", S[0], S[1], S[2], S[3]);
     return HNR_ERR_BADARG;
