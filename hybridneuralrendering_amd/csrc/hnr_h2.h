@@ -46,8 +46,11 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // MFMA waits at the issue stage for the matrix pipe blocks the SIMD's VALU port for every other wave (tools/coissue_probe.hip: the
 // co-resident wave is starved completely); parked in s_nop for the ~24 cycles the pipe is busy anyway, it leaves the port to the other
 // group's epilogue (6.2 instead of 5.0 cycles per VALU instruction there, 34.0 instead of 32.0 cycles per MFMA here).
-template <int RT, int CT, int S, int PRELOAD_ALL, int WSTEP, int SLOT, int BAR = -1, int WSAME = 0, int PACE = 0, class Mid>
-__device__ __forceinline__ void h2_mfma_layer(__amdgpu_buffer_rsrc_t wsrd, int wbase, unsigned woff, const char *lds, int lane, f32x16 (&acc)[RT][CT], Mid mid)
+// after(): called once, right after the layer's LAST weight-fragment loads have been issued: loads placed there (gathered addends ...) are
+// not waited for by any later weight wait of the layer (vmcnt counts in order), yet run under the remaining k steps' MFMAs.
+struct H2NoHook { __device__ __forceinline__ void operator()() const {} };
+template <int RT, int CT, int S, int PRELOAD_ALL, int WSTEP, int SLOT, int BAR = -1, int WSAME = 0, int PACE = 0, class Mid, class After = H2NoHook>
+__device__ __forceinline__ void h2_mfma_layer(__amdgpu_buffer_rsrc_t wsrd, int wbase, unsigned woff, const char *lds, int lane, f32x16 (&acc)[RT][CT], Mid mid, After after = After())
 {
     constexpr int PD = RT * CT >= 8 ? 2 : 3;
     // fragment (s, column tile c of the wave, plane p) at s * WSTEP + (c * 2 + p) * 1024 + woff of the layer image; the per-lane part
@@ -85,6 +88,7 @@ __device__ __forceinline__ void h2_mfma_layer(__amdgpu_buffer_rsrc_t wsrd, int w
             if (!PRELOAD_ALL && s + PD < S) load_w((s + PD) % (PD + 1), s + PD);
             if (s + 1 < S) load_b((s + 1) & 1, s + 1);
         }
+        if (s == (PRELOAD_ALL || S <= PD ? 0 : S - 1 - PD)) { __builtin_amdgcn_sched_barrier(0); after(); __builtin_amdgcn_sched_barrier(0); }
         const int ws = PRELOAD_ALL ? s : s % (PD + 1), bs = s & 1;
 #define CH_W(c, p) __builtin_bit_cast(f16x8, wf[ws][c][p])
 #define CH_X(rt, p) __builtin_bit_cast(f16x8, bf[bs][rt][p])

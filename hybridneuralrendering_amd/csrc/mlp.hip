@@ -40,7 +40,7 @@ struct MlpArgs {
 };
 
 #ifdef HNR_MLP_PROBE
-__device__ long long g_mlp_probe[16];
+__device__ long long g_mlp_probe[24];
 #define MLP_STAMP(i_) do { const long long t_ = clock64(); tm_[i_] += t_ - tp_; tp_ = t_; if ((i_) == 0) ++ntile_; } while (0)
 #else
 #define MLP_STAMP(i_) do { } while (0)
@@ -88,10 +88,12 @@ __global__ __launch_bounds__(256, (MODE == 1 || RT < 4) ? 2 : 1) void mlp3_kerne
     const f32x2 slope2 = {a.slope, a.slope};
 
 #ifdef HNR_MLP_PROBE
-    long long tm_[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tp_ = clock64(), ntile_ = 0;
+    long long tm_[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tp_ = clock64(), ntile_ = 0;
 #endif
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const long long row_base = (long long)tile * ROWS;
+        int tid_t = tid;                                                   // laundered per tile: the per-thread index arithmetic below (idx / 45 ...) is cheap, but hoisted out of the
+        asm volatile("" : "+v"(tid_t));                                    // tile loop it becomes a dozen 64-bit addresses per thread that the register allocator spills to scratch
         MLP_STAMP(0);
         float inv[RT];
         if (MODE == 1) {
@@ -125,13 +127,22 @@ __global__ __launch_bounds__(256, (MODE == 1 || RT < 4) ? 2 : 1) void mlp3_kerne
                 const float nn = sqrtf(nx * nx + ny * ny + nz * nz) + 1e-6f;
                 s_f[tid * 48 + 45] = nx / nn - cx / cn; s_f[tid * 48 + 46] = ny / nn - cy / cn; s_f[tid * 48 + 47] = nz / nn - cz / cn;
             }
+            MLP_STAMP(13);
             __syncthreads();
             // (b) the 45 feature channels of the pixel (192-B contiguous per row; channels 45..47 of the map are padding);
-            for (int idx = tid; idx < 128 * 12; idx += 256) {
-                const int row = idx / 12, q = idx - row * 12;
-                float4 f4 = *reinterpret_cast<const float4 *>(a.fm + (size_t)s_pix[row] + 4 * q);
-                float *d = s_f + row * 48 + 4 * q;
-                if (q < 11) *reinterpret_cast<float4 *>(d) = f4; else d[0] = f4.x;          // column 44; 45..47 hold the direction deltas
+            {
+                float4 f4[6];                                                // all six scattered 16-B loads of a thread in flight together
+#pragma unroll
+                for (int it = 0; it < 6; ++it) {
+                    const int idx = tid_t + 256 * it, row = idx / 12, q = idx - row * 12;
+                    f4[it] = *reinterpret_cast<const float4 *>(a.fm + (size_t)s_pix[row] + 4 * q);
+                }
+#pragma unroll
+                for (int it = 0; it < 6; ++it) {
+                    const int idx = tid_t + 256 * it, row = idx / 12, q = idx - row * 12;
+                    float *d = s_f + row * 48 + 4 * q;
+                    if (q < 11) *reinterpret_cast<float4 *>(d) = f4[it]; else d[0] = f4[it].x;      // column 44; 45..47 hold the direction deltas
+                }
             }
             __syncthreads();
             // (c) layer-0 operand planes of the rows 32 wave + j
@@ -240,6 +251,15 @@ __global__ __launch_bounds__(256, (MODE == 1 || RT < 4) ? 2 : 1) void mlp3_kerne
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[rt][0][r] = 0.f;
         };
+        // the gathered first-layer addend rows of all row tiles: asked for BEFORE the layer's MFMA loop, used in its epilogue
+        float4 ad[2][4];                                                   // ring of two row tiles: two rows' loads in flight while one is used
+        auto load_addend = [&](int rt) {
+            long long row = row_base + 32 * rt + j;
+            if (row >= M) row = M - 1;
+            const float *rrow = a.R + (size_t)(MODE == 1 ? row / 4 : (long long)a.ridx[phys(row)]) * a.ldr + col0;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) ad[rt & 1][q4] = *reinterpret_cast<const float4 *>(rrow + 4 * q4);
+        };
         // v = acc * inv + bias (+ addend) (+ LeakyReLU); returns the per-row maxima of this wave's columns
         auto activate = [&](int layer, float (&amax)[RT], auto with_addend) {
             constexpr bool ADD = decltype(with_addend)::value;
@@ -250,26 +270,22 @@ __global__ __launch_bounds__(256, (MODE == 1 || RT < 4) ? 2 : 1) void mlp3_kerne
                 bias[2 * q] = f32x2{b.x, b.y}; bias[2 * q + 1] = f32x2{b.z, b.w};
             }
             const bool act = a.act[layer] != 0;
+            if (ADD) { load_addend(0); if (RT > 1) load_addend(1); }
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
                 float m = 0.f;
                 const f32x2 inv2 = {inv[rt], inv[rt]};
-                const float *rrow = nullptr;
-                if (ADD) {
-                    long long row = row_base + 32 * rt + j;
-                    if (row >= M) row = M - 1;
-                    rrow = a.R + (size_t)(MODE == 1 ? row / 4 : (long long)a.ridx[phys(row)]) * a.ldr + col0;
-                }
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     f32x2 add = bias[q];
-                    if (ADD) { const float2 t2 = *reinterpret_cast<const float2 *>(rrow + 2 * q); add = add + f32x2{t2.x, t2.y}; }
+                    if (ADD) { const float4 t4 = ad[rt & 1][q >> 1]; add = add + ((q & 1) ? f32x2{t4.z, t4.w} : f32x2{t4.x, t4.y}); }
                     f32x2 v = __builtin_elementwise_fma(f32x2{acc[rt][0][2 * q], acc[rt][0][2 * q + 1]}, inv2, add);
                     if (act) { const f32x2 sv = v * slope2; v.x = fmaxf(v.x, sv.x); v.y = fmaxf(v.y, sv.y); }
                     acc[rt][0][2 * q] = v.x; acc[rt][0][2 * q + 1] = v.y;
                     m = fmaxf(fmaxf(m, fabsf(v.x)), fabsf(v.y));
                 }
                 amax[rt] = m;
+                if (ADD && rt + 2 < RT) load_addend(rt + 2);
             }
         };
         auto publish = [&](int next_layer, bool active, float (&amax)[RT]) {
@@ -323,7 +339,7 @@ __global__ __launch_bounds__(256, (MODE == 1 || RT < 4) ? 2 : 1) void mlp3_kerne
         // ---- layer 0
         zero_acc();
         if (act0) {
-            h2_mfma_layer<RT, 1, S0, 0, ML_WSTEP, SLOT>(wsrd, a.wbase[0], woff, lds, lane, acc, []() {});
+            h2_mfma_layer<RT, 1, S0, 0, ML_WSTEP, SLOT>(wsrd, a.wbase[0], woff, lds, lane, acc, []() {}, H2NoHook());
             MLP_STAMP(3);
             if (a.R) activate(0, amax, std::true_type{}); else activate(0, amax, std::false_type{});
             MLP_STAMP(4);
@@ -340,6 +356,8 @@ __global__ __launch_bounds__(256, (MODE == 1 || RT < 4) ? 2 : 1) void mlp3_kerne
         publish(2, act1, amax);
         MLP_STAMP(7);
         // ---- layer 2 -> fp32 rows
+        float cfv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float4 wl4[4];                                                     // MODE 1: this lane's 16 weights of aux_merge_weight_block's last layer
         zero_acc();
         if (act2) {
             h2_mfma_layer<RT, 1, S2, 0, ML_WSTEP, SLOT>(wsrd, a.wbase[2], woff, lds, lane, acc, []() {});
@@ -350,6 +368,18 @@ __global__ __launch_bounds__(256, (MODE == 1 || RT < 4) ? 2 : 1) void mlp3_kerne
             MLP_STAMP(10);
         }
         if (MODE == 1) {
+            // the last layer's weights and the colour-feature columns that open the mix-up rows: asked for here, after the tile's last weight load (a wait for a weight
+            // fragment also waits for every older load), used after the two barriers of the merge-weight epilogue
+#pragma unroll
+            for (int it = 0; it < 6; ++it) {
+                const int idx = tid_t + 256 * it, ls = idx / 45, ch = idx - ls * 45;
+                const long long sidx = row_base / 4 + ls;
+                cfv[it] = (idx < 32 * 45 && sidx * 4 < M) ? a.CF[(size_t)sidx * a.ldcf + ch] : 0.f;
+            }
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) wl4[q4] = *reinterpret_cast<const float4 *>(a.w_last + (act2 ? col0 : 0) + 4 * q4);
+        }
+        if (MODE == 1) {
             // ---- last layer of aux_merge_weight_block (64 -> 1) + sigmoid, validity / frame weights (:1199), weighted merge over the 4 views
             // (:1217) and the mix-up row (:1286-1292)
 #pragma unroll
@@ -357,12 +387,13 @@ __global__ __launch_bounds__(256, (MODE == 1 || RT < 4) ? 2 : 1) void mlp3_kerne
                 float d = 0.f;
                 if (act2) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) d = fmaf(acc[rt][0][r], a.w_last[col0 + r], d);
+                    for (int r = 0; r < 16; ++r) d = fmaf(acc[rt][0][r], reinterpret_cast<const float *>(wl4)[r], d);
                     d = __fadd_rn(d, __shfl_xor(d, 32));
                 }
                 if (h == 0) exch[(32 * rt + j) * 4 + wave] = d;
             }
             __syncthreads();
+            MLP_STAMP(14);
             if (tid < 128) {
                 const float4 d4 = *reinterpret_cast<const float4 *>(exch + tid * 4);
                 const float d = __fadd_rn(__fadd_rn(d4.x, d4.y), __fadd_rn(d4.z, d4.w));
@@ -372,17 +403,22 @@ __global__ __launch_bounds__(256, (MODE == 1 || RT < 4) ? 2 : 1) void mlp3_kerne
                 s_w[tid] = wv;
             }
             __syncthreads();
-            for (int idx = tid; idx < 32 * 45; idx += 256) {
-                const int ls = idx / 45, ch = idx - ls * 45;
-                const long long sidx = row_base / 4 + ls;
-                if (sidx * 4 < M) {
-                    float fsum = 0.f, wsum = 0.f;
+            MLP_STAMP(15);
+            {
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) { const float wv = s_w[4 * ls + v]; fsum += s_f[(4 * ls + v) * 48 + ch] * wv; wsum += wv; }
-                    float *o = a.X7 + (size_t)sidx * a.ld7;
-                    o[ch] = a.CF[(size_t)sidx * a.ldcf + ch];
-                    o[45 + ch] = fsum / (wsum + 1e-6f);
+                for (int it = 0; it < 6; ++it) {
+                    const int idx = tid_t + 256 * it, ls = idx / 45, ch = idx - ls * 45;
+                    const long long sidx = row_base / 4 + ls;
+                    if (idx < 32 * 45 && sidx * 4 < M) {
+                        float fsum = 0.f, wsum = 0.f;
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) { const float wv = s_w[4 * ls + v]; fsum += s_f[(4 * ls + v) * 48 + ch] * wv; wsum += wv; }
+                        float *o = a.X7 + (size_t)sidx * a.ld7;
+                        o[ch] = cfv[it];
+                        o[45 + ch] = fsum / (wsum + 1e-6f);
+                    }
                 }
+                MLP_STAMP(17);
             }
         }
         if (S3 > 0) {
@@ -400,7 +436,7 @@ __global__ __launch_bounds__(256, (MODE == 1 || RT < 4) ? 2 : 1) void mlp3_kerne
         MLP_STAMP(12);
     }
 #ifdef HNR_MLP_PROBE
-    if (blockIdx.x == 0 && threadIdx.x == 0) { for (int i = 0; i < 14; ++i) g_mlp_probe[i] = tm_[i]; g_mlp_probe[14] = ntile_; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { for (int i = 0; i < 20; ++i) g_mlp_probe[i] = tm_[i]; g_mlp_probe[20] = ntile_; }
 #endif
 }
 
@@ -495,11 +531,12 @@ static void mlp3_probe_print(hipStream_t st, int n_layers, int K0)
 #ifdef HNR_MLP_PROBE
     if (getenv("HNR_MLP_PROBE_PRINT")) {
         (void)hipStreamSynchronize(st);
-        long long h[16];
-        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_mlp_probe), sizeof(h)) == hipSuccess && h[14] > 0) {
+        long long h[24];
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_mlp_probe), sizeof(h)) == hipSuccess && h[20] > 0) {
             const char *nm[13] = {"wait/prev", "A load + split", "barrier", "L0 mfma", "L0 act", "L0 publish", "L1 mfma+act", "L1 publish", "L2 mfma", "L2 act", "store", "tail", "end barrier"};
-            fprintf(stderr, "[mlp3 probe] n_layers %d K0 %d tiles %lld:", n_layers, K0, h[14]);
-            for (int i = 0; i < 13; ++i) fprintf(stderr, " %s %lld", nm[i], h[i] / h[14]);
+            fprintf(stderr, "[mlp3 probe] n_layers %d K0 %d tiles %lld:", n_layers, K0, h[20]);
+            for (int i = 0; i < 13; ++i) fprintf(stderr, " %s %lld", nm[i], h[i] / h[20]);
+            fprintf(stderr, " [merge (a) %lld | tail: dot %lld, sigmoid %lld, loads %lld, merge+stores %lld]", h[13] / h[20], h[14] / h[20], h[15] / h[20], h[16] / h[20], h[17] / h[20]);
             fprintf(stderr, "\n");
         }
     }
@@ -513,7 +550,7 @@ extern "C" int hnr_mlp3_forward(const float *d_A, int lda, int64_t M_cap, const 
                                 const int32_t *d_ridx, int ldr, float *d_C, int ldc, float *d_C2, int ldc2, void *stream)
 {
     if ((n_layers != 3 && n_layers != 4) || !N || !K || !act || M_cap < 0 || seg_stride < 0 || (seg_stride > 0 && (count_mult < 1 || count_mult > 8)) || lda < K[0] || (lda & 3) || ldc < N[2] || (ldc & 3) ||
-        !(slope > 0.f && slope < 1.f) || (d_R && (!d_ridx || ldr < N[0] || (ldr & 1))) || (n_layers == 4 && (!d_C2 || ldc2 < N[3] || (ldc2 & 3) || ((uintptr_t)d_C2 & 15)))) {
+        !(slope > 0.f && slope < 1.f) || (d_R && (!d_ridx || ldr < N[0] || (ldr & 3) || ((uintptr_t)d_R & 15))) || (n_layers == 4 && (!d_C2 || ldc2 < N[3] || (ldc2 & 3) || ((uintptr_t)d_C2 & 15)))) {
         set_error("hnr_mlp3_forward: bad sizes (n_layers=%d lda=%d ldc=%d ldr=%d ldc2=%d slope=%g)", n_layers, lda, ldc, ldr, ldc2, (double)slope);
         return HNR_ERR_BADARG;
     }
@@ -578,7 +615,7 @@ extern "C" int hnr_merge_stage(const float *d_sample_loc_w, const int32_t *d_vs_
                                int cap_samples, float slope, float *d_X7, int ld7, void *stream)
 {
     if (V != 4) { set_error("hnr_merge_stage: built for V = 4 reference views (got %d); use hnr_proj_rows + hnr_mlp3_forward + hnr_merge", V); return HNR_ERR_BADARG; }
-    if (cap_samples < 0 || H <= 0 || W <= 0 || ldpre < 64 || (ldpre & 1) || ldcf < 45 || ld7 < 90 || !(slope > 0.f && slope < 1.f)) {
+    if (cap_samples < 0 || H <= 0 || W <= 0 || ldpre < 64 || (ldpre & 3) || ((uintptr_t)d_pre & 15) || ldcf < 45 || ld7 < 90 || !(slope > 0.f && slope < 1.f)) {
         set_error("hnr_merge_stage: bad sizes (cap_samples=%d H=%d W=%d ldpre=%d ldcf=%d ld7=%d)", cap_samples, H, W, ldpre, ldcf, ld7); return HNR_ERR_BADARG;
     }
     if (cap_samples == 0) return HNR_OK;
@@ -608,6 +645,7 @@ extern "C" int hnr_merge_stage(const float *d_sample_loc_w, const int32_t *d_vs_
     static bool attr = false;
     if (!attr) { HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(mlp3_kernel<3, 4, 4, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb)); attr = true; }
     mlp3_kernel<3, 4, 4, 0, 1><<<grid, 256, ldsb, (hipStream_t)stream>>>(a);
+    mlp3_probe_print((hipStream_t)stream, 3, 48);
     HNR_LAUNCH_CHECK();
     return HNR_OK;
 }
