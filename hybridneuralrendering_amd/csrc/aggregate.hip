@@ -540,35 +540,53 @@ struct FinalArgs {
     float *decoded;                                      // [R*SR, 4], pre-zeroed
 };
 
+// 16 lanes per sample (8 columns each, two 16-B loads of the colour feature per lane), four samples per wave; the three dot products are
+// reduced over the 16 lanes by DPP (a wave per sample with six ds_bpermute steps per output was latency-bound: 0.90 ms per frame).
 __global__ __launch_bounds__(256) void final_color_kernel(FinalArgs a)
 {
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, l16 = lane & 15, sub = lane >> 4;
     const int n_valid = (int)a.counts[HNR_CNT_SAMPLES_VALID];
-    for (int s = (int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6); s < n_valid; s += (int)((gridDim.x * (unsigned)blockDim.x) >> 6)) {
-    float r[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int c = lane + 64 * h;
-        const float cf = a.CF[(size_t)s * a.ldcf + c];
-        const float x = c < 45 ? a.Y[(size_t)s * a.ldy + c] + cf : cf;      // learn_residuals (:1294)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) r[j] += x * a.w_fin[j * 128 + c];
-    }
+    float w[3][8];
 #pragma unroll
     for (int j = 0; j < 3; ++j)
-        for (int o = 32; o > 0; o >>= 1) r[j] += __shfl_xor(r[j], o);
-    if (lane == 0) {
-        float4 out;
-        out.x = a.sigma[s];
-        float rgb[3];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) w[j][e] = a.w_fin[j * 128 + 8 * l16 + e];
+    const float b0 = a.b_fin[0], b1 = a.b_fin[1], b2 = a.b_fin[2];
+    const int wave_g = (int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6), n_waves = (int)((gridDim.x * (unsigned)blockDim.x) >> 6);
+    for (int s0 = 4 * wave_g; s0 < n_valid; s0 += 4 * n_waves) {
+        const int s = s0 + sub;
+        const bool ok = s < n_valid;
+        const size_t sc = ok ? (size_t)s : (size_t)(n_valid - 1);
+        const float4 c0 = *reinterpret_cast<const float4 *>(a.CF + sc * a.ldcf + 8 * l16), c1 = *reinterpret_cast<const float4 *>(a.CF + sc * a.ldcf + 8 * l16 + 4);
+        float x[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = 8 * l16 + e;
+            if (c < 45) x[e] = a.Y[sc * a.ldy + c] + x[e];                  // learn_residuals (:1294): mix-up output + colour feature, same operand order as before
+        }
+        float r[3] = {0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const float sg = 1.f / (1.f + expf(-(r[j] + a.b_fin[j])));
-            rgb[j] = sg * (1.f + 2.f * 0.001f) - 0.001f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) r[j] += x[e] * w[j][e];
+            r[j] += __builtin_amdgcn_update_dpp(0.f, r[j], 0xB1, 0xf, 0xf, false);      // quad_perm [1,0,3,2]
+            r[j] += __builtin_amdgcn_update_dpp(0.f, r[j], 0x4E, 0xf, 0xf, false);      // quad_perm [2,3,0,1]
+            r[j] += __builtin_amdgcn_update_dpp(0.f, r[j], 0x141, 0xf, 0xf, false);     // row_half_mirror
+            r[j] += __builtin_amdgcn_update_dpp(0.f, r[j], 0x140, 0xf, 0xf, false);     // row_mirror
         }
-        out.y = rgb[0]; out.z = rgb[1]; out.w = rgb[2];
-        reinterpret_cast<float4 *>(a.decoded)[a.vs_item[s]] = out;
-    }
+        if (l16 == 0 && ok) {
+            float4 out;
+            out.x = a.sigma[s];
+            const float bb[3] = {b0, b1, b2};
+            float rgb[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const float sg = 1.f / (1.f + expf(-(r[j] + bb[j])));
+                rgb[j] = sg * (1.f + 2.f * 0.001f) - 0.001f;
+            }
+            out.y = rgb[0]; out.z = rgb[1]; out.w = rgb[2];
+            reinterpret_cast<float4 *>(a.decoded)[a.vs_item[s]] = out;
+        }
     }
 }
 
@@ -948,14 +966,15 @@ extern "C" int hnr_final_color(const float *d_Y, int ldy, const float *d_CF, int
                                const float *d_sigma, const int32_t *d_vs_item, const int64_t *d_counts, int cap_samples,
                                float *d_decoded, void *stream)
 {
-    if (!d_Y || !d_CF || !d_w_fin || !d_b_fin || !d_sigma || !d_vs_item || !d_counts || !d_decoded || ldy < 45 || ldcf < 128) {
-        set_error("hnr_final_color: bad argument"); return HNR_ERR_BADARG;
+    if (!d_Y || !d_CF || !d_w_fin || !d_b_fin || !d_sigma || !d_vs_item || !d_counts || !d_decoded || ldy < 45 || ldcf < 128 || (ldcf & 3) ||
+        ((uintptr_t)d_CF & 15)) {
+        set_error("hnr_final_color: bad argument (NULL pointer, ldy < 45, ldcf < 128 or not a multiple of 4, colour feature not 16-B aligned)"); return HNR_ERR_BADARG;
     }
     if (cap_samples <= 0) return HNR_OK;
     FinalArgs a;
     a.Y = d_Y; a.ldy = ldy; a.CF = d_CF; a.ldcf = ldcf; a.w_fin = d_w_fin; a.b_fin = d_b_fin; a.sigma = d_sigma;
     a.vs_item = d_vs_item; a.counts = reinterpret_cast<const unsigned long long *>(d_counts); a.decoded = d_decoded;
-    { const int need = cdiv((int64_t)cap_samples * 64, 256); final_color_kernel<<<need < 8192 ? need : 8192, 256, 0, (hipStream_t)stream>>>(a); }
+    { const int need = cdiv((int64_t)cap_samples * 16, 256); final_color_kernel<<<need < 8192 ? need : 8192, 256, 0, (hipStream_t)stream>>>(a); }
     HNR_LAUNCH_CHECK();
     return HNR_OK;
 }
