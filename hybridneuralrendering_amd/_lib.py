@@ -59,7 +59,7 @@ class RenderCamera(ctypes.Structure):
 
 
 class RenderViews(ctypes.Structure):
-    _fields_ = [("d_w2c", _P), ("d_intrinsic", _P), ("d_campos_nearest", _P), ("d_featmap", _P), ("H", _I), ("W", _I), ("d_frame_w", _P)]
+    _fields_ = [("d_w2c", _P), ("d_intrinsic", _P), ("d_campos_nearest", _P), ("d_featmap", _P), ("H", _I), ("W", _I), ("d_frame_w", _P), ("featmap_ready", _P)]
 
 
 class RenderOutputs(ctypes.Structure):

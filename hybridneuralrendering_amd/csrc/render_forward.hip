@@ -119,6 +119,7 @@ extern "C" int hnr_render_forward(const hnr_grid *grid, const hnr_render_params 
     if ((rc = hnr_mlp3_forward(L.X5, 280, cap, o->d_counts, HNR_CNT_SAMPLES_VALID, 1, 0, w->d_mlp_cf, V > 0 ? 4 : 3, cfN, cfK, act1110, w->slope, nullptr, nullptr, 0,
                                L.CF, 128, L.pre, 64, stream)) != HNR_OK) return rc;
     HNR_MARK();
+    if (V > 0 && vw->featmap_ready) HNR_HIP_CHECK(hipStreamWaitEvent(st, (hipEvent_t)vw->featmap_ready, 0));      // the feature map may have been built on another stream
     if (V == 4) {
         // reprojection + feature gather + merge-weight MLP + weighted merge in one launch: nothing per (view, sample) row reaches HBM
         HNR_MARK();

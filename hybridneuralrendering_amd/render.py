@@ -103,6 +103,26 @@ class HybridRenderer:
             self._fm_src = images_nearest
         return self._fm
 
+    def feature_map_async(self, images_nearest):
+        """(feature map, event or None): a cached map needs no event; a rebuild is issued on a side stream (after everything already queued on the
+        current stream, so its inputs are complete) and the returned event marks its end."""
+        key = (images_nearest.data_ptr(), tuple(images_nearest.shape), images_nearest._version,
+               tuple((p.data_ptr(), p._version) for p in self.agg.parameters()))
+        if key == self._fm_key:
+            return self._fm, None
+        cur = torch.cuda.current_stream(images_nearest.device)
+        if getattr(self, "_side_stream", None) is None:
+            self._side_stream = torch.cuda.Stream(device=images_nearest.device)
+        side = self._side_stream
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            fm = self.feature_map(images_nearest)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        fm.record_stream(cur)                       # allocated under the side stream, consumed on the launch stream
+        self._fm_event = ev
+        return fm, ev
+
     def point_table(self, cloud):
         """Per-point addend of block1's first layer, rebuilt when the embeddings or the weights change."""
         key = (cloud.emb.data_ptr(), tuple(cloud.emb.shape), cloud.emb._version,
@@ -305,7 +325,7 @@ class HybridRenderer:
 
     # -- the whole path as ONE library call (no host read between query and composite) ---------------
     def _single_call(self, cloud, raydir, campos, camrot, bg_color, tmid, grid, radius2, w2c_nearest, campos_nearest, intrinsic_nearest, fm,
-                     frame_weight, want_weights, timers):
+                     frame_weight, want_weights, timers, fm_ready=None):
         """hnr_render_forward: every launch of the frame issued by the library on the current stream; workspaces sized for the worst
         case R*SR valid samples (or what fits: the status word reports an overflow), no `.cpu()` / `.item()` on the way."""
         L, p = _lib.lib(), _lib.ptr
@@ -340,7 +360,7 @@ class HybridRenderer:
         fw = None if frame_weight is None else _lib.require_gpu(frame_weight, "frame_weight", torch.float32).reshape(-1)
         if V > 0:
             vw = _lib.RenderViews(p(w2c_nearest), p(intrinsic_nearest), p(campos_nearest), p(fm), int(fm.shape[1]), int(fm.shape[2]),
-                                  p(fw) if fw is not None else None)
+                                  p(fw) if fw is not None else None, ctypes.c_void_p(fm_ready.cuda_event) if fm_ready is not None else None)
         col, opa, isbg = _f32((R, 3), dev), _f32((R, SR), dev), _f32((R,), dev)
         bw = _f32((R, SR), dev) if want_weights else None
         mask = torch.empty((R,), dtype=torch.int8, device=dev)
@@ -393,10 +413,14 @@ class HybridRenderer:
         grid, hp = q._grid_for(cloud.xyz[None])
         tmid = q._tmid_for(float(near), float(far), self.opt.z_depth_dim, raydir.shape[0], raydir.device)
         if self.dense == "f16x2" and self.opt.K == 8 and self.single_call and not pad and raydir.shape[0] > 0:
-            with _Stage(timers, "featmap"):
-                fm = None if getattr(self.opt, "use_nearest", 4) == 0 else self.feature_map(images_nearest)
+            # the reference-view feature pyramid does not depend on the rays: a rebuild (new reference views) runs on a side stream under the
+            # query and the per-neighbour chain; the library makes the launch stream wait for it right before the merge stage
+            fm, fm_ready = None, None
+            if getattr(self.opt, "use_nearest", 4) != 0:
+                with _Stage(timers, "featmap"):
+                    fm, fm_ready = self.feature_map_async(images_nearest)
             res = self._single_call(cloud, raydir, campos, camrot, bg_color, tmid, grid, np.float32(hp[0] ** 2), w2c_nearest, campos_nearest,
-                                    intrinsic_nearest, fm, frame_weight, want_weights, timers)
+                                    intrinsic_nearest, fm, frame_weight, want_weights, timers, fm_ready=fm_ready)
             if res is not None:
                 return res
         with _Stage(timers, "query"):

@@ -517,6 +517,9 @@ typedef struct {
     const float *d_w2c, *d_intrinsic, *d_campos_nearest; /* [V,4,4] inverse(c2w_nearest), [3,3], [V,3]                  */
     const float *d_featmap; int H, W;                    /* hnr_image_features output [V,H,W,48]                         */
     const float *d_frame_w;                              /* optional [V]                                                 */
+    void        *featmap_ready;                          /* optional hipEvent_t: the launch stream waits for it before the first kernel that
+                                                            reads d_featmap (the merge stage), so the caller may build the feature map on
+                                                            another stream while the query and the per-neighbour chain run            */
 } hnr_render_views;
 typedef struct {
     float   *d_raycolor, *d_opacity, *d_is_background;   /* [R,3] [R,SR] [R]  (fill_invalid applied)                     */
