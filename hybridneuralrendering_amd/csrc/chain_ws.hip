@@ -106,9 +106,9 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
     u32x4 bf[3][2];                                                        // activation fragment ring [k step % 3][plane]
     float inv[4] = {0.f, 0.f, 0.f, 0.f};
     int pid[4], pid_n[4] = {0, 0, 0, 0};
-    float wq[4], wq_n[4] = {0.f, 0.f, 0.f, 0.f}, wq_fin = 0.f;
-    float4 e0 = make_float4(0.f, 0.f, 0.f, 0.f), e1 = e0, e0_n = e0, e1_n = e0;
-    float4 tv[2][4];                                                       // layer 0: the row tile's rows of the per-point table (one set: fetched at the barrier of its pass)
+    float wq[4], wq_fin = 0.f;
+    float4 e0 = make_float4(0.f, 0.f, 0.f, 0.f), e1 = e0;
+    float4 tv[2][2][4];                                                    // layer 0: rows of the per-point table, two row tiles in flight ([row tile & 1][column tile][16 B])
     u32x4 xv[2] = {u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};
     int tile_fin = -1;
 
@@ -117,26 +117,37 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
         const int so_ = cw_wbase(L_) + (s_) * CH_WSTEP; \
         CW_LOAD_FRAG(16 * (s_) + 0, wsrd, woff, so_, 0); CW_LOAD_FRAG(16 * (s_) + 4, wsrd, woff, so_, 1024); \
         CW_LOAD_FRAG(16 * (s_) + 8, wsrd, woff, so_, 2048); CW_LOAD_FRAG(16 * (s_) + 12, wsrd, woff, so_, 3072); } while (0)
-    auto load_aux = [&](int tile, int (&pd)[4], float (&wd)[4], float4 &x0, float4 &x1) __attribute__((always_inline)) {
+    // per-row scalars of a tile: the point ids are needed first (table rows of layer 0: fetched into pid_n during the previous tile's last pass),
+    // the aggregation weights (layer 3) and the extras (layer 1) only later: they are fetched in pass (0, 1) of their own tile
+    auto load_ids = [&](int tile, int (&pd)[4]) __attribute__((always_inline)) {
         const char *aux = a.aux + (size_t)tile * 4 * CH_AUX_GROUP;
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) {
-            pd[rt] = reinterpret_cast<const int32_t *>(aux + rt * CH_AUX_GROUP)[j];
-            wd[rt] = reinterpret_cast<const float *>(aux + rt * CH_AUX_GROUP + 128)[j];
-        }
-        x0 = *reinterpret_cast<const float4 *>(aux + wave * CH_AUX_GROUP + 256 + j * 32);     // extras of the rows this wave publishes (row tile = wave)
-        x1 = *reinterpret_cast<const float4 *>(aux + wave * CH_AUX_GROUP + 256 + j * 32 + 16);
+        for (int rt = 0; rt < 4; ++rt) pd[rt] = reinterpret_cast<const int32_t *>(aux + rt * CH_AUX_GROUP)[j];
+    };
+    auto load_rest = [&](int tile) __attribute__((always_inline)) {
+        const char *aux = a.aux + (size_t)tile * 4 * CH_AUX_GROUP;
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) wq[rt] = reinterpret_cast<const float *>(aux + rt * CH_AUX_GROUP + 128)[j];
+        e0 = *reinterpret_cast<const float4 *>(aux + wave * CH_AUX_GROUP + 256 + j * 32);     // extras of the rows this wave publishes (row tile = wave)
+        e1 = *reinterpret_cast<const float4 *>(aux + wave * CH_AUX_GROUP + 256 + j * 32 + 16);
     };
     // layer-0 operand image of (tile, row tile rt): 8 chunks of 1 KiB (k step s = c >> 1, plane p = c & 1), this wave moves chunks wave, 4 + wave
     auto xp_src = [&](int tile, int rt, int i) __attribute__((always_inline)) { return a.xp + ((size_t)tile * 4 + rt) * CH_XP_GROUP + (i * 4 + wave) * 1024 + lane * 16; };
 
     // ---- prologue: first tile's row scalars, layer-0 images of row tiles 0..2 (row tile 3 is staged by pass (0,0) like in every later tile),
     //      layer-0 weights
-    load_aux(t_first, pid, wq, e0, e1);
+    load_ids(t_first, pid);
 #pragma unroll
     for (int rt = 0; rt < 3; ++rt)
 #pragma unroll
         for (int i = 0; i < 2; ++i) CW_LDS(u32x4, o_xp + i * 2 * SLOT + rt * 2048) = *reinterpret_cast<const u32x4 *>(xp_src(t_first, rt, i));
+    {
+        const float *trow = a.ptab + (size_t)(pid[0] < 0 ? 0 : pid[0]) * a.ldt + col0;
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) tv[0][cc][q] = *reinterpret_cast<const float4 *>(trow + 32 * cc + 4 * q);
+    }
     CW_LOAD_W(0, 0); CW_LOAD_W(0, 1); CW_LOAD_W(0, 2); CW_LOAD_W(0, 3);
     cw_wait_vm<0>();
     __syncthreads();
@@ -149,7 +160,7 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
     const float inv0 = __fmul_rn(pow2f(-14), meta[CH_META_DESCALE]), dw1 = meta[CH_META_DESCALE + 1], dw2 = meta[CH_META_DESCALE + 2], dw3 = meta[CH_META_DESCALE + 3],
                 alpha_b = meta[4 * 256 + 256];
     float amax = 0.f, ap = 0.f, sc_run = 1.f;                               // epilogue state carried between the pieces of one pass
-    f32x2 bias[8], aw[8];
+    f32x2 bias_c = {0.f, 0.f}, bias_n = {0.f, 0.f}, aw_c = {0.f, 0.f};     // constants of the running item (read from LDS one micro-stage ahead)
     unsigned ph[8], pm[8];
     float s1x = 0.f, s1y = 0.f, s1a = 0.f, s1b = 0.f;                       // values handed from an item's first micro-stage to its second
     unsigned s1h = 0u;
@@ -165,38 +176,38 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
         const int T = 6 * S, H = T / 2, se = PR & 1;
         const int exb = (PR & 1) * 512;
         const float inv_l = PL == 0 ? inv0 : inv[PR];
-        auto read_cst = [&](int c, int q4) __attribute__((always_inline)) {
-            const float4 b = (DBG == 5 || DBG == 7) ? make_float4(a.slope, 1.f, 2.f, 3.f) : CW_AT(const float4, q_cst, PL * 1024 + c * 128 + q4 * 16);
-            bias[2 * q4] = f32x2{b.x, b.y}; bias[2 * q4 + 1] = f32x2{b.z, b.w};
-            if (PL == 3) {
-                const float4 w4 = (DBG == 5 || DBG == 7) ? make_float4(a.slope, 1.f, 2.f, 3.f) : CW_AT(const float4, q_cst, 4 * 1024 + c * 128 + q4 * 16);
-                aw[2 * q4] = f32x2{w4.x, w4.y}; aw[2 * q4 + 1] = f32x2{w4.z, w4.w};
-            }
+        // bias pair of item `it` (and for layer 3 its alpha weights): 8 B each from the LDS copy of the constants
+        auto read_bias = [&](int it) __attribute__((always_inline)) {
+            return (DBG == 5 || DBG == 7) ? f32x2{a.slope, 1.f} : CW_AT(const f32x2, q_cst, PL * 1024 + (it >> 3) * 128 + (it & 7) * 8);
+        };
+        auto read_aw = [&](int it) __attribute__((always_inline)) {
+            return (DBG == 5 || DBG == 7) ? f32x2{a.slope, 1.f} : CW_AT(const f32x2, q_cst, 4 * 1024 + (it >> 3) * 128 + (it & 7) * 8);
         };
         if (slot < H) {
-            // -- first half.  micro-stage 0: constants of column tile 0; 1 + 2 i, 2 + 2 i: item i = (c, q), two values each; the constants of
-            //    (column tile 1, q4) are read once the items (0, 2 q4), (0, 2 q4 + 1) that used the registers are through; 33: row maximum / alpha
-            //    partial -> exchange buffer
+            // -- first half.  micro-stage 0: bias of item 0; 1 + 2 i, 2 + 2 i: item i = (c, q), two values each (the first stage also asks for
+            //    the next item's bias and, in layer 3, this item's alpha weights); 33: row maximum / alpha partial -> exchange buffer
             const int MS = 34, m0 = slot * MS / H, m1 = (slot + 1) * MS / H;
 #pragma unroll
             for (int ms = m0; ms < m1; ++ms) {
                 if (ms == 0) {
                     amax = 0.f; ap = 0.f;
-#pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4) read_cst(0, q4);
+                    bias_n = read_bias(0);
                 } else if (ms < 33) {
                     const int it = (ms - 1) >> 1, st = (ms - 1) & 1, c = it >> 3, q = it & 7;
                     if (st == 0) {
                         // scalar fp32 VALU on purpose: packed fp32 instructions (v_pk_fma_f32 ...) do not overlap with this wave's MFMAs -- one
                         // of them behind an MFMA costs 18 cycles of matrix-pipe time, a v_fma_f32 none (tools/interleave_probe.hip)
-                        float ax = bias[q].x, ay = bias[q].y;
-                        if (PL == 0) { const float4 t4 = tv[c][q >> 1]; ax = __fadd_rn(ax, (q & 1) ? t4.z : t4.x); ay = __fadd_rn(ay, (q & 1) ? t4.w : t4.y); }
+                        bias_c = bias_n;
+                        if (it + 1 < 16) bias_n = read_bias(it + 1);
+                        if (PL == 3) aw_c = read_aw(it);
+                        float ax = bias_c.x, ay = bias_c.y;
+                        if (PL == 0) { const float4 t4 = tv[PR & 1][c][q >> 1]; ax = __fadd_rn(ax, (q & 1) ? t4.z : t4.x); ay = __fadd_rn(ay, (q & 1) ? t4.w : t4.y); }
                         s1x = fmaf(acc[se][c][2 * q], inv_l, ax); s1y = fmaf(acc[se][c][2 * q + 1], inv_l, ay);
                         s1a = __fmul_rn(s1x, a.slope); s1b = __fmul_rn(s1y, a.slope);
                     } else {
                         const float vx = fmaxf(s1x, s1a), vy = fmaxf(s1y, s1b);
                         acc[se][c][2 * q] = vx; acc[se][c][2 * q + 1] = vy;
-                        if (PL == 3) { ap = fmaf(vx, aw[q].x, ap); ap = fmaf(vy, aw[q].y, ap); }
+                        if (PL == 3) { ap = fmaf(vx, aw_c.x, ap); ap = fmaf(vy, aw_c.y, ap); }
                         else amax = fmaxf(fmaxf(amax, fabsf(vx)), fabsf(vy));
                         if (DBG == 1) {
                             if (a.dbg && a.dbg_layer == PL && tile_e >= 0) {
@@ -204,7 +215,6 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
                                 o[0] = vx; o[1] = vy;
                             }
                         }
-                        if (c == 0 && (q & 1)) read_cst(1, q >> 1);
                     }
                 } else {
                     float m;
@@ -333,19 +343,25 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
 #pragma unroll
                 for (int i = 0; i < 2; ++i) xv[i] = *reinterpret_cast<const u32x4 *>(xp_src(tile_stage, PR, i));
             }
-            if (P == 15 && tile_next < t_end) load_aux(tile_next, pid_n, wq_n, e0_n, e1_n);
+            if (P == 15 && tile_next < t_end) load_ids(tile_next, pid_n);
+            if (P == 1) load_rest(tile);                                   // (pass (0, 0) still reads the previous tile's weight of row tile 3: wq_fin)
             __builtin_amdgcn_sched_barrier(0);
             cw_static_for<6 * S>([&](auto kc) __attribute__((always_inline)) {
                 // one piece per MFMA: slot = 6 s + 2 g + c (k step s, term g, column tile c)
                 constexpr int slot = decltype(kc)::value, s = slot / 6, g = (slot % 6) >> 1, c = slot & 1;
                 if (slot == H) {
                     cw_lds_barrier();
-                    if (L == 0) {                                           // the previous row tile's table rows were consumed in the first half
-                        const float *trow = a.ptab + (size_t)(pid[rt] < 0 ? 0 : pid[rt]) * a.ldt + col0;
+                    // layer 0's table rows are asked for one and a half passes before their epilogue: row tile rt + 1 at the barrier of pass
+                    // (0, rt) -- the set it goes into was consumed in this pass's first half --, the next tile's row tile 0 at the barrier of (3, 3)
+                    if ((L == 0 && rt < 3) || (L == 3 && rt == 3)) {
+                        const int pr = L == 0 ? pid[rt < 3 ? rt + 1 : 0] : pid_n[0];
+                        if (L == 0 || tile_next < t_end) {
+                            const float *trow = a.ptab + (size_t)(pr < 0 ? 0 : pr) * a.ldt + col0;
 #pragma unroll
-                        for (int cc = 0; cc < 2; ++cc)
+                            for (int cc = 0; cc < 2; ++cc)
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) tv[cc][q] = *reinterpret_cast<const float4 *>(trow + 32 * cc + 4 * q);
+                                for (int q = 0; q < 4; ++q) tv[L == 0 ? (rt + 1) & 1 : 0][cc][q] = *reinterpret_cast<const float4 *>(trow + 32 * cc + 4 * q);
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -382,8 +398,7 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
         wq_fin = wq[3]; tile_fin = tile;
         wq_sig = wave == 0 ? wq[0] : wave == 1 ? wq[1] : wave == 2 ? wq[2] : wq[3];
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) { pid[rt] = pid_n[rt]; wq[rt] = wq_n[rt]; }
-        e0 = e0_n; e1 = e1_n;
+        for (int rt = 0; rt < 4; ++rt) pid[rt] = pid_n[rt];
     }
     // ---- drain: the last tile's layer-3 epilogue of row tile 3
     CW_REFRESH();

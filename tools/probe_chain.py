@@ -15,7 +15,7 @@ X5 = torch.empty((nv, 280), dtype=torch.float32, device=dev); sg = torch.empty((
 ptab = W["rnd"].point_table(W["cloud"]); q = W["q"]; c = W["cloud"]
 _lib.check(L.hnr_chain_gather(p(c.xyz), p(c.conf), p(c.dir), p(c.color), p(q["sample_pidx"]), p(q["sample_loc_w"]), p(W["raydir"]), p(W["campos"]),
                               p(W["camrot"]), p(W["vs_item"]), p(q["counts"]), W["SR"], W["K"], nv, p(ws), p(X5), 280, None, None, _lib.stream()), "g")
-NW = 8 if os.environ.get('HNR_CHAIN_RT', '4') == '8' else 4          # waves per workgroup: 8 in the dual-group kernel (default)
+NW = 8 if os.environ.get('HNR_CHAIN_RT', '16') == '8' else 4          # waves per workgroup: 8 in the dual-group kernel (default)
 dbg = torch.zeros(((NW * 16 + 4 * 1024 + 64) * 2,), dtype=torch.float32, device=dev)
 pk = W["agg"].packed_chain()
 MODE = -int(os.environ.get('PROBE_MODE', '1'))          # -1: phase timing; -3 / -4 / -5 (dual-group kernel only): no epilogue work / same weights / both
@@ -26,7 +26,7 @@ for it in range(3):
     e1.record(); torch.cuda.synchronize()
     print("chain_forward %.3f ms, %d valid samples, %d tiles" % (e0.elapsed_time(e1), nv, (nv + 15) // 16))
 allv = dbg.view(torch.int64).cpu().numpy()
-if os.environ.get('HNR_CHAIN_RT') == '16':
+if os.environ.get('HNR_CHAIN_RT', '16') == '16':
     blk = allv[:4 * 1024].reshape(-1, 4); blk = blk[blk[:, 2] > 0]
     t = allv[4 * 1024:4 * 1024 + 64].reshape(4, 16)
     print('blocks %d: cycles/tile mean %.0f, GHz %.3f' % (len(blk), (blk[:, 0] / blk[:, 2]).mean(), (blk[:, 0] / blk[:, 1]).mean() * 0.1))
