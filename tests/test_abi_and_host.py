@@ -339,3 +339,35 @@ def test_three_bf16_terms_represent_fp32_exactly():
     f = lambda a: a.astype(np.float64)
     kept = f(h) * f(wh) + f(h) * f(wm) + f(m) * f(wh) + f(h) * f(wl) + f(m) * f(wm) + f(l) * f(wh)
     assert np.all(np.abs(f(x) * f(w) - kept) <= np.abs(f(x) * f(w)) * 2.0 ** -23 + 1e-300)
+
+
+def test_ctypes_structs_have_the_layout_of_the_c_header(tmp_path):
+    """Every struct that crosses the boundary by pointer: size and the offset of every field as a C compiler lays out include/hnr.h
+    (gcc, plain C -- the header is the contract a cgo / JNI / ctypes binding is written against) equal the ctypes mirror in _lib.py."""
+    import ctypes
+    import shutil
+    import subprocess
+    from hybridneuralrendering_amd import _lib
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    pairs = [("hnr_grid_params", _lib.GridParams), ("hnr_query_params", _lib.QueryParams), ("hnr_render_params", _lib.RenderParams),
+             ("hnr_render_cloud", _lib.RenderCloud), ("hnr_render_weights", _lib.RenderWeights), ("hnr_render_camera", _lib.RenderCamera),
+             ("hnr_render_views", _lib.RenderViews), ("hnr_render_outputs", _lib.RenderOutputs)]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "hnr.h"', 'int main(void) {']
+    for cname, cls in pairs:
+        lines.append('  printf("%s size %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in cls._fields_:
+            lines.append('  printf("%s %s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = {}
+    for ln in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines():
+        a, b, c = ln.split()
+        got[(a, b)] = int(c)
+    for cname, cls in pairs:
+        assert got[(cname, "size")] == ctypes.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert got[(cname, fname)] == getattr(cls, fname).offset, (cname, fname)
