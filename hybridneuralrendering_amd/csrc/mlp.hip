@@ -83,10 +83,14 @@ __global__ __launch_bounds__(256, (MODE == 1 || RT < 4) ? 2 : 1) void mlp3_kerne
     float *s_f = rowinv + ROWS;
     int *s_pix = reinterpret_cast<int *>(s_f + 128 * 48);
     float *s_vm = reinterpret_cast<float *>(s_pix + 128), *s_w = s_vm + 128;
+    float *s_wl = s_w + 128;                                               // MODE 1: the last merge-weight layer's 64 weights (+ zero padding to 128)
     const int col0 = 32 * wave + 16 * h;                                   // this lane's columns: col0 + r
     const unsigned woff = (unsigned)wave * 2048u + (unsigned)lane * 16u;
     const f32x2 slope2 = {a.slope, a.slope};
 
+    if (MODE == 1) {                                                       // (the first tile's prologue barriers order this before its first use)
+        for (int i = tid; i < 128; i += 256) s_wl[i] = i < a.N[2] ? a.w_last[i] : 0.f;
+    }
 #ifdef HNR_MLP_PROBE
     long long tm_[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tp_ = clock64(), ntile_ = 0;
 #endif
@@ -270,7 +274,7 @@ __global__ __launch_bounds__(256, (MODE == 1 || RT < 4) ? 2 : 1) void mlp3_kerne
                 bias[2 * q] = f32x2{b.x, b.y}; bias[2 * q + 1] = f32x2{b.z, b.w};
             }
             const bool act = a.act[layer] != 0;
-            if (ADD) { load_addend(0); if (RT > 1) load_addend(1); }
+            if (ADD && MODE != 1) { load_addend(0); if (RT > 1) load_addend(1); }          // (the merge stage asks for them under its layer-0 MFMAs)
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
                 float m = 0.f;
@@ -339,7 +343,7 @@ __global__ __launch_bounds__(256, (MODE == 1 || RT < 4) ? 2 : 1) void mlp3_kerne
         // ---- layer 0
         zero_acc();
         if (act0) {
-            h2_mfma_layer<RT, 1, S0, 0, ML_WSTEP, SLOT>(wsrd, a.wbase[0], woff, lds, lane, acc, []() {}, H2NoHook());
+            h2_mfma_layer<RT, 1, S0, 0, ML_WSTEP, SLOT>(wsrd, a.wbase[0], woff, lds, lane, acc, []() {}, [&]() { if (MODE == 1) { load_addend(0); load_addend(1); } });
             MLP_STAMP(3);
             if (a.R) activate(0, amax, std::true_type{}); else activate(0, amax, std::false_type{});
             MLP_STAMP(4);
@@ -377,7 +381,7 @@ __global__ __launch_bounds__(256, (MODE == 1 || RT < 4) ? 2 : 1) void mlp3_kerne
                 cfv[it] = (idx < 32 * 45 && sidx * 4 < M) ? a.CF[(size_t)sidx * a.ldcf + ch] : 0.f;
             }
 #pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) wl4[q4] = *reinterpret_cast<const float4 *>(a.w_last + (act2 ? col0 : 0) + 4 * q4);
+            for (int q4 = 0; q4 < 4; ++q4) wl4[q4] = *reinterpret_cast<const float4 *>(s_wl + col0 + 4 * q4);
         }
         if (MODE == 1) {
             // ---- last layer of aux_merge_weight_block (64 -> 1) + sigmoid, validity / frame weights (:1199), weighted merge over the 4 views
@@ -641,7 +645,7 @@ extern "C" int hnr_merge_stage(const float *d_sample_loc_w, const int32_t *d_vs_
     }
     const int64_t tiles = ((int64_t)cap_samples * 4 + 127) / 128;
     const int grid = (int)(tiles < 2 * n_cu ? tiles : 2 * n_cu);
-    constexpr int ldsb = 4 * ML_SLOT + 128 * 4 * 4 + 128 * 4 + 128 * 48 * 4 + 3 * 128 * 4;
+    constexpr int ldsb = 4 * ML_SLOT + 128 * 4 * 4 + 128 * 4 + 128 * 48 * 4 + 3 * 128 * 4 + 128 * 4;
     static bool attr = false;
     if (!attr) { HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(mlp3_kernel<3, 4, 4, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb)); attr = true; }
     mlp3_kernel<3, 4, 4, 0, 1><<<grid, 256, ldsb, (hipStream_t)stream>>>(a);
