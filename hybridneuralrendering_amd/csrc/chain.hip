@@ -663,6 +663,8 @@ __device__ __forceinline__ void chain_w2pers(const float *p, const float *campos
     out[0] = __fdiv_rn(c[0], c[2]); out[1] = __fdiv_rn(c[1], c[2]); out[2] = c[2];
 }
 
+typedef float f32x4g __attribute__((ext_vector_type(4)));
+
 __global__ __launch_bounds__(256) void chain_gather_kernel(ChainGatherArgs a)
 {
     __shared__ float s_d[128][8];                        // dists6 per row
@@ -709,10 +711,10 @@ __global__ __launch_bounds__(256) void chain_gather_kernel(ChainGatherArgs a)
         const float w = pid >= 0 ? __fdiv_rn(wraw, fmaxf(sum, 1e-8f)) : 0.f;
 #pragma unroll
         for (int i = 0; i < 6; ++i) s_d[tid][i] = d6[i];
-        reinterpret_cast<int32_t *>(aux)[jr] = pid;
-        reinterpret_cast<float *>(aux + 128)[jr] = __fmul_rn(w, confc);
-        *reinterpret_cast<float4 *>(aux + 256 + jr * 32) = make_float4(ext[0], ext[1], ext[2], ext[3]);
-        *reinterpret_cast<float4 *>(aux + 256 + jr * 32 + 16) = make_float4(ext[4], ext[5], ext[6], 0.f);
+        __builtin_nontemporal_store(pid, reinterpret_cast<int32_t *>(aux) + jr);
+        __builtin_nontemporal_store(__fmul_rn(w, confc), reinterpret_cast<float *>(aux + 128) + jr);
+        __builtin_nontemporal_store(f32x4g{ext[0], ext[1], ext[2], ext[3]}, reinterpret_cast<f32x4g *>(aux + 256 + jr * 32));
+        __builtin_nontemporal_store(f32x4g{ext[4], ext[5], ext[6], 0.f}, reinterpret_cast<f32x4g *>(aux + 256 + jr * 32 + 16));
         if (a.weight_out && pid >= 0) { a.weight_out[(size_t)item * 8 + kk] = w; a.conf_out[(size_t)item * 8 + kk] = confc; }
     } else if (tid < 128 + 64) {
         // view-direction encoding: positional_encoding(viewdirs, 4, ori=True)[3:] = [sin(d*4+f) x12 | cos x12]; 6 values per thread
@@ -748,9 +750,11 @@ __global__ __launch_bounds__(256) void chain_gather_kernel(ChainGatherArgs a)
             }
             split2h(__fmul_rn(sv, 16384.f), __fmul_rn(cv, 16384.f), ph[e], pm[e]);
         }
+        // streaming (nt) stores: the 6.7 GB image is written once here and read once by the chain kernel; with the default policy the kernel
+        // ran at 4.1 TB/s of writes (3.44 ms on the 3.5 M-sample probe frame), with nt stores 2.60 ms
         char *dst = xp + (s * 2) * 1024 + L * 16;
-        *reinterpret_cast<u32x4 *>(dst) = u32x4{ph[0], ph[1], ph[2], ph[3]};
-        *reinterpret_cast<u32x4 *>(dst + 1024) = u32x4{pm[0], pm[1], pm[2], pm[3]};
+        __builtin_nontemporal_store(u32x4{ph[0], ph[1], ph[2], ph[3]}, reinterpret_cast<u32x4 *>(dst));
+        __builtin_nontemporal_store(u32x4{pm[0], pm[1], pm[2], pm[3]}, reinterpret_cast<u32x4 *>(dst + 1024));
     }
     __syncthreads();                                     // s_d is rewritten by the next pass
     }

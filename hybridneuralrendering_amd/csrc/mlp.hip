@@ -39,6 +39,8 @@ struct MlpArgs {
     float *C; int ldc;                 // [M, ldc] output rows (N[2] columns)
 };
 
+typedef float f32x4m __attribute__((ext_vector_type(4)));
+
 #ifdef HNR_MLP_PROBE
 __device__ long long g_mlp_probe[24];
 #define MLP_STAMP(i_) do { const long long t_ = clock64(); tm_[i_] += t_ - tp_; tp_ = t_; if ((i_) == 0) ++ntile_; } while (0)
@@ -418,8 +420,8 @@ __global__ __launch_bounds__(256, (MODE == 1 || RT < 4) ? 2 : 1) void mlp3_kerne
 #pragma unroll
                         for (int v = 0; v < 4; ++v) { const float wv = s_w[4 * ls + v]; fsum += s_f[(4 * ls + v) * 48 + ch] * wv; wsum += wv; }
                         float *o = a.X7 + (size_t)sidx * a.ld7;
-                        o[ch] = cfv[it];
-                        o[45 + ch] = fsum / (wsum + 1e-6f);
+                        __builtin_nontemporal_store(cfv[it], o + ch);
+                        __builtin_nontemporal_store(fsum / (wsum + 1e-6f), o + 45 + ch);
                     }
                 }
                 MLP_STAMP(17);

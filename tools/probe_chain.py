@@ -16,6 +16,14 @@ ptab = W["rnd"].point_table(W["cloud"]); q = W["q"]; c = W["cloud"]
 _lib.check(L.hnr_chain_gather(p(c.xyz), p(c.conf), p(c.dir), p(c.color), p(q["sample_pidx"]), p(q["sample_loc_w"]), p(W["raydir"]), p(W["campos"]),
                               p(W["camrot"]), p(W["vs_item"]), p(q["counts"]), W["SR"], W["K"], nv, p(ws), p(X5), 280, None, None, _lib.stream()), "g")
 NW = 8 if os.environ.get('HNR_CHAIN_RT', '16') == '8' else 4          # waves per workgroup: 8 in the dual-group kernel (default)
+for it in range(2):
+    g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    g0.record()
+    for _ in range(5):
+        _lib.check(L.hnr_chain_gather(p(c.xyz), p(c.conf), p(c.dir), p(c.color), p(q["sample_pidx"]), p(q["sample_loc_w"]), p(W["raydir"]), p(W["campos"]),
+                                      p(W["camrot"]), p(W["vs_item"]), p(q["counts"]), W["SR"], W["K"], nv, p(ws), p(X5), 280, None, None, _lib.stream()), "g")
+    g1.record(); torch.cuda.synchronize()
+print("chain_gather %.3f ms per launch" % (g0.elapsed_time(g1) / 5))
 dbg = torch.zeros(((NW * 16 + 4 * 1024 + 64) * 2,), dtype=torch.float32, device=dev)
 pk = W["agg"].packed_chain()
 MODE = -int(os.environ.get('PROBE_MODE', '1'))          # -1: phase timing; -3 / -4 / -5 (dual-group kernel only): no epilogue work / same weights / both
