@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
             }
             if (PL == 3 && tile_stage < t_end) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) xv[i] = *reinterpret_cast<const u32x4 *>(xp_src(tile_stage, PR, i));
+                for (int i = 0; i < 2; ++i) xv[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(xp_src(tile_stage, PR, i)));      // read once
             }
             if (P == 15 && tile_next < t_end) load_ids(tile_next, pid_n);
             if (P == 1) load_rest(tile);                                   // (pass (0, 0) still reads the previous tile's weight of row tile 3: wq_fin)
