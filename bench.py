@@ -398,10 +398,12 @@ def main():
             flops_nb = 2.0 * n_rows * 256 * (284 + 256 + 263 + 256)
             ms_ch = stage_ms.get("chain", 0.0)
             if fused and ms_ch > 0:
-                # dominant kernel: the fused per-neighbour chain (csrc/chain.hip), ONE launch per frame.  Rows are padded to K = 8 slots
-                # per valid sample and to whole 128-row tiles; every fp32 product is issued as THREE fp16 MFMA products (two-term
-                # operand split), K rounded up to 16 per layer (60 -> 64, 263 -> 272).
-                rows_pad = 128 * ((n_valid + 15) // 16)
+                # dominant kernel: the fused per-neighbour chain (csrc/chain_ws.hip), ONE launch per frame.  Rows are padded to 8 slots
+                # per valid sample with more than four neighbours, 4 slots for the others (hnr_chain_plan's two classes), and to whole
+                # 128-row tiles per class; every fp32 product is issued as THREE fp16 MFMA products (two-term operand split), K rounded
+                # up to 16 per layer (60 -> 64, 263 -> 272).
+                n_small = int(counts[CNT["SAMPLES_SMALL"]])
+                rows_pad = 128 * ((n_valid - n_small + 15) // 16 + (n_small + 31) // 32)
                 issued = 3.0 * 2.0 * rows_pad * 256 * (64 + 256 + 272 + 256)
                 alg = 2.0 * n_rows * 256 * (60 + 256 + 263 + 256) + 2.0 * n_rows * 256          # executed layers + alpha branch (SURVEY 8d counts 284 columns
                 ach = issued / (ms_ch * 1e-3) / 1e12                                             # for block1.0: 224 of them live in the per-point table)
@@ -422,8 +424,9 @@ def main():
                             note="achieved = 16-bit MFMA flops issued (3 per fp32 product: wm*xh + wh*xm + wh*xh, fp16 two-term split with exact power-of-two "
                                  "row / layer scales, fp32 accumulate) / HIP-event time of the launch, against the 2.5 PFLOP/s dense 16-bit peak; "
                                  "frac_algorithmic = 2 M N K fp32 flops of the four layers on the VALID rows / time / the same peak; algorithmic bytes = "
-                                 "168 B per valid neighbour (SURVEY 8d) + 1028 B of sums per valid sample; padding to 8 slots per sample costs "
-                                 "%.1f %% extra rows" % (100.0 * (rows_pad / max(n_rows, 1) - 1.0)),
+                                 "168 B per valid neighbour (SURVEY 8d) + 1028 B of sums per valid sample; padding to 8 row slots per sample "
+                                 "(4 for the %d samples with at most four neighbours) costs %.1f %% extra rows" % (
+                                     n_small, 100.0 * (rows_pad / max(n_rows, 1) - 1.0)),
                             neighbour_stage=dict(chain_ms=round(ms_ch, 3), gather_ms=round(stage_ms.get("chain_gather", 0.0), 3)))
             elif split and ms_3 > 0:
                 # dominant kernel: the split-bf16 dense layer.  Algorithmic fp32 flops of the three layers = 2 M N K; the kernel

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # HNR_LIB_PATH: another build of the same library (A/B timing of kernel changes); there is no other fallback
 LIB_PATH = os.environ.get("HNR_LIB_PATH") or os.path.join(_HERE, "libhnr_hip.so")
 NCOUNTS = 8
-CNT = dict(RAYS_HIT=0, SAMPLES=1, RAYS_VALID=2, NEIGHBOURS=3, CELLS_VISITED=4, CANDIDATES=5, SAMPLES_VALID=6)
+CNT = dict(RAYS_HIT=0, SAMPLES=1, RAYS_VALID=2, NEIGHBOURS=3, CELLS_VISITED=4, CANDIDATES=5, SAMPLES_VALID=6, SAMPLES_SMALL=7)
 
 
 class HnrError(RuntimeError):
@@ -108,6 +108,8 @@ SIGNATURES = {
     "hnr_chain_workspace_bytes": (ctypes.c_int64, [_I]),
     "hnr_chain_pack": (_I, [_P, _I] + [_P] * 9 + [_P, _P]),
     "hnr_chain_gather": (_I, [_P] * 11 + [_I, _I, _I, _P, _P, _I, _P, _P, _P]),
+    "hnr_chain_classes": (_I, []),
+    "hnr_chain_plan": (_I, [_P, _P, _P, _I, _I, _I, _P, _I, _P, _P]),
     "hnr_chain_forward": (_I, [_P, _P, _I, _P, _P, _I, _F, _P, _I, _P, _P, _I, _P]),
     "hnr_mlp3_packed_bytes": (ctypes.c_int64, [_I, ctypes.POINTER(_I)]),
     "hnr_mlp3_pack": (_I, [_I, ctypes.POINTER(_P), ctypes.POINTER(_I), ctypes.POINTER(_I), ctypes.POINTER(_I), ctypes.POINTER(_P), _P, _P]),

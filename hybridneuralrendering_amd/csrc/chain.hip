@@ -668,13 +668,16 @@ typedef float f32x4g __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void chain_gather_kernel(ChainGatherArgs a)
 {
     __shared__ float s_d[128][8];                        // dists6 per row
-    int n_valid = (int)a.counts[HNR_CNT_SAMPLES_VALID];
-    if (n_valid > a.cap_samples) n_valid = a.cap_samples;
+    const ChainClasses cls = chain_classes(a.counts, a.cap_samples);
+    const int n_valid = cls.n_valid;
     const int tid = threadIdx.x;
-    for (int blk = blockIdx.x; blk * 16 < n_valid; blk += gridDim.x) {       // 16 samples = 4 groups per pass; the grid is sized from the capacity
+    for (int blk = blockIdx.x; blk < cls.n_tiles; blk += gridDim.x) {         // one 128-row tile = 4 groups per pass; the grid is sized from the capacity
+    // first class: 16 samples x 8 slots; second class (<= 4 neighbours, hnr_chain_plan): 32 samples x 4 slots
+    const bool small = blk >= cls.big_tiles;
+    const int s_base = small ? cls.n_big + 32 * (blk - cls.big_tiles) : 16 * blk, s_end = small ? n_valid : cls.n_big;
     if (tid < 128) {
-        const int ls = tid >> 3, kk = tid & 7;
-        const int s = blk * 16 + ls;
+        const int ls = small ? tid >> 2 : tid >> 3, kk = small ? tid & 3 : tid & 7;
+        const int s = s_base + ls;
         char *aux = a.aux + (size_t)(blk * 4 + (tid >> 5)) * CH_AUX_GROUP;
         const int jr = tid & 31;
         const float cp[3] = {a.campos[0], a.campos[1], a.campos[2]};
@@ -682,7 +685,7 @@ __global__ __launch_bounds__(256) void chain_gather_kernel(ChainGatherArgs a)
 #pragma unroll
         for (int i = 0; i < 9; ++i) cr[i] = a.camrot[i];
         int pid = -1, item = 0;
-        if (s < n_valid) { item = a.vs_item[s]; pid = a.pidx[(size_t)item * 8 + kk]; }
+        if (s < s_end) { item = a.vs_item[s]; pid = a.pidx[(size_t)item * 8 + kk]; }
         float wraw = 0.f, confc = 0.f, ext[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, d6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (pid >= 0) {
             const float *lw = a.loc_w + (size_t)item * 3;
@@ -707,7 +710,8 @@ __global__ __launch_bounds__(256) void chain_gather_kernel(ChainGatherArgs a)
             ext[6] = __fadd_rn(__fadd_rn(__fmul_rn(ddx, vx), __fmul_rn(ddy, vy)), __fmul_rn(ddz, vz));
         }
         float sum = wraw;
-        sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4);
+        sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2);
+        { const float s4 = __shfl_xor(sum, 4); sum += small ? 0.f : s4; }   // (a sample of the second class: 4 lanes)
         const float w = pid >= 0 ? __fdiv_rn(wraw, fmaxf(sum, 1e-8f)) : 0.f;
 #pragma unroll
         for (int i = 0; i < 6; ++i) s_d[tid][i] = d6[i];
@@ -716,11 +720,11 @@ __global__ __launch_bounds__(256) void chain_gather_kernel(ChainGatherArgs a)
         __builtin_nontemporal_store(f32x4g{ext[0], ext[1], ext[2], ext[3]}, reinterpret_cast<f32x4g *>(aux + 256 + jr * 32));
         __builtin_nontemporal_store(f32x4g{ext[4], ext[5], ext[6], 0.f}, reinterpret_cast<f32x4g *>(aux + 256 + jr * 32 + 16));
         if (a.weight_out && pid >= 0) { a.weight_out[(size_t)item * 8 + kk] = w; a.conf_out[(size_t)item * 8 + kk] = confc; }
-    } else if (tid < 128 + 64) {
+    } else if (tid < 128 + (small ? 128 : 64)) {
         // view-direction encoding: positional_encoding(viewdirs, 4, ori=True)[3:] = [sin(d*4+f) x12 | cos x12]; 6 values per thread
         const int t = tid - 128, ls = t >> 2, part = t & 3;
-        const int s = blk * 16 + ls;
-        if (s < n_valid) {
+        const int s = s_base + ls;
+        if (s < s_end) {
             const int ray = a.vs_item[s] / a.SR;
             float *o = a.X5 + (size_t)s * a.ld5 + 256;
 #pragma unroll
@@ -824,6 +828,86 @@ __global__ void chain_pack_kernel(ChainPackArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// hnr_chain_plan: the chain's list of valid samples.  Two-level scan over the kept-sample work list (no atomics, deterministic), like
+// hnr_sample_plan; with `classes` the samples with more than 4 neighbours come first, those with 1..4 after them (stable in both).
+__device__ __forceinline__ int chain_count_neighbours(const int32_t *__restrict__ p, int K)
+{
+    int n = 0;                                        // valid ids are a prefix (reference :494-496)
+    while (n < K && p[n] >= 0) ++n;
+    return n;
+}
+
+__global__ __launch_bounds__(1024) void chain_plan_sum_kernel(const int32_t *__restrict__ work, const int32_t *__restrict__ pidx,
+                                                              const unsigned long long *__restrict__ counts, int K, int classes,
+                                                              int32_t *__restrict__ block_sums)
+{
+    __shared__ int s_a[16], s_b[16];
+    const int n_items = (int)counts[HNR_CNT_SAMPLES];
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    const int nb = i < n_items ? chain_count_neighbours(pidx + (size_t)work[i] * K, K) : 0;
+    int big = (nb > 4 || (nb > 0 && !classes)) ? 1 : 0, small = (nb > 0 && !big) ? 1 : 0;
+    for (int o = 32; o > 0; o >>= 1) { big += __shfl_xor(big, o); small += __shfl_xor(small, o); }
+    if ((threadIdx.x & 63) == 0) { s_a[threadIdx.x >> 6] = big; s_b[threadIdx.x >> 6] = small; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int a = 0, b = 0;
+        for (int k = 0; k < 16; ++k) { a += s_a[k]; b += s_b[k]; }
+        block_sums[2 * blockIdx.x] = a;
+        block_sums[2 * blockIdx.x + 1] = b;
+    }
+}
+
+__global__ __launch_bounds__(1024) void chain_plan_scan_kernel(const int32_t *__restrict__ work, const int32_t *__restrict__ pidx,
+                                                               unsigned long long *__restrict__ counts, int K, int classes,
+                                                               const int32_t *__restrict__ block_sums, int n_blocks,
+                                                               int32_t *__restrict__ vs_item, int cap_samples)
+{
+    __shared__ int s_a[16], s_b[16], s_t[16];
+    __shared__ int s_base[3];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int n_items = (int)counts[HNR_CNT_SAMPLES];
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    int pa = 0, pb = 0, ta = 0;                       // big / small samples in the blocks before this one; big samples in all blocks
+    for (int k = threadIdx.x; k < n_blocks; k += 1024) {
+        const int a = block_sums[2 * k], b = block_sums[2 * k + 1];
+        ta += a;
+        if (k < (int)blockIdx.x) { pa += a; pb += b; }
+    }
+    for (int o = 32; o > 0; o >>= 1) { pa += __shfl_xor(pa, o); pb += __shfl_xor(pb, o); ta += __shfl_xor(ta, o); }
+    if (lane == 0) { s_a[wid] = pa; s_b[wid] = pb; s_t[wid] = ta; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int a = 0, b = 0, t = 0;
+        for (int k = 0; k < 16; ++k) { a += s_a[k]; b += s_b[k]; t += s_t[k]; }
+        s_base[0] = a; s_base[1] = b; s_base[2] = t;
+    }
+    __syncthreads();
+    const int total_big = s_base[2];
+    int item = 0, nb = 0;
+    if (i < n_items) { item = work[i]; nb = chain_count_neighbours(pidx + (size_t)item * K, K); }
+    const int big = (nb > 4 || (nb > 0 && !classes)) ? 1 : 0, small = (nb > 0 && !big) ? 1 : 0;
+    int ia = big, ib = small;
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t0 = __shfl_up(ia, o), t1 = __shfl_up(ib, o);
+        if (lane >= o) { ia += t0; ib += t1; }
+    }
+    __syncthreads();
+    if (lane == 63) { s_a[wid] = ia; s_b[wid] = ib; }
+    __syncthreads();
+    int oa = s_base[0] + ia - big, ob = s_base[1] + ib - small;
+    for (int k = 0; k < wid; ++k) { oa += s_a[k]; ob += s_b[k]; }
+    const int pos = big ? oa : total_big + ob;
+    if ((big || small) && pos < cap_samples) vs_item[pos] = item;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        // the second class as the consumers see it: what is left of the (possibly clamped) valid-sample count after the first class
+        long long nv = (long long)counts[HNR_CNT_SAMPLES_VALID];
+        if (nv > cap_samples) nv = cap_samples;
+        const long long first = total_big < nv ? total_big : nv;
+        counts[HNR_CNT_SAMPLES_SMALL] = (unsigned long long)(nv - first);
+    }
+}
+
 }  // namespace hnr
 
 using namespace hnr;
@@ -845,7 +929,7 @@ extern "C" int64_t hnr_chain_packed_bytes(void) { return (int64_t)CH_WBYTES + CH
 extern "C" int64_t hnr_chain_workspace_bytes(int cap_samples)
 {
     if (cap_samples < 0) return -1;
-    const int64_t groups = 4 * (((int64_t)cap_samples + 15) / 16);                // whole 4-group blocks of the gather kernel
+    const int64_t groups = 4 * (((int64_t)cap_samples + 15) / 16 + 1);            // whole 4-group blocks of the gather kernel (+ 1: each of the two slot classes ends in a partial block)
     return groups * (CH_XP_GROUP + CH_AUX_GROUP);
 }
 
@@ -874,6 +958,37 @@ extern "C" int hnr_chain_pack(const float *d_w_b1_0_dist, int ldw0, const float 
     return HNR_OK;
 }
 
+extern "C" int hnr_chain_classes(void)
+{
+    // the 4-slot class needs the weight-stationary kernel (the default); HNR_CHAIN_CLASSES=0 switches it off
+    static int on = -1;
+    if (on < 0) {
+        const char *e = getenv("HNR_CHAIN_RT"), *c = getenv("HNR_CHAIN_CLASSES");
+        const bool ws = !e || (atoi(e) != 2 && atoi(e) != 4 && atoi(e) != 8);
+        on = (ws && !(c && atoi(c) == 0)) ? 1 : 0;
+    }
+    return on;
+}
+
+extern "C" int hnr_chain_plan(const int32_t *d_work, const int32_t *d_sample_pidx, int64_t *d_counts, int K, int max_items, int classes,
+                              int32_t *d_vs_item, int cap_samples, int32_t *d_scratch, void *stream)
+{
+    if (!d_work || !d_sample_pidx || !d_counts || !d_vs_item || !d_scratch || K <= 0 || max_items < 0 || cap_samples < 0 || (classes != 0 && classes != 1)) {
+        set_error("hnr_chain_plan: bad argument"); return HNR_ERR_BADARG;
+    }
+    if (classes && (K != 8 || !hnr_chain_classes())) {
+        set_error("hnr_chain_plan: the 4-slot sample class needs K = 8 and the weight-stationary chain kernel (hnr_chain_classes())"); return HNR_ERR_BADARG;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (max_items == 0) return HNR_OK;
+    const int nb = cdiv(max_items, 1024);
+    unsigned long long *cnt = reinterpret_cast<unsigned long long *>(d_counts);
+    chain_plan_sum_kernel<<<nb, 1024, 0, st>>>(d_work, d_sample_pidx, cnt, K, classes, d_scratch);
+    chain_plan_scan_kernel<<<nb, 1024, 0, st>>>(d_work, d_sample_pidx, cnt, K, classes, d_scratch, nb, d_vs_item, cap_samples);
+    HNR_LAUNCH_CHECK();
+    return HNR_OK;
+}
+
 extern "C" int hnr_chain_gather(const float *d_xyz, const float *d_conf, const float *d_dir, const float *d_color,
                                 const int32_t *d_sample_pidx, const float *d_sample_loc_w, const float *d_raydir, const float *d_campos,
                                 const float *d_camrot, const int32_t *d_vs_item, const int64_t *d_counts, int SR, int K, int cap_samples,
@@ -887,7 +1002,7 @@ extern "C" int hnr_chain_gather(const float *d_xyz, const float *d_conf, const f
         set_error("hnr_chain_gather: NULL / unaligned pointer");
         return HNR_ERR_BADARG;
     }
-    const int blocks = cdiv(cap_samples, 16);
+    const int blocks = cdiv(cap_samples, 16) + 1;
     ChainGatherArgs a;
     a.xyz = d_xyz; a.conf = d_conf; a.pdir = d_dir; a.color = d_color; a.pidx = d_sample_pidx; a.loc_w = d_sample_loc_w;
     a.raydir = d_raydir; a.campos = d_campos; a.camrot = d_camrot; a.vs_item = d_vs_item;
@@ -912,7 +1027,7 @@ extern "C" int hnr_chain_forward(const void *d_workspace, const float *d_point_t
         set_error("hnr_chain_forward: NULL / unaligned pointer");
         return HNR_ERR_BADARG;
     }
-    const int blocks = cdiv(cap_samples, 16);
+    const int blocks = cdiv(cap_samples, 16) + 1;
     ChainArgs a;
     a.xp = (const char *)d_workspace; a.aux = (const char *)d_workspace + (size_t)blocks * 4 * CH_XP_GROUP;
     a.ptab = d_point_table; a.ldt = ldt; a.wimg = (const char *)d_packed;

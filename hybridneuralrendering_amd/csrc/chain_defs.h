@@ -34,6 +34,22 @@ struct ChainArgs {
     int skew;                          // RT = 2: the second half of the grid (the CUs' second workgroups) starts skew x 64 cycles late
 };
 
+// Row-slot classes (hnr_chain_plan): samples [0, n_big) own 8 row slots each (16 samples per 128-row tile), samples [n_big, n_valid) -- at most 4
+// neighbours -- own 4 (32 samples per tile); the tiles / 4-group blocks of the second class follow those of the first in the workspace.
+struct ChainClasses { int n_valid, n_big, big_tiles, n_tiles; };
+__device__ __forceinline__ ChainClasses chain_classes(const unsigned long long *counts, int cap_samples)
+{
+    ChainClasses c;
+    long long nv = (long long)counts[HNR_CNT_SAMPLES_VALID];
+    if (nv > cap_samples) nv = cap_samples;
+    long long ns = (long long)counts[HNR_CNT_SAMPLES_SMALL];
+    if (ns > nv) ns = nv;
+    c.n_valid = (int)nv; c.n_big = (int)(nv - ns);
+    c.big_tiles = (c.n_big + 15) / 16;
+    c.n_tiles = c.big_tiles + (int)((ns + 31) / 32);
+    return c;
+}
+
 __device__ __forceinline__ float chain_softplus_m1(float x)
 {
     const float y = __fsub_rn(x, 1.0f);                // raw2out_density: softplus(x - 1), beta = 1, threshold = 20 (:471-476)

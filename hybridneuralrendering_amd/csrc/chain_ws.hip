@@ -65,10 +65,9 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
 {
     constexpr int SLOT = ch_slot(4), SAMPLES = 16;
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, j = lane & 31;
-    int n_valid = (int)a.counts[HNR_CNT_SAMPLES_VALID];
-    if (n_valid > a.cap_samples) n_valid = a.cap_samples;
-    const int n_tiles = (n_valid + SAMPLES - 1) / SAMPLES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5, j = lane & 31;   // wave in an SGPR: its tests are scalar branches
+    const ChainClasses cls = chain_classes(a.counts, a.cap_samples);      // tiles [0, big_tiles): 16 samples x 8 row slots; the rest: 32 samples x 4
+    const int n_valid = cls.n_valid, n_tiles = cls.n_tiles;
     const float *meta = reinterpret_cast<const float *>(a.wimg + CH_META);
     const __amdgpu_buffer_rsrc_t wsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(a.wimg), 0, CH_WBYTES, 0x00020000);
     const int col0 = 64 * wave + 16 * h;
@@ -211,7 +210,9 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
                         else amax = fmaxf(fmaxf(amax, fabsf(vx)), fabsf(vy));
                         if (DBG == 1) {
                             if (a.dbg && a.dbg_layer == PL && tile_e >= 0) {
-                                float *o = a.dbg + ((size_t)tile_e * 128 + 32 * PR + j) * 256 + col0 + 32 * c + 2 * q;
+                                int te = tile_e;                                        // laundered: no 64-bit induction variable
+                                asm volatile("" : "+s"(te));
+                                float *o = a.dbg + ((size_t)te * 128 + 32 * PR + j) * 256 + col0 + 32 * c + 2 * q;
                                 o[0] = vx; o[1] = vy;
                             }
                         }
@@ -274,8 +275,10 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
         // -- second half, layer 3: K-weighted sums (8 adjacent lanes: three DPP steps), X5 / sigma stores, next tile's layer-0 image of row tile PR.
         //    micro-stage 0: exchange read; 1 + i: value pair i (16 pairs; a float4 store after every second pair); 17: sigma; 18: image
         const float wq_e = PR == 3 ? wq_fin : wq[PR];
-        const int s_row = tile_e >= 0 ? tile_e * SAMPLES + 4 * PR + (j >> 3) : n_valid;
-        const bool st_lane = (j & 7) == 0 && s_row < n_valid;
+        // a tile of the second slot class (hnr_chain_plan): 8 samples of 4 row slots per row tile -- the sum stops after two DPP steps
+        const bool small_e = tile_e >= cls.big_tiles;
+        const int s_row = tile_e < 0 ? n_valid : small_e ? cls.n_big + 32 * (tile_e - cls.big_tiles) + 8 * PR + (j >> 2) : tile_e * SAMPLES + 4 * PR + (j >> 3);
+        const bool st_lane = (j & (small_e ? 3 : 7)) == 0 && s_row < (small_e || tile_e < 0 ? n_valid : cls.n_big);
         const int MS = 19, m0 = k2 * MS / N2, m1 = (k2 + 1) * MS / N2;
 #pragma unroll
         for (int ms = m0; ms < m1; ++ms) {
@@ -287,21 +290,21 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
                 f1 = __fadd_rn(f1, __builtin_amdgcn_update_dpp(0.f, f1, 0xB1, 0xf, 0xf, false));
                 f0 = __fadd_rn(f0, __builtin_amdgcn_update_dpp(0.f, f0, 0x4E, 0xf, 0xf, false));        // quad_perm [2,3,0,1]
                 f1 = __fadd_rn(f1, __builtin_amdgcn_update_dpp(0.f, f1, 0x4E, 0xf, 0xf, false));
-                f0 = __fadd_rn(f0, __builtin_amdgcn_update_dpp(0.f, f0, 0x141, 0xf, 0xf, false));       // row_half_mirror
-                f1 = __fadd_rn(f1, __builtin_amdgcn_update_dpp(0.f, f1, 0x141, 0xf, 0xf, false));
+                { const float g0 = __builtin_amdgcn_update_dpp(0.f, f0, 0x141, 0xf, 0xf, false), g1 = __builtin_amdgcn_update_dpp(0.f, f1, 0x141, 0xf, 0xf, false);   // row_half_mirror
+                  f0 = __fadd_rn(f0, small_e ? 0.f : g0); f1 = __fadd_rn(f1, small_e ? 0.f : g1); }
                 if ((pr & 1) == 0) { ks0 = f0; ks1 = f1; }
                 else if (st_lane) *reinterpret_cast<float4 *>(a.X5 + (size_t)s_row * a.ld5 + col0 + 32 * c + 2 * (pr & 6)) = make_float4(ks0, ks1, f0, f1);
             } else if (ms == 17) {
                 // the tile's densities, once per tile and in all four waves at the same time (softplus is ~100 instructions that cannot be cut
                 // into pieces; per row tile it stalled a different pass for each wave): wave w takes row tile w
                 if (PR == 3) {
-                    const int s_sig = tile_e >= 0 ? tile_e * SAMPLES + 4 * wave + (j >> 3) : n_valid;
+                    const int s_sig = tile_e < 0 ? n_valid : small_e ? cls.n_big + 32 * (tile_e - cls.big_tiles) + 8 * wave + (j >> 2) : tile_e * SAMPLES + 4 * wave + (j >> 3);
                     const float d = __fadd_rn(__fadd_rn(ex4.x, ex4.y), __fadd_rn(ex4.z, ex4.w));
                     float sg = __fmul_rn(chain_softplus_m1(__fadd_rn(d, alpha_b)), wq_sig);
                     sg = __fadd_rn(sg, __builtin_amdgcn_update_dpp(0.f, sg, 0xB1, 0xf, 0xf, false));
                     sg = __fadd_rn(sg, __builtin_amdgcn_update_dpp(0.f, sg, 0x4E, 0xf, 0xf, false));
-                    sg = __fadd_rn(sg, __builtin_amdgcn_update_dpp(0.f, sg, 0x141, 0xf, 0xf, false));
-                    if (h == 0 && (j & 7) == 0 && s_sig < n_valid) a.sigma[s_sig] = sg;
+                    { const float g = __builtin_amdgcn_update_dpp(0.f, sg, 0x141, 0xf, 0xf, false); sg = __fadd_rn(sg, small_e ? 0.f : g); }
+                    if (h == 0 && (j & (small_e ? 3 : 7)) == 0 && s_sig < (small_e ? n_valid : cls.n_big)) a.sigma[s_sig] = sg;
                 }
             } else if (stage_next && tile_stage < t_end) {
 #pragma unroll

@@ -100,9 +100,8 @@ extern "C" int hnr_render_forward(const hnr_grid *grid, const hnr_render_params 
     if ((rc = hnr_march_query(grid, cam->d_campos, cam->d_raydir, cam->d_tmid, &q, o->d_sample_pidx, o->d_sample_loc_w, o->d_ray_nsamp, o->d_ray_mask,
                               L.work, o->d_counts, stream)) != HNR_OK) return rc;
     HNR_MARK();
-    // ---- plan: the list of valid samples
-    // (the plan's own overflow word lands in status[1] and is then replaced by the true count)
-    if ((rc = hnr_sample_plan(L.work, o->d_sample_pidx, o->d_counts, K, R * SR, L.vs_item, L.vs_off, L.vs_cnt, cap, INT_MAX, L.scratch, o->d_status + 1, stream)) != HNR_OK) return rc;
+    // ---- plan: the list of valid samples, those with more than four neighbours first (8 row slots each), then the small ones (4 slots)
+    if ((rc = hnr_chain_plan(L.work, o->d_sample_pidx, o->d_counts, K, R * SR, hnr_chain_classes(), L.vs_item, cap, L.scratch, stream)) != HNR_OK) return rc;
     status_kernel<<<1, 1, 0, st>>>(reinterpret_cast<unsigned long long *>(o->d_counts), cap, o->d_status);
     HNR_LAUNCH_CHECK();
     HNR_HIP_CHECK(hipMemsetAsync(o->d_decoded, 0, (size_t)R * SR * 4 * sizeof(float), st));

@@ -159,10 +159,15 @@ class HybridRenderer:
         p = _lib.ptr
         T = lambda name: _Stage(timers, name)
         with torch.cuda.device(dev):
-          with T("plan_gather"):
-            _lib.check(L.hnr_sample_plan(p(work), p(pidx), p(counts), K, R * SR, p(vs_item), p(vs_off), p(vs_cnt), n_valid, n_rows,
-                                         p(scratch), p(overflow), st()), "hnr_sample_plan")
           fused = self.dense == "f16x2" and K == 8
+          with T("plan_gather"):
+            if fused:
+                # valid samples with more than four neighbours first, then the small ones (4 row slots each in the chain's row tiles)
+                _lib.check(L.hnr_chain_plan(p(work), p(pidx), p(counts), K, R * SR, int(L.hnr_chain_classes()), p(vs_item), n_valid,
+                                            p(scratch), st()), "hnr_chain_plan")
+            else:
+                _lib.check(L.hnr_sample_plan(p(work), p(pidx), p(counts), K, R * SR, p(vs_item), p(vs_off), p(vs_cnt), n_valid, n_rows,
+                                             p(scratch), p(overflow), st()), "hnr_sample_plan")
           # memory guard (the per-layer path keeps 3360 B per neighbour row, the fused chain 296 B per neighbour SLOT + ~3 KB per sample):
           # a frame that cannot fit is refused with the remedy named instead of dying in the allocator
           need = (n_valid * 8 * 296 + n_valid * 6000) if fused else (n_rows * 3400 + n_valid * 6000)

@@ -120,6 +120,8 @@ enum {
     HNR_CNT_CELLS_VISITED,    /* occupied cells whose lists were scanned by the k-NN            */
     HNR_CNT_CANDIDATES,       /* points distance-tested by the k-NN                             */
     HNR_CNT_SAMPLES_VALID,    /* shading samples with >= 1 neighbour                            */
+    HNR_CNT_SAMPLES_SMALL,    /* written by hnr_chain_plan: valid samples with <= 4 neighbours, listed AFTER the others in its
+                                 d_vs_item (0 after hnr_march_query: every sample counts as a full one)                  */
     HNR_NCOUNTS = 8
 };
 
@@ -301,11 +303,21 @@ int hnr_merge(const float *d_X6, int ld6, const float *d_Hm, int ldh, const floa
  *   (n_valid = d_counts[HNR_CNT_SAMPLES_VALID], read on the device; cap_samples bounds it) into d_workspace
  *   (hnr_chain_workspace_bytes(cap_samples)); also d_X5[s, 256:280] = view-direction encoding (:909-913) and, optionally, the
  *   reference's `weight` / `conf_coefficient` outputs [R,SR,K] (written for valid neighbour slots only).
+ * hnr_chain_plan: the list of valid samples the chain works on, d_vs_item[s] = ray * SR + slot, from the kept-sample work list of
+ *   hnr_march_query.  classes = 0: in (ray, slot) order, exactly hnr_sample_plan's list.  classes = 1: the samples with more than four
+ *   neighbours first, then those with 1..4 (each class in (ray, slot) order), and d_counts[HNR_CNT_SAMPLES_SMALL] = size of the second
+ *   class: the gather and the chain kernel give a small sample 4 row slots instead of 8 (82 % of the bench frame's samples have 8
+ *   neighbours, 11 % at most 4: 5.5 % fewer rows through the four dense layers; the sums are bit-identical, a slot without a neighbour
+ *   contributes an exact zero).  Everything downstream is per sample and order-free.  hnr_chain_classes() tells whether the chain
+ *   kernel selected in this process supports the second class.  d_scratch: int32[2 * ceil(max_items / 1024) + 2].
  * hnr_chain_forward: d_X5[s, 0:256] = sum_k w_k block3(...)_k, d_sigma[s] = sum_k w_k softplus(alpha_k - 1).
  *   d_point_table [N, ldt >= 256] = [emb | PE3(emb)] block1.0.weight[:, :224]^T.  d_dbg (probe, may be NULL): the post-activation
  *   output of layer dbg_layer (0..3) as [rows = 8 per valid sample, 256]. */
 int64_t hnr_chain_packed_bytes(void);
 int64_t hnr_chain_workspace_bytes(int cap_samples);
+int hnr_chain_classes(void);
+int hnr_chain_plan(const int32_t *d_work, const int32_t *d_sample_pidx, int64_t *d_counts, int K, int max_items, int classes,
+                   int32_t *d_vs_item, int cap_samples, int32_t *d_scratch, void *stream);
 int hnr_chain_pack(const float *d_w_b1_0_dist, int ldw0, const float *d_b_b1_0, const float *d_w_b1_2, const float *d_b_b1_2,
                    const float *d_w_b3_0, const float *d_b_b3_0, const float *d_w_b3_2, const float *d_b_b3_2,
                    const float *d_alpha_w, const float *d_alpha_b, void *d_packed, void *stream);
