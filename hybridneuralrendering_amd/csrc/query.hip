@@ -179,6 +179,7 @@ struct KBuf {
         }
         kid += ok ? 1 : 0;
     }
+    __device__ __forceinline__ void sync_kid() {}
     // reference :494-513
     __device__ __forceinline__ void offer(float v, int p)
     {
@@ -411,17 +412,49 @@ struct KSorted {
     __device__ __forceinline__ void offer_sel(float v, int p, bool ok)
     {
         const float vv = ok ? v : __int_as_float(0x7f800000);       // a rejected candidate is +inf: it is never < an entry
-        bool c[K];
+        if constexpr (K == 8) {
+            // the 4-instructions-per-slot form spelled out: left to itself the compiler turns the selects into exec-masked branches and
+            // copies (~105 instructions per candidate in the inner loop).  The eight compares come first (farthest slot first) so that
+            // every lane mask is at least two instructions old when a v_cndmask reads it (VALU-writes-SGPR -> VALU-reads-SGPR hazard:
+            // the assembler does not pad inline asm).  Slots are updated from the far end: slot i reads the OLD slot i - 1.
+            unsigned long long c0, c1, c2, c3, c4, c5, c6, c7;
+            asm volatile(
+                "v_cmp_lt_f32_e64 %[c7], %[vv], %[d7]\n\tv_cmp_lt_f32_e64 %[c6], %[vv], %[d6]\n\t"
+                "v_cmp_lt_f32_e64 %[c5], %[vv], %[d5]\n\tv_cmp_lt_f32_e64 %[c4], %[vv], %[d4]\n\t"
+                "v_cmp_lt_f32_e64 %[c3], %[vv], %[d3]\n\tv_cmp_lt_f32_e64 %[c2], %[vv], %[d2]\n\t"
+                "v_cmp_lt_f32_e64 %[c1], %[vv], %[d1]\n\tv_cmp_lt_f32_e64 %[c0], %[vv], %[d0]\n\t"
+                "v_cndmask_b32_e64 %[i7], %[i7], %[p], %[c7]\n\tv_med3_f32 %[d7], %[d6], %[d7], %[vv]\n\tv_cndmask_b32_e64 %[i7], %[i7], %[i6], %[c6]\n\t"
+                "v_cndmask_b32_e64 %[i6], %[i6], %[p], %[c6]\n\tv_med3_f32 %[d6], %[d5], %[d6], %[vv]\n\tv_cndmask_b32_e64 %[i6], %[i6], %[i5], %[c5]\n\t"
+                "v_cndmask_b32_e64 %[i5], %[i5], %[p], %[c5]\n\tv_med3_f32 %[d5], %[d4], %[d5], %[vv]\n\tv_cndmask_b32_e64 %[i5], %[i5], %[i4], %[c4]\n\t"
+                "v_cndmask_b32_e64 %[i4], %[i4], %[p], %[c4]\n\tv_med3_f32 %[d4], %[d3], %[d4], %[vv]\n\tv_cndmask_b32_e64 %[i4], %[i4], %[i3], %[c3]\n\t"
+                "v_cndmask_b32_e64 %[i3], %[i3], %[p], %[c3]\n\tv_med3_f32 %[d3], %[d2], %[d3], %[vv]\n\tv_cndmask_b32_e64 %[i3], %[i3], %[i2], %[c2]\n\t"
+                "v_cndmask_b32_e64 %[i2], %[i2], %[p], %[c2]\n\tv_med3_f32 %[d2], %[d1], %[d2], %[vv]\n\tv_cndmask_b32_e64 %[i2], %[i2], %[i1], %[c1]\n\t"
+                "v_cndmask_b32_e64 %[i1], %[i1], %[p], %[c1]\n\tv_med3_f32 %[d1], %[d0], %[d1], %[vv]\n\tv_cndmask_b32_e64 %[i1], %[i1], %[i0], %[c0]\n\t"
+                "v_cndmask_b32_e64 %[i0], %[i0], %[p], %[c0]\n\tv_min_f32 %[d0], %[d0], %[vv]"
+                : [d0] "+v"(d2[0]), [d1] "+v"(d2[1]), [d2] "+v"(d2[2]), [d3] "+v"(d2[3]), [d4] "+v"(d2[4]), [d5] "+v"(d2[5]), [d6] "+v"(d2[6]),
+                  [d7] "+v"(d2[7]), [i0] "+v"(id[0]), [i1] "+v"(id[1]), [i2] "+v"(id[2]), [i3] "+v"(id[3]), [i4] "+v"(id[4]), [i5] "+v"(id[5]),
+                  [i6] "+v"(id[6]), [i7] "+v"(id[7]), [c0] "=&s"(c0), [c1] "=&s"(c1), [c2] "=&s"(c2), [c3] "=&s"(c3), [c4] "=&s"(c4),
+                  [c5] "=&s"(c5), [c6] "=&s"(c6), [c7] "=&s"(c7)
+                : [vv] "v"(vv), [p] "v"(p));
+        } else {
+            bool c[K];
 #pragma unroll
-        for (int i = 0; i < K; ++i) c[i] = vv < d2[i];              // on the OLD list; monotone in i
+            for (int i = 0; i < K; ++i) c[i] = vv < d2[i];              // on the OLD list; monotone in i
 #pragma unroll
-        for (int i = K - 1; i >= 1; --i) {
-            id[i] = c[i - 1] ? id[i - 1] : (c[i] ? p : id[i]);
-            d2[i] = __builtin_amdgcn_fmed3f(d2[i - 1], d2[i], vv);
+            for (int i = K - 1; i >= 1; --i) {
+                id[i] = c[i - 1] ? id[i - 1] : (c[i] ? p : id[i]);
+                d2[i] = __builtin_amdgcn_fmed3f(d2[i - 1], d2[i], vv);
+            }
+            id[0] = c[0] ? p : id[0];
+            d2[0] = fminf(d2[0], vv);
         }
-        id[0] = c[0] ? p : id[0];
-        d2[0] = fminf(d2[0], vv);
-        kid += ok ? 1 : 0;
+    }
+    // entries held (<= K): the list itself says it (an empty slot is +inf), so the insertion carries no counter
+    __device__ __forceinline__ void sync_kid()
+    {
+        kid = 0;
+#pragma unroll
+        for (int i = 0; i < K; ++i) kid += d2[i] < __int_as_float(0x7f800000) ? 1 : 0;
     }
 };
 
@@ -503,19 +536,23 @@ __global__ __launch_bounds__(256) void knn3_kernel(GridView g, const int32_t *__
             // in flight across the insertion code instead of being waited for one by one
             int a0 = gen(), a1 = gen(), a2 = gen(), a3 = gen();
             float4 p0 = g.pts[a0 < 0 ? 0 : a0], p1 = g.pts[a1 < 0 ? 0 : a1], p2 = g.pts[a2 < 0 ? 0 : a2], p3 = g.pts[a3 < 0 ? 0 : a3];
-            while (__builtin_amdgcn_ballot_w64(a0 >= 0) != 0ull) {
-                consume(p0, a0 >= 0); a0 = gen(); p0 = g.pts[a0 < 0 ? 0 : a0];
-                consume(p1, a1 >= 0); a1 = gen(); p1 = g.pts[a1 < 0 ? 0 : a1];
-                consume(p2, a2 >= 0); a2 = gen(); p2 = g.pts[a2 < 0 ? 0 : a2];
-                consume(p3, a3 >= 0); a3 = gen(); p3 = g.pts[a3 < 0 ? 0 : a3];
+            if (__builtin_amdgcn_ballot_w64(a0 >= 0) != 0ull) {
+                do {                                             // bottom-tested: a top test makes the compiler keep two copies of the list
+                    consume(p0, a0 >= 0); a0 = gen(); p0 = g.pts[a0 < 0 ? 0 : a0];
+                    consume(p1, a1 >= 0); a1 = gen(); p1 = g.pts[a1 < 0 ? 0 : a1];
+                    consume(p2, a2 >= 0); a2 = gen(); p2 = g.pts[a2 < 0 ? 0 : a2];
+                    consume(p3, a3 >= 0); a3 = gen(); p3 = g.pts[a3 < 0 ? 0 : a3];
+                } while (__builtin_amdgcn_ballot_w64(a0 >= 0) != 0ull);
             }
         };
         const uint32_t m0 = occ & (1u << 13), m1 = occ & ~(1u << 13);
-        run_shell(occ_nz & (1u << 13));                         // shell 0 = the sample's own cell
+        if (layers > 0) run_shell(occ_nz & (1u << 13));         // shell 0 = the sample's own cell (layers = 0: probe of pass 1 alone)
+        kb.sync_kid();
         n_cells += m0 ? 1u : 0u;
         n_cand += cand0;
         if (layers > 1 && kb.kid < K) {                         // reference: `if (kid >= K) break;` after a layer
             run_shell(occ_nz & ~(1u << 13));
+            kb.sync_kid();
             n_cells += (unsigned)__popc(m1);
             n_cand += cand1;
         }
@@ -732,8 +769,10 @@ extern "C" int hnr_march_query(const hnr_grid *g, const float *d_campos, const f
             set_error("hnr_march_query: knn_order = 1 needs P <= 63 and < 2^26 points (P=%d)", gp.P);
             return HNR_ERR_BADARG;
         }
+        static int probe_pass1 = -1;                             // HNR_KNN_PROBE_PASS1=1: time the cell lookups alone (tools/probe_query.py; results are empty)
+        if (probe_pass1 < 0) { const char *e = getenv("HNR_KNN_PROBE_PASS1"); probe_pass1 = e ? atoi(e) : 0; }
         if (q->knn_order == 1)
-            knn3_kernel<8, 1><<<blocks, 256, 0, st>>>(v, d_work, d_sample_loc_w, q->SR, q->radius2, layers, d_sample_pidx, d_ray_mask, cnt, block_stats);
+            knn3_kernel<8, 1><<<blocks, 256, 0, st>>>(v, d_work, d_sample_loc_w, q->SR, q->radius2, probe_pass1 ? 0 : layers, d_sample_pidx, d_ray_mask, cnt, block_stats);
         else if (knn_sel == 3 && gp.P <= 63 && gs.n_points < (1ll << 26))
             knn3_kernel<8><<<blocks, 256, 0, st>>>(v, d_work, d_sample_loc_w, q->SR, q->radius2, layers, d_sample_pidx, d_ray_mask, cnt, block_stats);
         else
