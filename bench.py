@@ -6,7 +6,8 @@ on the scene0241_01-like synthetic config (BASELINE.json configs[2] / SURVEY.md 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 One "step" = one full 620x460 = 285 200-ray frame of the FIXED scene0241_01-like ray batch (north_star): with N ranks the
-frame's rays are split into N contiguous scan-line blocks (parallel.shard_bounds), every rank renders its block (cloud,
+frame's scan lines are dealt round-robin to the N ranks (parallel.shard_lines; --shard blocks: N contiguous blocks, whose work differs
+by up to 1.68x on this frame, tools/shard_balance.py), every rank renders its rays (cloud,
 grid, weights and reference-view features replicated and already resident in HBM) and the colours are reassembled on rank 0
 with ONE RCCL gather -- strong scaling, value = 285 200 rays / max-over-ranks step time.  `--scaling weak` instead lets every
 rank render a whole frame of its own (value = N x 285 200 / time).
@@ -47,6 +48,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-leg", action="store_true")
     ap.add_argument("--cpu-sample-rays", type=int, default=2304)
+    ap.add_argument("--shard", choices=("lines", "blocks"), default="lines",
+                    help="strong scaling: scan lines dealt round-robin to the ranks (balanced: busiest rank 1.01x the mean work at N = 8) or N "
+                         "contiguous blocks of scan lines (the reference's chunk order; busiest block 1.68x the mean on this frame)")
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
                     help="strong: the N ranks share ONE fixed frame (north_star); weak: one whole frame per rank")
     ap.add_argument("--dump-colors", default="", help="rank 0 writes the assembled [R,3] colours of the last step to this .npy file")
@@ -303,13 +307,19 @@ def main():
     # strong: every rank builds the SAME frame (pose 0) and renders its block of rays; weak: rank-specific pose, whole frame
     sc, opt, agg, cloud, rnd, cam = build_world(args, dev, 0 if strong else rank)
     R_frame = cam["raydir"].shape[0]
-    lo, hi = parallel.shard_bounds(R_frame, world, rank) if strong else (0, R_frame)
+    line = sc.w - 2 * args.margin                            # rays per scan line of the frame
+    def rays_of(r):                                          # ray indices of rank r (strong scaling)
+        if args.shard == "lines":
+            return parallel.shard_lines(R_frame, line, world, r)
+        return torch.arange(*parallel.shard_bounds(R_frame, world, r), dtype=torch.int64)
+    shards = [rays_of(r) for r in range(world)] if strong else [torch.arange(R_frame, dtype=torch.int64)] * world
     if strong and world > 1:
-        cam = dict(cam, raydir=cam["raydir"][lo:hi].contiguous(), rays_np=cam["rays_np"][lo:hi])
+        mine = shards[rank]
+        cam = dict(cam, raydir=cam["raydir"].index_select(0, mine.to(dev)).contiguous(), rays_np=cam["rays_np"][mine.numpy()])
     R = cam["raydir"].shape[0]
     R_job = R_frame if strong else world * R_frame          # rays the whole job renders per step
-    sizes = [parallel.shard_bounds(R_frame, world, r) for r in range(world)] if strong else [(0, R_frame)] * world
-    pad = max(b - a for a, b in sizes)
+    pad = max(int(s.numel()) for s in shards)
+    shards_at = [s if rehearsal else s.to(dev) for s in shards] if rank == 0 else None     # where the gathered rows live (rehearsal: host)
     gather_ev = []
 
     def step(timers=None, time_gather=False):
@@ -342,7 +352,12 @@ def main():
                 e1.record()
                 gather_ev.append((e0, e1))
             if rank == 0:
-                frame = torch.cat([o[:b - a] for o, (a, b) in zip(outs, sizes)], dim=0) if strong else outs[0]
+                if strong:                                   # every shard's rows go back to their place in the frame
+                    frame = torch.empty((R_frame, 3), dtype=c.dtype, device=c.device)
+                    for o, s in zip(outs, shards_at):
+                        frame[s] = o[:s.numel()]
+                else:
+                    frame = outs[0]
         return col, out, frame
 
     def barrier():
@@ -531,7 +546,7 @@ def main():
                                       opt.SR, opt.K, opt.P, opt.max_o, opt.z_depth_dim, sc.h, sc.w),
                        "entry": "hnr_render_forward (one library call per frame, no host read)" if getattr(rnd, "single_call", False) and fused else "per-stage C-ABI calls from Python",
                        "rays_per_step": R_job, "rays_per_gpu": R, "points": int(sc.xyz.shape[0]), "chunk_rays": args.chunk if args.chunk > 0 else R,
-                       "parallelism": ("one fixed frame ray-sharded x%d (contiguous scan-line blocks), one RCCL gather" if strong else
+                       "parallelism": (("one fixed frame ray-sharded x%%d (%s), one RCCL gather" % ("scan lines dealt round-robin" if args.shard == "lines" else "contiguous scan-line blocks")) if strong else
                                        "one frame per rank x%d, one RCCL gather") % world},
             "gather_ms": (round(sum(a.elapsed_time(b) for a, b in gather_ev) / max(len(gather_ev), 1), 4) if gather_ev else None),
             "roofline": roof, "roofline_query": roof_q, "roofline_train": (train or {}).get("roofline_train"), "cpu_baseline": cpu,

@@ -1,10 +1,18 @@
 """Ray sharding across the GPUs of one node (one process per GPU, torch.distributed over RCCL/xGMI).
 
 The path is embarrassingly parallel over rays: the point cloud, grid, MLP weights and
-reference-view feature pyramid are replicated on every GPU; rays are split into contiguous scan-line
-blocks (neighbouring rays share voxels -> L2 reuse); the only data-path collective is ONE gather of the
+reference-view feature pyramid are replicated on every GPU; the only data-path collective is ONE gather of the
 rendered colours to rank 0 (3.4 MB for a 620x460 frame) -- the reference's counterpart is the per-chunk
 `.cpu()` scatter into the image in run/test_ft.py:185-198.
+
+Two ways to split a frame's rays:
+  shard_bounds  N contiguous blocks of scan lines (the reference's chunk order).  The work per ray is NOT uniform over an image -- on
+                the bench frame the busiest of 8 blocks has 1.68x the mean number of neighbour rows (tools/shard_balance.py), which
+                caps strong scaling at 60 %;
+  shard_lines   whole scan lines dealt round-robin (rank r renders lines r, r + N, ...): rays of a line stay together (neighbouring
+                rays share voxels -> L2 reuse) and every rank sees every part of the image: busiest rank 1.01x the mean at N = 8.
+Every ray is rendered independently of its launch mates (tests: chunked == whole frame, bit for bit), so both reassemble the
+single-GPU image exactly.
 Works with backend "nccl" (= RCCL on ROCm) on GPUs and "gloo" on CPU tensors (tests).
 """
 import torch
@@ -16,6 +24,35 @@ def shard_bounds(n_rays, world_size, rank):
     base, rem = divmod(int(n_rays), int(world_size))
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_lines(n_rays, line, world_size, rank):
+    """Indices (ascending, int64, CPU) of the rays of rank `rank` when the scan lines -- runs of `line` consecutive rays, the last one
+    possibly shorter -- are dealt round-robin to the ranks."""
+    idx = torch.arange(int(n_rays), dtype=torch.int64)
+    return idx[(idx // int(line)) % int(world_size) == int(rank)]
+
+
+def gather_indexed(local, index_of_rank, n_total, dst=0, group=None):
+    """Reassemble rows rendered under an index sharding: rank r holds the rows index_of_rank(r) of the [n_total, C] result.
+    ONE gather of equal-size buffers (padded to the largest shard), then a scatter into place on `dst`.  None on the other ranks."""
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return local
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    idx = [index_of_rank(r) for r in range(world)]
+    pad = max(int(i.numel()) for i in idx)
+    buf = local
+    if local.shape[0] != pad:
+        buf = torch.zeros((pad,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        buf[:local.shape[0]] = local
+    outs = [torch.empty_like(buf) for _ in range(world)] if rank == dst else None
+    dist.gather(buf.contiguous(), outs, dst=dst, group=group)
+    if rank != dst:
+        return None
+    full = torch.empty((int(n_total),) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    for o, i in zip(outs, idx):
+        full[i.to(full.device)] = o[:i.numel()]
+    return full
 
 
 def shard_rays(raydir, world_size, rank):
@@ -42,11 +79,17 @@ def gather_rows(local, n_total, dst=0, group=None):
     return torch.cat([o[:s] for o, s in zip(outs, sizes)], dim=0)
 
 
-def render_sharded(render_fn, raydir, n_total=None, group=None):
-    """Each rank renders its block of `raydir` ([R,3], the SAME full tensor on every rank) with
-    render_fn(rays) -> [n_local, C]; rank 0 gets the assembled [R, C] image rows."""
+def render_sharded(render_fn, raydir, n_total=None, group=None, line=None):
+    """Each rank renders its share of `raydir` ([R,3], the SAME full tensor on every rank) with
+    render_fn(rays) -> [n_local, C]; rank 0 gets the assembled [R, C] image rows.  line = image width: scan lines dealt round-robin
+    (balanced, see the module docstring); line = None: contiguous blocks."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if line is not None:
+        R = raydir.shape[0]
+        mine = shard_lines(R, line, world, rank).to(raydir.device)
+        local = render_fn(raydir.index_select(0, mine))
+        return gather_indexed(local, lambda r: shard_lines(R, line, world, r), R if n_total is None else n_total, group=group)
     rays, (lo, hi) = shard_rays(raydir, world, rank)
     local = render_fn(rays)
     return gather_rows(local, raydir.shape[0] if n_total is None else n_total, group=group)

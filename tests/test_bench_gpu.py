@@ -48,13 +48,16 @@ def _run(extra, env=None, timeout=1500):
 
 def test_bench_gpus_2_spawns_two_ranks_and_reassembles_the_same_frame(tmp_path):
     """`python bench.py --gpus 2` with no launcher: the parent spawns the two ranks itself (rehearsal mode here: one GPU, gloo), the
-    fixed frame is split into two scan-line blocks and the gathered image equals the N=1 image (counterpart of the chunk scatter
-    at /root/reference/run/test_ft.py:185-198)."""
+    fixed frame's scan lines are dealt round-robin to the two ranks (default; `--shard blocks`: two contiguous blocks) and the gathered
+    image equals the N=1 image (counterpart of the chunk scatter at /root/reference/run/test_ft.py:185-198)."""
     import numpy as np
-    a, b = str(tmp_path / "n1.npy"), str(tmp_path / "n2.npy")
+    a, b, c = str(tmp_path / "n1.npy"), str(tmp_path / "n2.npy"), str(tmp_path / "n2b.npy")
     d1 = _run(["--gpus", "1", "--dump-colors", a])
     d2 = _run(["--gpus", "2", "--dump-colors", b], env={"HNR_BENCH_REHEARSAL": "1"})
+    d3 = _run(["--gpus", "2", "--shard", "blocks", "--dump-colors", c], env={"HNR_BENCH_REHEARSAL": "1"})
     assert d1["n_gpus"] == 1 and d2["n_gpus"] == 2 and d2["scaling"] == "strong"
+    assert "round-robin" in d2["config"]["parallelism"] and "contiguous" in d3["config"]["parallelism"]
+    assert np.array_equal(np.load(a), np.load(c))
     assert d2["config"]["rays_per_step"] == d1["config"]["rays_per_step"] and d2["config"]["rays_per_gpu"] * 2 == d1["config"]["rays_per_gpu"]
     assert "REHEARSAL" in d2["data"]
     c1, c2 = np.load(a), np.load(b)
