@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--shard", choices=("lines", "blocks"), default="lines",
                     help="strong scaling: scan lines dealt round-robin to the ranks (balanced: busiest rank 1.01x the mean work at N = 8) or N "
                          "contiguous blocks of scan lines (the reference's chunk order; busiest block 1.68x the mean on this frame)")
+    ap.add_argument("--band", type=int, default=1, help="--shard lines: scan lines per dealt band")
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
                     help="strong: the N ranks share ONE fixed frame (north_star); weak: one whole frame per rank")
     ap.add_argument("--dump-colors", default="", help="rank 0 writes the assembled [R,3] colours of the last step to this .npy file")
@@ -310,14 +311,24 @@ def main():
     line = sc.w - 2 * args.margin                            # rays per scan line of the frame
     def rays_of(r):                                          # ray indices of rank r (strong scaling)
         if args.shard == "lines":
-            return parallel.shard_lines(R_frame, line, world, r)
+            return parallel.shard_lines(R_frame, line * max(1, args.band), world, r)
         return torch.arange(*parallel.shard_bounds(R_frame, world, r), dtype=torch.int64)
     shards = [rays_of(r) for r in range(world)] if strong else [torch.arange(R_frame, dtype=torch.int64)] * world
+    emulate = os.environ.get("HNR_BENCH_EMULATE_RANK")      # "r/n" on ONE GPU: render only what rank r of n would (tools/predict_scaling.sh)
+    if emulate and world == 1:
+        er, en = (int(x) for x in emulate.split("/"))
+        saved_world, world = world, en
+        mine = rays_of(er)
+        world = saved_world
+        cam = dict(cam, raydir=cam["raydir"].index_select(0, mine.to(dev)).contiguous(), rays_np=cam["rays_np"][mine.numpy()])
+        shards = [torch.arange(mine.numel(), dtype=torch.int64)]
     if strong and world > 1:
         mine = shards[rank]
         cam = dict(cam, raydir=cam["raydir"].index_select(0, mine.to(dev)).contiguous(), rays_np=cam["rays_np"][mine.numpy()])
     R = cam["raydir"].shape[0]
     R_job = R_frame if strong else world * R_frame          # rays the whole job renders per step
+    if emulate and world == 1:
+        R_job = R                                            # the line then describes ONE rank's share, not the frame
     pad = max(int(s.numel()) for s in shards)
     shards_at = [s if rehearsal else s.to(dev) for s in shards] if rank == 0 else None     # where the gathered rows live (rehearsal: host)
     gather_ev = []
@@ -536,7 +547,7 @@ def main():
             "metric": "rays/sec (fwd render) scene0241_01 at 1/2/4/8 GPU; PSNR delta vs ref",
             "value": R_job * args.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": "f32", "dense_arithmetic": {"f32": "fp32 MFMA (v_mfma_f32_32x32x2_f32)", "bf16x3": "256-wide per-neighbour layers: fp32 operands split EXACTLY into 3 bf16 terms, 6 bf16 MFMAs per product, fp32 accumulate (fp32-class error, tests/test_linear_gpu.py); all other layers fp32 MFMA", "f16x2": "per-neighbour chain fused in one kernel: fp32 operands split into 2 fp16 terms under exact power-of-two row / layer scales, 3 fp16 MFMAs per product, fp32 accumulate (error vs fp64 at or below the fp32-MFMA path's, tests/test_chain_gpu.py); all other layers fp32 MFMA"}[getattr(rnd, "dense", "f32")], "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: ranks share GPUs, gloo collectives -- not a measurement)",
+            "dtype": "f32", "dense_arithmetic": {"f32": "fp32 MFMA (v_mfma_f32_32x32x2_f32)", "bf16x3": "256-wide per-neighbour layers: fp32 operands split EXACTLY into 3 bf16 terms, 6 bf16 MFMAs per product, fp32 accumulate (fp32-class error, tests/test_linear_gpu.py); all other layers fp32 MFMA", "f16x2": "per-neighbour chain fused in one kernel: fp32 operands split into 2 fp16 terms under exact power-of-two row / layer scales, 3 fp16 MFMAs per product, fp32 accumulate (error vs fp64 at or below the fp32-MFMA path's, tests/test_chain_gpu.py); all other layers fp32 MFMA"}[getattr(rnd, "dense", "f32")], "data": ("synthetic (EMULATION of rank %s on one GPU: not the frame metric)" % emulate) if (emulate and world == 1) else "synthetic" if not rehearsal else "synthetic (REHEARSAL: ranks share GPUs, gloo collectives -- not a measurement)",
             "config": {"workload": "%s synthetic scene (SURVEY 8d): %d points, %dx%d frame margin %d = %d rays per step (%s), "
                                    "SR=%d K=%d P=%d max_o=%d D=%d, 4 reference views %dx%d, hybrid viewmlp forward (query+gather+aggregate+composite); "
                                    "random-init weights with alpha_branch.0 rescaled (weight x30, bias = 30) so that opacities spread over (0,1)"
