@@ -51,6 +51,10 @@ def parse():
     ap.add_argument("--shard", choices=("lines", "blocks"), default="lines",
                     help="strong scaling: scan lines dealt round-robin to the ranks (balanced: busiest rank 1.01x the mean work at N = 8) or N "
                          "contiguous blocks of scan lines (the reference's chunk order; busiest block 1.68x the mean on this frame)")
+    ap.add_argument("--knn-order", choices=("sorted", "reference"), default="sorted",
+                    help="neighbour order of the query: sorted = the reference's neighbour SETS in ascending (d2, enumeration) order "
+                         "(hnr_query_params.knn_order = 1, the production mode: every consumer sums over the K slots); reference = slot for slot "
+                         "the reference's insertion history (the oracle-comparison mode)")
     ap.add_argument("--band", type=int, default=1, help="--shard lines: scan lines per dealt band")
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
                     help="strong: the N ranks share ONE fixed frame (north_star); weak: one whole frame per rank")
@@ -95,6 +99,8 @@ def build_world(args, dev, rank):
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     cloud = PointCloud(t(sc.xyz), t(sc.emb), t(sc.conf), t(sc.dir), t(sc.color))
     rnd = HybridRenderer(opt, agg, dev)
+    if "HNR_KNN_ORDER" not in os.environ:
+        rnd.knn_order = args.knn_order if opt.K == 8 else "reference"
     # rank-specific camera: same scene, slightly different pose (weak scaling: every GPU renders a whole frame)
     eye = sc.c2w[:3, 3] + np.array([0.05, -0.04, 0.01], np.float32) * rank
     tgt = sc.c2w[:3, 3] + sc.c2w[:3, 2] * 3.0
@@ -498,8 +504,8 @@ def main():
                               algorithmic_bytes=int(alg), avg_launch_ms=round(ms_q, 4),
                               per_ray=dict(samples=round(s_all / R, 2), cells_per_sample=round(cells / max(s_all, 1), 2),
                                            candidates_per_sample=round(cand / max(s_all, 1), 2)))
-            # the query with hnr_query_params.knn_order = 1 (same neighbour sets, ascending-distance order; HybridRenderer.knn_order =
-            # "sorted"), timed beside the timed region on the same frame: an OPTION, not what `value` was measured with
+            # the query in both neighbour orders, timed beside the timed region on the same frame; the roofline is quoted on the order the
+            # frame was rendered with (--knn-order)
             if roof_q is not None and opt.K == 8:
                 from hybridneuralrendering_amd import querier as Qm
                 grid_q, hp_q = rnd.querier._grid_for(cloud.xyz[None])
@@ -518,8 +524,12 @@ def main():
                         ms_o[order] = e0.elapsed_time(e1) / 5
                     # the in-frame query time shares the GPU with the feature-pyramid rebuild on the side stream: the roofline is quoted on the
                     # query alone (same frame, same buffers, 5 launches)
-                    roof_q.update(achieved=round(alg / (ms_o[0] * 1e-3) / 1e9, 1), frac=round(alg / (ms_o[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                  avg_launch_ms=round(ms_o[0], 4), in_frame_ms=round(ms_q, 4),
+                    fo = 1 if rnd.knn_order == "sorted" else 0
+                    roof_q.update(achieved=round(alg / (ms_o[fo] * 1e-3) / 1e9, 1), frac=round(alg / (ms_o[fo] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                  avg_launch_ms=round(ms_o[fo], 4), in_frame_ms=round(ms_q, 4),
+                                  neighbour_order=("sorted: the reference's neighbour sets in ascending (d2, enumeration) order (hnr_query_params.knn_order = 1)"
+                                                   if fo else "reference: slot for slot the reference's insertion history"),
+                                  kernel="hnr_march_query: march_kernel + worklist scans + knn3_kernel<8,%d>" % fo,
                                   timing="HIP events around 5 back-to-back hnr_march_query launches on the bench frame (in the frame the query overlaps the "
                                          "feature-pyramid rebuild on a side stream: in_frame_ms)")
                     roof_q["sorted_neighbour_order"] = dict(avg_launch_ms=round(ms_o[1], 4), reference_order_ms_same_loop=round(ms_o[0], 4),
@@ -537,6 +547,10 @@ def main():
         hp = rnd.querier._hp
         amort["grid_build_ms"] = _timed(lambda: Q.VoxelGrid(cloud.xyz, hp[2][:3], hp[5], hp[6], opt.query_size, opt.P, opt.max_o))
         amort["point_table_ms"] = _timed(lambda: agg.point_table(cloud.emb))
+        def _records():
+            rnd._rec_key = None
+            rnd.point_records(cloud)
+        amort["point_records_ms"] = _timed(_records)
         cpu = None
         if not args.no_cpu_baseline and world == 1:          # reported at N=1 only (rank 0)
             cpu = cpu_baseline(args, sc, opt, agg, cam, col.cpu().numpy())
@@ -549,12 +563,12 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "dense_arithmetic": {"f32": "fp32 MFMA (v_mfma_f32_32x32x2_f32)", "bf16x3": "256-wide per-neighbour layers: fp32 operands split EXACTLY into 3 bf16 terms, 6 bf16 MFMAs per product, fp32 accumulate (fp32-class error, tests/test_linear_gpu.py); all other layers fp32 MFMA", "f16x2": "per-neighbour chain fused in one kernel: fp32 operands split into 2 fp16 terms under exact power-of-two row / layer scales, 3 fp16 MFMAs per product, fp32 accumulate (error vs fp64 at or below the fp32-MFMA path's, tests/test_chain_gpu.py); all other layers fp32 MFMA"}[getattr(rnd, "dense", "f32")], "data": ("synthetic (EMULATION of rank %s on one GPU: not the frame metric)" % emulate) if (emulate and world == 1) else "synthetic" if not rehearsal else "synthetic (REHEARSAL: ranks share GPUs, gloo collectives -- not a measurement)",
             "config": {"workload": "%s synthetic scene (SURVEY 8d): %d points, %dx%d frame margin %d = %d rays per step (%s), "
-                                   "SR=%d K=%d P=%d max_o=%d D=%d, 4 reference views %dx%d, hybrid viewmlp forward (query+gather+aggregate+composite); "
+                                   "SR=%d K=%d P=%d max_o=%d D=%d, 4 reference views %dx%d, hybrid viewmlp forward (query+gather+aggregate+composite), neighbour lists in %s order; "
                                    "random-init weights with alpha_branch.0 rescaled (weight x30, bias = 30) so that opacities spread over (0,1)"
                                    % ({"scene0241": "scene0241_01-like room", "scene0101": "scene0101_04-like room"}.get(args.scene, args.scene + "-like object"),
                                       sc.xyz.shape[0], sc.w, sc.h, args.margin, R_frame,
                                       "ONE fixed frame sharded over the ranks" if strong else "one such frame per rank",
-                                      opt.SR, opt.K, opt.P, opt.max_o, opt.z_depth_dim, sc.h, sc.w),
+                                      opt.SR, opt.K, opt.P, opt.max_o, opt.z_depth_dim, sc.h, sc.w, rnd.knn_order),
                        "entry": "hnr_render_forward (one library call per frame, no host read)" if getattr(rnd, "single_call", False) and fused else "per-stage C-ABI calls from Python",
                        "rays_per_step": R_job, "rays_per_gpu": R, "points": int(sc.xyz.shape[0]), "chunk_rays": args.chunk if args.chunk > 0 else R,
                        "parallelism": (("one fixed frame ray-sharded x%%d (%s), one RCCL gather" % ("scan lines dealt round-robin" if args.shard == "lines" else "contiguous scan-line blocks")) if strong else

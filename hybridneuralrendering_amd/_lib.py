@@ -46,7 +46,7 @@ class RenderParams(ctypes.Structure):
 
 
 class RenderCloud(ctypes.Structure):
-    _fields_ = [("d_xyz", _P), ("d_conf", _P), ("d_dir", _P), ("d_color", _P), ("d_point_table", _P), ("ldt", _I)]
+    _fields_ = [("d_xyz", _P), ("d_conf", _P), ("d_dir", _P), ("d_color", _P), ("d_point_table", _P), ("ldt", _I), ("d_rec", _P)]
 
 
 class RenderWeights(ctypes.Structure):
@@ -110,6 +110,8 @@ SIGNATURES = {
     "hnr_chain_gather": (_I, [_P] * 11 + [_I, _I, _I, _P, _P, _I, _P, _P, _P]),
     "hnr_chain_classes": (_I, []),
     "hnr_chain_plan": (_I, [_P, _P, _P, _I, _I, _I, _P, _I, _P, _P]),
+    "hnr_point_records": (_I, [_P, _P, _P, _P, _I, _P, _P]),
+    "hnr_chain_gather_rec": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _I, _P, _P, _P]),
     "hnr_chain_forward": (_I, [_P, _P, _I, _P, _P, _I, _F, _P, _I, _P, _P, _I, _P]),
     "hnr_mlp3_packed_bytes": (ctypes.c_int64, [_I, ctypes.POINTER(_I)]),
     "hnr_mlp3_pack": (_I, [_I, ctypes.POINTER(_P), ctypes.POINTER(_I), ctypes.POINTER(_I), ctypes.POINTER(_I), ctypes.POINTER(_P), _P, _P]),

@@ -642,7 +642,8 @@ __global__ __launch_bounds__(512, 1) void chain2_kernel(ChainArgs a)
 //   X5[s, 256:280] = view-direction encoding of the sample's ray (:909-913),
 // and optionally the reference's `weight` / `conf_coefficient` outputs [R,SR,K].
 struct ChainGatherArgs {
-    const float *xyz, *conf, *pdir, *color;
+    const float *xyz, *conf, *pdir, *color;              // the four point buffers, or
+    const float4 *rec;                                   // hnr_point_records: [N][3] float4 {x y z conf | dir.xyz r | g b 0 0} (REC kernels)
     const int32_t *pidx;                                 // [R,SR,8]
     const float *loc_w, *raydir, *campos, *camrot;
     const int32_t *vs_item;
@@ -665,6 +666,7 @@ __device__ __forceinline__ void chain_w2pers(const float *p, const float *campos
 
 typedef float f32x4g __attribute__((ext_vector_type(4)));
 
+template <bool REC>
 __global__ __launch_bounds__(256) void chain_gather_kernel(ChainGatherArgs a)
 {
     __shared__ float s_d[128][8];                        // dists6 per row
@@ -691,7 +693,16 @@ __global__ __launch_bounds__(256) void chain_gather_kernel(ChainGatherArgs a)
             const float *lw = a.loc_w + (size_t)item * 3;
             float sp[3], pp[3];
             chain_w2pers(lw, cp, cr, sp);
-            const float px = a.xyz[3 * (size_t)pid], py = a.xyz[3 * (size_t)pid + 1], pz = a.xyz[3 * (size_t)pid + 2];
+            // REC: the point's ten floats from ONE 48-byte record (three 16-B loads, one or two 64-B sectors) instead of four scattered
+            // 4..12-byte reads from four buffers: the same values, fewer sectors fetched per neighbour
+            float4 r0, r1, r2;
+            if constexpr (REC) { r0 = a.rec[3 * (size_t)pid]; r1 = a.rec[3 * (size_t)pid + 1]; r2 = a.rec[3 * (size_t)pid + 2]; }
+            else {
+                r0 = make_float4(a.xyz[3 * (size_t)pid], a.xyz[3 * (size_t)pid + 1], a.xyz[3 * (size_t)pid + 2], a.conf[pid]);
+                r1 = make_float4(a.pdir[3 * (size_t)pid], a.pdir[3 * (size_t)pid + 1], a.pdir[3 * (size_t)pid + 2], a.color[3 * (size_t)pid]);
+                r2 = make_float4(a.color[3 * (size_t)pid + 1], a.color[3 * (size_t)pid + 2], 0.f, 0.f);
+            }
+            const float px = r0.x, py = r0.y, pz = r0.z;
             const float pw[3] = {px, py, pz};
             chain_w2pers(pw, cp, cr, pp);
             const float dx = __fsub_rn(px, lw[0]), dy = __fsub_rn(py, lw[1]), dz = __fsub_rn(pz, lw[2]);
@@ -701,11 +712,11 @@ __global__ __launch_bounds__(256) void chain_gather_kernel(ChainGatherArgs a)
             d6[5] = __fsub_rn(pp[2], sp[2]);
             const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
             wraw = __fdiv_rn(1.0f, fmaxf(nrm, 1e-6f));
-            confc = fminf(fmaxf(a.conf[pid], 0.0001f), 1.0f);
+            confc = fminf(fmaxf(r0.w, 0.0001f), 1.0f);
             const int ray = item / a.SR;
             const float vx = a.raydir[3 * (size_t)ray], vy = a.raydir[3 * (size_t)ray + 1], vz = a.raydir[3 * (size_t)ray + 2];
-            const float ddx = a.pdir[3 * (size_t)pid], ddy = a.pdir[3 * (size_t)pid + 1], ddz = a.pdir[3 * (size_t)pid + 2];
-            ext[0] = a.color[3 * (size_t)pid]; ext[1] = a.color[3 * (size_t)pid + 1]; ext[2] = a.color[3 * (size_t)pid + 2];
+            const float ddx = r1.x, ddy = r1.y, ddz = r1.z;
+            ext[0] = r1.w; ext[1] = r2.x; ext[2] = r2.y;
             ext[3] = __fsub_rn(ddx, vx); ext[4] = __fsub_rn(ddy, vy); ext[5] = __fsub_rn(ddz, vz);
             ext[6] = __fadd_rn(__fadd_rn(__fmul_rn(ddx, vx), __fmul_rn(ddy, vy)), __fmul_rn(ddz, vz));
         }
@@ -989,27 +1000,78 @@ extern "C" int hnr_chain_plan(const int32_t *d_work, const int32_t *d_sample_pid
     return HNR_OK;
 }
 
+namespace hnr {
+__global__ void point_records_kernel(const float *__restrict__ xyz, const float *__restrict__ conf, const float *__restrict__ pdir,
+                                     const float *__restrict__ color, int N, float4 *__restrict__ rec)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+        rec[3 * (size_t)i] = make_float4(xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], conf[i]);
+        rec[3 * (size_t)i + 1] = make_float4(pdir[3 * (size_t)i], pdir[3 * (size_t)i + 1], pdir[3 * (size_t)i + 2], color[3 * (size_t)i]);
+        rec[3 * (size_t)i + 2] = make_float4(color[3 * (size_t)i + 1], color[3 * (size_t)i + 2], 0.f, 0.f);
+    }
+}
+}  // namespace hnr
+
+extern "C" int hnr_point_records(const float *d_xyz, const float *d_conf, const float *d_dir, const float *d_color, int N, float *d_rec,
+                                 void *stream)
+{
+    if (N < 0 || (N > 0 && (!d_xyz || !d_conf || !d_dir || !d_color || !d_rec || ((uintptr_t)d_rec & 15)))) {
+        set_error("hnr_point_records: NULL / unaligned pointer or N < 0"); return HNR_ERR_BADARG;
+    }
+    if (N == 0) return HNR_OK;
+    const int blocks = cdiv(N, 256);
+    point_records_kernel<<<blocks < 8192 ? blocks : 8192, 256, 0, (hipStream_t)stream>>>(d_xyz, d_conf, d_dir, d_color, N, reinterpret_cast<float4 *>(d_rec));
+    HNR_LAUNCH_CHECK();
+    return HNR_OK;
+}
+
+static int chain_gather_impl(const float *d_rec, const float *d_xyz, const float *d_conf, const float *d_dir, const float *d_color,
+                             const int32_t *d_sample_pidx, const float *d_sample_loc_w, const float *d_raydir, const float *d_campos,
+                             const float *d_camrot, const int32_t *d_vs_item, const int64_t *d_counts, int SR, int K, int cap_samples,
+                             void *d_workspace, float *d_X5, int ld5, float *d_weight_out, float *d_conf_out, void *stream);
+
+extern "C" int hnr_chain_gather_rec(const float *d_rec, const int32_t *d_sample_pidx, const float *d_sample_loc_w, const float *d_raydir,
+                                    const float *d_campos, const float *d_camrot, const int32_t *d_vs_item, const int64_t *d_counts, int SR,
+                                    int K, int cap_samples, void *d_workspace, float *d_X5, int ld5, float *d_weight_out,
+                                    float *d_conf_out, void *stream)
+{
+    if (cap_samples > 0 && (!d_rec || ((uintptr_t)d_rec & 15))) { set_error("hnr_chain_gather_rec: NULL / unaligned point records"); return HNR_ERR_BADARG; }
+    return chain_gather_impl(d_rec, nullptr, nullptr, nullptr, nullptr, d_sample_pidx, d_sample_loc_w, d_raydir, d_campos, d_camrot, d_vs_item, d_counts,
+                             SR, K, cap_samples, d_workspace, d_X5, ld5, d_weight_out, d_conf_out, stream);
+}
+
 extern "C" int hnr_chain_gather(const float *d_xyz, const float *d_conf, const float *d_dir, const float *d_color,
                                 const int32_t *d_sample_pidx, const float *d_sample_loc_w, const float *d_raydir, const float *d_campos,
                                 const float *d_camrot, const int32_t *d_vs_item, const int64_t *d_counts, int SR, int K, int cap_samples,
                                 void *d_workspace, float *d_X5, int ld5, float *d_weight_out, float *d_conf_out, void *stream)
 {
+    if (cap_samples > 0 && (!d_xyz || !d_conf || !d_dir || !d_color)) { set_error("hnr_chain_gather: NULL / unaligned pointer"); return HNR_ERR_BADARG; }
+    return chain_gather_impl(nullptr, d_xyz, d_conf, d_dir, d_color, d_sample_pidx, d_sample_loc_w, d_raydir, d_campos, d_camrot, d_vs_item, d_counts,
+                             SR, K, cap_samples, d_workspace, d_X5, ld5, d_weight_out, d_conf_out, stream);
+}
+
+static int chain_gather_impl(const float *d_rec, const float *d_xyz, const float *d_conf, const float *d_dir, const float *d_color,
+                             const int32_t *d_sample_pidx, const float *d_sample_loc_w, const float *d_raydir, const float *d_campos,
+                             const float *d_camrot, const int32_t *d_vs_item, const int64_t *d_counts, int SR, int K, int cap_samples,
+                             void *d_workspace, float *d_X5, int ld5, float *d_weight_out, float *d_conf_out, void *stream)
+{
     if (K != 8) { set_error("hnr_chain_gather: the fused chain is built for K = 8 (got %d); use the per-layer path", K); return HNR_ERR_BADARG; }
     if (cap_samples < 0 || SR <= 0 || ld5 < 280 || (ld5 & 3)) { set_error("hnr_chain_gather: bad sizes (cap_samples=%d SR=%d ld5=%d)", cap_samples, SR, ld5); return HNR_ERR_BADARG; }
     if (cap_samples == 0) return HNR_OK;
-    if (!d_xyz || !d_conf || !d_dir || !d_color || !d_sample_pidx || !d_sample_loc_w || !d_raydir || !d_campos || !d_camrot || !d_vs_item ||
+    if (!d_sample_pidx || !d_sample_loc_w || !d_raydir || !d_campos || !d_camrot || !d_vs_item ||
         !d_counts || !d_workspace || !d_X5 || ((uintptr_t)d_workspace & 15) || (!d_weight_out != !d_conf_out)) {
         set_error("hnr_chain_gather: NULL / unaligned pointer");
         return HNR_ERR_BADARG;
     }
     const int blocks = cdiv(cap_samples, 16) + 1;
     ChainGatherArgs a;
-    a.xyz = d_xyz; a.conf = d_conf; a.pdir = d_dir; a.color = d_color; a.pidx = d_sample_pidx; a.loc_w = d_sample_loc_w;
+    a.xyz = d_xyz; a.conf = d_conf; a.pdir = d_dir; a.color = d_color; a.rec = reinterpret_cast<const float4 *>(d_rec); a.pidx = d_sample_pidx; a.loc_w = d_sample_loc_w;
     a.raydir = d_raydir; a.campos = d_campos; a.camrot = d_camrot; a.vs_item = d_vs_item;
     a.counts = reinterpret_cast<const unsigned long long *>(d_counts); a.SR = SR; a.cap_samples = cap_samples;
     a.xp = (char *)d_workspace; a.aux = (char *)d_workspace + (size_t)blocks * 4 * CH_XP_GROUP;
     a.X5 = d_X5; a.ld5 = ld5; a.weight_out = d_weight_out; a.conf_out = d_conf_out;
-    chain_gather_kernel<<<blocks < 16384 ? blocks : 16384, 256, 0, (hipStream_t)stream>>>(a);
+    if (d_rec) chain_gather_kernel<true><<<blocks < 16384 ? blocks : 16384, 256, 0, (hipStream_t)stream>>>(a);
+    else chain_gather_kernel<false><<<blocks < 16384 ? blocks : 16384, 256, 0, (hipStream_t)stream>>>(a);
     HNR_LAUNCH_CHECK();
     return HNR_OK;
 }

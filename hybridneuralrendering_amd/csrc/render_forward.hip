@@ -107,8 +107,11 @@ extern "C" int hnr_render_forward(const hnr_grid *grid, const hnr_render_params 
     HNR_HIP_CHECK(hipMemsetAsync(o->d_decoded, 0, (size_t)R * SR * 4 * sizeof(float), st));
     HNR_MARK();
     // ---- per-neighbour chain
-    if ((rc = hnr_chain_gather(cl->d_xyz, cl->d_conf, cl->d_dir, cl->d_color, o->d_sample_pidx, o->d_sample_loc_w, cam->d_raydir, cam->d_campos, cam->d_camrot,
-                               L.vs_item, o->d_counts, SR, K, cap, L.chain_ws, L.X5, 280, o->d_weight, o->d_conf_coefficient, stream)) != HNR_OK) return rc;
+    rc = cl->d_rec ? hnr_chain_gather_rec(cl->d_rec, o->d_sample_pidx, o->d_sample_loc_w, cam->d_raydir, cam->d_campos, cam->d_camrot, L.vs_item, o->d_counts,
+                                          SR, K, cap, L.chain_ws, L.X5, 280, o->d_weight, o->d_conf_coefficient, stream)
+                   : hnr_chain_gather(cl->d_xyz, cl->d_conf, cl->d_dir, cl->d_color, o->d_sample_pidx, o->d_sample_loc_w, cam->d_raydir, cam->d_campos, cam->d_camrot,
+                                      L.vs_item, o->d_counts, SR, K, cap, L.chain_ws, L.X5, 280, o->d_weight, o->d_conf_coefficient, stream);
+    if (rc != HNR_OK) return rc;
     HNR_MARK();
     if ((rc = hnr_chain_forward(L.chain_ws, cl->d_point_table, cl->ldt, w->d_chain, o->d_counts, cap, w->slope, L.X5, 280, L.sigma, nullptr, 0, stream)) != HNR_OK) return rc;
     HNR_MARK();

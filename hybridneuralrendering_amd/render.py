@@ -133,6 +133,20 @@ class HybridRenderer:
             self._pt_src = cloud.emb                             # same reason as in feature_map
         return self._pt
 
+    def point_records(self, cloud):
+        """hnr_point_records image of the cloud's xyz / conf / dir / colour buffers (48 B per point: what the fused gather reads per
+        neighbour), rebuilt when any of them changes."""
+        src = (cloud.xyz, cloud.conf, cloud.dir, cloud.color)
+        key = tuple((t.data_ptr(), tuple(t.shape), t._version) for t in src)
+        if key != getattr(self, "_rec_key", None):
+            n = int(cloud.xyz.reshape(-1, 3).shape[0])
+            rec = torch.empty((n, 12), dtype=torch.float32, device=cloud.xyz.device)
+            with torch.cuda.device(cloud.xyz.device):
+                _lib.check(_lib.lib().hnr_point_records(_lib.ptr(cloud.xyz), _lib.ptr(cloud.conf), _lib.ptr(cloud.dir), _lib.ptr(cloud.color), n,
+                                                        _lib.ptr(rec), _lib.stream()), "hnr_point_records")
+            self._rec, self._rec_key, self._rec_src = rec, key, src      # the sources stay referenced: a recycled address is not a stale hit
+        return self._rec
+
     # -- stage 3: gather + aggregate ----------------------------------------------------------------
     def aggregate(self, cloud, qres, raydir, campos, camrot, w2c_nearest, intrinsic_nearest, campos_nearest, featmap,
                   frame_weight=None, want_weights=False, timers=None):
@@ -187,10 +201,10 @@ class HybridRenderer:
                 c_out = cloud.conf[0].clamp(0.0001, 1.0).expand(R, SR, K).contiguous()
             ptab = self.point_table(cloud)
             with T("chain_gather"):
-                _lib.check(L.hnr_chain_gather(p(cloud.xyz), p(cloud.conf), p(cloud.dir), p(cloud.color), p(pidx), p(loc_w), p(raydir),
-                                              p(campos), p(camrot), p(vs_item), p(counts), SR, K, n_valid, p(ws), p(X5), 280,
-                                              p(w_out) if want_weights else None, p(c_out) if want_weights else None, st()),
-                           "hnr_chain_gather")
+                _lib.check(L.hnr_chain_gather_rec(p(self.point_records(cloud)), p(pidx), p(loc_w), p(raydir),
+                                                  p(campos), p(camrot), p(vs_item), p(counts), SR, K, n_valid, p(ws), p(X5), 280,
+                                                  p(w_out) if want_weights else None, p(c_out) if want_weights else None, st()),
+                           "hnr_chain_gather_rec")
             with T("chain"):
                 _lib.check(L.hnr_chain_forward(p(ws), p(ptab), int(ptab.stride(0)), p(self.agg.packed_chain()), p(counts), n_valid,
                                                float(pk["slope"]), p(X5), 280, p(sigma), None, 0, st()), "hnr_chain_forward")
@@ -357,7 +371,7 @@ class HybridRenderer:
         pk, agg = self.agg.packed(), self.agg
         m3 = agg.packed_mlp3()
         ptab = self.point_table(cloud)
-        cl = _lib.RenderCloud(p(cloud.xyz), p(cloud.conf), p(cloud.dir), p(cloud.color), p(ptab), int(ptab.stride(0)))
+        cl = _lib.RenderCloud(p(cloud.xyz), p(cloud.conf), p(cloud.dir), p(cloud.color), p(ptab), int(ptab.stride(0)), p(self.point_records(cloud)))
         wt = _lib.RenderWeights(p(agg.packed_chain()), p(m3["cf"].packed), p(m3["mw"].packed), p(m3["mx"].packed),
                                 p(pk["mw_last_w"]), p(pk["mw_last_b"]), p(pk["fin_w"]), p(pk["fin_b"]), float(pk["slope"]))
         cam = _lib.RenderCamera(p(campos), p(camrot), p(raydir), p(tmid), p(bg_color))

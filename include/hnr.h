@@ -325,6 +325,13 @@ int hnr_chain_gather(const float *d_xyz, const float *d_conf, const float *d_dir
                      const int32_t *d_sample_pidx, const float *d_sample_loc_w, const float *d_raydir, const float *d_campos,
                      const float *d_camrot, const int32_t *d_vs_item, const int64_t *d_counts, int SR, int K, int cap_samples,
                      void *d_workspace, float *d_X5, int ld5, float *d_weight_out, float *d_conf_out, void *stream);
+/* hnr_point_records: the four per-point buffers the gather reads, interleaved once per cloud version into 48-byte records
+ *   d_rec [N][12] f32 = {x y z conf | dir.x dir.y dir.z r | g b 0 0}; hnr_chain_gather_rec = hnr_chain_gather reading them (the same values,
+ *   bit-identical outputs): one or two 64-byte sectors per neighbour instead of four scattered reads (gather fetch 6.0 -> see profiles). */
+int hnr_point_records(const float *d_xyz, const float *d_conf, const float *d_dir, const float *d_color, int N, float *d_rec, void *stream);
+int hnr_chain_gather_rec(const float *d_rec, const int32_t *d_sample_pidx, const float *d_sample_loc_w, const float *d_raydir,
+                         const float *d_campos, const float *d_camrot, const int32_t *d_vs_item, const int64_t *d_counts, int SR, int K,
+                         int cap_samples, void *d_workspace, float *d_X5, int ld5, float *d_weight_out, float *d_conf_out, void *stream);
 int hnr_chain_forward(const void *d_workspace, const float *d_point_table, int ldt, const void *d_packed, const int64_t *d_counts,
                       int cap_samples, float slope, float *d_X5, int ld5, float *d_sigma, float *d_dbg, int dbg_layer, void *stream);
 
@@ -515,6 +522,8 @@ typedef struct {
 typedef struct {
     const float *d_xyz, *d_conf, *d_dir, *d_color;      /* [N,3] [N] [N,3] [N,3]                                       */
     const float *d_point_table; int ldt;                /* [N, ldt >= 256] per-point addend of block1.0                 */
+    const float *d_rec;                                 /* optional hnr_point_records image of the four buffers above ([N,12]); NULL: the
+                                                           gather reads the four buffers                                */
 } hnr_render_cloud;
 typedef struct {
     const void  *d_chain;                               /* hnr_chain_pack                                               */

@@ -24,6 +24,18 @@ for it in range(2):
                                       p(W["camrot"]), p(W["vs_item"]), p(q["counts"]), W["SR"], W["K"], nv, p(ws), p(X5), 280, None, None, _lib.stream()), "g")
     g1.record(); torch.cuda.synchronize()
 print("chain_gather %.3f ms per launch" % (g0.elapsed_time(g1) / 5))
+# the same gather reading hnr_point_records' 48-byte records: bit-identical workspace, fewer sectors per neighbour
+rec = torch.empty((c.xyz.shape[0], 12), dtype=torch.float32, device=dev)
+_lib.check(L.hnr_point_records(p(c.xyz), p(c.conf), p(c.dir), p(c.color), c.xyz.shape[0], p(rec), _lib.stream()), "r")
+ws2 = torch.empty_like(ws); X5b = torch.empty_like(X5)
+for it in range(2):
+    g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    g0.record()
+    for _ in range(5):
+        _lib.check(L.hnr_chain_gather_rec(p(rec), p(q["sample_pidx"]), p(q["sample_loc_w"]), p(W["raydir"]), p(W["campos"]), p(W["camrot"]), p(W["vs_item"]),
+                                          p(q["counts"]), W["SR"], W["K"], nv, p(ws2), p(X5b), 280, None, None, _lib.stream()), "g")
+    g1.record(); torch.cuda.synchronize()
+print("chain_gather_rec %.3f ms per launch; workspace identical: %s" % (g0.elapsed_time(g1) / 5, bool(torch.equal(ws, ws2))))
 dbg = torch.zeros(((NW * 16 + 4 * 1024 + 64) * 2,), dtype=torch.float32, device=dev)
 pk = W["agg"].packed_chain()
 MODE = -int(os.environ.get('PROBE_MODE', '1'))          # -1: phase timing; -3 / -4 / -5 (dual-group kernel only): no epilogue work / same weights / both
