@@ -50,8 +50,12 @@ __device__ long long g_mlp_probe[24];
 // RT = row tiles of 32 rows per workgroup tile.  RT = 4 (128 rows): one workgroup per CU when layer 0 is wide (280 inputs = 144 KiB of operand
 // planes); RT = 2 (64 rows): two workgroups per CU, so that one's prologue (row loads, scaling, fp16 split: latency and VALU) runs under the
 // other's MFMAs -- the phases of a single workgroup are serial.
+// workgroups per CU a variant is built for (registers) and launched with (the LDS planes of layer 0 allow them): the phases of a tile are
+// serial (load + split, MFMA, epilogue, barriers), so co-resident workgroups are what keeps the CU busy
+constexpr int mlp3_wgs_per_cu(int S0, int RT, int MODE) { return MODE == 1 ? 2 : RT >= 4 ? 1 : RT == 1 ? 4 : S0 <= 6 ? 3 : 2; }
+
 template <int S0, int S1, int S2, int S3, int MODE, int RT = 4>
-__global__ __launch_bounds__(256, (MODE == 1 || RT < 4) ? 2 : 1) void mlp3_kernel(MlpArgs a)
+__global__ __launch_bounds__(256, mlp3_wgs_per_cu(S0, RT, MODE)) void mlp3_kernel(MlpArgs a)
 {
     static_assert(MODE != 1 || RT == 4, "the merge stage is built on 128-row tiles (32 samples x 4 views)");
     constexpr int SLOT = RT * 2048, ROWS = 32 * RT;                        // LDS bytes per k step of the planes: [row tile RT][plane 2][64 lanes][16 B]
@@ -593,7 +597,7 @@ extern "C" int hnr_mlp3_forward(const float *d_A, int lda, int64_t M_cap, const 
         constexpr int smax3 = S0_ > S1_ ? (S0_ > S2_ ? S0_ : S2_) : (S1_ > S2_ ? S1_ : S2_), smax = smax3 > S3_ ? smax3 : S3_;          \
         constexpr int ldsb = smax * RT_ * 2048 + 32 * RT_ * 4 * 4 + 32 * RT_ * 4;                                                       \
         const int64_t tiles = (M_cap + 32 * RT_ - 1) / (32 * RT_);                                                                      \
-        const int wgs = (RT_ < 4 ? 2 : 1) * n_cu, grid = (int)(tiles < wgs ? tiles : wgs);                                              \
+        const int wgs = mlp3_wgs_per_cu(S0_, RT_, 0) * n_cu, grid = (int)(tiles < wgs ? tiles : wgs);                                              \
         static bool attr = false;                                                                                                       \
         if (!attr) { HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(mlp3_kernel<S0_, S1_, S2_, S3_, 0, RT_>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb)); attr = true; } \
         mlp3_kernel<S0_, S1_, S2_, S3_, 0, RT_><<<grid, 256, ldsb, st>>>(a);                                                             \
@@ -601,10 +605,10 @@ extern "C" int hnr_mlp3_forward(const float *d_A, int lda, int64_t M_cap, const 
         HNR_LAUNCH_CHECK();                                                                                                             \
         return HNR_OK;                                                                                                                  \
     }
-    HNR_MLP3_CASE(18, 8, 8, 0, 2)     // color_feature_branch: 280 -> 128 -> 128 -> 128
+    HNR_MLP3_CASE(18, 8, 8, 0, 2)     // color_feature_branch: 280 -> 128 -> 128 -> 128 (32-row tiles with 3 or 4 workgroups per CU: 2.63 / 2.61 vs 2.45 ms)
     HNR_MLP3_CASE(18, 8, 8, 8, 2)     // the same + tail 128 -> 64: the colour-feature columns of aux_merge_weight_block.0, once per sample
     HNR_MLP3_CASE(3, 4, 4, 0, 4)      // aux_merge_weight_block: 48 -> 64 -> 64 -> 64
-    HNR_MLP3_CASE(6, 3, 3, 0, 2)      // color_mixup_block: 90 -> 45 -> 45 -> 45
+    HNR_MLP3_CASE(6, 3, 3, 0, 2)      // color_mixup_block: 90 -> 45 -> 45 -> 45 (three workgroups per CU: 0.84 -> 0.66 ms; four spill: 0.80)
 #undef HNR_MLP3_CASE
     set_error("hnr_mlp3_forward: no kernel for k steps (%d, %d, %d, %d); built: (18,8,8,0) (18,8,8,8) (3,4,4,0) (6,3,3,0)", S[0], S[1], S[2], S[3]);
     return HNR_ERR_BADARG;
