@@ -52,7 +52,7 @@ __device__ long long g_mlp_probe[24];
 // other's MFMAs -- the phases of a single workgroup are serial.
 // workgroups per CU a variant is built for (registers) and launched with (the LDS planes of layer 0 allow them): the phases of a tile are
 // serial (load + split, MFMA, epilogue, barriers), so co-resident workgroups are what keeps the CU busy
-constexpr int mlp3_wgs_per_cu(int S0, int RT, int MODE) { return MODE == 1 ? 2 : RT >= 4 ? 1 : RT == 1 ? 4 : S0 <= 6 ? 3 : 2; }
+constexpr int mlp3_wgs_per_cu(int S0, int RT, int MODE) { return MODE == 1 ? 2 : RT >= 4 ? 1 : (RT == 1 || S0 <= 6) ? 4 : 2; }
 
 template <int S0, int S1, int S2, int S3, int MODE, int RT = 4>
 __global__ __launch_bounds__(256, mlp3_wgs_per_cu(S0, RT, MODE)) void mlp3_kernel(MlpArgs a)
@@ -90,8 +90,15 @@ __global__ __launch_bounds__(256, mlp3_wgs_per_cu(S0, RT, MODE)) void mlp3_kerne
     int *s_pix = reinterpret_cast<int *>(s_f + 128 * 48);
     float *s_vm = reinterpret_cast<float *>(s_pix + 128), *s_w = s_vm + 128;
     float *s_wl = s_w + 128;                                               // MODE 1: the last merge-weight layer's 64 weights (+ zero padding to 128)
-    const int col0 = 32 * wave + 16 * h;                                   // this lane's columns: col0 + r
-    const unsigned woff = (unsigned)wave * 2048u + (unsigned)lane * 16u;
+    // Which (row tile, column tile) pairs a wave multiplies.  Wide layers (N = 128): wave w = column tile w of all RT row tiles.  When every layer is
+    // at most 64 wide (merge weights 48 -> 64 -> 64 -> 64, mix-up 90 -> 45 -> 45 -> 45) that left waves 2 and 3 idle through every MFMA loop and
+    // epilogue: there the rows are split too (RS) -- wave w = column tile w & 1 of the row tiles (w >> 1) RTW .. + RTW - 1.  Same arithmetic per element.
+    constexpr bool RS = S1 <= 4 && S2 <= 4 && S3 == 0 && RT >= 2;
+    constexpr int RTW = RS ? RT / 2 : RT;                                  // row tiles per wave
+    const int cw = RS ? (wave & 1) : wave, rt0 = RS ? (wave >> 1) * RTW : 0;
+    const int col0 = 32 * cw + 16 * h;                                     // this lane's columns: col0 + r
+    const unsigned woff = (unsigned)cw * 2048u + (unsigned)lane * 16u;
+    const char *lds_b = lds + rt0 * 2048;                                  // the wave's first row tile in every k step's slot
     const f32x2 slope2 = {a.slope, a.slope};
 
     if (MODE == 1) {                                                       // (the first tile's prologue barriers order this before its first use)
@@ -105,7 +112,7 @@ __global__ __launch_bounds__(256, mlp3_wgs_per_cu(S0, RT, MODE)) void mlp3_kerne
         int tid_t = tid;                                                   // laundered per tile: the per-thread index arithmetic below (idx / 45 ...) is cheap, but hoisted out of the
         asm volatile("" : "+v"(tid_t));                                    // tile loop it becomes a dozen 64-bit addresses per thread that the register allocator spills to scratch
         MLP_STAMP(0);
-        float inv[RT];
+        float inv[RTW];
         if (MODE == 1) {
             // ---- merge-stage prologue.  Row t of the tile = (sample ls = t >> 2, view v = t & 3): a sample's four views sit in adjacent rows.
             // (a) reprojection into the view (w2iproject, neural_points_volumetric_model.py:248-255), truncation to a pixel + bounds rule
@@ -251,27 +258,27 @@ __global__ __launch_bounds__(256, mlp3_wgs_per_cu(S0, RT, MODE)) void mlp3_kerne
         {
             const float dw0 = meta[ML_DESC + 0];
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) inv[rt] = __fmul_rn(rowinv[32 * rt + j], dw0);
+            for (int rt = 0; rt < RTW; ++rt) inv[rt] = __fmul_rn(rowinv[32 * (rt0 + rt) + j], dw0);
         }
 
-        f32x16 acc[RT][1];
+        f32x16 acc[RTW][1];
         auto zero_acc = [&]() {
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
+            for (int rt = 0; rt < RTW; ++rt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[rt][0][r] = 0.f;
         };
         // the gathered first-layer addend rows of all row tiles: asked for BEFORE the layer's MFMA loop, used in its epilogue
         float4 ad[2][4];                                                   // ring of two row tiles: two rows' loads in flight while one is used
         auto load_addend = [&](int rt) {
-            long long row = row_base + 32 * rt + j;
+            long long row = row_base + 32 * (rt0 + rt) + j;
             if (row >= M) row = M - 1;
             const float *rrow = a.R + (size_t)(MODE == 1 ? row / 4 : (long long)a.ridx[phys(row)]) * a.ldr + col0;
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) ad[rt & 1][q4] = *reinterpret_cast<const float4 *>(rrow + 4 * q4);
         };
         // v = acc * inv + bias (+ addend) (+ LeakyReLU); returns the per-row maxima of this wave's columns
-        auto activate = [&](int layer, float (&amax)[RT], auto with_addend) {
+        auto activate = [&](int layer, float (&amax)[RTW], auto with_addend) {
             constexpr bool ADD = decltype(with_addend)::value;
             f32x2 bias[8];
 #pragma unroll
@@ -280,9 +287,9 @@ __global__ __launch_bounds__(256, mlp3_wgs_per_cu(S0, RT, MODE)) void mlp3_kerne
                 bias[2 * q] = f32x2{b.x, b.y}; bias[2 * q + 1] = f32x2{b.z, b.w};
             }
             const bool act = a.act[layer] != 0;
-            if (ADD && MODE != 1) { load_addend(0); if (RT > 1) load_addend(1); }          // (the merge stage asks for them under its layer-0 MFMAs)
+            if (ADD && MODE != 1) { load_addend(0); if (RTW > 1) load_addend(1); }         // (the merge stage asks for them under its layer-0 MFMAs)
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
+            for (int rt = 0; rt < RTW; ++rt) {
                 float m = 0.f;
                 const f32x2 inv2 = {inv[rt], inv[rt]};
 #pragma unroll
@@ -295,20 +302,21 @@ __global__ __launch_bounds__(256, mlp3_wgs_per_cu(S0, RT, MODE)) void mlp3_kerne
                     m = fmaxf(fmaxf(m, fabsf(v.x)), fabsf(v.y));
                 }
                 amax[rt] = m;
-                if (ADD && rt + 2 < RT) load_addend(rt + 2);
+                if (ADD && rt + 2 < RTW) load_addend(rt + 2);
             }
         };
-        auto publish = [&](int next_layer, bool active, float (&amax)[RT]) {
+        auto publish = [&](int next_layer, bool active, float (&amax)[RTW]) {
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
+            for (int rt = 0; rt < RTW; ++rt) {
                 const float m = active ? fmaxf(amax[rt], __shfl_xor(amax[rt], 32)) : 0.f;
-                if (h == 0) exch[(32 * rt + j) * 4 + wave] = m;
+                if (h == 0) exch[(32 * (rt0 + rt) + j) * 4 + cw] = m;
             }
             __syncthreads();                                               // every wave has finished reading the previous planes
             const float dw = meta[ML_DESC + next_layer];
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
-                const float4 m4 = *reinterpret_cast<const float4 *>(exch + (32 * rt + j) * 4);
+            for (int rt = 0; rt < RTW; ++rt) {
+                float4 m4 = *reinterpret_cast<const float4 *>(exch + (32 * (rt0 + rt) + j) * 4);
+                if (RS) { m4.z = 0.f; m4.w = 0.f; }                        // two column tiles only (what the idle waves 2, 3 used to contribute: 0)
                 const int k = row_scale_exp(fmaxf(fmaxf(m4.x, m4.y), fmaxf(m4.z, m4.w)));
                 const float sc = pow2f(k);
                 const f32x2 sc2 = {sc, sc};
@@ -320,7 +328,7 @@ __global__ __launch_bounds__(256, mlp3_wgs_per_cu(S0, RT, MODE)) void mlp3_kerne
                         const f32x2 vs = f32x2{acc[rt][0][2 * q], acc[rt][0][2 * q + 1]} * sc2;
                         split2h(vs.x, vs.y, ph[q], pm[q]);
                     }
-                    char *dst = lds + (2 * wave + h) * SLOT + (rt * 2) * 1024 + j * 16;
+                    char *dst = lds + (2 * cw + h) * SLOT + ((rt0 + rt) * 2) * 1024 + j * 16;
                     *reinterpret_cast<u32x4 *>(dst) = u32x4{ph[0], ph[1], ph[2], ph[3]};
                     *reinterpret_cast<u32x4 *>(dst + 512) = u32x4{ph[4], ph[5], ph[6], ph[7]};
                     *reinterpret_cast<u32x4 *>(dst + 1024) = u32x4{pm[0], pm[1], pm[2], pm[3]};
@@ -331,8 +339,8 @@ __global__ __launch_bounds__(256, mlp3_wgs_per_cu(S0, RT, MODE)) void mlp3_kerne
         };
         auto store = [&](float *C, int ldc) {
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
-                const long long row = row_base + 32 * rt + j;
+            for (int rt = 0; rt < RTW; ++rt) {
+                const long long row = row_base + 32 * (rt0 + rt) + j;
                 if (row < M) {
                     float *o = C + (size_t)phys(row) * ldc + col0;
 #pragma unroll
@@ -344,12 +352,12 @@ __global__ __launch_bounds__(256, mlp3_wgs_per_cu(S0, RT, MODE)) void mlp3_kerne
                 }
             }
         };
-        const bool act0 = 32 * wave < a.N[0], act1 = 32 * wave < a.N[1], act2 = 32 * wave < a.N[2];
-        float amax[RT];
+        const bool act0 = 32 * cw < a.N[0], act1 = 32 * cw < a.N[1], act2 = 32 * cw < a.N[2];
+        float amax[RTW];
         // ---- layer 0
         zero_acc();
         if (act0) {
-            h2_mfma_layer<RT, 1, S0, 0, ML_WSTEP, SLOT>(wsrd, a.wbase[0], woff, lds, lane, acc, []() {}, [&]() { if (MODE == 1) { load_addend(0); load_addend(1); } });
+            h2_mfma_layer<RTW, 1, S0, 0, ML_WSTEP, SLOT>(wsrd, a.wbase[0], woff, lds_b, lane, acc, []() {}, [&]() { if (MODE == 1) { load_addend(0); load_addend(1); } });
             MLP_STAMP(3);
             if (a.R) activate(0, amax, std::true_type{}); else activate(0, amax, std::false_type{});
             MLP_STAMP(4);
@@ -359,7 +367,7 @@ __global__ __launch_bounds__(256, mlp3_wgs_per_cu(S0, RT, MODE)) void mlp3_kerne
         // ---- layer 1
         zero_acc();
         if (act1) {
-            h2_mfma_layer<RT, 1, S1, 0, ML_WSTEP, SLOT>(wsrd, a.wbase[1], woff, lds, lane, acc, []() {});
+            h2_mfma_layer<RTW, 1, S1, 0, ML_WSTEP, SLOT>(wsrd, a.wbase[1], woff, lds_b, lane, acc, []() {});
             MLP_STAMP(6);
             activate(1, amax, std::false_type{});
         }
@@ -370,7 +378,7 @@ __global__ __launch_bounds__(256, mlp3_wgs_per_cu(S0, RT, MODE)) void mlp3_kerne
         float4 wl4[4];                                                     // MODE 1: this lane's 16 weights of aux_merge_weight_block's last layer
         zero_acc();
         if (act2) {
-            h2_mfma_layer<RT, 1, S2, 0, ML_WSTEP, SLOT>(wsrd, a.wbase[2], woff, lds, lane, acc, []() {});
+            h2_mfma_layer<RTW, 1, S2, 0, ML_WSTEP, SLOT>(wsrd, a.wbase[2], woff, lds_b, lane, acc, []() {});
             MLP_STAMP(8);
             activate(2, amax, std::false_type{});
             MLP_STAMP(9);
@@ -393,19 +401,20 @@ __global__ __launch_bounds__(256, mlp3_wgs_per_cu(S0, RT, MODE)) void mlp3_kerne
             // ---- last layer of aux_merge_weight_block (64 -> 1) + sigmoid, validity / frame weights (:1199), weighted merge over the 4 views
             // (:1217) and the mix-up row (:1286-1292)
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
+            for (int rt = 0; rt < RTW; ++rt) {
                 float d = 0.f;
                 if (act2) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) d = fmaf(acc[rt][0][r], reinterpret_cast<const float *>(wl4)[r], d);
                     d = __fadd_rn(d, __shfl_xor(d, 32));
                 }
-                if (h == 0) exch[(32 * rt + j) * 4 + wave] = d;
+                if (h == 0) exch[(32 * (rt0 + rt) + j) * 4 + cw] = d;
             }
             __syncthreads();
             MLP_STAMP(14);
             if (tid < 128) {
-                const float4 d4 = *reinterpret_cast<const float4 *>(exch + tid * 4);
+                float4 d4 = *reinterpret_cast<const float4 *>(exch + tid * 4);
+                if (RS) { d4.z = 0.f; d4.w = 0.f; }
                 const float d = __fadd_rn(__fadd_rn(d4.x, d4.y), __fadd_rn(d4.z, d4.w));
                 float wv = 1.f / (1.f + expf(-(d + a.b_last[0])));
                 wv *= s_vm[tid];
@@ -436,7 +445,7 @@ __global__ __launch_bounds__(256, mlp3_wgs_per_cu(S0, RT, MODE)) void mlp3_kerne
             publish(3, act2, amax);
             zero_acc();
             if (32 * wave < a.N[3]) {
-                h2_mfma_layer<RT, 1, (S3 > 0 ? S3 : 1), 0, ML_WSTEP, SLOT>(wsrd, a.wbase[3], woff, lds, lane, acc, []() {});
+                h2_mfma_layer<RTW, 1, (S3 > 0 ? S3 : 1), 0, ML_WSTEP, SLOT>(wsrd, a.wbase[3], woff, lds_b, lane, acc, []() {});
                 activate(3, amax, std::false_type{});
                 store(a.C2, a.ldc2);
             }
@@ -594,6 +603,8 @@ extern "C" int hnr_mlp3_forward(const float *d_A, int lda, int64_t M_cap, const 
     // RT_ = row tiles per workgroup tile: 2 (64 rows, two workgroups per CU) where four (128 rows) would leave room for one workgroup only
 #define HNR_MLP3_CASE(S0_, S1_, S2_, S3_, RT_)                                                                                         \
     if (S[0] == S0_ && S[1] == S1_ && S[2] == S2_ && S[3] == S3_) {                                                                     \
+        if (S1_ <= 4 && S2_ <= 4 && S3_ == 0 && RT_ >= 2 && N[2] > 64) {   /* the row-split wave mapping of the narrow variants: two column tiles */ \
+            set_error("hnr_mlp3_forward: N[2] = %d > 64 with 64-wide hidden layers is not built", N[2]); return HNR_ERR_BADARG; }             \
         constexpr int smax3 = S0_ > S1_ ? (S0_ > S2_ ? S0_ : S2_) : (S1_ > S2_ ? S1_ : S2_), smax = smax3 > S3_ ? smax3 : S3_;          \
         constexpr int ldsb = smax * RT_ * 2048 + 32 * RT_ * 4 * 4 + 32 * RT_ * 4;                                                       \
         const int64_t tiles = (M_cap + 32 * RT_ - 1) / (32 * RT_);                                                                      \
