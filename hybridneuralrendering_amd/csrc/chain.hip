@@ -842,11 +842,13 @@ __global__ void chain_pack_kernel(ChainPackArgs a)
 // ------------------------------------------------------------------------------------------------------------------------
 // hnr_chain_plan: the chain's list of valid samples.  Two-level scan over the kept-sample work list (no atomics, deterministic), like
 // hnr_sample_plan; with `classes` the samples with more than 4 neighbours come first, those with 1..4 after them (stable in both).
-__device__ __forceinline__ int chain_count_neighbours(const int32_t *__restrict__ p, int K)
+// class of a kept sample: 1 = more than four neighbours (or any, with one class), 2 = one to four, 0 = none.  Valid ids are a prefix of the K
+// slots (reference :494-496; the sorted order too), so slots 0 and 4 decide -- two independent loads, not a dependent walk over the slots
+__device__ __forceinline__ int chain_sample_class(const int32_t *__restrict__ p, int K, int classes)
 {
-    int n = 0;                                        // valid ids are a prefix (reference :494-496)
-    while (n < K && p[n] >= 0) ++n;
-    return n;
+    const int p0 = p[0], p4 = (classes && K > 4) ? p[4] : -1;
+    if (p0 < 0) return 0;
+    return (!classes || p4 >= 0) ? 1 : 2;
 }
 
 __global__ __launch_bounds__(1024) void chain_plan_sum_kernel(const int32_t *__restrict__ work, const int32_t *__restrict__ pidx,
@@ -856,8 +858,8 @@ __global__ __launch_bounds__(1024) void chain_plan_sum_kernel(const int32_t *__r
     __shared__ int s_a[16], s_b[16];
     const int n_items = (int)counts[HNR_CNT_SAMPLES];
     const int i = blockIdx.x * 1024 + threadIdx.x;
-    const int nb = i < n_items ? chain_count_neighbours(pidx + (size_t)work[i] * K, K) : 0;
-    int big = (nb > 4 || (nb > 0 && !classes)) ? 1 : 0, small = (nb > 0 && !big) ? 1 : 0;
+    const int cl = i < n_items ? chain_sample_class(pidx + (size_t)work[i] * K, K, classes) : 0;
+    int big = cl == 1 ? 1 : 0, small = cl == 2 ? 1 : 0;
     for (int o = 32; o > 0; o >>= 1) { big += __shfl_xor(big, o); small += __shfl_xor(small, o); }
     if ((threadIdx.x & 63) == 0) { s_a[threadIdx.x >> 6] = big; s_b[threadIdx.x >> 6] = small; }
     __syncthreads();
@@ -895,9 +897,9 @@ __global__ __launch_bounds__(1024) void chain_plan_scan_kernel(const int32_t *__
     }
     __syncthreads();
     const int total_big = s_base[2];
-    int item = 0, nb = 0;
-    if (i < n_items) { item = work[i]; nb = chain_count_neighbours(pidx + (size_t)item * K, K); }
-    const int big = (nb > 4 || (nb > 0 && !classes)) ? 1 : 0, small = (nb > 0 && !big) ? 1 : 0;
+    int item = 0, cl = 0;
+    if (i < n_items) { item = work[i]; cl = chain_sample_class(pidx + (size_t)item * K, K, classes); }
+    const int big = cl == 1 ? 1 : 0, small = cl == 2 ? 1 : 0;
     int ia = big, ib = small;
     for (int o = 1; o < 64; o <<= 1) {
         const int t0 = __shfl_up(ia, o), t1 = __shfl_up(ib, o);
