@@ -586,6 +586,7 @@ __global__ __launch_bounds__(256) void final_color_kernel(FinalArgs a)
 #pragma unroll
         for (int e = 0; e < 8; ++e) w[j][e] = a.w_fin[j * 128 + 8 * l16 + e];
     const float b0 = a.b_fin[0], b1 = a.b_fin[1], b2 = a.b_fin[2];
+    const bool yvec = a.ldy >= 48 && (a.ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(a.Y) & 15) == 0;
     const int wave_g = (int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6), n_waves = (int)((gridDim.x * (unsigned)blockDim.x) >> 6);
     for (int s0 = 4 * wave_g; s0 < n_valid; s0 += 4 * n_waves) {
         const int s = s0 + sub;
@@ -593,10 +594,19 @@ __global__ __launch_bounds__(256) void final_color_kernel(FinalArgs a)
         const size_t sc = ok ? (size_t)s : (size_t)(n_valid - 1);
         const float4 c0 = *reinterpret_cast<const float4 *>(a.CF + sc * a.ldcf + 8 * l16), c1 = *reinterpret_cast<const float4 *>(a.CF + sc * a.ldcf + 8 * l16 + 4);
         float x[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+        if (yvec) {                                                         // mix-up rows padded to 48 columns: two 16-B loads in the six lanes that hold them
+            if (l16 < 6) {
+                const float4 y0 = *reinterpret_cast<const float4 *>(a.Y + sc * a.ldy + 8 * l16), y1 = *reinterpret_cast<const float4 *>(a.Y + sc * a.ldy + 8 * l16 + 4);
+                const float y[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int c = 8 * l16 + e;
-            if (c < 45) x[e] = a.Y[sc * a.ldy + c] + x[e];                  // learn_residuals (:1294): mix-up output + colour feature, same operand order as before
+                for (int e = 0; e < 8; ++e) if (8 * l16 + e < 45) x[e] = y[e] + x[e];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int c = 8 * l16 + e;
+                if (c < 45) x[e] = a.Y[sc * a.ldy + c] + x[e];              // learn_residuals (:1294): mix-up output + colour feature, same operand order as before
+            }
         }
         float r[3] = {0.f, 0.f, 0.f};
 #pragma unroll
