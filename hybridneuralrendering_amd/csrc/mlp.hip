@@ -117,12 +117,14 @@ __global__ __launch_bounds__(256, mlp3_wgs_per_cu(S0, RT, MODE)) void mlp3_kerne
             // ---- merge-stage prologue.  Row t of the tile = (sample ls = t >> 2, view v = t & 3): a sample's four views sit in adjacent rows.
             // (a) reprojection into the view (w2iproject, neural_points_volumetric_model.py:248-255), truncation to a pixel + bounds rule
             //     (point_aggregators.py:1077-1088), delta view direction (:296-310) -- the arithmetic of proj_rows_kernel;
-            if (tid < 128) {
-                const int ls = tid >> 2, v = tid & 3;
+            //     threads 0..127 take the projection of row tid, threads 128..255 the direction deltas of row tid - 128 (waves 2, 3 used to idle here)
+            {
+                const int row_t = tid & 127, ls = row_t >> 2, v = row_t & 3;
                 long long sidx = row_base / 4 + ls;
                 if (sidx * 4 >= M) sidx = M / 4 - 1;
                 const float *pw = a.loc_w + (size_t)a.vs_item[sidx] * 3;
                 const float x = pw[0], y = pw[1], z = pw[2];
+              if (tid < 128) {
                 const float *mm = a.w2c + 16 * v;
                 float c[3];
 #pragma unroll
@@ -138,11 +140,13 @@ __global__ __launch_bounds__(256, mlp3_wgs_per_cu(S0, RT, MODE)) void mlp3_kerne
                 if (inval) { px = 0; py = 0; }
                 s_pix[tid] = ((v * a.H + py) * a.W + px) * 48;
                 s_vm[tid] = inval ? 0.f : 1.f;
+              } else {
                 const float cx = x - a.campos[0], cy = y - a.campos[1], cz = z - a.campos[2];
                 const float cn = sqrtf(cx * cx + cy * cy + cz * cz) + 1e-6f;
                 const float nx = x - a.campos_n[3 * v], ny = y - a.campos_n[3 * v + 1], nz = z - a.campos_n[3 * v + 2];
                 const float nn = sqrtf(nx * nx + ny * ny + nz * nz) + 1e-6f;
-                s_f[tid * 48 + 45] = nx / nn - cx / cn; s_f[tid * 48 + 46] = ny / nn - cy / cn; s_f[tid * 48 + 47] = nz / nn - cz / cn;
+                s_f[row_t * 48 + 45] = nx / nn - cx / cn; s_f[row_t * 48 + 46] = ny / nn - cy / cn; s_f[row_t * 48 + 47] = nz / nn - cz / cn;
+              }
             }
             MLP_STAMP(13);
             __syncthreads();
