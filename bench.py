@@ -100,7 +100,7 @@ def build_world(args, dev, rank):
     cloud = PointCloud(t(sc.xyz), t(sc.emb), t(sc.conf), t(sc.dir), t(sc.color))
     rnd = HybridRenderer(opt, agg, dev)
     if "HNR_KNN_ORDER" not in os.environ:
-        rnd.knn_order = args.knn_order if opt.K == 8 else "reference"
+        rnd.knn_order = getattr(args, "knn_order", "sorted") if opt.K == 8 else "reference"
     # rank-specific camera: same scene, slightly different pose (weak scaling: every GPU renders a whole frame)
     eye = sc.c2w[:3, 3] + np.array([0.05, -0.04, 0.01], np.float32) * rank
     tgt = sc.c2w[:3, 3] + sc.c2w[:3, 2] * 3.0
@@ -434,8 +434,8 @@ def main():
                 # per valid sample with more than four neighbours, 4 slots for the others (hnr_chain_plan's two classes), and to whole
                 # 128-row tiles per class; every fp32 product is issued as THREE fp16 MFMA products (two-term operand split), K rounded
                 # up to 16 per layer (60 -> 64, 263 -> 272).
-                n_small = int(counts[CNT["SAMPLES_SMALL"]])
-                rows_pad = 128 * ((n_valid - n_small + 15) // 16 + (n_small + 31) // 32)
+                n_small, n_tiny = int(counts[CNT["SAMPLES_SMALL"]]), int(counts[CNT["SAMPLES_TINY"]])
+                rows_pad = 128 * ((n_valid - n_small - n_tiny + 15) // 16 + (n_small + 31) // 32 + (n_tiny + 63) // 64)
                 issued = 3.0 * 2.0 * rows_pad * 256 * (64 + 256 + 272 + 256)
                 alg = 2.0 * n_rows * 256 * (60 + 256 + 263 + 256) + 2.0 * n_rows * 256          # executed layers + alpha branch (SURVEY 8d counts 284 columns
                 ach = issued / (ms_ch * 1e-3) / 1e12                                             # for block1.0: 224 of them live in the per-point table)
@@ -457,8 +457,8 @@ def main():
                                  "row / layer scales, fp32 accumulate) / HIP-event time of the launch, against the 2.5 PFLOP/s dense 16-bit peak; "
                                  "frac_algorithmic = 2 M N K fp32 flops of the four layers on the VALID rows / time / the same peak; algorithmic bytes = "
                                  "168 B per valid neighbour (SURVEY 8d) + 1028 B of sums per valid sample; padding to 8 row slots per sample "
-                                 "(4 for the %d samples with at most four neighbours) costs %.1f %% extra rows" % (
-                                     n_small, 100.0 * (rows_pad / max(n_rows, 1) - 1.0)),
+                                 "(4 for the %d samples with three or four neighbours, 2 for the %d with one or two) costs %.1f %% extra rows" % (
+                                     n_small, n_tiny, 100.0 * (rows_pad / max(n_rows, 1) - 1.0)),
                             neighbour_stage=dict(chain_ms=round(ms_ch, 3), gather_ms=round(stage_ms.get("chain_gather", 0.0), 3)))
             elif split and ms_3 > 0:
                 # dominant kernel: the split-bf16 dense layer.  Algorithmic fp32 flops of the three layers = 2 M N K; the kernel

@@ -11,8 +11,8 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # HNR_LIB_PATH: another build of the same library (A/B timing of kernel changes); there is no other fallback
 LIB_PATH = os.environ.get("HNR_LIB_PATH") or os.path.join(_HERE, "libhnr_hip.so")
-NCOUNTS = 8
-CNT = dict(RAYS_HIT=0, SAMPLES=1, RAYS_VALID=2, NEIGHBOURS=3, CELLS_VISITED=4, CANDIDATES=5, SAMPLES_VALID=6, SAMPLES_SMALL=7)
+NCOUNTS = 9
+CNT = dict(RAYS_HIT=0, SAMPLES=1, RAYS_VALID=2, NEIGHBOURS=3, CELLS_VISITED=4, CANDIDATES=5, SAMPLES_VALID=6, SAMPLES_SMALL=7, SAMPLES_TINY=8)
 
 
 class HnrError(RuntimeError):

@@ -674,11 +674,11 @@ __global__ __launch_bounds__(256) void chain_gather_kernel(ChainGatherArgs a)
     const int n_valid = cls.n_valid;
     const int tid = threadIdx.x;
     for (int blk = blockIdx.x; blk < cls.n_tiles; blk += gridDim.x) {         // one 128-row tile = 4 groups per pass; the grid is sized from the capacity
-    // first class: 16 samples x 8 slots; second class (<= 4 neighbours, hnr_chain_plan): 32 samples x 4 slots
-    const bool small = blk >= cls.big_tiles;
-    const int s_base = small ? cls.n_big + 32 * (blk - cls.big_tiles) : 16 * blk, s_end = small ? n_valid : cls.n_big;
+    // first class: 16 samples x 8 slots; second class (hnr_chain_plan): 32 samples x 4 slots; third: 64 samples x 2 slots
+    const int kc = chain_tile_class(cls, blk);
+    const int s_base = chain_tile_first(cls, blk, kc), s_end = chain_class_end(cls, kc);
     if (tid < 128) {
-        const int ls = small ? tid >> 2 : tid >> 3, kk = small ? tid & 3 : tid & 7;
+        const int ls = tid >> (3 - kc), kk = tid & ((8 >> kc) - 1);
         const int s = s_base + ls;
         char *aux = a.aux + (size_t)(blk * 4 + (tid >> 5)) * CH_AUX_GROUP;
         const int jr = tid & 31;
@@ -721,8 +721,9 @@ __global__ __launch_bounds__(256) void chain_gather_kernel(ChainGatherArgs a)
             ext[6] = __fadd_rn(__fadd_rn(__fmul_rn(ddx, vx), __fmul_rn(ddy, vy)), __fmul_rn(ddz, vz));
         }
         float sum = wraw;
-        sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2);
-        { const float s4 = __shfl_xor(sum, 4); sum += small ? 0.f : s4; }   // (a sample of the second class: 4 lanes)
+        sum += __shfl_xor(sum, 1);
+        { const float s2 = __shfl_xor(sum, 2); sum += kc > 1 ? 0.f : s2; }  // (a sample of the third class: 2 lanes)
+        { const float s4 = __shfl_xor(sum, 4); sum += kc > 0 ? 0.f : s4; }  // (a sample of the second class: 4 lanes)
         const float w = pid >= 0 ? __fdiv_rn(wraw, fmaxf(sum, 1e-8f)) : 0.f;
 #pragma unroll
         for (int i = 0; i < 6; ++i) s_d[tid][i] = d6[i];
@@ -731,9 +732,10 @@ __global__ __launch_bounds__(256) void chain_gather_kernel(ChainGatherArgs a)
         __builtin_nontemporal_store(f32x4g{ext[0], ext[1], ext[2], ext[3]}, reinterpret_cast<f32x4g *>(aux + 256 + jr * 32));
         __builtin_nontemporal_store(f32x4g{ext[4], ext[5], ext[6], 0.f}, reinterpret_cast<f32x4g *>(aux + 256 + jr * 32 + 16));
         if (a.weight_out && pid >= 0) { a.weight_out[(size_t)item * 8 + kk] = w; a.conf_out[(size_t)item * 8 + kk] = confc; }
-    } else if (tid < 128 + (small ? 128 : 64)) {
+    } else
+    for (int t = tid - 128; t < (64 << kc); t += 128) {
         // view-direction encoding: positional_encoding(viewdirs, 4, ori=True)[3:] = [sin(d*4+f) x12 | cos x12]; 6 values per thread
-        const int t = tid - 128, ls = t >> 2, part = t & 3;
+        const int ls = t >> 2, part = t & 3;
         const int s = s_base + ls;
         if (s < s_end) {
             const int ray = a.vs_item[s] / a.SR;
@@ -842,32 +844,35 @@ __global__ void chain_pack_kernel(ChainPackArgs a)
 // ------------------------------------------------------------------------------------------------------------------------
 // hnr_chain_plan: the chain's list of valid samples.  Two-level scan over the kept-sample work list (no atomics, deterministic), like
 // hnr_sample_plan; with `classes` the samples with more than 4 neighbours come first, those with 1..4 after them (stable in both).
-// class of a kept sample: 1 = more than four neighbours (or any, with one class), 2 = one to four, 0 = none.  Valid ids are a prefix of the K
-// slots (reference :494-496; the sorted order too), so slots 0 and 4 decide -- two independent loads, not a dependent walk over the slots
+// class of a kept sample: 1 = more than four neighbours (or any, with one class), 2 = three or four (one to four with two classes), 3 = one or two,
+// 0 = none.  Valid ids are a prefix of the K slots (reference :494-496; the sorted order too), so slots 0, 2 and 4 decide -- independent loads, not
+// a dependent walk over the slots
 __device__ __forceinline__ int chain_sample_class(const int32_t *__restrict__ p, int K, int classes)
 {
-    const int p0 = p[0], p4 = (classes && K > 4) ? p[4] : -1;
+    const int p0 = p[0], p4 = (classes && K > 4) ? p[4] : -1, p2 = (classes > 1 && K > 2) ? p[2] : 0;
     if (p0 < 0) return 0;
-    return (!classes || p4 >= 0) ? 1 : 2;
+    if (!classes || p4 >= 0) return 1;
+    return p2 >= 0 ? 2 : 3;
 }
 
 __global__ __launch_bounds__(1024) void chain_plan_sum_kernel(const int32_t *__restrict__ work, const int32_t *__restrict__ pidx,
                                                               const unsigned long long *__restrict__ counts, int K, int classes,
                                                               int32_t *__restrict__ block_sums)
 {
-    __shared__ int s_a[16], s_b[16];
+    __shared__ int s_a[16], s_b[16], s_c[16];
     const int n_items = (int)counts[HNR_CNT_SAMPLES];
     const int i = blockIdx.x * 1024 + threadIdx.x;
     const int cl = i < n_items ? chain_sample_class(pidx + (size_t)work[i] * K, K, classes) : 0;
-    int big = cl == 1 ? 1 : 0, small = cl == 2 ? 1 : 0;
-    for (int o = 32; o > 0; o >>= 1) { big += __shfl_xor(big, o); small += __shfl_xor(small, o); }
-    if ((threadIdx.x & 63) == 0) { s_a[threadIdx.x >> 6] = big; s_b[threadIdx.x >> 6] = small; }
+    int big = cl == 1 ? 1 : 0, small = cl == 2 ? 1 : 0, tiny = cl == 3 ? 1 : 0;
+    for (int o = 32; o > 0; o >>= 1) { big += __shfl_xor(big, o); small += __shfl_xor(small, o); tiny += __shfl_xor(tiny, o); }
+    if ((threadIdx.x & 63) == 0) { s_a[threadIdx.x >> 6] = big; s_b[threadIdx.x >> 6] = small; s_c[threadIdx.x >> 6] = tiny; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        int a = 0, b = 0;
-        for (int k = 0; k < 16; ++k) { a += s_a[k]; b += s_b[k]; }
-        block_sums[2 * blockIdx.x] = a;
-        block_sums[2 * blockIdx.x + 1] = b;
+        int a = 0, b = 0, t = 0;
+        for (int k = 0; k < 16; ++k) { a += s_a[k]; b += s_b[k]; t += s_c[k]; }
+        block_sums[3 * blockIdx.x] = a;
+        block_sums[3 * blockIdx.x + 1] = b;
+        block_sums[3 * blockIdx.x + 2] = t;
     }
 }
 
@@ -876,48 +881,52 @@ __global__ __launch_bounds__(1024) void chain_plan_scan_kernel(const int32_t *__
                                                                const int32_t *__restrict__ block_sums, int n_blocks,
                                                                int32_t *__restrict__ vs_item, int cap_samples)
 {
-    __shared__ int s_a[16], s_b[16], s_t[16];
-    __shared__ int s_base[3];
+    __shared__ int s_a[16], s_b[16], s_c[16], s_ta[16], s_tb[16];
+    __shared__ int s_base[5];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int n_items = (int)counts[HNR_CNT_SAMPLES];
     const int i = blockIdx.x * 1024 + threadIdx.x;
-    int pa = 0, pb = 0, ta = 0;                       // big / small samples in the blocks before this one; big samples in all blocks
+    int pa = 0, pb = 0, pc = 0, ta = 0, tb = 0;       // big / small / tiny samples in the blocks before this one; big and small samples in all blocks
     for (int k = threadIdx.x; k < n_blocks; k += 1024) {
-        const int a = block_sums[2 * k], b = block_sums[2 * k + 1];
-        ta += a;
-        if (k < (int)blockIdx.x) { pa += a; pb += b; }
+        const int a = block_sums[3 * k], b = block_sums[3 * k + 1], c = block_sums[3 * k + 2];
+        ta += a; tb += b;
+        if (k < (int)blockIdx.x) { pa += a; pb += b; pc += c; }
     }
-    for (int o = 32; o > 0; o >>= 1) { pa += __shfl_xor(pa, o); pb += __shfl_xor(pb, o); ta += __shfl_xor(ta, o); }
-    if (lane == 0) { s_a[wid] = pa; s_b[wid] = pb; s_t[wid] = ta; }
+    for (int o = 32; o > 0; o >>= 1) {
+        pa += __shfl_xor(pa, o); pb += __shfl_xor(pb, o); pc += __shfl_xor(pc, o); ta += __shfl_xor(ta, o); tb += __shfl_xor(tb, o);
+    }
+    if (lane == 0) { s_a[wid] = pa; s_b[wid] = pb; s_c[wid] = pc; s_ta[wid] = ta; s_tb[wid] = tb; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        int a = 0, b = 0, t = 0;
-        for (int k = 0; k < 16; ++k) { a += s_a[k]; b += s_b[k]; t += s_t[k]; }
-        s_base[0] = a; s_base[1] = b; s_base[2] = t;
+        int a = 0, b = 0, c = 0, t = 0, u = 0;
+        for (int k = 0; k < 16; ++k) { a += s_a[k]; b += s_b[k]; c += s_c[k]; t += s_ta[k]; u += s_tb[k]; }
+        s_base[0] = a; s_base[1] = b; s_base[2] = c; s_base[3] = t; s_base[4] = u;
     }
     __syncthreads();
-    const int total_big = s_base[2];
+    const int total_big = s_base[3], total_small = s_base[4];
     int item = 0, cl = 0;
     if (i < n_items) { item = work[i]; cl = chain_sample_class(pidx + (size_t)item * K, K, classes); }
-    const int big = cl == 1 ? 1 : 0, small = cl == 2 ? 1 : 0;
-    int ia = big, ib = small;
+    const int big = cl == 1 ? 1 : 0, small = cl == 2 ? 1 : 0, tiny = cl == 3 ? 1 : 0;
+    int ia = big, ib = small, ic = tiny;
     for (int o = 1; o < 64; o <<= 1) {
-        const int t0 = __shfl_up(ia, o), t1 = __shfl_up(ib, o);
-        if (lane >= o) { ia += t0; ib += t1; }
+        const int t0 = __shfl_up(ia, o), t1 = __shfl_up(ib, o), t2 = __shfl_up(ic, o);
+        if (lane >= o) { ia += t0; ib += t1; ic += t2; }
     }
     __syncthreads();
-    if (lane == 63) { s_a[wid] = ia; s_b[wid] = ib; }
+    if (lane == 63) { s_a[wid] = ia; s_b[wid] = ib; s_c[wid] = ic; }
     __syncthreads();
-    int oa = s_base[0] + ia - big, ob = s_base[1] + ib - small;
-    for (int k = 0; k < wid; ++k) { oa += s_a[k]; ob += s_b[k]; }
-    const int pos = big ? oa : total_big + ob;
-    if ((big || small) && pos < cap_samples) vs_item[pos] = item;
+    int oa = s_base[0] + ia - big, ob = s_base[1] + ib - small, oc = s_base[2] + ic - tiny;
+    for (int k = 0; k < wid; ++k) { oa += s_a[k]; ob += s_b[k]; oc += s_c[k]; }
+    const int pos = big ? oa : (small ? total_big + ob : total_big + total_small + oc);
+    if (cl != 0 && pos < cap_samples) vs_item[pos] = item;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        // the second class as the consumers see it: what is left of the (possibly clamped) valid-sample count after the first class
+        // the later classes as the consumers see them: what is left of the (possibly clamped) valid-sample count after the classes before
         long long nv = (long long)counts[HNR_CNT_SAMPLES_VALID];
         if (nv > cap_samples) nv = cap_samples;
         const long long first = total_big < nv ? total_big : nv;
-        counts[HNR_CNT_SAMPLES_SMALL] = (unsigned long long)(nv - first);
+        const long long second = total_small < nv - first ? total_small : nv - first;
+        counts[HNR_CNT_SAMPLES_SMALL] = (unsigned long long)(classes > 1 ? second : nv - first);
+        counts[HNR_CNT_SAMPLES_TINY] = (unsigned long long)(classes > 1 ? nv - first - second : 0);
     }
 }
 
@@ -942,7 +951,7 @@ extern "C" int64_t hnr_chain_packed_bytes(void) { return (int64_t)CH_WBYTES + CH
 extern "C" int64_t hnr_chain_workspace_bytes(int cap_samples)
 {
     if (cap_samples < 0) return -1;
-    const int64_t groups = 4 * (((int64_t)cap_samples + 15) / 16 + 1);            // whole 4-group blocks of the gather kernel (+ 1: each of the two slot classes ends in a partial block)
+    const int64_t groups = 4 * (((int64_t)cap_samples + 15) / 16 + 2);            // whole 4-group blocks of the gather kernel (+ 2: each of the three slot classes ends in a partial block)
     return groups * (CH_XP_GROUP + CH_AUX_GROUP);
 }
 
@@ -973,12 +982,13 @@ extern "C" int hnr_chain_pack(const float *d_w_b1_0_dist, int ldw0, const float 
 
 extern "C" int hnr_chain_classes(void)
 {
-    // the 4-slot class needs the weight-stationary kernel (the default); HNR_CHAIN_CLASSES=0 switches it off
+    // the 4- and 2-slot classes need the weight-stationary kernel (the default); HNR_CHAIN_CLASSES = 0 / 1 limits them
     static int on = -1;
     if (on < 0) {
         const char *e = getenv("HNR_CHAIN_RT"), *c = getenv("HNR_CHAIN_CLASSES");
         const bool ws = !e || (atoi(e) != 2 && atoi(e) != 4 && atoi(e) != 8);
-        on = (ws && !(c && atoi(c) == 0)) ? 1 : 0;
+        const int want = c ? atoi(c) : 2;
+        on = ws ? (want < 0 ? 0 : want > 2 ? 2 : want) : 0;
     }
     return on;
 }
@@ -986,11 +996,11 @@ extern "C" int hnr_chain_classes(void)
 extern "C" int hnr_chain_plan(const int32_t *d_work, const int32_t *d_sample_pidx, int64_t *d_counts, int K, int max_items, int classes,
                               int32_t *d_vs_item, int cap_samples, int32_t *d_scratch, void *stream)
 {
-    if (!d_work || !d_sample_pidx || !d_counts || !d_vs_item || !d_scratch || K <= 0 || max_items < 0 || cap_samples < 0 || (classes != 0 && classes != 1)) {
+    if (!d_work || !d_sample_pidx || !d_counts || !d_vs_item || !d_scratch || K <= 0 || max_items < 0 || cap_samples < 0 || classes < 0 || classes > 2) {
         set_error("hnr_chain_plan: bad argument"); return HNR_ERR_BADARG;
     }
-    if (classes && (K != 8 || !hnr_chain_classes())) {
-        set_error("hnr_chain_plan: the 4-slot sample class needs K = 8 and the weight-stationary chain kernel (hnr_chain_classes())"); return HNR_ERR_BADARG;
+    if (classes && (K != 8 || classes > hnr_chain_classes())) {
+        set_error("hnr_chain_plan: the 4- / 2-slot sample classes need K = 8 and the weight-stationary chain kernel (classes <= hnr_chain_classes() = %d)", hnr_chain_classes()); return HNR_ERR_BADARG;
     }
     hipStream_t st = (hipStream_t)stream;
     if (max_items == 0) return HNR_OK;
@@ -1065,7 +1075,7 @@ static int chain_gather_impl(const float *d_rec, const float *d_xyz, const float
         set_error("hnr_chain_gather: NULL / unaligned pointer");
         return HNR_ERR_BADARG;
     }
-    const int blocks = cdiv(cap_samples, 16) + 1;
+    const int blocks = cdiv(cap_samples, 16) + 2;
     ChainGatherArgs a;
     a.xyz = d_xyz; a.conf = d_conf; a.pdir = d_dir; a.color = d_color; a.rec = reinterpret_cast<const float4 *>(d_rec); a.pidx = d_sample_pidx; a.loc_w = d_sample_loc_w;
     a.raydir = d_raydir; a.campos = d_campos; a.camrot = d_camrot; a.vs_item = d_vs_item;
@@ -1091,7 +1101,7 @@ extern "C" int hnr_chain_forward(const void *d_workspace, const float *d_point_t
         set_error("hnr_chain_forward: NULL / unaligned pointer");
         return HNR_ERR_BADARG;
     }
-    const int blocks = cdiv(cap_samples, 16) + 1;
+    const int blocks = cdiv(cap_samples, 16) + 2;
     ChainArgs a;
     a.xp = (const char *)d_workspace; a.aux = (const char *)d_workspace + (size_t)blocks * 4 * CH_XP_GROUP;
     a.ptab = d_point_table; a.ldt = ldt; a.wimg = (const char *)d_packed;

@@ -34,21 +34,31 @@ struct ChainArgs {
     int skew;                          // RT = 2: the second half of the grid (the CUs' second workgroups) starts skew x 64 cycles late
 };
 
-// Row-slot classes (hnr_chain_plan): samples [0, n_big) own 8 row slots each (16 samples per 128-row tile), samples [n_big, n_valid) -- at most 4
-// neighbours -- own 4 (32 samples per tile); the tiles / 4-group blocks of the second class follow those of the first in the workspace.
-struct ChainClasses { int n_valid, n_big, big_tiles, n_tiles; };
+// Row-slot classes (hnr_chain_plan): samples [0, n_big) own 8 row slots each (16 samples per 128-row tile), the next n_small 4 (32 per tile), the
+// rest -- one or two neighbours -- 2 (64 per tile); the tiles / 4-group blocks of a class follow those of the class before it in the workspace.
+struct ChainClasses { int n_valid, n_big, n_small, big_tiles, small_tiles, n_tiles; };
 __device__ __forceinline__ ChainClasses chain_classes(const unsigned long long *counts, int cap_samples)
 {
     ChainClasses c;
     long long nv = (long long)counts[HNR_CNT_SAMPLES_VALID];
     if (nv > cap_samples) nv = cap_samples;
+    long long nt = (long long)counts[HNR_CNT_SAMPLES_TINY];
+    if (nt > nv) nt = nv;
     long long ns = (long long)counts[HNR_CNT_SAMPLES_SMALL];
-    if (ns > nv) ns = nv;
-    c.n_valid = (int)nv; c.n_big = (int)(nv - ns);
+    if (ns > nv - nt) ns = nv - nt;
+    c.n_valid = (int)nv; c.n_small = (int)ns; c.n_big = (int)(nv - ns - nt);
     c.big_tiles = (c.n_big + 15) / 16;
-    c.n_tiles = c.big_tiles + (int)((ns + 31) / 32);
+    c.small_tiles = (int)((ns + 31) / 32);
+    c.n_tiles = c.big_tiles + c.small_tiles + (int)((nt + 63) / 64);
     return c;
 }
+// class k of tile t (0: 8 row slots per sample, 1: 4, 2: 2); first sample of the tile; end of the class's sample range
+__device__ __forceinline__ int chain_tile_class(const ChainClasses &c, int t) { return t < c.big_tiles ? 0 : (t < c.big_tiles + c.small_tiles ? 1 : 2); }
+__device__ __forceinline__ int chain_tile_first(const ChainClasses &c, int t, int k)
+{
+    return k == 0 ? 16 * t : (k == 1 ? c.n_big + 32 * (t - c.big_tiles) : c.n_big + c.n_small + 64 * (t - c.big_tiles - c.small_tiles));
+}
+__device__ __forceinline__ int chain_class_end(const ChainClasses &c, int k) { return k == 0 ? c.n_big : (k == 1 ? c.n_big + c.n_small : c.n_valid); }
 
 __device__ __forceinline__ float chain_softplus_m1(float x)
 {

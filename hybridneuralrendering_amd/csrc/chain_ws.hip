@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
     // range (the store is dropped) in the lanes that hold no sum; x5_flag = 1 / 0: the third step of the K-sum runs / is a no-op (4-slot samples)
     __amdgpu_buffer_rsrc_t x5_rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(a.X5), 0, 0, 0x00020000);
     int x5_voff = 0x40000000;
-    float x5_flag = 1.f;
+    float x5_flag = 1.f, x5_flag2 = 1.f;                                    // (x5_flag2: the second step, a no-op for 2-slot samples)
     float ks0 = 0.f, ks1 = 0.f, wq_sig = 0.f;                               // wq_sig: this wave's own row tile (= wave) of the tile whose densities are due
     float4 ex4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
@@ -280,34 +280,36 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
         // -- second half, layer 3: K-weighted sums (8 adjacent lanes: three DPP steps), X5 / sigma stores, next tile's layer-0 image of row tile PR.
         //    micro-stage 0: exchange read; 1 + i: value pair i (16 pairs; a float4 store after every second pair); 17: sigma; 18: image
         const float wq_e = PR == 3 ? wq_fin : wq[PR];
-        // a tile of the second slot class (hnr_chain_plan): 8 samples of 4 row slots per row tile -- the sum stops after two DPP steps
-        const bool small_e = tile_e >= cls.big_tiles;
+        // a tile of the second / third slot class (hnr_chain_plan): 8 samples of 4 row slots / 16 samples of 2 per row tile -- the sum stops after two
+        // DPP steps / one
+        const int kc_e = tile_e < 0 ? 0 : chain_tile_class(cls, tile_e);
         const int MS = 19, m0 = k2 * MS / N2, m1 = (k2 + 1) * MS / N2;
 #pragma unroll
         for (int ms = m0; ms < m1; ++ms) {
             if (ms == 0) {
                 if (PR == 3) ex4 = CW_AT(const float4, q_dsr, 0);
                 // where this row tile's sums go (once per pass: per store it cost a 64-bit multiply, a three-way select and an exec-masked branch)
-                const int row0 = tile_e < 0 ? n_valid : small_e ? cls.n_big + 32 * (tile_e - cls.big_tiles) + 8 * PR : tile_e * SAMPLES + 4 * PR;
-                const int ls = small_e ? (j >> 2) : (j >> 3);
-                const bool st = (j & (small_e ? 3 : 7)) == 0 && row0 + ls < (small_e || tile_e < 0 ? n_valid : cls.n_big);
+                const int row0 = tile_e < 0 ? n_valid : chain_tile_first(cls, tile_e, kc_e) + (4 << kc_e) * PR;
+                const int ls = j >> (3 - kc_e);
+                const bool st = (j & ((8 >> kc_e) - 1)) == 0 && row0 + ls < (tile_e < 0 ? n_valid : chain_class_end(cls, kc_e));
                 x5_voff = st ? (ls * a.ld5 + col0) * 4 : 0x40000000;
-                x5_rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(a.X5) + (size_t)row0 * a.ld5 * 4, 0, 8 * a.ld5 * 4, 0x00020000);
-                x5_flag = small_e ? 0.f : 1.f;
+                x5_rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(a.X5) + (size_t)row0 * a.ld5 * 4, 0, 16 * a.ld5 * 4, 0x00020000);
+                x5_flag = kc_e > 0 ? 0.f : 1.f;
+                x5_flag2 = kc_e > 1 ? 0.f : 1.f;
             } else if (ms < 17) {
                 const int pr = ms - 1, c = pr >> 3, e0i = 2 * (pr & 7);
-                // the sum over a sample's 8 (4) row slots = 8 (4) adjacent lanes: quad swap, quad-pair swap, half-row mirror; the third step as
-                // f += dpp(f) * flag (exactly f + dpp(f) or f).  One block: every DPP read sits two wait states after the write it reads
+                // the sum over a sample's 8 (4, 2) row slots = 8 (4, 2) adjacent lanes: pair swap, quad-pair swap, half-row mirror; the second and
+                // third step as f += dpp(f) * flag (exactly f + dpp(f) or f).  One block: every DPP read sits two wait states after the write it reads
                 // (the assembler does not pad inline asm), and the compiler cannot expand the steps into moves / selects / branches
                 float f0, f1;
                 asm volatile("v_mul_f32 %0, %2, %4\n\tv_mul_f32 %1, %3, %4\n\ts_nop 0\n\t"
                              "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
                              "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
-                             "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-                             "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
+                             "v_fmac_f32_dpp %0, %0, %6 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                             "v_fmac_f32_dpp %1, %1, %6 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
                              "v_fmac_f32_dpp %0, %0, %5 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
                              "v_fmac_f32_dpp %1, %1, %5 row_half_mirror row_mask:0xf bank_mask:0xf"
-                             : "=&v"(f0), "=&v"(f1) : "v"(acc[se][c][e0i]), "v"(acc[se][c][e0i + 1]), "v"(wq_e), "v"(x5_flag));
+                             : "=&v"(f0), "=&v"(f1) : "v"(acc[se][c][e0i]), "v"(acc[se][c][e0i + 1]), "v"(wq_e), "v"(x5_flag), "v"(x5_flag2));
                 if ((pr & 1) == 0) { ks0 = f0; ks1 = f1; }
                 else __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(ks0), __float_as_uint(ks1), __float_as_uint(f0), __float_as_uint(f1)}, x5_rs,
                                                             x5_voff + (32 * c + 2 * (pr & 6)) * 4, 0, 0);
@@ -315,13 +317,13 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
                 // the tile's densities, once per tile and in all four waves at the same time (softplus is ~100 instructions that cannot be cut
                 // into pieces; per row tile it stalled a different pass for each wave): wave w takes row tile w
                 if (PR == 3) {
-                    const int s_sig = tile_e < 0 ? n_valid : small_e ? cls.n_big + 32 * (tile_e - cls.big_tiles) + 8 * wave + (j >> 2) : tile_e * SAMPLES + 4 * wave + (j >> 3);
+                    const int s_sig = tile_e < 0 ? n_valid : chain_tile_first(cls, tile_e, kc_e) + (4 << kc_e) * wave + (j >> (3 - kc_e));
                     const float d = __fadd_rn(__fadd_rn(ex4.x, ex4.y), __fadd_rn(ex4.z, ex4.w));
                     float sg = __fmul_rn(chain_softplus_m1(__fadd_rn(d, alpha_b)), wq_sig);
                     sg = __fadd_rn(sg, __builtin_amdgcn_update_dpp(0.f, sg, 0xB1, 0xf, 0xf, false));
-                    sg = __fadd_rn(sg, __builtin_amdgcn_update_dpp(0.f, sg, 0x4E, 0xf, 0xf, false));
-                    { const float g = __builtin_amdgcn_update_dpp(0.f, sg, 0x141, 0xf, 0xf, false); sg = __fadd_rn(sg, small_e ? 0.f : g); }
-                    if (h == 0 && (j & (small_e ? 3 : 7)) == 0 && s_sig < (small_e ? n_valid : cls.n_big)) a.sigma[s_sig] = sg;
+                    { const float g = __builtin_amdgcn_update_dpp(0.f, sg, 0x4E, 0xf, 0xf, false); sg = __fadd_rn(sg, kc_e > 1 ? 0.f : g); }
+                    { const float g = __builtin_amdgcn_update_dpp(0.f, sg, 0x141, 0xf, 0xf, false); sg = __fadd_rn(sg, kc_e > 0 ? 0.f : g); }
+                    if (h == 0 && (j & ((8 >> kc_e) - 1)) == 0 && s_sig < (tile_e < 0 ? 0 : chain_class_end(cls, kc_e))) a.sigma[s_sig] = sg;
                 }
             } else if (stage_next && tile_stage < t_end) {
 #pragma unroll

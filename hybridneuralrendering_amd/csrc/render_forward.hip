@@ -40,7 +40,7 @@ Layout carve(void *ws, size_t ws_bytes, const hnr_render_params *p, bool *ok)
     const size_t cap = (size_t)p->cap_samples, V = (size_t)p->V;
     L.work = c.take<int32_t>((size_t)hnr_query_work_elems(p->R, p->SR));
     L.vs_item = c.take<int32_t>(cap + 1); L.vs_off = c.take<int32_t>(cap + 1); L.vs_cnt = c.take<int32_t>(cap + 1);
-    L.scratch = c.take<int32_t>(2 * (((size_t)p->R * p->SR + 1023) / 1024) + 2);
+    L.scratch = c.take<int32_t>(3 * (((size_t)p->R * p->SR + 1023) / 1024) + 3);
     L.chain_ws = c.take<char>((size_t)hnr_chain_workspace_bytes(p->cap_samples));
     L.X5 = c.take<float>(cap * 280); L.sigma = c.take<float>(cap + 1);
     L.CF = c.take<float>(cap * 128); L.pre = c.take<float>(cap * 64);

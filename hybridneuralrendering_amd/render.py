@@ -168,7 +168,7 @@ class HybridRenderer:
         if n_valid == 0:
             return out
         vs_item, vs_off, vs_cnt = _i32(n_valid, dev), _i32(n_valid, dev), _i32(n_valid, dev)
-        scratch = _i32(2 * ((R * SR + 1023) // 1024) + 2, dev)
+        scratch = _i32(3 * ((R * SR + 1023) // 1024) + 3, dev)
         overflow = torch.zeros(1, dtype=torch.int32, device=dev)
         p = _lib.ptr
         T = lambda name: _Stage(timers, name)

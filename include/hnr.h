@@ -120,9 +120,11 @@ enum {
     HNR_CNT_CELLS_VISITED,    /* occupied cells whose lists were scanned by the k-NN            */
     HNR_CNT_CANDIDATES,       /* points distance-tested by the k-NN                             */
     HNR_CNT_SAMPLES_VALID,    /* shading samples with >= 1 neighbour                            */
-    HNR_CNT_SAMPLES_SMALL,    /* written by hnr_chain_plan: valid samples with <= 4 neighbours, listed AFTER the others in its
-                                 d_vs_item (0 after hnr_march_query: every sample counts as a full one)                  */
-    HNR_NCOUNTS = 8
+    HNR_CNT_SAMPLES_SMALL,    /* written by hnr_chain_plan: valid samples of its second class (4 row slots: at most 4 neighbours
+                                 with classes = 1, 3..4 with classes = 2), listed AFTER the first class in its d_vs_item (0 after
+                                 hnr_march_query: every sample counts as a full one)                                      */
+    HNR_CNT_SAMPLES_TINY,     /* written by hnr_chain_plan(classes = 2): valid samples with 1..2 neighbours (2 row slots), listed last */
+    HNR_NCOUNTS = 9
 };
 
 /*
@@ -308,8 +310,10 @@ int hnr_merge(const float *d_X6, int ld6, const float *d_Hm, int ldh, const floa
  *   neighbours first, then those with 1..4 (each class in (ray, slot) order), and d_counts[HNR_CNT_SAMPLES_SMALL] = size of the second
  *   class: the gather and the chain kernel give a small sample 4 row slots instead of 8 (82 % of the bench frame's samples have 8
  *   neighbours, 11 % at most 4: 5.5 % fewer rows through the four dense layers; the sums are bit-identical, a slot without a neighbour
- *   contributes an exact zero).  Everything downstream is per sample and order-free.  hnr_chain_classes() tells whether the chain
- *   kernel selected in this process supports the second class.  d_scratch: int32[2 * ceil(max_items / 1024) + 2].
+ *   contributes an exact zero).  classes = 2: three classes -- more than 4 neighbours (8 slots), 3..4 (4 slots,
+ *   HNR_CNT_SAMPLES_SMALL), 1..2 (2 slots, HNR_CNT_SAMPLES_TINY; 7.5 % of the bench frame's samples): another 2 % fewer rows.
+ *   Everything downstream is per sample and order-free.  hnr_chain_classes() = the largest `classes` the chain kernel selected in
+ *   this process supports (0 for the older kernel variants).  d_scratch: int32[3 * ceil(max_items / 1024) + 3].
  * hnr_chain_forward: d_X5[s, 0:256] = sum_k w_k block3(...)_k, d_sigma[s] = sum_k w_k softplus(alpha_k - 1).
  *   d_point_table [N, ldt >= 256] = [emb | PE3(emb)] block1.0.weight[:, :224]^T.  d_dbg (probe, may be NULL): the post-activation
  *   output of layer dbg_layer (0..3) as [rows = 8 per valid sample, 256]. */

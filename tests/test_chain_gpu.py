@@ -209,54 +209,58 @@ def test_chain_result_is_independent_of_tile_composition():
     assert torch.equal(X5a[5:], X5b) and torch.equal(siga[5:], sigb)
 
 
-def test_chain_small_sample_class_is_bit_identical():
-    """hnr_chain_plan(classes=1) lists the samples with 1..4 neighbours after the others and the gather / chain kernels give them 4 row
-    slots instead of 8: every sample's sums are bit for bit those of the one-class layout (an empty slot adds an exact zero)."""
+def test_chain_sample_classes_are_bit_identical():
+    """hnr_chain_plan(classes = 1 / 2) lists the samples with few neighbours after the others (1..4 neighbours: 4 row slots; with
+    classes = 2: 3..4 neighbours 4 slots, 1..2 neighbours 2 slots) and the gather / chain kernels size their row slots by class: every
+    sample's sums are bit for bit those of the one-class layout (an empty slot adds an exact zero)."""
     from hybridneuralrendering_amd import _lib
     L, p = _lib.lib(), _lib.ptr
+    CNT = _lib.CNT
     W = _world(seed=7)
     q, dev, K = W["q"], W["dev"], W["K"]
     n_valid, n_items = W["n_valid"], W["R"] * W["SR"]
-    scratch = torch.empty((2 * ((n_items + 1023) // 1024) + 2,), dtype=torch.int32, device=dev)
-    def plan(classes):
+    scratch = torch.empty((3 * ((n_items + 1023) // 1024) + 3,), dtype=torch.int32, device=dev)
+    def plan(classes, cap=n_valid):
         cnt = q["counts"].clone()
         vs = torch.full((n_valid,), -1, dtype=torch.int32, device=dev)
-        _lib.check(L.hnr_chain_plan(p(q["work"]), p(q["sample_pidx"]), p(cnt), K, n_items, classes, p(vs), n_valid, p(scratch), _lib.stream()),
+        _lib.check(L.hnr_chain_plan(p(q["work"]), p(q["sample_pidx"]), p(cnt), K, n_items, classes, p(vs), cap, p(scratch), _lib.stream()),
                    "hnr_chain_plan")
         torch.cuda.synchronize()
         return vs, cnt
     vs0, cnt0 = plan(0)
-    assert torch.equal(vs0, W["vs_item"]) and int(cnt0[_lib.CNT["SAMPLES_SMALL"]]) == 0
+    assert torch.equal(vs0, W["vs_item"]) and int(cnt0[CNT["SAMPLES_SMALL"]]) == 0 and int(cnt0[CNT["SAMPLES_TINY"]]) == 0
     X5a, siga, _, _ = _run_chain(W)
-    if not L.hnr_chain_classes():
-        assert L.hnr_chain_plan(p(q["work"]), p(q["sample_pidx"]), p(cnt0), K, n_items, 1, p(vs0), n_valid, p(scratch), _lib.stream()) != 0
+    have = int(L.hnr_chain_classes())
+    assert 0 <= have <= 2
+    if have < 2:
+        assert L.hnr_chain_plan(p(q["work"]), p(q["sample_pidx"]), p(cnt0), K, n_items, have + 1, p(vs0), n_valid, p(scratch), _lib.stream()) != 0
+    if have == 0:
         pytest.skip("the selected chain kernel has one sample class")
-    vs1, cnt1 = plan(1)
-    n_small = int(cnt1[_lib.CNT["SAMPLES_SMALL"]])
-    n_big = n_valid - n_small
-    assert 0 < n_small < n_valid
-    nb = (q["sample_pidx"].reshape(-1, K)[vs1.long()] >= 0).sum(-1)
-    assert bool((nb[:n_big] > 4).all()) and bool(((nb[n_big:] >= 1) & (nb[n_big:] <= 4)).all())
-    assert bool((vs1[1:n_big] > vs1[:n_big - 1]).all()) and bool((vs1[n_big + 1:] > vs1[n_big:-1]).all())
-    pos = torch.searchsorted(W["vs_item"], vs1)                     # where each sample sits in the one-class list
-    assert torch.equal(W["vs_item"][pos], vs1)
-    X5b, sigb, _, _ = _run_chain(dict(W, vs_item=vs1, q=dict(q, counts=cnt1)))
-    assert torch.equal(X5a[pos], X5b) and torch.equal(siga[pos], sigb)
-    # a capacity below the first class: the small samples are the ones dropped, the count of the second class drops to zero
-    cap = n_big - 3
-    cnt = q["counts"].clone()
-    vs = torch.full((n_valid,), -1, dtype=torch.int32, device=dev)
-    _lib.check(L.hnr_chain_plan(p(q["work"]), p(q["sample_pidx"]), p(cnt), K, n_items, 1, p(vs), cap, p(scratch), _lib.stream()), "hnr_chain_plan")
-    torch.cuda.synchronize()
-    assert int(cnt[_lib.CNT["SAMPLES_SMALL"]]) == 0 and torch.equal(vs[:cap], vs1[:cap]) and bool((vs[cap:] == -1).all())
-    # and one between the classes: part of the second class survives
-    cap = n_big + max(1, n_small // 2)
-    cnt = q["counts"].clone()
-    _lib.check(L.hnr_chain_plan(p(q["work"]), p(q["sample_pidx"]), p(cnt), K, n_items, 1, p(vs), cap, p(scratch), _lib.stream()), "hnr_chain_plan")
-    torch.cuda.synchronize()
-    assert int(cnt[_lib.CNT["SAMPLES_SMALL"]]) == cap - n_big
-    X5c, sigc, _, _ = _run_chain(dict(W, vs_item=vs, q=dict(q, counts=cnt)), cap=cap)
-    assert torch.equal(X5a[pos[:cap]], X5c) and torch.equal(siga[pos[:cap]], sigc)
+    nb_all = (q["sample_pidx"].reshape(-1, K) >= 0).sum(-1)
+    for classes in range(1, have + 1):
+        vs1, cnt1 = plan(classes)
+        n_small, n_tiny = int(cnt1[CNT["SAMPLES_SMALL"]]), int(cnt1[CNT["SAMPLES_TINY"]])
+        n_big = n_valid - n_small - n_tiny
+        assert 0 < n_small < n_valid and (n_tiny > 0) == (classes == 2)
+        nb = nb_all[vs1.long()]
+        lo_small = 1 if classes == 1 else 3
+        assert bool((nb[:n_big] > 4).all()) and bool(((nb[n_big:n_big + n_small] >= lo_small) & (nb[n_big:n_big + n_small] <= 4)).all())
+        assert bool(((nb[n_big + n_small:] >= 1) & (nb[n_big + n_small:] <= 2)).all())
+        for lo, hi in ((0, n_big), (n_big, n_big + n_small), (n_big + n_small, n_valid)):       # (ray, slot) order inside every class
+            assert bool((vs1[lo + 1:hi] > vs1[lo:hi - 1]).all())
+        pos = torch.searchsorted(W["vs_item"], vs1)                 # where each sample sits in the one-class list
+        assert torch.equal(W["vs_item"][pos], vs1)
+        X5b, sigb, _, _ = _run_chain(dict(W, vs_item=vs1, q=dict(q, counts=cnt1)))
+        assert torch.equal(X5a[pos], X5b) and torch.equal(siga[pos], sigb)
+        # capacities that cut the list inside the first class, between the classes and inside the last one: the later classes are the ones dropped
+        for cap in (n_big - 3, n_big + max(1, n_small // 2), n_valid - max(1, (n_tiny or n_small) // 3)):
+            vs, cnt = plan(classes, cap)
+            first = min(n_big, cap)
+            second = min(n_small, cap - first)
+            assert int(cnt[CNT["SAMPLES_SMALL"]]) == second and int(cnt[CNT["SAMPLES_TINY"]]) == cap - first - second
+            assert torch.equal(vs[:cap], vs1[:cap]) and bool((vs[cap:] == -1).all())
+            X5c, sigc, _, _ = _run_chain(dict(W, vs_item=vs, q=dict(q, counts=cnt)), cap=cap)
+            assert torch.equal(X5a[pos[:cap]], X5c) and torch.equal(siga[pos[:cap]], sigc)
 
 
 def test_point_records_gather_is_bit_identical():
@@ -310,5 +314,5 @@ def test_chain_capacity_bounds_and_bad_arguments():
                                       None), "hnr_chain_gather")
     with pytest.raises(HnrError):
         _lib.check(L.hnr_chain_forward(None, None, 256, None, None, 16, ctypes.c_float(1.5), None, 280, None, None, 0, None), "hnr_chain_forward")
-    # whole 16-sample blocks, plus one: each of the two slot classes may end in a partial block
-    assert L.hnr_chain_workspace_bytes(0) == 4 * (8192 + 1280) and L.hnr_chain_workspace_bytes(17) == 12 * (8192 + 1280)
+    # whole 16-sample blocks, plus two: each of the three slot classes may end in a partial block
+    assert L.hnr_chain_workspace_bytes(0) == 8 * (8192 + 1280) and L.hnr_chain_workspace_bytes(17) == 16 * (8192 + 1280)

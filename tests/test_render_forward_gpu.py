@@ -93,7 +93,7 @@ def test_workspace_capacity_overflow_is_reported_not_overrun():
     mask = torch.empty((R,), dtype=torch.int8, device=dev)
     pidx = torch.empty((R, SR, K), dtype=torch.int32, device=dev)
     nsamp = torch.empty((R,), dtype=torch.int32, device=dev)
-    counts = torch.empty((8,), dtype=torch.int64, device=dev)
+    counts = torch.empty((_lib.NCOUNTS,), dtype=torch.int64, device=dev)
     status = torch.empty((2,), dtype=torch.int32, device=dev)
     out = _lib.RenderOutputs(p(col), p(opa), p(isbg), None, p(mask), p(dec), p(pidx), p(loc), p(nsamp), p(counts), p(status), None, None, None)
     _lib.check(L.hnr_render_forward(grid.handle, ctypes.byref(prm), ctypes.byref(cl), ctypes.byref(wt), ctypes.byref(cam), ctypes.byref(vw),
