@@ -13,6 +13,15 @@ nv = W["n_valid"]
 ws = torch.empty((int(L.hnr_chain_workspace_bytes(nv)),), dtype=torch.uint8, device=dev)
 X5 = torch.empty((nv, 280), dtype=torch.float32, device=dev); sg = torch.empty((nv,), dtype=torch.float32, device=dev)
 ptab = W["rnd"].point_table(W["cloud"]); q = W["q"]; c = W["cloud"]
+# the product's sample list: hnr_chain_plan with the slot classes of the selected kernel (PROBE_CLASSES=0: the one-class list of hnr_sample_plan)
+CL = min(int(os.environ.get("PROBE_CLASSES", "2")), int(L.hnr_chain_classes()))
+if CL > 0:
+    n_items = W["R"] * W["SR"]
+    scratch = torch.empty((3 * ((n_items + 1023) // 1024) + 3,), dtype=torch.int32, device=dev)
+    cnt = q["counts"].clone(); vs = torch.empty_like(W["vs_item"])
+    _lib.check(L.hnr_chain_plan(p(q["work"]), p(q["sample_pidx"]), p(cnt), W["K"], n_items, CL, p(vs), nv, p(scratch), _lib.stream()), "plan")
+    W["vs_item"] = vs; q = dict(q, counts=cnt); W["q"] = q
+    print("classes %d: small %d tiny %d of %d" % (CL, int(cnt[_lib.CNT["SAMPLES_SMALL"]]), int(cnt[_lib.CNT["SAMPLES_TINY"]]), nv))
 _lib.check(L.hnr_chain_gather(p(c.xyz), p(c.conf), p(c.dir), p(c.color), p(q["sample_pidx"]), p(q["sample_loc_w"]), p(W["raydir"]), p(W["campos"]),
                               p(W["camrot"]), p(W["vs_item"]), p(q["counts"]), W["SR"], W["K"], nv, p(ws), p(X5), 280, None, None, _lib.stream()), "g")
 NW = 8 if os.environ.get('HNR_CHAIN_RT', '16') == '8' else 4          # waves per workgroup: 8 in the dual-group kernel (default)
