@@ -934,6 +934,92 @@ extern "C" int hnr_ksum(const float *d_H4, int ldh, const float *d_wagg, const f
     return HNR_OK;
 }
 
+namespace hnr {
+// The same convolution with one thread per output PIXEL and all CT output channels of a group in registers: an input tap is loaded once for
+// the CT channels (the kernel above loads it once per channel), the weights of a tap are wave-uniform (scalar loads), and with CIN known the
+// nine taps of an input channel are in flight together -- the pyramid's six launches were latency-bound (0.9 GFLOP in 0.37 ms).  Per output
+// the products are accumulated in the same order (ci, ky, kx) by the same fmaf: bit-identical results.  Border pixels take the checked loop.
+template <int CIN, int CT, int CL>
+__global__ __launch_bounds__(256) void conv3x3_lrelu_tile_kernel(const float *__restrict__ in, int Hin, int Win, int in_cstride, const float *__restrict__ w,
+                                                                 const float *__restrict__ b, int Cout, int stride, int Hout, int Wout, float slope,
+                                                                 float *__restrict__ out, int V)
+{
+    // the group's weights, transposed to [ci][tap][c] in LDS: the CT weights of a tap are one broadcast read (as scalar loads from the [co][ci][tap]
+    // image they were 2592 single-dword loads per wave for 24 -> 24 channels, with SGPR spills: 81 us for 0.1 GFLOP)
+    __shared__ __attribute__((aligned(16))) float s_w[CIN * 9 * CT];
+    const int co0 = blockIdx.y * CT;
+    {   // (the group's weights are one contiguous range of the [co][ci][tap] image: coalesced reads, all in flight, transposed on the LDS side)
+        constexpr int NW = CIN * 9 * CT, IT = (NW + 255) / 256;
+        float wv[IT];
+#pragma unroll
+        for (int k = 0; k < IT; ++k) { const int i = threadIdx.x + 256 * k; wv[k] = i < NW ? w[co0 * CIN * 9 + i] : 0.f; }
+#pragma unroll
+        for (int k = 0; k < IT; ++k) { const int i = threadIdx.x + 256 * k; if (i < NW) s_w[(i % (CIN * 9)) * CT + i / (CIN * 9)] = wv[k]; }
+    }
+    __syncthreads();
+    const int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= (int64_t)V * Hout * Wout) return;
+    const int ox = (int)(pix % Wout), oy = (int)((pix / Wout) % Hout), v = (int)(pix / ((int64_t)Wout * Hout));
+    float acc[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) acc[c] = b[co0 + c];
+    const int iy0 = oy * stride - 1, ix0 = ox * stride - 1;
+    auto at = [&](int ci, int iy, int ix) -> float {
+        return CL ? in[(((size_t)v * Hin + iy) * Win + ix) * in_cstride + ci] : in[(((size_t)v * CIN + ci) * Hin + iy) * Win + ix];
+    };
+    constexpr int CB = CIN % 6 == 0 ? 6 : 3;                                 // input channels whose 9 taps are in flight together
+    const bool interior = iy0 >= 0 && iy0 + 2 < Hin && ix0 >= 0 && ix0 + 2 < Win;
+    if (__builtin_amdgcn_ballot_w64(!interior) == 0ull) {                    // wave-uniform: no pixel of the wave touches the border
+        for (int cb = 0; cb < CIN; cb += CB) {
+            float x[CB][9];
+#pragma unroll
+            for (int u = 0; u < CB; ++u)
+#pragma unroll
+                for (int t = 0; t < 9; ++t) x[u][t] = at(cb + u, iy0 + t / 3, ix0 + t % 3);
+#pragma unroll
+            for (int u = 0; u < CB; ++u) {
+                float wr[9 * CT];                                           // the channel's 9 x CT weights: all reads issued before the first use
+#pragma unroll
+                for (int i = 0; i < 9 * CT; i += 2) *reinterpret_cast<float2 *>(wr + i) = *reinterpret_cast<const float2 *>(s_w + (cb + u) * 9 * CT + i);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) acc[c] = fmaf(x[u][t], wr[t * CT + c], acc[c]);
+            }
+        }
+    } else {
+        // a wave with border pixels (every wave of the 80-pixel-wide level): the same unrolled form with clamped addresses, a tap outside the image is
+        // SKIPPED by a select after the fmaf (not multiplied by zero: the skipped sum keeps the bits of the checked loop).  A divergent checked loop
+        // here cost 216 dependent load round trips per wave: 55 us of the 24 -> 24 launch
+        bool ok[9];
+        int iyc[3], ixc[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            iyc[k] = iy0 + k < 0 ? 0 : (iy0 + k >= Hin ? Hin - 1 : iy0 + k);
+            ixc[k] = ix0 + k < 0 ? 0 : (ix0 + k >= Win ? Win - 1 : ix0 + k);
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) ok[t] = iy0 + t / 3 >= 0 && iy0 + t / 3 < Hin && ix0 + t % 3 >= 0 && ix0 + t % 3 < Win;
+        for (int cb = 0; cb < CIN; cb += CB) {
+            float x[CB][9];
+#pragma unroll
+            for (int u = 0; u < CB; ++u)
+#pragma unroll
+                for (int t = 0; t < 9; ++t) x[u][t] = at(cb + u, iyc[t / 3], ixc[t % 3]);
+#pragma unroll
+            for (int u = 0; u < CB; ++u)
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) { const float f = fmaf(x[u][t], s_w[((cb + u) * 9 + t) * CT + c], acc[c]); acc[c] = ok[t] ? f : acc[c]; }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CT; ++c) out[(((size_t)v * Cout + co0 + c) * Hout + oy) * Wout + ox] = acc[c] > 0.f ? acc[c] : acc[c] * slope;
+}
+}  // namespace hnr
+
 extern "C" int hnr_image_features(const float *d_img, int V, int H, int W, const float *const *d_conv_w,
                                   const float *const *d_conv_b, float slope, float *d_scratch, float *d_featmap, void *stream)
 {
@@ -947,8 +1033,17 @@ extern "C" int hnr_image_features(const float *d_img, int V, int H, int W, const
     float *s1a = d_scratch, *s1 = s1a + (size_t)V * 6 * H1 * W1;
     float *s2a = s1 + (size_t)V * 6 * H1 * W1, *s2 = s2a + (size_t)V * 12 * H2 * W2;
     float *s3a = s2 + (size_t)V * 12 * H2 * W2, *s3 = s3a + (size_t)V * 24 * H3 * W3;
+    static int old_conv = -1;                                              // HNR_CONV_OLD=1: the one-thread-per-output-element kernel (A/B, tests)
+    if (old_conv < 0) { const char *e = getenv("HNR_CONV_OLD"); old_conv = e ? atoi(e) : 0; }
     auto conv = [&](const float *in, int Cin, int Hin, int Win, int cl, int cstride, int li, int Cout, int stride, int Hout, int Wout, float *out) {
-        const int64_t total = (int64_t)V * Cout * Hout * Wout;
+        const int64_t total = (int64_t)V * Cout * Hout * Wout, pixels = (int64_t)V * Hout * Wout;
+#define HNR_CONV_TILE(CIN_, CT_, CL_) \
+        if (!old_conv && Cin == CIN_ && Cout % CT_ == 0 && cl == CL_) { \
+            conv3x3_lrelu_tile_kernel<CIN_, CT_, CL_><<<dim3((unsigned)cdiv(pixels, 256), Cout / CT_), 256, 0, st>>>(in, Hin, Win, cstride, d_conv_w[li], d_conv_b[li], \
+                                                                                                                 Cout, stride, Hout, Wout, slope, out, V); \
+            return; }
+        HNR_CONV_TILE(3, 6, 1) HNR_CONV_TILE(6, 6, 0) HNR_CONV_TILE(12, 6, 0) HNR_CONV_TILE(24, 6, 0)       // (groups of 12 channels: 20.5 / 34.7 us instead of 15.0 / 22.2)
+#undef HNR_CONV_TILE
         conv3x3_lrelu_kernel<<<cdiv(total, 256), 256, 0, st>>>(in, Cin, Hin, Win, cl, cstride, d_conv_w[li], d_conv_b[li], Cout, stride,
                                                                 Hout, Wout, slope, out, V);
     };
