@@ -401,36 +401,49 @@ __device__ __forceinline__ float bilinear_apply(const float *__restrict__ p, con
 
 // four threads per pixel, 12 channels (three 16-B stores) each: [img 3 | s1 6 | s2 0..2], [s2 3..11 | s3 0..2], [s3 3..14], [s3 15..23 | pad 3];
 // the taps of a level are computed once per thread (one thread per (pixel, channel) recomputed them 45 times per pixel: 0.43 ms per frame)
-__global__ void featmap_kernel(const float *__restrict__ img /*[V,H,W,3]*/, const float *__restrict__ s1, const float *__restrict__ s2,
-                               const float *__restrict__ s3, int V, int H, int W, int H1, int W1, int H2, int W2, int H3, int W3,
-                               float *__restrict__ fm /*[V,H,W,48]*/)
+// One block = 256 pixels of ONE part (blockIdx.y): the part decides which levels a thread samples, and with the four parts of a pixel in adjacent lanes
+// every wave ran all four variants under exec masks.
+template <int PART>
+__device__ __forceinline__ void featmap_part(const float *__restrict__ img, const float *__restrict__ s1, const float *__restrict__ s2,
+                                             const float *__restrict__ s3, int V, int H, int W, int H1, int W1, int H2, int W2, int H3, int W3,
+                                             float *__restrict__ fm, int64_t pix)
 {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t total = (int64_t)V * H * W * 4;
-    if (idx >= total) return;
-    const int part = (int)(idx & 3);
-    const int64_t pix = idx >> 2;
     const int x = (int)(pix % W), y = (int)((pix / W) % H), v = (int)(pix / ((int64_t)W * H));
     float o[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) o[i] = 0.f;
     if (!(x == 0 && y == 0)) {                     // aux_feature_output[:, :, 0, 0] *= 0  (:1089)
-        const bool need1 = part == 0, need2 = part <= 1, need3 = part >= 1;
+        constexpr bool need1 = PART == 0, need2 = PART <= 1, need3 = PART >= 1;
         BilinearTap t1 = {}, t2 = {}, t3 = {};
         if (need1) t1 = bilinear_tap(H1, W1, H, W, y, x);
         if (need2) t2 = bilinear_tap(H2, W2, H, W, y, x);
         if (need3) t3 = bilinear_tap(H3, W3, H, W, y, x);
 #pragma unroll
         for (int i = 0; i < 12; ++i) {
-            const int c = 12 * part + i;
+            constexpr int c0 = 12 * PART;
+            const int c = c0 + i;
             if (c < 3) o[i] = img[pix * 3 + c];
             else if (c < 9) o[i] = bilinear_apply(s1 + ((size_t)v * 6 + (c - 3)) * H1 * W1, t1);
             else if (c < 21) o[i] = bilinear_apply(s2 + ((size_t)v * 12 + (c - 9)) * H2 * W2, t2);
             else if (c < 45) o[i] = bilinear_apply(s3 + ((size_t)v * 24 + (c - 21)) * H3 * W3, t3);
         }
     }
-    float4 *dst = reinterpret_cast<float4 *>(fm + pix * 48 + 12 * part);
+    float4 *dst = reinterpret_cast<float4 *>(fm + pix * 48 + 12 * PART);
     dst[0] = make_float4(o[0], o[1], o[2], o[3]); dst[1] = make_float4(o[4], o[5], o[6], o[7]); dst[2] = make_float4(o[8], o[9], o[10], o[11]);
+}
+
+__global__ __launch_bounds__(256) void featmap_kernel(const float *__restrict__ img /*[V,H,W,3]*/, const float *__restrict__ s1, const float *__restrict__ s2,
+                                                      const float *__restrict__ s3, int V, int H, int W, int H1, int W1, int H2, int W2, int H3, int W3,
+                                                      float *__restrict__ fm /*[V,H,W,48]*/)
+{
+    const int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= (int64_t)V * H * W) return;
+    switch (blockIdx.y) {
+        case 0: featmap_part<0>(img, s1, s2, s3, V, H, W, H1, W1, H2, W2, H3, W3, fm, pix); break;
+        case 1: featmap_part<1>(img, s1, s2, s3, V, H, W, H1, W1, H2, W2, H3, W3, fm, pix); break;
+        case 2: featmap_part<2>(img, s1, s2, s3, V, H, W, H1, W1, H2, W2, H3, W3, fm, pix); break;
+        default: featmap_part<3>(img, s1, s2, s3, V, H, W, H1, W1, H2, W2, H3, W3, fm, pix); break;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1053,8 +1066,8 @@ extern "C" int hnr_image_features(const float *d_img, int V, int H, int W, const
     conv(s2a, 12, H2, W2, 0, 0, 3, 12, 1, H2, W2, s2);
     conv(s2, 12, H2, W2, 0, 0, 4, 24, 2, H3, W3, s3a);
     conv(s3a, 24, H3, W3, 0, 0, 5, 24, 1, H3, W3, s3);
-    const int64_t total = (int64_t)V * H * W * 4;                          // four threads per pixel
-    featmap_kernel<<<cdiv(total, 256), 256, 0, st>>>(d_img, s1, s2, s3, V, H, W, H1, W1, H2, W2, H3, W3, d_featmap);
+    // four threads per pixel, one part (12 channels) each; a block's threads share the part
+    featmap_kernel<<<dim3((unsigned)cdiv((int64_t)V * H * W, 256), 4), 256, 0, st>>>(d_img, s1, s2, s3, V, H, W, H1, W1, H2, W2, H3, W3, d_featmap);
     HNR_LAUNCH_CHECK();
     return HNR_OK;
 }
