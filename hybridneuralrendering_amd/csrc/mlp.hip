@@ -54,6 +54,9 @@ __device__ long long g_mlp_probe[24];
 // serial (load + split, MFMA, epilogue, barriers), so co-resident workgroups are what keeps the CU busy
 constexpr int mlp3_wgs_per_cu(int S0, int RT, int MODE) { return MODE == 1 ? 2 : RT >= 4 ? 1 : (RT == 1 || S0 <= 6) ? 4 : 2; }
 
+#ifndef HNR_MLP_LPR16
+#define HNR_MLP_LPR16 1
+#endif
 template <int S0, int S1, int S2, int S3, int MODE, int RT = 4>
 __global__ __launch_bounds__(256, mlp3_wgs_per_cu(S0, RT, MODE)) void mlp3_kernel(MlpArgs a)
 {
@@ -198,10 +201,12 @@ __global__ __launch_bounds__(256, mlp3_wgs_per_cu(S0, RT, MODE)) void mlp3_kerne
         // Row maximum by a butterfly over the LPR lanes, power-of-two scale, fp16 split, and each lane drops its 4 columns (8 B per plane)
         // into the fragment slot (k step = col >> 4, lane half = (col >> 3) & 1, element = col & 7) of the layer-0 operand planes.
         {
-            constexpr int COLS = 16 * S0, LPR = COLS > 128 ? 64 : (COLS > 64 ? 32 : 16), RPI = 64 / LPR, NB = (COLS + 4 * LPR - 1) / (4 * LPR);
+            // lanes per row: the fewest float4 slots over the row's columns -- 288 columns on 64 lanes x 2 bursts left 44 % of the lanes converting
+            // zeros (the second burst holds 32 real columns); on 16 lanes x 5 bursts 10 %
+            constexpr int COLS = 16 * S0, LPR = HNR_MLP_LPR16 && COLS == 288 ? 16 : (COLS > 128 ? 64 : (COLS > 64 ? 32 : 16)), RPI = 64 / LPR, NB = (COLS + 4 * LPR - 1) / (4 * LPR);
             const int lr = lane % LPR, sub = lane / LPR;                   // lane within the row, row within the instruction
             constexpr int RW = 8 * RT;                                     // rows of this wave
-            constexpr int ROWS_B = (NB * RW * 4 <= (RT < 4 ? 128 : 256)) ? RW : RW / 2;       // rows in flight per batch
+            constexpr int ROWS_B = ((RW / RPI) * NB * 4 <= (RT < 4 ? 128 : 256)) ? RW : RW / 2;   // rows in flight per batch (registers: BATCH x NB float4)
             constexpr int BATCH = ROWS_B / RPI;
 #pragma unroll 1
             for (int r0 = 0; r0 < RW; r0 += ROWS_B) {
