@@ -54,6 +54,12 @@ __device__ long long g_mlp_probe[24];
 // serial (load + split, MFMA, epilogue, barriers), so co-resident workgroups are what keeps the CU busy
 constexpr int mlp3_wgs_per_cu(int S0, int RT, int MODE) { return MODE == 1 ? 2 : RT >= 4 ? 1 : (RT == 1 || S0 <= 6) ? 4 : 2; }
 
+// rendezvous that waits for this wave's LDS traffic only (a __syncthreads() also waits for every global load in flight)
+#ifdef HNR_MLP_FULL_BARRIER
+#define MLP_LDS_BARRIER() __syncthreads()
+#else
+#define MLP_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
 #ifndef HNR_MLP_LPR16
 #define HNR_MLP_LPR16 1
 #endif
@@ -419,7 +425,7 @@ __global__ __launch_bounds__(256, mlp3_wgs_per_cu(S0, RT, MODE)) void mlp3_kerne
                 }
                 if (h == 0) exch[(32 * (rt0 + rt) + j) * 4 + cw] = d;
             }
-            __syncthreads();
+            MLP_LDS_BARRIER();                                             // LDS traffic only: the colour-feature loads asked for above stay in flight across it
             MLP_STAMP(14);
             if (tid < 128) {
                 float4 d4 = *reinterpret_cast<const float4 *>(exch + tid * 4);
@@ -430,7 +436,7 @@ __global__ __launch_bounds__(256, mlp3_wgs_per_cu(S0, RT, MODE)) void mlp3_kerne
                 if (a.frame_w) wv *= a.frame_w[tid & 3];
                 s_w[tid] = wv;
             }
-            __syncthreads();
+            MLP_LDS_BARRIER();
             MLP_STAMP(15);
             {
 #pragma unroll
