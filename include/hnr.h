@@ -305,7 +305,8 @@ int hnr_merge(const float *d_X6, int ld6, const float *d_Hm, int ldh, const floa
  *   (n_valid = d_counts[HNR_CNT_SAMPLES_VALID], read on the device; cap_samples bounds it) into d_workspace
  *   (hnr_chain_workspace_bytes(cap_samples)); also d_X5[s, 256:280] = view-direction encoding (:909-913) and, optionally, the
  *   reference's `weight` / `conf_coefficient` outputs [R,SR,K] (written for valid neighbour slots only).
- * hnr_chain_plan: the list of valid samples the chain works on, d_vs_item[s] = ray * SR + slot, from the kept-sample work list of
+ * hnr_chain_plan: the list of valid samples the chain works on (the packing by `pnt_mask_flat` / `sampled_Rw2c` masks of
+ *   models/aggregators/point_aggregators.py:924,935,961-970), d_vs_item[s] = ray * SR + slot, from the kept-sample work list of
  *   hnr_march_query.  classes = 0: in (ray, slot) order, exactly hnr_sample_plan's list.  classes = 1: the samples with more than four
  *   neighbours first, then those with 1..4 (each class in (ray, slot) order), and d_counts[HNR_CNT_SAMPLES_SMALL] = size of the second
  *   class: the gather and the chain kernel give a small sample 4 row slots instead of 8 (82 % of the bench frame's samples have 8
@@ -329,9 +330,11 @@ int hnr_chain_gather(const float *d_xyz, const float *d_conf, const float *d_dir
                      const int32_t *d_sample_pidx, const float *d_sample_loc_w, const float *d_raydir, const float *d_campos,
                      const float *d_camrot, const int32_t *d_vs_item, const int64_t *d_counts, int SR, int K, int cap_samples,
                      void *d_workspace, float *d_X5, int ld5, float *d_weight_out, float *d_conf_out, void *stream);
-/* hnr_point_records: the four per-point buffers the gather reads, interleaved once per cloud version into 48-byte records
+/* hnr_point_records: the four per-point buffers the gather reads (NeuralPoints' xyz / points_conf / points_dir / points_color, indexed by
+ *   sample_pidx in models/neural_points/neural_points.py:709-720), interleaved once per cloud version into 48-byte records
  *   d_rec [N][12] f32 = {x y z conf | dir.x dir.y dir.z r | g b 0 0}; hnr_chain_gather_rec = hnr_chain_gather reading them (the same values,
- *   bit-identical outputs): one or two 64-byte sectors per neighbour instead of four scattered reads (gather fetch 6.0 -> see profiles). */
+ *   bit-identical outputs): one or two 64-byte sectors per neighbour instead of four scattered reads (6.0 -> 1.8 GB fetched per frame,
+ *   profiles/r02_traffic.json). */
 int hnr_point_records(const float *d_xyz, const float *d_conf, const float *d_dir, const float *d_color, int N, float *d_rec, void *stream);
 int hnr_chain_gather_rec(const float *d_rec, const int32_t *d_sample_pidx, const float *d_sample_loc_w, const float *d_raydir,
                          const float *d_campos, const float *d_camrot, const int32_t *d_vs_item, const int64_t *d_counts, int SR, int K,
