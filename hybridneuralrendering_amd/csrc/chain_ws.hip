@@ -111,9 +111,13 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
     u32x4 xv[2] = {u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};
     int tile_fin = -1;
 
-    // weight fragments of (layer L, k step s) -> a[16 s ..]: four loads
+    // weight fragments of (layer L, k step s) -> a[16 s ..]: four loads  (probe build -DHNR_CHAIN_WS_SAME_W=1: every k step reads the layer's
+    // first one -- 64 KiB instead of 848 KiB of weights per tile from L2; results are garbage, the time shows what the weight stream costs)
+#ifndef HNR_CHAIN_WS_SAME_W
+#define HNR_CHAIN_WS_SAME_W 0
+#endif
 #define CW_LOAD_W(L_, s_) do { \
-        const int so_ = cw_wbase(L_) + (s_) * CH_WSTEP; \
+        const int so_ = cw_wbase(L_) + (HNR_CHAIN_WS_SAME_W ? 0 : (s_)) * CH_WSTEP; \
         CW_LOAD_FRAG(16 * (s_) + 0, wsrd, woff, so_, 0); CW_LOAD_FRAG(16 * (s_) + 4, wsrd, woff, so_, 1024); \
         CW_LOAD_FRAG(16 * (s_) + 8, wsrd, woff, so_, 2048); CW_LOAD_FRAG(16 * (s_) + 12, wsrd, woff, so_, 3072); } while (0)
     // per-row scalars of a tile: the point ids are needed first (table rows of layer 0: fetched into pid_n during the previous tile's last pass),
