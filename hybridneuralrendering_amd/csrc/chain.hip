@@ -861,6 +861,7 @@ __global__ __launch_bounds__(1024) void chain_plan_sum_kernel(const int32_t *__r
 {
     __shared__ int s_a[16], s_b[16], s_c[16];
     const int n_items = (int)counts[HNR_CNT_SAMPLES];
+    if ((long long)blockIdx.x * 1024 >= n_items) return;             // (the scan kernel reads the sums of the blocks that hold items only)
     const int i = blockIdx.x * 1024 + threadIdx.x;
     const int cl = i < n_items ? chain_sample_class(pidx + (size_t)work[i] * K, K, classes) : 0;
     int big = cl == 1 ? 1 : 0, small = cl == 2 ? 1 : 0, tiny = cl == 3 ? 1 : 0;
@@ -886,8 +887,12 @@ __global__ __launch_bounds__(1024) void chain_plan_scan_kernel(const int32_t *__
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int n_items = (int)counts[HNR_CNT_SAMPLES];
     const int i = blockIdx.x * 1024 + threadIdx.x;
+    // the grid is sized for the capacity (R * SR kept samples); the blocks past the last kept sample have nothing to place (block 0 stays: it
+    // writes the class counters) and their sums -- never written by the sum kernel's early exit -- are not read
+    if (blockIdx.x > 0 && (long long)blockIdx.x * 1024 >= n_items) return;
+    const int nb_used = (n_items + 1023) / 1024 < n_blocks ? (n_items + 1023) / 1024 : n_blocks;
     int pa = 0, pb = 0, pc = 0, ta = 0, tb = 0;       // big / small / tiny samples in the blocks before this one; big and small samples in all blocks
-    for (int k = threadIdx.x; k < n_blocks; k += 1024) {
+    for (int k = threadIdx.x; k < nb_used; k += 1024) {
         const int a = block_sums[3 * k], b = block_sums[3 * k + 1], c = block_sums[3 * k + 2];
         ta += a; tb += b;
         if (k < (int)blockIdx.x) { pa += a; pb += b; pc += c; }
