@@ -154,6 +154,14 @@ SIGNATURES = {
     "hnr_point_rows_bwd": (_I, [_P, _I, _P, _I, _P, _I, _I, _P, _P]),
     "hnr_dleaky": (_I, [_P, _I, _P, _I, ctypes.c_int64, _I, _F, _P]),
     "hnr_sum_views": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P]),
+    # training-step dense layers on the 16-bit matrix pipe (csrc/h2gemm.hip)
+    "hnr_h2lin_packed_bytes": (ctypes.c_int64, [_I]),
+    "hnr_h2lin_pack": (_I, [_I, ctypes.POINTER(_P), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(_I), ctypes.POINTER(_I),
+                            ctypes.POINTER(_P), ctypes.POINTER(_P), _P]),
+    "hnr_h2lin": (_I, [_P, _I, ctypes.c_int64, _P, _P, _I, _I, _I, _I, _F, _P, _I, _P, _I, _P, _P]),
+    "hnr_h2wgrad_scratch_bytes": (ctypes.c_int64, [_I, _I]),
+    "hnr_h2wgrad": (_I, [_P, _I, _P, _I, ctypes.c_int64, _P, _I, _I, _P, _P, _P, _I, _P, _I, _P, _P]),
+    "hnr_absmax": (_I, [_P, _I, ctypes.c_int64, _P, _I, _P, _P]),
 }
 
 _lib = None

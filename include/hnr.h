@@ -507,6 +507,33 @@ int hnr_dleaky(float *d_g, int ldg, const float *d_y, int ldy, int64_t M, int N,
 int hnr_sum_views(const float *d_in, int ldi, int V, int cap, int n_samples, int N, float *d_out, int ldo, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Dense layers of the TRAINING step on the 16-bit matrix pipe (csrc/h2gemm.hip), fp32 in / fp32 out, the chain's two-term fp16 split
+ * arithmetic.  They replace what torch autograd runs for the nn.Linear (+ LeakyReLU) layers of PointAggregator.viewmlp in the reference's
+ * train step (models/aggregators/point_aggregators.py:948, :972, :1037, :1199, :1292; loss.backward() at
+ * models/mvs_points_volumetric_model.py:111-131).  Every row count is read on the DEVICE: rows = min(M_cap, *d_m) (d_m may be NULL).
+ *   hnr_h2lin_pack   n_jobs <= 16 weight matrices -> kernel images, two launches for all of them.  Element (n, k) of job j is
+ *                    d_W[j][n * rs[j] + k * cs[j]]: (rs, cs) = (ld, 1) packs an nn.Linear weight [N, K], (1, ld) its transpose (input
+ *                    gradients: dX = dZ W is the layer "dZ (W^T)^T").  N <= 256, K <= 288; image bytes: hnr_h2lin_packed_bytes(K).
+ *   hnr_h2lin        mode 0: C = act(A W^T + bias)  (act != 0: LeakyReLU(slope));
+ *                    mode 1: C = (A W^T) * (side > 0 ? 1 : slope)   -- side [M, ld_side] is the stored forward activation: the input
+ *                    gradient through a LeakyReLU.  K in {<= 48, <= 64, <= 128, <= 224, <= 256}.  d_absmax (optional): max |C| is
+ *                    atomically max-ed into it as a bit pattern (the scale of a later hnr_h2wgrad).
+ *   hnr_h2wgrad      dW[N, K] (row stride lddw) = dZ[M, N]^T X[M, K], db[N] = column sums of dZ (d_db may be NULL); accumulate != 0 adds.
+ *                    d_absmax_z / d_absmax_x: bit patterns of (an upper bound of) max |dZ|, max |X| (hnr_absmax or a producer's output).
+ *                    N <= 256, K <= 287.  Deterministic (fixed-order partials, no atomics); d_scratch: hnr_h2wgrad_scratch_bytes(N, K).
+ *   hnr_absmax       *d_out = max(*d_out, max |A[0:M, 0:N]|) as a bit pattern. */
+int64_t hnr_h2lin_packed_bytes(int K);
+int hnr_h2lin_pack(int n_jobs, const float *const *d_W, const int64_t *rs, const int64_t *cs, const int *N, const int *K,
+                   const float *const *d_bias /*may be NULL*/, void *const *d_packed, void *stream);
+int hnr_h2lin(const float *d_A, int lda, int64_t M_cap, const int64_t *d_m, const void *d_packed, int N, int K, int mode, int act, float slope,
+              const float *d_side, int ld_side, float *d_C, int ldc, uint32_t *d_absmax, void *stream);
+int64_t hnr_h2wgrad_scratch_bytes(int N, int K);
+int hnr_h2wgrad(const float *d_dZ, int ldz, const float *d_X, int ldx, int64_t M_cap, const int64_t *d_m, int N, int K,
+                const uint32_t *d_absmax_z, const uint32_t *d_absmax_x, float *d_dW, int lddw, float *d_db, int accumulate,
+                void *d_scratch, void *stream);
+int hnr_absmax(const float *d_A, int lda, int64_t M_cap, const int64_t *d_m, int N, uint32_t *d_out, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
  * The whole forward path in ONE call (csrc/render_forward.hip): one pass of NeuralPointsRayMarching.forward + fill_invalid
  * (models/neural_points_volumetric_model.py:257-391, :87-126) over R rays -- query, gather / aggregate (fused chain + fused
  * per-sample MLPs), composite -- with every launch issued here, back to back on the caller's stream.  The reference's three host

@@ -1,0 +1,140 @@
+"""Dense layers of the training step on the 16-bit matrix pipe (csrc/h2gemm.hip) against fp64 numpy, through the C ABI.
+
+What is checked is what torch autograd computes for an nn.Linear (+ LeakyReLU) of PointAggregator.viewmlp in the reference's train step
+(/root/reference/models/aggregators/point_aggregators.py:948, :972, :1037, :1199, :1292): forward, input gradient through the activation,
+weight / bias gradient.  Tolerances are those of an fp32 GEMM: |err| <= tol * sum_k |a_k w_k| per element (fp32 MFMA measures ~1.5e-7 here,
+tests/test_linear_gpu.py)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from hybridneuralrendering_amd import _lib  # noqa: E402
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def pack(W_list, transposed=None, biases=None):
+    """hnr_h2lin_pack over a list of torch weights [N,K]; transposed[j]: pack W^T (the input-gradient layer)."""
+    L = _lib.lib()
+    n = len(W_list)
+    transposed = transposed or [False] * n
+    biases = biases or [None] * n
+    outs, Ns, Ks, rs, cs = [], [], [], [], []
+    for W, t in zip(W_list, transposed):
+        rows, cols = W.shape
+        N, K = (cols, rows) if t else (rows, cols)
+        Ns.append(N); Ks.append(K)
+        rs.append(1 if t else cols); cs.append(cols if t else 1)
+        outs.append(torch.empty((int(L.hnr_h2lin_packed_bytes(K)),), dtype=torch.uint8, device=W.device))
+    P, I, I64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
+    _lib.check(L.hnr_h2lin_pack(n, (P * n)(*[w.data_ptr() for w in W_list]), (I64 * n)(*rs), (I64 * n)(*cs), (I * n)(*Ns), (I * n)(*Ks),
+                                (P * n)(*[(b.data_ptr() if b is not None else None) for b in biases]), (P * n)(*[o.data_ptr() for o in outs]),
+                                _lib.stream()), "hnr_h2lin_pack")
+    return outs
+
+
+@pytest.mark.parametrize("M,N,K,mode", [(1000, 256, 256, 0), (777, 256, 224, 0), (5000, 256, 256, 1), (300, 224, 256, 1), (2049, 128, 128, 1),
+                                        (513, 64, 64, 1), (64, 48, 64, 1), (1500, 128, 45, 0), (4097, 90, 45, 1), (1, 256, 256, 0)])
+def test_h2lin_matches_fp64(M, N, K, mode):
+    dev = _dev()
+    L = _lib.lib()
+    g = torch.Generator(device="cpu").manual_seed(M * 7 + N + K)
+    lda, ldc = (K + 3) // 4 * 4, (N + 3) // 4 * 4
+    A = torch.zeros((M, lda))
+    A[:, :K] = torch.randn((M, K), generator=g) * torch.exp(2.0 * torch.randn((M, 1), generator=g))      # rows of very different magnitude
+    W = torch.randn((N, K), generator=g) / np.sqrt(K)
+    b = torch.randn((N,), generator=g)
+    side = torch.randn((M, ldc), generator=g)
+    Ad, Wd, bd, sd = A.to(dev), W.to(dev), b.to(dev), side.to(dev)
+    img = pack([Wd], biases=[bd])[0]
+    C = torch.full((M + 3, ldc), 7.0, device=dev)
+    mx = torch.zeros(1, dtype=torch.int32, device=dev)
+    dm = torch.tensor([M], dtype=torch.int64, device=dev)
+    slope = 0.01
+    _lib.check(L.hnr_h2lin(_lib.ptr(Ad), lda, M + 3, _lib.ptr(dm), _lib.ptr(img), N, K, mode, 1, slope, _lib.ptr(sd) if mode == 1 else None, ldc,
+                           _lib.ptr(C), ldc, _lib.ptr(mx), _lib.stream()), "hnr_h2lin")
+    got = C.cpu().numpy().astype(np.float64)
+    A64, W64 = A[:, :K].numpy().astype(np.float64), W.numpy().astype(np.float64)
+    ref = A64 @ W64.T
+    mag = np.abs(A64) @ np.abs(W64).T
+    if mode == 0:
+        ref = ref + b.numpy().astype(np.float64)
+        mag = mag + np.abs(b.numpy().astype(np.float64))
+        ref = np.where(ref > 0, ref, slope * ref)
+    else:
+        ref = ref * np.where(side[:, :N].numpy() > 0, 1.0, slope)
+    err = np.abs(got[:M, :N] - ref) / (mag + 1e-30)
+    assert err.max() < 4e-7, (err.max(), np.unravel_index(err.argmax(), err.shape))
+    assert (got[M:] == 7.0).all(), "rows past *d_m were written"
+    if mode == 1:
+        gmax = float(np.frombuffer(np.int32(mx.item()).tobytes(), dtype=np.float32)[0])
+        assert gmax >= np.abs(got[:M, :N]).max() * (1 - 1e-6) and gmax <= np.abs(got[:M, :N]).max() * 1.0001 + 1e-30
+
+
+@pytest.mark.parametrize("M,N,K", [(20000, 256, 256), (777, 256, 263), (3001, 256, 60), (999, 256, 224), (4096, 128, 280), (5000, 128, 128),
+                                   (3333, 64, 48), (2500, 64, 64), (1200, 64, 128), (900, 45, 90), (31, 45, 45), (1, 256, 256)])
+def test_h2wgrad_matches_fp64(M, N, K):
+    dev = _dev()
+    L = _lib.lib()
+    g = torch.Generator(device="cpu").manual_seed(M + 3 * N + 5 * K)
+    ldz, ldx = (N + 3) // 4 * 4, (K + 3) // 4 * 4
+    Z = torch.full((M + 5, ldz), float("nan"))
+    X = torch.full((M + 5, ldx), float("nan"))
+    Z[:M, :N] = torch.randn((M, N), generator=g) * torch.exp(1.5 * torch.randn((M, 1), generator=g)) * 1e-3
+    X[:M, :K] = torch.randn((M, K), generator=g).abs() * torch.exp(torch.randn((1, K), generator=g))
+    Z[:M, N:] = 3.0; X[:M, K:] = -2.0                                              # padding columns must not leak in
+    Zd, Xd = Z.to(dev), X.to(dev)
+    dm = torch.tensor([M], dtype=torch.int64, device=dev)
+    mz = torch.zeros(1, dtype=torch.int32, device=dev)
+    mx = torch.zeros(1, dtype=torch.int32, device=dev)
+    _lib.check(L.hnr_absmax(_lib.ptr(Zd), ldz, M + 5, _lib.ptr(dm), N, _lib.ptr(mz), _lib.stream()), "hnr_absmax")
+    _lib.check(L.hnr_absmax(_lib.ptr(Xd), ldx, M + 5, _lib.ptr(dm), K, _lib.ptr(mx), _lib.stream()), "hnr_absmax")
+    zmax = float(np.frombuffer(np.int32(mz.item()).tobytes(), dtype=np.float32)[0])
+    assert zmax == float(Z[:M, :N].abs().max())
+    scratch = torch.empty((int(L.hnr_h2wgrad_scratch_bytes(N, K)),), dtype=torch.uint8, device=dev)
+    dW = torch.full((N, K + 2), 5.0, device=dev)
+    db = torch.full((N,), 5.0, device=dev)
+    for acc in (0, 1):
+        _lib.check(L.hnr_h2wgrad(_lib.ptr(Zd), ldz, _lib.ptr(Xd), ldx, M + 5, _lib.ptr(dm), N, K, _lib.ptr(mz), _lib.ptr(mx), _lib.ptr(dW), K + 2,
+                                 _lib.ptr(db), acc, _lib.ptr(scratch), _lib.stream()), "hnr_h2wgrad")
+    Z64, X64 = Z[:M, :N].numpy().astype(np.float64), X[:M, :K].numpy().astype(np.float64)
+    ref, mag = Z64.T @ X64, np.abs(Z64).T @ np.abs(X64)
+    got = dW.cpu().numpy().astype(np.float64)
+    err = np.abs(got[:, :K] / 2.0 - ref) / (mag + 1e-30)
+    # (a single product carries the split error of both operands, 2 x 2^-22; over a sum the terms' errors average out)
+    assert err.max() < (1e-6 if M < 8 else 4e-7), (err.max(), np.unravel_index(err.argmax(), err.shape))
+    assert (got[:, K:] == 5.0).all()
+    errb = np.abs(db.cpu().numpy().astype(np.float64) / 2.0 - Z64.sum(0)) / (np.abs(Z64).sum(0) + 1e-30)
+    assert errb.max() < 4e-7, errb.max()
+
+
+def test_h2wgrad_is_bit_identical_run_to_run_and_zero_rows_are_inert():
+    dev = _dev()
+    L = _lib.lib()
+    M, N, K = 30000, 256, 256
+    g = torch.Generator(device="cpu").manual_seed(3)
+    Z, X = torch.randn((M, N), generator=g), torch.randn((M, K), generator=g)
+    Z[::3] = 0.0                                                                   # empty neighbour slots of the padded row layout: exact zeros
+    X[::3] = 50.0                                                                  # ... whatever (finite) activations those rows carry
+    Zd, Xd = Z.to(dev), X.to(dev)
+    one = torch.tensor([np.float32(8.0).view(np.int32)], dtype=torch.int32, device=dev)      # upper bounds of the maxima are enough
+    big = torch.tensor([np.float32(64.0).view(np.int32)], dtype=torch.int32, device=dev)
+    scratch = torch.empty((int(L.hnr_h2wgrad_scratch_bytes(N, K)),), dtype=torch.uint8, device=dev)
+    outs = []
+    for _ in range(2):
+        dW, db = torch.empty((N, K), device=dev), torch.empty((N,), device=dev)
+        _lib.check(L.hnr_h2wgrad(_lib.ptr(Zd), N, _lib.ptr(Xd), K, M, None, N, K, _lib.ptr(one), _lib.ptr(big), _lib.ptr(dW), K, _lib.ptr(db), 0,
+                                 _lib.ptr(scratch), _lib.stream()), "hnr_h2wgrad")
+        outs.append((dW.cpu().numpy(), db.cpu().numpy()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    ref = Z.numpy().astype(np.float64).T @ X.numpy().astype(np.float64)
+    mag = np.abs(Z.numpy().astype(np.float64)).T @ np.abs(X.numpy().astype(np.float64))
+    assert (np.abs(outs[0][0] - ref) / mag).max() < 4e-7
