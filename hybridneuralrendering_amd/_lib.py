@@ -68,6 +68,30 @@ class RenderOutputs(ctypes.Structure):
                 ("d_conf_coefficient", _P), ("stage_events", ctypes.POINTER(_P))]
 
 
+class TrainParams(ctypes.Structure):
+    _fields_ = [("R", _I), ("SR", _I), ("K", _I), ("D", _I), ("tmid_stride", _I), ("kernel_size", _I * 3), ("radius2", _F), ("vsize_z", _F),
+                ("raydist_mode_unit", _I), ("V", _I), ("H", _I), ("W", _I), ("n_points", _I), ("cap_samples", _I), ("knn_order", _I), ("slope", _F)]
+
+
+class TrainCloud(ctypes.Structure):
+    _fields_ = [("d_xyz", _P), ("d_emb", _P), ("d_conf", _P), ("d_dir", _P), ("d_color", _P)]
+
+
+class TrainCloudGrads(ctypes.Structure):
+    _fields_ = [("d_emb", _P), ("d_conf", _P), ("d_dir", _P), ("d_color", _P)]
+
+
+class TrainWeights(ctypes.Structure):
+    """hnr_train_weights: raw parameter pointers under the reference's names; the gradient block has the same layout."""
+    _fields_ = [(n, _P) for n in ("block1_0_w", "block1_0_b", "block1_2_w", "block1_2_b", "block3_0_w", "block3_0_b", "block3_2_w", "block3_2_b", "alpha_w", "alpha_b")] + \
+               [("cf_w", _P * 3), ("cf_b", _P * 3), ("mw_w", _P * 4), ("mw_b", _P * 4), ("mx_w", _P * 3), ("mx_b", _P * 3), ("fin_w", _P), ("fin_b", _P),
+                ("conv_w", _P * 6), ("conv_b", _P * 6)]
+
+
+class TrainViews(ctypes.Structure):
+    _fields_ = [("d_w2c", _P), ("d_intrinsic", _P), ("d_campos_nearest", _P), ("d_images", _P), ("d_frame_w", _P)]
+
+
 RENDER_STAGES = ("query", "plan_gather", "chain_gather", "chain", "mlp_colorfeat", "proj_rows", "mlp_merge", "merge", "mlp_mixup", "final_color",
                  "composite")
 
@@ -158,10 +182,17 @@ SIGNATURES = {
     "hnr_h2lin_packed_bytes": (ctypes.c_int64, [_I]),
     "hnr_h2lin_pack": (_I, [_I, ctypes.POINTER(_P), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(_I), ctypes.POINTER(_I),
                             ctypes.POINTER(_P), ctypes.POINTER(_P), _P]),
-    "hnr_h2lin": (_I, [_P, _I, ctypes.c_int64, _P, _P, _I, _I, _I, _I, _F, _P, _I, _P, _I, _P, _P]),
+    "hnr_h2lin": (_I, [_P, _I, ctypes.c_int64, _P, _I, ctypes.c_int64, _P, _I, _I, _I, _I, _F, _P, _I, _P, _I, _P, _P]),
     "hnr_h2wgrad_scratch_bytes": (ctypes.c_int64, [_I, _I]),
-    "hnr_h2wgrad": (_I, [_P, _I, _P, _I, ctypes.c_int64, _P, _I, _I, _P, _P, _P, _I, _P, _I, _P, _P]),
-    "hnr_absmax": (_I, [_P, _I, ctypes.c_int64, _P, _I, _P, _P]),
+    "hnr_h2wgrad": (_I, [_P, _I, _P, _I, ctypes.c_int64, _P, _I, ctypes.c_int64, _I, _I, _P, _P, _P, _I, _P, _I, _P, _P]),
+    "hnr_absmax": (_I, [_P, _I, ctypes.c_int64, _P, _I, ctypes.c_int64, _I, _P, _P]),
+    # the training step as two calls (csrc/render_train.hip)
+    "hnr_render_train_workspace_bytes": (ctypes.c_int64, [ctypes.POINTER(TrainParams)]),
+    "hnr_render_train_forward": (_I, [_P, ctypes.POINTER(TrainParams), ctypes.POINTER(TrainCloud), ctypes.POINTER(TrainWeights), ctypes.POINTER(RenderCamera),
+                                      ctypes.POINTER(TrainViews), _P, _P, _P, ctypes.c_int64, ctypes.POINTER(RenderOutputs), _P]),
+    "hnr_render_train_backward": (_I, [ctypes.POINTER(TrainParams), ctypes.POINTER(TrainCloud), ctypes.POINTER(TrainWeights), ctypes.POINTER(RenderCamera),
+                                       ctypes.POINTER(TrainViews), _P, ctypes.c_int64, ctypes.POINTER(RenderOutputs), _P, _P, ctypes.POINTER(TrainCloudGrads),
+                                       ctypes.POINTER(TrainWeights), _P]),
 }
 
 _lib = None

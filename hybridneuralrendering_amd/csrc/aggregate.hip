@@ -266,9 +266,10 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(GatherArgs a)
 // of work items per point; E feeds one dense layer that yields the per-point addend table of hnr_linear_f32_gather_add.
 template <int F>
 __global__ __launch_bounds__(256) void point_rows_kernel(const float *__restrict__ emb, const int32_t *__restrict__ ids, int n,
-                                                         float *__restrict__ E, int lde)
+                                                         float *__restrict__ E, int lde, const long long *__restrict__ d_n = nullptr)
 {
     constexpr int NITEM = F / 4 + 3 * F;
+    if (d_n && *d_n < n) n = (int)*d_n;                              // device-count form (csrc/render_train.hip)
     const int64_t total = (int64_t)n * NITEM;
     for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (int64_t)gridDim.x * blockDim.x) {
         const int p = (int)(it / NITEM), w = (int)(it - (int64_t)p * NITEM);
@@ -1189,3 +1190,16 @@ extern "C" int hnr_probe_outputs(const float *d_opacity, const float *d_sample_l
     HNR_LAUNCH_CHECK();
     return HNR_OK;
 }
+
+namespace hnr {
+int point_rows_dc(const float *d_emb, const int32_t *d_ids, int n_cap, const long long *d_n, float *d_E, int lde, hipStream_t st)
+{
+    if (n_cap <= 0) return HNR_OK;
+    const int64_t total = (int64_t)n_cap * (32 / 4 + 3 * 32);
+    int blocks = cdiv(total, 256);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    point_rows_kernel<32><<<blocks, 256, 0, st>>>(d_emb, d_ids, n_cap, d_E, lde, d_n);
+    HNR_LAUNCH_CHECK();
+    return HNR_OK;
+}
+}  // namespace hnr

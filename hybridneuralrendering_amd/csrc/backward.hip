@@ -436,6 +436,7 @@ struct KsumBwdArgs {
     float *gZ4; int ldgz;                                // [rows, ldgz] out: d PRE-activation of block3's last layer (256)
     float *g_wagg;                                       // [rows] out
     float *g_alpha_w, *g_alpha_b;                        // [256], [1] atomics
+    unsigned *absmax;                                    // optional: max |gZ4| (bit pattern, atomicMax): the scale of the weight-gradient GEMM that reads it
 };
 
 __global__ __launch_bounds__(256) void ksum_bwd_kernel(KsumBwdArgs a)
@@ -447,7 +448,7 @@ __global__ __launch_bounds__(256) void ksum_bwd_kernel(KsumBwdArgs a)
     const float4 aw = reinterpret_cast<const float4 *>(a.alpha_w)[lane];
     const float ab = a.alpha_b[0];
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    float acc_b = 0.f;
+    float acc_b = 0.f, gmax = 0.f;
     for (int s = wave; s < n_valid; s += n_waves) {
         const int off = a.vs_off[s], cnt = a.vs_cnt[s];
         const float4 gf = reinterpret_cast<const float4 *>(a.gX5 + (size_t)s * a.ldg5)[lane];
@@ -469,6 +470,7 @@ __global__ __launch_bounds__(256) void ksum_bwd_kernel(KsumBwdArgs a)
             o.z = (w * gf.z + da * aw.z) * (h.z > 0.f ? 1.f : a.slope);
             o.w = (w * gf.w + da * aw.w) * (h.w > 0.f ? 1.f : a.slope);
             reinterpret_cast<float4 *>(a.gZ4 + row * a.ldgz)[lane] = o;
+            gmax = fmaxf(fmaxf(gmax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
             const float hf = wave_sum(h.x * gf.x + h.y * gf.y + h.z * gf.z + h.w * gf.w);
             if (lane == 0) a.g_wagg[row] = sp * gs + hf;
             acc.x += da * h.x; acc.y += da * h.y; acc.z += da * h.z; acc.w += da * h.w;
@@ -486,6 +488,10 @@ __global__ __launch_bounds__(256) void ksum_bwd_kernel(KsumBwdArgs a)
         atomicAdd(a.g_alpha_w + 4 * lane, p0.x + p1.x + p2.x + p3.x); atomicAdd(a.g_alpha_w + 4 * lane + 1, p0.y + p1.y + p2.y + p3.y);
         atomicAdd(a.g_alpha_w + 4 * lane + 2, p0.z + p1.z + p2.z + p3.z); atomicAdd(a.g_alpha_w + 4 * lane + 3, p0.w + p1.w + p2.w + p3.w);
         if (lane == 0) atomicAdd(a.g_alpha_b, s_b[0] + s_b[1] + s_b[2] + s_b[3]);
+    }
+    if (a.absmax) {
+        for (int o = 32; o > 0; o >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, o));
+        if (lane == 0 && gmax > 0.f) atomicMax(a.absmax, __float_as_uint(gmax));
     }
 }
 
@@ -537,9 +543,10 @@ __global__ __launch_bounds__(256) void gather_rows_bwd_kernel(GatherBwdArgs a)
 
 // [U, 8] per-point sums -> the three point buffers (every touched point once: plain adds)
 __global__ void point_small_grads_kernel(const float *__restrict__ P8, const int32_t *__restrict__ ulist, int U, float *__restrict__ g_conf,
-                                         float *__restrict__ g_dir, float *__restrict__ g_color)
+                                         float *__restrict__ g_dir, float *__restrict__ g_color, const long long *__restrict__ d_n = nullptr)
 {
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d_n && *d_n < U) U = (int)*d_n;
     if (u >= U) return;
     const float4 a0 = reinterpret_cast<const float4 *>(P8 + (size_t)u * 8)[0], a1 = reinterpret_cast<const float4 *>(P8 + (size_t)u * 8)[1];
     const size_t p = (size_t)ulist[u];
@@ -565,10 +572,12 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float *__re
 // d emb from d [emb | PE3(emb)] rows of the touched points; E holds the forward sin/cos values
 template <int F>
 __global__ __launch_bounds__(256) void point_rows_bwd_kernel(const float *__restrict__ gE, int ldg, const float *__restrict__ E, int lde,
-                                                             const int32_t *__restrict__ ids, int n, float *__restrict__ g_emb)
+                                                             const int32_t *__restrict__ ids, int n, float *__restrict__ g_emb,
+                                                             const long long *__restrict__ d_n = nullptr)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int u = (int)(t / F), d = (int)(t - (int64_t)u * F);
+    if (d_n && *d_n < n) n = (int)*d_n;
     if (u >= n) return;
     const float *g = gE + (size_t)u * ldg, *e = E + (size_t)u * lde;
     float acc = g[d];
@@ -584,20 +593,24 @@ __global__ __launch_bounds__(256) void point_rows_bwd_kernel(const float *__rest
 
 // ------------------------------------------------------------------------------------------------ small helpers
 // g[m, n] *= (y[m, n] > 0 ? 1 : slope)
-__global__ void dleaky_kernel(float *__restrict__ g, int ldg, const float *__restrict__ y, int ldy, int64_t M, int N, float slope)
+__global__ void dleaky_kernel(float *__restrict__ g, int ldg, const float *__restrict__ y, int ldy, int64_t M, int N, float slope,
+                              const long long *__restrict__ d_n = nullptr)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t m = t / N;
+    if (d_n && *d_n < M) M = *d_n;
     if (m >= M) return;
     const int n = (int)(t - m * N);
     if (!(y[(size_t)m * ldy + n] > 0.f)) g[(size_t)m * ldg + n] *= slope;
 }
 
 // out[s, :] = sum_v in[v * cap + s, :]
-__global__ void sum_views_kernel(const float *__restrict__ in, int ldi, int V, int cap, int n_samples, int N, float *__restrict__ out, int ldo)
+__global__ void sum_views_kernel(const float *__restrict__ in, int ldi, int V, int cap, int n_samples, int N, float *__restrict__ out, int ldo,
+                                 const long long *__restrict__ d_n = nullptr)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t s = t / N;
+    if (d_n && *d_n < n_samples) n_samples = (int)*d_n;
     if (s >= n_samples) return;
     const int n = (int)(t - s * N);
     float acc = 0.f;
@@ -606,10 +619,11 @@ __global__ void sum_views_kernel(const float *__restrict__ in, int ldi, int V, i
 }
 
 // Unique touched points: flags -> exclusive scan (two-level, deterministic) -> compact list + per-row compact index.
-__global__ void mark_points_kernel(const int32_t *__restrict__ row_pid, int64_t M, int32_t *__restrict__ flags)
+__global__ void mark_points_kernel(const int32_t *__restrict__ row_pid, int64_t M, int32_t *__restrict__ flags, const long long *__restrict__ d_n = nullptr)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < M) flags[row_pid[t]] = 1;
+    if (d_n && *d_n < M) M = *d_n;
+    if (t < M && (!d_n || row_pid[t] >= 0)) flags[row_pid[t]] = 1;           // (device-count form: rows of empty neighbour slots carry -1)
 }
 
 __global__ __launch_bounds__(1024) void flag_block_sum_kernel(const int32_t *__restrict__ flags, int n, int32_t *__restrict__ block_sums)
@@ -664,10 +678,13 @@ __global__ __launch_bounds__(1024) void flag_scan_kernel(int32_t *__restrict__ f
     }
 }
 
-__global__ void map_rows_kernel(const int32_t *__restrict__ row_pid, int64_t M, const int32_t *__restrict__ uidx, int32_t *__restrict__ row_u)
+__global__ void map_rows_kernel(const int32_t *__restrict__ row_pid, int64_t M, const int32_t *__restrict__ uidx, int32_t *__restrict__ row_u,
+                                const long long *__restrict__ d_n = nullptr)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < M) row_u[t] = uidx[row_pid[t]];
+    if (!d_n) { if (t < M) row_u[t] = uidx[row_pid[t]]; return; }
+    // device-count form: every row of the capacity gets a key; rows past *d_n and empty slots (-1) get -1 (sorted first, skipped by the sums)
+    if (t < M) row_u[t] = (t < *d_n && row_pid[t] >= 0) ? uidx[row_pid[t]] : -1;
 }
 
 }  // namespace hnr
@@ -840,7 +857,7 @@ extern "C" int hnr_ksum_bwd(const float *d_H4, int ldh, const float *d_wagg, con
     KsumBwdArgs a;
     a.H4 = d_H4; a.ldh = ldh; a.wagg = d_wagg; a.alpha_w = d_alpha_w; a.alpha_b = d_alpha_b; a.vs_off = d_vs_off; a.vs_cnt = d_vs_cnt;
     a.counts = reinterpret_cast<const unsigned long long *>(d_counts); a.gX5 = d_gX5; a.ldg5 = ldg5; a.g_sigma = d_g_sigma; a.slope = slope;
-    a.gZ4 = d_gZ4; a.ldgz = ldgz; a.g_wagg = d_g_wagg; a.g_alpha_w = d_g_alpha_w; a.g_alpha_b = d_g_alpha_b;
+    a.gZ4 = d_gZ4; a.ldgz = ldgz; a.g_wagg = d_g_wagg; a.g_alpha_w = d_g_alpha_w; a.g_alpha_b = d_g_alpha_b; a.absmax = nullptr;
     ksum_bwd_kernel<<<persistent_blocks(cap_samples), 256, 0, (hipStream_t)stream>>>(a);
     HNR_LAUNCH_CHECK();
     return HNR_OK;
@@ -950,3 +967,49 @@ extern "C" int hnr_unique_points(const int32_t *d_row_pid, int64_t M, int n_poin
     HNR_LAUNCH_CHECK();
     return HNR_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ device-count forms (csrc/render_train.hip)
+// The same kernels with their work sizes read on the device (*d_n, clamped to the capacity the grid is sized for): the single-call training
+// step never learns a count on the host.
+namespace hnr {
+int unique_points_dc(const int32_t *d_row_pid, int64_t M_cap, const long long *d_m, int n_points, int32_t *d_uidx, int32_t *d_ulist, int cap,
+                     int32_t *d_row_u, int32_t *d_count, int32_t *d_scratch, hipStream_t st)
+{
+    HNR_HIP_CHECK(hipMemsetAsync(d_uidx, 0, (size_t)n_points * 4, st));
+    if (M_cap > 0) mark_points_kernel<<<cdiv(M_cap, 256), 256, 0, st>>>(d_row_pid, M_cap, d_uidx, d_m);
+    const int nb = cdiv(n_points, 1024);
+    flag_block_sum_kernel<<<nb, 1024, 0, st>>>(d_uidx, n_points, d_scratch);
+    flag_scan_kernel<<<nb, 1024, 0, st>>>(d_uidx, n_points, d_scratch, d_ulist, cap, d_count);
+    if (M_cap > 0) map_rows_kernel<<<cdiv(M_cap, 256), 256, 0, st>>>(d_row_pid, M_cap, d_uidx, d_row_u, d_m);
+    HNR_LAUNCH_CHECK();
+    return HNR_OK;
+}
+int point_small_grads_dc(const float *d_P8, const int32_t *d_ulist, int U_cap, const long long *d_u, float *d_g_conf, float *d_g_dir, float *d_g_color, hipStream_t st)
+{
+    if (U_cap <= 0) return HNR_OK;
+    point_small_grads_kernel<<<cdiv(U_cap, 256), 256, 0, st>>>(d_P8, d_ulist, U_cap, d_g_conf, d_g_dir, d_g_color, d_u);
+    HNR_LAUNCH_CHECK();
+    return HNR_OK;
+}
+int point_rows_bwd_dc(const float *d_gE, int ldg, const float *d_E, int lde, const int32_t *d_ids, int n_cap, const long long *d_n, float *d_g_emb, hipStream_t st)
+{
+    if (n_cap <= 0) return HNR_OK;
+    point_rows_bwd_kernel<32><<<cdiv((int64_t)n_cap * 32, 256), 256, 0, st>>>(d_gE, ldg, d_E, lde, d_ids, n_cap, d_g_emb, d_n);
+    HNR_LAUNCH_CHECK();
+    return HNR_OK;
+}
+int dleaky_dc(float *d_g, int ldg, const float *d_y, int ldy, int64_t M_cap, const long long *d_m, int N, float slope, hipStream_t st)
+{
+    if (M_cap <= 0) return HNR_OK;
+    dleaky_kernel<<<cdiv(M_cap * N, 256), 256, 0, st>>>(d_g, ldg, d_y, ldy, M_cap, N, slope, d_m);
+    HNR_LAUNCH_CHECK();
+    return HNR_OK;
+}
+int sum_views_dc(const float *d_in, int ldi, int V, int cap, const long long *d_n, int N, float *d_out, int ldo, hipStream_t st)
+{
+    if (cap <= 0) return HNR_OK;
+    sum_views_kernel<<<cdiv((int64_t)cap * N, 256), 256, 0, st>>>(d_in, ldi, V, cap, cap, N, d_out, ldo, d_n);
+    HNR_LAUNCH_CHECK();
+    return HNR_OK;
+}
+}  // namespace hnr

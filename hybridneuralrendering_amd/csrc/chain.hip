@@ -75,6 +75,7 @@ __global__ __launch_bounds__(256, RT >= 4 ? 1 : 2) void chain_kernel(ChainArgs a
     // DBG == 2: per-phase cycle counts of block 0 (s_memtime) -> a.dbg as long long [wave][16]
     long long tm[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0, t_start = 0, w_start = 0;
     int n_my = 0;
+    float hmax_run[4] = {0.f, 0.f, 0.f, 0.f};                              // training: running maxima of the four layers' outputs
     if (DBG == 2) { t_start = t_prev = clock64(); w_start = wall_clock64(); }
 #define CH_STAMP(i_) do { if (DBG == 2) { const long long t_ = clock64(); tm[i_] += t_ - t_prev; t_prev = t_; } } while (0)
     for (int tile = xcd_order ? t_lo + bi : (int)blockIdx.x; tile < (xcd_order ? t_hi : n_tiles); tile += xcd_order ? nb : (int)gridDim.x) {
@@ -155,6 +156,16 @@ __global__ __launch_bounds__(256, RT >= 4 ? 1 : 2) void chain_kernel(ChainArgs a
                         }
                     }
                 amax[rt] = m;
+                if (DBG == 3) {
+                    // training: the layer's output rows go to HBM (64 B per lane and column tile: the 16 columns this lane owns)
+                    float *o = a.H[layer] + ((size_t)tile * ROWS + 32 * rt + j) * a.ldh[layer] + col0;
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            *reinterpret_cast<float4 *>(o + 32 * c + 4 * q) = make_float4(acc[rt][c][4 * q], acc[rt][c][4 * q + 1], acc[rt][c][4 * q + 2], acc[rt][c][4 * q + 3]);
+                    hmax_run[layer] = fmaxf(hmax_run[layer], m);
+                }
             }
         };
         // per-row scale from the maxima of all four waves, split, publish the next layer's operand planes
@@ -190,6 +201,12 @@ __global__ __launch_bounds__(256, RT >= 4 ? 1 : 2) void chain_kernel(ChainArgs a
                     *reinterpret_cast<u32x4 *>(dst + 1024) = u32x4{pm[0], pm[1], pm[2], pm[3]};
                     *reinterpret_cast<u32x4 *>(dst + 1024 + 512) = u32x4{pm[4], pm[5], pm[6], pm[7]};
                 }
+                if (DBG == 3 && with_extras && rt == wave && h == 0) {
+                    float *o = a.H[1] + ((size_t)tile * ROWS + 32 * rt + j) * a.ldh[1] + 256;       // X3 = [H2 | colour3 | dir - viewdir | dir . viewdir | 0]
+                    *reinterpret_cast<float4 *>(o) = e0;
+                    *reinterpret_cast<float4 *>(o + 4) = make_float4(e1.x, e1.y, e1.z, 0.f);
+                    hmax_run[1] = fmaxf(hmax_run[1], emax);
+                }
                 if (with_extras && rt == wave && h == 0) {
                     unsigned ph[4], pm[4];
                     split2h(__fmul_rn(e0.x, sc), __fmul_rn(e0.y, sc), ph[0], pm[0]);
@@ -214,7 +231,9 @@ __global__ __launch_bounds__(256, RT >= 4 ? 1 : 2) void chain_kernel(ChainArgs a
             h2_mfma_layer<RT, 2, CH_S0, 1, CH_WSTEP, ch_slot(RT)>(wsrd, CH_W0, woff, lds, lane, acc, [&]() {
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) {
-                    const float *trow = a.ptab + (size_t)(pid[rt] < 0 ? 0 : pid[rt]) * a.ldt + col0;
+                    int prow = pid[rt] < 0 ? 0 : pid[rt];
+                    if (DBG == 3 && a.uidx) { prow = pid[rt] < 0 ? 0 : a.uidx[prow]; if (prow < 0) prow = 0; }
+                    const float *trow = a.ptab + (size_t)prow * a.ldt + col0;
 #pragma unroll
                     for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -321,6 +340,14 @@ __global__ __launch_bounds__(256, RT >= 4 ? 1 : 2) void chain_kernel(ChainArgs a
     if (DBG == 2 && tid == 0 && a.dbg) {                                   // every block: {cycles, wall ticks, tiles, XCC id}
         long long *o = reinterpret_cast<long long *>(a.dbg) + 64 + 4 * (size_t)blockIdx.x;
         o[0] = clock64() - t_start; o[1] = wall_clock64() - w_start; o[2] = n_my; o[3] = (__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 0xf) | ((long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)) << 8);
+    }
+    if (DBG == 3 && a.hmax) {
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            float m = hmax_run[l];
+            for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+            if (lane == 0 && m > 0.f) atomicMax(a.hmax + l, __float_as_uint(m));
+        }
     }
 #undef CH_STAMP
 }
@@ -652,6 +679,8 @@ struct ChainGatherArgs {
     char *xp, *aux;
     float *X5; int ld5;
     float *weight_out, *conf_out;
+    float *Xd;                                           // training: [rows, 64] fp32 PE5(dists6) (60 columns + 4 zeros): block1.0's distance inputs, for its weight gradient
+    int32_t *row_pid;                                    // training: [rows] point id of every row (-1: empty slot)
 };
 
 __device__ __forceinline__ void chain_w2pers(const float *p, const float *campos, const float *camrot, float out[3])
@@ -727,6 +756,7 @@ __global__ __launch_bounds__(256) void chain_gather_kernel(ChainGatherArgs a)
         const float w = pid >= 0 ? __fdiv_rn(wraw, fmaxf(sum, 1e-8f)) : 0.f;
 #pragma unroll
         for (int i = 0; i < 6; ++i) s_d[tid][i] = d6[i];
+        if (a.row_pid) a.row_pid[(size_t)blk * 128 + tid] = pid;
         __builtin_nontemporal_store(pid, reinterpret_cast<int32_t *>(aux) + jr);
         __builtin_nontemporal_store(__fmul_rn(w, confc), reinterpret_cast<float *>(aux + 128) + jr);
         __builtin_nontemporal_store(f32x4g{ext[0], ext[1], ext[2], ext[3]}, reinterpret_cast<f32x4g *>(aux + 256 + jr * 32));
@@ -757,6 +787,7 @@ __global__ __launch_bounds__(256) void chain_gather_kernel(ChainGatherArgs a)
     for (int s = 0; s < CH_S0; ++s) {
         const int row = 32 * rt + (L & 31), k0 = 16 * s + 8 * (L >> 5);
         unsigned ph[4], pm[4];
+        float xd8[8];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int p = (k0 >> 1) + e;
@@ -765,7 +796,13 @@ __global__ __launch_bounds__(256) void chain_gather_kernel(ChainGatherArgs a)
                 const int d = p / 5, f = p - 5 * d;
                 sincosf(__fmul_rn(s_d[row][d], (float)(1 << f)), &sv, &cv);
             }
+            xd8[2 * e] = sv; xd8[2 * e + 1] = cv;
             split2h(__fmul_rn(sv, 16384.f), __fmul_rn(cv, 16384.f), ph[e], pm[e]);
+        }
+        if (a.Xd) {
+            float *o = a.Xd + ((size_t)blk * 128 + row) * 64 + k0;
+            *reinterpret_cast<float4 *>(o) = make_float4(xd8[0], xd8[1], xd8[2], xd8[3]);
+            *reinterpret_cast<float4 *>(o + 4) = make_float4(xd8[4], xd8[5], xd8[6], xd8[7]);
         }
         // streaming (nt) stores: the 6.7 GB image is written once here and read once by the chain kernel; with the default policy the kernel
         // ran at 4.1 TB/s of writes (3.44 ms on the 3.5 M-sample probe frame), with nt stores 2.60 ms
@@ -1045,7 +1082,7 @@ extern "C" int hnr_point_records(const float *d_xyz, const float *d_conf, const 
 static int chain_gather_impl(const float *d_rec, const float *d_xyz, const float *d_conf, const float *d_dir, const float *d_color,
                              const int32_t *d_sample_pidx, const float *d_sample_loc_w, const float *d_raydir, const float *d_campos,
                              const float *d_camrot, const int32_t *d_vs_item, const int64_t *d_counts, int SR, int K, int cap_samples,
-                             void *d_workspace, float *d_X5, int ld5, float *d_weight_out, float *d_conf_out, void *stream);
+                             void *d_workspace, float *d_X5, int ld5, float *d_weight_out, float *d_conf_out, float *d_Xd, int32_t *d_row_pid, void *stream);
 
 extern "C" int hnr_chain_gather_rec(const float *d_rec, const int32_t *d_sample_pidx, const float *d_sample_loc_w, const float *d_raydir,
                                     const float *d_campos, const float *d_camrot, const int32_t *d_vs_item, const int64_t *d_counts, int SR,
@@ -1054,7 +1091,7 @@ extern "C" int hnr_chain_gather_rec(const float *d_rec, const int32_t *d_sample_
 {
     if (cap_samples > 0 && (!d_rec || ((uintptr_t)d_rec & 15))) { set_error("hnr_chain_gather_rec: NULL / unaligned point records"); return HNR_ERR_BADARG; }
     return chain_gather_impl(d_rec, nullptr, nullptr, nullptr, nullptr, d_sample_pidx, d_sample_loc_w, d_raydir, d_campos, d_camrot, d_vs_item, d_counts,
-                             SR, K, cap_samples, d_workspace, d_X5, ld5, d_weight_out, d_conf_out, stream);
+                             SR, K, cap_samples, d_workspace, d_X5, ld5, d_weight_out, d_conf_out, nullptr, nullptr, stream);
 }
 
 extern "C" int hnr_chain_gather(const float *d_xyz, const float *d_conf, const float *d_dir, const float *d_color,
@@ -1064,13 +1101,13 @@ extern "C" int hnr_chain_gather(const float *d_xyz, const float *d_conf, const f
 {
     if (cap_samples > 0 && (!d_xyz || !d_conf || !d_dir || !d_color)) { set_error("hnr_chain_gather: NULL / unaligned pointer"); return HNR_ERR_BADARG; }
     return chain_gather_impl(nullptr, d_xyz, d_conf, d_dir, d_color, d_sample_pidx, d_sample_loc_w, d_raydir, d_campos, d_camrot, d_vs_item, d_counts,
-                             SR, K, cap_samples, d_workspace, d_X5, ld5, d_weight_out, d_conf_out, stream);
+                             SR, K, cap_samples, d_workspace, d_X5, ld5, d_weight_out, d_conf_out, nullptr, nullptr, stream);
 }
 
 static int chain_gather_impl(const float *d_rec, const float *d_xyz, const float *d_conf, const float *d_dir, const float *d_color,
                              const int32_t *d_sample_pidx, const float *d_sample_loc_w, const float *d_raydir, const float *d_campos,
                              const float *d_camrot, const int32_t *d_vs_item, const int64_t *d_counts, int SR, int K, int cap_samples,
-                             void *d_workspace, float *d_X5, int ld5, float *d_weight_out, float *d_conf_out, void *stream)
+                             void *d_workspace, float *d_X5, int ld5, float *d_weight_out, float *d_conf_out, float *d_Xd, int32_t *d_row_pid, void *stream)
 {
     if (K != 8) { set_error("hnr_chain_gather: the fused chain is built for K = 8 (got %d); use the per-layer path", K); return HNR_ERR_BADARG; }
     if (cap_samples < 0 || SR <= 0 || ld5 < 280 || (ld5 & 3)) { set_error("hnr_chain_gather: bad sizes (cap_samples=%d SR=%d ld5=%d)", cap_samples, SR, ld5); return HNR_ERR_BADARG; }
@@ -1086,7 +1123,7 @@ static int chain_gather_impl(const float *d_rec, const float *d_xyz, const float
     a.raydir = d_raydir; a.campos = d_campos; a.camrot = d_camrot; a.vs_item = d_vs_item;
     a.counts = reinterpret_cast<const unsigned long long *>(d_counts); a.SR = SR; a.cap_samples = cap_samples;
     a.xp = (char *)d_workspace; a.aux = (char *)d_workspace + (size_t)blocks * 4 * CH_XP_GROUP;
-    a.X5 = d_X5; a.ld5 = ld5; a.weight_out = d_weight_out; a.conf_out = d_conf_out;
+    a.X5 = d_X5; a.ld5 = ld5; a.weight_out = d_weight_out; a.conf_out = d_conf_out; a.Xd = d_Xd; a.row_pid = d_row_pid;
     if (d_rec) chain_gather_kernel<true><<<blocks < 16384 ? blocks : 16384, 256, 0, (hipStream_t)stream>>>(a);
     else chain_gather_kernel<false><<<blocks < 16384 ? blocks : 16384, 256, 0, (hipStream_t)stream>>>(a);
     HNR_LAUNCH_CHECK();
@@ -1168,3 +1205,37 @@ extern "C" int hnr_chain_forward(const void *d_workspace, const float *d_point_t
     HNR_LAUNCH_CHECK();
     return HNR_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Training forward of the chain (csrc/render_train.hip): the gather also leaves block1.0's distance inputs in fp32 and the rows' point ids,
+// the chain kernel keeps every layer's output for the backward pass (chain_kernel<4, 3>) and reads the per-point table through d_uidx.
+namespace hnr {
+int chain_gather_train(const float *d_xyz, const float *d_conf, const float *d_dir, const float *d_color, const int32_t *d_sample_pidx,
+                       const float *d_sample_loc_w, const float *d_raydir, const float *d_campos, const float *d_camrot, const int32_t *d_vs_item,
+                       const int64_t *d_counts, int SR, int K, int cap_samples, void *d_workspace, float *d_X5, int ld5, float *d_weight_out,
+                       float *d_conf_out, float *d_Xd, int32_t *d_row_pid, void *stream)
+{
+    return chain_gather_impl(nullptr, d_xyz, d_conf, d_dir, d_color, d_sample_pidx, d_sample_loc_w, d_raydir, d_campos, d_camrot, d_vs_item, d_counts,
+                             SR, K, cap_samples, d_workspace, d_X5, ld5, d_weight_out, d_conf_out, d_Xd, d_row_pid, stream);
+}
+
+int chain_forward_train(const void *d_workspace, const float *d_point_table, int ldt, const int32_t *d_uidx, const void *d_packed, const int64_t *d_counts,
+                        int cap_samples, float slope, float *d_X5, int ld5, float *d_sigma, float *const *d_H, const int *ldh, uint32_t *d_hmax, void *stream)
+{
+    if (cap_samples <= 0) return HNR_OK;
+    const int blocks = cdiv(cap_samples, 16) + 2;
+    ChainArgs a;
+    a.xp = (const char *)d_workspace; a.aux = (const char *)d_workspace + (size_t)blocks * 4 * CH_XP_GROUP;
+    a.ptab = d_point_table; a.ldt = ldt; a.wimg = (const char *)d_packed;
+    a.counts = reinterpret_cast<const unsigned long long *>(d_counts);
+    a.X5 = d_X5; a.ld5 = ld5; a.sigma = d_sigma; a.slope = slope; a.cap_samples = cap_samples; a.dbg = nullptr; a.dbg_layer = 0; a.skew = 0;
+    for (int l = 0; l < 4; ++l) { a.H[l] = d_H[l]; a.ldh[l] = ldh[l]; }
+    a.uidx = d_uidx; a.hmax = d_hmax;
+    const int n_cu = chain_num_cus();
+    const int tiles = cdiv(cap_samples, 16), grid = tiles < n_cu ? tiles : n_cu;
+    HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chain_kernel<4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, ch_lds_bytes(4)));
+    chain_kernel<4, 3><<<grid, 256, ch_lds_bytes(4), (hipStream_t)stream>>>(a);
+    HNR_LAUNCH_CHECK();
+    return HNR_OK;
+}
+}  // namespace hnr

@@ -32,6 +32,10 @@ struct ChainArgs {
     int cap_samples;
     float *dbg; int dbg_layer;         // probe: post-activation output of layer dbg_layer -> [rows, 256]
     int skew;                          // RT = 2: the second half of the grid (the CUs' second workgroups) starts skew x 64 cycles late
+    // TRAINING forward (chain_kernel<4, 3>): every layer's post-activation output is kept for the backward pass
+    float *H[4]; int ldh[4];           // [rows, ldh >= 256] block1.0 / block1.2 / block3.0 / block3.2 outputs; H[1] has ldh >= 264: columns 256..263 = block3's 7 extras + 0
+    const int32_t *uidx;               // optional: point id -> row of ptab (the table holds the batch's touched points only)
+    unsigned *hmax;                    // [4] bit patterns of max |H[l]| (atomicMax; H[1]'s includes the extras): scales of the weight-gradient GEMMs
 };
 
 // Row-slot classes (hnr_chain_plan): samples [0, n_big) own 8 row slots each (16 samples per 128-row tile), the next n_small 4 (32 per tile), the

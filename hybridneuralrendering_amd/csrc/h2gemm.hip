@@ -77,6 +77,7 @@ __global__ void h2_pack_kernel(H2PackArgs a)
 struct H2LinArgs {
     const float *A; int lda;
     const long long *d_m; long long M_cap;     // rows = min(M_cap, *d_m) (d_m may be NULL)
+    int n_seg; long long seg_stride;           // n_seg > 1: the rows are n_seg SEGMENTS of min(*d_m, seg_stride) rows each, segment v starting at physical row v * seg_stride
     const char *wimg;
     int N, K;
     int mode;                                  // 0: C = act(A W^T + bias); 1: C = (A W^T) * (side > 0 ? 1 : slope)
@@ -94,8 +95,16 @@ __global__ __launch_bounds__(256, 2) void h2lin_kernel(H2LinArgs a)
     constexpr int RT = 2, SLOT = RT * 2048, ROWS = 32 * RT;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, j = lane & 31;
-    long long M = a.M_cap;
+    long long M = a.M_cap, n_unit = a.M_cap;
     if (a.d_m) { const long long c = *a.d_m; if (c < M) M = c; }
+    if (a.n_seg > 1) { n_unit = M < a.seg_stride ? M : a.seg_stride; M = n_unit * a.n_seg; }
+    // logical row -> physical row (segments: at most 7 compares, no integer division)
+    auto phys = [&](long long m) -> long long {
+        if (a.n_seg <= 1) return m;
+        int q = 0;
+        for (int v = 1; v < a.n_seg && v < 8; ++v) q += (m >= (long long)v * n_unit) ? 1 : 0;
+        return (long long)q * a.seg_stride + (m - (long long)q * n_unit);
+    };
     const int n_tiles = (int)((M + ROWS - 1) / ROWS);
     const float *meta = reinterpret_cast<const float *>(a.wimg + (size_t)S * CH_WSTEP);
     const __amdgpu_buffer_rsrc_t wsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(a.wimg), 0, S * CH_WSTEP, 0x00020000);
@@ -121,7 +130,7 @@ __global__ __launch_bounds__(256, 2) void h2lin_kernel(H2LinArgs a)
                 const int rl = RW * wave + b * RPI + sub;
                 long long row = row_base + rl;
                 if (row >= M) row = M - 1;
-                const float *src = a.A + (size_t)row * a.lda;
+                const float *src = a.A + (size_t)phys(row) * a.lda;
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
                     const int c = 4 * (nb * LPR + lr);
@@ -182,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void h2lin_kernel(H2LinArgs a)
             auto load_side = [&](int rt) {
                 long long row = row_base + 32 * rt + j;
                 if (row >= M) row = M - 1;
-                const float *srow = a.side + (size_t)row * a.lds_ + col0;
+                const float *srow = a.side + (size_t)phys(row) * a.lds_ + col0;
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -211,7 +220,7 @@ __global__ __launch_bounds__(256, 2) void h2lin_kernel(H2LinArgs a)
                         }
                     }
                     if (row < M) {
-                        float *dst = a.C + (size_t)row * a.ldc + col0 + 32 * c;
+                        float *dst = a.C + (size_t)phys(row) * a.ldc + col0 + 32 * c;
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
                             if (col0 + 32 * c + 4 * q + 4 <= a.ldc && col0 + 32 * c + 4 * q < ((a.N + 3) & ~3))
@@ -231,15 +240,18 @@ __global__ __launch_bounds__(256, 2) void h2lin_kernel(H2LinArgs a)
 
 // ------------------------------------------------------------------------------------------------------------------------ absmax
 __global__ __launch_bounds__(256) void h2_absmax_kernel(const float *__restrict__ A, int lda, const long long *__restrict__ d_m, long long M_cap, int N,
-                                                        unsigned *__restrict__ out)
+                                                        unsigned *__restrict__ out, int n_seg, long long seg_stride)
 {
-    long long M = M_cap;
+    long long M = M_cap, n_unit = M_cap;
     if (d_m) { const long long c = *d_m; if (c < M) M = c; }
+    if (n_seg > 1) { n_unit = M < seg_stride ? M : seg_stride; M = n_unit * n_seg; }
     const int n4 = (N + 3) >> 2;
     float m = 0.f;
     for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < M * n4; t += (long long)gridDim.x * blockDim.x) {
-        const long long row = t / n4;
-        const int c = 4 * (int)(t - row * n4);
+        long long row = t / n4;
+        const long long lrow = row;
+        if (n_seg > 1) { const long long q = row / n_unit; row = q * seg_stride + (row - q * n_unit); }
+        const int c = 4 * (int)(t - lrow * n4);
         const float *p = A + (size_t)row * lda + c;
 #pragma unroll
         for (int e = 0; e < 4; ++e) if (c + e < N) m = fmaxf(m, fabsf(p[e]));
@@ -253,6 +265,7 @@ struct H2WgradArgs {
     const float *dZ; int ldz;                  // [M, ldz], N columns used
     const float *X; int ldx;                   // [M, ldx], K columns used
     const long long *d_m; long long M_cap;
+    int n_seg; long long seg_stride;           // as in H2LinArgs
     int N, K;
     const unsigned *zmax, *xmax;               // bit patterns of max |dZ|, max |X| (device)
     float *partial;                            // [gridDim.x][NP][KP] fixed-order partials; column K = db (the staged X rows carry a 1 there)
@@ -299,8 +312,9 @@ __global__ __launch_bounds__(512, 1) void h2wgrad_kernel(H2WgradArgs a)
     constexpr int Z4 = WZ / 4, X4 = WX / 4, NLD = (32 * (Z4 + X4) + 511) / 512;      // float4 loads per thread per block
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wn = wave % WN, wk = wave / WN;
-    long long M = a.M_cap;
+    long long M = a.M_cap, n_unit = a.M_cap;
     if (a.d_m) { const long long c = *a.d_m; if (c < M) M = c; }
+    if (a.n_seg > 1) { n_unit = M < a.seg_stride ? M : a.seg_stride; M = n_unit * a.n_seg; }
     const long long n_blocks = (M + 31) / 32;
     const int kz = row_scale_exp(__uint_as_float(*a.zmax)), kx = row_scale_exp(__uint_as_float(*a.xmax));
     const float sz = pow2f(kz), sx = pow2f(kx);
@@ -329,7 +343,9 @@ __global__ __launch_bounds__(512, 1) void h2wgrad_kernel(H2WgradArgs a)
                 const long long m = blk * 32 + row;
                 const int lim = isx ? a.K : a.N, ld = isx ? a.ldx : a.ldz;
                 if (m < M && c < lim && c + 4 <= ld) {                          // (columns past lim are staged as zeros: their outputs are never read)
-                    v = *reinterpret_cast<const float4 *>((isx ? a.X : a.dZ) + (size_t)m * ld + c);
+                    long long pm = m;
+                    if (a.n_seg > 1) { int q = 0; for (int sv = 1; sv < a.n_seg && sv < 8; ++sv) q += (m >= (long long)sv * n_unit) ? 1 : 0; pm = (long long)q * a.seg_stride + (m - (long long)q * n_unit); }
+                    v = *reinterpret_cast<const float4 *>((isx ? a.X : a.dZ) + (size_t)pm * ld + c);
                     if (c + 1 >= lim) v.y = 0.f;
                     if (c + 2 >= lim) v.z = 0.f;
                     if (c + 3 >= lim) v.w = 0.f;
@@ -426,10 +442,12 @@ __global__ __launch_bounds__(512, 1) void h2wgrad_kernel(H2WgradArgs a)
 
 // dW[n, k] (+)= sum over the workgroups that had rows, in index order; db[n] likewise (column KP of the partials)
 __global__ __launch_bounds__(256) void h2wgrad_reduce_kernel(const float *__restrict__ partial, int n_wg, const long long *__restrict__ d_m, long long M_cap,
-                                                             int NP, int LDP, int N, int K, float *__restrict__ dW, int lddw, float *__restrict__ db, int accumulate)
+                                                             int NP, int LDP, int N, int K, float *__restrict__ dW, int lddw, float *__restrict__ db, int accumulate,
+                                                             int n_seg, long long seg_stride)
 {
     long long M = M_cap;
     if (d_m) { const long long c = *d_m; if (c < M) M = c; }
+    if (n_seg > 1) M = (M < seg_stride ? M : seg_stride) * n_seg;
     const long long n_blocks = (M + 31) / 32;
     const int used = (int)(n_blocks < n_wg ? n_blocks : n_wg);
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -496,9 +514,10 @@ extern "C" int hnr_h2lin_pack(int n_jobs, const float *const *d_W, const int64_t
     return HNR_OK;
 }
 
-extern "C" int hnr_h2lin(const float *d_A, int lda, int64_t M_cap, const int64_t *d_m, const void *d_packed, int N, int K, int mode, int act, float slope,
-                         const float *d_side, int ld_side, float *d_C, int ldc, uint32_t *d_absmax, void *stream)
+extern "C" int hnr_h2lin(const float *d_A, int lda, int64_t M_cap, const int64_t *d_m, int n_seg, int64_t seg_stride, const void *d_packed, int N, int K, int mode,
+                         int act, float slope, const float *d_side, int ld_side, float *d_C, int ldc, uint32_t *d_absmax, void *stream)
 {
+    if (n_seg < 1 || n_seg > 8 || (n_seg > 1 && seg_stride <= 0)) { set_error("hnr_h2lin: n_seg must be 1..8 (got %d) with a positive seg_stride", n_seg); return HNR_ERR_BADARG; }
     if (M_cap < 0 || N <= 0 || N > 256 || K <= 0 || K > 288 || lda < K || (lda & 3) || ldc < N || (ldc & 3) || (mode != 0 && mode != 1) ||
         (mode == 1 && (!d_side || ld_side < N || (ld_side & 3) || ((uintptr_t)d_side & 15))) || !(slope > 0.f && slope < 1.f)) {
         set_error("hnr_h2lin: bad sizes (N=%d K=%d lda=%d ldc=%d mode=%d ld_side=%d slope=%g)", N, K, lda, ldc, mode, ld_side, (double)slope);
@@ -507,10 +526,11 @@ extern "C" int hnr_h2lin(const float *d_A, int lda, int64_t M_cap, const int64_t
     if (M_cap == 0) return HNR_OK;
     if (!d_A || !d_packed || !d_C || ((uintptr_t)d_A & 15) || ((uintptr_t)d_C & 15) || ((uintptr_t)d_packed & 15)) { set_error("hnr_h2lin: NULL / unaligned pointer"); return HNR_ERR_BADARG; }
     H2LinArgs a;
-    a.A = d_A; a.lda = lda; a.d_m = reinterpret_cast<const long long *>(d_m); a.M_cap = M_cap; a.wimg = (const char *)d_packed; a.N = N; a.K = K;
+    a.A = d_A; a.lda = lda; a.d_m = reinterpret_cast<const long long *>(d_m); a.M_cap = M_cap; a.n_seg = n_seg; a.seg_stride = seg_stride;
+    a.wimg = (const char *)d_packed; a.N = N; a.K = K;
     a.mode = mode; a.act = act; a.slope = slope; a.side = d_side; a.lds_ = ld_side; a.C = d_C; a.ldc = ldc; a.absmax = d_absmax;
     const int S = (K + 15) / 16;
-    const int64_t tiles = (M_cap + 63) / 64;
+    const int64_t tiles = (M_cap * n_seg + 63) / 64;
     const int wgs = 2 * h2_num_cus(), grid = (int)(tiles < wgs ? tiles : wgs);
     hipStream_t st = (hipStream_t)stream;
 #define HNR_H2LIN_CASE(S_)                                                                                                              \
@@ -527,14 +547,14 @@ extern "C" int hnr_h2lin(const float *d_A, int lda, int64_t M_cap, const int64_t
     return HNR_ERR_BADARG;
 }
 
-extern "C" int hnr_absmax(const float *d_A, int lda, int64_t M_cap, const int64_t *d_m, int N, uint32_t *d_out, void *stream)
+extern "C" int hnr_absmax(const float *d_A, int lda, int64_t M_cap, const int64_t *d_m, int n_seg, int64_t seg_stride, int N, uint32_t *d_out, void *stream)
 {
-    if (M_cap < 0 || N <= 0 || lda < N || !d_out) { set_error("hnr_absmax: bad argument"); return HNR_ERR_BADARG; }
+    if (M_cap < 0 || N <= 0 || lda < N || !d_out || n_seg < 1 || n_seg > 8 || (n_seg > 1 && seg_stride <= 0)) { set_error("hnr_absmax: bad argument"); return HNR_ERR_BADARG; }
     if (M_cap == 0) return HNR_OK;
     if (!d_A) { set_error("hnr_absmax: NULL pointer"); return HNR_ERR_BADARG; }
-    const int64_t work = M_cap * ((N + 3) / 4);
+    const int64_t work = M_cap * n_seg * ((N + 3) / 4);
     const int64_t blocks = (work + 255) / 256;
-    h2_absmax_kernel<<<(int)(blocks < 1024 ? blocks : 1024), 256, 0, (hipStream_t)stream>>>(d_A, lda, reinterpret_cast<const long long *>(d_m), M_cap, N, d_out);
+    h2_absmax_kernel<<<(int)(blocks < 1024 ? blocks : 1024), 256, 0, (hipStream_t)stream>>>(d_A, lda, reinterpret_cast<const long long *>(d_m), M_cap, N, d_out, n_seg, seg_stride);
     HNR_LAUNCH_CHECK();
     return HNR_OK;
 }
@@ -556,10 +576,11 @@ extern "C" int64_t hnr_h2wgrad_scratch_bytes(int N, int K)
     return (int64_t)h2_num_cus() * (32 * NT) * (32 * KT) * 4;
 }
 
-extern "C" int hnr_h2wgrad(const float *d_dZ, int ldz, const float *d_X, int ldx, int64_t M_cap, const int64_t *d_m, int N, int K,
+extern "C" int hnr_h2wgrad(const float *d_dZ, int ldz, const float *d_X, int ldx, int64_t M_cap, const int64_t *d_m, int n_seg, int64_t seg_stride, int N, int K,
                            const uint32_t *d_absmax_z, const uint32_t *d_absmax_x, float *d_dW, int lddw, float *d_db, int accumulate,
                            void *d_scratch, void *stream)
 {
+    if (n_seg < 1 || n_seg > 8 || (n_seg > 1 && seg_stride <= 0)) { set_error("hnr_h2wgrad: n_seg must be 1..8 (got %d) with a positive seg_stride", n_seg); return HNR_ERR_BADARG; }
     if (M_cap < 0 || N <= 0 || N > 256 || K <= 0 || K > 287 || ldz < N || (ldz & 3) || ldx < K || (ldx & 3) || lddw < K) {
         set_error("hnr_h2wgrad: bad sizes (N=%d K=%d ldz=%d ldx=%d lddw=%d)", N, K, ldz, ldx, lddw); return HNR_ERR_BADARG;
     }
@@ -567,9 +588,10 @@ extern "C" int hnr_h2wgrad(const float *d_dZ, int ldz, const float *d_X, int ldx
     int NT, KT;
     h2wgrad_cfg(N, K, &NT, &KT);
     H2WgradArgs a;
-    a.dZ = d_dZ; a.ldz = ldz; a.X = d_X; a.ldx = ldx; a.d_m = reinterpret_cast<const long long *>(d_m); a.M_cap = M_cap; a.N = N; a.K = K;
+    a.dZ = d_dZ; a.ldz = ldz; a.X = d_X; a.ldx = ldx; a.d_m = reinterpret_cast<const long long *>(d_m); a.M_cap = M_cap; a.n_seg = n_seg; a.seg_stride = seg_stride;
+    a.N = N; a.K = K;
     a.zmax = d_absmax_z; a.xmax = d_absmax_x; a.partial = (float *)d_scratch;
-    const int64_t blocks = (M_cap + 31) / 32;
+    const int64_t blocks = (M_cap * n_seg + 31) / 32;
     const int n_cu = h2_num_cus();
     int grid = (int)(blocks < n_cu ? blocks : n_cu);
     if (grid < 1) grid = 1;
@@ -587,7 +609,7 @@ extern "C" int hnr_h2wgrad(const float *d_dZ, int ldz, const float *d_X, int ldx
     const int NP = 32 * NT, LDP = 32 * KT;
     const int total = N * (K + 1);
     h2wgrad_reduce_kernel<<<(total + 255) / 256, 256, 0, st>>>((const float *)d_scratch, grid, reinterpret_cast<const long long *>(d_m), M_cap, NP, LDP, N, K,
-                                                              d_dW, lddw, d_db, accumulate);
+                                                              d_dW, lddw, d_db, accumulate, n_seg, seg_stride);
     HNR_LAUNCH_CHECK();
     return HNR_OK;
 }

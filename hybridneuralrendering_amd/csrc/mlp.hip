@@ -37,6 +37,9 @@ struct MlpArgs {
     const unsigned long long *counts; int count_index, count_mult; long long M_cap;     // M = min(M_cap, counts[index] * mult) (counts may be NULL)
     int seg_stride;                    // > 0: the rows are count_mult segments of counts[index] rows each, segment v starting at row v * seg_stride
     float *C; int ldc;                 // [M, ldc] output rows (N[2] columns)
+    // training forward: the outputs of layers 0 and 1 are kept too (the backward pass needs them), and the three layers' output maxima
+    float *T0; int ldt0; float *T1; int ldt1;
+    unsigned *tmax;                    // [3] bit patterns (atomicMax), may be NULL
 };
 
 typedef float f32x4m __attribute__((ext_vector_type(4)));
@@ -113,6 +116,7 @@ __global__ __launch_bounds__(256, mlp3_wgs_per_cu(S0, RT, MODE)) void mlp3_kerne
     if (MODE == 1) {                                                       // (the first tile's prologue barriers order this before its first use)
         for (int i = tid; i < 128; i += 256) s_wl[i] = i < a.N[2] ? a.w_last[i] : 0.f;
     }
+    float tmax_run[3] = {0.f, 0.f, 0.f};
 #ifdef HNR_MLP_PROBE
     long long tm_[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tp_ = clock64(), ntile_ = 0;
 #endif
@@ -376,6 +380,11 @@ __global__ __launch_bounds__(256, mlp3_wgs_per_cu(S0, RT, MODE)) void mlp3_kerne
             MLP_STAMP(3);
             if (a.R) activate(0, amax, std::true_type{}); else activate(0, amax, std::false_type{});
             MLP_STAMP(4);
+            if (MODE == 0 && a.T0) {
+                store(a.T0, a.ldt0);
+#pragma unroll
+                for (int rt = 0; rt < RTW; ++rt) tmax_run[0] = fmaxf(tmax_run[0], amax[rt]);
+            }
         }
         publish(1, act0, amax);
         MLP_STAMP(5);
@@ -385,6 +394,11 @@ __global__ __launch_bounds__(256, mlp3_wgs_per_cu(S0, RT, MODE)) void mlp3_kerne
             h2_mfma_layer<RTW, 1, S1, 0, ML_WSTEP, SLOT>(wsrd, a.wbase[1], woff, lds_b, lane, acc, []() {});
             MLP_STAMP(6);
             activate(1, amax, std::false_type{});
+            if (MODE == 0 && a.T1) {
+                store(a.T1, a.ldt1);
+#pragma unroll
+                for (int rt = 0; rt < RTW; ++rt) tmax_run[1] = fmaxf(tmax_run[1], amax[rt]);
+            }
         }
         publish(2, act1, amax);
         MLP_STAMP(7);
@@ -398,6 +412,10 @@ __global__ __launch_bounds__(256, mlp3_wgs_per_cu(S0, RT, MODE)) void mlp3_kerne
             activate(2, amax, std::false_type{});
             MLP_STAMP(9);
             if (MODE != 1) store(a.C, a.ldc);
+            if (MODE == 0 && a.tmax) {
+#pragma unroll
+                for (int rt = 0; rt < RTW; ++rt) tmax_run[2] = fmaxf(tmax_run[2], amax[rt]);
+            }
             MLP_STAMP(10);
         }
         if (MODE == 1) {
@@ -468,6 +486,14 @@ __global__ __launch_bounds__(256, mlp3_wgs_per_cu(S0, RT, MODE)) void mlp3_kerne
         MLP_STAMP(11);
         __syncthreads();                                                   // the planes and rowinv are rewritten by the next tile's prologue
         MLP_STAMP(12);
+    }
+    if (MODE == 0 && a.tmax) {
+#pragma unroll
+        for (int l = 0; l < 3; ++l) {
+            float m = tmax_run[l];
+            for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+            if (lane == 0 && m > 0.f) atomicMax(a.tmax + l, __float_as_uint(m));
+        }
     }
 #ifdef HNR_MLP_PROBE
     if (blockIdx.x == 0 && threadIdx.x == 0) { for (int i = 0; i < 20; ++i) g_mlp_probe[i] = tm_[i]; g_mlp_probe[20] = ntile_; }
@@ -579,9 +605,37 @@ static void mlp3_probe_print(hipStream_t st, int n_layers, int K0)
 #endif
 }
 
+static int mlp3_forward_impl(const float *d_A, int lda, int64_t M_cap, const int64_t *d_counts, int count_index, int count_mult, int seg_stride,
+                             const void *d_packed, int n_layers, const int *N, const int *K, const int *act, float slope, const float *d_R,
+                             const int32_t *d_ridx, int ldr, float *d_C, int ldc, float *d_C2, int ldc2, float *d_T0, int ldt0, float *d_T1, int ldt1,
+                             uint32_t *d_tmax, void *stream);
+
 extern "C" int hnr_mlp3_forward(const float *d_A, int lda, int64_t M_cap, const int64_t *d_counts, int count_index, int count_mult, int seg_stride,
                                 const void *d_packed, int n_layers, const int *N, const int *K, const int *act, float slope, const float *d_R,
                                 const int32_t *d_ridx, int ldr, float *d_C, int ldc, float *d_C2, int ldc2, void *stream)
+{
+    return mlp3_forward_impl(d_A, lda, M_cap, d_counts, count_index, count_mult, seg_stride, d_packed, n_layers, N, K, act, slope, d_R, d_ridx, ldr, d_C, ldc,
+                             d_C2, ldc2, nullptr, 0, nullptr, 0, nullptr, stream);
+}
+
+// training forward (csrc/render_train.hip): the same launch, keeping the outputs of layers 0 and 1 ([M, ldt0 / ldt1], same row mapping as d_C) and the
+// three layers' output maxima for the backward pass
+namespace hnr {
+int mlp3_forward_train(const float *d_A, int lda, int64_t M_cap, const int64_t *d_counts, int count_index, int count_mult, int seg_stride,
+                       const void *d_packed, int n_layers, const int *N, const int *K, const int *act, float slope, const float *d_R,
+                       const int32_t *d_ridx, int ldr, float *d_C, int ldc, float *d_C2, int ldc2, float *d_T0, int ldt0, float *d_T1, int ldt1,
+                       uint32_t *d_tmax, void *stream)
+{
+    if (!d_T0 || !d_T1 || ldt0 < N[0] || ldt1 < N[1] || (ldt0 & 3) || (ldt1 & 3) || ((uintptr_t)d_T0 & 15) || ((uintptr_t)d_T1 & 15)) { set_error("mlp3_forward_train: bad activation buffers"); return HNR_ERR_BADARG; }
+    return mlp3_forward_impl(d_A, lda, M_cap, d_counts, count_index, count_mult, seg_stride, d_packed, n_layers, N, K, act, slope, d_R, d_ridx, ldr, d_C, ldc,
+                             d_C2, ldc2, d_T0, ldt0, d_T1, ldt1, d_tmax, stream);
+}
+}  // namespace hnr
+
+static int mlp3_forward_impl(const float *d_A, int lda, int64_t M_cap, const int64_t *d_counts, int count_index, int count_mult, int seg_stride,
+                             const void *d_packed, int n_layers, const int *N, const int *K, const int *act, float slope, const float *d_R,
+                             const int32_t *d_ridx, int ldr, float *d_C, int ldc, float *d_C2, int ldc2, float *d_T0, int ldt0, float *d_T1, int ldt1,
+                             uint32_t *d_tmax, void *stream)
 {
     if ((n_layers != 3 && n_layers != 4) || !N || !K || !act || M_cap < 0 || seg_stride < 0 || (seg_stride > 0 && (count_mult < 1 || count_mult > 8)) || lda < K[0] || (lda & 3) || ldc < N[2] || (ldc & 3) ||
         !(slope > 0.f && slope < 1.f) || (d_R && (!d_ridx || ldr < N[0] || (ldr & 3) || ((uintptr_t)d_R & 15))) || (n_layers == 4 && (!d_C2 || ldc2 < N[3] || (ldc2 & 3) || ((uintptr_t)d_C2 & 15)))) {
@@ -605,6 +659,7 @@ extern "C" int hnr_mlp3_forward(const float *d_A, int lda, int64_t M_cap, const 
     a.counts = reinterpret_cast<const unsigned long long *>(d_counts); a.count_index = count_index; a.count_mult = count_mult; a.M_cap = M_cap;
     a.seg_stride = seg_stride;
     a.C = d_C; a.ldc = ldc; a.C2 = d_C2; a.ldc2 = ldc2;
+    a.T0 = d_T0; a.ldt0 = ldt0; a.T1 = d_T1; a.ldt1 = ldt1; a.tmax = d_tmax;
     a.loc_w = nullptr; a.vs_item = nullptr; a.w2c = a.Kmat = a.campos = a.campos_n = a.fm = a.frame_w = a.w_last = a.b_last = a.CF = nullptr;
     a.H = a.W = a.ldcf = a.ld7 = 0; a.X7 = nullptr;
     static int n_cu = 0;
@@ -666,6 +721,7 @@ extern "C" int hnr_merge_stage(const float *d_sample_loc_w, const int32_t *d_vs_
     a.slope = slope;
     a.counts = reinterpret_cast<const unsigned long long *>(d_counts); a.count_index = HNR_CNT_SAMPLES_VALID; a.count_mult = 4; a.M_cap = (long long)cap_samples * 4;
     a.seg_stride = 0; a.C = nullptr; a.ldc = 64; a.C2 = nullptr; a.ldc2 = 0;
+    a.T0 = a.T1 = nullptr; a.ldt0 = a.ldt1 = 0; a.tmax = nullptr;
     a.loc_w = d_sample_loc_w; a.vs_item = d_vs_item; a.w2c = d_w2c; a.Kmat = d_intrinsic; a.campos = d_campos; a.campos_n = d_campos_nearest;
     a.fm = d_featmap; a.H = H; a.W = W; a.frame_w = d_frame_w; a.w_last = d_w_last; a.b_last = d_b_last; a.CF = d_CF; a.ldcf = ldcf; a.X7 = d_X7; a.ld7 = ld7;
     static int n_cu = 0;

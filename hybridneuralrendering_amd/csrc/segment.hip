@@ -60,10 +60,11 @@ __global__ __launch_bounds__(256) void segment_sum_rows_kernel(const float *__re
 __global__ __launch_bounds__(256) void segment_sum_rows_det_kernel(const float *__restrict__ A, int lda, const int32_t *__restrict__ keys_sorted,
                                                                    const int32_t *__restrict__ perm, int64_t M, int n_cols, int n_keys,
                                                                    const int32_t *__restrict__ dst_index, float *__restrict__ dst,
-                                                                   int64_t dst_stride, int accumulate)
+                                                                   int64_t dst_stride, int accumulate, const long long *__restrict__ d_nkeys = nullptr)
 {
     const int lane = threadIdx.x & 63;
     const int key = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (d_nkeys && *d_nkeys < n_keys) n_keys = (int)*d_nkeys;
     if (key >= n_keys) return;
     int64_t lo = 0, hi = M;                               // first entry with keys_sorted >= key
     while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (keys_sorted[mid] < key) lo = mid + 1; else hi = mid; }
@@ -135,3 +136,15 @@ extern "C" int hnr_segment_sum_rows(const float *d_A, int lda, const float *d_B,
     HNR_LAUNCH_CHECK();
     return HNR_OK;
 }
+
+// device-count form (csrc/render_train.hip): the grid is sized for keys_cap keys, the number of keys is read on the device
+namespace hnr {
+int segment_sum_rows_det_dc(const float *d_A, int lda, const int32_t *d_keys_sorted, const int32_t *d_perm, int64_t M, int n_cols, int keys_cap,
+                            const long long *d_nkeys, float *d_dst, int64_t dst_stride, hipStream_t st)
+{
+    if (keys_cap <= 0) return HNR_OK;
+    segment_sum_rows_det_kernel<<<cdiv((int64_t)keys_cap * 64, 256), 256, 0, st>>>(d_A, lda, d_keys_sorted, d_perm, M, n_cols, keys_cap, nullptr, d_dst, dst_stride, 0, d_nkeys);
+    HNR_LAUNCH_CHECK();
+    return HNR_OK;
+}
+}  // namespace hnr

@@ -1,0 +1,33 @@
+// Library-internal entry points of the training step (csrc/render_train.hip drives them): forms of the stage launchers whose work sizes are
+// read on the device, and the training variants of the fused forward kernels that keep their activations.
+#pragma once
+#include "hnr_common.h"
+
+namespace hnr {
+
+// csrc/chain.hip
+int chain_gather_train(const float *d_xyz, const float *d_conf, const float *d_dir, const float *d_color, const int32_t *d_sample_pidx,
+                       const float *d_sample_loc_w, const float *d_raydir, const float *d_campos, const float *d_camrot, const int32_t *d_vs_item,
+                       const int64_t *d_counts, int SR, int K, int cap_samples, void *d_workspace, float *d_X5, int ld5, float *d_weight_out,
+                       float *d_conf_out, float *d_Xd, int32_t *d_row_pid, void *stream);
+int chain_forward_train(const void *d_workspace, const float *d_point_table, int ldt, const int32_t *d_uidx, const void *d_packed, const int64_t *d_counts,
+                        int cap_samples, float slope, float *d_X5, int ld5, float *d_sigma, float *const *d_H, const int *ldh, uint32_t *d_hmax, void *stream);
+// csrc/mlp.hip
+int mlp3_forward_train(const float *d_A, int lda, int64_t M_cap, const int64_t *d_counts, int count_index, int count_mult, int seg_stride,
+                       const void *d_packed, int n_layers, const int *N, const int *K, const int *act, float slope, const float *d_R,
+                       const int32_t *d_ridx, int ldr, float *d_C, int ldc, float *d_C2, int ldc2, float *d_T0, int ldt0, float *d_T1, int ldt1,
+                       uint32_t *d_tmax, void *stream);
+// csrc/aggregate.hip
+int point_rows_dc(const float *d_emb, const int32_t *d_ids, int n_cap, const long long *d_n, float *d_E, int lde, hipStream_t st);
+// csrc/backward.hip
+int unique_points_dc(const int32_t *d_row_pid, int64_t M_cap, const long long *d_m, int n_points, int32_t *d_uidx, int32_t *d_ulist, int cap,
+                     int32_t *d_row_u, int32_t *d_count, int32_t *d_scratch, hipStream_t st);
+int point_small_grads_dc(const float *d_P8, const int32_t *d_ulist, int U_cap, const long long *d_u, float *d_g_conf, float *d_g_dir, float *d_g_color, hipStream_t st);
+int point_rows_bwd_dc(const float *d_gE, int ldg, const float *d_E, int lde, const int32_t *d_ids, int n_cap, const long long *d_n, float *d_g_emb, hipStream_t st);
+int dleaky_dc(float *d_g, int ldg, const float *d_y, int ldy, int64_t M_cap, const long long *d_m, int N, float slope, hipStream_t st);
+int sum_views_dc(const float *d_in, int ldi, int V, int cap, const long long *d_n, int N, float *d_out, int ldo, hipStream_t st);
+// csrc/segment.hip
+int segment_sum_rows_det_dc(const float *d_A, int lda, const int32_t *d_keys_sorted, const int32_t *d_perm, int64_t M, int n_cols, int keys_cap,
+                            const long long *d_nkeys, float *d_dst, int64_t dst_stride, hipStream_t st);
+
+}  // namespace hnr

@@ -1,15 +1,17 @@
-"""Training step of the fused path: forward with saved activations + hand-written HIP backward, wrapped in one
-torch.autograd.Function so the reference's shell (losses, optimisers, schedulers) works unchanged.
+"""Training step of the path: TWO library calls per step (hnr_render_train_forward / hnr_render_train_backward, csrc/render_train.hip),
+wrapped in one torch.autograd.Function so the reference's shell (losses, optimisers, schedulers) works unchanged.
 
 Counterpart of NeuralPointsRayMarching.forward in train mode (/root/reference/models/neural_points_volumetric_model.py:257-427:
 jittered depths models/neural_points/query_point_indices_worldcoords.py:87, patch drop
-models/aggregators/point_aggregators.py:1222-1237, straight-through conf clamp :1422-1424) and of what torch autograd
-derives from it.  Gradients are produced for points_embeding / points_conf / points_dir / points_color and every aggregator
-parameter that takes part in the order-2 hybrid path (`color_branch` is constructed but unused, :542-553, and gets none).
-Differentiable outputs: coarse_raycolor and conf_coefficient (the two the shipped loss terms read,
+models/aggregators/point_aggregators.py:1222-1237, straight-through conf clamp :1422-1424) and of what torch autograd derives from it
+(models/mvs_points_volumetric_model.py:111-131).  Gradients are produced for points_embeding / points_conf / points_dir / points_color
+and every aggregator parameter that takes part in the order-2 hybrid path (`color_branch` is constructed but unused, :542-553, and gets
+none).  Differentiable outputs: coarse_raycolor and conf_coefficient (the two the shipped loss terms read,
 dev_scripts/w_scannet_etf/scene241.sh:146-151); every other output is returned detached.
 
-All arithmetic runs in libhnr_hip.so; torch supplies device memory, streams and a handful of index bookkeeping ops.
+Nothing here reads a device value: the library sizes every stage from device counters inside a workspace of `cap_samples` valid shading
+samples (default R * SR, always enough); `TrainPath.check_status` reads the overflow word when the caller wants to (a host sync).
+All arithmetic runs in libhnr_hip.so; torch supplies device memory and the stream.
 """
 import ctypes
 
@@ -17,10 +19,9 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import HnrError, CNT
+from ._lib import HnrError
 from . import querier as Q
-from .linear import PackedLinear, weight_grad
-from .render import _i32, _f32, PointCloud
+from .render import _f32, PointCloud
 
 
 def drop_patch_rays(patch_size, patch_num, drop_ratio):
@@ -33,16 +34,34 @@ def drop_patch_rays(patch_size, patch_num, drop_ratio):
     return np.where(flag.flatten())[0]
 
 
-def ray_drop_flags(opt, ray_mask):
-    """[R] uint8: rays whose merged image feature is zeroed at train time.  The reference indexes the drop pattern by
-    VALID-ray row (`drop_ray_flag[ray_drop_positions, :]` over the R' compacted rays, :1225-1233), reproduced here."""
+def _drop_mode(opt):
+    """None: no image-feature drop; "patch": the deterministic patch pattern; "random": an exact-size random subset of the valid rays."""
     if not (getattr(opt, "is_train", 0) and getattr(opt, "drop_ratio", 0) > 0 and getattr(opt, "random_position", 0) == 1):
         return None
     if not getattr(opt, "ray_points", 0) or getattr(opt, "drop_disturb_range", 0) != 0:
         raise HnrError("only ray-based image-feature drop with drop_disturb_range=0 is implemented (all 19 shipped scripts)")
+    return "patch" if getattr(opt, "drop_patch", 0) else "random"
+
+
+def drop_lut(opt, R, device):
+    """[R] uint8 indexed by VALID-ray row: the reference applies `drop_ray_flag[ray_drop_positions, :]` to the R' compacted rays (:1225-1233),
+    so the library looks the pattern up by the number of valid rays before a ray (hnr_render_train_forward's d_drop_lut)."""
+    ps, pn = int(opt.dilation_setup.split("_")[1]), int(opt.dilation_setup.split("_")[0])
+    pos = drop_patch_rays(ps, pn, opt.drop_ratio)
+    lut = np.zeros((R,), dtype=np.uint8)
+    lut[pos[pos < R]] = 1
+    return torch.from_numpy(lut).to(device)
+
+
+def ray_drop_flags(opt, ray_mask):
+    """[R] uint8: rays whose merged image feature is zeroed at train time, from a ray mask (host-side form of what the library does with
+    d_drop_lut; also the random mode's flag builder).  The reference indexes the drop pattern by VALID-ray row."""
+    mode = _drop_mode(opt)
+    if mode is None:
+        return None
     R = ray_mask.shape[0]
     m = ray_mask > 0
-    if not getattr(opt, "drop_patch", 0):
+    if mode == "random":
         # `random.sample(range(R'), int(R' * drop_ratio))` over the valid-ray rows (:1231-1232; Python's RNG there, torch's here):
         # an exact-size uniform subset, chosen on the device without reading R' back
         keys = torch.rand(R, device=ray_mask.device).masked_fill(~m, 2.0)
@@ -50,14 +69,43 @@ def ray_drop_flags(opt, ray_mask):
         rank[torch.argsort(keys)] = torch.arange(R, device=ray_mask.device)
         n_drop = (m.sum() * float(opt.drop_ratio)).to(torch.long)           # int() truncation, like the reference
         return (m & (rank < n_drop)).to(torch.uint8).contiguous()
-    ps, pn = int(opt.dilation_setup.split("_")[1]), int(opt.dilation_setup.split("_")[0])
-    pos = drop_patch_rays(ps, pn, opt.drop_ratio)
-    lut = torch.zeros(R + 1, dtype=torch.bool, device=ray_mask.device)
-    pos = pos[pos < R]
-    lut[torch.from_numpy(pos).to(ray_mask.device)] = True
-    m = ray_mask > 0
+    lut = drop_lut(opt, R, ray_mask.device).to(torch.bool)
     row = torch.cumsum(m.to(torch.int32), 0) - 1                      # valid-ray row of every ray
     return (m & lut[row.clamp(min=0).long()]).to(torch.uint8).contiguous()
+
+
+# parameter name -> (field of hnr_train_weights, index or None)
+def _weight_slots():
+    slots = {}
+    for nm, fld in (("block1.0", "block1_0"), ("block1.2", "block1_2"), ("block3.0", "block3_0"), ("block3.2", "block3_2"), ("alpha_branch.0", "alpha"),
+                    ("color_final_block.0", "fin")):
+        slots[nm + ".weight"] = (fld + "_w", None)
+        slots[nm + ".bias"] = (fld + "_b", None)
+    for i, l in enumerate((0, 2, 4)):
+        slots["color_feature_branch.%d.weight" % l] = ("cf_w", i); slots["color_feature_branch.%d.bias" % l] = ("cf_b", i)
+        slots["color_mixup_block.%d.weight" % l] = ("mx_w", i); slots["color_mixup_block.%d.bias" % l] = ("mx_b", i)
+    for i, l in enumerate((0, 2, 4, 6)):
+        slots["aux_merge_weight_block.%d.weight" % l] = ("mw_w", i); slots["aux_merge_weight_block.%d.bias" % l] = ("mw_b", i)
+    for lvl in (1, 2, 3):
+        for j, l in enumerate((0, 2)):
+            slots["aux_block_s%d.%d.weight" % (lvl, l)] = ("conv_w", 2 * (lvl - 1) + j); slots["aux_block_s%d.%d.bias" % (lvl, l)] = ("conv_b", 2 * (lvl - 1) + j)
+    return slots
+
+
+_SLOTS = _weight_slots()
+
+
+def _fill_weights(tensors):
+    """hnr_train_weights from {parameter name: contiguous fp32 GPU tensor}."""
+    w = _lib.TrainWeights()
+    for name, (fld, idx) in _SLOTS.items():
+        t = tensors.get(name)
+        p = ctypes.c_void_p(t.data_ptr()) if t is not None else None
+        if idx is None:
+            setattr(w, fld, p)
+        else:
+            getattr(w, fld)[idx] = p
+    return w
 
 
 class _Saved:
@@ -65,40 +113,20 @@ class _Saved:
 
 
 class TrainPath:
-    """Forward (activations kept) and backward of one ray batch.  `renderer` is a HybridRenderer (grid / feature caches)."""
+    """Forward (activations kept in the library's workspace) and backward of one ray batch.  `renderer` is a HybridRenderer (grid cache)."""
 
     def __init__(self, renderer):
         self.r = renderer
         self.agg = renderer.agg
         self.opt = renderer.opt
-        self._pt_key, self._pt = None, None
-        self._bbox0, self._bbox_key = None, None
-
-    # transposed weights for the input-gradient GEMMs, cached with the forward pack
-    def packed_t(self):
-        pk = self.agg.packed()
-        if "t" in pk:
-            return pk["t"]
-        a = self.agg
-        tr = lambda w: PackedLinear(w.detach().t().contiguous(), None)
-        w0 = a.aux_merge_weight_block[0].weight
-        t = dict(
-            b1_1=tr(a.block1[2].weight), b1_point=tr(a.block1[0].weight[:, :224]),
-            b3_0=tr(a.block3[0].weight), b3_1=tr(a.block3[2].weight),
-            cf=[tr(a.color_feature_branch[i].weight) for i in (0, 2, 4)],
-            mw0_fd=tr(torch.cat([w0[:, :45], w0[:, 173:176]], dim=1)), mw0_cf=tr(w0[:, 45:173]),
-            mw=[None, tr(a.aux_merge_weight_block[2].weight), tr(a.aux_merge_weight_block[4].weight)],
-            mx=[tr(a.color_mixup_block[i].weight) for i in (0, 2, 4)],
-        )
-        pk["t"] = t
-        return t
+        self.cap_samples = None            # valid-sample capacity of the workspace (None: R * SR, the worst case)
 
     # ---------------------------------------------------------------------------------------------- forward
     def forward(self, cloud, raydir, campos, camrot, bg_color, near, far, c2w_nearest, campos_nearest, intrinsic_nearest,
                 images_nearest, frame_weight=None, tmid=None, ray_drop=None):
         L = _lib.lib()
         r, opt = self.r, self.opt
-        g = _lib.require_gpu
+        g, p = _lib.require_gpu, _lib.ptr
         raydir = g(raydir, "raydir", torch.float32).reshape(-1, 3)
         campos = g(campos, "campos", torch.float32).reshape(3)
         camrot = g(camrot, "camrotc2w", torch.float32).reshape(3, 3)
@@ -106,263 +134,123 @@ class TrainPath:
         c2w_nearest = g(c2w_nearest, "c2w_nearest", torch.float32).reshape(-1, 4, 4)
         campos_nearest = g(campos_nearest, "campos_nearest", torch.float32).reshape(-1, 3)
         intrinsic_nearest = g(intrinsic_nearest, "intrinsic_nearest", torch.float32).reshape(3, 3)
-        w2c_nearest = torch.inverse(c2w_nearest).contiguous()
         dev = raydir.device
+        if int(opt.K) != 8 or cloud.F != 32:
+            raise HnrError("the training path is built for K = 8 neighbours and 32 point features (got K=%d, F=%d)" % (opt.K, cloud.F))
+        R, SR, K = raydir.shape[0], int(opt.SR), 8
+        if R == 0:
+            raise HnrError("render_train: empty ray batch")
         grid, hp = r.querier._grid_for(cloud.xyz[None])
         if tmid is None:
-            tmid = r.querier._tmid_for(float(near), float(far), opt.z_depth_dim, raydir.shape[0], dev)
-        qres = Q.march_query(grid, campos, raydir, tmid, opt.SR, opt.K, np.float32(hp[0] ** 2), opt.kernel_size, pad=True)
-        pidx, loc_w, counts, work = qres["sample_pidx"], qres["sample_loc_w"], qres["counts"], qres["work"]
-        R, SR, K = pidx.shape
-        st, p = _lib.stream, _lib.ptr
-        pk = self.agg.packed()
-        sl = pk["slope"]
-        S = _Saved()
-        S.cloud, S.qres, S.raydir, S.campos, S.camrot, S.bg = cloud, qres, raydir, campos, camrot, bg_color
-        S.w2c, S.Kn, S.campos_n = w2c_nearest, intrinsic_nearest, campos_nearest
-        S.R, S.SR, S.K = R, SR, K
-        decoded = torch.zeros((R, SR, 4), dtype=torch.float32, device=dev)
-        S.decoded = decoded
-        w_out = torch.zeros((R, SR, K), dtype=torch.float32, device=dev)
-        c_out = cloud.conf[0].clamp(0.0001, 1.0).expand(R, SR, K).contiguous()
-        S.w_out = w_out
-        c = counts.cpu()
-        n_valid, n_rows = int(c[CNT["SAMPLES_VALID"]]), int(c[CNT["NEIGHBOURS"]])
-        S.n_valid, S.n_rows = n_valid, n_rows
-        # ray_drop: explicit [R] flags (a rank's slice of the batch-wide drop pattern when the batch is sharded over GPUs)
-        S.ray_drop = ray_drop_flags(opt, qres["ray_mask"]) if ray_drop is None else \
-            (_lib.require_gpu(ray_drop, "ray_drop", torch.uint8).reshape(-1) & (qres["ray_mask"] > 0).to(torch.uint8)).contiguous()
+            tmid = r.querier._tmid_for(float(near), float(far), opt.z_depth_dim, R, dev)
+        tmid = g(tmid, "tmid", torch.float32)
+        no_views = getattr(opt, "use_nearest", 4) == 0        # scene241.sh: image branch off, merged = 0 (point_aggregators.py:1257-1258)
         img = g(images_nearest, "images_nearest", torch.float32)
         if img.dim() == 5:
             img = img[0]
-        S.img = img
-        V, H, W = img.shape[0], img.shape[1], img.shape[2]
-        S.V, S.H, S.W = V, H, W
-        S.no_views = getattr(opt, "use_nearest", 4) == 0        # scene241.sh: image branch off, merged = 0 (point_aggregators.py:1257-1258)
+        V, H, W = (0, 0, 0) if no_views else (int(img.shape[0]), int(img.shape[1]), int(img.shape[2]))
+        S = _Saved()
+        prm = _lib.TrainParams()
+        prm.R, prm.SR, prm.K, prm.D = R, SR, K, int(tmid.shape[-1])
+        prm.tmid_stride = 0 if tmid.dim() == 1 else int(tmid.shape[1])
+        for i in range(3):
+            prm.kernel_size[i] = int(opt.kernel_size[i])
+        prm.radius2, prm.vsize_z = float(np.float32(hp[0] ** 2)), float(np.float32(opt.vsize[2]))
+        prm.raydist_mode_unit = int(getattr(opt, "raydist_mode_unit", 0) > 0)
+        prm.V, prm.H, prm.W = V, H, W
+        prm.n_points = int(cloud.xyz.shape[0])
+        prm.cap_samples = int(self.cap_samples) if self.cap_samples else R * SR
+        prm.knn_order = 0
+        prm.slope = float(self.agg.block1[1].negative_slope)
+        nbytes = int(L.hnr_render_train_workspace_bytes(ctypes.byref(prm)))
+        if nbytes < 0:
+            raise HnrError("hnr_render_train_workspace_bytes: %s" % L.hnr_last_error().decode("utf-8", "replace"))
+        free, _total = torch.cuda.mem_get_info(dev)
+        cached = torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+        if nbytes > 0.9 * (free + cached):
+            raise HnrError("render_train: the workspace for %d rays x SR %d (%.1f GB) does not fit the %.1f GB that are free; set TrainPath.cap_samples to the "
+                           "number of valid shading samples a batch can produce" % (R, SR, nbytes / 1e9, (free + cached) / 1e9))
+        ws = torch.empty((nbytes + 256,), dtype=torch.uint8, device=dev)
+        off = (-ws.data_ptr()) % 256
+        # parameters as contiguous fp32 tensors under the reference's names (views of the nn.Parameters)
+        wt = {n: g(q.detach(), n, torch.float32) for n, q in self.agg.named_parameters() if n in _SLOTS}
+        S.wt, S.weights = wt, _fill_weights(wt)
+        S.cloud_t = (cloud.xyz, cloud.emb, cloud.conf, cloud.dir, cloud.color)
+        S.cl = _lib.TrainCloud(p(cloud.xyz), p(cloud.emb), p(cloud.conf), p(cloud.dir), p(cloud.color))
+        S.cam_t = (campos, camrot, raydir, tmid, bg_color)
+        S.cam = _lib.RenderCamera(p(campos), p(camrot), p(raydir), p(tmid), p(bg_color))
+        S.vw, S.vw_t = None, None
+        if V > 0:
+            w2c = torch.inverse(c2w_nearest).contiguous()          # 4x4 plumbing op (neural_points_volumetric_model.py:250)
+            fw = None if frame_weight is None else g(frame_weight, "frame_weight", torch.float32).reshape(-1)
+            S.vw_t = (w2c, intrinsic_nearest, campos_nearest, img, fw)
+            S.vw = _lib.TrainViews(p(w2c), p(intrinsic_nearest), p(campos_nearest), p(img), p(fw) if fw is not None else None)
+        lut = flags = None
+        mode = _drop_mode(opt)
+        if ray_drop is not None:
+            # explicit [R] flags (a rank's slice of the batch-wide drop pattern when the batch is sharded over GPUs)
+            flags = g(ray_drop, "ray_drop", torch.uint8).reshape(-1)
+        elif mode == "patch" and V > 0:
+            lut = drop_lut(opt, R, dev)
+        elif mode == "random" and V > 0:
+            # the random subset needs the ray mask first: one extra query launch (no host read), then explicit flags
+            q0 = Q.march_query(grid, campos, raydir, tmid, SR, K, np.float32(hp[0] ** 2), opt.kernel_size, pad=True)
+            flags = ray_drop_flags(opt, q0["ray_mask"])
+        col, opa, isbg, bw = _f32((R, 3), dev), _f32((R, SR), dev), _f32((R,), dev), _f32((R, SR), dev)
+        mask = torch.empty((R,), dtype=torch.int8, device=dev)
+        decoded = _f32((R, SR, 4), dev)
+        pidx = torch.empty((R, SR, K), dtype=torch.int32, device=dev)
+        loc = _f32((R, SR, 3), dev)
+        nsamp = torch.empty((R,), dtype=torch.int32, device=dev)
+        counts = torch.empty((_lib.NCOUNTS,), dtype=torch.int64, device=dev)
+        status = torch.empty((2,), dtype=torch.int32, device=dev)
+        w_out, c_out = _f32((R, SR, K), dev), _f32((R, SR, K), dev)
+        S.out = _lib.RenderOutputs(p(col), p(opa), p(isbg), p(bw), p(mask), p(decoded), p(pidx), p(loc), p(nsamp), p(counts), p(status), p(w_out), p(c_out), None)
+        S.prm, S.ws, S.ws_ptr, S.nbytes, S.dev = prm, ws, ctypes.c_void_p(ws.data_ptr() + off), nbytes, dev
+        S.R, S.SR, S.K, S.V, S.no_views = R, SR, K, V, no_views
         with torch.cuda.device(dev):
-            if n_valid > 0 and not S.no_views:
-                # reference-view pyramid (activations kept for the conv backward)
-                fm = torch.empty((V, H, W, 48), dtype=torch.float32, device=dev)
-                S.fm_scratch = torch.empty((max(int(L.hnr_image_features_scratch_elems(V, H, W)), 1),), dtype=torch.float32, device=dev)
-                wp = (ctypes.c_void_p * 6)(*[t.data_ptr() for t in pk["conv_w"]])
-                bp = (ctypes.c_void_p * 6)(*[t.data_ptr() for t in pk["conv_b"]])
-                _lib.check(L.hnr_image_features(p(img), V, H, W, wp, bp, sl, p(S.fm_scratch), p(fm), st()), "hnr_image_features")
-            if n_valid > 0:
-                S.vs_item, S.vs_off, S.vs_cnt = _i32(n_valid, dev), _i32(n_valid, dev), _i32(n_valid, dev)
-                scratch = _i32(2 * ((R * SR + 1023) // 1024) + 2, dev)
-                overflow = torch.zeros(1, dtype=torch.int32, device=dev)
-                _lib.check(L.hnr_sample_plan(p(work), p(pidx), p(counts), K, R * SR, p(S.vs_item), p(S.vs_off), p(S.vs_cnt), n_valid,
-                                             n_rows, p(scratch), p(overflow), st()), "hnr_sample_plan")
-                S.Xd, S.X3, S.wagg = _f32((n_rows, 64), dev), _f32((n_rows, 264), dev), _f32((n_rows,), dev)
-                S.row_pid = _i32(n_rows, dev)
-                _lib.check(L.hnr_gather_rows(p(cloud.xyz), p(cloud.emb), p(cloud.conf), p(cloud.dir), p(cloud.color), cloud.F,
-                                             p(pidx), p(loc_w), p(raydir), p(campos), p(camrot), p(S.vs_item), p(S.vs_off), p(S.vs_cnt),
-                                             p(counts), SR, K, n_valid, p(S.Xd), 64, p(S.X3), 264, p(S.wagg), p(w_out), p(c_out),
-                                             p(S.row_pid), st()), "hnr_gather_rows")
-                # the points this batch touches: only their rows of the per-point table are computed
-                N = cloud.xyz.shape[0]
-                cap_u = min(n_rows, N)
-                S.uidx, S.ulist, S.row_u = _i32(N, dev), _i32(cap_u, dev), _i32(n_rows, dev)
-                ucount = torch.zeros(1, dtype=torch.int32, device=dev)
-                scan_scratch = _i32((N + 1023) // 1024 + 1, dev)
-                _lib.check(L.hnr_unique_points(p(S.row_pid), n_rows, N, p(S.uidx), p(S.ulist), cap_u, p(S.row_u), p(ucount),
-                                               p(scan_scratch), st()), "hnr_unique_points")
-                S.U = int(ucount.item())
-                Tu, S.E = self.agg.point_table(cloud.emb, ids=S.ulist, n_ids=S.U, want_rows=True)
-                S.H1 = pk["b1_dist"].gather_add(S.Xd, Tu, S.row_u, act=True, slope=sl, K=60)
-                if getattr(r, "dense", "f32") == "bf16x3":                           # the forward's 256-wide layers as in inference (exactly split bf16 operands)
-                    ps = self.agg.packed_split()
-                    l12, l30, l32 = ps["b1_2"], ps["b3_0"], ps["b3_2"]
-                else:
-                    l12, l30, l32 = pk["b1"][1], pk["b3"][0], pk["b3"][1]
-                l12(S.H1, out=S.X3, act=True, slope=sl)                              # H2 into X3[:, :256]
-                S.H3 = l30(S.X3, act=True, slope=sl, K=263)
-                S.H4 = l32(S.H3, act=True, slope=sl)
-                S.X5, S.sigma = _f32((n_valid, 280), dev), _f32((n_valid,), dev)
-                _lib.check(L.hnr_ksum(p(S.H4), 256, p(S.wagg), p(pk["alpha_w"]), p(pk["alpha_b"]), p(S.vs_item), p(S.vs_off), p(S.vs_cnt),
-                                      p(raydir), p(counts), SR, n_valid, p(S.X5), 280, p(S.sigma), st()), "hnr_ksum")
-                S.T1 = pk["cf"][0](S.X5, act=True, slope=sl)
-                S.T2 = pk["cf"][1](S.T1, act=True, slope=sl)
-                S.CF = pk["cf"][2](S.T2, act=True, slope=sl)
-                if S.no_views:
-                    S.X7 = torch.zeros((n_valid, 92), dtype=torch.float32, device=dev)
-                    S.X7[:, :45] = S.CF[:, :45]
-                    S.fw = None
-                else:
-                    S.X6, S.vmask, S.row_s = _f32((V * n_valid, 48), dev), _f32((V * n_valid,), dev), _i32(V * n_valid, dev)
-                    _lib.check(L.hnr_proj_rows(p(loc_w), p(S.vs_item), p(counts), p(w2c_nearest), p(intrinsic_nearest), p(campos),
-                                               p(campos_nearest), p(fm), V, H, W, p(S.CF), 128, n_valid, p(S.X6), 48, p(S.vmask),
-                                               p(S.row_s), st()), "hnr_proj_rows")
-                    del fm
-                    pre = pk["mw0_cf"](S.CF, act=False)
-                    S.M1 = pk["mw0_fd"].gather_add(S.X6, pre, S.row_s, act=True, slope=sl)
-                    S.M2 = pk["mw"][1](S.M1, act=True, slope=sl)
-                    S.M3 = pk["mw"][2](S.M2, act=True, slope=sl)
-                    S.X7 = _f32((n_valid, 92), dev)
-                    S.fw = None if frame_weight is None else g(frame_weight, "frame_weight", torch.float32).reshape(-1)
-                    _lib.check(L.hnr_merge(p(S.X6), 48, p(S.M3), 64, p(pk["mw_last_w"]), p(pk["mw_last_b"]), p(S.vmask),
-                                           p(S.fw) if S.fw is not None else None, p(S.CF), 128, p(counts), V, n_valid, p(S.X7), 92,
-                                           p(S.ray_drop) if S.ray_drop is not None else None, p(S.vs_item), SR, st()), "hnr_merge")
-                S.Y1 = pk["mx"][0](S.X7, out=_f32((n_valid, 48), dev), act=True, slope=sl, K=90)
-                S.Y2 = pk["mx"][1](S.Y1, out=_f32((n_valid, 48), dev), act=True, slope=sl, K=45)
-                S.Y3 = pk["mx"][2](S.Y2, out=_f32((n_valid, 48), dev), act=False, K=45)
-                _lib.check(L.hnr_final_color(p(S.Y3), 48, p(S.CF), 128, p(pk["fin_w"]), p(pk["fin_b"]), p(S.sigma), p(S.vs_item),
-                                             p(counts), n_valid, p(decoded), st()), "hnr_final_color")
-                if int(overflow.item()) != 0:
-                    raise HnrError("hnr_sample_plan: row buffers too small (internal sizing error)")
-        comp = r.composite(decoded, qres, campos, camrot, bg_color, want_blend=True)
-        out = dict(comp)
-        out.update(ray_mask=qres["ray_mask"], decoded=decoded, sample_pidx=pidx, sample_loc_w=loc_w, ray_nsamp=qres["ray_nsamp"],
-                   counts=counts, weight=w_out, conf_coefficient=c_out)
+            _lib.check(L.hnr_render_train_forward(grid.handle, ctypes.byref(prm), ctypes.byref(S.cl), ctypes.byref(S.weights), ctypes.byref(S.cam),
+                                                  ctypes.byref(S.vw) if S.vw is not None else None, p(lut) if lut is not None else None,
+                                                  p(flags) if flags is not None else None, S.ws_ptr, nbytes, ctypes.byref(S.out), _lib.stream()),
+                       "hnr_render_train_forward")
+        S.keep = (lut, flags, grid)
+        out = dict(coarse_raycolor=col, coarse_point_opacity=opa, coarse_is_background=isbg, blend_weight=bw, ray_mask=mask, decoded=decoded,
+                   sample_pidx=pidx, sample_loc_w=loc, ray_nsamp=nsamp, counts=counts, status=status, weight=w_out, conf_coefficient=c_out)
+        S.outs = out
         return out, S
+
+    @staticmethod
+    def check_status(out):
+        """Reads the forward's status word (a host synchronisation): raises when the workspace capacity was exceeded."""
+        st = out["status"].cpu()
+        if int(st[0]) != 0:
+            raise HnrError("render_train: %d valid shading samples exceed the workspace capacity (TrainPath.cap_samples); the extra ones were dropped" % int(st[1]))
 
     # ---------------------------------------------------------------------------------------------- backward
     def backward(self, S, g_raycolor, g_conf_out=None):
         """Returns (point grads dict, aggregator grads dict keyed by parameter name)."""
         L = _lib.lib()
-        a, pk, t = self.agg, self.agg.packed(), self.packed_t()
-        sl = pk["slope"]
-        dev = S.raydir.device
-        cloud, qres = S.cloud, S.qres
-        R, SR, K, V = S.R, S.SR, S.K, S.V
-        nS, M = S.n_valid, S.n_rows
-        N = cloud.xyz.shape[0]
-        st, p = _lib.stream, _lib.ptr
-        z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
-        pg = dict(points_embeding=z(N, cloud.F), points_conf=z(N), points_dir=z(N, 3), points_color=z(N, 3))
-        ag = {}
-        names = dict(a.named_parameters())
-        for k, prm in names.items():
-            skip = ("color_branch.", "learn_blur_kernel")         # unused head / modules the training shell runs itself
-            if S.no_views:
-                skip += ("aux_block_", "aux_merge_weight_block.")    # image branch off: like unused parameters in the reference, no gradient
-            if not k.startswith(skip):
-                ag[k] = torch.zeros_like(prm, dtype=torch.float32)
+        dev, p = S.dev, _lib.ptr
+        N = int(S.cloud_t[0].shape[0])
+        g_raycolor = _lib.require_gpu(g_raycolor, "grad coarse_raycolor", torch.float32).reshape(S.R, 3)
         if g_conf_out is not None:
-            g_conf_out = _lib.require_gpu(g_conf_out, "grad conf_coefficient", torch.float32).reshape(R, SR, K)
-            # empty slots read point 0 through the index clamp (neural_points.py:711): their gradient lands on conf[0]
-            pg["points_conf"][0] += (g_conf_out * (qres["sample_pidx"] < 0)).sum()
-        if nS == 0:
-            return pg, ag
-        g_raycolor = _lib.require_gpu(g_raycolor, "grad coarse_raycolor", torch.float32).reshape(R, 3)
-        pidx, loc_w, counts = qres["sample_pidx"], qres["sample_loc_w"], qres["counts"]
-
-        def lin_bwd(dZ, Xin, wname, bname, Nout, Kin, tw, prev=None, prev_cols=None, out=None, Kt=None):
-            """dW/db of layer y = x W^T + b from dZ [rows, Nout] and its input Xin [rows, Kin]; returns dZ_prev =
-            (dZ W) * LeakyReLU'(prev) (prev = stored activation of the producing layer) or the raw dZ W when prev is None."""
-            weight_grad(dZ, Xin, Nout, Kin, dW=ag[wname], db=ag[bname] if bname else None, accumulate=False, want_bias=bname is not None)
-            if tw is None:
-                return None
-            if prev is None:
-                return tw(dZ, out=out, act=False, K=Kt if Kt is not None else Nout)
-            return tw.side(dZ, prev, r_cols=prev_cols, r_mode=1, out=out, slope=sl, K=Kt if Kt is not None else Nout)
-
+            g_conf_out = _lib.require_gpu(g_conf_out, "grad conf_coefficient", torch.float32).reshape(S.R, S.SR, S.K)
+        pg = dict(points_embeding=_f32((N, 32), dev), points_conf=_f32((N,), dev), points_dir=_f32((N, 3), dev), points_color=_f32((N, 3), dev))
+        skip = ()
+        if S.no_views:
+            skip = ("aux_block_", "aux_merge_weight_block.")     # image branch off: like unused parameters in the reference, no gradient
+        names = [n for n in S.wt if not n.startswith(skip)]
+        sizes = [int(S.wt[n].numel()) for n in names]
+        offs = np.concatenate([[0], np.cumsum([(s + 63) // 64 * 64 for s in sizes])])
+        flat = _f32((int(offs[-1]),), dev)                        # one buffer for all weight gradients (256-byte aligned slices)
+        ag = {n: flat[int(offs[i]):int(offs[i]) + sizes[i]].view(S.wt[n].shape) for i, n in enumerate(names)}
+        gw = _fill_weights(ag)
+        cg = _lib.TrainCloudGrads(p(pg["points_embeding"]), p(pg["points_conf"]), p(pg["points_dir"]), p(pg["points_color"]))
         with torch.cuda.device(dev):
-            # 1. composite
-            g_dec = _f32((R, SR, 4), dev)
-            _lib.check(L.hnr_composite_bwd(p(S.decoded), p(loc_w), p(pidx), p(qres["ray_mask"]), None, p(S.campos), p(S.camrot),
-                                           p(S.bg), R, SR, K, float(np.float32(self.opt.vsize[2])),
-                                           int(getattr(self.opt, "raydist_mode_unit", 0) > 0), p(g_raycolor), p(g_dec), st()),
-                       "hnr_composite_bwd")
-            # 2. final colour
-            gY3, gCF, g_sigma = _f32((nS, 48), dev), _f32((nS, 128), dev), _f32((nS,), dev)
-            _lib.check(L.hnr_final_color_bwd(p(S.Y3), 48, p(S.CF), 128, p(pk["fin_w"]), p(pk["fin_b"]), p(S.vs_item), p(counts), nS,
-                                             p(g_dec), p(gY3), 48, p(gCF), 128, p(g_sigma), p(ag["color_final_block.0.weight"]),
-                                             p(ag["color_final_block.0.bias"]), st()), "hnr_final_color_bwd")
-            # 3. mix-up block (last layer has no activation)
-            dZ = lin_bwd(gY3, S.Y2, "color_mixup_block.4.weight", "color_mixup_block.4.bias", 45, 45, t["mx"][2], prev=S.Y2,
-                         out=_f32((nS, 48), dev))
-            dZ = lin_bwd(dZ, S.Y1, "color_mixup_block.2.weight", "color_mixup_block.2.bias", 45, 45, t["mx"][1], prev=S.Y1,
-                         out=_f32((nS, 48), dev))
-            gX7 = lin_bwd(dZ, S.X7, "color_mixup_block.0.weight", "color_mixup_block.0.bias", 45, 90, t["mx"][0], out=_f32((nS, 92), dev))
-            if S.no_views:
-                gCF[:, :45] += gX7[:, :45]                               # X7 = [colfeat[:45] | 0]
-            else:
-                # 4. merge
-                gF, gZ3 = _f32((V * nS, 48), dev), _f32((V * nS, 64), dev)
-                g_wl, g_bl = z(64), z(1)
-                _lib.check(L.hnr_merge_bwd(p(S.X6), 48, p(S.M3), 64, p(pk["mw_last_w"]), p(pk["mw_last_b"]), p(S.vmask),
-                                           p(S.fw) if S.fw is not None else None, p(counts), V, nS, sl,
-                                           p(S.ray_drop) if S.ray_drop is not None else None, p(S.vs_item), SR, p(gX7), 92, p(gF), 48,
-                                           p(gZ3), 64, p(gCF), 128, p(g_wl), p(g_bl), st()), "hnr_merge_bwd")
-                ag["aux_merge_weight_block.6.weight"].copy_(g_wl.view(1, 64))
-                ag["aux_merge_weight_block.6.bias"].copy_(g_bl)
-                # 5. merge-weight MLP (first layer split: [imgfeat45 | ddir3] per row, colour feature once per sample)
-                dZ = lin_bwd(gZ3, S.M2, "aux_merge_weight_block.4.weight", "aux_merge_weight_block.4.bias", 64, 64, t["mw"][2], prev=S.M2)
-                dZ1 = lin_bwd(dZ, S.M1, "aux_merge_weight_block.2.weight", "aux_merge_weight_block.2.bias", 64, 64, t["mw"][1], prev=S.M1)
-                G0 = ag["aux_merge_weight_block.0.weight"]                                # [64,176]
-                gWfd, _ = weight_grad(dZ1, S.X6, 64, 48, want_bias=False)
-                G0[:, :45].copy_(gWfd[:, :45])
-                G0[:, 173:176].copy_(gWfd[:, 45:48])
-                gpre = _f32((nS, 64), dev)
-                _lib.check(L.hnr_sum_views(p(dZ1), 64, V, nS, nS, 64, p(gpre), 64, st()), "hnr_sum_views")
-                weight_grad(gpre, S.CF, 64, 128, dW=G0[:, 45:173], db=ag["aux_merge_weight_block.0.bias"])
-                gX6 = t["mw0_fd"](dZ1, act=False, K=64)                                   # [V*S,48]
-                t["mw0_cf"].side(gpre, gCF, r_mode=0, out=gCF, act=False, K=64)           # gCF += gpre Wcf
-                del dZ, dZ1, gZ3
-                # 6. pixel gather + upsample + conv pyramid
-                g_pyr = torch.zeros_like(S.fm_scratch)
-                g_fm = z(V, S.H, S.W, 48)
-                if self._bbox0 is None or self._bbox_key != (V, S.H, S.W, dev):
-                    self._bbox0 = torch.tensor([[S.W, S.H, -1, -1]] * V, dtype=torch.int32, device=dev)
-                    self._bbox_key = (V, S.H, S.W, dev)
-                bbox = self._bbox0.clone()
-                sb = int(L.hnr_sort_rows_scratch_bytes(V * nS))
-                key_scratch, sort_scratch = _i32(3 * V * nS, dev), torch.empty((sb,), dtype=torch.uint8, device=dev)   # named: both must stay alive
-                _lib.check(L.hnr_proj_rows_bwd(p(loc_w), p(S.vs_item), p(counts), p(S.w2c), p(S.Kn), V, S.H, S.W, nS, p(gF), 48, p(gX6), 48,
-                                               p(g_fm), p(bbox), p(g_pyr), p(key_scratch), p(sort_scratch), sb, st()), "hnr_proj_rows_bwd")
-                del g_fm
-                conv_names = [("aux_block_s%d.%d" % (lvl, i)) for lvl in (1, 2, 3) for i in (0, 2)]
-                wp = (ctypes.c_void_p * 6)(*[tt.data_ptr() for tt in pk["conv_w"]])
-                gw = (ctypes.c_void_p * 6)(*[ag[n + ".weight"].data_ptr() for n in conv_names])
-                gb = (ctypes.c_void_p * 6)(*[ag[n + ".bias"].data_ptr() for n in conv_names])
-                _lib.check(L.hnr_image_features_bwd(p(S.img), V, S.H, S.W, wp, sl, p(S.fm_scratch), p(g_pyr), gw, gb, st()),
-                           "hnr_image_features_bwd")
-                del g_pyr, gF, gX6
-            # 7. colour-feature branch
-            _lib.check(L.hnr_dleaky(p(gCF), 128, p(S.CF), 128, nS, 128, sl, st()), "hnr_dleaky")
-            dZ = lin_bwd(gCF, S.T2, "color_feature_branch.4.weight", "color_feature_branch.4.bias", 128, 128, t["cf"][2], prev=S.T2)
-            dZ = lin_bwd(dZ, S.T1, "color_feature_branch.2.weight", "color_feature_branch.2.bias", 128, 128, t["cf"][1], prev=S.T1)
-            gX5 = lin_bwd(dZ, S.X5, "color_feature_branch.0.weight", "color_feature_branch.0.bias", 128, 280, t["cf"][0])
-            # 8. K-sum + alpha branch
-            gZ4, g_wagg = _f32((M, 256), dev), _f32((M,), dev)
-            g_aw, g_ab = z(256), z(1)
-            _lib.check(L.hnr_ksum_bwd(p(S.H4), 256, p(S.wagg), p(pk["alpha_w"]), p(pk["alpha_b"]), p(S.vs_off), p(S.vs_cnt), p(counts), nS,
-                                      p(gX5), 280, p(g_sigma), sl, p(gZ4), 256, p(g_wagg), p(g_aw), p(g_ab), st()), "hnr_ksum_bwd")
-            ag["alpha_branch.0.weight"].copy_(g_aw.view(1, 256))
-            ag["alpha_branch.0.bias"].copy_(g_ab)
-            # 9. block3
-            dZ3 = lin_bwd(gZ4, S.H3, "block3.2.weight", "block3.2.bias", 256, 256, t["b3_1"], prev=S.H3)
-            del gZ4
-            gX3 = lin_bwd(dZ3, S.X3, "block3.0.weight", "block3.0.bias", 256, 263, t["b3_0"], prev=S.X3, prev_cols=256,
-                          out=_f32((M, 264), dev))
-            del dZ3
-            # rows -> touched point: sort the rows by touched-point index ONCE; both per-point reductions below then add a point's rows in
-            # that fixed order (one wave per point, no atomics): gradients are bit-identical run to run
-            sb = int(L.hnr_sort_rows_scratch_bytes(M))
-            ks, perm, sort_scratch = _i32(M, dev), _i32(M, dev), torch.empty((sb,), dtype=torch.uint8, device=dev)
-            _lib.check(L.hnr_sort_rows_by_key(p(S.row_u), M, p(ks), p(perm), p(sort_scratch), sb, st()), "hnr_sort_rows_by_key")
-            # 10. point colour / direction / confidence
-            G8, P8 = _f32((M, 8), dev), _f32((max(S.U, 1), 8), dev)
-            _lib.check(L.hnr_gather_rows_bwd_rows(p(pidx), p(S.raydir), p(S.vs_item), p(S.vs_off), p(S.vs_cnt), p(counts), SR, K, nS, p(gX3), 264,
-                                                  p(g_wagg), p(S.w_out), p(g_conf_out) if g_conf_out is not None else None, p(G8), st()),
-                       "hnr_gather_rows_bwd_rows")
-            _lib.check(L.hnr_segment_sum_rows_det(p(G8), 8, p(ks), p(perm), M, 8, S.U, None, p(P8), 8, 0, st()), "hnr_segment_sum_rows_det")
-            _lib.check(L.hnr_point_small_grads(p(P8), p(S.ulist), S.U, p(pg["points_conf"]), p(pg["points_dir"]), p(pg["points_color"]), st()),
-                       "hnr_point_small_grads")
-            # 11. block1 (first layer split: 60 distance columns per row + per-point table)
-            dZ2 = gX3[:, :256]
-            dZ1 = lin_bwd(dZ2, S.H1, "block1.2.weight", "block1.2.bias", 256, 256, t["b1_1"], prev=S.H1)
-            G1 = ag["block1.0.weight"]                                                # [256,284]
-            weight_grad(dZ1, S.Xd, 256, 60, dW=G1[:, 224:284], db=ag["block1.0.bias"])
-            gTu = _f32((max(S.U, 1), 256), dev)
-            _lib.check(L.hnr_segment_sum_rows_det(p(dZ1), 256, p(ks), p(perm), M, 256, S.U, None, p(gTu), 256, 0, st()), "hnr_segment_sum_rows_det")
-            if S.U > 0:
-                gTu = gTu[:S.U]
-                weight_grad(gTu, S.E, 256, 224, dW=G1[:, :224], want_bias=False)
-                gE = t["b1_point"](gTu, act=False, K=256)                             # [U,224]
-                _lib.check(L.hnr_point_rows_bwd(p(gE), 224, p(S.E), 224, p(S.ulist), S.U, cloud.F, p(pg["points_embeding"]), st()),
-                           "hnr_point_rows_bwd")
+            _lib.check(L.hnr_render_train_backward(ctypes.byref(S.prm), ctypes.byref(S.cl), ctypes.byref(S.weights), ctypes.byref(S.cam),
+                                                   ctypes.byref(S.vw) if S.vw is not None else None, S.ws_ptr, S.nbytes, ctypes.byref(S.out), p(g_raycolor),
+                                                   p(g_conf_out) if g_conf_out is not None else None, ctypes.byref(cg), ctypes.byref(gw), _lib.stream()),
+                       "hnr_render_train_backward")
         return pg, ag
 
 
@@ -388,7 +276,7 @@ class _RenderFn(torch.autograd.Function):
     def backward(ctx, g_col, g_cc):
         S = ctx.S
         if g_col is None:
-            g_col = torch.zeros((S.R, 3), dtype=torch.float32, device=S.raydir.device)
+            g_col = torch.zeros((S.R, 3), dtype=torch.float32, device=S.dev)
         pg, ag = ctx.path.backward(S, g_col.contiguous(), None if g_cc is None else g_cc.contiguous())
         es, cs, ds, ks = ctx.shapes
         grads = [None, None, pg["points_embeding"].reshape(es), pg["points_conf"].reshape(cs), pg["points_dir"].reshape(ds),

@@ -511,6 +511,8 @@ int hnr_sum_views(const float *d_in, int ldi, int V, int cap, int n_samples, int
  * arithmetic.  They replace what torch autograd runs for the nn.Linear (+ LeakyReLU) layers of PointAggregator.viewmlp in the reference's
  * train step (models/aggregators/point_aggregators.py:948, :972, :1037, :1199, :1292; loss.backward() at
  * models/mvs_points_volumetric_model.py:111-131).  Every row count is read on the DEVICE: rows = min(M_cap, *d_m) (d_m may be NULL).
+ * n_seg > 1: the rows are n_seg SEGMENTS of min(*d_m, seg_stride) rows each, segment v starting at physical row v * seg_stride -- the
+ * (view, sample) rows of hnr_proj_rows (row = v * cap_samples + s); n_seg = 1: plain rows.
  *   hnr_h2lin_pack   n_jobs <= 16 weight matrices -> kernel images, two launches for all of them.  Element (n, k) of job j is
  *                    d_W[j][n * rs[j] + k * cs[j]]: (rs, cs) = (ld, 1) packs an nn.Linear weight [N, K], (1, ld) its transpose (input
  *                    gradients: dX = dZ W is the layer "dZ (W^T)^T").  N <= 256, K <= 288; image bytes: hnr_h2lin_packed_bytes(K).
@@ -525,13 +527,13 @@ int hnr_sum_views(const float *d_in, int ldi, int V, int cap, int n_samples, int
 int64_t hnr_h2lin_packed_bytes(int K);
 int hnr_h2lin_pack(int n_jobs, const float *const *d_W, const int64_t *rs, const int64_t *cs, const int *N, const int *K,
                    const float *const *d_bias /*may be NULL*/, void *const *d_packed, void *stream);
-int hnr_h2lin(const float *d_A, int lda, int64_t M_cap, const int64_t *d_m, const void *d_packed, int N, int K, int mode, int act, float slope,
-              const float *d_side, int ld_side, float *d_C, int ldc, uint32_t *d_absmax, void *stream);
+int hnr_h2lin(const float *d_A, int lda, int64_t M_cap, const int64_t *d_m, int n_seg, int64_t seg_stride, const void *d_packed, int N, int K, int mode,
+              int act, float slope, const float *d_side, int ld_side, float *d_C, int ldc, uint32_t *d_absmax, void *stream);
 int64_t hnr_h2wgrad_scratch_bytes(int N, int K);
-int hnr_h2wgrad(const float *d_dZ, int ldz, const float *d_X, int ldx, int64_t M_cap, const int64_t *d_m, int N, int K,
+int hnr_h2wgrad(const float *d_dZ, int ldz, const float *d_X, int ldx, int64_t M_cap, const int64_t *d_m, int n_seg, int64_t seg_stride, int N, int K,
                 const uint32_t *d_absmax_z, const uint32_t *d_absmax_x, float *d_dW, int lddw, float *d_db, int accumulate,
                 void *d_scratch, void *stream);
-int hnr_absmax(const float *d_A, int lda, int64_t M_cap, const int64_t *d_m, int N, uint32_t *d_out, void *stream);
+int hnr_absmax(const float *d_A, int lda, int64_t M_cap, const int64_t *d_m, int n_seg, int64_t seg_stride, int N, uint32_t *d_out, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * The whole forward path in ONE call (csrc/render_forward.hip): one pass of NeuralPointsRayMarching.forward + fill_invalid
@@ -594,6 +596,51 @@ int64_t hnr_render_workspace_bytes(const hnr_render_params *p);
 int hnr_render_forward(const hnr_grid *grid, const hnr_render_params *p, const hnr_render_cloud *cloud, const hnr_render_weights *weights,
                        const hnr_render_camera *camera, const hnr_render_views *views, void *d_workspace, int64_t workspace_bytes,
                        const hnr_render_outputs *out, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * The TRAINING step of the path as two calls (csrc/render_train.hip): hnr_render_train_forward = one pass of NeuralPointsRayMarching.forward in
+ * train mode + fill_invalid (models/neural_points_volumetric_model.py:257-427, :87-126: jittered depths through cam->d_tmid with
+ * tmid_stride = D, query_point_indices_worldcoords.py:87; patch drop point_aggregators.py:1222-1237; straight-through conf clamp :1422-1424),
+ * keeping in the caller's workspace what the backward pass needs; hnr_render_train_backward = what loss.backward() makes torch autograd compute
+ * for it (models/mvs_points_volumetric_model.py:111-131; there is no custom autograd.Function in the reference): the gradients of
+ * points_embeding / points_conf / points_dir / points_color and of every aggregator parameter of the order-2 hybrid path, from the gradients of
+ * coarse_raycolor [R,3] and (optionally) conf_coefficient [R,SR,K].  Every launch is issued by the library on the caller's stream; every work
+ * size (valid samples, neighbour rows, touched points) is read from device counters; nothing is allocated, nothing is read back.
+ * K = 8, point_features_dim = 32.  The weights are the raw nn.Linear / nn.Conv2d tensors under the reference's names (their kernel images are
+ * re-packed inside each call: they change every step).  Weight gradients are OVERWRITTEN, point gradients too ([N,32] [N] [N,3] [N,3], zero
+ * outside the batch's points).  Per-point sums are formed in a fixed order: bit-identical gradients run to run.
+ *   d_drop_lut [R] u8 (optional): patch-drop pattern indexed by VALID-ray row (drop_patch_rays, point_aggregators.py:14-23, :1225-1233);
+ *   d_ray_drop [R] u8 (optional, wins): explicit per-ray flags (a rank's slice of a batch-wide pattern); both are ANDed with ray_mask.
+ * `out` as for hnr_render_forward (padded query outputs; d_blend_weight, d_weight, d_conf_coefficient required; stage_events ignored);
+ * d_status[0] = 1 when cap_samples was exceeded (R * SR always suffices). */
+typedef struct {
+    int   R, SR, K, D;
+    int   tmid_stride;
+    int   kernel_size[3];
+    float radius2, vsize_z;
+    int   raydist_mode_unit;
+    int   V, H, W;                /* reference views and their size (V = 0: use_nearest = 0, image branch off)             */
+    int   n_points;               /* N                                                                                    */
+    int   cap_samples;
+    int   knn_order;
+    float slope;                  /* LeakyReLU slope                                                                      */
+} hnr_train_params;
+typedef struct { const float *d_xyz, *d_emb, *d_conf, *d_dir, *d_color; } hnr_train_cloud;          /* [N,3] [N,32] [N] [N,3] [N,3] */
+typedef struct { float *d_emb, *d_conf, *d_dir, *d_color; } hnr_train_cloud_grads;
+typedef struct {   /* aggregator.{block1.0, block1.2, block3.0, block3.2, alpha_branch.0, color_feature_branch.{0,2,4}, aux_merge_weight_block.{0,2,4,6},
+                      color_mixup_block.{0,2,4}, color_final_block.0, aux_block_s1.{0,2}, s2.{0,2}, s3.{0,2}} .weight / .bias (device pointers) */
+    const float *block1_0_w, *block1_0_b, *block1_2_w, *block1_2_b, *block3_0_w, *block3_0_b, *block3_2_w, *block3_2_b, *alpha_w, *alpha_b;
+    const float *cf_w[3], *cf_b[3], *mw_w[4], *mw_b[4], *mx_w[3], *mx_b[3], *fin_w, *fin_b, *conv_w[6], *conv_b[6];
+} hnr_train_weights;           /* the gradient block handed to hnr_render_train_backward has the same layout (its buffers are written)      */
+typedef struct { const float *d_w2c, *d_intrinsic, *d_campos_nearest, *d_images /*[V,H,W,3]*/, *d_frame_w /*optional [V]*/; } hnr_train_views;
+int64_t hnr_render_train_workspace_bytes(const hnr_train_params *p);
+int hnr_render_train_forward(const hnr_grid *grid, const hnr_train_params *p, const hnr_train_cloud *cloud, const hnr_train_weights *weights,
+                             const hnr_render_camera *camera, const hnr_train_views *views, const uint8_t *d_drop_lut, const uint8_t *d_ray_drop,
+                             void *d_workspace, int64_t workspace_bytes, const hnr_render_outputs *out, void *stream);
+int hnr_render_train_backward(const hnr_train_params *p, const hnr_train_cloud *cloud, const hnr_train_weights *weights, const hnr_render_camera *camera,
+                              const hnr_train_views *views, void *d_workspace, int64_t workspace_bytes, const hnr_render_outputs *forward_out,
+                              const float *d_g_raycolor, const float *d_g_conf_coefficient /*may be NULL*/, const hnr_train_cloud_grads *cloud_grads,
+                              const hnr_train_weights *weight_grads, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * "Next" row: hole probing, run/train_ft.py:527-549 (`probe_hole`) + :571-581 (`bloat_inds`).  Per probed frame: a cast

@@ -369,7 +369,9 @@ def test_ctypes_structs_have_the_layout_of_the_c_header(tmp_path):
         pytest.skip("no gcc")
     pairs = [("hnr_grid_params", _lib.GridParams), ("hnr_query_params", _lib.QueryParams), ("hnr_render_params", _lib.RenderParams),
              ("hnr_render_cloud", _lib.RenderCloud), ("hnr_render_weights", _lib.RenderWeights), ("hnr_render_camera", _lib.RenderCamera),
-             ("hnr_render_views", _lib.RenderViews), ("hnr_render_outputs", _lib.RenderOutputs)]
+             ("hnr_render_views", _lib.RenderViews), ("hnr_render_outputs", _lib.RenderOutputs), ("hnr_train_params", _lib.TrainParams),
+             ("hnr_train_cloud", _lib.TrainCloud), ("hnr_train_cloud_grads", _lib.TrainCloudGrads), ("hnr_train_weights", _lib.TrainWeights),
+             ("hnr_train_views", _lib.TrainViews)]
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "hnr.h"', 'int main(void) {']
     for cname, cls in pairs:
         lines.append('  printf("%s size %%zu\\n", sizeof(%s));' % (cname, cname))

@@ -59,7 +59,7 @@ def test_h2lin_matches_fp64(M, N, K, mode):
     mx = torch.zeros(1, dtype=torch.int32, device=dev)
     dm = torch.tensor([M], dtype=torch.int64, device=dev)
     slope = 0.01
-    _lib.check(L.hnr_h2lin(_lib.ptr(Ad), lda, M + 3, _lib.ptr(dm), _lib.ptr(img), N, K, mode, 1, slope, _lib.ptr(sd) if mode == 1 else None, ldc,
+    _lib.check(L.hnr_h2lin(_lib.ptr(Ad), lda, M + 3, _lib.ptr(dm), 1, 0, _lib.ptr(img), N, K, mode, 1, slope, _lib.ptr(sd) if mode == 1 else None, ldc,
                            _lib.ptr(C), ldc, _lib.ptr(mx), _lib.stream()), "hnr_h2lin")
     got = C.cpu().numpy().astype(np.float64)
     A64, W64 = A[:, :K].numpy().astype(np.float64), W.numpy().astype(np.float64)
@@ -95,15 +95,15 @@ def test_h2wgrad_matches_fp64(M, N, K):
     dm = torch.tensor([M], dtype=torch.int64, device=dev)
     mz = torch.zeros(1, dtype=torch.int32, device=dev)
     mx = torch.zeros(1, dtype=torch.int32, device=dev)
-    _lib.check(L.hnr_absmax(_lib.ptr(Zd), ldz, M + 5, _lib.ptr(dm), N, _lib.ptr(mz), _lib.stream()), "hnr_absmax")
-    _lib.check(L.hnr_absmax(_lib.ptr(Xd), ldx, M + 5, _lib.ptr(dm), K, _lib.ptr(mx), _lib.stream()), "hnr_absmax")
+    _lib.check(L.hnr_absmax(_lib.ptr(Zd), ldz, M + 5, _lib.ptr(dm), 1, 0, N, _lib.ptr(mz), _lib.stream()), "hnr_absmax")
+    _lib.check(L.hnr_absmax(_lib.ptr(Xd), ldx, M + 5, _lib.ptr(dm), 1, 0, K, _lib.ptr(mx), _lib.stream()), "hnr_absmax")
     zmax = float(np.frombuffer(np.int32(mz.item()).tobytes(), dtype=np.float32)[0])
     assert zmax == float(Z[:M, :N].abs().max())
     scratch = torch.empty((int(L.hnr_h2wgrad_scratch_bytes(N, K)),), dtype=torch.uint8, device=dev)
     dW = torch.full((N, K + 2), 5.0, device=dev)
     db = torch.full((N,), 5.0, device=dev)
     for acc in (0, 1):
-        _lib.check(L.hnr_h2wgrad(_lib.ptr(Zd), ldz, _lib.ptr(Xd), ldx, M + 5, _lib.ptr(dm), N, K, _lib.ptr(mz), _lib.ptr(mx), _lib.ptr(dW), K + 2,
+        _lib.check(L.hnr_h2wgrad(_lib.ptr(Zd), ldz, _lib.ptr(Xd), ldx, M + 5, _lib.ptr(dm), 1, 0, N, K, _lib.ptr(mz), _lib.ptr(mx), _lib.ptr(dW), K + 2,
                                  _lib.ptr(db), acc, _lib.ptr(scratch), _lib.stream()), "hnr_h2wgrad")
     Z64, X64 = Z[:M, :N].numpy().astype(np.float64), X[:M, :K].numpy().astype(np.float64)
     ref, mag = Z64.T @ X64, np.abs(Z64).T @ np.abs(X64)
@@ -131,7 +131,7 @@ def test_h2wgrad_is_bit_identical_run_to_run_and_zero_rows_are_inert():
     outs = []
     for _ in range(2):
         dW, db = torch.empty((N, K), device=dev), torch.empty((N,), device=dev)
-        _lib.check(L.hnr_h2wgrad(_lib.ptr(Zd), N, _lib.ptr(Xd), K, M, None, N, K, _lib.ptr(one), _lib.ptr(big), _lib.ptr(dW), K, _lib.ptr(db), 0,
+        _lib.check(L.hnr_h2wgrad(_lib.ptr(Zd), N, _lib.ptr(Xd), K, M, None, 1, 0, N, K, _lib.ptr(one), _lib.ptr(big), _lib.ptr(dW), K, _lib.ptr(db), 0,
                                  _lib.ptr(scratch), _lib.stream()), "hnr_h2wgrad")
         outs.append((dW.cpu().numpy(), db.cpu().numpy()))
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])

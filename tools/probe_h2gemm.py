@@ -31,7 +31,7 @@ for M, N, K in [(306000, 256, 256), (306000, 256, 264), (306000, 256, 64), (1000
     scratch = torch.empty((int(L.hnr_h2wgrad_scratch_bytes(N, min(K, 287))),), dtype=torch.uint8, device=dev)
     dW, db = torch.empty((N, K), device=dev), torch.empty((N,), device=dev)
     Kw = min(K, 287)
-    ms = timed(lambda: _lib.check(L.hnr_h2wgrad(_lib.ptr(Z), ldz, _lib.ptr(X), ldx, M, None, N, Kw, _lib.ptr(mz), _lib.ptr(mz), _lib.ptr(dW), K, _lib.ptr(db), 0,
+    ms = timed(lambda: _lib.check(L.hnr_h2wgrad(_lib.ptr(Z), ldz, _lib.ptr(X), ldx, M, None, 1, 0, N, Kw, _lib.ptr(mz), _lib.ptr(mz), _lib.ptr(dW), K, _lib.ptr(db), 0,
                                                _lib.ptr(scratch), _lib.stream()), "wgrad"))
     print("wgrad  M=%6d N=%3d K=%3d  %.3f ms  %.1f TFLOP/s(fp32-equivalent)  %.2f TB/s" % (M, N, K, ms, 2.0 * M * N * K / ms / 1e9, M * (ldz + ldx) * 4 / ms / 1e9))
     if K in (256, 224, 128, 64, 48) or K <= 48:
@@ -40,6 +40,6 @@ for M, N, K in [(306000, 256, 256), (306000, 256, 264), (306000, 256, 64), (1000
         C = torch.empty((M, ldz), device=dev)
         side = torch.randn((M, ldz), device=dev)
         for mode in (0, 1):
-            ms = timed(lambda: _lib.check(L.hnr_h2lin(_lib.ptr(X), ldx, M, None, _lib.ptr(img), N, K, mode, 1, 0.01, _lib.ptr(side), ldz, _lib.ptr(C), ldz, None,
+            ms = timed(lambda: _lib.check(L.hnr_h2lin(_lib.ptr(X), ldx, M, None, 1, 0, _lib.ptr(img), N, K, mode, 1, 0.01, _lib.ptr(side), ldz, _lib.ptr(C), ldz, None,
                                                      _lib.stream()), "h2lin"))
             print("h2lin%d M=%6d N=%3d K=%3d  %.3f ms  %.1f TFLOP/s(fp32-equivalent)  %.2f TB/s" % (mode, M, N, K, ms, 2.0 * M * N * K / ms / 1e9, M * (ldz * (1 + mode) + ldx) * 4 / ms / 1e9))
