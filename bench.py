@@ -246,31 +246,44 @@ def train_leg(args, sc, opt, agg, cloud, rnd, cam, dev, steps=5, warmup=2):
         fwd = sum(e[0].elapsed_time(e[1]) for e in evs) / steps
         bwd = sum(e[1].elapsed_time(e[2]) for e in evs) / steps
         c = out["counts"].cpu().numpy()
-        # roofline of the training step's dominant kernel family: the weight-gradient GEMMs dW = dZ^T X (linear_wgrad_kernel, fp32 MFMA),
-        # bracketed with HIP events on the launch stream in one extra step
-        import hybridneuralrendering_amd.train as TR
-        orig, rec = TR.weight_grad, []
-        def timed_wgrad(dZ, X, N, K, *a, **k):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(); r = orig(dZ, X, N, K, *a, **k); e1.record()
-            rec.append((e0, e1, 2.0 * dZ.shape[0] * N * K, dZ.shape[0] * (N + K) * 4.0))
-            return r
-        TR.weight_grad = timed_wgrad
-        try:
-            one()
-            torch.cuda.synchronize()
-        finally:
-            TR.weight_grad = orig
-        ms_w = sum(e0.elapsed_time(e1) for e0, e1, _, _ in rec)
-        fl_w = sum(f for _, _, f, _ in rec)
-        roof_t = dict(kernel="linear_wgrad_kernel + linear_wgrad_reduce_kernel (dW = dZ^T X of every nn.Linear, %d launches per step)" % len(rec), bound="mfma",
-                      achieved=round(fl_w / (ms_w * 1e-3) / 1e12, 2), peak=F32_MFMA_PEAK_TF, unit="TFLOP/s",
-                      frac=round(fl_w / (ms_w * 1e-3) / 1e12 / F32_MFMA_PEAK_TF, 4), traffic=None, flops_per_step=fl_w,
-                      algorithmic_bytes_per_step=sum(b for _, _, _, b in rec), ms_per_step=round(ms_w, 3),
-                      note="v_mfma_f32_32x32x2_f32 (exact fp32); achieved = 2 M N K of all weight-gradient GEMMs of the step / their HIP-event time") if ms_w > 0 else None
+        # stage times of the two library calls (HIP events recorded by the library at its stage boundaries, one extra step)
+        path.timers = {}
+        one()
+        torch.cuda.synchronize()
+        stage = {("fwd." + k): round(v, 4) for k, v in path.timers["fwd"][0].elapsed_ms().items()}
+        stage.update({("bwd." + k): round(v, 4) for k, v in path.timers["bwd"][0].elapsed_ms().items()})
+        path.timers = None
+        # roofline of the step's dominant kernel: the weight-gradient GEMM dW = dZ^T X of a 256 x 256 per-neighbour layer (hnr_h2wgrad, five such
+        # launches per step), timed alone with HIP events on tensors of the step's row count (8 row slots per valid sample)
+        from hybridneuralrendering_amd import _lib
+        Lh = _lib.lib()
+        M8 = 8 * int(c[6])
+        Zt, Xt = torch.randn((max(M8, 1), 256), device=dev), torch.randn((max(M8, 1), 256), device=dev)
+        mz = torch.tensor([np.float32(8.0).view(np.int32)], dtype=torch.int32, device=dev)
+        scr = torch.empty((int(Lh.hnr_h2wgrad_scratch_bytes(256, 256)),), dtype=torch.uint8, device=dev)
+        dW, db = torch.empty((256, 256), device=dev), torch.empty((256,), device=dev)
+        def wg():
+            _lib.check(Lh.hnr_h2wgrad(_lib.ptr(Zt), 256, _lib.ptr(Xt), 256, M8, None, 1, 0, 256, 256, _lib.ptr(mz), _lib.ptr(mz), _lib.ptr(dW), 256, _lib.ptr(db), 0,
+                                      _lib.ptr(scr), _lib.stream()), "hnr_h2wgrad")
+        for _ in range(3):
+            wg()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            wg()
+        e1.record(); torch.cuda.synchronize()
+        ms_w = e0.elapsed_time(e1) / 10
+        issued = 3.0 * 2.0 * M8 * 256 * 288                                  # 3 fp16 MFMAs per fp32 product, K + 1 (bias column) padded to 9 tiles of 32
+        roof_t = dict(kernel="h2wgrad_kernel<8,9,8,1> + reduce (dW = dZ^T X, db of one 256 x 256 per-neighbour layer; M = %d row slots)" % M8, bound="hbm",
+                      achieved=round(M8 * 2048.0 / (ms_w * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(M8 * 2048.0 / (ms_w * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                      traffic=None, avg_launch_ms=round(ms_w, 4), algorithmic_bytes_per_launch=int(M8 * 2048),
+                      mfma_tflops_issued=round(issued / (ms_w * 1e-3) / 1e12, 1), fp32_equivalent_tflops=round(2.0 * M8 * 256 * 256 / (ms_w * 1e-3) / 1e12, 1),
+                      note="algorithmic bytes = the two fp32 operands read once (2 KiB per row); the f16x2 MFMA work of this shape (3 x 2 M N K) would take "
+                           "%.3f ms at the 2.5 PFLOP/s peak, the operand stream %.3f ms at 8 TB/s: HBM is the nearer roof" % (issued / 2.5e15 * 1e3, M8 * 2048.0 / 8e12 * 1e3)) if M8 > 0 else None
         return dict(workload="C3: 56x56 = %d rays, fwd (train mode) + bwd, shipped loss" % raydir.shape[0], ms_per_step=round(dt * 1e3, 3),
                     rays_per_s=round(raydir.shape[0] / dt, 1), fwd_ms=round(fwd, 3), loss_bwd_ms=round(bwd, 3),
-                    neighbour_rows=int(c[3]), valid_samples=int(c[6]), steps=steps, roofline_train=roof_t)
+                    neighbour_rows=int(c[3]), valid_samples=int(c[6]), steps=steps, entry="hnr_render_train_forward + hnr_render_train_backward (two library calls per step, no host read)",
+                    stage_ms=stage, roofline_train=roof_t)
     finally:
         opt.is_train = old
         for prm in agg.parameters():

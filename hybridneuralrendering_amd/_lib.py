@@ -95,6 +95,10 @@ class TrainViews(ctypes.Structure):
 RENDER_STAGES = ("query", "plan_gather", "chain_gather", "chain", "mlp_colorfeat", "proj_rows", "mlp_merge", "merge", "mlp_mixup", "final_color",
                  "composite")
 
+# stage boundaries of the two training calls (their stage_events hook: one more event than stages)
+TRAIN_FWD_STAGES = ("pack", "query_plan", "featmap", "gather_table", "chain", "per_sample", "composite")
+TRAIN_BWD_STAGES = ("zero_pack", "composite_mixup", "merge_mlp", "proj_conv", "colorfeat", "ksum", "block3", "point_sums", "block1")
+
 # name -> (restype, argtypes); must list every symbol include/hnr.h declares (tests check this)
 SIGNATURES = {
     "hnr_version": (ctypes.c_char_p, []),
@@ -267,11 +271,12 @@ def hip_runtime():
 
 
 class StageEvents:
-    """len(RENDER_STAGES) + 1 hipEvent_t handles; elapsed_ms() after the stream has been synchronised."""
+    """len(stages) + 1 hipEvent_t handles; elapsed_ms() after the stream has been synchronised."""
 
-    def __init__(self):
+    def __init__(self, stages=RENDER_STAGES):
         H = hip_runtime()
-        self.n = len(RENDER_STAGES) + 1
+        self.stages = tuple(stages)
+        self.n = len(self.stages) + 1
         self.arr = (_P * self.n)()
         for i in range(self.n):
             e = _P()
@@ -282,7 +287,7 @@ class StageEvents:
     def elapsed_ms(self):
         H = hip_runtime()
         out = {}
-        for i, name in enumerate(RENDER_STAGES):
+        for i, name in enumerate(self.stages):
             ms = _F()
             if H.hipEventElapsedTime(ctypes.byref(ms), self.arr[i], self.arr[i + 1]) != 0:
                 raise HnrError("hipEventElapsedTime failed (events not recorded / not complete)")

@@ -350,13 +350,18 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float *__restri
 // data gradient: one lane per input element, gather form (no atomics), ACCUMULATES into g_in
 __global__ void conv3x3_bwd_data_kernel(const float *__restrict__ g_out, const float *__restrict__ out, const float *__restrict__ w,
                                         int Cin, int Hin, int Win, int Cout, int stride, int Hout, int Wout, float slope,
-                                        float *__restrict__ g_in, int V)
+                                        float *__restrict__ g_in, int V, const int32_t *__restrict__ bbox = nullptr, int f = 1, int halo = 0)
 {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t total = (int64_t)V * Cin * Hin * Win;
     if (idx >= total) return;
     const int ix = (int)(idx % Win), iy = (int)((idx / Win) % Hin), ci = (int)((idx / ((int64_t)Win * Hin)) % Cin),
               v = (int)(idx / ((int64_t)Win * Hin * Cin));
+    if (bbox) {
+        // the gradient is zero outside the (generously dilated) image of the pixels the batch touched in this view: nothing to add there
+        const int bx0 = bbox[4 * v], by0 = bbox[4 * v + 1], bx1 = bbox[4 * v + 2], by1 = bbox[4 * v + 3];
+        if (bx1 < bx0 || ix < bx0 / f - halo || ix > bx1 / f + halo || iy < by0 / f - halo || iy > by1 / f + halo) return;
+    }
     float acc = 0.f;
     for (int ky = 0; ky < 3; ++ky) {
         const int ty = iy + 1 - ky;
@@ -382,7 +387,8 @@ __global__ void conv3x3_bwd_data_kernel(const float *__restrict__ g_out, const f
 __global__ __launch_bounds__(256) void conv3x3_bwd_weight_kernel(const float *__restrict__ g_out, const float *__restrict__ out,
                                                                  const float *__restrict__ in, int in_cl, int in_cstride,
                                                                  int Cin, int Hin, int Win, int Cout, int stride, int Hout, int Wout,
-                                                                 float slope, float *__restrict__ g_w, float *__restrict__ g_b, int V)
+                                                                 float slope, float *__restrict__ g_w, float *__restrict__ g_b, int V,
+                                                                 const int32_t *__restrict__ bbox = nullptr, int f = 1, int halo = 0)
 {
     __shared__ float s_red[4][10];
     const int co = blockIdx.x / Cin, ci = blockIdx.x % Cin;
@@ -392,6 +398,10 @@ __global__ __launch_bounds__(256) void conv3x3_bwd_weight_kernel(const float *__
     for (int i = 0; i < 10; ++i) acc[i] = 0.f;
     for (int64_t pix = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; pix < npix; pix += (int64_t)gridDim.y * blockDim.x) {
         const int ox = (int)(pix % Wout), oy = (int)((pix / Wout) % Hout), v = (int)(pix / ((int64_t)Wout * Hout));
+        if (bbox) {
+            const int bx0 = bbox[4 * v], by0 = bbox[4 * v + 1], bx1 = bbox[4 * v + 2], by1 = bbox[4 * v + 3];
+            if (bx1 < bx0 || ox < bx0 / f - halo || ox > bx1 / f + halo || oy < by0 / f - halo || oy > by1 / f + halo) continue;
+        }
         const size_t o = (((size_t)v * Cout + co) * Hout + oy) * Wout + ox;
         const float dz = g_out[o] * (out[o] > 0.f ? 1.f : slope);
         if (dz == 0.f) continue;
@@ -679,12 +689,13 @@ __global__ __launch_bounds__(1024) void flag_scan_kernel(int32_t *__restrict__ f
 }
 
 __global__ void map_rows_kernel(const int32_t *__restrict__ row_pid, int64_t M, const int32_t *__restrict__ uidx, int32_t *__restrict__ row_u,
-                                const long long *__restrict__ d_n = nullptr)
+                                const long long *__restrict__ d_n = nullptr, int skip_key = -1)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (!d_n) { if (t < M) row_u[t] = uidx[row_pid[t]]; return; }
-    // device-count form: every row of the capacity gets a key; rows past *d_n and empty slots (-1) get -1 (sorted first, skipped by the sums)
-    if (t < M) row_u[t] = (t < *d_n && row_pid[t] >= 0) ? uidx[row_pid[t]] : -1;
+    // device-count form: every row of the capacity gets a key; rows past *d_n and empty slots (-1) get the sentinel `skip_key` (> every compact
+    // index: sorted last, outside every segment)
+    if (t < M) row_u[t] = (t < *d_n && row_pid[t] >= 0) ? uidx[row_pid[t]] : skip_key;
 }
 
 }  // namespace hnr
@@ -803,9 +814,30 @@ extern "C" int hnr_proj_rows_bwd(const float *d_sample_loc_w, const int32_t *d_v
     return HNR_OK;
 }
 
+static int image_features_bwd_impl(const float *d_img, int V, int H, int W, const float *const *conv_w, float slope,
+                                   const float *d_scratch, float *d_g_pyramid, float *const *g_conv_w, float *const *g_conv_b,
+                                   const int32_t *d_bbox, void *stream);
+
 extern "C" int hnr_image_features_bwd(const float *d_img, int V, int H, int W, const float *const *conv_w, float slope,
                                       const float *d_scratch, float *d_g_pyramid, float *const *g_conv_w, float *const *g_conv_b,
                                       void *stream)
+{
+    return image_features_bwd_impl(d_img, V, H, W, conv_w, slope, d_scratch, d_g_pyramid, g_conv_w, g_conv_b, nullptr, stream);
+}
+
+// csrc/render_train.hip: the same with the per-view rectangle of touched pixels (hnr_proj_rows_bwd's d_bbox): every kernel skips what lies outside
+// its image at the level's resolution, dilated by more than the 3x3 / stride-2 chain can spread a gradient
+namespace hnr {
+int image_features_bwd_bbox(const float *d_img, int V, int H, int W, const float *const *conv_w, float slope, const float *d_scratch, float *d_g_pyramid,
+                            float *const *g_conv_w, float *const *g_conv_b, const int32_t *d_bbox, void *stream)
+{
+    return image_features_bwd_impl(d_img, V, H, W, conv_w, slope, d_scratch, d_g_pyramid, g_conv_w, g_conv_b, d_bbox, stream);
+}
+}
+
+static int image_features_bwd_impl(const float *d_img, int V, int H, int W, const float *const *conv_w, float slope,
+                                   const float *d_scratch, float *d_g_pyramid, float *const *g_conv_w, float *const *g_conv_b,
+                                   const int32_t *d_bbox, void *stream)
 {
     if (!d_img || !conv_w || !d_scratch || !d_g_pyramid || !g_conv_w || !g_conv_b || V <= 0 || H <= 1 || W <= 1) {
         set_error("hnr_image_features_bwd: bad argument"); return HNR_ERR_BADARG;
@@ -815,18 +847,22 @@ extern "C" int hnr_image_features_bwd(const float *d_img, int V, int H, int W, c
     const size_t n1 = (size_t)V * 6 * H1 * W1, n2 = (size_t)V * 12 * H2 * W2, n3 = (size_t)V * 24 * H3 * W3;
     const float *s1a = d_scratch, *s1 = s1a + n1, *s2a = s1 + n1, *s2 = s2a + n2, *s3a = s2 + n2, *s3 = s3a + n3;
     float *g1a = d_g_pyramid, *g1 = g1a + n1, *g2a = g1 + n1, *g2 = g2a + n2, *g3a = g2 + n2, *g3 = g3a + n3;
+    // resolution divisor and dilation of a tensor at pyramid level 1 / 2 / 3 (upsample +-1, every 3x3 conv +-1, every stride-2 step x2 + 1)
+    auto lvl_f = [&](int Hl) { return Hl == H1 ? 2 : (Hl == H2 ? 4 : 8); };
+    auto lvl_halo = [&](int Hl) { return Hl == H1 ? 30 : (Hl == H2 ? 14 : 6); };
     auto wgrad = [&](const float *g_out, const float *out, const float *in, int cl, int cstride, int Cin, int Hin, int Win, int Cout,
                      int stride, int Hout, int Wout, int li) {
         const int64_t npix = (int64_t)V * Hout * Wout;
         int chunks = cdiv(npix, 256 * 8);
         if (chunks > 64) chunks = 64;
         conv3x3_bwd_weight_kernel<<<dim3(Cout * Cin, chunks), 256, 0, st>>>(g_out, out, in, cl, cstride, Cin, Hin, Win, Cout, stride, Hout,
-                                                                             Wout, slope, g_conv_w[li], g_conv_b[li], V);
+                                                                             Wout, slope, g_conv_w[li], g_conv_b[li], V, d_bbox, lvl_f(Hout), lvl_halo(Hout));
     };
     auto dgrad = [&](const float *g_out, const float *out, int li, int Cin, int Hin, int Win, int Cout, int stride, int Hout, int Wout,
                      float *g_in) {
         const int64_t total = (int64_t)V * Cin * Hin * Win;
-        conv3x3_bwd_data_kernel<<<cdiv(total, 256), 256, 0, st>>>(g_out, out, conv_w[li], Cin, Hin, Win, Cout, stride, Hout, Wout, slope, g_in, V);
+        conv3x3_bwd_data_kernel<<<cdiv(total, 256), 256, 0, st>>>(g_out, out, conv_w[li], Cin, Hin, Win, Cout, stride, Hout, Wout, slope, g_in, V,
+                                                                  d_bbox, lvl_f(Hin), lvl_halo(Hin));
     };
     // conv5: s3a -> s3 ; conv4: s2 -> s3a (stride 2) ; conv3: s2a -> s2 ; conv2: s1 -> s2a (stride 2) ; conv1: s1a -> s1 ; conv0: img -> s1a
     wgrad(g3, s3, s3a, 0, 0, 24, H3, W3, 24, 1, H3, W3, 5);
@@ -980,7 +1016,7 @@ int unique_points_dc(const int32_t *d_row_pid, int64_t M_cap, const long long *d
     const int nb = cdiv(n_points, 1024);
     flag_block_sum_kernel<<<nb, 1024, 0, st>>>(d_uidx, n_points, d_scratch);
     flag_scan_kernel<<<nb, 1024, 0, st>>>(d_uidx, n_points, d_scratch, d_ulist, cap, d_count);
-    if (M_cap > 0) map_rows_kernel<<<cdiv(M_cap, 256), 256, 0, st>>>(d_row_pid, M_cap, d_uidx, d_row_u, d_m);
+    if (M_cap > 0) map_rows_kernel<<<cdiv(M_cap, 256), 256, 0, st>>>(d_row_pid, M_cap, d_uidx, d_row_u, d_m, cap);
     HNR_LAUNCH_CHECK();
     return HNR_OK;
 }

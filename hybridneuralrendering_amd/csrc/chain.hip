@@ -342,12 +342,16 @@ __global__ __launch_bounds__(256, RT >= 4 ? 1 : 2) void chain_kernel(ChainArgs a
         o[0] = clock64() - t_start; o[1] = wall_clock64() - w_start; o[2] = n_my; o[3] = (__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 0xf) | ((long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)) << 8);
     }
     if (DBG == 3 && a.hmax) {
+        // one atomic per workgroup and layer
+        __syncthreads();
 #pragma unroll
         for (int l = 0; l < 4; ++l) {
             float m = hmax_run[l];
             for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-            if (lane == 0 && m > 0.f) atomicMax(a.hmax + l, __float_as_uint(m));
+            if (lane == 0) exch[4 * l + wave] = m;
         }
+        __syncthreads();
+        if (tid < 4) { const float m = fmaxf(fmaxf(exch[4 * tid], exch[4 * tid + 1]), fmaxf(exch[4 * tid + 2], exch[4 * tid + 3])); if (m > 0.f) atomicMax(a.hmax + tid, __float_as_uint(m)); }
     }
 #undef CH_STAMP
 }

@@ -29,6 +29,12 @@ struct H2PackJob { const float *W; long long rs, cs; int N, K; const float *bias
 constexpr int H2_MAX_JOBS = 16;
 struct H2PackArgs { H2PackJob job[H2_MAX_JOBS]; };
 
+__global__ void h2_meta_zero_kernel(H2PackArgs a)
+{
+    const int j = threadIdx.x;
+    if (j < H2_MAX_JOBS && a.job[j].W) reinterpret_cast<unsigned *>(a.job[j].out + (size_t)((a.job[j].K + 15) / 16) * CH_WSTEP)[HL_WMAX] = 0u;
+}
+
 __global__ void h2_wmax_kernel(H2PackArgs a)
 {
     const H2PackJob &jb = a.job[blockIdx.y];
@@ -232,9 +238,12 @@ __global__ __launch_bounds__(256, 2) void h2lin_kernel(H2LinArgs a)
         __syncthreads();                                                       // the planes are rewritten by the next tile's prologue
     }
     if (a.absmax) {
-        // rows past M repeat row M - 1 (values that exist anyway); padded columns are exact zeros
+        // rows past M repeat row M - 1 (values that exist anyway); padded columns are exact zeros.  One atomic per workgroup.
         for (int o = 32; o > 0; o >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, o));
-        if (lane == 0 && gmax > 0.f) atomicMax(a.absmax, __float_as_uint(gmax));
+        float *s_m = rowinv;                                                   // (free after the last tile's barrier)
+        if (lane == 0) s_m[wave] = gmax;
+        __syncthreads();
+        if (tid == 0) { gmax = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3])); if (gmax > 0.f) atomicMax(a.absmax, __float_as_uint(gmax)); }
     }
 }
 
@@ -245,19 +254,35 @@ __global__ __launch_bounds__(256) void h2_absmax_kernel(const float *__restrict_
     long long M = M_cap, n_unit = M_cap;
     if (d_m) { const long long c = *d_m; if (c < M) M = c; }
     if (n_seg > 1) { n_unit = M < seg_stride ? M : seg_stride; M = n_unit * n_seg; }
-    const int n4 = (N + 3) >> 2;
+    // 64 / LPR rows per wave pass, LPR lanes x float4 per row pass
+    const int n4 = (N + 3) >> 2, LPR = n4 >= 64 ? 64 : (n4 > 16 ? 32 : (n4 > 8 ? 16 : 8)), RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63, lr = lane % LPR, sub = lane / LPR;
+    const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((long long)gridDim.x * blockDim.x) >> 6;
     float m = 0.f;
-    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < M * n4; t += (long long)gridDim.x * blockDim.x) {
-        long long row = t / n4;
-        const long long lrow = row;
-        if (n_seg > 1) { const long long q = row / n_unit; row = q * seg_stride + (row - q * n_unit); }
-        const int c = 4 * (int)(t - lrow * n4);
-        const float *p = A + (size_t)row * lda + c;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) if (c + e < N) m = fmaxf(m, fabsf(p[e]));
+    for (long long r0 = wave * RPW; r0 < M; r0 += n_waves * RPW) {
+        long long row = r0 + sub;
+        if (row >= M) continue;
+        if (n_seg > 1) { int q = 0; for (int v = 1; v < n_seg && v < 8; ++v) q += (row >= (long long)v * n_unit) ? 1 : 0; row = (long long)q * seg_stride + (row - (long long)q * n_unit); }
+        const float *p = A + (size_t)row * lda;
+        for (int c4 = lr; c4 < n4; c4 += LPR) {
+            const int c = 4 * c4;
+            if (c + 4 <= lda) {
+                const float4 v = *reinterpret_cast<const float4 *>(p + c);
+                m = fmaxf(m, fabsf(v.x));
+                if (c + 1 < N) m = fmaxf(m, fabsf(v.y));
+                if (c + 2 < N) m = fmaxf(m, fabsf(v.z));
+                if (c + 3 < N) m = fmaxf(m, fabsf(v.w));
+            } else {
+                for (int e = 0; e < 4; ++e) if (c + e < N) m = fmaxf(m, fabsf(p[c + e]));
+            }
+        }
     }
+    // one atomic per workgroup (thousands of same-address atomics cost ~12 ns each)
+    __shared__ float s_m[4];
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
+    if (lane == 0) s_m[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) { m = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3])); if (m > 0.f) atomicMax(out, __float_as_uint(m)); }
 }
 
 // ------------------------------------------------------------------------------------------------------------------------ h2wgrad
@@ -506,8 +531,8 @@ extern "C" int hnr_h2lin_pack(int n_jobs, const float *const *d_W, const int64_t
         }
         a.job[j].W = d_W[j]; a.job[j].rs = rs[j]; a.job[j].cs = cs[j]; a.job[j].N = N[j]; a.job[j].K = K[j];
         a.job[j].bias = d_bias ? d_bias[j] : nullptr; a.job[j].out = (char *)d_packed[j];
-        HNR_HIP_CHECK(hipMemsetAsync((char *)d_packed[j] + (size_t)((K[j] + 15) / 16) * CH_WSTEP, 0, HL_META_FLOATS * 4, st));
     }
+    h2_meta_zero_kernel<<<1, 64, 0, st>>>(a);                                           // the max |W| words of all jobs (one launch instead of a memset per job)
     h2_wmax_kernel<<<dim3(16, n_jobs), 256, 0, st>>>(a);
     h2_pack_kernel<<<dim3(32, n_jobs), 256, 0, st>>>(a);
     HNR_LAUNCH_CHECK();
@@ -553,8 +578,8 @@ extern "C" int hnr_absmax(const float *d_A, int lda, int64_t M_cap, const int64_
     if (M_cap == 0) return HNR_OK;
     if (!d_A) { set_error("hnr_absmax: NULL pointer"); return HNR_ERR_BADARG; }
     const int64_t work = M_cap * n_seg * ((N + 3) / 4);
-    const int64_t blocks = (work + 255) / 256;
-    h2_absmax_kernel<<<(int)(blocks < 1024 ? blocks : 1024), 256, 0, (hipStream_t)stream>>>(d_A, lda, reinterpret_cast<const long long *>(d_m), M_cap, N, d_out, n_seg, seg_stride);
+    const int64_t blocks = (work + 1023) / 1024;                                      // ~4 float4 per thread
+    h2_absmax_kernel<<<(int)(blocks < 512 ? (blocks < 1 ? 1 : blocks) : 512), 256, 0, (hipStream_t)stream>>>(d_A, lda, reinterpret_cast<const long long *>(d_m), M_cap, N, d_out, n_seg, seg_stride);
     HNR_LAUNCH_CHECK();
     return HNR_OK;
 }
@@ -593,7 +618,7 @@ extern "C" int hnr_h2wgrad(const float *d_dZ, int ldz, const float *d_X, int ldx
     a.zmax = d_absmax_z; a.xmax = d_absmax_x; a.partial = (float *)d_scratch;
     const int64_t blocks = (M_cap * n_seg + 31) / 32;
     const int n_cu = h2_num_cus();
-    int grid = (int)(blocks < n_cu ? blocks : n_cu);
+    int grid = (int)((blocks + 7) / 8 < n_cu ? (blocks + 7) / 8 : n_cu);           // at least 8 row blocks per workgroup: every workgroup writes (and the reduction reads) a whole partial
     if (grid < 1) grid = 1;
     hipStream_t st = (hipStream_t)stream;
 #define HNR_H2WG_CASE(NT_, KT_, WN_, WK_)                                                                                               \

@@ -488,12 +488,16 @@ __global__ __launch_bounds__(256, mlp3_wgs_per_cu(S0, RT, MODE)) void mlp3_kerne
         MLP_STAMP(12);
     }
     if (MODE == 0 && a.tmax) {
+        // one atomic per workgroup and layer
+        __syncthreads();
 #pragma unroll
         for (int l = 0; l < 3; ++l) {
             float m = tmax_run[l];
             for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-            if (lane == 0 && m > 0.f) atomicMax(a.tmax + l, __float_as_uint(m));
+            if (lane == 0) exch[4 * l + wave] = m;
         }
+        __syncthreads();
+        if (tid < 3) { const float m = fmaxf(fmaxf(exch[4 * tid], exch[4 * tid + 1]), fmaxf(exch[4 * tid + 2], exch[4 * tid + 3])); if (m > 0.f) atomicMax(a.tmax + tid, __float_as_uint(m)); }
     }
 #ifdef HNR_MLP_PROBE
     if (blockIdx.x == 0 && threadIdx.x == 0) { for (int i = 0; i < 20; ++i) g_mlp_probe[i] = tm_[i]; g_mlp_probe[20] = ntile_; }

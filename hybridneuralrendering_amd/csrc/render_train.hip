@@ -56,7 +56,7 @@ struct Layout {
     // backward temporaries
     float *g_dec, *gY3, *gCF, *g_sigma, *dY2, *dY1, *gX7, *gF, *gZ3m, *dM2, *dM1, *gX6, *gpre, *tmpCF, *tmpWfd, *g_pyr, *g_fm, *dT2, *dT1, *gX5, *gZ4, *g_wagg,
           *dZ3, *gX3, *dZ1, *G8, *P8, *gTu, *gE;
-    int32_t *bbox, *key_scratch, *ks, *perm;
+    int32_t *bbox, *key_scratch, *ks, *perm, *seg_start;
     char *sort_scratch, *sort_scratch2, *wg_scratch;
     size_t sort_bytes, sort_bytes2, wg_bytes;
     size_t rows_cap, ucap, VS, fm_elems, bytes;
@@ -111,7 +111,7 @@ Layout carve(void *ws, size_t ws_bytes, const hnr_train_params *p, bool *ok)
     L.dT2 = c.take<float>(cap * 128); L.dT1 = c.take<float>(cap * 128); L.gX5 = c.take<float>(cap * 256);
     L.gZ4 = c.take<float>(rows * 256); L.g_wagg = c.take<float>(rows);
     L.dZ3 = c.take<float>(rows * 256); L.gX3 = c.take<float>(rows * 264); L.dZ1 = c.take<float>(rows * 256);
-    L.ks = c.take<int32_t>(rows); L.perm = c.take<int32_t>(rows);
+    L.ks = c.take<int32_t>(rows); L.perm = c.take<int32_t>(rows); L.seg_start = c.take<int32_t>(ucap + 1);
     L.sort_bytes2 = (size_t)hnr_sort_rows_scratch_bytes((int64_t)rows); L.sort_scratch2 = c.take<char>(L.sort_bytes2);
     L.G8 = c.take<float>(rows * 8); L.P8 = c.take<float>(ucap * 8); L.gTu = c.take<float>(ucap * 256); L.gE = c.take<float>(ucap * 224);
     L.wg_bytes = (size_t)hnr_h2wgrad_scratch_bytes(256, 280); L.wg_scratch = c.take<char>(L.wg_bytes);
@@ -218,16 +218,26 @@ __global__ void train_add_cols_kernel(float *__restrict__ dst, int ldd, const fl
     dst[s * ldd + c] += src[s * lds_ + c];
 }
 
-// g_conf[0] += sum of g_conf_out over the EMPTY neighbour slots (they read point 0 through the index clamp).  One block, fixed order.
-__global__ __launch_bounds__(1024) void train_conf0_kernel(const float *__restrict__ g_conf_out, const int32_t *__restrict__ pidx, long long n, float *__restrict__ g_conf)
+// g_conf[0] += sum of g_conf_out over the EMPTY neighbour slots (they read point 0 through the index clamp).  Two stages, fixed order.
+__global__ __launch_bounds__(256) void train_conf0_partial_kernel(const float *__restrict__ g_conf_out, const int32_t *__restrict__ pidx, long long n, float *__restrict__ part)
 {
-    __shared__ float s_w[16];
+    __shared__ float s_w[4];
     float acc = 0.f;
-    for (long long i = threadIdx.x; i < n; i += 1024) acc += pidx[i] < 0 ? g_conf_out[i] : 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) acc += pidx[i] < 0 ? g_conf_out[i] : 0.f;
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
     if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) { float t = 0.f; for (int k = 0; k < 16; ++k) t += s_w[k]; g_conf[0] += t; }
+    if (threadIdx.x == 0) part[blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+}
+__global__ __launch_bounds__(256) void train_conf0_final_kernel(const float *__restrict__ part, int n_part, float *__restrict__ g_conf)
+{
+    __shared__ float s_w[4];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n_part; i += 256) acc += part[i];
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) g_conf[0] += (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
 }
 
 // alpha branch + softplus(x - 1) + K-weighted sums transposed (point_aggregators.py:1005-1026, :471-476), 8-slot row layout: one wave per valid sample
@@ -255,15 +265,25 @@ __global__ __launch_bounds__(256) void train_ksum_bwd_kernel(KsumPadArgs a)
     for (int s = wave; s < n_valid; s += n_waves) {
         const float4 gf = reinterpret_cast<const float4 *>(a.gX5 + (size_t)s * a.ldg5)[lane];
         const float gs = a.g_sigma[s];
+        // the sample's 8 rows sit in one 32-row group of the chain workspace; all their loads go out together
+        const size_t row0 = (size_t)8 * s;
+        const char *ax = a.aux + (row0 >> 5) * CH_AUX_GROUP;
+        const int j0 = (int)(row0 & 31);
+        int pid[8]; float wv[8]; float4 hv[8];
+#pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const size_t row = (size_t)8 * s + k;
-            const char *ax = a.aux + (row >> 5) * CH_AUX_GROUP;
-            const int pid = reinterpret_cast<const int32_t *>(ax)[row & 31];
+            pid[k] = reinterpret_cast<const int32_t *>(ax)[j0 + k];
+            wv[k] = reinterpret_cast<const float *>(ax + 128)[j0 + k];
+            hv[k] = reinterpret_cast<const float4 *>(a.H4 + (row0 + k) * 256)[lane];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const size_t row = row0 + k;
             float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
             float gw = 0.f;
-            if (pid >= 0) {
-                const float w = reinterpret_cast<const float *>(ax + 128)[row & 31];
-                const float4 h = reinterpret_cast<const float4 *>(a.H4 + row * 256)[lane];
+            if (pid[k] >= 0) {
+                const float w = wv[k];
+                const float4 h = hv[k];
                 const float d = train_wave_sum(h.x * aw.x + h.y * aw.y + h.z * aw.z + h.w * aw.w);
                 const float yv = __fsub_rn(d + ab, 1.0f);
                 const float ez = expf(yv);
@@ -297,7 +317,10 @@ __global__ __launch_bounds__(256) void train_ksum_bwd_kernel(KsumPadArgs a)
         if (lane == 0) atomicAdd(a.g_alpha_b, s_b[0] + s_b[1] + s_b[2] + s_b[3]);
     }
     for (int o = 32; o > 0; o >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, o));
-    if (lane == 0 && gmax > 0.f) atomicMax(a.absmax, __float_as_uint(gmax));
+    __syncthreads();
+    if (lane == 0) s_b[wid] = gmax;
+    __syncthreads();
+    if (threadIdx.x == 0) { gmax = fmaxf(fmaxf(s_b[0], s_b[1]), fmaxf(s_b[2], s_b[3])); if (gmax > 0.f) atomicMax(a.absmax, __float_as_uint(gmax)); }
 }
 
 // gX3[row, 256 + e] = sum_n dZ3[row, n] W30[n, 256 + e], e < 7 (column 263: 0): the gradient of block3's 7 extra inputs (point colour, direction
@@ -334,6 +357,15 @@ __global__ __launch_bounds__(256) void train_extras_dgrad_kernel(const float *__
             *reinterpret_cast<float4 *>(o + 4) = make_float4(acc[4], acc[5], acc[6], 0.f);
         }
     }
+}
+
+// the small accumulated-into gradient buffers of one step, zeroed by one launch (a memset per buffer is a launch per buffer)
+struct ZeroJobs { float *p[24]; int n[24]; };
+__global__ void train_zero_kernel(ZeroJobs z)
+{
+    float *p = z.p[blockIdx.x];
+    if (!p) return;
+    for (int i = threadIdx.x; i < z.n[blockIdx.x]; i += blockDim.x) p[i] = 0.f;
 }
 
 __global__ void train_bbox_init_kernel(int32_t *bbox, int V, int H, int W)
@@ -381,6 +413,13 @@ extern "C" int hnr_render_train_forward(const hnr_grid *grid, const hnr_train_pa
     const float sl = p->slope;
     const int64_t *dS = reinterpret_cast<const int64_t *>(L.tc + TC_S), *dU = reinterpret_cast<const int64_t *>(L.tc + TC_U);
     unsigned long long *cnt = reinterpret_cast<unsigned long long *>(o->d_counts);
+    int stage = 0;
+    auto mark = [&]() -> int {      // optional HIP events at the stage boundaries (profiling hook, as in hnr_render_forward)
+        if (o->stage_events && o->stage_events[stage]) { if (hipEventRecord((hipEvent_t)o->stage_events[stage], st) != hipSuccess) { set_error("hipEventRecord failed"); return HNR_ERR_HIP; } }
+        ++stage;
+        return HNR_OK;
+    };
+    TR(mark());
 
     // ---- kernel images of this step's weights
     TR(hnr_chain_pack(w->block1_0_w + 224, 284, w->block1_0_b, w->block1_2_w, w->block1_2_b, w->block3_0_w, w->block3_0_b, w->block3_2_w, w->block3_2_b,
@@ -406,6 +445,7 @@ extern "C" int hnr_render_train_forward(const hnr_grid *grid, const hnr_train_pa
         const float *W[1] = {w->block1_0_w}; const int64_t rs[1] = {284}, cs[1] = {1}; const int N1[1] = {256}, K1[1] = {224}; void *out[1] = {L.img[IM_TAB]};
         TR(hnr_h2lin_pack(1, W, rs, cs, N1, K1, nullptr, out, stream));
     }
+    TR(mark());
     // ---- query (jittered depths: cam->d_tmid with tmid_stride = D), padded outputs
     hnr_query_params q;
     q.R = R; q.D = p->D; q.SR = SR; q.K = K; q.radius2 = p->radius2; q.tmid_stride = p->tmid_stride; q.pad_outputs = 1; q.knn_order = p->knn_order;
@@ -419,8 +459,10 @@ extern "C" int hnr_render_train_forward(const hnr_grid *grid, const hnr_train_pa
     HNR_HIP_CHECK(hipMemsetAsync(o->d_decoded, 0, (size_t)R * SR * 4 * sizeof(float), st));
     HNR_HIP_CHECK(hipMemsetAsync(o->d_weight, 0, (size_t)R * SR * K * sizeof(float), st));
     train_conf_fill_kernel<<<256, 256, 0, st>>>(cl->d_conf, o->d_conf_coefficient, (long long)R * SR * K);
+    TR(mark());
     // ---- reference-view feature pyramid (activations kept for the conv backward)
     if (V > 0) TR(hnr_image_features(vw->d_images, V, p->H, p->W, w->conv_w, w->conv_b, sl, L.fm_scratch, L.fm, stream));
+    TR(mark());
     // ---- per-neighbour chain
     TR(chain_gather_train(cl->d_xyz, cl->d_conf, cl->d_dir, cl->d_color, o->d_sample_pidx, o->d_sample_loc_w, cam->d_raydir, cam->d_campos, cam->d_camrot, L.vs_item,
                           o->d_counts, SR, K, cap, L.chain_ws, L.X5, 280, o->d_weight, o->d_conf_coefficient, L.Xd, L.row_pid, stream));
@@ -428,10 +470,12 @@ extern "C" int hnr_render_train_forward(const hnr_grid *grid, const hnr_train_pa
     train_ucount_kernel<<<1, 1, 0, st>>>(L.ucount, (long long)L.ucap, L.tc);
     TR(point_rows_dc(cl->d_emb, L.ulist, (int)L.ucap, L.tc + TC_U, L.E, 224, st));
     TR(hnr_h2lin(L.E, 224, (int64_t)L.ucap, dU, 1, 0, L.img[IM_TAB], 256, 224, 0, 0, sl, nullptr, 0, L.Tu, 256, nullptr, stream));
+    TR(mark());
     {
         float *H[4] = {L.H1, L.X3, L.H3, L.H4}; const int ldh[4] = {256, 264, 256, 256};
         TR(chain_forward_train(L.chain_ws, L.Tu, 256, L.uidx, L.img_chain, o->d_counts, cap, sl, L.X5, 280, L.sigma, H, ldh, L.amax + AM_H1, stream));
     }
+    TR(mark());
     TR(hnr_absmax(L.X5, 280, cap, dS, 1, 0, 280, L.amax + AM_X5, stream));
     // ---- per-sample MLPs
     const int act1110[4] = {1, 1, 1, 0}, act111[3] = {1, 1, 1}, act110[3] = {1, 1, 0};
@@ -450,9 +494,11 @@ extern "C" int hnr_render_train_forward(const hnr_grid *grid, const hnr_train_pa
     TR(hnr_absmax(L.X7, 92, cap, dS, 1, 0, 90, L.amax + AM_X7, stream));
     TR(mlp3_forward_train(L.X7, 92, cap, o->d_counts, HNR_CNT_SAMPLES_VALID, 1, 0, L.img_mx, 3, mxN, mxK, act110, sl, nullptr, nullptr, 0, L.Y3, 48, nullptr, 0,
                           L.Y1, 48, L.Y2, 48, L.amax + AM_Y1, stream));
+    TR(mark());
     TR(hnr_final_color(L.Y3, 48, L.CF, 128, w->fin_w, w->fin_b, L.sigma, L.vs_item, o->d_counts, cap, o->d_decoded, stream));
     TR(hnr_composite(o->d_decoded, o->d_sample_loc_w, o->d_sample_pidx, o->d_ray_mask, nullptr, cam->d_campos, cam->d_camrot, cam->d_bg_color, R, SR, K, p->vsize_z,
                      p->raydist_mode_unit, o->d_raycolor, o->d_opacity, o->d_is_background, o->d_blend_weight, stream));
+    TR(mark());
     HNR_LAUNCH_CHECK();
     return HNR_OK;
 }
@@ -479,18 +525,31 @@ extern "C" int hnr_render_train_backward(const hnr_train_params *p, const hnr_tr
     const int64_t *dS = reinterpret_cast<const int64_t *>(L.tc + TC_S), *dM = reinterpret_cast<const int64_t *>(L.tc + TC_M8), *dU = reinterpret_cast<const int64_t *>(L.tc + TC_U);
     const int64_t rows = (int64_t)L.rows_cap, ucap = (int64_t)L.ucap;
     uint32_t *am = L.amax;
+    int stage = 0;
+    auto mark = [&]() -> int {
+        if (o->stage_events && o->stage_events[stage]) { if (hipEventRecord((hipEvent_t)o->stage_events[stage], st) != hipSuccess) { set_error("hipEventRecord failed"); return HNR_ERR_HIP; } }
+        ++stage;
+        return HNR_OK;
+    };
+    TR(mark());
 
     // ---- zero what is accumulated into
     HNR_HIP_CHECK(hipMemsetAsync(gc->d_emb, 0, (size_t)N * 32 * 4, st));
     HNR_HIP_CHECK(hipMemsetAsync(gc->d_conf, 0, (size_t)N * 4, st));
     HNR_HIP_CHECK(hipMemsetAsync(gc->d_dir, 0, (size_t)N * 12, st));
     HNR_HIP_CHECK(hipMemsetAsync(gc->d_color, 0, (size_t)N * 12, st));
-    HNR_HIP_CHECK(hipMemsetAsync(g.fin_w, 0, 3 * 128 * 4, st)); HNR_HIP_CHECK(hipMemsetAsync(g.fin_b, 0, 3 * 4, st));
-    HNR_HIP_CHECK(hipMemsetAsync(g.alpha_w, 0, 256 * 4, st)); HNR_HIP_CHECK(hipMemsetAsync(g.alpha_b, 0, 4, st));
-    if (V > 0) {
-        HNR_HIP_CHECK(hipMemsetAsync(g.mw_w[3], 0, 64 * 4, st)); HNR_HIP_CHECK(hipMemsetAsync(g.mw_b[3], 0, 4, st));
-        const int cw[6] = {6 * 3 * 9, 6 * 6 * 9, 12 * 6 * 9, 12 * 12 * 9, 24 * 12 * 9, 24 * 24 * 9}, cb[6] = {6, 6, 12, 12, 24, 24};
-        for (int i = 0; i < 6; ++i) { HNR_HIP_CHECK(hipMemsetAsync(g.conv_w[i], 0, (size_t)cw[i] * 4, st)); HNR_HIP_CHECK(hipMemsetAsync(g.conv_b[i], 0, (size_t)cb[i] * 4, st)); }
+    {
+        ZeroJobs z;
+        int nz = 0;
+        auto add = [&](float *ptr, int n) { z.p[nz] = ptr; z.n[nz] = n; ++nz; };
+        add(g.fin_w, 3 * 128); add(g.fin_b, 3); add(g.alpha_w, 256); add(g.alpha_b, 1);
+        if (V > 0) {
+            add(g.mw_w[3], 64); add(g.mw_b[3], 1);
+            const int cw[6] = {6 * 3 * 9, 6 * 6 * 9, 12 * 6 * 9, 12 * 12 * 9, 24 * 12 * 9, 24 * 24 * 9}, cb[6] = {6, 6, 12, 12, 24, 24};
+            for (int i = 0; i < 6; ++i) { add(g.conv_w[i], cw[i]); add(g.conv_b[i], cb[i]); }
+        }
+        for (int i = nz; i < 24; ++i) { z.p[i] = nullptr; z.n[i] = 0; }
+        train_zero_kernel<<<nz, 256, 0, st>>>(z);
     }
     // ---- images of the transposed weights (input gradients)
     {
@@ -513,7 +572,11 @@ extern "C" int hnr_render_train_backward(const hnr_train_params *p, const hnr_tr
             TR(hnr_h2lin_pack(10, W2, rs2, cs2, N2, K2, nullptr, out2, stream));
         }
     }
-    if (d_g_conf_coefficient) train_conf0_kernel<<<1, 1024, 0, st>>>(d_g_conf_coefficient, o->d_sample_pidx, (long long)R * SR * K, gc->d_conf);
+    if (d_g_conf_coefficient) {
+        // (the partials live in the first words of the weight-gradient scratch: it is not in use yet)
+        train_conf0_partial_kernel<<<512, 256, 0, st>>>(d_g_conf_coefficient, o->d_sample_pidx, (long long)R * SR * K, reinterpret_cast<float *>(L.wg_scratch));
+        train_conf0_final_kernel<<<1, 256, 0, st>>>(reinterpret_cast<const float *>(L.wg_scratch), 512, gc->d_conf);
+    }
     // weight gradient of one layer: dW = dZ^T X, db = column sums of dZ
     auto wgrad = [&](const float *dZ, int ldz, const float *X, int ldx, int64_t Mcap, const int64_t *dm, int nseg, int64_t segs, int Nn, int Kk, int amz, int amx,
                      float *dW, int lddw, float *db) -> int {
@@ -524,6 +587,7 @@ extern "C" int hnr_render_train_backward(const hnr_train_params *p, const hnr_tr
                      int amo) -> int {
         return hnr_h2lin(dZ, ldz, Mcap, dm, nseg, segs, L.img[im], Nn, Kk, side ? 1 : 0, 0, sl, side, lds_, out, ldo, amo >= 0 ? am + amo : nullptr, stream);
     };
+    TR(mark());
     // ---- 1. composite, 2. final colour
     TR(hnr_composite_bwd(o->d_decoded, o->d_sample_loc_w, o->d_sample_pidx, o->d_ray_mask, nullptr, cam->d_campos, cam->d_camrot, cam->d_bg_color, R, SR, K, p->vsize_z,
                          p->raydist_mode_unit, d_g_raycolor, L.g_dec, stream));
@@ -536,6 +600,7 @@ extern "C" int hnr_render_train_backward(const hnr_train_params *p, const hnr_tr
     TR(dgrad(L.dY2, 48, cap, dS, 1, 0, IM_MX1T, 45, 45, L.Y1, 48, L.dY1, 48, AM_dY1));
     TR(wgrad(L.dY1, 48, L.X7, 92, cap, dS, 1, 0, 45, 90, AM_dY1, AM_X7, g.mx_w[0], 90, g.mx_b[0]));
     TR(dgrad(L.dY1, 48, cap, dS, 1, 0, IM_MX0T, 90, 45, nullptr, 0, L.gX7, 92, -1));
+    TR(mark());
     if (V > 0) {
         // ---- 4. merge; 5. merge-weight MLP (first layer split: [imgfeat45 | ddir3] per (view, sample) row, colour feature once per sample)
         TR(hnr_merge_bwd(L.X6, 48, L.M3, 64, w->mw_w[3], w->mw_b[3], L.vmask, vw->d_frame_w, o->d_counts, V, cap, sl, L.ray_drop, L.vs_item, SR, L.gX7, 92, L.gF, 48, L.gZ3m, 64,
@@ -553,16 +618,19 @@ extern "C" int hnr_render_train_backward(const hnr_train_params *p, const hnr_tr
         TR(dgrad(L.dM1, 64, cap, dS, V, cap, IM_MW0FDT, 48, 64, nullptr, 0, L.gX6, 48, -1));
         TR(dgrad(L.gpre, 64, cap, dS, 1, 0, IM_MW0CFT, 128, 64, nullptr, 0, L.tmpCF, 128, -1));
         train_add_cols_kernel<<<cdiv((int64_t)cap * 128, 256), 256, 0, st>>>(L.gCF, 128, L.tmpCF, 128, 128, L.tc + TC_S);
+        TR(mark());
         // ---- 6. pixel gather + upsample + conv pyramid
         HNR_HIP_CHECK(hipMemsetAsync(L.g_pyr, 0, L.fm_elems * 4, st));
         HNR_HIP_CHECK(hipMemsetAsync(L.g_fm, 0, (size_t)V * p->H * p->W * 48 * 4, st));
         train_bbox_init_kernel<<<1, 64, 0, st>>>(L.bbox, V, p->H, p->W);
         TR(hnr_proj_rows_bwd(o->d_sample_loc_w, L.vs_item, o->d_counts, vw->d_w2c, vw->d_intrinsic, V, p->H, p->W, cap, L.gF, 48, L.gX6, 48, L.g_fm, L.bbox, L.g_pyr, L.key_scratch,
                              L.sort_scratch, (int64_t)L.sort_bytes, stream));
-        TR(hnr_image_features_bwd(vw->d_images, V, p->H, p->W, w->conv_w, sl, L.fm_scratch, L.g_pyr, g.conv_w, g.conv_b, stream));
+        TR(image_features_bwd_bbox(vw->d_images, V, p->H, p->W, w->conv_w, sl, L.fm_scratch, L.g_pyr, g.conv_w, g.conv_b, L.bbox, stream));
     } else {
         train_add_cols_kernel<<<cdiv((int64_t)cap * 45, 256), 256, 0, st>>>(L.gCF, 128, L.gX7, 92, 45, L.tc + TC_S);       // X7 = [colfeat[:45] | 0]
+        TR(mark());
     }
+    TR(mark());
     // ---- 7. colour-feature branch
     TR(dleaky_dc(L.gCF, 128, L.CF, 128, cap, L.tc + TC_S, 128, sl, st));
     TR(hnr_absmax(L.gCF, 128, cap, dS, 1, 0, 128, am + AM_gCF, stream));
@@ -572,6 +640,7 @@ extern "C" int hnr_render_train_backward(const hnr_train_params *p, const hnr_tr
     TR(dgrad(L.dT2, 128, cap, dS, 1, 0, IM_CF1T, 128, 128, L.T1, 128, L.dT1, 128, AM_dT1));
     TR(wgrad(L.dT1, 128, L.X5, 280, cap, dS, 1, 0, 128, 280, AM_dT1, AM_X5, g.cf_w[0], 280, g.cf_b[0]));
     TR(dgrad(L.dT1, 128, cap, dS, 1, 0, IM_CF0T, 256, 128, nullptr, 0, L.gX5, 256, -1));
+    TR(mark());
     // ---- 8. K-sums + alpha branch
     {
         KsumPadArgs a;
@@ -583,6 +652,7 @@ extern "C" int hnr_render_train_backward(const hnr_train_params *p, const hnr_tr
         train_ksum_bwd_kernel<<<nb, 256, 0, st>>>(a);
         HNR_LAUNCH_CHECK();
     }
+    TR(mark());
     // ---- 9. block3
     TR(wgrad(L.gZ4, 256, L.H3, 256, rows, dM, 1, 0, 256, 256, AM_gZ4, AM_H3, g.block3_2_w, 256, g.block3_2_b));
     TR(dgrad(L.gZ4, 256, rows, dM, 1, 0, IM_B32T, 256, 256, L.H3, 256, L.dZ3, 256, AM_dZ3));
@@ -593,22 +663,30 @@ extern "C" int hnr_render_train_backward(const hnr_train_params *p, const hnr_tr
         train_extras_dgrad_kernel<<<nb, 256, 0, st>>>(L.dZ3, w->block3_0_w, L.tc + TC_M8, L.gX3);
         HNR_LAUNCH_CHECK();
     }
+    TR(mark());
     // ---- 10. rows -> touched point (sorted ONCE; both per-point reductions add a point's rows in that fixed order: deterministic)
-    TR(hnr_sort_rows_by_key(L.row_u, rows, L.ks, L.perm, L.sort_scratch2, (int64_t)L.sort_bytes2, stream));
+    {
+        int bits = 1;
+        while ((1ll << bits) <= (long long)ucap) ++bits;                 // keys 0 .. ucap (the sentinel of rows without a point)
+        TR(sort_rows_by_key_bits(L.row_u, rows, bits, L.ks, L.perm, L.sort_scratch2, (int64_t)L.sort_bytes2, st));
+    }
     TR(hnr_gather_rows_bwd_rows(o->d_sample_pidx, cam->d_raydir, L.vs_item, L.vs_off, L.vs_cnt, o->d_counts, SR, K, cap, L.gX3, 264, L.g_wagg, o->d_weight, d_g_conf_coefficient,
                                 L.G8, stream));
-    TR(segment_sum_rows_det_dc(L.G8, 8, L.ks, L.perm, rows, 8, (int)ucap, L.tc + TC_U, L.P8, 8, st));
+    TR(segment_starts(L.ks, rows, L.seg_start, st));
+    TR(segment_sum_rows_det_dc(L.G8, 8, L.ks, L.perm, rows, 8, (int)ucap, L.tc + TC_U, L.seg_start, L.P8, 8, st));
     TR(point_small_grads_dc(L.P8, L.ulist, (int)ucap, L.tc + TC_U, gc->d_conf, gc->d_dir, gc->d_color, st));
+    TR(mark());
     // ---- 11. block1 (first layer split: 60 distance columns per row + the per-point table)
     TR(wgrad(L.gX3, 264, L.H1, 256, rows, dM, 1, 0, 256, 256, AM_dZ2, AM_H1, g.block1_2_w, 256, g.block1_2_b));
     TR(dgrad(L.gX3, 264, rows, dM, 1, 0, IM_B12T, 256, 256, L.H1, 256, L.dZ1, 256, AM_dZ1));
     TR(wgrad(L.dZ1, 256, L.Xd, 64, rows, dM, 1, 0, 256, 60, AM_dZ1, AM_ONE, g.block1_0_w + 224, 284, g.block1_0_b));
-    TR(segment_sum_rows_det_dc(L.dZ1, 256, L.ks, L.perm, rows, 256, (int)ucap, L.tc + TC_U, L.gTu, 256, st));
+    TR(segment_sum_rows_det_dc(L.dZ1, 256, L.ks, L.perm, rows, 256, (int)ucap, L.tc + TC_U, L.seg_start, L.gTu, 256, st));
     TR(hnr_absmax(L.gTu, 256, ucap, dU, 1, 0, 256, am + AM_gTu, stream));
     TR(hnr_absmax(L.E, 224, ucap, dU, 1, 0, 224, am + AM_E, stream));
     TR(wgrad(L.gTu, 256, L.E, 224, ucap, dU, 1, 0, 256, 224, AM_gTu, AM_E, g.block1_0_w, 284, nullptr));
     TR(dgrad(L.gTu, 256, ucap, dU, 1, 0, IM_TABT, 224, 256, nullptr, 0, L.gE, 224, -1));
     TR(point_rows_bwd_dc(L.gE, 224, L.E, 224, L.ulist, (int)ucap, L.tc + TC_U, gc->d_emb, st));
+    TR(mark());
     HNR_LAUNCH_CHECK();
     return HNR_OK;
 }

@@ -60,14 +60,16 @@ __global__ __launch_bounds__(256) void segment_sum_rows_kernel(const float *__re
 __global__ __launch_bounds__(256) void segment_sum_rows_det_kernel(const float *__restrict__ A, int lda, const int32_t *__restrict__ keys_sorted,
                                                                    const int32_t *__restrict__ perm, int64_t M, int n_cols, int n_keys,
                                                                    const int32_t *__restrict__ dst_index, float *__restrict__ dst,
-                                                                   int64_t dst_stride, int accumulate, const long long *__restrict__ d_nkeys = nullptr)
+                                                                   int64_t dst_stride, int accumulate, const long long *__restrict__ d_nkeys = nullptr,
+                                                                   const int32_t *__restrict__ seg_start = nullptr)
 {
     const int lane = threadIdx.x & 63;
     const int key = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     if (d_nkeys && *d_nkeys < n_keys) n_keys = (int)*d_nkeys;
     if (key >= n_keys) return;
     int64_t lo = 0, hi = M;                               // first entry with keys_sorted >= key
-    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (keys_sorted[mid] < key) lo = mid + 1; else hi = mid; }
+    if (seg_start) lo = seg_start[key];                   // (precomputed once per sort: 20 dependent loads per wave otherwise)
+    else while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (keys_sorted[mid] < key) lo = mid + 1; else hi = mid; }
     if (4 * lane >= n_cols) return;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int64_t e = lo; e < M && keys_sorted[e] == key; ++e) {
@@ -139,11 +141,37 @@ extern "C" int hnr_segment_sum_rows(const float *d_A, int lda, const float *d_B,
 
 // device-count form (csrc/render_train.hip): the grid is sized for keys_cap keys, the number of keys is read on the device
 namespace hnr {
+// sort of NON-NEGATIVE keys < 2^bits (compact point indices + a sentinel): fewer radix passes than the 32-bit signed sort
+int sort_rows_by_key_bits(const int32_t *d_keys, int64_t M, int bits, int32_t *d_keys_sorted, int32_t *d_perm, void *d_scratch, int64_t scratch_bytes, hipStream_t st)
+{
+    if (M <= 0) return HNR_OK;
+    size_t sz = (size_t)scratch_bytes;
+    rocprim::counting_iterator<int32_t> iota(0);
+    HNR_HIP_CHECK(rocprim::radix_sort_pairs(d_scratch, sz, reinterpret_cast<const uint32_t *>(d_keys), reinterpret_cast<uint32_t *>(d_keys_sorted), iota, d_perm, (size_t)M, 0,
+                                            (unsigned)bits, st));
+    return HNR_OK;
+}
+// start[k] = first sorted entry of key k (every dense key 0 .. n_keys-1 occurs at least once)
+__global__ void segment_starts_kernel(const int32_t *__restrict__ keys_sorted, int64_t M, int32_t *__restrict__ start)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= M) return;
+    const int k = keys_sorted[e];
+    if (k >= 0 && (e == 0 || keys_sorted[e - 1] != k)) start[k] = (int32_t)e;
+}
+int segment_starts(const int32_t *d_keys_sorted, int64_t M, int32_t *d_start, hipStream_t st)
+{
+    if (M <= 0) return HNR_OK;
+    segment_starts_kernel<<<cdiv(M, 256), 256, 0, st>>>(d_keys_sorted, M, d_start);
+    HNR_LAUNCH_CHECK();
+    return HNR_OK;
+}
 int segment_sum_rows_det_dc(const float *d_A, int lda, const int32_t *d_keys_sorted, const int32_t *d_perm, int64_t M, int n_cols, int keys_cap,
-                            const long long *d_nkeys, float *d_dst, int64_t dst_stride, hipStream_t st)
+                            const long long *d_nkeys, const int32_t *d_start, float *d_dst, int64_t dst_stride, hipStream_t st)
 {
     if (keys_cap <= 0) return HNR_OK;
-    segment_sum_rows_det_kernel<<<cdiv((int64_t)keys_cap * 64, 256), 256, 0, st>>>(d_A, lda, d_keys_sorted, d_perm, M, n_cols, keys_cap, nullptr, d_dst, dst_stride, 0, d_nkeys);
+    segment_sum_rows_det_kernel<<<cdiv((int64_t)keys_cap * 64, 256), 256, 0, st>>>(d_A, lda, d_keys_sorted, d_perm, M, n_cols, keys_cap, nullptr, d_dst, dst_stride, 0, d_nkeys,
+                                                                                d_start);
     HNR_LAUNCH_CHECK();
     return HNR_OK;
 }

@@ -26,8 +26,12 @@ int point_small_grads_dc(const float *d_P8, const int32_t *d_ulist, int U_cap, c
 int point_rows_bwd_dc(const float *d_gE, int ldg, const float *d_E, int lde, const int32_t *d_ids, int n_cap, const long long *d_n, float *d_g_emb, hipStream_t st);
 int dleaky_dc(float *d_g, int ldg, const float *d_y, int ldy, int64_t M_cap, const long long *d_m, int N, float slope, hipStream_t st);
 int sum_views_dc(const float *d_in, int ldi, int V, int cap, const long long *d_n, int N, float *d_out, int ldo, hipStream_t st);
+int image_features_bwd_bbox(const float *d_img, int V, int H, int W, const float *const *conv_w, float slope, const float *d_scratch, float *d_g_pyramid,
+                            float *const *g_conv_w, float *const *g_conv_b, const int32_t *d_bbox, void *stream);
 // csrc/segment.hip
+int sort_rows_by_key_bits(const int32_t *d_keys, int64_t M, int bits, int32_t *d_keys_sorted, int32_t *d_perm, void *d_scratch, int64_t scratch_bytes, hipStream_t st);
+int segment_starts(const int32_t *d_keys_sorted, int64_t M, int32_t *d_start, hipStream_t st);
 int segment_sum_rows_det_dc(const float *d_A, int lda, const int32_t *d_keys_sorted, const int32_t *d_perm, int64_t M, int n_cols, int keys_cap,
-                            const long long *d_nkeys, float *d_dst, int64_t dst_stride, hipStream_t st);
+                            const long long *d_nkeys, const int32_t *d_start, float *d_dst, int64_t dst_stride, hipStream_t st);
 
 }  // namespace hnr

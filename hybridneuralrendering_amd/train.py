@@ -120,6 +120,7 @@ class TrainPath:
         self.agg = renderer.agg
         self.opt = renderer.opt
         self.cap_samples = None            # valid-sample capacity of the workspace (None: R * SR, the worst case)
+        self.timers = None                 # a dict: the library records HIP events at its stage boundaries (profiling; read them after a synchronise)
 
     # ---------------------------------------------------------------------------------------------- forward
     def forward(self, cloud, raydir, campos, camrot, bg_color, near, far, c2w_nearest, campos_nearest, intrinsic_nearest,
@@ -207,6 +208,10 @@ class TrainPath:
         w_out, c_out = _f32((R, SR, K), dev), _f32((R, SR, K), dev)
         S.out = _lib.RenderOutputs(p(col), p(opa), p(isbg), p(bw), p(mask), p(decoded), p(pidx), p(loc), p(nsamp), p(counts), p(status), p(w_out), p(c_out), None)
         S.prm, S.ws, S.ws_ptr, S.nbytes, S.dev = prm, ws, ctypes.c_void_p(ws.data_ptr() + off), nbytes, dev
+        if self.timers is not None:
+            ev = _lib.StageEvents(_lib.TRAIN_FWD_STAGES)
+            self.timers.setdefault("fwd", []).append(ev)
+            S.out.stage_events = ev.arr
         S.R, S.SR, S.K, S.V, S.no_views = R, SR, K, V, no_views
         with torch.cuda.device(dev):
             _lib.check(L.hnr_render_train_forward(grid.handle, ctypes.byref(prm), ctypes.byref(S.cl), ctypes.byref(S.weights), ctypes.byref(S.cam),
@@ -246,6 +251,11 @@ class TrainPath:
         ag = {n: flat[int(offs[i]):int(offs[i]) + sizes[i]].view(S.wt[n].shape) for i, n in enumerate(names)}
         gw = _fill_weights(ag)
         cg = _lib.TrainCloudGrads(p(pg["points_embeding"]), p(pg["points_conf"]), p(pg["points_dir"]), p(pg["points_color"]))
+        S.out.stage_events = None
+        if self.timers is not None:
+            ev = _lib.StageEvents(_lib.TRAIN_BWD_STAGES)
+            self.timers.setdefault("bwd", []).append(ev)
+            S.out.stage_events = ev.arr
         with torch.cuda.device(dev):
             _lib.check(L.hnr_render_train_backward(ctypes.byref(S.prm), ctypes.byref(S.cl), ctypes.byref(S.weights), ctypes.byref(S.cam),
                                                    ctypes.byref(S.vw) if S.vw is not None else None, S.ws_ptr, S.nbytes, ctypes.byref(S.out), p(g_raycolor),
