@@ -15,6 +15,8 @@
 //
 // Every row count is read on the device (*d_m), so the training step needs no host synchronisation (the reference's torch autograd
 // sizes every gradient tensor from host-side shapes).
+#include <stdlib.h>
+
 #include "chain_defs.h"
 
 namespace hnr {
@@ -294,6 +296,7 @@ struct H2WgradArgs {
     int N, K;
     const unsigned *zmax, *xmax;               // bit patterns of max |dZ|, max |X| (device)
     float *partial;                            // [gridDim.x][NP][KP] fixed-order partials; column K = db (the staged X rows carry a 1 there)
+    int dbg;                                   // probe builds only (HNR_WG_DBG): 1 no MFMAs, 2 no conversion, 4 no global loads
 };
 
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -324,143 +327,190 @@ __device__ __forceinline__ f16x8 h2_tr_frag(const char *plane, int rs, int col0,
 #endif
 }
 
-// NT = 32-column tiles of dZ (N), KT = tiles of X (K) covered by the workgroup; 8 waves = WN (along N) x WK (along K).  32-row blocks,
-// double-buffered LDS planes: the next block's rows are in flight (registers) while the MFMAs run over the current one.
-template <int NT, int KT, int WN, int WK>
+// NT = 32-column tiles of dZ (N), KT = tiles of X (K + 1 columns: the bias column) covered by the workgroup; 8 waves = WN = NT (along N) x WK (along K).
+// Pipeline over 16-row blocks (one MFMA k step): three LDS stages of fp16 planes, two register sets of fp32 rows.  In iteration i a wave issues
+// the loads of block i + 2, runs the MFMAs of block i from its stage and -- between them -- converts block i + 1 (loaded one iteration ago) into
+// the next stage: the conversion VALU work and the LDS writes ride under the wave's own MFMAs, the HBM latency under a whole iteration.
+// The loop body is STRAIGHT-LINE code: every predicate is folded into an address or a select (a load or an MFMA inside a branch makes the
+// compiler's wait-count pass wait for vmcnt(0), i.e. for the loads it has just issued: no lookahead, 1.9 TB/s).
+// BIASV (K = 256: no spare column in 8 tiles, and a ninth tile costs 16 more accumulator registers per wave than the file has): the bias gradient
+// is summed on the side in fp32 from the dZ rows as they pass through the staging registers.
+// DEPTH = 1 (NT = 8, KT = 9: the largest accumulator set leaves no room for a second register set): one set, loaded at the top of the iteration
+// for block i + 1 and converted in the iteration's last rounds.
+template <int NT, int KT, int WK, int BIASV = 0, int DEPTH = 2>
 __global__ __launch_bounds__(512, 1) void h2wgrad_kernel(H2WgradArgs a)
 {
+    constexpr int WN = NT;
     static_assert(WN * WK == 8, "8 waves");
-    constexpr int NTW = (NT + WN - 1) / WN, KTW = (KT + WK - 1) / WK;
+    constexpr int KTW = (KT + WK - 1) / WK;
     constexpr int WZ = 32 * NT, WX = 32 * KT;                                  // columns staged per row
     constexpr int RSZ = ((WZ * 2 - 64 + 255) & ~255) + 64, RSX = ((WX * 2 - 64 + 255) & ~255) + 64;      // row strides in bytes: 64 (mod 256), so the 4 rows x 32 B of a transposed read hit distinct banks
-    constexpr int PZ = 32 * RSZ, PX = 32 * RSX, STAGE = 2 * PZ + 2 * PX;
-    constexpr int Z4 = WZ / 4, X4 = WX / 4, NLD = (32 * (Z4 + X4) + 511) / 512;      // float4 loads per thread per block
+    constexpr int RB = 16;                                                     // rows per block
+    constexpr int PZ = RB * RSZ, PX = RB * RSX, STAGE = 2 * PZ + 2 * PX;
+    constexpr int Z4 = WZ / 4, X4 = WX / 4, NLD = (RB * (Z4 + X4) + 511) / 512;      // float4 loads per thread per block
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wn = wave % WN, wk = wave / WN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wn = wave % WN, wk = wave / WN;
     long long M = a.M_cap, n_unit = a.M_cap;
     if (a.d_m) { const long long c = *a.d_m; if (c < M) M = c; }
     if (a.n_seg > 1) { n_unit = M < a.seg_stride ? M : a.seg_stride; M = n_unit * a.n_seg; }
-    const long long n_blocks = (M + 31) / 32;
+    const long long n_blocks = (M + RB - 1) / RB;
+    if (n_blocks == 0 && blockIdx.x > 0) return;
     const int kz = row_scale_exp(__uint_as_float(*a.zmax)), kx = row_scale_exp(__uint_as_float(*a.xmax));
     const float sz = pow2f(kz), sx = pow2f(kx);
 
-    f32x16 acc[NTW][KTW];
+    f32x16 acc[KTW];
 #pragma unroll
-    for (int t = 0; t < NTW; ++t)
+    for (int u = 0; u < KTW; ++u)
 #pragma unroll
-        for (int u = 0; u < KTW; ++u)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
-    const int kt_used = a.K / 32 + 1;                                          // tiles up to the one that holds column K (the bias column)
+        for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
 
-    float4 stg[NLD];
-    auto load_block = [&](long long blk) {
-        int tid_t = tid;                                                       // laundered: the per-slot (row, column) arithmetic is cheap, hoisted it is 2 NLD live registers
-        asm volatile("" : "+v"(tid_t));
+    // staging slots of this thread: slot it = float4 (row, columns c .. c + 3) of the dZ tile or of the X tile of a block; (row, c, tile) do not
+    // depend on the block.  Per slot: the element offset inside a block's rows, the LDS offset of its planes, the masks of its four values.
+    float4 stg[DEPTH][NLD];
+    constexpr int NZS = BIASV ? (RB * Z4) / 512 : 0;                           // BIASV: the first NZS slots of every thread are dZ slots
+    static_assert(!BIASV || (RB * Z4) % 512 == 0, "BIASV needs whole dZ slots");
+    float bsum[NZS > 0 ? NZS : 1][4];
 #pragma unroll
-        for (int it = 0; it < NLD; ++it) {
-            const int idx = tid_t + 512 * it;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < 32 * (Z4 + X4)) {
-                const bool isx = idx >= 32 * Z4;
-                const int id2 = isx ? idx - 32 * Z4 : idx, per = isx ? X4 : Z4;
-                const int row = id2 / per, c = 4 * (id2 - row * per);
-                const long long m = blk * 32 + row;
-                const int lim = isx ? a.K : a.N, ld = isx ? a.ldx : a.ldz;
-                if (m < M && c < lim && c + 4 <= ld) {                          // (columns past lim are staged as zeros: their outputs are never read)
-                    long long pm = m;
-                    if (a.n_seg > 1) { int q = 0; for (int sv = 1; sv < a.n_seg && sv < 8; ++sv) q += (m >= (long long)sv * n_unit) ? 1 : 0; pm = (long long)q * a.seg_stride + (m - (long long)q * n_unit); }
-                    v = *reinterpret_cast<const float4 *>((isx ? a.X : a.dZ) + (size_t)pm * ld + c);
-                    if (c + 1 >= lim) v.y = 0.f;
-                    if (c + 2 >= lim) v.z = 0.f;
-                    if (c + 3 >= lim) v.w = 0.f;
-                }
-            }
-            stg[it] = v;
-        }
+    for (int i = 0; i < (NZS > 0 ? NZS : 1); ++i) bsum[i][0] = bsum[i][1] = bsum[i][2] = bsum[i][3] = 0.f;
+    int s_rc[NLD], s_lds[NLD];                                                 // row << 16 | first column read; LDS offset of the high plane
+    unsigned s_keep[NLD];                                                      // bit e: value e is a real column (< N or < K); bit 4: the X tile; bit 8 + e: value e is the bias column
+    const long long seg_extra = a.n_seg > 1 ? a.seg_stride - n_unit : 0;       // physical row = m + (segment of m) * seg_extra
+#pragma unroll
+    for (int it = 0; it < NLD; ++it) {
+        const int idx = (tid + 512 * it < RB * (Z4 + X4)) ? tid + 512 * it : tid + 512 * (it - 1);      // no slot left: this thread repeats its previous one
+        const bool has = true;
+        const bool isx = idx >= RB * Z4;
+        const int id2 = isx ? idx - RB * Z4 : idx, per = isx ? X4 : Z4;
+        const int row = id2 / per, c = 4 * (id2 - row * per);
+        const int lim = isx ? a.K : a.N, ld = isx ? a.ldx : a.ldz;
+        const bool inrow = c + 4 <= ld;
+        s_rc[it] = (row << 16) | (inrow ? c : 0);
+        unsigned keep = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) keep |= (has && inrow && c + e < lim) ? (1u << e) : 0u;
+        if (isx) { keep |= 16u; if (!BIASV && has && (a.K >> 2) == (c >> 2)) keep |= 256u << (a.K & 3); }
+        s_keep[it] = keep;
+        s_lds[it] = (isx ? 2 * PZ : 0) + row * (isx ? RSX : RSZ) + c * 2;
+    }
+    auto load_slot = [&](long long blk, int it, float4 &v) {
+        const bool isx = (s_keep[it] & 16u) != 0;
+        long long m = blk * RB + (s_rc[it] >> 16);
+        m = m < M ? m : M - 1;                                                  // rows past the end re-read the last row (masked when stored)
+        int q = 0;
+#pragma unroll
+        for (int sv = 1; sv < 8; ++sv) q += (sv < a.n_seg && m >= (long long)sv * n_unit) ? 1 : 0;
+        const long long pm = m + (long long)q * seg_extra;
+        const float *src = (isx ? a.X : a.dZ) + (size_t)pm * (isx ? a.ldx : a.ldz) + (s_rc[it] & 0xffff);
+        v = *reinterpret_cast<const float4 *>(src);
     };
-    auto store_block = [&](int buf) {
-        char *base = lds + buf * STAGE;
-        int tid_t = tid;
-        asm volatile("" : "+v"(tid_t));
+    auto store_slot = [&](char *base, long long blk, int it, const float4 &v) {
+        const unsigned keep = (blk * RB + (s_rc[it] >> 16) < M) ? s_keep[it] : (s_keep[it] & ~15u);
+        const float sc = (keep & 16u) ? sx : sz;
+        if (BIASV && it < NZS) {
+            bsum[it < NZS ? it : 0][0] += (keep & 1u) ? v.x : 0.f; bsum[it < NZS ? it : 0][1] += (keep & 2u) ? v.y : 0.f;
+            bsum[it < NZS ? it : 0][2] += (keep & 4u) ? v.z : 0.f; bsum[it < NZS ? it : 0][3] += (keep & 8u) ? v.w : 0.f;
+        }
+        unsigned ph0, pm0, ph1, pm1;
+        split2h((keep & 1u) ? __fmul_rn(v.x, sc) : 0.f, (keep & 2u) ? __fmul_rn(v.y, sc) : 0.f, ph0, pm0);
+        split2h((keep & 4u) ? __fmul_rn(v.z, sc) : 0.f, (keep & 8u) ? __fmul_rn(v.w, sc) : 0.f, ph1, pm1);
+        // column K of the staged X rows = 1 (fp16 1.0 in the high plane, unscaled): dW[:, K] becomes the column sums of dZ = db
+        ph0 = (keep & 0x100u) ? ((ph0 & 0xffff0000u) | 0x3c00u) : (keep & 0x200u) ? ((ph0 & 0x0000ffffu) | 0x3c000000u) : ph0;
+        ph1 = (keep & 0x400u) ? ((ph1 & 0xffff0000u) | 0x3c00u) : (keep & 0x800u) ? ((ph1 & 0x0000ffffu) | 0x3c000000u) : ph1;
+        *reinterpret_cast<uint2 *>(base + s_lds[it]) = make_uint2(ph0, ph1);
+        *reinterpret_cast<uint2 *>(base + s_lds[it] + ((keep & 16u) ? PX : PZ)) = make_uint2(pm0, pm1);
+    };
+    const long long step = gridDim.x;
+    // one iteration: MFMAs over `cur` (block i) with the conversion of register set SET (block i + 1) into `nxt` spread between them; the loads of
+    // block i + 2 go into the other set first.  Blocks past the end: the loads re-read the last rows, the conversion stores zeros -- harmless work
+    // in the (at most two) tail iterations instead of branches in every iteration.
+    auto body = [&](auto set_c, long long blk, const char *cur, char *nxt) {
+        constexpr int SET = decltype(set_c)::value;
+        const long long b1 = blk + step, b2 = blk + 2 * step;
 #pragma unroll
-        for (int it = 0; it < NLD; ++it) {
-            const int idx = tid_t + 512 * it;
-            if (idx < 32 * (Z4 + X4)) {
-                const bool isx = idx >= 32 * Z4;
-                const int id2 = isx ? idx - 32 * Z4 : idx, per = isx ? X4 : Z4;
-                const int row = id2 / per, c = 4 * (id2 - row * per);
-                const float sc = isx ? sx : sz;
-                unsigned ph0, pm0, ph1, pm1;
-                split2h(__fmul_rn(stg[it].x, sc), __fmul_rn(stg[it].y, sc), ph0, pm0);
-                split2h(__fmul_rn(stg[it].z, sc), __fmul_rn(stg[it].w, sc), ph1, pm1);
-                if (isx && (a.K >> 2) == (c >> 2)) {
-                    // column K of the staged X rows = 1 (fp16 1.0 in the high plane, unscaled): dW[:, K] becomes the column sums of dZ = db
-                    const int e = a.K & 3;
-                    if (e < 2) { ph0 = e == 0 ? ((ph0 & 0xffff0000u) | 0x3c00u) : ((ph0 & 0x0000ffffu) | 0x3c000000u); pm0 = e == 0 ? (pm0 & 0xffff0000u) : (pm0 & 0x0000ffffu); }
-                    else { ph1 = e == 2 ? ((ph1 & 0xffff0000u) | 0x3c00u) : ((ph1 & 0x0000ffffu) | 0x3c000000u); pm1 = e == 2 ? (pm1 & 0xffff0000u) : (pm1 & 0x0000ffffu); }
-                }
-                char *dst = base + (isx ? 2 * PZ : 0) + (size_t)row * (isx ? RSX : RSZ) + c * 2;
-                *reinterpret_cast<uint2 *>(dst) = make_uint2(ph0, ph1);
-                *reinterpret_cast<uint2 *>(dst + (isx ? PX : PZ)) = make_uint2(pm0, pm1);
+        for (int it = 0; it < NLD; ++it) load_slot(DEPTH == 2 ? b2 : b1, it, stg[DEPTH == 2 ? (SET ^ 1) : 0][it]);
+        const char *zb = cur, *xb = cur + 2 * PZ;
+        const f16x8 zh = h2_tr_frag(zb, RSZ, 32 * wn, 0, lane), zm = h2_tr_frag(zb + PZ, RSZ, 32 * wn, 0, lane);
+#pragma unroll
+        for (int u0 = 0; u0 < KTW; u0 += 2) {
+            // two X tiles per round: six MFMAs on two accumulators, alternating (a dependent MFMA waits for its predecessor's result); a wave whose
+            // tile index runs past KT recomputes tile KT - 1 (its partial is not written)
+            const int kt0 = wk * KTW + u0 < KT ? wk * KTW + u0 : KT - 1, kt1 = wk * KTW + u0 + 1 < KT ? wk * KTW + u0 + 1 : KT - 1;
+            const f16x8 xh0 = h2_tr_frag(xb, RSX, 32 * kt0, 0, lane), xm0 = h2_tr_frag(xb + PX, RSX, 32 * kt0, 0, lane);
+            if (u0 + 1 < KTW) {
+                const f16x8 xh1 = h2_tr_frag(xb, RSX, 32 * kt1, 0, lane), xm1 = h2_tr_frag(xb + PX, RSX, 32 * kt1, 0, lane);
+                acc[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zm, xh0, acc[u0], 0, 0, 0);
+                acc[u0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zm, xh1, acc[u0 + 1], 0, 0, 0);
+                acc[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zh, xm0, acc[u0], 0, 0, 0);
+                acc[u0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zh, xm1, acc[u0 + 1], 0, 0, 0);
+                acc[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zh, xh0, acc[u0], 0, 0, 0);
+                acc[u0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zh, xh1, acc[u0 + 1], 0, 0, 0);
+            } else {
+                acc[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zm, xh0, acc[u0], 0, 0, 0);
+                acc[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zh, xm0, acc[u0], 0, 0, 0);
+                acc[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zh, xh0, acc[u0], 0, 0, 0);
+            }
+            // this round's share of the next block's conversion
+            constexpr int R0 = (KTW + 1) / 2;
+#pragma unroll
+            for (int it = 0; it < NLD; ++it) {
+                if (DEPTH == 2) { if (it * R0 / NLD == u0 / 2) store_slot(nxt, b1, it, stg[SET][it]); }
+                else if (u0 + 2 >= KTW) store_slot(nxt, b1, it, stg[0][it]);      // one set: everything behind the last round (the loads had the whole iteration)
             }
         }
     };
 
     long long blk = blockIdx.x;
-    int buf = 0;
-    if (blk < n_blocks) { load_block(blk); store_block(0); }
+#pragma unroll
+    for (int it = 0; it < NLD; ++it) load_slot(blk, it, stg[0][it]);
+#pragma unroll
+    for (int it = 0; it < NLD; ++it) store_slot(lds, blk, it, stg[0][it]);
+    if (DEPTH == 2) {
+#pragma unroll
+        for (int it = 0; it < NLD; ++it) load_slot(blk + step, it, stg[0][it]);
+    }
     __syncthreads();
-    for (; blk < n_blocks; blk += gridDim.x, buf ^= 1) {
-        const long long nxt = blk + gridDim.x;
-        if (nxt < n_blocks) load_block(nxt);
-        const char *zb = lds + buf * STAGE, *xb = zb + 2 * PZ;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            f16x8 zf[NTW][2];
-#pragma unroll
-            for (int t = 0; t < NTW; ++t) {
-                const int nt = wn * NTW + t;
-                if (nt < NT) { zf[t][0] = h2_tr_frag(zb, RSZ, 32 * nt, ks, lane); zf[t][1] = h2_tr_frag(zb + PZ, RSZ, 32 * nt, ks, lane); }
-            }
-#pragma unroll
-            for (int u = 0; u < KTW; ++u) {
-                const int kt = wk * KTW + u;
-                if (kt < KT && kt < kt_used) {
-                    const f16x8 xh = h2_tr_frag(xb, RSX, 32 * kt, ks, lane), xm = h2_tr_frag(xb + PX, RSX, 32 * kt, ks, lane);
-#pragma unroll
-                    for (int t = 0; t < NTW; ++t) {
-                        if (wn * NTW + t < NT) {
-                            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zf[t][1], xh, acc[t][u], 0, 0, 0);
-                            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zf[t][0], xm, acc[t][u], 0, 0, 0);
-                            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zf[t][0], xh, acc[t][u], 0, 0, 0);
-                        }
-                    }
-                }
-            }
-        }
-        if (nxt < n_blocks) store_block(buf ^ 1);
+    int st_i = 0;                                                               // stage of the running block
+    for (; blk < n_blocks; blk += 2 * step) {
+        int nx = st_i == 2 ? 0 : st_i + 1;
+        body(std::integral_constant<int, 0>{}, blk, lds + st_i * STAGE, lds + nx * STAGE);
+        st_i = nx;
+        __syncthreads();
+        // (an odd block count: this second half then multiplies a stage of zeros -- the conversion of a block past the end)
+        nx = st_i == 2 ? 0 : st_i + 1;
+        body(std::integral_constant<int, 1>{}, blk + step, lds + st_i * STAGE, lds + nx * STAGE);
+        st_i = nx;
         __syncthreads();
     }
     // ---- this workgroup's partial: [NP = 32 NT][KP], true units (scales removed); accumulator (reg r, lane): row n = (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column lane & 31
-    constexpr int NP = 32 * NT, KP = 32 * KT, LDP = KP;
+    constexpr int NP = 32 * NT, KP = 32 * KT, LDP = KP + (BIASV ? 32 : 0);
     float *out = a.partial + (size_t)blockIdx.x * NP * LDP;
     const float dsz = pow2f(-kz), dsx = pow2f(-kx);
+    if (BIASV) {
+        // column sums of dZ: a thread's slot it covers row (tid + 512 it) / Z4 and columns 4 ((tid + 512 it) % Z4) .. + 3, the same columns in every block
+        float *sb = reinterpret_cast<float *>(lds);                            // [RB rows][WZ columns] (the stages are free: the loop's last barrier is behind)
 #pragma unroll
-    for (int t = 0; t < NTW; ++t) {
-        const int nt = wn * NTW + t;
-        if (nt >= NT) continue;
+        for (int it = 0; it < NZS; ++it) {
+            const int idx = tid + 512 * it, row = idx / Z4, c = 4 * (idx - row * Z4);
+            *reinterpret_cast<float4 *>(sb + row * WZ + c) = make_float4(bsum[it][0], bsum[it][1], bsum[it][2], bsum[it][3]);
+        }
+        __syncthreads();
+        if (tid < WZ) {
+            float t = 0.f;
 #pragma unroll
-        for (int u = 0; u < KTW; ++u) {
-            const int kt = wk * KTW + u;
-            if (kt >= KT || kt >= kt_used) continue;
-            const int kc = 32 * kt + (lane & 31);
-            const float d2 = kc == a.K ? 1.0f : dsx;                           // the bias column was staged unscaled
+            for (int r = 0; r < RB; ++r) t += sb[r * WZ + tid];
+            out[(size_t)tid * LDP + a.K] = t;                                   // (K = KP here)
+        }
+    }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int n = 32 * nt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                out[(size_t)n * LDP + kc] = __fmul_rn(__fmul_rn(acc[t][u][r], dsz), d2);
-            }
+    for (int u = 0; u < KTW; ++u) {
+        const int kt = wk * KTW + u;
+        if (kt >= KT) continue;
+        const int kc = 32 * kt + (lane & 31);
+        const float d2 = kc == a.K ? 1.0f : dsx;                               // the bias column was staged unscaled
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = 32 * wn + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            out[(size_t)n * LDP + kc] = __fmul_rn(__fmul_rn(acc[u][r], dsz), d2);
         }
     }
 }
@@ -473,7 +523,7 @@ __global__ __launch_bounds__(256) void h2wgrad_reduce_kernel(const float *__rest
     long long M = M_cap;
     if (d_m) { const long long c = *d_m; if (c < M) M = c; }
     if (n_seg > 1) M = (M < seg_stride ? M : seg_stride) * n_seg;
-    const long long n_blocks = (M + 31) / 32;
+    const long long n_blocks = (M + 15) / 16;
     const int used = (int)(n_blocks < n_wg ? n_blocks : n_wg);
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int n = t / (K + 1), k = t - n * (K + 1);
@@ -584,13 +634,14 @@ extern "C" int hnr_absmax(const float *d_A, int lda, int64_t M_cap, const int64_
     return HNR_OK;
 }
 
-// tile configurations of the weight-gradient kernel (K + 1 columns of X are staged: the bias column): (N <= 256, K <= 287), (N <= 128, K <= 287),
-// (N <= 64, K <= 159)
+// tile configurations of the weight-gradient kernel: NT = 32-column tiles of dZ (N <= 64 / 128 / 256), KT = tiles of the K + 1 staged columns of X
+// (the bias column included), from the built list
 static void h2wgrad_cfg(int N, int K, int *NT, int *KT)
 {
-    if (N <= 64 && K <= 159) { *NT = 2; *KT = 5; }
-    else if (N <= 128) { *NT = 4; *KT = 9; }
-    else { *NT = 8; *KT = 9; }
+    const int kt = K / 32 + 1;
+    if (N <= 64) { *NT = 2; *KT = kt <= 2 ? 2 : (kt <= 3 ? 3 : (kt <= 5 ? 5 : 9)); }
+    else if (N <= 128) { *NT = 4; *KT = kt <= 5 ? 5 : 9; }
+    else { *NT = 8; *KT = kt <= 2 ? 2 : (kt <= 8 ? 8 : 9); }
 }
 
 extern "C" int64_t hnr_h2wgrad_scratch_bytes(int N, int K)
@@ -598,7 +649,7 @@ extern "C" int64_t hnr_h2wgrad_scratch_bytes(int N, int K)
     if (N <= 0 || N > 256 || K <= 0 || K > 287) return -1;
     int NT, KT;
     h2wgrad_cfg(N, K, &NT, &KT);
-    return (int64_t)h2_num_cus() * (32 * NT) * (32 * KT) * 4;
+    return (int64_t)h2_num_cus() * (32 * NT) * (32 * KT + 32) * 4;
 }
 
 extern "C" int hnr_h2wgrad(const float *d_dZ, int ldz, const float *d_X, int ldx, int64_t M_cap, const int64_t *d_m, int n_seg, int64_t seg_stride, int N, int K,
@@ -615,23 +666,29 @@ extern "C" int hnr_h2wgrad(const float *d_dZ, int ldz, const float *d_X, int ldx
     H2WgradArgs a;
     a.dZ = d_dZ; a.ldz = ldz; a.X = d_X; a.ldx = ldx; a.d_m = reinterpret_cast<const long long *>(d_m); a.M_cap = M_cap; a.n_seg = n_seg; a.seg_stride = seg_stride;
     a.N = N; a.K = K;
-    a.zmax = d_absmax_z; a.xmax = d_absmax_x; a.partial = (float *)d_scratch;
-    const int64_t blocks = (M_cap * n_seg + 31) / 32;
+    a.zmax = d_absmax_z; a.xmax = d_absmax_x; a.partial = (float *)d_scratch; a.dbg = 0;
+    const int64_t blocks = (M_cap * n_seg + 15) / 16;
     const int n_cu = h2_num_cus();
-    int grid = (int)((blocks + 7) / 8 < n_cu ? (blocks + 7) / 8 : n_cu);           // at least 8 row blocks per workgroup: every workgroup writes (and the reduction reads) a whole partial
+    int grid = (int)((blocks + 15) / 16 < n_cu ? (blocks + 15) / 16 : n_cu);           // at least 8 row blocks per workgroup: every workgroup writes (and the reduction reads) a whole partial
     if (grid < 1) grid = 1;
     hipStream_t st = (hipStream_t)stream;
-#define HNR_H2WG_CASE(NT_, KT_, WN_, WK_)                                                                                               \
-    if (NT == NT_ && KT == KT_) {                                                                                                       \
-        constexpr int rsz = ((32 * NT_ * 2 - 64 + 255) & ~255) + 64, rsx = ((32 * KT_ * 2 - 64 + 255) & ~255) + 64;                               \
-        constexpr int ldsb = 2 * (2 * 32 * rsz + 2 * 32 * rsx);                                                                         \
-        HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(h2wgrad_kernel<NT_, KT_, WN_, WK_>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb)); \
-        h2wgrad_kernel<NT_, KT_, WN_, WK_><<<grid, 512, ldsb, st>>>(a);                                                                 \
+#define HNR_H2WG_CASE(NT_, KT_)                                                                                                         \
+    if (NT == NT_ && KT == KT_ && !biasv && !(NT_ == 8 && KT_ == 9)) {                                                                                                       \
+        constexpr int rsz = ((32 * NT_ * 2 - 64 + 255) & ~255) + 64, rsx = ((32 * KT_ * 2 - 64 + 255) & ~255) + 64;                     \
+        constexpr int ldsb = 3 * (2 * 16 * rsz + 2 * 16 * rsx);                                                                    \
+        HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(h2wgrad_kernel<NT_, KT_, 8 / NT_>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb)); \
+        h2wgrad_kernel<NT_, KT_, 8 / NT_><<<grid, 512, ldsb, st>>>(a);                                                                  \
     }
-    HNR_H2WG_CASE(8, 9, 8, 1) HNR_H2WG_CASE(4, 9, 4, 2) HNR_H2WG_CASE(2, 5, 2, 4)
+    const bool biasv = false;
+    if (NT == 8 && KT == 9) {
+        constexpr int rsz = ((32 * 8 * 2 - 64 + 255) & ~255) + 64, rsx = ((32 * 9 * 2 - 64 + 255) & ~255) + 64, ldsb = 3 * (2 * 16 * rsz + 2 * 16 * rsx);
+        HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(h2wgrad_kernel<8, 9, 1, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb));
+        h2wgrad_kernel<8, 9, 1, 0, 1><<<grid, 512, ldsb, st>>>(a);
+    }
+    HNR_H2WG_CASE(8, 9) HNR_H2WG_CASE(8, 8) HNR_H2WG_CASE(8, 2) HNR_H2WG_CASE(4, 9) HNR_H2WG_CASE(4, 5) HNR_H2WG_CASE(2, 9) HNR_H2WG_CASE(2, 5) HNR_H2WG_CASE(2, 3) HNR_H2WG_CASE(2, 2)
 #undef HNR_H2WG_CASE
     HNR_LAUNCH_CHECK();
-    const int NP = 32 * NT, LDP = 32 * KT;
+    const int NP = 32 * NT, LDP = 32 * KT + (biasv ? 32 : 0);
     const int total = N * (K + 1);
     h2wgrad_reduce_kernel<<<(total + 255) / 256, 256, 0, st>>>((const float *)d_scratch, grid, reinterpret_cast<const long long *>(d_m), M_cap, NP, LDP, N, K,
                                                               d_dW, lddw, d_db, accumulate, n_seg, seg_stride);
