@@ -113,7 +113,7 @@ def build_world(args, dev, rank):
     return sc, opt, agg, cloud, rnd, cam
 
 
-def render_frame(rnd, cloud, cam, sc, chunk, timers=None):
+def render_frame(rnd, cloud, cam, sc, chunk, timers=None, statuses=None):
     R = cam["raydir"].shape[0]
     chunk = R if chunk <= 0 else chunk
     cols = []
@@ -121,11 +121,14 @@ def render_frame(rnd, cloud, cam, sc, chunk, timers=None):
         out = rnd.render_rays(cloud, cam["raydir"][lo:lo + chunk], cam["campos"], cam["camrot"], cam["bg"], sc.near, sc.far,
                               cam["c2w_nearest"], cam["campos_nearest"], cam["intrinsic"], cam["images"],
                               w2c_nearest=cam["w2c_nearest"], timers=timers)
+        if statuses is not None and out.get("status") is not None:
+            statuses.append(dict(status=out["status"]))
         cols.append(out["coarse_raycolor"])
     return cols[0] if len(cols) == 1 else torch.cat(cols, dim=0), out
 
 
-TRAFFIC_JSON = "r02_traffic.json"
+TRAFFIC_JSON = "r03_traffic.json"
+CHAIN_PMC_JSON = "r03_chain_pmc.json"
 
 
 def pmc_traffic():
@@ -181,6 +184,26 @@ def cpu_baseline(args, sc, opt, agg, cam, gpu_colors):
     mse = float(np.mean((refc.astype(np.float64) - got.astype(np.float64)) ** 2))
     psnr = 99.0 if mse == 0 else -10.0 * np.log10(mse)
     dt3 = float(np.mean(times))
+    # the error bound over the WHOLE frame, not one block: further 48x48 blocks spread over the frame (corners, edges, between), same oracle (one grid
+    # build for all of them: these passes are checks, not timings)
+    from oracle import query_oracle as qo, render_oracle as ro
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    hp = qo.hyperparameters(sc.xyz, opt.vsize, opt.vscale, opt.kernel_size, opt.ranges, opt.radius_limit_scale)
+    og = qo.OracleGrid(sc.xyz, hp["origin"], hp["cell"], hp["dims"], opt.query_size, opt.P, opt.max_o)
+    tm = qo.tmid_table(sc.near, sc.far, opt.z_depth_dim)
+    blocks = [dict(x0=int(x0), y0=int(y0), max_abs=float(np.abs(refc - got).max()), psnr_db=round(psnr, 2))]
+    for fx, fy in ((0.0, 0.0), (1.0, 0.0), (0.0, 1.0), (1.0, 1.0), (0.5, 0.05), (0.25, 0.6), (0.8, 0.35)):
+        bx, by = int(fx * (W - side)), int(fy * (H - side))
+        bi = ((by + np.arange(side))[:, None] * W + (bx + np.arange(side))[None, :]).reshape(-1)
+        q = og.query(cam["c2w"][:3, 3], cam["rays_np"][bi], tm, opt.SR, opt.K, hp["radius2"], opt.kernel_size)
+        with torch.no_grad():
+            rb = ro.render(tt(sc.xyz), tt(sc.emb), tt(sc.conf), tt(sc.dir), tt(sc.color), sd, q, tt(cam["c2w"][:3, 3])[None], tt(cam["c2w"][:3, :3])[None],
+                           tt(cam["rays_np"][bi])[None], tt(sc.bg_color)[None], tt(sc.c2w_nearest)[None], tt(sc.c2w_nearest[:, :3, 3])[None],
+                           tt(sc.intrinsic)[None], tt(sc.images_nearest)[None], opt.vsize)["full_coarse_raycolor"][0].numpy()
+        gb = gpu_colors[bi]
+        m2 = float(np.mean((rb.astype(np.float64) - gb.astype(np.float64)) ** 2))
+        blocks.append(dict(x0=bx, y0=by, max_abs=float(np.abs(rb - gb).max()), psnr_db=round(99.0 if m2 == 0 else -10.0 * np.log10(m2), 2)))
+    worst = max(b["max_abs"] for b in blocks)
     # C1
     sc1 = scenes.make_scene("chair", 100000, 0)
     sc1.opt.agg_axis_weight = None
@@ -198,7 +221,9 @@ def cpu_baseline(args, sc, opt, agg, cam, gpu_colors):
                 c1_chair=dict(value=round(rays1.shape[0] / float(np.mean(t1)), 1), unit="rays/s",
                               sample="C1: chair 200x200 camera, one 32x32 = 1024-ray batch, 100 k points, SR 80, P 12; 1 warm-up + 3 timed passes "
                                      "(%.2f s each)" % float(np.mean(t1))),
-                psnr_gpu_vs_oracle_db=round(psnr, 2), max_abs_gpu_vs_oracle=float(np.abs(refc - got).max()))
+                psnr_gpu_vs_oracle_db=round(min(b["psnr_db"] for b in blocks), 2), max_abs_gpu_vs_oracle=worst,
+                checked_blocks=blocks, tolerance="fp32 max-abs <= 1e-4 on coarse_raycolor (SURVEY 8d); worst of %d blocks of %dx%d rays spread over the frame" % (
+                    len(blocks), side, side))
 
 
 def train_leg(args, sc, opt, agg, cloud, rnd, cam, dev, steps=5, warmup=2):
@@ -351,6 +376,7 @@ def main():
     pad = max(int(s.numel()) for s in shards)
     shards_at = [s if rehearsal else s.to(dev) for s in shards] if rank == 0 else None     # where the gathered rows live (rehearsal: host)
     gather_ev = []
+    statuses = []                                             # device status words of every launch of the timed loop (read once, after it)
 
     def step(timers=None, time_gather=False):
         rnd._fm_key = None          # a new frame has new reference views: their feature pyramid is rebuilt inside every step
@@ -360,11 +386,11 @@ def main():
             # profiles/README.md: 216 of 285 200 pixels of a block); the rehearsal checks the sharding / gather path, not throughput
             for r in range(world):
                 if r == rank:
-                    col, out = render_frame(rnd, cloud, cam, sc, args.chunk, timers)
+                    col, out = render_frame(rnd, cloud, cam, sc, args.chunk, timers, statuses)
                     torch.cuda.synchronize()
                 dist.barrier()
         else:
-            col, out = render_frame(rnd, cloud, cam, sc, args.chunk, timers)
+            col, out = render_frame(rnd, cloud, cam, sc, args.chunk, timers, statuses)
         frame = col
         if world > 1:
             # reassemble the frame (strong) / the N frames (weak) on rank 0: ONE gather over xGMI, equal-size blocks
@@ -404,9 +430,15 @@ def main():
         col, out, frame = step(timers, time_gather=True)
     barrier()
     dt = time.perf_counter() - t0
-    tmax = coll(torch.tensor([dt], dtype=torch.float64, device=dev))
+    # every rank: an overflow of a single-call workspace (samples dropped) must fail the run, not shade the number
+    rnd.check_status(statuses)
+    tmine = coll(torch.tensor([dt], dtype=torch.float64, device=dev))
+    per_rank = [tmine.clone() for _ in range(world)]
+    tmax = tmine.clone()
     if world > 1:
+        dist.all_gather(per_rank, tmine)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    per_rank_ms = [round(float(t.item()) / args.steps * 1e3, 3) for t in per_rank]
     dt = float(tmax.item())
     if rank == 0 and args.dump_colors:
         np.save(args.dump_colors, frame.detach().cpu().numpy())
@@ -433,7 +465,8 @@ def main():
         if lin:
             n = sum(v["launches"] for v in lin.values())
             t_lin = dict(hbm_bytes=sum(v["hbm_bytes"] * v["launches"] for v in lin.values()) / max(n, 1))
-        t_q = [v for k, v in pmc.items() if "march_kernel" in k or "knn3_kernel" in k]
+        knn_name = "knn3_kernel<8, %d>" % (1 if rnd.knn_order == "sorted" else 0)
+        t_q = [v for k, v in pmc.items() if "march_kernel" in k or knn_name in k]
         if counts is not None:
             n_rows, n_valid = int(counts[CNT["NEIGHBOURS"]]), int(counts[CNT["SAMPLES_VALID"]])
             s_all, cells, cand = int(counts[CNT["SAMPLES"]]), int(counts[CNT["CELLS_VISITED"]]), int(counts[CNT["CANDIDATES"]])
@@ -473,6 +506,12 @@ def main():
                                  "(4 for the %d samples with three or four neighbours, 2 for the %d with one or two) costs %.1f %% extra rows" % (
                                      n_small, n_tiny, 100.0 * (rows_pad / max(n_rows, 1) - 1.0)),
                             neighbour_stage=dict(chain_ms=round(ms_ch, 3), gather_ms=round(stage_ms.get("chain_gather", 0.0), 3)))
+                try:
+                    pm = json.load(open(os.path.join(ROOT, "profiles", CHAIN_PMC_JSON)))
+                    roof["mfma_busy"] = pm["chain_ws_kernel"]["mfma_busy_fraction"]
+                    roof["mfma_busy_source"] = "profiles/%s (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles from GRBM_GUI_ACTIVE), separate passes)" % CHAIN_PMC_JSON
+                except Exception:
+                    roof["mfma_busy"] = None
             elif split and ms_3 > 0:
                 # dominant kernel: the split-bf16 dense layer.  Algorithmic fp32 flops of the three layers = 2 M N K; the kernel
                 # issues SIX bf16 MFMA products per fp32 product (exact 3-way operand split, csrc/linear_s3.hip), K rounded up to 16.
@@ -587,6 +626,7 @@ def main():
                        "parallelism": (("one fixed frame ray-sharded x%%d (%s), one RCCL gather" % ("scan lines dealt round-robin" if args.shard == "lines" else "contiguous scan-line blocks")) if strong else
                                        "one frame per rank x%d, one RCCL gather") % world},
             "gather_ms": (round(sum(a.elapsed_time(b) for a, b in gather_ev) / max(len(gather_ev), 1), 4) if gather_ev else None),
+            "per_rank_ms_per_step": per_rank_ms, "status_words_checked": len(statuses),
             "roofline": roof, "roofline_query": roof_q, "roofline_train": (train or {}).get("roofline_train"), "cpu_baseline": cpu,
             "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
             "amortised_ms": amort, "train_step": train, "grid": rnd.querier.last_grid_stats,

@@ -44,8 +44,11 @@ Layout carve(void *ws, size_t ws_bytes, const hnr_render_params *p, bool *ok)
     L.chain_ws = c.take<char>((size_t)hnr_chain_workspace_bytes(p->cap_samples));
     L.X5 = c.take<float>(cap * 280); L.sigma = c.take<float>(cap + 1);
     L.CF = c.take<float>(cap * 128); L.pre = c.take<float>(cap * 64);
-    L.X6 = c.take<float>(V * cap * 48); L.vmask = c.take<float>(V * cap + 1); L.row_s = c.take<int32_t>(V * cap + 1);
-    L.M1 = c.take<float>(V * cap * 64);
+    // the per-(view, sample) rows exist only on the un-fused merge path (V != 4): hnr_merge_stage keeps them on chip (12 GB of the bench frame's
+    // worst-case carve otherwise)
+    const size_t VR = V == 4 ? 0 : V;
+    L.X6 = c.take<float>(VR * cap * 48); L.vmask = c.take<float>(VR * cap + 1); L.row_s = c.take<int32_t>(VR * cap + 1);
+    L.M1 = c.take<float>(VR * cap * 64);
     L.X7 = c.take<float>(cap * 92); L.Y1 = c.take<float>(cap * 48);
     L.bytes = (c.off + 255) & ~(size_t)255;
     if (ok) *ok = c.ok;

@@ -33,6 +33,8 @@ def render_image(renderer, cloud, frame, chunk_rays=0, sharded=None, group=None)
     if sharded is None:
         sharded = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
 
+    statuses = []
+
     def render(rays):
         outs = []
         step = rays.shape[0] if chunk_rays <= 0 else chunk_rays
@@ -41,6 +43,7 @@ def render_image(renderer, cloud, frame, chunk_rays=0, sharded=None, group=None)
                                      sq(frame["bg_color"], 1), near, far, sq(frame["c2w_nearest"], 3), sq(frame["campos_nearest"], 2),
                                      sq(frame["intrinsic_nearest"], 2), sq(frame["images_nearest"], 4),
                                      frame_weight=None if fw is None else sq(fw, 1))
+            statuses.append(o)
             outs.append(torch.cat([o["coarse_raycolor"], o["ray_mask"].to(torch.float32)[:, None]], dim=1))
         return outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
 
@@ -57,6 +60,9 @@ def render_image(renderer, cloud, frame, chunk_rays=0, sharded=None, group=None)
         return render(rays)
 
     rows = parallel.render_sharded(render_auto, raydir, group=group) if sharded else render_auto(raydir)
+    # the device status words of this rank's launches, read once per frame (after everything is queued): an overflow of a workspace capacity
+    # must not pass silently
+    renderer.check_status([dict(status=o.get("status")) for o in statuses])
     if rows is None:
         return None
     col, mask = rows[:, :3].contiguous(), rows[:, 3].to(torch.int8)

@@ -49,9 +49,11 @@ def probe_hole(frames, height, width, far_thresh=0.0, opacity_thresh=0.7, prob_m
         ids = probe_select(output, pixel_idx, gt_image, bg, height, width, far_thresh, opacity_thresh)
         take = lambda k: output[k].reshape(-1, output[k].shape[-1]).index_select(0, ids)
         xyz = cat(xyz, take("ray_max_sample_loc_w"))
-        conf = cat(conf, take("shading_avg_conf")) * prob_mul
-        col = cat(col, take("shading_avg_color"))
-        dr = cat(dr, take("shading_avg_dir"))
+        # a cloud without confidence / colour / direction buffers renders these outputs as None: the reference then returns None for them
+        # (run/train_ft.py:545-550)
+        conf = cat(conf, take("shading_avg_conf")) * prob_mul if output.get("shading_avg_conf") is not None else None
+        col = cat(col, take("shading_avg_color")) if output.get("shading_avg_color") is not None else None
+        dr = cat(dr, take("shading_avg_dir")) if output.get("shading_avg_dir") is not None else None
         emb = cat(emb, take("shading_avg_embedding"))
     if xyz is None:
         raise HnrError("probe_hole: no frame given")

@@ -98,6 +98,7 @@ class NeuralPoints(nn.Module):
             # the reference differentiates through sampled_xyz / dists (neural_points.py:132-138); the HIP backward carries no
             # position gradient, and an optimiser that silently never moves xyz would be a different training run
             raise HnrError("xyz_grad > 0 is not implemented (no shipped script sets it): the HIP backward has no gradient w.r.t. point positions")
+        fresh_conf = False
         if getattr(opt, "load_points", 0) == 1:
             saved = torch.load(checkpoint, map_location=device) if checkpoint else None
             if saved is None or "neural_points.xyz" not in saved:
@@ -112,10 +113,16 @@ class NeuralPoints(nn.Module):
                 saved.setdefault("neural_points.points_embeding", emb)
                 if "neural_points.points_conf" not in saved and not checkpoint:
                     saved["neural_points.points_conf"] = conf
+                    fresh_conf = True
             par = lambda k, g: nn.Parameter(saved[k], requires_grad=g) if k in saved else None
             self.xyz = nn.Parameter(saved["neural_points.xyz"], requires_grad=opt.xyz_grad > 0)
             self.points_embeding = par("neural_points.points_embeding", opt.feat_grad > 0)
-            self.points_conf = par("neural_points.points_conf", opt.conf_grad > 0)
+            if fresh_conf:
+                # a cloud initialised from a file: the reference keeps points_conf as a plain ones tensor (neural_points.py:303) -- not a Parameter,
+                # not in the state_dict, never seen by an optimiser
+                self.points_conf = saved["neural_points.points_conf"]
+            else:
+                self.points_conf = par("neural_points.points_conf", opt.conf_grad > 0)
             self.points_dir = par("neural_points.points_dir", opt.dir_grad > 0)
             self.points_color = par("neural_points.points_color", opt.color_grad > 0)
             self.Rw2c = torch.eye(3, device=self.xyz.device, dtype=self.xyz.dtype)

@@ -93,11 +93,15 @@ class HybridRenderer:
 
     # -- per-frame reference-view features, cached -------------------------------------------------
     def feature_map(self, images_nearest):
+        ev = getattr(self, "_fm_event", None)
+        if ev is not None:
+            torch.cuda.current_stream(images_nearest.device).wait_event(ev)      # (a map built on the side stream: order this stream behind it)
         key = (images_nearest.data_ptr(), tuple(images_nearest.shape), images_nearest._version,
                tuple((p.data_ptr(), p._version) for p in self.agg.parameters()))
         if key != self._fm_key:
             self._fm = self.agg.image_features(images_nearest)
             self._fm_key = key
+            self._fm_event = None                   # built on the calling stream (feature_map_async records an event when it builds on the side stream)
             # keep the keyed tensor alive: a freed buffer's address (and version 0) can be handed to the NEXT frame's images by the
             # caching allocator, which would look like a cache hit
             self._fm_src = images_nearest
@@ -109,7 +113,9 @@ class HybridRenderer:
         key = (images_nearest.data_ptr(), tuple(images_nearest.shape), images_nearest._version,
                tuple((p.data_ptr(), p._version) for p in self.agg.parameters()))
         if key == self._fm_key:
-            return self._fm, None
+            # a cached map may still be in flight on the side stream (built for a launch on another stream, or for a launch that fell back to the
+            # staged path): hand its event out until the consumer has been ordered behind it -- an extra wait on a complete event costs nothing
+            return self._fm, getattr(self, "_fm_event", None)
         cur = torch.cuda.current_stream(images_nearest.device)
         if getattr(self, "_side_stream", None) is None:
             self._side_stream = torch.cuda.Stream(device=images_nearest.device)
@@ -411,6 +417,23 @@ class HybridRenderer:
             res.update(weight=w_out, conf_coefficient=c_out)
         return res
 
+    @staticmethod
+    def check_status(outs):
+        """Reads the status word(s) of single-call launches (ONE host read for any number of launches): raises when a workspace capacity was
+        exceeded -- the frame would be missing samples.  `outs`: an output dict of render_rays or a list of them (dicts of the staged path carry
+        no status word: their buffers are sized exactly)."""
+        if isinstance(outs, dict):
+            outs = [outs]
+        st = [o["status"] for o in outs if isinstance(o, dict) and o.get("status") is not None]
+        if not st:
+            return
+        st = torch.stack(st).cpu()
+        bad = (st[:, 0] != 0).nonzero().reshape(-1)
+        if bad.numel():
+            i = int(bad[0])
+            raise HnrError("hnr_render_forward: launch %d of %d produced %d valid shading samples, more than its workspace capacity; the extra samples "
+                           "were dropped (render in chunks: driver.render_image(chunk_rays=...))" % (i, st.shape[0], int(st[i, 1])))
+
     # -- the whole path -------------------------------------------------------------------------------
     def render_rays(self, cloud, raydir, campos, camrot, bg_color, near, far, c2w_nearest, campos_nearest, intrinsic_nearest,
                     images_nearest, frame_weight=None, want_weights=False, w2c_nearest=None, timers=None, pad=False):
@@ -442,6 +465,9 @@ class HybridRenderer:
                                     intrinsic_nearest, fm, frame_weight, want_weights, timers, fm_ready=fm_ready)
             if res is not None:
                 return res
+            if fm_ready is not None:
+                # the single call did not run (workspace larger than the free memory): the staged path below reads the map on the current stream
+                torch.cuda.current_stream(raydir.device).wait_event(fm_ready)
         with _Stage(timers, "query"):
             # pad=False: only kept slots are written (no -1 / 0 padding stores); everything downstream takes ray_nsamp
             qres = Q.march_query(grid, campos, raydir, tmid, self.opt.SR, self.opt.K, np.float32(hp[0] ** 2), self.opt.kernel_size, pad=pad,

@@ -123,3 +123,35 @@ def test_fused_merge_stage_equals_its_three_kernel_form(tag):
     assert float((a["decoded"] - b["decoded"]).abs().max()) < 2e-6
     assert float((a["coarse_raycolor"] - b["coarse_raycolor"]).abs().max()) < 2e-6
     assert torch.equal(a["decoded"][..., 0], b["decoded"][..., 0])              # densities do not pass through the image branch
+
+
+def test_c1_chair_batch_through_the_single_call_matches_the_imported_reference():
+    """BASELINE config C1 (nerf_synthetic/chair 200x200, one 32x32 = 1024-ray batch, 100 k points, SR 80, P 12, max_o 410000;
+    dev_scripts/w_n360/chair_hybrid.sh) on the HIP path: hnr_render_forward against tests/golden/render_c1_chair.npz -- the outputs of the imported
+    reference's NeuralPointsRayMarching.forward + fill_invalid on the same batch (models/neural_points_volumetric_model.py:257-391, :87-126)."""
+    from tests.golden_io import c1_chair
+    from hybridneuralrendering_amd.aggregator import PointAggregator
+    from hybridneuralrendering_amd.render import HybridRenderer, PointCloud
+    sc, pix, raydir, sd, exp = c1_chair()
+    opt = sc.opt
+    assert raydir.shape == (1024, 3) and opt.SR == 80 and opt.P == 12 and opt.max_o == 410000 and sc.xyz.shape[0] == 100000
+    dev = torch.device("cuda:0")
+    agg = PointAggregator(opt)
+    agg.load_state_dict(sd, strict=True)
+    agg = agg.to(dev)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    rnd = HybridRenderer(opt, agg, dev)
+    assert rnd.single_call and rnd.dense == "f16x2" and rnd.knn_order == "reference"
+    cloud = PointCloud(t(sc.xyz), t(sc.emb), t(sc.conf), t(sc.dir), t(sc.color))
+    out = rnd.render_rays(cloud, t(raydir), t(sc.c2w[:3, 3]), t(sc.c2w[:3, :3]), t(sc.bg_color), sc.near, sc.far, t(sc.c2w_nearest),
+                          t(sc.c2w_nearest[:, :3, 3]), t(sc.intrinsic), t(sc.images_nearest), w2c_nearest=torch.inverse(torch.from_numpy(sc.c2w_nearest)).to(dev))
+    torch.cuda.synchronize()
+    assert "status" in out and int(out["status"][0]) == 0                       # the single-call entry ran; no capacity overflow
+    counts = out["counts"].cpu().numpy()
+    from hybridneuralrendering_amd._lib import CNT
+    assert int(counts[CNT["SAMPLES"]]) == exp["counts"]["n_samples"] and int(counts[CNT["NEIGHBOURS"]]) == exp["counts"]["n_neighbours"]
+    np.testing.assert_array_equal(out["ray_mask"].cpu().numpy(), exp["ray_mask"].reshape(-1))
+    got = out["coarse_raycolor"].cpu().numpy()
+    assert np.abs(got - exp["full_coarse_raycolor"][0]).max() < 2e-4 and _psnr(got, exp["full_coarse_raycolor"][0]) > 70.0       # fp32 max-abs tolerance of the path (SURVEY 8d: 1e-4 on the bench frame)
+    np.testing.assert_allclose(out["coarse_point_opacity"].cpu().numpy(), exp["full_coarse_point_opacity"][0], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(out["coarse_is_background"].cpu().numpy().reshape(-1), exp["full_coarse_is_background"].reshape(-1), rtol=0, atol=2e-4)

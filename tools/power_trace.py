@@ -62,10 +62,10 @@ def main():
     rows, t0, last_smi = [], time.time(), 0.0
     while child.poll() is None:
         t = time.time() - t0
-        for p, f in hw[:1]:
+        for ci, (p, f) in enumerate(hw):                       # every card the box exposes: the one under load is picked in the summary
             pw = read_num(p) if p else None
             fr = read_num(f) if f else None
-            rows.append((t, None if pw is None else pw / 1e6, None if fr is None else fr / 1e6, "hwmon"))
+            rows.append((t, None if pw is None else pw / 1e6, None if fr is None else fr / 1e6, "hwmon%d" % ci))
         if t - last_smi > 1.0:
             last_smi = t
             pw, mhz = smi_sample()
@@ -81,10 +81,14 @@ def main():
     # the rendering phase = the last steps * ms_per_step seconds before the child exits (minus ~1 s of teardown)
     t_end = rows[-1][0] if rows else 0.0
     span = (a.steps * ms / 1e3) if ms else 5.0
-    busy = [r for r in rows if r[3] == "hwmon" and t_end - 1.0 - span <= r[0] <= t_end - 1.0]
+    window = [r for r in rows if r[3].startswith("hwmon") and t_end - 1.0 - span <= r[0] <= t_end - 1.0]
+    cards = sorted(set(r[3] for r in window))
+    mean_p = {c: (sum(r[1] for r in window if r[3] == c and r[1] is not None) / max(1, sum(1 for r in window if r[3] == c and r[1] is not None))) for c in cards}
+    card = max(mean_p, key=mean_p.get) if mean_p else None         # the GPU this process's child was given = the one drawing power
+    busy = [r for r in window if r[3] == card]
     pws = [r[1] for r in busy if r[1] is not None]
     cks = [r[2] for r in busy if r[2] is not None]
-    print(json.dumps(dict(ms_per_step=ms, samples=len(busy), power_w_mean=sum(pws) / len(pws) if pws else None, power_w_max=max(pws) if pws else None,
+    print(json.dumps(dict(ms_per_step=ms, card=card, samples=len(busy), power_w_mean=sum(pws) / len(pws) if pws else None, power_w_max=max(pws) if pws else None,
                           sclk_mhz_mean=sum(cks) / len(cks) if cks else None, sclk_mhz_min=min(cks) if cks else None, sclk_mhz_max=max(cks) if cks else None,
                           hwmon=[list(x) for x in hw], smi=[r for r in rows if r[3] == "rocm-smi"][-3:])))
     return child.returncode
