@@ -100,7 +100,7 @@ struct H2LinArgs {
 template <int S>
 __global__ __launch_bounds__(256, 2) void h2lin_kernel(H2LinArgs a)
 {
-    constexpr int RT = 2, SLOT = RT * 2048, ROWS = 32 * RT;
+    constexpr int RT = 2, SLOT = RT * 2048 + 32, ROWS = 32 * RT;             // (+ 32 B between the k steps' slots: the prologue's plane stores of one row spread over the banks)
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, j = lane & 31;
     long long M = a.M_cap, n_unit = a.M_cap;
@@ -610,7 +610,7 @@ extern "C" int hnr_h2lin(const float *d_A, int lda, int64_t M_cap, const int64_t
     hipStream_t st = (hipStream_t)stream;
 #define HNR_H2LIN_CASE(S_)                                                                                                              \
     if (S == S_) {                                                                                                                      \
-        constexpr int ldsb = S_ * 4096 + 64 * 4;                                                                                        \
+        constexpr int ldsb = S_ * (4096 + 32) + 64 * 4;                                                                                        \
         HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(h2lin_kernel<S_>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb)); \
         h2lin_kernel<S_><<<grid, 256, ldsb, st>>>(a);                                                                                   \
         HNR_LAUNCH_CHECK();                                                                                                             \

@@ -13,7 +13,9 @@
 
 namespace hnr {
 
-constexpr int ML_SLOT = 8192;                      // LDS bytes per k step of the activation planes: [row tile 4][plane 2][64 lanes][16 B]
+constexpr int ML_PAD = 32;                         // bytes between the k steps' slots: the prologue's 8-byte plane stores of one row go to 4 .. 16 k steps at once, and at a
+                                                   // stride of a whole slot (a multiple of 128 B) they all hit the same banks (rocprofv3: half of the kernels' LDS cycles were conflicts)
+constexpr int ML_SLOT = 8192 + ML_PAD;             // LDS bytes per k step of the activation planes: [row tile 4][plane 2][64 lanes][16 B] + pad
 constexpr int ML_WSTEP = 8192;                     // weight image bytes per k step: [column tile 4][plane 2][64 lanes][16 B]
 constexpr int ML_META_FLOATS = 4 * 128 + 4 + 4;    // bias[4][128], descale[4], max|W| bits[4]
 constexpr int ML_DESC = 4 * 128, ML_WMAX = 4 * 128 + 4;
@@ -70,7 +72,7 @@ template <int S0, int S1, int S2, int S3, int MODE, int RT = 4>
 __global__ __launch_bounds__(256, mlp3_wgs_per_cu(S0, RT, MODE)) void mlp3_kernel(MlpArgs a)
 {
     static_assert(MODE != 1 || RT == 4, "the merge stage is built on 128-row tiles (32 samples x 4 views)");
-    constexpr int SLOT = RT * 2048, ROWS = 32 * RT;                        // LDS bytes per k step of the planes: [row tile RT][plane 2][64 lanes][16 B]
+    constexpr int SLOT = RT * 2048 + ML_PAD, ROWS = 32 * RT;               // LDS bytes per k step of the planes: [row tile RT][plane 2][64 lanes][16 B] + pad
     constexpr int SMAX3 = S0 > S1 ? (S0 > S2 ? S0 : S2) : (S1 > S2 ? S1 : S2), SMAX = SMAX3 > S3 ? SMAX3 : S3;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, j = lane & 31;
@@ -680,7 +682,7 @@ static int mlp3_forward_impl(const float *d_A, int lda, int64_t M_cap, const int
         if (S1_ <= 4 && S2_ <= 4 && S3_ == 0 && RT_ >= 2 && N[2] > 64) {   /* the row-split wave mapping of the narrow variants: two column tiles */ \
             set_error("hnr_mlp3_forward: N[2] = %d > 64 with 64-wide hidden layers is not built", N[2]); return HNR_ERR_BADARG; }             \
         constexpr int smax3 = S0_ > S1_ ? (S0_ > S2_ ? S0_ : S2_) : (S1_ > S2_ ? S1_ : S2_), smax = smax3 > S3_ ? smax3 : S3_;          \
-        constexpr int ldsb = smax * RT_ * 2048 + 32 * RT_ * 4 * 4 + 32 * RT_ * 4;                                                       \
+        constexpr int ldsb = smax * (RT_ * 2048 + ML_PAD) + 32 * RT_ * 4 * 4 + 32 * RT_ * 4;                                                       \
         const int64_t tiles = (M_cap + 32 * RT_ - 1) / (32 * RT_);                                                                      \
         const int wgs = mlp3_wgs_per_cu(S0_, RT_, 0) * n_cu, grid = (int)(tiles < wgs ? tiles : wgs);                                              \
         static bool attr = false;                                                                                                       \

@@ -1,4 +1,4 @@
-"""Summarise the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py (tools/run_traffic.sh) into profiles/r02_traffic.json.
+"""Summarise the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py (tools/run_traffic.sh) into profiles/r03_traffic.json.
 
     bash tools/run_traffic.sh                      # on the GPU box: writes gpurun_out/traffic5/{pmc_FETCH_SIZE,pmc_WRITE_SIZE,stats}
     python tools/collect_traffic.py gpurun_out/traffic5
@@ -39,4 +39,4 @@ note = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `
         "(gfx950 tallies 128-B requests as 64 B on wide coalesced reads; calibrated in round 1 on ksum_kernel: 12.4 GB raw vs 24.3 GB of rows actually read). "
         "chain_ws_kernel<0> = the fused per-neighbour chain (one launch per frame); its weight image (848 KiB) is re-read by every workgroup tile from L2, "
         "which these memory-side counters do not see.")
-json.dump(dict(note=note, kernels=kern), open(os.path.join(ROOT, "profiles", "r02_traffic.json"), "w"), indent=1)
+json.dump(dict(note=note, kernels=kern), open(os.path.join(ROOT, "profiles", "r03_traffic.json"), "w"), indent=1)
