@@ -455,11 +455,9 @@ def main():
         # recorded on the launch stream inside the timed region
         roof, roof_q = None, None
         pmc = pmc_traffic() if (int(args.points) == 2000000 and args.scene == "scene0241" and args.chunk <= 0) else {}
-        split = getattr(rnd, "dense", "f32") == "bf16x3"
         fused = getattr(rnd, "dense", "f32") == "f16x2" and opt.K == 8
-        # the per-neighbour layers: bf16x3 -> three linear_s3w_kernel launches (block1.2, block3.0, block3.2) + the fp32-MFMA K=60
-        # layer with its gathered addend; f32 -> four linear_f32_kernel launches
-        kname = "linear_s3w_kernel" if split else "linear_f32_kernel<2, 2, 1, 0, 4"
+        # HNR_DENSE=f32: four linear_f32_kernel launches per frame for the per-neighbour layers
+        kname = "linear_f32_kernel<2, 2, 1, 0, 4"
         lin = {k: v for k, v in pmc.items() if kname in k}
         t_lin = None
         if lin:
@@ -486,7 +484,7 @@ def main():
                 alg = 2.0 * n_rows * 256 * (60 + 256 + 263 + 256) + 2.0 * n_rows * 256          # executed layers + alpha branch (SURVEY 8d counts 284 columns
                 ach = issued / (ms_ch * 1e-3) / 1e12                                             # for block1.0: 224 of them live in the per-point table)
                 variant = os.environ.get("HNR_CHAIN_RT", "16")
-                kname = {"16": "chain_ws_kernel", "4": "chain_kernel<4", "2": "chain_kernel<2", "8": "chain2_kernel"}.get(variant, "chain_ws_kernel")
+                kname = {"16": "chain_ws_kernel", "4": "chain_kernel<4"}.get(variant, "chain_ws_kernel")
                 t_ch = [v for k, v in pmc.items() if kname in k]
                 roof = dict(kernel="%s: block1 -> block3 -> alpha + K-sums fused (1 launch, %d valid neighbour rows in %d padded rows)" % (
                                 {"chain_ws_kernel": "chain_ws_kernel<0> (weight-stationary, epilogue pieces between the wave's own MFMAs)"}.get(kname, kname), n_rows, rows_pad),
@@ -512,26 +510,6 @@ def main():
                     roof["mfma_busy_source"] = "profiles/%s (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles from GRBM_GUI_ACTIVE), separate passes)" % CHAIN_PMC_JSON
                 except Exception:
                     roof["mfma_busy"] = None
-            elif split and ms_3 > 0:
-                # dominant kernel: the split-bf16 dense layer.  Algorithmic fp32 flops of the three layers = 2 M N K; the kernel
-                # issues SIX bf16 MFMA products per fp32 product (exact 3-way operand split, csrc/linear_s3.hip), K rounded up to 16.
-                alg = 2.0 * n_rows * 256 * (256 + 263 + 256)
-                issued = 6.0 * 2.0 * n_rows * 256 * (256 + 272 + 256)
-                ach = issued / (ms_3 * 1e-3) / 1e12
-                roof = dict(kernel="linear_s3w_kernel<16|17,1,0> (block1.2, block3.0, block3.2: 3 launches, M=%d rows, N=256)" % n_rows, bound="mfma",
-                            achieved=round(ach, 1), peak=BF16_MFMA_PEAK_TF, unit="TFLOP/s", frac=round(ach / BF16_MFMA_PEAK_TF, 4),
-                            traffic=int(t_lin["hbm_bytes"]) if t_lin else None,
-                            traffic_source=("profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)" % TRAFFIC_JSON) if t_lin else None,
-                            flops_per_launch=issued / 3, avg_launch_ms=round(ms_3 / 3, 4),
-                            fp32_equivalent_tflops=round(alg / (ms_3 * 1e-3) / 1e12, 2),
-                            algorithmic_bytes_per_launch=int(n_rows * (256 + 256) * 4),
-                            hbm_gbs=round(n_rows * 2048.0 * 3 / (ms_3 * 1e-3) / 1e9, 1),
-                            note="achieved = bf16 MFMA flops issued (6 per fp32 product) / time, against the bf16 dense peak; with real operand data the matrix pipe "
-                                 "sustains less than the spec peak: tools/mfma_peak_bf16 reaches 1860-1930 TFLOP/s (1.87-1.92 GHz) with random / split-plane and "
-                                 "2470 (2.39 GHz) with constant operands on this chip; fp32_equivalent_tflops = 2 M N K / time "
-                                 "(the fp32-MFMA kernel it replaces: 119-125, peak 157.3)",
-                            neighbour_mlp=dict(ms=round(ms_nb, 3), algorithmic_tflops=round(flops_nb / (ms_nb * 1e-3) / 1e12, 2) if ms_nb > 0 else None,
-                                               k60_layer_ms=round(ms_nb - ms_3, 3)))
             elif ms_nb > 0:
                 # per-neighbour MLP on fp32 MFMA: 4 launches of linear_f32_kernel<2,2,1,0,4>; the kernels EXECUTE fewer flops than
                 # the algorithmic count because block1.0's 224 point-only input columns are folded into a per-point table
@@ -613,7 +591,7 @@ def main():
             "metric": "rays/sec (fwd render) scene0241_01 at 1/2/4/8 GPU; PSNR delta vs ref",
             "value": R_job * args.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": "f32", "dense_arithmetic": {"f32": "fp32 MFMA (v_mfma_f32_32x32x2_f32)", "bf16x3": "256-wide per-neighbour layers: fp32 operands split EXACTLY into 3 bf16 terms, 6 bf16 MFMAs per product, fp32 accumulate (fp32-class error, tests/test_linear_gpu.py); all other layers fp32 MFMA", "f16x2": "per-neighbour chain fused in one kernel: fp32 operands split into 2 fp16 terms under exact power-of-two row / layer scales, 3 fp16 MFMAs per product, fp32 accumulate (error vs fp64 at or below the fp32-MFMA path's, tests/test_chain_gpu.py); all other layers fp32 MFMA"}[getattr(rnd, "dense", "f32")], "data": ("synthetic (EMULATION of rank %s on one GPU: not the frame metric)" % emulate) if (emulate and world == 1) else "synthetic" if not rehearsal else "synthetic (REHEARSAL: ranks share GPUs, gloo collectives -- not a measurement)",
+            "dtype": "f32", "dense_arithmetic": {"f32": "fp32 MFMA (v_mfma_f32_32x32x2_f32)", "f16x2": "per-neighbour chain fused in one kernel: fp32 operands split into 2 fp16 terms under exact power-of-two row / layer scales, 3 fp16 MFMAs per product, fp32 accumulate (error vs fp64 at or below the fp32-MFMA path's, tests/test_chain_gpu.py); all other layers fp32 MFMA"}[getattr(rnd, "dense", "f32")], "data": ("synthetic (EMULATION of rank %s on one GPU: not the frame metric)" % emulate) if (emulate and world == 1) else "synthetic" if not rehearsal else "synthetic (REHEARSAL: ranks share GPUs, gloo collectives -- not a measurement)",
             "config": {"workload": "%s synthetic scene (SURVEY 8d): %d points, %dx%d frame margin %d = %d rays per step (%s), "
                                    "SR=%d K=%d P=%d max_o=%d D=%d, 4 reference views %dx%d, hybrid viewmlp forward (query+gather+aggregate+composite), neighbour lists in %s order; "
                                    "random-init weights with alpha_branch.0 rescaled (weight x30, bias = 30) so that opacities spread over (0,1)"

@@ -118,11 +118,6 @@ SIGNATURES = {
     "hnr_linear_f32": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "hnr_linear_f32_gather_add": (_I, [_P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P]),
     "hnr_linear_f32_side": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _P, _I, _I, _I, _I, _I, _F, _P]),
-    "hnr_linear_s3_packed_bytes": (ctypes.c_int64, [_I, _I]),
-    "hnr_linear_s3_pack": (_I, [_P, _P, _I, _I, _P, _P, _P]),
-    "hnr_linear_s3": (_I, [_P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P]),
-    "hnr_linear_wgrad_scratch_elems": (ctypes.c_int64, [_I, _I, _I]),
-    "hnr_linear_f32_wgrad": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P]),
     "hnr_sample_plan": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _P, _P, _P]),
     "hnr_gather_rows": (_I, [_P] * 5 + [_I] + [_P] * 9 + [_I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P]),
     "hnr_point_rows": (_I, [_P, _P, _I, _I, _P, _I, _P]),
@@ -171,17 +166,9 @@ SIGNATURES = {
     "hnr_sort_rows_by_key": (_I, [_P, ctypes.c_int64, _P, _P, _P, ctypes.c_int64, _P]),
     "hnr_segment_sum_rows": (_I, [_P, _I, _P, _I, _P, _P, ctypes.c_int64, _I, _P, ctypes.c_int64, _P]),
     "hnr_image_features_bwd": (_I, [_P, _I, _I, _I, ctypes.POINTER(_P), _F, _P, _P, ctypes.POINTER(_P), ctypes.POINTER(_P), _P]),
-    "hnr_ksum_bwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _F, _P, _I, _P, _P, _P, _P]),
-    "hnr_gather_rows_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P]),
     "hnr_gather_rows_bwd_rows": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P]),
-    "hnr_point_small_grads": (_I, [_P, _P, _I, _P, _P, _P, _P]),
     "hnr_segment_sum_rows_det": (_I, [_P, _I, _P, _P, ctypes.c_int64, _I, _I, _P, _P, ctypes.c_int64, _I, _P]),
     "hnr_probe_select": (_I, [_P, _P, _P, _P, ctypes.POINTER(_F), _P, _P, _I, _I, _I, _F, _F, _P, _P, _P]),
-    "hnr_unique_points": (_I, [_P, ctypes.c_int64, _I, _P, _P, _I, _P, _P, _P, _P]),
-    "hnr_scatter_add_rows": (_I, [_P, _I, _P, ctypes.c_int64, _I, _P, _I, _P]),
-    "hnr_point_rows_bwd": (_I, [_P, _I, _P, _I, _P, _I, _I, _P, _P]),
-    "hnr_dleaky": (_I, [_P, _I, _P, _I, ctypes.c_int64, _I, _F, _P]),
-    "hnr_sum_views": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P]),
     # training-step dense layers on the 16-bit matrix pipe (csrc/h2gemm.hip)
     "hnr_h2lin_packed_bytes": (ctypes.c_int64, [_I]),
     "hnr_h2lin_pack": (_I, [_I, ctypes.POINTER(_P), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(_I), ctypes.POINTER(_I),

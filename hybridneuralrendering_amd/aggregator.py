@@ -17,7 +17,7 @@ import torch.nn as nn
 
 from . import _lib
 from ._lib import HnrError
-from .linear import PackedLinear, SplitLinear, FusedMlp3
+from .linear import PackedLinear, FusedMlp3
 
 _REQUIRED = dict(which_agg_model="viewmlp", agg_distance_kernel="linear", agg_intrp_order=2, agg_dist_pers=20,
                  apply_pnt_mask=1, num_feat_freqs=3, dist_xyz_freq=5, num_viewdir_freqs=4, view_ori=0,
@@ -166,19 +166,9 @@ class PointAggregator(nn.Module):
             slope=float(self.block1[1].negative_slope),
         )
         self._packed, self._packed_key = pk, key
-        self._packed_split = None
         self._packed_chain = None
         self._packed_mlp3 = None
         return pk
-
-    def packed_split(self):
-        """The three 256 x (256 | 263) per-neighbour layers (block1.2, block3.0, block3.2) as exactly split bf16 operands for
-        hnr_linear_s3 (csrc/linear_s3.hip); packed with the fp32 images, re-packed when a parameter changes."""
-        self.packed()
-        if getattr(self, "_packed_split", None) is None:
-            sl = lambda seq, i: SplitLinear(seq[i].weight, seq[i].bias)
-            self._packed_split = dict(b1_2=sl(self.block1, 2), b3_0=sl(self.block3, 0), b3_2=sl(self.block3, 2))
-        return self._packed_split
 
     def packed_chain(self):
         """block1 / block3 / alpha_branch in the image of the fused per-neighbour chain (hnr_chain_pack; csrc/chain.hip), packed

@@ -1,5 +1,6 @@
-// Backward of the gather / aggregate / composite path (everything that is not a dense layer; those are in linear.hip
-// (input gradient = another forward GEMM with the LeakyReLU derivative as its side operand) and linear_bwd.hip (weights)).
+// Backward of the gather / aggregate / composite path: everything that is not a dense layer (those are in h2gemm.hip: input gradients =
+// hnr_h2lin with the transposed weights and the LeakyReLU derivative in its epilogue, weight gradients = hnr_h2wgrad); csrc/render_train.hip
+// drives them.
 //
 // The reference gets these from torch autograd over its eager ops; the formulas below are the analytic derivatives of the
 // forward kernels in aggregate.hip, one backward kernel per forward kernel, in the same row order:
@@ -8,7 +9,7 @@
 //   merge_bwd          <- weighted merge + last layer      :1199-1217, :1222-1237 (train-time patch drop), :1286-1292
 //   proj_rows_bwd      <- pixel gather + F.interpolate     :1064-1067, :1077-1089, :1193
 //   conv3x3_bwd_*      <- aux_block_s1..3                  :1047-1063
-//   ksum_bwd           <- alpha branch + K-weighted sums   :1005-1026, :471-476
+//   (the alpha branch + K-weighted sums, :1005-1026, :471-476, are transposed by train_ksum_bwd_kernel in render_train.hip: 8-slot row layout)
 //   gather_rows_bwd    <- NeuralPoints gather, block3 extras, conf straight-through clamp
 //                                                          models/neural_points/neural_points.py:709-720, :957-971, :1422-1424, :1508-1512
 //   point_rows_bwd     <- positional encoding of the embedding (:931-938)
@@ -434,77 +435,6 @@ __global__ __launch_bounds__(256) void conv3x3_bwd_weight_kernel(const float *__
     }
 }
 
-// ------------------------------------------------------------------------------------------------ K-sum + alpha branch
-struct KsumBwdArgs {
-    const float *H4; int ldh;
-    const float *wagg, *alpha_w, *alpha_b;
-    const int32_t *vs_off, *vs_cnt;
-    const unsigned long long *counts;
-    const float *gX5; int ldg5;                          // [S, ldg5] d colour-feature-branch input; columns 0..255 = d sum_k w feat_k
-    const float *g_sigma;                                // [S]
-    float slope;
-    float *gZ4; int ldgz;                                // [rows, ldgz] out: d PRE-activation of block3's last layer (256)
-    float *g_wagg;                                       // [rows] out
-    float *g_alpha_w, *g_alpha_b;                        // [256], [1] atomics
-    unsigned *absmax;                                    // optional: max |gZ4| (bit pattern, atomicMax): the scale of the weight-gradient GEMM that reads it
-};
-
-__global__ __launch_bounds__(256) void ksum_bwd_kernel(KsumBwdArgs a)
-{
-    const int lane = threadIdx.x & 63;
-    const int wave = (int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6);
-    const int n_waves = (int)((gridDim.x * (unsigned)blockDim.x) >> 6);
-    const int n_valid = (int)a.counts[HNR_CNT_SAMPLES_VALID];
-    const float4 aw = reinterpret_cast<const float4 *>(a.alpha_w)[lane];
-    const float ab = a.alpha_b[0];
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    float acc_b = 0.f, gmax = 0.f;
-    for (int s = wave; s < n_valid; s += n_waves) {
-        const int off = a.vs_off[s], cnt = a.vs_cnt[s];
-        const float4 gf = reinterpret_cast<const float4 *>(a.gX5 + (size_t)s * a.ldg5)[lane];
-        const float gs = a.g_sigma[s];
-        for (int k = 0; k < cnt; ++k) {
-            const size_t row = (size_t)(off + k);
-            const float4 h = reinterpret_cast<const float4 *>(a.H4 + row * a.ldh)[lane];
-            const float w = a.wagg[row];
-            const float d = wave_sum(h.x * aw.x + h.y * aw.y + h.z * aw.z + h.w * aw.w);
-            const float yv = __fsub_rn(d + ab, 1.0f);
-            // softplus(beta = 1, threshold = 20) and its derivative (torch: z / (z + 1), z = exp(y), identity above the threshold)
-            const float ez = expf(yv);
-            const float sp = yv > 20.f ? yv : log1pf(ez);
-            const float spd = yv > 20.f ? 1.f : ez / (ez + 1.f);
-            const float da = w * gs * spd;
-            float4 o;
-            o.x = (w * gf.x + da * aw.x) * (h.x > 0.f ? 1.f : a.slope);
-            o.y = (w * gf.y + da * aw.y) * (h.y > 0.f ? 1.f : a.slope);
-            o.z = (w * gf.z + da * aw.z) * (h.z > 0.f ? 1.f : a.slope);
-            o.w = (w * gf.w + da * aw.w) * (h.w > 0.f ? 1.f : a.slope);
-            reinterpret_cast<float4 *>(a.gZ4 + row * a.ldgz)[lane] = o;
-            gmax = fmaxf(fmaxf(gmax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
-            const float hf = wave_sum(h.x * gf.x + h.y * gf.y + h.z * gf.z + h.w * gf.w);
-            if (lane == 0) a.g_wagg[row] = sp * gs + hf;
-            acc.x += da * h.x; acc.y += da * h.y; acc.z += da * h.z; acc.w += da * h.w;
-            acc_b += da;
-        }
-    }
-    __shared__ float4 s_w[4][64];
-    __shared__ float s_b[4];
-    const int wid = threadIdx.x >> 6;
-    s_w[wid][lane] = acc;
-    if (lane == 0) s_b[wid] = acc_b;
-    __syncthreads();
-    if (wid == 0) {
-        const float4 p0 = s_w[0][lane], p1 = s_w[1][lane], p2 = s_w[2][lane], p3 = s_w[3][lane];
-        atomicAdd(a.g_alpha_w + 4 * lane, p0.x + p1.x + p2.x + p3.x); atomicAdd(a.g_alpha_w + 4 * lane + 1, p0.y + p1.y + p2.y + p3.y);
-        atomicAdd(a.g_alpha_w + 4 * lane + 2, p0.z + p1.z + p2.z + p3.z); atomicAdd(a.g_alpha_w + 4 * lane + 3, p0.w + p1.w + p2.w + p3.w);
-        if (lane == 0) atomicAdd(a.g_alpha_b, s_b[0] + s_b[1] + s_b[2] + s_b[3]);
-    }
-    if (a.absmax) {
-        for (int o = 32; o > 0; o >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, o));
-        if (lane == 0 && gmax > 0.f) atomicMax(a.absmax, __float_as_uint(gmax));
-    }
-}
-
 // ------------------------------------------------------------------------------------------------ gather
 struct GatherBwdArgs {
     const int32_t *pidx;
@@ -516,8 +446,7 @@ struct GatherBwdArgs {
     const float *g_wagg;                                 // [rows] d (normalised weight * clamp(conf))
     const float *weight;                                 // [R,SR,K] normalised weights (forward output)
     const float *g_conf_out;                             // [R,SR,K] d conf_coefficient output, may be NULL
-    float *g_conf, *g_dir, *g_color;                     // [N], [N,3], [N,3] atomics
-    float *G8;                                           // deterministic mode: per-row [rows, 8] contributions instead (no atomics)
+    float *G8;                                           // per-row [rows, 8] contributions (summed per point by a segment sum: no atomics)
 };
 
 __global__ __launch_bounds__(256) void gather_rows_bwd_kernel(GatherBwdArgs a)
@@ -535,20 +464,12 @@ __global__ __launch_bounds__(256) void gather_rows_bwd_kernel(GatherBwdArgs a)
     // w_agg = w_norm * clamp_ST(conf): the clamp passes the gradient through unchanged (gradiant_clamp, :1422-1424)
     float gc = a.g_wagg[row] * a.weight[e];
     if (a.g_conf_out) gc += a.g_conf_out[e];
-    if (a.G8) {
-        // deterministic mode: the row's contribution [d color 3 | d dir 3 | d conf | 0] is parked; hnr_segment_sum_rows_det adds the rows of
-        // every touched point in a fixed order (atomics into the point buffers sum in a run-dependent order)
-        float4 *o = reinterpret_cast<float4 *>(a.G8 + row * 8);
-        o[0] = make_float4(g[0], g[1], g[2], g[3] + gd * a.raydir[3 * (size_t)ray]);
-        o[1] = make_float4(g[4] + gd * a.raydir[3 * (size_t)ray + 1], g[5] + gd * a.raydir[3 * (size_t)ray + 2], gc, 0.f);
-        return;
-    }
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        atomicAdd(a.g_color + 3 * (size_t)pid + j, g[j]);
-        atomicAdd(a.g_dir + 3 * (size_t)pid + j, g[3 + j] + gd * a.raydir[3 * (size_t)ray + j]);
-    }
-    atomicAdd(a.g_conf + pid, gc);
+    // the row's contribution [d color 3 | d dir 3 | d conf | 0] is parked; a segment sum over the rows sorted by touched point adds the rows of
+    // every point in a fixed order (atomics into the point buffers would sum in a run-dependent order)
+    float4 *o = reinterpret_cast<float4 *>(a.G8 + row * 8);
+    o[0] = make_float4(g[0], g[1], g[2], g[3] + gd * a.raydir[3 * (size_t)ray]);
+    o[1] = make_float4(g[4] + gd * a.raydir[3 * (size_t)ray + 1], g[5] + gd * a.raydir[3 * (size_t)ray + 2], gc, 0.f);
+    (void)pid;
 }
 
 // [U, 8] per-point sums -> the three point buffers (every touched point once: plain adds)
@@ -563,20 +484,6 @@ __global__ void point_small_grads_kernel(const float *__restrict__ P8, const int
     g_color[3 * p] += a0.x; g_color[3 * p + 1] += a0.y; g_color[3 * p + 2] += a0.z;
     g_dir[3 * p] += a0.w; g_dir[3 * p + 1] += a1.x; g_dir[3 * p + 2] += a1.y;
     g_conf[p] += a1.z;
-}
-
-// dst[idx[m], :] += src[m, :]  (n_cols a multiple of 4): the per-point accumulation of block1's first-layer gradient
-__global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float *__restrict__ src, int lds, const int32_t *__restrict__ idx,
-                                                               int64_t M, int n_cols, float *__restrict__ dst, int ldd)
-{
-    const int per_row = n_cols >> 2;
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t m = t / per_row;
-    if (m >= M) return;
-    const int c4 = (int)(t - m * per_row);
-    const float4 v = reinterpret_cast<const float4 *>(src + (size_t)m * lds)[c4];
-    float *d = dst + (size_t)idx[m] * ldd + 4 * c4;
-    atomicAdd(d, v.x); atomicAdd(d + 1, v.y); atomicAdd(d + 2, v.z); atomicAdd(d + 3, v.w);
 }
 
 // d emb from d [emb | PE3(emb)] rows of the touched points; E holds the forward sin/cos values
@@ -880,44 +787,6 @@ static int image_features_bwd_impl(const float *d_img, int V, int H, int W, cons
     return HNR_OK;
 }
 
-extern "C" int hnr_ksum_bwd(const float *d_H4, int ldh, const float *d_wagg, const float *d_alpha_w, const float *d_alpha_b,
-                            const int32_t *d_vs_off, const int32_t *d_vs_cnt, const int64_t *d_counts, int cap_samples,
-                            const float *d_gX5, int ldg5, const float *d_g_sigma, float slope, float *d_gZ4, int ldgz, float *d_g_wagg,
-                            float *d_g_alpha_w, float *d_g_alpha_b, void *stream)
-{
-    if (!d_H4 || !d_wagg || !d_alpha_w || !d_alpha_b || !d_vs_off || !d_vs_cnt || !d_counts || !d_gX5 || !d_g_sigma || !d_gZ4 || !d_g_wagg ||
-        !d_g_alpha_w || !d_g_alpha_b || ldh < 256 || (ldh & 3) || ldg5 < 256 || (ldg5 & 3) || ldgz < 256 || (ldgz & 3)) {
-        set_error("hnr_ksum_bwd: bad argument"); return HNR_ERR_BADARG;
-    }
-    if (cap_samples <= 0) return HNR_OK;
-    KsumBwdArgs a;
-    a.H4 = d_H4; a.ldh = ldh; a.wagg = d_wagg; a.alpha_w = d_alpha_w; a.alpha_b = d_alpha_b; a.vs_off = d_vs_off; a.vs_cnt = d_vs_cnt;
-    a.counts = reinterpret_cast<const unsigned long long *>(d_counts); a.gX5 = d_gX5; a.ldg5 = ldg5; a.g_sigma = d_g_sigma; a.slope = slope;
-    a.gZ4 = d_gZ4; a.ldgz = ldgz; a.g_wagg = d_g_wagg; a.g_alpha_w = d_g_alpha_w; a.g_alpha_b = d_g_alpha_b; a.absmax = nullptr;
-    ksum_bwd_kernel<<<persistent_blocks(cap_samples), 256, 0, (hipStream_t)stream>>>(a);
-    HNR_LAUNCH_CHECK();
-    return HNR_OK;
-}
-
-extern "C" int hnr_gather_rows_bwd(const int32_t *d_sample_pidx, const float *d_raydir, const int32_t *d_vs_item, const int32_t *d_vs_off,
-                                   const int32_t *d_vs_cnt, const int64_t *d_counts, int SR, int K, int cap_samples, const float *d_gX3,
-                                   int ldg3, const float *d_g_wagg, const float *d_weight, const float *d_g_conf_out, float *d_g_conf,
-                                   float *d_g_dir, float *d_g_color, void *stream)
-{
-    if (!d_sample_pidx || !d_raydir || !d_vs_item || !d_vs_off || !d_vs_cnt || !d_counts || !d_gX3 || !d_g_wagg || !d_weight || !d_g_conf ||
-        !d_g_dir || !d_g_color || ldg3 < 263 || SR <= 0 || K <= 0) {
-        set_error("hnr_gather_rows_bwd: bad argument"); return HNR_ERR_BADARG;
-    }
-    if (cap_samples <= 0) return HNR_OK;
-    GatherBwdArgs a;
-    a.pidx = d_sample_pidx; a.raydir = d_raydir; a.vs_item = d_vs_item; a.vs_off = d_vs_off; a.vs_cnt = d_vs_cnt;
-    a.counts = reinterpret_cast<const unsigned long long *>(d_counts); a.SR = SR; a.K = K; a.gX3 = d_gX3; a.ldg3 = ldg3; a.g_wagg = d_g_wagg;
-    a.weight = d_weight; a.g_conf_out = d_g_conf_out; a.g_conf = d_g_conf; a.g_dir = d_g_dir; a.g_color = d_g_color; a.G8 = nullptr;
-    gather_rows_bwd_kernel<<<cdiv((int64_t)cap_samples * K, 256), 256, 0, (hipStream_t)stream>>>(a);
-    HNR_LAUNCH_CHECK();
-    return HNR_OK;
-}
-
 extern "C" int hnr_gather_rows_bwd_rows(const int32_t *d_sample_pidx, const float *d_raydir, const int32_t *d_vs_item, const int32_t *d_vs_off,
                                         const int32_t *d_vs_cnt, const int64_t *d_counts, int SR, int K, int cap_samples, const float *d_gX3,
                                         int ldg3, const float *d_g_wagg, const float *d_weight, const float *d_g_conf_out, float *d_G8, void *stream)
@@ -930,76 +799,8 @@ extern "C" int hnr_gather_rows_bwd_rows(const int32_t *d_sample_pidx, const floa
     GatherBwdArgs a;
     a.pidx = d_sample_pidx; a.raydir = d_raydir; a.vs_item = d_vs_item; a.vs_off = d_vs_off; a.vs_cnt = d_vs_cnt;
     a.counts = reinterpret_cast<const unsigned long long *>(d_counts); a.SR = SR; a.K = K; a.gX3 = d_gX3; a.ldg3 = ldg3; a.g_wagg = d_g_wagg;
-    a.weight = d_weight; a.g_conf_out = d_g_conf_out; a.g_conf = nullptr; a.g_dir = nullptr; a.g_color = nullptr; a.G8 = d_G8;
+    a.weight = d_weight; a.g_conf_out = d_g_conf_out; a.G8 = d_G8;
     gather_rows_bwd_kernel<<<cdiv((int64_t)cap_samples * K, 256), 256, 0, (hipStream_t)stream>>>(a);
-    HNR_LAUNCH_CHECK();
-    return HNR_OK;
-}
-
-extern "C" int hnr_point_small_grads(const float *d_P8, const int32_t *d_ulist, int U, float *d_g_conf, float *d_g_dir, float *d_g_color, void *stream)
-{
-    if (U < 0) { set_error("hnr_point_small_grads: bad size"); return HNR_ERR_BADARG; }
-    if (U == 0) return HNR_OK;
-    if (!d_P8 || !d_ulist || !d_g_conf || !d_g_dir || !d_g_color || ((uintptr_t)d_P8 & 15)) { set_error("hnr_point_small_grads: NULL / unaligned argument"); return HNR_ERR_BADARG; }
-    point_small_grads_kernel<<<cdiv(U, 256), 256, 0, (hipStream_t)stream>>>(d_P8, d_ulist, U, d_g_conf, d_g_dir, d_g_color);
-    HNR_LAUNCH_CHECK();
-    return HNR_OK;
-}
-
-extern "C" int hnr_scatter_add_rows(const float *d_src, int lds, const int32_t *d_idx, int64_t M, int n_cols, float *d_dst, int ldd,
-                                    void *stream)
-{
-    if (M < 0 || n_cols <= 0 || (n_cols & 3) || lds < n_cols || (lds & 3) || ldd < n_cols) { set_error("hnr_scatter_add_rows: bad sizes"); return HNR_ERR_BADARG; }
-    if (M == 0) return HNR_OK;
-    if (!d_src || !d_idx || !d_dst) { set_error("hnr_scatter_add_rows: NULL argument"); return HNR_ERR_BADARG; }
-    scatter_add_rows_kernel<<<cdiv(M * (n_cols >> 2), 256), 256, 0, (hipStream_t)stream>>>(d_src, lds, d_idx, M, n_cols, d_dst, ldd);
-    HNR_LAUNCH_CHECK();
-    return HNR_OK;
-}
-
-extern "C" int hnr_point_rows_bwd(const float *d_gE, int ldg, const float *d_E, int lde, const int32_t *d_ids, int n, int F, float *d_g_emb,
-                                  void *stream)
-{
-    if (n < 0 || F != 32 || ldg < 7 * F || lde < 7 * F) { set_error("hnr_point_rows_bwd: bad argument"); return HNR_ERR_BADARG; }
-    if (n == 0) return HNR_OK;
-    if (!d_gE || !d_E || !d_g_emb) { set_error("hnr_point_rows_bwd: NULL argument"); return HNR_ERR_BADARG; }
-    point_rows_bwd_kernel<32><<<cdiv((int64_t)n * F, 256), 256, 0, (hipStream_t)stream>>>(d_gE, ldg, d_E, lde, d_ids, n, d_g_emb);
-    HNR_LAUNCH_CHECK();
-    return HNR_OK;
-}
-
-extern "C" int hnr_dleaky(float *d_g, int ldg, const float *d_y, int ldy, int64_t M, int N, float slope, void *stream)
-{
-    if (M < 0 || N <= 0 || ldg < N || ldy < N) { set_error("hnr_dleaky: bad sizes"); return HNR_ERR_BADARG; }
-    if (M == 0) return HNR_OK;
-    if (!d_g || !d_y) { set_error("hnr_dleaky: NULL argument"); return HNR_ERR_BADARG; }
-    dleaky_kernel<<<cdiv(M * N, 256), 256, 0, (hipStream_t)stream>>>(d_g, ldg, d_y, ldy, M, N, slope);
-    HNR_LAUNCH_CHECK();
-    return HNR_OK;
-}
-
-extern "C" int hnr_sum_views(const float *d_in, int ldi, int V, int cap, int n_samples, int N, float *d_out, int ldo, void *stream)
-{
-    if (V <= 0 || cap < n_samples || n_samples < 0 || N <= 0 || ldi < N || ldo < N) { set_error("hnr_sum_views: bad sizes"); return HNR_ERR_BADARG; }
-    if (n_samples == 0) return HNR_OK;
-    if (!d_in || !d_out) { set_error("hnr_sum_views: NULL argument"); return HNR_ERR_BADARG; }
-    sum_views_kernel<<<cdiv((int64_t)n_samples * N, 256), 256, 0, (hipStream_t)stream>>>(d_in, ldi, V, cap, n_samples, N, d_out, ldo);
-    HNR_LAUNCH_CHECK();
-    return HNR_OK;
-}
-
-extern "C" int hnr_unique_points(const int32_t *d_row_pid, int64_t M, int n_points, int32_t *d_uidx, int32_t *d_ulist, int cap,
-                                 int32_t *d_row_u, int32_t *d_count, int32_t *d_scratch, void *stream)
-{
-    if (M < 0 || n_points <= 0 || cap < 0) { set_error("hnr_unique_points: bad sizes"); return HNR_ERR_BADARG; }
-    if (!d_uidx || !d_ulist || !d_count || !d_scratch || (M > 0 && (!d_row_pid || !d_row_u))) { set_error("hnr_unique_points: NULL argument"); return HNR_ERR_BADARG; }
-    hipStream_t st = (hipStream_t)stream;
-    HNR_HIP_CHECK(hipMemsetAsync(d_uidx, 0, (size_t)n_points * 4, st));
-    if (M > 0) mark_points_kernel<<<cdiv(M, 256), 256, 0, st>>>(d_row_pid, M, d_uidx);
-    const int nb = cdiv(n_points, 1024);
-    flag_block_sum_kernel<<<nb, 1024, 0, st>>>(d_uidx, n_points, d_scratch);
-    flag_scan_kernel<<<nb, 1024, 0, st>>>(d_uidx, n_points, d_scratch, d_ulist, cap, d_count);
-    if (M > 0) map_rows_kernel<<<cdiv(M, 256), 256, 0, st>>>(d_row_pid, M, d_uidx, d_row_u);
     HNR_LAUNCH_CHECK();
     return HNR_OK;
 }

@@ -5,7 +5,7 @@
 //   K-weighted sums of the density and of the 256 features per shading sample :1008-1026
 // Activations never leave the CU: each workgroup carries a tile of 128 neighbour rows (16 shading samples x K = 8 slots)
 // through the four dense layers with the layer outputs staged in LDS, and only the per-sample sums go back to HBM.
-// (The unfused path -- linear_s3.hip / linear.hip + ksum_kernel -- writes and re-reads a [rows, 256] fp32 matrix between all
+// (The unfused path -- linear.hip + ksum_kernel -- writes and re-reads a [rows, 256] fp32 matrix between all
 // launches: 232 GB of HBM traffic per 285 200-ray frame against 4 GB of algorithmic bytes.)
 //
 // Arithmetic: "f16x2".  gfx950 has no TF32 and runs fp32 MFMA at 1/16 of the 16-bit matrix rate.  Every operand x (an
@@ -352,314 +352,6 @@ __global__ __launch_bounds__(256, RT >= 4 ? 1 : 2) void chain_kernel(ChainArgs a
         }
         __syncthreads();
         if (tid < 4) { const float m = fmaxf(fmaxf(exch[4 * tid], exch[4 * tid + 1]), fmaxf(exch[4 * tid + 2], exch[4 * tid + 3])); if (m > 0.f) atomicMax(a.hmax + tid, __float_as_uint(m)); }
-    }
-#undef CH_STAMP
-}
-
-// ------------------------------------------------------------------------------------------------------------------------
-// Dual-group form of the same kernel: 512 threads = two GROUPS of four waves (two waves per SIMD, <= 256 registers each).  Group g owns
-// the row tiles 2 g, 2 g + 1 of the workgroup's 128-row tile (same LDS and workspace layout as chain_kernel<4>) and runs them through
-// the same layer sequence as an independent 64-row problem -- nothing is shared between the groups except the hardware barrier.  A
-// group's work per layer is a PHASE PAIR: M (the MFMA loop over the k steps) and E (the layer's epilogue: bias, LeakyReLU, row
-// scales, split, publish the next layer's operand planes; for layer 3 the alpha dot and the K-sums).  Group 1 starts one phase behind
-// group 0, and every phase contains exactly two workgroup barriers (in M after k step BAR and at the end; in E between the two
-// halves of the epilogue and at the end), so the hardware barrier forces the groups into anti-phase: while one group's waves issue
-// MFMAs, the other group's waves -- resident on the same SIMDs -- run their VALU / LDS / memory epilogue in the issue slots the matrix
-// pipe leaves free.  (In chain_kernel all four waves of the CU are in the same phase, and the matrix pipe idles through every
-// epilogue: 40 % of the tile time.)  The price: each group streams the whole weight image for 64 rows (twice the L2 -> CU traffic).
-template <int DBG, int PACE>
-__global__ __launch_bounds__(512, 1) void chain2_kernel(ChainArgs a)
-{
-    constexpr int RT = 2, SLOT = ch_slot(4), SAMPLES = 16, WS = (DBG == 4) ? 1 : 0;
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, grp = tid >> 8, h = lane >> 5, j = lane & 31;
-    int n_valid = (int)a.counts[HNR_CNT_SAMPLES_VALID];
-    if (n_valid > a.cap_samples) n_valid = a.cap_samples;
-    const int n_tiles = (n_valid + SAMPLES - 1) / SAMPLES;
-    const float *meta = reinterpret_cast<const float *>(a.wimg + CH_META);
-    const __amdgpu_buffer_rsrc_t wsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(a.wimg), 0, CH_WBYTES, 0x00020000);
-    char *pl = lds + grp * (RT * 2048);                                    // this group's planes: fragment (s, rt, p) at s * SLOT + (rt * 2 + p) * 1024
-    float *exch = reinterpret_cast<float *>(lds + ch_lds_exch(4)) + grp * (32 * RT * 4);       // [row 64][wave 4]
-    const int col0 = 64 * wave + 16 * h;
-    const f32x2 slope2 = {a.slope, a.slope};
-    const unsigned woff = (unsigned)(2 * wave) * 2048u + (unsigned)lane * 16u;
-
-    for (int i = tid & 255; i < 2 * RT * 32; i += 256)
-        *reinterpret_cast<u32x4 *>(pl + 16 * SLOT + (i >> 5) * 1024 + (32 + (i & 31)) * 16) = u32x4{0u, 0u, 0u, 0u};
-
-    const int xcd = blockIdx.x & 7, nb = (gridDim.x + 7 - xcd) / 8, bi = blockIdx.x >> 3;
-    const int per = (n_tiles + 7) / 8, t_lo = xcd * per, t_hi = (t_lo + per < n_tiles) ? t_lo + per : n_tiles;
-    const bool xcd_order = gridDim.x >= 8;
-    const int t_first = xcd_order ? t_lo + bi : (int)blockIdx.x, t_end = xcd_order ? t_hi : n_tiles, t_step = xcd_order ? nb : (int)gridDim.x;
-
-    long long tm[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0, t_start = 0, w_start = 0;
-    int n_my = 0;
-    if (DBG >= 2) { t_start = t_prev = clock64(); w_start = wall_clock64(); }
-#define CH_STAMP(i_) do { if (DBG >= 2) { const long long t_ = clock64(); tm[i_] += t_ - t_prev; t_prev = t_; } } while (0)
-
-    // per-tile row scalars of this group's 64 rows; the layer-0 operand image of a tile: 16 KiB per group = 4 x 16 B per lane
-    int pid[RT];
-    float wq[RT];
-    float4 e0 = make_float4(0.f, 0.f, 0.f, 0.f), e1 = e0;                  // extras of the rows this wave publishes (row tile = wave, waves 0, 1)
-    u32x4 xv[4];
-    auto load_tile_inputs = [&](int tile, float (&wq_dst)[RT]) {
-        const char *aux = a.aux + ((size_t)tile * 4 + 2 * grp) * CH_AUX_GROUP;
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            pid[rt] = reinterpret_cast<const int32_t *>(aux + rt * CH_AUX_GROUP)[j];
-            wq_dst[rt] = reinterpret_cast<const float *>(aux + rt * CH_AUX_GROUP + 128)[j];
-        }
-        if (wave < RT) {
-            e0 = *reinterpret_cast<const float4 *>(aux + wave * CH_AUX_GROUP + 256 + j * 32);
-            e1 = *reinterpret_cast<const float4 *>(aux + wave * CH_AUX_GROUP + 256 + j * 32 + 16);
-        }
-        // 1-KiB chunk c = i * 4 + wave of the group's 16: (row tile rt = c >> 3, k step s = (c >> 1) & 3, plane p = c & 1)
-        const char *src = a.xp + ((size_t)tile * 4 + 2 * grp) * CH_XP_GROUP + lane * 16;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) xv[i] = *reinterpret_cast<const u32x4 *>(src + (i * 4 + wave) * 1024);
-    };
-    auto store_xp = [&]() {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = i * 4 + wave, rt = c >> 3, sp = c & 7;
-            *reinterpret_cast<u32x4 *>(pl + (sp >> 1) * SLOT + (rt * 2 + (sp & 1)) * 1024 + lane * 16) = xv[i];
-        }
-    };
-    if (t_first < t_end) { load_tile_inputs(t_first, wq); store_xp(); }
-    __syncthreads();
-    // group 1 runs one phase (two barriers) behind group 0
-    if (grp == 1) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); }
-
-    for (int tile = t_first; tile < t_end; tile += t_step) {
-        ++n_my;
-        CH_STAMP(0);
-        f32x16 acc[RT][2];
-        float inv[RT];
-        auto zero_acc = [&]() {
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                for (int c = 0; c < 2; ++c)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[rt][c][r] = 0.f;
-        };
-        float4 tv[RT][2][4];
-        auto activate = [&](int layer, float (&amax)[RT], auto with_table) {
-            constexpr bool TV = decltype(with_table)::value;
-            if (DBG == 3) { for (int rt = 0; rt < RT; ++rt) amax[rt] = fabsf(acc[rt][0][0]) + fabsf(acc[rt][1][0]); return; }     // probe: keeps the MFMAs alive, no epilogue work
-            f32x2 bias[2][8];
-#pragma unroll
-            for (int c = 0; c < 2; ++c)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 b = *reinterpret_cast<const float4 *>(meta + layer * 256 + col0 + 32 * c + 4 * q);
-                    bias[c][2 * q] = f32x2{b.x, b.y}; bias[c][2 * q + 1] = f32x2{b.z, b.w};
-                }
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
-                float m = 0.f;
-                const f32x2 inv2 = {inv[rt], inv[rt]};
-#pragma unroll
-                for (int c = 0; c < 2; ++c)
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        f32x2 add = bias[c][q];
-                        if (TV) { const float4 t4 = tv[rt][c][q >> 1]; add = add + ((q & 1) ? f32x2{t4.z, t4.w} : f32x2{t4.x, t4.y}); }
-                        f32x2 v = __builtin_elementwise_fma(f32x2{acc[rt][c][2 * q], acc[rt][c][2 * q + 1]}, inv2, add);
-                        const f32x2 sv = v * slope2;
-                        v.x = fmaxf(v.x, sv.x); v.y = fmaxf(v.y, sv.y);
-                        acc[rt][c][2 * q] = v.x; acc[rt][c][2 * q + 1] = v.y;
-                        m = fmaxf(fmaxf(m, fabsf(v.x)), fabsf(v.y));
-                        if (DBG == 1) {
-                            if (a.dbg && a.dbg_layer == layer) {
-                                float *o = a.dbg + ((size_t)tile * 128 + 32 * (2 * grp + rt) + j) * 256 + col0 + 32 * c + 2 * q;
-                                o[0] = v.x; o[1] = v.y;
-                            }
-                        }
-                    }
-                amax[rt] = m;
-            }
-        };
-        auto publish = [&](int next_layer, float (&amax)[RT], bool with_extras) {
-            float emax = 0.f;
-            if (with_extras) emax = fmaxf(fmaxf(fmaxf(fabsf(e0.x), fabsf(e0.y)), fmaxf(fabsf(e0.z), fabsf(e0.w))), fmaxf(fmaxf(fabsf(e1.x), fabsf(e1.y)), fabsf(e1.z)));
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
-                float m = fmaxf(amax[rt], __shfl_xor(amax[rt], 32));
-                if (with_extras && rt == wave) m = fmaxf(m, emax);
-                if (h == 0) exch[(32 * rt + j) * 4 + wave] = m;
-            }
-            __syncthreads();                                               // E barrier 1
-            if (DBG == 3) {
-                for (int rt = 0; rt < RT; ++rt) {
-                    inv[rt] = 1.f;
-                    *reinterpret_cast<u32x4 *>(pl + (4 * wave + h) * SLOT + (rt * 2) * 1024 + j * 16) = u32x4{__float_as_uint(exch[(32 * rt + j) * 4]) & 0x3c003c00u, 0u, 0u, 0u};
-                }
-                __syncthreads();
-                return;
-            }
-            const float dw = meta[CH_META_DESCALE + next_layer];
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
-                const float4 m4 = *reinterpret_cast<const float4 *>(exch + (32 * rt + j) * 4);
-                const int k = row_scale_exp(fmaxf(fmaxf(m4.x, m4.y), fmaxf(m4.z, m4.w)));
-                const float sc = pow2f(k);
-                const f32x2 sc2 = {sc, sc};
-                inv[rt] = __fmul_rn(pow2f(-k), dw);
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    unsigned ph[8], pm[8];
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const f32x2 vs = f32x2{acc[rt][c][2 * q], acc[rt][c][2 * q + 1]} * sc2;
-                        split2h(vs.x, vs.y, ph[q], pm[q]);
-                    }
-                    char *dst = pl + (2 * (2 * wave + c) + h) * SLOT + (rt * 2) * 1024 + j * 16;
-                    *reinterpret_cast<u32x4 *>(dst) = u32x4{ph[0], ph[1], ph[2], ph[3]};
-                    *reinterpret_cast<u32x4 *>(dst + 512) = u32x4{ph[4], ph[5], ph[6], ph[7]};
-                    *reinterpret_cast<u32x4 *>(dst + 1024) = u32x4{pm[0], pm[1], pm[2], pm[3]};
-                    *reinterpret_cast<u32x4 *>(dst + 1024 + 512) = u32x4{pm[4], pm[5], pm[6], pm[7]};
-                }
-                if (with_extras && rt == wave && h == 0) {
-                    unsigned ph[4], pm[4];
-                    split2h(__fmul_rn(e0.x, sc), __fmul_rn(e0.y, sc), ph[0], pm[0]);
-                    split2h(__fmul_rn(e0.z, sc), __fmul_rn(e0.w, sc), ph[1], pm[1]);
-                    split2h(__fmul_rn(e1.x, sc), __fmul_rn(e1.y, sc), ph[2], pm[2]);
-                    split2h(__fmul_rn(e1.z, sc), 0.f, ph[3], pm[3]);
-                    char *dst = pl + 16 * SLOT + (rt * 2) * 1024 + j * 16;
-                    *reinterpret_cast<u32x4 *>(dst) = u32x4{ph[0], ph[1], ph[2], ph[3]};
-                    *reinterpret_cast<u32x4 *>(dst + 1024) = u32x4{pm[0], pm[1], pm[2], pm[3]};
-                }
-            }
-            __syncthreads();                                               // E barrier 2
-        };
-
-        // ---- layer 0
-        {
-            const float dw0 = meta[CH_META_DESCALE + 0];
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) inv[rt] = __fmul_rn(pow2f(-14), dw0);
-            zero_acc();
-            h2_mfma_layer<RT, 2, CH_S0, 1, CH_WSTEP, SLOT, 1, WS, PACE>(wsrd, CH_W0, woff, pl, lane, acc, [&]() {
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt) {
-                    const float *trow = a.ptab + (size_t)(pid[rt] < 0 ? 0 : pid[rt]) * a.ldt + col0;
-#pragma unroll
-                    for (int c = 0; c < 2; ++c)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) tv[rt][c][q] = *reinterpret_cast<const float4 *>(trow + 32 * c + 4 * q);
-                }
-            });
-            __builtin_amdgcn_s_barrier();                                  // M barrier 2
-            CH_STAMP(1);
-            float amax[RT];
-            activate(0, amax, std::true_type{});
-            CH_STAMP(2);
-            publish(1, amax, false);
-            CH_STAMP(3);
-        }
-        // ---- layer 1
-        {
-            zero_acc();
-            h2_mfma_layer<RT, 2, CH_S1, 0, CH_WSTEP, SLOT, 5, WS, PACE>(wsrd, CH_W1, woff, pl, lane, acc, []() {});
-            __builtin_amdgcn_s_barrier();
-            CH_STAMP(4);
-            float amax[RT];
-            activate(1, amax, std::false_type{});
-            CH_STAMP(5);
-            publish(2, amax, true);
-            CH_STAMP(6);
-        }
-        // ---- layer 2
-        {
-            zero_acc();
-            h2_mfma_layer<RT, 2, CH_S2, 0, CH_WSTEP, SLOT, 5, WS, PACE>(wsrd, CH_W2, woff, pl, lane, acc, []() {});
-            __builtin_amdgcn_s_barrier();
-            CH_STAMP(7);
-            float amax[RT];
-            activate(2, amax, std::false_type{});
-            CH_STAMP(5);
-            publish(3, amax, false);
-            CH_STAMP(6);
-        }
-        // ---- layer 3 + alpha branch + K-weighted sums; the next tile's inputs are fetched under it
-        {
-            zero_acc();
-            h2_mfma_layer<RT, 2, CH_S3, 0, CH_WSTEP, SLOT, 5, WS, PACE>(wsrd, CH_W3, woff, pl, lane, acc, []() {});
-            __builtin_amdgcn_s_barrier();
-            CH_STAMP(8);
-            const int tile_next = tile + t_step;
-            float wq_next[RT] = {0.f, 0.f};
-            if (tile_next < t_end) load_tile_inputs(tile_next, wq_next);
-            float amax[RT];
-            activate(3, amax, std::false_type{});
-            float aw[2][16];
-#pragma unroll
-            for (int c = 0; c < 2; ++c)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 b = *reinterpret_cast<const float4 *>(meta + 4 * 256 + col0 + 32 * c + 4 * q);
-                    aw[c][4 * q] = b.x; aw[c][4 * q + 1] = b.y; aw[c][4 * q + 2] = b.z; aw[c][4 * q + 3] = b.w;
-                }
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
-                float ap = 0.f;
-#pragma unroll
-                for (int c = 0; c < 2; ++c)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) ap = fmaf(acc[rt][c][r], aw[c][r], ap);
-                ap = __fadd_rn(ap, __shfl_xor(ap, 32));
-                if (h == 0) exch[(32 * rt + j) * 4 + wave] = ap;
-            }
-            __syncthreads();                                               // E barrier 1; the group's planes are free (its layer 3 is complete)
-            if (tile_next < t_end) store_xp();
-            const float ab = meta[4 * 256 + 256];
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
-#pragma unroll
-                for (int c = 0; c < 2; ++c)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        float f = __fmul_rn(acc[rt][c][r], wq[rt]);
-                        f = __fadd_rn(f, __builtin_amdgcn_update_dpp(0.f, f, 0xB1, 0xf, 0xf, false));
-                        f = __fadd_rn(f, __builtin_amdgcn_update_dpp(0.f, f, 0x4E, 0xf, 0xf, false));
-                        f = __fadd_rn(f, __builtin_amdgcn_update_dpp(0.f, f, 0x141, 0xf, 0xf, false));
-                        acc[rt][c][r] = f;
-                    }
-                const int s = tile * SAMPLES + 4 * (2 * grp + rt) + (j >> 3);
-                if ((j & 7) == 0 && s < n_valid) {
-                    float *o = a.X5 + (size_t)s * a.ld5 + col0;
-#pragma unroll
-                    for (int c = 0; c < 2; ++c)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            *reinterpret_cast<float4 *>(o + 32 * c + 4 * q) = make_float4(acc[rt][c][4 * q], acc[rt][c][4 * q + 1], acc[rt][c][4 * q + 2], acc[rt][c][4 * q + 3]);
-                }
-                if (rt == wave) {
-                    const float4 d4 = *reinterpret_cast<const float4 *>(exch + (32 * rt + j) * 4);
-                    const float d = __fadd_rn(__fadd_rn(d4.x, d4.y), __fadd_rn(d4.z, d4.w));
-                    float sg = __fmul_rn(chain_softplus_m1(__fadd_rn(d, ab)), wq[rt]);
-                    sg = __fadd_rn(sg, __builtin_amdgcn_update_dpp(0.f, sg, 0xB1, 0xf, 0xf, false));
-                    sg = __fadd_rn(sg, __builtin_amdgcn_update_dpp(0.f, sg, 0x4E, 0xf, 0xf, false));
-                    sg = __fadd_rn(sg, __builtin_amdgcn_update_dpp(0.f, sg, 0x141, 0xf, 0xf, false));
-                    if (h == 0 && (j & 7) == 0 && s < n_valid) a.sigma[s] = sg;
-                }
-            }
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) wq[rt] = wq_next[rt];
-            __syncthreads();                                               // E barrier 2
-            CH_STAMP(9);
-        }
-    }
-    if (grp == 0) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); }
-    if (DBG >= 2 && blockIdx.x == 0 && lane == 0 && a.dbg) {
-        long long *o = reinterpret_cast<long long *>(a.dbg) + (grp * 4 + wave) * 16;
-        for (int i = 0; i < 10; ++i) o[i] = tm[i];
-        o[10] = clock64() - t_start; o[11] = wall_clock64() - w_start; o[12] = n_my;
-    }
-    if (DBG >= 2 && tid == 0 && a.dbg) {
-        long long *o = reinterpret_cast<long long *>(a.dbg) + 128 + 4 * (size_t)blockIdx.x;
-        o[0] = clock64() - t_start; o[1] = wall_clock64() - w_start; o[2] = n_my; o[3] = (__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 0xf) | ((long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)) << 8);
     }
 #undef CH_STAMP
 }
@@ -1032,7 +724,7 @@ extern "C" int hnr_chain_classes(void)
     static int on = -1;
     if (on < 0) {
         const char *e = getenv("HNR_CHAIN_RT"), *c = getenv("HNR_CHAIN_CLASSES");
-        const bool ws = !e || (atoi(e) != 2 && atoi(e) != 4 && atoi(e) != 8);
+        const bool ws = !e || atoi(e) != 4;
         const int want = c ? atoi(c) : 2;
         on = ws ? (want < 0 ? 0 : want > 2 ? 2 : want) : 0;
     }
@@ -1155,57 +847,25 @@ extern "C" int hnr_chain_forward(const void *d_workspace, const float *d_point_t
     a.X5 = d_X5; a.ld5 = ld5; a.sigma = d_sigma; a.slope = slope; a.cap_samples = cap_samples; a.dbg = d_dbg; a.dbg_layer = dbg_layer;
     const int n_cu = chain_num_cus();
     hipStream_t st = (hipStream_t)stream;
-    // HNR_CHAIN_RT = 4 (default): one 128-row workgroup per CU; 2: two 64-row workgroups per CU.  Measured equal (35.9 vs 36.1 ms on
-    // the 3.5 M-sample probe frame: the pair needs 9 % fewer cycles but the chip clocks 1.80 instead of 2.02 GHz under it), so the
-    // variant that streams the weight image half as often is the default.
-    static int rt_mode = 0, skew = 0;
-    if (rt_mode == 0) {
-        const char *e = getenv("HNR_CHAIN_RT"); rt_mode = (e && atoi(e) == 2) ? 2 : (e && atoi(e) == 8) ? 8 : (e && atoi(e) == 4) ? 4 : 16;    // default: the weight-stationary pipelined kernel   // 8: dual-group kernel (measured slower: 39.8 vs 33.3 ms, profiles/README.md)
-        const char *k = getenv("HNR_CHAIN_SKEW"); skew = k ? atoi(k) : 0;            // x 64 cycles (probe; measured: no effect)
-    }
-    a.skew = skew;
+    // HNR_CHAIN_RT = 4: the compiler-scheduled one-workgroup-per-CU kernel of this file (the training forward runs its activation-keeping form);
+    // default: the weight-stationary pipelined kernel (csrc/chain_ws.hip)
+    static int rt_mode = 0;
+    if (rt_mode == 0) { const char *e = getenv("HNR_CHAIN_RT"); rt_mode = (e && atoi(e) == 4) ? 4 : 16; }
+    a.skew = 0; a.uidx = nullptr; a.hmax = nullptr;
+    for (int l = 0; l < 4; ++l) { a.H[l] = nullptr; a.ldh[l] = 0; }
     static bool attr_set = false;
     if (!attr_set) {
         HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chain_kernel<4, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, ch_lds_bytes(4)));
         HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chain_kernel<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, ch_lds_bytes(4)));
         HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chain_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, ch_lds_bytes(4)));
-#define CH2_ATTR(D_, P_) HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chain2_kernel<D_, P_>), hipFuncAttributeMaxDynamicSharedMemorySize, ch_lds_bytes(4)))
-#define CH2_ATTRS(P_) do { CH2_ATTR(0, P_); CH2_ATTR(1, P_); CH2_ATTR(2, P_); CH2_ATTR(3, P_); CH2_ATTR(4, P_); } while (0)
-        CH2_ATTRS(0); CH2_ATTRS(6);
-#undef CH2_ATTRS
-#undef CH2_ATTR
-        HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chain_kernel<2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, ch_lds_bytes(2)));
-        HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chain_kernel<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, ch_lds_bytes(2)));
-        HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chain_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, ch_lds_bytes(2)));
         attr_set = true;
     }
-    if (rt_mode == 16) {                                                    // weight-stationary pipelined kernel (csrc/chain_ws.hip)
-        const int tiles = cdiv(cap_samples, 16), grid = tiles < n_cu ? tiles : n_cu;
+    const int tiles = cdiv(cap_samples, 16), grid = tiles < n_cu ? tiles : n_cu;
+    if (rt_mode == 16)                                                      // weight-stationary pipelined kernel (csrc/chain_ws.hip)
         return launch_chain_ws(a, grid, st, (d_dbg && dbg_layer <= -3 && dbg_layer >= -7) ? -dbg_layer : (d_dbg && dbg_layer < 0) ? 2 : d_dbg ? 1 : 0);
-    }
-    if (rt_mode == 8) {
-        const int tiles = cdiv(cap_samples, 16), grid = tiles < n_cu ? tiles : n_cu;
-        static int pace = -1;
-        if (pace < 0) { const char *e = getenv("HNR_CHAIN_PACE"); pace = e ? atoi(e) : 0; }
-#define CH2_LAUNCH(P_) do { \
-        if (d_dbg && dbg_layer == -3) chain2_kernel<3, P_><<<grid, 512, ch_lds_bytes(4), st>>>(a);      /* probes: no epilogue work / same weights / both */ \
-        else if (d_dbg && dbg_layer == -4) chain2_kernel<4, P_><<<grid, 512, ch_lds_bytes(4), st>>>(a); \
-        else if (d_dbg && dbg_layer < 0) chain2_kernel<2, P_><<<grid, 512, ch_lds_bytes(4), st>>>(a); \
-        else if (d_dbg) chain2_kernel<1, P_><<<grid, 512, ch_lds_bytes(4), st>>>(a); \
-        else chain2_kernel<0, P_><<<grid, 512, ch_lds_bytes(4), st>>>(a); } while (0)
-        if (pace == 6) CH2_LAUNCH(6); else CH2_LAUNCH(0);
-#undef CH2_LAUNCH
-    } else if (rt_mode == 4) {
-        const int tiles = cdiv(cap_samples, 16), grid = tiles < n_cu ? tiles : n_cu;
-        if (d_dbg && dbg_layer < 0) chain_kernel<4, 2><<<grid, 256, ch_lds_bytes(4), st>>>(a);      // probe: per-phase cycle counts of block 0
-        else if (d_dbg) chain_kernel<4, 1><<<grid, 256, ch_lds_bytes(4), st>>>(a);
-        else chain_kernel<4, 0><<<grid, 256, ch_lds_bytes(4), st>>>(a);
-    } else {
-        const int tiles = cdiv(cap_samples, 8), grid = tiles < 2 * n_cu ? tiles : 2 * n_cu;
-        if (d_dbg && dbg_layer < 0) chain_kernel<2, 2><<<grid, 256, ch_lds_bytes(2), st>>>(a);
-        else if (d_dbg) chain_kernel<2, 1><<<grid, 256, ch_lds_bytes(2), st>>>(a);
-        else chain_kernel<2, 0><<<grid, 256, ch_lds_bytes(2), st>>>(a);
-    }
+    if (d_dbg && dbg_layer < 0) chain_kernel<4, 2><<<grid, 256, ch_lds_bytes(4), st>>>(a);      // probe: per-phase cycle counts of block 0
+    else if (d_dbg) chain_kernel<4, 1><<<grid, 256, ch_lds_bytes(4), st>>>(a);
+    else chain_kernel<4, 0><<<grid, 256, ch_lds_bytes(4), st>>>(a);
     HNR_LAUNCH_CHECK();
     return HNR_OK;
 }

@@ -278,117 +278,8 @@ __global__ __launch_bounds__(256) void knn_kernel(GridView g, const int32_t *__r
 }
 
 // ------------------------------------------------------------------------------------------------
-// k-NN, two passes per lane (one lane per shading sample), for the 3x3x3 neighbourhood:
-//  pass 1: all 27 brick records are fetched in a branch-free unrolled loop (the loads are independent, so they are
-//          in flight together instead of forming a 27-long dependent chain); the lane keeps a 27-bit occupancy
-//          mask and parks the CSR slot of every occupied cell in LDS;
-//  pass 2: only the occupied cells are walked (9 of 27 on the bench scene), in the reference's order; the next cell's
-//          {start,count} is requested before the current cell's candidates are scanned, and candidates are fetched
-//          two at a time.
-// Same visiting order and insertion rule as knn_kernel / the oracle: results are bit-identical.
-// Measured alternatives (profiles/README.md): 8 lanes per sample with coalesced candidate reads 2.2x slower (per-cell
-// control paid by 8 lanes); wave = 8x8 pixel tile x one slot 1.4-1.5x slower (idle lanes where ray_nsamp differs).
-template <int K>
-__global__ __launch_bounds__(256) void knn2_kernel(GridView g, const int32_t *__restrict__ work, const float *__restrict__ loc,
-                                                   int SR, float radius2, int layers, int32_t *__restrict__ pidx,
-                                                   int8_t *__restrict__ ray_mask, const unsigned long long *__restrict__ counts,
-                                                   unsigned long long *__restrict__ block_stats)
-{
-    __shared__ unsigned long long s_st[4][4];
-    __shared__ uint32_t s_slot[27][256];                      // [cell][thread]: conflict-free (consecutive lanes, consecutive banks)
-    const int n = (int)counts[HNR_CNT_SAMPLES];
-    unsigned long long n_cells = 0, n_cand = 0, n_nb = 0, n_sv = 0;
-    for (int w = blockIdx.x * blockDim.x + threadIdx.x; w < n; w += gridDim.x * blockDim.x) {
-        const int item = work[w];
-        const float cx = loc[3 * (size_t)item], cy = loc[3 * (size_t)item + 1], cz = loc[3 * (size_t)item + 2];
-        const int fx = cell_coord(cx, g.ox, g.cx), fy = cell_coord(cy, g.oy, g.cy), fz = cell_coord(cz, g.oz, g.cz);
-        // ---- pass 1 (three x-planes of 9 cells: 9 brick records in flight at a time keeps the VGPR count, hence the
-        // number of resident waves, reasonable) ----
-        uint32_t occ = 0;
-#pragma unroll 1
-        for (int xp = 0; xp < 3; ++xp) {
-#pragma unroll
-            for (int yz = 0; yz < 9; ++yz) {
-                const int c = xp * 9 + yz;
-                const int x = xp - 1, y = yz / 3 - 1, z = yz % 3 - 1;
-                const int vx = fx + x, vy = fy + y, vz = fz + z;
-                const bool inb = in_bounds(g, vx, vy, vz);
-                const int qx = inb ? vx : fx, qy = inb ? vy : fy, qz = inb ? vz : fz;     // clamp: the load is unconditional
-                const uint4 rec = g.occ_rec[brick_word(g, qx, qy, qz)];
-                const unsigned long long bb = (unsigned long long)rec.x | ((unsigned long long)rec.y << 32);
-                const int b = brick_bit(qx, qy, qz);
-                const bool o = inb && ((bb >> b) & 1ull);
-                occ |= (o ? 1u : 0u) << c;
-                s_slot[c][threadIdx.x] = rec.z + (uint32_t)__popcll(bb & ((1ull << b) - 1ull));
-            }
-        }
-        // ---- pass 2: one flat candidate stream per lane.  Every loop trip either tests ONE candidate or steps to the next
-        // occupied cell, so lanes with many small cells and lanes with few large cells stay busy together (nested per-cell
-        // loops ran at ~20 % lane utilisation: each trip waited for the longest list in the wave). ----
-        KBuf<K> kb;
-        kb.init();
-        int layer = 0;
-        uint32_t m = occ & (1u << 13);                         // shell 0 = the sample's own cell
-        int start = 0, cnt = 0, j = 0;
-        bool done = false;
-        while (!done) {
-            if (j < cnt) {
-                const float4 p0 = g.pts[start + j];
-                ++j;
-                const float xv = __fsub_rn(p0.x, cx), yv = __fsub_rn(p0.y, cy), zv = __fsub_rn(p0.z, cz);
-                const float v = __fadd_rn(__fadd_rn(__fmul_rn(xv, xv), __fmul_rn(yv, yv)), __fmul_rn(zv, zv));
-                if (radius2 == 0.f || v <= radius2) kb.offer(v, __float_as_int(p0.w));
-            } else {
-                if (m == 0) {                                   // shell finished (reference: `if (kid >= K) break;` after a layer)
-                    if (layer == 0 && layers > 1 && kb.kid < K) { layer = 1; m = occ & ~(1u << 13); }
-                    else done = true;
-                }
-                if (!done && m) {
-                    const int c = __ffs((int)m) - 1;
-                    m &= m - 1;
-                    const int2 rg = g.cell_rng[s_slot[c][threadIdx.x]];
-                    start = rg.x; cnt = rg.y; j = 0;
-                    ++n_cells;
-                    n_cand += (unsigned)rg.y;
-                }
-            }
-        }
-        {   // every kept sample gets its K ids (-1 where empty): the march kernel pads only the unused slots
-            int32_t *o = pidx + (size_t)item * K;
-            if constexpr ((K & 3) == 0) {
-#pragma unroll
-                for (int i = 0; i < K; i += 4)
-                    reinterpret_cast<int4 *>(o)[i >> 2] = make_int4(kb.id[i], kb.id[i + 1], kb.id[i + 2], kb.id[i + 3]);
-            } else {
-#pragma unroll
-                for (int i = 0; i < K; ++i) o[i] = kb.id[i];
-            }
-        }
-        if (kb.kid > 0) {
-            ray_mask[item / SR] = 1;
-            n_nb += (unsigned)(kb.kid < K ? kb.kid : K);
-            ++n_sv;
-        }
-    }
-    for (int o = 32; o > 0; o >>= 1) {
-        n_cells += __shfl_xor(n_cells, o);
-        n_cand += __shfl_xor(n_cand, o);
-        n_nb += __shfl_xor(n_nb, o);
-        n_sv += __shfl_xor(n_sv, o);
-    }
-    if ((threadIdx.x & 63) == 0) {
-        const int wv = threadIdx.x >> 6;
-        s_st[wv][0] = n_cells; s_st[wv][1] = n_cand; s_st[wv][2] = n_nb; s_st[wv][3] = n_sv;
-    }
-    __syncthreads();
-    if (threadIdx.x < 4)
-        block_stats[4 * (size_t)blockIdx.x + threadIdx.x] =
-            s_st[0][threadIdx.x] + s_st[1][threadIdx.x] + s_st[2][threadIdx.x] + s_st[3][threadIdx.x];
-}
-
-// ------------------------------------------------------------------------------------------------
 // k-NN, pipelined (K = 8, 3x3x3, the shipped configuration).  Same visiting order and insertion rule as knn_kernel /
-// knn2_kernel / the oracle -- results are bit-identical -- but the candidate records are no longer fetched one dependent
+// the oracle -- results are bit-identical -- but the candidate records are no longer fetched one dependent
 // load per loop trip (rocprofv3: ~1 us per trip and wave slot = one exposed L2/HBM round trip, 0.9 ms per frame):
 //  pass 1: per x-plane, 9 brick records in flight, then the 9 {start,count} records of the occupied cells in flight; each
 //          cell's list is parked in LDS as one word (start << 6 | count; P <= 63, N < 2^26 checked by the launcher);
@@ -752,31 +643,30 @@ extern "C" int hnr_march_query(const hnr_grid *g, const float *d_campos, const f
     nsamp_block_sum_kernel<<<nb, 1024, 0, st>>>(d_ray_nsamp, q->R, block_sums);
     worklist_kernel<<<nb, 1024, 0, st>>>(d_ray_nsamp, q->R, q->SR, block_sums, nb, d_work, cnt);
     HNR_LAUNCH_CHECK();
-    // K = 8 with a 3x3x3 neighbourhood (every shipped config): the pipelined kernel (HNR_KNN=2 / =1 select the older ones)
+    // K = 8 with a 3x3x3 neighbourhood (every shipped config): the pipelined kernel (HNR_KNN=1: the generic one-cell-at-a-time kernel)
     static int knn_sel = -1;
     if (knn_sel < 0) { const char *e = getenv("HNR_KNN"); knn_sel = e ? atoi(e) : 3; }
     if (q->knn_order == 1 && !(q->K == 8 && layers <= 2)) {
         set_error("hnr_march_query: knn_order = 1 (canonical neighbour order) is built for K = 8 with a 3x3x3 neighbourhood (K=%d)", q->K);
         return HNR_ERR_BADARG;
     }
-    if (q->K == 8 && layers <= 2 && (knn_sel != 1 || q->knn_order == 1)) {
+    hnr_grid_params gp;
+    hnr_grid_stats gs;
+    hnr_grid_get_params(g, &gp);
+    hnr_grid_get_stats(g, &gs);
+    const bool packable = gp.P <= 63 && gs.n_points < (1ll << 26);      // the pipelined kernel parks a cell's list as one word (start << 6 | count)
+    if (q->knn_order == 1 && !packable) {
+        set_error("hnr_march_query: knn_order = 1 needs P <= 63 and < 2^26 points (P=%d)", gp.P);
+        return HNR_ERR_BADARG;
+    }
+    if (q->K == 8 && layers <= 2 && packable && (knn_sel != 1 || q->knn_order == 1)) {
         const int blocks = knn_blocks(max_items);
-        hnr_grid_params gp;
-        hnr_grid_stats gs;
-        hnr_grid_get_params(g, &gp);
-        hnr_grid_get_stats(g, &gs);
-        if (q->knn_order == 1 && !(gp.P <= 63 && gs.n_points < (1ll << 26))) {
-            set_error("hnr_march_query: knn_order = 1 needs P <= 63 and < 2^26 points (P=%d)", gp.P);
-            return HNR_ERR_BADARG;
-        }
         static int probe_pass1 = -1;                             // HNR_KNN_PROBE_PASS1=1: time the cell lookups alone (tools/probe_query.py; results are empty)
         if (probe_pass1 < 0) { const char *e = getenv("HNR_KNN_PROBE_PASS1"); probe_pass1 = e ? atoi(e) : 0; }
         if (q->knn_order == 1)
             knn3_kernel<8, 1><<<blocks, 256, 0, st>>>(v, d_work, d_sample_loc_w, q->SR, q->radius2, probe_pass1 ? 0 : layers, d_sample_pidx, d_ray_mask, cnt, block_stats);
-        else if (knn_sel == 3 && gp.P <= 63 && gs.n_points < (1ll << 26))
-            knn3_kernel<8><<<blocks, 256, 0, st>>>(v, d_work, d_sample_loc_w, q->SR, q->radius2, layers, d_sample_pidx, d_ray_mask, cnt, block_stats);
         else
-            knn2_kernel<8><<<blocks, 256, 0, st>>>(v, d_work, d_sample_loc_w, q->SR, q->radius2, layers, d_sample_pidx, d_ray_mask, cnt, block_stats);
+            knn3_kernel<8><<<blocks, 256, 0, st>>>(v, d_work, d_sample_loc_w, q->SR, q->radius2, layers, d_sample_pidx, d_ray_mask, cnt, block_stats);
         knn_finalize_kernel<<<1, 256, 0, st>>>(block_stats, blocks, cnt);
         HNR_LAUNCH_CHECK();
         return HNR_OK;

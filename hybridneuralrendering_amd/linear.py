@@ -39,23 +39,6 @@ class PackedLinear:
                                                    _lib.stream()), "hnr_linear_f32_gather_add")
         return out
 
-    def side(self, a, R, ridx=None, r_cols=None, r_mode=0, out=None, act=False, slope=0.01, K=None):
-        """hnr_linear_f32_side: r_mode 0 -> out = act(a W^T + b + R[ridx[m]]) on the first r_cols columns (R is out itself for "+=");
-        r_mode 1 -> out = (a W^T + b) * LeakyReLU'(R[m]) on the first r_cols columns (backward: input gradient)."""
-        L = _lib.lib()
-        M, lda = a.shape[0], a.stride(0) if a.shape[0] > 1 else a.shape[1]
-        if out is None:
-            out = torch.empty((M, self.N), dtype=torch.float32, device=a.device)
-        ldc = out.stride(0) if M > 1 else out.shape[1]
-        ldr = R.stride(0) if R.shape[0] > 1 else R.shape[1]
-        with torch.cuda.device(a.device):
-            _lib.check(L.hnr_linear_f32_side(ctypes.c_void_p(a.data_ptr()), int(lda), _lib.ptr(self.wp), _lib.ptr(self.bp),
-                                             ctypes.c_void_p(R.data_ptr()), _lib.ptr(ridx) if ridx is not None else None, int(ldr),
-                                             int(self.N if r_cols is None else r_cols), int(r_mode), ctypes.c_void_p(out.data_ptr()),
-                                             int(ldc), M, self.N, self.K if K is None else K, 1 if act else 0, float(slope),
-                                             _lib.stream()), "hnr_linear_f32_side")
-        return out
-
     def __call__(self, a, out=None, act=False, slope=0.01, K=None):
         """a: [M, lda] fp32 (lda % 4 == 0, lda >= K); out: optional [M, ldc] buffer (ldc >= N). Returns out."""
         L = _lib.lib()
@@ -70,70 +53,6 @@ class PackedLinear:
                                         ctypes.c_void_p(out.data_ptr()), int(ldc), M, self.N, self.K if K is None else K,
                                         1 if act else 0, float(slope), _lib.stream()), "hnr_linear_f32")
         return out
-
-
-class SplitLinear:
-    """A 256-wide nn.Linear on the bf16 matrix cores with exactly split fp32 operands (hnr_linear_s3; csrc/linear_s3.hip).
-    Same call surface as PackedLinear.__call__ / gather_add."""
-
-    def __init__(self, weight, bias):
-        L = _lib.lib()
-        weight = _lib.require_gpu(weight.detach(), "weight", torch.float32)
-        self.N, self.K = int(weight.shape[0]), int(weight.shape[1])
-        nbytes = int(L.hnr_linear_s3_packed_bytes(self.N, self.K))
-        if nbytes <= 0 or self.N != 256:
-            raise HnrError("SplitLinear: N must be 256 (got %d)" % self.N)
-        dev = weight.device
-        self.w3 = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
-        self.bp = torch.empty((256,), dtype=torch.float32, device=dev)
-        b = None if bias is None else _lib.require_gpu(bias.detach(), "bias", torch.float32)
-        with torch.cuda.device(dev):
-            _lib.check(L.hnr_linear_s3_pack(_lib.ptr(weight), _lib.ptr(b) if b is not None else None, self.N, self.K,
-                                            _lib.ptr(self.w3), _lib.ptr(self.bp), _lib.stream()), "hnr_linear_s3_pack")
-
-    def _run(self, a, R, ridx, out, act, slope, K):
-        L = _lib.lib()
-        if a.dim() != 2 or a.stride(1) != 1:
-            raise HnrError("SplitLinear: A must be 2-D with unit inner stride")
-        M, lda = a.shape[0], a.stride(0) if a.shape[0] > 1 else a.shape[1]
-        if out is None:
-            out = torch.empty((M, self.N), dtype=torch.float32, device=a.device)
-        ldc = out.stride(0) if M > 1 else out.shape[1]
-        with torch.cuda.device(a.device):
-            _lib.check(L.hnr_linear_s3(ctypes.c_void_p(a.data_ptr()), int(lda), _lib.ptr(self.w3), _lib.ptr(self.bp),
-                                       _lib.ptr(R) if R is not None else None, _lib.ptr(ridx) if ridx is not None else None,
-                                       int(R.stride(0)) if R is not None else 0, ctypes.c_void_p(out.data_ptr()), int(ldc), M, self.N,
-                                       self.K if K is None else K, 1 if act else 0, float(slope), _lib.stream()), "hnr_linear_s3")
-        return out
-
-    def __call__(self, a, out=None, act=False, slope=0.01, K=None):
-        return self._run(a, None, None, out, act, slope, K)
-
-    def gather_add(self, a, R, ridx, out=None, act=False, slope=0.01, K=None):
-        return self._run(a, R, ridx, out, act, slope, K)
-
-
-def weight_grad(dZ, X, N, K, dW=None, db=None, accumulate=False, want_bias=True):
-    """dW[N,K] = dZ[:, :N]^T X[:, :K], db[N] = column sums of dZ (hnr_linear_f32_wgrad).  dZ / X: 2-D fp32, unit inner
-    stride, row strides multiples of 4.  dW may be a column slice of a larger gradient (its row stride is honoured)."""
-    L = _lib.lib()
-    M = int(dZ.shape[0])
-    if X.shape[0] != M:
-        raise HnrError("weight_grad: dZ and X must have the same number of rows")
-    dev = dZ.device
-    if dW is None:
-        dW = torch.empty((N, K), dtype=torch.float32, device=dev)
-        accumulate = False
-    if db is None and want_bias:
-        db = torch.empty((N,), dtype=torch.float32, device=dev)
-    ldz = dZ.stride(0) if M > 1 else dZ.shape[1]
-    ldx = X.stride(0) if M > 1 else X.shape[1]
-    scratch = torch.empty((max(int(L.hnr_linear_wgrad_scratch_elems(M, N, K)), 1),), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
-        _lib.check(L.hnr_linear_f32_wgrad(ctypes.c_void_p(dZ.data_ptr()), int(ldz), ctypes.c_void_p(X.data_ptr()), int(ldx), M, N, K,
-                                          ctypes.c_void_p(dW.data_ptr()), int(dW.stride(0)), _lib.ptr(db) if db is not None else None,
-                                          1 if accumulate else 0, _lib.ptr(scratch), _lib.stream()), "hnr_linear_f32_wgrad")
-    return dW, db
 
 
 class FusedMlp3:

@@ -71,11 +71,10 @@ class HybridRenderer:
         # dense arithmetic of the per-neighbour layers (fp32 in / out, fp32-class error in every mode):
         #   "f16x2"  (default) the whole per-neighbour chain in ONE kernel (hnr_chain_forward, K = 8): operands split into two fp16
         #            terms, three 16-bit MFMAs per product, activations never leave the CU;
-        #   "bf16x3" one launch per layer, fp32 operands split exactly into three bf16 terms (hnr_linear_s3);
         #   "f32"    one launch per layer on fp32 MFMA (hnr_linear_f32).
         self.dense = os.environ.get("HNR_DENSE", "f16x2")
-        if self.dense not in ("f16x2", "bf16x3", "f32"):
-            raise HnrError("HNR_DENSE must be f16x2, bf16x3 or f32, got %r" % self.dense)
+        if self.dense not in ("f16x2", "f32"):
+            raise HnrError("HNR_DENSE must be f16x2 or f32, got %r" % self.dense)
         self.split_merge = True           # multiply the colour-feature columns of aux_merge_weight_block.0 once per sample
         # the whole frame as ONE library call (hnr_render_forward: no host read between query and composite); HNR_SINGLE_CALL=0 runs the
         # same kernels stage by stage from Python with exactly sized buffers (one host read of the counters)
@@ -241,11 +240,7 @@ class HybridRenderer:
                   pk["b1_dist"].gather_add(Xd, ptab, row_pid, out=B, act=True, slope=sl, K=60)   # 60 -> 256 (+ per-point addend)
               else:
                   pk["b1"][0](A, out=B, act=True, slope=sl)                   # 284 -> 256
-              if self.dense == "bf16x3":
-                  ps = self.agg.packed_split()
-                  l12, l30, l32 = ps["b1_2"], ps["b3_0"], ps["b3_2"]
-              else:
-                  l12, l30, l32 = pk["b1"][1], pk["b3"][0], pk["b3"][1]
+              l12, l30, l32 = pk["b1"][1], pk["b3"][0], pk["b3"][1]
               with T("dense_b1_2"):
                   l12(B, out=C, act=True, slope=sl)                           # 256 -> 256 into X3[:, :256]
               H3 = A[:, :256]

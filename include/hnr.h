@@ -193,23 +193,6 @@ int hnr_linear_f32_gather_add(const float *d_A, int lda, const float *d_Wp, cons
 int hnr_linear_f32_side(const float *d_A, int lda, const float *d_Wp, const float *d_bias_p, const float *d_R,
                         const int32_t *d_ridx, int ldr, int r_cols, int r_mode, float *d_C, int ldc, int M, int N, int K,
                         int act, float slope, void *stream);
-/* The same dense layer on the bf16 matrix cores by EXACT operand splitting (csrc/linear_s3.hip): every fp32 operand is the
- * exact sum of three bf16 values (x = h + m + l), the six partial products >= 2^-16 |a w| are issued as
- * v_mfma_f32_32x32x16_bf16 with fp32 accumulation, the three dropped ones sum to <= 2^-23 |a w| (one fp32 rounding of the
- * product): fp32-class results at 6/16 of the fp32 matrix-pipe time.  N must be 256 (the per-neighbour layers block1 / block3,
- * point_aggregators.py:948,:972).  d_W3: hnr_linear_s3_packed_bytes(N,K) bytes, d_bias_p: float[256], packed once per
- * checkpoint.  d_R / d_ridx (may both be NULL): per-row addend R[ridx[m], 0..N) added before the activation (ldr >= N). */
-int64_t hnr_linear_s3_packed_bytes(int N, int K);
-int hnr_linear_s3_pack(const float *d_W, const float *d_bias /*may be NULL*/, int N, int K, void *d_W3, float *d_bias_p, void *stream);
-int hnr_linear_s3(const float *d_A, int lda, const void *d_W3, const float *d_bias_p, const float *d_R, const int32_t *d_ridx,
-                  int ldr, float *d_C, int ldc, int M, int N, int K, int act, float slope, void *stream);
-/* Weight and bias gradient of a dense layer:  dW[N,K] (row stride lddw) = dZ[M,N]^T X[M,K],  db[N] = column sums of dZ
- * (d_db may be NULL); accumulate != 0 adds to the existing values.  ldz, ldx multiples of 4; d_scratch:
- * float[hnr_linear_wgrad_scratch_elems(M,N,K)].  Deterministic (fixed-order two-stage reduction, no atomics). */
-int64_t hnr_linear_wgrad_scratch_elems(int M, int N, int K);
-int hnr_linear_f32_wgrad(const float *d_dZ, int ldz, const float *d_X, int ldx, int M, int N, int K, float *d_dW, int lddw,
-                         float *d_db, int accumulate, float *d_scratch, void *stream);
-
 /* ------------------------------------------------------------------------------------------------
  * Stage 3b: everything of the gather / aggregate / composite path that is not a dense layer.
  * Row order is the reference's boolean-mask order, (ray, slot, k) ascending, so packed rows line up
@@ -468,45 +451,17 @@ int hnr_image_features_bwd(const float *d_img, int V, int H, int W, const float 
                            const float *d_scratch, float *d_g_pyramid, float *const *g_conv_w, float *const *g_conv_b,
                            void *stream);
 
-/* alpha branch + softplus(x-1) + K-weighted sums (:1005-1026, :471-476): d_gX5[:, :256], d_g_sigma ->
- * d_gZ4 [rows,256] (d pre-activation of block3's last layer), d_g_wagg [rows]; alpha weights: atomics. */
-int hnr_ksum_bwd(const float *d_H4, int ldh, const float *d_wagg, const float *d_alpha_w, const float *d_alpha_b,
-                 const int32_t *d_vs_off, const int32_t *d_vs_cnt, const int64_t *d_counts, int cap_samples,
-                 const float *d_gX5, int ldg5, const float *d_g_sigma, float slope, float *d_gZ4, int ldgz, float *d_g_wagg,
-                 float *d_g_alpha_w, float *d_g_alpha_b, void *stream);
-
-/* NeuralPoints gather (neural_points.py:709-720), block3 extras (:957-971), conf straight-through clamp (:1422-1424, :1508-1512):
- * d_gX3[:, 256:263], d_g_wagg, optional d_g_conf_out [R,SR,K] (gradient of the conf_coefficient output) ->
- * points_conf / points_dir / points_color gradients (atomics into [N], [N,3], [N,3]). */
-int hnr_gather_rows_bwd(const int32_t *d_sample_pidx, const float *d_raydir, const int32_t *d_vs_item, const int32_t *d_vs_off,
-                        const int32_t *d_vs_cnt, const int64_t *d_counts, int SR, int K, int cap_samples, const float *d_gX3,
-                        int ldg3, const float *d_g_wagg, const float *d_weight, const float *d_g_conf_out, float *d_g_conf,
-                        float *d_g_dir, float *d_g_color, void *stream);
-
-/* Deterministic form of the same: the per-row contributions [d color 3 | d dir 3 | d conf | 0] are written to d_G8 [rows, 8] instead of
- * being added with atomics; hnr_segment_sum_rows_det over the rows sorted by touched-point index (hnr_sort_rows_by_key of d_row_u) and
- * hnr_point_small_grads then add them per point in a fixed order: bit-identical gradients run to run. */
+/* NeuralPoints gather (neural_points.py:709-720), block3 extras (:957-971), conf straight-through clamp (:1422-1424, :1508-1512) transposed:
+ * d_gX3[:, 256:263], d_g_wagg, optional d_g_conf_out [R,SR,K] (gradient of the conf_coefficient output) -> per-row contributions
+ * [d color 3 | d dir 3 | d conf | 0] in d_G8 [rows, 8]; hnr_segment_sum_rows_det over the rows sorted by touched-point index
+ * (hnr_sort_rows_by_key) adds them per point in a fixed order: bit-identical gradients run to run, no float atomics. */
 int hnr_gather_rows_bwd_rows(const int32_t *d_sample_pidx, const float *d_raydir, const int32_t *d_vs_item, const int32_t *d_vs_off,
                              const int32_t *d_vs_cnt, const int64_t *d_counts, int SR, int K, int cap_samples, const float *d_gX3,
                              int ldg3, const float *d_g_wagg, const float *d_weight, const float *d_g_conf_out, float *d_G8, void *stream);
-int hnr_point_small_grads(const float *d_P8, const int32_t *d_ulist, int U, float *d_g_conf, float *d_g_dir, float *d_g_color, void *stream);
 /* dst[(dst_index ? dst_index[k] : k), 0:n_cols] (+)= sum of the rows A[perm[e], :] with keys_sorted[e] == k, for the DENSE keys k = 0 .. n_keys-1;
  * one wave per key, rows added in sorted (= original row) order, no atomics.  n_cols a multiple of 4, <= 256. */
 int hnr_segment_sum_rows_det(const float *d_A, int lda, const int32_t *d_keys_sorted, const int32_t *d_perm, int64_t M, int n_cols,
                              int n_keys, const int32_t *d_dst_index, float *d_dst, int64_t dst_stride, int accumulate, void *stream);
-
-/* The set of points a batch touches: d_uidx [n_points] = compact index or -1, d_ulist [<= cap] = their ids (ascending),
- * d_row_u [M] = compact index of every neighbour row, *d_count = how many.  d_scratch: int32[ceil(n_points/1024)]. */
-int hnr_unique_points(const int32_t *d_row_pid, int64_t M, int n_points, int32_t *d_uidx, int32_t *d_ulist, int cap,
-                      int32_t *d_row_u, int32_t *d_count, int32_t *d_scratch, void *stream);
-/* d_dst[d_idx[m], :] += d_src[m, :] (atomics; n_cols a multiple of 4): per-point sum of block1's first-layer gradient. */
-int hnr_scatter_add_rows(const float *d_src, int lds, const int32_t *d_idx, int64_t M, int n_cols, float *d_dst, int ldd, void *stream);
-/* positional encoding of the embedding (:931-938) transposed: d_gE [n,224] (+ forward rows d_E) -> d_g_emb[ids[u], :] +=. */
-int hnr_point_rows_bwd(const float *d_gE, int ldg, const float *d_E, int lde, const int32_t *d_ids, int n, int F, float *d_g_emb,
-                       void *stream);
-/* g *= LeakyReLU'(y) in place;  out[s,:] = sum over the V view rows of a sample. */
-int hnr_dleaky(float *d_g, int ldg, const float *d_y, int ldy, int64_t M, int N, float slope, void *stream);
-int hnr_sum_views(const float *d_in, int ldi, int V, int cap, int n_samples, int N, float *d_out, int ldo, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Dense layers of the TRAINING step on the 16-bit matrix pipe (csrc/h2gemm.hip), fp32 in / fp32 out, the chain's two-term fp16 split

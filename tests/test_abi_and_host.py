@@ -267,8 +267,15 @@ def test_c_abi_rejects_bad_arguments_without_touching_the_gpu():
     assert L.hnr_linear_f32(null, 64, one, one, one, 256, 0, 256, 60, 1, 0.01, null) == 0          # M == 0: nothing to do
     assert L.hnr_linear_f32_side(one, 64, one, one, null, null, 256, 256, 0, one, 256, 10, 256, 60, 0, 0.01, null) == bad   # side operand missing
     assert L.hnr_linear_f32_side(one, 64, one, one, one, null, 256, 256, 1, one, 256, 10, 256, 60, 1, 0.01, null) == bad    # r_mode 1 with act
-    assert L.hnr_linear_f32_wgrad(one, 255, one, 64, 10, 256, 60, one, 60, null, 0, one, null) == bad                        # ldz % 4
-    assert L.hnr_linear_wgrad_scratch_elems(1000, 256, 256) >= 256 * 256
+    # training-step GEMMs: device-side row counts, segments, shapes
+    assert L.hnr_h2lin(one, 254, 10, null, 1, 0, one, 256, 256, 0, 1, 0.01, null, 0, one, 256, null, null) == bad               # lda % 4
+    assert L.hnr_h2lin(one, 256, 10, null, 1, 0, one, 256, 256, 1, 0, 0.01, null, 0, one, 256, null, null) == bad               # mode 1 without the stored activation
+    assert L.hnr_h2lin(one, 256, 10, null, 9, 100, one, 256, 256, 0, 1, 0.01, null, 0, one, 256, null, null) == bad             # more than 8 segments
+    assert L.hnr_h2lin(one, 100, 10, null, 1, 0, one, 256, 100, 0, 1, 0.01, null, 0, one, 256, null, null) == bad               # no kernel for 7 k steps
+    assert b"k steps" in L.hnr_last_error()
+    assert L.hnr_h2wgrad(one, 255, one, 64, 10, null, 1, 0, 256, 60, one, one, one, 60, null, 0, one, null) == bad             # ldz % 4
+    assert L.hnr_h2wgrad(one, 256, one, 288, 10, null, 1, 0, 256, 288, one, one, one, 288, null, 0, one, null) == bad          # K + 1 columns must fit 9 tiles
+    assert L.hnr_h2wgrad_scratch_bytes(256, 256) >= 256 * 256 * 4 and L.hnr_h2lin_packed_bytes(300) == -1
     q = _lib.QueryParams(R=10, D=400, SR=24, K=40, kernel_size=(3, 3, 3), radius2=1.0, tmid_stride=0, pad_outputs=1)
     assert L.hnr_march_query(one, one, one, one, ctypes.byref(q), one, one, one, one, one, one, null) == bad                # K > HNR_MAX_K
     assert b"K=40" in L.hnr_last_error()
@@ -281,15 +288,6 @@ def test_c_abi_rejects_bad_arguments_without_touching_the_gpu():
     assert L.hnr_blur_select(one, one, one, 40, 9, 7, 8, one, one, null) == bad                                               # too many kernels
     assert L.hnr_blur_select(one, one, one, 12, 8, 7, 8, one, one, null) == bad                                               # even kernel size
     assert L.hnr_segment_sum_rows(one, 48, null, 0, one, one, 10, 46, one, 48, null) == bad                                   # n_cols % 4
-    # split-bf16 dense layer: N must be 256, strides multiples of 4, addend needs its index
-    assert L.hnr_linear_s3_packed_bytes(128, 256) == 8 * 49152 and L.hnr_linear_s3_packed_bytes(300, 256) == -1
-    assert L.hnr_linear_s3_pack(one, null, 300, 256, one, one, null) == bad
-    assert L.hnr_linear_s3(one, 256, one, one, null, null, 0, one, 256, 10, 128, 256, 1, 0.01, null) == bad                    # N != 256
-    assert b"N must be 256" in L.hnr_last_error()
-    assert L.hnr_linear_s3(one, 254, one, one, null, null, 0, one, 256, 10, 256, 250, 1, 0.01, null) == bad                    # lda % 4
-    assert L.hnr_linear_s3(one, 256, one, one, one, null, 256, one, 256, 10, 256, 256, 1, 0.01, null) == bad                   # addend without index
-    assert L.hnr_linear_s3(one, 256, one, one, null, null, 0, one, 258, 10, 256, 256, 1, 0.01, null) == bad                    # ldc % 4
-    assert L.hnr_linear_s3(null, 256, one, one, null, null, 0, one, 256, 0, 256, 256, 1, 0.01, null) == 0                      # M == 0
     # learnable blur / voxel down-sampling
     assert L.hnr_blur_apply(one, one, 8, 7, 8, 1, one, null) == bad                                                           # even kernel size
     assert L.hnr_blur_apply(one, one, 9, 7, 8, 3, one, null) == bad                                                           # boundary_mode 3
@@ -329,33 +327,6 @@ def test_install_rebinds_the_reference_globals():
             assert po[:len(pt)] == pt or set(pt) <= set(po), (po, pt)
     finally:
         (ref.vol.NeuralPoints, ref.vol.PointAggregator, ref.vol.NeuralPointsRayMarching, ref.vol.ray_march, ref.npts.lighting_fast_querier_w) = saved
-
-
-def test_three_bf16_terms_represent_fp32_exactly():
-    """The arithmetic claim behind hnr_linear_s3 (csrc/linear_s3.hip): x = h + m + l with h = bf16(x), m = bf16(x - h),
-    l = bf16(x - h - m) (round to nearest even) is EXACT for fp32 x, and the three partial products the kernel drops
-    (m*l, l*m, l*l) are <= 2^-23 |a w| together."""
-    rng = np.random.default_rng(5)
-    x = np.concatenate([rng.standard_normal(200000).astype(np.float32) * np.float32(10.0) ** rng.integers(-6, 6, 200000).astype(np.float32),
-                        np.array([0.0, 1.0, -1.0, 3.0e38, 1.17549435e-38 * 2 ** 20, 0.1, 1 / 3], np.float32)])
-
-    def bf16(v):
-        u = v.astype(np.float32).view(np.uint32).astype(np.uint64)
-        u = (u + 0x7FFF + ((u >> 16) & 1)) >> 16 << 16
-        return u.astype(np.uint32).view(np.float32)
-
-    h = bf16(x)
-    r1 = x - h
-    m = bf16(r1)
-    r2 = r1 - m
-    l = bf16(r2)
-    assert np.array_equal(h.astype(np.float64) + m.astype(np.float64) + l.astype(np.float64), x.astype(np.float64))
-    assert np.all(np.abs(m) <= np.abs(x) * 2.0 ** -8) and np.all(np.abs(l) <= np.abs(x) * 2.0 ** -16)
-    w = rng.standard_normal(x.size).astype(np.float32)
-    wh = bf16(w); wm = bf16(w - wh); wl = bf16(w - wh - wm)
-    f = lambda a: a.astype(np.float64)
-    kept = f(h) * f(wh) + f(h) * f(wm) + f(m) * f(wh) + f(h) * f(wl) + f(m) * f(wm) + f(l) * f(wh)
-    assert np.all(np.abs(f(x) * f(w) - kept) <= np.abs(f(x) * f(w)) * 2.0 ** -23 + 1e-300)
 
 
 def test_ctypes_structs_have_the_layout_of_the_c_header(tmp_path):

@@ -154,54 +154,6 @@ def test_train_step_matches_oracle_on_a_fresh_batch():
     _check_grads(got, ref64, "vs fp64", tol_weights=TOL_POINTS)
 
 
-@pytest.mark.parametrize("M,N,K,ldz,ldx", [(1000, 256, 256, 256, 256), (777, 256, 263, 256, 264), (5000, 128, 280, 128, 280),
-                                           (300, 64, 48, 64, 48), (4097, 45, 90, 48, 92), (1, 256, 60, 256, 64), (0, 64, 64, 64, 64),
-                                           (100000, 256, 224, 256, 224)])
-def test_weight_grad_matches_torch(M, N, K, ldz, ldx):
-    from hybridneuralrendering_amd.linear import weight_grad
-    g = torch.Generator(device="cpu").manual_seed(M + N + K)
-    dZ = torch.randn((M, ldz), generator=g).cuda()
-    X = torch.randn((M, ldx), generator=g).cuda()
-    dW, db = weight_grad(dZ, X, N, K)
-    ref = (dZ[:, :N].double().t() @ X[:, :K].double())
-    refb = dZ[:, :N].double().sum(0)
-    tol = 2e-6 * max(M, 1) ** 0.5 * 8
-    assert (dW.double() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
-    assert (db.double() - refb).abs().max().item() <= tol * max(1.0, refb.abs().max().item())
-    # accumulate into a column slice of a wider gradient
-    G = torch.ones((N, K + 10), device="cuda")
-    weight_grad(dZ, X, N, K, dW=G[:, 5:5 + K], want_bias=False, accumulate=True)
-    assert (G[:, 5:5 + K].double() - 1 - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
-    assert torch.all(G[:, :5] == 1) and torch.all(G[:, 5 + K:] == 1)
-
-
-@pytest.mark.parametrize("M,N,K", [(1000, 256, 256), (333, 263, 256), (2000, 45, 45), (500, 280, 128), (129, 48, 64)])
-def test_input_grad_gemm_with_leaky_derivative(M, N, K):
-    """hnr_linear_f32_side r_mode=1: dZ_prev = (dZ W) * LeakyReLU'(Y_prev) on the first r_cols columns; r_mode=0 with R = out: '+='."""
-    from hybridneuralrendering_amd.linear import PackedLinear
-    g = torch.Generator(device="cpu").manual_seed(M * 3 + N)
-    W = (torch.randn((K, N), generator=g) * 0.1).cuda()           # forward layer [out=K, in=N]; input gradient has N columns
-    dZ = torch.randn((M, K), generator=g).cuda()
-    ldy = (N + 3) // 4 * 4
-    Y = torch.randn((M, ldy), generator=g).cuda()
-    Y[:, ::7] = 0.0                                                   # leaky'(0) = slope (torch convention)
-    tw = PackedLinear(W.t().contiguous(), None)
-    r_cols = min(N, 256)
-    ldk = (K + 3) // 4 * 4
-    dZp = torch.zeros((M, ldk), device="cuda")
-    dZp[:, :K] = dZ
-    out = tw.side(dZp, Y, r_cols=r_cols, r_mode=1, slope=0.01, K=K, out=torch.empty((M, ldy), device="cuda"))
-    ref = dZ.double() @ W.double()
-    mask = torch.where(Y[:, :N].double() > 0, 1.0, 0.01)
-    mask[:, r_cols:] = 1.0
-    ref = ref * mask
-    assert (out[:, :N].double() - ref).abs().max().item() < 5e-5 * max(1.0, ref.abs().max().item())
-    acc = torch.full((M, ldy), 2.0, device="cuda")
-    tw.side(dZp, acc, r_mode=0, out=acc, K=K)
-    ref2 = dZ.double() @ W.double() + 2.0
-    assert (acc[:, :N].double() - ref2).abs().max().item() < 5e-5 * max(1.0, ref2.abs().max().item())
-
-
 @pytest.mark.parametrize("M,n_cols,n_keys,two", [(5000, 256, 300, False), (20000, 48, 1500, True), (17, 48, 5, True), (100000, 256, 40000, False)])
 def test_sort_and_segment_sum_equal_index_add(M, n_cols, n_keys, two):
     """hnr_sort_rows_by_key + hnr_segment_sum_rows == torch index_add over the rows with key >= 0."""
