@@ -843,6 +843,7 @@ extern "C" int hnr_chain_forward(const void *d_workspace, const float *d_point_t
     ChainArgs a;
     a.xp = (const char *)d_workspace; a.aux = (const char *)d_workspace + (size_t)blocks * 4 * CH_XP_GROUP;
     a.ptab = d_point_table; a.ldt = ldt; a.wimg = (const char *)d_packed;
+    { static int tab0 = -1; if (tab0 < 0) { const char *e = getenv("HNR_CHAIN_PROBE_TAB0"); tab0 = e ? atoi(e) : 0; } if (tab0) a.ldt = 0; }      // probe: every row reads table row 0 (what the gather's latency costs; results are garbage)
     a.counts = reinterpret_cast<const unsigned long long *>(d_counts);
     a.X5 = d_X5; a.ld5 = ld5; a.sigma = d_sigma; a.slope = slope; a.cap_samples = cap_samples; a.dbg = d_dbg; a.dbg_layer = dbg_layer;
     const int n_cu = chain_num_cus();

@@ -57,7 +57,7 @@ __device__ long long g_mlp_probe[24];
 // other's MFMAs -- the phases of a single workgroup are serial.
 // workgroups per CU a variant is built for (registers) and launched with (the LDS planes of layer 0 allow them): the phases of a tile are
 // serial (load + split, MFMA, epilogue, barriers), so co-resident workgroups are what keeps the CU busy
-constexpr int mlp3_wgs_per_cu(int S0, int RT, int MODE) { return MODE == 1 ? 2 : RT >= 4 ? 1 : (RT == 1 || S0 <= 6) ? 4 : 2; }
+constexpr int mlp3_wgs_per_cu(int S0, int RT, int MODE) { return MODE == 1 ? (RT >= 4 ? 2 : 4) : RT >= 4 ? 1 : (RT == 1 || S0 <= 6) ? 4 : 2; }
 
 // rendezvous that waits for this wave's LDS traffic only (a __syncthreads() also waits for every global load in flight)
 #ifdef HNR_MLP_FULL_BARRIER
@@ -71,7 +71,7 @@ constexpr int mlp3_wgs_per_cu(int S0, int RT, int MODE) { return MODE == 1 ? 2 :
 template <int S0, int S1, int S2, int S3, int MODE, int RT = 4>
 __global__ __launch_bounds__(256, mlp3_wgs_per_cu(S0, RT, MODE)) void mlp3_kernel(MlpArgs a)
 {
-    static_assert(MODE != 1 || RT == 4, "the merge stage is built on 128-row tiles (32 samples x 4 views)");
+    static_assert(MODE != 1 || RT == 4 || RT == 2, "the merge stage is built on 128- or 64-row tiles (32 / 16 samples x 4 views)");
     constexpr int SLOT = RT * 2048 + ML_PAD, ROWS = 32 * RT;               // LDS bytes per k step of the planes: [row tile RT][plane 2][64 lanes][16 B] + pad
     constexpr int SMAX3 = S0 > S1 ? (S0 > S2 ? S0 : S2) : (S1 > S2 ? S1 : S2), SMAX = SMAX3 > S3 ? SMAX3 : S3;
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -101,9 +101,9 @@ __global__ __launch_bounds__(256, mlp3_wgs_per_cu(S0, RT, MODE)) void mlp3_kerne
     float *rowinv = exch + ROWS * 4;                                       // [row ROWS]: 2^-k of the input row's scale
     // MODE 1 extras: fp32 rows [128][48] = [imgfeat45 | ddir3] of the tile's (sample, view) rows, per-row pixel offset / validity / merge weight
     float *s_f = rowinv + ROWS;
-    int *s_pix = reinterpret_cast<int *>(s_f + 128 * 48);
-    float *s_vm = reinterpret_cast<float *>(s_pix + 128), *s_w = s_vm + 128;
-    float *s_wl = s_w + 128;                                               // MODE 1: the last merge-weight layer's 64 weights (+ zero padding to 128)
+    int *s_pix = reinterpret_cast<int *>(s_f + ROWS * 48);
+    float *s_vm = reinterpret_cast<float *>(s_pix + ROWS), *s_w = s_vm + ROWS;
+    float *s_wl = s_w + ROWS;                                              // MODE 1: the last merge-weight layer's 64 weights (+ zero padding to 128)
     // Which (row tile, column tile) pairs a wave multiplies.  Wide layers (N = 128): wave w = column tile w of all RT row tiles.  When every layer is
     // at most 64 wide (merge weights 48 -> 64 -> 64 -> 64, mix-up 90 -> 45 -> 45 -> 45) that left waves 2 and 3 idle through every MFMA loop and
     // epilogue: there the rows are split too (RS) -- wave w = column tile w & 1 of the row tiles (w >> 1) RTW .. + RTW - 1.  Same arithmetic per element.
@@ -133,13 +133,13 @@ __global__ __launch_bounds__(256, mlp3_wgs_per_cu(S0, RT, MODE)) void mlp3_kerne
             // (a) reprojection into the view (w2iproject, neural_points_volumetric_model.py:248-255), truncation to a pixel + bounds rule
             //     (point_aggregators.py:1077-1088), delta view direction (:296-310) -- the arithmetic of proj_rows_kernel;
             //     threads 0..127 take the projection of row tid, threads 128..255 the direction deltas of row tid - 128 (waves 2, 3 used to idle here)
-            {
-                const int row_t = tid & 127, ls = row_t >> 2, v = row_t & 3;
+            if (tid < 2 * ROWS) {
+                const int row_t = tid % ROWS, ls = row_t >> 2, v = row_t & 3;
                 long long sidx = row_base / 4 + ls;
                 if (sidx * 4 >= M) sidx = M / 4 - 1;
                 const float *pw = a.loc_w + (size_t)a.vs_item[sidx] * 3;
                 const float x = pw[0], y = pw[1], z = pw[2];
-              if (tid < 128) {
+              if (tid < ROWS) {
                 const float *mm = a.w2c + 16 * v;
                 float c[3];
 #pragma unroll
@@ -167,14 +167,15 @@ __global__ __launch_bounds__(256, mlp3_wgs_per_cu(S0, RT, MODE)) void mlp3_kerne
             __syncthreads();
             // (b) the 45 feature channels of the pixel (192-B contiguous per row; channels 45..47 of the map are padding);
             {
-                float4 f4[6];                                                // all six scattered 16-B loads of a thread in flight together
+                constexpr int NF = ROWS * 12 / 256;                          // scattered 16-B loads per thread, all in flight together
+                float4 f4[NF];
 #pragma unroll
-                for (int it = 0; it < 6; ++it) {
+                for (int it = 0; it < NF; ++it) {
                     const int idx = tid_t + 256 * it, row = idx / 12, q = idx - row * 12;
                     f4[it] = *reinterpret_cast<const float4 *>(a.fm + (size_t)s_pix[row] + 4 * q);
                 }
 #pragma unroll
-                for (int it = 0; it < 6; ++it) {
+                for (int it = 0; it < NF; ++it) {
                     const int idx = tid_t + 256 * it, row = idx / 12, q = idx - row * 12;
                     float *d = s_f + row * 48 + 4 * q;
                     if (q < 11) *reinterpret_cast<float4 *>(d) = f4[it]; else d[0] = f4[it].x;      // column 44; 45..47 hold the direction deltas
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(256, mlp3_wgs_per_cu(S0, RT, MODE)) void mlp3_kerne
             }
             __syncthreads();
             // (c) layer-0 operand planes of the rows 32 wave + j
-            {
+            if (wave < RT) {
                 const float *src = s_f + (32 * wave + j) * 48 + 8 * h;
                 float x[3][8];
                 float m = 0.f;
@@ -424,10 +425,10 @@ __global__ __launch_bounds__(256, mlp3_wgs_per_cu(S0, RT, MODE)) void mlp3_kerne
             // the last layer's weights and the colour-feature columns that open the mix-up rows: asked for here, after the tile's last weight load (a wait for a weight
             // fragment also waits for every older load), used after the two barriers of the merge-weight epilogue
 #pragma unroll
-            for (int it = 0; it < 6; ++it) {
+            for (int it = 0; it < (8 * RT * 45 + 255) / 256; ++it) {
                 const int idx = tid_t + 256 * it, ls = idx / 45, ch = idx - ls * 45;
                 const long long sidx = row_base / 4 + ls;
-                cfv[it] = (idx < 32 * 45 && sidx * 4 < M) ? a.CF[(size_t)sidx * a.ldcf + ch] : 0.f;
+                cfv[it] = (idx < 8 * RT * 45 && sidx * 4 < M) ? a.CF[(size_t)sidx * a.ldcf + ch] : 0.f;
             }
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) wl4[q4] = *reinterpret_cast<const float4 *>(s_wl + col0 + 4 * q4);
@@ -447,7 +448,7 @@ __global__ __launch_bounds__(256, mlp3_wgs_per_cu(S0, RT, MODE)) void mlp3_kerne
             }
             MLP_LDS_BARRIER();                                             // LDS traffic only: the colour-feature loads asked for above stay in flight across it
             MLP_STAMP(14);
-            if (tid < 128) {
+            if (tid < ROWS) {
                 float4 d4 = *reinterpret_cast<const float4 *>(exch + tid * 4);
                 if (RS) { d4.z = 0.f; d4.w = 0.f; }
                 const float d = __fadd_rn(__fadd_rn(d4.x, d4.y), __fadd_rn(d4.z, d4.w));
@@ -460,10 +461,10 @@ __global__ __launch_bounds__(256, mlp3_wgs_per_cu(S0, RT, MODE)) void mlp3_kerne
             MLP_STAMP(15);
             {
 #pragma unroll
-                for (int it = 0; it < 6; ++it) {
+                for (int it = 0; it < (8 * RT * 45 + 255) / 256; ++it) {
                     const int idx = tid_t + 256 * it, ls = idx / 45, ch = idx - ls * 45;
                     const long long sidx = row_base / 4 + ls;
-                    if (idx < 32 * 45 && sidx * 4 < M) {
+                    if (idx < 8 * RT * 45 && sidx * 4 < M) {
                         float fsum = 0.f, wsum = 0.f;
 #pragma unroll
                         for (int v = 0; v < 4; ++v) { const float wv = s_w[4 * ls + v]; fsum += s_f[(4 * ls + v) * 48 + ch] * wv; wsum += wv; }
@@ -737,12 +738,22 @@ extern "C" int hnr_merge_stage(const float *d_sample_loc_w, const int32_t *d_vs_
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
         if (n_cu <= 0) n_cu = 256;
     }
-    const int64_t tiles = ((int64_t)cap_samples * 4 + 127) / 128;
-    const int grid = (int)(tiles < 2 * n_cu ? tiles : 2 * n_cu);
-    constexpr int ldsb = 4 * ML_SLOT + 128 * 4 * 4 + 128 * 4 + 128 * 48 * 4 + 3 * 128 * 4 + 128 * 4;
+    // 64-row tiles (16 samples x 4 views), four workgroups per CU: the stage is a chain of dependent memory round trips (sample -> projection ->
+    // pixel -> feature rows) and barriers, so it is the number of co-resident workgroups that keeps a CU busy (128-row tiles, two per CU: HNR_MERGE_RT=4)
+    static int rt_sel = 0;
+    if (rt_sel == 0) { const char *e = getenv("HNR_MERGE_RT"); rt_sel = (e && atoi(e) == 4) ? 4 : 2; }
+    const int rows = 32 * rt_sel, wgs = mlp3_wgs_per_cu(3, rt_sel, 1);
+    const int64_t tiles = ((int64_t)cap_samples * 4 + rows - 1) / rows;
+    const int grid = (int)(tiles < (int64_t)wgs * n_cu ? tiles : (int64_t)wgs * n_cu);
+    const int ldsb = 4 * (rt_sel * 2048 + ML_PAD) + rows * 4 * 4 + rows * 4 + rows * 48 * 4 + 3 * rows * 4 + 128 * 4;
     static bool attr = false;
-    if (!attr) { HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(mlp3_kernel<3, 4, 4, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb)); attr = true; }
-    mlp3_kernel<3, 4, 4, 0, 1><<<grid, 256, ldsb, (hipStream_t)stream>>>(a);
+    if (!attr) {
+        HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(mlp3_kernel<3, 4, 4, 0, 1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * ML_SLOT + 128 * 4 * 4 + 128 * 4 + 128 * 48 * 4 + 3 * 128 * 4 + 128 * 4));
+        HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(mlp3_kernel<3, 4, 4, 0, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (2 * 2048 + ML_PAD) + 64 * 4 * 4 + 64 * 4 + 64 * 48 * 4 + 3 * 64 * 4 + 128 * 4));
+        attr = true;
+    }
+    if (rt_sel == 4) mlp3_kernel<3, 4, 4, 0, 1, 4><<<grid, 256, ldsb, (hipStream_t)stream>>>(a);
+    else mlp3_kernel<3, 4, 4, 0, 1, 2><<<grid, 256, ldsb, (hipStream_t)stream>>>(a);
     mlp3_probe_print((hipStream_t)stream, 3, 48);
     HNR_LAUNCH_CHECK();
     return HNR_OK;
