@@ -49,10 +49,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // after(): called once, right after the layer's LAST weight-fragment loads have been issued: loads placed there (gathered addends ...) are
 // not waited for by any later weight wait of the layer (vmcnt counts in order), yet run under the remaining k steps' MFMAs.
 struct H2NoHook { __device__ __forceinline__ void operator()() const {} };
-template <int RT, int CT, int S, int PRELOAD_ALL, int WSTEP, int SLOT, int BAR = -1, int WSAME = 0, int PACE = 0, class Mid, class After = H2NoHook>
+template <int RT, int CT, int S, int PRELOAD_ALL, int WSTEP, int SLOT, int BAR = -1, int WSAME = 0, int PACE = 0, int PDO = 0, class Mid, class After = H2NoHook>
 __device__ __forceinline__ void h2_mfma_layer(__amdgpu_buffer_rsrc_t wsrd, int wbase, unsigned woff, const char *lds, int lane, f32x16 (&acc)[RT][CT], Mid mid, After after = After())
 {
-    constexpr int PD = RT * CT >= 8 ? 2 : 3;
+    constexpr int PD = PDO > 0 ? PDO : (RT * CT >= 8 ? 2 : 3);          // k steps of weight fragments in flight
     // fragment (s, column tile c of the wave, plane p) at s * WSTEP + (c * 2 + p) * 1024 + woff of the layer image; the per-lane part
     // is ONE 32-bit offset beside the uniform buffer descriptor, so no load needs a 64-bit address register pair
     asm volatile("" : "+s"(wbase));                                       // per-tile opaque: the k-step offsets are s_add'ed here, not hoisted out of the tile loop (SGPR spills)

@@ -507,6 +507,297 @@ __global__ __launch_bounds__(256, mlp3_wgs_per_cu(S0, RT, MODE)) void mlp3_kerne
 #endif
 }
 
+// ---- merge stage, one WAVE per 32-row tile (8 samples x 4 views) --------------------------------------------------------------------------
+// The arithmetic of mlp3_kernel<3, 4, 4, 0, 1, RT> element for element (same products, same accumulation order, same scales), laid out so
+// that a wave never waits for another: it owns both 32-column tiles of its 32 rows, so the row maxima, the operand planes of the next layer,
+// the 64 -> 1 last layer and the merge over the four views all stay inside the wave -- no workgroup barrier anywhere in the tile loop.
+// What bounded the workgroup-per-tile form (and a first wave-per-tile form that still streamed its weights from L2) was neither HBM nor the
+// matrix pipe but the CU's vector-memory front end: 115 load instructions per 32 rows, 44 KiB of them weight fragments, kept the texture
+// addresser 95 % busy (rocprofv3 TA_TA_BUSY) while VALU sat at 42 % and MFMA at 17 %.  Here the weights (44 KiB: two column tiles of the
+// 11 k steps), biases and camera matrices live in LDS for the whole kernel, the fp32 feature rows are not staged at all (layer-0 operand planes
+// straight from the gathered registers, row maxima through 32 LDS atomics), the merge re-reads the (L2-resident) feature rows with one lane per
+// (sample, 4 channels) so that its sum over the views needs no exchange, and the mix-up rows leave through LDS as whole 16-B chunks:
+// 28 loads and 3 stores per tile.  12 waves per CU (one workgroup): a tile is a serial chain of ~1250 VALU instructions and 66 MFMAs, and it
+// is the other waves of the SIMD that fill its gaps.
+constexpr int MW_SLOT = 2048 + ML_PAD;                                     // one k step of a wave's operand planes: [plane 2][64 lanes][16 B] + pad
+constexpr int MW_WAVE_LDS = 4 * MW_SLOT + 4 * 32 * 4 + 32 * 3 * 4;         // planes; pixel offset / validity / merge weight / row maximum per row; direction deltas [32][3]
+constexpr int MW_WAVES = 12;
+constexpr int MW_WBYTES = 11 * 4096;                                       // weights [k step 11][column tile 2][plane 2][64 lanes][16 B]
+constexpr int MW_SHARED = MW_WBYTES + 3 * 64 * 4 + 64 * 4 + 128 * 4;       // + bias [3][64], last layer [64], w2c [64] | K [12] | campos [4] | campos_nearest [12]
+constexpr int MW_LDS = MW_SHARED + MW_WAVES * MW_WAVE_LDS;
+#define MW_WAVE_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")  /* LDS traffic of ONE wave is in order: this only pins the compiler */
+template <int S>
+__device__ __forceinline__ void mw_layer(const char *wp, const char *bp, f32x16 (&acc)[2])
+{
+    // fragment (s, c, p) of the layer at wp + s * 4096 + (c * 2 + p) * 1024, operand planes (s, p) at bp + s * MW_SLOT + p * 1024 (both + lane * 16)
+    u32x4 wf[2][2][2], bf[2][2];
+    auto ld = [&](int slot, int s) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) wf[slot][c][q] = *reinterpret_cast<const u32x4 *>(wp + s * 4096 + (c * 2 + q) * 1024);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) bf[slot][q] = *reinterpret_cast<const u32x4 *>(bp + s * MW_SLOT + q * 1024);
+    };
+    ld(0, 0);
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        if (s + 1 < S) ld((s + 1) & 1, s + 1);
+        const int b = s & 1;
+#define MW_W(c, q) __builtin_bit_cast(f16x8, wf[b][c][q])
+#define MW_X(q) __builtin_bit_cast(f16x8, bf[b][q])
+        // smallest terms first (wm*xh, wh*xm, wh*xh), the order of h2_mfma_layer
+#pragma unroll
+        for (int c = 0; c < 2; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(MW_W(c, 1), MW_X(0), acc[c], 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(MW_W(c, 0), MW_X(1), acc[c], 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(MW_W(c, 0), MW_X(0), acc[c], 0, 0, 0);
+#undef MW_W
+#undef MW_X
+    }
+}
+
+__global__ __launch_bounds__(64 * MW_WAVES, 1) void merge_wp_kernel(MlpArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    long long M = a.M_cap;
+    if (a.counts) { const long long c = (long long)a.counts[a.count_index] * a.count_mult; if (c < M) M = c; }
+    const long long n_samp = M / 4;
+    const int n_tiles = (int)((n_samp + 7) / 8);
+    const float *meta = reinterpret_cast<const float *>(a.wimg + (size_t)11 * ML_WSTEP);
+    float *s_bias = reinterpret_cast<float *>(lds + MW_WBYTES);            // [3][64]
+    float *s_wl = s_bias + 3 * 64;                                         // the last layer's 64 weights
+    float *s_cam = s_wl + 64;                                              // w2c [4][16] | K [9] (+3) | campos [3] (+1) | campos_nearest [4][3]
+    char *wl = lds + MW_SHARED + wave * MW_WAVE_LDS;
+    int *s_pix = reinterpret_cast<int *>(wl + 4 * MW_SLOT);
+    float *s_vm = reinterpret_cast<float *>(s_pix + 32), *s_w = s_vm + 32;
+    unsigned *s_max = reinterpret_cast<unsigned *>(s_w + 32);
+    float *s_dd = reinterpret_cast<float *>(s_max + 32);
+    for (int i = tid; i < MW_WBYTES / 16; i += 64 * MW_WAVES) {            // chunk i = (s, c, p, lane)
+        const int s = i >> 8, cp = (i >> 6) & 3, ln = i & 63;
+        *reinterpret_cast<u32x4 *>(lds + i * 16) = *reinterpret_cast<const u32x4 *>(a.wimg + (size_t)s * ML_WSTEP + cp * 1024 + ln * 16);
+    }
+    for (int i = tid; i < 3 * 64; i += 64 * MW_WAVES) s_bias[i] = meta[(i >> 6) * 128 + (i & 63)];
+    for (int i = tid; i < 64; i += 64 * MW_WAVES) { s_wl[i] = a.w_last[i]; s_cam[i] = a.w2c[i]; }
+    if (tid < 9) s_cam[64 + tid] = a.Kmat[tid];
+    if (tid < 3) s_cam[76 + tid] = a.campos[tid];
+    if (tid < 12) s_cam[80 + tid] = a.campos_n[tid];
+    __syncthreads();
+    const float dw0 = meta[ML_DESC + 0], dw1 = meta[ML_DESC + 1], dw2 = meta[ML_DESC + 2], b_last = a.b_last[0];
+    const f32x2 slope2 = {a.slope, a.slope};
+    for (int tile = blockIdx.x * MW_WAVES + wave; tile < n_tiles; tile += gridDim.x * MW_WAVES) {
+        int lane = tid & 63;
+        asm volatile("" : "+v"(lane));                                     // per-tile opaque (see mlp3_kernel)
+        const int h = lane >> 5, j = lane & 31;
+        const long long sbase = (long long)tile * 8;
+        // (a) lanes 0..31: reprojection of row lane; lanes 32..63: direction deltas of row lane - 32 (arithmetic of mlp3_kernel MODE 1 / proj_rows_kernel)
+        {
+            const int ls = j >> 2, v = j & 3;
+            long long sidx = sbase + ls;
+            if (sidx >= n_samp) sidx = n_samp - 1;
+            const float *pw = a.loc_w + (size_t)a.vs_item[sidx] * 3;
+            const float x = pw[0], y = pw[1], z = pw[2];
+            if (h == 0) {
+                const float *mm = s_cam + 16 * v, *Km = s_cam + 64;
+                float c[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) c[q] = x * mm[4 * q] + y * mm[4 * q + 1] + z * mm[4 * q + 2] + mm[4 * q + 3];
+                float i3[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) i3[q] = c[0] * Km[3 * q] + c[1] * Km[3 * q + 1] + c[2] * Km[3 * q + 2];
+                const float den = i3[2] + 1e-10f;
+                const float fx = i3[0] / den, fy = i3[1] / den;
+                int px = (fx > -2.0e9f && fx < 2.0e9f) ? (int)fx : -1;
+                int py = (fy > -2.0e9f && fy < 2.0e9f) ? (int)fy : -1;
+                const bool inval = px < 0 || px >= a.W || py < 0 || py >= a.H;
+                if (inval) { px = 0; py = 0; }
+                s_pix[j] = ((v * a.H + py) * a.W + px) * 48;
+                s_vm[j] = inval ? 0.f : 1.f;
+                s_max[j] = 0u;
+            } else {
+                const float *cp = s_cam + 76, *cnp = s_cam + 80 + 3 * v;
+                const float cx = x - cp[0], cy = y - cp[1], cz = z - cp[2];
+                const float cn = sqrtf(cx * cx + cy * cy + cz * cz) + 1e-6f;
+                const float nx = x - cnp[0], ny = y - cnp[1], nz = z - cnp[2];
+                const float nn = sqrtf(nx * nx + ny * ny + nz * nz) + 1e-6f;
+                s_dd[j * 3] = nx / nn - cx / cn; s_dd[j * 3 + 1] = ny / nn - cy / cn; s_dd[j * 3 + 2] = nz / nn - cz / cn;
+            }
+        }
+        MW_WAVE_FENCE();
+        // (b) the rows [imgfeat45 | ddir3] of the 32 (sample, view) pairs as 32 x 12 chunks of 4 columns, 6 per lane: the feature chunk of the
+        //     row's pixel (scattered 16-B loads, all in flight together), the row maxima through LDS, then the layer-0 operand planes
+        float inv;
+        {
+            float4 f4[6];
+#pragma unroll
+            for (int it = 0; it < 6; ++it) {
+                const int idx = lane + 64 * it, row = idx / 12, q = idx - row * 12;
+                f4[it] = *reinterpret_cast<const float4 *>(a.fm + (size_t)s_pix[row] + 4 * q);
+            }
+#pragma unroll
+            for (int it = 0; it < 6; ++it) {
+                const int idx = lane + 64 * it, row = idx / 12, q = idx - row * 12;
+                if (q == 11) { f4[it].y = s_dd[row * 3]; f4[it].z = s_dd[row * 3 + 1]; f4[it].w = s_dd[row * 3 + 2]; }   // columns 45..47: the direction deltas
+                const float m = fmaxf(fmaxf(fabsf(f4[it].x), fabsf(f4[it].y)), fmaxf(fabsf(f4[it].z), fabsf(f4[it].w)));
+                atomicMax(s_max + row, __float_as_uint(m));
+            }
+            MW_WAVE_FENCE();
+#pragma unroll
+            for (int it = 0; it < 6; ++it) {
+                const int idx = lane + 64 * it, row = idx / 12, q = idx - row * 12, c = 4 * q;
+                const float sc = pow2f(row_scale_exp(__uint_as_float(s_max[row])));
+                unsigned ph0, pm0, ph1, pm1;
+                split2h(__fmul_rn(f4[it].x, sc), __fmul_rn(f4[it].y, sc), ph0, pm0);
+                split2h(__fmul_rn(f4[it].z, sc), __fmul_rn(f4[it].w, sc), ph1, pm1);
+                char *dst = wl + (c >> 4) * MW_SLOT + ((((c >> 3) & 1) * 32 + row) * 16) + (c & 7) * 2;
+                *reinterpret_cast<uint2 *>(dst) = make_uint2(ph0, ph1);
+                *reinterpret_cast<uint2 *>(dst + 1024) = make_uint2(pm0, pm1);
+            }
+            inv = __fmul_rn(pow2f(-row_scale_exp(__uint_as_float(s_max[j]))), dw0);
+        }
+        // the sample's colour-feature addend of layer 0 (this lane's 2 x 16 columns): asked for here, used in the layer's epilogue
+        float4 ad[2][4];
+        {
+            long long sidx = sbase + (j >> 2);
+            if (sidx >= n_samp) sidx = n_samp - 1;
+            const float *rrow = a.R + (size_t)sidx * a.ldr + 16 * h;
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) ad[c][q4] = *reinterpret_cast<const float4 *>(rrow + 32 * c + 4 * q4);
+        }
+        MW_WAVE_FENCE();
+        f32x16 acc[2];
+        auto zero_acc = [&]() {
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+        };
+        // v = acc * inv + bias (+ addend), LeakyReLU; returns the row maximum over this lane's 32 columns
+        auto activate = [&](int layer, auto with_addend) -> float {
+            constexpr bool ADD = decltype(with_addend)::value;
+            float m = 0.f;
+            const f32x2 inv2 = {inv, inv};
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const float4 b = *reinterpret_cast<const float4 *>(s_bias + layer * 64 + 32 * c + 16 * h + 4 * q4);
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int q = 2 * q4 + e;
+                        f32x2 add = e ? f32x2{b.z, b.w} : f32x2{b.x, b.y};
+                        if (ADD) { const float4 t4 = ad[c][q4]; add = add + (e ? f32x2{t4.z, t4.w} : f32x2{t4.x, t4.y}); }
+                        f32x2 v = __builtin_elementwise_fma(f32x2{acc[c][2 * q], acc[c][2 * q + 1]}, inv2, add);
+                        const f32x2 sv = v * slope2;
+                        v.x = fmaxf(v.x, sv.x); v.y = fmaxf(v.y, sv.y);
+                        acc[c][2 * q] = v.x; acc[c][2 * q + 1] = v.y;
+                        m = fmaxf(fmaxf(m, fabsf(v.x)), fabsf(v.y));
+                    }
+                }
+            }
+            return m;
+        };
+        auto publish = [&](float dw, float m) {
+            m = fmaxf(m, __shfl_xor(m, 32));
+            const int k = row_scale_exp(m);
+            const float sc = pow2f(k);
+            const f32x2 sc2 = {sc, sc};
+            inv = __fmul_rn(pow2f(-k), dw);
+            MW_WAVE_FENCE();                                               // (this wave's reads of the previous planes have returned)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                unsigned ph[8], pm[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const f32x2 vs = f32x2{acc[c][2 * q], acc[c][2 * q + 1]} * sc2;
+                    split2h(vs.x, vs.y, ph[q], pm[q]);
+                }
+                char *dst = wl + (2 * c + h) * MW_SLOT + j * 16;
+                *reinterpret_cast<u32x4 *>(dst) = u32x4{ph[0], ph[1], ph[2], ph[3]};
+                *reinterpret_cast<u32x4 *>(dst + 512) = u32x4{ph[4], ph[5], ph[6], ph[7]};
+                *reinterpret_cast<u32x4 *>(dst + 1024) = u32x4{pm[0], pm[1], pm[2], pm[3]};
+                *reinterpret_cast<u32x4 *>(dst + 1024 + 512) = u32x4{pm[4], pm[5], pm[6], pm[7]};
+            }
+            MW_WAVE_FENCE();
+        };
+        const char *wp = lds + lane * 16, *bp = wl + lane * 16;
+        zero_acc();
+        mw_layer<3>(wp, bp, acc);
+        publish(dw1, activate(0, std::true_type{}));
+        zero_acc();
+        mw_layer<4>(wp + 3 * 4096, bp, acc);
+        publish(dw2, activate(1, std::false_type{}));
+        zero_acc();
+        mw_layer<4>(wp + 7 * 4096, bp, acc);
+        (void)activate(2, std::false_type{});
+        // ---- last layer (64 -> 1) + sigmoid, validity / frame weights
+        {
+            float d2[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                float d = 0.f;
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const float4 w4 = *reinterpret_cast<const float4 *>(s_wl + 32 * c + 16 * h + 4 * q4);
+                    d = fmaf(acc[c][4 * q4], w4.x, d); d = fmaf(acc[c][4 * q4 + 1], w4.y, d);
+                    d = fmaf(acc[c][4 * q4 + 2], w4.z, d); d = fmaf(acc[c][4 * q4 + 3], w4.w, d);
+                }
+                d2[c] = __fadd_rn(d, __shfl_xor(d, 32));
+            }
+            const float d = __fadd_rn(d2[0], d2[1]);
+            float wv = 1.f / (1.f + expf(-(d + b_last)));
+            wv *= s_vm[j];
+            if (a.frame_w) wv *= a.frame_w[j & 3];
+            if (h == 0) s_w[j] = wv;
+        }
+        MW_WAVE_FENCE();
+        // ---- weighted merge over the 4 views (:1217) and the mix-up row (:1286-1292): lane = (sample ls, channels 4 q .. 4 q + 3), 96 of them per
+        // tile; the rows [colfeat45 | merged45 | 0 0] are put together in LDS (over the planes, which are dead now) and leave as 16-B chunks
+        float *s_x7 = reinterpret_cast<float *>(wl);                       // [8][92]
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int p = lane + 64 * it, ls = p / 12, q = p - ls * 12;
+            long long sidx = sbase + ls;
+            if (sidx >= n_samp) sidx = n_samp - 1;
+            if (p < 96) {
+                float4 fv[4];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) fv[v] = *reinterpret_cast<const float4 *>(a.fm + (size_t)s_pix[4 * ls + v] + 4 * q);
+                const float4 c4 = *reinterpret_cast<const float4 *>(a.CF + (size_t)sidx * a.ldcf + 4 * q);
+                float fs[4] = {0.f, 0.f, 0.f, 0.f}, wsum = 0.f;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const float wv = s_w[4 * ls + v];
+                    fs[0] += fv[v].x * wv; fs[1] += fv[v].y * wv; fs[2] += fv[v].z * wv; fs[3] += fv[v].w * wv;
+                    wsum += wv;
+                }
+                const float den = wsum + 1e-6f;
+                float *o = s_x7 + ls * 92;
+                o[4 * q] = c4.x; o[45 + 4 * q] = fs[0] / den;
+                if (q < 11) {
+                    o[4 * q + 1] = c4.y; o[4 * q + 2] = c4.z; o[4 * q + 3] = c4.w;
+                    o[45 + 4 * q + 1] = fs[1] / den; o[45 + 4 * q + 2] = fs[2] / den; o[45 + 4 * q + 3] = fs[3] / den;
+                } else { o[90] = 0.f; o[91] = 0.f; }
+            }
+        }
+        MW_WAVE_FENCE();
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {
+            const int idx = lane + 64 * it, ls = idx / 23, c4 = idx - ls * 23;
+            const long long sidx = sbase + ls;
+            if (idx < 8 * 23 && sidx < n_samp) {
+                const f32x4m v = *reinterpret_cast<const f32x4m *>(s_x7 + ls * 92 + 4 * c4);
+                __builtin_nontemporal_store(v, reinterpret_cast<f32x4m *>(a.X7 + (size_t)sidx * a.ld7 + 4 * c4));
+            }
+        }
+        MW_WAVE_FENCE();                                                   // the per-row words and planes are rewritten by the wave's next tile
+    }
+}
+
 struct MlpPackArgs {
     const float *W[4]; int ldw[4], N[4], K[4], S[4], base[4];
     const float *b[4];
@@ -741,18 +1032,30 @@ extern "C" int hnr_merge_stage(const float *d_sample_loc_w, const int32_t *d_vs_
     // 64-row tiles (16 samples x 4 views), four workgroups per CU: the stage is a chain of dependent memory round trips (sample -> projection ->
     // pixel -> feature rows) and barriers, so it is the number of co-resident workgroups that keeps a CU busy (128-row tiles, two per CU: HNR_MERGE_RT=4)
     static int rt_sel = 0;
-    if (rt_sel == 0) { const char *e = getenv("HNR_MERGE_RT"); rt_sel = (e && atoi(e) == 4) ? 4 : 2; }
-    const int rows = 32 * rt_sel, wgs = mlp3_wgs_per_cu(3, rt_sel, 1);
+    if (rt_sel == 0) { const char *e = getenv("HNR_MERGE_RT"); rt_sel = e ? atoi(e) : 1; if (rt_sel != 4 && rt_sel != 2) rt_sel = 1; }
+    // (the wave-per-tile kernel moves the colour-feature and mix-up rows as 16-B chunks, and writes the two padding columns 90, 91 of the mix-up rows)
+    const bool wp_ok = ldcf >= 48 && !(ldcf & 3) && !((uintptr_t)d_CF & 15) && ld7 >= 92 && !(ld7 & 3) && !((uintptr_t)d_X7 & 15);
+    if (rt_sel == 1 && wp_ok) {
+        const int64_t wtiles = ((int64_t)cap_samples + 7) / 8, wg_tiles = (wtiles + MW_WAVES - 1) / MW_WAVES;
+        const int g = (int)(wg_tiles < (int64_t)n_cu ? wg_tiles : (int64_t)n_cu);
+        static bool attr_wp = false;
+        if (!attr_wp) { HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(merge_wp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, MW_LDS)); attr_wp = true; }
+        merge_wp_kernel<<<g, 64 * MW_WAVES, MW_LDS, (hipStream_t)stream>>>(a);
+        HNR_LAUNCH_CHECK();
+        return HNR_OK;
+    }
+    const int rt_k = rt_sel == 4 ? 4 : 2;
+    const int rows = 32 * rt_k, wgs = mlp3_wgs_per_cu(3, rt_k, 1);
     const int64_t tiles = ((int64_t)cap_samples * 4 + rows - 1) / rows;
     const int grid = (int)(tiles < (int64_t)wgs * n_cu ? tiles : (int64_t)wgs * n_cu);
-    const int ldsb = 4 * (rt_sel * 2048 + ML_PAD) + rows * 4 * 4 + rows * 4 + rows * 48 * 4 + 3 * rows * 4 + 128 * 4;
+    const int ldsb = 4 * (rt_k * 2048 + ML_PAD) + rows * 4 * 4 + rows * 4 + rows * 48 * 4 + 3 * rows * 4 + 128 * 4;
     static bool attr = false;
     if (!attr) {
         HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(mlp3_kernel<3, 4, 4, 0, 1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * ML_SLOT + 128 * 4 * 4 + 128 * 4 + 128 * 48 * 4 + 3 * 128 * 4 + 128 * 4));
         HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(mlp3_kernel<3, 4, 4, 0, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (2 * 2048 + ML_PAD) + 64 * 4 * 4 + 64 * 4 + 64 * 48 * 4 + 3 * 64 * 4 + 128 * 4));
         attr = true;
     }
-    if (rt_sel == 4) mlp3_kernel<3, 4, 4, 0, 1, 4><<<grid, 256, ldsb, (hipStream_t)stream>>>(a);
+    if (rt_k == 4) mlp3_kernel<3, 4, 4, 0, 1, 4><<<grid, 256, ldsb, (hipStream_t)stream>>>(a);
     else mlp3_kernel<3, 4, 4, 0, 1, 2><<<grid, 256, ldsb, (hipStream_t)stream>>>(a);
     mlp3_probe_print((hipStream_t)stream, 3, 48);
     HNR_LAUNCH_CHECK();
