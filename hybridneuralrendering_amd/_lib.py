@@ -144,6 +144,7 @@ SIGNATURES = {
                                 ctypes.POINTER(RenderCamera), ctypes.POINTER(RenderViews), _P, ctypes.c_int64, ctypes.POINTER(RenderOutputs), _P]),
     "hnr_merge_stage": (_I, [_P] * 8 + [_I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _I, _I, _F, _P, _I, _P]),
     "hnr_final_color": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P]),
+    "hnr_mixup_stage": (_I, [_P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _I, _F, _P, _I, _P, _P]),
     "hnr_composite": (_I, [_P] * 8 + [_I, _I, _I, _F, _I, _P, _P, _P, _P, _P]),
     "hnr_probe_outputs": (_I, [_P] * 10 + [_I, _I, _I, _I] + [_P] * 7 + [_P]),
     "hnr_ray_march": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P]),

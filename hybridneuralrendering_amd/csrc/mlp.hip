@@ -798,6 +798,243 @@ __global__ __launch_bounds__(64 * MW_WAVES, 1) void merge_wp_kernel(MlpArgs a)
     }
 }
 
+// ---- mix-up stage, one wave per 32 samples: color_mixup_block (90 -> 45 -> 45 -> 45, :1285-1292) + learn_residuals (:1294) +
+// color_final_block + sigmoid decode (:1295, :1334, :478-482), scattered with sigma into the decoded rows.  Same layout as merge_wp_kernel
+// (weights, biases in LDS; no workgroup barrier in the tile loop); the arithmetic is that of mlp3_kernel<6, 3, 3, 0, 0, RT> followed by
+// final_color_kernel element for element -- including the order of final_color_kernel's sum over the 128 columns (16 partial sums of 8
+// columns, combined as a tree), which is rebuilt here from the two lanes that hold a sample's row.
+struct MixArgs {
+    const float *X7; int ld7;                            // [S, ld7 >= 92] mix-up rows (90 columns + padding)
+    const char *wimg;                                    // hnr_mlp_pack image of the three layers (12 k steps)
+    const float *CF; int ldcf;                           // colour feature [S,128]
+    const float *w_fin, *b_fin;                          // color_final_block.0 [3,128], [3]
+    const float *sigma; const int32_t *vs_item;
+    const unsigned long long *counts; long long S_cap;
+    float slope;
+    float *Y; int ldy;                                   // optional: the mix-up output rows [S, ldy >= 48]
+    float *decoded;                                      // [R*SR,4]
+};
+constexpr int MX_WAVES = 12;
+constexpr int MX_WAVE_LDS = 3 * MW_SLOT + 32 * 4;                          // planes of 3 k steps (layer 0 goes through them in two halves of 48 columns), row maxima
+constexpr int MX_WBYTES = 12 * 4096;
+constexpr int MX_SHARED = MX_WBYTES + 3 * 64 * 4 + 3 * 128 * 4;            // + bias [3][64], color_final_block weights [3][128]
+constexpr int MX_LDS = MX_SHARED + MX_WAVES * MX_WAVE_LDS;
+__global__ __launch_bounds__(64 * MX_WAVES, 1) void mixfinal_wp_kernel(MixArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    long long n_samp = a.S_cap;
+    if (a.counts) { const long long c = (long long)a.counts[HNR_CNT_SAMPLES_VALID]; if (c < n_samp) n_samp = c; }
+    const int n_tiles = (int)((n_samp + 31) / 32);
+    const float *meta = reinterpret_cast<const float *>(a.wimg + (size_t)12 * ML_WSTEP);
+    float *s_bias = reinterpret_cast<float *>(lds + MX_WBYTES);            // [3][64]
+    float *s_fin = s_bias + 3 * 64;                                        // [3][128]
+    char *wl = lds + MX_SHARED + wave * MX_WAVE_LDS;
+    unsigned *s_max = reinterpret_cast<unsigned *>(wl + 3 * MW_SLOT);
+    for (int i = tid; i < MX_WBYTES / 16; i += 64 * MX_WAVES) {            // chunk i = (s, c, p, lane)
+        const int s = i >> 8, cp = (i >> 6) & 3, ln = i & 63;
+        *reinterpret_cast<u32x4 *>(lds + i * 16) = *reinterpret_cast<const u32x4 *>(a.wimg + (size_t)s * ML_WSTEP + cp * 1024 + ln * 16);
+    }
+    for (int i = tid; i < 3 * 64; i += 64 * MX_WAVES) s_bias[i] = meta[(i >> 6) * 128 + (i & 63)];
+    for (int i = tid; i < 3 * 128; i += 64 * MX_WAVES) s_fin[i] = a.w_fin[i];
+    __syncthreads();
+    const float dw0 = meta[ML_DESC + 0], dw1 = meta[ML_DESC + 1], dw2 = meta[ML_DESC + 2];
+    const float bfin[3] = {a.b_fin[0], a.b_fin[1], a.b_fin[2]};
+    const f32x2 slope2 = {a.slope, a.slope};
+    for (int tile = blockIdx.x * MX_WAVES + wave; tile < n_tiles; tile += gridDim.x * MX_WAVES) {
+        int lane = tid & 63;
+        asm volatile("" : "+v"(lane));
+        const int h = lane >> 5, j = lane & 31;
+        const long long sbase = (long long)tile * 32;
+        if (h == 0) s_max[j] = 0u;
+        MW_WAVE_FENCE();
+        // (a) the 32 rows as 32 x 24 chunks of 4 columns (90 real columns, 96 in the planes), 12 per lane, read as contiguous bursts;
+        //     row maxima through LDS, power-of-two scale, fp16 split; the layer-0 operand planes are written (and multiplied) in two halves
+        //     of 48 columns, so that a wave needs the LDS of 3 k steps only
+        float inv;
+        float4 f4[12];
+#pragma unroll
+        for (int it = 0; it < 12; ++it) {
+            const int idx = lane + 64 * it, row = idx / 24, q = idx - row * 24;
+            long long sidx = sbase + row;
+            if (sidx >= n_samp) sidx = n_samp - 1;
+            if (q < 23) {
+                f4[it] = *reinterpret_cast<const float4 *>(a.X7 + (size_t)sidx * a.ld7 + 4 * q);
+            } else f4[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int it = 0; it < 12; ++it) {
+            const int idx = lane + 64 * it, row = idx / 24, q = idx - row * 24;
+            if (q == 22) { f4[it].z = 0.f; f4[it].w = 0.f; }               // columns 90, 91: padding of the rows
+            const float m = fmaxf(fmaxf(fabsf(f4[it].x), fabsf(f4[it].y)), fmaxf(fabsf(f4[it].z), fabsf(f4[it].w)));
+            atomicMax(s_max + row, __float_as_uint(m));
+        }
+        MW_WAVE_FENCE();
+        auto planes_half = [&](int half) {
+#pragma unroll
+            for (int it = 0; it < 12; ++it) {
+                const int idx = lane + 64 * it, row = idx / 24, q = idx - row * 24, c = 4 * q - 48 * half;
+                if (c >= 0 && c < 48) {
+                    const float sc = pow2f(row_scale_exp(__uint_as_float(s_max[row])));
+                    unsigned ph0, pm0, ph1, pm1;
+                    split2h(__fmul_rn(f4[it].x, sc), __fmul_rn(f4[it].y, sc), ph0, pm0);
+                    split2h(__fmul_rn(f4[it].z, sc), __fmul_rn(f4[it].w, sc), ph1, pm1);
+                    char *dst = wl + (c >> 4) * MW_SLOT + ((((c >> 3) & 1) * 32 + row) * 16) + (c & 7) * 2;
+                    *reinterpret_cast<uint2 *>(dst) = make_uint2(ph0, ph1);
+                    *reinterpret_cast<uint2 *>(dst + 1024) = make_uint2(pm0, pm1);
+                }
+            }
+        };
+        planes_half(0);
+        inv = __fmul_rn(pow2f(-row_scale_exp(__uint_as_float(s_max[j]))), dw0);
+        MW_WAVE_FENCE();
+        f32x16 acc[2];
+        auto zero_acc = [&]() {
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+        };
+        auto activate = [&](int layer, bool act) -> float {
+            float m = 0.f;
+            const f32x2 inv2 = {inv, inv};
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const float4 b = *reinterpret_cast<const float4 *>(s_bias + layer * 64 + 32 * c + 16 * h + 4 * q4);
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int q = 2 * q4 + e;
+                        const f32x2 add = e ? f32x2{b.z, b.w} : f32x2{b.x, b.y};
+                        f32x2 v = __builtin_elementwise_fma(f32x2{acc[c][2 * q], acc[c][2 * q + 1]}, inv2, add);
+                        if (act) { const f32x2 sv = v * slope2; v.x = fmaxf(v.x, sv.x); v.y = fmaxf(v.y, sv.y); }
+                        acc[c][2 * q] = v.x; acc[c][2 * q + 1] = v.y;
+                        m = fmaxf(fmaxf(m, fabsf(v.x)), fabsf(v.y));
+                    }
+                }
+            }
+            return m;
+        };
+        auto publish = [&](float dw, float m) {
+            m = fmaxf(m, __shfl_xor(m, 32));
+            const int k = row_scale_exp(m);
+            const float sc = pow2f(k);
+            const f32x2 sc2 = {sc, sc};
+            inv = __fmul_rn(pow2f(-k), dw);
+            MW_WAVE_FENCE();
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                unsigned ph[8], pm[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const f32x2 vs = f32x2{acc[c][2 * q], acc[c][2 * q + 1]} * sc2;
+                    split2h(vs.x, vs.y, ph[q], pm[q]);
+                }
+                if (2 * c + h < 3) {                                       // (columns 48..63 are padding: the next layers read 3 k steps)
+                    char *dst = wl + (2 * c + h) * MW_SLOT + j * 16;
+                    *reinterpret_cast<u32x4 *>(dst) = u32x4{ph[0], ph[1], ph[2], ph[3]};
+                    *reinterpret_cast<u32x4 *>(dst + 512) = u32x4{ph[4], ph[5], ph[6], ph[7]};
+                    *reinterpret_cast<u32x4 *>(dst + 1024) = u32x4{pm[0], pm[1], pm[2], pm[3]};
+                    *reinterpret_cast<u32x4 *>(dst + 1024 + 512) = u32x4{pm[4], pm[5], pm[6], pm[7]};
+                }
+            }
+            MW_WAVE_FENCE();
+        };
+        const char *wp = lds + lane * 16, *bp = wl + lane * 16;
+        long long srow = sbase + j;
+        const bool ok = srow < n_samp;
+        if (!ok) srow = n_samp - 1;
+        zero_acc();
+        mw_layer<3>(wp, bp, acc);
+        MW_WAVE_FENCE();
+        planes_half(1);
+        MW_WAVE_FENCE();
+        mw_layer<3>(wp + 3 * 4096, bp, acc);
+        publish(dw1, activate(0, true));
+        zero_acc();
+        mw_layer<3>(wp + 6 * 4096, bp, acc);
+        publish(dw2, activate(1, true));
+        // the sample's colour feature: this lane's columns 16 h + [0, 16), 32 + 16 h + [0, 16), 64 + 32 h + [0, 32) (asked for under the last layer)
+        const float *cfrow = a.CF + (size_t)srow * a.ldcf;
+        float4 cfa[2][4], cfb[8];
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) cfa[c][q4] = *reinterpret_cast<const float4 *>(cfrow + 32 * c + 16 * h + 4 * q4);
+#pragma unroll
+        for (int q4 = 0; q4 < 8; ++q4) cfb[q4] = *reinterpret_cast<const float4 *>(cfrow + 64 + 32 * h + 4 * q4);
+        zero_acc();
+        mw_layer<3>(wp + 9 * 4096, bp, acc);
+        (void)activate(2, false);
+        if (a.Y && ok) {
+            float *o = a.Y + (size_t)srow * a.ldy;
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int col = 32 * c + 16 * h + 4 * q4;
+                    if (col + 4 <= 48) *reinterpret_cast<float4 *>(o + col) = make_float4(acc[c][4 * q4], acc[c][4 * q4 + 1], acc[c][4 * q4 + 2], acc[c][4 * q4 + 3]);
+                }
+        }
+        // ---- residual (mix-up output + colour feature on the first 45 columns) and the three dot products over the 128 columns.
+        // final_color_kernel sums them as 16 partial sums p_i of 8 columns (lane i of 16), then by the tree
+        //   ((p0+p1)+(p2+p3)) + ((p7+p6)+(p5+p4))  +  (((p15+p14)+(p13+p12)) + ((p8+p9)+(p10+p11)));
+        // lane (j, h = 0) holds the columns of p0 p1 p4 p5 p8..p11, lane (j, 1) those of p2 p3 p6 p7 p12..p15.
+        float x[2][16];
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float cfv = reinterpret_cast<const float *>(&cfa[c][0])[r];
+                x[c][r] = (32 * c + 16 * h + r < 45) ? acc[c][r] + cfv : cfv;
+            }
+        float rj[3];
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            const float *wf = s_fin + o * 128;
+            float pa[2][2];                                                // [c][half of 8 columns]: p_{4 c + 2 h + half}
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    float r = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) r += x[c][8 * hf + e] * wf[32 * c + 16 * h + 8 * hf + e];
+                    pa[c][hf] = r;
+                }
+            float pb[4];                                                   // p_{8 + 4 h + i}
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float r = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) r += reinterpret_cast<const float *>(&cfb[0])[8 * i + e] * wf[64 + 32 * h + 8 * i + e];
+                pb[i] = r;
+            }
+            const float u0 = pa[0][0] + pa[0][1];                          // h = 0: p0+p1   h = 1: p2+p3
+            const float u1 = pa[1][0] + pa[1][1];                          // h = 0: p4+p5   h = 1: p6+p7
+            const float uh = (pb[0] + pb[1]) + (pb[2] + pb[3]);            // h = 0: (p8+p9)+(p10+p11)   h = 1: (p12+p13)+(p14+p15)
+            const float v0 = __shfl_xor(u0, 32), v1 = __shfl_xor(u1, 32), vh = __shfl_xor(uh, 32);
+            // (written for h = 0; lane h = 1 computes a mirrored, unused value)
+            const float lo = (u0 + v0) + (v1 + u1);
+            const float hi = vh + uh;
+            rj[o] = lo + hi;
+        }
+        if (ok && h == 0) {
+            float4 out;
+            out.x = a.sigma[srow];
+#pragma unroll
+            for (int o = 0; o < 3; ++o) {
+                const float sg = 1.f / (1.f + expf(-(rj[o] + bfin[o])));
+                const float cch = sg * (1.f + 2.f * 0.001f) - 0.001f;
+                if (o == 0) out.y = cch; else if (o == 1) out.z = cch; else out.w = cch;
+            }
+            reinterpret_cast<float4 *>(a.decoded)[a.vs_item[srow]] = out;
+        }
+        MW_WAVE_FENCE();
+    }
+}
+
 struct MlpPackArgs {
     const float *W[4]; int ldw[4], N[4], K[4], S[4], base[4];
     const float *b[4];
@@ -1058,6 +1295,38 @@ extern "C" int hnr_merge_stage(const float *d_sample_loc_w, const int32_t *d_vs_
     if (rt_k == 4) mlp3_kernel<3, 4, 4, 0, 1, 4><<<grid, 256, ldsb, (hipStream_t)stream>>>(a);
     else mlp3_kernel<3, 4, 4, 0, 1, 2><<<grid, 256, ldsb, (hipStream_t)stream>>>(a);
     mlp3_probe_print((hipStream_t)stream, 3, 48);
+    HNR_LAUNCH_CHECK();
+    return HNR_OK;
+}
+
+extern "C" int hnr_mixup_stage(const float *d_X7, int ld7, const void *d_mlp_mx, const float *d_CF, int ldcf, const float *d_w_fin, const float *d_b_fin,
+                               const float *d_sigma, const int32_t *d_vs_item, const int64_t *d_counts, int cap_samples, float slope, float *d_Y, int ldy,
+                               float *d_decoded, void *stream)
+{
+    if (cap_samples < 0 || ld7 < 92 || (ld7 & 3) || ldcf < 128 || (ldcf & 3) || (d_Y && (ldy < 48 || (ldy & 3))) || !(slope > 0.f && slope < 1.f)) {
+        set_error("hnr_mixup_stage: bad sizes (cap_samples=%d ld7=%d ldcf=%d ldy=%d)", cap_samples, ld7, ldcf, ldy); return HNR_ERR_BADARG;
+    }
+    if (cap_samples == 0) return HNR_OK;
+    if (!d_X7 || !d_mlp_mx || !d_CF || !d_w_fin || !d_b_fin || !d_sigma || !d_vs_item || !d_counts || !d_decoded || ((uintptr_t)d_X7 & 15) ||
+        ((uintptr_t)d_CF & 15) || ((uintptr_t)d_mlp_mx & 15) || ((uintptr_t)d_Y & 15) || ((uintptr_t)d_decoded & 15)) {
+        set_error("hnr_mixup_stage: NULL / unaligned pointer"); return HNR_ERR_BADARG;
+    }
+    MixArgs a;
+    a.X7 = d_X7; a.ld7 = ld7; a.wimg = (const char *)d_mlp_mx; a.CF = d_CF; a.ldcf = ldcf; a.w_fin = d_w_fin; a.b_fin = d_b_fin; a.sigma = d_sigma;
+    a.vs_item = d_vs_item; a.counts = reinterpret_cast<const unsigned long long *>(d_counts); a.S_cap = cap_samples; a.slope = slope;
+    a.Y = d_Y; a.ldy = ldy; a.decoded = d_decoded;
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+        if (n_cu <= 0) n_cu = 256;
+    }
+    const int64_t tiles = ((int64_t)cap_samples + 31) / 32, wg_tiles = (tiles + MX_WAVES - 1) / MX_WAVES;
+    const int g = (int)(wg_tiles < (int64_t)n_cu ? wg_tiles : (int64_t)n_cu);
+    static bool attr = false;
+    if (!attr) { HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(mixfinal_wp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, MX_LDS)); attr = true; }
+    mixfinal_wp_kernel<<<g, 64 * MX_WAVES, MX_LDS, (hipStream_t)stream>>>(a);
     HNR_LAUNCH_CHECK();
     return HNR_OK;
 }

@@ -149,10 +149,10 @@ extern "C" int hnr_render_forward(const hnr_grid *grid, const hnr_render_params 
         HNR_MARK(); HNR_MARK();
     }
     HNR_MARK();
-    const int mxN[3] = {45, 45, 45}, mxK[3] = {90, 45, 45}, act110[3] = {1, 1, 0};
-    if ((rc = hnr_mlp3_forward(L.X7, 92, cap, o->d_counts, HNR_CNT_SAMPLES_VALID, 1, 0, w->d_mlp_mx, 3, mxN, mxK, act110, w->slope, nullptr, nullptr, 0, L.Y1, 48, nullptr, 0, stream)) != HNR_OK) return rc;
+    // color_mixup_block + residual + color_final_block + decode in one launch: the mix-up output never reaches HBM
+    if ((rc = hnr_mixup_stage(L.X7, 92, w->d_mlp_mx, L.CF, 128, w->d_fin_w, w->d_fin_b, L.sigma, L.vs_item, o->d_counts, cap, w->slope, nullptr, 0,
+                              o->d_decoded, stream)) != HNR_OK) return rc;
     HNR_MARK();
-    if ((rc = hnr_final_color(L.Y1, 48, L.CF, 128, w->d_fin_w, w->d_fin_b, L.sigma, L.vs_item, o->d_counts, cap, o->d_decoded, stream)) != HNR_OK) return rc;
     HNR_MARK();
     // ---- composite + fill_invalid
     rc = hnr_composite(o->d_decoded, o->d_sample_loc_w, o->d_sample_pidx, o->d_ray_mask, o->d_ray_nsamp, cam->d_campos, cam->d_camrot, cam->d_bg_color,

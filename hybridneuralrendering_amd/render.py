@@ -84,6 +84,7 @@ class HybridRenderer:
         self.knn_order = os.environ.get("HNR_KNN_ORDER", "reference")
         if self.knn_order not in ("reference", "sorted"):
             raise HnrError("HNR_KNN_ORDER must be 'reference' or 'sorted' (got %r)" % (self.knn_order,))
+        self.fuse_mixup = True            # hnr_mixup_stage instead of the mix-up MLP + hnr_final_color (staged path switch)
         self.fuse_merge = True            # V = 4: hnr_merge_stage instead of hnr_proj_rows + the merge-weight MLP + hnr_merge (staged path switch)
         self.last_counts = None
         if getattr(opt, "which_render_func", "radiance") != "radiance" or getattr(opt, "which_blend_func", "alpha") != "alpha" \
@@ -310,7 +311,13 @@ class HybridRenderer:
                 _lib.check(L.hnr_merge(p(X6), ld6, p(M1), 64, p(pk["mw_last_w"]), p(pk["mw_last_b"]), p(vmask),
                                        p(fw) if fw is not None else None, p(CF), 128, p(counts), V, n_valid, p(X7), 92,
                                        None, None, 0, st()), "hnr_merge")
-          with T("mlp_mixup"):
+          if fused_s and self.fuse_mixup:
+            # color_mixup_block + residual + color_final_block + decode in one launch (hnr_mixup_stage)
+            with T("mlp_mixup"):
+                _lib.check(L.hnr_mixup_stage(p(X7), 92, p(m3["mx"].packed), p(CF), 128, p(pk["fin_w"]), p(pk["fin_b"]), p(sigma), p(vs_item), p(counts),
+                                             n_valid, float(sl), None, 0, p(decoded), st()), "hnr_mixup_stage")
+          else:
+           with T("mlp_mixup"):
             Y1 = _f32((n_valid, 48), dev)
             if fused_s:
                 m3["mx"](X7, Y1, n_valid, counts, ci, 1, slope=sl)
@@ -319,7 +326,7 @@ class HybridRenderer:
                 pk["mx"][0](X7, out=Y1, act=True, slope=sl, K=90)
                 pk["mx"][1](Y1, out=Y2, act=True, slope=sl, K=45)
                 pk["mx"][2](Y2, out=Y1, act=False, K=45)
-          with T("final_color"):
+           with T("final_color"):
             _lib.check(L.hnr_final_color(p(Y1), 48, p(CF), 128, p(pk["fin_w"]), p(pk["fin_b"]), p(sigma), p(vs_item), p(counts),
                                          n_valid, p(decoded), st()), "hnr_final_color")
         out["overflow"] = overflow                 # checked by render_rays AFTER the composite is queued (no pipeline drain here)

@@ -358,6 +358,14 @@ int hnr_merge_stage(const float *d_sample_loc_w, const int32_t *d_vs_item, const
                     const float *d_pre, int ldpre, const void *d_mlp_mw, const float *d_w_last, const float *d_b_last, const float *d_CF, int ldcf,
                     int cap_samples, float slope, float *d_X7, int ld7, void *stream);
 
+/* Mix-up stage in one launch: color_mixup_block (90 -> 45 -> 45 -> 45, :1285-1292; d_mlp_mx = its hnr_mlp_pack image), learn_residuals (:1294),
+ * color_final_block + sigmoid*1.002-0.001 (:1295, :1334, :478-482), scattered with sigma into d_decoded [R*SR,4] (:1337-1338).  Equals
+ * hnr_mlp3_forward + hnr_final_color bit for bit.  d_X7 [S, ld7 >= 92] (ld7 a multiple of 4, 16-B aligned), d_CF [S, ldcf >= 128];
+ * d_Y (optional) receives the mix-up output rows [S, ldy >= 48]. */
+int hnr_mixup_stage(const float *d_X7, int ld7, const void *d_mlp_mx, const float *d_CF, int ldcf, const float *d_w_fin, const float *d_b_fin,
+                    const float *d_sigma, const int32_t *d_vs_item, const int64_t *d_counts, int cap_samples, float slope, float *d_Y, int ldy,
+                    float *d_decoded, void *stream);
+
 /* Residual + color_final_block + sigmoid*1.002-0.001 (:1294-1295, :1334, :478-482), scattered with sigma into
  * d_decoded [R*SR,4] (pre-zeroed by the caller; :1337-1338). */
 int hnr_final_color(const float *d_Y, int ldy, const float *d_CF, int ldcf, const float *d_w_fin, const float *d_b_fin,

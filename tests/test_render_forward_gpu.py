@@ -125,6 +125,19 @@ def test_fused_merge_stage_equals_its_three_kernel_form(tag):
     assert torch.equal(a["decoded"][..., 0], b["decoded"][..., 0])              # densities do not pass through the image branch
 
 
+@pytest.mark.parametrize("tag", ["scannet_small", "synth_small"])
+def test_fused_mixup_stage_equals_its_two_kernel_form(tag):
+    """hnr_mixup_stage (color_mixup_block + residual + color_final_block + decode in one launch) against hnr_mlp3_forward + hnr_final_color on the
+    same frame: the same arithmetic in the same order, so the decoded rows are equal bit for bit."""
+    d, ti, opt, cloud, rnd = _setup(tag)
+    rnd.single_call = False
+    a = _render(rnd, cloud, ti, d)
+    rnd.fuse_mixup = False
+    b = _render(rnd, cloud, ti, d)
+    assert torch.equal(a["decoded"], b["decoded"])
+    assert torch.equal(a["coarse_raycolor"], b["coarse_raycolor"])
+
+
 def test_c1_chair_batch_through_the_single_call_matches_the_imported_reference():
     """BASELINE config C1 (nerf_synthetic/chair 200x200, one 32x32 = 1024-ray batch, 100 k points, SR 80, P 12, max_o 410000;
     dev_scripts/w_n360/chair_hybrid.sh) on the HIP path: hnr_render_forward against tests/golden/render_c1_chair.npz -- the outputs of the imported

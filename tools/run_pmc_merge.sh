@@ -20,5 +20,5 @@ for g in (1,2,3,4):
     for r in rows:
         per[r['Kernel_Name'].split('(')[0][:48]][r['Counter_Name']].append(float(r['Counter_Value']))
     for k,v in per.items():
-        if 'merge_wp' in k or 'mlp3_kernel' in k: print(g,k,{c:max(x) for c,x in v.items()})
+        if "merge_wp" in k or "mlp3_kernel" in k or "mixfinal" in k: print(g,k,{c:max(x) for c,x in v.items()})
 PY
