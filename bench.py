@@ -230,8 +230,7 @@ def train_leg(args, sc, opt, agg, cloud, rnd, cam, dev, steps=5, warmup=2):
     """SURVEY 8d config C3 (fwd+bwd): one 56x56 = 3136-ray training batch (random window, jittered depths, patch drop) through
     the HIP forward + backward with the shipped loss terms.  Reported beside the headline metric, never part of `value`."""
     from hybridneuralrendering_amd import scenes
-    from hybridneuralrendering_amd.train import TrainPath, render_train
-    from hybridneuralrendering_amd.losses import shipped_loss
+    from hybridneuralrendering_amd.train import TrainPath, train_step
     old = opt.is_train
     opt.is_train = 1
     try:
@@ -250,26 +249,23 @@ def train_leg(args, sc, opt, agg, cloud, rnd, cam, dev, steps=5, warmup=2):
                 t.grad = None
             agg.zero_grad(set_to_none=True)
             if ev: ev[0].record()
-            out = render_train(path, agg, cloud.xyz, leaves[0], leaves[1], leaves[2], leaves[3], raydir, cam["campos"], cam["camrot"],
-                               cam["bg"], sc.near, sc.far, cam["c2w_nearest"], cam["campos_nearest"], cam["intrinsic"], cam["images"])
+            # forward -> the shipped loss terms (masked colour MSE + zero-one regulariser on conf_coefficient of the valid rays; value and
+            # gradients on the device, hnr_shipped_loss_rows) -> backward, queued back to back (train.train_step): no autograd graph, no host read
+            out, _pg, _ag = train_step(path, agg, cloud.xyz, leaves[0], leaves[1], leaves[2], leaves[3], raydir, cam["campos"], cam["camrot"],
+                                       cam["bg"], sc.near, sc.far, cam["c2w_nearest"], cam["campos_nearest"], cam["intrinsic"], cam["images"], gt,
+                                       zero_epsilon=1e-3, w_color=1.0, w_zero_one=1e-4)
             if ev: ev[1].record()
-            # the shipped loss terms (masked colour MSE + zero-one regulariser on conf_coefficient of the valid rays), value and
-            # gradients on the device (hnr_shipped_loss)
-            loss, _parts = shipped_loss(out["coarse_raycolor"], out["conf_coefficient"][out["ray_mask"] > 0], gt, out["ray_mask"], 1e-3, 1.0, 1e-4)
-            loss.backward()
-            if ev: ev[2].record()
             return out
         for _ in range(warmup):
             out = one()
         torch.cuda.synchronize()
-        evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
+        evs = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(steps)]
         t0 = time.perf_counter()
         for i in range(steps):
             out = one(evs[i])
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
-        fwd = sum(e[0].elapsed_time(e[1]) for e in evs) / steps
-        bwd = sum(e[1].elapsed_time(e[2]) for e in evs) / steps
+        gpu_ms = sum(e[0].elapsed_time(e[1]) for e in evs) / steps
         c = out["counts"].cpu().numpy()
         # stage times of the two library calls (HIP events recorded by the library at its stage boundaries, one extra step)
         path.timers = {}
@@ -278,6 +274,8 @@ def train_leg(args, sc, opt, agg, cloud, rnd, cam, dev, steps=5, warmup=2):
         stage = {("fwd." + k): round(v, 4) for k, v in path.timers["fwd"][0].elapsed_ms().items()}
         stage.update({("bwd." + k): round(v, 4) for k, v in path.timers["bwd"][0].elapsed_ms().items()})
         path.timers = None
+        fwd = sum(v for k, v in stage.items() if k.startswith("fwd."))          # the forward call's share (its stage events); the rest: loss kernels + backward
+        bwd = gpu_ms - fwd
         # roofline of the step's dominant kernel: the weight-gradient GEMM dW = dZ^T X of a 256 x 256 per-neighbour layer (hnr_h2wgrad, five such
         # launches per step), timed alone with HIP events on tensors of the step's row count (8 row slots per valid sample)
         from hybridneuralrendering_amd import _lib

@@ -152,6 +152,7 @@ SIGNATURES = {
     "hnr_blur_select_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "hnr_shipped_loss_scratch_bytes": (ctypes.c_int64, []),
     "hnr_shipped_loss": (_I, [_P, _P, _P, _I, _P, ctypes.c_int64, _F, _F, _F, _F, _P, _P, _P, _P, _P]),
+    "hnr_shipped_loss_rows": (_I, [_P, _P, _P, _I, _P, _I, _F, _F, _F, _F, _P, _P, _P, _P, _P]),
     "hnr_voxel_downsample_scratch_bytes": (ctypes.c_int64, [ctypes.c_int64]),
     "hnr_voxel_downsample": (_I, [_P, _I, ctypes.POINTER(_F), _F, _P, _P, _P, _P, _P, _P, ctypes.c_int64, _P]),
     "hnr_blur_gray_patches": (_I, [_P, _P, _I, _I, _P, _P]),

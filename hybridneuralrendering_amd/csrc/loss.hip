@@ -21,6 +21,7 @@ struct LossArgs {
     const int8_t *ray_mask;           // [R]
     const float *conf;                // [n_conf]
     int R; long long n_conf;
+    int conf_per_ray;                 // > 0: conf is [R, conf_per_ray] and only the rows of rays with ray_mask > 0 count (n_conf = R * conf_per_ray)
     float eps, w_color, w_zero_one, frame_weight;
     double *partial;                  // [LOSS_BLOCKS][3]: squared error, valid rays, zero-one sum
     float *out;                       // {total, colour, zero_one, n_valid}
@@ -39,6 +40,7 @@ __global__ __launch_bounds__(256) void loss_partial_kernel(LossArgs a)
         }
     }
     for (long long i = t0; i < a.n_conf; i += stride) {
+        if (a.conf_per_ray > 0 && !(a.ray_mask[i / a.conf_per_ray] > 0)) continue;
         const float v = fminf(fmaxf(a.conf[i], a.eps), 1.f - a.eps);
         zo += (double)(logf(v) + logf(1.f - v));
     }
@@ -56,9 +58,10 @@ __global__ __launch_bounds__(256) void loss_finish_kernel(LossArgs a)
         double se = 0.0, nv = 0.0, zo = 0.0;
         for (int b = 0; b < LOSS_BLOCKS; ++b) { se += a.partial[3 * b]; nv += a.partial[3 * b + 1]; zo += a.partial[3 * b + 2]; }
         const float lc = nv > 0.0 ? (float)(se / (3.0 * nv)) : 0.f;
-        const float lz = a.n_conf > 0 ? (float)(zo / (double)a.n_conf) : 0.f;
+        const double n_conf = a.conf_per_ray > 0 ? nv * (double)a.conf_per_ray : (double)a.n_conf;
+        const float lz = n_conf > 0.0 ? (float)(zo / n_conf) : 0.f;
         s_scale[0] = nv > 0.0 ? (float)(2.0 / (3.0 * nv)) * a.w_color * a.frame_weight : 0.f;
-        s_scale[1] = a.n_conf > 0 ? a.w_zero_one / (float)a.n_conf : 0.f;
+        s_scale[1] = n_conf > 0.0 ? a.w_zero_one / (float)n_conf : 0.f;
         if (blockIdx.x == 0) {
             a.out[0] = (lc * a.w_color + 1e-6f) * a.frame_weight + lz * a.w_zero_one;
             a.out[1] = lc; a.out[2] = lz; a.out[3] = (float)nv;
@@ -74,8 +77,9 @@ __global__ __launch_bounds__(256) void loss_finish_kernel(LossArgs a)
     }
     for (long long i = t0; i < a.n_conf; i += stride) {
         const float x = a.conf[i];
+        const bool on = a.conf_per_ray <= 0 || a.ray_mask[i / a.conf_per_ray] > 0;
         // torch.clamp passes the gradient where eps <= x <= 1 - eps
-        a.g_conf[i] = (x >= a.eps && x <= 1.f - a.eps) ? (1.f / x - 1.f / (1.f - x)) * sz : 0.f;
+        a.g_conf[i] = (on && x >= a.eps && x <= 1.f - a.eps) ? (1.f / x - 1.f / (1.f - x)) * sz : 0.f;
     }
 }
 
@@ -85,16 +89,16 @@ using namespace hnr;
 
 extern "C" int64_t hnr_shipped_loss_scratch_bytes(void) { return (int64_t)(LOSS_BLOCKS * 3 * sizeof(double)); }
 
-extern "C" int hnr_shipped_loss(const float *d_color, const float *d_gt, const int8_t *d_ray_mask, int R, const float *d_conf, int64_t n_conf,
-                                float zero_epsilon, float w_color, float w_zero_one, float frame_weight, float *d_out4, float *d_g_color,
-                                float *d_g_conf, void *d_scratch, void *stream)
+static int shipped_loss_impl(const float *d_color, const float *d_gt, const int8_t *d_ray_mask, int R, const float *d_conf, int64_t n_conf, int conf_per_ray,
+                             float zero_epsilon, float w_color, float w_zero_one, float frame_weight, float *d_out4, float *d_g_color,
+                             float *d_g_conf, void *d_scratch, void *stream)
 {
-    if (R < 0 || n_conf < 0 || !(zero_epsilon >= 0.f && zero_epsilon < 0.5f)) { set_error("hnr_shipped_loss: bad sizes or zero_epsilon"); return HNR_ERR_BADARG; }
+    if (R < 0 || n_conf < 0 || conf_per_ray < 0 || !(zero_epsilon >= 0.f && zero_epsilon < 0.5f)) { set_error("hnr_shipped_loss: bad sizes or zero_epsilon"); return HNR_ERR_BADARG; }
     if ((R > 0 && (!d_color || !d_gt || !d_ray_mask)) || (n_conf > 0 && !d_conf) || !d_out4 || !d_scratch || (!d_g_color != !d_g_conf && n_conf > 0 && R > 0)) {
         set_error("hnr_shipped_loss: NULL argument (the two gradient outputs go together)"); return HNR_ERR_BADARG;
     }
     LossArgs a;
-    a.color = d_color; a.gt = d_gt; a.ray_mask = d_ray_mask; a.conf = d_conf; a.R = R; a.n_conf = n_conf;
+    a.color = d_color; a.gt = d_gt; a.ray_mask = d_ray_mask; a.conf = d_conf; a.R = R; a.n_conf = n_conf; a.conf_per_ray = conf_per_ray;
     a.eps = zero_epsilon; a.w_color = w_color; a.w_zero_one = w_zero_one; a.frame_weight = frame_weight;
     a.partial = (double *)d_scratch; a.out = d_out4; a.g_color = d_g_color; a.g_conf = d_g_conf;
     loss_partial_kernel<<<LOSS_BLOCKS, 256, 0, (hipStream_t)stream>>>(a);
@@ -102,4 +106,19 @@ extern "C" int hnr_shipped_loss(const float *d_color, const float *d_gt, const i
     loss_finish_kernel<<<LOSS_BLOCKS, 256, 0, (hipStream_t)stream>>>(a);
     HNR_LAUNCH_CHECK();
     return HNR_OK;
+}
+
+extern "C" int hnr_shipped_loss(const float *d_color, const float *d_gt, const int8_t *d_ray_mask, int R, const float *d_conf, int64_t n_conf,
+                                float zero_epsilon, float w_color, float w_zero_one, float frame_weight, float *d_out4, float *d_g_color,
+                                float *d_g_conf, void *d_scratch, void *stream)
+{
+    return shipped_loss_impl(d_color, d_gt, d_ray_mask, R, d_conf, n_conf, 0, zero_epsilon, w_color, w_zero_one, frame_weight, d_out4, d_g_color, d_g_conf, d_scratch, stream);
+}
+
+extern "C" int hnr_shipped_loss_rows(const float *d_color, const float *d_gt, const int8_t *d_ray_mask, int R, const float *d_conf, int conf_per_ray,
+                                     float zero_epsilon, float w_color, float w_zero_one, float frame_weight, float *d_out4, float *d_g_color,
+                                     float *d_g_conf, void *d_scratch, void *stream)
+{
+    return shipped_loss_impl(d_color, d_gt, d_ray_mask, R, d_conf, (int64_t)R * conf_per_ray, conf_per_ray, zero_epsilon, w_color, w_zero_one, frame_weight, d_out4,
+                             d_g_color, d_g_conf, d_scratch, stream);
 }

@@ -10,26 +10,41 @@ from . import _lib
 from ._lib import HnrError
 
 
+def _loss_call(color, conf, gt, ray_mask, zero_epsilon, w_color, w_zero_one, frame_weight, conf_rows, want_grads=True):
+    """One hnr_shipped_loss[_rows] launch pair: returns (out4, g_color, g_conf) -- all device tensors, nothing is read back."""
+    L = _lib.lib()
+    c = _lib.require_gpu(color.detach(), "coarse_raycolor", torch.float32).reshape(-1, 3)
+    g = _lib.require_gpu(gt, "gt_image", torch.float32).reshape(-1, 3)
+    m = _lib.require_gpu(ray_mask, "ray_mask").reshape(-1)
+    if m.dtype != torch.int8:
+        m = m.to(torch.int8)
+    x = _lib.require_gpu(conf.detach(), "conf_coefficient", torch.float32).reshape(-1)
+    if g.shape[0] != c.shape[0] or m.shape[0] != c.shape[0]:
+        raise HnrError("shipped_loss: coarse_raycolor, gt_image and ray_mask disagree on the number of rays")
+    R = int(c.shape[0])
+    if conf_rows and (R == 0 or x.shape[0] % R):
+        raise HnrError("shipped_loss: conf_rows needs conf_coefficient with one row per ray of the batch")
+    dev = c.device
+    out = torch.empty((4,), dtype=torch.float32, device=dev)
+    g_c, g_x = (torch.empty_like(c), torch.empty_like(x)) if want_grads else (None, None)
+    scratch = torch.empty((int(L.hnr_shipped_loss_scratch_bytes()),), dtype=torch.uint8, device=dev)
+    p = _lib.ptr
+    with torch.cuda.device(dev):
+        if conf_rows:
+            _lib.check(L.hnr_shipped_loss_rows(p(c), p(g), p(m), R, p(x), int(x.shape[0] // R), float(zero_epsilon), float(w_color), float(w_zero_one),
+                                               float(frame_weight), p(out), p(g_c) if want_grads else None, p(g_x) if want_grads else None, p(scratch),
+                                               _lib.stream()), "hnr_shipped_loss_rows")
+        else:
+            _lib.check(L.hnr_shipped_loss(p(c), p(g), p(m), R, p(x), x.shape[0], float(zero_epsilon), float(w_color), float(w_zero_one),
+                                          float(frame_weight), p(out), p(g_c) if want_grads else None, p(g_x) if want_grads else None, p(scratch),
+                                          _lib.stream()), "hnr_shipped_loss")
+    return out, g_c, g_x
+
+
 class _ShippedLoss(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, color, conf, gt, ray_mask, zero_epsilon, w_color, w_zero_one, frame_weight):
-        L = _lib.lib()
-        c = _lib.require_gpu(color.detach(), "coarse_raycolor", torch.float32).reshape(-1, 3)
-        g = _lib.require_gpu(gt, "gt_image", torch.float32).reshape(-1, 3)
-        m = _lib.require_gpu(ray_mask, "ray_mask").reshape(-1)
-        if m.dtype != torch.int8:
-            m = m.to(torch.int8)
-        x = _lib.require_gpu(conf.detach(), "conf_coefficient", torch.float32).reshape(-1)
-        if g.shape[0] != c.shape[0] or m.shape[0] != c.shape[0]:
-            raise HnrError("shipped_loss: coarse_raycolor, gt_image and ray_mask disagree on the number of rays")
-        dev = c.device
-        out = torch.empty((4,), dtype=torch.float32, device=dev)
-        g_c, g_x = torch.empty_like(c), torch.empty_like(x)
-        scratch = torch.empty((int(L.hnr_shipped_loss_scratch_bytes()),), dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev):
-            _lib.check(L.hnr_shipped_loss(_lib.ptr(c), _lib.ptr(g), _lib.ptr(m), c.shape[0], _lib.ptr(x), x.shape[0], float(zero_epsilon),
-                                          float(w_color), float(w_zero_one), float(frame_weight), _lib.ptr(out), _lib.ptr(g_c), _lib.ptr(g_x),
-                                          _lib.ptr(scratch), _lib.stream()), "hnr_shipped_loss")
+    def forward(ctx, color, conf, gt, ray_mask, zero_epsilon, w_color, w_zero_one, frame_weight, conf_rows):
+        out, g_c, g_x = _loss_call(color, conf, gt, ray_mask, zero_epsilon, w_color, w_zero_one, frame_weight, conf_rows)
         ctx.save_for_backward(g_c, g_x)
         ctx.shapes = (color.shape, conf.shape)
         ctx.mark_non_differentiable(out)
@@ -39,11 +54,23 @@ class _ShippedLoss(torch.autograd.Function):
     def backward(ctx, g_total, _g_out):
         g_c, g_x = ctx.saved_tensors
         cs, xs = ctx.shapes
-        return (g_c * g_total).reshape(cs), (g_x * g_total).reshape(xs), None, None, None, None, None, None
+        return (g_c * g_total).reshape(cs), (g_x * g_total).reshape(xs), None, None, None, None, None, None, None
 
 
-def shipped_loss(coarse_raycolor, conf_coefficient, gt_image, ray_mask, zero_epsilon, w_color=1.0, w_zero_one=1e-4, frame_weight=None):
+def _fw(frame_weight):
+    return 1.0 if frame_weight is None else float(torch.as_tensor(frame_weight).reshape(-1)[0])
+
+
+def shipped_loss(coarse_raycolor, conf_coefficient, gt_image, ray_mask, zero_epsilon, w_color=1.0, w_zero_one=1e-4, frame_weight=None, conf_rows=False):
     """Returns (loss_total, parts) with parts = tensor {total, colour MSE, zero-one mean, valid rays}; loss_total is differentiable
-    w.r.t. coarse_raycolor [.., R, 3] and conf_coefficient (any shape).  frame_weight: the dataset item's scalar (or None)."""
-    fw = 1.0 if frame_weight is None else float(torch.as_tensor(frame_weight).reshape(-1)[0])
-    return _ShippedLoss.apply(coarse_raycolor, conf_coefficient, gt_image, ray_mask, zero_epsilon, w_color, w_zero_one, fw)
+    w.r.t. coarse_raycolor [.., R, 3] and conf_coefficient (any shape).  frame_weight: the dataset item's scalar (or None).
+    conf_rows: conf_coefficient holds one row per ray of the BATCH ([R, SR, K], what render_train returns) and the rows of rays with
+    ray_mask = 0 are left out on the device -- instead of indexing it with the mask first (a masked copy, a host read of the number of
+    valid rays, and an index_put in the backward pass)."""
+    return _ShippedLoss.apply(coarse_raycolor, conf_coefficient, gt_image, ray_mask, zero_epsilon, w_color, w_zero_one, _fw(frame_weight), bool(conf_rows))
+
+
+def shipped_loss_grads(coarse_raycolor, conf_coefficient, gt_image, ray_mask, zero_epsilon, w_color=1.0, w_zero_one=1e-4, frame_weight=None, conf_rows=True):
+    """The loss terms and their gradients without an autograd graph: (parts [4] = {total, colour MSE, zero-one mean, valid rays},
+    d total / d coarse_raycolor [R,3], d total / d conf_coefficient (flat)) -- what train.train_step feeds to the backward pass."""
+    return _loss_call(coarse_raycolor, conf_coefficient, gt_image, ray_mask, zero_epsilon, w_color, w_zero_one, _fw(frame_weight), bool(conf_rows))

@@ -311,3 +311,35 @@ def render_train(path, aggregator, xyz, emb, conf, pdir, color, raydir, campos, 
     out = dict(static.pop("_out"))
     out["coarse_raycolor"], out["conf_coefficient"] = col, cc
     return out
+
+
+def train_step(path, aggregator, xyz, emb, conf, pdir, color, raydir, campos, camrot, bg_color, near, far, c2w_nearest, campos_nearest,
+               intrinsic_nearest, images_nearest, gt_image, zero_epsilon=1e-3, w_color=1.0, w_zero_one=1e-4, frame_weight=None, tmid=None,
+               ray_drop=None, assign_grads=True):
+    """forward -> shipped loss terms -> backward of one ray batch as three groups of library launches queued back to back: no autograd
+    graph, no masked copies, nothing read back to the host -- the body of the reference's optimize_parameters before its optimizer steps
+    (models/neural_points_volumetric_model.py:202-214: self.forward(); loss_total.backward(), with compute_losses of
+    models/base_rendering_model.py:1060-1245 in between).  Same arithmetic as render_train + losses.shipped_loss + loss.backward().
+
+    emb/conf/pdir/color and the aggregator's parameters are read as they are; with assign_grads their .grad fields are set (or added to,
+    as autograd does).  Returns (outputs dict with `loss` = {total, colour MSE, zero-one mean, valid rays} on the device,
+    point grads dict, aggregator grads dict keyed by parameter name)."""
+    from .losses import shipped_loss_grads
+    cloud = PointCloud(xyz, emb.detach(), conf.detach(), pdir.detach(), color.detach())
+    out, S = path.forward(cloud, raydir, campos, camrot, bg_color, near, far, c2w_nearest, campos_nearest, intrinsic_nearest, images_nearest,
+                          frame_weight=frame_weight, tmid=tmid, ray_drop=ray_drop)
+    parts, g_col, g_cc = shipped_loss_grads(out["coarse_raycolor"], out["conf_coefficient"], gt_image, out["ray_mask"], zero_epsilon, w_color,
+                                            w_zero_one, frame_weight, conf_rows=True)
+    pg, ag = path.backward(S, g_col, g_cc)
+    out = dict(out)
+    out["loss"] = parts
+    if assign_grads:
+        def put(t, g):
+            if isinstance(t, torch.Tensor) and t.requires_grad:
+                g = g.reshape(t.shape)
+                t.grad = g if t.grad is None else t.grad + g
+        put(emb, pg["points_embeding"]); put(conf, pg["points_conf"]); put(pdir, pg["points_dir"]); put(color, pg["points_color"])
+        for n, q in aggregator.named_parameters():
+            if n in ag:
+                put(q, ag[n])
+    return out, pg, ag

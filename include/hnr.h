@@ -656,6 +656,12 @@ int64_t hnr_shipped_loss_scratch_bytes(void);
 int hnr_shipped_loss(const float *d_color, const float *d_gt, const int8_t *d_ray_mask, int R, const float *d_conf, int64_t n_conf,
                      float zero_epsilon, float w_color, float w_zero_one, float frame_weight, float *d_out4, float *d_g_color,
                      float *d_g_conf, void *d_scratch, void *stream);
+/* The same with d_conf [R, conf_per_ray] holding a row per ray of the batch (the layout hnr_render_train_forward writes): only the rows of rays with
+ * ray_mask > 0 enter the mean (and receive a gradient) -- the reference's conf_coefficient holds the R' valid rays only
+ * (PointAggregator.forward's return, models/aggregators/point_aggregators.py:1519-1522) -- without a masked copy or a host read of the number of valid rays. */
+int hnr_shipped_loss_rows(const float *d_color, const float *d_gt, const int8_t *d_ray_mask, int R, const float *d_conf, int conf_per_ray,
+                          float zero_epsilon, float w_color, float w_zero_one, float frame_weight, float *d_out4, float *d_g_color,
+                          float *d_g_conf, void *d_scratch, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * "Next" row: voxel down-sampling of the initial point cloud, models/mvs/mvs_utils.py:537-563

@@ -99,6 +99,39 @@ def test_train_step_matches_reference_gradients(tag):
     _check_grads(got, d["grad"], "vs reference")
 
 
+@pytest.mark.parametrize("tag", ["scannet_small", "scannet_small_nearest0"])
+def test_graph_free_train_step_matches_reference_gradients(tag):
+    """train.train_step (forward, hnr_shipped_loss_rows, backward queued back to back: no autograd graph, no masked copies, no host read)
+    against the same golden gradients as the autograd path, and the loss terms against the reference's."""
+    from hybridneuralrendering_amd.train import train_step
+    d, ti, opt, agg, path = _setup(tag)
+    emb, conf, pdir, color = _leaves(ti)
+    near, far = d["near_far"]
+    tmid = torch.from_numpy(d["tmid"]).to(emb.device)
+    gt = torch.from_numpy(d["gt"][0]).to(emb.device)
+    agg.zero_grad(set_to_none=True)
+    out, pg, ag = train_step(path, agg, ti["xyz"], emb, conf, pdir, color, ti["raydir"][0], ti["campos"][0], ti["camrotc2w"][0], ti["bg_color"][0],
+                             near, far, ti["c2w_nearest"][0], ti["campos_nearest"][0], ti["intrinsic_nearest"][0], ti["images_nearest"][0], gt,
+                             zero_epsilon=float(d["zero_epsilon"]), w_color=1.0, w_zero_one=1e-4, tmid=tmid)
+    parts = out["loss"].cpu().numpy()
+    np.testing.assert_allclose([parts[1], parts[2]], d["loss"][1:], rtol=2e-5)
+    np.testing.assert_allclose(parts[0] - 1e-6, d["loss"][0], rtol=2e-5, atol=1e-7)              # (`+ 1e-6` of compute_losses, base_rendering_model.py:1198)
+    assert int(parts[3]) == int(d["q_ray_mask"].sum())
+    got = {"neural_points.points_embeding": emb.grad, "neural_points.points_conf": conf.grad,
+           "neural_points.points_dir": pdir.grad, "neural_points.points_color": color.grad}
+    for k, prm in agg.named_parameters():
+        if prm.grad is not None:
+            got["aggregator." + k] = prm.grad
+    assert sorted(k for k in got if k.startswith("aggregator.")) == d["grad_names"], set(got) ^ set(d["grad_names"])
+    _check_grads(got, d["grad"], "graph-free vs reference")
+    # a second call accumulates like autograd does
+    before = emb.grad.clone()
+    train_step(path, agg, ti["xyz"], emb, conf, pdir, color, ti["raydir"][0], ti["campos"][0], ti["camrotc2w"][0], ti["bg_color"][0],
+               near, far, ti["c2w_nearest"][0], ti["campos_nearest"][0], ti["intrinsic_nearest"][0], ti["images_nearest"][0], gt,
+               zero_epsilon=float(d["zero_epsilon"]), tmid=tmid)
+    assert torch.equal(emb.grad, before + before)
+
+
 def test_train_step_matches_oracle_on_a_fresh_batch():
     """Different camera window, fresh jitter, random upstream gradient: HIP backward vs the CPU oracle's autograd."""
     from hybridneuralrendering_amd import scenes
