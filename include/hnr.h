@@ -110,7 +110,10 @@ typedef struct {
                              history, farthest-first replacement: query_point_indices_worldcoords.py:494-513);
                              1: the same neighbour SET in canonical order, ascending (d^2, enumeration order) -- a sorted
                              insertion instead of the replay of that rule (K = 8, 3x3x3 neighbourhood); every consumer of
-                             the path sums over the K slots, so only the fp32 summation order of a sample changes       */
+                             the path sums over the K slots, so only the fp32 summation order of a sample changes.
+                             Caveat: with EXACT d^2 ties at the current maximum of a full list the retained point can differ
+                             (the reference evicts the first maximum in slot order, the sorted list the latest-enumerated
+                             of the tied entries): use 0 for golden / PSNR comparisons on clouds with duplicate distances */
 } hnr_query_params;
 
 /* counters written by hnr_march_query (device, int64[HNR_NCOUNTS]) */
