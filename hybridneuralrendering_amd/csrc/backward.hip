@@ -263,7 +263,7 @@ struct ProjBwdArgs {
     int32_t *bbox;                                       // [V,4] = min x, min y, max x, max y; initialised {W, H, -1, -1}
 };
 
-__global__ __launch_bounds__(256) void proj_rows_bwd_kernel(ProjBwdArgs a)
+__global__ __launch_bounds__(1024) void proj_rows_bwd_kernel(ProjBwdArgs a)
 {
     // one lane per (view, sample) row: pixel key; per-wave min/max of the touched pixels -> one atomic per wave and bound
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -291,8 +291,12 @@ __global__ __launch_bounds__(256) void proj_rows_bwd_kernel(ProjBwdArgs a)
         none = px < 0 || px >= a.W || py < 0 || py >= a.H || (px == 0 && py == 0);
         a.keys[(size_t)v * a.cap + s] = none ? -1 : (v * a.H + py) * a.W + px;
     }
-    // the lanes of a wave almost always belong to one view (rows are view-major): reduce for the first lane's view, the
-    // few lanes of another view fall back to their own atomics
+    // bounds of the touched pixels per view: wave reduction (the lanes of a wave almost always belong to one view: rows are view-major; the few
+    // lanes of another view go by themselves) -> LDS -> at most 16 global atomics per 1024-thread block.  (One set of global atomics per WAVE
+    // was 9600 atomics on one cache line, ~12 ns each: 0.116 ms of the training step for a kernel with 10 us of work.)
+    __shared__ int s_bb[8][4];
+    if (threadIdx.x < 32) s_bb[threadIdx.x >> 2][threadIdx.x & 3] = (threadIdx.x & 2) ? -1 : 0x7fffffff;
+    __syncthreads();
     const int v0 = __shfl(v, 0);
     const bool mine = !none && v == v0;
     int x0 = mine ? px : 0x7fffffff, y0 = mine ? py : 0x7fffffff, x1 = mine ? px : -1, y1 = mine ? py : -1;
@@ -301,12 +305,17 @@ __global__ __launch_bounds__(256) void proj_rows_bwd_kernel(ProjBwdArgs a)
         x1 = max(x1, __shfl_xor(x1, o)); y1 = max(y1, __shfl_xor(y1, o));
     }
     if ((threadIdx.x & 63) == 0 && x1 >= 0) {
-        int32_t *bb = a.bbox + 4 * v0;
+        int *bb = v0 < 8 ? s_bb[v0] : a.bbox + 4 * v0;                      // (more than 8 reference views: straight to the global words)
         atomicMin(bb, x0); atomicMin(bb + 1, y0); atomicMax(bb + 2, x1); atomicMax(bb + 3, y1);
     }
     if (!none && v != v0) {
-        int32_t *bb = a.bbox + 4 * v;
+        int *bb = v < 8 ? s_bb[v] : a.bbox + 4 * v;
         atomicMin(bb, px); atomicMin(bb + 1, py); atomicMax(bb + 2, px); atomicMax(bb + 3, py);
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        const int vv = threadIdx.x >> 2, k = threadIdx.x & 3;
+        if (vv < a.V && s_bb[vv][2] >= 0) { if (k < 2) atomicMin(a.bbox + 4 * vv + k, s_bb[vv][k]); else atomicMax(a.bbox + 4 * vv + k, s_bb[vv][k]); }
     }
 }
 
@@ -704,7 +713,7 @@ extern "C" int hnr_proj_rows_bwd(const float *d_sample_loc_w, const int32_t *d_v
     a.w2c = d_w2c; a.Kmat = d_intrinsic; a.V = V; a.H = H; a.W = W; a.cap = cap_samples; a.keys = keys; a.bbox = d_bbox;
     // rows past counts[SAMPLES_VALID] (none when cap_samples is exact) must not carry stale keys
     HNR_HIP_CHECK(hipMemsetAsync(keys, 0xff, (size_t)rows * 4, st));
-    proj_rows_bwd_kernel<<<cdiv(rows, 256), 256, 0, st>>>(a);
+    proj_rows_bwd_kernel<<<cdiv(rows, 1024), 1024, 0, st>>>(a);
     HNR_LAUNCH_CHECK();
     int rc = hnr_sort_rows_by_key(keys, rows, keys_sorted, perm, d_sort_scratch, sort_scratch_bytes, stream);
     if (rc != HNR_OK) return rc;
