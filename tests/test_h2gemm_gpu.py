@@ -138,3 +138,55 @@ def test_h2wgrad_is_bit_identical_run_to_run_and_zero_rows_are_inert():
     ref = Z.numpy().astype(np.float64).T @ X.numpy().astype(np.float64)
     mag = np.abs(Z.numpy().astype(np.float64)).T @ np.abs(X.numpy().astype(np.float64))
     assert (np.abs(outs[0][0] - ref) / mag).max() < 4e-7
+
+
+def test_segmented_rows_equal_the_packed_layout():
+    """n_seg > 1 (the (view, sample) layout of the merge-weight MLP's rows: segment v starts at physical row v * seg_stride, every segment holds
+    *d_m rows): hnr_h2lin, hnr_h2wgrad and hnr_absmax give what they give on the same rows packed back to back."""
+    dev = _dev()
+    L = _lib.lib()
+    g = torch.Generator(device="cpu").manual_seed(11)
+    n, V, stride, N, K = 1234, 4, 2000, 64, 48
+    packed = torch.randn((V * n, K), generator=g) * torch.exp(torch.randn((V * n, 1), generator=g))
+    Zp = torch.randn((V * n, N), generator=g) * 1e-2
+    seg = torch.full((V * stride, K), float("nan")); segz = torch.full((V * stride, N), float("nan"))
+    for v in range(V):
+        seg[v * stride:v * stride + n] = packed[v * n:(v + 1) * n]
+        segz[v * stride:v * stride + n] = Zp[v * n:(v + 1) * n]
+    W = torch.randn((N, K), generator=g) / np.sqrt(K); b = torch.randn((N,), generator=g)
+    Wd, bd = W.to(dev), b.to(dev)
+    img = pack([Wd], biases=[bd])[0]
+    dn = torch.tensor([n], dtype=torch.int64, device=dev)
+    dall = torch.tensor([V * n], dtype=torch.int64, device=dev)
+    outs = []
+    for A, nseg, ss, dm, rows in ((seg.to(dev), V, stride, dn, V * stride), (packed.to(dev), 1, 0, dall, V * n)):
+        C = torch.full((rows, N), 7.0, device=dev)
+        mx = torch.zeros(1, dtype=torch.int32, device=dev)
+        _lib.check(L.hnr_h2lin(_lib.ptr(A), K, stride if nseg > 1 else rows, _lib.ptr(dm), nseg, ss, _lib.ptr(img), N, K, 0, 1, 0.01, None, 0, _lib.ptr(C), N, _lib.ptr(mx),
+                               _lib.stream()), "hnr_h2lin")
+        am = torch.zeros(1, dtype=torch.int32, device=dev)
+        _lib.check(L.hnr_absmax(_lib.ptr(A), K, stride if nseg > 1 else rows, _lib.ptr(dm), nseg, ss, K, _lib.ptr(am), _lib.stream()), "hnr_absmax")
+        outs.append((C, int(mx.item()), int(am.item())))
+    Cs, Cp = outs[0][0], outs[1][0]
+    for v in range(V):
+        assert torch.equal(Cs[v * stride:v * stride + n], Cp[v * n:(v + 1) * n])
+        assert bool((Cs[v * stride + n:(v + 1) * stride] == 7.0).all()), "rows between the segments were written"
+    assert outs[0][1] == outs[1][1] and outs[0][2] == outs[1][2]
+    assert np.frombuffer(np.int32(outs[0][2]).tobytes(), dtype=np.float32)[0] == float(packed.abs().max())
+    # weight gradient over the segmented rows = over the packed rows (same 16-row blocks: n is not a multiple of 16, so the block boundaries
+    # differ and only the fp64-referenced tolerance holds)
+    res = []
+    for Zt, Xt, nseg, ss, dm, rows in ((segz.to(dev), seg.to(dev), V, stride, dn, stride), (Zp.to(dev), packed.to(dev), 1, 0, dall, V * n)):
+        mz = torch.zeros(1, dtype=torch.int32, device=dev); mx = torch.zeros(1, dtype=torch.int32, device=dev)
+        _lib.check(L.hnr_absmax(_lib.ptr(Zt), N, rows, _lib.ptr(dm), nseg, ss, N, _lib.ptr(mz), _lib.stream()), "hnr_absmax")
+        _lib.check(L.hnr_absmax(_lib.ptr(Xt), K, rows, _lib.ptr(dm), nseg, ss, K, _lib.ptr(mx), _lib.stream()), "hnr_absmax")
+        scratch = torch.empty((int(L.hnr_h2wgrad_scratch_bytes(N, K)),), dtype=torch.uint8, device=dev)
+        dW, db = torch.empty((N, K), device=dev), torch.empty((N,), device=dev)
+        _lib.check(L.hnr_h2wgrad(_lib.ptr(Zt), N, _lib.ptr(Xt), K, rows, _lib.ptr(dm), nseg, ss, N, K, _lib.ptr(mz), _lib.ptr(mx), _lib.ptr(dW), K, _lib.ptr(db), 0,
+                                 _lib.ptr(scratch), _lib.stream()), "hnr_h2wgrad")
+        res.append((dW.cpu().numpy().astype(np.float64), db.cpu().numpy().astype(np.float64)))
+    Z64, X64 = Zp.numpy().astype(np.float64), packed.numpy().astype(np.float64)
+    ref, mag = Z64.T @ X64, np.abs(Z64).T @ np.abs(X64)
+    for dW, db in res:
+        assert (np.abs(dW - ref) / mag).max() < 4e-7
+        assert (np.abs(db - Z64.sum(0)) / np.abs(Z64).sum(0)).max() < 4e-7
