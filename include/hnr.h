@@ -437,7 +437,8 @@ int hnr_merge_bwd(const float *d_X6, int ld6, const float *d_Hm, int ldh, const 
 /* pixel gather (:1077-1089, :1193) + F.interpolate (:1064-1067) transposed: the rows' image-feature gradients (two sources
  * added: d_gFa from hnr_merge_bwd, optional d_gFb from the merge-weight MLP's first layer) are first added to their pixel
  * of d_g_featmap ([V,H,W,48], ZERO-INITIALISED; d_bbox int32[V,4] initialised to {W,H,-1,-1} receives the touched
- * rectangle; rows are summed per pixel by sort + segment sum, row strides lda/ldb >= 48), then gathered with the bilinear weights into the s1/s2/s3 slots of d_g_pyramid, a ZERO-INITIALISED buffer
+ * rectangle; rows are added to their pixel with float atomics, row strides lda/ldb >= 48; d_key_scratch: 3 * V * cap_samples int32,
+ * d_sort_scratch is no longer used), then gathered with the bilinear weights into the s1/s2/s3 slots of d_g_pyramid, a ZERO-INITIALISED buffer
  * laid out like the forward scratch of hnr_image_features. */
 int hnr_proj_rows_bwd(const float *d_sample_loc_w, const int32_t *d_vs_item, const int64_t *d_counts, const float *d_w2c,
                       const float *d_intrinsic, int V, int H, int W, int cap_samples, const float *d_gFa, int lda,
