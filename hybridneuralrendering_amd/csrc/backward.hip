@@ -572,69 +572,78 @@ __global__ void mark_points_kernel(const int32_t *__restrict__ row_pid, int64_t 
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (d_n && *d_n < M) M = *d_n;
-    if (t < M && (!d_n || row_pid[t] >= 0)) flags[row_pid[t]] = 1;           // (device-count form: rows of empty neighbour slots carry -1)
+    if (t < M && (!d_n || row_pid[t] >= 0)) atomicAdd(flags + row_pid[t], 1);          // the point's NUMBER of rows (device-count form: rows of empty neighbour slots carry -1)
 }
 
+// flags[i] = number of rows of point i (0: untouched).  Per 1024-point block: the touched points and the rows -- the two prefix sums of
+// flag_scan_kernel give a touched point its compact index AND the start of its rows in the point-major row list.
 __global__ __launch_bounds__(1024) void flag_block_sum_kernel(const int32_t *__restrict__ flags, int n, int32_t *__restrict__ block_sums)
 {
-    __shared__ int s_a[16];
+    __shared__ int s_a[16], s_b[16];
     const int i = blockIdx.x * 1024 + threadIdx.x;
-    int v = i < n ? flags[i] : 0;
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    if ((threadIdx.x & 63) == 0) s_a[threadIdx.x >> 6] = v;
+    int c = i < n ? flags[i] : 0, v = c > 0 ? 1 : 0;
+    for (int o = 32; o > 0; o >>= 1) { v += __shfl_xor(v, o); c += __shfl_xor(c, o); }
+    if ((threadIdx.x & 63) == 0) { s_a[threadIdx.x >> 6] = v; s_b[threadIdx.x >> 6] = c; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        int a = 0;
-        for (int k = 0; k < 16; ++k) a += s_a[k];
-        block_sums[blockIdx.x] = a;
+        int a = 0, b = 0;
+        for (int k = 0; k < 16; ++k) { a += s_a[k]; b += s_b[k]; }
+        block_sums[2 * blockIdx.x] = a; block_sums[2 * blockIdx.x + 1] = b;
     }
 }
 
-__global__ __launch_bounds__(1024) void flag_scan_kernel(int32_t *__restrict__ flags /* in: 0/1, out: compact index or -1 */, int n,
+__global__ __launch_bounds__(1024) void flag_scan_kernel(int32_t *__restrict__ flags /* in: rows per point, out: compact index or -1 */, int n,
                                                          const int32_t *__restrict__ block_sums, int32_t *__restrict__ ulist, int cap,
-                                                         int32_t *__restrict__ count)
+                                                         int32_t *__restrict__ count, int32_t *__restrict__ seg_start /* [cap + 1]: first row-list entry of compact point u */)
 {
-    __shared__ int s_a[16];
-    __shared__ int s_base;
+    __shared__ int s_a[16], s_b[16];
+    __shared__ int s_base, s_base_b;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int i = blockIdx.x * 1024 + threadIdx.x;
-    int pa = 0;
-    for (int k = threadIdx.x; k < (int)blockIdx.x; k += 1024) pa += block_sums[k];
-    for (int o = 32; o > 0; o >>= 1) pa += __shfl_xor(pa, o);
-    if (lane == 0) s_a[wid] = pa;
+    int pa = 0, pb = 0;
+    for (int k = threadIdx.x; k < (int)blockIdx.x; k += 1024) { pa += block_sums[2 * k]; pb += block_sums[2 * k + 1]; }
+    for (int o = 32; o > 0; o >>= 1) { pa += __shfl_xor(pa, o); pb += __shfl_xor(pb, o); }
+    if (lane == 0) { s_a[wid] = pa; s_b[wid] = pb; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        int a = 0;
-        for (int k = 0; k < 16; ++k) a += s_a[k];
-        s_base = a;
+        int a = 0, b = 0;
+        for (int k = 0; k < 16; ++k) { a += s_a[k]; b += s_b[k]; }
+        s_base = a; s_base_b = b;
     }
     __syncthreads();
-    const int v = i < n ? flags[i] : 0;
-    int ia = v;
+    const int c = i < n ? flags[i] : 0, v = c > 0 ? 1 : 0;
+    int ia = v, ib = c;
     for (int o = 1; o < 64; o <<= 1) {
-        const int ta = __shfl_up(ia, o);
-        if (lane >= o) ia += ta;
+        const int ta = __shfl_up(ia, o), tb = __shfl_up(ib, o);
+        if (lane >= o) { ia += ta; ib += tb; }
     }
     __syncthreads();
-    if (lane == 63) s_a[wid] = ia;
+    if (lane == 63) { s_a[wid] = ia; s_b[wid] = ib; }
     __syncthreads();
-    int oa = s_base + ia - v;
-    for (int k = 0; k < wid; ++k) oa += s_a[k];
+    int oa = s_base + ia - v, ob = s_base_b + ib - c;
+    for (int k = 0; k < wid; ++k) { oa += s_a[k]; ob += s_b[k]; }
     if (i < n) {
         flags[i] = v ? oa : -1;
-        if (v && oa < cap) ulist[oa] = i;
-        if (i == n - 1) *count = oa + v;
+        if (v && oa < cap) { ulist[oa] = i; if (seg_start) seg_start[oa] = ob; }
+        if (i == n - 1) { *count = oa + v; if (seg_start && oa + v <= cap) seg_start[oa + v] = ob + c; }
     }
 }
 
 __global__ void map_rows_kernel(const int32_t *__restrict__ row_pid, int64_t M, const int32_t *__restrict__ uidx, int32_t *__restrict__ row_u,
-                                const long long *__restrict__ d_n = nullptr, int skip_key = -1)
+                                const long long *__restrict__ d_n = nullptr, int skip_key = -1, const int32_t *__restrict__ seg_start = nullptr,
+                                int32_t *__restrict__ cursor = nullptr, int32_t *__restrict__ row_list = nullptr)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (!d_n) { if (t < M) row_u[t] = uidx[row_pid[t]]; return; }
     // device-count form: every row of the capacity gets a key; rows past *d_n and empty slots (-1) get the sentinel `skip_key` (> every compact
     // index: sorted last, outside every segment)
-    if (t < M) row_u[t] = (t < *d_n && row_pid[t] >= 0) ? uidx[row_pid[t]] : skip_key;
+    if (t < M) {
+        const int u = (t < *d_n && row_pid[t] >= 0) ? uidx[row_pid[t]] : skip_key;
+        row_u[t] = u;
+        // the point-major row list: entry order inside a point's segment is whatever the atomics give -- the consumers sort a segment's rows
+        // before they add them (segment_sum_rows_csr_kernel), so the sums stay bit-identical run to run
+        if (row_list && u != skip_key && u < skip_key) row_list[seg_start[u] + atomicAdd(cursor + u, 1)] = (int32_t)t;
+    }
 }
 
 }  // namespace hnr
@@ -844,14 +853,16 @@ extern "C" int hnr_gather_rows_bwd_rows(const int32_t *d_sample_pidx, const floa
 // step never learns a count on the host.
 namespace hnr {
 int unique_points_dc(const int32_t *d_row_pid, int64_t M_cap, const long long *d_m, int n_points, int32_t *d_uidx, int32_t *d_ulist, int cap,
-                     int32_t *d_row_u, int32_t *d_count, int32_t *d_scratch, hipStream_t st)
+                     int32_t *d_row_u, int32_t *d_count, int32_t *d_scratch /* 2 x ceil(n_points / 1024) */, int32_t *d_seg_start /* [cap + 1] */,
+                     int32_t *d_seg_count /* [cap] */, int32_t *d_row_list /* [M_cap] */, hipStream_t st)
 {
     HNR_HIP_CHECK(hipMemsetAsync(d_uidx, 0, (size_t)n_points * 4, st));
+    if (d_seg_count) HNR_HIP_CHECK(hipMemsetAsync(d_seg_count, 0, (size_t)cap * 4, st));
     if (M_cap > 0) mark_points_kernel<<<cdiv(M_cap, 256), 256, 0, st>>>(d_row_pid, M_cap, d_uidx, d_m);
     const int nb = cdiv(n_points, 1024);
     flag_block_sum_kernel<<<nb, 1024, 0, st>>>(d_uidx, n_points, d_scratch);
-    flag_scan_kernel<<<nb, 1024, 0, st>>>(d_uidx, n_points, d_scratch, d_ulist, cap, d_count);
-    if (M_cap > 0) map_rows_kernel<<<cdiv(M_cap, 256), 256, 0, st>>>(d_row_pid, M_cap, d_uidx, d_row_u, d_m, cap);
+    flag_scan_kernel<<<nb, 1024, 0, st>>>(d_uidx, n_points, d_scratch, d_ulist, cap, d_count, d_seg_start);
+    if (M_cap > 0) map_rows_kernel<<<cdiv(M_cap, 256), 256, 0, st>>>(d_row_pid, M_cap, d_uidx, d_row_u, d_m, cap, d_seg_start, d_seg_count, d_row_list);
     HNR_LAUNCH_CHECK();
     return HNR_OK;
 }

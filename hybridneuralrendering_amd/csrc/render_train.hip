@@ -56,9 +56,9 @@ struct Layout {
     // backward temporaries
     float *g_dec, *gY3, *gCF, *g_sigma, *dY2, *dY1, *gX7, *gF, *gZ3m, *dM2, *dM1, *gX6, *gpre, *tmpCF, *tmpWfd, *g_pyr, *g_fm, *dT2, *dT1, *gX5, *gZ4, *g_wagg,
           *dZ3, *gX3, *dZ1, *G8, *P8, *gTu, *gE;
-    int32_t *bbox, *key_scratch, *ks, *perm, *seg_start;
-    char *sort_scratch, *sort_scratch2, *wg_scratch;
-    size_t sort_bytes, sort_bytes2, wg_bytes;
+    int32_t *bbox, *key_scratch, *row_list, *seg_cnt, *seg_start;
+    char *sort_scratch, *wg_scratch;
+    size_t sort_bytes, wg_bytes;
     size_t rows_cap, ucap, VS, fm_elems, bytes;
 };
 
@@ -76,7 +76,7 @@ Layout carve(void *ws, size_t ws_bytes, const hnr_train_params *p, bool *ok)
     L.vs_item = c.take<int32_t>(cap + 1); L.vs_off = c.take<int32_t>(cap + 1); L.vs_cnt = c.take<int32_t>(cap + 1);
     L.scratch = c.take<int32_t>(3 * ((R * p->SR + 1023) / 1024) + 3);
     L.row_pid = c.take<int32_t>(rows); L.row_u = c.take<int32_t>(rows);
-    L.uidx = c.take<int32_t>(N); L.ulist = c.take<int32_t>(ucap + 1); L.ucount = c.take<int32_t>(4); L.uscratch = c.take<int32_t>((N + 1023) / 1024 + 1);
+    L.uidx = c.take<int32_t>(N); L.ulist = c.take<int32_t>(ucap + 1); L.ucount = c.take<int32_t>(4); L.uscratch = c.take<int32_t>(2 * ((N + 1023) / 1024) + 2);
     L.row_s = c.take<int32_t>(VS + 1);
     L.ray_drop = c.take<uint8_t>(R);
     L.tc = c.take<long long>(TC_N);
@@ -107,12 +107,11 @@ Layout carve(void *ws, size_t ws_bytes, const hnr_train_params *p, bool *ok)
     L.gpre = c.take<float>(cap * 64); L.tmpCF = c.take<float>(cap * 128); L.tmpWfd = c.take<float>(64 * 48);
     L.g_pyr = c.take<float>(L.fm_elems); L.g_fm = c.take<float>(V > 0 ? V * p->H * p->W * 48 : 4);
     L.bbox = c.take<int32_t>(V > 0 ? 4 * V : 4); L.key_scratch = c.take<int32_t>(3 * VS);
-    L.sort_bytes = (size_t)hnr_sort_rows_scratch_bytes((int64_t)VS); L.sort_scratch = c.take<char>(L.sort_bytes);
+    L.sort_bytes = 256; L.sort_scratch = c.take<char>(L.sort_bytes);                        // (hnr_proj_rows_bwd no longer sorts: a token buffer for its argument check)
     L.dT2 = c.take<float>(cap * 128); L.dT1 = c.take<float>(cap * 128); L.gX5 = c.take<float>(cap * 256);
     L.gZ4 = c.take<float>(rows * 256); L.g_wagg = c.take<float>(rows);
     L.dZ3 = c.take<float>(rows * 256); L.gX3 = c.take<float>(rows * 264); L.dZ1 = c.take<float>(rows * 256);
-    L.ks = c.take<int32_t>(rows); L.perm = c.take<int32_t>(rows); L.seg_start = c.take<int32_t>(ucap + 1);
-    L.sort_bytes2 = (size_t)hnr_sort_rows_scratch_bytes((int64_t)rows); L.sort_scratch2 = c.take<char>(L.sort_bytes2);
+    L.row_list = c.take<int32_t>(rows); L.seg_cnt = c.take<int32_t>(ucap + 1); L.seg_start = c.take<int32_t>(ucap + 1);
     L.G8 = c.take<float>(rows * 8); L.P8 = c.take<float>(ucap * 8); L.gTu = c.take<float>(ucap * 256); L.gE = c.take<float>(ucap * 224);
     L.wg_bytes = (size_t)hnr_h2wgrad_scratch_bytes(256, 280); L.wg_scratch = c.take<char>(L.wg_bytes);
     L.bytes = (c.off + 255) & ~(size_t)255;
@@ -466,7 +465,8 @@ extern "C" int hnr_render_train_forward(const hnr_grid *grid, const hnr_train_pa
     // ---- per-neighbour chain
     TR(chain_gather_train(cl->d_xyz, cl->d_conf, cl->d_dir, cl->d_color, o->d_sample_pidx, o->d_sample_loc_w, cam->d_raydir, cam->d_campos, cam->d_camrot, L.vs_item,
                           o->d_counts, SR, K, cap, L.chain_ws, L.X5, 280, o->d_weight, o->d_conf_coefficient, L.Xd, L.row_pid, stream));
-    TR(unique_points_dc(L.row_pid, (int64_t)L.rows_cap, L.tc + TC_M8, p->n_points, L.uidx, L.ulist, (int)L.ucap, L.row_u, L.ucount, L.uscratch, st));
+    TR(unique_points_dc(L.row_pid, (int64_t)L.rows_cap, L.tc + TC_M8, p->n_points, L.uidx, L.ulist, (int)L.ucap, L.row_u, L.ucount, L.uscratch, L.seg_start, L.seg_cnt,
+                        L.row_list, st));
     train_ucount_kernel<<<1, 1, 0, st>>>(L.ucount, (long long)L.ucap, L.tc);
     TR(point_rows_dc(cl->d_emb, L.ulist, (int)L.ucap, L.tc + TC_U, L.E, 224, st));
     TR(hnr_h2lin(L.E, 224, (int64_t)L.ucap, dU, 1, 0, L.img[IM_TAB], 256, 224, 0, 0, sl, nullptr, 0, L.Tu, 256, nullptr, stream));
@@ -664,23 +664,18 @@ extern "C" int hnr_render_train_backward(const hnr_train_params *p, const hnr_tr
         HNR_LAUNCH_CHECK();
     }
     TR(mark());
-    // ---- 10. rows -> touched point (sorted ONCE; both per-point reductions add a point's rows in that fixed order: deterministic)
-    {
-        int bits = 1;
-        while ((1ll << bits) <= (long long)ucap) ++bits;                 // keys 0 .. ucap (the sentinel of rows without a point)
-        TR(sort_rows_by_key_bits(L.row_u, rows, bits, L.ks, L.perm, L.sort_scratch2, (int64_t)L.sort_bytes2, st));
-    }
+    // ---- 10. rows -> touched point: the point-major row list was built in the forward pass (unique_points_dc); both per-point reductions add a
+    //          point's rows in ascending row order (deterministic)
     TR(hnr_gather_rows_bwd_rows(o->d_sample_pidx, cam->d_raydir, L.vs_item, L.vs_off, L.vs_cnt, o->d_counts, SR, K, cap, L.gX3, 264, L.g_wagg, o->d_weight, d_g_conf_coefficient,
                                 L.G8, stream));
-    TR(segment_starts(L.ks, rows, L.seg_start, st));
-    TR(segment_sum_rows_det_dc(L.G8, 8, L.ks, L.perm, rows, 8, (int)ucap, L.tc + TC_U, L.seg_start, L.P8, 8, st));
+    TR(segment_sum_rows_csr_dc(L.G8, 8, L.row_list, L.seg_start, L.seg_cnt, 8, (int)ucap, L.tc + TC_U, L.P8, 8, st));
     TR(point_small_grads_dc(L.P8, L.ulist, (int)ucap, L.tc + TC_U, gc->d_conf, gc->d_dir, gc->d_color, st));
     TR(mark());
     // ---- 11. block1 (first layer split: 60 distance columns per row + the per-point table)
     TR(wgrad(L.gX3, 264, L.H1, 256, rows, dM, 1, 0, 256, 256, AM_dZ2, AM_H1, g.block1_2_w, 256, g.block1_2_b));
     TR(dgrad(L.gX3, 264, rows, dM, 1, 0, IM_B12T, 256, 256, L.H1, 256, L.dZ1, 256, AM_dZ1));
     TR(wgrad(L.dZ1, 256, L.Xd, 64, rows, dM, 1, 0, 256, 60, AM_dZ1, AM_ONE, g.block1_0_w + 224, 284, g.block1_0_b));
-    TR(segment_sum_rows_det_dc(L.dZ1, 256, L.ks, L.perm, rows, 256, (int)ucap, L.tc + TC_U, L.seg_start, L.gTu, 256, st));
+    TR(segment_sum_rows_csr_dc(L.dZ1, 256, L.row_list, L.seg_start, L.seg_cnt, 256, (int)ucap, L.tc + TC_U, L.gTu, 256, st));
     TR(hnr_absmax(L.gTu, 256, ucap, dU, 1, 0, 256, am + AM_gTu, stream));
     TR(hnr_absmax(L.E, 224, ucap, dU, 1, 0, 224, am + AM_E, stream));
     TR(wgrad(L.gTu, 256, L.E, 224, ucap, dU, 1, 0, 256, 224, AM_gTu, AM_E, g.block1_0_w, 284, nullptr));

@@ -81,6 +81,50 @@ __global__ __launch_bounds__(256) void segment_sum_rows_det_kernel(const float *
     *d = acc;
 }
 
+// Point-major row list (csrc/backward.hip unique_points_dc: start / count per compact point, the rows of a segment in arbitrary order): one
+// wave per key sorts its segment's row indices (bitonic network over the lanes; segments of more than 64 rows -- a point that is a neighbour
+// of very many samples -- by repeated minimum search) and adds the rows in ascending row order: the order of a stable sort by key, without
+// the sort (21 launches of the library's merge sort per training step), bit-identical run to run.
+__global__ __launch_bounds__(256) void segment_sum_rows_csr_kernel(const float *__restrict__ A, int lda, const int32_t *__restrict__ row_list,
+                                                                   const int32_t *__restrict__ seg_start, const int32_t *__restrict__ seg_count, int n_cols,
+                                                                   int n_keys, const long long *__restrict__ d_nkeys, float *__restrict__ dst, int64_t dst_stride)
+{
+    const int lane = threadIdx.x & 63;
+    const int key = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (d_nkeys && *d_nkeys < n_keys) n_keys = (int)*d_nkeys;
+    if (key >= n_keys) return;
+    const int lo = seg_start[key], cnt = seg_count[key];
+    const bool col = 4 * lane < n_cols;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (cnt <= 64) {
+        int r = lane < cnt ? row_list[lo + lane] : 0x7fffffff;
+        // bitonic sort of 64 lanes, ascending
+#pragma unroll
+        for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                const int o = __shfl_xor(r, j);
+                const bool up = (lane & k) == 0, lower = (lane & j) == 0;
+                r = (lower == up) ? min(r, o) : max(r, o);
+            }
+        }
+        for (int e = 0; e < cnt; ++e) {
+            const int row = __shfl(r, e);
+            if (col) { const float4 v = reinterpret_cast<const float4 *>(A + (size_t)row * lda)[lane]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+        }
+    } else {
+        int last = -1;
+        for (int e = 0; e < cnt; ++e) {
+            int m = 0x7fffffff;
+            for (int i = lane; i < cnt; i += 64) { const int r = row_list[lo + i]; m = (r > last && r < m) ? r : m; }
+            for (int o = 32; o > 0; o >>= 1) m = min(m, __shfl_xor(m, o));
+            last = m;
+            if (col) { const float4 v = reinterpret_cast<const float4 *>(A + (size_t)m * lda)[lane]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+        }
+    }
+    if (col) reinterpret_cast<float4 *>(dst + (size_t)key * dst_stride)[lane] = acc;
+}
+
 }  // namespace hnr
 
 using namespace hnr;
@@ -172,6 +216,17 @@ int segment_sum_rows_det_dc(const float *d_A, int lda, const int32_t *d_keys_sor
     if (keys_cap <= 0) return HNR_OK;
     segment_sum_rows_det_kernel<<<cdiv((int64_t)keys_cap * 64, 256), 256, 0, st>>>(d_A, lda, d_keys_sorted, d_perm, M, n_cols, keys_cap, nullptr, d_dst, dst_stride, 0, d_nkeys,
                                                                                 d_start);
+    HNR_LAUNCH_CHECK();
+    return HNR_OK;
+}
+}  // namespace hnr
+
+namespace hnr {
+int segment_sum_rows_csr_dc(const float *d_A, int lda, const int32_t *d_row_list, const int32_t *d_seg_start, const int32_t *d_seg_count, int n_cols, int keys_cap,
+                            const long long *d_nkeys, float *d_dst, int64_t dst_stride, hipStream_t st)
+{
+    if (keys_cap <= 0) return HNR_OK;
+    segment_sum_rows_csr_kernel<<<cdiv((int64_t)keys_cap * 64, 256), 256, 0, st>>>(d_A, lda, d_row_list, d_seg_start, d_seg_count, n_cols, keys_cap, d_nkeys, d_dst, dst_stride);
     HNR_LAUNCH_CHECK();
     return HNR_OK;
 }

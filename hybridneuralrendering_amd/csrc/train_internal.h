@@ -21,7 +21,7 @@ int mlp3_forward_train(const float *d_A, int lda, int64_t M_cap, const int64_t *
 int point_rows_dc(const float *d_emb, const int32_t *d_ids, int n_cap, const long long *d_n, float *d_E, int lde, hipStream_t st);
 // csrc/backward.hip
 int unique_points_dc(const int32_t *d_row_pid, int64_t M_cap, const long long *d_m, int n_points, int32_t *d_uidx, int32_t *d_ulist, int cap,
-                     int32_t *d_row_u, int32_t *d_count, int32_t *d_scratch, hipStream_t st);
+                     int32_t *d_row_u, int32_t *d_count, int32_t *d_scratch, int32_t *d_seg_start, int32_t *d_seg_count, int32_t *d_row_list, hipStream_t st);
 int point_small_grads_dc(const float *d_P8, const int32_t *d_ulist, int U_cap, const long long *d_u, float *d_g_conf, float *d_g_dir, float *d_g_color, hipStream_t st);
 int point_rows_bwd_dc(const float *d_gE, int ldg, const float *d_E, int lde, const int32_t *d_ids, int n_cap, const long long *d_n, float *d_g_emb, hipStream_t st);
 int dleaky_dc(float *d_g, int ldg, const float *d_y, int ldy, int64_t M_cap, const long long *d_m, int N, float slope, hipStream_t st);
@@ -33,5 +33,7 @@ int sort_rows_by_key_bits(const int32_t *d_keys, int64_t M, int bits, int32_t *d
 int segment_starts(const int32_t *d_keys_sorted, int64_t M, int32_t *d_start, hipStream_t st);
 int segment_sum_rows_det_dc(const float *d_A, int lda, const int32_t *d_keys_sorted, const int32_t *d_perm, int64_t M, int n_cols, int keys_cap,
                             const long long *d_nkeys, const int32_t *d_start, float *d_dst, int64_t dst_stride, hipStream_t st);
+int segment_sum_rows_csr_dc(const float *d_A, int lda, const int32_t *d_row_list, const int32_t *d_seg_start, const int32_t *d_seg_count, int n_cols, int keys_cap,
+                            const long long *d_nkeys, float *d_dst, int64_t dst_stride, hipStream_t st);
 
 }  // namespace hnr
