@@ -531,16 +531,16 @@ __global__ __launch_bounds__(256) void h2wgrad_reduce_kernel(const float *__rest
     const bool isb = k == K;
     if (isb && !db) return;
     const float *p = partial + (size_t)n * LDP + k;                                 // (column K of the partials = the column sums of dZ)
-    // fixed order: eight interleaved running sums (their loads are independent: a single dependent chain of `used` loads is latency-bound), then a fixed tree
-    float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // fixed order: sixteen interleaved running sums (their loads are independent: a single dependent chain of `used` loads is latency-bound), then a fixed tree
+    float s8[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const size_t gs = (size_t)NP * LDP;
     int g = 0;
-    for (; g + 8 <= used; g += 8) {
+    for (; g + 16 <= used; g += 16) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) s8[i] += p[(size_t)(g + i) * gs];
+        for (int i = 0; i < 16; ++i) s8[i] += p[(size_t)(g + i) * gs];
     }
     for (int i = 0; g + i < used; ++i) s8[i] += p[(size_t)(g + i) * gs];
-    const float s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+    const float s = (((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]))) + (((s8[8] + s8[9]) + (s8[10] + s8[11])) + ((s8[12] + s8[13]) + (s8[14] + s8[15])));
     if (isb) db[n] = accumulate ? db[n] + s : s;
     else dW[(size_t)n * lddw + k] = accumulate ? dW[(size_t)n * lddw + k] + s : s;
 }

@@ -668,14 +668,13 @@ extern "C" int hnr_render_train_backward(const hnr_train_params *p, const hnr_tr
     //          point's rows in ascending row order (deterministic)
     TR(hnr_gather_rows_bwd_rows(o->d_sample_pidx, cam->d_raydir, L.vs_item, L.vs_off, L.vs_cnt, o->d_counts, SR, K, cap, L.gX3, 264, L.g_wagg, o->d_weight, d_g_conf_coefficient,
                                 L.G8, stream));
-    TR(segment_sum_rows_csr_dc(L.G8, 8, L.row_list, L.seg_start, L.seg_cnt, 8, (int)ucap, L.tc + TC_U, L.P8, 8, st));
-    TR(point_small_grads_dc(L.P8, L.ulist, (int)ucap, L.tc + TC_U, gc->d_conf, gc->d_dir, gc->d_color, st));
-    TR(mark());
+    TR(mark());                                                      // (the rows' small gradients G8 are summed per point together with block1's rows below)
     // ---- 11. block1 (first layer split: 60 distance columns per row + the per-point table)
     TR(wgrad(L.gX3, 264, L.H1, 256, rows, dM, 1, 0, 256, 256, AM_dZ2, AM_H1, g.block1_2_w, 256, g.block1_2_b));
     TR(dgrad(L.gX3, 264, rows, dM, 1, 0, IM_B12T, 256, 256, L.H1, 256, L.dZ1, 256, AM_dZ1));
     TR(wgrad(L.dZ1, 256, L.Xd, 64, rows, dM, 1, 0, 256, 60, AM_dZ1, AM_ONE, g.block1_0_w + 224, 284, g.block1_0_b));
-    TR(segment_sum_rows_csr_dc(L.dZ1, 256, L.row_list, L.seg_start, L.seg_cnt, 256, (int)ucap, L.tc + TC_U, L.gTu, 256, st));
+    TR(segment_sum_rows_csr_dc(L.dZ1, 256, L.row_list, L.seg_start, L.seg_cnt, 256, (int)ucap, L.tc + TC_U, L.gTu, 256, L.G8, 8, 8, L.P8, 8, st));
+    TR(point_small_grads_dc(L.P8, L.ulist, (int)ucap, L.tc + TC_U, gc->d_conf, gc->d_dir, gc->d_color, st));
     TR(hnr_absmax(L.gTu, 256, ucap, dU, 1, 0, 256, am + AM_gTu, stream));
     TR(hnr_absmax(L.E, 224, ucap, dU, 1, 0, 224, am + AM_E, stream));
     TR(wgrad(L.gTu, 256, L.E, 224, ucap, dU, 1, 0, 256, 224, AM_gTu, AM_E, g.block1_0_w, 284, nullptr));

@@ -87,15 +87,19 @@ __global__ __launch_bounds__(256) void segment_sum_rows_det_kernel(const float *
 // the sort (21 launches of the library's merge sort per training step), bit-identical run to run.
 __global__ __launch_bounds__(256) void segment_sum_rows_csr_kernel(const float *__restrict__ A, int lda, const int32_t *__restrict__ row_list,
                                                                    const int32_t *__restrict__ seg_start, const int32_t *__restrict__ seg_count, int n_cols,
-                                                                   int n_keys, const long long *__restrict__ d_nkeys, float *__restrict__ dst, int64_t dst_stride)
+                                                                   int n_keys, const long long *__restrict__ d_nkeys, float *__restrict__ dst, int64_t dst_stride,
+                                                                   const float *__restrict__ A2, int lda2, int n_cols2, float *__restrict__ dst2, int64_t dst_stride2)
 {
+    // (A2: an optional second, narrow matrix summed over the same segments in the same pass by the first n_cols2 / 4 lanes)
     const int lane = threadIdx.x & 63;
     const int key = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     if (d_nkeys && *d_nkeys < n_keys) n_keys = (int)*d_nkeys;
     if (key >= n_keys) return;
     const int lo = seg_start[key], cnt = seg_count[key];
-    const bool col = 4 * lane < n_cols;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool on = 4 * lane < n_cols, on2 = A2 && 4 * lane < n_cols2;
+    const float *base = A + 4 * lane, *base2 = A2 + 4 * lane;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), acc2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto add = [&](float4 &a, const float4 &v) { a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; };
     if (cnt <= 64) {
         int r = lane < cnt ? row_list[lo + lane] : 0x7fffffff;
         // bitonic sort of 64 lanes, ascending
@@ -108,9 +112,25 @@ __global__ __launch_bounds__(256) void segment_sum_rows_csr_kernel(const float *
                 r = (lower == up) ? min(r, o) : max(r, o);
             }
         }
-        for (int e = 0; e < cnt; ++e) {
+        // four rows' loads in flight, added in row order
+        int e = 0;
+        for (; e + 4 <= cnt; e += 4) {
+            const int r0 = __shfl(r, e), r1 = __shfl(r, e + 1), r2 = __shfl(r, e + 2), r3 = __shfl(r, e + 3);
+            if (on) {
+                const float4 v0 = *reinterpret_cast<const float4 *>(base + (size_t)r0 * lda), v1 = *reinterpret_cast<const float4 *>(base + (size_t)r1 * lda);
+                const float4 v2 = *reinterpret_cast<const float4 *>(base + (size_t)r2 * lda), v3 = *reinterpret_cast<const float4 *>(base + (size_t)r3 * lda);
+                add(acc, v0); add(acc, v1); add(acc, v2); add(acc, v3);
+            }
+            if (on2) {
+                const float4 v0 = *reinterpret_cast<const float4 *>(base2 + (size_t)r0 * lda2), v1 = *reinterpret_cast<const float4 *>(base2 + (size_t)r1 * lda2);
+                const float4 v2 = *reinterpret_cast<const float4 *>(base2 + (size_t)r2 * lda2), v3 = *reinterpret_cast<const float4 *>(base2 + (size_t)r3 * lda2);
+                add(acc2, v0); add(acc2, v1); add(acc2, v2); add(acc2, v3);
+            }
+        }
+        for (; e < cnt; ++e) {
             const int row = __shfl(r, e);
-            if (col) { const float4 v = reinterpret_cast<const float4 *>(A + (size_t)row * lda)[lane]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+            if (on) add(acc, *reinterpret_cast<const float4 *>(base + (size_t)row * lda));
+            if (on2) add(acc2, *reinterpret_cast<const float4 *>(base2 + (size_t)row * lda2));
         }
     } else {
         int last = -1;
@@ -119,10 +139,12 @@ __global__ __launch_bounds__(256) void segment_sum_rows_csr_kernel(const float *
             for (int i = lane; i < cnt; i += 64) { const int r = row_list[lo + i]; m = (r > last && r < m) ? r : m; }
             for (int o = 32; o > 0; o >>= 1) m = min(m, __shfl_xor(m, o));
             last = m;
-            if (col) { const float4 v = reinterpret_cast<const float4 *>(A + (size_t)m * lda)[lane]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+            if (on) add(acc, *reinterpret_cast<const float4 *>(base + (size_t)m * lda));
+            if (on2) add(acc2, *reinterpret_cast<const float4 *>(base2 + (size_t)m * lda2));
         }
     }
-    if (col) reinterpret_cast<float4 *>(dst + (size_t)key * dst_stride)[lane] = acc;
+    if (on) reinterpret_cast<float4 *>(dst + (size_t)key * dst_stride)[lane] = acc;
+    if (on2) reinterpret_cast<float4 *>(dst2 + (size_t)key * dst_stride2)[lane] = acc2;
 }
 
 }  // namespace hnr
@@ -223,10 +245,13 @@ int segment_sum_rows_det_dc(const float *d_A, int lda, const int32_t *d_keys_sor
 
 namespace hnr {
 int segment_sum_rows_csr_dc(const float *d_A, int lda, const int32_t *d_row_list, const int32_t *d_seg_start, const int32_t *d_seg_count, int n_cols, int keys_cap,
-                            const long long *d_nkeys, float *d_dst, int64_t dst_stride, hipStream_t st)
+                            const long long *d_nkeys, float *d_dst, int64_t dst_stride, const float *d_A2, int lda2, int n_cols2, float *d_dst2, int64_t dst_stride2,
+                            hipStream_t st)
 {
     if (keys_cap <= 0) return HNR_OK;
-    segment_sum_rows_csr_kernel<<<cdiv((int64_t)keys_cap * 64, 256), 256, 0, st>>>(d_A, lda, d_row_list, d_seg_start, d_seg_count, n_cols, keys_cap, d_nkeys, d_dst, dst_stride);
+    if (d_A2 && (n_cols2 <= 0 || n_cols2 > 256 || (n_cols2 & 3))) { set_error("segment_sum_rows_csr: bad second matrix"); return HNR_ERR_BADARG; }
+    segment_sum_rows_csr_kernel<<<cdiv((int64_t)keys_cap * 64, 256), 256, 0, st>>>(d_A, lda, d_row_list, d_seg_start, d_seg_count, n_cols, keys_cap, d_nkeys, d_dst, dst_stride,
+                                                                                   d_A2, lda2, d_A2 ? n_cols2 : 0, d_dst2, dst_stride2);
     HNR_LAUNCH_CHECK();
     return HNR_OK;
 }

@@ -34,6 +34,7 @@ int segment_starts(const int32_t *d_keys_sorted, int64_t M, int32_t *d_start, hi
 int segment_sum_rows_det_dc(const float *d_A, int lda, const int32_t *d_keys_sorted, const int32_t *d_perm, int64_t M, int n_cols, int keys_cap,
                             const long long *d_nkeys, const int32_t *d_start, float *d_dst, int64_t dst_stride, hipStream_t st);
 int segment_sum_rows_csr_dc(const float *d_A, int lda, const int32_t *d_row_list, const int32_t *d_seg_start, const int32_t *d_seg_count, int n_cols, int keys_cap,
-                            const long long *d_nkeys, float *d_dst, int64_t dst_stride, hipStream_t st);
+                            const long long *d_nkeys, float *d_dst, int64_t dst_stride, const float *d_A2, int lda2, int n_cols2, float *d_dst2, int64_t dst_stride2,
+                            hipStream_t st);
 
 }  // namespace hnr
