@@ -515,33 +515,39 @@ __global__ __launch_bounds__(512, 1) void h2wgrad_kernel(H2WgradArgs a)
     }
 }
 
-// dW[n, k] (+)= sum over the workgroups that had rows, in index order; db[n] likewise (column KP of the partials)
+// dW[n, k] (+)= sum over the workgroups that had rows, in a FIXED order; db[n] likewise (column KP of the partials).  64 outputs per block
+// (coalesced along k), the partials dealt to the block's four waves (wave w takes partials w, w + 4, ...: eight interleaved running sums each),
+// the four results added in wave order -- a single chain of `used` dependent loads per output was 13 us of latency per launch, fifteen times
+// per training step.
 __global__ __launch_bounds__(256) void h2wgrad_reduce_kernel(const float *__restrict__ partial, int n_wg, const long long *__restrict__ d_m, long long M_cap,
                                                              int NP, int LDP, int N, int K, float *__restrict__ dW, int lddw, float *__restrict__ db, int accumulate,
-                                                             int n_seg, long long seg_stride)
+                                                             int n_seg, long long seg_stride, int rows_per_block = 16)
 {
+    __shared__ float s_p[4][64];
     long long M = M_cap;
     if (d_m) { const long long c = *d_m; if (c < M) M = c; }
     if (n_seg > 1) M = (M < seg_stride ? M : seg_stride) * n_seg;
-    const long long n_blocks = (M + 15) / 16;
+    const long long n_blocks = (M + rows_per_block - 1) / rows_per_block;
     const int used = (int)(n_blocks < n_wg ? n_blocks : n_wg);
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lx = threadIdx.x & 63, wy = threadIdx.x >> 6;
+    const int t = blockIdx.x * 64 + lx;
     const int n = t / (K + 1), k = t - n * (K + 1);
-    if (n >= N) return;
-    const bool isb = k == K;
-    if (isb && !db) return;
-    const float *p = partial + (size_t)n * LDP + k;                                 // (column K of the partials = the column sums of dZ)
-    // fixed order: sixteen interleaved running sums (their loads are independent: a single dependent chain of `used` loads is latency-bound), then a fixed tree
-    float s8[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bool live = n < N;
+    const float *p = partial + (size_t)(live ? n : 0) * LDP + (live ? k : 0);      // (column K of the partials = the column sums of dZ)
+    float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const size_t gs = (size_t)NP * LDP;
-    int g = 0;
-    for (; g + 16 <= used; g += 16) {
+    int g = wy;
+    for (; g + 28 < used; g += 32) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) s8[i] += p[(size_t)(g + i) * gs];
+        for (int i = 0; i < 8; ++i) s8[i] += p[(size_t)(g + 4 * i) * gs];
     }
-    for (int i = 0; g + i < used; ++i) s8[i] += p[(size_t)(g + i) * gs];
-    const float s = (((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]))) + (((s8[8] + s8[9]) + (s8[10] + s8[11])) + ((s8[12] + s8[13]) + (s8[14] + s8[15])));
-    if (isb) db[n] = accumulate ? db[n] + s : s;
+    for (int i = 0; g + 4 * i < used; ++i) s8[i] += p[(size_t)(g + 4 * i) * gs];
+    s_p[wy][lx] = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+    __syncthreads();
+    if (wy != 0 || !live) return;
+    const float s = (s_p[0][lx] + s_p[1][lx]) + (s_p[2][lx] + s_p[3][lx]);
+    const bool isb = k == K;
+    if (isb) { if (db) db[n] = accumulate ? db[n] + s : s; }
     else dW[(size_t)n * lddw + k] = accumulate ? dW[(size_t)n * lddw + k] + s : s;
 }
 
@@ -690,7 +696,7 @@ extern "C" int hnr_h2wgrad(const float *d_dZ, int ldz, const float *d_X, int ldx
     HNR_LAUNCH_CHECK();
     const int NP = 32 * NT, LDP = 32 * KT + (biasv ? 32 : 0);
     const int total = N * (K + 1);
-    h2wgrad_reduce_kernel<<<(total + 255) / 256, 256, 0, st>>>((const float *)d_scratch, grid, reinterpret_cast<const long long *>(d_m), M_cap, NP, LDP, N, K,
+    h2wgrad_reduce_kernel<<<(total + 63) / 64, 256, 0, st>>>((const float *)d_scratch, grid, reinterpret_cast<const long long *>(d_m), M_cap, NP, LDP, N, K,
                                                               d_dW, lddw, d_db, accumulate, n_seg, seg_stride);
     HNR_LAUNCH_CHECK();
     return HNR_OK;
