@@ -381,11 +381,11 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float *__restri
 // ------------------------------------------------------------------------------------------------ 3x3 convolutions
 // g_out is the gradient w.r.t. the POST-activation output `out`; d pre-activation = g_out * (out > 0 ? 1 : slope).
 // data gradient: one lane per input element, gather form (no atomics), ACCUMULATES into g_in
-__global__ void conv3x3_bwd_data_kernel(const float *__restrict__ g_out, const float *__restrict__ out, const float *__restrict__ w,
-                                        int Cin, int Hin, int Win, int Cout, int stride, int Hout, int Wout, float slope,
-                                        float *__restrict__ g_in, int V, const int32_t *__restrict__ bbox = nullptr, int f = 1, int halo = 0)
+__device__ __forceinline__ void conv3x3_bwd_data_body(int64_t block, const float *__restrict__ g_out, const float *__restrict__ out, const float *__restrict__ w,
+                                                      int Cin, int Hin, int Win, int Cout, int stride, int Hout, int Wout, float slope,
+                                                      float *__restrict__ g_in, int V, const int32_t *__restrict__ bbox, int f, int halo)
 {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t idx = block * blockDim.x + threadIdx.x;
     const int64_t total = (int64_t)V * Cin * Hin * Win;
     if (idx >= total) return;
     const int ix = (int)(idx % Win), iy = (int)((idx / Win) % Hin), ci = (int)((idx / ((int64_t)Win * Hin)) % Cin),
@@ -415,21 +415,27 @@ __global__ void conv3x3_bwd_data_kernel(const float *__restrict__ g_out, const f
     }
     g_in[idx] += acc;
 }
+__global__ void conv3x3_bwd_data_kernel(const float *__restrict__ g_out, const float *__restrict__ out, const float *__restrict__ w,
+                                        int Cin, int Hin, int Win, int Cout, int stride, int Hout, int Wout, float slope,
+                                        float *__restrict__ g_in, int V, const int32_t *__restrict__ bbox = nullptr, int f = 1, int halo = 0)
+{
+    conv3x3_bwd_data_body(blockIdx.x, g_out, out, w, Cin, Hin, Win, Cout, stride, Hout, Wout, slope, g_in, V, bbox, f, halo);
+}
 
 // weight + bias gradient: blockIdx.x = co * Cin + ci, blockIdx.y = pixel chunk; block reduction, then 9 (+1) atomics
-__global__ __launch_bounds__(256) void conv3x3_bwd_weight_kernel(const float *__restrict__ g_out, const float *__restrict__ out,
-                                                                 const float *__restrict__ in, int in_cl, int in_cstride,
-                                                                 int Cin, int Hin, int Win, int Cout, int stride, int Hout, int Wout,
-                                                                 float slope, float *__restrict__ g_w, float *__restrict__ g_b, int V,
-                                                                 const int32_t *__restrict__ bbox = nullptr, int f = 1, int halo = 0)
+__device__ __forceinline__ void conv3x3_bwd_weight_body(int bx, int by, int ny, const float *__restrict__ g_out, const float *__restrict__ out,
+                                                        const float *__restrict__ in, int in_cl, int in_cstride,
+                                                        int Cin, int Hin, int Win, int Cout, int stride, int Hout, int Wout,
+                                                        float slope, float *__restrict__ g_w, float *__restrict__ g_b, int V,
+                                                        const int32_t *__restrict__ bbox, int f, int halo)
 {
     __shared__ float s_red[4][10];
-    const int co = blockIdx.x / Cin, ci = blockIdx.x % Cin;
+    const int co = bx / Cin, ci = bx % Cin;
     const int64_t npix = (int64_t)V * Hout * Wout;
     float acc[10];
 #pragma unroll
     for (int i = 0; i < 10; ++i) acc[i] = 0.f;
-    for (int64_t pix = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; pix < npix; pix += (int64_t)gridDim.y * blockDim.x) {
+    for (int64_t pix = (int64_t)by * blockDim.x + threadIdx.x; pix < npix; pix += (int64_t)ny * blockDim.x) {
         const int ox = (int)(pix % Wout), oy = (int)((pix / Wout) % Hout), v = (int)(pix / ((int64_t)Wout * Hout));
         if (bbox) {
             const int bx0 = bbox[4 * v], by0 = bbox[4 * v + 1], bx1 = bbox[4 * v + 2], by1 = bbox[4 * v + 3];
@@ -464,6 +470,31 @@ __global__ __launch_bounds__(256) void conv3x3_bwd_weight_kernel(const float *__
         const float t = s_red[0][threadIdx.x] + s_red[1][threadIdx.x] + s_red[2][threadIdx.x] + s_red[3][threadIdx.x];
         if (threadIdx.x < 9) atomicAdd(g_w + (size_t)(co * Cin + ci) * 9 + threadIdx.x, t);
         else if (ci == 0) atomicAdd(g_b + co, t);
+    }
+}
+__global__ __launch_bounds__(256) void conv3x3_bwd_weight_kernel(const float *__restrict__ g_out, const float *__restrict__ out,
+                                                                 const float *__restrict__ in, int in_cl, int in_cstride,
+                                                                 int Cin, int Hin, int Win, int Cout, int stride, int Hout, int Wout,
+                                                                 float slope, float *__restrict__ g_w, float *__restrict__ g_b, int V,
+                                                                 const int32_t *__restrict__ bbox = nullptr, int f = 1, int halo = 0)
+{
+    conv3x3_bwd_weight_body(blockIdx.x, blockIdx.y, gridDim.y, g_out, out, in, in_cl, in_cstride, Cin, Hin, Win, Cout, stride, Hout, Wout, slope, g_w, g_b, V, bbox, f, halo);
+}
+// One launch for a layer's two gradients (both read the same g_out / out and neither reads what the other writes): blocks [0, n_data) the data
+// gradient, the rest the weight gradient (bx = pair (co, ci), by = pixel chunk).  Two small latency-bound kernels back to back took the sum of
+// their times; side by side they take the longer one's.
+struct ConvBwdArgs {
+    const float *g_out, *out, *w, *in; int in_cl, in_cstride, Cin, Hin, Win, Cout, stride, Hout, Wout; float slope;
+    float *g_in, *g_w, *g_b; int V; const int32_t *bbox; int f_in, halo_in, f_out, halo_out; int n_data, ny;
+};
+__global__ __launch_bounds__(256) void conv3x3_bwd_both_kernel(ConvBwdArgs a)
+{
+    if ((int)blockIdx.x < a.n_data) {
+        conv3x3_bwd_data_body(blockIdx.x, a.g_out, a.out, a.w, a.Cin, a.Hin, a.Win, a.Cout, a.stride, a.Hout, a.Wout, a.slope, a.g_in, a.V, a.bbox, a.f_in, a.halo_in);
+    } else {
+        const int b = (int)blockIdx.x - a.n_data;
+        conv3x3_bwd_weight_body(b / a.ny, b % a.ny, a.ny, a.g_out, a.out, a.in, a.in_cl, a.in_cstride, a.Cin, a.Hin, a.Win, a.Cout, a.stride, a.Hout, a.Wout, a.slope, a.g_w,
+                                a.g_b, a.V, a.bbox, a.f_out, a.halo_out);
     }
 }
 
@@ -815,16 +846,23 @@ static int image_features_bwd_impl(const float *d_img, int V, int H, int W, cons
                                                                   d_bbox, lvl_f(Hin), lvl_halo(Hin));
     };
     // conv5: s3a -> s3 ; conv4: s2 -> s3a (stride 2) ; conv3: s2a -> s2 ; conv2: s1 -> s2a (stride 2) ; conv1: s1a -> s1 ; conv0: img -> s1a
-    wgrad(g3, s3, s3a, 0, 0, 24, H3, W3, 24, 1, H3, W3, 5);
-    dgrad(g3, s3, 5, 24, H3, W3, 24, 1, H3, W3, g3a);
-    wgrad(g3a, s3a, s2, 0, 0, 12, H2, W2, 24, 2, H3, W3, 4);
-    dgrad(g3a, s3a, 4, 12, H2, W2, 24, 2, H3, W3, g2);
-    wgrad(g2, s2, s2a, 0, 0, 12, H2, W2, 12, 1, H2, W2, 3);
-    dgrad(g2, s2, 3, 12, H2, W2, 12, 1, H2, W2, g2a);
-    wgrad(g2a, s2a, s1, 0, 0, 6, H1, W1, 12, 2, H2, W2, 2);
-    dgrad(g2a, s2a, 2, 6, H1, W1, 12, 2, H2, W2, g1);
-    wgrad(g1, s1, s1a, 0, 0, 6, H1, W1, 6, 1, H1, W1, 1);
-    dgrad(g1, s1, 1, 6, H1, W1, 6, 1, H1, W1, g1a);
+    auto both = [&](const float *g_out, const float *out, const float *in, int Cin, int Hin, int Win, int Cout, int stride, int Hout, int Wout, int li, float *g_in) {
+        ConvBwdArgs a;
+        a.g_out = g_out; a.out = out; a.w = conv_w[li]; a.in = in; a.in_cl = 0; a.in_cstride = 0; a.Cin = Cin; a.Hin = Hin; a.Win = Win; a.Cout = Cout; a.stride = stride;
+        a.Hout = Hout; a.Wout = Wout; a.slope = slope; a.g_in = g_in; a.g_w = g_conv_w[li]; a.g_b = g_conv_b[li]; a.V = V; a.bbox = d_bbox;
+        a.f_in = lvl_f(Hin); a.halo_in = lvl_halo(Hin); a.f_out = lvl_f(Hout); a.halo_out = lvl_halo(Hout);
+        a.n_data = cdiv((int64_t)V * Cin * Hin * Win, 256);
+        int chunks = cdiv((int64_t)V * Hout * Wout, 256 * 8);
+        if (chunks > 64) chunks = 64;
+        a.ny = chunks;
+        conv3x3_bwd_both_kernel<<<a.n_data + Cout * Cin * chunks, 256, 0, st>>>(a);
+    };
+    (void)dgrad;
+    both(g3, s3, s3a, 24, H3, W3, 24, 1, H3, W3, 5, g3a);
+    both(g3a, s3a, s2, 12, H2, W2, 24, 2, H3, W3, 4, g2);
+    both(g2, s2, s2a, 12, H2, W2, 12, 1, H2, W2, 3, g2a);
+    both(g2a, s2a, s1, 6, H1, W1, 12, 2, H2, W2, 2, g1);
+    both(g1, s1, s1a, 6, H1, W1, 6, 1, H1, W1, 1, g1a);
     wgrad(g1a, s1a, d_img, 1, 3, 3, H, W, 6, 2, H1, W1, 0);
     HNR_LAUNCH_CHECK();
     return HNR_OK;
