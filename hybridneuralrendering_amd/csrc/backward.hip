@@ -15,6 +15,8 @@
 //   point_rows_bwd     <- positional encoding of the embedding (:931-938)
 // Gradients flow to points_embeding / points_conf / points_dir / points_color and to every aggregator weight; positions
 // (xyz, sample locations, view directions) carry no gradient (xyz_grad = 0 in every shipped script).
+#include <utility>
+
 #include "hnr_common.h"
 
 namespace hnr {
@@ -341,10 +343,10 @@ __global__ __launch_bounds__(256) void pixel_scatter_add_kernel(const float *__r
 }
 
 // transpose of bilinear_at (aggregate.hip): one lane per (view, source cell, channel of the level), channel fastest
-__global__ __launch_bounds__(256) void upsample_bwd_kernel(const float *__restrict__ g_fm, const int32_t *__restrict__ bbox, int V, int H, int W,
-                                                           int Hs, int Ws, int C, int c0, float *__restrict__ g_level /*[V,C,Hs,Ws]*/)
+__device__ __forceinline__ void upsample_bwd_body(int64_t block, const float *__restrict__ g_fm, const int32_t *__restrict__ bbox, int V, int H, int W,
+                                                  int Hs, int Ws, int C, int c0, float *__restrict__ g_level /*[V,C,Hs,Ws]*/)
 {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t idx = block * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)V * Hs * Ws * C) return;
     const int cl = (int)(idx % C), xs = (int)((idx / C) % Ws), ys = (int)((idx / ((int64_t)C * Ws)) % Hs), v = (int)(idx / ((int64_t)C * Ws * Hs));
     const int bx0 = bbox[4 * v], by0 = bbox[4 * v + 1], bx1 = bbox[4 * v + 2], by1 = bbox[4 * v + 3];
@@ -376,6 +378,17 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float *__restri
         }
     }
     g_level[(((size_t)v * C + cl) * Hs + ys) * Ws + xs] = acc;
+}
+// the three pyramid levels in one launch (independent of one another): blocks [0, n1) level 1, [n1, n1 + n2) level 2, the rest level 3
+struct UpsampleBwdArgs { const float *g_fm; const int32_t *bbox; int V, H, W; int Hs[3], Ws[3], C[3], c0[3]; float *g[3]; int nb[3]; };
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(UpsampleBwdArgs a)
+{
+    int b = (int)blockIdx.x;
+    if (b < a.nb[0]) { upsample_bwd_body(b, a.g_fm, a.bbox, a.V, a.H, a.W, a.Hs[0], a.Ws[0], a.C[0], a.c0[0], a.g[0]); return; }
+    b -= a.nb[0];
+    if (b < a.nb[1]) { upsample_bwd_body(b, a.g_fm, a.bbox, a.V, a.H, a.W, a.Hs[1], a.Ws[1], a.C[1], a.c0[1], a.g[1]); return; }
+    b -= a.nb[1];
+    upsample_bwd_body(b, a.g_fm, a.bbox, a.V, a.H, a.W, a.Hs[2], a.Ws[2], a.C[2], a.c0[2], a.g[2]);
 }
 
 // ------------------------------------------------------------------------------------------------ 3x3 convolutions
@@ -788,9 +801,15 @@ extern "C" int hnr_proj_rows_bwd(const float *d_sample_loc_w, const int32_t *d_v
     // same layout as the forward scratch of hnr_image_features: s1a s1 s2a s2 s3a s3
     const size_t n1 = (size_t)V * 6 * H1 * W1, n2 = (size_t)V * 12 * H2 * W2, n3 = (size_t)V * 24 * H3 * W3;
     float *g1 = d_g_pyramid + n1, *g2 = d_g_pyramid + 2 * n1 + n2, *g3 = d_g_pyramid + 2 * n1 + 2 * n2 + n3;
-    upsample_bwd_kernel<<<cdiv((int64_t)n1, 256), 256, 0, st>>>(d_g_featmap, d_bbox, V, H, W, H1, W1, 6, 3, g1);
-    upsample_bwd_kernel<<<cdiv((int64_t)n2, 256), 256, 0, st>>>(d_g_featmap, d_bbox, V, H, W, H2, W2, 12, 9, g2);
-    upsample_bwd_kernel<<<cdiv((int64_t)n3, 256), 256, 0, st>>>(d_g_featmap, d_bbox, V, H, W, H3, W3, 24, 21, g3);
+    UpsampleBwdArgs ua;
+    ua.g_fm = d_g_featmap; ua.bbox = d_bbox; ua.V = V; ua.H = H; ua.W = W;
+    ua.Hs[0] = H1; ua.Ws[0] = W1; ua.C[0] = 6; ua.c0[0] = 3; ua.g[0] = g1; ua.nb[0] = cdiv((int64_t)n1, 256);
+    ua.Hs[1] = H2; ua.Ws[1] = W2; ua.C[1] = 12; ua.c0[1] = 9; ua.g[1] = g2; ua.nb[1] = cdiv((int64_t)n2, 256);
+    ua.Hs[2] = H3; ua.Ws[2] = W3; ua.C[2] = 24; ua.c0[2] = 21; ua.g[2] = g3; ua.nb[2] = cdiv((int64_t)n3, 256);
+    // level 3 first in block order? its cells loop over the most pixels: the slowest blocks should start first -- levels are dispatched 1, 2, 3 by
+    // block index, so level 3 is given the LOWEST indices by swapping the roles
+    { std::swap(ua.Hs[0], ua.Hs[2]); std::swap(ua.Ws[0], ua.Ws[2]); std::swap(ua.C[0], ua.C[2]); std::swap(ua.c0[0], ua.c0[2]); std::swap(ua.g[0], ua.g[2]); std::swap(ua.nb[0], ua.nb[2]); }
+    upsample_bwd_kernel<<<ua.nb[0] + ua.nb[1] + ua.nb[2], 256, 0, st>>>(ua);
     HNR_LAUNCH_CHECK();
     return HNR_OK;
 }
