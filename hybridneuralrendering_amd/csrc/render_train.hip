@@ -16,6 +16,8 @@
 #include <limits.h>
 
 #include "chain_defs.h"
+#include <stdlib.h>
+
 #include "train_internal.h"
 
 using namespace hnr;
@@ -532,6 +534,17 @@ extern "C" int hnr_render_train_backward(const hnr_train_params *p, const hnr_tr
         return HNR_OK;
     };
     TR(mark());
+    // side stream of the image-branch stage (one process per GPU: created once; see stage 6)
+    static hipStream_t side_stream = nullptr;
+    static hipEvent_t side_fork = nullptr, side_join = nullptr;
+    static int side_on = -1;
+    if (side_on < 0) {
+        const char *e = getenv("HNR_TRAIN_SIDE");
+        side_on = (e && atoi(e) == 0) ? 0 : 1;
+        if (side_on && (hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&side_fork, hipEventDisableTiming) != hipSuccess ||
+                        hipEventCreateWithFlags(&side_join, hipEventDisableTiming) != hipSuccess)) side_on = 0;
+    }
+    bool forked = false;
 
     // ---- zero what is accumulated into
     HNR_HIP_CHECK(hipMemsetAsync(gc->d_emb, 0, (size_t)N * 32 * 4, st));
@@ -619,13 +632,23 @@ extern "C" int hnr_render_train_backward(const hnr_train_params *p, const hnr_tr
         TR(dgrad(L.gpre, 64, cap, dS, 1, 0, IM_MW0CFT, 128, 64, nullptr, 0, L.tmpCF, 128, -1));
         train_add_cols_kernel<<<cdiv((int64_t)cap * 128, 256), 256, 0, st>>>(L.gCF, 128, L.tmpCF, 128, 128, L.tc + TC_S);
         TR(mark());
-        // ---- 6. pixel gather + upsample + conv pyramid
-        HNR_HIP_CHECK(hipMemsetAsync(L.g_pyr, 0, L.fm_elems * 4, st));
-        HNR_HIP_CHECK(hipMemsetAsync(L.g_fm, 0, (size_t)V * p->H * p->W * 48 * 4, st));
-        train_bbox_init_kernel<<<1, 64, 0, st>>>(L.bbox, V, p->H, p->W);
+        // ---- 6. pixel gather + upsample + conv pyramid.  Nothing downstream reads this stage's results (the reference-view CNN's weight gradients),
+        //      and it is 0.6 ms of small latency-bound kernels: it runs on a side stream of the library beside stages 7 - 11 (forked here, joined
+        //      before the call returns; HNR_TRAIN_SIDE=0: in line on the caller's stream)
+        hipStream_t s6 = st;
+        if (side_on) {
+            HNR_HIP_CHECK(hipEventRecord(side_fork, st));
+            HNR_HIP_CHECK(hipStreamWaitEvent(side_stream, side_fork, 0));
+            s6 = side_stream;
+            forked = true;
+        }
+        HNR_HIP_CHECK(hipMemsetAsync(L.g_pyr, 0, L.fm_elems * 4, s6));
+        HNR_HIP_CHECK(hipMemsetAsync(L.g_fm, 0, (size_t)V * p->H * p->W * 48 * 4, s6));
+        train_bbox_init_kernel<<<1, 64, 0, s6>>>(L.bbox, V, p->H, p->W);
         TR(hnr_proj_rows_bwd(o->d_sample_loc_w, L.vs_item, o->d_counts, vw->d_w2c, vw->d_intrinsic, V, p->H, p->W, cap, L.gF, 48, L.gX6, 48, L.g_fm, L.bbox, L.g_pyr, L.key_scratch,
-                             L.sort_scratch, (int64_t)L.sort_bytes, stream));
-        TR(image_features_bwd_bbox(vw->d_images, V, p->H, p->W, w->conv_w, sl, L.fm_scratch, L.g_pyr, g.conv_w, g.conv_b, L.bbox, stream));
+                             L.sort_scratch, (int64_t)L.sort_bytes, (void *)s6));
+        TR(image_features_bwd_bbox(vw->d_images, V, p->H, p->W, w->conv_w, sl, L.fm_scratch, L.g_pyr, g.conv_w, g.conv_b, L.bbox, (void *)s6));
+        if (forked) HNR_HIP_CHECK(hipEventRecord(side_join, side_stream));
     } else {
         train_add_cols_kernel<<<cdiv((int64_t)cap * 45, 256), 256, 0, st>>>(L.gCF, 128, L.gX7, 92, 45, L.tc + TC_S);       // X7 = [colfeat[:45] | 0]
         TR(mark());
@@ -680,6 +703,7 @@ extern "C" int hnr_render_train_backward(const hnr_train_params *p, const hnr_tr
     TR(wgrad(L.gTu, 256, L.E, 224, ucap, dU, 1, 0, 256, 224, AM_gTu, AM_E, g.block1_0_w, 284, nullptr));
     TR(dgrad(L.gTu, 256, ucap, dU, 1, 0, IM_TABT, 224, 256, nullptr, 0, L.gE, 224, -1));
     TR(point_rows_bwd_dc(L.gE, 224, L.E, 224, L.ulist, (int)ucap, L.tc + TC_U, gc->d_emb, st));
+    if (forked) HNR_HIP_CHECK(hipStreamWaitEvent(st, side_join, 0));      // the image-branch stage (side stream) is part of this call
     TR(mark());
     HNR_LAUNCH_CHECK();
     return HNR_OK;
