@@ -389,6 +389,24 @@ int check_params(const hnr_train_params *p, const char *who)
 
 #define TR(call) do { int rc_ = (call); if (rc_ != HNR_OK) return rc_; } while (0)
 
+// Side stream of the library (one process per GPU: created once): the reference-view CNN's forward runs on it beside the query and the
+// per-neighbour chain, its backward beside the backward stages 7 - 11 -- both are strings of small latency-bound kernels whose results are
+// needed late (forward) or not at all downstream (backward).  Forked from / joined to the caller's stream with events inside each call.
+// HNR_TRAIN_SIDE=0: everything in line on the caller's stream.
+struct TrainSide { hipStream_t stream = nullptr; hipEvent_t fork_f = nullptr, join_f = nullptr, fork_b = nullptr, join_b = nullptr; int on = -1; };
+TrainSide &train_side()
+{
+    static TrainSide t;
+    if (t.on < 0) {
+        const char *e = getenv("HNR_TRAIN_SIDE");
+        t.on = (e && atoi(e) == 0) ? 0 : 1;
+        if (t.on && (hipStreamCreateWithFlags(&t.stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&t.fork_f, hipEventDisableTiming) != hipSuccess ||
+                     hipEventCreateWithFlags(&t.join_f, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&t.fork_b, hipEventDisableTiming) != hipSuccess ||
+                     hipEventCreateWithFlags(&t.join_b, hipEventDisableTiming) != hipSuccess)) t.on = 0;
+    }
+    return t;
+}
+
 }  // namespace
 
 extern "C" int64_t hnr_render_train_workspace_bytes(const hnr_train_params *p)
@@ -421,6 +439,16 @@ extern "C" int hnr_render_train_forward(const hnr_grid *grid, const hnr_train_pa
         return HNR_OK;
     };
     TR(mark());
+    // the reference-view feature pyramid needs the images and the conv weights only and is first read by the merge stage: side stream, from here
+    TrainSide &side = train_side();
+    bool fwd_forked = false;
+    if (V > 0 && side.on) {
+        HNR_HIP_CHECK(hipEventRecord(side.fork_f, st));
+        HNR_HIP_CHECK(hipStreamWaitEvent(side.stream, side.fork_f, 0));
+        TR(hnr_image_features(vw->d_images, V, p->H, p->W, w->conv_w, w->conv_b, sl, L.fm_scratch, L.fm, (void *)side.stream));
+        HNR_HIP_CHECK(hipEventRecord(side.join_f, side.stream));
+        fwd_forked = true;
+    }
 
     // ---- kernel images of this step's weights
     TR(hnr_chain_pack(w->block1_0_w + 224, 284, w->block1_0_b, w->block1_2_w, w->block1_2_b, w->block3_0_w, w->block3_0_b, w->block3_2_w, w->block3_2_b,
@@ -461,8 +489,8 @@ extern "C" int hnr_render_train_forward(const hnr_grid *grid, const hnr_train_pa
     HNR_HIP_CHECK(hipMemsetAsync(o->d_weight, 0, (size_t)R * SR * K * sizeof(float), st));
     train_conf_fill_kernel<<<256, 256, 0, st>>>(cl->d_conf, o->d_conf_coefficient, (long long)R * SR * K);
     TR(mark());
-    // ---- reference-view feature pyramid (activations kept for the conv backward)
-    if (V > 0) TR(hnr_image_features(vw->d_images, V, p->H, p->W, w->conv_w, w->conv_b, sl, L.fm_scratch, L.fm, stream));
+    // ---- reference-view feature pyramid (activations kept for the conv backward): on the side stream, forked at the start of the call
+    if (V > 0 && !fwd_forked) TR(hnr_image_features(vw->d_images, V, p->H, p->W, w->conv_w, w->conv_b, sl, L.fm_scratch, L.fm, stream));
     TR(mark());
     // ---- per-neighbour chain
     TR(chain_gather_train(cl->d_xyz, cl->d_conf, cl->d_dir, cl->d_color, o->d_sample_pidx, o->d_sample_loc_w, cam->d_raydir, cam->d_campos, cam->d_camrot, L.vs_item,
@@ -484,6 +512,7 @@ extern "C" int hnr_render_train_forward(const hnr_grid *grid, const hnr_train_pa
     TR(mlp3_forward_train(L.X5, 280, cap, o->d_counts, HNR_CNT_SAMPLES_VALID, 1, 0, L.img_cf, V > 0 ? 4 : 3, cfN, cfK, act1110, sl, nullptr, nullptr, 0, L.CF, 128,
                           V > 0 ? L.pre : nullptr, 64, L.T1, 128, L.T2, 128, L.amax + AM_T1, stream));
     if (V > 0) {
+        if (fwd_forked) HNR_HIP_CHECK(hipStreamWaitEvent(st, side.join_f, 0));      // the feature map is ready
         TR(hnr_proj_rows(o->d_sample_loc_w, L.vs_item, o->d_counts, vw->d_w2c, vw->d_intrinsic, cam->d_campos, vw->d_campos_nearest, L.fm, V, p->H, p->W, L.CF, 128, cap,
                          L.X6, 48, L.vmask, L.row_s, stream));
         TR(hnr_absmax(L.X6, 48, cap, dS, V, cap, 48, L.amax + AM_X6, stream));
@@ -534,16 +563,10 @@ extern "C" int hnr_render_train_backward(const hnr_train_params *p, const hnr_tr
         return HNR_OK;
     };
     TR(mark());
-    // side stream of the image-branch stage (one process per GPU: created once; see stage 6)
-    static hipStream_t side_stream = nullptr;
-    static hipEvent_t side_fork = nullptr, side_join = nullptr;
-    static int side_on = -1;
-    if (side_on < 0) {
-        const char *e = getenv("HNR_TRAIN_SIDE");
-        side_on = (e && atoi(e) == 0) ? 0 : 1;
-        if (side_on && (hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&side_fork, hipEventDisableTiming) != hipSuccess ||
-                        hipEventCreateWithFlags(&side_join, hipEventDisableTiming) != hipSuccess)) side_on = 0;
-    }
+    TrainSide &side = train_side();
+    const int side_on = side.on;
+    hipStream_t side_stream = side.stream;
+    hipEvent_t side_fork = side.fork_b, side_join = side.join_b;
     bool forked = false;
 
     // ---- zero what is accumulated into
