@@ -393,7 +393,7 @@ int check_params(const hnr_train_params *p, const char *who)
 // per-neighbour chain, its backward beside the backward stages 7 - 11 -- both are strings of small latency-bound kernels whose results are
 // needed late (forward) or not at all downstream (backward).  Forked from / joined to the caller's stream with events inside each call.
 // HNR_TRAIN_SIDE=0: everything in line on the caller's stream.
-struct TrainSide { hipStream_t stream = nullptr; hipEvent_t fork_f = nullptr, join_f = nullptr, fork_b = nullptr, join_b = nullptr; int on = -1; };
+struct TrainSide { hipStream_t stream = nullptr; hipEvent_t fork_f = nullptr, join_f = nullptr, fork_b = nullptr, join_b = nullptr, fork_z = nullptr, join_z = nullptr; int on = -1; };
 TrainSide &train_side()
 {
     static TrainSide t;
@@ -402,7 +402,8 @@ TrainSide &train_side()
         t.on = (e && atoi(e) == 0) ? 0 : 1;
         if (t.on && (hipStreamCreateWithFlags(&t.stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&t.fork_f, hipEventDisableTiming) != hipSuccess ||
                      hipEventCreateWithFlags(&t.join_f, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&t.fork_b, hipEventDisableTiming) != hipSuccess ||
-                     hipEventCreateWithFlags(&t.join_b, hipEventDisableTiming) != hipSuccess)) t.on = 0;
+                     hipEventCreateWithFlags(&t.join_b, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&t.fork_z, hipEventDisableTiming) != hipSuccess ||
+                     hipEventCreateWithFlags(&t.join_z, hipEventDisableTiming) != hipSuccess)) t.on = 0;
     }
     return t;
 }
@@ -569,11 +570,17 @@ extern "C" int hnr_render_train_backward(const hnr_train_params *p, const hnr_tr
     hipEvent_t side_fork = side.fork_b, side_join = side.join_b;
     bool forked = false;
 
-    // ---- zero what is accumulated into
-    HNR_HIP_CHECK(hipMemsetAsync(gc->d_emb, 0, (size_t)N * 32 * 4, st));
-    HNR_HIP_CHECK(hipMemsetAsync(gc->d_conf, 0, (size_t)N * 4, st));
-    HNR_HIP_CHECK(hipMemsetAsync(gc->d_dir, 0, (size_t)N * 12, st));
-    HNR_HIP_CHECK(hipMemsetAsync(gc->d_color, 0, (size_t)N * 12, st));
+    // ---- zero what is accumulated into.  The dense point-gradient buffers (312 MB at 2 M points) are first written by the call's last kernels:
+    //      cleared on the side stream, waited for before stage 10
+    {
+        hipStream_t sz = st;
+        if (side_on) { HNR_HIP_CHECK(hipEventRecord(side.fork_z, st)); HNR_HIP_CHECK(hipStreamWaitEvent(side_stream, side.fork_z, 0)); sz = side_stream; }
+        HNR_HIP_CHECK(hipMemsetAsync(gc->d_emb, 0, (size_t)N * 32 * 4, sz));
+        HNR_HIP_CHECK(hipMemsetAsync(gc->d_conf, 0, (size_t)N * 4, sz));
+        HNR_HIP_CHECK(hipMemsetAsync(gc->d_dir, 0, (size_t)N * 12, sz));
+        HNR_HIP_CHECK(hipMemsetAsync(gc->d_color, 0, (size_t)N * 12, sz));
+        if (side_on) HNR_HIP_CHECK(hipEventRecord(side.join_z, side_stream));
+    }
     {
         ZeroJobs z;
         int nz = 0;
@@ -607,11 +614,6 @@ extern "C" int hnr_render_train_backward(const hnr_train_params *p, const hnr_tr
             void *out2[10] = {out[0], out[1], out[2], out[3], out[4], out[5], out[6], out[11], out[12], out[13]};
             TR(hnr_h2lin_pack(10, W2, rs2, cs2, N2, K2, nullptr, out2, stream));
         }
-    }
-    if (d_g_conf_coefficient) {
-        // (the partials live in the first words of the weight-gradient scratch: it is not in use yet)
-        train_conf0_partial_kernel<<<512, 256, 0, st>>>(d_g_conf_coefficient, o->d_sample_pidx, (long long)R * SR * K, reinterpret_cast<float *>(L.wg_scratch));
-        train_conf0_final_kernel<<<1, 256, 0, st>>>(reinterpret_cast<const float *>(L.wg_scratch), 512, gc->d_conf);
     }
     // weight gradient of one layer: dW = dZ^T X, db = column sums of dZ
     auto wgrad = [&](const float *dZ, int ldz, const float *X, int ldx, int64_t Mcap, const int64_t *dm, int nseg, int64_t segs, int Nn, int Kk, int amz, int amx,
@@ -710,6 +712,13 @@ extern "C" int hnr_render_train_backward(const hnr_train_params *p, const hnr_tr
         HNR_LAUNCH_CHECK();
     }
     TR(mark());
+    if (side_on) HNR_HIP_CHECK(hipStreamWaitEvent(st, side.join_z, 0));       // the point-gradient buffers are clear
+    if (d_g_conf_coefficient) {
+        // the empty slots' share of d conf_coefficient lands on point 0 (the reference's index clamp); the partials live in the first words of the
+        // weight-gradient scratch (free between two weight-gradient launches of this stream)
+        train_conf0_partial_kernel<<<512, 256, 0, st>>>(d_g_conf_coefficient, o->d_sample_pidx, (long long)R * SR * K, reinterpret_cast<float *>(L.wg_scratch));
+        train_conf0_final_kernel<<<1, 256, 0, st>>>(reinterpret_cast<const float *>(L.wg_scratch), 512, gc->d_conf);
+    }
     // ---- 10. rows -> touched point: the point-major row list was built in the forward pass (unique_points_dc); both per-point reductions add a
     //          point's rows in ascending row order (deterministic)
     TR(hnr_gather_rows_bwd_rows(o->d_sample_pidx, cam->d_raydir, L.vs_item, L.vs_off, L.vs_cnt, o->d_counts, SR, K, cap, L.gX3, 264, L.g_wagg, o->d_weight, d_g_conf_coefficient,
