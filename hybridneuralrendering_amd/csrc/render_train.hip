@@ -60,6 +60,7 @@ struct Layout {
           *dZ3, *gX3, *dZ1, *G8, *P8, *gTu, *gE;
     int32_t *bbox, *key_scratch, *row_list, *seg_cnt, *seg_start;
     char *sort_scratch, *wg_scratch;
+    float *conf0;
     size_t sort_bytes, wg_bytes;
     size_t rows_cap, ucap, VS, fm_elems, bytes;
 };
@@ -116,6 +117,7 @@ Layout carve(void *ws, size_t ws_bytes, const hnr_train_params *p, bool *ok)
     L.row_list = c.take<int32_t>(rows); L.seg_cnt = c.take<int32_t>(ucap + 1); L.seg_start = c.take<int32_t>(ucap + 1);
     L.G8 = c.take<float>(rows * 8); L.P8 = c.take<float>(ucap * 8); L.gTu = c.take<float>(ucap * 256); L.gE = c.take<float>(ucap * 224);
     L.wg_bytes = (size_t)hnr_h2wgrad_scratch_bytes(256, 280); L.wg_scratch = c.take<char>(L.wg_bytes);
+    L.conf0 = c.take<float>(512);
     L.bytes = (c.off + 255) & ~(size_t)255;
     if (ok) *ok = c.ok;
     return L;
@@ -391,9 +393,14 @@ int check_params(const hnr_train_params *p, const char *who)
 
 // Side stream of the library (one process per GPU: created once): the reference-view CNN's forward runs on it beside the query and the
 // per-neighbour chain, its backward beside the backward stages 7 - 11 -- both are strings of small latency-bound kernels whose results are
-// needed late (forward) or not at all downstream (backward).  Forked from / joined to the caller's stream with events inside each call.
+// needed late (forward) or not at all downstream (backward); a second one takes the backward's weight-gradient GEMMs (dW = dZ^T X: final outputs,
+// each needs only the dZ the input-gradient chain has just produced).  Forked from / joined to the caller's stream with events inside each call.
 // HNR_TRAIN_SIDE=0: everything in line on the caller's stream.
-struct TrainSide { hipStream_t stream = nullptr; hipEvent_t fork_f = nullptr, join_f = nullptr, fork_b = nullptr, join_b = nullptr, fork_z = nullptr, join_z = nullptr; int on = -1; };
+struct TrainSide {
+    hipStream_t stream = nullptr, stream_w = nullptr;                     // image branch / clears; weight gradients
+    hipEvent_t fork_f = nullptr, join_f = nullptr, fork_b = nullptr, join_b = nullptr, fork_z = nullptr, join_z = nullptr, join_w = nullptr, ev_w[16] = {};
+    int on = -1;
+};
 TrainSide &train_side()
 {
     static TrainSide t;
@@ -403,7 +410,9 @@ TrainSide &train_side()
         if (t.on && (hipStreamCreateWithFlags(&t.stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&t.fork_f, hipEventDisableTiming) != hipSuccess ||
                      hipEventCreateWithFlags(&t.join_f, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&t.fork_b, hipEventDisableTiming) != hipSuccess ||
                      hipEventCreateWithFlags(&t.join_b, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&t.fork_z, hipEventDisableTiming) != hipSuccess ||
-                     hipEventCreateWithFlags(&t.join_z, hipEventDisableTiming) != hipSuccess)) t.on = 0;
+                     hipEventCreateWithFlags(&t.join_z, hipEventDisableTiming) != hipSuccess || hipStreamCreateWithFlags(&t.stream_w, hipStreamNonBlocking) != hipSuccess ||
+                     hipEventCreateWithFlags(&t.join_w, hipEventDisableTiming) != hipSuccess)) t.on = 0;
+        for (int i = 0; i < 16 && t.on; ++i) if (hipEventCreateWithFlags(&t.ev_w[i], hipEventDisableTiming) != hipSuccess) t.on = 0;
     }
     return t;
 }
@@ -569,6 +578,7 @@ extern "C" int hnr_render_train_backward(const hnr_train_params *p, const hnr_tr
     hipStream_t side_stream = side.stream;
     hipEvent_t side_fork = side.fork_b, side_join = side.join_b;
     bool forked = false;
+    int n_wg_forks = 0;
 
     // ---- zero what is accumulated into.  The dense point-gradient buffers (312 MB at 2 M points) are first written by the call's last kernels:
     //      cleared on the side stream, waited for before stage 10
@@ -618,7 +628,15 @@ extern "C" int hnr_render_train_backward(const hnr_train_params *p, const hnr_tr
     // weight gradient of one layer: dW = dZ^T X, db = column sums of dZ
     auto wgrad = [&](const float *dZ, int ldz, const float *X, int ldx, int64_t Mcap, const int64_t *dm, int nseg, int64_t segs, int Nn, int Kk, int amz, int amx,
                      float *dW, int lddw, float *db) -> int {
-        return hnr_h2wgrad(dZ, ldz, X, ldx, Mcap, dm, nseg, segs, Nn, Kk, am + amz, am + amx, dW, lddw, db, 0, L.wg_scratch, stream);
+        void *sw = stream;
+        if (side_on) {
+            // dZ (and its maximum) is complete on the caller's stream here: the GEMM goes to the weight-gradient stream behind an event
+            hipEvent_t ev = side.ev_w[n_wg_forks++ & 15];
+            HNR_HIP_CHECK(hipEventRecord(ev, st));
+            HNR_HIP_CHECK(hipStreamWaitEvent(side.stream_w, ev, 0));
+            sw = (void *)side.stream_w;
+        }
+        return hnr_h2wgrad(dZ, ldz, X, ldx, Mcap, dm, nseg, segs, Nn, Kk, am + amz, am + amx, dW, lddw, db, 0, L.wg_scratch, sw);
     };
     // input gradient through a LeakyReLU: out = (dZ W) * LeakyReLU'(side); side == NULL: out = dZ W
     auto dgrad = [&](const float *dZ, int ldz, int64_t Mcap, const int64_t *dm, int nseg, int64_t segs, int im, int Nn, int Kk, const float *side, int lds_, float *out, int ldo,
@@ -649,7 +667,7 @@ extern "C" int hnr_render_train_backward(const hnr_train_params *p, const hnr_tr
         TR(wgrad(L.dM2, 64, L.M1, 64, cap, dS, V, cap, 64, 64, AM_dM2, AM_M1, g.mw_w[1], 64, g.mw_b[1]));
         TR(dgrad(L.dM2, 64, cap, dS, V, cap, IM_MW1T, 64, 64, L.M1, 64, L.dM1, 64, AM_dM1));
         TR(wgrad(L.dM1, 64, L.X6, 48, cap, dS, V, cap, 64, 48, AM_dM1, AM_X6, L.tmpWfd, 48, nullptr));
-        train_w0fd_grad_kernel<<<(64 * 48 + 255) / 256, 256, 0, st>>>(L.tmpWfd, g.mw_w[0]);
+        train_w0fd_grad_kernel<<<(64 * 48 + 255) / 256, 256, 0, side_on ? side.stream_w : st>>>(L.tmpWfd, g.mw_w[0]);      // (behind the weight gradient that wrote tmpWfd)
         TR(sum_views_dc(L.dM1, 64, V, cap, L.tc + TC_S, 64, L.gpre, 64, st));
         TR(hnr_absmax(L.gpre, 64, cap, dS, 1, 0, 64, am + AM_gpre, stream));
         TR(wgrad(L.gpre, 64, L.CF, 128, cap, dS, 1, 0, 64, 128, AM_gpre, AM_CF, g.mw_w[0] + 45, 176, g.mw_b[0]));
@@ -714,10 +732,9 @@ extern "C" int hnr_render_train_backward(const hnr_train_params *p, const hnr_tr
     TR(mark());
     if (side_on) HNR_HIP_CHECK(hipStreamWaitEvent(st, side.join_z, 0));       // the point-gradient buffers are clear
     if (d_g_conf_coefficient) {
-        // the empty slots' share of d conf_coefficient lands on point 0 (the reference's index clamp); the partials live in the first words of the
-        // weight-gradient scratch (free between two weight-gradient launches of this stream)
-        train_conf0_partial_kernel<<<512, 256, 0, st>>>(d_g_conf_coefficient, o->d_sample_pidx, (long long)R * SR * K, reinterpret_cast<float *>(L.wg_scratch));
-        train_conf0_final_kernel<<<1, 256, 0, st>>>(reinterpret_cast<const float *>(L.wg_scratch), 512, gc->d_conf);
+        // the empty slots' share of d conf_coefficient lands on point 0 (the reference's index clamp)
+        train_conf0_partial_kernel<<<512, 256, 0, st>>>(d_g_conf_coefficient, o->d_sample_pidx, (long long)R * SR * K, L.conf0);
+        train_conf0_final_kernel<<<1, 256, 0, st>>>(L.conf0, 512, gc->d_conf);
     }
     // ---- 10. rows -> touched point: the point-major row list was built in the forward pass (unique_points_dc); both per-point reductions add a
     //          point's rows in ascending row order (deterministic)
@@ -736,6 +753,7 @@ extern "C" int hnr_render_train_backward(const hnr_train_params *p, const hnr_tr
     TR(dgrad(L.gTu, 256, ucap, dU, 1, 0, IM_TABT, 224, 256, nullptr, 0, L.gE, 224, -1));
     TR(point_rows_bwd_dc(L.gE, 224, L.E, 224, L.ulist, (int)ucap, L.tc + TC_U, gc->d_emb, st));
     if (forked) HNR_HIP_CHECK(hipStreamWaitEvent(st, side_join, 0));      // the image-branch stage (side stream) is part of this call
+    if (side_on && n_wg_forks > 0) { HNR_HIP_CHECK(hipEventRecord(side.join_w, side.stream_w)); HNR_HIP_CHECK(hipStreamWaitEvent(st, side.join_w, 0)); }      // ... and so are the weight gradients
     TR(mark());
     HNR_LAUNCH_CHECK();
     return HNR_OK;
