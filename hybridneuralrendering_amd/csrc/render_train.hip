@@ -393,12 +393,14 @@ int check_params(const hnr_train_params *p, const char *who)
 
 // Side stream of the library (one process per GPU: created once): the reference-view CNN's forward runs on it beside the query and the
 // per-neighbour chain, its backward beside the backward stages 7 - 11 -- both are strings of small latency-bound kernels whose results are
-// needed late (forward) or not at all downstream (backward); a second one takes the backward's weight-gradient GEMMs (dW = dZ^T X: final outputs,
-// each needs only the dZ the input-gradient chain has just produced).  Forked from / joined to the caller's stream with events inside each call.
+// needed late (forward) or not at all downstream (backward); a second one packs the step's weight images while the query runs.  Forked from /
+// joined to the caller's stream with events inside each call.  (Not on a side stream: the weight-gradient GEMMs.  Forked behind per-layer events they
+// bought 0.12 ms, but 1 step in 10 then showed gradients that differed in the last bits of a few rows -- each of them alone beside the chain was
+// clean, standalone pairs of the kernels were clean (tools/race_pair.py); not understood, so not shipped.)
 // HNR_TRAIN_SIDE=0: everything in line on the caller's stream.
 struct TrainSide {
-    hipStream_t stream = nullptr, stream_w = nullptr;                     // image branch / clears; weight gradients
-    hipEvent_t fork_f = nullptr, join_f = nullptr, fork_b = nullptr, join_b = nullptr, fork_z = nullptr, join_z = nullptr, join_w = nullptr, ev_w[16] = {};
+    hipStream_t stream = nullptr, stream_w = nullptr;                     // image branch / clears; weight packs
+    hipEvent_t fork_f = nullptr, join_f = nullptr, fork_b = nullptr, join_b = nullptr, fork_z = nullptr, join_z = nullptr, ev_w[2] = {};
     int on = -1;
 };
 TrainSide &train_side()
@@ -406,13 +408,12 @@ TrainSide &train_side()
     static TrainSide t;
     if (t.on < 0) {
         const char *e = getenv("HNR_TRAIN_SIDE");
-        t.on = (e && atoi(e) == 0) ? 0 : 1;
+        t.on = e ? atoi(e) : 11;                                         // bit 0: image branch (forward + backward), 1: clears, 3: weight packs
         if (t.on && (hipStreamCreateWithFlags(&t.stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&t.fork_f, hipEventDisableTiming) != hipSuccess ||
                      hipEventCreateWithFlags(&t.join_f, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&t.fork_b, hipEventDisableTiming) != hipSuccess ||
                      hipEventCreateWithFlags(&t.join_b, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&t.fork_z, hipEventDisableTiming) != hipSuccess ||
-                     hipEventCreateWithFlags(&t.join_z, hipEventDisableTiming) != hipSuccess || hipStreamCreateWithFlags(&t.stream_w, hipStreamNonBlocking) != hipSuccess ||
-                     hipEventCreateWithFlags(&t.join_w, hipEventDisableTiming) != hipSuccess)) t.on = 0;
-        for (int i = 0; i < 16 && t.on; ++i) if (hipEventCreateWithFlags(&t.ev_w[i], hipEventDisableTiming) != hipSuccess) t.on = 0;
+                     hipEventCreateWithFlags(&t.join_z, hipEventDisableTiming) != hipSuccess || hipStreamCreateWithFlags(&t.stream_w, hipStreamNonBlocking) != hipSuccess)) t.on = 0;
+        for (int i = 0; i < 2 && t.on; ++i) if (hipEventCreateWithFlags(&t.ev_w[i], hipEventDisableTiming) != hipSuccess) t.on = 0;
     }
     return t;
 }
@@ -452,7 +453,7 @@ extern "C" int hnr_render_train_forward(const hnr_grid *grid, const hnr_train_pa
     // the reference-view feature pyramid needs the images and the conv weights only and is first read by the merge stage: side stream, from here
     TrainSide &side = train_side();
     bool fwd_forked = false;
-    if (V > 0 && side.on) {
+    if (V > 0 && (side.on & 1)) {
         HNR_HIP_CHECK(hipEventRecord(side.fork_f, st));
         HNR_HIP_CHECK(hipStreamWaitEvent(side.stream, side.fork_f, 0));
         TR(hnr_image_features(vw->d_images, V, p->H, p->W, w->conv_w, w->conv_b, sl, L.fm_scratch, L.fm, (void *)side.stream));
@@ -460,25 +461,33 @@ extern "C" int hnr_render_train_forward(const hnr_grid *grid, const hnr_train_pa
         fwd_forked = true;
     }
 
-    // ---- kernel images of this step's weights
+    // ---- kernel images of this step's weights: first used by the chain kernel -- packed on the second side stream meanwhile (the per-point table's
+    //      image, needed at once, on the caller's)
+    void *sp = stream;
+    if (side.on & 8) {
+        HNR_HIP_CHECK(hipEventRecord(side.ev_w[0], st));
+        HNR_HIP_CHECK(hipStreamWaitEvent(side.stream_w, side.ev_w[0], 0));
+        sp = (void *)side.stream_w;
+    }
     TR(hnr_chain_pack(w->block1_0_w + 224, 284, w->block1_0_b, w->block1_2_w, w->block1_2_b, w->block3_0_w, w->block3_0_b, w->block3_2_w, w->block3_2_b,
-                      w->alpha_w, w->alpha_b, L.img_chain, stream));
+                      w->alpha_w, w->alpha_b, L.img_chain, sp));
     const int cfN[4] = {128, 128, 128, 64}, cfK[4] = {280, 128, 128, 128}, cfld[4] = {280, 128, 128, 176};
     {
         const float *W[4] = {w->cf_w[0], w->cf_w[1], w->cf_w[2], V > 0 ? w->mw_w[0] + 45 : nullptr}, *B[4] = {w->cf_b[0], w->cf_b[1], w->cf_b[2], V > 0 ? w->mw_b[0] : nullptr};
-        TR(hnr_mlp3_pack(V > 0 ? 4 : 3, W, cfld, cfN, cfK, B, L.img_cf, stream));
+        TR(hnr_mlp3_pack(V > 0 ? 4 : 3, W, cfld, cfN, cfK, B, L.img_cf, sp));
     }
     const int mwN[3] = {64, 64, 64}, mwK[3] = {48, 64, 64}, mwld[3] = {48, 64, 64};
     if (V > 0) {
-        train_w0fd_kernel<<<(64 * 48 + 255) / 256, 256, 0, st>>>(w->mw_w[0], L.W0fd);
+        train_w0fd_kernel<<<(64 * 48 + 255) / 256, 256, 0, (hipStream_t)sp>>>(w->mw_w[0], L.W0fd);
         const float *W[3] = {L.W0fd, w->mw_w[1], w->mw_w[2]}, *B[3] = {nullptr, w->mw_b[1], w->mw_b[2]};
-        TR(hnr_mlp3_pack(3, W, mwld, mwN, mwK, B, L.img_mw, stream));
+        TR(hnr_mlp3_pack(3, W, mwld, mwN, mwK, B, L.img_mw, sp));
     }
     const int mxN[3] = {45, 45, 45}, mxK[3] = {90, 45, 45}, mxld[3] = {90, 45, 45};
     {
         const float *W[3] = {w->mx_w[0], w->mx_w[1], w->mx_w[2]}, *B[3] = {w->mx_b[0], w->mx_b[1], w->mx_b[2]};
-        TR(hnr_mlp3_pack(3, W, mxld, mxN, mxK, B, L.img_mx, stream));
+        TR(hnr_mlp3_pack(3, W, mxld, mxN, mxK, B, L.img_mx, sp));
     }
+    if (side.on & 8) HNR_HIP_CHECK(hipEventRecord(side.ev_w[1], side.stream_w));
     {
         // per-point table layer: [emb | PE(emb)] W0[:, :224]^T (no bias: block1.0's bias is added per row by the chain kernel)
         const float *W[1] = {w->block1_0_w}; const int64_t rs[1] = {284}, cs[1] = {1}; const int N1[1] = {256}, K1[1] = {224}; void *out[1] = {L.img[IM_TAB]};
@@ -511,6 +520,7 @@ extern "C" int hnr_render_train_forward(const hnr_grid *grid, const hnr_train_pa
     TR(point_rows_dc(cl->d_emb, L.ulist, (int)L.ucap, L.tc + TC_U, L.E, 224, st));
     TR(hnr_h2lin(L.E, 224, (int64_t)L.ucap, dU, 1, 0, L.img[IM_TAB], 256, 224, 0, 0, sl, nullptr, 0, L.Tu, 256, nullptr, stream));
     TR(mark());
+    if (side.on & 8) HNR_HIP_CHECK(hipStreamWaitEvent(st, side.ev_w[1], 0));    // the weight images are packed
     {
         float *H[4] = {L.H1, L.X3, L.H3, L.H4}; const int ldh[4] = {256, 264, 256, 256};
         TR(chain_forward_train(L.chain_ws, L.Tu, 256, L.uidx, L.img_chain, o->d_counts, cap, sl, L.X5, 280, L.sigma, H, ldh, L.amax + AM_H1, stream));
@@ -574,22 +584,21 @@ extern "C" int hnr_render_train_backward(const hnr_train_params *p, const hnr_tr
     };
     TR(mark());
     TrainSide &side = train_side();
-    const int side_on = side.on;
+    const int side_on = side.on & 1, side_z = side.on & 2;
     hipStream_t side_stream = side.stream;
     hipEvent_t side_fork = side.fork_b, side_join = side.join_b;
     bool forked = false;
-    int n_wg_forks = 0;
 
     // ---- zero what is accumulated into.  The dense point-gradient buffers (312 MB at 2 M points) are first written by the call's last kernels:
     //      cleared on the side stream, waited for before stage 10
     {
         hipStream_t sz = st;
-        if (side_on) { HNR_HIP_CHECK(hipEventRecord(side.fork_z, st)); HNR_HIP_CHECK(hipStreamWaitEvent(side_stream, side.fork_z, 0)); sz = side_stream; }
+        if (side_z) { HNR_HIP_CHECK(hipEventRecord(side.fork_z, st)); HNR_HIP_CHECK(hipStreamWaitEvent(side_stream, side.fork_z, 0)); sz = side_stream; }
         HNR_HIP_CHECK(hipMemsetAsync(gc->d_emb, 0, (size_t)N * 32 * 4, sz));
         HNR_HIP_CHECK(hipMemsetAsync(gc->d_conf, 0, (size_t)N * 4, sz));
         HNR_HIP_CHECK(hipMemsetAsync(gc->d_dir, 0, (size_t)N * 12, sz));
         HNR_HIP_CHECK(hipMemsetAsync(gc->d_color, 0, (size_t)N * 12, sz));
-        if (side_on) HNR_HIP_CHECK(hipEventRecord(side.join_z, side_stream));
+        if (side_z) HNR_HIP_CHECK(hipEventRecord(side.join_z, side_stream));
     }
     {
         ZeroJobs z;
@@ -628,15 +637,7 @@ extern "C" int hnr_render_train_backward(const hnr_train_params *p, const hnr_tr
     // weight gradient of one layer: dW = dZ^T X, db = column sums of dZ
     auto wgrad = [&](const float *dZ, int ldz, const float *X, int ldx, int64_t Mcap, const int64_t *dm, int nseg, int64_t segs, int Nn, int Kk, int amz, int amx,
                      float *dW, int lddw, float *db) -> int {
-        void *sw = stream;
-        if (side_on) {
-            // dZ (and its maximum) is complete on the caller's stream here: the GEMM goes to the weight-gradient stream behind an event
-            hipEvent_t ev = side.ev_w[n_wg_forks++ & 15];
-            HNR_HIP_CHECK(hipEventRecord(ev, st));
-            HNR_HIP_CHECK(hipStreamWaitEvent(side.stream_w, ev, 0));
-            sw = (void *)side.stream_w;
-        }
-        return hnr_h2wgrad(dZ, ldz, X, ldx, Mcap, dm, nseg, segs, Nn, Kk, am + amz, am + amx, dW, lddw, db, 0, L.wg_scratch, sw);
+        return hnr_h2wgrad(dZ, ldz, X, ldx, Mcap, dm, nseg, segs, Nn, Kk, am + amz, am + amx, dW, lddw, db, 0, L.wg_scratch, stream);
     };
     // input gradient through a LeakyReLU: out = (dZ W) * LeakyReLU'(side); side == NULL: out = dZ W
     auto dgrad = [&](const float *dZ, int ldz, int64_t Mcap, const int64_t *dm, int nseg, int64_t segs, int im, int Nn, int Kk, const float *side, int lds_, float *out, int ldo,
@@ -667,7 +668,7 @@ extern "C" int hnr_render_train_backward(const hnr_train_params *p, const hnr_tr
         TR(wgrad(L.dM2, 64, L.M1, 64, cap, dS, V, cap, 64, 64, AM_dM2, AM_M1, g.mw_w[1], 64, g.mw_b[1]));
         TR(dgrad(L.dM2, 64, cap, dS, V, cap, IM_MW1T, 64, 64, L.M1, 64, L.dM1, 64, AM_dM1));
         TR(wgrad(L.dM1, 64, L.X6, 48, cap, dS, V, cap, 64, 48, AM_dM1, AM_X6, L.tmpWfd, 48, nullptr));
-        train_w0fd_grad_kernel<<<(64 * 48 + 255) / 256, 256, 0, side_on ? side.stream_w : st>>>(L.tmpWfd, g.mw_w[0]);      // (behind the weight gradient that wrote tmpWfd)
+        train_w0fd_grad_kernel<<<(64 * 48 + 255) / 256, 256, 0, st>>>(L.tmpWfd, g.mw_w[0]);
         TR(sum_views_dc(L.dM1, 64, V, cap, L.tc + TC_S, 64, L.gpre, 64, st));
         TR(hnr_absmax(L.gpre, 64, cap, dS, 1, 0, 64, am + AM_gpre, stream));
         TR(wgrad(L.gpre, 64, L.CF, 128, cap, dS, 1, 0, 64, 128, AM_gpre, AM_CF, g.mw_w[0] + 45, 176, g.mw_b[0]));
@@ -730,7 +731,7 @@ extern "C" int hnr_render_train_backward(const hnr_train_params *p, const hnr_tr
         HNR_LAUNCH_CHECK();
     }
     TR(mark());
-    if (side_on) HNR_HIP_CHECK(hipStreamWaitEvent(st, side.join_z, 0));       // the point-gradient buffers are clear
+    if (side_z) HNR_HIP_CHECK(hipStreamWaitEvent(st, side.join_z, 0));        // the point-gradient buffers are clear
     if (d_g_conf_coefficient) {
         // the empty slots' share of d conf_coefficient lands on point 0 (the reference's index clamp)
         train_conf0_partial_kernel<<<512, 256, 0, st>>>(d_g_conf_coefficient, o->d_sample_pidx, (long long)R * SR * K, L.conf0);
@@ -753,7 +754,6 @@ extern "C" int hnr_render_train_backward(const hnr_train_params *p, const hnr_tr
     TR(dgrad(L.gTu, 256, ucap, dU, 1, 0, IM_TABT, 224, 256, nullptr, 0, L.gE, 224, -1));
     TR(point_rows_bwd_dc(L.gE, 224, L.E, 224, L.ulist, (int)ucap, L.tc + TC_U, gc->d_emb, st));
     if (forked) HNR_HIP_CHECK(hipStreamWaitEvent(st, side_join, 0));      // the image-branch stage (side stream) is part of this call
-    if (side_on && n_wg_forks > 0) { HNR_HIP_CHECK(hipEventRecord(side.join_w, side.stream_w)); HNR_HIP_CHECK(hipStreamWaitEvent(st, side.join_w, 0)); }      // ... and so are the weight gradients
     TR(mark());
     HNR_LAUNCH_CHECK();
     return HNR_OK;
