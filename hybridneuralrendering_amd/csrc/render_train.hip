@@ -403,6 +403,12 @@ struct TrainSide {
     hipEvent_t fork_f = nullptr, join_f = nullptr, fork_b = nullptr, join_b = nullptr, fork_z = nullptr, join_z = nullptr, ev_w[2] = {};
     int on = -1;
 };
+// An error return between a fork and its join must not leave side-stream work running on a workspace the caller may free: the guard drains the
+// side streams unless the call reached its joins.
+struct TrainSideGuard {
+    TrainSide *t = nullptr; bool armed = false;
+    ~TrainSideGuard() { if (armed && t) { if (t->stream) (void)hipStreamSynchronize(t->stream); if (t->stream_w) (void)hipStreamSynchronize(t->stream_w); } }
+};
 TrainSide &train_side()
 {
     static TrainSide t;
@@ -452,6 +458,7 @@ extern "C" int hnr_render_train_forward(const hnr_grid *grid, const hnr_train_pa
     TR(mark());
     // the reference-view feature pyramid needs the images and the conv weights only and is first read by the merge stage: side stream, from here
     TrainSide &side = train_side();
+    TrainSideGuard guard; guard.t = &side; guard.armed = side.on != 0;
     bool fwd_forked = false;
     if (V > 0 && (side.on & 1)) {
         HNR_HIP_CHECK(hipEventRecord(side.fork_f, st));
@@ -551,6 +558,7 @@ extern "C" int hnr_render_train_forward(const hnr_grid *grid, const hnr_train_pa
                      p->raydist_mode_unit, o->d_raycolor, o->d_opacity, o->d_is_background, o->d_blend_weight, stream));
     TR(mark());
     HNR_LAUNCH_CHECK();
+    guard.armed = false;                                             // every fork of this call has been joined
     return HNR_OK;
 }
 
@@ -584,6 +592,7 @@ extern "C" int hnr_render_train_backward(const hnr_train_params *p, const hnr_tr
     };
     TR(mark());
     TrainSide &side = train_side();
+    TrainSideGuard guard; guard.t = &side; guard.armed = side.on != 0;
     const int side_on = side.on & 1, side_z = side.on & 2;
     hipStream_t side_stream = side.stream;
     hipEvent_t side_fork = side.fork_b, side_join = side.join_b;
@@ -756,5 +765,6 @@ extern "C" int hnr_render_train_backward(const hnr_train_params *p, const hnr_tr
     if (forked) HNR_HIP_CHECK(hipStreamWaitEvent(st, side_join, 0));      // the image-branch stage (side stream) is part of this call
     TR(mark());
     HNR_LAUNCH_CHECK();
+    guard.armed = false;
     return HNR_OK;
 }
