@@ -235,3 +235,30 @@ def test_point_buffer_gradients_are_bit_identical_run_to_run():
     for other in runs[1:]:
         for a, b, name in zip(runs[0], other, ("points_embeding", "points_conf", "points_dir", "points_color")):
             assert torch.equal(a, b), name
+
+
+@pytest.mark.parametrize("tag", ["scannet_small", "scannet_small_nearest0"])
+def test_train_step_is_bit_identical_run_to_run_with_the_side_streams(tag):
+    """The training calls fork the reference-view CNN, their buffer clears and weight packs onto streams of the library (csrc/render_train.hip) and
+    join them before returning: every gradient that is not an atomic sum by design must come out with the same bits in every repetition of a
+    step (a missing dependency between the streams shows up as last-bit differences in a few rows -- tools/race_probe.py)."""
+    from hybridneuralrendering_amd.train import train_step
+    d, ti, opt, agg, path = _setup(tag)
+    near, far = d["near_far"]
+    tmid = torch.from_numpy(d["tmid"]).to(ti["emb"].device)
+    gt = torch.from_numpy(d["gt"][0]).to(ti["emb"].device)
+    atomic = ("aux_block", "alpha_branch", "color_final", "aux_merge_weight_block.6")      # weight gradients summed with float atomics
+    ref = None
+    for it in range(12):
+        emb, conf, pdir, color = _leaves(ti)
+        out, pg, ag = train_step(path, agg, ti["xyz"], emb, conf, pdir, color, ti["raydir"][0], ti["campos"][0], ti["camrotc2w"][0], ti["bg_color"][0], near, far,
+                                 ti["c2w_nearest"][0], ti["campos_nearest"][0], ti["intrinsic_nearest"][0], ti["images_nearest"][0], gt,
+                                 zero_epsilon=float(d["zero_epsilon"]), tmid=tmid, assign_grads=False)
+        cur = {("points." + k): v.clone() for k, v in pg.items()}
+        cur.update({k: v.clone() for k, v in ag.items() if not k.startswith(atomic)})
+        cur["coarse_raycolor"] = out["coarse_raycolor"].clone()
+        if ref is None:
+            ref = cur
+            continue
+        bad = [k for k in ref if not torch.equal(cur[k], ref[k])]
+        assert not bad, (it, bad)
