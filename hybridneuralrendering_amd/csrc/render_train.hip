@@ -395,8 +395,11 @@ int check_params(const hnr_train_params *p, const char *who)
 // per-neighbour chain, its backward beside the backward stages 7 - 11 -- both are strings of small latency-bound kernels whose results are
 // needed late (forward) or not at all downstream (backward); a second one packs the step's weight images while the query runs.  Forked from /
 // joined to the caller's stream with events inside each call.  (Not on a side stream: the weight-gradient GEMMs.  Forked behind per-layer events they
-// bought 0.12 ms, but 1 step in 10 then showed gradients that differed in the last bits of a few rows -- each of them alone beside the chain was
-// clean, standalone pairs of the kernels were clean (tools/race_pair.py); not understood, so not shipped.)
+// bought 0.12 ms, but 1 step in 10 then came out different: with all six small per-sample GEMMs queued on the side stream, train_ksum_bwd_kernel --
+// on the caller's stream, with bit-identical inputs -- wrote one row of one or two samples with the .x / .z components of lanes 48..63 changed.
+// Every weight gradient alone beside the chain was clean, any five of the six were clean, standalone pairs of the kernels are clean
+// (tools/race_pair.py): no dependency is missing in the step, so this looks like the platform under three busy queues -- not shipped.  The shipped
+// configuration ran 1200 steps without a differing bit, tools/race_probe.py.)
 // HNR_TRAIN_SIDE=0: everything in line on the caller's stream.
 struct TrainSide {
     hipStream_t stream = nullptr, stream_w = nullptr;                     // image branch / clears; weight packs

@@ -9,7 +9,7 @@ near, far = d["near_far"]
 tmid = torch.from_numpy(d["tmid"]).to(ti["emb"].device)
 gt = torch.from_numpy(d["gt"][0]).to(ti["emb"].device)
 ref = None
-for it in range(40):
+for it in range(int(os.environ.get("RACE_ITERS", "40"))):
     emb, conf, pdir, color = _leaves(ti)
     out, pg, ag = train_step(path, agg, ti["xyz"], emb, conf, pdir, color, ti["raydir"][0], ti["campos"][0], ti["camrotc2w"][0], ti["bg_color"][0], near, far,
                              ti["c2w_nearest"][0], ti["campos_nearest"][0], ti["intrinsic_nearest"][0], ti["images_nearest"][0], gt, zero_epsilon=float(d["zero_epsilon"]),
