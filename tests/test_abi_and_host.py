@@ -296,6 +296,14 @@ def test_c_abi_rejects_bad_arguments_without_touching_the_gpu():
     assert L.hnr_voxel_downsample_scratch_bytes(0) == 256
     assert L.hnr_shipped_loss(one, one, one, 10, one, 5, ctypes.c_float(0.7), 1.0, 1e-4, 1.0, one, one, one, one, null) == bad       # zero_epsilon >= 0.5
     assert L.hnr_shipped_loss(one, one, one, 10, one, 5, ctypes.c_float(1e-3), 1.0, 1e-4, 1.0, null, one, one, one, null) == bad      # no output
+    assert L.hnr_shipped_loss_rows(one, one, one, 10, one, -1, ctypes.c_float(1e-3), 1.0, 1e-4, 1.0, one, one, one, one, null) == bad  # negative row length
+    # the wave-per-tile stages: layout preconditions are refused up front
+    one16 = ctypes.c_void_p(0x1000)
+    assert L.hnr_mixup_stage(one16, 90, one16, one16, 128, one, one, one, one, one, 10, ctypes.c_float(0.01), null, 0, one16, null) == bad   # mix-up rows need 92 columns
+    assert L.hnr_mixup_stage(one16, 92, one16, one16, 100, one, one, one, one, one, 10, ctypes.c_float(0.01), null, 0, one16, null) == bad   # colour feature rows need 128
+    assert L.hnr_mixup_stage(one16, 92, one16, one16, 128, one, one, one, one, one, 10, ctypes.c_float(1.5), null, 0, one16, null) == bad    # slope
+    assert L.hnr_mixup_stage(null, 92, one16, one16, 128, one, one, one, one, one, 10, ctypes.c_float(0.01), null, 0, one16, null) == bad
+    assert L.hnr_mixup_stage(one16, 92, one16, one16, 128, one, one, one, one, one, 0, ctypes.c_float(0.01), null, 0, one16, null) == 0       # nothing to do
     assert L.hnr_voxel_downsample(one, 10, None, ctypes.c_float(0.1), one, one, one, null, one, one, 1 << 20, null) == bad     # no space_min
     assert L.hnr_voxel_downsample(one, 10, (ctypes.c_float * 3)(0, 0, 0), ctypes.c_float(0.0), one, one, one, null, one, one, 1 << 20, null) == bad
     assert L.hnr_query_work_elems(285200, 24) > 285200 * 24
