@@ -394,7 +394,7 @@ typedef float f32x4g __attribute__((ext_vector_type(4)));
 template <bool REC>
 __global__ __launch_bounds__(256) void chain_gather_kernel(ChainGatherArgs a)
 {
-    __shared__ float s_d[128][8];                        // dists6 per row
+    __shared__ float s_d[128][7];                        // dists6 per row (odd stride: rows of consecutive lanes on distinct banks)
     const ChainClasses cls = chain_classes(a.counts, a.cap_samples);
     const int n_valid = cls.n_valid;
     const int tid = threadIdx.x;
