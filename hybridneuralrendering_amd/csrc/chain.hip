@@ -76,6 +76,7 @@ __global__ __launch_bounds__(256, RT >= 4 ? 1 : 2) void chain_kernel(ChainArgs a
     long long tm[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0, t_start = 0, w_start = 0;
     int n_my = 0;
     float hmax_run[4] = {0.f, 0.f, 0.f, 0.f};                              // training: running maxima of the four layers' outputs
+    float x5max_run = 0.f;
     if (DBG == 2) { t_start = t_prev = clock64(); w_start = wall_clock64(); }
 #define CH_STAMP(i_) do { if (DBG == 2) { const long long t_ = clock64(); tm[i_] += t_ - t_prev; t_prev = t_; } } while (0)
     for (int tile = xcd_order ? t_lo + bi : (int)blockIdx.x; tile < (xcd_order ? t_hi : n_tiles); tile += xcd_order ? nb : (int)gridDim.x) {
@@ -317,6 +318,12 @@ __global__ __launch_bounds__(256, RT >= 4 ? 1 : 2) void chain_kernel(ChainArgs a
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
                             *reinterpret_cast<float4 *>(o + 32 * c + 4 * q) = make_float4(acc[rt][c][4 * q], acc[rt][c][4 * q + 1], acc[rt][c][4 * q + 2], acc[rt][c][4 * q + 3]);
+                    if (DBG == 3) {
+#pragma unroll
+                        for (int c = 0; c < 2; ++c)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) x5max_run = fmaxf(x5max_run, fabsf(acc[rt][c][r]));
+                    }
                 }
                 if (rt == wave) {
                     const float4 d4 = *reinterpret_cast<const float4 *>(exch + (32 * rt + j) * 4);
@@ -352,6 +359,14 @@ __global__ __launch_bounds__(256, RT >= 4 ? 1 : 2) void chain_kernel(ChainArgs a
         }
         __syncthreads();
         if (tid < 4) { const float m = fmaxf(fmaxf(exch[4 * tid], exch[4 * tid + 1]), fmaxf(exch[4 * tid + 2], exch[4 * tid + 3])); if (m > 0.f) atomicMax(a.hmax + tid, __float_as_uint(m)); }
+        if (a.x5max) {
+            __syncthreads();
+            float m = x5max_run;
+            for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+            if (lane == 0) exch[wave] = m;
+            __syncthreads();
+            if (tid == 0) { const float mm = fmaxf(fmaxf(exch[0], exch[1]), fmaxf(exch[2], exch[3])); if (mm > 0.f) atomicMax(a.x5max, __float_as_uint(mm)); }
+        }
     }
 #undef CH_STAMP
 }
@@ -852,7 +867,7 @@ extern "C" int hnr_chain_forward(const void *d_workspace, const float *d_point_t
     // default: the weight-stationary pipelined kernel (csrc/chain_ws.hip)
     static int rt_mode = 0;
     if (rt_mode == 0) { const char *e = getenv("HNR_CHAIN_RT"); rt_mode = (e && atoi(e) == 4) ? 4 : 16; }
-    a.skew = 0; a.uidx = nullptr; a.hmax = nullptr;
+    a.skew = 0; a.uidx = nullptr; a.hmax = nullptr; a.x5max = nullptr;
     for (int l = 0; l < 4; ++l) { a.H[l] = nullptr; a.ldh[l] = 0; }
     static bool attr_set = false;
     if (!attr_set) {
@@ -885,7 +900,7 @@ int chain_gather_train(const float *d_xyz, const float *d_conf, const float *d_d
 }
 
 int chain_forward_train(const void *d_workspace, const float *d_point_table, int ldt, const int32_t *d_uidx, const void *d_packed, const int64_t *d_counts,
-                        int cap_samples, float slope, float *d_X5, int ld5, float *d_sigma, float *const *d_H, const int *ldh, uint32_t *d_hmax, void *stream)
+                        int cap_samples, float slope, float *d_X5, int ld5, float *d_sigma, float *const *d_H, const int *ldh, uint32_t *d_hmax, uint32_t *d_x5max, void *stream)
 {
     if (cap_samples <= 0) return HNR_OK;
     const int blocks = cdiv(cap_samples, 16) + 2;
@@ -895,7 +910,7 @@ int chain_forward_train(const void *d_workspace, const float *d_point_table, int
     a.counts = reinterpret_cast<const unsigned long long *>(d_counts);
     a.X5 = d_X5; a.ld5 = ld5; a.sigma = d_sigma; a.slope = slope; a.cap_samples = cap_samples; a.dbg = nullptr; a.dbg_layer = 0; a.skew = 0;
     for (int l = 0; l < 4; ++l) { a.H[l] = d_H[l]; a.ldh[l] = ldh[l]; }
-    a.uidx = d_uidx; a.hmax = d_hmax;
+    a.uidx = d_uidx; a.hmax = d_hmax; a.x5max = d_x5max;
     const int n_cu = chain_num_cus();
     const int tiles = cdiv(cap_samples, 16), grid = tiles < n_cu ? tiles : n_cu;
     HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chain_kernel<4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, ch_lds_bytes(4)));

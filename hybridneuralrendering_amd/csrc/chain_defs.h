@@ -36,6 +36,7 @@ struct ChainArgs {
     float *H[4]; int ldh[4];           // [rows, ldh >= 256] block1.0 / block1.2 / block3.0 / block3.2 outputs; H[1] has ldh >= 264: columns 256..263 = block3's 7 extras + 0
     const int32_t *uidx;               // optional: point id -> row of ptab (the table holds the batch's touched points only)
     unsigned *hmax;                    // [4] bit patterns of max |H[l]| (atomicMax; H[1]'s includes the extras): scales of the weight-gradient GEMMs
+    unsigned *x5max;                   // optional: bit pattern of max |weighted feature sum| (the first 256 columns of X5), atomicMax
 };
 
 // Row-slot classes (hnr_chain_plan): samples [0, n_big) own 8 row slots each (16 samples per 128-row tile), the next n_small 4 (32 per tile), the

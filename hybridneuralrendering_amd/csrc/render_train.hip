@@ -135,6 +135,7 @@ __global__ void train_counts_kernel(unsigned long long *counts, int cap_samples,
     tc[TC_S] = (long long)s; tc[TC_M8] = 8 * (long long)s; tc[TC_U] = 0;
     for (int i = 0; i < AM_N; ++i) amax[i] = 0u;
     amax[AM_ONE] = __float_as_uint(1.0f);               // |sin|, |cos| <= 1: block1.0's distance inputs
+    amax[AM_X5] = __float_as_uint(1.0f);                // ... and X5's 24 direction-encoding columns; the chain kernel adds the maximum of its 256 feature sums
 }
 
 __global__ void train_ucount_kernel(const int32_t *ucount, long long ucap, long long *tc) { const long long u = ucount[0]; tc[TC_U] = u < ucap ? u : ucap; }
@@ -533,10 +534,9 @@ extern "C" int hnr_render_train_forward(const hnr_grid *grid, const hnr_train_pa
     if (side.on & 8) HNR_HIP_CHECK(hipStreamWaitEvent(st, side.ev_w[1], 0));    // the weight images are packed
     {
         float *H[4] = {L.H1, L.X3, L.H3, L.H4}; const int ldh[4] = {256, 264, 256, 256};
-        TR(chain_forward_train(L.chain_ws, L.Tu, 256, L.uidx, L.img_chain, o->d_counts, cap, sl, L.X5, 280, L.sigma, H, ldh, L.amax + AM_H1, stream));
+        TR(chain_forward_train(L.chain_ws, L.Tu, 256, L.uidx, L.img_chain, o->d_counts, cap, sl, L.X5, 280, L.sigma, H, ldh, L.amax + AM_H1, L.amax + AM_X5, stream));     // (AM_X5 starts at 1: the direction encoding's columns)
     }
     TR(mark());
-    TR(hnr_absmax(L.X5, 280, cap, dS, 1, 0, 280, L.amax + AM_X5, stream));
     // ---- per-sample MLPs
     const int act1110[4] = {1, 1, 1, 0}, act111[3] = {1, 1, 1}, act110[3] = {1, 1, 0};
     TR(mlp3_forward_train(L.X5, 280, cap, o->d_counts, HNR_CNT_SAMPLES_VALID, 1, 0, L.img_cf, V > 0 ? 4 : 3, cfN, cfK, act1110, sl, nullptr, nullptr, 0, L.CF, 128,
