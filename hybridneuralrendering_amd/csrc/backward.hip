@@ -392,123 +392,178 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(UpsampleBwdArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------ 3x3 convolutions
-// g_out is the gradient w.r.t. the POST-activation output `out`; d pre-activation = g_out * (out > 0 ? 1 : slope).
-// data gradient: one lane per input element, gather form (no atomics), ACCUMULATES into g_in
-__device__ __forceinline__ void conv3x3_bwd_data_body(int64_t block, const float *__restrict__ g_out, const float *__restrict__ out, const float *__restrict__ w,
-                                                      int Cin, int Hin, int Win, int Cout, int stride, int Hout, int Wout, float slope,
-                                                      float *__restrict__ g_in, int V, const int32_t *__restrict__ bbox, int f, int halo)
-{
-    const int64_t idx = block * blockDim.x + threadIdx.x;
-    const int64_t total = (int64_t)V * Cin * Hin * Win;
-    if (idx >= total) return;
-    const int ix = (int)(idx % Win), iy = (int)((idx / Win) % Hin), ci = (int)((idx / ((int64_t)Win * Hin)) % Cin),
-              v = (int)(idx / ((int64_t)Win * Hin * Cin));
-    if (bbox) {
-        // the gradient is zero outside the (generously dilated) image of the pixels the batch touched in this view: nothing to add there
-        const int bx0 = bbox[4 * v], by0 = bbox[4 * v + 1], bx1 = bbox[4 * v + 2], by1 = bbox[4 * v + 3];
-        if (bx1 < bx0 || ix < bx0 / f - halo || ix > bx1 / f + halo || iy < by0 / f - halo || iy > by1 / f + halo) return;
-    }
-    float acc = 0.f;
-    for (int ky = 0; ky < 3; ++ky) {
-        const int ty = iy + 1 - ky;
-        if (ty < 0 || ty % stride) continue;
-        const int oy = ty / stride;
-        if (oy >= Hout) continue;
-        for (int kx = 0; kx < 3; ++kx) {
-            const int tx = ix + 1 - kx;
-            if (tx < 0 || tx % stride) continue;
-            const int ox = tx / stride;
-            if (ox >= Wout) continue;
-            for (int co = 0; co < Cout; ++co) {
-                const size_t o = (((size_t)v * Cout + co) * Hout + oy) * Wout + ox;
-                const float dz = g_out[o] * (out[o] > 0.f ? 1.f : slope);
-                acc = fmaf(dz, w[((co * Cin + ci) * 3 + ky) * 3 + kx], acc);
-            }
-        }
-    }
-    g_in[idx] += acc;
-}
-__global__ void conv3x3_bwd_data_kernel(const float *__restrict__ g_out, const float *__restrict__ out, const float *__restrict__ w,
-                                        int Cin, int Hin, int Win, int Cout, int stride, int Hout, int Wout, float slope,
-                                        float *__restrict__ g_in, int V, const int32_t *__restrict__ bbox = nullptr, int f = 1, int halo = 0)
-{
-    conv3x3_bwd_data_body(blockIdx.x, g_out, out, w, Cin, Hin, Win, Cout, stride, Hout, Wout, slope, g_in, V, bbox, f, halo);
-}
-
-// weight + bias gradient: blockIdx.x = co * Cin + ci, blockIdx.y = pixel chunk; block reduction, then 9 (+1) atomics
-__device__ __forceinline__ void conv3x3_bwd_weight_body(int bx, int by, int ny, const float *__restrict__ g_out, const float *__restrict__ out,
-                                                        const float *__restrict__ in, int in_cl, int in_cstride,
-                                                        int Cin, int Hin, int Win, int Cout, int stride, int Hout, int Wout,
-                                                        float slope, float *__restrict__ g_w, float *__restrict__ g_b, int V,
-                                                        const int32_t *__restrict__ bbox, int f, int halo)
-{
-    __shared__ float s_red[4][10];
-    const int co = bx / Cin, ci = bx % Cin;
-    const int64_t npix = (int64_t)V * Hout * Wout;
-    float acc[10];
-#pragma unroll
-    for (int i = 0; i < 10; ++i) acc[i] = 0.f;
-    for (int64_t pix = (int64_t)by * blockDim.x + threadIdx.x; pix < npix; pix += (int64_t)ny * blockDim.x) {
-        const int ox = (int)(pix % Wout), oy = (int)((pix / Wout) % Hout), v = (int)(pix / ((int64_t)Wout * Hout));
-        if (bbox) {
-            const int bx0 = bbox[4 * v], by0 = bbox[4 * v + 1], bx1 = bbox[4 * v + 2], by1 = bbox[4 * v + 3];
-            if (bx1 < bx0 || ox < bx0 / f - halo || ox > bx1 / f + halo || oy < by0 / f - halo || oy > by1 / f + halo) continue;
-        }
-        const size_t o = (((size_t)v * Cout + co) * Hout + oy) * Wout + ox;
-        const float dz = g_out[o] * (out[o] > 0.f ? 1.f : slope);
-        if (dz == 0.f) continue;
-        acc[9] += dz;
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const int iy = oy * stride - 1 + ky;
-            if (iy < 0 || iy >= Hin) continue;
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int ix = ox * stride - 1 + kx;
-                if (ix < 0 || ix >= Win) continue;
-                const float xv = in_cl ? in[(((size_t)v * Hin + iy) * Win + ix) * in_cstride + ci]
-                                       : in[(((size_t)v * Cin + ci) * Hin + iy) * Win + ix];
-                acc[ky * 3 + kx] = fmaf(dz, xv, acc[ky * 3 + kx]);
-            }
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 10; ++i) acc[i] = wave_sum(acc[i]);
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    if (lane == 0)
-#pragma unroll
-        for (int i = 0; i < 10; ++i) s_red[wid][i] = acc[i];
-    __syncthreads();
-    if (threadIdx.x < 10) {
-        const float t = s_red[0][threadIdx.x] + s_red[1][threadIdx.x] + s_red[2][threadIdx.x] + s_red[3][threadIdx.x];
-        if (threadIdx.x < 9) atomicAdd(g_w + (size_t)(co * Cin + ci) * 9 + threadIdx.x, t);
-        else if (ci == 0) atomicAdd(g_b + co, t);
-    }
-}
-__global__ __launch_bounds__(256) void conv3x3_bwd_weight_kernel(const float *__restrict__ g_out, const float *__restrict__ out,
-                                                                 const float *__restrict__ in, int in_cl, int in_cstride,
-                                                                 int Cin, int Hin, int Win, int Cout, int stride, int Hout, int Wout,
-                                                                 float slope, float *__restrict__ g_w, float *__restrict__ g_b, int V,
-                                                                 const int32_t *__restrict__ bbox = nullptr, int f = 1, int halo = 0)
-{
-    conv3x3_bwd_weight_body(blockIdx.x, blockIdx.y, gridDim.y, g_out, out, in, in_cl, in_cstride, Cin, Hin, Win, Cout, stride, Hout, Wout, slope, g_w, g_b, V, bbox, f, halo);
-}
-// One launch for a layer's two gradients (both read the same g_out / out and neither reads what the other writes): blocks [0, n_data) the data
-// gradient, the rest the weight gradient (bx = pair (co, ci), by = pixel chunk).  Two small latency-bound kernels back to back took the sum of
-// their times; side by side they take the longer one's.
-struct ConvBwdArgs {
-    const float *g_out, *out, *w, *in; int in_cl, in_cstride, Cin, Hin, Win, Cout, stride, Hout, Wout; float slope;
-    float *g_in, *g_w, *g_b; int V; const int32_t *bbox; int f_in, halo_in, f_out, halo_out; int n_data, ny;
+// g_out is the gradient w.r.t. the POST-activation output `out`; d pre-activation dz = g_out * (out > 0 ? 1 : slope).
+// One block per tile of TO x TO OUTPUT pixels of one view (and the S*TO x S*TO input pixels under it).
+// Both gradients of a layer from one LDS copy of the tile: dz = g_out * leaky'(out) with its one-pixel halo, the layer input with its halo, the
+// weights transposed to [tap][co][ci].  Data gradient: a thread owns one input pixel (stride 1) or one 2x2 input quad (stride 2: each of the
+// nine taps reaches exactly one pixel of the quad, so no lane multiplies by a structural zero) for CIN / NG channels and writes g_in itself (no
+// atomics).  Weight gradient: a thread owns 3 output channels x 1 input channel x 9 taps over every `slices`-th pixel of the tile; the slices are
+// summed in a fixed order through LDS and the block adds ONE partial per weight with a float atomic (the sum over blocks is the only
+// order-dependent part).  A per-element form (one lane per input element / per (co, ci) pair, operands from L2) spent ~10 integer and address
+// instructions per multiply-add: 1.35 ms of kernel time per training step against 0.68 ms here (both stretched by the main stream's kernels
+// they run beside -- profiles/README.md).
+struct ConvTileArgs {
+    const float *g_out, *out, *w, *in; int in_cstride, Hin, Win, Hout, Wout; float slope;
+    float *g_in, *g_w, *g_b; int V; const int32_t *bbox; int f_out, halo_out; int tiles_x, tiles_y;
 };
-__global__ __launch_bounds__(256) void conv3x3_bwd_both_kernel(ConvBwdArgs a)
+template <int CIN, int COUT, int S, int TO, bool DGRAD, bool IN_CL>
+__global__ __launch_bounds__(256) void conv3x3_bwd_tile_kernel(ConvTileArgs a)
 {
-    if ((int)blockIdx.x < a.n_data) {
-        conv3x3_bwd_data_body(blockIdx.x, a.g_out, a.out, a.w, a.Cin, a.Hin, a.Win, a.Cout, a.stride, a.Hout, a.Wout, a.slope, a.g_in, a.V, a.bbox, a.f_in, a.halo_in);
-    } else {
-        const int b = (int)blockIdx.x - a.n_data;
-        conv3x3_bwd_weight_body(b / a.ny, b % a.ny, a.ny, a.g_out, a.out, a.in, a.in_cl, a.in_cstride, a.Cin, a.Hin, a.Win, a.Cout, a.stride, a.Hout, a.Wout, a.slope, a.g_w,
-                                a.g_b, a.V, a.bbox, a.f_out, a.halo_out);
+    constexpr int NP = TO * TO;                       // output pixels (= input pixels at stride 1, input quads at stride 2) of the tile
+    constexpr int DR = (S == 1) ? TO + 2 : TO + 1;    // dz rows/cols held: stride 1 [oy0 - 1, oy0 + TO], stride 2 [oy0, oy0 + TO]
+    constexpr int IR = S * TO + ((S == 1) ? 2 : 1);   // input rows/cols held: [S * oy0 - 1, S * oy0 + S * TO - 1 (+1 at stride 1)]
+    constexpr int DSTR = (DR * DR) | 1, ISTR = (IR * IR) | 1;        // odd channel strides: lanes that differ in channel hit different banks
+    constexpr int CG = COUT / 3, UNITS = CG * CIN, SLICES = 256 / UNITS;
+    constexpr int NG = 256 / NP, CPG = CIN / NG;      // data gradient: channel groups per pixel, channels per group
+    static_assert(COUT % 3 == 0 && UNITS <= 256 && NP <= 256 && 256 % NP == 0 && CIN % NG == 0, "tile shape");
+    extern __shared__ float smem[];
+    float *s_dz = smem, *s_in = s_dz + COUT * DSTR, *s_w = s_in + CIN * ISTR, *s_part = s_w + (DGRAD ? 9 * COUT * CIN : 0);
+    const int t = threadIdx.x;
+    int b = blockIdx.x;
+    const int tx = b % a.tiles_x; b /= a.tiles_x;
+    const int ty = b % a.tiles_y, v = b / a.tiles_y;
+    const int oy0 = ty * TO, ox0 = tx * TO;
+    if (a.bbox) {
+        // nothing outside the (dilated) image of the pixels the batch touched in this view carries a gradient
+        const int bx0 = a.bbox[4 * v], by0 = a.bbox[4 * v + 1], bx1 = a.bbox[4 * v + 2], by1 = a.bbox[4 * v + 3];
+        if (bx1 < bx0 || ox0 + TO + 1 < bx0 / a.f_out - a.halo_out || ox0 - 1 > bx1 / a.f_out + a.halo_out ||
+            oy0 + TO + 1 < by0 / a.f_out - a.halo_out || oy0 - 1 > by1 / a.f_out + a.halo_out) return;
     }
+    // ---- load
+    constexpr int D0 = (S == 1) ? 1 : 0;
+    for (int i = t; i < COUT * DR * DR; i += 256) {
+        const int c = i / (DR * DR), r = i % (DR * DR), oy = oy0 - D0 + r / DR, ox = ox0 - D0 + r % DR;
+        float dz = 0.f;
+        if (oy >= 0 && oy < a.Hout && ox >= 0 && ox < a.Wout) {
+            const size_t o = (((size_t)v * COUT + c) * a.Hout + oy) * a.Wout + ox;
+            dz = a.g_out[o] * (a.out[o] > 0.f ? 1.f : a.slope);
+        }
+        s_dz[c * DSTR + r] = dz;
+    }
+    for (int i = t; i < CIN * IR * IR; i += 256) {
+        const int c = i / (IR * IR), r = i % (IR * IR), iy = S * oy0 - 1 + r / IR, ix = S * ox0 - 1 + r % IR;
+        float x = 0.f;
+        if (iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win)
+            x = IN_CL ? a.in[(((size_t)v * a.Hin + iy) * a.Win + ix) * a.in_cstride + c] : a.in[(((size_t)v * CIN + c) * a.Hin + iy) * a.Win + ix];
+        s_in[c * ISTR + r] = x;
+    }
+    if (DGRAD)
+        for (int i = t; i < 9 * COUT * CIN; i += 256) {             // w[co][ci][k] -> s_w[k][co][ci]
+            const int k = i % 9, ci = (i / 9) % CIN, co = i / (9 * CIN);
+            s_w[(k * COUT + co) * CIN + ci] = a.w[i];
+        }
+    __syncthreads();
+    // ---- data gradient
+    if (DGRAD) {
+        const int p = t % NP, g = __builtin_amdgcn_readfirstlane(t / NP), ly = p / TO, lx = p % TO;
+        if (S == 1) {
+            float acc[CPG];
+#pragma unroll
+            for (int c = 0; c < CPG; ++c) acc[c] = 0.f;
+#pragma unroll 1
+            for (int co = 0; co < COUT; ++co) {
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const float dz = s_dz[co * DSTR + (ly + 2 - ky) * DR + (lx + 2 - kx)];
+                        const float *wp = s_w + ((ky * 3 + kx) * COUT + co) * CIN + g * CPG;
+#pragma unroll
+                        for (int c = 0; c < CPG; ++c) acc[c] = fmaf(dz, wp[c], acc[c]);
+                    }
+            }
+            const int iy = oy0 + ly, ix = ox0 + lx;
+            if (iy < a.Hin && ix < a.Win)
+#pragma unroll
+                for (int c = 0; c < CPG; ++c) a.g_in[(((size_t)v * CIN + g * CPG + c) * a.Hin + iy) * a.Win + ix] += acc[c];
+        } else {
+            float acc[2][2][CPG];
+#pragma unroll
+            for (int i = 0; i < 4 * CPG; ++i) (&acc[0][0][0])[i] = 0.f;
+#pragma unroll 1
+            for (int co = 0; co < COUT; ++co) {
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        // input row 2q + py meets tap ky at output row (2q + py + 1 - ky) / 2: py = 0 -> ky = 1 (row q); py = 1 -> ky = 0 (row q + 1), ky = 2 (row q)
+                        const int py = (ky == 1) ? 0 : 1, px = (kx == 1) ? 0 : 1, dy = (ky == 0) ? 1 : 0, dx = (kx == 0) ? 1 : 0;
+                        const float dz = s_dz[co * DSTR + (ly + dy) * DR + (lx + dx)];
+                        const float *wp = s_w + ((ky * 3 + kx) * COUT + co) * CIN + g * CPG;
+#pragma unroll
+                        for (int c = 0; c < CPG; ++c) acc[py][px][c] = fmaf(dz, wp[c], acc[py][px][c]);
+                    }
+            }
+#pragma unroll
+            for (int py = 0; py < 2; ++py)
+#pragma unroll
+                for (int px = 0; px < 2; ++px) {
+                    const int iy = 2 * (oy0 + ly) + py, ix = 2 * (ox0 + lx) + px;
+                    if (iy < a.Hin && ix < a.Win)
+#pragma unroll
+                        for (int c = 0; c < CPG; ++c) a.g_in[(((size_t)v * CIN + g * CPG + c) * a.Hin + iy) * a.Win + ix] += acc[py][px][c];
+                }
+        }
+    }
+    // ---- weight gradient
+    const int u = t % UNITS, slice = t / UNITS, ci = u % CIN, cg = u / CIN;
+    float wacc[3][9];
+#pragma unroll
+    for (int i = 0; i < 27; ++i) (&wacc[0][0])[i] = 0.f;
+    if (slice < SLICES) {
+        for (int p = slice; p < NP; p += SLICES) {
+            const int ly = p / TO, lx = p % TO;
+            const float *dp = s_dz + (3 * cg) * DSTR + (ly + D0) * DR + (lx + D0);
+            const float d0 = dp[0], d1 = dp[DSTR], d2 = dp[2 * DSTR];
+            const float *ip = s_in + ci * ISTR + (S * ly) * IR + S * lx;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float x = ip[ky * IR + kx];
+                    wacc[0][ky * 3 + kx] = fmaf(d0, x, wacc[0][ky * 3 + kx]);
+                    wacc[1][ky * 3 + kx] = fmaf(d1, x, wacc[1][ky * 3 + kx]);
+                    wacc[2][ky * 3 + kx] = fmaf(d2, x, wacc[2][ky * 3 + kx]);
+                }
+        }
+    }
+    if (SLICES == 1) {
+        if (slice < SLICES)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int k = 0; k < 9; ++k) atomicAdd(a.g_w + ((size_t)(3 * cg + j) * CIN + ci) * 9 + k, wacc[j][k]);
+    } else {
+        if (slice < SLICES)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int k = 0; k < 9; ++k) s_part[(size_t)slice * (COUT * CIN * 9) + ((3 * cg + j) * CIN + ci) * 9 + k] = wacc[j][k];
+        __syncthreads();
+        for (int o = t; o < COUT * CIN * 9; o += 256) {
+            float sum = 0.f;
+            for (int sl = 0; sl < SLICES; ++sl) sum += s_part[(size_t)sl * (COUT * CIN * 9) + o];
+            atomicAdd(a.g_w + o, sum);
+        }
+    }
+    // bias: sum of dz over the tile's own pixels
+    if (t < COUT) {
+        float sum = 0.f;
+        for (int p = 0; p < NP; ++p) sum += s_dz[t * DSTR + (p / TO + D0) * DR + (p % TO + D0)];
+        atomicAdd(a.g_b + t, sum);
+    }
+}
+template <int CIN, int COUT, int S, int TO, bool DGRAD, bool IN_CL>
+static void conv3x3_bwd_tile_launch(ConvTileArgs a, hipStream_t st)
+{
+    constexpr int DR = (S == 1) ? TO + 2 : TO + 1, IR = S * TO + ((S == 1) ? 2 : 1), DSTR = (DR * DR) | 1, ISTR = (IR * IR) | 1;
+    constexpr int UNITS = (COUT / 3) * CIN, SLICES = 256 / UNITS;
+    constexpr size_t lds = sizeof(float) * ((size_t)COUT * DSTR + (size_t)CIN * ISTR + (DGRAD ? 9 * COUT * CIN : 0) + (SLICES > 1 ? (size_t)SLICES * COUT * CIN * 9 : 0));
+    static_assert(lds <= 160 * 1024, "tile does not fit the LDS");
+    auto kern = conv3x3_bwd_tile_kernel<CIN, COUT, S, TO, DGRAD, IN_CL>;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return;   // (per device, cheap: set on every launch; a failure shows up as the launch error)
+    a.tiles_x = (a.Wout + TO - 1) / TO; a.tiles_y = (a.Hout + TO - 1) / TO;
+    kern<<<a.tiles_x * a.tiles_y * a.V, 256, lds, st>>>(a);
 }
 
 // ------------------------------------------------------------------------------------------------ gather
@@ -850,39 +905,20 @@ static int image_features_bwd_impl(const float *d_img, int V, int H, int W, cons
     // resolution divisor and dilation of a tensor at pyramid level 1 / 2 / 3 (upsample +-1, every 3x3 conv +-1, every stride-2 step x2 + 1)
     auto lvl_f = [&](int Hl) { return Hl == H1 ? 2 : (Hl == H2 ? 4 : 8); };
     auto lvl_halo = [&](int Hl) { return Hl == H1 ? 30 : (Hl == H2 ? 14 : 6); };
-    auto wgrad = [&](const float *g_out, const float *out, const float *in, int cl, int cstride, int Cin, int Hin, int Win, int Cout,
-                     int stride, int Hout, int Wout, int li) {
-        const int64_t npix = (int64_t)V * Hout * Wout;
-        int chunks = cdiv(npix, 256 * 8);
-        if (chunks > 64) chunks = 64;
-        conv3x3_bwd_weight_kernel<<<dim3(Cout * Cin, chunks), 256, 0, st>>>(g_out, out, in, cl, cstride, Cin, Hin, Win, Cout, stride, Hout,
-                                                                             Wout, slope, g_conv_w[li], g_conv_b[li], V, d_bbox, lvl_f(Hout), lvl_halo(Hout));
-    };
-    auto dgrad = [&](const float *g_out, const float *out, int li, int Cin, int Hin, int Win, int Cout, int stride, int Hout, int Wout,
-                     float *g_in) {
-        const int64_t total = (int64_t)V * Cin * Hin * Win;
-        conv3x3_bwd_data_kernel<<<cdiv(total, 256), 256, 0, st>>>(g_out, out, conv_w[li], Cin, Hin, Win, Cout, stride, Hout, Wout, slope, g_in, V,
-                                                                  d_bbox, lvl_f(Hin), lvl_halo(Hin));
-    };
     // conv5: s3a -> s3 ; conv4: s2 -> s3a (stride 2) ; conv3: s2a -> s2 ; conv2: s1 -> s2a (stride 2) ; conv1: s1a -> s1 ; conv0: img -> s1a
-    auto both = [&](const float *g_out, const float *out, const float *in, int Cin, int Hin, int Win, int Cout, int stride, int Hout, int Wout, int li, float *g_in) {
-        ConvBwdArgs a;
-        a.g_out = g_out; a.out = out; a.w = conv_w[li]; a.in = in; a.in_cl = 0; a.in_cstride = 0; a.Cin = Cin; a.Hin = Hin; a.Win = Win; a.Cout = Cout; a.stride = stride;
-        a.Hout = Hout; a.Wout = Wout; a.slope = slope; a.g_in = g_in; a.g_w = g_conv_w[li]; a.g_b = g_conv_b[li]; a.V = V; a.bbox = d_bbox;
-        a.f_in = lvl_f(Hin); a.halo_in = lvl_halo(Hin); a.f_out = lvl_f(Hout); a.halo_out = lvl_halo(Hout);
-        a.n_data = cdiv((int64_t)V * Cin * Hin * Win, 256);
-        int chunks = cdiv((int64_t)V * Hout * Wout, 256 * 8);
-        if (chunks > 64) chunks = 64;
-        a.ny = chunks;
-        conv3x3_bwd_both_kernel<<<a.n_data + Cout * Cin * chunks, 256, 0, st>>>(a);
+    auto tile = [&](const float *g_out, const float *out, const float *in, int cstride, int Hin, int Win, int Hout, int Wout, int li, float *g_in) {
+        ConvTileArgs a;
+        a.g_out = g_out; a.out = out; a.w = conv_w[li]; a.in = in; a.in_cstride = cstride; a.Hin = Hin; a.Win = Win; a.Hout = Hout; a.Wout = Wout; a.slope = slope;
+        a.g_in = g_in; a.g_w = g_conv_w[li]; a.g_b = g_conv_b[li]; a.V = V; a.bbox = d_bbox; a.f_out = lvl_f(Hout); a.halo_out = lvl_halo(Hout);
+        a.tiles_x = a.tiles_y = 0;
+        return a;
     };
-    (void)dgrad;
-    both(g3, s3, s3a, 24, H3, W3, 24, 1, H3, W3, 5, g3a);
-    both(g3a, s3a, s2, 12, H2, W2, 24, 2, H3, W3, 4, g2);
-    both(g2, s2, s2a, 12, H2, W2, 12, 1, H2, W2, 3, g2a);
-    both(g2a, s2a, s1, 6, H1, W1, 12, 2, H2, W2, 2, g1);
-    both(g1, s1, s1a, 6, H1, W1, 6, 1, H1, W1, 1, g1a);
-    wgrad(g1a, s1a, d_img, 1, 3, 3, H, W, 6, 2, H1, W1, 0);
+    conv3x3_bwd_tile_launch<24, 24, 1, 8, true, false>(tile(g3, s3, s3a, 0, H3, W3, H3, W3, 5, g3a), st);
+    conv3x3_bwd_tile_launch<12, 24, 2, 8, true, false>(tile(g3a, s3a, s2, 0, H2, W2, H3, W3, 4, g2), st);
+    conv3x3_bwd_tile_launch<12, 12, 1, 16, true, false>(tile(g2, s2, s2a, 0, H2, W2, H2, W2, 3, g2a), st);
+    conv3x3_bwd_tile_launch<6, 12, 2, 16, true, false>(tile(g2a, s2a, s1, 0, H1, W1, H2, W2, 2, g1), st);
+    conv3x3_bwd_tile_launch<6, 6, 1, 16, true, false>(tile(g1, s1, s1a, 0, H1, W1, H1, W1, 1, g1a), st);
+    conv3x3_bwd_tile_launch<3, 6, 2, 16, false, true>(tile(g1a, s1a, d_img, 3, H, W, H1, W1, 0, nullptr), st);
     HNR_LAUNCH_CHECK();
     return HNR_OK;
 }
