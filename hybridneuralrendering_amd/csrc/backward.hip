@@ -18,6 +18,7 @@
 #include <utility>
 
 #include "hnr_common.h"
+#include "train_internal.h"
 
 namespace hnr {
 
@@ -41,7 +42,8 @@ struct CompositeBwdArgs {
     float *g_decoded;                                    // [R,SR,4] out: (d sigma, d rgb); doubles as the per-ray scratch
 };
 
-__global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a)
+// one thread per ray: any SR (the wave-per-ray form below holds a ray's samples in the lanes of one wave: SR <= 64)
+__global__ __launch_bounds__(256) void composite_bwd_serial_kernel(CompositeBwdArgs a)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= a.R) return;
@@ -101,6 +103,76 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a)
     }
 }
 
+// One WAVE per ray, lane = shading sample (SR <= 64): every lane loads its own sample's operands up front, the two serial recurrences (front
+// to back: running depth maximum and transmittance; back to front: the suffix sum S) then run over wave-uniform values fetched with
+// v_readlane, each lane keeping the step that is its own.  The same operations in the same order as one thread per ray -- which took 56 us
+// for 3 136 rays: 2 x 24 dependent steps, each waiting for its own loads (thirteen workgroups on the whole chip).
+__global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int r = (int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6);
+    if (r >= a.R) return;
+    float4 *dd = reinterpret_cast<float4 *>(a.g_decoded) + (size_t)r * a.SR;
+    if (!a.ray_mask[r]) {
+        if (lane < a.SR) dd[lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    const int ns = a.nsamp ? a.nsamp[r] : a.SR;
+    const bool in = lane < a.SR;
+    // this lane's sample: camera depth, validity, decoded (sigma, rgb)
+    float z_l = 0.f;
+    bool valid_l = false;
+    float4 d_l = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (in) {
+        const float *p = a.loc_w + ((size_t)r * a.SR + lane) * 3;
+        const float q0 = lane < ns ? p[0] : 0.f, q1 = lane < ns ? p[1] : 0.f, q2 = lane < ns ? p[2] : 0.f;
+        const float s0 = __fsub_rn(q0, a.campos[0]), s1 = __fsub_rn(q1, a.campos[1]), s2 = __fsub_rn(q2, a.campos[2]);
+        z_l = __fadd_rn(__fadd_rn(__fmul_rn(a.camrot[2], s0), __fmul_rn(a.camrot[5], s1)), __fmul_rn(a.camrot[8], s2));
+        valid_l = lane < ns && a.pidx[((size_t)r * a.SR + lane) * a.K] >= 0;
+        d_l = reinterpret_cast<const float4 *>(a.decoded)[(size_t)r * a.SR + lane];
+    }
+    const float sig_l = valid_l ? d_l.x : 0.f;
+    auto bc = [&](float v, int s) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), s)); };
+    // pass 1 (front to back, identical to composite_kernel): (opacity, ray_dist * valid, T before the sample) of every sample
+    float T = 1.f, zmax = bc(z_l, 0);
+    float o_l = 0.f, rd_l = 0.f, T_l = 1.f;
+    for (int s = 0; s < a.SR; ++s) {
+        float dist;
+        if (s + 1 < a.SR) {
+            const float zn = fmaxf(zmax, bc(z_l, s + 1));
+            dist = __fsub_rn(zn, zmax);
+            zmax = zn;
+        } else {
+            dist = a.vsize_z;
+        }
+        if (dist < 1e-8f || (a.unit_mode && dist > 2.f * a.vsize_z)) dist = a.vsize_z;
+        const bool valid = __builtin_amdgcn_readlane((int)valid_l, s) != 0;
+        const float sigma = bc(sig_l, s);
+        const float rd = valid ? dist : 0.f;
+        const float o = 1.f - expf(-sigma * rd);
+        if (lane == s) { o_l = o; rd_l = rd; T_l = T; }
+        T *= (1.f - o + 1e-10f);
+    }
+    // pass 2 (back to front).  colour = sum_s w_s rgb_s + bg T_end,  w_s = o_s T_s,  T_s = prod_{j<s} q_j,  q = 1 - o + 1e-10:
+    //   d/d o_s = T_s (rgb_s . g) - (sum_{j>s} w_j (rgb_j . g) + (bg . g) T_end) / q_s
+    const float g0 = a.g_raycolor[3 * (size_t)r], g1 = a.g_raycolor[3 * (size_t)r + 1], g2 = a.g_raycolor[3 * (size_t)r + 2];
+    float S = (a.bg[0] * g0 + a.bg[1] * g1 + a.bg[2] * g2) * T;
+    const float gs_l = d_l.y * g0 + d_l.z * g1 + d_l.w * g2;
+    const float w_l = o_l * T_l;
+    float S_l = 0.f;                                     // S as it stands when the loop reaches this lane's sample
+    for (int s = a.SR - 1; s >= 0; --s) {
+        if (lane == s) S_l = S;
+        S += bc(gs_l, s) * bc(w_l, s);
+    }
+    if (in) {
+        const float q = 1.f - o_l + 1e-10f;
+        const float d_o = T_l * gs_l - S_l / q;
+        const float sigma = rd_l > 0.f ? d_l.x : 0.f;
+        const float d_sigma = d_o * rd_l * expf(-sigma * rd_l);
+        dd[lane] = make_float4(d_sigma, w_l * g0, w_l * g1, w_l * g2);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ final colour
 struct FinalBwdArgs {
     const float *Y; int ldy;
@@ -113,32 +185,34 @@ struct FinalBwdArgs {
     float *gCF; int ldgcf;                               // [S, ldgcf] d colour feature (128 columns, OVERWRITTEN)
     float *g_sigma;                                      // [S]
     float *g_w_fin, *g_b_fin;                            // [3*128], [3]  accumulated with atomics
+    unsigned *gY_max;                                    // optional: max |gY| (bit pattern, atomicMax)
 };
 
-__global__ __launch_bounds__(256) void final_color_bwd_kernel(FinalBwdArgs a)
+__global__ __launch_bounds__(1024) void final_color_bwd_kernel(FinalBwdArgs a)
 {
     const int lane = threadIdx.x & 63;
     const int wave = (int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6);
     const int n_waves = (int)((gridDim.x * (unsigned)blockDim.x) >> 6);
     const int n_valid = (int)a.counts[HNR_CNT_SAMPLES_VALID];
     float aw[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}}, ab[3] = {0.f, 0.f, 0.f};
+    float gy_max = 0.f;
+    float wf[2][3], bf[3];                               // this lane's six weights: loaded once, not per sample
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { wf[0][j] = a.w_fin[j * 128 + lane]; wf[1][j] = a.w_fin[j * 128 + 64 + lane]; bf[j] = a.b_fin[j]; }
     for (int s = wave; s < n_valid; s += n_waves) {
-        float x[2], r[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int c = lane + 64 * h;
-            const float cf = a.CF[(size_t)s * a.ldcf + c];
-            x[h] = c < 45 ? a.Y[(size_t)s * a.ldy + c] + cf : cf;
-#pragma unroll
-            for (int j = 0; j < 3; ++j) r[j] += x[h] * a.w_fin[j * 128 + c];
-        }
+        // every load of the sample is issued before the first use (the upstream gradient is behind an index: its two dependent loads go first)
         const float4 g = reinterpret_cast<const float4 *>(a.g_decoded)[a.vs_item[s]];
+        const float cf0 = a.CF[(size_t)s * a.ldcf + lane], cf1 = a.CF[(size_t)s * a.ldcf + 64 + lane];
+        const float y0 = lane < 45 ? a.Y[(size_t)s * a.ldy + lane] : 0.f;
+        float x[2] = {lane < 45 ? y0 + cf0 : cf0, cf1}, r[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { r[j] = 0.f; r[j] += x[0] * wf[0][j]; r[j] += x[1] * wf[1][j]; }
         const float gc[3] = {g.y, g.z, g.w};
         float dz[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             r[j] = wave_sum(r[j]);
-            const float sg = 1.f / (1.f + expf(-(r[j] + a.b_fin[j])));
+            const float sg = 1.f / (1.f + expf(-(r[j] + bf[j])));
             dz[j] = gc[j] * (1.f + 2.f * 0.001f) * sg * (1.f - sg);
             ab[j] += dz[j];
         }
@@ -148,15 +222,21 @@ __global__ __launch_bounds__(256) void final_color_bwd_kernel(FinalBwdArgs a)
             const int c = lane + 64 * h;
             float dx = 0.f;
 #pragma unroll
-            for (int j = 0; j < 3; ++j) { dx += dz[j] * a.w_fin[j * 128 + c]; aw[h][j] += dz[j] * x[h]; }
+            for (int j = 0; j < 3; ++j) { dx += dz[j] * wf[h][j]; aw[h][j] += dz[j] * x[h]; }
             a.gCF[(size_t)s * a.ldgcf + c] = dx;
-            if (c < 45) a.gY[(size_t)s * a.ldgy + c] = dx;
+            if (c < 45) { a.gY[(size_t)s * a.ldgy + c] = dx; gy_max = fmaxf(gy_max, fabsf(dx)); }
         }
     }
-    // the 4 waves of the block add up in LDS first: one atomic per block and address
-    __shared__ float s_w[4][6][64];
-    __shared__ float s_b[4][3];
+    // the 16 waves of the block add up in LDS first: one atomic per block and address (the atomics of one address retire one per ~23 ns: the
+    // grid is one 16-wave block per CU, not many small ones)
+    __shared__ float s_w[16][6][64];
+    __shared__ float s_b[16][3];
+    __shared__ float s_m[16];
     const int wid = threadIdx.x >> 6;
+    if (a.gY_max) {
+        for (int o = 32; o > 0; o >>= 1) gy_max = fmaxf(gy_max, __shfl_xor(gy_max, o));
+        if (lane == 0) s_m[wid] = gy_max;
+    }
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -165,14 +245,22 @@ __global__ __launch_bounds__(256) void final_color_bwd_kernel(FinalBwdArgs a)
 #pragma unroll
         for (int j = 0; j < 3; ++j) s_b[wid][j] = ab[j];
     __syncthreads();
-    if (wid == 0) {
+    if (wid < 6) {
+        float t = 0.f;
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int w = 0; w < 16; ++w) t += s_w[w][wid][lane];
+        const int h = wid / 3, j = wid - 3 * h;
+        atomicAdd(a.g_w_fin + j * 128 + lane + 64 * h, t);
+    } else if (wid == 6 && lane < 3) {
+        float t = 0.f;
 #pragma unroll
-            for (int j = 0; j < 3; ++j)
-                atomicAdd(a.g_w_fin + j * 128 + lane + 64 * h,
-                          s_w[0][h * 3 + j][lane] + s_w[1][h * 3 + j][lane] + s_w[2][h * 3 + j][lane] + s_w[3][h * 3 + j][lane]);
-        if (lane < 3) atomicAdd(a.g_b_fin + lane, s_b[0][lane] + s_b[1][lane] + s_b[2][lane] + s_b[3][lane]);
+        for (int w = 0; w < 16; ++w) t += s_b[w][lane];
+        atomicAdd(a.g_b_fin + lane, t);
+    } else if (wid == 7 && lane == 0 && a.gY_max) {
+        float m = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) m = fmaxf(m, s_m[w]);
+        absmax_publish(a.gY_max, m);
     }
 }
 
@@ -191,61 +279,80 @@ struct MergeBwdArgs {
     float *gZ3; int ldgz;                                // [V*cap, ldgz] out: d PRE-activation of the last hidden layer (64)
     float *gCF; int ldgcf;                               // [S, ldgcf] += d colfeat[:45]
     float *g_w_last, *g_b_last;                          // [64], [1] atomics
+    unsigned *gZ3_max;                                   // optional: max |gZ3| (bit pattern, atomicMax)
 };
 
 constexpr int MAXV = 8;
 
-__global__ __launch_bounds__(256) void merge_bwd_kernel(MergeBwdArgs a)
+// VT: compile-time bound of the view loops (4: the shipped configurations; MAXV: any a.V <= MAXV, twice the registers)
+template <int VT, int NW>
+__global__ __launch_bounds__(64 * NW) void merge_bwd_kernel(MergeBwdArgs a)
 {
     const int lane = threadIdx.x & 63;
     const int wave = (int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6);
     const int n_waves = (int)((gridDim.x * (unsigned)blockDim.x) >> 6);
     const int n_valid = (int)a.counts[HNR_CNT_SAMPLES_VALID];
     const float wl = a.w_last[lane], bl = a.b_last[0];
-    float acc_w = 0.f, acc_b = 0.f;
+    float acc_w = 0.f, acc_b = 0.f, gz_max = 0.f;
     for (int s = wave; s < n_valid; s += n_waves) {
-        float sg[MAXV], wv[MAXV], f[MAXV], hm[MAXV], scale[MAXV];
+        float sg[VT], wv[VT], f[VT], hm[VT], scale[VT], vm[VT];
         float fsum = 0.f, wsum = 0.f;
+        // all loads of the sample first: with each view's loads behind the previous view's wave reduction an iteration was five dependent
+        // memory round trips (8 us per sample and wave)
+        const bool drop = a.ray_drop && a.ray_drop[a.vs_item[s] / a.SR];
+        const float dm_in = lane < 45 ? a.gX7[(size_t)s * a.ldg7 + 45 + lane] : 0.f;
+        const float gcf_in = lane < 45 ? a.gX7[(size_t)s * a.ldg7 + lane] : 0.f;
 #pragma unroll
-        for (int v = 0; v < MAXV; ++v) {
+        for (int v = 0; v < VT; ++v) {
             if (v >= a.V) break;
             const size_t row = (size_t)v * a.cap + s;
             hm[v] = a.Hm[row * a.ldh + lane];
+            vm[v] = a.vmask[row];
+            f[v] = lane < 45 ? a.X6[row * a.ld6 + lane] : 0.f;
+        }
+#pragma unroll
+        for (int v = 0; v < VT; ++v) {
+            if (v >= a.V) break;
             const float d = wave_sum(hm[v] * wl);
             sg[v] = 1.f / (1.f + expf(-(d + bl)));
-            scale[v] = a.vmask[row] * (a.frame_w ? a.frame_w[v] : 1.f);
-            wv[v] = sg[v] * a.vmask[row];
+            scale[v] = vm[v] * (a.frame_w ? a.frame_w[v] : 1.f);
+            wv[v] = sg[v] * vm[v];
             if (a.frame_w) wv[v] *= a.frame_w[v];
-            f[v] = lane < 45 ? a.X6[row * a.ld6 + lane] : 0.f;
             fsum += f[v] * wv[v];
             wsum += wv[v];
         }
         const float den = wsum + 1e-6f;
         const float merged = fsum / den;
-        const bool drop = a.ray_drop && a.ray_drop[a.vs_item[s] / a.SR];
-        const float dm = (lane < 45 && !drop) ? a.gX7[(size_t)s * a.ldg7 + 45 + lane] : 0.f;
+        const float dm = drop ? 0.f : dm_in;
 #pragma unroll
-        for (int v = 0; v < MAXV; ++v) {
+        for (int v = 0; v < VT; ++v) {
             if (v >= a.V) break;
             const size_t row = (size_t)v * a.cap + s;
             if (lane < 48) a.gF[row * a.ldgf + lane] = dm * wv[v] / den;
             const float d_wv = wave_sum(dm * (f[v] - merged) / den);
             const float d_pre = d_wv * scale[v] * sg[v] * (1.f - sg[v]);
-            a.gZ3[row * a.ldgz + lane] = d_pre * wl * (hm[v] > 0.f ? 1.f : a.slope);
+            const float gz = d_pre * wl * (hm[v] > 0.f ? 1.f : a.slope);
+            a.gZ3[row * a.ldgz + lane] = gz;
+            gz_max = fmaxf(gz_max, fabsf(gz));
             acc_w += d_pre * hm[v];
             acc_b += d_pre;
         }
-        if (lane < 45) a.gCF[(size_t)s * a.ldgcf + lane] += a.gX7[(size_t)s * a.ldg7 + lane];
+        if (lane < 45) a.gCF[(size_t)s * a.ldgcf + lane] += gcf_in;
     }
-    __shared__ float s_w[4][64];
-    __shared__ float s_b[4];
+    __shared__ float s_w[NW][64];
+    __shared__ float s_b[NW], s_m[NW];
     const int wid = threadIdx.x >> 6;
     s_w[wid][lane] = acc_w;
-    if (lane == 0) s_b[wid] = acc_b;
+    for (int o = 32; o > 0; o >>= 1) gz_max = fmaxf(gz_max, __shfl_xor(gz_max, o));
+    if (lane == 0) { s_b[wid] = acc_b; s_m[wid] = gz_max; }
     __syncthreads();
     if (wid == 0) {
-        atomicAdd(a.g_w_last + lane, s_w[0][lane] + s_w[1][lane] + s_w[2][lane] + s_w[3][lane]);
-        if (lane == 0) atomicAdd(a.g_b_last, s_b[0] + s_b[1] + s_b[2] + s_b[3]);
+        float t = 0.f, tb = 0.f, m = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { t += s_w[w][lane]; tb += s_b[w]; m = fmaxf(m, s_m[w]); }
+        atomicAdd(a.g_w_last + lane, t);
+        if (lane == 0) atomicAdd(a.g_b_last, tb);
+        if (lane == 0 && a.gZ3_max) absmax_publish(a.gZ3_max, m);
     }
 }
 
@@ -640,30 +747,72 @@ __global__ __launch_bounds__(256) void point_rows_bwd_kernel(const float *__rest
 }
 
 // ------------------------------------------------------------------------------------------------ small helpers
-// g[m, n] *= (y[m, n] > 0 ? 1 : slope)
-__global__ void dleaky_kernel(float *__restrict__ g, int ldg, const float *__restrict__ y, int ldy, int64_t M, int N, float slope,
-                              const long long *__restrict__ d_n = nullptr)
+// block maximum of |v| -> absmax_publish (hnr_common.h)
+__device__ __forceinline__ void block_absmax(float mx, unsigned *absmax)
 {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t m = t / N;
-    if (d_n && *d_n < M) M = *d_n;
-    if (m >= M) return;
-    const int n = (int)(t - m * N);
-    if (!(y[(size_t)m * ldy + n] > 0.f)) g[(size_t)m * ldg + n] *= slope;
+    __shared__ float s_mx[4];
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0) s_mx[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) absmax_publish(absmax, fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3])));
 }
 
-// out[s, :] = sum_v in[v * cap + s, :]
-__global__ void sum_views_kernel(const float *__restrict__ in, int ldi, int V, int cap, int n_samples, int N, float *__restrict__ out, int ldo,
-                                 const long long *__restrict__ d_n = nullptr)
+// g[m, n] = (g[m, n] + (n < n_add ? add[m, n] : 0)) * (y[m, n] > 0 ? 1 : slope); optionally max |g| -> absmax.  float4 per lane, a fixed grid
+// striding over the rows the device count leaves (one lane per element over the CAPACITY was 125 k workgroups, most of them empty, a 64-bit
+// division per element, and two more launches for the addend and the maximum).
+__global__ __launch_bounds__(256) void dleaky_add_kernel(float *__restrict__ g, int ldg, const float *__restrict__ add, int lda, int n_add, const float *__restrict__ y, int ldy,
+                                                         int64_t M, int N, float slope, const long long *__restrict__ d_n, unsigned *__restrict__ absmax)
 {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t s = t / N;
+    if (d_n && *d_n < M) M = *d_n;
+    const int n4 = N >> 2;
+    float mx = 0.f;
+    // (n4 divides 256 in every use: a thread keeps its column and steps over the rows -- no division in the loop)
+    const bool fixed_col = (256 % n4) == 0;
+    const int64_t t0 = (int64_t)blockIdx.x * 256 + threadIdx.x, m0 = t0 / n4, m_step = fixed_col ? (int64_t)gridDim.x * 256 / n4 : 0;
+    const int c0 = 4 * (int)(t0 - m0 * n4);
+    int64_t it = 0;
+    for (int64_t t = t0; t < M * n4; t += (int64_t)gridDim.x * 256, ++it) {
+        const int64_t m = fixed_col ? m0 + it * m_step : t / n4;
+        const int c = fixed_col ? c0 : 4 * (int)(t - m * n4);
+        float4 v = *reinterpret_cast<const float4 *>(g + (size_t)m * ldg + c);
+        const float4 yy = *reinterpret_cast<const float4 *>(y + (size_t)m * ldy + c);
+        if (add && c < n_add) {
+            const float4 ad = *reinterpret_cast<const float4 *>(add + (size_t)m * lda + c);
+            v.x += ad.x; v.y += c + 1 < n_add ? ad.y : 0.f; v.z += c + 2 < n_add ? ad.z : 0.f; v.w += c + 3 < n_add ? ad.w : 0.f;
+        }
+        if (!(yy.x > 0.f)) v.x *= slope;
+        if (!(yy.y > 0.f)) v.y *= slope;
+        if (!(yy.z > 0.f)) v.z *= slope;
+        if (!(yy.w > 0.f)) v.w *= slope;
+        *reinterpret_cast<float4 *>(g + (size_t)m * ldg + c) = v;
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    if (absmax) block_absmax(mx, absmax);
+}
+
+// out[s, :] = sum_v in[v * cap + s, :]; optionally max |out| -> absmax
+__global__ __launch_bounds__(256) void sum_views_kernel(const float *__restrict__ in, int ldi, int V, int cap, int n_samples, int N, float *__restrict__ out, int ldo,
+                                                        const long long *__restrict__ d_n, unsigned *__restrict__ absmax)
+{
     if (d_n && *d_n < n_samples) n_samples = (int)*d_n;
-    if (s >= n_samples) return;
-    const int n = (int)(t - s * N);
-    float acc = 0.f;
-    for (int v = 0; v < V; ++v) acc += in[((size_t)v * cap + s) * ldi + n];
-    out[(size_t)s * ldo + n] = acc;
+    const int n4 = N >> 2;
+    float mx = 0.f;
+    const bool fixed_col = (256 % n4) == 0;
+    const int64_t t0 = (int64_t)blockIdx.x * 256 + threadIdx.x, s0 = t0 / n4, s_step = fixed_col ? (int64_t)gridDim.x * 256 / n4 : 0;
+    const int c0 = 4 * (int)(t0 - s0 * n4);
+    int64_t it = 0;
+    for (int64_t t = t0; t < (int64_t)n_samples * n4; t += (int64_t)gridDim.x * 256, ++it) {
+        const int64_t s = fixed_col ? s0 + it * s_step : t / n4;
+        const int c = fixed_col ? c0 : 4 * (int)(t - s * n4);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int v = 0; v < V; ++v) {
+            const float4 x = *reinterpret_cast<const float4 *>(in + ((size_t)v * cap + s) * ldi + c);
+            acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+        }
+        *reinterpret_cast<float4 *>(out + (size_t)s * ldo + c) = acc;
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(acc.x), fabsf(acc.y))), fmaxf(fabsf(acc.z), fabsf(acc.w)));
+    }
+    if (absmax) block_absmax(mx, absmax);
 }
 
 // Unique touched points: flags -> exclusive scan (two-level, deterministic) -> compact list + per-row compact index.
@@ -749,10 +898,11 @@ __global__ void map_rows_kernel(const int32_t *__restrict__ row_pid, int64_t M, 
 
 using namespace hnr;
 
+// 16-wave blocks, two per CU at most: the loops are latency-bound (one sample per wave and iteration) and every block ends with one atomic per weight
 static int persistent_blocks(int64_t n_waves_wanted)
 {
-    int64_t b = (n_waves_wanted + 3) / 4;
-    if (b > 512) b = 512;                           // 2 blocks per CU; every block ends with one atomic per weight
+    int64_t b = (n_waves_wanted + 15) / 16;
+    if (b > 512) b = 512;
     if (b < 1) b = 1;
     return (int)b;
 }
@@ -772,7 +922,8 @@ extern "C" int hnr_composite_bwd(const float *d_decoded, const float *d_sample_l
     a.decoded = d_decoded; a.loc_w = d_sample_loc_w; a.pidx = d_sample_pidx; a.ray_mask = d_ray_mask; a.nsamp = d_ray_nsamp;
     a.campos = d_campos; a.camrot = d_camrot; a.bg = d_bg_color; a.R = R; a.SR = SR; a.K = K; a.vsize_z = vsize_z;
     a.unit_mode = raydist_mode_unit; a.g_raycolor = d_g_raycolor; a.g_decoded = d_g_decoded;
-    composite_bwd_kernel<<<cdiv(R, 256), 256, 0, (hipStream_t)stream>>>(a);
+    if (SR <= 64) composite_bwd_kernel<<<cdiv((int64_t)R * 64, 256), 256, 0, (hipStream_t)stream>>>(a);
+    else composite_bwd_serial_kernel<<<cdiv(R, 256), 256, 0, (hipStream_t)stream>>>(a);
     HNR_LAUNCH_CHECK();
     return HNR_OK;
 }
@@ -782,6 +933,16 @@ extern "C" int hnr_final_color_bwd(const float *d_Y, int ldy, const float *d_CF,
                                    float *d_gY, int ldgy, float *d_gCF, int ldgcf, float *d_g_sigma, float *d_g_w_fin, float *d_g_b_fin,
                                    void *stream)
 {
+    return hnr::final_color_bwd_max(d_Y, ldy, d_CF, ldcf, d_w_fin, d_b_fin, d_vs_item, d_counts, cap_samples, d_g_decoded, d_gY, ldgy, d_gCF, ldgcf, d_g_sigma, d_g_w_fin,
+                                    d_g_b_fin, nullptr, stream);
+}
+
+// csrc/render_train.hip: the same, and max |d_gY| into *d_gY_max (atomicMax on the bit pattern; hnr_absmax's convention) -- one launch less
+int hnr::final_color_bwd_max(const float *d_Y, int ldy, const float *d_CF, int ldcf, const float *d_w_fin, const float *d_b_fin,
+                             const int32_t *d_vs_item, const int64_t *d_counts, int cap_samples, const float *d_g_decoded,
+                             float *d_gY, int ldgy, float *d_gCF, int ldgcf, float *d_g_sigma, float *d_g_w_fin, float *d_g_b_fin,
+                             uint32_t *d_gY_max, void *stream)
+{
     if (!d_Y || !d_CF || !d_w_fin || !d_b_fin || !d_vs_item || !d_counts || !d_g_decoded || !d_gY || !d_gCF || !d_g_sigma || !d_g_w_fin ||
         !d_g_b_fin || ldy < 45 || ldcf < 128 || ldgy < 45 || ldgcf < 128) {
         set_error("hnr_final_color_bwd: bad argument"); return HNR_ERR_BADARG;
@@ -790,8 +951,8 @@ extern "C" int hnr_final_color_bwd(const float *d_Y, int ldy, const float *d_CF,
     FinalBwdArgs a;
     a.Y = d_Y; a.ldy = ldy; a.CF = d_CF; a.ldcf = ldcf; a.w_fin = d_w_fin; a.b_fin = d_b_fin; a.vs_item = d_vs_item;
     a.counts = reinterpret_cast<const unsigned long long *>(d_counts); a.g_decoded = d_g_decoded; a.gY = d_gY; a.ldgy = ldgy;
-    a.gCF = d_gCF; a.ldgcf = ldgcf; a.g_sigma = d_g_sigma; a.g_w_fin = d_g_w_fin; a.g_b_fin = d_g_b_fin;
-    final_color_bwd_kernel<<<persistent_blocks(cap_samples), 256, 0, (hipStream_t)stream>>>(a);
+    a.gCF = d_gCF; a.ldgcf = ldgcf; a.g_sigma = d_g_sigma; a.g_w_fin = d_g_w_fin; a.g_b_fin = d_g_b_fin; a.gY_max = d_gY_max;
+    final_color_bwd_kernel<<<persistent_blocks(cap_samples), 1024, 0, (hipStream_t)stream>>>(a);
     HNR_LAUNCH_CHECK();
     return HNR_OK;
 }
@@ -802,6 +963,17 @@ extern "C" int hnr_merge_bwd(const float *d_X6, int ld6, const float *d_Hm, int 
                              float *d_gF, int ldgf, float *d_gZ3, int ldgz, float *d_gCF, int ldgcf, float *d_g_w_last, float *d_g_b_last,
                              void *stream)
 {
+    return hnr::merge_bwd_max(d_X6, ld6, d_Hm, ldh, d_w_last, d_b_last, d_vmask, d_frame_w, d_counts, V, cap_samples, slope, d_ray_drop, d_vs_item, SR, d_gX7, ldg7, d_gF, ldgf,
+                              d_gZ3, ldgz, d_gCF, ldgcf, d_g_w_last, d_g_b_last, nullptr, stream);
+}
+
+// csrc/render_train.hip: the same, and max |d_gZ3| into *d_gZ3_max
+int hnr::merge_bwd_max(const float *d_X6, int ld6, const float *d_Hm, int ldh, const float *d_w_last, const float *d_b_last,
+                       const float *d_vmask, const float *d_frame_w, const int64_t *d_counts, int V, int cap_samples, float slope,
+                       const uint8_t *d_ray_drop, const int32_t *d_vs_item, int SR, const float *d_gX7, int ldg7,
+                       float *d_gF, int ldgf, float *d_gZ3, int ldgz, float *d_gCF, int ldgcf, float *d_g_w_last, float *d_g_b_last,
+                       uint32_t *d_gZ3_max, void *stream)
+{
     if (!d_X6 || !d_Hm || !d_w_last || !d_b_last || !d_vmask || !d_counts || !d_vs_item || !d_gX7 || !d_gF || !d_gZ3 || !d_gCF ||
         !d_g_w_last || !d_g_b_last || V <= 0 || V > MAXV || ldh < 64 || ldg7 < 90 || ldgf < 48 || ldgz < 64 || ldgcf < 45 || SR <= 0) {
         set_error("hnr_merge_bwd: bad argument (V <= %d)", MAXV); return HNR_ERR_BADARG;
@@ -811,8 +983,9 @@ extern "C" int hnr_merge_bwd(const float *d_X6, int ld6, const float *d_Hm, int 
     a.X6 = d_X6; a.ld6 = ld6; a.Hm = d_Hm; a.ldh = ldh; a.w_last = d_w_last; a.b_last = d_b_last; a.vmask = d_vmask; a.frame_w = d_frame_w;
     a.counts = reinterpret_cast<const unsigned long long *>(d_counts); a.V = V; a.cap = cap_samples; a.slope = slope;
     a.ray_drop = d_ray_drop; a.vs_item = d_vs_item; a.SR = SR; a.gX7 = d_gX7; a.ldg7 = ldg7; a.gF = d_gF; a.ldgf = ldgf;
-    a.gZ3 = d_gZ3; a.ldgz = ldgz; a.gCF = d_gCF; a.ldgcf = ldgcf; a.g_w_last = d_g_w_last; a.g_b_last = d_g_b_last;
-    merge_bwd_kernel<<<persistent_blocks(cap_samples), 256, 0, (hipStream_t)stream>>>(a);
+    a.gZ3 = d_gZ3; a.ldgz = ldgz; a.gCF = d_gCF; a.ldgcf = ldgcf; a.g_w_last = d_g_w_last; a.g_b_last = d_g_b_last; a.gZ3_max = d_gZ3_max;
+    if (V <= 4) merge_bwd_kernel<4, 16><<<persistent_blocks(cap_samples), 1024, 0, (hipStream_t)stream>>>(a);
+    else merge_bwd_kernel<MAXV, 4><<<persistent_blocks(cap_samples), 256, 0, (hipStream_t)stream>>>(a);      // (more than 4 views: twice the registers per lane, 4-wave blocks)
     HNR_LAUNCH_CHECK();
     return HNR_OK;
 }
@@ -973,17 +1146,24 @@ int point_rows_bwd_dc(const float *d_gE, int ldg, const float *d_E, int lde, con
     HNR_LAUNCH_CHECK();
     return HNR_OK;
 }
-int dleaky_dc(float *d_g, int ldg, const float *d_y, int ldy, int64_t M_cap, const long long *d_m, int N, float slope, hipStream_t st)
+int dleaky_add_dc(float *d_g, int ldg, const float *d_add, int lda, int n_add, const float *d_y, int ldy, int64_t M_cap, const long long *d_m, int N, float slope,
+                  uint32_t *d_absmax, hipStream_t st)
 {
     if (M_cap <= 0) return HNR_OK;
-    dleaky_kernel<<<cdiv(M_cap * N, 256), 256, 0, st>>>(d_g, ldg, d_y, ldy, M_cap, N, slope, d_m);
+    if ((N & 3) || (ldg & 3) || (ldy & 3) || (d_add && (lda & 3)) || ((uintptr_t)d_g & 15) || ((uintptr_t)d_y & 15) || ((uintptr_t)d_add & 15)) {
+        set_error("dleaky_add: rows must be 16-byte aligned"); return HNR_ERR_BADARG;
+    }
+    int64_t nb = cdiv(M_cap * (N / 4), 256);
+    dleaky_add_kernel<<<(int)(nb < 1024 ? nb : 1024), 256, 0, st>>>(d_g, ldg, d_add, lda, n_add, d_y, ldy, M_cap, N, slope, d_m, d_absmax);
     HNR_LAUNCH_CHECK();
     return HNR_OK;
 }
-int sum_views_dc(const float *d_in, int ldi, int V, int cap, const long long *d_n, int N, float *d_out, int ldo, hipStream_t st)
+int sum_views_dc(const float *d_in, int ldi, int V, int cap, const long long *d_n, int N, float *d_out, int ldo, uint32_t *d_absmax, hipStream_t st)
 {
     if (cap <= 0) return HNR_OK;
-    sum_views_kernel<<<cdiv((int64_t)cap * N, 256), 256, 0, st>>>(d_in, ldi, V, cap, cap, N, d_out, ldo, d_n);
+    if ((N & 3) || (ldi & 3) || (ldo & 3) || ((uintptr_t)d_in & 15) || ((uintptr_t)d_out & 15)) { set_error("sum_views: rows must be 16-byte aligned"); return HNR_ERR_BADARG; }
+    int64_t nb = cdiv((int64_t)cap * (N / 4), 256);
+    sum_views_kernel<<<(int)(nb < 1024 ? nb : 1024), 256, 0, st>>>(d_in, ldi, V, cap, cap, N, d_out, ldo, d_n, d_absmax);
     HNR_LAUNCH_CHECK();
     return HNR_OK;
 }

@@ -46,6 +46,19 @@ struct GridView {
 // floor((p - shift) / size) with fp32 subtract and IEEE fp32 divide, exactly as the reference
 // kernels write it (query_point_indices_worldcoords.py:259-261, :400-402, :465-467).
 // Returns INT_MIN for values that do not fit an int (C leaves that cast undefined).
+// Publishes a kernel's running max |value| (mx >= 0) into a maximum word that per-tensor power-of-two scales are derived from (row_scale_exp
+// reads the EXPONENT only): atomicMax on the bit pattern, skipped when the stored value already has the same or a larger exponent.  The
+// stored word therefore has the exponent of the true maximum, not necessarily its mantissa (hnr_absmax itself stores the exact maximum).
+// Same-address atomics retire one per ~23 ns: thousands of waves each publishing a slightly larger value cost more than the kernel.
+__device__ __forceinline__ void absmax_publish(unsigned *dst, float mx)
+{
+    const unsigned b = __float_as_uint(mx);
+    if (b == 0u) return;
+    // (device-scope relaxed load: served by L2.  The filter only helps publishers that arrive one after another: waves that all finish
+    // at the same moment all read the old value -- publish once per workgroup, from kernels whose workgroups end at different times)
+    if ((b >> 23) > (__hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 23)) atomicMax(dst, b);
+}
+
 __device__ __forceinline__ int cell_coord(float p, float o, float c)
 {
     float d = __fsub_rn(p, o);

@@ -212,16 +212,6 @@ __global__ void train_x7_noviews_kernel(const float *__restrict__ CF, const long
     X7[t] = c < 45 ? CF[s * 128 + c] : 0.f;
 }
 
-// dst[s, c] += src[s, c], c < n_cols, s < *d_s
-__global__ void train_add_cols_kernel(float *__restrict__ dst, int ldd, const float *__restrict__ src, int lds_, int n_cols, const long long *__restrict__ d_s)
-{
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long s = t / n_cols;
-    if (s >= *d_s) return;
-    const int c = (int)(t - s * n_cols);
-    dst[s * ldd + c] += src[s * lds_ + c];
-}
-
 // g_conf[0] += sum of g_conf_out over the EMPTY neighbour slots (they read point 0 through the index clamp).  Two stages, fixed order.
 __global__ __launch_bounds__(256) void train_conf0_partial_kernel(const float *__restrict__ g_conf_out, const int32_t *__restrict__ pidx, long long n, float *__restrict__ part)
 {
@@ -660,9 +650,9 @@ extern "C" int hnr_render_train_backward(const hnr_train_params *p, const hnr_tr
     // ---- 1. composite, 2. final colour
     TR(hnr_composite_bwd(o->d_decoded, o->d_sample_loc_w, o->d_sample_pidx, o->d_ray_mask, nullptr, cam->d_campos, cam->d_camrot, cam->d_bg_color, R, SR, K, p->vsize_z,
                          p->raydist_mode_unit, d_g_raycolor, L.g_dec, stream));
-    TR(hnr_final_color_bwd(L.Y3, 48, L.CF, 128, w->fin_w, w->fin_b, L.vs_item, o->d_counts, cap, L.g_dec, L.gY3, 48, L.gCF, 128, L.g_sigma, g.fin_w, g.fin_b, stream));
+    TR(final_color_bwd_max(L.Y3, 48, L.CF, 128, w->fin_w, w->fin_b, L.vs_item, o->d_counts, cap, L.g_dec, L.gY3, 48, L.gCF, 128, L.g_sigma, g.fin_w, g.fin_b, am + AM_gY3,
+                           stream));
     // ---- 3. mix-up block (its last layer has no activation: gY3 is the gradient of its pre-activation)
-    TR(hnr_absmax(L.gY3, 48, cap, dS, 1, 0, 45, am + AM_gY3, stream));
     TR(wgrad(L.gY3, 48, L.Y2, 48, cap, dS, 1, 0, 45, 45, AM_gY3, AM_Y2, g.mx_w[2], 45, g.mx_b[2]));
     TR(dgrad(L.gY3, 48, cap, dS, 1, 0, IM_MX2T, 45, 45, L.Y2, 48, L.dY2, 48, AM_dY2));
     TR(wgrad(L.dY2, 48, L.Y1, 48, cap, dS, 1, 0, 45, 45, AM_dY2, AM_Y1, g.mx_w[1], 45, g.mx_b[1]));
@@ -672,22 +662,19 @@ extern "C" int hnr_render_train_backward(const hnr_train_params *p, const hnr_tr
     TR(mark());
     if (V > 0) {
         // ---- 4. merge; 5. merge-weight MLP (first layer split: [imgfeat45 | ddir3] per (view, sample) row, colour feature once per sample)
-        TR(hnr_merge_bwd(L.X6, 48, L.M3, 64, w->mw_w[3], w->mw_b[3], L.vmask, vw->d_frame_w, o->d_counts, V, cap, sl, L.ray_drop, L.vs_item, SR, L.gX7, 92, L.gF, 48, L.gZ3m, 64,
-                         L.gCF, 128, g.mw_w[3], g.mw_b[3], stream));
-        TR(hnr_absmax(L.gZ3m, 64, cap, dS, V, cap, 64, am + AM_gZ3m, stream));
+        TR(merge_bwd_max(L.X6, 48, L.M3, 64, w->mw_w[3], w->mw_b[3], L.vmask, vw->d_frame_w, o->d_counts, V, cap, sl, L.ray_drop, L.vs_item, SR, L.gX7, 92, L.gF, 48, L.gZ3m, 64,
+                         L.gCF, 128, g.mw_w[3], g.mw_b[3], am + AM_gZ3m, stream));
         TR(wgrad(L.gZ3m, 64, L.M2, 64, cap, dS, V, cap, 64, 64, AM_gZ3m, AM_M2, g.mw_w[2], 64, g.mw_b[2]));
         TR(dgrad(L.gZ3m, 64, cap, dS, V, cap, IM_MW2T, 64, 64, L.M2, 64, L.dM2, 64, AM_dM2));
         TR(wgrad(L.dM2, 64, L.M1, 64, cap, dS, V, cap, 64, 64, AM_dM2, AM_M1, g.mw_w[1], 64, g.mw_b[1]));
         TR(dgrad(L.dM2, 64, cap, dS, V, cap, IM_MW1T, 64, 64, L.M1, 64, L.dM1, 64, AM_dM1));
         TR(wgrad(L.dM1, 64, L.X6, 48, cap, dS, V, cap, 64, 48, AM_dM1, AM_X6, L.tmpWfd, 48, nullptr));
         train_w0fd_grad_kernel<<<(64 * 48 + 255) / 256, 256, 0, st>>>(L.tmpWfd, g.mw_w[0]);
-        TR(sum_views_dc(L.dM1, 64, V, cap, L.tc + TC_S, 64, L.gpre, 64, st));
-        TR(hnr_absmax(L.gpre, 64, cap, dS, 1, 0, 64, am + AM_gpre, stream));
+        TR(sum_views_dc(L.dM1, 64, V, cap, L.tc + TC_S, 64, L.gpre, 64, am + AM_gpre, st));
         TR(wgrad(L.gpre, 64, L.CF, 128, cap, dS, 1, 0, 64, 128, AM_gpre, AM_CF, g.mw_w[0] + 45, 176, g.mw_b[0]));
         TR(dgrad(L.dM1, 64, cap, dS, V, cap, IM_MW0FDT, 48, 64, nullptr, 0, L.gX6, 48, -1));
         TR(dgrad(L.gpre, 64, cap, dS, 1, 0, IM_MW0CFT, 128, 64, nullptr, 0, L.tmpCF, 128, -1));
-        train_add_cols_kernel<<<cdiv((int64_t)cap * 128, 256), 256, 0, st>>>(L.gCF, 128, L.tmpCF, 128, 128, L.tc + TC_S);
-        TR(mark());
+        TR(mark());                                                      // (tmpCF is added to gCF by stage 7's kernel)
         // ---- 6. pixel gather + upsample + conv pyramid.  Nothing downstream reads this stage's results (the reference-view CNN's weight gradients),
         //      and it is 0.6 ms of small latency-bound kernels: it runs on a side stream of the library beside stages 7 - 11 (forked here, joined
         //      before the call returns; HNR_TRAIN_SIDE=0: in line on the caller's stream)
@@ -706,13 +693,12 @@ extern "C" int hnr_render_train_backward(const hnr_train_params *p, const hnr_tr
         TR(image_features_bwd_bbox(vw->d_images, V, p->H, p->W, w->conv_w, sl, L.fm_scratch, L.g_pyr, g.conv_w, g.conv_b, L.bbox, (void *)s6));
         if (forked) HNR_HIP_CHECK(hipEventRecord(side_join, side_stream));
     } else {
-        train_add_cols_kernel<<<cdiv((int64_t)cap * 45, 256), 256, 0, st>>>(L.gCF, 128, L.gX7, 92, 45, L.tc + TC_S);       // X7 = [colfeat[:45] | 0]
-        TR(mark());
+        TR(mark());                                                      // (X7 = [colfeat[:45] | 0]: gX7[:, :45] is added to gCF by stage 7's kernel)
     }
     TR(mark());
     // ---- 7. colour-feature branch
-    TR(dleaky_dc(L.gCF, 128, L.CF, 128, cap, L.tc + TC_S, 128, sl, st));
-    TR(hnr_absmax(L.gCF, 128, cap, dS, 1, 0, 128, am + AM_gCF, stream));
+    //      gCF = (gCF + d colfeat from the merge-weight MLP's first layer [or, without views, from the mix-up input]) * LeakyReLU'(CF), and its maximum
+    TR(dleaky_add_dc(L.gCF, 128, V > 0 ? L.tmpCF : L.gX7, V > 0 ? 128 : 92, V > 0 ? 128 : 45, L.CF, 128, cap, L.tc + TC_S, 128, sl, am + AM_gCF, st));
     TR(wgrad(L.gCF, 128, L.T2, 128, cap, dS, 1, 0, 128, 128, AM_gCF, AM_T2, g.cf_w[2], 128, g.cf_b[2]));
     TR(dgrad(L.gCF, 128, cap, dS, 1, 0, IM_CF2T, 128, 128, L.T2, 128, L.dT2, 128, AM_dT2));
     TR(wgrad(L.dT2, 128, L.T1, 128, cap, dS, 1, 0, 128, 128, AM_dT2, AM_T1, g.cf_w[1], 128, g.cf_b[1]));
@@ -758,9 +744,8 @@ extern "C" int hnr_render_train_backward(const hnr_train_params *p, const hnr_tr
     TR(wgrad(L.gX3, 264, L.H1, 256, rows, dM, 1, 0, 256, 256, AM_dZ2, AM_H1, g.block1_2_w, 256, g.block1_2_b));
     TR(dgrad(L.gX3, 264, rows, dM, 1, 0, IM_B12T, 256, 256, L.H1, 256, L.dZ1, 256, AM_dZ1));
     TR(wgrad(L.dZ1, 256, L.Xd, 64, rows, dM, 1, 0, 256, 60, AM_dZ1, AM_ONE, g.block1_0_w + 224, 284, g.block1_0_b));
-    TR(segment_sum_rows_csr_dc(L.dZ1, 256, L.row_list, L.seg_start, L.seg_cnt, 256, (int)ucap, L.tc + TC_U, L.gTu, 256, L.G8, 8, 8, L.P8, 8, st));
+    TR(segment_sum_rows_csr_dc(L.dZ1, 256, L.row_list, L.seg_start, L.seg_cnt, 256, (int)ucap, L.tc + TC_U, L.gTu, 256, L.G8, 8, 8, L.P8, 8, am + AM_gTu, st));
     TR(point_small_grads_dc(L.P8, L.ulist, (int)ucap, L.tc + TC_U, gc->d_conf, gc->d_dir, gc->d_color, st));
-    TR(hnr_absmax(L.gTu, 256, ucap, dU, 1, 0, 256, am + AM_gTu, stream));
     TR(hnr_absmax(L.E, 224, ucap, dU, 1, 0, 224, am + AM_E, stream));
     TR(wgrad(L.gTu, 256, L.E, 224, ucap, dU, 1, 0, 256, 224, AM_gTu, AM_E, g.block1_0_w, 284, nullptr));
     TR(dgrad(L.gTu, 256, ucap, dU, 1, 0, IM_TABT, 224, 256, nullptr, 0, L.gE, 224, -1));

@@ -24,8 +24,16 @@ int unique_points_dc(const int32_t *d_row_pid, int64_t M_cap, const long long *d
                      int32_t *d_row_u, int32_t *d_count, int32_t *d_scratch, int32_t *d_seg_start, int32_t *d_seg_count, int32_t *d_row_list, hipStream_t st);
 int point_small_grads_dc(const float *d_P8, const int32_t *d_ulist, int U_cap, const long long *d_u, float *d_g_conf, float *d_g_dir, float *d_g_color, hipStream_t st);
 int point_rows_bwd_dc(const float *d_gE, int ldg, const float *d_E, int lde, const int32_t *d_ids, int n_cap, const long long *d_n, float *d_g_emb, hipStream_t st);
-int dleaky_dc(float *d_g, int ldg, const float *d_y, int ldy, int64_t M_cap, const long long *d_m, int N, float slope, hipStream_t st);
-int sum_views_dc(const float *d_in, int ldi, int V, int cap, const long long *d_n, int N, float *d_out, int ldo, hipStream_t st);
+int final_color_bwd_max(const float *d_Y, int ldy, const float *d_CF, int ldcf, const float *d_w_fin, const float *d_b_fin, const int32_t *d_vs_item,
+                        const int64_t *d_counts, int cap_samples, const float *d_g_decoded, float *d_gY, int ldgy, float *d_gCF, int ldgcf, float *d_g_sigma,
+                        float *d_g_w_fin, float *d_g_b_fin, uint32_t *d_gY_max, void *stream);
+int merge_bwd_max(const float *d_X6, int ld6, const float *d_Hm, int ldh, const float *d_w_last, const float *d_b_last, const float *d_vmask, const float *d_frame_w,
+                  const int64_t *d_counts, int V, int cap_samples, float slope, const uint8_t *d_ray_drop, const int32_t *d_vs_item, int SR, const float *d_gX7,
+                  int ldg7, float *d_gF, int ldgf, float *d_gZ3, int ldgz, float *d_gCF, int ldgcf, float *d_g_w_last, float *d_g_b_last, uint32_t *d_gZ3_max,
+                  void *stream);
+int dleaky_add_dc(float *d_g, int ldg, const float *d_add, int lda, int n_add, const float *d_y, int ldy, int64_t M_cap, const long long *d_m, int N, float slope,
+                  uint32_t *d_absmax, hipStream_t st);
+int sum_views_dc(const float *d_in, int ldi, int V, int cap, const long long *d_n, int N, float *d_out, int ldo, uint32_t *d_absmax, hipStream_t st);
 int image_features_bwd_bbox(const float *d_img, int V, int H, int W, const float *const *conv_w, float slope, const float *d_scratch, float *d_g_pyramid,
                             float *const *g_conv_w, float *const *g_conv_b, const int32_t *d_bbox, void *stream);
 // csrc/segment.hip
@@ -35,6 +43,6 @@ int segment_sum_rows_det_dc(const float *d_A, int lda, const int32_t *d_keys_sor
                             const long long *d_nkeys, const int32_t *d_start, float *d_dst, int64_t dst_stride, hipStream_t st);
 int segment_sum_rows_csr_dc(const float *d_A, int lda, const int32_t *d_row_list, const int32_t *d_seg_start, const int32_t *d_seg_count, int n_cols, int keys_cap,
                             const long long *d_nkeys, float *d_dst, int64_t dst_stride, const float *d_A2, int lda2, int n_cols2, float *d_dst2, int64_t dst_stride2,
-                            hipStream_t st);
+                            uint32_t *d_absmax, hipStream_t st);
 
 }  // namespace hnr
