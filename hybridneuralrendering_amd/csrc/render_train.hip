@@ -394,7 +394,7 @@ int check_params(const hnr_train_params *p, const char *who)
 // HNR_TRAIN_SIDE=0: everything in line on the caller's stream.
 struct TrainSide {
     hipStream_t stream = nullptr, stream_w = nullptr;                     // image branch / clears; weight packs
-    hipEvent_t fork_f = nullptr, join_f = nullptr, fork_b = nullptr, join_b = nullptr, fork_z = nullptr, join_z = nullptr, ev_w[2] = {};
+    hipEvent_t fork_f = nullptr, join_f = nullptr, fork_b = nullptr, join_b = nullptr, fork_z = nullptr, join_z = nullptr, ev_w[3] = {};
     int on = -1;
 };
 // An error return between a fork and its join must not leave side-stream work running on a workspace the caller may free: the guard drains the
@@ -413,9 +413,34 @@ TrainSide &train_side()
                      hipEventCreateWithFlags(&t.join_f, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&t.fork_b, hipEventDisableTiming) != hipSuccess ||
                      hipEventCreateWithFlags(&t.join_b, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&t.fork_z, hipEventDisableTiming) != hipSuccess ||
                      hipEventCreateWithFlags(&t.join_z, hipEventDisableTiming) != hipSuccess || hipStreamCreateWithFlags(&t.stream_w, hipStreamNonBlocking) != hipSuccess)) t.on = 0;
-        for (int i = 0; i < 2 && t.on; ++i) if (hipEventCreateWithFlags(&t.ev_w[i], hipEventDisableTiming) != hipSuccess) t.on = 0;
+        for (int i = 0; i < 3 && t.on; ++i) if (hipEventCreateWithFlags(&t.ev_w[i], hipEventDisableTiming) != hipSuccess) t.on = 0;
     }
     return t;
+}
+
+// Images of the transposed weights for the backward call's input-gradient GEMMs (hnr_h2lin); L.W0fd (the merge-weight MLP's first layer without
+// its colour-feature columns) must have been written on `stream` before.
+static int pack_transposed_images(const Layout &L, const hnr_train_weights *w, int V, void *stream)
+{
+    const float *W[IM_N - 1] = {w->block1_0_w, w->block3_2_w, w->block3_0_w, w->block1_2_w, w->cf_w[2], w->cf_w[1], w->cf_w[0], w->mw_w[2], w->mw_w[1], L.W0fd, w->mw_w[0] + 45,
+                                w->mx_w[2], w->mx_w[1], w->mx_w[0]};
+    //                         IM_TABT [224 <- 256]  B32T  B30T [256 <- 256: the H2 columns]  B12T  CF2T  CF1T  CF0T [256 <- 128]  MW2T  MW1T  MW0FDT [48 <- 64]  MW0CFT [128 <- 64]  MX2T  MX1T  MX0T [90 <- 45]
+    const int64_t rs[IM_N - 1] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
+    const int64_t cs[IM_N - 1] = {284, 256, 263, 256, 128, 128, 280, 64, 64, 48, 176, 45, 45, 90};
+    const int Nn[IM_N - 1] = {224, 256, 256, 256, 128, 128, 256, 64, 64, 48, 128, 45, 45, 90};
+    const int Kk[IM_N - 1] = {256, 256, 256, 256, 128, 128, 128, 64, 64, 64, 64, 45, 45, 45};
+    void *out[IM_N - 1];
+    for (int i = 1; i < IM_N; ++i) out[i - 1] = L.img[i];
+    if (V > 0) TR(hnr_h2lin_pack(IM_N - 1, W, rs, cs, Nn, Kk, nullptr, out, stream));
+    else {
+        // image branch off: no merge-weight layers
+        const float *W2[10] = {W[0], W[1], W[2], W[3], W[4], W[5], W[6], W[11], W[12], W[13]};
+        const int64_t rs2[10] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1}, cs2[10] = {cs[0], cs[1], cs[2], cs[3], cs[4], cs[5], cs[6], cs[11], cs[12], cs[13]};
+        const int N2[10] = {Nn[0], Nn[1], Nn[2], Nn[3], Nn[4], Nn[5], Nn[6], Nn[11], Nn[12], Nn[13]}, K2[10] = {Kk[0], Kk[1], Kk[2], Kk[3], Kk[4], Kk[5], Kk[6], Kk[11], Kk[12], Kk[13]};
+        void *out2[10] = {out[0], out[1], out[2], out[3], out[4], out[5], out[6], out[11], out[12], out[13]};
+        TR(hnr_h2lin_pack(10, W2, rs2, cs2, N2, K2, nullptr, out2, stream));
+    }
+    return HNR_OK;
 }
 
 }  // namespace
@@ -470,6 +495,11 @@ extern "C" int hnr_render_train_forward(const hnr_grid *grid, const hnr_train_pa
         HNR_HIP_CHECK(hipStreamWaitEvent(side.stream_w, side.ev_w[0], 0));
         sp = (void *)side.stream_w;
     }
+    {
+        // per-point table layer: [emb | PE(emb)] W0[:, :224]^T (no bias: block1.0's bias is added per row by the chain kernel); first: it is the first image used
+        const float *W[1] = {w->block1_0_w}; const int64_t rs[1] = {284}, cs[1] = {1}; const int N1[1] = {256}, K1[1] = {224}; void *out[1] = {L.img[IM_TAB]};
+        TR(hnr_h2lin_pack(1, W, rs, cs, N1, K1, nullptr, out, sp));
+    }
     TR(hnr_chain_pack(w->block1_0_w + 224, 284, w->block1_0_b, w->block1_2_w, w->block1_2_b, w->block3_0_w, w->block3_0_b, w->block3_2_w, w->block3_2_b,
                       w->alpha_w, w->alpha_b, L.img_chain, sp));
     const int cfN[4] = {128, 128, 128, 64}, cfK[4] = {280, 128, 128, 128}, cfld[4] = {280, 128, 128, 176};
@@ -489,11 +519,10 @@ extern "C" int hnr_render_train_forward(const hnr_grid *grid, const hnr_train_pa
         TR(hnr_mlp3_pack(3, W, mxld, mxN, mxK, B, L.img_mx, sp));
     }
     if (side.on & 8) HNR_HIP_CHECK(hipEventRecord(side.ev_w[1], side.stream_w));
-    {
-        // per-point table layer: [emb | PE(emb)] W0[:, :224]^T (no bias: block1.0's bias is added per row by the chain kernel)
-        const float *W[1] = {w->block1_0_w}; const int64_t rs[1] = {284}, cs[1] = {1}; const int N1[1] = {256}, K1[1] = {224}; void *out[1] = {L.img[IM_TAB]};
-        TR(hnr_h2lin_pack(1, W, rs, cs, N1, K1, nullptr, out, stream));
-    }
+    // ---- images of the TRANSPOSED weights (the backward call's input-gradient GEMMs): the same weights, so they are packed here, behind the
+    //      forward's own images on the pack stream, instead of at the head of the backward call on the caller's stream (0.07 ms there)
+    TR(pack_transposed_images(L, w, V, sp));
+    if (side.on & 8) HNR_HIP_CHECK(hipEventRecord(side.ev_w[2], side.stream_w));
     TR(mark());
     // ---- query (jittered depths: cam->d_tmid with tmid_stride = D), padded outputs
     hnr_query_params q;
@@ -519,9 +548,9 @@ extern "C" int hnr_render_train_forward(const hnr_grid *grid, const hnr_train_pa
                         L.row_list, st));
     train_ucount_kernel<<<1, 1, 0, st>>>(L.ucount, (long long)L.ucap, L.tc);
     TR(point_rows_dc(cl->d_emb, L.ulist, (int)L.ucap, L.tc + TC_U, L.E, 224, st));
+    if (side.on & 8) HNR_HIP_CHECK(hipStreamWaitEvent(st, side.ev_w[1], 0));    // the forward's weight images are packed
     TR(hnr_h2lin(L.E, 224, (int64_t)L.ucap, dU, 1, 0, L.img[IM_TAB], 256, 224, 0, 0, sl, nullptr, 0, L.Tu, 256, nullptr, stream));
     TR(mark());
-    if (side.on & 8) HNR_HIP_CHECK(hipStreamWaitEvent(st, side.ev_w[1], 0));    // the weight images are packed
     {
         float *H[4] = {L.H1, L.X3, L.H3, L.H4}; const int ldh[4] = {256, 264, 256, 256};
         TR(chain_forward_train(L.chain_ws, L.Tu, 256, L.uidx, L.img_chain, o->d_counts, cap, sl, L.X5, 280, L.sigma, H, ldh, L.amax + AM_H1, L.amax + AM_X5, stream));     // (AM_X5 starts at 1: the direction encoding's columns)
@@ -550,6 +579,7 @@ extern "C" int hnr_render_train_forward(const hnr_grid *grid, const hnr_train_pa
     TR(hnr_composite(o->d_decoded, o->d_sample_loc_w, o->d_sample_pidx, o->d_ray_mask, nullptr, cam->d_campos, cam->d_camrot, cam->d_bg_color, R, SR, K, p->vsize_z,
                      p->raydist_mode_unit, o->d_raycolor, o->d_opacity, o->d_is_background, o->d_blend_weight, stream));
     TR(mark());
+    if (side.on & 8) HNR_HIP_CHECK(hipStreamWaitEvent(st, side.ev_w[2], 0));    // ... and the backward's (long done)
     HNR_LAUNCH_CHECK();
     guard.armed = false;                                             // every fork of this call has been joined
     return HNR_OK;
@@ -615,27 +645,7 @@ extern "C" int hnr_render_train_backward(const hnr_train_params *p, const hnr_tr
         for (int i = nz; i < 24; ++i) { z.p[i] = nullptr; z.n[i] = 0; }
         train_zero_kernel<<<nz, 256, 0, st>>>(z);
     }
-    // ---- images of the transposed weights (input gradients)
-    {
-        const float *W[IM_N - 1] = {w->block1_0_w, w->block3_2_w, w->block3_0_w, w->block1_2_w, w->cf_w[2], w->cf_w[1], w->cf_w[0], w->mw_w[2], w->mw_w[1], L.W0fd, w->mw_w[0] + 45,
-                                    w->mx_w[2], w->mx_w[1], w->mx_w[0]};
-        //                         IM_TABT [224 <- 256]  B32T  B30T [256 <- 256: the H2 columns]  B12T  CF2T  CF1T  CF0T [256 <- 128]  MW2T  MW1T  MW0FDT [48 <- 64]  MW0CFT [128 <- 64]  MX2T  MX1T  MX0T [90 <- 45]
-        const int64_t rs[IM_N - 1] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
-        const int64_t cs[IM_N - 1] = {284, 256, 263, 256, 128, 128, 280, 64, 64, 48, 176, 45, 45, 90};
-        const int Nn[IM_N - 1] = {224, 256, 256, 256, 128, 128, 256, 64, 64, 48, 128, 45, 45, 90};
-        const int Kk[IM_N - 1] = {256, 256, 256, 256, 128, 128, 128, 64, 64, 64, 64, 45, 45, 45};
-        void *out[IM_N - 1];
-        for (int i = 1; i < IM_N; ++i) out[i - 1] = L.img[i];
-        if (V > 0) TR(hnr_h2lin_pack(IM_N - 1, W, rs, cs, Nn, Kk, nullptr, out, stream));
-        else {
-            // image branch off: no merge-weight layers
-            const float *W2[10] = {W[0], W[1], W[2], W[3], W[4], W[5], W[6], W[11], W[12], W[13]};
-            const int64_t rs2[10] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1}, cs2[10] = {cs[0], cs[1], cs[2], cs[3], cs[4], cs[5], cs[6], cs[11], cs[12], cs[13]};
-            const int N2[10] = {Nn[0], Nn[1], Nn[2], Nn[3], Nn[4], Nn[5], Nn[6], Nn[11], Nn[12], Nn[13]}, K2[10] = {Kk[0], Kk[1], Kk[2], Kk[3], Kk[4], Kk[5], Kk[6], Kk[11], Kk[12], Kk[13]};
-            void *out2[10] = {out[0], out[1], out[2], out[3], out[4], out[5], out[6], out[11], out[12], out[13]};
-            TR(hnr_h2lin_pack(10, W2, rs2, cs2, N2, K2, nullptr, out2, stream));
-        }
-    }
+    // (the images of the transposed weights were packed by the forward call: pack_transposed_images)
     // weight gradient of one layer: dW = dZ^T X, db = column sums of dZ
     auto wgrad = [&](const float *dZ, int ldz, const float *X, int ldx, int64_t Mcap, const int64_t *dm, int nseg, int64_t segs, int Nn, int Kk, int amz, int amx,
                      float *dW, int lddw, float *db) -> int {
