@@ -246,7 +246,9 @@ struct KsumPadArgs {
     unsigned *absmax;
 };
 __device__ __forceinline__ float train_wave_sum(float v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); return v; }
-__global__ __launch_bounds__(256) void train_ksum_bwd_kernel(KsumPadArgs a)
+// 16-wave workgroups (the loop is latency-bound -- 16 wave reductions in series per sample -- and every workgroup ends with 257 float atomics on the same
+// addresses: many waves, few workgroups)
+__global__ __launch_bounds__(1024) void train_ksum_bwd_kernel(KsumPadArgs a)
 {
     const int lane = threadIdx.x & 63;
     const int wave = (int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6);
@@ -298,23 +300,22 @@ __global__ __launch_bounds__(256) void train_ksum_bwd_kernel(KsumPadArgs a)
             if (lane == 0) a.g_wagg[row] = gw;
         }
     }
-    __shared__ float4 s_w[4][64];
-    __shared__ float s_b[4];
+    __shared__ float4 s_w[16][64];
+    __shared__ float s_b[16], s_m[16];
     const int wid = threadIdx.x >> 6;
     s_w[wid][lane] = acc;
-    if (lane == 0) s_b[wid] = acc_b;
+    for (int o = 32; o > 0; o >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, o));
+    if (lane == 0) { s_b[wid] = acc_b; s_m[wid] = gmax; }
     __syncthreads();
     if (wid == 0) {
-        const float4 p0 = s_w[0][lane], p1 = s_w[1][lane], p2 = s_w[2][lane], p3 = s_w[3][lane];
-        atomicAdd(a.g_alpha_w + 4 * lane, p0.x + p1.x + p2.x + p3.x); atomicAdd(a.g_alpha_w + 4 * lane + 1, p0.y + p1.y + p2.y + p3.y);
-        atomicAdd(a.g_alpha_w + 4 * lane + 2, p0.z + p1.z + p2.z + p3.z); atomicAdd(a.g_alpha_w + 4 * lane + 3, p0.w + p1.w + p2.w + p3.w);
-        if (lane == 0) atomicAdd(a.g_alpha_b, s_b[0] + s_b[1] + s_b[2] + s_b[3]);
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        float tb = 0.f, m = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { const float4 p = s_w[w][lane]; t.x += p.x; t.y += p.y; t.z += p.z; t.w += p.w; tb += s_b[w]; m = fmaxf(m, s_m[w]); }
+        atomicAdd(a.g_alpha_w + 4 * lane, t.x); atomicAdd(a.g_alpha_w + 4 * lane + 1, t.y);
+        atomicAdd(a.g_alpha_w + 4 * lane + 2, t.z); atomicAdd(a.g_alpha_w + 4 * lane + 3, t.w);
+        if (lane == 0) { atomicAdd(a.g_alpha_b, tb); if (m > 0.f) atomicMax(a.absmax, __float_as_uint(m)); }
     }
-    for (int o = 32; o > 0; o >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, o));
-    __syncthreads();
-    if (lane == 0) s_b[wid] = gmax;
-    __syncthreads();
-    if (threadIdx.x == 0) { gmax = fmaxf(fmaxf(s_b[0], s_b[1]), fmaxf(s_b[2], s_b[3])); if (gmax > 0.f) atomicMax(a.absmax, __float_as_uint(gmax)); }
 }
 
 // gX3[row, 256 + e] = sum_n dZ3[row, n] W30[n, 256 + e], e < 7 (column 263: 0): the gradient of block3's 7 extra inputs (point colour, direction
@@ -723,8 +724,8 @@ extern "C" int hnr_render_train_backward(const hnr_train_params *p, const hnr_tr
         a.H4 = L.H4; a.aux = L.chain_ws + (size_t)blocks_g * 4 * CH_XP_GROUP; a.alpha_w = w->alpha_w; a.alpha_b = w->alpha_b;
         a.counts = reinterpret_cast<const unsigned long long *>(o->d_counts); a.gX5 = L.gX5; a.ldg5 = 256; a.g_sigma = L.g_sigma; a.slope = sl;
         a.gZ4 = L.gZ4; a.g_wagg = L.g_wagg; a.g_alpha_w = g.alpha_w; a.g_alpha_b = g.alpha_b; a.absmax = am + AM_gZ4;
-        int nb = cdiv(cap, 4); if (nb > 512) nb = 512; if (nb < 1) nb = 1;
-        train_ksum_bwd_kernel<<<nb, 256, 0, st>>>(a);
+        int nb = cdiv(cap, 16); if (nb > 512) nb = 512; if (nb < 1) nb = 1;
+        train_ksum_bwd_kernel<<<nb, 1024, 0, st>>>(a);
         HNR_LAUNCH_CHECK();
     }
     TR(mark());
