@@ -576,7 +576,8 @@ int hnr_render_forward(const hnr_grid *grid, const hnr_render_params *p, const h
  * coarse_raycolor [R,3] and (optionally) conf_coefficient [R,SR,K].  Every launch is issued by the library on the caller's stream; every work
  * size (valid samples, neighbour rows, touched points) is read from device counters; nothing is allocated, nothing is read back.
  * K = 8, point_features_dim = 32.  The weights are the raw nn.Linear / nn.Conv2d tensors under the reference's names (their kernel images are
- * re-packed inside each call: they change every step).  Weight gradients are OVERWRITTEN, point gradients too ([N,32] [N] [N,3] [N,3], zero
+ * re-packed every step -- all of them, the backward call's transposed images included, by the FORWARD call: hnr_render_train_backward needs the
+ * forward call of the same step, with the same weights and workspace, to have run, as it does for the stored activations).  Weight gradients are OVERWRITTEN, point gradients too ([N,32] [N] [N,3] [N,3], zero
  * outside the batch's points).  Per-point sums are formed in a fixed order: bit-identical gradients run to run.
  *   d_drop_lut [R] u8 (optional): patch-drop pattern indexed by VALID-ray row (drop_patch_rays, point_aggregators.py:14-23, :1225-1233);
  *   d_ray_drop [R] u8 (optional, wins): explicit per-ray flags (a rank's slice of a batch-wide pattern); both are ANDed with ray_mask.
