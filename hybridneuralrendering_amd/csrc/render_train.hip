@@ -59,7 +59,7 @@ struct Layout {
     float *g_dec, *gY3, *gCF, *g_sigma, *dY2, *dY1, *gX7, *gF, *gZ3m, *dM2, *dM1, *gX6, *gpre, *tmpCF, *tmpWfd, *g_pyr, *g_fm, *dT2, *dT1, *gX5, *gZ4, *g_wagg,
           *dZ3, *gX3, *dZ1, *G8, *P8, *gTu, *gE;
     int32_t *bbox, *key_scratch, *row_list, *seg_cnt, *seg_start;
-    char *sort_scratch, *wg_scratch;
+    char *sort_scratch, *wg_scratch, *wg_scratch2;
     float *conf0;
     size_t sort_bytes, wg_bytes;
     size_t rows_cap, ucap, VS, fm_elems, bytes;
@@ -117,6 +117,7 @@ Layout carve(void *ws, size_t ws_bytes, const hnr_train_params *p, bool *ok)
     L.row_list = c.take<int32_t>(rows); L.seg_cnt = c.take<int32_t>(ucap + 1); L.seg_start = c.take<int32_t>(ucap + 1);
     L.G8 = c.take<float>(rows * 8); L.P8 = c.take<float>(ucap * 8); L.gTu = c.take<float>(ucap * 256); L.gE = c.take<float>(ucap * 224);
     L.wg_bytes = (size_t)hnr_h2wgrad_scratch_bytes(256, 280); L.wg_scratch = c.take<char>(L.wg_bytes);
+    L.wg_scratch2 = c.take<char>((size_t)hnr_h2wgrad_scratch_bytes(128, 280));      // the narrow layers' weight gradients on the side stream
     L.conf0 = c.take<float>(512);
     L.bytes = (c.off + 255) & ~(size_t)255;
     if (ok) *ok = c.ok;
@@ -395,7 +396,7 @@ int check_params(const hnr_train_params *p, const char *who)
 // HNR_TRAIN_SIDE=0: everything in line on the caller's stream.
 struct TrainSide {
     hipStream_t stream = nullptr, stream_w = nullptr;                     // image branch / clears; weight packs
-    hipEvent_t fork_f = nullptr, join_f = nullptr, fork_b = nullptr, join_b = nullptr, fork_z = nullptr, join_z = nullptr, ev_w[3] = {};
+    hipEvent_t fork_f = nullptr, join_f = nullptr, fork_b = nullptr, join_b = nullptr, fork_z = nullptr, join_z = nullptr, fork_g = nullptr, ev_w[3] = {};
     int on = -1;
 };
 // An error return between a fork and its join must not leave side-stream work running on a workspace the caller may free: the guard drains the
@@ -409,11 +410,12 @@ TrainSide &train_side()
     static TrainSide t;
     if (t.on < 0) {
         const char *e = getenv("HNR_TRAIN_SIDE");
-        t.on = e ? atoi(e) : 11;                                         // bit 0: image branch (forward + backward), 1: clears, 3: weight packs
+        t.on = e ? atoi(e) : 15;                                         // bit 0: image branch (forward + backward), 1: clears, 2: the per-sample MLPs' weight gradients, 3: weight packs
         if (t.on && (hipStreamCreateWithFlags(&t.stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&t.fork_f, hipEventDisableTiming) != hipSuccess ||
                      hipEventCreateWithFlags(&t.join_f, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&t.fork_b, hipEventDisableTiming) != hipSuccess ||
                      hipEventCreateWithFlags(&t.join_b, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&t.fork_z, hipEventDisableTiming) != hipSuccess ||
-                     hipEventCreateWithFlags(&t.join_z, hipEventDisableTiming) != hipSuccess || hipStreamCreateWithFlags(&t.stream_w, hipStreamNonBlocking) != hipSuccess)) t.on = 0;
+                     hipEventCreateWithFlags(&t.join_z, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&t.fork_g, hipEventDisableTiming) != hipSuccess ||
+                     hipStreamCreateWithFlags(&t.stream_w, hipStreamNonBlocking) != hipSuccess)) t.on = 0;
         for (int i = 0; i < 3 && t.on; ++i) if (hipEventCreateWithFlags(&t.ev_w[i], hipEventDisableTiming) != hipSuccess) t.on = 0;
     }
     return t;
@@ -652,6 +654,17 @@ extern "C" int hnr_render_train_backward(const hnr_train_params *p, const hnr_tr
                      float *dW, int lddw, float *db) -> int {
         return hnr_h2wgrad(dZ, ldz, X, ldx, Mcap, dm, nseg, segs, Nn, Kk, am + amz, am + amx, dW, lddw, db, 0, L.wg_scratch, stream);
     };
+    // The per-sample MLPs' weight gradients (ten narrow GEMMs + reductions, 0.4 ms) are results nothing in this call reads: they go to the side stream
+    // (the one the image branch's backward runs on: two busy queues, not three), each behind an event recorded after the kernel that wrote its dZ
+    const bool side_g = (side.on & 4) != 0;
+    auto wgrad_n = [&](const float *dZ, int ldz, const float *X, int ldx, int64_t Mcap, const int64_t *dm, int nseg, int64_t segs, int Nn, int Kk, int amz, int amx,
+                       float *dW, int lddw, float *db) -> int {
+        if (!side_g) return wgrad(dZ, ldz, X, ldx, Mcap, dm, nseg, segs, Nn, Kk, amz, amx, dW, lddw, db);
+        HNR_HIP_CHECK(hipEventRecord(side.fork_g, st));
+        HNR_HIP_CHECK(hipStreamWaitEvent(side_stream, side.fork_g, 0));
+        forked = true;
+        return hnr_h2wgrad(dZ, ldz, X, ldx, Mcap, dm, nseg, segs, Nn, Kk, am + amz, am + amx, dW, lddw, db, 0, L.wg_scratch2, (void *)side_stream);
+    };
     // input gradient through a LeakyReLU: out = (dZ W) * LeakyReLU'(side); side == NULL: out = dZ W
     auto dgrad = [&](const float *dZ, int ldz, int64_t Mcap, const int64_t *dm, int nseg, int64_t segs, int im, int Nn, int Kk, const float *side, int lds_, float *out, int ldo,
                      int amo) -> int {
@@ -664,25 +677,25 @@ extern "C" int hnr_render_train_backward(const hnr_train_params *p, const hnr_tr
     TR(final_color_bwd_max(L.Y3, 48, L.CF, 128, w->fin_w, w->fin_b, L.vs_item, o->d_counts, cap, L.g_dec, L.gY3, 48, L.gCF, 128, L.g_sigma, g.fin_w, g.fin_b, am + AM_gY3,
                            stream));
     // ---- 3. mix-up block (its last layer has no activation: gY3 is the gradient of its pre-activation)
-    TR(wgrad(L.gY3, 48, L.Y2, 48, cap, dS, 1, 0, 45, 45, AM_gY3, AM_Y2, g.mx_w[2], 45, g.mx_b[2]));
+    TR(wgrad_n(L.gY3, 48, L.Y2, 48, cap, dS, 1, 0, 45, 45, AM_gY3, AM_Y2, g.mx_w[2], 45, g.mx_b[2]));
     TR(dgrad(L.gY3, 48, cap, dS, 1, 0, IM_MX2T, 45, 45, L.Y2, 48, L.dY2, 48, AM_dY2));
-    TR(wgrad(L.dY2, 48, L.Y1, 48, cap, dS, 1, 0, 45, 45, AM_dY2, AM_Y1, g.mx_w[1], 45, g.mx_b[1]));
+    TR(wgrad_n(L.dY2, 48, L.Y1, 48, cap, dS, 1, 0, 45, 45, AM_dY2, AM_Y1, g.mx_w[1], 45, g.mx_b[1]));
     TR(dgrad(L.dY2, 48, cap, dS, 1, 0, IM_MX1T, 45, 45, L.Y1, 48, L.dY1, 48, AM_dY1));
-    TR(wgrad(L.dY1, 48, L.X7, 92, cap, dS, 1, 0, 45, 90, AM_dY1, AM_X7, g.mx_w[0], 90, g.mx_b[0]));
+    TR(wgrad_n(L.dY1, 48, L.X7, 92, cap, dS, 1, 0, 45, 90, AM_dY1, AM_X7, g.mx_w[0], 90, g.mx_b[0]));
     TR(dgrad(L.dY1, 48, cap, dS, 1, 0, IM_MX0T, 90, 45, nullptr, 0, L.gX7, 92, -1));
     TR(mark());
     if (V > 0) {
         // ---- 4. merge; 5. merge-weight MLP (first layer split: [imgfeat45 | ddir3] per (view, sample) row, colour feature once per sample)
         TR(merge_bwd_max(L.X6, 48, L.M3, 64, w->mw_w[3], w->mw_b[3], L.vmask, vw->d_frame_w, o->d_counts, V, cap, sl, L.ray_drop, L.vs_item, SR, L.gX7, 92, L.gF, 48, L.gZ3m, 64,
                          L.gCF, 128, g.mw_w[3], g.mw_b[3], am + AM_gZ3m, stream));
-        TR(wgrad(L.gZ3m, 64, L.M2, 64, cap, dS, V, cap, 64, 64, AM_gZ3m, AM_M2, g.mw_w[2], 64, g.mw_b[2]));
+        TR(wgrad_n(L.gZ3m, 64, L.M2, 64, cap, dS, V, cap, 64, 64, AM_gZ3m, AM_M2, g.mw_w[2], 64, g.mw_b[2]));
         TR(dgrad(L.gZ3m, 64, cap, dS, V, cap, IM_MW2T, 64, 64, L.M2, 64, L.dM2, 64, AM_dM2));
-        TR(wgrad(L.dM2, 64, L.M1, 64, cap, dS, V, cap, 64, 64, AM_dM2, AM_M1, g.mw_w[1], 64, g.mw_b[1]));
+        TR(wgrad_n(L.dM2, 64, L.M1, 64, cap, dS, V, cap, 64, 64, AM_dM2, AM_M1, g.mw_w[1], 64, g.mw_b[1]));
         TR(dgrad(L.dM2, 64, cap, dS, V, cap, IM_MW1T, 64, 64, L.M1, 64, L.dM1, 64, AM_dM1));
-        TR(wgrad(L.dM1, 64, L.X6, 48, cap, dS, V, cap, 64, 48, AM_dM1, AM_X6, L.tmpWfd, 48, nullptr));
-        train_w0fd_grad_kernel<<<(64 * 48 + 255) / 256, 256, 0, st>>>(L.tmpWfd, g.mw_w[0]);
+        TR(wgrad_n(L.dM1, 64, L.X6, 48, cap, dS, V, cap, 64, 48, AM_dM1, AM_X6, L.tmpWfd, 48, nullptr));
+        train_w0fd_grad_kernel<<<(64 * 48 + 255) / 256, 256, 0, side_g ? side_stream : st>>>(L.tmpWfd, g.mw_w[0]);      // (behind the weight gradient that wrote tmpWfd)
         TR(sum_views_dc(L.dM1, 64, V, cap, L.tc + TC_S, 64, L.gpre, 64, am + AM_gpre, st));
-        TR(wgrad(L.gpre, 64, L.CF, 128, cap, dS, 1, 0, 64, 128, AM_gpre, AM_CF, g.mw_w[0] + 45, 176, g.mw_b[0]));
+        TR(wgrad_n(L.gpre, 64, L.CF, 128, cap, dS, 1, 0, 64, 128, AM_gpre, AM_CF, g.mw_w[0] + 45, 176, g.mw_b[0]));
         TR(dgrad(L.dM1, 64, cap, dS, V, cap, IM_MW0FDT, 48, 64, nullptr, 0, L.gX6, 48, -1));
         TR(dgrad(L.gpre, 64, cap, dS, 1, 0, IM_MW0CFT, 128, 64, nullptr, 0, L.tmpCF, 128, -1));
         TR(mark());                                                      // (tmpCF is added to gCF by stage 7's kernel)
@@ -702,7 +715,6 @@ extern "C" int hnr_render_train_backward(const hnr_train_params *p, const hnr_tr
         TR(hnr_proj_rows_bwd(o->d_sample_loc_w, L.vs_item, o->d_counts, vw->d_w2c, vw->d_intrinsic, V, p->H, p->W, cap, L.gF, 48, L.gX6, 48, L.g_fm, L.bbox, L.g_pyr, L.key_scratch,
                              L.sort_scratch, (int64_t)L.sort_bytes, (void *)s6));
         TR(image_features_bwd_bbox(vw->d_images, V, p->H, p->W, w->conv_w, sl, L.fm_scratch, L.g_pyr, g.conv_w, g.conv_b, L.bbox, (void *)s6));
-        if (forked) HNR_HIP_CHECK(hipEventRecord(side_join, side_stream));
     } else {
         TR(mark());                                                      // (X7 = [colfeat[:45] | 0]: gX7[:, :45] is added to gCF by stage 7's kernel)
     }
@@ -710,11 +722,11 @@ extern "C" int hnr_render_train_backward(const hnr_train_params *p, const hnr_tr
     // ---- 7. colour-feature branch
     //      gCF = (gCF + d colfeat from the merge-weight MLP's first layer [or, without views, from the mix-up input]) * LeakyReLU'(CF), and its maximum
     TR(dleaky_add_dc(L.gCF, 128, V > 0 ? L.tmpCF : L.gX7, V > 0 ? 128 : 92, V > 0 ? 128 : 45, L.CF, 128, cap, L.tc + TC_S, 128, sl, am + AM_gCF, st));
-    TR(wgrad(L.gCF, 128, L.T2, 128, cap, dS, 1, 0, 128, 128, AM_gCF, AM_T2, g.cf_w[2], 128, g.cf_b[2]));
+    TR(wgrad_n(L.gCF, 128, L.T2, 128, cap, dS, 1, 0, 128, 128, AM_gCF, AM_T2, g.cf_w[2], 128, g.cf_b[2]));
     TR(dgrad(L.gCF, 128, cap, dS, 1, 0, IM_CF2T, 128, 128, L.T2, 128, L.dT2, 128, AM_dT2));
-    TR(wgrad(L.dT2, 128, L.T1, 128, cap, dS, 1, 0, 128, 128, AM_dT2, AM_T1, g.cf_w[1], 128, g.cf_b[1]));
+    TR(wgrad_n(L.dT2, 128, L.T1, 128, cap, dS, 1, 0, 128, 128, AM_dT2, AM_T1, g.cf_w[1], 128, g.cf_b[1]));
     TR(dgrad(L.dT2, 128, cap, dS, 1, 0, IM_CF1T, 128, 128, L.T1, 128, L.dT1, 128, AM_dT1));
-    TR(wgrad(L.dT1, 128, L.X5, 280, cap, dS, 1, 0, 128, 280, AM_dT1, AM_X5, g.cf_w[0], 280, g.cf_b[0]));
+    TR(wgrad_n(L.dT1, 128, L.X5, 280, cap, dS, 1, 0, 128, 280, AM_dT1, AM_X5, g.cf_w[0], 280, g.cf_b[0]));
     TR(dgrad(L.dT1, 128, cap, dS, 1, 0, IM_CF0T, 256, 128, nullptr, 0, L.gX5, 256, -1));
     TR(mark());
     // ---- 8. K-sums + alpha branch
@@ -761,7 +773,10 @@ extern "C" int hnr_render_train_backward(const hnr_train_params *p, const hnr_tr
     TR(wgrad(L.gTu, 256, L.E, 224, ucap, dU, 1, 0, 256, 224, AM_gTu, AM_E, g.block1_0_w, 284, nullptr));
     TR(dgrad(L.gTu, 256, ucap, dU, 1, 0, IM_TABT, 224, 256, nullptr, 0, L.gE, 224, -1));
     TR(point_rows_bwd_dc(L.gE, 224, L.E, 224, L.ulist, (int)ucap, L.tc + TC_U, gc->d_emb, st));
-    if (forked) HNR_HIP_CHECK(hipStreamWaitEvent(st, side_join, 0));      // the image-branch stage (side stream) is part of this call
+    if (forked) {                                                          // the side stream's work (image branch, narrow weight gradients) is part of this call
+        HNR_HIP_CHECK(hipEventRecord(side_join, side_stream));
+        HNR_HIP_CHECK(hipStreamWaitEvent(st, side_join, 0));
+    }
     TR(mark());
     HNR_LAUNCH_CHECK();
     guard.armed = false;

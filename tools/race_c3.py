@@ -1,0 +1,53 @@
+"""Run-to-run bit check of the graph-free training step on the bench's C3 batch (3136 rays, 307 k row slots): every gradient that is not an atomic
+sum by design must repeat exactly.  RACE_ITERS steps (default 100)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from hybridneuralrendering_amd import scenes  # noqa: E402
+from hybridneuralrendering_amd.train import TrainPath, train_step  # noqa: E402
+
+sys.argv = [sys.argv[0]]
+args = bench.parse()
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+sc, opt, agg, cloud, rnd, cam = bench.build_world(args, dev, 0)
+opt.is_train = 1
+path = TrainPath(rnd)
+rng = np.random.default_rng(17)
+x0 = int(rng.integers(args.margin, sc.w - args.margin - 56)); y0 = int(rng.integers(args.margin, sc.h - args.margin - 56))
+px, py = np.meshgrid(np.arange(x0, x0 + 56), np.arange(y0, y0 + 56), indexing="ij")
+pix = np.stack([px, py], axis=-1).reshape(-1, 2).astype(np.int32)
+raydir = torch.from_numpy(scenes.camera_rays(pix, sc.intrinsic, sc.c2w)).to(dev)
+gt = torch.rand((raydir.shape[0], 3), device=dev)
+leaves = [t.clone().requires_grad_(True) for t in (cloud.emb, cloud.conf, cloud.dir, cloud.color)]
+for prm in agg.parameters():
+    prm.requires_grad_(True)
+tmid = rnd.querier._tmid_for(float(sc.near), float(sc.far), opt.z_depth_dim, raydir.shape[0], dev)      # ONE jittered depth table for every step (train_step draws a new one otherwise)
+atomic = ("aux_block", "alpha_branch", "color_final", "aux_merge_weight_block.6")
+ref, n_bad = None, 0
+for it in range(int(os.environ.get("RACE_ITERS", "100"))):
+    out, pg, ag = train_step(path, agg, cloud.xyz, leaves[0], leaves[1], leaves[2], leaves[3], raydir, cam["campos"], cam["camrot"], cam["bg"], sc.near, sc.far,
+                             cam["c2w_nearest"], cam["campos_nearest"], cam["intrinsic"], cam["images"], gt, zero_epsilon=1e-3, w_color=1.0, w_zero_one=1e-4,
+                             tmid=tmid, assign_grads=False)
+    cur = {("points." + k): v.clone() for k, v in pg.items()}
+    cur.update({k: v.clone() for k, v in ag.items() if not k.startswith(atomic)})
+    cur["coarse_raycolor"] = out["coarse_raycolor"].clone()
+    torch.cuda.synchronize()
+    if it == 0:
+        first = cur                                   # the first step of a process: compared with the second separately (cold caches / fresh workspace)
+        continue
+    if ref is None:
+        ref = cur
+        bad0 = [k for k in ref if not torch.equal(first[k], ref[k])]
+        print("step 0 vs step 1:", (len(bad0), bad0[:8]) if bad0 else "identical")
+        continue
+    bad = [(k, float((cur[k] - ref[k]).abs().max() / (ref[k].abs().max() + 1e-30)), int((cur[k] != ref[k]).sum())) for k in ref if not torch.equal(cur[k], ref[k])]
+    if bad:
+        n_bad += 1
+        if n_bad <= 5: print("step", it, len(bad), [(b[0], "%.1e" % b[1], b[2]) for b in bad[:6]])
+print("steps (2 ..) with a bit differing from step 1:", n_bad)
