@@ -59,7 +59,7 @@ struct Layout {
     float *g_dec, *gY3, *gCF, *g_sigma, *dY2, *dY1, *gX7, *gF, *gZ3m, *dM2, *dM1, *gX6, *gpre, *tmpCF, *tmpWfd, *g_pyr, *g_fm, *dT2, *dT1, *gX5, *gZ4, *g_wagg,
           *dZ3, *gX3, *dZ1, *G8, *P8, *gTu, *gE;
     int32_t *bbox, *key_scratch, *row_list, *seg_cnt, *seg_start;
-    char *sort_scratch, *wg_scratch, *wg_scratch2;
+    char *sort_scratch, *wg_scratch;
     float *conf0;
     size_t sort_bytes, wg_bytes;
     size_t rows_cap, ucap, VS, fm_elems, bytes;
@@ -117,7 +117,6 @@ Layout carve(void *ws, size_t ws_bytes, const hnr_train_params *p, bool *ok)
     L.row_list = c.take<int32_t>(rows); L.seg_cnt = c.take<int32_t>(ucap + 1); L.seg_start = c.take<int32_t>(ucap + 1);
     L.G8 = c.take<float>(rows * 8); L.P8 = c.take<float>(ucap * 8); L.gTu = c.take<float>(ucap * 256); L.gE = c.take<float>(ucap * 224);
     L.wg_bytes = (size_t)hnr_h2wgrad_scratch_bytes(256, 280); L.wg_scratch = c.take<char>(L.wg_bytes);
-    L.wg_scratch2 = c.take<char>((size_t)hnr_h2wgrad_scratch_bytes(128, 280));      // the narrow layers' weight gradients on the side stream
     L.conf0 = c.take<float>(512);
     L.bytes = (c.off + 255) & ~(size_t)255;
     if (ok) *ok = c.ok;
@@ -410,7 +409,7 @@ TrainSide &train_side()
     static TrainSide t;
     if (t.on < 0) {
         const char *e = getenv("HNR_TRAIN_SIDE");
-        t.on = e ? atoi(e) : 15;                                         // bit 0: image branch (forward + backward), 1: clears, 2: the per-sample MLPs' weight gradients, 3: weight packs
+        t.on = e ? atoi(e) : 15;                                         // bit 0: image branch (forward + backward), 1: clears, 2: weight gradients, 3: weight packs, 4 (opt-in): the image branch's backward on the pack stream
         if (t.on && (hipStreamCreateWithFlags(&t.stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&t.fork_f, hipEventDisableTiming) != hipSuccess ||
                      hipEventCreateWithFlags(&t.join_f, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&t.fork_b, hipEventDisableTiming) != hipSuccess ||
                      hipEventCreateWithFlags(&t.join_b, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&t.fork_z, hipEventDisableTiming) != hipSuccess ||
@@ -622,7 +621,7 @@ extern "C" int hnr_render_train_backward(const hnr_train_params *p, const hnr_tr
     const int side_on = side.on & 1, side_z = side.on & 2;
     hipStream_t side_stream = side.stream;
     hipEvent_t side_fork = side.fork_b, side_join = side.join_b;
-    bool forked = false;
+    bool forked = false, forked6w = false;
 
     // ---- zero what is accumulated into.  The dense point-gradient buffers (312 MB at 2 M points) are first written by the call's last kernels:
     //      cleared on the side stream, waited for before stage 10
@@ -654,8 +653,9 @@ extern "C" int hnr_render_train_backward(const hnr_train_params *p, const hnr_tr
                      float *dW, int lddw, float *db) -> int {
         return hnr_h2wgrad(dZ, ldz, X, ldx, Mcap, dm, nseg, segs, Nn, Kk, am + amz, am + amx, dW, lddw, db, 0, L.wg_scratch, stream);
     };
-    // The per-sample MLPs' weight gradients (ten narrow GEMMs + reductions, 0.4 ms) are results nothing in this call reads: they go to the side stream
-    // (the one the image branch's backward runs on: two busy queues, not three), each behind an event recorded after the kernel that wrote its dZ
+    // The weight gradients (fifteen GEMMs + reductions, 1.5 ms of kernels) are results nothing in this call reads: they go to the side stream (the one the
+    // image branch's backward runs on: two busy queues), each behind an event recorded after the kernel that wrote its dZ; the stream runs them in order,
+    // so they share one partial-sum scratch
     const bool side_g = (side.on & 4) != 0;
     auto wgrad_n = [&](const float *dZ, int ldz, const float *X, int ldx, int64_t Mcap, const int64_t *dm, int nseg, int64_t segs, int Nn, int Kk, int amz, int amx,
                        float *dW, int lddw, float *db) -> int {
@@ -663,7 +663,7 @@ extern "C" int hnr_render_train_backward(const hnr_train_params *p, const hnr_tr
         HNR_HIP_CHECK(hipEventRecord(side.fork_g, st));
         HNR_HIP_CHECK(hipStreamWaitEvent(side_stream, side.fork_g, 0));
         forked = true;
-        return hnr_h2wgrad(dZ, ldz, X, ldx, Mcap, dm, nseg, segs, Nn, Kk, am + amz, am + amx, dW, lddw, db, 0, L.wg_scratch2, (void *)side_stream);
+        return hnr_h2wgrad(dZ, ldz, X, ldx, Mcap, dm, nseg, segs, Nn, Kk, am + amz, am + amx, dW, lddw, db, 0, L.wg_scratch, (void *)side_stream);
     };
     // input gradient through a LeakyReLU: out = (dZ W) * LeakyReLU'(side); side == NULL: out = dZ W
     auto dgrad = [&](const float *dZ, int ldz, int64_t Mcap, const int64_t *dm, int nseg, int64_t segs, int im, int Nn, int Kk, const float *side, int lds_, float *out, int ldo,
@@ -705,9 +705,13 @@ extern "C" int hnr_render_train_backward(const hnr_train_params *p, const hnr_tr
         hipStream_t s6 = st;
         if (side_on) {
             HNR_HIP_CHECK(hipEventRecord(side_fork, st));
-            HNR_HIP_CHECK(hipStreamWaitEvent(side_stream, side_fork, 0));
-            s6 = side_stream;
+            // bit 4 (HNR_TRAIN_SIDE=31, opt-in): the image branch on the pack stream beside the weight gradients' stream -- three busy queues: 4.55 instead of
+            // 4.69 ms per step and 22 000 repeated steps without a differing bit, but an earlier three-queue arrangement produced unexplained run-to-run
+            // differences, so the default keeps two
+            s6 = (side.on & 16) ? side.stream_w : side_stream;
+            HNR_HIP_CHECK(hipStreamWaitEvent(s6, side_fork, 0));
             forked = true;
+            forked6w = (side.on & 16) != 0;
         }
         HNR_HIP_CHECK(hipMemsetAsync(L.g_pyr, 0, L.fm_elems * 4, s6));
         HNR_HIP_CHECK(hipMemsetAsync(L.g_fm, 0, (size_t)V * p->H * p->W * 48 * 4, s6));
@@ -742,9 +746,9 @@ extern "C" int hnr_render_train_backward(const hnr_train_params *p, const hnr_tr
     }
     TR(mark());
     // ---- 9. block3
-    TR(wgrad(L.gZ4, 256, L.H3, 256, rows, dM, 1, 0, 256, 256, AM_gZ4, AM_H3, g.block3_2_w, 256, g.block3_2_b));
+    TR(wgrad_n(L.gZ4, 256, L.H3, 256, rows, dM, 1, 0, 256, 256, AM_gZ4, AM_H3, g.block3_2_w, 256, g.block3_2_b));
     TR(dgrad(L.gZ4, 256, rows, dM, 1, 0, IM_B32T, 256, 256, L.H3, 256, L.dZ3, 256, AM_dZ3));
-    TR(wgrad(L.dZ3, 256, L.X3, 264, rows, dM, 1, 0, 256, 263, AM_dZ3, AM_X3, g.block3_0_w, 263, g.block3_0_b));
+    TR(wgrad_n(L.dZ3, 256, L.X3, 264, rows, dM, 1, 0, 256, 263, AM_dZ3, AM_X3, g.block3_0_w, 263, g.block3_0_b));
     TR(dgrad(L.dZ3, 256, rows, dM, 1, 0, IM_B30T, 256, 256, L.X3, 264, L.gX3, 264, AM_dZ2));
     {
         int nb = cdiv(rows, 16); if (nb > 2048) nb = 2048;
@@ -764,18 +768,19 @@ extern "C" int hnr_render_train_backward(const hnr_train_params *p, const hnr_tr
                                 L.G8, stream));
     TR(mark());                                                      // (the rows' small gradients G8 are summed per point together with block1's rows below)
     // ---- 11. block1 (first layer split: 60 distance columns per row + the per-point table)
-    TR(wgrad(L.gX3, 264, L.H1, 256, rows, dM, 1, 0, 256, 256, AM_dZ2, AM_H1, g.block1_2_w, 256, g.block1_2_b));
+    TR(wgrad_n(L.gX3, 264, L.H1, 256, rows, dM, 1, 0, 256, 256, AM_dZ2, AM_H1, g.block1_2_w, 256, g.block1_2_b));
     TR(dgrad(L.gX3, 264, rows, dM, 1, 0, IM_B12T, 256, 256, L.H1, 256, L.dZ1, 256, AM_dZ1));
-    TR(wgrad(L.dZ1, 256, L.Xd, 64, rows, dM, 1, 0, 256, 60, AM_dZ1, AM_ONE, g.block1_0_w + 224, 284, g.block1_0_b));
+    TR(wgrad_n(L.dZ1, 256, L.Xd, 64, rows, dM, 1, 0, 256, 60, AM_dZ1, AM_ONE, g.block1_0_w + 224, 284, g.block1_0_b));
     TR(segment_sum_rows_csr_dc(L.dZ1, 256, L.row_list, L.seg_start, L.seg_cnt, 256, (int)ucap, L.tc + TC_U, L.gTu, 256, L.G8, 8, 8, L.P8, 8, am + AM_gTu, st));
     TR(point_small_grads_dc(L.P8, L.ulist, (int)ucap, L.tc + TC_U, gc->d_conf, gc->d_dir, gc->d_color, st));
     TR(hnr_absmax(L.E, 224, ucap, dU, 1, 0, 224, am + AM_E, stream));
-    TR(wgrad(L.gTu, 256, L.E, 224, ucap, dU, 1, 0, 256, 224, AM_gTu, AM_E, g.block1_0_w, 284, nullptr));
+    TR(wgrad_n(L.gTu, 256, L.E, 224, ucap, dU, 1, 0, 256, 224, AM_gTu, AM_E, g.block1_0_w, 284, nullptr));
     TR(dgrad(L.gTu, 256, ucap, dU, 1, 0, IM_TABT, 224, 256, nullptr, 0, L.gE, 224, -1));
     TR(point_rows_bwd_dc(L.gE, 224, L.E, 224, L.ulist, (int)ucap, L.tc + TC_U, gc->d_emb, st));
-    if (forked) {                                                          // the side stream's work (image branch, narrow weight gradients) is part of this call
+    if (forked) {                                                          // the side stream's work (image branch, weight gradients) is part of this call
         HNR_HIP_CHECK(hipEventRecord(side_join, side_stream));
         HNR_HIP_CHECK(hipStreamWaitEvent(st, side_join, 0));
+        if (forked6w) { HNR_HIP_CHECK(hipEventRecord(side.ev_w[1], side.stream_w)); HNR_HIP_CHECK(hipStreamWaitEvent(st, side.ev_w[1], 0)); }
     }
     TR(mark());
     HNR_LAUNCH_CHECK();
