@@ -687,17 +687,7 @@ __global__ __launch_bounds__(1024) void chain_plan_scan_kernel(const int32_t *__
 
 using namespace hnr;
 
-static int chain_num_cus()
-{
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-        if (n_cu <= 0) n_cu = 256;
-    }
-    return n_cu;
-}
+static int chain_num_cus() { return device_num_cus(); }
 
 extern "C" int64_t hnr_chain_packed_bytes(void) { return (int64_t)CH_WBYTES + CH_META_FLOATS * 4; }
 
@@ -869,12 +859,11 @@ extern "C" int hnr_chain_forward(const void *d_workspace, const float *d_point_t
     if (rt_mode == 0) { const char *e = getenv("HNR_CHAIN_RT"); rt_mode = (e && atoi(e) == 4) ? 4 : 16; }
     a.skew = 0; a.uidx = nullptr; a.hmax = nullptr; a.x5max = nullptr;
     for (int l = 0; l < 4; ++l) { a.H[l] = nullptr; a.ldh[l] = 0; }
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_once;
+    if (attr_once.first()) {
         HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chain_kernel<4, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, ch_lds_bytes(4)));
         HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chain_kernel<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, ch_lds_bytes(4)));
         HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chain_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, ch_lds_bytes(4)));
-        attr_set = true;
     }
     const int tiles = cdiv(cap_samples, 16), grid = tiles < n_cu ? tiles : n_cu;
     if (rt_mode == 16)                                                      // weight-stationary pipelined kernel (csrc/chain_ws.hip)

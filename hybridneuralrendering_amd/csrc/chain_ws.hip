@@ -445,8 +445,8 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
 
 int launch_chain_ws(const ChainArgs &a, int grid, hipStream_t st, int mode)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_once;
+    if (attr_once.first()) {
         HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chain_ws_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, cw_lds_bytes()));
         HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chain_ws_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, cw_lds_bytes()));
         HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chain_ws_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, cw_lds_bytes()));
@@ -457,7 +457,6 @@ int launch_chain_ws(const ChainArgs &a, int grid, hipStream_t st, int mode)
         HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chain_ws_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, cw_lds_bytes()));
         HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chain_ws_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, cw_lds_bytes()));
 #endif
-        attr_set = true;
     }
 #ifdef HNR_CHAIN_WS_PROBES                                                       // timing probes (results are garbage): make EXTRA=-DHNR_CHAIN_WS_PROBES
     if (mode == 5) chain_ws_kernel<5><<<grid, 256, cw_lds_bytes(), st>>>(a);           // epilogue without its LDS reads

@@ -555,17 +555,7 @@ __global__ __launch_bounds__(256) void h2wgrad_reduce_kernel(const float *__rest
 
 using namespace hnr;
 
-static int h2_num_cus()
-{
-    int dev = 0;
-    static int n_cu[64] = {0};
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-    if (n_cu[dev] == 0) {
-        hipDeviceProp_t prop;
-        n_cu[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-    }
-    return n_cu[dev];
-}
+static int h2_num_cus() { return device_num_cus(); }
 
 extern "C" int64_t hnr_h2lin_packed_bytes(int K)
 {

@@ -46,6 +46,31 @@ struct GridView {
 // floor((p - shift) / size) with fp32 subtract and IEEE fp32 divide, exactly as the reference
 // kernels write it (query_point_indices_worldcoords.py:259-261, :400-402, :465-467).
 // Returns INT_MIN for values that do not fit an int (C leaves that cast undefined).
+// Host-side per-DEVICE caches (hipFuncSetAttribute and the CU count belong to the current device: a process that renders on a second GPU must
+// not reuse the first one's).  Not thread-safe beyond "the same value is written twice".
+inline int device_num_cus()
+{
+    static int n_cu[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (n_cu[dev] == 0) {
+        hipDeviceProp_t prop;
+        n_cu[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    return n_cu[dev];
+}
+struct PerDeviceOnce {          // `static PerDeviceOnce once; if (once.first()) { ... set the kernel attributes ... }`
+    bool done[64] = {};
+    bool first()
+    {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+        if (done[dev]) return false;
+        done[dev] = true;
+        return true;
+    }
+};
+
 // Publishes a kernel's running max |value| (mx >= 0) into a maximum word that per-tensor power-of-two scales are derived from (row_scale_exp
 // reads the EXPONENT only): atomicMax on the bit pattern, skipped when the stored value already has the same or a larger exponent.  The
 // stored word therefore has the exponent of the true maximum, not necessarily its mantissa (hnr_absmax itself stores the exact maximum).

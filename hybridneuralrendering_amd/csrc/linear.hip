@@ -713,13 +713,7 @@ static int linear_launch(const float *d_A, int lda, const float *d_Wp, const flo
     hnr_linear_packed_dims(N, K, &Np, &Kp);
     hipStream_t st = (hipStream_t)stream;
     // persistent workgroups: 2 per CU fit (registers + 2 x LDS double buffers); they stride over the M tiles
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-        if (n_cu <= 0) n_cu = 256;
-    }
+    const int n_cu = device_num_cus();
     const int n_mtiles = cdiv(M, 128);
     static int dbg = -1;
     if (dbg < 0) { const char *e = getenv("HNR_LINEAR_DBG"); dbg = e ? atoi(e) : 0; }

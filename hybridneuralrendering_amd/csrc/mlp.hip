@@ -1197,13 +1197,7 @@ static int mlp3_forward_impl(const float *d_A, int lda, int64_t M_cap, const int
     a.T0 = d_T0; a.ldt0 = ldt0; a.T1 = d_T1; a.ldt1 = ldt1; a.tmax = d_tmax;
     a.loc_w = nullptr; a.vs_item = nullptr; a.w2c = a.Kmat = a.campos = a.campos_n = a.fm = a.frame_w = a.w_last = a.b_last = a.CF = nullptr;
     a.H = a.W = a.ldcf = a.ld7 = 0; a.X7 = nullptr;
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-        if (n_cu <= 0) n_cu = 256;
-    }
+    const int n_cu = device_num_cus();
     hipStream_t st = (hipStream_t)stream;
     // RT_ = row tiles per workgroup tile: 2 (64 rows, two workgroups per CU) where four (128 rows) would leave room for one workgroup only
 #define HNR_MLP3_CASE(S0_, S1_, S2_, S3_, RT_)                                                                                         \
@@ -1214,8 +1208,8 @@ static int mlp3_forward_impl(const float *d_A, int lda, int64_t M_cap, const int
         constexpr int ldsb = smax * (RT_ * 2048 + ML_PAD) + 32 * RT_ * 4 * 4 + 32 * RT_ * 4;                                                       \
         const int64_t tiles = (M_cap + 32 * RT_ - 1) / (32 * RT_);                                                                      \
         const int wgs = mlp3_wgs_per_cu(S0_, RT_, 0) * n_cu, grid = (int)(tiles < wgs ? tiles : wgs);                                              \
-        static bool attr = false;                                                                                                       \
-        if (!attr) { HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(mlp3_kernel<S0_, S1_, S2_, S3_, 0, RT_>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb)); attr = true; } \
+        static PerDeviceOnce attr;                                                                                                      \
+        if (attr.first()) HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(mlp3_kernel<S0_, S1_, S2_, S3_, 0, RT_>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb)); \
         mlp3_kernel<S0_, S1_, S2_, S3_, 0, RT_><<<grid, 256, ldsb, st>>>(a);                                                             \
         mlp3_probe_print(st, n_layers, K[0]);                                                                                          \
         HNR_LAUNCH_CHECK();                                                                                                             \
@@ -1259,13 +1253,7 @@ extern "C" int hnr_merge_stage(const float *d_sample_loc_w, const int32_t *d_vs_
     a.T0 = a.T1 = nullptr; a.ldt0 = a.ldt1 = 0; a.tmax = nullptr;
     a.loc_w = d_sample_loc_w; a.vs_item = d_vs_item; a.w2c = d_w2c; a.Kmat = d_intrinsic; a.campos = d_campos; a.campos_n = d_campos_nearest;
     a.fm = d_featmap; a.H = H; a.W = W; a.frame_w = d_frame_w; a.w_last = d_w_last; a.b_last = d_b_last; a.CF = d_CF; a.ldcf = ldcf; a.X7 = d_X7; a.ld7 = ld7;
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-        if (n_cu <= 0) n_cu = 256;
-    }
+    const int n_cu = device_num_cus();
     // 64-row tiles (16 samples x 4 views), four workgroups per CU: the stage is a chain of dependent memory round trips (sample -> projection ->
     // pixel -> feature rows) and barriers, so it is the number of co-resident workgroups that keeps a CU busy (128-row tiles, two per CU: HNR_MERGE_RT=4)
     static int rt_sel = 0;
@@ -1275,8 +1263,8 @@ extern "C" int hnr_merge_stage(const float *d_sample_loc_w, const int32_t *d_vs_
     if (rt_sel == 1 && wp_ok) {
         const int64_t wtiles = ((int64_t)cap_samples + 7) / 8, wg_tiles = (wtiles + MW_WAVES - 1) / MW_WAVES;
         const int g = (int)(wg_tiles < (int64_t)n_cu ? wg_tiles : (int64_t)n_cu);
-        static bool attr_wp = false;
-        if (!attr_wp) { HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(merge_wp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, MW_LDS)); attr_wp = true; }
+        static PerDeviceOnce attr_wp;
+        if (attr_wp.first()) HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(merge_wp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, MW_LDS));
         merge_wp_kernel<<<g, 64 * MW_WAVES, MW_LDS, (hipStream_t)stream>>>(a);
         HNR_LAUNCH_CHECK();
         return HNR_OK;
@@ -1286,11 +1274,10 @@ extern "C" int hnr_merge_stage(const float *d_sample_loc_w, const int32_t *d_vs_
     const int64_t tiles = ((int64_t)cap_samples * 4 + rows - 1) / rows;
     const int grid = (int)(tiles < (int64_t)wgs * n_cu ? tiles : (int64_t)wgs * n_cu);
     const int ldsb = 4 * (rt_k * 2048 + ML_PAD) + rows * 4 * 4 + rows * 4 + rows * 48 * 4 + 3 * rows * 4 + 128 * 4;
-    static bool attr = false;
-    if (!attr) {
+    static PerDeviceOnce attr;
+    if (attr.first()) {
         HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(mlp3_kernel<3, 4, 4, 0, 1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * ML_SLOT + 128 * 4 * 4 + 128 * 4 + 128 * 48 * 4 + 3 * 128 * 4 + 128 * 4));
         HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(mlp3_kernel<3, 4, 4, 0, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (2 * 2048 + ML_PAD) + 64 * 4 * 4 + 64 * 4 + 64 * 48 * 4 + 3 * 64 * 4 + 128 * 4));
-        attr = true;
     }
     if (rt_k == 4) mlp3_kernel<3, 4, 4, 0, 1, 4><<<grid, 256, ldsb, (hipStream_t)stream>>>(a);
     else mlp3_kernel<3, 4, 4, 0, 1, 2><<<grid, 256, ldsb, (hipStream_t)stream>>>(a);
@@ -1315,17 +1302,11 @@ extern "C" int hnr_mixup_stage(const float *d_X7, int ld7, const void *d_mlp_mx,
     a.X7 = d_X7; a.ld7 = ld7; a.wimg = (const char *)d_mlp_mx; a.CF = d_CF; a.ldcf = ldcf; a.w_fin = d_w_fin; a.b_fin = d_b_fin; a.sigma = d_sigma;
     a.vs_item = d_vs_item; a.counts = reinterpret_cast<const unsigned long long *>(d_counts); a.S_cap = cap_samples; a.slope = slope;
     a.Y = d_Y; a.ldy = ldy; a.decoded = d_decoded;
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-        if (n_cu <= 0) n_cu = 256;
-    }
+    const int n_cu = device_num_cus();
     const int64_t tiles = ((int64_t)cap_samples + 31) / 32, wg_tiles = (tiles + MX_WAVES - 1) / MX_WAVES;
     const int g = (int)(wg_tiles < (int64_t)n_cu ? wg_tiles : (int64_t)n_cu);
-    static bool attr = false;
-    if (!attr) { HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(mixfinal_wp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, MX_LDS)); attr = true; }
+    static PerDeviceOnce attr;
+    if (attr.first()) HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(mixfinal_wp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, MX_LDS));
     mixfinal_wp_kernel<<<g, 64 * MX_WAVES, MX_LDS, (hipStream_t)stream>>>(a);
     HNR_LAUNCH_CHECK();
     return HNR_OK;

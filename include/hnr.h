@@ -12,8 +12,9 @@
  *     reference is always 1 and is dropped;
  *   - the caller owns every buffer; the only internal allocations are the index arrays owned by an
  *     hnr_grid handle and a small per-process scratch of counters;
- *   - ONE PROCESS PER GPU: kernel attributes (large dynamic LDS) and the CU count are set up once per process for the device that is current at
- *     the first launch; a process that renders on several devices is not supported (the multi-GPU path is one rank per GPU over RCCL).
+ *   - ONE PROCESS PER GPU is the supported deployment (the multi-GPU path is one rank per GPU over RCCL): kernel attributes (large dynamic
+ *     LDS) and the CU count are cached per device, but the training calls' side streams and the small per-process scratch belong to the
+ *     device that was current when they were first used.
  *
  * Each entry point cites the reference interface it replaces (paths relative to the reference repo).
  */
