@@ -128,14 +128,15 @@ def render_frame(rnd, cloud, cam, sc, chunk, timers=None, statuses=None):
 
 
 TRAFFIC_JSON = "r03_traffic.json"
+TRAIN_TRAFFIC_JSON = "r03_train_traffic.json"
 CHAIN_PMC_JSON = "r03_chain_pmc.json"
 
 
-def pmc_traffic():
+def pmc_traffic(name=TRAFFIC_JSON):
     """HBM bytes per launch from the rocprofv3 PMC passes kept under profiles/ (FETCH_SIZE / WRITE_SIZE cannot be read
-    from inside the process; the passes are re-collected with tools/collect_traffic.py whenever the kernels change)."""
+    from inside the process; the passes are re-collected with tools/collect_traffic.py / collect_train_traffic.py whenever the kernels change)."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_JSON)))["kernels"]
+        d = json.load(open(os.path.join(ROOT, "profiles", name)))["kernels"]
     except Exception:
         return {}
     return d
@@ -319,9 +320,14 @@ def train_leg(args, sc, opt, agg, cloud, rnd, cam, dev, steps=5, warmup=2):
         e1.record(); torch.cuda.synchronize()
         ms_w = e0.elapsed_time(e1) / 10
         issued = 3.0 * 2.0 * M8 * 256 * 288                                  # 3 fp16 MFMAs per fp32 product, K + 1 (bias column) padded to 9 tiles of 32
+        # HBM bytes of the same kernel inside the step (PMC passes over tools/probe_train.py; only valid for the default C3 batch: 307 120 row slots)
+        t_wg = [v for k, v in pmc_traffic(TRAIN_TRAFFIC_JSON).items() if "h2wgrad_kernel<8, 9" in k] if M8 == 307120 else []
         roof_t = dict(kernel="h2wgrad_kernel<8,9,8,1> + reduce (dW = dZ^T X, db of one 256 x 256 per-neighbour layer; M = %d row slots)" % M8, bound="hbm",
                       achieved=round(M8 * 2048.0 / (ms_w * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(M8 * 2048.0 / (ms_w * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                      traffic=None, avg_launch_ms=round(ms_w, 4), algorithmic_bytes_per_launch=int(M8 * 2048),
+                      traffic=int(t_wg[0]["hbm_bytes"]) if t_wg else None,
+                      traffic_source=("profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE over tools/probe_train.py, bytes per launch: operands + %d KiB of "
+                                      "per-workgroup partial sums)" % (TRAIN_TRAFFIC_JSON, 256 * 288 * 4 * 256 // 1024)) if t_wg else None,
+                      avg_launch_ms=round(ms_w, 4), algorithmic_bytes_per_launch=int(M8 * 2048),
                       mfma_tflops_issued=round(issued / (ms_w * 1e-3) / 1e12, 1), fp32_equivalent_tflops=round(2.0 * M8 * 256 * 256 / (ms_w * 1e-3) / 1e12, 1),
                       note="algorithmic bytes = the two fp32 operands read once (2 KiB per row); the f16x2 MFMA work of this shape (3 x 2 M N K) would take "
                            "%.3f ms at the 2.5 PFLOP/s peak, the operand stream %.3f ms at 8 TB/s: HBM is the nearer roof" % (issued / 2.5e15 * 1e3, M8 * 2048.0 / 8e12 * 1e3)) if M8 > 0 else None
