@@ -558,6 +558,15 @@ extern "C" int hnr_render_train_forward(const hnr_grid *grid, const hnr_train_pa
         TR(chain_forward_train(L.chain_ws, L.Tu, 256, L.uidx, L.img_chain, o->d_counts, cap, sl, L.X5, 280, L.sigma, H, ldh, L.amax + AM_H1, L.amax + AM_X5, stream));     // (AM_X5 starts at 1: the direction encoding's columns)
     }
     TR(mark());
+    // maxima that only the backward call's weight gradients read (per-tensor scales of X6, X7): on the side stream once the image branch is done with it
+    bool fwd_side2 = false;
+    auto absmax_bwd = [&](const float *A, int lda, int nseg, int64_t segs, int Nn, int slot) -> int {
+        if (!(side.on & 1)) return hnr_absmax(A, lda, cap, dS, nseg, segs, Nn, L.amax + slot, stream);
+        HNR_HIP_CHECK(hipEventRecord(side.fork_g, st));
+        HNR_HIP_CHECK(hipStreamWaitEvent(side.stream, side.fork_g, 0));
+        fwd_side2 = true;
+        return hnr_absmax(A, lda, cap, dS, nseg, segs, Nn, L.amax + slot, (void *)side.stream);
+    };
     // ---- per-sample MLPs
     const int act1110[4] = {1, 1, 1, 0}, act111[3] = {1, 1, 1}, act110[3] = {1, 1, 0};
     TR(mlp3_forward_train(L.X5, 280, cap, o->d_counts, HNR_CNT_SAMPLES_VALID, 1, 0, L.img_cf, V > 0 ? 4 : 3, cfN, cfK, act1110, sl, nullptr, nullptr, 0, L.CF, 128,
@@ -566,14 +575,14 @@ extern "C" int hnr_render_train_forward(const hnr_grid *grid, const hnr_train_pa
         if (fwd_forked) HNR_HIP_CHECK(hipStreamWaitEvent(st, side.join_f, 0));      // the feature map is ready
         TR(hnr_proj_rows(o->d_sample_loc_w, L.vs_item, o->d_counts, vw->d_w2c, vw->d_intrinsic, cam->d_campos, vw->d_campos_nearest, L.fm, V, p->H, p->W, L.CF, 128, cap,
                          L.X6, 48, L.vmask, L.row_s, stream));
-        TR(hnr_absmax(L.X6, 48, cap, dS, V, cap, 48, L.amax + AM_X6, stream));
+        TR(absmax_bwd(L.X6, 48, V, cap, 48, AM_X6));
         TR(mlp3_forward_train(L.X6, 48, (int64_t)V * cap, o->d_counts, HNR_CNT_SAMPLES_VALID, V, cap, L.img_mw, 3, mwN, mwK, act111, sl, L.pre, L.row_s, 64, L.M3, 64,
                               nullptr, 0, L.M1, 64, L.M2, 64, L.amax + AM_M1, stream));
         TR(hnr_merge(L.X6, 48, L.M3, 64, w->mw_w[3], w->mw_b[3], L.vmask, vw->d_frame_w, L.CF, 128, o->d_counts, V, cap, L.X7, 92, L.ray_drop, L.vs_item, SR, stream));
     } else {
         train_x7_noviews_kernel<<<cdiv((int64_t)cap * 92, 256), 256, 0, st>>>(L.CF, L.tc + TC_S, L.X7);
     }
-    TR(hnr_absmax(L.X7, 92, cap, dS, 1, 0, 90, L.amax + AM_X7, stream));
+    TR(absmax_bwd(L.X7, 92, 1, 0, 90, AM_X7));
     TR(mlp3_forward_train(L.X7, 92, cap, o->d_counts, HNR_CNT_SAMPLES_VALID, 1, 0, L.img_mx, 3, mxN, mxK, act110, sl, nullptr, nullptr, 0, L.Y3, 48, nullptr, 0,
                           L.Y1, 48, L.Y2, 48, L.amax + AM_Y1, stream));
     TR(mark());
@@ -582,6 +591,7 @@ extern "C" int hnr_render_train_forward(const hnr_grid *grid, const hnr_train_pa
                      p->raydist_mode_unit, o->d_raycolor, o->d_opacity, o->d_is_background, o->d_blend_weight, stream));
     TR(mark());
     if (side.on & 8) HNR_HIP_CHECK(hipStreamWaitEvent(st, side.ev_w[2], 0));    // ... and the backward's (long done)
+    if (fwd_side2) { HNR_HIP_CHECK(hipEventRecord(side.join_f, side.stream)); HNR_HIP_CHECK(hipStreamWaitEvent(st, side.join_f, 0)); }
     HNR_LAUNCH_CHECK();
     guard.armed = false;                                             // every fork of this call has been joined
     return HNR_OK;
@@ -773,7 +783,14 @@ extern "C" int hnr_render_train_backward(const hnr_train_params *p, const hnr_tr
     TR(wgrad_n(L.dZ1, 256, L.Xd, 64, rows, dM, 1, 0, 256, 60, AM_dZ1, AM_ONE, g.block1_0_w + 224, 284, g.block1_0_b));
     TR(segment_sum_rows_csr_dc(L.dZ1, 256, L.row_list, L.seg_start, L.seg_cnt, 256, (int)ucap, L.tc + TC_U, L.gTu, 256, L.G8, 8, 8, L.P8, 8, am + AM_gTu, st));
     TR(point_small_grads_dc(L.P8, L.ulist, (int)ucap, L.tc + TC_U, gc->d_conf, gc->d_dir, gc->d_color, st));
-    TR(hnr_absmax(L.E, 224, ucap, dU, 1, 0, 224, am + AM_E, stream));
+    if (side_g) {                                                          // (max |E| is read by the weight gradient below only: same stream)
+        HNR_HIP_CHECK(hipEventRecord(side.fork_g, st));
+        HNR_HIP_CHECK(hipStreamWaitEvent(side_stream, side.fork_g, 0));
+        forked = true;
+        TR(hnr_absmax(L.E, 224, ucap, dU, 1, 0, 224, am + AM_E, (void *)side_stream));
+    } else {
+        TR(hnr_absmax(L.E, 224, ucap, dU, 1, 0, 224, am + AM_E, stream));
+    }
     TR(wgrad_n(L.gTu, 256, L.E, 224, ucap, dU, 1, 0, 256, 224, AM_gTu, AM_E, g.block1_0_w, 284, nullptr));
     TR(dgrad(L.gTu, 256, ucap, dU, 1, 0, IM_TABT, 224, 256, nullptr, 0, L.gE, 224, -1));
     TR(point_rows_bwd_dc(L.gE, 224, L.E, 224, L.ulist, (int)ucap, L.tc + TC_U, gc->d_emb, st));
