@@ -170,6 +170,7 @@ SIGNATURES = {
     "hnr_image_features_bwd": (_I, [_P, _I, _I, _I, ctypes.POINTER(_P), _F, _P, _P, ctypes.POINTER(_P), ctypes.POINTER(_P), _P]),
     "hnr_gather_rows_bwd_rows": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P]),
     "hnr_segment_sum_rows_det": (_I, [_P, _I, _P, _P, ctypes.c_int64, _I, _I, _P, _P, ctypes.c_int64, _I, _P]),
+    "hnr_segment_sum_rows_csr": (_I, [_P, _I, _P, _P, _P, _I, _I, _P, ctypes.c_int64, _P, _I, _I, _P, ctypes.c_int64, _P, _P]),
     "hnr_probe_select": (_I, [_P, _P, _P, _P, ctypes.POINTER(_F), _P, _P, _I, _I, _I, _F, _F, _P, _P, _P]),
     # training-step dense layers on the 16-bit matrix pipe (csrc/h2gemm.hip)
     "hnr_h2lin_packed_bytes": (ctypes.c_int64, [_I]),

@@ -12,6 +12,7 @@
 #include <rocprim/iterator/counting_iterator.hpp>
 
 #include "hnr_common.h"
+#include "train_internal.h"
 
 namespace hnr {
 
@@ -193,6 +194,22 @@ extern "C" int hnr_segment_sum_rows_det(const float *d_A, int lda, const int32_t
                                                                                                  d_dst, dst_stride, accumulate);
     HNR_LAUNCH_CHECK();
     return HNR_OK;
+}
+
+extern "C" int hnr_segment_sum_rows_csr(const float *d_A, int lda, const int32_t *d_row_list, const int32_t *d_seg_start, const int32_t *d_seg_count,
+                                        int n_cols, int n_keys, float *d_dst, int64_t dst_stride, const float *d_A2, int lda2, int n_cols2,
+                                        float *d_dst2, int64_t dst_stride2, uint32_t *d_absmax, void *stream)
+{
+    if (n_keys < 0 || n_cols <= 0 || n_cols > 256 || (n_cols & 3) || lda < n_cols || (lda & 3) || dst_stride < n_cols || (dst_stride & 3) ||
+        (d_A2 && (n_cols2 <= 0 || n_cols2 > 256 || (n_cols2 & 3) || lda2 < n_cols2 || (lda2 & 3) || dst_stride2 < n_cols2 || (dst_stride2 & 3) || !d_dst2))) {
+        set_error("hnr_segment_sum_rows_csr: bad sizes (column counts multiples of 4, <= 256; strides multiples of 4)"); return HNR_ERR_BADARG;
+    }
+    if (n_keys == 0) return HNR_OK;
+    if (!d_A || !d_row_list || !d_seg_start || !d_seg_count || !d_dst || ((uintptr_t)d_A & 15) || ((uintptr_t)d_dst & 15) || ((uintptr_t)d_A2 & 15) || ((uintptr_t)d_dst2 & 15)) {
+        set_error("hnr_segment_sum_rows_csr: NULL / unaligned argument"); return HNR_ERR_BADARG;
+    }
+    return hnr::segment_sum_rows_csr_dc(d_A, lda, d_row_list, d_seg_start, d_seg_count, n_cols, n_keys, nullptr, d_dst, dst_stride, d_A2, lda2, n_cols2, d_dst2,
+                                        dst_stride2, d_absmax, (hipStream_t)stream);
 }
 
 extern "C" int64_t hnr_sort_rows_scratch_bytes(int64_t M)

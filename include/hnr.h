@@ -475,6 +475,15 @@ int hnr_gather_rows_bwd_rows(const int32_t *d_sample_pidx, const float *d_raydir
  * one wave per key, rows added in sorted (= original row) order, no atomics.  n_cols a multiple of 4, <= 256. */
 int hnr_segment_sum_rows_det(const float *d_A, int lda, const int32_t *d_keys_sorted, const int32_t *d_perm, int64_t M, int n_cols,
                              int n_keys, const int32_t *d_dst_index, float *d_dst, int64_t dst_stride, int accumulate, void *stream);
+/* The form the training step uses (torch autograd's index_add for the point-buffer gradients, models/neural_points/neural_points.py:709-720
+ * transposed): the rows of key k are listed, in ANY order, in d_row_list[d_seg_start[k] .. + d_seg_count[k]) (a point-major list built without a
+ * sort); dst[k, 0:n_cols] = their sum, added in an order that depends on the row indices only (one workgroup per key: row indices rank-sorted
+ * in LDS, four partial sums over the sorted quarters added in wave order) -- bit-identical run to run, no float atomics.  Row indices of a
+ * segment must be distinct.  Optional second matrix d_A2 (n_cols2 <= 256) summed into d_dst2 over the same segments; optional d_absmax:
+ * max |dst| as a float bit pattern with atomicMax (exponent-exact: see csrc/hnr_common.h absmax_publish).  n_cols, n_cols2 multiples of 4. */
+int hnr_segment_sum_rows_csr(const float *d_A, int lda, const int32_t *d_row_list, const int32_t *d_seg_start, const int32_t *d_seg_count,
+                             int n_cols, int n_keys, float *d_dst, int64_t dst_stride, const float *d_A2, int lda2, int n_cols2,
+                             float *d_dst2, int64_t dst_stride2, uint32_t *d_absmax, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Dense layers of the TRAINING step on the 16-bit matrix pipe (csrc/h2gemm.hip), fp32 in / fp32 out, the chain's two-term fp16 split

@@ -262,3 +262,51 @@ def test_train_step_is_bit_identical_run_to_run_with_the_side_streams(tag):
             continue
         bad = [k for k in ref if not torch.equal(cur[k], ref[k])]
         assert not bad, (it, bad)
+
+
+@pytest.mark.parametrize("n_keys,max_rows,n_cols,two", [(300, 40, 256, True), (64, 700, 256, False), (5, 5000, 64, True), (1, 1, 8, False), (2000, 3, 128, True)])
+def test_point_major_segment_sum_equals_index_add(n_keys, max_rows, n_cols, two):
+    """hnr_segment_sum_rows_csr (the training step's per-point sums: a point-major row list in ANY order, no sort) == torch index_add, for segments on
+    every path of the kernel -- up to a few rows, hundreds (rank sort in LDS), and more than 2 048 rows (the repeated-minimum fallback) -- and its
+    optional second matrix and maximum; a second call on a differently shuffled list gives the same bits (the order of the list must not matter)."""
+    from hybridneuralrendering_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(n_keys * 7 + max_rows)
+    cnt = rng.integers(0, max_rows + 1, size=n_keys).astype(np.int32)
+    cnt[rng.integers(0, n_keys)] = max_rows                         # at least one segment of the largest size
+    start = np.concatenate([[0], np.cumsum(cnt)[:-1]]).astype(np.int32)
+    M = int(cnt.sum())
+    rows = rng.permutation(M + 37)[:M].astype(np.int32)              # distinct row indices, arbitrary order inside every segment
+    A = torch.randn((M + 37, n_cols), generator=torch.Generator().manual_seed(1)).cuda()
+    A2 = torch.randn((M + 37, 8), generator=torch.Generator().manual_seed(2)).cuda() if two else None
+    key_of = np.repeat(np.arange(n_keys), cnt)
+    ref = torch.zeros((n_keys, n_cols), dtype=torch.float64).index_add_(0, torch.from_numpy(key_of).long(), A.cpu().double()[rows.astype(np.int64)])
+    ref2 = torch.zeros((n_keys, 8), dtype=torch.float64).index_add_(0, torch.from_numpy(key_of).long(), A2.cpu().double()[rows.astype(np.int64)]) if two else None
+
+    def run(row_list):
+        dst = torch.full((n_keys, n_cols + 4), 9.0, device="cuda")
+        dst2 = torch.full((n_keys, 8), 9.0, device="cuda") if two else None
+        amax = torch.zeros((1,), dtype=torch.int32, device="cuda")
+        rl, st, ct = (torch.from_numpy(x).cuda() for x in (row_list, start, cnt))
+        _lib.check(L.hnr_segment_sum_rows_csr(_lib.ptr(A), n_cols, _lib.ptr(rl), _lib.ptr(st), _lib.ptr(ct), n_cols, n_keys, _lib.ptr(dst), n_cols + 4,
+                                              _lib.ptr(A2) if two else None, 8 if two else 0, 8 if two else 0, _lib.ptr(dst2) if two else None, 8 if two else 0,
+                                              _lib.ptr(amax), _lib.stream()), "hnr_segment_sum_rows_csr")
+        return dst, dst2, amax
+
+    dst, dst2, amax = run(rows)
+    scale = max(1.0, float(ref.abs().max()))
+    assert (dst[:, :n_cols].cpu().double() - ref).abs().max().item() < 2e-6 * scale * max(1, max_rows) ** 0.5
+    assert torch.all(dst[:, n_cols:] == 9.0)
+    if two:
+        assert (dst2.cpu().double() - ref2).abs().max().item() < 2e-6 * max(1.0, float(ref2.abs().max())) * max(1, max_rows) ** 0.5
+    # the published maximum has the exponent of the true one (csrc/hnr_common.h absmax_publish)
+    true_max = float(dst[:, :n_cols].abs().max())
+    got = float(amax.view(torch.float32).item())
+    assert true_max == 0.0 or (got <= true_max and np.frexp(got)[1] == np.frexp(true_max)[1])
+    # any order of a segment's rows gives the same bits
+    shuffled = rows.copy()
+    for k in range(n_keys):
+        seg = shuffled[start[k]:start[k] + cnt[k]]
+        rng.shuffle(seg)
+    d_b, d2_b, _ = run(shuffled)
+    assert torch.equal(d_b, dst) and (not two or torch.equal(d2_b, dst2))
