@@ -661,16 +661,19 @@ __global__ __launch_bounds__(256) void conv3x3_bwd_tile_kernel(ConvTileArgs a)
     }
 }
 template <int CIN, int COUT, int S, int TO, bool DGRAD, bool IN_CL>
-static void conv3x3_bwd_tile_launch(ConvTileArgs a, hipStream_t st)
+static int conv3x3_bwd_tile_launch(ConvTileArgs a, hipStream_t st)
 {
     constexpr int DR = (S == 1) ? TO + 2 : TO + 1, IR = S * TO + ((S == 1) ? 2 : 1), DSTR = (DR * DR) | 1, ISTR = (IR * IR) | 1;
     constexpr int UNITS = (COUT / 3) * CIN, SLICES = 256 / UNITS;
     constexpr size_t lds = sizeof(float) * ((size_t)COUT * DSTR + (size_t)CIN * ISTR + (DGRAD ? 9 * COUT * CIN : 0) + (SLICES > 1 ? (size_t)SLICES * COUT * CIN * 9 : 0));
     static_assert(lds <= 160 * 1024, "tile does not fit the LDS");
     auto kern = conv3x3_bwd_tile_kernel<CIN, COUT, S, TO, DGRAD, IN_CL>;
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return;   // (per device, cheap: set on every launch; a failure shows up as the launch error)
+    static PerDeviceOnce attr;
+    if (attr.first()) HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     a.tiles_x = (a.Wout + TO - 1) / TO; a.tiles_y = (a.Hout + TO - 1) / TO;
     kern<<<a.tiles_x * a.tiles_y * a.V, 256, lds, st>>>(a);
+    HNR_LAUNCH_CHECK();
+    return HNR_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ gather
@@ -1086,12 +1089,12 @@ static int image_features_bwd_impl(const float *d_img, int V, int H, int W, cons
         a.tiles_x = a.tiles_y = 0;
         return a;
     };
-    conv3x3_bwd_tile_launch<24, 24, 1, 8, true, false>(tile(g3, s3, s3a, 0, H3, W3, H3, W3, 5, g3a), st);
-    conv3x3_bwd_tile_launch<12, 24, 2, 8, true, false>(tile(g3a, s3a, s2, 0, H2, W2, H3, W3, 4, g2), st);
-    conv3x3_bwd_tile_launch<12, 12, 1, 16, true, false>(tile(g2, s2, s2a, 0, H2, W2, H2, W2, 3, g2a), st);
-    conv3x3_bwd_tile_launch<6, 12, 2, 16, true, false>(tile(g2a, s2a, s1, 0, H1, W1, H2, W2, 2, g1), st);
-    conv3x3_bwd_tile_launch<6, 6, 1, 16, true, false>(tile(g1, s1, s1a, 0, H1, W1, H1, W1, 1, g1a), st);
-    conv3x3_bwd_tile_launch<3, 6, 2, 16, false, true>(tile(g1a, s1a, d_img, 3, H, W, H1, W1, 0, nullptr), st);
+    { const int rc = conv3x3_bwd_tile_launch<24, 24, 1, 8, true, false>(tile(g3, s3, s3a, 0, H3, W3, H3, W3, 5, g3a), st); if (rc != HNR_OK) return rc; }
+    { const int rc = conv3x3_bwd_tile_launch<12, 24, 2, 8, true, false>(tile(g3a, s3a, s2, 0, H2, W2, H3, W3, 4, g2), st); if (rc != HNR_OK) return rc; }
+    { const int rc = conv3x3_bwd_tile_launch<12, 12, 1, 16, true, false>(tile(g2, s2, s2a, 0, H2, W2, H2, W2, 3, g2a), st); if (rc != HNR_OK) return rc; }
+    { const int rc = conv3x3_bwd_tile_launch<6, 12, 2, 16, true, false>(tile(g2a, s2a, s1, 0, H1, W1, H2, W2, 2, g1), st); if (rc != HNR_OK) return rc; }
+    { const int rc = conv3x3_bwd_tile_launch<6, 6, 1, 16, true, false>(tile(g1, s1, s1a, 0, H1, W1, H1, W1, 1, g1a), st); if (rc != HNR_OK) return rc; }
+    { const int rc = conv3x3_bwd_tile_launch<3, 6, 2, 16, false, true>(tile(g1a, s1a, d_img, 3, H, W, H1, W1, 0, nullptr), st); if (rc != HNR_OK) return rc; }
     HNR_LAUNCH_CHECK();
     return HNR_OK;
 }
