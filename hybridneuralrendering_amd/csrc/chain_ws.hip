@@ -14,6 +14,18 @@
 //     layer-0 operand image).
 // The next layer's weights are fetched into a k step's registers as soon as the last pass of the layer has used them, the per-point
 // table rows of layer 0 one pass ahead.  One barrier per pass; the MFMA stream never waits for an epilogue.
+//
+// Load schedule (round 4).  `s_waitcnt vmcnt(N)` counts in issue order, and the compiler's waits for its own loads know nothing of the asm
+// loads queued between them: every wait that lands behind a FRESH load stalls the wave (and with it the matrix pipe) for a full L2 / HBM
+// latency.  The per-pass clocks showed exactly that (pass (0,0) 7.0 k cycles for 24 MFMAs, the other layer-0 passes 3.5 k): so
+//   * block1.2's k steps 4..15 are fetched during pass (3,3) (layer 0 only occupies register blocks 0..3), not during the short layer-0
+//     passes whose epilogues consume the table rows; block1.2 runs its k steps in the order 8..15, 0..7, so that the four blocks that can
+//     only be fetched during pass (0,3) are used half a pass later (every row tile uses the same order: results do not depend on the slot);
+//   * the next tile's layer-0 operand image goes global -> LDS by DMA (no registers, no wait inside a pass: issued after the barrier of the
+//     pass that read the region last, waited for -- by count -- before the barrier two or three passes later);
+//   * block3.0's 17th k step (VGPRs) is fetched once per tile, the next tile's point ids two passes before its table rows are asked for;
+//   * nothing inside a pass is conditional on "is there a next tile" (the last tile re-fetches its own data): no branches, so the
+//     compiler cannot sink an epilogue piece past the MFMAs it was placed between.
 #include <utility>
 
 #include "chain_defs.h"
@@ -50,15 +62,118 @@ template <int K> __device__ __forceinline__ void cw_wait_vm() { asm volatile("s_
 // LDS traffic of this wave complete, then rendezvous -- no vmcnt wait (weight / table loads stay in flight across it)
 __device__ __forceinline__ void cw_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// the layer-0 operand image of one row tile: two 1-KiB chunks per wave, global -> LDS (lane l's 16 B land at M0 + 16 l)
+__device__ __forceinline__ void cw_dma_image(const char *g0, const char *g1, int voff, unsigned lds0, unsigned lds1)
+{
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt\n\t"
+                 "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2 nt" :: "v"(voff), "s"(g0), "s"(g1), "s"(lds0), "s"(lds1) : "memory");
+}
+
+// Per-point table rows (layer 0's addend).  A lane (h, j) needs 16 consecutive floats of row j per column tile; fetched that way (four 16-B loads
+// per lane and column tile) the four lanes of a quad hit four different rows in every instruction, and the CU's vector-memory front end spends one
+// cycle per (quad, cache line): 64 per instruction, 2.1 k cycles per row tile for the four waves -- what the layer-0 passes were bound by
+// (tools/gather_probe.hip: 2146 cycles per row tile that way against 696 when a quad reads 64 contiguous bytes).  So instruction r of a column tile
+// reads row (j & ~3) + r for the whole quad, lane t = j & 3 taking piece r ^ t of its 64 bytes, and the 4 x 4 transpose happens in registers: first
+// inside each lane (slot d <- register t ^ d: two exec-masked rounds of v_swap_b32), then across the lanes for free -- piece p of the lane's own row
+// now sits in slot p of lane t ^ p, and the epilogue's `bias + table` add reads it through DPP (quad_perm = xor p).
+__device__ __forceinline__ void cw_table_swap(float4 &r0, float4 &r1, float4 &r2, float4 &r3)
+{
+    unsigned long long keep;
+    asm volatile("s_mov_b64 %16, exec\n\ts_mov_b32 exec_lo, 0xaaaaaaaa\n\ts_mov_b32 exec_hi, 0xaaaaaaaa\n\t"
+                 "v_swap_b32 %0, %4\n\tv_swap_b32 %1, %5\n\tv_swap_b32 %2, %6\n\tv_swap_b32 %3, %7\n\t"
+                 "v_swap_b32 %8, %12\n\tv_swap_b32 %9, %13\n\tv_swap_b32 %10, %14\n\tv_swap_b32 %11, %15\n\t"
+                 "s_mov_b32 exec_lo, 0xcccccccc\n\ts_mov_b32 exec_hi, 0xcccccccc\n\t"
+                 "v_swap_b32 %0, %8\n\tv_swap_b32 %1, %9\n\tv_swap_b32 %2, %10\n\tv_swap_b32 %3, %11\n\t"
+                 "v_swap_b32 %4, %12\n\tv_swap_b32 %5, %13\n\tv_swap_b32 %6, %14\n\tv_swap_b32 %7, %15\n\t"
+                 "s_mov_b64 exec, %16\n\ts_nop 1"
+                 : "+v"(r0.x), "+v"(r0.y), "+v"(r0.z), "+v"(r0.w), "+v"(r1.x), "+v"(r1.y), "+v"(r1.z), "+v"(r1.w),
+                   "+v"(r2.x), "+v"(r2.y), "+v"(r2.z), "+v"(r2.w), "+v"(r3.x), "+v"(r3.y), "+v"(r3.z), "+v"(r3.w), "=&s"(keep));
+}
+template <int P> __device__ __forceinline__ float cw_table_add(float t, float b)      // b + (slot-P value of lane t ^ P): fp32 add, either operand order
+{
+    float r;
+    if constexpr (P == 0) r = __fadd_rn(b, t);
+    else if constexpr (P == 1) asm("v_add_f32_dpp %0, %1, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(t), "v"(b));
+    else if constexpr (P == 2) asm("v_add_f32_dpp %0, %1, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(t), "v"(b));
+    else asm("v_add_f32_dpp %0, %1, %2 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(t), "v"(b));
+    return r;
+}
+
 // compile-time loops: the pass / k step / piece indices must be constants at every use (register arrays, asm operands), and the body is too
 // large for `#pragma unroll` to accept
 template <class F, int... Is> __device__ __forceinline__ void cw_static_seq(F &&f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
 template <int N, class F> __device__ __forceinline__ void cw_static_for(F &&f) { cw_static_seq(f, std::make_integer_sequence<int, N>{}); }
 
 constexpr int cw_steps(int L) { return L == 0 ? CH_S0 : L == 1 ? CH_S1 : L == 2 ? CH_S2 : CH_S3; }
+constexpr int cw_korder(int L, int i) { return L == 1 ? ((i + 8) & 15) : i; }     // k step of a pass's i-th iteration (see "Load schedule")
 constexpr int cw_wbase(int L) { return L == 0 ? CH_W0 : L == 1 ? CH_W1 : L == 2 ? CH_W2 : CH_W3; }
 constexpr int cw_goff(int P) { int g = 0; for (int p = 0; p < P; ++p) g += cw_steps(p >> 2); return g; }     // k steps of the tile before pass P
 constexpr int CW_GTOT = cw_goff(16);
+
+// ---- the weight stream's static schedule.  A layer's 256 KiB of fragments pass the CU's vector-memory front end at 64 B / clock: 4.1 k
+// cycles -- more than a pass's 3.1 k cycles of MFMAs, so a pass that fetches a whole layer (as passes (1,3), (2,3), (3,3) did) is bound by
+// the fetch (4.1 - 4.3 k cycles even without any epilogue).  A register block can be refilled any time between its last use by the layer's last
+// pass and its first use one pass later, so half of each layer is fetched during the NEXT layer's first pass, and block1.2's twelve blocks
+// that layer 0 does not occupy during the four short layer-0 passes (second halves: the first halves consume the table rows, and a wait for
+// those would also wait for any younger load).  cw_issue(P, slot): the block (layer * 32 + k step) fetched behind MFMA `slot` of pass P, or -1.
+constexpr int cw_issue(int P, int slot)
+{
+    const int L = P >> 2, rt = P & 3;
+    if (L == 0) {                                                          // block1.2: 8..11, 12..15, 4..7 (any time), 0..3 (once pass (0,3) has used them)
+        if (rt < 3) { const int k = slot == 13 ? 0 : slot == 16 ? 1 : slot == 19 ? 2 : slot == 22 ? 3 : -1; return k < 0 ? -1 : 32 + (rt == 0 ? 8 : rt == 1 ? 12 : 4) + k; }
+        return slot == 12 ? 32 + 0 : slot == 14 ? 32 + 1 : slot == 17 ? 32 + 2 : slot == 23 ? 32 + 3 : -1;
+    }
+    if (slot % 6 != 5) return -1;
+    const int it = slot / 6;
+    if (P == 7) {                                                          // block3.0 (block1.2 runs k steps 8..15, 0..7: block b is free after iteration (b + 8) & 15)
+        const int t[16] = {-1, -1, 8, -1, -1, 9, -1, -1, 0, 1, -1, 2, 3, -1, 4, 5};
+        return t[it] < 0 ? -1 : 64 + t[it];
+    }
+    if (P == 8) { const int t[17] = {6, 7, 10, 11, -1, 12, -1, 13, -1, 14, 15, -1, -1, -1, -1, -1, -1}; return t[it] < 0 ? -1 : 64 + t[it]; }
+    if (P == 11) return (it & 1) && it < 16 ? 96 + (it >> 1) : -1;          // block3.2: 0..7 behind iterations 1, 3, .., 15
+    if (P == 12) { const int t[16] = {8, 9, 10, -1, 11, 12, -1, 13, 14, -1, 15, -1, -1, -1, -1, -1}; return t[it] < 0 ? -1 : 96 + t[it]; }
+    if (P == 15) return it < 4 ? it : -1;                                   // layer 0's four k steps
+    return -1;
+}
+// time stamps in program order: (pass, slot, phase) with phase 0 = the barrier's DMA, 1 = the wait in front of the MFMA, 2 = the fetch behind it
+constexpr int cw_stamp(int P, int slot, int ph) { return (P * 128 + slot) * 4 + ph; }
+constexpr int CW_TILE_STAMPS = 16 * 128 * 4;
+// asm loads (weight fetches: 4 each; image DMAs behind the barriers of passes (3, 0..3): 2 each) with a time stamp in (t0, t1); stamps of the previous
+// tile are the same minus CW_TILE_STAMPS.  Only asm loads count: the compiler's loads and stores between them make the true number of operations
+// in flight larger, so a wait derived from this count is conservative.
+constexpr int cw_asm_between(int t0, int t1)
+{
+    int n = 0;
+    for (int wrap = -1; wrap <= 0; ++wrap)
+        for (int Q = 0; Q < 16; ++Q)
+            for (int sl = 0; sl < 6 * cw_steps(Q >> 2); ++sl) {
+                if (cw_issue(Q, sl) >= 0) { const int t = cw_stamp(Q, sl, 2) + wrap * CW_TILE_STAMPS; if (t > t0 && t < t1) n += 4; }
+                if ((Q >> 2) == 3 && sl == 3 * cw_steps(3)) { const int t = cw_stamp(Q, sl, 0) + wrap * CW_TILE_STAMPS; if (t > t0 && t < t1) n += 2; }
+            }
+    return n;
+}
+// what `s_waitcnt vmcnt` may leave in flight in front of the MFMA (P, slot) that needs block `blk`: the asm loads issued after the block's own
+constexpr int cw_need_count(int blk, int P, int slot)
+{
+    const int t_need = cw_stamp(P, slot, 1);
+    int t_blk = -2 * CW_TILE_STAMPS;
+    for (int wrap = -1; wrap <= 0; ++wrap)
+        for (int Q = 0; Q < 16; ++Q)
+            for (int sl = 0; sl < 6 * cw_steps(Q >> 2); ++sl)
+                if (cw_issue(Q, sl) == blk) { const int t = cw_stamp(Q, sl, 2) + wrap * CW_TILE_STAMPS; if (t < t_need && t > t_blk) t_blk = t; }
+    return cw_asm_between(t_blk, t_need);
+}
+// ... in front of the barrier of pass Pw, for the image DMA issued behind the barrier of pass (3, rt)
+constexpr int cw_dma_count(int rt, int Pw)
+{
+    const int t1 = cw_stamp(Pw, 3 * cw_steps(Pw >> 2), 0);
+    int t0 = cw_stamp(12 + rt, 48, 0);
+    if (t0 >= t1) t0 -= CW_TILE_STAMPS;
+    return cw_asm_between(t0, t1);
+}
+static_assert(cw_need_count(32 + 0, 4, 48) == 12 && cw_need_count(32 + 3, 4, 66) == 0, "block1.2's k steps 0..3 are the last fetches before pass (1,0) uses them");
+static_assert(cw_need_count(3, 0, 18) == 10 && cw_need_count(0, 0, 0) == 14, "layer 0 fetches: followed by the image DMA of row tile 3, then by the first block1.2 fetches of pass (0,0)");
+static_assert(cw_dma_count(3, 2) == 32 && cw_dma_count(0, 15) >= 16, "image DMA waits");
 
 template <int DBG>
 __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
@@ -100,16 +215,14 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
     for (int i = tid; i < CW_CST_FLOATS; i += 256) CW_LDS(float, CW_CST + 4 * i) = meta[i];
 
     asm volatile("" ::: "a255");                                          // the kernel owns all 256 AGPRs (see above)
-    u32x4 wx[2][2];                                                        // block3.0's 17th k step (VGPRs, per pass)
+    u32x4 wx[2][2];                                                        // block3.0's 17th k step (VGPRs, once per tile)
     f32x16 acc[2][2];                                                      // [row-tile parity][column tile]
-    u32x4 bf[3][2];                                                        // activation fragment ring [k step % 3][plane]
+    u32x4 bf[3][2];                                                        // activation fragment ring [iteration % 3][plane]
     float inv[4] = {0.f, 0.f, 0.f, 0.f};
     int pid[4], pid_n[4] = {0, 0, 0, 0};
     float wq[4], wq_fin = 0.f;
     float4 e0 = make_float4(0.f, 0.f, 0.f, 0.f), e1 = e0;
     float4 tv[2][2][4];                                                    // layer 0: rows of the per-point table, two row tiles in flight ([row tile & 1][column tile][16 B])
-    u32x4 xv[2] = {u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};
-    int tile_fin = -1;
 
     // weight fragments of (layer L, k step s) -> a[16 s ..]: four loads  (probe build -DHNR_CHAIN_WS_SAME_W=1: every k step reads the layer's
     // first one -- 64 KiB instead of 848 KiB of weights per tile from L2; results are garbage, the time shows what the weight stream costs)
@@ -120,8 +233,8 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
         const int so_ = cw_wbase(L_) + (HNR_CHAIN_WS_SAME_W ? 0 : (s_)) * CH_WSTEP; \
         CW_LOAD_FRAG(16 * (s_) + 0, wsrd, woff, so_, 0); CW_LOAD_FRAG(16 * (s_) + 4, wsrd, woff, so_, 1024); \
         CW_LOAD_FRAG(16 * (s_) + 8, wsrd, woff, so_, 2048); CW_LOAD_FRAG(16 * (s_) + 12, wsrd, woff, so_, 3072); } while (0)
-    // per-row scalars of a tile: the point ids are needed first (table rows of layer 0: fetched into pid_n during the previous tile's last pass),
-    // the aggregation weights (layer 3) and the extras (layer 1) only later: they are fetched in pass (0, 1) of their own tile
+    // per-row scalars of a tile: the point ids are needed first (table rows of layer 0: fetched into pid_n two passes before the next tile's
+    // first table rows are asked for), the aggregation weights (layer 3) and the extras (layer 1) only later: fetched in pass (0, 1) of their own tile
     auto load_ids = [&](int tile, int (&pd)[4]) __attribute__((always_inline)) {
         const char *aux = a.aux + (size_t)tile * 4 * CH_AUX_GROUP;
 #pragma unroll
@@ -134,23 +247,52 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
         e0 = *reinterpret_cast<const float4 *>(aux + wave * CH_AUX_GROUP + 256 + j * 32);     // extras of the rows this wave publishes (row tile = wave)
         e1 = *reinterpret_cast<const float4 *>(aux + wave * CH_AUX_GROUP + 256 + j * 32 + 16);
     };
-    // layer-0 operand image of (tile, row tile rt): 8 chunks of 1 KiB (k step s = c >> 1, plane p = c & 1), this wave moves chunks wave, 4 + wave
-    auto xp_src = [&](int tile, int rt, int i) __attribute__((always_inline)) { return a.xp + ((size_t)tile * 4 + rt) * CH_XP_GROUP + (i * 4 + wave) * 1024 + lane * 16; };
+    auto load_table = [&](int pr, float4 (&t)[2][4]) __attribute__((always_inline)) {        // see cw_table_swap: t[column tile][r] = piece r ^ (j & 3) of row (j & ~3) + r
+        const int tq = j & 3;
+        const int p0 = __builtin_amdgcn_update_dpp(0, pr, 0x00, 0xf, 0xf, false), p1 = __builtin_amdgcn_update_dpp(0, pr, 0x55, 0xf, 0xf, false),
+                  p2 = __builtin_amdgcn_update_dpp(0, pr, 0xAA, 0xf, 0xf, false), p3 = __builtin_amdgcn_update_dpp(0, pr, 0xFF, 0xf, 0xf, false);
+        const int pp[4] = {p0, p1, p2, p3};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float *trow = a.ptab + (size_t)(pp[r] < 0 ? 0 : pp[r]) * a.ldt + col0 + 4 * (r ^ tq);
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) t[cc][r] = *reinterpret_cast<const float4 *>(trow + 32 * cc);
+        }
+    };
+    // layer-0 operand image of (tile, row tile rt): 8 chunks of 1 KiB (k step s = c >> 1, plane p = c & 1); this wave moves chunks wave and 4 + wave
+    // to k-step slots wave >> 1 and 2 + (wave >> 1), plane wave & 1, by DMA
+    const unsigned lds_base = (unsigned)reinterpret_cast<uintptr_t>(lds);
+    const int dma_voff = lane * 16;
+    auto dma_image = [&](int tile, int rt) __attribute__((always_inline)) {
+        const char *g = a.xp + ((size_t)tile * 4 + rt) * CH_XP_GROUP + wave * 1024;
+        const unsigned l0 = lds_base + (unsigned)((wave >> 1) * SLOT + (wave & 1) * 1024 + rt * 2048);
+        cw_dma_image(g, g + 4096, dma_voff, l0, l0 + 2 * SLOT);
+    };
+    // where a tile's weighted sums go: ONE buffer descriptor per tile on the tile's first sample (uniform) + a per-lane byte offset per pass, out of
+    // range (the store is dropped) in the lanes that hold no sum and past the end of the tile's class; class 1 / 2 tiles hold 32 / 64 samples of 4 / 2 row slots
+    struct TileOut { __amdgpu_buffer_rsrc_t rs, rs_aux; int kc, first, end, t; };
+    auto tile_out = [&](int t) __attribute__((always_inline)) {
+        TileOut o;
+        o.t = t;
+        const int tt = t < 0 ? 0 : t;
+        o.kc = (tt >= cls.big_tiles ? 1 : 0) + (tt >= cls.big_tiles + cls.small_tiles ? 1 : 0);
+        const int f0 = 16 * tt, f1 = cls.n_big + 32 * (tt - cls.big_tiles), f2 = cls.n_big + cls.n_small + 64 * (tt - cls.big_tiles - cls.small_tiles);
+        o.first = o.kc == 0 ? f0 : (o.kc == 1 ? f1 : f2);
+        o.end = o.kc == 0 ? cls.n_big : (o.kc == 1 ? cls.n_big + cls.n_small : n_valid);
+        if (t < 0) { o.first = n_valid; o.end = 0; }
+        int n = o.end - o.first; n = n < 0 ? 0 : (n > (16 << o.kc) ? (16 << o.kc) : n);
+        o.rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(a.X5) + (size_t)o.first * a.ld5 * 4, 0, n * a.ld5 * 4, 0x00020000);
+        // the tile's own row scalars: the rows' density inputs go to the unused eighth `ext` float (chain_sigma_kernel reads them)
+        o.rs_aux = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(a.aux) + (size_t)tt * 4 * CH_AUX_GROUP, 0, t < 0 ? 0 : 4 * CH_AUX_GROUP, 0x00020000);
+        return o;
+    };
 
-    // ---- prologue: first tile's row scalars, layer-0 images of row tiles 0..2 (row tile 3 is staged by pass (0,0) like in every later tile),
-    //      layer-0 weights
+    // ---- prologue: first tile's row scalars, its four layer-0 images (DMA), its first table rows, layer-0 weights
     load_ids(t_first, pid);
+    __syncthreads();                                                       // constants / zeroed extras visible; nobody DMAs into LDS before everybody is here
 #pragma unroll
-    for (int rt = 0; rt < 3; ++rt)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) CW_LDS(u32x4, o_xp + i * 2 * SLOT + rt * 2048) = *reinterpret_cast<const u32x4 *>(xp_src(t_first, rt, i));
-    {
-        const float *trow = a.ptab + (size_t)(pid[0] < 0 ? 0 : pid[0]) * a.ldt + col0;
-#pragma unroll
-        for (int cc = 0; cc < 2; ++cc)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) tv[0][cc][q] = *reinterpret_cast<const float4 *>(trow + 32 * cc + 4 * q);
-    }
+    for (int rt = 0; rt < 4; ++rt) dma_image(t_first, rt);
+    load_table(pid[0], tv[0]);
     CW_LOAD_W(0, 0); CW_LOAD_W(0, 1); CW_LOAD_W(0, 2); CW_LOAD_W(0, 3);
     cw_wait_vm<0>();
     __syncthreads();
@@ -162,64 +304,65 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
     // uniform scalars of the packed image (SGPRs)
     const float inv0 = __fmul_rn(pow2f(-14), meta[CH_META_DESCALE]), dw1 = meta[CH_META_DESCALE + 1], dw2 = meta[CH_META_DESCALE + 2], dw3 = meta[CH_META_DESCALE + 3],
                 alpha_b = meta[4 * 256 + 256];
+    (void)alpha_b;
     float amax = 0.f, ap = 0.f, sc_run = 1.f;                               // epilogue state carried between the pieces of one pass
-    f32x2 bias_c = {0.f, 0.f}, bias_n = {0.f, 0.f}, aw_c = {0.f, 0.f};     // constants of the running item (read from LDS one micro-stage ahead)
+    // constants of the running items: biases (and, for layer 3, alpha weights) as 16-B chunks of two items from the LDS copy, two chunks in flight.
+    // A chunk is asked for two items (four micro-stages) before its first use -- the first two chunks of a pass's epilogue by the last
+    // micro-stage of the epilogue before it --: in the short layer-0 passes a read asked for one micro-stage ahead was waited for (~100 cycles each).
+    float4 bq[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)}, aq[2] = {bq[0], bq[0]};
     unsigned ph[8], pm[8];
     float s1x = 0.f, s1y = 0.f, s1a = 0.f, s1b = 0.f;                       // values handed from an item's first micro-stage to its second
-    unsigned s1h = 0u;
-    // X5 rows of the row tile whose sums are being stored: a buffer descriptor on its first sample (uniform) + ONE per-lane byte offset, out of
-    // range (the store is dropped) in the lanes that hold no sum; x5_flag = 1 / 0: the third step of the K-sum runs / is a no-op (4-slot samples)
-    __amdgpu_buffer_rsrc_t x5_rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(a.X5), 0, 0, 0x00020000);
+    // X5 rows of the row tile whose sums are being stored: the tile's descriptor (tile_out) + ONE per-lane byte offset, out of range (the store
+    // is dropped) in the lanes that hold no sum; x5_flag = 1 / 0: the third step of the K-sum runs / is a no-op (4-slot samples)
     int x5_voff = 0x40000000;
     float x5_flag = 1.f, x5_flag2 = 1.f;                                    // (x5_flag2: the second step, a no-op for 2-slot samples)
-    float ks0 = 0.f, ks1 = 0.f, wq_sig = 0.f;                               // wq_sig: this wave's own row tile (= wave) of the tile whose densities are due
+    float kf[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     float4 ex4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
+    auto read_cst = [&](int L4, int k) __attribute__((always_inline)) {   // chunk k (items 2 k, 2 k + 1) of constants row L4 (0..3: biases, 4: alpha weights)
+        return (DBG == 5 || DBG == 7) ? make_float4(a.slope, 1.f, a.slope, 1.f) : CW_AT(const float4, q_cst, L4 * 1024 + (k >> 2) * 128 + (k & 3) * 16);
+    };
     // ---- epilogue of pass PP = (PL, PR), accumulator set se, cut into MICRO-STAGES of 3..8 VALU instructions.  A wave issues in order, and a
     //      dependent VALU instruction issues 8 cycles after its producer, an independent one 4: so every micro-stage holds two independent
     //      chains (the x and the y value of an item), an item's chain is cut in two stages that land behind different MFMAs, and LDS reads
-    //      are issued a stage or more before their first use.  `slot` counts the 6 S MFMAs of the RUNNING pass, H = first slot of its second
+    //      are issued well before their first use.  `slot` counts the 6 S MFMAs of the RUNNING pass, H = first slot of its second
     //      half; micro-stages [slot * MS / H, (slot + 1) * MS / H) run behind MFMA `slot`.  All arguments are constants after unrolling.
-    auto epilogue_piece = [&](int PL, int PR, int S, int slot, int tile_e, bool stage_next, int tile_stage) __attribute__((always_inline)) {
+    auto epilogue_piece = [&](int PL, int PR, int S, int slot, const TileOut &to) __attribute__((always_inline)) {
         const int T = 6 * S, H = T / 2, se = PR & 1;
         const int exb = (PR & 1) * 512;
         const float inv_l = PL == 0 ? inv0 : inv[PR];
-        // bias pair of item `it` (and for layer 3 its alpha weights): 8 B each from the LDS copy of the constants
-        auto read_bias = [&](int it) __attribute__((always_inline)) {
-            return (DBG == 5 || DBG == 7) ? f32x2{a.slope, 1.f} : CW_AT(const f32x2, q_cst, PL * 1024 + (it >> 3) * 128 + (it & 7) * 8);
-        };
-        auto read_aw = [&](int it) __attribute__((always_inline)) {
-            return (DBG == 5 || DBG == 7) ? f32x2{a.slope, 1.f} : CW_AT(const f32x2, q_cst, 4 * 1024 + (it >> 3) * 128 + (it & 7) * 8);
-        };
+        const int PLn = PR == 3 ? (PL + 1) & 3 : PL;                       // layer of the epilogue that follows this one
         if (slot < H) {
-            // -- first half.  micro-stage 0: bias of item 0; 1 + 2 i, 2 + 2 i: item i = (c, q), two values each (the first stage also asks for
-            //    the next item's bias and, in layer 3, this item's alpha weights); 33: row maximum / alpha partial -> exchange buffer
-            const int MS = 34, m0 = slot * MS / H, m1 = (slot + 1) * MS / H;
+            // -- first half.  micro-stages 2 i, 2 i + 1: item i = (c, q), two values each; 32: row maximum / alpha partial -> exchange buffer
+            const int MS = 33, m0 = slot * MS / H, m1 = (slot + 1) * MS / H;
 #pragma unroll
             for (int ms = m0; ms < m1; ++ms) {
-                if (ms == 0) {
-                    amax = 0.f; ap = 0.f;
-                    bias_n = read_bias(0);
-                } else if (ms < 33) {
-                    const int it = (ms - 1) >> 1, st = (ms - 1) & 1, c = it >> 3, q = it & 7;
+                if (ms < 32) {
+                    const int it = ms >> 1, st = ms & 1, c = it >> 3, q = it & 7, k = it >> 1;
                     if (st == 0) {
                         // scalar fp32 VALU on purpose: packed fp32 instructions (v_pk_fma_f32 ...) do not overlap with this wave's MFMAs -- one
                         // of them behind an MFMA costs 18 cycles of matrix-pipe time, a v_fma_f32 none (tools/interleave_probe.hip)
-                        bias_c = bias_n;
-                        if (it + 1 < 16) bias_n = read_bias(it + 1);
-                        if (PL == 3) aw_c = read_aw(it);
-                        float ax = bias_c.x, ay = bias_c.y;
-                        if (PL == 0) { const float4 t4 = tv[PR & 1][c][q >> 1]; ax = __fadd_rn(ax, (q & 1) ? t4.z : t4.x); ay = __fadd_rn(ay, (q & 1) ? t4.w : t4.y); }
+                        if (it == 0) { amax = 0.f; ap = 0.f; }
+                        if ((it & 1) == 0 && k >= 1 && k + 1 < 8) { bq[(k + 1) & 1] = read_cst(PL, k + 1); if (PL == 3) aq[(k + 1) & 1] = read_cst(4, k + 1); }
+                        float ax = (it & 1) ? bq[k & 1].z : bq[k & 1].x, ay = (it & 1) ? bq[k & 1].w : bq[k & 1].y;
+                        if (PL == 0) {
+                            if (q == 0) cw_table_swap(tv[PR & 1][c][0], tv[PR & 1][c][1], tv[PR & 1][c][2], tv[PR & 1][c][3]);
+                            const float4 t4 = tv[PR & 1][c][q >> 1];
+                            if ((q >> 1) == 0) { ax = cw_table_add<0>((q & 1) ? t4.z : t4.x, ax); ay = cw_table_add<0>((q & 1) ? t4.w : t4.y, ay); }
+                            else if ((q >> 1) == 1) { ax = cw_table_add<1>((q & 1) ? t4.z : t4.x, ax); ay = cw_table_add<1>((q & 1) ? t4.w : t4.y, ay); }
+                            else if ((q >> 1) == 2) { ax = cw_table_add<2>((q & 1) ? t4.z : t4.x, ax); ay = cw_table_add<2>((q & 1) ? t4.w : t4.y, ay); }
+                            else { ax = cw_table_add<3>((q & 1) ? t4.z : t4.x, ax); ay = cw_table_add<3>((q & 1) ? t4.w : t4.y, ay); }
+                        }
                         s1x = fmaf(acc[se][c][2 * q], inv_l, ax); s1y = fmaf(acc[se][c][2 * q + 1], inv_l, ay);
                         s1a = __fmul_rn(s1x, a.slope); s1b = __fmul_rn(s1y, a.slope);
                     } else {
                         const float vx = fmaxf(s1x, s1a), vy = fmaxf(s1y, s1b);
                         acc[se][c][2 * q] = vx; acc[se][c][2 * q + 1] = vy;
-                        if (PL == 3) { ap = fmaf(vx, aw_c.x, ap); ap = fmaf(vy, aw_c.y, ap); }
+                        if (PL == 3) { ap = fmaf(vx, (it & 1) ? aq[k & 1].z : aq[k & 1].x, ap); ap = fmaf(vy, (it & 1) ? aq[k & 1].w : aq[k & 1].y, ap); }
                         else amax = fmaxf(fmaxf(amax, fabsf(vx)), fabsf(vy));
                         if (DBG == 1) {
-                            if (a.dbg && a.dbg_layer == PL && tile_e >= 0) {
-                                int te = tile_e;                                        // laundered: no 64-bit induction variable
+                            if (a.dbg && a.dbg_layer == PL && to.t >= 0) {
+                                int te = to.t;                                          // laundered: no 64-bit induction variable
                                 asm volatile("" : "+s"(te));
                                 float *o = a.dbg + ((size_t)te * 128 + 32 * PR + j) * 256 + col0 + 32 * c + 2 * q;
                                 o[0] = vx; o[1] = vy;
@@ -240,10 +383,16 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
             return;
         }
         const int k2 = slot - H, N2 = T - H;
+        // the next epilogue's first two chunks of constants (its layer is known at compile time); the last micro-stage of either second half
+        auto prefetch_next = [&]() __attribute__((always_inline)) {
+            bq[0] = read_cst(PLn, 0); bq[1] = read_cst(PLn, 1);
+            if (PLn == 3) { aq[0] = read_cst(4, 0); aq[1] = read_cst(4, 1); }
+        };
         if (PL != 3) {
-            // -- second half, hidden layers: micro-stage 0: exchange read; 1: row scale; 2 + 2 i, 3 + 2 i: item i: scale + fp16 high parts, then
-            //    residuals + low parts (+ the operand-plane stores after q = 3, 7); 34: the 7 extra inputs of block3.0
-            const int MS = 35, m0 = k2 * MS / N2, m1 = (k2 + 1) * MS / N2;
+            // -- second half, hidden layers: micro-stage 0: exchange read; 1: row scale; 2 + i (i = 0..16): fp16 high parts of item i and low parts
+            //    (residuals) of item i - 1, interleaved so that no instruction reads the register written just before it (+ the operand-plane
+            //    stores after q = 3, 7); 19: the 7 extra inputs of block3.0; 20: the next epilogue's constants
+            const int MS = 21, m0 = k2 * MS / N2, m1 = (k2 + 1) * MS / N2;
 #pragma unroll
             for (int ms = m0; ms < m1; ++ms) {
                 if (ms == 0) ex4 = (DBG == 5 || DBG == 7) ? make_float4(amax, 1.f, 2.f, 3.f) : CW_AT(const float4, q_exr, exb);
@@ -251,88 +400,101 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
                     const int k = row_scale_exp(fmaxf(fmaxf(ex4.x, ex4.y), fmaxf(ex4.z, ex4.w)));
                     sc_run = pow2f(k);
                     inv[PR] = __fmul_rn(pow2f(-k), PL == 0 ? dw1 : PL == 1 ? dw2 : dw3);
-                } else if (ms < 34) {
-                    const int it = (ms - 2) >> 1, st = (ms - 2) & 1, c = it >> 3, q = it & 7;
-                    if (st == 0) {
-                        s1x = __fmul_rn(acc[se][c][2 * q], sc_run); s1y = __fmul_rn(acc[se][c][2 * q + 1], sc_run);
-                        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(s1h) : "v"(s1x), "v"(s1y));
+                } else if (ms < 19) {
+                    // h = RN16(x 2^k): the product with a power of two is exact, so the fused multiply-convert rounds once, like a separate multiply +
+                    // v_cvt_pk_f16_f32; the y value goes to the high half of the same register.  m = RN16(x 2^k - h): the difference is exact in fp32
+                    // (h holds the leading 11 bits of x 2^k).  One asm block per stage: the order inside is the point.
+                    const int it = ms - 2, ip = it - 1;
+                    if (it == 0) {
+                        asm volatile("v_fma_mixlo_f16 %0, %1, %3, 0\n\ts_nop 0\n\tv_fma_mixhi_f16 %0, %2, %3, 0"
+                                     : "=&v"(ph[0]) : "v"(acc[se][0][0]), "v"(acc[se][0][1]), "v"(sc_run));
+                    } else if (it < 16) {
+                        const int c = it >> 3, q = it & 7, cp = ip >> 3, qp = ip & 7;
+                        asm volatile("v_fma_mixlo_f16 %0, %2, %6, 0\n\t"
+                                     "v_fma_mixlo_f16 %1, %4, %6, -%7 op_sel_hi:[0,0,1]\n\t"
+                                     "v_fma_mixhi_f16 %0, %3, %6, 0\n\t"
+                                     "v_fma_mixhi_f16 %1, %5, %6, -%7 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+                                     : "=&v"(ph[q]), "=&v"(pm[qp])
+                                     : "v"(acc[se][c][2 * q]), "v"(acc[se][c][2 * q + 1]), "v"(acc[se][cp][2 * qp]), "v"(acc[se][cp][2 * qp + 1]), "v"(sc_run), "v"(ph[qp]));
                     } else {
-                        float r0, r1;
-                        asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(s1h), "v"(s1x));
-                        asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(s1h), "v"(s1y));
-                        ph[q] = s1h;
-                        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(pm[q]) : "v"(r0), "v"(r1));
-                        if ((q == 3 || q == 7) && (DBG == 6 || DBG == 7)) { asm volatile("" :: "v"(ph[q]), "v"(pm[q]), "v"(ph[q - 1]), "v"(pm[q - 1]), "v"(ph[q - 2]), "v"(pm[q - 2]), "v"(ph[q - 3]), "v"(pm[q - 3])); }
-                        else if (q == 3 || q == 7) {
-                            const int dst = c * 2 * SLOT + PR * 2048 + (q == 7 ? 512 : 0);
-                            CW_AT(u32x4, q_pub, dst) = u32x4{ph[q - 3], ph[q - 2], ph[q - 1], ph[q]};
-                            CW_AT(u32x4, q_pub, dst + 1024) = u32x4{pm[q - 3], pm[q - 2], pm[q - 1], pm[q]};
+                        asm volatile("v_fma_mixlo_f16 %0, %1, %3, -%4 op_sel_hi:[0,0,1]\n\ts_nop 0\n\tv_fma_mixhi_f16 %0, %2, %3, -%4 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+                                     : "=&v"(pm[7]) : "v"(acc[se][1][14]), "v"(acc[se][1][15]), "v"(sc_run), "v"(ph[7]));
+                    }
+                    if (ip >= 0) {
+                        const int cp = ip >> 3, qp = ip & 7;
+                        if ((qp == 3 || qp == 7) && (DBG == 6 || DBG == 7)) { asm volatile("" :: "v"(ph[qp]), "v"(pm[qp]), "v"(ph[qp - 1]), "v"(pm[qp - 1]), "v"(ph[qp - 2]), "v"(pm[qp - 2]), "v"(ph[qp - 3]), "v"(pm[qp - 3])); }
+                        else if (qp == 3 || qp == 7) {
+                            const int dst = cp * 2 * SLOT + PR * 2048 + (qp == 7 ? 512 : 0);
+                            CW_AT(u32x4, q_pub, dst) = u32x4{ph[qp - 3], ph[qp - 2], ph[qp - 1], ph[qp]};
+                            CW_AT(u32x4, q_pub, dst + 1024) = u32x4{pm[qp - 3], pm[qp - 2], pm[qp - 1], pm[qp]};
                         }
                     }
-                } else if (PL == 1 && PR == wave && h == 0) {
-                    unsigned xh[4], xm[4];
-                    split2h(__fmul_rn(e0.x, sc_run), __fmul_rn(e0.y, sc_run), xh[0], xm[0]);
-                    split2h(__fmul_rn(e0.z, sc_run), __fmul_rn(e0.w, sc_run), xh[1], xm[1]);
-                    split2h(__fmul_rn(e1.x, sc_run), __fmul_rn(e1.y, sc_run), xh[2], xm[2]);
-                    split2h(__fmul_rn(e1.z, sc_run), 0.f, xh[3], xm[3]);
-                    CW_AT(u32x4, q_ext, PR * 2048) = u32x4{xh[0], xh[1], xh[2], xh[3]};
-                    CW_AT(u32x4, q_ext, PR * 2048 + 1024) = u32x4{xm[0], xm[1], xm[2], xm[3]};
-                }
+                } else if (ms == 19) {
+                    if (PL == 1 && PR == wave && h == 0) {
+                        unsigned xh[4], xm[4];
+                        split2h(__fmul_rn(e0.x, sc_run), __fmul_rn(e0.y, sc_run), xh[0], xm[0]);
+                        split2h(__fmul_rn(e0.z, sc_run), __fmul_rn(e0.w, sc_run), xh[1], xm[1]);
+                        split2h(__fmul_rn(e1.x, sc_run), __fmul_rn(e1.y, sc_run), xh[2], xm[2]);
+                        split2h(__fmul_rn(e1.z, sc_run), 0.f, xh[3], xm[3]);
+                        CW_AT(u32x4, q_ext, PR * 2048) = u32x4{xh[0], xh[1], xh[2], xh[3]};
+                        CW_AT(u32x4, q_ext, PR * 2048 + 1024) = u32x4{xm[0], xm[1], xm[2], xm[3]};
+                    }
+                } else prefetch_next();
             }
             return;
         }
-        // -- second half, layer 3: K-weighted sums (8 adjacent lanes: three DPP steps), X5 / sigma stores, next tile's layer-0 image of row tile PR.
-        //    micro-stage 0: exchange read; 1 + i: value pair i (16 pairs; a float4 store after every second pair); 17: sigma; 18: image
+        // -- second half, layer 3: K-weighted sums (8 adjacent lanes: three DPP steps), X5 / sigma stores.
+        //    micro-stage 0: exchange read, store offsets; 1 + 4 d + t: value pairs 2 d, 2 d + 1 (four values), step t = 0: times the row's weight, 1..3: the
+        //    three lane steps (a float4 store after the last); 33: sigma; 34: the next epilogue's constants
         const float wq_e = PR == 3 ? wq_fin : wq[PR];
         // a tile of the second / third slot class (hnr_chain_plan): 8 samples of 4 row slots / 16 samples of 2 per row tile -- the sum stops after two
         // DPP steps / one
-        const int kc_e = tile_e < 0 ? 0 : chain_tile_class(cls, tile_e);
-        const int MS = 19, m0 = k2 * MS / N2, m1 = (k2 + 1) * MS / N2;
+        const int kc_e = to.kc;
+        const int MS = 35, m0 = k2 * MS / N2, m1 = (k2 + 1) * MS / N2;
 #pragma unroll
         for (int ms = m0; ms < m1; ++ms) {
             if (ms == 0) {
                 if (PR == 3) ex4 = CW_AT(const float4, q_dsr, 0);
-                // where this row tile's sums go (once per pass: per store it cost a 64-bit multiply, a three-way select and an exec-masked branch)
-                const int row0 = tile_e < 0 ? n_valid : chain_tile_first(cls, tile_e, kc_e) + (4 << kc_e) * PR;
-                const int ls = j >> (3 - kc_e);
-                const bool st = (j & ((8 >> kc_e) - 1)) == 0 && row0 + ls < (tile_e < 0 ? n_valid : chain_class_end(cls, kc_e));
+                // this row tile's samples: (4 << kc) of them from sample PR (4 << kc) of the tile; lanes past the tile's / class's end are out of the descriptor's range
+                const int ls = (j >> (3 - kc_e)) + (4 << kc_e) * PR;
+                const bool st = (j & ((8 >> kc_e) - 1)) == 0;
                 x5_voff = st ? (ls * a.ld5 + col0) * 4 : 0x40000000;
-                x5_rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(a.X5) + (size_t)row0 * a.ld5 * 4, 0, 16 * a.ld5 * 4, 0x00020000);
                 x5_flag = kc_e > 0 ? 0.f : 1.f;
                 x5_flag2 = kc_e > 1 ? 0.f : 1.f;
-            } else if (ms < 17) {
-                const int pr = ms - 1, c = pr >> 3, e0i = 2 * (pr & 7);
+            } else if (ms < 33) {
                 // the sum over a sample's 8 (4, 2) row slots = 8 (4, 2) adjacent lanes: pair swap, quad-pair swap, half-row mirror; the second and
-                // third step as f += dpp(f) * flag (exactly f + dpp(f) or f).  One block: every DPP read sits two wait states after the write it reads
-                // (the assembler does not pad inline asm), and the compiler cannot expand the steps into moves / selects / branches
-                float f0, f1;
-                asm volatile("v_mul_f32 %0, %2, %4\n\tv_mul_f32 %1, %3, %4\n\ts_nop 0\n\t"
-                             "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                             "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
-                             "v_fmac_f32_dpp %0, %0, %6 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-                             "v_fmac_f32_dpp %1, %1, %6 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
-                             "v_fmac_f32_dpp %0, %0, %5 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-                             "v_fmac_f32_dpp %1, %1, %5 row_half_mirror row_mask:0xf bank_mask:0xf"
-                             : "=&v"(f0), "=&v"(f1) : "v"(acc[se][c][e0i]), "v"(acc[se][c][e0i + 1]), "v"(wq_e), "v"(x5_flag), "v"(x5_flag2));
-                if ((pr & 1) == 0) { ks0 = f0; ks1 = f1; }
-                else __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(ks0), __float_as_uint(ks1), __float_as_uint(f0), __float_as_uint(f1)}, x5_rs,
-                                                            x5_voff + (32 * c + 2 * (pr & 6)) * 4, 0, 0);
-            } else if (ms == 17) {
-                // the tile's densities, once per tile and in all four waves at the same time (softplus is ~100 instructions that cannot be cut
-                // into pieces; per row tile it stalled a different pass for each wave): wave w takes row tile w
-                if (PR == 3) {
-                    const int s_sig = tile_e < 0 ? n_valid : chain_tile_first(cls, tile_e, kc_e) + (4 << kc_e) * wave + (j >> (3 - kc_e));
-                    const float d = __fadd_rn(__fadd_rn(ex4.x, ex4.y), __fadd_rn(ex4.z, ex4.w));
-                    float sg = __fmul_rn(chain_softplus_m1(__fadd_rn(d, alpha_b)), wq_sig);
-                    sg = __fadd_rn(sg, __builtin_amdgcn_update_dpp(0.f, sg, 0xB1, 0xf, 0xf, false));
-                    { const float g = __builtin_amdgcn_update_dpp(0.f, sg, 0x4E, 0xf, 0xf, false); sg = __fadd_rn(sg, kc_e > 1 ? 0.f : g); }
-                    { const float g = __builtin_amdgcn_update_dpp(0.f, sg, 0x141, 0xf, 0xf, false); sg = __fadd_rn(sg, kc_e > 0 ? 0.f : g); }
-                    if (h == 0 && (j & ((8 >> kc_e) - 1)) == 0 && s_sig < (tile_e < 0 ? 0 : chain_class_end(cls, kc_e))) a.sigma[s_sig] = sg;
+                // third step as f += dpp(f) * flag (exactly f + dpp(f) or f).  Four values per step and one asm block per step: a DPP read sits four
+                // instructions (or an MFMA) after the write it reads -- the assembler does not pad inline asm, and the compiler cannot expand the
+                // steps into moves / selects / branches
+                const int d = (ms - 1) >> 2, t = (ms - 1) & 3, c = d >> 2, e0i = 4 * (d & 3), kb = d & 1;      // two sets of sums: a set is stored while the next one is formed
+                if (t == 0)
+                    asm volatile("v_mul_f32 %0, %4, %8\n\tv_mul_f32 %1, %5, %8\n\tv_mul_f32 %2, %6, %8\n\tv_mul_f32 %3, %7, %8"
+                                 : "=&v"(kf[kb][0]), "=&v"(kf[kb][1]), "=&v"(kf[kb][2]), "=&v"(kf[kb][3])
+                                 : "v"(acc[se][c][e0i]), "v"(acc[se][c][e0i + 1]), "v"(acc[se][c][e0i + 2]), "v"(acc[se][c][e0i + 3]), "v"(wq_e));
+                else if (t == 1)
+                    asm volatile("v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                                 "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+                                 : "+v"(kf[kb][0]), "+v"(kf[kb][1]), "+v"(kf[kb][2]), "+v"(kf[kb][3]));
+                else if (t == 2)
+                    asm volatile("v_fmac_f32_dpp %0, %0, %4 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\tv_fmac_f32_dpp %1, %1, %4 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                                 "v_fmac_f32_dpp %2, %2, %4 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\tv_fmac_f32_dpp %3, %3, %4 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+                                 : "+v"(kf[kb][0]), "+v"(kf[kb][1]), "+v"(kf[kb][2]), "+v"(kf[kb][3]) : "v"(x5_flag2));
+                else {
+                    asm volatile("v_fmac_f32_dpp %0, %0, %4 row_half_mirror row_mask:0xf bank_mask:0xf\n\tv_fmac_f32_dpp %1, %1, %4 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                                 "v_fmac_f32_dpp %2, %2, %4 row_half_mirror row_mask:0xf bank_mask:0xf\n\tv_fmac_f32_dpp %3, %3, %4 row_half_mirror row_mask:0xf bank_mask:0xf"
+                                 : "+v"(kf[kb][0]), "+v"(kf[kb][1]), "+v"(kf[kb][2]), "+v"(kf[kb][3]) : "v"(x5_flag));
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(kf[kb][0]), __float_as_uint(kf[kb][1]), __float_as_uint(kf[kb][2]), __float_as_uint(kf[kb][3])}, to.rs,
+                                                           x5_voff + (32 * c + e0i) * 4, 0, 0);
                 }
-            } else if (stage_next && tile_stage < t_end) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i) CW_AT(u32x4, q_xp, i * 2 * SLOT + PR * 2048) = xv[i];
-            }
+            } else if (ms == 33) {
+                // the tile's density inputs (the alpha dot of every row = the four waves' partial sums): wave w stores row tile w's 32 values into the
+                // tile's row scalars; softplus, the rows' weights and the K-sum are chain_sigma_kernel's (~160 instructions per wave and tile that
+                // no MFMA of this kernel could hide: they ran in the 24-MFMA pass (0,0))
+                if (PR == 3) {
+                    const float d = __fadd_rn(__fadd_rn(ex4.x, ex4.y), __fadd_rn(ex4.z, ex4.w));
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d), to.rs_aux, h == 0 ? wave * CH_AUX_GROUP + 256 + j * 32 + 28 : 0x40000000, 0, 0);
+                }
+            } else prefetch_next();
         }
     };
 
@@ -341,62 +503,61 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
         return off < 65536 ? CW_AT(const u32x4, q_b0, off) : off < 131072 ? CW_AT(const u32x4, q_b1, off - 65536) : CW_AT(const u32x4, q_b2, off - 131072);
     };
 
+    TileOut to_fin = tile_out(-1);                                         // the tile whose last row tile's sums are still due (none yet)
+    CW_REFRESH();
+    bq[0] = read_cst(3, 0); bq[1] = read_cst(3, 1); aq[0] = read_cst(4, 0); aq[1] = read_cst(4, 1);      // the first epilogue piece is (3,3)'s (of no tile: its stores are dropped)
+    bf[0][0] = b_read(0, 0, 0); bf[0][1] = b_read(0, 0, 1);                // iteration 0 of the first tile's pass (0,0); later tiles: asked for at the end of pass (3,3)
     for (int tile = t_first; tile < t_end; tile += t_step) {
         ++n_my;
         const int tile_next = tile + t_step;
+        const int tile_nx = tile_next < t_end ? tile_next : tile;         // what is fetched ahead (the last tile fetches itself again: no branch in the passes)
+        const TileOut to_cur = tile_out(tile);
         CW_REFRESH();
-        // k steps 0, 1 of pass (0,0)
-        bf[0][0] = b_read(0, 0, 0); bf[0][1] = b_read(0, 0, 1);
-        bf[1][0] = b_read(0, 1, 0); bf[1][1] = b_read(0, 1, 1);
+        bf[1][0] = b_read(0, 1, 0); bf[1][1] = b_read(0, 1, 1);            // iteration 1 of pass (0,0)
         cw_static_for<16>([&](auto Pc) __attribute__((always_inline)) {
             constexpr int P = decltype(Pc)::value;
             constexpr int L = P >> 2, rt = P & 3, S = cw_steps(L), G0 = cw_goff(P);
             constexpr int PP = (P + 15) & 15, PL = PP >> 2, PR = PP & 3, sm = rt & 1;
             constexpr int T = 6 * S, H = T / 2;
-            const int tile_e = P == 0 ? tile_fin : tile;                   // tile of the row tile whose epilogue runs here
-            const int tile_stage = P == 0 ? tile : tile_next;              // tile whose layer-0 image a layer-3 epilogue stages
+            const TileOut &to_e = P == 0 ? to_fin : to_cur;                // tile of the row tile whose epilogue runs here
             if (DBG >= 2) { const long long t_ = clock64(); tm[(P + 15) & 15] += t_ - t_prev; t_prev = t_; }
             if (P != 0) CW_REFRESH();
-            // ---- pass start: loads that ride ahead
-            if (L == 2) {
+            // ---- pass start: loads that ride ahead (each placed where no wait of the following passes lands right behind it)
+            if (P == 6) {                                                  // block3.0's 17th k step: used by the last MFMAs of passes (2, 0..3)
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
 #pragma unroll
                     for (int p = 0; p < 2; ++p)
                         wx[c][p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wsrd, woff + (c * 2 + p) * 1024, CH_W2 + 16 * CH_WSTEP, 0));
             }
-            if (PL == 3 && tile_stage < t_end) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i) xv[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(xp_src(tile_stage, PR, i)));      // read once
-            }
-            if (P == 15 && tile_next < t_end) load_ids(tile_next, pid_n);
+            if (P == 13) load_ids(tile_nx, pid_n);
             if (P == 1) load_rest(tile);                                   // (pass (0, 0) still reads the previous tile's weight of row tile 3: wq_fin)
             __builtin_amdgcn_sched_barrier(0);
             cw_static_for<6 * S>([&](auto kc) __attribute__((always_inline)) {
-                // one piece per MFMA: slot = 6 s + 2 g + c (k step s, term g, column tile c)
-                constexpr int slot = decltype(kc)::value, s = slot / 6, g = (slot % 6) >> 1, c = slot & 1;
+                // one piece per MFMA: slot = 6 i + 2 g + c (iteration i = k step cw_korder(L, i), term g, column tile c)
+                constexpr int slot = decltype(kc)::value, it = slot / 6, s = cw_korder(L, it), g = (slot % 6) >> 1, c = slot & 1;
                 if (slot == H) {
+                    // DMA'd layer-0 images: row tile 0's must have landed before the barrier of (3,3) (read from that pass's last iterations on), row
+                    // tile 3's before the barrier of (0,2); row tiles 1, 2: covered by the wait at the head of (0,0).  Counted in the asm loads this wave
+                    // has issued since (cw_dma_count)
+                    if constexpr (P == 15) cw_wait_vm<cw_dma_count(0, 15)>();
+                    if constexpr (P == 2) cw_wait_vm<cw_dma_count(3, 2)>();
                     cw_lds_barrier();
+                    // every wave is past the first k steps of pass (3, rt): the next tile's image of row tile rt may overwrite their operand planes
+                    if constexpr (L == 3) dma_image(tile_nx, rt);
                     // layer 0's table rows are asked for one and a half passes before their epilogue: row tile rt + 1 at the barrier of pass
-                    // (0, rt) -- the set it goes into was consumed in this pass's first half --, the next tile's row tile 0 at the barrier of (3, 3)
-                    if ((L == 0 && rt < 3) || (L == 3 && rt == 3)) {
-                        const int pr = L == 0 ? pid[rt < 3 ? rt + 1 : 0] : pid_n[0];
-                        if (L == 0 || tile_next < t_end) {
-                            const float *trow = a.ptab + (size_t)(pr < 0 ? 0 : pr) * a.ldt + col0;
-#pragma unroll
-                            for (int cc = 0; cc < 2; ++cc)
-#pragma unroll
-                                for (int q = 0; q < 4; ++q) tv[L == 0 ? (rt + 1) & 1 : 0][cc][q] = *reinterpret_cast<const float4 *>(trow + 32 * cc + 4 * q);
-                        }
-                    }
+                    // (0, rt) -- the set it goes into was consumed in this pass's first half --, the next tile's row tile 0 at the barrier of (3, 2)
+                    if constexpr (L == 0 && rt < 3) load_table(pid[rt + 1], tv[(rt + 1) & 1]);
+                    if constexpr (P == 14) load_table(pid_n[0], tv[0]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 constexpr int wp = g == 0 ? 1 : 0, xp_ = g == 1 ? 1 : 0;   // wm*xh, wh*xm, wh*xh: smallest terms first
-                constexpr int ring = (G0 + s) % 3;
-                // first pass of a layer: the k step's fragments were fetched during the previous layer's last pass; `after` = k steps fetched after it
+                constexpr int ring = (G0 + it) % 3;
+                // first pass of a layer: wait for the k step's fragments, counted in the asm loads issued after them (cw_need_count).  Pass (0,0):
+                // the eight X5 stores of (3,2)'s epilogue also follow layer 0's fetches (a wait that did not allow for them would drain them)
                 if constexpr (rt == 0 && g == 0 && c == 0 && s < 16) {
-                    constexpr int after = L == 1 ? (s < 4 ? 3 - s : 15 - s + 4) : L == 0 ? 3 - s : 15 - s;
-                    cw_wait_vm<(4 * after < 60 ? 4 * after : 60)>();
+                    constexpr int n_ = cw_need_count(32 * L + s, P, slot) + (P == 0 ? 8 : 0);
+                    if constexpr (n_ <= 56) cw_wait_vm<n_>();
                 }
                 constexpr int A0 = 16 * (s < 16 ? s : 0) + 4 * wp + 8 * c;
                 if constexpr (DBG == 4) { if (slot < 2) { acc[sm][c] = f32x16{} + bf[ring][xp_][0]; } }
@@ -404,25 +565,20 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
                 else if constexpr (slot < 2) cw_mfma_first<A0>(acc[sm][c], bf[ring][xp_]);
                 else cw_mfma<A0>(acc[sm][c], bf[ring][xp_]);
                 __builtin_amdgcn_sched_barrier(0);                          // nothing of the epilogue is hoisted above the MFMA (an accumulator is read two MFMAs after its last writer at the earliest)
-                // activation fragments two k steps ahead (possibly the next pass's)
-                if constexpr (g < 2 && c == 0 && G0 + s + 2 < CW_GTOT) {
-                    constexpr int s2 = s + 2 >= S ? s + 2 - S : s + 2, P2 = s + 2 >= S ? P + 1 : P;
-                    if constexpr (P2 < 16 && s2 < cw_steps((P2 & 15) >> 2)) bf[(G0 + s + 2) % 3][g] = b_read(P2 & 3, s2, g);
+                // activation fragments two iterations ahead (possibly the next pass's; the next tile's first ones from the last iteration of (3,3))
+                if constexpr (g < 2 && c == 0 && G0 + it + 2 < CW_GTOT) {
+                    constexpr int i2 = it + 2 >= S ? it + 2 - S : it + 2, P2 = it + 2 >= S ? P + 1 : P;
+                    if constexpr (P2 < 16 && i2 < cw_steps((P2 & 15) >> 2)) bf[(G0 + it + 2) % 3][g] = b_read(P2 & 3, cw_korder((P2 & 15) >> 2, i2), g);
                 }
-                // the next layer's weights move into a k step's registers once the layer's last pass has used them; during layer 0 (4 k steps
-                // resident) k steps 4..15 of block1.2 are fetched early in the pass, before the pass's table rows are asked for
-                if constexpr (g == 2 && c == 1 && rt == 3 && s < 16 && s < cw_steps((L + 1) & 3)) {
-                    if constexpr (L == 3) { if (tile_next < t_end) CW_LOAD_W(0, s); }
-                    else CW_LOAD_W(L + 1, s);
-                }
-                if constexpr (L == 0 && rt < 3 && slot >= 2 && slot <= 8 && (slot & 1) == 0) CW_LOAD_W(1, 4 + 4 * rt + (slot / 2 - 1));
-                if (DBG != 3) epilogue_piece(PL, PR, S, slot, tile_e, true, tile_stage);
+                if constexpr (g < 2 && c == 0 && P == 15 && it == 15) bf[0][g] = b_read(0, 0, g);
+                // the weight stream (cw_issue)
+                { constexpr int blk = cw_issue(P, slot); if constexpr (blk >= 0) CW_LOAD_W(blk >> 5, blk & 31); }
+                if (DBG != 3) epilogue_piece(PL, PR, S, slot, to_e);
                 __builtin_amdgcn_sched_barrier(0);
             });
         });
         // tile switch
-        wq_fin = wq[3]; tile_fin = tile;
-        wq_sig = wave == 0 ? wq[0] : wave == 1 ? wq[1] : wave == 2 ? wq[2] : wq[3];
+        wq_fin = wq[3]; to_fin = to_cur;
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) pid[rt] = pid_n[rt];
     }
@@ -431,8 +587,9 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
     cw_static_for<6 * CH_S0>([&](auto kc) __attribute__((always_inline)) {
         constexpr int slot = decltype(kc)::value;
         if (slot == (6 * CH_S0) / 2) cw_lds_barrier();
-        epilogue_piece(3, 3, CH_S0, slot, tile_fin, false, 0);
+        epilogue_piece(3, 3, CH_S0, slot, to_fin);
     });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // the last tile's fetch-ahead (DMA into this workgroup's LDS) must not outlive the workgroup
     if (DBG >= 2 && blockIdx.x == 0 && lane == 0 && a.dbg) {               // block 0: cycles per pass [wave][16]
         long long *o = reinterpret_cast<long long *>(a.dbg) + 4 * 1024 + wave * 16;
         for (int i = 0; i < 16; ++i) o[i] = tm[i];
@@ -441,6 +598,27 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
         long long *o = reinterpret_cast<long long *>(a.dbg) + 4 * (size_t)blockIdx.x;
         o[0] = clock64() - t_start; o[1] = wall_clock64() - w_start; o[2] = n_my; o[3] = 0;
     }
+}
+
+// The samples' densities from the row tiles' density inputs chain_ws_kernel left in the row scalars (ext[.][7]): sigma = sum over the sample's row
+// slots of softplus(d + alpha_b - 1) x aggregation weight, added in the order of the lane steps the chain kernels use (pairs, quad pairs, halves).
+// One 128-thread block per tile, thread = row; raw2out_density: models/aggregators/point_aggregators.py:471-476.
+__global__ __launch_bounds__(128) void chain_sigma_kernel(ChainArgs a)
+{
+    const ChainClasses cls = chain_classes(a.counts, a.cap_samples);
+    const int tile = blockIdx.x;
+    if (tile >= cls.n_tiles) return;
+    const int lane = threadIdx.x & 63, rt = threadIdx.x >> 5, j = lane & 31;
+    const char *aux = a.aux + ((size_t)tile * 4 + rt) * CH_AUX_GROUP;
+    const float d = reinterpret_cast<const float *>(aux + 256 + j * 32)[7], wq = reinterpret_cast<const float *>(aux + 128)[j];
+    const float alpha_b = reinterpret_cast<const float *>(a.wimg + CH_META)[4 * 256 + 256];
+    const int kc = chain_tile_class(cls, tile);
+    float sg = __fmul_rn(chain_softplus_m1(__fadd_rn(d, alpha_b)), wq);
+    sg = __fadd_rn(sg, __builtin_amdgcn_update_dpp(0.f, sg, 0xB1, 0xf, 0xf, false));
+    { const float g = __builtin_amdgcn_update_dpp(0.f, sg, 0x4E, 0xf, 0xf, false); sg = __fadd_rn(sg, kc > 1 ? 0.f : g); }
+    { const float g = __builtin_amdgcn_update_dpp(0.f, sg, 0x141, 0xf, 0xf, false); sg = __fadd_rn(sg, kc > 0 ? 0.f : g); }
+    const int s_sig = chain_tile_first(cls, tile, kc) + (4 << kc) * rt + (j >> (3 - kc));
+    if ((j & ((8 >> kc) - 1)) == 0 && s_sig < chain_class_end(cls, kc)) a.sigma[s_sig] = sg;
 }
 
 int launch_chain_ws(const ChainArgs &a, int grid, hipStream_t st, int mode)
@@ -469,6 +647,9 @@ int launch_chain_ws(const ChainArgs &a, int grid, hipStream_t st, int mode)
     if (mode == 2) chain_ws_kernel<2><<<grid, 256, cw_lds_bytes(), st>>>(a);
     else if (mode == 1) chain_ws_kernel<1><<<grid, 256, cw_lds_bytes(), st>>>(a);
     else chain_ws_kernel<0><<<grid, 256, cw_lds_bytes(), st>>>(a);
+    HNR_LAUNCH_CHECK();
+    const int tiles = (a.cap_samples + 15) / 16 + 2;                        // capacity (each slot class may end in a partial tile): the kernel reads the real tile count from the device counters
+    chain_sigma_kernel<<<tiles, 128, 0, st>>>(a);
     HNR_LAUNCH_CHECK();
     return HNR_OK;
 }
