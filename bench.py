@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--margin", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-leg", action="store_true")
+    ap.add_argument("--no-f32-anchor", action="store_true", help="skip the one fp32-MFMA frame rendered beside the timed region (fp32_mfma_anchor)")
     ap.add_argument("--cpu-sample-rays", type=int, default=2304)
     ap.add_argument("--shard", choices=("lines", "blocks"), default="lines",
                     help="strong scaling: scan lines dealt round-robin to the ranks (balanced: busiest rank 1.01x the mean work at N = 8) or N "
@@ -127,9 +128,17 @@ def render_frame(rnd, cloud, cam, sc, chunk, timers=None, statuses=None):
     return cols[0] if len(cols) == 1 else torch.cat(cols, dim=0), out
 
 
-TRAFFIC_JSON = "r03_traffic.json"
-TRAIN_TRAFFIC_JSON = "r03_train_traffic.json"
-CHAIN_PMC_JSON = "r03_chain_pmc.json"
+def _newest_profile(suffix):
+    """profiles/rNN_<suffix> of the latest round that has one (the PMC passes are re-collected when the kernels change: tools/run_r4_evidence.sh)"""
+    for tag in ("r04", "r03"):
+        if os.path.exists(os.path.join(ROOT, "profiles", "%s_%s" % (tag, suffix))):
+            return "%s_%s" % (tag, suffix)
+    return "r04_" + suffix
+
+
+TRAFFIC_JSON = _newest_profile("traffic.json")
+TRAIN_TRAFFIC_JSON = _newest_profile("train_traffic.json")
+CHAIN_PMC_JSON = _newest_profile("chain_pmc.json")
 
 
 def pmc_traffic(name=TRAFFIC_JSON):
@@ -249,7 +258,7 @@ def cpu_baseline(args, sc, opt, agg, cam, gpu_colors):
                 "rounding of the 4x4 inverse / projection; oracle_f32_vs_f64_* = the same effect between two evaluations of the oracle itself)" % (len(blocks), side, side))
 
 
-def train_leg(args, sc, opt, agg, cloud, rnd, cam, dev, steps=5, warmup=2):
+def train_leg(args, sc, opt, agg, cloud, rnd, cam, dev, steps=20, warmup=3):
     """SURVEY 8d config C3 (fwd+bwd): one 56x56 = 3136-ray training batch (random window, jittered depths, patch drop) through
     the HIP forward + backward with the shipped loss terms.  Reported beside the headline metric, never part of `value`."""
     from hybridneuralrendering_amd import scenes
@@ -321,7 +330,9 @@ def train_leg(args, sc, opt, agg, cloud, rnd, cam, dev, steps=5, warmup=2):
         ms_w = e0.elapsed_time(e1) / 10
         issued = 3.0 * 2.0 * M8 * 256 * 288                                  # 3 fp16 MFMAs per fp32 product, K + 1 (bias column) padded to 9 tiles of 32
         # HBM bytes of the same kernel inside the step (PMC passes over tools/probe_train.py; only valid for the default C3 batch: 307 120 row slots)
-        t_wg = [v for k, v in pmc_traffic(TRAIN_TRAFFIC_JSON).items() if "h2wgrad_kernel<8, 9" in k] if M8 == 307120 else []
+        # PMC bytes of the 256-wide weight gradient (its launches inside the training step, profiles/<TRAIN_TRAFFIC_JSON>), selected by kernel name;
+        # the batch behind that file is this one up to the depth jitter (row slots within 1 %: `traffic_rows` beside it)
+        t_wg = [v for k, v in pmc_traffic(TRAIN_TRAFFIC_JSON).items() if "h2wgrad_kernel<8, 9" in k]
         roof_t = dict(kernel="h2wgrad_kernel<8,9,8,1> + reduce (dW = dZ^T X, db of one 256 x 256 per-neighbour layer; M = %d row slots)" % M8, bound="hbm",
                       achieved=round(M8 * 2048.0 / (ms_w * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(M8 * 2048.0 / (ms_w * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                       traffic=int(t_wg[0]["hbm_bytes"]) if t_wg else None,
@@ -512,23 +523,26 @@ def main():
                 variant = os.environ.get("HNR_CHAIN_RT", "16")
                 kname = {"16": "chain_ws_kernel", "4": "chain_kernel<4"}.get(variant, "chain_ws_kernel")
                 t_ch = [v for k, v in pmc.items() if kname in k]
+                alg8d = 542720.0 * n_rows                                                        # 2 x 256 x (284 + 256 + 263 + 256) + 2 x 256 flop per valid neighbour
+                ach_alg = alg8d / (ms_ch * 1e-3) / 1e12
                 roof = dict(kernel="%s: block1 -> block3 -> alpha + K-sums fused (1 launch, %d valid neighbour rows in %d padded rows)" % (
                                 {"chain_ws_kernel": "chain_ws_kernel<0> (weight-stationary, epilogue pieces between the wave's own MFMAs)"}.get(kname, kname), n_rows, rows_pad),
-                            bound="mfma", achieved=round(ach, 1), peak=BF16_MFMA_PEAK_TF, unit="TFLOP/s", frac=round(ach / BF16_MFMA_PEAK_TF, 4),
-                            frac_issued=round(ach / BF16_MFMA_PEAK_TF, 4),
-                            frac_algorithmic=round(alg / (ms_ch * 1e-3) / 1e12 / BF16_MFMA_PEAK_TF, 4),
+                            bound="mfma", achieved=round(ach_alg, 1), peak=BF16_MFMA_PEAK_TF, unit="TFLOP/s", frac=round(ach_alg / BF16_MFMA_PEAK_TF, 4),
+                            achieved_issued=round(ach, 1), frac_issued=round(ach / BF16_MFMA_PEAK_TF, 4),
+                            frac_executed_fp32=round(alg / (ms_ch * 1e-3) / 1e12 / BF16_MFMA_PEAK_TF, 4),
                             traffic=int(t_ch[0]["hbm_bytes"]) if t_ch else None,
                             traffic_source=("profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)" % TRAFFIC_JSON) if t_ch else None,
-                            flops_per_launch=issued, avg_launch_ms=round(ms_ch, 4),
-                            fp32_equivalent_tflops=round(alg / (ms_ch * 1e-3) / 1e12, 2),
-                            algorithmic_flops_per_launch=alg,
+                            flops_per_launch=alg8d, flops_issued_per_launch=issued, avg_launch_ms=round(ms_ch, 4),
+                            fp32_equivalent_tflops=round(ach_alg, 2),
+                            executed_fp32_flops_per_launch=alg,
                             algorithmic_bytes_per_launch=int(n_rows * 168 + n_valid * 1028),
-                            note="achieved = 16-bit MFMA flops issued (3 per fp32 product: wm*xh + wh*xm + wh*xh, fp16 two-term split with exact power-of-two "
-                                 "row / layer scales, fp32 accumulate) / HIP-event time of the launch, against the 2.5 PFLOP/s dense 16-bit peak; "
-                                 "frac_algorithmic = 2 M N K fp32 flops of the four layers on the VALID rows / time / the same peak; algorithmic bytes = "
-                                 "168 B per valid neighbour (SURVEY 8d) + 1028 B of sums per valid sample; padding to 8 row slots per sample "
-                                 "(4 for the %d samples with three or four neighbours, 2 for the %d with one or two) costs %.1f %% extra rows" % (
-                                     n_small, n_tiny, 100.0 * (rows_pad / max(n_rows, 1) - 1.0)),
+                            note="achieved / frac = ALGORITHMIC flops (SURVEY 8d: 542 720 per valid neighbour, block1.0 counted with all 284 input columns) / HIP-event "
+                                 "time of the launch / the 2.5 PFLOP/s dense 16-bit peak.  achieved_issued / frac_issued = 16-bit MFMA flops issued (3 per fp32 product: "
+                                 "wm*xh + wh*xm + wh*xh, fp16 two-term split with exact power-of-two row / layer scales, fp32 accumulate; K and row-slot padding) -- what "
+                                 "the matrix pipe does, the figure mfma_busy corroborates.  frac_executed_fp32 = 2 M N K of the layers as executed (224 of block1.0's columns "
+                                 "live in the per-point table) on the valid rows.  algorithmic bytes = 168 B per valid neighbour (SURVEY 8d) + 1028 B of sums per valid "
+                                 "sample; padding to 8 row slots per sample (4 for the %d samples with three or four neighbours, 2 for the %d with one or two) costs "
+                                 "%.1f %% extra rows" % (n_small, n_tiny, 100.0 * (rows_pad / max(n_rows, 1) - 1.0)),
                             neighbour_stage=dict(chain_ms=round(ms_ch, 3), gather_ms=round(stage_ms.get("chain_gather", 0.0), 3)))
                 try:
                     pm = json.load(open(os.path.join(ROOT, "profiles", CHAIN_PMC_JSON)))
@@ -607,6 +621,27 @@ def main():
             rnd._rec_key = None
             rnd.point_records(cloud)
         amort["point_records_ms"] = _timed(_records)
+        # same-run anchor for `dtype: f32`: the identical frame with every per-neighbour layer on fp32 MFMA (HNR_DENSE=f32: v_mfma_f32_32x32x2_f32,
+        # per-stage calls), one warm-up + one timed frame, and its largest colour difference from the f16x2 frame of the timed region
+        f32_anchor = None
+        if world == 1 and fused and not emulate and not getattr(args, "no_f32_anchor", False):
+            from hybridneuralrendering_amd.render import HybridRenderer
+            old_env = os.environ.get("HNR_DENSE")
+            os.environ["HNR_DENSE"] = "f32"
+            try:
+                rnd32 = HybridRenderer(opt, agg, dev)
+                rnd32.knn_order = rnd.knn_order
+                render_frame(rnd32, cloud, cam, sc, args.chunk)
+                torch.cuda.synchronize(); ta = time.perf_counter()
+                col32, _ = render_frame(rnd32, cloud, cam, sc, args.chunk)
+                torch.cuda.synchronize()
+                f32_anchor = dict(fp32_mfma_ms_per_step=round((time.perf_counter() - ta) * 1e3, 3),
+                                  max_abs_vs_f16x2_frame=float((col32 - col).abs().max()),
+                                  note="HNR_DENSE=f32: the per-neighbour layers as four fp32-MFMA launches (the round-1 path, parity-tested); same frame, same process")
+                del rnd32, col32
+            finally:
+                if old_env is None: os.environ.pop("HNR_DENSE", None)
+                else: os.environ["HNR_DENSE"] = old_env
         cpu = None
         if not args.no_cpu_baseline and world == 1:          # reported at N=1 only (rank 0)
             cpu = cpu_baseline(args, sc, opt, agg, cam, col.cpu().numpy())
@@ -631,6 +666,7 @@ def main():
                                        "one frame per rank x%d, one RCCL gather") % world},
             "gather_ms": (round(sum(a.elapsed_time(b) for a, b in gather_ev) / max(len(gather_ev), 1), 4) if gather_ev else None),
             "per_rank_ms_per_step": per_rank_ms, "status_words_checked": len(statuses),
+            "fp32_mfma_anchor": f32_anchor,
             "roofline": roof, "roofline_query": roof_q, "roofline_train": (train or {}).get("roofline_train"), "cpu_baseline": cpu,
             "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
             "amortised_ms": amort, "train_step": train, "grid": rnd.querier.last_grid_stats,

@@ -395,7 +395,7 @@ __global__ __launch_bounds__(512, 1) void h2wgrad_kernel(H2WgradArgs a)
     auto load_slot = [&](long long blk, int it, float4 &v) {
         const bool isx = (s_keep[it] & 16u) != 0;
         long long m = blk * RB + (s_rc[it] >> 16);
-        m = m < M ? m : M - 1;                                                  // rows past the end re-read the last row (masked when stored)
+        m = m < M ? m : (M > 0 ? M - 1 : 0);                                    // rows past the end re-read the last row (masked when stored); M = 0: row 0 of the (capacity-sized) operands
         int q = 0;
 #pragma unroll
         for (int sv = 1; sv < 8; ++sv) q += (sv < a.n_seg && m >= (long long)sv * n_unit) ? 1 : 0;
@@ -672,13 +672,15 @@ extern "C" int hnr_h2wgrad(const float *d_dZ, int ldz, const float *d_X, int ldx
     if (NT == NT_ && KT == KT_ && !biasv && !(NT_ == 8 && KT_ == 9)) {                                                                                                       \
         constexpr int rsz = ((32 * NT_ * 2 - 64 + 255) & ~255) + 64, rsx = ((32 * KT_ * 2 - 64 + 255) & ~255) + 64;                     \
         constexpr int ldsb = 3 * (2 * 16 * rsz + 2 * 16 * rsx);                                                                    \
-        HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(h2wgrad_kernel<NT_, KT_, 8 / NT_>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb)); \
+        static PerDeviceOnce once_;                                                                                                     \
+        if (once_.first()) HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(h2wgrad_kernel<NT_, KT_, 8 / NT_>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb)); \
         h2wgrad_kernel<NT_, KT_, 8 / NT_><<<grid, 512, ldsb, st>>>(a);                                                                  \
     }
     const bool biasv = false;
     if (NT == 8 && KT == 9) {
         constexpr int rsz = ((32 * 8 * 2 - 64 + 255) & ~255) + 64, rsx = ((32 * 9 * 2 - 64 + 255) & ~255) + 64, ldsb = 3 * (2 * 16 * rsz + 2 * 16 * rsx);
-        HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(h2wgrad_kernel<8, 9, 1, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb));
+        static PerDeviceOnce once89;
+        if (once89.first()) HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(h2wgrad_kernel<8, 9, 1, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb));
         h2wgrad_kernel<8, 9, 1, 0, 1><<<grid, 512, ldsb, st>>>(a);
     }
     HNR_H2WG_CASE(8, 9) HNR_H2WG_CASE(8, 8) HNR_H2WG_CASE(8, 2) HNR_H2WG_CASE(4, 9) HNR_H2WG_CASE(4, 5) HNR_H2WG_CASE(2, 9) HNR_H2WG_CASE(2, 5) HNR_H2WG_CASE(2, 3) HNR_H2WG_CASE(2, 2)

@@ -13,6 +13,7 @@
 // Dense layers: forward = the fused f16x2 kernels of the render path (csrc/chain.hip in its activation-keeping form, csrc/mlp.hip);
 // input gradients = hnr_h2lin with the transposed weights, weight / bias gradients = hnr_h2wgrad (csrc/h2gemm.hip); the weights change every
 // step, so their kernel images are re-packed at the top of each call.
+#include <mutex>
 #include <limits.h>
 
 #include "chain_defs.h"
@@ -383,16 +384,17 @@ int check_params(const hnr_train_params *p, const char *who)
 
 #define TR(call) do { int rc_ = (call); if (rc_ != HNR_OK) return rc_; } while (0)
 
-// Side stream of the library (one process per GPU: created once): the reference-view CNN's forward runs on it beside the query and the
-// per-neighbour chain, its backward beside the backward stages 7 - 11 -- both are strings of small latency-bound kernels whose results are
-// needed late (forward) or not at all downstream (backward); a second one packs the step's weight images while the query runs.  Forked from /
-// joined to the caller's stream with events inside each call.  (Not on a side stream: the weight-gradient GEMMs.  Forked behind per-layer events they
-// bought 0.12 ms, but 1 step in 10 then came out different: with all six small per-sample GEMMs queued on the side stream, train_ksum_bwd_kernel --
-// on the caller's stream, with bit-identical inputs -- wrote one row of one or two samples with the .x / .z components of lanes 48..63 changed.
-// Every weight gradient alone beside the chain was clean, any five of the six were clean, standalone pairs of the kernels are clean
-// (tools/race_pair.py): no dependency is missing in the step, so this looks like the platform under three busy queues -- not shipped.  The shipped
-// configuration ran 1200 steps without a differing bit, tools/race_probe.py.)
-// HNR_TRAIN_SIDE=0: everything in line on the caller's stream.
+// Side streams of the library, per device (created at the first training call on that device).  HNR_TRAIN_SIDE is a bit mask, default 15:
+//   bit 0 (1): the reference-view CNN on `stream` -- its forward beside the query and the per-neighbour chain, its backward (pixel scatter, upsample,
+//              conv pyramid) beside the backward stages 7 - 11: strings of small latency-bound kernels whose results are needed late / not at all downstream;
+//   bit 1 (2): the backward call's buffer clears on `stream`;
+//   bit 2 (4): ALL fifteen weight-gradient GEMMs (hnr_h2wgrad) on `stream`, each behind an event recorded after the kernel that wrote its dZ (the stream is
+//              in order, so they share one partial-sum scratch) -- shipped: 4.9 -> 4.65 ms per step, 6 000 + 16 000 repeated steps bit-identical;
+//   bit 3 (8): the step's weight-image packs (forward images, the backward's transposed images, the per-point table image) on `stream_w`, the pack stream;
+//   bit 4 (16, opt-in): the image branch's backward on the pack stream instead -- three busy queues.  An earlier three-queue arrangement (weight
+//              gradients on the pack stream) made ~1 step in 10 differ (train_ksum_bwd_kernel, lanes 48..63; profiles/README.md) and was never
+//              explained; this one soaked clean (22 000 steps) but stays opt-in.
+// Forked from / joined to the caller's stream with events inside each call.  HNR_TRAIN_SIDE=0: everything in line on the caller's stream.
 struct TrainSide {
     hipStream_t stream = nullptr, stream_w = nullptr;                     // image branch / clears; weight packs
     hipEvent_t fork_f = nullptr, join_f = nullptr, fork_b = nullptr, join_b = nullptr, fork_z = nullptr, join_z = nullptr, fork_g = nullptr, ev_w[3] = {};
@@ -406,10 +408,15 @@ struct TrainSideGuard {
 };
 TrainSide &train_side()
 {
-    static TrainSide t;
+    static TrainSide per_dev[64];                                          // one process per GPU is the deployment; a second device in the process gets its own streams
+    static std::mutex mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    std::lock_guard<std::mutex> lock(mu);
+    TrainSide &t = per_dev[dev];
     if (t.on < 0) {
         const char *e = getenv("HNR_TRAIN_SIDE");
-        t.on = e ? atoi(e) : 15;                                         // bit 0: image branch (forward + backward), 1: clears, 2: weight gradients, 3: weight packs, 4 (opt-in): the image branch's backward on the pack stream
+        t.on = e ? atoi(e) : 15;                                         // see the bit list above
         if (t.on && (hipStreamCreateWithFlags(&t.stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&t.fork_f, hipEventDisableTiming) != hipSuccess ||
                      hipEventCreateWithFlags(&t.join_f, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&t.fork_b, hipEventDisableTiming) != hipSuccess ||
                      hipEventCreateWithFlags(&t.join_b, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&t.fork_z, hipEventDisableTiming) != hipSuccess ||

@@ -58,7 +58,18 @@ class _ShippedLoss(torch.autograd.Function):
 
 
 def _fw(frame_weight):
-    return 1.0 if frame_weight is None else float(torch.as_tensor(frame_weight).reshape(-1)[0])
+    """The dataset item's scalar loss weight (models/base_rendering_model.py:1205) as a Python float.  A device tensor is refused: reading it
+    would be a host synchronisation inside the training step (convert it once where the item is loaded)."""
+    if frame_weight is None:
+        return 1.0
+    if isinstance(frame_weight, torch.Tensor):
+        if frame_weight.is_cuda:
+            raise HnrError("frame_weight (the item's scalar loss weight) must be a Python float or a CPU tensor, not a device tensor: "
+                           "the per-view weights of the feature merge are `frame_weight_nearest`")
+        if frame_weight.numel() != 1:
+            raise HnrError("frame_weight is the item's scalar loss weight (1 value), got %d values" % frame_weight.numel())
+        return float(frame_weight.reshape(-1)[0])
+    return float(frame_weight)
 
 
 def shipped_loss(coarse_raycolor, conf_coefficient, gt_image, ray_mask, zero_epsilon, w_color=1.0, w_zero_one=1e-4, frame_weight=None, conf_rows=False):

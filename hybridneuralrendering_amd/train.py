@@ -183,7 +183,10 @@ class TrainPath:
         S.vw, S.vw_t = None, None
         if V > 0:
             w2c = torch.inverse(c2w_nearest).contiguous()          # 4x4 plumbing op (neural_points_volumetric_model.py:250)
-            fw = None if frame_weight is None else g(frame_weight, "frame_weight", torch.float32).reshape(-1)
+            fw = None if frame_weight is None else g(frame_weight, "frame_weight_nearest", torch.float32).reshape(-1)
+            if fw is not None and fw.numel() != V:
+                raise HnrError("frame_weight_nearest must hold one weight per reference view (%d), got %d values -- the item's scalar loss weight "
+                               "`frame_weight` is a different input (train_step(frame_weight=...))" % (V, fw.numel()))
             S.vw_t = (w2c, intrinsic_nearest, campos_nearest, img, fw)
             S.vw = _lib.TrainViews(p(w2c), p(intrinsic_nearest), p(campos_nearest), p(img), p(fw) if fw is not None else None)
         lut = flags = None
@@ -315,11 +318,16 @@ def render_train(path, aggregator, xyz, emb, conf, pdir, color, raydir, campos, 
 
 def train_step(path, aggregator, xyz, emb, conf, pdir, color, raydir, campos, camrot, bg_color, near, far, c2w_nearest, campos_nearest,
                intrinsic_nearest, images_nearest, gt_image, zero_epsilon=1e-3, w_color=1.0, w_zero_one=1e-4, frame_weight=None, tmid=None,
-               ray_drop=None, assign_grads=True):
+               ray_drop=None, assign_grads=True, frame_weight_nearest=None):
     """forward -> shipped loss terms -> backward of one ray batch as three groups of library launches queued back to back: no autograd
     graph, no masked copies, nothing read back to the host -- the body of the reference's optimize_parameters before its optimizer steps
     (models/neural_points_volumetric_model.py:202-214: self.forward(); loss_total.backward(), with compute_losses of
     models/base_rendering_model.py:1060-1245 in between).  Same arithmetic as render_train + losses.shipped_loss + loss.backward().
+
+    The reference has TWO frame-weight inputs and so has this call: `frame_weight` is the dataset item's scalar that multiplies loss_total
+    (models/base_rendering_model.py:1205; a Python float or a CPU tensor -- converted once, no device read in the step) and
+    `frame_weight_nearest` [V] / [1,V] the per-reference-view weights of the image-feature merge under downweight_blurry_feats
+    (models/aggregators/point_aggregators.py:1203), a device tensor that only the forward / backward calls read.
 
     emb/conf/pdir/color and the aggregator's parameters are read as they are; with assign_grads their .grad fields are set (or added to,
     as autograd does).  Returns (outputs dict with `loss` = {total, colour MSE, zero-one mean, valid rays} on the device,
@@ -327,7 +335,7 @@ def train_step(path, aggregator, xyz, emb, conf, pdir, color, raydir, campos, ca
     from .losses import shipped_loss_grads
     cloud = PointCloud(xyz, emb.detach(), conf.detach(), pdir.detach(), color.detach())
     out, S = path.forward(cloud, raydir, campos, camrot, bg_color, near, far, c2w_nearest, campos_nearest, intrinsic_nearest, images_nearest,
-                          frame_weight=frame_weight, tmid=tmid, ray_drop=ray_drop)
+                          frame_weight=frame_weight_nearest, tmid=tmid, ray_drop=ray_drop)
     parts, g_col, g_cc = shipped_loss_grads(out["coarse_raycolor"], out["conf_coefficient"], gt_image, out["ray_mask"], zero_epsilon, w_color,
                                             w_zero_one, frame_weight, conf_rows=True)
     pg, ag = path.backward(S, g_col, g_cc)

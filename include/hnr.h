@@ -591,7 +591,7 @@ int hnr_render_forward(const hnr_grid *grid, const hnr_render_params *p, const h
  * outside the batch's points).  Per-point sums are formed in a fixed order: bit-identical gradients run to run.
  *   d_drop_lut [R] u8 (optional): patch-drop pattern indexed by VALID-ray row (drop_patch_rays, point_aggregators.py:14-23, :1225-1233);
  *   d_ray_drop [R] u8 (optional, wins): explicit per-ray flags (a rank's slice of a batch-wide pattern); both are ANDed with ray_mask.
- * `out` as for hnr_render_forward (padded query outputs; d_blend_weight, d_weight, d_conf_coefficient required; stage_events ignored);
+ * `out` as for hnr_render_forward (padded query outputs; d_blend_weight, d_weight, d_conf_coefficient required; stage_events: optional HIP events recorded at the stage boundaries, as in hnr_render_forward -- bench.py reads them);
  * d_status[0] = 1 when cap_samples was exceeded (R * SR always suffices). */
 typedef struct {
     int   R, SR, K, D;

@@ -244,8 +244,8 @@ def ray_march(rd, ray_valid, feats, bg_color):
 
 
 def render(xyz, emb, conf, pdir, color, sd, q, campos, camrotc2w, raydir_all, bg_color, c2w_nearest, campos_nearest,
-           intrinsic_nearest, images_nearest, vsize, raydist_mode_unit=1, is_train=False, drop_ray_rows=None, use_nearest=4):
-    """NeuralPointsRayMarching.forward (:257-391) after the query, + fill_invalid (:87-126).
+           intrinsic_nearest, images_nearest, vsize, raydist_mode_unit=1, is_train=False, drop_ray_rows=None, use_nearest=4, frame_weight_n=None):
+    """NeuralPointsRayMarching.forward (:257-391) after the query, + fill_invalid (:87-126).  frame_weight_n [1,V]: downweight_blurry_feats.
 
     q: dict(sample_pidx [R',SR,K], sample_loc_w [R',SR,3], ray_mask [R]) numpy or tensors (the query 7-tuple core).
     All other arguments are torch CPU tensors shaped like the reference's inputs (leading batch dim 1)."""
@@ -257,7 +257,7 @@ def render(xyz, emb, conf, pdir, color, sd, q, campos, camrotc2w, raydir_all, bg
     g = gather_points(xyz, emb, conf, pdir, color, pidx, camrotc2w, campos)
     loc_i, dvd = project_nearest(loc_w, campos, c2w_nearest, campos_nearest, intrinsic_nearest)
     a = aggregate(g, sample_loc, loc_w, dirs, sd, loc_i, dvd, images_nearest, is_train=is_train, drop_ray_rows=drop_ray_rows,
-                  use_nearest=use_nearest)
+                  use_nearest=use_nearest, frame_weight_n=frame_weight_n)
     rd = ray_dist(sample_loc, a["ray_valid"], vsize[2], raydist_mode_unit)
     m = ray_march(rd, a["ray_valid"], a["decoded"], bg_color)
     out = dict(coarse_raycolor=m["ray_color"], coarse_point_opacity=m["opacity"], coarse_is_background=m["background_transmission"],
@@ -303,8 +303,10 @@ def shipped_loss(full_raycolor, ray_mask, conf_coefficient, gt, zero_epsilon, w_
 
 
 def train_step(xyz, emb, conf, pdir, color, sd, q, campos, camrotc2w, raydir_all, bg_color, c2w_nearest, campos_nearest,
-               intrinsic_nearest, images_nearest, vsize, gt, zero_epsilon, drop_ray_rows, raydist_mode_unit=1, dtype=None, use_nearest=4):
-    """Forward in train mode + autograd of shipped_loss.  Returns (outputs, loss triple, grads dict) with grads keyed
+               intrinsic_nearest, images_nearest, vsize, gt, zero_epsilon, drop_ray_rows, raydist_mode_unit=1, dtype=None, use_nearest=4,
+               frame_weight=None, frame_weight_n=None):
+    """Forward in train mode + autograd of shipped_loss.  frame_weight: the item's scalar on loss_total (models/base_rendering_model.py:1204-1205);
+    frame_weight_n [1,V]: the per-view weights of the image-feature merge (models/aggregators/point_aggregators.py:1202-1203).  Returns (outputs, loss triple, grads dict) with grads keyed
     `neural_points.points_*` and `aggregator.<param>` like the reference's named parameters.
     dtype=torch.float64 re-runs the same graph in double precision (the query result q is kept): the yardstick for how much
     of a gradient difference is fp32 rounding noise."""
@@ -316,7 +318,8 @@ def train_step(xyz, emb, conf, pdir, color, sd, q, campos, camrotc2w, raydir_all
         try:
             return train_step(c(xyz), c(emb), c(conf), c(pdir), c(color), {k: c(v) for k, v in sd.items()}, q, c(campos), c(camrotc2w),
                               c(raydir_all), c(bg_color), c(c2w_nearest), c(campos_nearest), c(intrinsic_nearest), c(images_nearest),
-                              vsize, c(gt), zero_epsilon, drop_ray_rows, raydist_mode_unit, use_nearest=use_nearest)
+                              vsize, c(gt), zero_epsilon, drop_ray_rows, raydist_mode_unit, use_nearest=use_nearest, frame_weight=frame_weight,
+                              frame_weight_n=c(frame_weight_n))
         finally:
             torch.set_default_dtype(old)
     leaves = dict(emb=emb.clone().requires_grad_(True), conf=conf.clone().requires_grad_(True),
@@ -324,8 +327,10 @@ def train_step(xyz, emb, conf, pdir, color, sd, q, campos, camrotc2w, raydir_all
     sdl = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     out = render(xyz, leaves["emb"], leaves["conf"], leaves["pdir"], leaves["color"], sdl, q, campos, camrotc2w, raydir_all,
                  bg_color, c2w_nearest, campos_nearest, intrinsic_nearest, images_nearest, vsize, raydist_mode_unit,
-                 is_train=True, drop_ray_rows=drop_ray_rows, use_nearest=use_nearest)
+                 is_train=True, drop_ray_rows=drop_ray_rows, use_nearest=use_nearest, frame_weight_n=frame_weight_n)
     loss, lc, lz = shipped_loss(out["full_coarse_raycolor"], out["ray_mask"], out["conf_coefficient"], gt, zero_epsilon)
+    if frame_weight is not None:
+        loss = loss * frame_weight
     loss.backward()
     grads = {"neural_points.points_embeding": leaves["emb"].grad, "neural_points.points_conf": leaves["conf"].grad,
              "neural_points.points_dir": leaves["pdir"].grad, "neural_points.points_color": leaves["color"].grad}
