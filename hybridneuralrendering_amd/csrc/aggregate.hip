@@ -479,20 +479,8 @@ __global__ __launch_bounds__(256) void proj_rows_kernel(ProjArgs a)
     const int s = (int)(rowi - (int64_t)v * n_valid);
     const float *p = a.loc_w + (size_t)a.vs_item[s] * 3;
     const float x = p[0], y = p[1], z = p[2];
-    const float *m = a.w2c + 16 * v;
-    float c[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) c[j] = x * m[4 * j] + y * m[4 * j + 1] + z * m[4 * j + 2] + m[4 * j + 3];
-    float i3[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) i3[j] = c[0] * a.Kmat[3 * j] + c[1] * a.Kmat[3 * j + 1] + c[2] * a.Kmat[3 * j + 2];
-    const float den = i3[2] + 1e-10f;
-    const float fx = i3[0] / den, fy = i3[1] / den;
-    // .to(torch.int32): truncation toward zero; out-of-range / NaN -> invalid
-    int px = (fx > -2.0e9f && fx < 2.0e9f) ? (int)fx : -1;
-    int py = (fy > -2.0e9f && fy < 2.0e9f) ? (int)fy : -1;
-    const bool inval = px < 0 || px >= a.W || py < 0 || py >= a.H;
-    if (inval) { px = 0; py = 0; }
+    int px, py;
+    const bool inval = hnr_project_pixel(x, y, z, a.w2c + 16 * v, a.Kmat, a.W, a.H, px, py);
     const size_t row = (size_t)v * a.cap + s;
     float *o = a.X6 + row * a.ld6;
     const float *f = a.fm + (((size_t)v * a.H + py) * a.W + px) * 48;
@@ -522,6 +510,21 @@ __global__ __launch_bounds__(256) void proj_rows_kernel(ProjArgs a)
         o[dcol + sub] = nea - cur;
     }
     if (sub == 0) a.vmask[row] = inval ? 0.f : 1.f;
+    }
+}
+
+// Probe: the pixel every (view, valid sample) row of the merge stage gathers -- the same hnr_project_pixel the merge kernels call.
+__global__ __launch_bounds__(256) void proj_pixels_kernel(const float *loc_w, const int32_t *vs_item, const unsigned long long *counts, const float *w2c, const float *Kmat,
+                                                          int V, int H, int W, int cap, int32_t *pix)
+{
+    const int n_valid = (int)counts[HNR_CNT_SAMPLES_VALID] < cap ? (int)counts[HNR_CNT_SAMPLES_VALID] : cap;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < (int64_t)V * n_valid; t += (int64_t)gridDim.x * blockDim.x) {
+        const int v = (int)(t / n_valid), s = (int)(t - (int64_t)v * n_valid);
+        const float *p = loc_w + (size_t)vs_item[s] * 3;
+        int px, py;
+        const bool inval = hnr_project_pixel(p[0], p[1], p[2], w2c + 16 * v, Kmat, W, H, px, py);
+        int32_t *o = pix + ((size_t)v * cap + s) * 2;
+        o[0] = inval ? -1 : px; o[1] = inval ? -1 : py;
     }
 }
 
@@ -1096,6 +1099,20 @@ extern "C" int hnr_proj_rows(const float *d_sample_loc_w, const int32_t *d_vs_it
     a.w2c = d_w2c; a.Kmat = d_intrinsic; a.campos = d_campos; a.campos_n = d_campos_nearest; a.fm = d_featmap; a.H = H; a.W = W;
     a.CF = d_CF; a.ldcf = ldcf; a.V = V; a.cap = cap_samples; a.X6 = d_X6; a.ld6 = ld6; a.vmask = d_vmask; a.row_sample = d_row_sample;
     { const int need = cdiv((int64_t)V * cap_samples * 16, 256); proj_rows_kernel<<<need < 8192 ? need : 8192, 256, 0, (hipStream_t)stream>>>(a); }
+    HNR_LAUNCH_CHECK();
+    return HNR_OK;
+}
+
+extern "C" int hnr_proj_pixels(const float *d_sample_loc_w, const int32_t *d_vs_item, const int64_t *d_counts, const float *d_w2c,
+                               const float *d_intrinsic, int V, int H, int W, int cap_samples, int32_t *d_pix, void *stream)
+{
+    if (!d_sample_loc_w || !d_vs_item || !d_counts || !d_w2c || !d_intrinsic || !d_pix || V <= 0 || H <= 0 || W <= 0) {
+        set_error("hnr_proj_pixels: bad argument"); return HNR_ERR_BADARG;
+    }
+    if (cap_samples <= 0) return HNR_OK;
+    const int need = cdiv((int64_t)V * cap_samples, 256);
+    proj_pixels_kernel<<<need < 8192 ? need : 8192, 256, 0, (hipStream_t)stream>>>(d_sample_loc_w, d_vs_item, reinterpret_cast<const unsigned long long *>(d_counts), d_w2c,
+                                                                                      d_intrinsic, V, H, W, cap_samples, d_pix);
     HNR_LAUNCH_CHECK();
     return HNR_OK;
 }

@@ -385,19 +385,8 @@ __global__ __launch_bounds__(1024) void proj_rows_bwd_kernel(ProjBwdArgs a)
         const int s = (int)(t - (int64_t)v * n_valid);
         const float *p = a.loc_w + (size_t)a.vs_item[s] * 3;
         const float x = p[0], y = p[1], z = p[2];
-        const float *m = a.w2c + 16 * v;
-        float c[3];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) c[j] = x * m[4 * j] + y * m[4 * j + 1] + z * m[4 * j + 2] + m[4 * j + 3];
-        float i3[3];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) i3[j] = c[0] * a.Kmat[3 * j] + c[1] * a.Kmat[3 * j + 1] + c[2] * a.Kmat[3 * j + 2];
-        const float den = i3[2] + 1e-10f;
-        const float fx = i3[0] / den, fy = i3[1] / den;
-        px = (fx > -2.0e9f && fx < 2.0e9f) ? (int)fx : -1;
-        py = (fy > -2.0e9f && fy < 2.0e9f) ? (int)fy : -1;
         // masked row: reads the zeroed pixel (0,0), no gradient; the feature at (0,0) is the constant 0 (:1089)
-        none = px < 0 || px >= a.W || py < 0 || py >= a.H || (px == 0 && py == 0);
+        none = hnr_project_pixel(x, y, z, a.w2c + 16 * v, a.Kmat, a.W, a.H, px, py) || (px == 0 && py == 0);
         a.keys[(size_t)v * a.cap + s] = none ? -1 : (v * a.H + py) * a.W + px;
     }
     // bounds of the touched pixels per view: wave reduction (the lanes of a wave almost always belong to one view: rows are view-major; the few

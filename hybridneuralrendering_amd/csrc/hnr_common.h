@@ -107,6 +107,29 @@ __device__ __forceinline__ int brick_bit(int x, int y, int z)
     return ((x & 3) << 4) | ((y & 3) << 2) | (z & 3);
 }
 
+// Reprojection of a world-space sample into reference view v + truncation to a pixel + bounds rule (models/neural_points_volumetric_model.py:248-255,
+// models/aggregators/point_aggregators.py:1077-1088): w2c row-major 4x4, Kmat row-major 3x3, every fp32 operation rounded separately in this order
+// (-ffp-contract=off), the divisions correctly rounded.  ONE text for every kernel that gathers reference-view pixels (merge stage fused / un-fused,
+// its backward, the hnr_proj_pixels probe): a sample within an ulp of a pixel border must land on the same pixel everywhere.  Returns `invalid`
+// (then px = py = 0, the zeroed pixel).
+__device__ __forceinline__ bool hnr_project_pixel(float x, float y, float z, const float *m, const float *Kmat, int W, int H, int &px, int &py)
+{
+    float c[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) c[q] = x * m[4 * q] + y * m[4 * q + 1] + z * m[4 * q + 2] + m[4 * q + 3];
+    float i3[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) i3[q] = c[0] * Kmat[3 * q] + c[1] * Kmat[3 * q + 1] + c[2] * Kmat[3 * q + 2];
+    const float den = i3[2] + 1e-10f;
+    const float fx = i3[0] / den, fy = i3[1] / den;
+    // .to(torch.int32): truncation toward zero; out-of-range / NaN -> invalid
+    px = (fx > -2.0e9f && fx < 2.0e9f) ? (int)fx : -1;
+    py = (fy > -2.0e9f && fy < 2.0e9f) ? (int)fy : -1;
+    const bool inval = px < 0 || px >= W || py < 0 || py >= H;
+    if (inval) { px = 0; py = 0; }
+    return inval;
+}
+
 }  // namespace hnr
 
 struct hnr_grid {

@@ -140,19 +140,8 @@ __global__ __launch_bounds__(256, mlp3_wgs_per_cu(S0, RT, MODE)) void mlp3_kerne
                 const float *pw = a.loc_w + (size_t)a.vs_item[sidx] * 3;
                 const float x = pw[0], y = pw[1], z = pw[2];
               if (tid < ROWS) {
-                const float *mm = a.w2c + 16 * v;
-                float c[3];
-#pragma unroll
-                for (int q = 0; q < 3; ++q) c[q] = x * mm[4 * q] + y * mm[4 * q + 1] + z * mm[4 * q + 2] + mm[4 * q + 3];
-                float i3[3];
-#pragma unroll
-                for (int q = 0; q < 3; ++q) i3[q] = c[0] * a.Kmat[3 * q] + c[1] * a.Kmat[3 * q + 1] + c[2] * a.Kmat[3 * q + 2];
-                const float den = i3[2] + 1e-10f;
-                const float fx = i3[0] / den, fy = i3[1] / den;
-                int px = (fx > -2.0e9f && fx < 2.0e9f) ? (int)fx : -1;
-                int py = (fy > -2.0e9f && fy < 2.0e9f) ? (int)fy : -1;
-                const bool inval = px < 0 || px >= a.W || py < 0 || py >= a.H;
-                if (inval) { px = 0; py = 0; }
+                int px, py;
+                const bool inval = hnr_project_pixel(x, y, z, a.w2c + 16 * v, a.Kmat, a.W, a.H, px, py);
                 s_pix[tid] = ((v * a.H + py) * a.W + px) * 48;
                 s_vm[tid] = inval ? 0.f : 1.f;
               } else {
@@ -600,19 +589,8 @@ __global__ __launch_bounds__(64 * MW_WAVES, 1) void merge_wp_kernel(MlpArgs a)
             const float *pw = a.loc_w + (size_t)a.vs_item[sidx] * 3;
             const float x = pw[0], y = pw[1], z = pw[2];
             if (h == 0) {
-                const float *mm = s_cam + 16 * v, *Km = s_cam + 64;
-                float c[3];
-#pragma unroll
-                for (int q = 0; q < 3; ++q) c[q] = x * mm[4 * q] + y * mm[4 * q + 1] + z * mm[4 * q + 2] + mm[4 * q + 3];
-                float i3[3];
-#pragma unroll
-                for (int q = 0; q < 3; ++q) i3[q] = c[0] * Km[3 * q] + c[1] * Km[3 * q + 1] + c[2] * Km[3 * q + 2];
-                const float den = i3[2] + 1e-10f;
-                const float fx = i3[0] / den, fy = i3[1] / den;
-                int px = (fx > -2.0e9f && fx < 2.0e9f) ? (int)fx : -1;
-                int py = (fy > -2.0e9f && fy < 2.0e9f) ? (int)fy : -1;
-                const bool inval = px < 0 || px >= a.W || py < 0 || py >= a.H;
-                if (inval) { px = 0; py = 0; }
+                int px, py;
+                const bool inval = hnr_project_pixel(x, y, z, s_cam + 16 * v, s_cam + 64, a.W, a.H, px, py);
                 s_pix[j] = ((v * a.H + py) * a.W + px) * 48;
                 s_vm[j] = inval ? 0.f : 1.f;
                 s_max[j] = 0u;

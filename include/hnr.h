@@ -271,6 +271,14 @@ int hnr_proj_rows(const float *d_sample_loc_w, const int32_t *d_vs_item, const i
                   int V, int H, int W, const float *d_CF, int ldcf, int cap_samples, float *d_X6, int ld6, float *d_vmask,
                   int32_t *d_row_sample, void *stream);
 
+/* Probe (parity evidence, not on the render path): the integer pixel every (view v, valid sample s) row of the merge stage gathers,
+ * d_pix[(v * cap_samples + s) * 2 + {0,1}] = (px, py), or (-1, -1) where the reference's bounds rule masks the row -- computed by the one
+ * device function (hnr_project_pixel, csrc/hnr_common.h) that hnr_proj_rows, hnr_merge_stage and hnr_proj_rows_bwd call, so that a test or
+ * bench.py can tell a sample that truncates to another pixel than the CPU oracle's projection (point_aggregators.py:1077-1078: `.to(torch.int32)`
+ * of a coordinate within an ulp of a pixel border) from an arithmetic difference. */
+int hnr_proj_pixels(const float *d_sample_loc_w, const int32_t *d_vs_item, const int64_t *d_counts, const float *d_w2c,
+                    const float *d_intrinsic, int V, int H, int W, int cap_samples, int32_t *d_pix, void *stream);
+
 /* Last layer + sigmoid of aux_merge_weight_block, weighted merge (:1199-1217) and the mix-up input (:1286-1292):
  *   d_X7[s, 0:90] = [colfeat[:45] | sum_v w_v f_v / (sum_v w_v + 1e-6)].  d_frame_w: optional [V].
  * d_ray_drop: optional [R] u8; samples on flagged rays get merged = 0 (train-time patch drop, :1222-1237; the caller

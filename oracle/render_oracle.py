@@ -90,6 +90,20 @@ def project_nearest(sample_loc_w, campos, c2w_nearest, campos_nearest, intrinsic
     return loc_i, torch.stack(dl)
 
 
+def gathered_pixels(sample_loc_w, c2w_nearest, intrinsic_nearest, H, W):
+    """The integer pixel (px, py) of every reference view that `aggregate` gathers for world positions sample_loc_w [R', SR, 3] (w2iproject :248-255, then
+    `.to(torch.int32)` + the bounds rule, point_aggregators.py:1077-1088); (-1, -1) where the rule masks the row.  Returns int64 [V, ..., 2].
+    Test infrastructure for the whole-frame check of bench.py: which rays gather the same pixels in the oracle and in the HIP path."""
+    V = c2w_nearest.shape[1]
+    out = []
+    for v in range(V):
+        li = w2iproject(sample_loc_w, intrinsic_nearest[0], c2w_nearest[0, v]).reshape(-1, 2)      # the shape `render` projects ([R', SR, 3]): same BLAS path
+        px, py = li[:, 0].to(torch.int32), li[:, 1].to(torch.int32)
+        inval = (px < 0) | (px >= W) | (py < 0) | (py >= H)
+        out.append(torch.stack([torch.where(inval, torch.full_like(px, -1), px), torch.where(inval, torch.full_like(py, -1), py)], dim=-1).long())
+    return torch.stack(out).reshape((V,) + tuple(sample_loc_w.shape[:-1]) + (2,))
+
+
 def _seq(x, sd, name, idxs, act_last=True, slope=0.01):
     """nn.Sequential of Linear(+LeakyReLU) with the reference's parameter names `<name>.<i>.weight`."""
     for j, i in enumerate(idxs):
@@ -288,18 +302,22 @@ def drop_patch_rays(patch_size, patch_num, drop_ratio):
     return np.where(flag.flatten() == 1)[0]
 
 
-def shipped_loss(full_raycolor, ray_mask, conf_coefficient, gt, zero_epsilon, w_color=1.0, w_zero_one=1e-4):
+def shipped_loss(full_raycolor, ray_mask, conf_coefficient, gt, zero_epsilon, w_color=1.0, w_zero_one=1e-4, frame_weight=None):
     """The two loss terms the shipped ScanNet scripts enable (dev_scripts/w_scannet_etf/scene241.sh:146-151):
     `ray_masked_coarse_raycolor` MSE (models/base_rendering_model.py:1113-1118) and the zero-one regulariser on
     conf_coefficient (:1228-1240).  Returns (total, color, zero_one).  The shell's compute_losses adds a constant 1e-6 per colour
-    loss item on top (:1198; no gradient) -- tests/golden/train_*.npz keeps its value as `loss_compute_losses`."""
+    loss item on top (:1198; no gradient) -- tests/golden/train_*.npz keeps its value as `loss_compute_losses`.  frame_weight: the item's scalar,
+    applied to loss_total after the colour items and BEFORE the zero-one items are added (:1204-1205 vs :1228-1240)."""
     m3 = (ray_mask > 0)[..., None].expand(-1, -1, 3)
     mo = torch.masked_select(full_raycolor, m3).reshape(1, -1, 3)
     mg = torch.masked_select(gt, m3).reshape(1, -1, 3)
     lc = F.mse_loss(mo, mg)
     val = torch.clamp(conf_coefficient, zero_epsilon, 1 - zero_epsilon)
     lz = torch.mean(torch.log(val) + torch.log(1 - val))
-    return lc * w_color + lz * w_zero_one, lc, lz
+    col = lc * w_color
+    if frame_weight is not None:
+        col = col * frame_weight
+    return col + lz * w_zero_one, lc, lz
 
 
 def train_step(xyz, emb, conf, pdir, color, sd, q, campos, camrotc2w, raydir_all, bg_color, c2w_nearest, campos_nearest,
@@ -328,9 +346,7 @@ def train_step(xyz, emb, conf, pdir, color, sd, q, campos, camrotc2w, raydir_all
     out = render(xyz, leaves["emb"], leaves["conf"], leaves["pdir"], leaves["color"], sdl, q, campos, camrotc2w, raydir_all,
                  bg_color, c2w_nearest, campos_nearest, intrinsic_nearest, images_nearest, vsize, raydist_mode_unit,
                  is_train=True, drop_ray_rows=drop_ray_rows, use_nearest=use_nearest, frame_weight_n=frame_weight_n)
-    loss, lc, lz = shipped_loss(out["full_coarse_raycolor"], out["ray_mask"], out["conf_coefficient"], gt, zero_epsilon)
-    if frame_weight is not None:
-        loss = loss * frame_weight
+    loss, lc, lz = shipped_loss(out["full_coarse_raycolor"], out["ray_mask"], out["conf_coefficient"], gt, zero_epsilon, frame_weight=frame_weight)
     loss.backward()
     grads = {"neural_points.points_embeding": leaves["emb"].grad, "neural_points.points_conf": leaves["conf"].grad,
              "neural_points.points_dir": leaves["pdir"].grad, "neural_points.points_color": leaves["color"].grad}

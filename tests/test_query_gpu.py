@@ -243,6 +243,59 @@ def test_sorted_neighbour_order_is_the_reference_set_in_ascending_distance(seed,
     assert (a != b).any()                                                                  # and it is not the reference's slot order
 
 
+def test_sorted_neighbour_order_with_exact_distance_ties(capsys):
+    """Exact d^2 ties (a cloud mirrored in z, camera and rays in the plane z = 0: every point and its mirror image are equidistant from every
+    sample, bit for bit).  knn_order = 0 replays the reference's insertion history slot for slot, ties included (first maximum evicted,
+    strict `<`: query_point_indices_worldcoords.py:493-513).  knn_order = 1 keeps the K smallest (d^2, enumeration order) keys: where two
+    equidistant points compete for the LAST place of a full list it may keep the other one of the pair (include/hnr.h) -- the
+    reference's own choice there depends on the order its atomics filled the cell lists in.  What must hold, and is asserted: the same
+    distances (the sorted d^2 lists are bit-identical to the oracle's), the same points wherever the distance is below the list's largest
+    one, and a point of the right distance in the tied places."""
+    from oracle import query_oracle as qo
+    from hybridneuralrendering_amd import querier as Q
+    rng = np.random.default_rng(3)
+    half, _ = scenes.room_cloud(20000, 3, size=(1.0, 0.8, 0.25), n_clutter=3, thickness=0.003)
+    half = half[np.abs(half[:, 2]) > 1e-4]
+    half[:, 2] = np.abs(half[:, 2])
+    xyz = np.ascontiguousarray(np.concatenate([half, half * np.array([1, 1, -1], np.float32)], axis=0).astype(np.float32))
+    n_half = half.shape[0]
+    hp = qo.hyperparameters(xyz, [0.008] * 3, [2, 2, 2], [3, 3, 3], [-10.0] * 3 + [10.0] * 3, 4.0)
+    campos = np.array([-0.3, -0.25, 0.0], np.float32)
+    ang = rng.uniform(0.15, 1.2, size=96).astype(np.float32)
+    rays = np.ascontiguousarray(np.stack([np.cos(ang), np.sin(ang), np.zeros_like(ang)], axis=1).astype(np.float32))
+    cs = dict(xyz=xyz, hp=hp, campos=campos, camrot=np.eye(3, dtype=np.float32), rays=rays, tmid=qo.tmid_table(0.05, 1.5, 200), P=26, max_o=100000, K=8, SR=24)
+    og, ref, g, res = _run_both(cs)
+    _assert_query_equal(ref, res, cs)                                                      # reference order: slot-exact, ties or not
+    d = _dev()
+    srt = Q.march_query(g, torch.from_numpy(campos).to(d), torch.from_numpy(rays).to(d), torch.from_numpy(np.ascontiguousarray(cs["tmid"])).to(d),
+                        cs["SR"], 8, hp["radius2"], [3, 3, 3], knn_order=1)
+    for k in ("ray_nsamp", "sample_loc_w", "ray_mask", "counts"):
+        assert torch.equal(srt[k], res[k]), k
+    a, b = srt["sample_pidx"].cpu().numpy().reshape(-1, 8), ref["full_pidx"].reshape(-1, 8)
+    loc = ref["full_loc"].reshape(-1, 3)
+    assert (loc[:, 2] == 0).all()
+    def dist2(ids):
+        dv = xyz[np.maximum(ids, 0)] - loc[:, None, :]
+        d2 = (dv[..., 0] * dv[..., 0] + dv[..., 1] * dv[..., 1]) + dv[..., 2] * dv[..., 2]
+        return np.where(ids >= 0, d2, np.float32(np.inf)).astype(np.float32)
+    da, db = dist2(a), dist2(b)
+    assert ((a >= 0).sum(axis=1) == (b >= 0).sum(axis=1)).all()
+    assert (da[:, :-1] <= da[:, 1:]).all()                                                 # ascending
+    np.testing.assert_array_equal(da, np.sort(db, axis=1))                                 # the same distances, bit for bit
+    kth = np.sort(db, axis=1)[:, -1:]                                                      # the list's largest distance (inf while it is not full)
+    inner_a = np.where(da < kth, a, -2); inner_b = np.where(db < kth, b, -2)
+    np.testing.assert_array_equal(np.sort(inner_a, axis=1), np.sort(inner_b, axis=1))      # the same points below it
+    full = (b >= 0).all(axis=1)
+    tied_inside = ((da[:, :-1] == da[:, 1:]) & np.isfinite(da[:, 1:])).any(axis=1)
+    partner = np.where(a >= n_half, a - n_half, a + n_half)
+    last_alone = full & ~(partner[:, -1:] == a).any(axis=1)                               # a full list whose last point's mirror image is not in it: a tie decided the last place (if the mirror image was a candidate)
+    differ = (np.sort(a, axis=1) != np.sort(b, axis=1)).any(axis=1)
+    assert tied_inside.sum() > 200 and last_alone.sum() > 20, (int(tied_inside.sum()), int(last_alone.sum()))
+    with capsys.disabled():
+        print("\n[k-NN ties] %d samples (%d full lists): %d with equidistant neighbours, %d full lists end on one point of a mirror pair, %d sets differ from the "
+              "reference-order replay (in tied last places only)" % (a.shape[0], int(full.sum()), int(tied_inside.sum()), int(last_alone.sum()), int(differ.sum())))
+
+
 def test_sorted_neighbour_order_bad_arguments():
     from hybridneuralrendering_amd import querier as Q
     from hybridneuralrendering_amd._lib import HnrError
