@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--margin", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-leg", action="store_true")
+    ap.add_argument("--train-sharded-only", action="store_true", help="of the training legs run only the C5 patch-sharded step (tools/predict_train_scaling.sh)")
     ap.add_argument("--no-f32-anchor", action="store_true", help="skip the one fp32-MFMA frame rendered beside the timed region (fp32_mfma_anchor)")
     ap.add_argument("--cpu-sample-rays", type=int, default=2304)
     ap.add_argument("--shard", choices=("lines", "blocks"), default="lines",
@@ -291,6 +292,108 @@ def cpu_baseline(args, sc, opt, agg, cam, gpu_colors):
                 "rounding of the 4x4 inverse / projection; oracle_f32_vs_f64_* = the same effect between two evaluations of the oracle itself)" % (len(blocks), side, side))
 
 
+def train_leg_sharded(args, sc, opt, agg, cloud, rnd, cam, dev, world, rank, rehearsal, emulate, steps=10, warmup=2):
+    """BASELINE config C5 the way it runs on N GPUs (models/mvs_points_volumetric_model.py:111-131, models/base_rendering_model.py:677-745): one batch of
+    49 dilated 8x8 patches (3136 rays, dilation_setup 7_8_1_6), the blur-handling module (12 symmetric 9x9 kernels) and the item's frame weight; the batch is
+    sharded by WHOLE patches (parallel.shard_patches), every rank runs forward + blur + loss + backward on its 6-7 patches with the replicated cloud and
+    weights, then the gradients are summed: the network's 449 k parameters as one flat all-reduce, the embedding gradient as (id, row) pairs of the touched
+    points (all-gather + local scatter-add), conf / dir / colour as dense all-reduces.  Timed with HIP events per part; max over ranks.
+    world == 1 and HNR_BENCH_EMULATE_RANK=r/n: rank r's share of an n-way split alone on this GPU, without the collectives, whose byte counts are
+    reported instead (tools/predict_train_scaling.sh)."""
+    import torch.distributed as dist
+    from hybridneuralrendering_amd import scenes, parallel
+    from hybridneuralrendering_amd.train import TrainPath, render_train
+    from hybridneuralrendering_amd.blur import blur_update_output
+    old_train, old_dil = opt.is_train, getattr(opt, "dilation_setup", None)
+    opt.is_train, opt.dilation_setup = 1, "7_8_1_6"
+    try:
+        pix, pn, ps = scenes.dilated_patch_batch(sc.w, sc.h, args.margin, opt.dilation_setup, seed=4)
+        S = pn * ps
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        rays_all = t(scenes.camera_rays(pix, sc.intrinsic, sc.c2w))
+        kern = t(scenes.blur_kernels_v2())[None]
+        g = torch.Generator().manual_seed(9)
+        gt = torch.rand((S * S, 3), generator=g).to(dev)
+        drop = parallel.global_drop_flags(pn, ps, opt.drop_ratio).to(dev)
+        frame_weight = 0.7
+        n_way, r_of = (world, rank)
+        if emulate and world == 1:
+            r_of, n_way = (int(x) for x in emulate.split("/"))
+        ids, ray_ids = parallel.shard_patches(pn, ps, n_way, r_of)
+        ray_ids = (torch.arange(S * S) if n_way == 1 else ray_ids).to(dev)       # one rank: the batch in its own (row-major) order
+        layout, n_patches = ("grid", pn) if n_way == 1 else ("patch_major", int(ids.numel()))
+        path = TrainPath(rnd)
+        leaves = [x.clone().requires_grad_(True) for x in (cloud.emb, cloud.conf, cloud.dir, cloud.color)]
+        for prm in agg.parameters():
+            prm.requires_grad_(True)
+        ev = lambda: torch.cuda.Event(enable_timing=True)
+        def one(timed=None):
+            for x in leaves:
+                x.grad = None
+            agg.zero_grad(set_to_none=True)
+            e = [ev() for _ in range(4)] if timed is not None else None
+            if e: e[0].record()
+            out = render_train(path, agg, cloud.xyz, leaves[0], leaves[1], leaves[2], leaves[3], rays_all[ray_ids], cam["campos"], cam["camrot"], cam["bg"],
+                               sc.near, sc.far, cam["c2w_nearest"], cam["campos_nearest"], cam["intrinsic"], cam["images"], ray_drop=drop[ray_ids])
+            col = blur_update_output(out["coarse_raycolor"][None], gt[ray_ids][None], kern, n_patches, ps, layout=layout)[0]
+            m = out["ray_mask"] > 0
+            loss = torch.nn.functional.mse_loss(col[m], gt[ray_ids][m]) * frame_weight * (float(ray_ids.numel()) / float(S * S))
+            loss.backward()
+            if e: e[1].record()
+            grads = [q.grad if q.grad is not None else torch.zeros_like(q) for q in agg.parameters()]
+            touched = torch.unique(out["sample_pidx"][out["sample_pidx"] >= 0]).long()
+            nbytes = dict(weights_allreduce=int(sum(x.numel() for x in grads) * 4), touched_points=int(touched.numel()),
+                          embedding_rows_allgather_per_rank=int(touched.numel() * (32 * 4 + 8)), dense_conf_dir_color_allreduce=int(sum(leaves[i].grad.numel() for i in (1, 2, 3)) * 4))
+            if world > 1:
+                if rehearsal:                                                   # gloo on host copies: control flow only
+                    host = [x.detach().cpu() for x in grads]
+                    parallel.allreduce_gradients(host)
+                    parallel.allreduce_point_gradients_sparse(leaves[0].grad.reshape(-1, 32).cpu(), touched.cpu())
+                    dense = [leaves[i].grad.detach().cpu().clone() for i in (1, 2, 3)]
+                    parallel.allreduce_gradients(dense)
+                else:
+                    parallel.allreduce_gradients(grads)
+                    if e: e[2].record()
+                    leaves[0].grad = parallel.allreduce_point_gradients_sparse(leaves[0].grad.reshape(-1, 32), touched).reshape(leaves[0].shape)
+                    parallel.allreduce_gradients([leaves[i].grad for i in (1, 2, 3)])
+            if e and (world == 1 or rehearsal): e[2].record()
+            if e: e[3].record()
+            if timed is not None: timed.append(e)
+            return out, nbytes
+        for _ in range(warmup):
+            out, nbytes = one()
+        if world > 1: dist.barrier()
+        torch.cuda.synchronize()
+        evs = []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out, nbytes = one(evs)
+        if world > 1: dist.barrier()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        comp = sum(e[0].elapsed_time(e[1]) for e in evs) / steps
+        ar_w = sum(e[1].elapsed_time(e[2]) for e in evs) / steps
+        ar_p = sum(e[2].elapsed_time(e[3]) for e in evs) / steps
+        tt = torch.tensor([dt, comp * 1e-3, ar_w * 1e-3, ar_p * 1e-3], dtype=torch.float64, device=dev)
+        if world > 1:
+            tt = tt.cpu() if rehearsal else tt
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt, comp, ar_w, ar_p = (float(x) for x in tt)
+        c = out["counts"].cpu().numpy()
+        return dict(workload="C5: %d dilated %dx%d patches (dilation_setup 7_8_1_6) = %d rays, blur module (12 kernels 9x9) + frame weight, fwd + bwd%s" % (
+                        pn * pn, ps, ps, S * S, "" if n_way == 1 else "; rank %d of %d: %d patches = %d rays" % (r_of, n_way, int(ids.numel()), int(ray_ids.numel()))),
+                    ms_per_step=round(dt * 1e3, 3), compute_ms=round(comp * 1e3, 3), allreduce_weights_ms=round(ar_w * 1e3, 3) if world > 1 and not rehearsal else None,
+                    allreduce_points_ms=round(ar_p * 1e3, 3) if world > 1 and not rehearsal else None, n_ranks=n_way, steps=steps,
+                    emulated_rank=("%d/%d on one GPU, no collectives" % (r_of, n_way)) if (emulate and world == 1) else None,
+                    valid_samples=int(c[6]), neighbour_rows=int(c[3]), collective_bytes=nbytes,
+                    note="max over ranks; collectives: parallel.allreduce_gradients (one flat bucket of the network's gradients; dense conf / dir / colour) + "
+                         "parallel.allreduce_point_gradients_sparse (all-gather of the touched points' embedding rows + local scatter-add)")
+    finally:
+        opt.is_train, opt.dilation_setup = old_train, old_dil
+        for prm in agg.parameters():
+            prm.requires_grad_(False)
+
+
 def train_leg(args, sc, opt, agg, cloud, rnd, cam, dev, steps=20, warmup=3):
     """SURVEY 8d config C3 (fwd+bwd): one 56x56 = 3136-ray training batch (random window, jittered depths, patch drop) through
     the HIP forward + backward with the shipped loss terms.  Reported beside the headline metric, never part of `value`."""
@@ -512,6 +615,9 @@ def main():
     dt = float(tmax.item())
     if rank == 0 and args.dump_colors:
         np.save(args.dump_colors, frame.detach().cpu().numpy())
+    train_sharded = None
+    if not args.no_train_leg:
+        train_sharded = train_leg_sharded(args, sc, opt, agg, cloud, rnd, cam, dev, world, rank, rehearsal, emulate)
 
     if rank == 0:
         counts = out["counts"].cpu().numpy() if args.chunk <= 0 or args.chunk >= R else None
@@ -679,7 +785,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:          # reported at N=1 only (rank 0)
             cpu = cpu_baseline(args, sc, opt, agg, cam, col.cpu().numpy())
         train = None
-        if world == 1 and not args.no_train_leg:
+        if world == 1 and not args.no_train_leg and not args.train_sharded_only:
             train = train_leg(args, sc, opt, agg, cloud, rnd, cam, dev)
         res = {
             "metric": "rays/sec (fwd render) scene0241_01 at 1/2/4/8 GPU; PSNR delta vs ref",
@@ -702,7 +808,7 @@ def main():
             "fp32_mfma_anchor": f32_anchor,
             "roofline": roof, "roofline_query": roof_q, "roofline_train": (train or {}).get("roofline_train"), "cpu_baseline": cpu,
             "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
-            "amortised_ms": amort, "train_step": train, "grid": rnd.querier.last_grid_stats,
+            "amortised_ms": amort, "train_step": train, "train_step_sharded": train_sharded, "grid": rnd.querier.last_grid_stats,
         }
         if counts is not None:
             res["counts"] = {k: int(counts[v]) for k, v in CNT.items()}

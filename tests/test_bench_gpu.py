@@ -33,6 +33,23 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
         assert k in c, k
     assert c["kind"] == "port" and c["value"] > 0 and c["psnr_gpu_vs_oracle_db"] > 60
     assert d["roofline_query"]["bound"] == "hbm" and d["train_step"]["ms_per_step"] > 0
+    assert d["train_step_sharded"]["ms_per_step"] > 0 and d["train_step_sharded"]["n_ranks"] == 1 and d["train_step_sharded"]["collective_bytes"]["weights_allreduce"] > 1000000
+    assert d["fp32_mfma_anchor"]["fp32_mfma_ms_per_step"] > 0 and d["fp32_mfma_anchor"]["max_abs_vs_f16x2_frame"] < 1e-4
+    assert c["max_abs_gpu_vs_oracle_same_pixels"] <= 1e-4
+    assert abs(r["frac_issued"] - r["achieved_issued"] / r["peak"]) < 1e-3 and r["frac"] < r["frac_issued"]
+
+
+def test_bench_two_rank_rehearsal_of_the_patch_sharded_train_step():
+    """BASELINE config 5 as it runs on N ranks (train_leg_sharded): two ranks on one GPU, gloo collectives on host copies -- control flow and shapes of
+    the patch sharding + the three gradient collectives, not a measurement."""
+    e = dict(os.environ, HNR_BENCH_REHEARSAL="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--points", "2e5", "--no-cpu-baseline",
+                        "--no-f32-anchor", "--train-sharded-only"], cwd=ROOT, capture_output=True, text=True, timeout=1500, env=e)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.strip().startswith("{")][0])
+    t = d["train_step_sharded"]
+    assert t["n_ranks"] == 2 and "25 patches" in t["workload"] or "24 patches" in t["workload"]
+    assert t["ms_per_step"] > 0 and t["collective_bytes"]["touched_points"] > 0
 
 
 def _run(extra, env=None, timeout=1500):
