@@ -420,14 +420,17 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
                         asm volatile("v_fma_mixlo_f16 %0, %1, %3, -%4 op_sel_hi:[0,0,1]\n\ts_nop 0\n\tv_fma_mixhi_f16 %0, %2, %3, -%4 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
                                      : "=&v"(pm[7]) : "v"(acc[se][1][14]), "v"(acc[se][1][15]), "v"(sc_run), "v"(ph[7]));
                     }
+                    // operand-plane stores, ONE per stage (two 16-B stores behind one MFMA do not fit its shadow: 13 cycles of data transfer each): the
+                    // high parts of items q - 3 .. q are complete after stage q, their low parts one stage later
+                    if (it < 16 && ((it & 3) == 3) && !(DBG == 6 || DBG == 7)) {
+                        const int c = it >> 3, q = it & 7;
+                        CW_AT(u32x4, q_pub, c * 2 * SLOT + PR * 2048 + (q == 7 ? 512 : 0)) = u32x4{ph[q - 3], ph[q - 2], ph[q - 1], ph[q]};
+                    }
                     if (ip >= 0) {
                         const int cp = ip >> 3, qp = ip & 7;
                         if ((qp == 3 || qp == 7) && (DBG == 6 || DBG == 7)) { asm volatile("" :: "v"(ph[qp]), "v"(pm[qp]), "v"(ph[qp - 1]), "v"(pm[qp - 1]), "v"(ph[qp - 2]), "v"(pm[qp - 2]), "v"(ph[qp - 3]), "v"(pm[qp - 3])); }
-                        else if (qp == 3 || qp == 7) {
-                            const int dst = cp * 2 * SLOT + PR * 2048 + (qp == 7 ? 512 : 0);
-                            CW_AT(u32x4, q_pub, dst) = u32x4{ph[qp - 3], ph[qp - 2], ph[qp - 1], ph[qp]};
-                            CW_AT(u32x4, q_pub, dst + 1024) = u32x4{pm[qp - 3], pm[qp - 2], pm[qp - 1], pm[qp]};
-                        }
+                        else if (qp == 3 || qp == 7)
+                            CW_AT(u32x4, q_pub, cp * 2 * SLOT + PR * 2048 + (qp == 7 ? 512 : 0) + 1024) = u32x4{pm[qp - 3], pm[qp - 2], pm[qp - 1], pm[qp]};
                     }
                 } else if (ms == 19) {
                     if (PL == 1 && PR == wave && h == 0) {
