@@ -119,12 +119,18 @@ constexpr int CW_GTOT = cw_goff(16);
 constexpr int cw_issue(int P, int slot)
 {
     const int L = P >> 2, rt = P & 3;
-    if (L == 0) {                                                          // block1.2: 8..11, 12..15, 4..7 (any time), 0..3 (once pass (0,3) has used them)
-        if (rt < 3) { const int k = slot == 13 ? 0 : slot == 16 ? 1 : slot == 19 ? 2 : slot == 22 ? 3 : -1; return k < 0 ? -1 : 32 + (rt == 0 ? 8 : rt == 1 ? 12 : 4) + k; }
-        return slot == 12 ? 32 + 0 : slot == 14 ? 32 + 1 : slot == 17 ? 32 + 2 : slot == 23 ? 32 + 3 : -1;
+    // block1.2 (runs its k steps in the order 8..15, 0..7): blocks 8..11 behind iterations 8..11 of pass (3,3) (layer 0 does not use them), 12..15 one or
+    // two per short layer-0 pass (second halves -- every vector-memory instruction costs the wave ~40 cycles of issue there: 16 a pass made the
+    // layer-0 passes fetch-bound), 0..7 during the first half of pass (1,0) itself, which uses them from iteration 8 on
+    if (L == 0) {
+        if (rt == 0) return slot == 14 ? 32 + 12 : slot == 20 ? 32 + 13 : -1;
+        if (rt == 1) return slot == 17 ? 32 + 14 : -1;
+        if (rt == 2) return slot == 17 ? 32 + 15 : -1;
+        return -1;
     }
     if (slot % 6 != 5) return -1;
     const int it = slot / 6;
+    if (P == 4) return it < 8 ? 32 + it : -1;                              // behind iteration it (k step 8 + it): block `it`, used from iteration 8 + it on
     if (P == 7) {                                                          // block3.0 (block1.2 runs k steps 8..15, 0..7: block b is free after iteration (b + 8) & 15)
         const int t[16] = {-1, -1, 8, -1, -1, 9, -1, -1, 0, 1, -1, 2, 3, -1, 4, 5};
         return t[it] < 0 ? -1 : 64 + t[it];
@@ -132,7 +138,7 @@ constexpr int cw_issue(int P, int slot)
     if (P == 8) { const int t[17] = {6, 7, 10, 11, -1, 12, -1, 13, -1, 14, 15, -1, -1, -1, -1, -1, -1}; return t[it] < 0 ? -1 : 64 + t[it]; }
     if (P == 11) return (it & 1) && it < 16 ? 96 + (it >> 1) : -1;          // block3.2: 0..7 behind iterations 1, 3, .., 15
     if (P == 12) { const int t[16] = {8, 9, 10, -1, 11, 12, -1, 13, 14, -1, 15, -1, -1, -1, -1, -1}; return t[it] < 0 ? -1 : 96 + t[it]; }
-    if (P == 15) return it < 4 ? it : -1;                                   // layer 0's four k steps
+    if (P == 15) return it < 4 ? it : (it >= 8 && it < 12) ? 32 + it : -1;  // layer 0's four k steps; block1.2's 8..11
     return -1;
 }
 // time stamps in program order: (pass, slot, phase) with phase 0 = the barrier's DMA, 1 = the wait in front of the MFMA, 2 = the fetch behind it
@@ -171,9 +177,9 @@ constexpr int cw_dma_count(int rt, int Pw)
     if (t0 >= t1) t0 -= CW_TILE_STAMPS;
     return cw_asm_between(t0, t1);
 }
-static_assert(cw_need_count(32 + 0, 4, 48) == 12 && cw_need_count(32 + 3, 4, 66) == 0, "block1.2's k steps 0..3 are the last fetches before pass (1,0) uses them");
-static_assert(cw_need_count(3, 0, 18) == 10 && cw_need_count(0, 0, 0) == 14, "layer 0 fetches: followed by the image DMA of row tile 3, then by the first block1.2 fetches of pass (0,0)");
-static_assert(cw_dma_count(3, 2) == 32 && cw_dma_count(0, 15) >= 16, "image DMA waits");
+static_assert(cw_need_count(32 + 0, 4, 48) == 28 && cw_need_count(32 + 7, 4, 90) == 0, "block1.2's k steps 0..7 are fetched behind the first eight iterations of pass (1,0)");
+static_assert(cw_need_count(3, 0, 18) == 22 && cw_need_count(0, 0, 0) == 30, "layer 0 fetches: followed by the image DMA of row tile 3, block1.2's 8..11, then by the first fetch of pass (0,0)");
+static_assert(cw_dma_count(3, 2) == 28 && cw_dma_count(0, 15) >= 16, "image DMA waits");
 
 template <int DBG>
 __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
@@ -287,18 +293,20 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
         return o;
     };
 
-    // ---- prologue: first tile's row scalars, its four layer-0 images (DMA), its first table rows, layer-0 weights
+    // ---- prologue: first tile's row scalars, its four layer-0 images (DMA), its first table rows, layer-0 weights + block1.2's k steps 8..11
     load_ids(t_first, pid);
     __syncthreads();                                                       // constants / zeroed extras visible; nobody DMAs into LDS before everybody is here
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) dma_image(t_first, rt);
     load_table(pid[0], tv[0]);
     CW_LOAD_W(0, 0); CW_LOAD_W(0, 1); CW_LOAD_W(0, 2); CW_LOAD_W(0, 3);
+    CW_LOAD_W(1, 8); CW_LOAD_W(1, 9); CW_LOAD_W(1, 10); CW_LOAD_W(1, 11);         // (what pass (3,3) of a previous tile would have fetched: cw_issue)
     cw_wait_vm<0>();
     __syncthreads();
 
     long long t_start = 0, w_start = 0, t_prev = 0, tm[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     int n_my = 0;
+    long long tmf[4] = {0, 0, 0, 0}, tf_prev = 0;
     if (DBG >= 2) { t_start = t_prev = clock64(); w_start = wall_clock64(); }
 
     // uniform scalars of the packed image (SGPRs)
@@ -311,7 +319,7 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
     // micro-stage of the epilogue before it --: in the short layer-0 passes a read asked for one micro-stage ahead was waited for (~100 cycles each).
     float4 bq[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)}, aq[2] = {bq[0], bq[0]};
     unsigned ph[8], pm[8];
-    float s1x = 0.f, s1y = 0.f, s1a = 0.f, s1b = 0.f;                       // values handed from an item's first micro-stage to its second
+    float s1x = 0.f, s1y = 0.f, s1a = 0.f, s1b = 0.f, s2x = 0.f, s2y = 0.f, s2a = 0.f, s2b = 0.f;     // values handed from an item's first step to its second
     // X5 rows of the row tile whose sums are being stored: the tile's descriptor (tile_out) + ONE per-lane byte offset, out of range (the store
     // is dropped) in the lanes that hold no sum; x5_flag = 1 / 0: the third step of the K-sum runs / is a no-op (4-slot samples)
     int x5_voff = 0x40000000;
@@ -333,41 +341,55 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
         const float inv_l = PL == 0 ? inv0 : inv[PR];
         const int PLn = PR == 3 ? (PL + 1) & 3 : PL;                       // layer of the epilogue that follows this one
         if (slot < H) {
-            // -- first half.  micro-stages 2 i, 2 i + 1: item i = (c, q), two values each; 32: row maximum / alpha partial -> exchange buffer
-            const int MS = 33, m0 = slot * MS / H, m1 = (slot + 1) * MS / H;
+            // -- first half.  Item i = (c, q), two values each, in two steps (st0: bias / table add, descale, slope product; st1: LeakyReLU, row
+            //    maximum / alpha partial).  Long passes: micro-stages 2 i, 2 i + 1 = the two steps of item i (3 - 4 VALU behind an MFMA); the short
+            //    layer-0 passes (S = 4) hold ~12 VALU per MFMA anyway: there two items go through a step together -- four independent chains instead
+            //    of two, every instruction at least four issue slots behind the one it depends on.  Last micro-stage: row maximum / alpha partial ->
+            //    exchange buffer
+            auto fh_st0 = [&](int it, float &o_x, float &o_y, float &o_a, float &o_b) __attribute__((always_inline)) {
+                const int c = it >> 3, q = it & 7, k = it >> 1;
+                // scalar fp32 VALU on purpose: packed fp32 instructions (v_pk_fma_f32 ...) do not overlap with this wave's MFMAs -- one
+                // of them behind an MFMA costs 18 cycles of matrix-pipe time, a v_fma_f32 none (tools/interleave_probe.hip)
+                if (it == 0) { amax = 0.f; ap = 0.f; }
+                if ((it & 1) == 0 && k >= 1 && k + 1 < 8) { bq[(k + 1) & 1] = read_cst(PL, k + 1); if (PL == 3) aq[(k + 1) & 1] = read_cst(4, k + 1); }
+                float ax = (it & 1) ? bq[k & 1].z : bq[k & 1].x, ay = (it & 1) ? bq[k & 1].w : bq[k & 1].y;
+                if (PL == 0) {
+                    if (q == 0) cw_table_swap(tv[PR & 1][c][0], tv[PR & 1][c][1], tv[PR & 1][c][2], tv[PR & 1][c][3]);
+                    const float4 t4 = tv[PR & 1][c][q >> 1];
+                    if ((q >> 1) == 0) { ax = cw_table_add<0>((q & 1) ? t4.z : t4.x, ax); ay = cw_table_add<0>((q & 1) ? t4.w : t4.y, ay); }
+                    else if ((q >> 1) == 1) { ax = cw_table_add<1>((q & 1) ? t4.z : t4.x, ax); ay = cw_table_add<1>((q & 1) ? t4.w : t4.y, ay); }
+                    else if ((q >> 1) == 2) { ax = cw_table_add<2>((q & 1) ? t4.z : t4.x, ax); ay = cw_table_add<2>((q & 1) ? t4.w : t4.y, ay); }
+                    else { ax = cw_table_add<3>((q & 1) ? t4.z : t4.x, ax); ay = cw_table_add<3>((q & 1) ? t4.w : t4.y, ay); }
+                }
+                o_x = fmaf(acc[se][c][2 * q], inv_l, ax); o_y = fmaf(acc[se][c][2 * q + 1], inv_l, ay);
+                o_a = __fmul_rn(o_x, a.slope); o_b = __fmul_rn(o_y, a.slope);
+            };
+            auto fh_st1 = [&](int it, float i_x, float i_y, float i_a, float i_b) __attribute__((always_inline)) {
+                const int c = it >> 3, q = it & 7, k = it >> 1;
+                const float vx = fmaxf(i_x, i_a), vy = fmaxf(i_y, i_b);
+                acc[se][c][2 * q] = vx; acc[se][c][2 * q + 1] = vy;
+                if (PL == 3) { ap = fmaf(vx, (it & 1) ? aq[k & 1].z : aq[k & 1].x, ap); ap = fmaf(vy, (it & 1) ? aq[k & 1].w : aq[k & 1].y, ap); }
+                else amax = fmaxf(fmaxf(amax, fabsf(vx)), fabsf(vy));
+                if (DBG == 1) {
+                    if (a.dbg && a.dbg_layer == PL && to.t >= 0) {
+                        int te = to.t;                                          // laundered: no 64-bit induction variable
+                        asm volatile("" : "+s"(te));
+                        float *o = a.dbg + ((size_t)te * 128 + 32 * PR + j) * 256 + col0 + 32 * c + 2 * q;
+                        o[0] = vx; o[1] = vy;
+                    }
+                }
+            };
+            const bool wide = S == 4;
+            const int MS = wide ? 17 : 33, m0 = slot * MS / H, m1 = (slot + 1) * MS / H;
 #pragma unroll
             for (int ms = m0; ms < m1; ++ms) {
-                if (ms < 32) {
-                    const int it = ms >> 1, st = ms & 1, c = it >> 3, q = it & 7, k = it >> 1;
-                    if (st == 0) {
-                        // scalar fp32 VALU on purpose: packed fp32 instructions (v_pk_fma_f32 ...) do not overlap with this wave's MFMAs -- one
-                        // of them behind an MFMA costs 18 cycles of matrix-pipe time, a v_fma_f32 none (tools/interleave_probe.hip)
-                        if (it == 0) { amax = 0.f; ap = 0.f; }
-                        if ((it & 1) == 0 && k >= 1 && k + 1 < 8) { bq[(k + 1) & 1] = read_cst(PL, k + 1); if (PL == 3) aq[(k + 1) & 1] = read_cst(4, k + 1); }
-                        float ax = (it & 1) ? bq[k & 1].z : bq[k & 1].x, ay = (it & 1) ? bq[k & 1].w : bq[k & 1].y;
-                        if (PL == 0) {
-                            if (q == 0) cw_table_swap(tv[PR & 1][c][0], tv[PR & 1][c][1], tv[PR & 1][c][2], tv[PR & 1][c][3]);
-                            const float4 t4 = tv[PR & 1][c][q >> 1];
-                            if ((q >> 1) == 0) { ax = cw_table_add<0>((q & 1) ? t4.z : t4.x, ax); ay = cw_table_add<0>((q & 1) ? t4.w : t4.y, ay); }
-                            else if ((q >> 1) == 1) { ax = cw_table_add<1>((q & 1) ? t4.z : t4.x, ax); ay = cw_table_add<1>((q & 1) ? t4.w : t4.y, ay); }
-                            else if ((q >> 1) == 2) { ax = cw_table_add<2>((q & 1) ? t4.z : t4.x, ax); ay = cw_table_add<2>((q & 1) ? t4.w : t4.y, ay); }
-                            else { ax = cw_table_add<3>((q & 1) ? t4.z : t4.x, ax); ay = cw_table_add<3>((q & 1) ? t4.w : t4.y, ay); }
-                        }
-                        s1x = fmaf(acc[se][c][2 * q], inv_l, ax); s1y = fmaf(acc[se][c][2 * q + 1], inv_l, ay);
-                        s1a = __fmul_rn(s1x, a.slope); s1b = __fmul_rn(s1y, a.slope);
+                if (ms < MS - 1) {
+                    if (wide) {
+                        const int i0 = 2 * (ms >> 1), st = ms & 1;
+                        if (st == 0) { fh_st0(i0, s1x, s1y, s1a, s1b); fh_st0(i0 + 1, s2x, s2y, s2a, s2b); }
+                        else { fh_st1(i0, s1x, s1y, s1a, s1b); fh_st1(i0 + 1, s2x, s2y, s2a, s2b); }
                     } else {
-                        const float vx = fmaxf(s1x, s1a), vy = fmaxf(s1y, s1b);
-                        acc[se][c][2 * q] = vx; acc[se][c][2 * q + 1] = vy;
-                        if (PL == 3) { ap = fmaf(vx, (it & 1) ? aq[k & 1].z : aq[k & 1].x, ap); ap = fmaf(vy, (it & 1) ? aq[k & 1].w : aq[k & 1].y, ap); }
-                        else amax = fmaxf(fmaxf(amax, fabsf(vx)), fabsf(vy));
-                        if (DBG == 1) {
-                            if (a.dbg && a.dbg_layer == PL && to.t >= 0) {
-                                int te = to.t;                                          // laundered: no 64-bit induction variable
-                                asm volatile("" : "+s"(te));
-                                float *o = a.dbg + ((size_t)te * 128 + 32 * PR + j) * 256 + col0 + 32 * c + 2 * q;
-                                o[0] = vx; o[1] = vy;
-                            }
-                        }
+                        if ((ms & 1) == 0) fh_st0(ms >> 1, s1x, s1y, s1a, s1b); else fh_st1(ms >> 1, s1x, s1y, s1a, s1b);
                     }
                 } else {
                     float m;
@@ -523,7 +545,7 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
             constexpr int PP = (P + 15) & 15, PL = PP >> 2, PR = PP & 3, sm = rt & 1;
             constexpr int T = 6 * S, H = T / 2;
             const TileOut &to_e = P == 0 ? to_fin : to_cur;                // tile of the row tile whose epilogue runs here
-            if (DBG >= 2) { const long long t_ = clock64(); tm[(P + 15) & 15] += t_ - t_prev; t_prev = t_; }
+            if (DBG >= 2) { const long long t_ = clock64(); tm[(P + 15) & 15] += t_ - t_prev; t_prev = t_; if (P == 2) tmf[3] += t_ - tf_prev; if (P == 1) tf_prev = t_; }
             if (P != 0) CW_REFRESH();
             // ---- pass start: loads that ride ahead (each placed where no wait of the following passes lands right behind it)
             if (P == 6) {                                                  // block3.0's 17th k step: used by the last MFMAs of passes (2, 0..3)
@@ -545,13 +567,16 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
                     // has issued since (cw_dma_count)
                     if constexpr (P == 15) cw_wait_vm<cw_dma_count(0, 15)>();
                     if constexpr (P == 2) cw_wait_vm<cw_dma_count(3, 2)>();
+                    if (DBG >= 2 && P == 1) { const long long t_ = clock64(); tmf[0] += t_ - tf_prev; tf_prev = t_; }
                     cw_lds_barrier();
+                    if (DBG >= 2 && P == 1) { const long long t_ = clock64(); tmf[1] += t_ - tf_prev; tf_prev = t_; }
                     // every wave is past the first k steps of pass (3, rt): the next tile's image of row tile rt may overwrite their operand planes
                     if constexpr (L == 3) dma_image(tile_nx, rt);
                     // layer 0's table rows are asked for one and a half passes before their epilogue: row tile rt + 1 at the barrier of pass
                     // (0, rt) -- the set it goes into was consumed in this pass's first half --, the next tile's row tile 0 at the barrier of (3, 2)
                     if constexpr (L == 0 && rt < 3) load_table(pid[rt + 1], tv[(rt + 1) & 1]);
                     if constexpr (P == 14) load_table(pid_n[0], tv[0]);
+                    if (DBG >= 2 && P == 1) { const long long t_ = clock64(); tmf[2] += t_ - tf_prev; tf_prev = t_; }
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 constexpr int wp = g == 0 ? 1 : 0, xp_ = g == 1 ? 1 : 0;   // wm*xh, wh*xm, wh*xh: smallest terms first
@@ -596,6 +621,7 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
     if (DBG >= 2 && blockIdx.x == 0 && lane == 0 && a.dbg) {               // block 0: cycles per pass [wave][16]
         long long *o = reinterpret_cast<long long *>(a.dbg) + 4 * 1024 + wave * 16;
         for (int i = 0; i < 16; ++i) o[i] = tm[i];
+        if (wave == 0) { long long *o2 = reinterpret_cast<long long *>(a.dbg) + 4 * 1024 + 64; for (int i = 0; i < 4; ++i) o2[i] = tmf[i]; }
     }
     if (DBG >= 2 && tid == 0 && a.dbg) {                                   // every block: {cycles, wall ticks, tiles}
         long long *o = reinterpret_cast<long long *>(a.dbg) + 4 * (size_t)blockIdx.x;

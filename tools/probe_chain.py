@@ -45,7 +45,7 @@ for it in range(2):
                                           p(q["counts"]), W["SR"], W["K"], nv, p(ws2), p(X5b), 280, None, None, _lib.stream()), "g")
     g1.record(); torch.cuda.synchronize()
 print("chain_gather_rec %.3f ms per launch; workspace identical: %s" % (g0.elapsed_time(g1) / 5, bool(torch.equal(ws, ws2))))
-dbg = torch.zeros(((NW * 16 + 4 * 1024 + 64) * 2,), dtype=torch.float32, device=dev)
+dbg = torch.zeros(((NW * 16 + 4 * 1024 + 64 + 16) * 2,), dtype=torch.float32, device=dev)
 pk = W["agg"].packed_chain()
 MODE = -int(os.environ.get('PROBE_MODE', '1'))          # -1: phase timing; -3 / -4 / -5 (dual-group kernel only): no epilogue work / same weights / both
 for it in range(3):
@@ -61,6 +61,8 @@ if os.environ.get('HNR_CHAIN_RT', '16') == '16':
     print('blocks %d: cycles/tile mean %.0f, GHz %.3f' % (len(blk), (blk[:, 0] / blk[:, 2]).mean(), (blk[:, 0] / blk[:, 1]).mean() * 0.1))
     for w in range(4):
         print('wave %d cycles per pass (L, rt): ' % w + ' '.join('%d' % (t[w, i] / max(blk[0, 2], 1)) for i in range(16)))
+    f = allv[4 * 1024 + 64:4 * 1024 + 68]
+    print('pass (0,1) of wave 0: first half %d, barrier wait %d, table-row load issue %d, second half %d' % tuple(int(x / max(blk[0, 2], 1)) for x in f))
     sys.exit(0)
 t = allv[:NW * 16].reshape(NW, 16)
 blk = allv[NW * 16:].reshape(-1, 4)
