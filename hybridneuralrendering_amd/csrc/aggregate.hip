@@ -505,8 +505,8 @@ __global__ __launch_bounds__(256) void proj_rows_kernel(ProjArgs a)
         const float cn = sqrtf(cx * cx + cy * cy + cz * cz) + 1e-6f;
         const float nx = x - a.campos_n[3 * v], ny = y - a.campos_n[3 * v + 1], nz = z - a.campos_n[3 * v + 2];
         const float nn = sqrtf(nx * nx + ny * ny + nz * nz) + 1e-6f;
-        const float cur = (sub == 0 ? cx : sub == 1 ? cy : cz) / cn;
-        const float nea = (sub == 0 ? nx : sub == 1 ? ny : nz) / nn;
+        const float cur = hnr_div(sub == 0 ? cx : sub == 1 ? cy : cz, cn);
+        const float nea = hnr_div(sub == 0 ? nx : sub == 1 ? ny : nz, nn);
         o[dcol + sub] = nea - cur;
     }
     if (sub == 0) a.vmask[row] = inval ? 0.f : 1.f;
@@ -564,7 +564,7 @@ __global__ __launch_bounds__(256) void merge_kernel(MergeArgs a)
             if (v0 + u >= a.V) break;
             float d = hm[u] * wl;
             for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
-            float wv = 1.f / (1.f + expf(-(d + a.b_last[0])));
+            float wv = hnr_div(1.f, 1.f + expf(-(d + a.b_last[0])));
             wv *= vm[u];
             if (a.frame_w) wv *= a.frame_w[v0 + u];
             fsum += f[u] * wv;
@@ -575,7 +575,7 @@ __global__ __launch_bounds__(256) void merge_kernel(MergeArgs a)
     if (lane < 45) {
         o[lane] = a.CF[(size_t)s * a.ldcf + lane];
         const bool drop = a.ray_drop && a.ray_drop[a.vs_item[s] / a.SR];
-        o[45 + lane] = drop ? 0.f : fsum / (wsum + 1e-6f);
+        o[45 + lane] = drop ? 0.f : hnr_div(fsum, wsum + 1e-6f);
     }
     }
 }
@@ -642,7 +642,7 @@ __global__ __launch_bounds__(256) void final_color_kernel(FinalArgs a)
             float rgb[3];
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                const float sg = 1.f / (1.f + expf(-(r[j] + bb[j])));
+                const float sg = hnr_div(1.f, 1.f + expf(-(r[j] + bb[j])));
                 rgb[j] = sg * (1.f + 2.f * 0.001f) - 0.001f;
             }
             out.y = rgb[0]; out.z = rgb[1]; out.w = rgb[2];
@@ -1099,6 +1099,21 @@ extern "C" int hnr_proj_rows(const float *d_sample_loc_w, const int32_t *d_vs_it
     a.w2c = d_w2c; a.Kmat = d_intrinsic; a.campos = d_campos; a.campos_n = d_campos_nearest; a.fm = d_featmap; a.H = H; a.W = W;
     a.CF = d_CF; a.ldcf = ldcf; a.V = V; a.cap = cap_samples; a.X6 = d_X6; a.ld6 = ld6; a.vmask = d_vmask; a.row_sample = d_row_sample;
     { const int need = cdiv((int64_t)V * cap_samples * 16, 256); proj_rows_kernel<<<need < 8192 ? need : 8192, 256, 0, (hipStream_t)stream>>>(a); }
+    HNR_LAUNCH_CHECK();
+    return HNR_OK;
+}
+
+// Probe: hnr_div (csrc/hnr_common.h) beside the compiler's correctly rounded `/` on caller-supplied operand pairs
+__global__ void div_probe_kernel(const float *n, const float *d, int count, float *q_hnr, float *q_ieee)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) { q_hnr[i] = hnr::hnr_div(n[i], d[i]); q_ieee[i] = n[i] / d[i]; }
+}
+extern "C" int hnr_div_probe(const float *d_num, const float *d_den, int n, float *d_q_hnr, float *d_q_ieee, void *stream)
+{
+    if (n < 0 || (n > 0 && (!d_num || !d_den || !d_q_hnr || !d_q_ieee))) { set_error("hnr_div_probe: bad argument"); return HNR_ERR_BADARG; }
+    if (n == 0) return HNR_OK;
+    div_probe_kernel<<<cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(d_num, d_den, n, d_q_hnr, d_q_ieee);
     HNR_LAUNCH_CHECK();
     return HNR_OK;
 }

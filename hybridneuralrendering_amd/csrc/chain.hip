@@ -401,7 +401,7 @@ __device__ __forceinline__ void chain_w2pers(const float *p, const float *campos
 #pragma unroll
     for (int q = 0; q < 3; ++q)
         c[q] = __fadd_rn(__fadd_rn(__fmul_rn(camrot[q], s0), __fmul_rn(camrot[3 + q], s1)), __fmul_rn(camrot[6 + q], s2));
-    out[0] = __fdiv_rn(c[0], c[2]); out[1] = __fdiv_rn(c[1], c[2]); out[2] = c[2];
+    out[0] = hnr_div(c[0], c[2]); out[1] = hnr_div(c[1], c[2]); out[2] = c[2];          // (not `/`: see hnr_div)
 }
 
 typedef float f32x4g __attribute__((ext_vector_type(4)));
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(256) void chain_gather_kernel(ChainGatherArgs a)
             d6[4] = __fsub_rn(__fmul_rn(pp[1], pp[2]), __fmul_rn(sp[1], sp[2]));
             d6[5] = __fsub_rn(pp[2], sp[2]);
             const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
-            wraw = __fdiv_rn(1.0f, fmaxf(nrm, 1e-6f));
+            wraw = hnr_div(1.0f, fmaxf(nrm, 1e-6f));
             confc = fminf(fmaxf(r0.w, 0.0001f), 1.0f);
             const int ray = item / a.SR;
             const float vx = a.raydir[3 * (size_t)ray], vy = a.raydir[3 * (size_t)ray + 1], vz = a.raydir[3 * (size_t)ray + 2];
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(256) void chain_gather_kernel(ChainGatherArgs a)
         sum += __shfl_xor(sum, 1);
         { const float s2 = __shfl_xor(sum, 2); sum += kc > 1 ? 0.f : s2; }  // (a sample of the third class: 2 lanes)
         { const float s4 = __shfl_xor(sum, 4); sum += kc > 0 ? 0.f : s4; }  // (a sample of the second class: 4 lanes)
-        const float w = pid >= 0 ? __fdiv_rn(wraw, fmaxf(sum, 1e-8f)) : 0.f;
+        const float w = pid >= 0 ? hnr_div(wraw, fmaxf(sum, 1e-8f)) : 0.f;
 #pragma unroll
         for (int i = 0; i < 6; ++i) s_d[tid][i] = d6[i];
         if (a.row_pid) a.row_pid[(size_t)blk * 128 + tid] = pid;

@@ -107,6 +107,23 @@ __device__ __forceinline__ int brick_bit(int x, int y, int z)
     return ((x & 3) << 4) | ((y & 3) << 2) | (z & 3);
 }
 
+// Correctly rounded fp32 division WITHOUT v_div_scale / v_div_fmas: the steps of the compiler's own expansion (reciprocal, one refinement of it,
+// quotient, two residual corrections -- the same fused operations in the same order, hence the same bits) minus the operand scaling that only
+// matters at the ends of the exponent range; operands out there take the compiler's `/`.  Why: v_div_fmas reads the lane mask v_div_scale left
+// in VCC, and twice -- in two unrelated kernels, always lanes 48..63, only with several busy queues / processes on the GPU -- a quotient came out as if
+// that mask had been someone else's (profiles/README.md: shared-GPU renders, three-queue training).  The kernels where it was seen divide with this.
+__device__ __forceinline__ float hnr_div(float n, float d)
+{
+    const unsigned en = (__float_as_uint(n) >> 23) & 0xffu, ed = (__float_as_uint(d) >> 23) & 0xffu;
+    if (__builtin_expect(ed - 32u > 190u || (en - 32u > 190u && n != 0.f) || (int)en - (int)ed > 120 || (int)en - (int)ed < -120, 0))
+        return n / d;                                                       // zero / denormal / huge / inf / nan operands, quotients near the range's ends
+    float r = __builtin_amdgcn_rcpf(d);
+    r = fmaf(fmaf(-d, r, 1.0f), r, r);
+    float q = __fmul_rn(n, r);
+    q = fmaf(fmaf(-d, q, n), r, q);
+    return fmaf(fmaf(-d, q, n), r, q);
+}
+
 // Reprojection of a world-space sample into reference view v + truncation to a pixel + bounds rule (models/neural_points_volumetric_model.py:248-255,
 // models/aggregators/point_aggregators.py:1077-1088): w2c row-major 4x4, Kmat row-major 3x3, every fp32 operation rounded separately in this order
 // (-ffp-contract=off), the divisions correctly rounded.  ONE text for every kernel that gathers reference-view pixels (merge stage fused / un-fused,
@@ -121,7 +138,7 @@ __device__ __forceinline__ bool hnr_project_pixel(float x, float y, float z, con
 #pragma unroll
     for (int q = 0; q < 3; ++q) i3[q] = c[0] * Kmat[3 * q] + c[1] * Kmat[3 * q + 1] + c[2] * Kmat[3 * q + 2];
     const float den = i3[2] + 1e-10f;
-    const float fx = i3[0] / den, fy = i3[1] / den;
+    const float fx = hnr_div(i3[0], den), fy = hnr_div(i3[1], den);          // (correctly rounded; not the v_div_fmas expansion: see hnr_div)
     // .to(torch.int32): truncation toward zero; out-of-range / NaN -> invalid
     px = (fx > -2.0e9f && fx < 2.0e9f) ? (int)fx : -1;
     py = (fy > -2.0e9f && fy < 2.0e9f) ? (int)fy : -1;

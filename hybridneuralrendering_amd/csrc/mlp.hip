@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256, mlp3_wgs_per_cu(S0, RT, MODE)) void mlp3_kerne
                 const float cn = sqrtf(cx * cx + cy * cy + cz * cz) + 1e-6f;
                 const float nx = x - a.campos_n[3 * v], ny = y - a.campos_n[3 * v + 1], nz = z - a.campos_n[3 * v + 2];
                 const float nn = sqrtf(nx * nx + ny * ny + nz * nz) + 1e-6f;
-                s_f[row_t * 48 + 45] = nx / nn - cx / cn; s_f[row_t * 48 + 46] = ny / nn - cy / cn; s_f[row_t * 48 + 47] = nz / nn - cz / cn;
+                s_f[row_t * 48 + 45] = hnr_div(nx, nn) - hnr_div(cx, cn); s_f[row_t * 48 + 46] = hnr_div(ny, nn) - hnr_div(cy, cn); s_f[row_t * 48 + 47] = hnr_div(nz, nn) - hnr_div(cz, cn);
               }
             }
             MLP_STAMP(13);
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(256, mlp3_wgs_per_cu(S0, RT, MODE)) void mlp3_kerne
                 float4 d4 = *reinterpret_cast<const float4 *>(exch + tid * 4);
                 if (RS) { d4.z = 0.f; d4.w = 0.f; }
                 const float d = __fadd_rn(__fadd_rn(d4.x, d4.y), __fadd_rn(d4.z, d4.w));
-                float wv = 1.f / (1.f + expf(-(d + a.b_last[0])));
+                float wv = hnr_div(1.f, 1.f + expf(-(d + a.b_last[0])));
                 wv *= s_vm[tid];
                 if (a.frame_w) wv *= a.frame_w[tid & 3];
                 s_w[tid] = wv;
@@ -459,7 +459,7 @@ __global__ __launch_bounds__(256, mlp3_wgs_per_cu(S0, RT, MODE)) void mlp3_kerne
                         for (int v = 0; v < 4; ++v) { const float wv = s_w[4 * ls + v]; fsum += s_f[(4 * ls + v) * 48 + ch] * wv; wsum += wv; }
                         float *o = a.X7 + (size_t)sidx * a.ld7;
                         __builtin_nontemporal_store(cfv[it], o + ch);
-                        __builtin_nontemporal_store(fsum / (wsum + 1e-6f), o + 45 + ch);
+                        __builtin_nontemporal_store(hnr_div(fsum, wsum + 1e-6f), o + 45 + ch);
                     }
                 }
                 MLP_STAMP(17);
@@ -600,7 +600,7 @@ __global__ __launch_bounds__(64 * MW_WAVES, 1) void merge_wp_kernel(MlpArgs a)
                 const float cn = sqrtf(cx * cx + cy * cy + cz * cz) + 1e-6f;
                 const float nx = x - cnp[0], ny = y - cnp[1], nz = z - cnp[2];
                 const float nn = sqrtf(nx * nx + ny * ny + nz * nz) + 1e-6f;
-                s_dd[j * 3] = nx / nn - cx / cn; s_dd[j * 3 + 1] = ny / nn - cy / cn; s_dd[j * 3 + 2] = nz / nn - cz / cn;
+                s_dd[j * 3] = hnr_div(nx, nn) - hnr_div(cx, cn); s_dd[j * 3 + 1] = hnr_div(ny, nn) - hnr_div(cy, cn); s_dd[j * 3 + 2] = hnr_div(nz, nn) - hnr_div(cz, cn);
             }
         }
         MW_WAVE_FENCE();
@@ -727,7 +727,7 @@ __global__ __launch_bounds__(64 * MW_WAVES, 1) void merge_wp_kernel(MlpArgs a)
                 d2[c] = __fadd_rn(d, __shfl_xor(d, 32));
             }
             const float d = __fadd_rn(d2[0], d2[1]);
-            float wv = 1.f / (1.f + expf(-(d + b_last)));
+            float wv = hnr_div(1.f, 1.f + expf(-(d + b_last)));
             wv *= s_vm[j];
             if (a.frame_w) wv *= a.frame_w[j & 3];
             if (h == 0) s_w[j] = wv;
@@ -755,10 +755,10 @@ __global__ __launch_bounds__(64 * MW_WAVES, 1) void merge_wp_kernel(MlpArgs a)
                 }
                 const float den = wsum + 1e-6f;
                 float *o = s_x7 + ls * 92;
-                o[4 * q] = c4.x; o[45 + 4 * q] = fs[0] / den;
+                o[4 * q] = c4.x; o[45 + 4 * q] = hnr_div(fs[0], den);
                 if (q < 11) {
                     o[4 * q + 1] = c4.y; o[4 * q + 2] = c4.z; o[4 * q + 3] = c4.w;
-                    o[45 + 4 * q + 1] = fs[1] / den; o[45 + 4 * q + 2] = fs[2] / den; o[45 + 4 * q + 3] = fs[3] / den;
+                    o[45 + 4 * q + 1] = hnr_div(fs[1], den); o[45 + 4 * q + 2] = hnr_div(fs[2], den); o[45 + 4 * q + 3] = hnr_div(fs[3], den);
                 } else { o[90] = 0.f; o[91] = 0.f; }
             }
         }
@@ -1003,7 +1003,7 @@ __global__ __launch_bounds__(64 * MX_WAVES, 1) void mixfinal_wp_kernel(MixArgs a
             out.x = a.sigma[srow];
 #pragma unroll
             for (int o = 0; o < 3; ++o) {
-                const float sg = 1.f / (1.f + expf(-(rj[o] + bfin[o])));
+                const float sg = hnr_div(1.f, 1.f + expf(-(rj[o] + bfin[o])));
                 const float cch = sg * (1.f + 2.f * 0.001f) - 0.001f;
                 if (o == 0) out.y = cch; else if (o == 1) out.z = cch; else out.w = cch;
             }

@@ -285,7 +285,7 @@ __global__ __launch_bounds__(1024) void train_ksum_bwd_kernel(KsumPadArgs a)
                 const float yv = __fsub_rn(d + ab, 1.0f);
                 const float ez = expf(yv);
                 const float sp = yv > 20.f ? yv : log1pf(ez);
-                const float spd = yv > 20.f ? 1.f : ez / (ez + 1.f);
+                const float spd = yv > 20.f ? 1.f : hnr_div(ez, ez + 1.f);                 // (not `/`: see hnr_div)
                 const float da = w * gs * spd;
                 o.x = (w * gf.x + da * aw.x) * (h.x > 0.f ? 1.f : a.slope);
                 o.y = (w * gf.y + da * aw.y) * (h.y > 0.f ? 1.f : a.slope);

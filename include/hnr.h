@@ -271,6 +271,10 @@ int hnr_proj_rows(const float *d_sample_loc_w, const int32_t *d_vs_item, const i
                   int V, int H, int W, const float *d_CF, int ldcf, int cap_samples, float *d_X6, int ld6, float *d_vmask,
                   int32_t *d_row_sample, void *stream);
 
+/* Probe (parity evidence): q_hnr[i] = the library's divide-free correctly rounded quotient (hnr_div, csrc/hnr_common.h: what chain_gather_kernel and
+ * train_ksum_bwd_kernel divide with instead of the v_div_scale / v_div_fmas expansion), q_ieee[i] = num[i] / den[i] as the compiler expands it. */
+int hnr_div_probe(const float *d_num, const float *d_den, int n, float *d_q_hnr, float *d_q_ieee, void *stream);
+
 /* Probe (parity evidence, not on the render path): the integer pixel every (view v, valid sample s) row of the merge stage gathers,
  * d_pix[(v * cap_samples + s) * 2 + {0,1}] = (px, py), or (-1, -1) where the reference's bounds rule masks the row -- computed by the one
  * device function (hnr_project_pixel, csrc/hnr_common.h) that hnr_proj_rows, hnr_merge_stage and hnr_proj_rows_bwd call, so that a test or

@@ -214,3 +214,29 @@ def test_sorted_neighbour_order_renders_the_same_colours(tag):
     for k, tol in (("coarse_raycolor", 1e-6), ("coarse_point_opacity", 1e-6)):
         assert float((a[k] - ref[k]).abs().max()) <= tol, (k, float((a[k] - ref[k]).abs().max()))
     assert _psnr(a["coarse_raycolor"].cpu().numpy(), d["full_coarse_raycolor"][0]) > 70.0
+
+
+def test_divide_free_quotient_is_the_correctly_rounded_one():
+    """hnr_div (what chain_gather_kernel / train_ksum_bwd_kernel divide with: the steps of the compiler's own fp32 division without v_div_scale /
+    v_div_fmas, see csrc/hnr_common.h) against numpy's IEEE division and against the compiler's `/` on the device: bit-identical on 4 M operand
+    pairs over the exponent range, the softplus-derivative quotients e / (e + 1), perspective divisions, and the special values (which take `/`)."""
+    from hybridneuralrendering_amd import _lib
+    L, p = _lib.lib(), _lib.ptr
+    rng = np.random.default_rng(0)
+    n = 1 << 22
+    num = (rng.standard_normal(n) * np.exp2(rng.integers(-100, 100, n))).astype(np.float32)
+    den = (rng.standard_normal(n) * np.exp2(rng.integers(-100, 100, n))).astype(np.float32)
+    e = np.exp(rng.uniform(-30, 20, 1 << 18)).astype(np.float32)
+    sp = [np.array([0.0, -0.0, 1.0, np.inf, -np.inf, np.nan, 1e-45, 3e38, 1e-38, 1.0, 1.0, 2.0, 1e-30], np.float32),
+          np.array([1.0, 1.0, 0.0, 1.0, np.inf, 1.0, 1.0, 1e-38, 3e38, 3.0, np.nan, -0.0, 1e30], np.float32)]
+    num = np.concatenate([num, e, rng.uniform(-3, 3, 1 << 18).astype(np.float32), sp[0]])
+    den = np.concatenate([den, (e + np.float32(1)).astype(np.float32), rng.uniform(0.05, 9, 1 << 18).astype(np.float32), sp[1]])
+    dn, dd = torch.from_numpy(num).cuda(), torch.from_numpy(den).cuda()
+    qh, qi = torch.empty_like(dn), torch.empty_like(dn)
+    _lib.check(L.hnr_div_probe(p(dn), p(dd), int(dn.numel()), p(qh), p(qi), _lib.stream()), "hnr_div_probe")
+    with np.errstate(all="ignore"):
+        want = (num / den).astype(np.float32)
+    a, b = qh.cpu().numpy(), qi.cpu().numpy()
+    same = lambda x, y: (x.view(np.uint32) == y.view(np.uint32)) | (np.isnan(x) & np.isnan(y))
+    assert same(b, want).all(), "the compiler's division is not IEEE on %d pairs" % int((~same(b, want)).sum())
+    assert same(a, want).all(), int((~same(a, want)).sum())
