@@ -515,6 +515,155 @@ __global__ __launch_bounds__(512, 1) void h2wgrad_kernel(H2WgradArgs a)
     }
 }
 
+// The 256-wide weight gradient (NT = 8, KT = 9) with the fp32 rows staged through LDS by DMA.  h2wgrad_kernel<8, 9, 1, 0, 1> has room for ONE register
+// set of staged rows beside its 144 accumulator registers, so a block's loads have one iteration of MFMAs (864 cycles) to arrive and the kernel ran at
+// the latency of its loads: 3.2 us per 16-row block, 2.3 - 2.5 TB/s (32 KiB in flight per CU).  Here the rows of block i + 2 go global -> LDS (raw fp32,
+// `global_load_lds_dwordx4`: no registers) while block i is multiplied, and block i + 1 is converted to its fp16 planes AFTER the MFMAs of the iteration:
+// every block has nearly two iterations to land, two blocks (68 KiB) are in flight per CU.  Same staging arithmetic, the same MFMA order per
+// accumulator and the same blocks per workgroup as h2wgrad_kernel: bit-identical partials.
+__device__ __forceinline__ void h2_dma_row(const float *src, int voff, unsigned lds_dst)
+{
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(src), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void h2_dma_row8(const float *src, int voff, unsigned lds_dst)      // lanes 0..7 only (the 32 columns past the 256th)
+{
+    unsigned long long keep;
+    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 0xff\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b64 exec, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(src), "s"(lds_dst) : "memory");
+}
+__global__ __launch_bounds__(512, 1) void h2wgrad_dma_kernel(H2WgradArgs a)
+{
+    constexpr int NT = 8, KT = 9, KTW = KT;
+    constexpr int WZ = 32 * NT, WX = 32 * KT;
+    constexpr int RSZ = ((WZ * 2 - 64 + 255) & ~255) + 64, RSX = ((WX * 2 - 64 + 255) & ~255) + 64;
+    constexpr int RB = 16;
+    constexpr int PZ = RB * RSZ, PX = RB * RSX, STAGE = 2 * PZ + 2 * PX;
+    constexpr int RAWZ = RB * WZ * 4, RAWX = RB * WX * 4, RAW = RAWZ + RAWX;   // raw fp32 rows of a block: [16][256] dZ, then [16][288] X
+    constexpr int Z4 = WZ / 4, X4 = WX / 4, NLD = (RB * (Z4 + X4) + 511) / 512;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wn = wave;
+    long long M = a.M_cap, n_unit = a.M_cap;
+    if (a.d_m) { const long long c = *a.d_m; if (c < M) M = c; }
+    if (a.n_seg > 1) { n_unit = M < a.seg_stride ? M : a.seg_stride; M = n_unit * a.n_seg; }
+    const long long n_blocks = (M + RB - 1) / RB;
+    if (n_blocks == 0 && blockIdx.x > 0) return;
+    const int kz = row_scale_exp(__uint_as_float(*a.zmax)), kx = row_scale_exp(__uint_as_float(*a.xmax));
+    const float sz = pow2f(kz), sx = pow2f(kx);
+    f32x16 acc[KTW];
+#pragma unroll
+    for (int u = 0; u < KTW; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
+    // conversion slots of this thread (as in h2wgrad_kernel): float4 (row, columns c .. c + 3) of the dZ or the X tile
+    int s_row[NLD], s_raw[NLD], s_lds[NLD];
+    unsigned s_keep[NLD];
+    const long long seg_extra = a.n_seg > 1 ? a.seg_stride - n_unit : 0;
+#pragma unroll
+    for (int it = 0; it < NLD; ++it) {
+        const int idx = (tid + 512 * it < RB * (Z4 + X4)) ? tid + 512 * it : tid + 512 * (it - 1);
+        const bool isx = idx >= RB * Z4;
+        const int id2 = isx ? idx - RB * Z4 : idx, per = isx ? X4 : Z4;
+        const int row = id2 / per, c = 4 * (id2 - row * per);
+        const int lim = isx ? a.K : a.N, ld = isx ? a.ldx : a.ldz;
+        const bool inrow = c + 4 <= ld;
+        s_row[it] = row;
+        unsigned keep = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) keep |= (inrow && c + e < lim) ? (1u << e) : 0u;
+        if (isx) { keep |= 16u; if ((a.K >> 2) == (c >> 2)) keep |= 256u << (a.K & 3); }
+        s_keep[it] = keep;
+        s_lds[it] = (isx ? 2 * PZ : 0) + row * (isx ? RSX : RSZ) + c * 2;
+        s_raw[it] = isx ? RAWZ + (row * WX + c) * 4 : (row * WZ + c) * 4;
+    }
+    const unsigned lds_base = (unsigned)reinterpret_cast<uintptr_t>(lds);
+    // this wave's rows of a block: 2 w, 2 w + 1 of dZ and of X.  A lane past the row's allocated width (ld) re-reads the row's first columns
+    // (its values are masked by `keep`); rows past M re-read the last row (masked when converted)
+    const int vz = (4 * lane + 4 <= a.ldz) ? lane * 16 : 0, vx = (4 * lane + 4 <= a.ldx) ? lane * 16 : 0;
+    const int vx8 = (lane < 8 && 256 + 4 * lane + 4 <= a.ldx) ? (256 + 4 * lane) * 4 : 0;
+    auto dma_block = [&](long long blk, unsigned raw) {
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int row = 2 * wave + rr;
+            long long m = blk * RB + row;
+            m = m < M ? m : (M > 0 ? M - 1 : 0);
+            int q = 0;
+#pragma unroll
+            for (int sv = 1; sv < 8; ++sv) q += (sv < a.n_seg && m >= (long long)sv * n_unit) ? 1 : 0;
+            const long long pm = m + (long long)q * seg_extra;
+            h2_dma_row(a.dZ + (size_t)pm * a.ldz, vz, raw + (unsigned)(row * WZ * 4));
+            h2_dma_row(a.X + (size_t)pm * a.ldx, vx, raw + (unsigned)(RAWZ + row * WX * 4));
+            h2_dma_row8(a.X + (size_t)pm * a.ldx, vx8, raw + (unsigned)(RAWZ + row * WX * 4 + 1024));
+        }
+    };
+    auto convert = [&](const char *raw, char *base, long long blk) {
+#pragma unroll
+        for (int it = 0; it < NLD; ++it) {
+            const float4 v = *reinterpret_cast<const float4 *>(raw + s_raw[it]);
+            const unsigned keep = (blk * RB + s_row[it] < M) ? s_keep[it] : (s_keep[it] & ~15u);
+            const float sc = (keep & 16u) ? sx : sz;
+            unsigned ph0, pm0, ph1, pm1;
+            split2h((keep & 1u) ? __fmul_rn(v.x, sc) : 0.f, (keep & 2u) ? __fmul_rn(v.y, sc) : 0.f, ph0, pm0);
+            split2h((keep & 4u) ? __fmul_rn(v.z, sc) : 0.f, (keep & 8u) ? __fmul_rn(v.w, sc) : 0.f, ph1, pm1);
+            ph0 = (keep & 0x100u) ? ((ph0 & 0xffff0000u) | 0x3c00u) : (keep & 0x200u) ? ((ph0 & 0x0000ffffu) | 0x3c000000u) : ph0;
+            ph1 = (keep & 0x400u) ? ((ph1 & 0xffff0000u) | 0x3c00u) : (keep & 0x800u) ? ((ph1 & 0x0000ffffu) | 0x3c000000u) : ph1;
+            *reinterpret_cast<uint2 *>(base + s_lds[it]) = make_uint2(ph0, ph1);
+            *reinterpret_cast<uint2 *>(base + s_lds[it] + ((keep & 16u) ? PX : PZ)) = make_uint2(pm0, pm1);
+        }
+    };
+    const long long step = gridDim.x;
+    long long blk = blockIdx.x;
+    auto planes = [&](int p_) { return lds + p_ * STAGE; };
+    auto raw_p = [&](int p_) { return lds + 2 * STAGE + p_ * RAW; };
+    auto raw_l = [&](int p_) { return lds_base + (unsigned)(2 * STAGE + p_ * RAW); };
+    dma_block(blk, raw_l(0));
+    dma_block(blk + step, raw_l(1));
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __syncthreads();
+    convert(raw_p(0), planes(0), blk);
+    __syncthreads();
+    int par = 0;
+    for (; blk < n_blocks; blk += step, par ^= 1) {
+        dma_block(blk + 2 * step, raw_l(par));                                 // (block i's raw rows were converted before the last barrier)
+        const char *zb = planes(par), *xb = planes(par) + 2 * PZ;
+        const f16x8 zh = h2_tr_frag(zb, RSZ, 32 * wn, 0, lane), zm = h2_tr_frag(zb + PZ, RSZ, 32 * wn, 0, lane);
+#pragma unroll
+        for (int u0 = 0; u0 < KTW; u0 += 2) {
+            const f16x8 xh0 = h2_tr_frag(xb, RSX, 32 * u0, 0, lane), xm0 = h2_tr_frag(xb + PX, RSX, 32 * u0, 0, lane);
+            if (u0 + 1 < KTW) {
+                const f16x8 xh1 = h2_tr_frag(xb, RSX, 32 * (u0 + 1), 0, lane), xm1 = h2_tr_frag(xb + PX, RSX, 32 * (u0 + 1), 0, lane);
+                acc[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zm, xh0, acc[u0], 0, 0, 0);
+                acc[u0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zm, xh1, acc[u0 + 1], 0, 0, 0);
+                acc[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zh, xm0, acc[u0], 0, 0, 0);
+                acc[u0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zh, xm1, acc[u0 + 1], 0, 0, 0);
+                acc[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zh, xh0, acc[u0], 0, 0, 0);
+                acc[u0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zh, xh1, acc[u0 + 1], 0, 0, 0);
+            } else {
+                acc[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zm, xh0, acc[u0], 0, 0, 0);
+                acc[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zh, xm0, acc[u0], 0, 0, 0);
+                acc[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zh, xh0, acc[u0], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                        // this wave's rows of block i + 1 have landed (block i + 2's six requests may be in flight)
+        __syncthreads();                                                        // ... everybody's; and everybody is done with the planes block i + 1 goes into
+        convert(raw_p(par ^ 1), planes(par ^ 1), blk + step);
+        __syncthreads();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                            // no DMA into this workgroup's LDS may outlive it
+    constexpr int NP = 32 * NT, KP = 32 * KT, LDP = KP;
+    float *out = a.partial + (size_t)blockIdx.x * NP * LDP;
+    const float dsz = pow2f(-kz), dsx = pow2f(-kx);
+#pragma unroll
+    for (int u = 0; u < KTW; ++u) {
+        const int kc = 32 * u + (lane & 31);
+        const float d2 = kc == a.K ? 1.0f : dsx;                               // the bias column was staged unscaled
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = 32 * wn + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            out[(size_t)n * LDP + kc] = __fmul_rn(__fmul_rn(acc[u][r], dsz), d2);
+        }
+    }
+}
+
 // dW[n, k] (+)= sum over the workgroups that had rows, in a FIXED order; db[n] likewise (column KP of the partials).  64 outputs per block
 // (coalesced along k), the partials dealt to the block's four waves (wave w takes partials w, w + 4, ...: eight interleaved running sums each),
 // the four results added in wave order -- a single chain of `used` dependent loads per output was 13 us of latency per launch, fifteen times
@@ -679,9 +828,16 @@ extern "C" int hnr_h2wgrad(const float *d_dZ, int ldz, const float *d_X, int ldx
     const bool biasv = false;
     if (NT == 8 && KT == 9) {
         constexpr int rsz = ((32 * 8 * 2 - 64 + 255) & ~255) + 64, rsx = ((32 * 9 * 2 - 64 + 255) & ~255) + 64, ldsb = 3 * (2 * 16 * rsz + 2 * 16 * rsx);
+        constexpr int lds_dma = 2 * (2 * 16 * rsz + 2 * 16 * rsx) + 2 * 16 * (256 + 288) * 4;     // two plane stages + two raw blocks
+        static int use_dma = -1;
+        if (use_dma < 0) { const char *e = getenv("HNR_WGRAD_DMA"); use_dma = e ? atoi(e) : 1; }   // 0: the register-staged kernel (A/B timing)
         static PerDeviceOnce once89;
-        if (once89.first()) HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(h2wgrad_kernel<8, 9, 1, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb));
-        h2wgrad_kernel<8, 9, 1, 0, 1><<<grid, 512, ldsb, st>>>(a);
+        if (once89.first()) {
+            HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(h2wgrad_kernel<8, 9, 1, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb));
+            HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(h2wgrad_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_dma));
+        }
+        if (use_dma) h2wgrad_dma_kernel<<<grid, 512, lds_dma, st>>>(a);
+        else h2wgrad_kernel<8, 9, 1, 0, 1><<<grid, 512, ldsb, st>>>(a);
     }
     HNR_H2WG_CASE(8, 9) HNR_H2WG_CASE(8, 8) HNR_H2WG_CASE(8, 2) HNR_H2WG_CASE(4, 9) HNR_H2WG_CASE(4, 5) HNR_H2WG_CASE(2, 9) HNR_H2WG_CASE(2, 5) HNR_H2WG_CASE(2, 3) HNR_H2WG_CASE(2, 2)
 #undef HNR_H2WG_CASE

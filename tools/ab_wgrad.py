@@ -1,0 +1,23 @@
+"""hnr_h2wgrad 256 x 256 at the C3 batch's row count: DMA-staged kernel (default) vs the register-staged one (HNR_WGRAD_DMA=0), same process is not
+possible (the switch is read once): run twice.  python tools/ab_wgrad.py"""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hybridneuralrendering_amd import _lib
+L = _lib.lib(); dev = torch.device("cuda:0")
+for (M, N, K) in ((306832, 256, 256), (306832, 256, 263)):
+    Z, X = torch.randn((M, N), device=dev), torch.randn((M, K + (4 - K % 4) % 4), device=dev)
+    mz = torch.tensor([np.float32(8.0).view(np.int32)], dtype=torch.int32, device=dev)
+    scratch = torch.empty((int(L.hnr_h2wgrad_scratch_bytes(N, K)),), dtype=torch.uint8, device=dev)
+    dW, db = torch.empty((N, K), device=dev), torch.empty((N,), device=dev)
+    run = lambda: _lib.check(L.hnr_h2wgrad(_lib.ptr(Z), N, _lib.ptr(X), X.shape[1], M, None, 1, 0, N, K, _lib.ptr(mz), _lib.ptr(mz), _lib.ptr(dW), K, _lib.ptr(db), 0, _lib.ptr(scratch), _lib.stream()), "wgrad")
+    for _ in range(3): run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20): run()
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 20
+    ref = Z.double().t() @ X[:, :K].double()
+    err = float((dW.double() - ref).abs().max() / ref.abs().max())
+    print("HNR_WGRAD_DMA=%s M=%d N=%d K=%d: %.4f ms per launch (+ reduce), %.2f TB/s of operands, max rel err vs fp64 %.2e, checksum %.9e" % (
+        os.environ.get("HNR_WGRAD_DMA", "1"), M, N, K, ms, M * (N + K) * 4 / ms / 1e9, err, float(dW.double().sum())))
