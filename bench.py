@@ -296,8 +296,8 @@ def train_leg_sharded(args, sc, opt, agg, cloud, rnd, cam, dev, world, rank, reh
     """BASELINE config C5 the way it runs on N GPUs (models/mvs_points_volumetric_model.py:111-131, models/base_rendering_model.py:677-745): one batch of
     49 dilated 8x8 patches (3136 rays, dilation_setup 7_8_1_6), the blur-handling module (12 symmetric 9x9 kernels) and the item's frame weight; the batch is
     sharded by WHOLE patches (parallel.shard_patches), every rank runs forward + blur + loss + backward on its 6-7 patches with the replicated cloud and
-    weights, then the gradients are summed: the network's 449 k parameters as one flat all-reduce, the embedding gradient as (id, row) pairs of the touched
-    points (all-gather + local scatter-add), conf / dir / colour as dense all-reduces.  Timed with HIP events per part; max over ranks.
+    weights, then the gradients are summed: the network's 449 k parameters as one flat all-reduce, the four point-buffer gradients as (id, 39-float row) pairs of
+    the touched points (ONE all-gather of ids + one of rows + a local scatter-add: parallel.allreduce_point_buffers_sparse).  Timed with HIP events per part; max over ranks.
     world == 1 and HNR_BENCH_EMULATE_RANK=r/n: rank r's share of an n-way split alone on this GPU, without the collectives, whose byte counts are
     reported instead (tools/predict_train_scaling.sh)."""
     import torch.distributed as dist
@@ -343,19 +343,18 @@ def train_leg_sharded(args, sc, opt, agg, cloud, rnd, cam, dev, world, rank, reh
             grads = [q.grad if q.grad is not None else torch.zeros_like(q) for q in agg.parameters()]
             touched = torch.unique(out["sample_pidx"][out["sample_pidx"] >= 0]).long()
             nbytes = dict(weights_allreduce=int(sum(x.numel() for x in grads) * 4), touched_points=int(touched.numel()),
-                          embedding_rows_allgather_per_rank=int(touched.numel() * (32 * 4 + 8)), dense_conf_dir_color_allreduce=int(sum(leaves[i].grad.numel() for i in (1, 2, 3)) * 4))
+                          point_rows_allgather_per_rank=int(touched.numel() * (39 * 4 + 8)), dense_point_allreduce_avoided=int(sum(x.grad.numel() for x in leaves) * 4))
             if world > 1:
                 if rehearsal:                                                   # gloo on host copies: control flow only
                     host = [x.detach().cpu() for x in grads]
                     parallel.allreduce_gradients(host)
-                    parallel.allreduce_point_gradients_sparse(leaves[0].grad.reshape(-1, 32).cpu(), touched.cpu())
-                    dense = [leaves[i].grad.detach().cpu().clone() for i in (1, 2, 3)]
-                    parallel.allreduce_gradients(dense)
+                    parallel.allreduce_point_buffers_sparse([x.grad.detach().cpu() for x in leaves], touched.cpu())
                 else:
                     parallel.allreduce_gradients(grads)
                     if e: e[2].record()
-                    leaves[0].grad = parallel.allreduce_point_gradients_sparse(leaves[0].grad.reshape(-1, 32), touched).reshape(leaves[0].shape)
-                    parallel.allreduce_gradients([leaves[i].grad for i in (1, 2, 3)])
+                    summed = parallel.allreduce_point_buffers_sparse([x.grad for x in leaves], touched)
+                    for x, gsum in zip(leaves, summed):
+                        x.grad = gsum
             if e and (world == 1 or rehearsal): e[2].record()
             if e: e[3].record()
             if timed is not None: timed.append(e)
@@ -386,8 +385,8 @@ def train_leg_sharded(args, sc, opt, agg, cloud, rnd, cam, dev, world, rank, reh
                     allreduce_points_ms=round(ar_p * 1e3, 3) if world > 1 and not rehearsal else None, n_ranks=n_way, steps=steps,
                     emulated_rank=("%d/%d on one GPU, no collectives" % (r_of, n_way)) if (emulate and world == 1) else None,
                     valid_samples=int(c[6]), neighbour_rows=int(c[3]), collective_bytes=nbytes,
-                    note="max over ranks; collectives: parallel.allreduce_gradients (one flat bucket of the network's gradients; dense conf / dir / colour) + "
-                         "parallel.allreduce_point_gradients_sparse (all-gather of the touched points' embedding rows + local scatter-add)")
+                    note="max over ranks; collectives: parallel.allreduce_gradients (one flat bucket of the network's gradients) + "
+                         "parallel.allreduce_point_buffers_sparse (all-gather of the touched points' ids and 39-float rows + local scatter-add)")
     finally:
         opt.is_train, opt.dilation_setup = old_train, old_dil
         for prm in agg.parameters():

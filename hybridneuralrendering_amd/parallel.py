@@ -191,3 +191,40 @@ def allreduce_point_gradients_sparse(grad, touched, group=None):
         if k:
             out.index_add_(0, i[:k], r[:k])
     return out
+
+
+def allreduce_point_buffers_sparse(grads, touched, group=None):
+    """SUM over ranks of ALL the point-buffer gradients of a training step -- embeddings [N,32], conf [N,1], dir [N,3], colour [N,3] (any list of
+    [N, C_i] or [1, N, C_i] tensors) -- that are non-zero only on the rows `touched` (int64 ids of the points this rank's rays referenced): the
+    touched rows of all buffers are packed side by side into ONE [n, sum C_i] matrix, so the step's point gradients cost one all-gather of ids and one
+    of rows (~12 k points x 164 B per rank for a 6-7-patch share of the C5 batch) and a local scatter-add, instead of a dense all-reduce of
+    N x 39 floats (312 MB at 2 M points; the dense conf / dir / colour all-reduce alone was 56 MB).  Returns the summed dense gradients (new tensors,
+    shaped like the inputs).  Deterministic: every rank adds the ranks' rows in rank order."""
+    shapes = [g.shape for g in grads]
+    flat = [g.reshape(-1, g.shape[-1]) for g in grads]
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return [g for g in grads]
+    widths = [f.shape[1] for f in flat]
+    packed = torch.cat([f.index_select(0, touched) for f in flat], dim=1) if touched.numel() else torch.zeros((0, sum(widths)), dtype=flat[0].dtype, device=flat[0].device)
+    world = dist.get_world_size(group)
+    n_local = torch.tensor([touched.numel()], dtype=torch.int64, device=packed.device)
+    counts = [torch.zeros_like(n_local) for _ in range(world)]
+    dist.all_gather(counts, n_local, group=group)
+    cap = max(1, int(max(int(c.item()) for c in counts)))
+    ids = torch.full((cap,), -1, dtype=torch.int64, device=packed.device)
+    rows = torch.zeros((cap, packed.shape[1]), dtype=packed.dtype, device=packed.device)
+    ids[:touched.numel()] = touched
+    rows[:touched.numel()] = packed
+    all_ids = [torch.empty_like(ids) for _ in range(world)]
+    all_rows = [torch.empty_like(rows) for _ in range(world)]
+    dist.all_gather(all_ids, ids, group=group)
+    dist.all_gather(all_rows, rows, group=group)
+    outs = [torch.zeros_like(f) for f in flat]
+    for i, r, c in zip(all_ids, all_rows, counts):
+        k = int(c.item())
+        off = 0
+        for o, w in zip(outs, widths):
+            if k:
+                o.index_add_(0, i[:k], r[:k, off:off + w])
+            off += w
+    return [o.reshape(sh) for o, sh in zip(outs, shapes)]

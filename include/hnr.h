@@ -17,6 +17,17 @@
  *     device that was current when they were first used.
  *
  * Each entry point cites the reference interface it replaces (paths relative to the reference repo).
+ *
+ * STABILITY.  Two tiers:
+ *   STABLE  -- what a reference-side binding needs and what later versions keep source- and binary-compatible: hnr_version,
+ *              hnr_last_error, hnr_points_bounds, hnr_grid_* (build / destroy / stats / bytes), hnr_march_query, hnr_ray_compact*, hnr_point_records,
+ *              hnr_image_features*, hnr_render_forward* (+ workspace sizing), hnr_render_train_forward / _backward (+ sizing), hnr_shipped_loss*,
+ *              hnr_composite, hnr_ray_march, hnr_voxel_downsample*, hnr_probe_select, hnr_blur_*.
+ *   STAGE   -- everything else (hnr_chain_*, hnr_mlp3_*, hnr_merge*, hnr_mixup_stage, hnr_proj_*, hnr_h2*, hnr_linear_*, hnr_gather_*, hnr_ksum*,
+ *              hnr_segment_*, hnr_absmax, hnr_div_probe, ...): the individual stages the two single-call entries are built from.  They are exported so
+ *              that tests/ can compare every stage with the oracle and so that tools/ can time them alone; their signatures, workspace layouts and
+ *              packed-image formats follow the kernels and MAY CHANGE from one version to the next (round 4 changed what hnr_chain_forward leaves
+ *              in the workspace's row scalars, for example).  Do not bind to them from outside this repository.
  */
 #ifndef HNR_H
 #define HNR_H

@@ -183,6 +183,18 @@ def pg(r):
 d, ids = pg(rank)
 s = parallel.allreduce_point_gradients_sparse(d, ids)
 assert torch.allclose(s, pg(0)[0] + pg(1)[0], rtol=0, atol=1e-6)
+# all four point buffers in one exchange (embeddings, conf, dir, colour: reference shapes with the leading 1)
+def pb(r):
+    d_, ids_ = pg(r)
+    g = torch.Generator().manual_seed(70 + r)
+    bufs = [d_.reshape(1, N, 32)]
+    for w in (1, 3, 3):
+        t = torch.zeros(1, N, w); t[0, ids_] = torch.randn(ids_.numel(), w, generator=g); bufs.append(t)
+    return bufs, ids_
+bufs, ids4 = pb(rank)
+summed = parallel.allreduce_point_buffers_sparse(bufs, ids4)
+for got, a, b in zip(summed, pb(0)[0], pb(1)[0]):
+    assert got.shape == a.shape and torch.allclose(got, a + b, rtol=0, atol=1e-6)
 assert abs(parallel.loss_scale(hi - lo, 49 * 64) - (hi - lo) / 3136.0) < 1e-12
 if rank == 0:
     print("GRAD_OK")
