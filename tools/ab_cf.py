@@ -1,4 +1,4 @@
-"""The colour-feature launch (280 -> 128^3 + tail 64) of hnr_mlp3_forward on M rows: weight-stationary kernel (default) vs mlp3_kernel (HNR_CF_WS=0).
+"""The colour-feature launch (280 -> 128^3 + tail 64) of hnr_mlp3_forward on M rows: weight-stationary kernel (HNR_CF_WS=1) vs mlp3_kernel (default).
 The switch is read once per process: run once per setting; the printed SHA-1 of the two outputs must agree (bit-identical kernels).
 python tools/ab_cf.py [M]"""
 import os, sys, hashlib
@@ -31,4 +31,4 @@ t = x @ Ws[3].to(dev).double().t() + bs[3].to(dev).double()
 err = float((C[idx].double() - x).abs().max() / x.abs().max()), float((C2[idx].double() - t).abs().max() / t.abs().max())
 untouched = bool((C[M - 37:] == 7.0).all() and (C2[M - 37:] == 7.0).all())
 h = hashlib.sha1(C[:M - 37].cpu().numpy().tobytes() + C2[:M - 37].cpu().numpy().tobytes()).hexdigest()
-print("HNR_CF_WS=%s M=%d: %.3f ms per launch; max rel err vs fp64 (CF, tail) %.2e %.2e; rows past the count untouched: %s; sha1 %s" % (os.environ.get("HNR_CF_WS", "1"), M, ms, err[0], err[1], untouched, h))
+print("HNR_CF_WS=%s M=%d: %.3f ms per launch; max rel err vs fp64 (CF, tail) %.2e %.2e; rows past the count untouched: %s; sha1 %s" % (os.environ.get("HNR_CF_WS", "0"), M, ms, err[0], err[1], untouched, h))
