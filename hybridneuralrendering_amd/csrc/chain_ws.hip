@@ -181,6 +181,14 @@ static_assert(cw_need_count(32 + 0, 4, 48) == 28 && cw_need_count(32 + 7, 4, 90)
 static_assert(cw_need_count(3, 0, 18) == 22 && cw_need_count(0, 0, 0) == 30, "layer 0 fetches: followed by the image DMA of row tile 3, block1.2's 8..11, then by the first fetch of pass (0,0)");
 static_assert(cw_dma_count(3, 2) == 28 && cw_dma_count(0, 15) >= 16, "image DMA waits");
 
+// lanes l and l ^ 32 exchange a value: v_permlane32_swap_b32 on two copies leaves the low half's value (lo) and the high half's (hi) in both lanes
+__device__ __forceinline__ void cw_halves(float x, float &lo, float &hi)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    lo = __uint_as_float(r[0]); hi = __uint_as_float(r[1]);
+}
+typedef float cw_f32x4 __attribute__((ext_vector_type(4)));
+template <class T> using cw_lptr = __attribute__((address_space(3))) T *;      // LDS pointer (32 bits): what the laundered bases are
 template <int DBG>
 __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
 {
@@ -205,10 +213,23 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
     const int o_xp = (int)(wave >> 1) * SLOT + (int)(wave & 1) * 1024 + (int)lane * 16;   // layer-0 image chunks wave, 4 + wave: + i * 2 SLOT + rt * 2048
 #define CW_KEEP(x_) ({ int k_ = (x_); asm volatile("" : "+v"(k_)); k_; })
 #define CW_LDS(T_, off_) (*reinterpret_cast<T_ *>(lds + (off_)))
-#define CW_AT(T_, ptr_, off_) (*reinterpret_cast<T_ *>((ptr_) + (off_)))
-    char *q_b0 = lds, *q_b1 = lds, *q_b2 = lds, *q_pub = lds, *q_ext = lds, *q_exw = lds, *q_exr = lds, *q_cst = lds, *q_xp = lds, *q_dsw = lds, *q_dsr = lds;      // refreshed at every pass start
-#define CW_REFRESH() do { q_b0 = lds + CW_KEEP(o_b0); q_b1 = lds + CW_KEEP(o_b1); q_b2 = lds + CW_KEEP(o_b2); q_pub = lds + CW_KEEP(o_pub); q_ext = lds + CW_KEEP(o_ext); \
-        q_exw = lds + CW_KEEP(o_exw); q_exr = lds + CW_KEEP(o_exr); q_cst = lds + CW_KEEP(o_cst); q_xp = lds + CW_KEEP(o_xp); q_dsw = lds + CW_KEEP(o_dsw); q_dsr = lds + CW_KEEP(o_dsr); } while (0)
+#define CW_AT(T_, ptr_, off_) (*reinterpret_cast<cw_lptr<T_>>((ptr_) + (off_)))
+#define CW_AT_F4(ptr_, off_) ({ const cw_f32x4 v_ = CW_AT(const cw_f32x4, ptr_, off_); make_float4(v_[0], v_[1], v_[2], v_[3]); })
+    // The laundered values are 32-bit LDS POINTERS (copies of p_*, one v_mov each), refreshed at the start of a pass for the bases that pass uses
+    // (CW_REFRESH(P): the running pass's MFMA operands + the epilogue of pass P - 1); a base a pass does not use keeps its older copy.  (Laundered
+    // offsets + `lds +` cost a v_mov, a v_add of the zero LDS base and, for the bases a pass did not use, dead copies with hazard pads: ~30
+    // instructions at the head of every pass.)
+    cw_lptr<char> const lds3 = (cw_lptr<char>)lds;
+    cw_lptr<char> const p_b0 = lds3 + o_b0, p_b1 = lds3 + o_b1, p_b2 = lds3 + o_b2, p_pub = lds3 + o_pub, p_ext = lds3 + o_ext, p_exw = lds3 + o_exw, p_exr = lds3 + o_exr,
+                        p_cst = lds3 + o_cst, p_dsw = lds3 + o_dsw, p_dsr = lds3 + o_dsr;
+    cw_lptr<char> q_b0 = p_b0, q_b1 = p_b1, q_b2 = p_b2, q_pub = p_pub, q_ext = p_ext, q_exw = p_exw, q_exr = p_exr, q_cst = p_cst, q_dsw = p_dsw, q_dsr = p_dsr;
+#define CW_KEEPP(x_) ({ cw_lptr<char> k_ = (x_); asm volatile("" : "+v"(k_)); k_; })
+#define CW_REFRESH(P_) do { constexpr int pe_ = ((((P_) + 15) & 15) >> 2); \
+        q_b0 = CW_KEEPP(p_b0); q_cst = CW_KEEPP(p_cst); \
+        if constexpr ((P_) >= 3) { q_b1 = CW_KEEPP(p_b1); q_b2 = CW_KEEPP(p_b2); } \
+        if constexpr (pe_ != 3) { q_pub = CW_KEEPP(p_pub); q_exw = CW_KEEPP(p_exw); q_exr = CW_KEEPP(p_exr); } \
+        if constexpr (pe_ == 1) q_ext = CW_KEEPP(p_ext); \
+        if constexpr (pe_ == 3) { q_dsw = CW_KEEPP(p_dsw); q_dsr = CW_KEEPP(p_dsr); } } while (0)
 
     const int xcd = blockIdx.x & 7, nb = (gridDim.x + 7 - xcd) / 8, bi = blockIdx.x >> 3;
     const int per = (n_tiles + 7) / 8, t_lo = xcd * per, t_hi = (t_lo + per < n_tiles) ? t_lo + per : n_tiles;
@@ -328,7 +349,7 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
     float4 ex4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
     auto read_cst = [&](int L4, int k) __attribute__((always_inline)) {   // chunk k (items 2 k, 2 k + 1) of constants row L4 (0..3: biases, 4: alpha weights)
-        return (DBG == 5 || DBG == 7) ? make_float4(a.slope, 1.f, a.slope, 1.f) : CW_AT(const float4, q_cst, L4 * 1024 + (k >> 2) * 128 + (k & 3) * 16);
+        return (DBG == 5 || DBG == 7) ? make_float4(a.slope, 1.f, a.slope, 1.f) : CW_AT_F4(q_cst, L4 * 1024 + (k >> 2) * 128 + (k & 3) * 16);
     };
     // ---- epilogue of pass PP = (PL, PR), accumulator set se, cut into MICRO-STAGES of 3..8 VALU instructions.  A wave issues in order, and a
     //      dependent VALU instruction issues 8 cycles after its producer, an independent one 4: so every micro-stage holds two independent
@@ -393,13 +414,17 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
                     }
                 } else {
                     float m;
-                    if (PL == 3) { m = __fadd_rn(ap, __shfl_xor(ap, 32)); if (h == 0) CW_AT(float, q_dsw, PR * 512) = m; }
+                    // the two half-waves' partial results meet through v_permlane32_swap (one VALU instruction; a ds_bpermute's wait also drained the
+                    // operand reads in flight); both halves then hold the same value and both store it (same address: no exec-masked branch)
+                    float v_lo, v_hi;
+                    if (PL == 3) { cw_halves(ap, v_lo, v_hi); m = __fadd_rn(v_lo, v_hi); CW_AT(float, q_dsw, PR * 512) = m; }
                     else {
-                        m = fmaxf(amax, __shfl_xor(amax, 32));
+                        cw_halves(amax, v_lo, v_hi);
+                        m = fmaxf(v_lo, v_hi);
                         if (PL == 1 && PR == wave)
                             m = fmaxf(m, fmaxf(fmaxf(fmaxf(fabsf(e0.x), fabsf(e0.y)), fmaxf(fabsf(e0.z), fabsf(e0.w))), fmaxf(fmaxf(fabsf(e1.x), fabsf(e1.y)), fabsf(e1.z))));
                     }
-                    if (PL != 3 && h == 0 && DBG != 6 && DBG != 7) CW_AT(float, q_exw, exb) = m;
+                    if (PL != 3 && DBG != 6 && DBG != 7) CW_AT(float, q_exw, exb) = m;
                 }
             }
             return;
@@ -417,7 +442,7 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
             const int MS = 21, m0 = k2 * MS / N2, m1 = (k2 + 1) * MS / N2;
 #pragma unroll
             for (int ms = m0; ms < m1; ++ms) {
-                if (ms == 0) ex4 = (DBG == 5 || DBG == 7) ? make_float4(amax, 1.f, 2.f, 3.f) : CW_AT(const float4, q_exr, exb);
+                if (ms == 0) ex4 = (DBG == 5 || DBG == 7) ? make_float4(amax, 1.f, 2.f, 3.f) : CW_AT_F4(q_exr, exb);
                 else if (ms == 1) {
                     const int k = row_scale_exp(fmaxf(fmaxf(ex4.x, ex4.y), fmaxf(ex4.z, ex4.w)));
                     sc_run = pow2f(k);
@@ -479,7 +504,7 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
 #pragma unroll
         for (int ms = m0; ms < m1; ++ms) {
             if (ms == 0) {
-                if (PR == 3) ex4 = CW_AT(const float4, q_dsr, 0);
+                if (PR == 3) ex4 = CW_AT_F4(q_dsr, 0);
                 // this row tile's samples: (4 << kc) of them from sample PR (4 << kc) of the tile; lanes past the tile's / class's end are out of the descriptor's range
                 const int ls = (j >> (3 - kc_e)) + (4 << kc_e) * PR;
                 const bool st = (j & ((8 >> kc_e) - 1)) == 0;
@@ -529,7 +554,7 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
     };
 
     TileOut to_fin = tile_out(-1);                                         // the tile whose last row tile's sums are still due (none yet)
-    CW_REFRESH();
+    CW_REFRESH(0);
     bq[0] = read_cst(3, 0); bq[1] = read_cst(3, 1); aq[0] = read_cst(4, 0); aq[1] = read_cst(4, 1);      // the first epilogue piece is (3,3)'s (of no tile: its stores are dropped)
     bf[0][0] = b_read(0, 0, 0); bf[0][1] = b_read(0, 0, 1);                // iteration 0 of the first tile's pass (0,0); later tiles: asked for at the end of pass (3,3)
     for (int tile = t_first; tile < t_end; tile += t_step) {
@@ -537,7 +562,7 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
         const int tile_next = tile + t_step;
         const int tile_nx = tile_next < t_end ? tile_next : tile;         // what is fetched ahead (the last tile fetches itself again: no branch in the passes)
         const TileOut to_cur = tile_out(tile);
-        CW_REFRESH();
+        CW_REFRESH(0);
         bf[1][0] = b_read(0, 1, 0); bf[1][1] = b_read(0, 1, 1);            // iteration 1 of pass (0,0)
         cw_static_for<16>([&](auto Pc) __attribute__((always_inline)) {
             constexpr int P = decltype(Pc)::value;
@@ -546,7 +571,7 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
             constexpr int T = 6 * S, H = T / 2;
             const TileOut &to_e = P == 0 ? to_fin : to_cur;                // tile of the row tile whose epilogue runs here
             if (DBG >= 2) { const long long t_ = clock64(); tm[(P + 15) & 15] += t_ - t_prev; t_prev = t_; if (P == 2) tmf[3] += t_ - tf_prev; if (P == 1) tf_prev = t_; }
-            if (P != 0) CW_REFRESH();
+            if constexpr (P != 0) CW_REFRESH(P);
             // ---- pass start: loads that ride ahead (each placed where no wait of the following passes lands right behind it)
             if (P == 6) {                                                  // block3.0's 17th k step: used by the last MFMAs of passes (2, 0..3)
 #pragma unroll
@@ -611,7 +636,7 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
         for (int rt = 0; rt < 4; ++rt) pid[rt] = pid_n[rt];
     }
     // ---- drain: the last tile's layer-3 epilogue of row tile 3
-    CW_REFRESH();
+    CW_REFRESH(0);
     cw_static_for<6 * CH_S0>([&](auto kc) __attribute__((always_inline)) {
         constexpr int slot = decltype(kc)::value;
         if (slot == (6 * CH_S0) / 2) cw_lds_barrier();
