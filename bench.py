@@ -342,6 +342,8 @@ def train_leg_sharded(args, sc, opt, agg, cloud, rnd, cam, dev, world, rank, reh
             if e: e[1].record()
             grads = [q.grad if q.grad is not None else torch.zeros_like(q) for q in agg.parameters()]
             touched = torch.unique(out["sample_pidx"][out["sample_pidx"] >= 0]).long()
+            assert touched.numel() == 0 or int(touched.max()) < leaves[0].shape[-2], "sample_pidx holds id %d >= %d points (shapes %s, pidx %s)" % (
+                int(touched.max()), leaves[0].shape[-2], [tuple(x.shape) for x in leaves], tuple(out["sample_pidx"].shape))
             nbytes = dict(weights_allreduce=int(sum(x.numel() for x in grads) * 4), touched_points=int(touched.numel()),
                           point_rows_allgather_per_rank=int(touched.numel() * (39 * 4 + 8)), dense_point_allreduce_avoided=int(sum(x.grad.numel() for x in leaves) * 4))
             if world > 1:

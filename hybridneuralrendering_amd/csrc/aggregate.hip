@@ -119,7 +119,7 @@ __device__ __forceinline__ void w2pers(const float *p, const float *campos, cons
 #pragma unroll
     for (int j = 0; j < 3; ++j)
         c[j] = __fadd_rn(__fadd_rn(__fmul_rn(camrot[j], s0), __fmul_rn(camrot[3 + j], s1)), __fmul_rn(camrot[6 + j], s2));
-    out[0] = __fdiv_rn(c[0], c[2]); out[1] = __fdiv_rn(c[1], c[2]); out[2] = c[2];
+    out[0] = hnr_div(c[0], c[2]); out[1] = hnr_div(c[1], c[2]); out[2] = c[2];
 }
 
 // SPLIT = 1: X1 rows hold only the 60 distance-encoding columns (the point-only 224 columns of block1's input are folded
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(GatherArgs a)
             raw[F + 5] = __fsub_rn(pp[2], sp[2]);
             // linear kernel (:825-833)
             const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
-            wraw = __fdiv_rn(1.0f, fmaxf(nrm, 1e-6f));
+            wraw = hnr_div(1.0f, fmaxf(nrm, 1e-6f));
             const float cf = a.conf[pid];
             confc = fminf(fmaxf(cf, 0.0001f), 1.0f);                 // gradiant_clamp forward value (:1422-1424)
             // block3 extras (:957-971): colour, dir - viewdir, dir . viewdir (viewdir = raw ray direction)
@@ -204,13 +204,13 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(GatherArgs a)
                     const float ex = __fsub_rn(a.xyz[3 * (size_t)pid2], lw[0]), ey = __fsub_rn(a.xyz[3 * (size_t)pid2 + 1], lw[1]),
                                 ez = __fsub_rn(a.xyz[3 * (size_t)pid2 + 2], lw[2]);
                     const float n2 = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)), __fmul_rn(ez, ez)));
-                    extra += __fdiv_rn(1.0f, fmaxf(n2, 1e-6f));
+                    extra += hnr_div(1.0f, fmaxf(n2, 1e-6f));
                 }
             }
             sum += extra;
         }
         if (row >= 0) {
-            const float w = __fdiv_rn(wraw, fmaxf(sum, 1e-8f));
+            const float w = hnr_div(wraw, fmaxf(sum, 1e-8f));
             a.wagg[row] = __fmul_rn(w, confc);
             if (SPLIT) a.row_pid[row] = a.pidx[(size_t)item * K + kk];
             if (a.weight_out) { a.weight_out[(size_t)item * K + kk] = w; a.conf_out[(size_t)item * K + kk] = confc; }
@@ -370,7 +370,7 @@ __global__ void conv3x3_lrelu_kernel(const float *__restrict__ in, int Cin, int 
 __device__ __forceinline__ float bilinear_at(const float *__restrict__ p, int Hs, int Ws, int H, int W, int y, int x)
 {
     // F.interpolate(mode='bilinear', align_corners=False): src = (dst + 0.5) * (in/out) - 0.5, clamped at 0
-    const float sy = (float)Hs / (float)H, sx = (float)Ws / (float)W;
+    const float sy = hnr_div((float)Hs, (float)H), sx = hnr_div((float)Ws, (float)W);
     float fy = ((float)y + 0.5f) * sy - 0.5f, fx = ((float)x + 0.5f) * sx - 0.5f;
     if (fy < 0.f) fy = 0.f;
     if (fx < 0.f) fx = 0.f;
@@ -384,7 +384,7 @@ __device__ __forceinline__ float bilinear_at(const float *__restrict__ p, int Hs
 struct BilinearTap { size_t i00, i01, i10, i11; float hy, hx, ly, lx; };
 __device__ __forceinline__ BilinearTap bilinear_tap(int Hs, int Ws, int H, int W, int y, int x)
 {
-    const float sy = (float)Hs / (float)H, sx = (float)Ws / (float)W;
+    const float sy = hnr_div((float)Hs, (float)H), sx = hnr_div((float)Ws, (float)W);
     float fy = ((float)y + 0.5f) * sy - 0.5f, fx = ((float)x + 0.5f) * sx - 0.5f;
     if (fy < 0.f) fy = 0.f;
     if (fx < 0.f) fx = 0.f;

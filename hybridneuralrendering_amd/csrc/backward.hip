@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void composite_bwd_serial_kernel(CompositeBwdA
         const float4 d = reinterpret_cast<const float4 *>(a.decoded)[(size_t)r * a.SR + s];
         const float gs = d.y * g0 + d.z * g1 + d.w * g2;
         const float q = 1.f - o + 1e-10f;
-        const float d_o = Ts * gs - S / q;
+        const float d_o = Ts * gs - hnr_div(S, q);
         const float w = o * Ts;
         S += gs * w;
         const float sigma = rd > 0.f ? d.x : 0.f;
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a)
     }
     if (in) {
         const float q = 1.f - o_l + 1e-10f;
-        const float d_o = T_l * gs_l - S_l / q;
+        const float d_o = T_l * gs_l - hnr_div(S_l, q);
         const float sigma = rd_l > 0.f ? d_l.x : 0.f;
         const float d_sigma = d_o * rd_l * expf(-sigma * rd_l);
         dd[lane] = make_float4(d_sigma, w_l * g0, w_l * g1, w_l * g2);
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(1024) void final_color_bwd_kernel(FinalBwdArgs a)
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             r[j] = wave_sum(r[j]);
-            const float sg = 1.f / (1.f + expf(-(r[j] + bf[j])));
+            const float sg = hnr_div(1.f, 1.f + expf(-(r[j] + bf[j])));
             dz[j] = gc[j] * (1.f + 2.f * 0.001f) * sg * (1.f - sg);
             ab[j] += dz[j];
         }
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(64 * NW) void merge_bwd_kernel(MergeBwdArgs a)
         for (int v = 0; v < VT; ++v) {
             if (v >= a.V) break;
             const float d = wave_sum(hm[v] * wl);
-            sg[v] = 1.f / (1.f + expf(-(d + bl)));
+            sg[v] = hnr_div(1.f, 1.f + expf(-(d + bl)));
             scale[v] = vm[v] * (a.frame_w ? a.frame_w[v] : 1.f);
             wv[v] = sg[v] * vm[v];
             if (a.frame_w) wv[v] *= a.frame_w[v];
@@ -322,14 +322,14 @@ __global__ __launch_bounds__(64 * NW) void merge_bwd_kernel(MergeBwdArgs a)
             wsum += wv[v];
         }
         const float den = wsum + 1e-6f;
-        const float merged = fsum / den;
+        const float merged = hnr_div(fsum, den);
         const float dm = drop ? 0.f : dm_in;
 #pragma unroll
         for (int v = 0; v < VT; ++v) {
             if (v >= a.V) break;
             const size_t row = (size_t)v * a.cap + s;
-            if (lane < 48) a.gF[row * a.ldgf + lane] = dm * wv[v] / den;
-            const float d_wv = wave_sum(dm * (f[v] - merged) / den);
+            if (lane < 48) a.gF[row * a.ldgf + lane] = hnr_div(dm * wv[v], den);
+            const float d_wv = wave_sum(hnr_div(dm * (f[v] - merged), den));
             const float d_pre = d_wv * scale[v] * sg[v] * (1.f - sg[v]);
             const float gz = d_pre * wl * (hm[v] > 0.f ? 1.f : a.slope);
             a.gZ3[row * a.ldgz + lane] = gz;
@@ -447,12 +447,12 @@ __device__ __forceinline__ void upsample_bwd_body(int64_t block, const float *__
     const int cl = (int)(idx % C), xs = (int)((idx / C) % Ws), ys = (int)((idx / ((int64_t)C * Ws)) % Hs), v = (int)(idx / ((int64_t)C * Ws * Hs));
     const int bx0 = bbox[4 * v], by0 = bbox[4 * v + 1], bx1 = bbox[4 * v + 2], by1 = bbox[4 * v + 3];
     if (bx1 < bx0) return;
-    const float sy = (float)Hs / (float)H, sx = (float)Ws / (float)W;
+    const float sy = hnr_div((float)Hs, (float)H), sx = hnr_div((float)Ws, (float)W);
     // destination pixels that can touch this source cell: source coordinate (y + 0.5) sy - 0.5 within (ys - 1, ys + 1), i.e. y within
     // ((ys - 0.5) / sy - 0.5, (ys + 1.5) / sy - 0.5), widened by one pixel; row / column 0 also takes the coordinates clamped up to 0
     // (the window used to be (3 r + 2)^2 pixels, r = H / Hs, for the (2 r)^2 that carry weight: 2.6x the loop trips at level 3)
-    int ylo = ys == 0 ? 0 : (int)floorf(((float)ys - 0.5f) / sy - 0.5f) - 1, yhi = (int)ceilf(((float)ys + 1.5f) / sy - 0.5f) + 1;
-    int xlo = xs == 0 ? 0 : (int)floorf(((float)xs - 0.5f) / sx - 0.5f) - 1, xhi = (int)ceilf(((float)xs + 1.5f) / sx - 0.5f) + 1;
+    int ylo = ys == 0 ? 0 : (int)floorf(hnr_div((float)ys - 0.5f, sy) - 0.5f) - 1, yhi = (int)ceilf(hnr_div((float)ys + 1.5f, sy) - 0.5f) + 1;
+    int xlo = xs == 0 ? 0 : (int)floorf(hnr_div((float)xs - 0.5f, sx) - 0.5f) - 1, xhi = (int)ceilf(hnr_div((float)xs + 1.5f, sx) - 0.5f) + 1;
     ylo = ylo < by0 ? by0 : ylo; yhi = yhi > by1 + 1 ? by1 + 1 : yhi;
     xlo = xlo < bx0 ? bx0 : xlo; xhi = xhi > bx1 + 1 ? bx1 + 1 : xhi;
     float acc = 0.f;

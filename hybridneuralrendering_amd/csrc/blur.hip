@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void blur_select_kernel(BlurArgs a)
                 msk += w;
             }
         }
-        return acc / msk;
+        return hnr_div(acc, msk);
     };
     // L1 distance of every candidate: (candidate, position) pairs over the block, wave partial sums -> LDS atomics
     for (int n = 0; n <= a.N; ++n) {
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void blur_select_bwd_kernel(BlurBwdArgs a)
                     if (xx >= 0 && xx < ps) msk += k[dy * a.ks + dx];
                 }
             }
-            g /= msk;
+            g = hnr_div(g, msk);
         }
         s_g[c][y][x] = g;
     }
@@ -177,8 +177,8 @@ __global__ __launch_bounds__(256) void blur_gray_kernel(BlurLearnArgs a)
         const int y = t / ps, x = t % ps;
         const size_t ray = blur_ray(p, y, x, a.pn, ps, a.patch_major);
         const float *g = a.gt + 3 * ray, *c = a.color + 3 * ray;
-        a.gray[((size_t)p * 2 + 0) * ps * ps + t] = ((g[0] + g[1]) + g[2]) / 3.0f;
-        a.gray[((size_t)p * 2 + 1) * ps * ps + t] = ((c[0] + c[1]) + c[2]) / 3.0f;
+        a.gray[((size_t)p * 2 + 0) * ps * ps + t] = hnr_div((g[0] + g[1]) + g[2], 3.0f);
+        a.gray[((size_t)p * 2 + 1) * ps * ps + t] = hnr_div((c[0] + c[1]) + c[2], 3.0f);
     }
 }
 
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void blur_gray_bwd_kernel(BlurLearnArgs a)
     for (int t = threadIdx.x; t < ps * ps; t += blockDim.x) {
         const int y = t / ps, x = t % ps;
         const size_t ray = blur_ray(p, y, x, a.pn, ps, a.patch_major);
-        const float g = a.g_gray[((size_t)p * 2 + 1) * ps * ps + t] / 3.0f;
+        const float g = hnr_div(a.g_gray[((size_t)p * 2 + 1) * ps * ps + t], 3.0f);
         a.g_color[3 * ray + 0] = g; a.g_color[3 * ray + 1] = g; a.g_color[3 * ray + 2] = g;
     }
 }
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void blur_apply_kernel(BlurLearnArgs a)
         }
         if (!BWD) {
             const size_t ray = blur_ray(p, y, x, a.pn, ps, a.patch_major);
-            a.out[3 * ray + c] = a.mode == 0 ? acc / (msk + 1e-10f) : acc + (1.f - msk) * s_in[c][y][x];
+            a.out[3 * ray + c] = a.mode == 0 ? hnr_div(acc, msk + 1e-10f) : acc + (1.f - msk) * s_in[c][y][x];
         } else {
             s_conv[c][y][x] = acc;
             if (c == 0) s_msk[y][x] = msk;
@@ -243,8 +243,8 @@ __global__ __launch_bounds__(256) void blur_apply_kernel(BlurLearnArgs a)
             const float g = s_g[c][y][x];
             if (a.mode == 0) {
                 const float d = m + 1e-10f;
-                dm -= g * s_conv[c][y][x] / (d * d);
-                s_g[c][y][x] = g / d;
+                dm -= hnr_div(g * s_conv[c][y][x], d * d);
+                s_g[c][y][x] = hnr_div(g, d);
             } else {
                 dm -= g * s_in[c][y][x];
             }

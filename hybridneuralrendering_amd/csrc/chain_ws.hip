@@ -192,7 +192,7 @@ template <class T> using cw_lptr = __attribute__((address_space(3))) T *;      /
 template <int DBG>
 __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
 {
-    constexpr int SLOT = ch_slot(4), SAMPLES = 16;
+    constexpr int SLOT = ch_slot(4);
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5, j = lane & 31;   // wave in an SGPR: its tests are scalar branches
     const ChainClasses cls = chain_classes(a.counts, a.cap_samples);      // tiles [0, big_tiles): 16 samples x 8 row slots; the rest: 32 samples x 4
@@ -210,7 +210,6 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
     const int o_exw = (int)ch_lds_exch(4) + (int)(j * 4 + wave) * 4, o_exr = (int)ch_lds_exch(4) + (int)j * 16;   // exchange [2][32 rows][4 waves]
     const int o_dsw = (int)CW_DSUM + (int)(j * 4 + wave) * 4, o_dsr = (int)CW_DSUM + (int)wave * 512 + (int)j * 16;    // write: + rt * 512; read: this wave's row tile
     const int o_cst = (int)CW_CST + (int)col0 * 4;                                  // constants: + layer * 1024 + c * 128 + q4 * 16
-    const int o_xp = (int)(wave >> 1) * SLOT + (int)(wave & 1) * 1024 + (int)lane * 16;   // layer-0 image chunks wave, 4 + wave: + i * 2 SLOT + rt * 2048
 #define CW_KEEP(x_) ({ int k_ = (x_); asm volatile("" : "+v"(k_)); k_; })
 #define CW_LDS(T_, off_) (*reinterpret_cast<T_ *>(lds + (off_)))
 #define CW_AT(T_, ptr_, off_) (*reinterpret_cast<cw_lptr<T_>>((ptr_) + (off_)))

@@ -84,10 +84,48 @@ __device__ __forceinline__ void absmax_publish(unsigned *dst, float mx)
     if ((b >> 23) > (__hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 23)) atomicMax(dst, b);
 }
 
+// Correctly rounded fp32 division WITHOUT v_div_scale / v_div_fmas: the steps of the compiler's own expansion (reciprocal, one refinement of it,
+// quotient, two residual corrections -- the same fused operations in the same order, hence the same bits) minus the operand scaling that only
+// matters at the ends of the exponent range; operands out there take the compiler's `/`.  Why: v_div_fmas reads the lane mask v_div_scale left
+// in VCC, and twice -- in two unrelated kernels, always lanes 48..63, only with several busy queues / processes on the GPU -- a quotient came out as if
+// that mask had been someone else's (profiles/README.md: shared-GPU renders, three-queue training).  The kernels where it was seen divide with this.
+__device__ __forceinline__ float hnr_div(float n, float d)
+{
+    const unsigned en = (__float_as_uint(n) >> 23) & 0xffu, ed = (__float_as_uint(d) >> 23) & 0xffu;
+    if (__builtin_expect(ed - 32u > 190u || (en - 32u > 190u && n != 0.f) || (int)en - (int)ed > 120 || (int)en - (int)ed < -120, 0))
+#ifdef HNR_DIV_NO_FALLBACK                                                  // tools/check_divisions.sh: with the fallback gone, no object may contain v_div_fmas
+        return 0.f;
+#else
+        return n / d;                                                       // zero / denormal / huge / inf / nan operands, quotients near the range's ends
+#endif
+    float r = __builtin_amdgcn_rcpf(d);
+    r = fmaf(fmaf(-d, r, 1.0f), r, r);
+    float q = __fmul_rn(n, r);
+    q = fmaf(fmaf(-d, q, n), r, q);
+    return fmaf(fmaf(-d, q, n), r, q);
+}
+
+// The same for fp64 (the loss kernels' scalar means): reciprocal refined twice, quotient, one residual correction -- the compiler's own steps.
+__device__ __forceinline__ double hnr_div64(double n, double d)
+{
+    const unsigned en = (unsigned)((__double_as_longlong(n) >> 52) & 0x7ff), ed = (unsigned)((__double_as_longlong(d) >> 52) & 0x7ff);
+    if (__builtin_expect(ed - 128u > 1790u || (en - 128u > 1790u && n != 0.0) || (int)en - (int)ed > 900 || (int)en - (int)ed < -900, 0))
+#ifdef HNR_DIV_NO_FALLBACK
+        return 0.0;
+#else
+        return n / d;
+#endif
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    const double q = n * r;
+    return fma(fma(-d, q, n), r, q);
+}
+
 __device__ __forceinline__ int cell_coord(float p, float o, float c)
 {
     float d = __fsub_rn(p, o);
-    float q = __fdiv_rn(d, c);
+    float q = hnr_div(d, c);
     if (!(q > -2.0e9f && q < 2.0e9f)) return INT32_MIN;
     return (int)floorf(q);
 }
@@ -105,23 +143,6 @@ __device__ __forceinline__ uint32_t brick_word(const GridView &g, int x, int y, 
 __device__ __forceinline__ int brick_bit(int x, int y, int z)
 {
     return ((x & 3) << 4) | ((y & 3) << 2) | (z & 3);
-}
-
-// Correctly rounded fp32 division WITHOUT v_div_scale / v_div_fmas: the steps of the compiler's own expansion (reciprocal, one refinement of it,
-// quotient, two residual corrections -- the same fused operations in the same order, hence the same bits) minus the operand scaling that only
-// matters at the ends of the exponent range; operands out there take the compiler's `/`.  Why: v_div_fmas reads the lane mask v_div_scale left
-// in VCC, and twice -- in two unrelated kernels, always lanes 48..63, only with several busy queues / processes on the GPU -- a quotient came out as if
-// that mask had been someone else's (profiles/README.md: shared-GPU renders, three-queue training).  The kernels where it was seen divide with this.
-__device__ __forceinline__ float hnr_div(float n, float d)
-{
-    const unsigned en = (__float_as_uint(n) >> 23) & 0xffu, ed = (__float_as_uint(d) >> 23) & 0xffu;
-    if (__builtin_expect(ed - 32u > 190u || (en - 32u > 190u && n != 0.f) || (int)en - (int)ed > 120 || (int)en - (int)ed < -120, 0))
-        return n / d;                                                       // zero / denormal / huge / inf / nan operands, quotients near the range's ends
-    float r = __builtin_amdgcn_rcpf(d);
-    r = fmaf(fmaf(-d, r, 1.0f), r, r);
-    float q = __fmul_rn(n, r);
-    q = fmaf(fmaf(-d, q, n), r, q);
-    return fmaf(fmaf(-d, q, n), r, q);
 }
 
 // Reprojection of a world-space sample into reference view v + truncation to a pixel + bounds rule (models/neural_points_volumetric_model.py:248-255,

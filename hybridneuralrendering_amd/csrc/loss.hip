@@ -57,11 +57,11 @@ __global__ __launch_bounds__(256) void loss_finish_kernel(LossArgs a)
     if (threadIdx.x == 0) {
         double se = 0.0, nv = 0.0, zo = 0.0;
         for (int b = 0; b < LOSS_BLOCKS; ++b) { se += a.partial[3 * b]; nv += a.partial[3 * b + 1]; zo += a.partial[3 * b + 2]; }
-        const float lc = nv > 0.0 ? (float)(se / (3.0 * nv)) : 0.f;
+        const float lc = nv > 0.0 ? (float)hnr_div64(se, 3.0 * nv) : 0.f;
         const double n_conf = a.conf_per_ray > 0 ? nv * (double)a.conf_per_ray : (double)a.n_conf;
-        const float lz = n_conf > 0.0 ? (float)(zo / n_conf) : 0.f;
-        s_scale[0] = nv > 0.0 ? (float)(2.0 / (3.0 * nv)) * a.w_color * a.frame_weight : 0.f;
-        s_scale[1] = n_conf > 0.0 ? a.w_zero_one / (float)n_conf : 0.f;
+        const float lz = n_conf > 0.0 ? (float)hnr_div64(zo, n_conf) : 0.f;
+        s_scale[0] = nv > 0.0 ? (float)hnr_div64(2.0, 3.0 * nv) * a.w_color * a.frame_weight : 0.f;
+        s_scale[1] = n_conf > 0.0 ? hnr_div(a.w_zero_one, (float)n_conf) : 0.f;
         if (blockIdx.x == 0) {
             a.out[0] = (lc * a.w_color + 1e-6f) * a.frame_weight + lz * a.w_zero_one;
             a.out[1] = lc; a.out[2] = lz; a.out[3] = (float)nv;
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void loss_finish_kernel(LossArgs a)
         const float x = a.conf[i];
         const bool on = a.conf_per_ray <= 0 || a.ray_mask[i / a.conf_per_ray] > 0;
         // torch.clamp passes the gradient where eps <= x <= 1 - eps
-        a.g_conf[i] = (on && x >= a.eps && x <= 1.f - a.eps) ? (1.f / x - 1.f / (1.f - x)) * sz : 0.f;
+        a.g_conf[i] = (on && x >= a.eps && x <= 1.f - a.eps) ? (hnr_div(1.f, x) - hnr_div(1.f, 1.f - x)) * sz : 0.f;
     }
 }
 

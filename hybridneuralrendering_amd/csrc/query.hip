@@ -582,7 +582,7 @@ __global__ __launch_bounds__(256) void compact_rows_kernel(const int32_t *__rest
         for (int j = 0; j < 3; ++j)
             c[j] = __fadd_rn(__fadd_rn(__fmul_rn(s0, camrot[j]), __fmul_rn(s1, camrot[3 + j])), __fmul_rn(s2, camrot[6 + j]));
         float *o = o_pers + ((size_t)row * SR + s) * 3;
-        o[0] = __fdiv_rn(c[0], c[2]); o[1] = __fdiv_rn(c[1], c[2]); o[2] = c[2];
+        o[0] = hnr_div(c[0], c[2]); o[1] = hnr_div(c[1], c[2]); o[2] = c[2];
     }
 }
 

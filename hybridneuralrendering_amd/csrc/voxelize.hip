@@ -24,9 +24,9 @@ __global__ void vox_keys_kernel(const float *__restrict__ xyz, int n, float mx, 
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float qx = floorf(__fdiv_rn(__fsub_rn(xyz[3 * i + 0], mx), sz));
-    const float qy = floorf(__fdiv_rn(__fsub_rn(xyz[3 * i + 1], my), sz));
-    const float qz = floorf(__fdiv_rn(__fsub_rn(xyz[3 * i + 2], mz), sz));
+    const float qx = floorf(hnr_div(__fsub_rn(xyz[3 * i + 0], mx), sz));
+    const float qy = floorf(hnr_div(__fsub_rn(xyz[3 * i + 1], my), sz));
+    const float qz = floorf(hnr_div(__fsub_rn(xyz[3 * i + 2], mz), sz));
     const float lim = (float)(1 << VOX_BITS);
     if (!(qx >= 0.f && qx < lim && qy >= 0.f && qy < lim && qz >= 0.f && qz < lim)) { atomicOr(bad, 1); keys[i] = ~0ull >> 1; return; }
     keys[i] = ((unsigned long long)(unsigned)qx << (2 * VOX_BITS)) | ((unsigned long long)(unsigned)qy << VOX_BITS) | (unsigned long long)(unsigned)qz;
@@ -57,7 +57,7 @@ __global__ void vox_reduce_kernel(const float *__restrict__ xyz, const unsigned 
         sx += xyz[3 * p + 0]; sy += xyz[3 * p + 1]; sz += xyz[3 * p + 2];
     }
     const float cnt = (float)(e - i);
-    const float cx = __fdiv_rn(sx, cnt), cy = __fdiv_rn(sy, cnt), cz = __fdiv_rn(sz, cnt);
+    const float cx = hnr_div(sx, cnt), cy = hnr_div(sy, cnt), cz = hnr_div(sz, cnt);
     float best = 0.f;
     int arg = -1;
     for (int k = i; k < e; ++k) {

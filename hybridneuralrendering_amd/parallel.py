@@ -195,13 +195,14 @@ def allreduce_point_gradients_sparse(grad, touched, group=None):
 
 def allreduce_point_buffers_sparse(grads, touched, group=None):
     """SUM over ranks of ALL the point-buffer gradients of a training step -- embeddings [N,32], conf [N,1], dir [N,3], colour [N,3] (any list of
-    [N, C_i] or [1, N, C_i] tensors) -- that are non-zero only on the rows `touched` (int64 ids of the points this rank's rays referenced): the
+    [N, C_i], [1, N, C_i] or [N] tensors, the first one 2-D or 3-D) -- that are non-zero only on the rows `touched` (int64 ids of the points this rank's rays referenced): the
     touched rows of all buffers are packed side by side into ONE [n, sum C_i] matrix, so the step's point gradients cost one all-gather of ids and one
     of rows (~12 k points x 164 B per rank for a 6-7-patch share of the C5 batch) and a local scatter-add, instead of a dense all-reduce of
     N x 39 floats (312 MB at 2 M points; the dense conf / dir / colour all-reduce alone was 56 MB).  Returns the summed dense gradients (new tensors,
     shaped like the inputs).  Deterministic: every rank adds the ranks' rows in rank order."""
     shapes = [g.shape for g in grads]
-    flat = [g.reshape(-1, g.shape[-1]) for g in grads]
+    n_rows = grads[0].reshape(-1, grads[0].shape[-1]).shape[0]             # the first buffer is [N, C] / [1, N, C]; the others may be [N] (conf)
+    flat = [g.reshape(n_rows, -1) for g in grads]
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return [g for g in grads]
     widths = [f.shape[1] for f in flat]

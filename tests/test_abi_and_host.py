@@ -195,6 +195,11 @@ bufs, ids4 = pb(rank)
 summed = parallel.allreduce_point_buffers_sparse(bufs, ids4)
 for got, a, b in zip(summed, pb(0)[0], pb(1)[0]):
     assert got.shape == a.shape and torch.allclose(got, a + b, rtol=0, atol=1e-6)
+# the shapes train.render_train's leaves have: [N, 32], [N] (conf), [N, 3], [N, 3]
+sq = lambda bs: [bs[0].reshape(N, 32), bs[1].reshape(N), bs[2].reshape(N, 3), bs[3].reshape(N, 3)]
+summed = parallel.allreduce_point_buffers_sparse(sq(bufs), ids4)
+for got, a, b in zip(summed, sq(pb(0)[0]), sq(pb(1)[0])):
+    assert got.shape == a.shape and torch.allclose(got, a + b, rtol=0, atol=1e-6)
 assert abs(parallel.loss_scale(hi - lo, 49 * 64) - (hi - lo) / 3136.0) < 1e-12
 if rank == 0:
     print("GRAD_OK")
