@@ -91,18 +91,22 @@ __device__ __forceinline__ void absmax_publish(unsigned *dst, float mx)
 // that mask had been someone else's (profiles/README.md: shared-GPU renders, three-queue training).  The kernels where it was seen divide with this.
 __device__ __forceinline__ float hnr_div(float n, float d)
 {
-    const unsigned en = (__float_as_uint(n) >> 23) & 0xffu, ed = (__float_as_uint(d) >> 23) & 0xffu;
-    if (__builtin_expect(ed - 32u > 190u || (en - 32u > 190u && n != 0.f) || (int)en - (int)ed > 120 || (int)en - (int)ed < -120, 0))
+    // fast path: d normal with exponent in [-95, 95], n zero or normal with an exponent within 120 of d's (no overflow / underflow of the quotient or
+    // the residuals).  Everything that depends on d alone comes first: with a loop-invariant divisor (cell sizes) the compiler hoists it.
+    const int ed = (int)((__float_as_uint(d) >> 23) & 0xffu), en = (int)((__float_as_uint(n) >> 23) & 0xffu);
+    const int lo = ed - 120 > 32 ? ed - 120 : 32, hi = ed + 120 < 222 ? ed + 120 : 222;
+    const bool d_ok = (unsigned)(ed - 32) <= 190u;
+    if (__builtin_expect(!(d_ok && ((unsigned)(en - lo) <= (unsigned)(hi - lo) || n == 0.f)), 0))
 #ifdef HNR_DIV_NO_FALLBACK                                                  // tools/check_divisions.sh: with the fallback gone, no object may contain v_div_fmas
         return 0.f;
 #else
-        return n / d;                                                       // zero / denormal / huge / inf / nan operands, quotients near the range's ends
+        return n / d;                                                       // denormal / huge / inf / nan operands, quotients near the range's ends
 #endif
     float r = __builtin_amdgcn_rcpf(d);
     r = fmaf(fmaf(-d, r, 1.0f), r, r);
-    float q = __fmul_rn(n, r);
-    q = fmaf(fmaf(-d, q, n), r, q);
-    return fmaf(fmaf(-d, q, n), r, q);
+    const float q0 = __fmul_rn(n, r);
+    const float q = fmaf(fmaf(-d, q0, n), r, q0);
+    return n == 0.f ? q0 : fmaf(fmaf(-d, q, n), r, q);                      // (a zero keeps the sign of n x r: the corrections would turn -0 / d into +0)
 }
 
 // The same for fp64 (the loss kernels' scalar means): reciprocal refined twice, quotient, one residual correction -- the compiler's own steps.
@@ -122,10 +126,30 @@ __device__ __forceinline__ double hnr_div64(double n, double d)
     return fma(fma(-d, q, n), r, q);
 }
 
+// hnr_div for the cell index floor((p - shift) / size): only the divisor is checked (the cell size: uniform, normal, exponent in [-95, 95]), so the
+// quotient costs five VALU instructions.  For a numerator whose exponent is more than 120 away from the divisor's the corrections may round
+// differently from IEEE division, but such a quotient is either below 2^-24 in magnitude (its floor is decided by its sign, which n x r carries) or
+// beyond the +-2e9 range test that follows (INT_MIN either way); inf / nan numerators give nan (INT_MIN, like inf / size).
+__device__ __forceinline__ float hnr_div_cell(float n, float d)
+{
+    const int ed = (int)((__float_as_uint(d) >> 23) & 0xffu);
+    if (__builtin_expect((unsigned)(ed - 32) > 190u, 0))
+#ifdef HNR_DIV_NO_FALLBACK
+        return 0.f;
+#else
+        return n / d;
+#endif
+    float r = __builtin_amdgcn_rcpf(d);
+    r = fmaf(fmaf(-d, r, 1.0f), r, r);
+    const float q0 = __fmul_rn(n, r);
+    const float q = fmaf(fmaf(-d, q0, n), r, q0);
+    return fmaf(fmaf(-d, q, n), r, q);
+}
+
 __device__ __forceinline__ int cell_coord(float p, float o, float c)
 {
     float d = __fsub_rn(p, o);
-    float q = hnr_div(d, c);
+    float q = hnr_div_cell(d, c);
     if (!(q > -2.0e9f && q < 2.0e9f)) return INT32_MIN;
     return (int)floorf(q);
 }

@@ -227,8 +227,8 @@ def test_divide_free_quotient_is_the_correctly_rounded_one():
     num = (rng.standard_normal(n) * np.exp2(rng.integers(-100, 100, n))).astype(np.float32)
     den = (rng.standard_normal(n) * np.exp2(rng.integers(-100, 100, n))).astype(np.float32)
     e = np.exp(rng.uniform(-30, 20, 1 << 18)).astype(np.float32)
-    sp = [np.array([0.0, -0.0, 1.0, np.inf, -np.inf, np.nan, 1e-45, 3e38, 1e-38, 1.0, 1.0, 2.0, 1e-30], np.float32),
-          np.array([1.0, 1.0, 0.0, 1.0, np.inf, 1.0, 1.0, 1e-38, 3e38, 3.0, np.nan, -0.0, 1e30], np.float32)]
+    sp = [np.array([0.0, -0.0, 1.0, np.inf, -np.inf, np.nan, 1e-45, 3e38, 1e-38, 1.0, 1.0, 2.0, 1e-30, 0.0, -0.0, 0.0, -0.0], np.float32),
+          np.array([1.0, 1.0, 0.0, 1.0, np.inf, 1.0, 1.0, 1e-38, 3e38, 3.0, np.nan, -0.0, 1e30, -2.0, -2.0, 0.016, 0.016], np.float32)]
     num = np.concatenate([num, e, rng.uniform(-3, 3, 1 << 18).astype(np.float32), sp[0]])
     den = np.concatenate([den, (e + np.float32(1)).astype(np.float32), rng.uniform(0.05, 9, 1 << 18).astype(np.float32), sp[1]])
     dn, dd = torch.from_numpy(num).cuda(), torch.from_numpy(den).cuda()
