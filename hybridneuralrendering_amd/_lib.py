@@ -184,6 +184,7 @@ SIGNATURES = {
     "hnr_absmax": (_I, [_P, _I, ctypes.c_int64, _P, _I, ctypes.c_int64, _I, _P, _P]),
     # the training step as two calls (csrc/render_train.hip)
     "hnr_render_train_workspace_bytes": (ctypes.c_int64, [ctypes.POINTER(TrainParams)]),
+    "hnr_render_train_debug_layout": (_I, [ctypes.POINTER(TrainParams), ctypes.POINTER(ctypes.c_int64), _I]),
     "hnr_render_train_forward": (_I, [_P, ctypes.POINTER(TrainParams), ctypes.POINTER(TrainCloud), ctypes.POINTER(TrainWeights), ctypes.POINTER(RenderCamera),
                                       ctypes.POINTER(TrainViews), _P, _P, _P, ctypes.c_int64, ctypes.POINTER(RenderOutputs), _P]),
     "hnr_render_train_backward": (_I, [ctypes.POINTER(TrainParams), ctypes.POINTER(TrainCloud), ctypes.POINTER(TrainWeights), ctypes.POINTER(RenderCamera),

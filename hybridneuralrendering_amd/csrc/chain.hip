@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256, RT >= 4 ? 1 : 2) void chain_kernel(ChainArgs a
                     for (int q = 0; q < 8; ++q) {
                         f32x2 add = bias[c][q];
                         if (TV) { const float4 t4 = tv[rt][c][q >> 1]; add = add + ((q & 1) ? f32x2{t4.z, t4.w} : f32x2{t4.x, t4.y}); }
-                        f32x2 v = __builtin_elementwise_fma(f32x2{acc[rt][c][2 * q], acc[rt][c][2 * q + 1]}, inv2, add);
+                        f32x2 v = f32x2_fma(f32x2{acc[rt][c][2 * q], acc[rt][c][2 * q + 1]}, inv2, add);
                         const f32x2 sv = v * slope2;
                         v.x = fmaxf(v.x, sv.x); v.y = fmaxf(v.y, sv.y);       // LeakyReLU, 0 < slope < 1
                         acc[rt][c][2 * q] = v.x; acc[rt][c][2 * q + 1] = v.y;

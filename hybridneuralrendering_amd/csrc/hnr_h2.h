@@ -34,7 +34,15 @@ __device__ __forceinline__ int row_scale_exp(float m)
     return CH_ACT_EXP + 126 - ex;
 }
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
+// A PAIR of floats with scalar arithmetic -- deliberately not ext_vector_type(2): vector float arithmetic (and the SLP vectoriser, hence
+// -fno-slp-vectorize in the Makefile) becomes v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32, and on gfx950 those give wrong results in lanes 48..63
+// of a wave while ANOTHER wave of the same SIMD runs MFMAs (another stream's GEMM, another process's frame): tools/featmap_contention.py reproduces
+// it in 764 of 2000 launches with the packed form and in 0 of 2000 without (profiles/README.md, round 4).  tests/test_abi_and_host.py checks that the
+// built library contains none.
+struct f32x2 { float x, y; };
+__device__ __forceinline__ f32x2 operator+(f32x2 a, f32x2 b) { return f32x2{__fadd_rn(a.x, b.x), __fadd_rn(a.y, b.y)}; }
+__device__ __forceinline__ f32x2 operator*(f32x2 a, f32x2 b) { return f32x2{__fmul_rn(a.x, b.x), __fmul_rn(a.y, b.y)}; }
+__device__ __forceinline__ f32x2 f32x2_fma(f32x2 a, f32x2 b, f32x2 c) { return f32x2{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)}; }
 
 // one dense layer of the tile: acc[rt][c] (+)= W[64 wave + 32 c .. +31, :] * X[32 rt .. +31, :]^T over S k steps.
 // PD = prefetch distance of the weight fragments in k steps (ring of PD + 1); PRELOAD_ALL: all S steps up front (layer 0).

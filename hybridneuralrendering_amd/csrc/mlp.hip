@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256, mlp3_wgs_per_cu(S0, RT, MODE)) void mlp3_kerne
                 for (int q = 0; q < 8; ++q) {
                     f32x2 add = bias[q];
                     if (ADD) { const float4 t4 = ad[rt & 1][q >> 1]; add = add + ((q & 1) ? f32x2{t4.z, t4.w} : f32x2{t4.x, t4.y}); }
-                    f32x2 v = __builtin_elementwise_fma(f32x2{acc[rt][0][2 * q], acc[rt][0][2 * q + 1]}, inv2, add);
+                    f32x2 v = f32x2_fma(f32x2{acc[rt][0][2 * q], acc[rt][0][2 * q + 1]}, inv2, add);
                     if (act) { const f32x2 sv = v * slope2; v.x = fmaxf(v.x, sv.x); v.y = fmaxf(v.y, sv.y); }
                     acc[rt][0][2 * q] = v.x; acc[rt][0][2 * q + 1] = v.y;
                     m = fmaxf(fmaxf(m, fabsf(v.x)), fabsf(v.y));
@@ -670,7 +670,7 @@ __global__ __launch_bounds__(64 * MW_WAVES, 1) void merge_wp_kernel(MlpArgs a)
                         const int q = 2 * q4 + e;
                         f32x2 add = e ? f32x2{b.z, b.w} : f32x2{b.x, b.y};
                         if (ADD) { const float4 t4 = ad[c][q4]; add = add + (e ? f32x2{t4.z, t4.w} : f32x2{t4.x, t4.y}); }
-                        f32x2 v = __builtin_elementwise_fma(f32x2{acc[c][2 * q], acc[c][2 * q + 1]}, inv2, add);
+                        f32x2 v = f32x2_fma(f32x2{acc[c][2 * q], acc[c][2 * q + 1]}, inv2, add);
                         const f32x2 sv = v * slope2;
                         v.x = fmaxf(v.x, sv.x); v.y = fmaxf(v.y, sv.y);
                         acc[c][2 * q] = v.x; acc[c][2 * q + 1] = v.y;
@@ -886,7 +886,7 @@ __global__ __launch_bounds__(64 * MX_WAVES, 1) void mixfinal_wp_kernel(MixArgs a
                     for (int e = 0; e < 2; ++e) {
                         const int q = 2 * q4 + e;
                         const f32x2 add = e ? f32x2{b.z, b.w} : f32x2{b.x, b.y};
-                        f32x2 v = __builtin_elementwise_fma(f32x2{acc[c][2 * q], acc[c][2 * q + 1]}, inv2, add);
+                        f32x2 v = f32x2_fma(f32x2{acc[c][2 * q], acc[c][2 * q + 1]}, inv2, add);
                         if (act) { const f32x2 sv = v * slope2; v.x = fmaxf(v.x, sv.x); v.y = fmaxf(v.y, sv.y); }
                         acc[c][2 * q] = v.x; acc[c][2 * q + 1] = v.y;
                         m = fmaxf(fmaxf(m, fabsf(v.x)), fabsf(v.y));

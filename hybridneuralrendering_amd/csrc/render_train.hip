@@ -454,6 +454,26 @@ static int pack_transposed_images(const Layout &L, const hnr_train_weights *w, i
 
 }  // namespace
 
+// Debug / tools: where the forward pass keeps its intermediate tensors inside the caller's workspace (tools/bisect_train_forward.py compares them between
+// repeated steps).  names: "Xd H1 X3 H3 H4 E Tu X5 sigma T1 T2 CF X6 vmask M1 M2 M3 X7 Y1 Y2 Y3 fm row_pid vs_item fm_scratch" in this order; out[2 i] = byte offset,
+// out[2 i + 1] = bytes.  Returns the number of entries.
+extern "C" int hnr_render_train_debug_layout(const hnr_train_params *p, int64_t *out, int max_entries)
+{
+    if (!p || !out || check_params(p, "hnr_render_train_debug_layout")) return -1;
+    bool ok = true;
+    char *base = reinterpret_cast<char *>(256);                              // a non-null base: only differences are used
+    const Layout L = carve(base, ~(size_t)0 >> 1, p, &ok);
+    const size_t rows = L.rows_cap, cap = (size_t)p->cap_samples, VS = L.VS > 0 ? L.VS : 1, uc = L.ucap;
+    const struct { const void *ptr; size_t bytes; } e[] = {
+        {L.Xd, rows * 64 * 4}, {L.H1, rows * 256 * 4}, {L.X3, rows * 264 * 4}, {L.H3, rows * 256 * 4}, {L.H4, rows * 256 * 4}, {L.E, uc * 224 * 4}, {L.Tu, uc * 256 * 4},
+        {L.X5, cap * 280 * 4}, {L.sigma, cap * 4}, {L.T1, cap * 128 * 4}, {L.T2, cap * 128 * 4}, {L.CF, cap * 128 * 4}, {L.X6, VS * 48 * 4}, {L.vmask, VS * 4},
+        {L.M1, VS * 64 * 4}, {L.M2, VS * 64 * 4}, {L.M3, VS * 64 * 4}, {L.X7, cap * 92 * 4}, {L.Y1, cap * 48 * 4}, {L.Y2, cap * 48 * 4}, {L.Y3, cap * 48 * 4},
+        {L.fm, (p->V > 0 ? (size_t)p->V * p->H * p->W * 48 : 4) * 4}, {L.row_pid, rows * 4}, {L.vs_item, cap * 4}, {L.fm_scratch, L.fm_elems * 4}};
+    const int n = (int)(sizeof(e) / sizeof(e[0]));
+    for (int i = 0; i < n && i < max_entries; ++i) { out[2 * i] = (int64_t)(reinterpret_cast<const char *>(e[i].ptr) - base); out[2 * i + 1] = (int64_t)e[i].bytes; }
+    return n < max_entries ? n : max_entries;
+}
+
 extern "C" int64_t hnr_render_train_workspace_bytes(const hnr_train_params *p)
 {
     if (check_params(p, "hnr_render_train_workspace_bytes") != HNR_OK) return -1;

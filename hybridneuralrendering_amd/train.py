@@ -121,6 +121,7 @@ class TrainPath:
         self.opt = renderer.opt
         self.cap_samples = None            # valid-sample capacity of the workspace (None: R * SR, the worst case)
         self.timers = None                 # a dict: the library records HIP events at its stage boundaries (profiling; read them after a synchronise)
+        self.workspace = None              # tools: a caller-owned uint8 tensor every forward uses instead of a fresh torch.empty (one step in flight at a time)
 
     # ---------------------------------------------------------------------------------------------- forward
     def forward(self, cloud, raydir, campos, camrot, bg_color, near, far, c2w_nearest, campos_nearest, intrinsic_nearest,
@@ -171,7 +172,7 @@ class TrainPath:
         if nbytes > 0.9 * (free + cached):
             raise HnrError("render_train: the workspace for %d rays x SR %d (%.1f GB) does not fit the %.1f GB that are free; set TrainPath.cap_samples to the "
                            "number of valid shading samples a batch can produce" % (R, SR, nbytes / 1e9, (free + cached) / 1e9))
-        ws = torch.empty((nbytes + 256,), dtype=torch.uint8, device=dev)
+        ws = self.workspace if (self.workspace is not None and self.workspace.numel() >= nbytes + 256) else torch.empty((nbytes + 256,), dtype=torch.uint8, device=dev)
         off = (-ws.data_ptr()) % 256
         # parameters as contiguous fp32 tensors under the reference's names (views of the nn.Parameters)
         wt = {n: g(q.detach(), n, torch.float32) for n, q in self.agg.named_parameters() if n in _SLOTS}
@@ -225,6 +226,7 @@ class TrainPath:
         out = dict(coarse_raycolor=col, coarse_point_opacity=opa, coarse_is_background=isbg, blend_weight=bw, ray_mask=mask, decoded=decoded,
                    sample_pidx=pidx, sample_loc_w=loc, ray_nsamp=nsamp, counts=counts, status=status, weight=w_out, conf_coefficient=c_out)
         S.outs = out
+        self.last_step = (prm, nbytes)     # tools (bisect_train_forward.py): the step's parameter block and workspace size
         return out, S
 
     @staticmethod

@@ -637,6 +637,10 @@ typedef struct {   /* aggregator.{block1.0, block1.2, block3.0, block3.2, alpha_
 } hnr_train_weights;           /* the gradient block handed to hnr_render_train_backward has the same layout (its buffers are written)      */
 typedef struct { const float *d_w2c, *d_intrinsic, *d_campos_nearest, *d_images /*[V,H,W,3]*/, *d_frame_w /*optional [V]*/; } hnr_train_views;
 int64_t hnr_render_train_workspace_bytes(const hnr_train_params *p);
+/* STAGE tier (tools only): byte offset / size pairs of the forward pass's intermediate tensors inside the workspace, in the order
+ * Xd H1 X3 H3 H4 E Tu X5 sigma T1 T2 CF X6 vmask M1 M2 M3 X7 Y1 Y2 Y3 fm row_pid vs_item fm_scratch (out[2 i], out[2 i + 1]); returns the number of entries or -1.
+ * The training-mode counterpart of reading PointAggregator.viewmlp's locals in a debugger (point_aggregators.py:892-1338). */
+int hnr_render_train_debug_layout(const hnr_train_params *p, int64_t *out, int max_entries);
 int hnr_render_train_forward(const hnr_grid *grid, const hnr_train_params *p, const hnr_train_cloud *cloud, const hnr_train_weights *weights,
                              const hnr_render_camera *camera, const hnr_train_views *views, const uint8_t *d_drop_lut, const uint8_t *d_ray_drop,
                              void *d_workspace, int64_t workspace_bytes, const hnr_render_outputs *out, void *stream);

@@ -1,0 +1,49 @@
+"""The reference-view feature pyramid alone (hnr_image_features: six conv launches + featmap_kernel), repeated on fixed buffers; every output is
+compared with the first one.  Run it beside another process that keeps the GPU busy (tools/r4_featmap.sh).  FM_ITERS launches (default 2000);
+FM_ONLY=1: the six convolutions once, then only featmap_kernel is repeated (needs the probe entry: not available -> runs everything)."""
+import ctypes, os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from hybridneuralrendering_amd import _lib  # noqa: E402
+
+sys.argv = [sys.argv[0], "--points", "2e5"]
+args = bench.parse()
+dev = torch.device("cuda", 0); torch.cuda.set_device(0)
+sc, opt, agg, cloud, rnd, cam = bench.build_world(args, dev, 0)
+L = _lib.lib()
+pk = agg.packed()
+img = cam["images"]
+if img.dim() == 5: img = img[0]
+img = img.contiguous()
+V, H, W, _ = img.shape
+fm = torch.empty((V, H, W, 48), dtype=torch.float32, device=dev)
+scratch = torch.empty((int(L.hnr_image_features_scratch_elems(V, H, W)),), dtype=torch.float32, device=dev)
+wp = (ctypes.c_void_p * 6)(*[t.data_ptr() for t in pk["conv_w"]]); bp = (ctypes.c_void_p * 6)(*[t.data_ptr() for t in pk["conv_b"]])
+def run():
+    _lib.check(L.hnr_image_features(_lib.ptr(img), V, H, W, wp, bp, pk["slope"], _lib.ptr(scratch), _lib.ptr(fm), _lib.stream()), "hnr_image_features")
+    torch.cuda.synchronize()
+run(); run()
+ref, ref_s = fm.clone(), scratch.clone()                            # quiet reference: the other process is started only now
+import subprocess
+hog = None
+if os.environ.get("FM_HOG", "1") == "1":
+    hog = subprocess.Popen([sys.executable, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"), "--steps", "100000", "--warmup", "1",
+                            "--no-cpu-baseline", "--no-train-leg", "--no-f32-anchor"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    time.sleep(float(os.environ.get("FM_HOG_WAIT", "30")))
+n = int(os.environ.get("FM_ITERS", "2000")); bad = 0; bad_s = 0; quarters = [0, 0, 0, 0]
+for it in range(n):
+    fm.fill_(float("nan"))
+    run()
+    same = (fm == ref) | ((fm != fm) & (ref != ref))
+    if not bool(same.all()):
+        bad += 1
+        rows = torch.nonzero((~same).reshape(-1, 48).any(dim=1)).reshape(-1)
+        for q in range(4): quarters[q] += int((((rows % 64) // 16) == q).sum())
+        if bad <= 4:
+            ch = sorted(set(torch.nonzero((~same).reshape(-1, 48).any(dim=0)).reshape(-1).tolist()))
+            print("launch %d: %d pixels differ, pixel index mod 64 in %s, channels %s" % (it, rows.numel(), sorted(set((rows % 64).tolist())), ch))
+    if not torch.equal(scratch, ref_s): bad_s += 1
+if hog is not None:
+    hog.kill(); hog.wait()
+print("%d of %d launches: feature map differs from the first (pixels by lane quarter %s); pyramid levels (conv outputs) differ in %d" % (bad, n, quarters, bad_s))

@@ -37,6 +37,9 @@ for it in range(int(os.environ.get("RACE_ITERS", "100"))):
     cur = {("points." + k): v.clone() for k, v in pg.items()}
     cur.update({k: v.clone() for k, v in ag.items() if not k.startswith(atomic)})
     cur["coarse_raycolor"] = out["coarse_raycolor"].clone()
+    if os.environ.get("RACE_VERBOSE"):
+        for k in ("decoded", "sample_pidx", "sample_loc_w", "weight", "conf_coefficient", "blend_weight", "ray_mask", "ray_nsamp"):
+            cur["out." + k] = out[k].clone()
     torch.cuda.synchronize()
     if it == 0:
         first = cur                                   # the first step of a process: compared with the second separately (cold caches / fresh workspace)
@@ -46,8 +49,9 @@ for it in range(int(os.environ.get("RACE_ITERS", "100"))):
         bad0 = [k for k in ref if not torch.equal(first[k], ref[k])]
         print("step 0 vs step 1:", (len(bad0), bad0[:8]) if bad0 else "identical")
         continue
-    bad = [(k, float((cur[k] - ref[k]).abs().max() / (ref[k].abs().max() + 1e-30)), int((cur[k] != ref[k]).sum())) for k in ref if not torch.equal(cur[k], ref[k])]
+    bad = [(k, float((cur[k].double() - ref[k].double()).abs().max() / (ref[k].double().abs().max() + 1e-30)), int((cur[k] != ref[k]).sum())) for k in ref if not torch.equal(cur[k], ref[k])]
     if bad:
         n_bad += 1
-        if n_bad <= 5: print("step", it, len(bad), [(b[0], "%.1e" % b[1], b[2]) for b in bad[:6]])
+        if n_bad <= 5: print("step", it, len(bad), [(b[0], "%.1e" % b[1], b[2]) for b in (bad if os.environ.get("RACE_VERBOSE") else bad[:6])])
+        if n_bad <= 5 and os.environ.get("RACE_VERBOSE"): print("   identical:", [k for k in ref if torch.equal(cur[k], ref[k])])
 print("steps (2 ..) with a bit differing from step 1:", n_bad)
