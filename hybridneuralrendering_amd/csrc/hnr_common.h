@@ -86,9 +86,9 @@ __device__ __forceinline__ void absmax_publish(unsigned *dst, float mx)
 
 // Correctly rounded fp32 division WITHOUT v_div_scale / v_div_fmas: the steps of the compiler's own expansion (reciprocal, one refinement of it,
 // quotient, two residual corrections -- the same fused operations in the same order, hence the same bits) minus the operand scaling that only
-// matters at the ends of the exponent range; operands out there take the compiler's `/`.  Why: v_div_fmas reads the lane mask v_div_scale left
-// in VCC, and twice -- in two unrelated kernels, always lanes 48..63, only with several busy queues / processes on the GPU -- a quotient came out as if
-// that mask had been someone else's (profiles/README.md: shared-GPU renders, three-queue training).  The kernels where it was seen divide with this.
+// matters at the ends of the exponent range; operands out there take the compiler's `/`.  History: written when wrong quotients in lanes 48..63 under
+// GPU contention were blamed on the lane mask v_div_fmas reads from VCC; the cause turned out to be packed fp32 arithmetic (hnr_h2.h).
+// Kept: bit-identical to `/`, cheaper for loop-invariant divisors, and no state handed from one instruction to another in VCC.
 __device__ __forceinline__ float hnr_div(float n, float d)
 {
     // fast path: d normal with exponent in [-95, 95], n zero or normal with an exponent within 120 of d's (no overflow / underflow of the quotient or
