@@ -90,3 +90,14 @@ def test_bench_weak_scaling_flag_and_world_size_mismatch():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], cwd=ROOT, capture_output=True, text=True, timeout=300,
                        env=dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
     assert p.returncode != 0 and "WORLD_SIZE" in (p.stderr + p.stdout)
+
+
+def test_feature_map_repeats_bit_for_bit_beside_another_process():
+    """The behaviour behind tests/test_abi_and_host.py::test_library_has_no_packed_fp32_arithmetic: hnr_image_features repeated while another process
+    renders frames on the same GPU.  With packed fp32 instructions in featmap_kernel 38 % of such launches came out wrong in lanes 48..63
+    (profiles/r04_contention.txt); 500 launches must all repeat the quiet result."""
+    e = dict(os.environ, FM_ITERS="500", FM_HOG_WAIT="25")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "featmap_contention.py")], cwd=ROOT, capture_output=True, text=True, timeout=900, env=e)
+    assert p.returncode == 0, p.stderr[-2000:]
+    last = [l for l in p.stdout.splitlines() if "launches: feature map differs" in l][-1]
+    assert last.startswith("0 of 500 launches"), last

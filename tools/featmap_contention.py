@@ -28,10 +28,13 @@ ref, ref_s = fm.clone(), scratch.clone()                            # quiet refe
 import subprocess
 hog = None
 if os.environ.get("FM_HOG", "1") == "1":
-    hog = subprocess.Popen([sys.executable, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"), "--steps", "100000", "--warmup", "1",
+    hog = subprocess.Popen([sys.executable, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"), "--steps", os.environ.get("FM_HOG_STEPS", "4000"), "--warmup", "1",      # (ends by itself after ~2.5 minutes)
                             "--no-cpu-baseline", "--no-train-leg", "--no-f32-anchor"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     time.sleep(float(os.environ.get("FM_HOG_WAIT", "30")))
 n = int(os.environ.get("FM_ITERS", "2000")); bad = 0; bad_s = 0; quarters = [0, 0, 0, 0]
+import atexit
+if hog is not None:
+    atexit.register(lambda: (hog.kill(), hog.wait()))                  # whatever happens below, the other process does not outlive this one
 for it in range(n):
     fm.fill_(float("nan"))
     run()
