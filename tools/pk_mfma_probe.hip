@@ -36,6 +36,15 @@ __global__ __launch_bounds__(256) void chain(const float *__restrict__ in, int n
         const f32x2v mm = {m, m}, aa = {a, a};
         for (int r = 0; r < reps; ++r) { v = v * mm; v = v + aa; v = __builtin_elementwise_fma(v, mm, aa); }
         x = v.x; y = v.y;
+    } else if (MODE == 4) {                                                        // packed, with the operand halves swapped / broadcast (op_sel / op_sel_hi modifiers)
+        f32x2v v = {x, y};
+        const f32x2v mm = {m, 1.001f}, aa = {a, -a};
+        for (int r = 0; r < reps; ++r) {
+            v = __builtin_shufflevector(v, v, 1, 0) * mm;                           // lo = v.hi * mm.lo, hi = v.lo * mm.hi
+            v = v + __builtin_shufflevector(aa, aa, 1, 0);
+            v = __builtin_shufflevector(v, v, 0, 0) * mm + __builtin_shufflevector(v, v, 1, 1) * aa;   // broadcasts
+        }
+        x = v.x; y = v.y;
     } else {
         for (int r = 0; r < reps; ++r) {
             x = __fmul_rn(x, m); y = __fmul_rn(y, m); x = __fadd_rn(x, a); y = __fadd_rn(y, a); x = fmaf(x, m, a); y = fmaf(y, m, a);
@@ -126,6 +135,7 @@ int main(int argc, char **argv)
     (void)hipMemcpy(din, h.data(), (size_t)n * 8, hipMemcpyHostToDevice);
     hipStream_t sa, sb; (void)hipStreamCreate(&sa); (void)hipStreamCreate(&sb);
     run<0>("packed fp32 (v_pk_mul/add/fma_f32)", launches, din, dout, n, sa, sb, sink, own_hog);
+    run<4>("packed fp32 with op_sel modifiers  ", launches, din, dout, n, sa, sb, sink, own_hog);
     run<1>("scalar fp32 (v_mul/add/fma_f32)   ", launches, din, dout, n, sa, sb, sink, own_hog);
     {   // gathered operands: n2 threads x 12 outputs; the planes are the first 12 x 4801 floats of din
         const int n2 = 480 * 640;
