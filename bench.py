@@ -485,8 +485,8 @@ def train_leg(args, sc, opt, agg, cloud, rnd, cam, dev, steps=20, warmup=3):
         # HBM bytes of the same kernel inside the step (PMC passes over tools/probe_train.py; only valid for the default C3 batch: 307 120 row slots)
         # PMC bytes of the 256-wide weight gradient (its launches inside the training step, profiles/<TRAIN_TRAFFIC_JSON>), selected by kernel name;
         # the batch behind that file is this one up to the depth jitter (row slots within 1 %: `traffic_rows` beside it)
-        t_wg = [v for k, v in pmc_traffic(TRAIN_TRAFFIC_JSON).items() if "h2wgrad_kernel<8, 9" in k]
-        roof_t = dict(kernel="h2wgrad_kernel<8,9,8,1> + reduce (dW = dZ^T X, db of one 256 x 256 per-neighbour layer; M = %d row slots)" % M8, bound="hbm",
+        t_wg = [v for k, v in pmc_traffic(TRAIN_TRAFFIC_JSON).items() if "h2wgrad_dma_kernel" in k or "h2wgrad_kernel<8, 9" in k]   # (the DMA-staged kernel is the default since round 4)
+        roof_t = dict(kernel="h2wgrad_dma_kernel + reduce (hnr_h2wgrad: dW = dZ^T X, db of one 256 x 256 per-neighbour layer; M = %d row slots)" % M8, bound="hbm",
                       achieved=round(M8 * 2048.0 / (ms_w * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(M8 * 2048.0 / (ms_w * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                       traffic=int(t_wg[0]["hbm_bytes"]) if t_wg else None,
                       traffic_source=("profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE over tools/probe_train.py, bytes per launch: operands + %d KiB of "

@@ -407,3 +407,16 @@ def test_library_has_no_packed_fp32_arithmetic(tmp_path):
         bad += [l.strip() for l in dis.splitlines() if "v_pk_mul_f32" in l or "v_pk_add_f32" in l or "v_pk_fma_f32" in l][:5]
     assert n_mfma > 1000, "the disassembly does not look like the library's device code"
     assert not bad, bad
+
+
+def test_committed_pmc_files_hold_the_kernels_bench_looks_up():
+    """bench.py fills roofline.traffic / roofline_train.traffic from the newest profiles/r04_*.json by KERNEL NAME (round-3 verdict: a renamed kernel must not
+    turn the field into null silently): the names it selects on are in the committed files."""
+    import glob, json
+    newest = lambda suf: sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r0*_" + suf)) if suf.startswith("train") or "train_" not in os.path.basename(f))[-1]
+    tr = json.load(open(newest("train_traffic.json")))["kernels"]
+    assert any("h2wgrad_dma_kernel" in k for k in tr), list(tr)
+    fr = json.load(open(newest("traffic.json")))["kernels"]
+    assert any("chain_ws_kernel<0>" in k for k in fr) and any("march_kernel" in k for k in fr) and any("knn3_kernel<8, 1>" in k for k in fr), list(fr)
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert '"h2wgrad_dma_kernel" in k' in src and "chain_ws_kernel<0>" in src
