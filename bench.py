@@ -798,9 +798,7 @@ def main():
             finally:
                 if old_env is None: os.environ.pop("HNR_DENSE", None)
                 else: os.environ["HNR_DENSE"] = old_env
-        cpu = None
-        if not args.no_cpu_baseline and world == 1:          # reported at N=1 only (rank 0)
-            cpu = cpu_baseline(args, sc, opt, agg, cam, col.cpu().numpy())
+        # (the training leg runs BEFORE the CPU baseline: 128 host threads that have just been spinning would perturb a leg whose launches are host-driven)
         train = None
         if world == 1 and not args.no_train_leg and not args.train_sharded_only:
             try:                                                               # a leg reported beside the headline must not take the line down
@@ -808,6 +806,9 @@ def main():
             except Exception as ex:                                            # noqa: BLE001
                 if os.environ.get("HNR_BENCH_STRICT", "0") == "1": raise
                 train = dict(workload="C3 train step", error="%s: %s" % (type(ex).__name__, str(ex)[:300]))
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:          # reported at N=1 only (rank 0)
+            cpu = cpu_baseline(args, sc, opt, agg, cam, col.cpu().numpy())
         res = {
             "metric": "rays/sec (fwd render) scene0241_01 at 1/2/4/8 GPU; PSNR delta vs ref",
             "value": R_job * args.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
