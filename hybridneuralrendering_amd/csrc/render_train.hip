@@ -60,7 +60,7 @@ struct Layout {
     float *g_dec, *gY3, *gCF, *g_sigma, *dY2, *dY1, *gX7, *gF, *gZ3m, *dM2, *dM1, *gX6, *gpre, *tmpCF, *tmpWfd, *g_pyr, *g_fm, *dT2, *dT1, *gX5, *gZ4, *g_wagg,
           *dZ3, *gX3, *dZ1, *G8, *P8, *gTu, *gE;
     int32_t *bbox, *key_scratch, *row_list, *seg_cnt, *seg_start;
-    char *sort_scratch, *wg_scratch;
+    char *sort_scratch, *wg_scratch, *wg_scratch2;                      // (wg_scratch2: the second weight-gradient queue of HNR_TRAIN_SIDE bit 5)
     float *conf0;
     size_t sort_bytes, wg_bytes;
     size_t rows_cap, ucap, VS, fm_elems, bytes;
@@ -117,7 +117,7 @@ Layout carve(void *ws, size_t ws_bytes, const hnr_train_params *p, bool *ok)
     L.dZ3 = c.take<float>(rows * 256); L.gX3 = c.take<float>(rows * 264); L.dZ1 = c.take<float>(rows * 256);
     L.row_list = c.take<int32_t>(rows); L.seg_cnt = c.take<int32_t>(ucap + 1); L.seg_start = c.take<int32_t>(ucap + 1);
     L.G8 = c.take<float>(rows * 8); L.P8 = c.take<float>(ucap * 8); L.gTu = c.take<float>(ucap * 256); L.gE = c.take<float>(ucap * 224);
-    L.wg_bytes = (size_t)hnr_h2wgrad_scratch_bytes(256, 280); L.wg_scratch = c.take<char>(L.wg_bytes);
+    L.wg_bytes = (size_t)hnr_h2wgrad_scratch_bytes(256, 280); L.wg_scratch = c.take<char>(L.wg_bytes); L.wg_scratch2 = c.take<char>(L.wg_bytes);
     L.conf0 = c.take<float>(512);
     L.bytes = (c.off + 255) & ~(size_t)255;
     if (ok) *ok = c.ok;
@@ -384,16 +384,19 @@ int check_params(const hnr_train_params *p, const char *who)
 
 #define TR(call) do { int rc_ = (call); if (rc_ != HNR_OK) return rc_; } while (0)
 
-// Side streams of the library, per device (created at the first training call on that device).  HNR_TRAIN_SIDE is a bit mask, default 15:
+// Side streams of the library, per device (created at the first training call on that device).  HNR_TRAIN_SIDE is a bit mask, default 63 (all of them;
+// 15 until round 4 found what had made three busy queues differ run to run -- packed fp32 instructions, DESIGN.md section 2 -- and removed it):
 //   bit 0 (1): the reference-view CNN on `stream` -- its forward beside the query and the per-neighbour chain, its backward (pixel scatter, upsample,
 //              conv pyramid) beside the backward stages 7 - 11: strings of small latency-bound kernels whose results are needed late / not at all downstream;
 //   bit 1 (2): the backward call's buffer clears on `stream`;
 //   bit 2 (4): ALL fifteen weight-gradient GEMMs (hnr_h2wgrad) on `stream`, each behind an event recorded after the kernel that wrote its dZ (the stream is
 //              in order, so they share one partial-sum scratch) -- shipped: 4.9 -> 4.65 ms per step, 6 000 + 16 000 repeated steps bit-identical;
 //   bit 3 (8): the step's weight-image packs (forward images, the backward's transposed images, the per-point table image) on `stream_w`, the pack stream;
-//   bit 4 (16, opt-in): the image branch's backward on the pack stream instead -- three busy queues.  An earlier three-queue arrangement (weight
-//              gradients on the pack stream) made ~1 step in 10 differ (train_ksum_bwd_kernel, lanes 48..63; profiles/README.md) and was never
-//              explained; this one soaked clean (22 000 steps) but stays opt-in.
+//   bit 4 (16): the image branch's backward on the pack stream instead -- three busy queues (in round 3 such an arrangement made ~1 step in 10 differ:
+//              train_ksum_bwd_kernel, lanes 48..63 -- the packed-fp32 failure);
+//   bit 5 (32): the weight gradients of the per-neighbour layers (the four 256-wide GEMMs over all row slots + block1.0's two) alternate between
+//              `stream` and the pack stream, each queue with its own partial-sum scratch: the last of them end the step (they trail the input-gradient
+//              chain by one kernel each), two queues shorten that tail.
 // Forked from / joined to the caller's stream with events inside each call.  HNR_TRAIN_SIDE=0: everything in line on the caller's stream.
 struct TrainSide {
     hipStream_t stream = nullptr, stream_w = nullptr;                     // image branch / clears; weight packs
@@ -416,7 +419,7 @@ TrainSide &train_side()
     TrainSide &t = per_dev[dev];
     if (t.on < 0) {
         const char *e = getenv("HNR_TRAIN_SIDE");
-        t.on = e ? atoi(e) : 15;                                         // see the bit list above
+        t.on = e ? atoi(e) : 63;                                         // see the bit list above
         if (t.on && (hipStreamCreateWithFlags(&t.stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&t.fork_f, hipEventDisableTiming) != hipSuccess ||
                      hipEventCreateWithFlags(&t.join_f, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&t.fork_b, hipEventDisableTiming) != hipSuccess ||
                      hipEventCreateWithFlags(&t.join_b, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&t.fork_z, hipEventDisableTiming) != hipSuccess ||
@@ -694,13 +697,17 @@ extern "C" int hnr_render_train_backward(const hnr_train_params *p, const hnr_tr
     // image branch's backward runs on: two busy queues), each behind an event recorded after the kernel that wrote its dZ; the stream runs them in order,
     // so they share one partial-sum scratch
     const bool side_g = (side.on & 4) != 0;
+    int n_big = 0;
     auto wgrad_n = [&](const float *dZ, int ldz, const float *X, int ldx, int64_t Mcap, const int64_t *dm, int nseg, int64_t segs, int Nn, int Kk, int amz, int amx,
                        float *dW, int lddw, float *db) -> int {
         if (!side_g) return wgrad(dZ, ldz, X, ldx, Mcap, dm, nseg, segs, Nn, Kk, amz, amx, dW, lddw, db);
         HNR_HIP_CHECK(hipEventRecord(side.fork_g, st));
-        HNR_HIP_CHECK(hipStreamWaitEvent(side_stream, side.fork_g, 0));
+        const bool alt = (side.on & 32) && Mcap == rows && ((n_big++) & 1);     // every second per-neighbour weight gradient: the other queue + its own scratch
+        hipStream_t sg = alt ? side.stream_w : side_stream;
+        HNR_HIP_CHECK(hipStreamWaitEvent(sg, side.fork_g, 0));
         forked = true;
-        return hnr_h2wgrad(dZ, ldz, X, ldx, Mcap, dm, nseg, segs, Nn, Kk, am + amz, am + amx, dW, lddw, db, 0, L.wg_scratch, (void *)side_stream);
+        if (alt) forked6w = true;                                               // (joined below like the image branch of bit 4)
+        return hnr_h2wgrad(dZ, ldz, X, ldx, Mcap, dm, nseg, segs, Nn, Kk, am + amz, am + amx, dW, lddw, db, 0, alt ? L.wg_scratch2 : L.wg_scratch, (void *)sg);
     };
     // input gradient through a LeakyReLU: out = (dZ W) * LeakyReLU'(side); side == NULL: out = dZ W
     auto dgrad = [&](const float *dZ, int ldz, int64_t Mcap, const int64_t *dm, int nseg, int64_t segs, int im, int Nn, int Kk, const float *side, int lds_, float *out, int ldo,
@@ -742,9 +749,7 @@ extern "C" int hnr_render_train_backward(const hnr_train_params *p, const hnr_tr
         hipStream_t s6 = st;
         if (side_on) {
             HNR_HIP_CHECK(hipEventRecord(side_fork, st));
-            // bit 4 (HNR_TRAIN_SIDE=31, opt-in): the image branch on the pack stream beside the weight gradients' stream -- three busy queues: 4.55 instead of
-            // 4.69 ms per step and 22 000 repeated steps without a differing bit, but an earlier three-queue arrangement produced unexplained run-to-run
-            // differences, so the default keeps two
+            // bit 4: the image branch on the pack stream beside the weight gradients' stream -- three busy queues
             s6 = (side.on & 16) ? side.stream_w : side_stream;
             HNR_HIP_CHECK(hipStreamWaitEvent(s6, side_fork, 0));
             forked = true;
