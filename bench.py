@@ -292,20 +292,24 @@ def cpu_baseline(args, sc, opt, agg, cam, gpu_colors):
                 "rounding of the 4x4 inverse / projection; oracle_f32_vs_f64_* = the same effect between two evaluations of the oracle itself)" % (len(blocks), side, side))
 
 
-def train_leg_sharded(args, sc, opt, agg, cloud, rnd, cam, dev, world, rank, rehearsal, emulate, steps=10, warmup=2):
-    """BASELINE config C5 the way it runs on N GPUs (models/mvs_points_volumetric_model.py:111-131, models/base_rendering_model.py:677-745): one batch of
+def train_leg_sharded(args, sc, opt, agg, cloud, rnd, cam, dev, world, rank, rehearsal, emulate, steps=20, warmup=3):
+    """BASELINE config C5 the way it runs on N GPUs (models/mvs_points_volumetric_model.py:111-152, models/base_rendering_model.py:677-745): one batch of
     49 dilated 8x8 patches (3136 rays, dilation_setup 7_8_1_6), the blur-handling module (12 symmetric 9x9 kernels) and the item's frame weight; the batch is
-    sharded by WHOLE patches (parallel.shard_patches), every rank runs forward + blur + loss + backward on its 6-7 patches with the replicated cloud and
-    weights, then the gradients are summed: the network's 449 k parameters as one flat all-reduce, the four point-buffer gradients as (id, 39-float row) pairs of
-    the touched points (ONE all-gather of ids + one of rows + a local scatter-add: parallel.allreduce_point_buffers_sparse).  Timed with HIP events per part; max over ranks.
-    world == 1 and HNR_BENCH_EMULATE_RANK=r/n: rank r's share of an n-way split alone on this GPU, without the collectives, whose byte counts are
-    reported instead (tools/predict_train_scaling.sh)."""
+    sharded by WHOLE patches (parallel.shard_patches), every rank runs forward -> blur module -> loss kernels -> blur backward -> backward on its 6-7 patches
+    (train.train_step: no autograd graph, no torch.unique, no host read; HNR_BENCH_TRAIN_GRAPH=1: captured in a hipGraph and replayed), then the gradients
+    meet in TWO collectives without a host read: ONE all-reduce of the flat weight-gradient buffer carrying the ranks' valid-ray counts
+    (parallel.allreduce_weight_grads: the loss is a mean over the batch's valid rays) and ONE fixed-capacity all-gather of packed (point id | 39 floats)
+    records of the touched points (parallel.PointGradExchange; the touched list is what the forward call left on the device).
+    Timed with HIP events per part; max over ranks.  world == 1 and HNR_BENCH_EMULATE_RANK=r/n: rank r's share of an n-way split alone on this GPU -- the
+    collectives degenerate to their local pack / apply parts, which are still run and timed (tools/predict_train_scaling.sh)."""
     import torch.distributed as dist
     from hybridneuralrendering_amd import scenes, parallel
-    from hybridneuralrendering_amd.train import TrainPath, render_train
-    from hybridneuralrendering_amd.blur import blur_update_output
+    from hybridneuralrendering_amd.train import TrainPath, train_step, CapturedTrainStep
     old_train, old_dil = opt.is_train, getattr(opt, "dilation_setup", None)
     opt.is_train, opt.dilation_setup = 1, "7_8_1_6"
+    # HNR_BENCH_TRAIN_GRAPH=1: replay the step from a hipGraph (train.CapturedTrainStep).  Measured in round 5 and NOT the default: the ROCm 7.2 graph
+    # executor runs the step's three queues one after the other (a 1/8 share: 2.60 ms replayed = the single-queue eager step, 2.18 ms eager with the side streams)
+    use_graph = os.environ.get("HNR_BENCH_TRAIN_GRAPH", "0") == "1"
     try:
         pix, pn, ps = scenes.dilated_patch_batch(sc.w, sc.h, args.margin, opt.dilation_setup, seed=4)
         S = pn * ps
@@ -326,85 +330,125 @@ def train_leg_sharded(args, sc, opt, agg, cloud, rnd, cam, dev, world, rank, reh
         leaves = [x.clone().requires_grad_(True) for x in (cloud.emb, cloud.conf, cloud.dir, cloud.color)]
         for prm in agg.parameters():
             prm.requires_grad_(True)
+        my_rays, my_gt, my_drop = rays_all[ray_ids].contiguous(), gt[ray_ids].contiguous(), drop[ray_ids].contiguous()
+        w2c = torch.inverse(cam["c2w_nearest"]).contiguous()
         ev = lambda: torch.cuda.Event(enable_timing=True)
+        state = dict(cap=None, ex=None)
+
+        def compute():
+            """one rank's step: eager (train_step) or a replay of the captured graph; the jittered depth tables are drawn inside either way"""
+            if state["cap"] is not None:
+                return state["cap"].step(assign_grads=False)
+            return train_step(path, agg, cloud.xyz, leaves[0], leaves[1], leaves[2], leaves[3], my_rays, cam["campos"], cam["camrot"], cam["bg"], sc.near, sc.far,
+                              cam["c2w_nearest"], cam["campos_nearest"], cam["intrinsic"], cam["images"], my_gt, zero_epsilon=1e-3, w_color=1.0, w_zero_one=1e-4,
+                              frame_weight=frame_weight, ray_drop=my_drop, assign_grads=False, blur_kernels=kern, patch_num=n_patches, patch_size=ps,
+                              patch_layout=layout, w2c_nearest=w2c)
+
         def one(timed=None, collect=True):
-            for x in leaves:
-                x.grad = None
-            agg.zero_grad(set_to_none=True)
             e = [ev() for _ in range(4)] if timed is not None else None
             if e: e[0].record()
-            out = render_train(path, agg, cloud.xyz, leaves[0], leaves[1], leaves[2], leaves[3], rays_all[ray_ids], cam["campos"], cam["camrot"], cam["bg"],
-                               sc.near, sc.far, cam["c2w_nearest"], cam["campos_nearest"], cam["intrinsic"], cam["images"], ray_drop=drop[ray_ids])
-            col = blur_update_output(out["coarse_raycolor"][None], gt[ray_ids][None], kern, n_patches, ps, layout=layout)[0]
-            m = out["ray_mask"] > 0
-            loss = torch.nn.functional.mse_loss(col[m], gt[ray_ids][m]) * frame_weight * (float(ray_ids.numel()) / float(S * S))
-            loss.backward()
+            out, pg, ag = compute()
             if e: e[1].record()
-            grads = [q.grad if q.grad is not None else torch.zeros_like(q) for q in agg.parameters()]
-            touched = torch.unique(out["sample_pidx"][out["sample_pidx"] >= 0]).long()
-            assert touched.numel() == 0 or int(touched.max()) < leaves[0].shape[-2], "sample_pidx holds id %d >= %d points (shapes %s, pidx %s)" % (
-                int(touched.max()), leaves[0].shape[-2], [tuple(x.shape) for x in leaves], tuple(out["sample_pidx"].shape))
-            nbytes = dict(weights_allreduce=int(sum(x.numel() for x in grads) * 4), touched_points=int(touched.numel()),
-                          point_rows_allgather_per_rank=int(touched.numel() * (39 * 4 + 8)), dense_point_allreduce_avoided=int(sum(x.grad.numel() for x in leaves) * 4))
-            if world > 1 and collect:
-                if rehearsal:                                                   # gloo on host copies: control flow only
-                    host = [x.detach().cpu() for x in grads]
-                    parallel.allreduce_gradients(host)
-                    parallel.allreduce_point_buffers_sparse([x.grad.detach().cpu() for x in leaves], touched.cpu())
-                else:
-                    parallel.allreduce_gradients(grads)
+            Sv = out["_saved"]
+            nv = out["loss"][3:4]
+            bufs = [pg["points_embeding"], pg["points_conf"], pg["points_dir"], pg["points_color"]]
+            if collect and state["ex"] is not None:
+                if rehearsal and world > 1:                                     # gloo on host copies: control flow only
+                    flat = Sv.flat.cpu()
+                    parallel.allreduce_weight_grads(flat, nv.cpu(), Sv.flat_payload)
+                    tids, tcnt = TrainPath.touched_points(Sv)
+                    hb = [b.cpu() for b in bufs]
+                    rec = state["ex"].pack(hb, tids.cpu(), tcnt.cpu(), nv.cpu())
+                    state["ex"].apply(state["ex"].exchange(rec), hb, rank)
                     if e: e[2].record()
-                    summed = parallel.allreduce_point_buffers_sparse([x.grad for x in leaves], touched)
-                    for x, gsum in zip(leaves, summed):
-                        x.grad = gsum
-            if e and (world == 1 or rehearsal): e[2].record()
+                else:
+                    parallel.allreduce_weight_grads(Sv.flat, nv, Sv.flat_payload)
+                    if e: e[2].record()
+                    tids, tcnt = TrainPath.touched_points(Sv)
+                    rec = state["ex"].pack(bufs, tids, tcnt, nv)
+                    _tot, over = state["ex"].apply(state["ex"].exchange(rec), bufs, rank if world > 1 else 0)
+                    state["over"] = over
+            elif e:
+                e[2].record()
             if e: e[3].record()
             if timed is not None: timed.append(e)
-            return out, nbytes
+            return out
         # Preflight: this leg is reported BESIDE the headline line, so it must not be able to take the run down or leave ranks waiting in a collective
-        # for one that raised.  Every rank runs one step without the collectives, the ranks agree on the outcome (one all-reduce that every rank
-        # reaches), and only then the collectives run.
-        err = None
+        # for one that raised.  Every rank runs one eager step (and, by default, captures the step in a hipGraph) without the collectives, the ranks agree
+        # on the outcome and on the exchange capacity (one all-reduce that every rank reaches), and only then the collectives run.
+        err, n_touched, graph_note = None, 0, "eager: train.train_step, launches queued back to back on three queues"
         try:
-            one(collect=False)
+            out = one(collect=False)
             torch.cuda.synchronize()
+            TrainPath.check_status(out)
+            n_touched = int(TrainPath.touched_points(out["_saved"])[1].item())
+            if use_graph:
+                try:
+                    sample = dict(raydir=my_rays, campos=cam["campos"], camrot=cam["camrot"], bg_color=cam["bg"], c2w_nearest=cam["c2w_nearest"], w2c_nearest=w2c,
+                                  campos_nearest=cam["campos_nearest"], intrinsic_nearest=cam["intrinsic"], images_nearest=cam["images"], gt_image=my_gt,
+                                  ray_drop=my_drop, blur_kernels=kern, frame_weight=frame_weight)
+                    state["cap"] = CapturedTrainStep(path, agg, cloud.xyz, leaves[0], leaves[1], leaves[2], leaves[3], sample, sc.near, sc.far, zero_epsilon=1e-3,
+                                                     w_color=1.0, w_zero_one=1e-4, patch_num=n_patches, patch_size=ps, patch_layout=layout)
+                    graph_note = "hipGraph replay (train.CapturedTrainStep)"
+                except Exception as ex:                                          # noqa: BLE001  (the eager step is the fallback of the MEASUREMENT, not of the product)
+                    if os.environ.get("HNR_BENCH_STRICT"):
+                        raise
+                    state["cap"] = None
+                    graph_note = "eager: capture failed (%s: %s)" % (type(ex).__name__, str(ex)[:200])
         except Exception as ex:                                                  # noqa: BLE001
+            if os.environ.get("HNR_BENCH_STRICT"):
+                raise
             err = "%s: %s" % (type(ex).__name__, str(ex)[:300])
+        flag = torch.tensor([0 if err else 1, -n_touched], dtype=torch.int64, device="cpu" if (rehearsal or world == 1) else dev)
         if world > 1:
-            flag = torch.tensor([0 if err else 1], dtype=torch.int32, device="cpu" if rehearsal else dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 0 and err is None:
+            if int(flag[0].item()) == 0 and err is None:
                 err = "another rank failed its preflight step"
         if err:
             return dict(workload="C5 sharded train step", error=err, n_ranks=n_way)
-        for _ in range(warmup):
-            out, nbytes = one()
-        if world > 1: dist.barrier()
-        torch.cuda.synchronize()
-        evs = []
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            out, nbytes = one(evs)
-        if world > 1: dist.barrier()
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / steps
+        capacity = max(1024, (int(-flag[1].item()) * 3 // 2 + 255) // 256 * 256)  # 1.5 x the busiest rank's touched points of the preflight step
+        state["ex"] = parallel.PointGradExchange(capacity) if n_way > 1 else None     # (one rank, nothing emulated: there is nothing to exchange)
+        try:
+            for _ in range(warmup):
+                out = one()
+            if world > 1: dist.barrier()
+            torch.cuda.synchronize()
+            evs = []
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                out = one(evs)
+            if world > 1: dist.barrier()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+        except Exception as ex:                                                  # noqa: BLE001
+            if os.environ.get("HNR_BENCH_STRICT") or world > 1:                  # (N > 1: the other ranks wait in a collective -- fail the run rather than hang it)
+                raise
+            return dict(workload="C5 sharded train step", error="%s: %s" % (type(ex).__name__, str(ex)[:300]), n_ranks=n_way)
         comp = sum(e[0].elapsed_time(e[1]) for e in evs) / steps
         ar_w = sum(e[1].elapsed_time(e[2]) for e in evs) / steps
         ar_p = sum(e[2].elapsed_time(e[3]) for e in evs) / steps
+        per_rank = [dt * 1e3]
         tt = torch.tensor([dt, comp * 1e-3, ar_w * 1e-3, ar_p * 1e-3], dtype=torch.float64, device=dev)
         if world > 1:
             tt = tt.cpu() if rehearsal else tt
+            allt = [torch.empty_like(tt) for _ in range(world)]
+            dist.all_gather(allt, tt)
+            per_rank = [round(float(x[0]) * 1e3, 3) for x in allt]
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt, comp, ar_w, ar_p = (float(x) for x in tt)
         c = out["counts"].cpu().numpy()
+        over = float(state.get("over", torch.zeros(())).item()) if "over" in state else 0.0
+        n_w = int(out["_saved"].flat_payload)
         return dict(workload="C5: %d dilated %dx%d patches (dilation_setup 7_8_1_6) = %d rays, blur module (12 kernels 9x9) + frame weight, fwd + bwd%s" % (
                         pn * pn, ps, ps, S * S, "" if n_way == 1 else "; rank %d of %d: %d patches = %d rays" % (r_of, n_way, int(ids.numel()), int(ray_ids.numel()))),
-                    ms_per_step=round(dt * 1e3, 3), compute_ms=round(comp * 1e3, 3), allreduce_weights_ms=round(ar_w * 1e3, 3) if world > 1 and not rehearsal else None,
-                    allreduce_points_ms=round(ar_p * 1e3, 3) if world > 1 and not rehearsal else None, n_ranks=n_way, steps=steps,
-                    emulated_rank=("%d/%d on one GPU, no collectives" % (r_of, n_way)) if (emulate and world == 1) else None,
-                    valid_samples=int(c[6]), neighbour_rows=int(c[3]), collective_bytes=nbytes,
-                    note="max over ranks; collectives: parallel.allreduce_gradients (one flat bucket of the network's gradients) + "
-                         "parallel.allreduce_point_buffers_sparse (all-gather of the touched points' ids and 39-float rows + local scatter-add)")
+                    ms_per_step=round(dt * 1e3, 3), compute_ms=round(comp * 1e3, 3), allreduce_weights_ms=round(ar_w * 1e3, 3), exchange_points_ms=round(ar_p * 1e3, 3),
+                    per_rank_ms_per_step=per_rank, n_ranks=n_way, rccl_ranks=(world if (world > 1 and not rehearsal) else 0), steps=steps, step_form=graph_note,
+                    emulated_rank=("%d/%d on one GPU: the collectives are their local pack / apply parts only" % (r_of, n_way)) if (emulate and world == 1) else None,
+                    valid_samples=int(c[6]), neighbour_rows=int(c[3]), touched_points=n_touched, exchange_capacity=capacity, exchange_overflow=bool(over),
+                    collective_bytes=dict(weights_allreduce=4 * (n_w + 1), point_records_allgather_per_rank=(capacity + 2) * 40 * 4,
+                                          dense_point_allreduce_avoided=int(sum(x.numel() for x in leaves) * 4)),
+                    note="max over ranks; no host read in the step; collectives: parallel.allreduce_weight_grads (ONE all-reduce of the flat weight-gradient buffer + the "
+                         "valid-ray count) and parallel.PointGradExchange (ONE fixed-capacity all-gather of packed (id | 39 floats) records, applied in rank order)")
     finally:
         opt.is_train, opt.dilation_setup = old_train, old_dil
         for prm in agg.parameters():
@@ -452,6 +496,31 @@ def train_leg(args, sc, opt, agg, cloud, rnd, cam, dev, steps=20, warmup=3):
         dt = (time.perf_counter() - t0) / steps
         gpu_ms = sum(e[0].elapsed_time(e[1]) for e in evs) / steps
         c = out["counts"].cpu().numpy()
+        # the same step captured once in a hipGraph and replayed (train.CapturedTrainStep; the depth jitter is drawn inside the graph), reported beside the
+        # eager number: on ROCm 7.2 the graph executor serialises the step's three queues, so the replay is the SLOWER form
+        captured_ms, graph_note = None, "not measured (HNR_BENCH_TRAIN_GRAPH=0)"
+        if os.environ.get("HNR_BENCH_TRAIN_GRAPH", "1") != "0":
+            try:
+                from hybridneuralrendering_amd.train import CapturedTrainStep
+                sample = dict(raydir=raydir, campos=cam["campos"], camrot=cam["camrot"], bg_color=cam["bg"], c2w_nearest=cam["c2w_nearest"],
+                              campos_nearest=cam["campos_nearest"], intrinsic_nearest=cam["intrinsic"], images_nearest=cam["images"], gt_image=gt)
+                capt = CapturedTrainStep(path, agg, cloud.xyz, leaves[0], leaves[1], leaves[2], leaves[3], sample, sc.near, sc.far, zero_epsilon=1e-3,
+                                         w_color=1.0, w_zero_one=1e-4)
+                for _ in range(warmup):
+                    capt.step()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(steps):
+                    out_c, _, _ = capt.step()
+                torch.cuda.synchronize()
+                captured_ms = round((time.perf_counter() - t0) / steps * 1e3, 3)
+                TrainPath.check_status(out_c)
+                graph_note = "hipGraph replay of the same launches (train.CapturedTrainStep)"
+                del capt
+            except Exception as ex:                                              # noqa: BLE001
+                if os.environ.get("HNR_BENCH_STRICT"):
+                    raise
+                graph_note = "capture failed (%s: %s)" % (type(ex).__name__, str(ex)[:200])
         # stage times of the two library calls (HIP events recorded by the library at its stage boundaries, one extra step)
         path.timers = {}
         one()
@@ -496,7 +565,7 @@ def train_leg(args, sc, opt, agg, cloud, rnd, cam, dev, steps=20, warmup=3):
                       note="algorithmic bytes = the two fp32 operands read once (2 KiB per row); the f16x2 MFMA work of this shape (3 x 2 M N K) would take "
                            "%.3f ms at the 2.5 PFLOP/s peak, the operand stream %.3f ms at 8 TB/s: HBM is the nearer roof" % (issued / 2.5e15 * 1e3, M8 * 2048.0 / 8e12 * 1e3)) if M8 > 0 else None
         return dict(workload="C3: 56x56 = %d rays, fwd (train mode) + bwd, shipped loss" % raydir.shape[0], ms_per_step=round(dt * 1e3, 3),
-                    rays_per_s=round(raydir.shape[0] / dt, 1), fwd_ms=round(fwd, 3), loss_bwd_ms=round(bwd, 3),
+                    captured_ms_per_step=captured_ms, captured_form=graph_note, rays_per_s=round(raydir.shape[0] / dt, 1), fwd_ms=round(fwd, 3), loss_bwd_ms=round(bwd, 3),
                     neighbour_rows=int(c[3]), valid_samples=int(c[6]), steps=steps, entry="hnr_render_train_forward + hnr_render_train_backward (two library calls per step, no host read)",
                     stage_ms=stage, roofline_train=roof_t)
     finally:

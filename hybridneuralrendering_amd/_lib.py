@@ -155,6 +155,7 @@ SIGNATURES = {
     "hnr_shipped_loss_scratch_bytes": (ctypes.c_int64, []),
     "hnr_shipped_loss": (_I, [_P, _P, _P, _I, _P, ctypes.c_int64, _F, _F, _F, _F, _P, _P, _P, _P, _P]),
     "hnr_shipped_loss_rows": (_I, [_P, _P, _P, _I, _P, _I, _F, _F, _F, _F, _P, _P, _P, _P, _P]),
+    "hnr_shipped_loss_rows_fw": (_I, [_P, _P, _P, _I, _P, _I, _F, _F, _F, _P, _P, _P, _P, _P, _P]),
     "hnr_voxel_downsample_scratch_bytes": (ctypes.c_int64, [ctypes.c_int64]),
     "hnr_voxel_downsample": (_I, [_P, _I, ctypes.POINTER(_F), _F, _P, _P, _P, _P, _P, _P, ctypes.c_int64, _P]),
     "hnr_blur_gray_patches": (_I, [_P, _P, _I, _I, _P, _P]),
@@ -182,9 +183,12 @@ SIGNATURES = {
     "hnr_h2wgrad_scratch_bytes": (ctypes.c_int64, [_I, _I]),
     "hnr_h2wgrad": (_I, [_P, _I, _P, _I, ctypes.c_int64, _P, _I, ctypes.c_int64, _I, _I, _P, _P, _P, _I, _P, _I, _P, _P]),
     "hnr_absmax": (_I, [_P, _I, ctypes.c_int64, _P, _I, ctypes.c_int64, _I, _P, _P]),
+    "hnr_point_grad_pack": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "hnr_point_grad_apply": (_I, [_P, _I, _I, _P, _P, _P, _P, _I, _P, _P]),
     # the training step as two calls (csrc/render_train.hip)
     "hnr_render_train_workspace_bytes": (ctypes.c_int64, [ctypes.POINTER(TrainParams)]),
     "hnr_render_train_debug_layout": (_I, [ctypes.POINTER(TrainParams), ctypes.POINTER(ctypes.c_int64), _I]),
+    "hnr_render_train_touched": (_I, [ctypes.POINTER(TrainParams), _P, ctypes.c_int64, ctypes.POINTER(_P), ctypes.POINTER(_P), ctypes.POINTER(ctypes.c_int64)]),
     "hnr_render_train_forward": (_I, [_P, ctypes.POINTER(TrainParams), ctypes.POINTER(TrainCloud), ctypes.POINTER(TrainWeights), ctypes.POINTER(RenderCamera),
                                       ctypes.POINTER(TrainViews), _P, _P, _P, ctypes.c_int64, ctypes.POINTER(RenderOutputs), _P]),
     "hnr_render_train_backward": (_I, [ctypes.POINTER(TrainParams), ctypes.POINTER(TrainCloud), ctypes.POINTER(TrainWeights), ctypes.POINTER(RenderCamera),

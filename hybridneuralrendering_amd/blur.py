@@ -12,24 +12,42 @@ from . import _lib
 from ._lib import HnrError
 
 
+def blur_select(color, gt, kernels, patch_num, patch_size):
+    """hnr_blur_select without an autograd graph: (new colours [R,3], selected kernel per patch int32 [n_patches]).  patch_num < 0: -patch_num whole
+    patches packed patch-major.  What train.train_step queues between the forward call and the loss kernels."""
+    L = _lib.lib()
+    c = _lib.require_gpu(color.detach(), "coarse_raycolor", torch.float32).reshape(-1, 3)
+    g = _lib.require_gpu(gt, "gt_image", torch.float32).reshape(-1, 3)
+    k = _lib.require_gpu(kernels, "blur_kernels", torch.float32)
+    k = k.reshape(-1, k.shape[-2], k.shape[-1])
+    if k.shape[-1] != k.shape[-2]:
+        raise HnrError("blur kernels must be square")
+    n_patches = -patch_num if patch_num < 0 else patch_num * patch_num          # patch_num < 0: patch-major list of whole patches
+    if c.shape[0] != n_patches * patch_size * patch_size or g.shape[0] != c.shape[0]:
+        raise HnrError("blur_update_output: expected %d patches of %dx%d rays, got %d rays" % (n_patches, patch_size, patch_size, c.shape[0]))
+    out = torch.empty_like(c)
+    sel = torch.empty((n_patches,), dtype=torch.int32, device=c.device)
+    with torch.cuda.device(c.device):
+        _lib.check(L.hnr_blur_select(_lib.ptr(c), _lib.ptr(g), _lib.ptr(k), k.shape[0], k.shape[-1], patch_num, patch_size, _lib.ptr(out),
+                                     _lib.ptr(sel), _lib.stream()), "hnr_blur_select")
+    return out, sel, k
+
+
+def blur_select_bwd(g_out, k, sel, patch_num, patch_size):
+    """d loss / d rendered colours through the selected kernels only (the selection itself is piecewise constant)."""
+    L = _lib.lib()
+    g = _lib.require_gpu(g_out.contiguous(), "grad", torch.float32).reshape(-1, 3)
+    g_in = torch.empty_like(g)
+    with torch.cuda.device(g.device):
+        _lib.check(L.hnr_blur_select_bwd(_lib.ptr(g), _lib.ptr(k), _lib.ptr(sel), k.shape[0], k.shape[-1], patch_num, patch_size, _lib.ptr(g_in),
+                                         _lib.stream()), "hnr_blur_select_bwd")
+    return g_in
+
+
 class _BlurSelect(torch.autograd.Function):
     @staticmethod
     def forward(ctx, color, gt, kernels, patch_num, patch_size):
-        L = _lib.lib()
-        c = _lib.require_gpu(color.detach(), "coarse_raycolor", torch.float32).reshape(-1, 3)
-        g = _lib.require_gpu(gt, "gt_image", torch.float32).reshape(-1, 3)
-        k = _lib.require_gpu(kernels, "blur_kernels", torch.float32)
-        k = k.reshape(-1, k.shape[-2], k.shape[-1])
-        if k.shape[-1] != k.shape[-2]:
-            raise HnrError("blur kernels must be square")
-        n_patches = -patch_num if patch_num < 0 else patch_num * patch_num          # patch_num < 0: patch-major list of whole patches
-        if c.shape[0] != n_patches * patch_size * patch_size or g.shape[0] != c.shape[0]:
-            raise HnrError("blur_update_output: expected %d patches of %dx%d rays, got %d rays" % (n_patches, patch_size, patch_size, c.shape[0]))
-        out = torch.empty_like(c)
-        sel = torch.empty((n_patches,), dtype=torch.int32, device=c.device)
-        with torch.cuda.device(c.device):
-            _lib.check(L.hnr_blur_select(_lib.ptr(c), _lib.ptr(g), _lib.ptr(k), k.shape[0], k.shape[-1], patch_num, patch_size, _lib.ptr(out),
-                                         _lib.ptr(sel), _lib.stream()), "hnr_blur_select")
+        out, sel, k = blur_select(color, gt, kernels, patch_num, patch_size)
         ctx.save_for_backward(k, sel)
         ctx.dims = (patch_num, patch_size, color.shape)
         ctx.mark_non_differentiable(sel)
@@ -37,15 +55,9 @@ class _BlurSelect(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_out, _g_sel):
-        L = _lib.lib()
         k, sel = ctx.saved_tensors
         pn, ps, shape = ctx.dims
-        g = _lib.require_gpu(g_out.contiguous(), "grad", torch.float32).reshape(-1, 3)
-        g_in = torch.empty_like(g)
-        with torch.cuda.device(g.device):
-            _lib.check(L.hnr_blur_select_bwd(_lib.ptr(g), _lib.ptr(k), _lib.ptr(sel), k.shape[0], k.shape[-1], pn, ps, _lib.ptr(g_in),
-                                             _lib.stream()), "hnr_blur_select_bwd")
-        return g_in.reshape(shape), None, None, None, None
+        return blur_select_bwd(g_out, k, sel, pn, ps).reshape(shape), None, None, None, None
 
 
 def blur_update_output(coarse_raycolor, gt_image, blur_kernels, patch_num, patch_size, return_select=False, layout="grid"):

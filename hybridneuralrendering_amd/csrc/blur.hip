@@ -30,9 +30,15 @@ __device__ __forceinline__ size_t blur_ray(int p, int y, int x, int pn, int ps, 
     return (size_t)((p / pn) * ps + y) * (pn * ps) + ((p % pn) * ps + x);
 }
 
-__global__ __launch_bounds__(256) void blur_select_kernel(BlurArgs a)
+// One 1024-thread block per patch; the (candidate, position) pairs -- 13 x 192 in the shipped configuration -- are spread over all 16 waves (the first
+// form walked the candidates one after the other with 192 of 256 threads busy: 113 us on the critical path of the training step for seven patches).
+// Every |candidate - gt| term goes to LDS and each candidate's L1 distance is summed in a FIXED order (positions lane, lane + 64, ... then a butterfly),
+// so the selection cannot change from run to run on a near-tie (LDS float atomics across waves could).
+constexpr int BLUR_CHUNK = 4096;     // (candidate, position) terms held in LDS at a time
+__global__ __launch_bounds__(1024) void blur_select_kernel(BlurArgs a)
 {
     __shared__ float s_in[3][BLUR_MAX_PS][BLUR_MAX_PS], s_gt[3][BLUR_MAX_PS][BLUR_MAX_PS];
+    __shared__ float s_term[BLUR_CHUNK];
     __shared__ float s_diff[BLUR_MAX_N + 1];
     __shared__ int s_sel;
     const int p = blockIdx.x;
@@ -44,7 +50,6 @@ __global__ __launch_bounds__(256) void blur_select_kernel(BlurArgs a)
         s_in[c][y][x] = a.color[3 * ray + c];
         s_gt[c][y][x] = a.gt[3 * ray + c];
     }
-    if (threadIdx.x <= a.N) s_diff[threadIdx.x] = 0.f;
     __syncthreads();
     auto blurred = [&](int n, int c, int y, int x) {
         if (n == a.N) return s_in[c][y][x];
@@ -63,17 +68,24 @@ __global__ __launch_bounds__(256) void blur_select_kernel(BlurArgs a)
         }
         return hnr_div(acc, msk);
     };
-    // L1 distance of every candidate: (candidate, position) pairs over the block, wave partial sums -> LDS atomics
-    for (int n = 0; n <= a.N; ++n) {
-        float d = 0.f;
-        for (int t = threadIdx.x; t < npos; t += blockDim.x) {
+    const int per_chunk = BLUR_CHUNK / npos;                   // candidates per LDS chunk (npos <= 768: at least 5)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    for (int n0 = 0; n0 <= a.N; n0 += per_chunk) {
+        const int nc = min(per_chunk, a.N + 1 - n0);
+        for (int it = threadIdx.x; it < nc * npos; it += blockDim.x) {
+            const int n = n0 + it / npos, t = it % npos;
             const int c = t / (ps * ps), y = (t / ps) % ps, x = t % ps;
-            d += fabsf(blurred(n, c, y, x) - s_gt[c][y][x]);
+            s_term[it] = fabsf(blurred(n, c, y, x) - s_gt[c][y][x]);
         }
-        for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
-        if ((threadIdx.x & 63) == 0) atomicAdd(&s_diff[n], d);
+        __syncthreads();
+        for (int m = wave; m < nc; m += n_waves) {             // one wave per candidate: fixed summation order
+            float d = 0.f;
+            for (int t = lane; t < npos; t += 64) d += s_term[m * npos + t];
+            for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
+            if (lane == 0) s_diff[n0 + m] = d;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     if (threadIdx.x == 0) {
         int best = 0;
         for (int n = 1; n <= a.N; ++n) if (s_diff[n] < s_diff[best]) best = n;      // first minimum (torch.argmin)
@@ -311,7 +323,7 @@ extern "C" int hnr_blur_select(const float *d_color, const float *d_gt, const fl
     a.color = d_color; a.gt = d_gt; a.kernels = d_kernels; a.N = n_kernels; a.ks = kernel_size; a.ps = patch_size;
     a.patch_major = patch_num < 0; a.pn = patch_num < 0 ? 1 : patch_num; a.n_patches = patch_num < 0 ? -patch_num : patch_num * patch_num;
     a.out = d_out; a.select = d_select;
-    blur_select_kernel<<<a.n_patches, 256, 0, (hipStream_t)stream>>>(a);
+    blur_select_kernel<<<a.n_patches, 1024, 0, (hipStream_t)stream>>>(a);
     HNR_LAUNCH_CHECK();
     return HNR_OK;
 }

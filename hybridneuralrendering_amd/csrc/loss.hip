@@ -23,6 +23,7 @@ struct LossArgs {
     int R; long long n_conf;
     int conf_per_ray;                 // > 0: conf is [R, conf_per_ray] and only the rows of rays with ray_mask > 0 count (n_conf = R * conf_per_ray)
     float eps, w_color, w_zero_one, frame_weight;
+    const float *d_frame_weight;      // optional: the item's scalar on the device (a captured step replays with another value); wins over frame_weight
     double *partial;                  // [LOSS_BLOCKS][3]: squared error, valid rays, zero-one sum
     float *out;                       // {total, colour, zero_one, n_valid}
     float *g_color, *g_conf;          // may be NULL (value only)
@@ -57,13 +58,14 @@ __global__ __launch_bounds__(256) void loss_finish_kernel(LossArgs a)
     if (threadIdx.x == 0) {
         double se = 0.0, nv = 0.0, zo = 0.0;
         for (int b = 0; b < LOSS_BLOCKS; ++b) { se += a.partial[3 * b]; nv += a.partial[3 * b + 1]; zo += a.partial[3 * b + 2]; }
+        const float fw = a.d_frame_weight ? a.d_frame_weight[0] : a.frame_weight;
         const float lc = nv > 0.0 ? (float)hnr_div64(se, 3.0 * nv) : 0.f;
         const double n_conf = a.conf_per_ray > 0 ? nv * (double)a.conf_per_ray : (double)a.n_conf;
         const float lz = n_conf > 0.0 ? (float)hnr_div64(zo, n_conf) : 0.f;
-        s_scale[0] = nv > 0.0 ? (float)hnr_div64(2.0, 3.0 * nv) * a.w_color * a.frame_weight : 0.f;
+        s_scale[0] = nv > 0.0 ? (float)hnr_div64(2.0, 3.0 * nv) * a.w_color * fw : 0.f;
         s_scale[1] = n_conf > 0.0 ? hnr_div(a.w_zero_one, (float)n_conf) : 0.f;
         if (blockIdx.x == 0) {
-            a.out[0] = (lc * a.w_color + 1e-6f) * a.frame_weight + lz * a.w_zero_one;
+            a.out[0] = (lc * a.w_color + 1e-6f) * fw + lz * a.w_zero_one;
             a.out[1] = lc; a.out[2] = lz; a.out[3] = (float)nv;
         }
     }
@@ -91,7 +93,7 @@ extern "C" int64_t hnr_shipped_loss_scratch_bytes(void) { return (int64_t)(LOSS_
 
 static int shipped_loss_impl(const float *d_color, const float *d_gt, const int8_t *d_ray_mask, int R, const float *d_conf, int64_t n_conf, int conf_per_ray,
                              float zero_epsilon, float w_color, float w_zero_one, float frame_weight, float *d_out4, float *d_g_color,
-                             float *d_g_conf, void *d_scratch, void *stream)
+                             float *d_g_conf, void *d_scratch, void *stream, const float *d_frame_weight = nullptr)
 {
     if (R < 0 || n_conf < 0 || conf_per_ray < 0 || !(zero_epsilon >= 0.f && zero_epsilon < 0.5f)) { set_error("hnr_shipped_loss: bad sizes or zero_epsilon"); return HNR_ERR_BADARG; }
     if ((R > 0 && (!d_color || !d_gt || !d_ray_mask)) || (n_conf > 0 && !d_conf) || !d_out4 || !d_scratch || (!d_g_color != !d_g_conf && n_conf > 0 && R > 0)) {
@@ -99,7 +101,7 @@ static int shipped_loss_impl(const float *d_color, const float *d_gt, const int8
     }
     LossArgs a;
     a.color = d_color; a.gt = d_gt; a.ray_mask = d_ray_mask; a.conf = d_conf; a.R = R; a.n_conf = n_conf; a.conf_per_ray = conf_per_ray;
-    a.eps = zero_epsilon; a.w_color = w_color; a.w_zero_one = w_zero_one; a.frame_weight = frame_weight;
+    a.eps = zero_epsilon; a.w_color = w_color; a.w_zero_one = w_zero_one; a.frame_weight = frame_weight; a.d_frame_weight = d_frame_weight;
     a.partial = (double *)d_scratch; a.out = d_out4; a.g_color = d_g_color; a.g_conf = d_g_conf;
     loss_partial_kernel<<<LOSS_BLOCKS, 256, 0, (hipStream_t)stream>>>(a);
     HNR_LAUNCH_CHECK();
@@ -121,4 +123,14 @@ extern "C" int hnr_shipped_loss_rows(const float *d_color, const float *d_gt, co
 {
     return shipped_loss_impl(d_color, d_gt, d_ray_mask, R, d_conf, (int64_t)R * conf_per_ray, conf_per_ray, zero_epsilon, w_color, w_zero_one, frame_weight, d_out4,
                              d_g_color, d_g_conf, d_scratch, stream);
+}
+
+// ... with the item's frame weight read from the device (d_frame_weight[0]): a training step captured in a hipGraph is replayed for items with different weights.
+extern "C" int hnr_shipped_loss_rows_fw(const float *d_color, const float *d_gt, const int8_t *d_ray_mask, int R, const float *d_conf, int conf_per_ray,
+                                        float zero_epsilon, float w_color, float w_zero_one, const float *d_frame_weight, float *d_out4, float *d_g_color,
+                                        float *d_g_conf, void *d_scratch, void *stream)
+{
+    if (!d_frame_weight) { set_error("hnr_shipped_loss_rows_fw: NULL d_frame_weight"); return HNR_ERR_BADARG; }
+    return shipped_loss_impl(d_color, d_gt, d_ray_mask, R, d_conf, (int64_t)R * conf_per_ray, conf_per_ray, zero_epsilon, w_color, w_zero_one, 1.0f, d_out4,
+                             d_g_color, d_g_conf, d_scratch, stream, d_frame_weight);
 }

@@ -477,6 +477,20 @@ extern "C" int hnr_render_train_debug_layout(const hnr_train_params *p, int64_t 
     return n < max_entries ? n : max_entries;
 }
 
+// The batch's touched points (ascending point ids) and their number, as the forward call left them in the workspace: what a sparse optimiser step or
+// a sparse gradient exchange between ranks needs (parallel.PointGradExchange) -- without a torch.unique over sample_pidx (a sort + a host read).
+extern "C" int hnr_render_train_touched(const hnr_train_params *p, void *d_workspace, int64_t workspace_bytes, const int32_t **d_ids, const int64_t **d_count,
+                                        int64_t *capacity)
+{
+    TR(check_params(p, "hnr_render_train_touched"));
+    if (!d_workspace || ((uintptr_t)d_workspace & 255) || !d_ids || !d_count || !capacity) { set_error("hnr_render_train_touched: NULL / unaligned argument"); return HNR_ERR_BADARG; }
+    bool ok = true;
+    const Layout L = carve(d_workspace, (size_t)workspace_bytes, p, &ok);
+    if (!ok) { set_error("hnr_render_train_touched: workspace too small"); return HNR_ERR_BADARG; }
+    *d_ids = L.ulist; *d_count = reinterpret_cast<const int64_t *>(L.tc + TC_U); *capacity = (int64_t)L.ucap;
+    return HNR_OK;
+}
+
 extern "C" int64_t hnr_render_train_workspace_bytes(const hnr_train_params *p)
 {
     if (check_params(p, "hnr_render_train_workspace_bytes") != HNR_OK) return -1;

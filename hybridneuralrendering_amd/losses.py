@@ -30,7 +30,15 @@ def _loss_call(color, conf, gt, ray_mask, zero_epsilon, w_color, w_zero_one, fra
     scratch = torch.empty((int(L.hnr_shipped_loss_scratch_bytes()),), dtype=torch.uint8, device=dev)
     p = _lib.ptr
     with torch.cuda.device(dev):
-        if conf_rows:
+        if isinstance(frame_weight, torch.Tensor):
+            # the item's scalar on the device (one float): read by the kernel, so a captured step replays with other values
+            if not conf_rows:
+                raise HnrError("shipped_loss: a device frame_weight needs conf_rows=True")
+            fw = _lib.require_gpu(frame_weight, "frame_weight", torch.float32).reshape(-1)
+            _lib.check(L.hnr_shipped_loss_rows_fw(p(c), p(g), p(m), R, p(x), int(x.shape[0] // R), float(zero_epsilon), float(w_color), float(w_zero_one),
+                                                  p(fw), p(out), p(g_c) if want_grads else None, p(g_x) if want_grads else None, p(scratch),
+                                                  _lib.stream()), "hnr_shipped_loss_rows_fw")
+        elif conf_rows:
             _lib.check(L.hnr_shipped_loss_rows(p(c), p(g), p(m), R, p(x), int(x.shape[0] // R), float(zero_epsilon), float(w_color), float(w_zero_one),
                                                float(frame_weight), p(out), p(g_c) if want_grads else None, p(g_x) if want_grads else None, p(scratch),
                                                _lib.stream()), "hnr_shipped_loss_rows")
@@ -81,7 +89,10 @@ def shipped_loss(coarse_raycolor, conf_coefficient, gt_image, ray_mask, zero_eps
     return _ShippedLoss.apply(coarse_raycolor, conf_coefficient, gt_image, ray_mask, zero_epsilon, w_color, w_zero_one, _fw(frame_weight), bool(conf_rows))
 
 
-def shipped_loss_grads(coarse_raycolor, conf_coefficient, gt_image, ray_mask, zero_epsilon, w_color=1.0, w_zero_one=1e-4, frame_weight=None, conf_rows=True):
+def shipped_loss_grads(coarse_raycolor, conf_coefficient, gt_image, ray_mask, zero_epsilon, w_color=1.0, w_zero_one=1e-4, frame_weight=None, conf_rows=True,
+                       device_frame_weight=None):
     """The loss terms and their gradients without an autograd graph: (parts [4] = {total, colour MSE, zero-one mean, valid rays},
-    d total / d coarse_raycolor [R,3], d total / d conf_coefficient (flat)) -- what train.train_step feeds to the backward pass."""
-    return _loss_call(coarse_raycolor, conf_coefficient, gt_image, ray_mask, zero_epsilon, w_color, w_zero_one, _fw(frame_weight), bool(conf_rows))
+    d total / d coarse_raycolor [R,3], d total / d conf_coefficient (flat)) -- what train.train_step feeds to the backward pass.
+    device_frame_weight: a one-float device tensor holding the item's scalar (a captured step; the kernel reads it)."""
+    fw = device_frame_weight if device_frame_weight is not None else _fw(frame_weight)
+    return _loss_call(coarse_raycolor, conf_coefficient, gt_image, ray_mask, zero_epsilon, w_color, w_zero_one, fw, bool(conf_rows))

@@ -122,10 +122,12 @@ class TrainPath:
         self.cap_samples = None            # valid-sample capacity of the workspace (None: R * SR, the worst case)
         self.timers = None                 # a dict: the library records HIP events at its stage boundaries (profiling; read them after a synchronise)
         self.workspace = None              # tools: a caller-owned uint8 tensor every forward uses instead of a fresh torch.empty (one step in flight at a time)
+        self._lut = {}
 
     # ---------------------------------------------------------------------------------------------- forward
     def forward(self, cloud, raydir, campos, camrot, bg_color, near, far, c2w_nearest, campos_nearest, intrinsic_nearest,
-                images_nearest, frame_weight=None, tmid=None, ray_drop=None):
+                images_nearest, frame_weight=None, tmid=None, ray_drop=None, w2c_nearest=None):
+        """w2c_nearest [V,4,4]: inverse(c2w_nearest) computed by the caller (torch.inverse may synchronise the host: a captured step passes it in)."""
         L = _lib.lib()
         r, opt = self.r, self.opt
         g, p = _lib.require_gpu, _lib.ptr
@@ -167,7 +169,8 @@ class TrainPath:
         nbytes = int(L.hnr_render_train_workspace_bytes(ctypes.byref(prm)))
         if nbytes < 0:
             raise HnrError("hnr_render_train_workspace_bytes: %s" % L.hnr_last_error().decode("utf-8", "replace"))
-        free, _total = torch.cuda.mem_get_info(dev)
+        capturing = torch.cuda.is_current_stream_capturing()
+        free, _total = (1 << 62, 0) if capturing else torch.cuda.mem_get_info(dev)
         cached = torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
         if nbytes > 0.9 * (free + cached):
             raise HnrError("render_train: the workspace for %d rays x SR %d (%.1f GB) does not fit the %.1f GB that are free; set TrainPath.cap_samples to the "
@@ -183,7 +186,10 @@ class TrainPath:
         S.cam = _lib.RenderCamera(p(campos), p(camrot), p(raydir), p(tmid), p(bg_color))
         S.vw, S.vw_t = None, None
         if V > 0:
-            w2c = torch.inverse(c2w_nearest).contiguous()          # 4x4 plumbing op (neural_points_volumetric_model.py:250)
+            if w2c_nearest is not None:
+                w2c = g(w2c_nearest, "w2c_nearest", torch.float32).reshape(-1, 4, 4)
+            else:
+                w2c = torch.inverse(c2w_nearest).contiguous()      # 4x4 plumbing op (neural_points_volumetric_model.py:250)
             fw = None if frame_weight is None else g(frame_weight, "frame_weight_nearest", torch.float32).reshape(-1)
             if fw is not None and fw.numel() != V:
                 raise HnrError("frame_weight_nearest must hold one weight per reference view (%d), got %d values -- the item's scalar loss weight "
@@ -196,7 +202,10 @@ class TrainPath:
             # explicit [R] flags (a rank's slice of the batch-wide drop pattern when the batch is sharded over GPUs)
             flags = g(ray_drop, "ray_drop", torch.uint8).reshape(-1)
         elif mode == "patch" and V > 0:
-            lut = drop_lut(opt, R, dev)
+            key = (R, str(opt.dilation_setup), float(opt.drop_ratio), str(dev))
+            if self._lut.get("key") != key:                      # (a host -> device copy: once per batch shape, never inside a captured step)
+                self._lut = dict(key=key, lut=drop_lut(opt, R, dev))
+            lut = self._lut["lut"]
         elif mode == "random" and V > 0:
             # the random subset needs the ray mask first: one extra query launch (no host read), then explicit flags
             q0 = Q.march_query(grid, campos, raydir, tmid, SR, K, np.float32(hp[0] ** 2), opt.kernel_size, pad=True)
@@ -230,6 +239,18 @@ class TrainPath:
         return out, S
 
     @staticmethod
+    def touched_points(S):
+        """(ids int32 [capacity] ascending, count int64 [1]) -- views INTO the step's workspace (valid until the next forward on it): the points the
+        batch referenced, as the forward call left them on the device (hnr_render_train_touched).  No sort, no host read."""
+        L = _lib.lib()
+        ids, cnt, cap = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_int64()
+        _lib.check(L.hnr_render_train_touched(ctypes.byref(S.prm), S.ws_ptr, S.nbytes, ctypes.byref(ids), ctypes.byref(cnt), ctypes.byref(cap)),
+                   "hnr_render_train_touched")
+        base = S.ws.data_ptr()
+        o_ids, o_cnt = ids.value - base, cnt.value - base
+        return S.ws[o_ids:o_ids + 4 * cap.value].view(torch.int32), S.ws[o_cnt:o_cnt + 8].view(torch.int64)
+
+    @staticmethod
     def check_status(out):
         """Reads the forward's status word (a host synchronisation): raises when the workspace capacity was exceeded."""
         st = out["status"].cpu()
@@ -252,9 +273,10 @@ class TrainPath:
         names = [n for n in S.wt if not n.startswith(skip)]
         sizes = [int(S.wt[n].numel()) for n in names]
         offs = np.concatenate([[0], np.cumsum([(s + 63) // 64 * 64 for s in sizes])])
-        flat = _f32((int(offs[-1]),), dev)                        # one buffer for all weight gradients (256-byte aligned slices)
+        flat = _f32((int(offs[-1]) + 64,), dev)                   # one buffer for all weight gradients (256-byte aligned slices) + a spare tail (parallel.allreduce_weight_grads)
         ag = {n: flat[int(offs[i]):int(offs[i]) + sizes[i]].view(S.wt[n].shape) for i, n in enumerate(names)}
         gw = _fill_weights(ag)
+        S.flat, S.flat_payload = flat, int(offs[-1])            # all weight gradients as ONE buffer: one all-reduce when the batch is sharded over ranks
         cg = _lib.TrainCloudGrads(p(pg["points_embeding"]), p(pg["points_conf"]), p(pg["points_dir"]), p(pg["points_color"]))
         S.out.stage_events = None
         if self.timers is not None:
@@ -318,13 +340,65 @@ def render_train(path, aggregator, xyz, emb, conf, pdir, color, raydir, campos, 
     return out
 
 
+def _queue_step(path, cloud, raydir, campos, camrot, bg_color, near, far, c2w_nearest, campos_nearest, intrinsic_nearest, images_nearest, gt_image,
+                zero_epsilon, w_color, w_zero_one, frame_weight, tmid, ray_drop, frame_weight_nearest, blur, w2c_nearest, device_frame_weight=None):
+    """The launches of one step, queued back to back on the current stream: forward -> [blur module] -> loss kernels -> [blur module backward] ->
+    backward.  Nothing is read back; shared by train_step (eager) and CapturedTrainStep (inside a hipGraph capture)."""
+    from .losses import shipped_loss_grads
+    from .blur import blur_select, blur_select_bwd
+    out, S = path.forward(cloud, raydir, campos, camrot, bg_color, near, far, c2w_nearest, campos_nearest, intrinsic_nearest, images_nearest,
+                          frame_weight=frame_weight_nearest, tmid=tmid, ray_drop=ray_drop, w2c_nearest=w2c_nearest)
+    col = out["coarse_raycolor"]
+    sel = None
+    if blur is not None:
+        # add_blur_sim=1 (models/mvs_points_volumetric_model.py:145-146 -> base_rendering_model.py:677-745): per patch, the pre-defined kernel whose
+        # blurred render is closest to the ground truth replaces the render before the losses
+        kernels, pn, ps = blur
+        col, sel, kk = blur_select(col, gt_image, kernels, pn, ps)
+    parts, g_col, g_cc = shipped_loss_grads(col, out["conf_coefficient"], gt_image, out["ray_mask"], zero_epsilon, w_color, w_zero_one, frame_weight,
+                                            conf_rows=True, device_frame_weight=device_frame_weight)
+    if blur is not None:
+        g_col = blur_select_bwd(g_col, kk, sel, pn, ps)
+    pg, ag = path.backward(S, g_col, g_cc)
+    out = dict(out)
+    out["loss"] = parts
+    if blur is not None:
+        out["blurred_raycolor"], out["blur_select"] = col, sel
+    return out, S, pg, ag
+
+
+def _blur_arg(blur_kernels, patch_num, patch_size, patch_layout):
+    if blur_kernels is None:
+        return None
+    if patch_layout not in ("grid", "patch_major") or not patch_num or not patch_size:
+        raise HnrError("train_step: blur_kernels need patch_num, patch_size and patch_layout 'grid' | 'patch_major'")
+    return (blur_kernels, -int(patch_num) if patch_layout == "patch_major" else int(patch_num), int(patch_size))
+
+
+def _assign_grads(aggregator, emb, conf, pdir, color, pg, ag, accumulate=True):
+    def put(t, g):
+        if isinstance(t, torch.Tensor) and t.requires_grad:
+            g = g.reshape(t.shape)
+            t.grad = g if (t.grad is None or not accumulate) else t.grad + g
+    put(emb, pg["points_embeding"]); put(conf, pg["points_conf"]); put(pdir, pg["points_dir"]); put(color, pg["points_color"])
+    for n, q in aggregator.named_parameters():
+        if n in ag:
+            put(q, ag[n])
+
+
 def train_step(path, aggregator, xyz, emb, conf, pdir, color, raydir, campos, camrot, bg_color, near, far, c2w_nearest, campos_nearest,
                intrinsic_nearest, images_nearest, gt_image, zero_epsilon=1e-3, w_color=1.0, w_zero_one=1e-4, frame_weight=None, tmid=None,
-               ray_drop=None, assign_grads=True, frame_weight_nearest=None):
-    """forward -> shipped loss terms -> backward of one ray batch as three groups of library launches queued back to back: no autograd
+               ray_drop=None, assign_grads=True, frame_weight_nearest=None, blur_kernels=None, patch_num=None, patch_size=None, patch_layout="grid",
+               w2c_nearest=None):
+    """forward -> [blur module] -> shipped loss terms -> backward of one ray batch as groups of library launches queued back to back: no autograd
     graph, no masked copies, nothing read back to the host -- the body of the reference's optimize_parameters before its optimizer steps
     (models/neural_points_volumetric_model.py:202-214: self.forward(); loss_total.backward(), with compute_losses of
     models/base_rendering_model.py:1060-1245 in between).  Same arithmetic as render_train + losses.shipped_loss + loss.backward().
+
+    blur_kernels [1,N,ks,ks] / [N,ks,ks] (the item's `blur_kernels`, add_blur_sim=1) with patch_num / patch_size / patch_layout: the blur-handling
+    module between the render and the losses (models/mvs_points_volumetric_model.py:145-146, base_rendering_model.py:677-745) -- hnr_blur_select before
+    the loss kernels, hnr_blur_select_bwd behind them; patch_layout="patch_major": the batch is `patch_num` whole patches packed (patch, y, x), a rank's
+    share of a patch-sharded batch (parallel.shard_patches).  Same arithmetic as render_train + blur.blur_update_output + the loss + loss.backward().
 
     The reference has TWO frame-weight inputs and so has this call: `frame_weight` is the dataset item's scalar that multiplies loss_total
     (models/base_rendering_model.py:1205; a Python float or a CPU tensor -- converted once, no device read in the step) and
@@ -332,24 +406,83 @@ def train_step(path, aggregator, xyz, emb, conf, pdir, color, raydir, campos, ca
     (models/aggregators/point_aggregators.py:1203), a device tensor that only the forward / backward calls read.
 
     emb/conf/pdir/color and the aggregator's parameters are read as they are; with assign_grads their .grad fields are set (or added to,
-    as autograd does).  Returns (outputs dict with `loss` = {total, colour MSE, zero-one mean, valid rays} on the device,
-    point grads dict, aggregator grads dict keyed by parameter name)."""
-    from .losses import shipped_loss_grads
+    as autograd does).  Returns (outputs dict with `loss` = {total, colour MSE, zero-one mean, valid rays} on the device and `_saved` = the step's
+    state for TrainPath.touched_points / the flat weight-gradient buffer, point grads dict, aggregator grads dict keyed by parameter name)."""
     cloud = PointCloud(xyz, emb.detach(), conf.detach(), pdir.detach(), color.detach())
-    out, S = path.forward(cloud, raydir, campos, camrot, bg_color, near, far, c2w_nearest, campos_nearest, intrinsic_nearest, images_nearest,
-                          frame_weight=frame_weight_nearest, tmid=tmid, ray_drop=ray_drop)
-    parts, g_col, g_cc = shipped_loss_grads(out["coarse_raycolor"], out["conf_coefficient"], gt_image, out["ray_mask"], zero_epsilon, w_color,
-                                            w_zero_one, frame_weight, conf_rows=True)
-    pg, ag = path.backward(S, g_col, g_cc)
-    out = dict(out)
-    out["loss"] = parts
+    out, S, pg, ag = _queue_step(path, cloud, raydir, campos, camrot, bg_color, near, far, c2w_nearest, campos_nearest, intrinsic_nearest, images_nearest,
+                                 gt_image, zero_epsilon, w_color, w_zero_one, frame_weight, tmid, ray_drop, frame_weight_nearest,
+                                 _blur_arg(blur_kernels, patch_num, patch_size, patch_layout), w2c_nearest)
+    out["_saved"] = S
     if assign_grads:
-        def put(t, g):
-            if isinstance(t, torch.Tensor) and t.requires_grad:
-                g = g.reshape(t.shape)
-                t.grad = g if t.grad is None else t.grad + g
-        put(emb, pg["points_embeding"]); put(conf, pg["points_conf"]); put(pdir, pg["points_dir"]); put(color, pg["points_color"])
-        for n, q in aggregator.named_parameters():
-            if n in ag:
-                put(q, ag[n])
+        _assign_grads(aggregator, emb, conf, pdir, color, pg, ag)
     return out, pg, ag
+
+
+class CapturedTrainStep:
+    """train_step captured ONCE in a hipGraph (torch.cuda.CUDAGraph over the HIP graph API) and replayed per step.
+
+    One step is ~150 launches of 10 - 50 us from three queues (the caller's stream and the library's two side streams, forked and joined with events
+    inside the two library calls: stream capture follows them, so the graph keeps the three branches); replaying it removes the host's launch cost and
+    the gaps between dependent launches -- what the reference pays per step in Python dispatch (models/neural_points_volumetric_model.py:202-214).
+    Every launch size of the step is capacity-fixed and reads its true size from device counters, so ONE graph serves every batch of the same shape.
+
+    Inputs live in static device buffers (`self.inputs`: raydir, campos, camrot, bg_color, c2w_nearest, w2c_nearest, campos_nearest, intrinsic_nearest,
+    images_nearest, gt_image and, when given at construction, tmid, ray_drop, frame_weight_nearest, blur_kernels; `frame_weight` = one float);
+    `step(**tensors)` copies what it is given into them and replays.  tmid=None at construction: the jittered depth tables are drawn INSIDE the graph
+    (torch.rand under capture advances the registered generator state on every replay: a fresh jitter per step, as at
+    models/neural_points/query_point_indices_worldcoords.py:87).  The weights and the point buffers are read through the pointers they had at capture:
+    optimisers that update in place are fine; after prune / grow (new buffers) build a new CapturedTrainStep.  Outputs and gradients are static
+    tensors overwritten by every replay."""
+
+    def __init__(self, path, aggregator, xyz, emb, conf, pdir, color, sample, near, far, zero_epsilon=1e-3, w_color=1.0, w_zero_one=1e-4,
+                 patch_num=None, patch_size=None, patch_layout="grid", warmup=2):
+        """sample: dict of example input tensors (see the class docstring) that fixes shapes and optional inputs."""
+        self.path, self.agg = path, aggregator
+        self.leaves = (emb, conf, pdir, color)
+        dev = xyz.device
+        req = ("raydir", "campos", "camrot", "bg_color", "c2w_nearest", "campos_nearest", "intrinsic_nearest", "images_nearest", "gt_image")
+        for k in req:
+            if k not in sample:
+                raise HnrError("CapturedTrainStep: sample input %r is missing" % k)
+        st = {k: _lib.require_gpu(v, k).clone() for k, v in sample.items() if isinstance(v, torch.Tensor)}
+        if "w2c_nearest" not in st:
+            st["w2c_nearest"] = torch.inverse(st["c2w_nearest"].reshape(-1, 4, 4)).contiguous()
+        st["frame_weight"] = torch.full((1,), float(sample.get("frame_weight", 1.0) if not isinstance(sample.get("frame_weight"), torch.Tensor) else 1.0),
+                                        dtype=torch.float32, device=dev)
+        self.inputs = st
+        blur = _blur_arg(st.get("blur_kernels"), patch_num, patch_size, patch_layout)
+        cloud = PointCloud(xyz, emb.detach(), conf.detach(), pdir.detach(), color.detach())
+
+        def body():
+            return _queue_step(path, cloud, st["raydir"], st["campos"], st["camrot"], st["bg_color"], near, far, st["c2w_nearest"], st["campos_nearest"],
+                               st["intrinsic_nearest"], st["images_nearest"], st["gt_image"], zero_epsilon, w_color, w_zero_one, None, st.get("tmid"),
+                               st.get("ray_drop"), st.get("frame_weight_nearest"), blur, st["w2c_nearest"], device_frame_weight=st["frame_weight"])
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(max(1, int(warmup))):       # lazy one-time work of the library (kernel attributes, side streams, the grid) happens here, not under capture
+                out, _S, _pg, _ag = body()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        TrainPath.check_status(out)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=side, capture_error_mode="thread_local"):
+            self.out, self.S, self.pg, self.ag = body()
+        self.out["_saved"] = self.S
+
+    def step(self, assign_grads=True, frame_weight=None, **tensors):
+        """Copies the given inputs into the static buffers (device-to-device, no synchronisation), replays the graph, returns (out, pg, ag) --
+        the same static tensors every time."""
+        for k, v in tensors.items():
+            if k not in self.inputs:
+                raise HnrError("CapturedTrainStep.step: %r was not an input at capture (have %s)" % (k, sorted(self.inputs)))
+            self.inputs[k].copy_(v.reshape(self.inputs[k].shape), non_blocking=True)
+        if "c2w_nearest" in tensors and "w2c_nearest" not in tensors:
+            self.inputs["w2c_nearest"].copy_(torch.inverse(self.inputs["c2w_nearest"].reshape(-1, 4, 4)))
+        if frame_weight is not None:
+            self.inputs["frame_weight"].fill_(float(frame_weight))
+        self.graph.replay()
+        if assign_grads:
+            emb, conf, pdir, color = self.leaves
+            _assign_grads(self.agg, emb, conf, pdir, color, self.pg, self.ag, accumulate=False)
+        return self.out, self.pg, self.ag

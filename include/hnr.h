@@ -641,6 +641,12 @@ int64_t hnr_render_train_workspace_bytes(const hnr_train_params *p);
  * Xd H1 X3 H3 H4 E Tu X5 sigma T1 T2 CF X6 vmask M1 M2 M3 X7 Y1 Y2 Y3 fm row_pid vs_item fm_scratch (out[2 i], out[2 i + 1]); returns the number of entries or -1.
  * The training-mode counterpart of reading PointAggregator.viewmlp's locals in a debugger (point_aggregators.py:892-1338). */
 int hnr_render_train_debug_layout(const hnr_train_params *p, int64_t *out, int max_entries);
+/* After hnr_render_train_forward: the batch's touched points inside the workspace -- *d_ids = ascending point ids [*capacity], *d_count = their number
+ * (one int64 on the device, already clamped to the capacity).  The reference has no counterpart (autograd's index_select backward writes dense
+ * [N, C] gradients, neural_points.py:712-720); a rank's gradient exchange (parallel.PointGradExchange) and a sparse optimiser step read it instead of
+ * torch.unique(sample_pidx).  Host pointers only: nothing is launched. */
+int hnr_render_train_touched(const hnr_train_params *p, void *d_workspace, int64_t workspace_bytes, const int32_t **d_ids, const int64_t **d_count,
+                             int64_t *capacity);
 int hnr_render_train_forward(const hnr_grid *grid, const hnr_train_params *p, const hnr_train_cloud *cloud, const hnr_train_weights *weights,
                              const hnr_render_camera *camera, const hnr_train_views *views, const uint8_t *d_drop_lut, const uint8_t *d_ray_drop,
                              void *d_workspace, int64_t workspace_bytes, const hnr_render_outputs *out, void *stream);
@@ -704,6 +710,27 @@ int hnr_shipped_loss(const float *d_color, const float *d_gt, const int8_t *d_ra
 int hnr_shipped_loss_rows(const float *d_color, const float *d_gt, const int8_t *d_ray_mask, int R, const float *d_conf, int conf_per_ray,
                           float zero_epsilon, float w_color, float w_zero_one, float frame_weight, float *d_out4, float *d_g_color,
                           float *d_g_conf, void *d_scratch, void *stream);
+/* ... with the item's frame weight (:1204-1205) read from the device, d_frame_weight[0]: a training step captured in a hipGraph (train.CapturedTrainStep)
+ * is replayed for dataset items with different weights. */
+int hnr_shipped_loss_rows_fw(const float *d_color, const float *d_gt, const int8_t *d_ray_mask, int R, const float *d_conf, int conf_per_ray,
+                             float zero_epsilon, float w_color, float w_zero_one, const float *d_frame_weight, float *d_out4, float *d_g_color,
+                             float *d_g_conf, void *d_scratch, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Multi-GPU training (BASELINE config C5): sparse exchange of the point-buffer gradients of a patch-sharded step.  No reference counterpart
+ * (its DataParallel wrapper runs on gpu_ids[0] only, models/neural_points_volumetric_model.py:161-167; autograd writes dense [N, C] gradients).
+ *   hnr_point_grad_pack   d_ids / d_count: the batch's touched points (hnr_render_train_touched); d_n_valid: this rank's number of valid rays (one
+ *                         float: d_out4[3] of hnr_shipped_loss_rows); the four dense gradients of hnr_render_train_backward.
+ *                         d_rec [capacity + 2][40] floats: row 0 = {records, valid rays, overflow flag}; rows 1..capacity = {point id (int32 bits) |
+ *                         emb 32 | conf | dir 3 | colour 3}, unused slots id -1; row capacity + 1 = point 0 when the batch did not touch it (the empty
+ *                         neighbour slots' d conf_coefficient lands there, neural_points.py:711).
+ *   hnr_point_grad_apply  d_all_rec [n_ranks][capacity + 2][40] (ONE all-gather of the ranks' d_rec): rewrites the dense gradients in place as
+ *                         sum_r (n_r / n) g_r -- the gradient of the loss's mean over ALL ranks' valid rays -- adding the ranks' rows in rank order (the
+ *                         same bits on every rank); only rows some rank touched are written.  d_out2 (optional) = {n, overflow flag of any rank}. */
+int hnr_point_grad_pack(const int32_t *d_ids, const int64_t *d_count, int capacity, const float *d_n_valid, const float *d_g_emb, const float *d_g_conf,
+                        const float *d_g_dir, const float *d_g_color, float *d_rec, void *stream);
+int hnr_point_grad_apply(const float *d_all_rec, int n_ranks, int capacity, float *d_g_emb, float *d_g_conf, float *d_g_dir, float *d_g_color, int n_points,
+                         float *d_out2, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * "Next" row: voxel down-sampling of the initial point cloud, models/mvs/mvs_utils.py:537-563

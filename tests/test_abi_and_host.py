@@ -201,6 +201,56 @@ summed = parallel.allreduce_point_buffers_sparse(sq(bufs), ids4)
 for got, a, b in zip(summed, sq(pb(0)[0]), sq(pb(1)[0])):
     assert got.shape == a.shape and torch.allclose(got, a + b, rtol=0, atol=1e-6)
 assert abs(parallel.loss_scale(hi - lo, 49 * 64) - (hi - lo) / 3136.0) < 1e-12
+# the sync-free form (round 5): fixed-capacity records, counts on the "device", the valid-ray weighting of a global-mean loss, and the empty slots' conf
+# gradient on point 0 although NO rank touched point 0 (round-4 advice)
+def step(r):
+    g = torch.Generator().manual_seed(900 + r)
+    n = 250 + 120 * r
+    ids = (torch.randperm(N - 1, generator=g)[:n] + 1).sort().values.to(torch.int32)       # never point 0
+    if r == 1: ids[0] = 0                                                                  # ... except on rank 1 in the second case below
+    bufs = [torch.zeros(N, 32), torch.zeros(N), torch.zeros(N, 3), torch.zeros(N, 3)]
+    for b in bufs:
+        b[ids.long()] = torch.randn((n,) + tuple(b.shape[1:]), generator=g)
+    return bufs, ids, torch.tensor([float(1400 + 300 * r)])
+for case in (0, 1):
+    bufs, ids, nv = step(rank)
+    if case == 0 and rank == 1:
+        bufs, ids, nv = step(1); bufs = [b.clone() for b in bufs]
+        for b in bufs: b[0] = 0
+        ids = ids.clone(); ids[0] = 1 if 1 not in ids.tolist() else ids[0]; ids = ids.sort().values
+    if case == 0:
+        bufs[1][0] = 0.25 * (rank + 1)                                                      # conf gradient of point 0 from the empty slots, point 0 NOT in ids
+    local = [b.clone() for b in bufs]
+    pad = torch.cat([ids, torch.full((77,), 12345, dtype=torch.int32)])                     # the workspace's list is longer than the count
+    ex = parallel.PointGradExchange(capacity=512)
+    rec = ex.pack(bufs, pad, torch.tensor([ids.numel()]), nv)
+    allr = ex.exchange(rec)
+    tot, over = ex.apply(allr, bufs, rank)
+    assert float(over) == 0 and float(tot) == 1400 + 1700
+    gath = [[torch.empty_like(b) for _ in range(world)] for b in local]
+    for b, gl in zip(local, gath): dist.all_gather(gl, b)
+    for got, gl in zip(bufs, gath):
+        want = gl[0] * (1400.0 / 3100.0) + gl[1] * (1700.0 / 3100.0)
+        assert torch.allclose(got, want, rtol=0, atol=1e-6), (case, float((got - want).abs().max()))
+    if case == 0:
+        assert abs(float(bufs[1][0]) - (0.25 * 1400 + 0.5 * 1700) / 3100) < 1e-6
+    # every rank holds the same bits
+    for b in bufs:
+        gl = [torch.empty_like(b) for _ in range(world)]
+        dist.all_gather(gl, b)
+        assert torch.equal(gl[0], gl[1])
+# overflow is flagged, not silent
+ex = parallel.PointGradExchange(capacity=64)
+bufs, ids, nv = step(rank)
+_, over = ex.apply(ex.exchange(ex.pack(bufs, ids, torch.tensor([ids.numel()]), nv)), bufs, rank)
+assert float(over) == 1
+# the network's gradients: one all-reduce carrying the valid-ray weights
+g = torch.Generator().manual_seed(40 + rank)
+flat = torch.randn(1000 + 64, generator=g); mine = flat[:1000].clone()
+tot = parallel.allreduce_weight_grads(flat, torch.tensor([float(1400 + 300 * rank)]), 1000)
+gl = [torch.empty_like(mine) for _ in range(world)]
+dist.all_gather(gl, mine)
+assert float(tot) == 3100 and torch.allclose(flat[:1000], (gl[0] * 1400 + gl[1] * 1700) / 3100, rtol=0, atol=1e-6)
 if rank == 0:
     print("GRAD_OK")
 dist.barrier()

@@ -370,3 +370,183 @@ def test_point_major_segment_sum_equals_index_add(n_keys, max_rows, n_cols, two)
         rng.shuffle(seg)
     d_b, d2_b, _ = run(shuffled)
     assert torch.equal(d_b, dst) and (not two or torch.equal(d2_b, dst2))
+
+
+def _blur_kernels(dev, n=6, ks=5, seed=5):
+    g = torch.Generator().manual_seed(seed)
+    k = torch.rand((n, ks, ks), generator=g) ** 3
+    return (k / k.sum(dim=(1, 2), keepdim=True)).to(dev)[None]
+
+
+def test_graph_free_step_with_the_blur_module_equals_the_autograd_form():
+    """train_step(blur_kernels=...) = forward -> hnr_blur_select -> loss kernels -> hnr_blur_select_bwd -> backward, queued back to back, against
+    render_train + blur.blur_update_output + losses.shipped_loss + loss.backward() (models/mvs_points_volumetric_model.py:145-146 between the
+    render and compute_losses): same launches, so the gradients agree bit for bit.  Also: the touched-point list the forward call leaves on
+    the device is torch.unique(sample_pidx >= 0)."""
+    from hybridneuralrendering_amd.train import train_step, render_train, TrainPath
+    from hybridneuralrendering_amd.blur import blur_update_output
+    from hybridneuralrendering_amd.losses import shipped_loss
+    d, ti, opt, agg, path = _setup()
+    dev = ti["emb"].device
+    near, far = d["near_far"]
+    tmid = torch.from_numpy(d["tmid"]).to(dev)
+    gt = torch.from_numpy(d["gt"][0]).to(dev)
+    pn, ps = (int(x) for x in d["opt"]["dilation_setup"].split("_")[:2])
+    assert pn * ps * pn * ps == gt.shape[0]
+    kern = _blur_kernels(dev)
+    args = (ti["raydir"][0], ti["campos"][0], ti["camrotc2w"][0], ti["bg_color"][0], near, far, ti["c2w_nearest"][0], ti["campos_nearest"][0],
+            ti["intrinsic_nearest"][0], ti["images_nearest"][0])
+    # autograd form
+    emb, conf, pdir, color = _leaves(ti)
+    agg.zero_grad(set_to_none=True)
+    o = render_train(path, agg, ti["xyz"], emb, conf, pdir, color, *args, tmid=tmid)
+    col = blur_update_output(o["coarse_raycolor"][None], gt[None], kern, pn, ps)[0]
+    loss, parts = shipped_loss(col, o["conf_coefficient"], gt, o["ray_mask"], float(d["zero_epsilon"]), 1.0, 1e-4, frame_weight=0.7, conf_rows=True)
+    loss.backward()
+    ref = dict(emb=emb.grad.clone(), conf=conf.grad.clone(), pdir=pdir.grad.clone(), color=color.grad.clone())
+    refw = {n: q.grad.clone() for n, q in agg.named_parameters() if q.grad is not None}
+    # graph-free form
+    emb2, conf2, pdir2, color2 = _leaves(ti)
+    agg.zero_grad(set_to_none=True)
+    out, pg, ag = train_step(path, agg, ti["xyz"], emb2, conf2, pdir2, color2, *args, gt, zero_epsilon=float(d["zero_epsilon"]), w_color=1.0, w_zero_one=1e-4,
+                             frame_weight=0.7, tmid=tmid, blur_kernels=kern, patch_num=pn, patch_size=ps)
+    assert torch.equal(out["loss"], parts)
+    assert torch.equal(out["blurred_raycolor"].reshape(col.shape), col.detach())
+    for k, t in (("emb", emb2), ("conf", conf2), ("pdir", pdir2), ("color", color2)):
+        assert torch.equal(t.grad, ref[k]), k
+    for n, q in agg.named_parameters():
+        if n in refw:
+            # (a few narrow weight gradients -- alpha branch, final colour, the 64 -> 1 merge-weight layer, the conv pyramid -- are float-atomic sums:
+            # equal up to the order of their additions; every other gradient is a fixed-order sum)
+            sc = float(refw[n].abs().max())
+            assert float((q.grad - refw[n]).abs().max()) <= 2e-6 * max(sc, 1e-30), n
+    # the blur module really changed the colours (some patch selected a non-identity kernel)
+    assert not torch.equal(out["blurred_raycolor"], out["coarse_raycolor"])
+    ids, cnt = TrainPath.touched_points(out["_saved"])
+    n = int(cnt.item())
+    want = torch.unique(out["sample_pidx"][out["sample_pidx"] >= 0])
+    assert n == want.numel() and torch.equal(ids[:n].long(), want.long())
+
+
+def test_captured_train_step_replays_bit_identically_and_follows_its_inputs():
+    """train.CapturedTrainStep: the step (forward, blur module, loss kernels, backward: ~150 launches on three queues) captured once in a hipGraph;
+    a replay with the same inputs equals the eager train_step bit for bit, a replay with another ray batch / ground truth / frame weight equals the
+    eager step on THOSE inputs (the launch sizes are capacity-fixed and read device counters), and a third replay of the first inputs returns the
+    first bits again."""
+    from hybridneuralrendering_amd.train import train_step, CapturedTrainStep
+    d, ti, opt, agg, path = _setup()
+    dev = ti["emb"].device
+    near, far = d["near_far"]
+    tmid = torch.from_numpy(d["tmid"]).to(dev)
+    gt = torch.from_numpy(d["gt"][0]).to(dev)
+    pn, ps = (int(x) for x in d["opt"]["dilation_setup"].split("_")[:2])
+    kern = _blur_kernels(dev)
+    raydir = ti["raydir"][0]
+    # a second batch: the same rays mirrored in order, another target, another jitter
+    perm = torch.arange(raydir.shape[0] - 1, -1, -1, device=dev)
+    raydir_b, gt_b, tmid_b = raydir[perm].contiguous(), torch.rand_like(gt), tmid[perm].contiguous()
+    emb, conf, pdir, color = _leaves(ti)
+
+    def eager(rd, g, tm, fw):
+        for t in (emb, conf, pdir, color):
+            t.grad = None
+        agg.zero_grad(set_to_none=True)
+        out, pg, ag = train_step(path, agg, ti["xyz"], emb, conf, pdir, color, rd, ti["campos"][0], ti["camrotc2w"][0], ti["bg_color"][0], near, far,
+                                 ti["c2w_nearest"][0], ti["campos_nearest"][0], ti["intrinsic_nearest"][0], ti["images_nearest"][0], g,
+                                 zero_epsilon=float(d["zero_epsilon"]), frame_weight=fw, tmid=tm, blur_kernels=kern, patch_num=pn, patch_size=ps)
+        return (out["loss"].clone(), out["coarse_raycolor"].clone(), {k: v.clone() for k, v in pg.items()}, {k: v.clone() for k, v in ag.items()})
+    ref_a, ref_b = eager(raydir, gt, tmid, 0.7), eager(raydir_b, gt_b, tmid_b, 0.4)
+    sample = dict(raydir=raydir, campos=ti["campos"][0], camrot=ti["camrotc2w"][0], bg_color=ti["bg_color"][0], c2w_nearest=ti["c2w_nearest"][0],
+                  campos_nearest=ti["campos_nearest"][0], intrinsic_nearest=ti["intrinsic_nearest"][0], images_nearest=ti["images_nearest"][0],
+                  gt_image=gt, tmid=tmid, blur_kernels=kern, frame_weight=0.7)
+    cap = CapturedTrainStep(path, agg, ti["xyz"], emb, conf, pdir, color, sample, near, far, zero_epsilon=float(d["zero_epsilon"]),
+                            patch_num=pn, patch_size=ps)
+
+    def same(got, ref, what):
+        out, pg, ag = got
+        assert torch.equal(out["loss"], ref[0]), (what, out["loss"], ref[0])
+        assert torch.equal(out["coarse_raycolor"], ref[1]), what
+        for k in ref[2]:
+            assert torch.equal(pg[k], ref[2][k]), (what, k)
+        for k in ref[3]:
+            sc = float(ref[3][k].abs().max())
+            assert float((ag[k] - ref[3][k]).abs().max()) <= 2e-6 * max(sc, 1e-30), (what, k)      # (float-atomic sums in a few narrow layers)
+    same(cap.step(), ref_a, "replay A")
+    same(cap.step(raydir=raydir_b, gt_image=gt_b, tmid=tmid_b, frame_weight=0.4), ref_b, "replay B")
+    same(cap.step(raydir=raydir, gt_image=gt, tmid=tmid, frame_weight=0.7), ref_a, "replay A again")
+    assert emb.grad is not None and torch.equal(emb.grad.reshape(-1, 32), cap.pg["points_embeding"])
+
+
+def test_captured_train_step_draws_a_fresh_jitter_per_replay():
+    """tmid=None at construction: the jittered depth tables are drawn inside the graph (torch.rand under capture); two replays use different
+    tables (different samples -> different losses), like two eager steps do (query_point_indices_worldcoords.py:87)."""
+    from hybridneuralrendering_amd.train import CapturedTrainStep
+    d, ti, opt, agg, path = _setup()
+    dev = ti["emb"].device
+    near, far = d["near_far"]
+    gt = torch.from_numpy(d["gt"][0]).to(dev)
+    emb, conf, pdir, color = _leaves(ti)
+    sample = dict(raydir=ti["raydir"][0], campos=ti["campos"][0], camrot=ti["camrotc2w"][0], bg_color=ti["bg_color"][0], c2w_nearest=ti["c2w_nearest"][0],
+                  campos_nearest=ti["campos_nearest"][0], intrinsic_nearest=ti["intrinsic_nearest"][0], images_nearest=ti["images_nearest"][0], gt_image=gt)
+    cap = CapturedTrainStep(path, agg, ti["xyz"], emb, conf, pdir, color, sample, near, far, zero_epsilon=float(d["zero_epsilon"]))
+    l1 = cap.step()[0]["loss"].clone()
+    l2 = cap.step()[0]["loss"].clone()
+    assert torch.isfinite(l1).all() and torch.isfinite(l2).all() and not torch.equal(l1, l2)
+    assert abs(float(l1[0]) - float(l2[0])) < 0.05 * abs(float(l1[0]))
+
+
+def test_point_gradient_exchange_kernels_equal_the_torch_form():
+    """parallel.PointGradExchange on the GPU: hnr_point_grad_pack / hnr_point_grad_apply (csrc/exchange.hip) against the torch-op form of the same
+    class (what the gloo tests run on CPU tensors), bit for bit, on three ranks' records stacked by hand: overlapping touched sets, point 0 touched by
+    one rank, reached only through the empty slots' conf gradient on another, and absent on the third; unequal valid-ray counts; an overflowing rank."""
+    import os
+    from hybridneuralrendering_amd import parallel
+    dev = torch.device("cuda:0")
+    N, cap = 20000, 700
+    g = torch.Generator().manual_seed(3)
+
+    def rank_data(r):
+        n = (300, 650, 120)[r]
+        ids = (torch.randperm(N - 1, generator=g)[:n] + 1).sort().values.to(torch.int32)
+        if r == 0:
+            ids[0] = 0
+        bufs = [torch.zeros(N, 32), torch.zeros(N), torch.zeros(N, 3), torch.zeros(N, 3)]
+        for b in bufs:
+            b[ids.long()] = torch.randn((n,) + tuple(b.shape[1:]), generator=g)
+        if r == 1:
+            bufs[1][0] = 0.375                     # the empty slots' conf gradient on point 0, which this rank did not touch
+        pad = torch.cat([ids, torch.full((50,), 7, dtype=torch.int32)])
+        return [b.to(dev) for b in bufs], pad.to(dev), torch.tensor([n], dtype=torch.int64, device=dev), torch.tensor([float(900 + 411 * r)], device=dev)
+    data = [rank_data(r) for r in range(3)]
+    ex = parallel.PointGradExchange(cap)
+    recs_hip = [ex.pack(b, i, c, nv) for b, i, c, nv in data]
+    os.environ["HNR_EXCHANGE_TORCH"] = "1"
+    try:
+        recs_t = [ex.pack(b, i, c, nv) for b, i, c, nv in data]
+        for a, b in zip(recs_hip, recs_t):
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+        allr = torch.stack(recs_t).contiguous()
+        want = []
+        for r in range(3):
+            bufs = [b.clone() for b in data[r][0]]
+            tot, over = ex.apply(allr, bufs, r)
+            want.append(bufs)
+        assert float(tot) == 900 * 3 + 411 * 3 and float(over) == 0
+    finally:
+        del os.environ["HNR_EXCHANGE_TORCH"]
+    for r in range(3):
+        bufs = [b.clone() for b in data[r][0]]
+        tot, over = ex.apply(allr, bufs, r)
+        assert float(tot) == 900 * 3 + 411 * 3 and float(over) == 0
+        for a, b, w0 in zip(bufs, want[r], want[0]):
+            assert torch.equal(a, b) and torch.equal(a, w0)           # HIP == torch, and every rank holds the same bits
+    # the weighted sum itself, against a dense fp64 evaluation
+    n = [900.0, 1311.0, 1722.0]
+    for k in range(4):
+        dense = sum(data[r][0][k].double() * (n[r] / sum(n)) for r in range(3))
+        assert float((want[0][k].double() - dense).abs().max()) < 1e-6
+    assert abs(float(want[0][1][0]) - 0.375 * n[1] / sum(n) - float(data[0][0][1][0]) * n[0] / sum(n)) < 1e-6
+    # an overflowing rank is flagged by both forms
+    small = parallel.PointGradExchange(256)
+    rec = small.pack(*data[1])
+    assert float(rec[0, 2]) == 1.0 and float(rec[0, 0]) == 256.0
