@@ -725,7 +725,8 @@ def main():
         if lin:
             n = sum(v["launches"] for v in lin.values())
             t_lin = dict(hbm_bytes=sum(v["hbm_bytes"] * v["launches"] for v in lin.values()) / max(n, 1))
-        knn_name = "knn3_kernel<8, %d>" % (1 if rnd.knn_order == "sorted" else 0)
+        # (round 5: the k-NN over the grid's 3x3x3 neighbourhood lists -- knn_quad_kernel for the set-exact order, knn_nb_kernel<8,0,1> for the reference order)
+        knn_name = "knn_quad_kernel" if rnd.knn_order == "sorted" else "knn_nb_kernel<8, 0"
         t_q = [v for k, v in pmc.items() if "march_kernel" in k or knn_name in k]
         if counts is not None:
             n_rows, n_valid = int(counts[CNT["NEIGHBOURS"]]), int(counts[CNT["SAMPLES_VALID"]])
@@ -792,7 +793,7 @@ def main():
             ms_q = stage_ms.get("query", 0.0)
             if ms_q > 0:
                 ach = alg / (ms_q * 1e-3) / 1e9
-                roof_q = dict(kernel="hnr_march_query: march_kernel + worklist scans + knn3_kernel<8>", bound="hbm", achieved=round(ach, 1),
+                roof_q = dict(kernel="hnr_march_query: march_kernel + worklist scans + k-NN over the neighbourhood lists", bound="hbm", achieved=round(ach, 1),
                               peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
                               traffic=int(sum(v["hbm_bytes"] for v in t_q)) if len(t_q) == 2 else None,
                               traffic_source=("profiles/%s (march_kernel + knn kernel, bytes per launch)" % TRAFFIC_JSON) if len(t_q) == 2 else None,
@@ -824,14 +825,15 @@ def main():
                                   avg_launch_ms=round(ms_o[fo], 4), in_frame_ms=round(ms_q, 4),
                                   neighbour_order=("sorted: the reference's neighbour sets in ascending (d2, enumeration) order (hnr_query_params.knn_order = 1)"
                                                    if fo else "reference: slot for slot the reference's insertion history"),
-                                  kernel="hnr_march_query: march_kernel + worklist scans + knn3_kernel<8,%d>" % fo,
+                                  kernel="hnr_march_query: march_kernel + worklist scans + %s (k-NN over the grid's 3x3x3 neighbourhood lists)" % (
+                                      "knn_quad_kernel" if fo else "knn_nb_kernel<8,0,1>"),
                                   timing="HIP events around 5 back-to-back hnr_march_query launches on the bench frame (in the frame the query overlaps the "
                                          "feature-pyramid rebuild on a side stream: in_frame_ms)")
                     roof_q["sorted_neighbour_order"] = dict(avg_launch_ms=round(ms_o[1], 4), reference_order_ms_same_loop=round(ms_o[0], 4),
                                                             achieved=round(alg / (ms_o[1] * 1e-3) / 1e9, 1), frac=round(alg / (ms_o[1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                                            note="hnr_query_params.knn_order = 1: sorted insertion (v_med3 network) instead of the replay of the reference's "
-                                                                 "farthest-first replacement; same sets, canonical order; VALU wave-instructions per launch of the k-NN kernel "
-                                                                 "in profiles/README.md")
+                                                            note="hnr_query_params.knn_order = 1: the reference's neighbour sets in ascending (d2, enumeration) order, a quad of lanes per "
+                                                                 "sample with the sorted list spread over the quad (csrc/query.hip knn_quad_kernel); reference order: one lane per sample "
+                                                                 "replaying the reference's farthest-first replacement; counters in profiles/r05_query_pmc.txt")
         # one-off work that is amortised over frames (rebuilt only when the cloud / the weights change), timed once here
         amort = {}
         def _timed(fn):

@@ -14,6 +14,7 @@
 // max_o in first-appearance order are dropped; the voxel that would own slot 0 (the voxel of the
 // first in-bounds point) keeps its occupancy but never lists points (`voxel_idx > 0`, :366).
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
@@ -259,6 +260,64 @@ __global__ void count_listed_kernel(const uint32_t *__restrict__ keys, int n, un
     if ((threadIdx.x & 63) == 0 && b) atomicAdd(out, (unsigned long long)__popcll(b));
 }
 
+// ---------------------------------------------------------------------------------- 3x3x3 neighbourhood lists (GridView::nb_*)
+// One wave per brick of the dilated mask, lane = cell.  The 27 cells in the reference's order: x-major, then y, then z, the own cell pulled to the front
+// (layer 0 before layer 1, query_point_indices_worldcoords.py:478-491); cells outside the grid or without points contribute nothing.
+__device__ __forceinline__ bool nb_cell(const GridView &g, int vx, int vy, int vz, int2 &rg)
+{
+    if (!in_bounds(g, vx, vy, vz)) return false;
+    const uint4 rec = g.occ_rec[brick_word(g, vx, vy, vz)];
+    const unsigned long long bb = (unsigned long long)rec.x | ((unsigned long long)rec.y << 32);
+    const int b = brick_bit(vx, vy, vz);
+    if (!((bb >> b) & 1ull)) return false;
+    rg = g.cell_rng[rec.z + (uint32_t)__popcll(bb & ((1ull << b) - 1ull))];
+    return true;
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void nb_lists_kernel(GridView g, const unsigned long long *__restrict__ dil, const uint32_t *__restrict__ dprefix, uint32_t n_words,
+                                                       const uint32_t *__restrict__ nb_start, uint32_t *__restrict__ nb_cnt, uint2 *__restrict__ nb_rng,
+                                                       float4 *__restrict__ nb_pts)
+{
+    const uint32_t w = (uint32_t)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (w >= n_words) return;
+    const unsigned long long bb = dil[w];
+    const int b = threadIdx.x & 63;
+    if (!((bb >> b) & 1ull)) return;
+    const int wz = (int)(w % (uint32_t)g.bz), wy = (int)((w / (uint32_t)g.bz) % (uint32_t)g.by), wx = (int)(w / ((uint32_t)g.bz * (uint32_t)g.by));
+    const int x = wx * 4 + (b >> 4), y = wy * 4 + ((b >> 2) & 3), z = wz * 4 + (b & 3);
+    const uint32_t slot = dprefix[w] + (uint32_t)__popcll(bb & ((1ull << b) - 1ull));
+    uint32_t c0 = 0, total = 0, cells1 = 0, cell0 = 0;
+    uint32_t out = FILL ? nb_start[slot] : 0u;
+    int2 rg;
+    if (nb_cell(g, x, y, z, rg)) {
+        cell0 = 1; c0 = (uint32_t)rg.y; total = c0;
+        if (FILL) for (int j = 0; j < rg.y; ++j) nb_pts[out++] = g.pts[rg.x + j];
+    }
+    // layout of a run (entries of 16 B): [own cell: c0 entries, padded to a multiple of 4][shell 1: total - c0 entries, padded to a multiple of 4] -- every
+    // run and both of its parts start on a 64-byte line, so the four lanes of a quad that read four consecutive candidates touch ONE line (knn_quad_kernel)
+    const uint32_t c0p = (c0 + 3u) & ~3u;
+    if (FILL) out = nb_start[slot] + c0p;
+    for (int dx = -1; dx <= 1; ++dx)
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dz = -1; dz <= 1; ++dz) {
+                if (dx == 0 && dy == 0 && dz == 0) continue;
+                if (!nb_cell(g, x + dx, y + dy, z + dz, rg)) continue;
+                ++cells1; total += (uint32_t)rg.y;
+                if (FILL) for (int j = 0; j < rg.y; ++j) nb_pts[out++] = g.pts[rg.x + j];
+            }
+    if (FILL) nb_rng[slot] = make_uint2(nb_start[slot], c0 | (total << 6) | (cells1 << 17) | (cell0 << 22));
+    else nb_cnt[slot] = c0p + ((total - c0 + 3u) & ~3u);
+}
+
+__global__ void pack_dil_rec_kernel(const unsigned long long *__restrict__ dil, const uint32_t *__restrict__ dprefix, uint32_t n_words, uint4 *rec)
+{
+    uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_words) return;
+    unsigned long long b = dil[w];
+    rec[w] = make_uint4((uint32_t)b, (uint32_t)(b >> 32), dprefix[w], 0u);
+}
+
 // ---------------------------------------------------------------------------------- host
 template <typename T>
 struct DevBuf {
@@ -397,6 +456,44 @@ static int build_impl(hnr_grid *g, const float *d_xyz, int n, hipStream_t st)
     g->dil = dil.release();
     g->cell_rng = cell_rng.release();
     g->pts = pts.release();
+    // ---- 3x3x3 neighbourhood lists for the k-NN (hnr_common.h, GridView::nb_*): count, scan, fill.  Needs P <= 63 (the packed record) and the lists to
+    //      fit 32-bit indices; HNR_NB_LISTS=0 skips them (the k-NN then walks the 27 cells itself: knn3_kernel).
+    int64_t nb_bytes = 0;
+    {
+        const char *e = getenv("HNR_NB_LISTS");
+        const int64_t n_dil = (int64_t)h_scal[2];
+        if (!(e && atoi(e) == 0) && p->P <= 63 && n_dil > 0 && n_listed > 0 && 27ll * n_listed + 8ll * n_dil < (1ll << 31)) {
+            DevBuf<uint32_t> dcnt, dprefix, nb_cnt, nb_start;
+            DevBuf<uint4> drec;
+            DevBuf<uint2> nbr;
+            DevBuf<float4> nbp;
+            DevBuf<char> tmp2;
+            GB_CHECK(dcnt.alloc(n_words)); GB_CHECK(dprefix.alloc(n_words));
+            GB_CHECK(nb_cnt.alloc(n_dil + 1)); GB_CHECK(nb_start.alloc(n_dil + 1));
+            GB_CHECK(drec.alloc(n_words)); GB_CHECK(nbr.alloc(n_dil));
+            size_t t1 = 0, t2 = 0;
+            GB_CHECK(rocprim::exclusive_scan(nullptr, t1, dcnt.p, dprefix.p, 0u, (size_t)n_words, rocprim::plus<uint32_t>(), st));
+            GB_CHECK(rocprim::exclusive_scan(nullptr, t2, nb_cnt.p, nb_start.p, 0u, (size_t)n_dil + 1, rocprim::plus<uint32_t>(), st));
+            GB_CHECK(tmp2.alloc(t1 > t2 ? t1 : t2));
+            popc_kernel<<<cdiv(n_words, TB), TB, 0, st>>>(g->dil, n_words, dcnt.p);
+            { size_t sz = t1; GB_CHECK(rocprim::exclusive_scan((void *)tmp2.p, sz, dcnt.p, dprefix.p, 0u, (size_t)n_words, rocprim::plus<uint32_t>(), st)); }
+            GB_CHECK(hipMemsetAsync(nb_cnt.p, 0, (size_t)(n_dil + 1) * 4, st));
+            const GridView v2 = g->view();                                  // (occ_rec, cell_rng, pts are in place; the nb_* pointers still null)
+            const int nb_blocks = cdiv((int64_t)n_words * 64, 256);
+            nb_lists_kernel<false><<<nb_blocks, 256, 0, st>>>(v2, g->dil, dprefix.p, n_words, nullptr, nb_cnt.p, nullptr, nullptr);
+            { size_t sz = t2; GB_CHECK(rocprim::exclusive_scan((void *)tmp2.p, sz, nb_cnt.p, nb_start.p, 0u, (size_t)n_dil + 1, rocprim::plus<uint32_t>(), st)); }
+            uint32_t nb_total = 0;
+            GB_CHECK(hipMemcpyAsync(&nb_total, nb_start.p + n_dil, 4, hipMemcpyDeviceToHost, st));
+            GB_CHECK(hipStreamSynchronize(st));
+            GB_CHECK(nbp.alloc((size_t)nb_total + 1));
+            nb_lists_kernel<true><<<nb_blocks, 256, 0, st>>>(v2, g->dil, dprefix.p, n_words, nb_start.p, nullptr, nbr.p, nbp.p);
+            pack_dil_rec_kernel<<<cdiv(n_words, TB), TB, 0, st>>>(g->dil, dprefix.p, n_words, drec.p);
+            GB_CHECK(hipGetLastError());
+            GB_CHECK(hipStreamSynchronize(st));                             // (the scratch buffers above die with this scope)
+            g->dil_rec = drec.release(); g->nb_rng = nbr.release(); g->nb_pts = nbp.release();
+            nb_bytes = (int64_t)n_words * 16 + n_dil * 8 + ((int64_t)nb_total + 1) * 16;
+        }
+    }
     g->st.n_points = n;
     g->st.n_inbounds = (int64_t)h_scal[0];
     g->st.n_occ = n_occ;
@@ -404,7 +501,7 @@ static int build_impl(hnr_grid *g, const float *d_xyz, int n, hipStream_t st)
     g->st.n_cells_over_P = (int64_t)h_scal[1];
     g->st.n_dilated = (int64_t)h_scal[2];
     g->st.n_words = n_words;
-    g->st.bytes = (int64_t)n_words * (16 + 8) + (int64_t)n_occ * 8 + (int64_t)n_listed * 16;
+    g->st.bytes = (int64_t)n_words * (16 + 8) + (int64_t)n_occ * 8 + (int64_t)n_listed * 16 + nb_bytes;
     return HNR_OK;
 }
 
@@ -433,6 +530,9 @@ extern "C" int hnr_grid_free(hnr_grid *g)
     if (g->dil) (void)hipFree(g->dil);
     if (g->cell_rng) (void)hipFree(g->cell_rng);
     if (g->pts) (void)hipFree(g->pts);
+    if (g->dil_rec) (void)hipFree(g->dil_rec);
+    if (g->nb_rng) (void)hipFree(g->nb_rng);
+    if (g->nb_pts) (void)hipFree(g->nb_pts);
     delete g;
     return HNR_OK;
 }
@@ -460,6 +560,10 @@ extern "C" int hnr_grid_build(const float *d_xyz, int n, const hnr_grid_params *
     for (int a = 0; a < 3; ++a)
         if (p->dims[a] <= 0 || !(p->cell[a] > 0.0f) || p->query_size[a] < 0) {
             set_error("hnr_grid_build: dims/cell must be positive, query_size non-negative"); return HNR_ERR_BADARG;
+        }
+    for (int a = 0; a < 3; ++a)
+        if (p->dims[a] >= (1 << 24)) {          // (the march tests cell indices as floats: exact below 2^24)
+            set_error("hnr_grid_build: grid of %d x %d x %d cells is too large", p->dims[0], p->dims[1], p->dims[2]); return HNR_ERR_TOOBIG;
         }
     int bd[3];
     for (int a = 0; a < 3; ++a) bd[a] = (p->dims[a] + 3) / 4;

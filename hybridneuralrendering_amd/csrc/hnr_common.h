@@ -41,6 +41,16 @@ struct GridView {
     const unsigned long long *dil;
     const int2 *cell_rng;
     const float4 *pts;
+    // 3x3x3 NEIGHBOURHOOD LISTS (round 5; built when P <= 63, NULL otherwise): for every cell of the dilated mask -- every cell a kept shading sample
+    // can sit in -- the candidates of its 27-cell neighbourhood as ONE contiguous run in the reference's enumeration order (own cell first = shell 0,
+    // then the other cells x-major / y / z = shell 1; query_point_indices_worldcoords.py:478-491), so the k-NN makes 2 dependent lookups per sample
+    // instead of 27 x 2 and streams its candidates from consecutive addresses.  16 B x 27 x listed points: 0.86 GB at 2 M points -- HBM is what this GPU has.
+    //   dil_rec[w]   = {dilated bits lo, hi, number of dilated cells before brick w, 0}
+    //   run layout  = [own cell: c0 entries, padded to a multiple of 4][the other cells: padded to a multiple of 4]: both parts start on a 64-byte line
+    //   nb_rng[slot] = {first index into nb_pts, own-cell candidates (6 bits) | all candidates << 6 (11 bits) | occupied shell-1 cells << 17 (5 bits) | own cell occupied << 22}
+    const uint4 *dil_rec;
+    const uint2 *nb_rng;
+    const float4 *nb_pts;
 };
 
 // floor((p - shift) / size) with fp32 subtract and IEEE fp32 divide, exactly as the reference
@@ -203,6 +213,9 @@ struct hnr_grid {
     unsigned long long *dil;
     int2 *cell_rng;
     float4 *pts;
+    uint4 *dil_rec;
+    uint2 *nb_rng;
+    float4 *nb_pts;
     hnr::GridView view() const
     {
         hnr::GridView v;
@@ -211,6 +224,7 @@ struct hnr_grid {
         v.dx = p.dims[0]; v.dy = p.dims[1]; v.dz = p.dims[2];
         v.by = bd[1]; v.bz = bd[2];
         v.occ_rec = occ_rec; v.dil = dil; v.cell_rng = cell_rng; v.pts = pts;
+        v.dil_rec = dil_rec; v.nb_rng = nb_rng; v.nb_pts = nb_pts;
         return v;
     }
 };

@@ -19,57 +19,128 @@
 namespace hnr {
 
 // ------------------------------------------------------------------------------------------------
-// March: one wavefront per ray.  64 lanes test 64 consecutive depth samples per step; the ballot of
-// occupied samples gives every hit its output slot; stops as soon as SR samples are kept.
+// March: a wavefront per ray, 64 lanes test 64 consecutive depths per block; the ballot of occupied samples gives every hit its output slot; the
+// first SR hits are kept.  Round 5: what bounded this kernel was neither its instructions (halving them changed nothing) nor its bytes but the life of
+// 285 200 short waves -- launch, one round trip for the ray, one per block of depths for the table and one for the mask words, 4 - 7 blocks in a row,
+// 24 - 32 waves per CU (0.21 ms per frame; 0.16 ms with every block skipped).  Now: PERSISTENT waves loop over rays; the depth table is loaded once per
+// wave when all rays share it (no jitter); the next ray's direction is requested while the current ray is worked on; all blocks of a ray are probed
+// together (all mask-word requests in flight at once: one round trip per ray); blocks that lie outside the grid's box are skipped by a slab test.
 __global__ __launch_bounds__(256) void march_kernel(GridView g, const float *__restrict__ campos,
                                                     const float *__restrict__ raydir,
                                                     const float *__restrict__ tmid, int R, int D, int SR, int K,
                                                     int tmid_stride, int pad, int32_t *__restrict__ pidx,
                                                     float *__restrict__ loc, int32_t *__restrict__ ray_nsamp,
-                                                    int8_t *__restrict__ ray_mask)
+                                                    int8_t *__restrict__ ray_mask, int probe_mode)
 {
     const int lane = threadIdx.x & 63;
-    const int r = (int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6);
-    if (r >= R) return;
+    const int wave0 = (int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6), n_waves = (int)((gridDim.x * (unsigned)blockDim.x) >> 6);
+    if (wave0 >= R) return;
     const float px = campos[0], py = campos[1], pz = campos[2];
-    const float dx = raydir[3 * (size_t)r], dy = raydir[3 * (size_t)r + 1], dz = raydir[3 * (size_t)r + 2];
-    const float *tt = tmid + (size_t)r * tmid_stride;
-    float *loc_r = loc + (size_t)r * SR * 3;
-
-    int base = 0;
-    for (int d0 = 0; d0 < D; d0 += 64) {
-        const int d = d0 + lane;
-        bool occ = false;
-        float sx = 0.f, sy = 0.f, sz = 0.f;
-        if (d < D) {
-            const float t = tt[d];
+    const float fdx = (float)g.dx, fdy = (float)g.dy, fdz = (float)g.dz;
+    // the grid's box widened by ONE CELL on every side: the widening covers the rounding of the slab test against the exact per-sample arithmetic by
+    // orders of magnitude (a cell is ~1e4 ulps of a coordinate)
+    const float blo[3] = {g.ox - g.cx, g.oy - g.cy, g.oz - g.cz};
+    const float bhi[3] = {g.ox + (float)(g.dx + 1) * g.cx, g.oy + (float)(g.dy + 1) * g.cy, g.oz + (float)(g.dz + 1) * g.cz};
+    const int nblk = (D + 63) >> 6;
+    const bool fast = D <= 512 && !(probe_mode & 2);           // HNR_MARCH_PROBE=2 (tools): block after block with an early exit instead (fewer instructions, 3 % slower)
+    float tv[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const int d = 64 * k + lane; tv[k] = (fast && tmid_stride == 0 && k < nblk && d < D) ? tmid[d] : NAN; }
+    float ndx = raydir[3 * (size_t)wave0], ndy = raydir[3 * (size_t)wave0 + 1], ndz = raydir[3 * (size_t)wave0 + 2];
+    for (int r = wave0; r < R; r += n_waves) {
+        const float dx = ndx, dy = ndy, dz = ndz;
+        {
+            const int rn = r + n_waves < R ? r + n_waves : r;    // the next ray's direction: in flight across this ray's work
+            ndx = raydir[3 * (size_t)rn]; ndy = raydir[3 * (size_t)rn + 1]; ndz = raydir[3 * (size_t)rn + 2];
+        }
+        const float *tt = tmid + (size_t)r * tmid_stride;
+        float *loc_r = loc + (size_t)r * SR * 3;
+        if (fast && tmid_stride != 0) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const int d = 64 * k + lane; tv[k] = (k < nblk && d < D) ? tt[d] : NAN; }
+        }
+        // the part of the ray that can be inside the grid at all
+        float t_in = -INFINITY, t_out = INFINITY;
+        {
+            const float pp[3] = {px, py, pz}, dd[3] = {dx, dy, dz};
+            bool ok = true;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                if (dd[a] != 0.f) {
+                    const float inv = __builtin_amdgcn_rcpf(dd[a]);
+                    const float ta = (blo[a] - pp[a]) * inv, tb = (bhi[a] - pp[a]) * inv;
+                    ok = ok && ta == ta && tb == tb;
+                    const float t0 = fminf(ta, tb), t1 = fmaxf(ta, tb);
+                    // (rcp is an approximation, ~1 ulp: relative slack on top of the one-cell widening)
+                    t_in = fmaxf(t_in, t0 - 1e-5f * fabsf(t0)); t_out = fminf(t_out, t1 + 1e-5f * fabsf(t1));
+                } else if (!(pp[a] >= blo[a] && pp[a] <= bhi[a])) {
+                    if (pp[a] == pp[a]) { t_in = INFINITY; t_out = -INFINITY; } else ok = false;
+                }
+            }
+            if (!ok || !(dx == dx && dy == dy && dz == dz)) { t_in = -INFINITY; t_out = INFINITY; }
+        }
+        if (probe_mode == 1) { t_in = INFINITY; t_out = -INFINITY; }    // tools: every block skipped (the kernel's fixed part alone; results are empty)
+        // one lane, one depth: position (fp32 multiply, then add, like the reference), cell, and the REQUEST for the cell's word of the dilated mask
+        auto probe = [&](float t, float &sx, float &sy, float &sz, unsigned long long &word, int &bit) -> bool {
             sx = __fadd_rn(px, __fmul_rn(dx, t));
             sy = __fadd_rn(py, __fmul_rn(dy, t));
             sz = __fadd_rn(pz, __fmul_rn(dz, t));
-            const int cx = cell_coord(sx, g.ox, g.cx), cy = cell_coord(sy, g.oy, g.cy), cz = cell_coord(sz, g.oz, g.cz);
-            if (in_bounds(g, cx, cy, cz))
-                occ = (g.dil[brick_word(g, cx, cy, cz)] >> brick_bit(cx, cy, cz)) & 1ull;
-        }
-        const unsigned long long b = __ballot(occ);
-        if (occ) {
-            const int slot = base + __popcll(b & ((1ull << lane) - 1ull));
-            if (slot < SR) {
-                loc_r[3 * slot] = sx; loc_r[3 * slot + 1] = sy; loc_r[3 * slot + 2] = sz;
+            // cell = floor((s - o) / c) is inside [0, dims) iff the quotient is in [0, dims) (dims < 2^24: exact as floats; NaN and the out-of-range
+            // quotients cell_coord maps to INT_MIN fail the compares), and then truncation IS the floor
+            const float qx = hnr_div_cell(__fsub_rn(sx, g.ox), g.cx), qy = hnr_div_cell(__fsub_rn(sy, g.oy), g.cy), qz = hnr_div_cell(__fsub_rn(sz, g.oz), g.cz);
+            const bool in = t >= t_in && t <= t_out && qx >= 0.f && qx < fdx && qy >= 0.f && qy < fdy && qz >= 0.f && qz < fdz;
+            const int cx = in ? (int)qx : 0, cy = in ? (int)qy : 0, cz = in ? (int)qz : 0;
+            word = g.dil[brick_word(g, cx, cy, cz)];             // unconditional (cell 0 for the lanes outside): the load carries no branch
+            bit = brick_bit(cx, cy, cz);
+            return in;
+        };
+        int base = 0;
+        auto keep = [&](bool occ, float sx, float sy, float sz) {
+            const unsigned long long b = __ballot(occ);
+            if (occ) {
+                const int slot = base + __popcll(b & ((1ull << lane) - 1ull));
+                if (slot < SR) { loc_r[3 * slot] = sx; loc_r[3 * slot + 1] = sy; loc_r[3 * slot + 2] = sz; }
+            }
+            base += __popcll(b);
+        };
+        if (fast) {
+            // (the blocks behind the one that fills the SR-th slot are probed for nothing; their loads are in flight anyway)
+            float sx[8], sy[8], sz[8];
+            unsigned long long wd[8];
+            int bt[8];
+            bool in[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                in[k] = false; wd[k] = 0ull; bt[k] = 0; sx[k] = sy[k] = sz[k] = 0.f;
+                if (k < nblk && __builtin_amdgcn_ballot_w64(tv[k] >= t_in && tv[k] <= t_out) != 0ull) in[k] = probe(tv[k], sx[k], sy[k], sz[k], wd[k], bt[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (k < nblk && base < SR) keep(in[k] && ((wd[k] >> bt[k]) & 1ull), sx[k], sy[k], sz[k]);
+        } else {
+            for (int d0 = 0; d0 < D; d0 += 64) {
+                const int d = d0 + lane;
+                const float t = d < D ? tt[d] : NAN;
+                if (__builtin_amdgcn_ballot_w64(t >= t_in && t <= t_out) == 0ull) continue;     // (a NaN depth passes no test here and none below)
+                float sx, sy, sz;
+                unsigned long long word;
+                int bit;
+                const bool in = probe(t, sx, sy, sz, word, bit);
+                keep(in && ((word >> bit) & 1ull), sx, sy, sz);
+                if (base >= SR) break;
             }
         }
-        base += __popcll(b);
-        if (base >= SR) break;
-    }
-    const int ns = base < SR ? base : SR;
-    if (pad) {
-        // pad: sample_loc zeros (torch.zeros, :647), sample_pidx -1 (torch.full, :648); kept slots are written by the k-NN
-        for (int i = ns * 3 + lane; i < SR * 3; i += 64) loc_r[i] = 0.f;
-        int32_t *pidx_r = pidx + (size_t)r * SR * K;
-        for (int i = ns * K + lane; i < SR * K; i += 64) pidx_r[i] = -1;
-    }
-    if (lane == 0) {
-        ray_nsamp[r] = ns;
-        ray_mask[r] = 0;
+        const int ns = base < SR ? base : SR;
+        if (pad) {
+            // pad: sample_loc zeros (torch.zeros, :647), sample_pidx -1 (torch.full, :648); kept slots are written by the k-NN
+            for (int i = ns * 3 + lane; i < SR * 3; i += 64) loc_r[i] = 0.f;
+            int32_t *pidx_r = pidx + (size_t)r * SR * K;
+            for (int i = ns * K + lane; i < SR * K; i += 64) pidx_r[i] = -1;
+        }
+        if (lane == 0) {
+            ray_nsamp[r] = ns;
+            ray_mask[r] = 0;
+        }
     }
 }
 
@@ -481,6 +552,340 @@ __global__ __launch_bounds__(256) void knn3_kernel(GridView g, const int32_t *__
             s_st[0][threadIdx.x] + s_st[1][threadIdx.x] + s_st[2][threadIdx.x] + s_st[3][threadIdx.x];
 }
 
+// ------------------------------------------------------------------------------------------------
+// k-NN over the 3x3x3 NEIGHBOURHOOD LISTS of the grid (round 5; K = 8, GridView::nb_*): the candidates of a sample's 27 cells are one contiguous
+// run in the reference's enumeration order (own cell first), so pass 1 of knn3_kernel -- 27 brick records + 27 {start, count} records per sample,
+// parked in LDS -- becomes TWO lookups and the 23-instruction address generator becomes a counter (54 instead of 72 instructions per candidate).
+// Same visiting order and the same insertion rules (KBuf slot-exact / KSorted set-exact): bit-identical results (tests/test_query_gpu.py).
+// BIN: one lane per sample is 44 % lane-efficient when the 64 samples of a wave are taken in work-list order (a wave runs as long as its longest
+// candidate list).  With the list length one lookup away, a workgroup takes NB_CHUNK consecutive samples, looks their lists up once, counting-sorts them
+// in LDS by the number of loop trips they need (4 candidates per trip, the two shells separately) and deals them to its lanes in that order: the
+// samples of a wave need the same number of trips up to +-1.  (Round 4 tried the same re-dealing over the 27-cell walk and gained nothing: there the
+// list length cost 54 lookups per sample.)  The order samples are taken in changes nothing a sample computes; the counters are integer sums.
+constexpr int NB_CHUNK = 1024;        // samples sorted per workgroup and round (4 per thread)
+constexpr int NB_BINS = 32;
+template <int K, int SORTED, int BIN>
+__global__ __launch_bounds__(256) void knn_nb_kernel(GridView g, const int32_t *__restrict__ work, const float *__restrict__ loc,
+                                                     int SR, float radius2, int layers, int32_t *__restrict__ pidx, int8_t *__restrict__ ray_mask,
+                                                     const unsigned long long *__restrict__ counts, unsigned long long *__restrict__ block_stats)
+{
+    __shared__ unsigned long long s_st[4][4];
+    __shared__ int32_t s_item[BIN ? NB_CHUNK : 1];
+    __shared__ uint2 s_rg[BIN ? NB_CHUNK : 1];
+    __shared__ int s_hist[NB_BINS], s_base[NB_BINS];
+    const int n = (int)counts[HNR_CNT_SAMPLES];
+    unsigned n_cells = 0, n_cand = 0, n_nb = 0, n_sv = 0;
+    auto lookup = [&](int item) -> uint2 {
+        const float cx = loc[3 * (size_t)item], cy = loc[3 * (size_t)item + 1], cz = loc[3 * (size_t)item + 2];
+        const int fx = cell_coord(cx, g.ox, g.cx), fy = cell_coord(cy, g.oy, g.cy), fz = cell_coord(cz, g.oz, g.cz);
+        // a kept sample sits in a cell of the dilated mask (the march tested that bit); anything else lists nothing
+        const bool inb = in_bounds(g, fx, fy, fz);
+        const uint4 rec = g.dil_rec[inb ? brick_word(g, fx, fy, fz) : 0u];
+        const unsigned long long bb = (unsigned long long)rec.x | ((unsigned long long)rec.y << 32);
+        const int b = inb ? brick_bit(fx, fy, fz) : 0;
+        const bool have = inb && ((bb >> b) & 1ull);
+        const uint2 rg = g.nb_rng[have ? rec.z + (uint32_t)__popcll(bb & ((1ull << b) - 1ull)) : 0u];
+        return have ? rg : make_uint2(0u, 0u);
+    };
+    auto one = [&](int item, uint2 rg) {
+        const float cx = loc[3 * (size_t)item], cy = loc[3 * (size_t)item + 1], cz = loc[3 * (size_t)item + 2];
+        const int start = (int)rg.x;
+        const int c0 = (int)(rg.y & 63u), tot = (int)((rg.y >> 6) & 2047u);
+        typename std::conditional<SORTED != 0, KSorted<K>, KBuf<K>>::type kb;
+        kb.init();
+        auto run = [&](int lo, int hi) {
+            int j = lo;
+            auto gen = [&]() -> int { const int a = j < hi ? j : -1; ++j; return a; };
+            auto consume = [&](const float4 &p, bool ok) {
+                const float xv = __fsub_rn(p.x, cx), yv = __fsub_rn(p.y, cy), zv = __fsub_rn(p.z, cz);
+                const float v = __fadd_rn(__fadd_rn(__fmul_rn(xv, xv), __fmul_rn(yv, yv)), __fmul_rn(zv, zv));
+                kb.offer_sel(v, __float_as_int(p.w), ok && (radius2 == 0.f || v <= radius2));
+            };
+            // unconditional loads (an exhausted lane re-reads record 0): four requests stay in flight across the insertion code
+            int a0 = gen(), a1 = gen(), a2 = gen(), a3 = gen();
+            float4 p0 = g.nb_pts[a0 < 0 ? 0 : a0], p1 = g.nb_pts[a1 < 0 ? 0 : a1], p2 = g.nb_pts[a2 < 0 ? 0 : a2], p3 = g.nb_pts[a3 < 0 ? 0 : a3];
+            if (__builtin_amdgcn_ballot_w64(a0 >= 0) != 0ull) {
+                do {
+                    consume(p0, a0 >= 0); a0 = gen(); p0 = g.nb_pts[a0 < 0 ? 0 : a0];
+                    consume(p1, a1 >= 0); a1 = gen(); p1 = g.nb_pts[a1 < 0 ? 0 : a1];
+                    consume(p2, a2 >= 0); a2 = gen(); p2 = g.nb_pts[a2 < 0 ? 0 : a2];
+                    consume(p3, a3 >= 0); a3 = gen(); p3 = g.nb_pts[a3 < 0 ? 0 : a3];
+                } while (__builtin_amdgcn_ballot_w64(a0 >= 0) != 0ull);
+            }
+        };
+        if (layers > 0) run(start, start + c0);                  // shell 0 = the sample's own cell
+        kb.sync_kid();
+        n_cells += (rg.y >> 22) & 1u;
+        n_cand += (unsigned)c0;
+        if (layers > 1 && kb.kid < K) {                          // reference: `if (kid >= K) break;` after a layer
+            const int s1 = start + ((c0 + 3) & ~3);              // (the own-cell part of a run is padded to a multiple of 4 entries)
+            run(s1, s1 + tot - c0);
+            kb.sync_kid();
+            n_cells += (rg.y >> 17) & 31u;
+            n_cand += (unsigned)(tot - c0);
+        }
+        {
+            int32_t *o = pidx + (size_t)item * K;
+#pragma unroll
+            for (int i = 0; i < K; i += 4)
+                reinterpret_cast<int4 *>(o)[i >> 2] = make_int4(kb.id[i], kb.id[i + 1], kb.id[i + 2], kb.id[i + 3]);
+        }
+        if (kb.kid > 0) {
+            ray_mask[item / SR] = 1;
+            n_nb += (unsigned)(kb.kid < K ? kb.kid : K);
+            ++n_sv;
+        }
+    };
+    if constexpr (BIN != 0) {
+        for (int w0 = blockIdx.x * NB_CHUNK; w0 < n; w0 += gridDim.x * NB_CHUNK) {
+            if (threadIdx.x < NB_BINS) s_hist[threadIdx.x] = 0;
+            __syncthreads();
+            int item[4], key[4], rank[4];
+            uint2 rg[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {                          // (all four lookups in flight)
+                const int w = w0 + q * 256 + (int)threadIdx.x;
+                item[q] = w < n ? work[w] : -1;
+                rg[q] = item[q] >= 0 ? lookup(item[q]) : make_uint2(0u, 0u);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c0 = (int)(rg[q].y & 63u), tot = (int)((rg[q].y >> 6) & 2047u);
+                const int trips = ((c0 + 3) >> 2) + ((tot - c0 + 3) >> 2);
+                key[q] = trips < NB_BINS - 1 ? trips : NB_BINS - 1;
+                rank[q] = item[q] >= 0 ? atomicAdd(&s_hist[key[q]], 1) : 0;
+            }
+            __syncthreads();
+            if (threadIdx.x < 64) {                                // exclusive scan of the 32 bin counts, longest lists first
+                const int t = threadIdx.x;
+                int v = t < NB_BINS ? s_hist[NB_BINS - 1 - t] : 0, inc = v;
+                for (int o = 1; o < NB_BINS; o <<= 1) { const int u = __shfl_up(inc, o); if (t >= o) inc += u; }
+                if (t < NB_BINS) s_base[NB_BINS - 1 - t] = inc - v;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (item[q] >= 0) { const int pos = s_base[key[q]] + rank[q]; s_item[pos] = item[q]; s_rg[pos] = rg[q]; }
+            __syncthreads();
+            const int m = min(NB_CHUNK, n - w0);
+            for (int t = threadIdx.x; t < m; t += 256) one(s_item[t], s_rg[t]);
+            __syncthreads();
+        }
+    } else {
+        for (int w = blockIdx.x * blockDim.x + threadIdx.x; w < n; w += gridDim.x * blockDim.x) {
+            const int item = work[w];
+            one(item, lookup(item));
+        }
+    }
+    unsigned long long t_cells = n_cells, t_cand = n_cand, t_nb = n_nb, t_sv = n_sv;
+    for (int o = 32; o > 0; o >>= 1) {
+        t_cells += __shfl_xor(t_cells, o);
+        t_cand += __shfl_xor(t_cand, o);
+        t_nb += __shfl_xor(t_nb, o);
+        t_sv += __shfl_xor(t_sv, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        const int wv = threadIdx.x >> 6;
+        s_st[wv][0] = t_cells; s_st[wv][1] = t_cand; s_st[wv][2] = t_nb; s_st[wv][3] = t_sv;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4)
+        block_stats[4 * (size_t)blockIdx.x + threadIdx.x] =
+            s_st[0][threadIdx.x] + s_st[1][threadIdx.x] + s_st[2][threadIdx.x] + s_st[3][threadIdx.x];
+}
+
+// ------------------------------------------------------------------------------------------------
+// k-NN over the neighbourhood lists, FOUR LANES PER SAMPLE (set-exact order, K = 8): the production kernel.
+// With the candidates contiguous, knn_nb_kernel (one lane per sample) stopped being bound by its instruction count (111 M VALU wave-instructions per frame
+// against 279 M for the 27-cell walk) and became bound by the texture addresser: every lane reads its own 16-byte record, so a wave's load instruction
+// touches 64 cache lines = 64 address cycles for 1 KiB (SQ_WAIT_INST_ANY 54 % of the wave cycles, rocprofv3 --pmc, profiles/r05_query_pmc.txt).  Here a
+// QUAD owns a sample: its four lanes read four CONSECUTIVE candidates -- one 64-byte line (runs are padded to lines, grid.hip) -- so a wave instruction
+// touches 16 lines for the same 1 KiB; each lane computes one distance, and the four candidates enter the sample's sorted list one after the other, the
+// list itself spread over the quad (lane i holds entries 2 i and 2 i + 1) with the neighbours' entries and the broadcast candidate moving through
+// quad_perm DPP -- 14 instructions per candidate and quad instead of 31 per candidate and lane.  Ascending (d2, enumeration order) exactly as KSorted:
+// a candidate is placed before the entries it is STRICTLY smaller than.
+template <int CTRL>
+__device__ __forceinline__ float quad_f(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true)); }
+template <int CTRL>
+__device__ __forceinline__ int quad_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+
+struct QuadList {
+    float a, b;           // entries 2 q and 2 q + 1 of the quad's ascending list (q = lane & 3)
+    int ia, ib;
+    __device__ __forceinline__ void init() { a = b = __int_as_float(0x7f800000); ia = ib = -1; }
+    // The quad's four candidates (lane s holds value v / id p; +inf = none) enter the list one after the other.  Per candidate, 14 instructions without a
+    // branch (left to itself the compiler turns the selects into exec-masked branches: 135 instructions per trip instead of 75):
+    //   vb, pb = the candidate, broadcast;  L, iL = the entry just below this lane's pair (quad_perm [0,0,1,2]; lane 0: -inf)
+    //   b' = med3(a, b, vb)   ib' = vb < a ? ia : vb < b ? pb : ib        a' = med3(L, a, vb)   ia' = vb < L ? iL : vb < a ? pb : ia
+    // Spacing: a DPP operand must be two instructions old (the assembler does not pad inline asm) -- b / ib are rewritten >= 5 instructions before the next
+    // step reads them through DPP -- and every compare result is >= 2 instructions old when a v_cndmask reads it.
+    __device__ __forceinline__ void insert4(float v, int p, unsigned long long m_first)
+    {
+        float vb, L; int pb, iL;
+        unsigned long long cL, ca, cb;
+        const float ninf = __int_as_float(0xff800000);
+#define HNR_QSTEP(S)                                                                                                   \
+        "v_mov_b32_dpp %[vb], %[v] quad_perm:[" #S "," #S "," #S "," #S "] row_mask:0xf bank_mask:0xf\n\t"                \
+        "v_mov_b32_dpp %[pb], %[p] quad_perm:[" #S "," #S "," #S "," #S "] row_mask:0xf bank_mask:0xf\n\t"                \
+        "v_mov_b32_dpp %[L], %[b] quad_perm:[0,0,1,2] row_mask:0xf bank_mask:0xf\n\t"                                   \
+        "v_mov_b32_dpp %[iL], %[ib] quad_perm:[0,0,1,2] row_mask:0xf bank_mask:0xf\n\t"                                 \
+        "v_cmp_lt_f32_e64 %[cb], %[vb], %[b]\n\t"                                                                       \
+        "v_cmp_lt_f32_e64 %[ca], %[vb], %[a]\n\t"                                                                       \
+        "v_cndmask_b32_e64 %[L], %[L], %[ninf], %[mf]\n\t"                                                              \
+        "v_cndmask_b32_e64 %[ib], %[ib], %[pb], %[cb]\n\t"                                                              \
+        "v_cmp_lt_f32_e64 %[cL], %[vb], %[L]\n\t"                                                                       \
+        "v_med3_f32 %[b], %[a], %[b], %[vb]\n\t"                                                                        \
+        "v_cndmask_b32_e64 %[ib], %[ib], %[ia], %[ca]\n\t"                                                              \
+        "v_cndmask_b32_e64 %[ia], %[ia], %[pb], %[ca]\n\t"                                                              \
+        "v_med3_f32 %[a], %[L], %[a], %[vb]\n\t"                                                                        \
+        "v_cndmask_b32_e64 %[ia], %[ia], %[iL], %[cL]\n\t"
+        asm volatile("s_nop 1\n\t" HNR_QSTEP(0) HNR_QSTEP(1) HNR_QSTEP(2) HNR_QSTEP(3)
+                     : [a] "+v"(a), [b] "+v"(b), [ia] "+v"(ia), [ib] "+v"(ib), [vb] "=&v"(vb), [pb] "=&v"(pb), [L] "=&v"(L), [iL] "=&v"(iL),
+                       [cL] "=&s"(cL), [ca] "=&s"(ca), [cb] "=&s"(cb)
+                     : [v] "v"(v), [p] "v"(p), [ninf] "v"(ninf), [mf] "s"(m_first));
+#undef HNR_QSTEP
+    }
+};
+
+template <int BIN>
+__global__ __launch_bounds__(256) void knn_quad_kernel(GridView g, const int32_t *__restrict__ work, const float *__restrict__ loc,
+                                                       int SR, float radius2, int layers, int32_t *__restrict__ pidx, int8_t *__restrict__ ray_mask,
+                                                       const unsigned long long *__restrict__ counts, unsigned long long *__restrict__ block_stats)
+{
+    constexpr int K = 8;
+    __shared__ unsigned long long s_st[4][4];
+    __shared__ float4 s_loc[NB_CHUNK + 64];                        // {x, y, z, item} in processing order (+ one idle round of zero records)
+    __shared__ uint2 s_rg[NB_CHUNK + 64];
+    __shared__ int s_hist[NB_BINS], s_base[NB_BINS];
+    const int n = (int)counts[HNR_CNT_SAMPLES];
+    const int q = threadIdx.x & 3, quad = threadIdx.x >> 2;
+    unsigned n_cells = 0, n_cand = 0, n_nb = 0, n_sv = 0;          // counted by lane 0 of each quad
+    const float inf = __int_as_float(0x7f800000);
+    auto lookup = [&](float cx, float cy, float cz) -> uint2 {
+        const int fx = cell_coord(cx, g.ox, g.cx), fy = cell_coord(cy, g.oy, g.cy), fz = cell_coord(cz, g.oz, g.cz);
+        const bool inb = in_bounds(g, fx, fy, fz);
+        const uint4 rec = g.dil_rec[inb ? brick_word(g, fx, fy, fz) : 0u];
+        const unsigned long long bb = (unsigned long long)rec.x | ((unsigned long long)rec.y << 32);
+        const int b = inb ? brick_bit(fx, fy, fz) : 0;
+        const bool have = inb && ((bb >> b) & 1ull);
+        const uint2 rg = g.nb_rng[have ? rec.z + (uint32_t)__popcll(bb & ((1ull << b) - 1ull)) : 0u];
+        return have ? rg : make_uint2(0u, 0u);
+    };
+    for (int w0 = blockIdx.x * NB_CHUNK; w0 < n; w0 += gridDim.x * NB_CHUNK) {
+        const int m = min(NB_CHUNK, n - w0);
+        // ---- phase A: the chunk's samples with their positions and run records into LDS, in the order they will be processed
+        if (threadIdx.x < NB_BINS) s_hist[threadIdx.x] = 0;
+        if (threadIdx.x < 64) { s_loc[m + threadIdx.x] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1)); s_rg[m + threadIdx.x] = make_uint2(0u, 0u); }
+        __syncthreads();
+        {
+            int item[4], key[4], rank[4];
+            float4 lc[4];
+            uint2 rg[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int w = w0 + u * 256 + (int)threadIdx.x;
+                item[u] = w < n ? work[w] : -1;
+                const size_t o = 3 * (size_t)(item[u] < 0 ? 0 : item[u]);
+                lc[u] = make_float4(loc[o], loc[o + 1], loc[o + 2], __int_as_float(item[u]));
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) rg[u] = item[u] >= 0 ? lookup(lc[u].x, lc[u].y, lc[u].z) : make_uint2(0u, 0u);
+            if constexpr (BIN != 0) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int c0 = (int)(rg[u].y & 63u), tot = (int)((rg[u].y >> 6) & 2047u);
+                    const int trips = ((c0 + 3) >> 2) + ((tot - c0 + 3) >> 2);
+                    key[u] = trips < NB_BINS - 1 ? trips : NB_BINS - 1;
+                    rank[u] = item[u] >= 0 ? atomicAdd(&s_hist[key[u]], 1) : 0;
+                }
+                __syncthreads();
+                if (threadIdx.x < 64) {                            // exclusive scan of the bin counts, longest lists first
+                    const int t = threadIdx.x;
+                    int v = t < NB_BINS ? s_hist[NB_BINS - 1 - t] : 0, inc = v;
+                    for (int o = 1; o < NB_BINS; o <<= 1) { const int u2 = __shfl_up(inc, o); if (t >= o) inc += u2; }
+                    if (t < NB_BINS) s_base[NB_BINS - 1 - t] = inc - v;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (item[u] >= 0) { const int pos = s_base[key[u]] + rank[u]; s_loc[pos] = lc[u]; s_rg[pos] = rg[u]; }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (item[u] >= 0) { const int pos = u * 256 + (int)threadIdx.x; s_loc[pos] = lc[u]; s_rg[pos] = rg[u]; }
+            }
+        }
+        __syncthreads();
+        // ---- phase B: a quad per sample.  The first line of BOTH shells of the next sample is requested before the current one is worked on, and inside
+        //      a shell the next line is in flight across the four insertions: no load is waited for right after its issue.
+        int t = quad;
+        float4 c = s_loc[t];
+        uint2 rg = s_rg[t];
+        int s1 = (int)rg.x + (((int)(rg.y & 63u) + 3) & ~3);
+        float4 pA = g.nb_pts[rg.x + q], pB = g.nb_pts[s1 + q];       // (an empty run reads record 0..3 of run 0: harmless, never used)
+        const int rounds = (m + 63) >> 6;
+        for (int r = 0; r < rounds; ++r) {
+            const int tn = min(t + 64, m + 63);                    // (one idle round of zero records follows the chunk; nothing beyond it is touched)
+            const float4 cn = s_loc[tn];
+            const uint2 rgn = s_rg[tn];
+            const int s1n = (int)rgn.x + (((int)(rgn.y & 63u) + 3) & ~3);
+            const float4 pAn = g.nb_pts[rgn.x + q], pBn = g.nb_pts[s1n + q];
+            const int item = __float_as_int(c.w);
+            const int start = (int)rg.x, c0 = (int)(rg.y & 63u), tot = (int)((rg.y >> 6) & 2047u);
+            QuadList kl;
+            kl.init();
+            auto run = [&](int lo, int hi, float4 p) {             // lo: a multiple of 4 entries; p: record lo + q, already loaded
+                int j = lo + q;
+                bool live = j < hi;
+                while (__builtin_amdgcn_ballot_w64(live) != 0ull) {
+                    const int jn = j + 4;
+                    const float4 pn = g.nb_pts[jn < hi ? jn : lo];
+                    const float xv = __fsub_rn(p.x, c.x), yv = __fsub_rn(p.y, c.y), zv = __fsub_rn(p.z, c.z);
+                    const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(xv, xv), __fmul_rn(yv, yv)), __fmul_rn(zv, zv));
+                    const float v = (live && (radius2 == 0.f || d2 <= radius2)) ? d2 : inf;
+                    kl.insert4(v, __float_as_int(p.w), 0x1111111111111111ull);
+                    j = jn; p = pn; live = j < hi;
+                }
+            };
+            if (layers > 0) run(start, start + c0, pA);
+            // the list is full after shell 0 iff its last entry (lane 3's b) is finite -- reference: `if (kid >= K) break;`
+            const bool full0 = quad_f<0xff>(kl.b) < inf;
+            unsigned cells = (rg.y >> 22) & 1u, cand = (unsigned)c0;
+            if (layers > 1 && !full0) {
+                run(s1, s1 + tot - c0, pB);
+                cells += (rg.y >> 17) & 31u; cand += (unsigned)(tot - c0);
+            }
+            if (item >= 0) {
+                reinterpret_cast<int2 *>(pidx + (size_t)item * K)[q] = make_int2(kl.ia, kl.ib);
+                int mine = (kl.a < inf ? 1 : 0) + (kl.b < inf ? 1 : 0);          // neighbours found: finite entries over the quad
+                mine += quad_i<0xb1>(mine);                        // quad_perm [1,0,3,2]
+                mine += quad_i<0x4e>(mine);                        // quad_perm [2,3,0,1]
+                if (q == 0) {
+                    n_cells += cells; n_cand += cand;
+                    if (mine > 0) { ray_mask[item / SR] = 1; n_nb += (unsigned)mine; ++n_sv; }
+                }
+            }
+            t = tn; c = cn; rg = rgn; s1 = s1n; pA = pAn; pB = pBn;
+        }
+        __syncthreads();
+    }
+    unsigned long long t_cells = n_cells, t_cand = n_cand, t_nb = n_nb, t_sv = n_sv;
+    for (int o = 32; o > 0; o >>= 1) {
+        t_cells += __shfl_xor(t_cells, o);
+        t_cand += __shfl_xor(t_cand, o);
+        t_nb += __shfl_xor(t_nb, o);
+        t_sv += __shfl_xor(t_sv, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        const int wv = threadIdx.x >> 6;
+        s_st[wv][0] = t_cells; s_st[wv][1] = t_cand; s_st[wv][2] = t_nb; s_st[wv][3] = t_sv;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4)
+        block_stats[4 * (size_t)blockIdx.x + threadIdx.x] =
+            s_st[0][threadIdx.x] + s_st[1][threadIdx.x] + s_st[2][threadIdx.x] + s_st[3][threadIdx.x];
+}
+
 __global__ __launch_bounds__(256) void knn_finalize_kernel(const unsigned long long *__restrict__ block_stats, int nblocks,
                                                            unsigned long long *__restrict__ counts)
 {
@@ -629,9 +1034,17 @@ extern "C" int hnr_march_query(const hnr_grid *g, const float *d_campos, const f
     if (q->R == 0) return HNR_OK;
     const GridView v = g->view();
     unsigned long long *cnt = reinterpret_cast<unsigned long long *>(d_counts);
-    march_kernel<<<cdiv((int64_t)q->R * 64, 256), 256, 0, st>>>(v, d_campos, d_raydir, d_tmid, q->R, q->D, q->SR, q->K,
+    static int march_probe = -1;                                 // HNR_MARCH_PROBE=1: time the march kernel's fixed part alone (tools; results are empty)
+    if (march_probe < 0) { const char *e = getenv("HNR_MARCH_PROBE"); march_probe = e ? atoi(e) : 0; }
+    // a wave works through ~8 rays (wave launches, not instructions, bounded the one-ray-per-wave form: 0.63 waves per cycle over the whole chip); enough
+    // workgroups that the last, partial round of residency is a few per cent of the launch (ONE workgroup per resident slot left a third of the CUs idle in a second round)
+    static int rays_per_wave = -1;
+    if (rays_per_wave < 0) { const char *e = getenv("HNR_MARCH_RAYS_PER_WAVE"); rays_per_wave = e ? atoi(e) : 8; if (rays_per_wave < 1) rays_per_wave = 1; }
+    int march_blocks = cdiv((int64_t)cdiv(q->R, rays_per_wave) * 64, 256);
+    if (march_blocks < 1) march_blocks = 1;
+    march_kernel<<<march_blocks, 256, 0, st>>>(v, d_campos, d_raydir, d_tmid, q->R, q->D, q->SR, q->K,
                                                                 q->tmid_stride, q->pad_outputs, d_sample_pidx, d_sample_loc_w,
-                                                                d_ray_nsamp, d_ray_mask);
+                                                                d_ray_nsamp, d_ray_mask, march_probe);
     HNR_LAUNCH_CHECK();
     const int layers = (q->kernel_size[0] + 1) / 2;
     const int max_items = q->R * q->SR;
@@ -645,7 +1058,7 @@ extern "C" int hnr_march_query(const hnr_grid *g, const float *d_campos, const f
     HNR_LAUNCH_CHECK();
     // K = 8 with a 3x3x3 neighbourhood (every shipped config): the pipelined kernel (HNR_KNN=1: the generic one-cell-at-a-time kernel)
     static int knn_sel = -1;
-    if (knn_sel < 0) { const char *e = getenv("HNR_KNN"); knn_sel = e ? atoi(e) : 3; }
+    if (knn_sel < 0) { const char *e = getenv("HNR_KNN"); knn_sel = e ? atoi(e) : 4; }
     if (q->knn_order == 1 && !(q->K == 8 && layers <= 2)) {
         set_error("hnr_march_query: knn_order = 1 (canonical neighbour order) is built for K = 8 with a 3x3x3 neighbourhood (K=%d)", q->K);
         return HNR_ERR_BADARG;
@@ -658,6 +1071,22 @@ extern "C" int hnr_march_query(const hnr_grid *g, const float *d_campos, const f
     if (q->knn_order == 1 && !packable) {
         set_error("hnr_march_query: knn_order = 1 needs P <= 63 and < 2^26 points (P=%d)", gp.P);
         return HNR_ERR_BADARG;
+    }
+    if (q->K == 8 && layers <= 2 && v.nb_pts && knn_sel != 1 && knn_sel != 3) {
+        // the grid carries 3x3x3 neighbourhood lists (P <= 63): two lookups per sample, contiguous candidates (HNR_KNN=3: the 27-cell walk below)
+        const int blocks = knn_blocks(max_items);
+        const bool bin = knn_sel != 5;                             // HNR_KNN=5: work-list order (no in-block sort by list length)
+#define HNR_NB_LAUNCH(S_, B_) knn_nb_kernel<8, S_, B_><<<blocks, 256, 0, st>>>(v, d_work, d_sample_loc_w, q->SR, q->radius2, layers, d_sample_pidx, d_ray_mask, cnt, block_stats)
+        // HNR_KNN: 4 (default) quad-per-sample kernel for the set-exact order; 6 the same in work-list order; 7 / 5 one lane per sample, sorted by list length / not
+        if (q->knn_order == 1 && (knn_sel == 4 || knn_sel == 6)) {
+            if (knn_sel == 4) knn_quad_kernel<1><<<blocks, 256, 0, st>>>(v, d_work, d_sample_loc_w, q->SR, q->radius2, layers, d_sample_pidx, d_ray_mask, cnt, block_stats);
+            else knn_quad_kernel<0><<<blocks, 256, 0, st>>>(v, d_work, d_sample_loc_w, q->SR, q->radius2, layers, d_sample_pidx, d_ray_mask, cnt, block_stats);
+        } else if (q->knn_order == 1) { if (bin) HNR_NB_LAUNCH(1, 1); else HNR_NB_LAUNCH(1, 0); }
+        else { if (bin) HNR_NB_LAUNCH(0, 1); else HNR_NB_LAUNCH(0, 0); }
+#undef HNR_NB_LAUNCH
+        knn_finalize_kernel<<<1, 256, 0, st>>>(block_stats, blocks, cnt);
+        HNR_LAUNCH_CHECK();
+        return HNR_OK;
     }
     if (q->K == 8 && layers <= 2 && packable && (knn_sel != 1 || q->knn_order == 1)) {
         const int blocks = knn_blocks(max_items);

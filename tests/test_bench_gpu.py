@@ -41,15 +41,18 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
 
 def test_bench_two_rank_rehearsal_of_the_patch_sharded_train_step():
     """BASELINE config 5 as it runs on N ranks (train_leg_sharded): two ranks on one GPU, gloo collectives on host copies -- control flow and shapes of
-    the patch sharding + the three gradient collectives, not a measurement."""
+    the patch sharding + the two gradient collectives (one all-reduce of the flat weight gradients carrying the valid-ray counts, one fixed-capacity
+    all-gather of packed point records), not a measurement."""
     e = dict(os.environ, HNR_BENCH_REHEARSAL="1")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--points", "2e5", "--no-cpu-baseline",
                         "--no-f32-anchor", "--train-sharded-only"], cwd=ROOT, capture_output=True, text=True, timeout=1500, env=e)
     assert p.returncode == 0, p.stderr[-2000:]
     d = json.loads([l for l in p.stdout.splitlines() if l.strip().startswith("{")][0])
     t = d["train_step_sharded"]
-    assert t["n_ranks"] == 2 and "25 patches" in t["workload"] or "24 patches" in t["workload"]
-    assert t["ms_per_step"] > 0 and t["collective_bytes"]["touched_points"] > 0
+    assert t.get("error") is None, t
+    assert t["n_ranks"] == 2 and ("25 patches" in t["workload"] or "24 patches" in t["workload"])
+    assert t["ms_per_step"] > 0 and t["touched_points"] > 0 and t["exchange_capacity"] >= t["touched_points"] and not t["exchange_overflow"]
+    assert len(t["per_rank_ms_per_step"]) == 2 and t["collective_bytes"]["point_records_allgather_per_rank"] == (t["exchange_capacity"] + 2) * 160
 
 
 def _run(extra, env=None, timeout=1500):

@@ -305,3 +305,51 @@ def test_sorted_neighbour_order_bad_arguments():
     with pytest.raises(HnrError, match="knn_order"):
         Q.march_query(g, torch.from_numpy(cs["campos"]).to(d), torch.from_numpy(cs["rays"]).to(d), torch.from_numpy(np.ascontiguousarray(cs["tmid"])).to(d),
                       cs["SR"], 4, cs["hp"]["radius2"], [3, 3, 3], knn_order=1)
+
+
+_VARIANT = r'''
+import sys, hashlib, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from hybridneuralrendering_amd import scenes, querier as Q
+from oracle import query_oracle as qo
+xyz, _ = scenes.room_cloud(60000, 11, size=(1.0, 0.8, 0.5), n_clutter=3, thickness=0.003)
+hp = qo.hyperparameters(xyz, [0.008] * 3, [2, 2, 2], [3, 3, 3], [-10.0] * 3 + [10.0] * 3, 4.0)
+s = np.asarray((1.0, 0.8, 0.5))
+cam = scenes.look_at(-0.3 * s + [0, 0, 0.25 * s[2]], 0.4 * s * [1, 1, -0.5])
+rays = scenes.camera_rays(scenes.pixel_grid(64, 48), scenes.pinhole(64, 48, 57.6), cam)
+d = torch.device("cuda:0")
+g = Q.VoxelGrid(torch.from_numpy(xyz).to(d), hp["origin"], hp["cell"], hp["dims"], [3, 3, 3], 12, 500000)
+tm = torch.from_numpy(qo.tmid_table(0.05, 1.5, 200)).to(d)
+out = []
+for order in (0, 1):
+    r = Q.march_query(g, torch.from_numpy(cam[:3, 3].copy()).to(d), torch.from_numpy(rays).to(d), tm, 24, 8, hp["radius2"], [3, 3, 3], knn_order=order)
+    h = hashlib.sha1()
+    for k in ("sample_pidx", "sample_loc_w", "ray_nsamp", "ray_mask", "counts"):
+        h.update(r[k].cpu().numpy().tobytes())
+    out.append(h.hexdigest())
+print("VARIANT", out[0], out[1], int(g.stats["bytes"]))
+'''
+
+
+def test_every_knn_kernel_variant_returns_the_same_bits(tmp_path):
+    """The k-NN has several forms (csrc/query.hip): over the grid's 3x3x3 neighbourhood lists with a quad of lanes per sample (HNR_KNN=4, the default for the
+    set-exact order) or one lane per sample (7 / 5: with / without the in-workgroup sort by list length; 6: the quad form in work-list order), and the
+    27-cell walk without the lists (HNR_KNN=3, and what runs when the grid carries no lists: HNR_NB_LISTS=0); the march probes a ray's blocks together or
+    one after the other (HNR_MARCH_PROBE=2).  Every combination must return the bits the default does -- which the tests above pin to the oracle --
+    in both neighbour orders, counters included."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "v.py"
+    script.write_text(_VARIANT)
+
+    def run(**env):
+        p = subprocess.run([sys.executable, str(script), root], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+        assert p.returncode == 0, p.stderr[-2000:]
+        return [l for l in p.stdout.splitlines() if l.startswith("VARIANT")][0].split()[1:]
+    base = run()
+    for env in (dict(HNR_KNN="3"), dict(HNR_KNN="5"), dict(HNR_KNN="6"), dict(HNR_KNN="7"), dict(HNR_NB_LISTS="0"), dict(HNR_MARCH_PROBE="2"),
+                dict(HNR_MARCH_RAYS_PER_WAVE="1"), dict(HNR_MARCH_RAYS_PER_WAVE="64")):
+        got = run(**env)
+        assert got[:2] == base[:2], (env, got, base)
+        if "HNR_NB_LISTS" in env:
+            assert int(got[2]) < int(base[2])                      # the lists are what the extra bytes of the handle are

@@ -6,6 +6,7 @@ from hybridneuralrendering_amd import scenes, querier as Q
 from hybridneuralrendering_amd._lib import CNT
 
 name = sys.argv[1] if len(sys.argv) > 1 else "scene0241"
+PAD = os.environ.get("PROBE_PAD", "1") != "0"                       # 0: un-padded outputs, what bench.py's roofline_query times
 ORDER = int(os.environ.get("PROBE_KNN_ORDER", "0"))              # 1: hnr_query_params.knn_order = 1 (sorted neighbour lists)
 N = int(float(sys.argv[2])) if len(sys.argv) > 2 else 2000000
 dev = torch.device("cuda:0")
@@ -27,7 +28,7 @@ campos = torch.from_numpy(sc.c2w[:3, 3].copy()).to(dev)
 tm = Q.tmid_table(sc.near, sc.far, opt.z_depth_dim, device=dev)
 r2 = np.float32(rl ** 2)
 for it in range(3):
-    res = Q.march_query(g, campos, rays, tm, opt.SR, opt.K, r2, opt.kernel_size, knn_order=ORDER)
+    res = Q.march_query(g, campos, rays, tm, opt.SR, opt.K, r2, opt.kernel_size, knn_order=ORDER, pad=PAD)
 torch.cuda.synchronize()
 c = res["counts"].cpu().numpy()
 print({k: int(c[v]) for k, v in CNT.items()})
@@ -35,7 +36,7 @@ e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tr
 e0.record()
 n = 10
 for it in range(n):
-    res = Q.march_query(g, campos, rays, tm, opt.SR, opt.K, r2, opt.kernel_size, knn_order=ORDER)
+    res = Q.march_query(g, campos, rays, tm, opt.SR, opt.K, r2, opt.kernel_size, knn_order=ORDER, pad=PAD)
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / n
 R = rays.shape[0]
