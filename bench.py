@@ -264,6 +264,14 @@ def cpu_baseline(args, sc, opt, agg, cam, gpu_colors):
     # difference of the reference's truncation rule, reported (count + its largest error), not an arithmetic error
     if not worst_same <= 1e-4:
         raise SystemExit("bench.py: GPU frame differs from the CPU oracle by %.3e (> 1e-4) on a ray whose reference-view pixels agree" % worst_same)
+    # ... and the rays left out of that assertion are bounded too (round-4 advice: a systematic projection error would move most rays into this set): a
+    # ray gathers another pixel only when a sample sits within an ulp of a pixel border -- the oracle's own fp32 and fp64 evaluations disagree on a
+    # handful of rays of 18 432 for the same reason -- and its colour then moves by one pixel's worth of one view's feature, not arbitrarily
+    n_other = int((~all_same).sum())
+    worst_other = float(all_err[~all_same].max()) if n_other else 0.0
+    if n_other > max(64, int(0.005 * all_err.size)) or worst_other > 5e-3:
+        raise SystemExit("bench.py: %d of %d checked rays gather another reference-view pixel than the oracle (max |d| %.3e): more than pixel-border ties explain"
+                         % (n_other, all_err.size, worst_other))
     # C1
     sc1 = scenes.make_scene("chair", 100000, 0)
     sc1.opt.agg_axis_weight = None
@@ -284,7 +292,8 @@ def cpu_baseline(args, sc, opt, agg, cam, gpu_colors):
                 psnr_gpu_vs_oracle_db=round(min(b["psnr_db"] for b in blocks), 2), max_abs_gpu_vs_oracle=worst,
                 max_abs_gpu_vs_oracle_same_pixels=worst_same, rays_gathering_another_pixel=int((~all_same).sum()),
                 max_abs_on_rays_gathering_another_pixel=float(all_err[~all_same].max()) if (~all_same).any() else 0.0,
-                asserted="max-abs <= 1e-4 on every checked ray whose gathered reference-view pixels equal the oracle's (hnr_proj_pixels vs oracle.gathered_pixels)",
+                asserted="max-abs <= 1e-4 on every checked ray whose gathered reference-view pixels equal the oracle's (hnr_proj_pixels vs oracle.gathered_pixels); "
+                         "the other rays: at most max(64, 0.5 %) of the checked ones, max-abs <= 5e-3",
                 rays_checked=int(all_err.size), rays_over_1e_4=int((all_err > 1e-4).sum()), p999_abs_gpu_vs_oracle=float(np.quantile(all_err, 0.999)),
                 oracle_f32_vs_f64_max_abs=max(b["oracle_f32_vs_f64_max_abs"] for b in blocks), oracle_rays_over_1e_4=sum(b["oracle_rays_over_1e_4"] for b in blocks),
                 checked_blocks=blocks, tolerance="fp32 max-abs <= 1e-4 on coarse_raycolor (SURVEY 8d) over %d blocks of %dx%d rays spread over the frame, except on rays "

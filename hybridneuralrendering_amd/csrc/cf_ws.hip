@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256, 1) void cf_ws_kernel(CfWsArgs a)
     auto dma_burst = [&](int tile, int b, int nb) __attribute__((always_inline)) {
         const int lr = CF_KEEP(lr0), c = 4 * (nb * 16 + lr);
         const float *p = row_ptr(tile, 0, b) + (c + 4 <= a.lda ? c : 0);
-        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(p), "s"(lds_base + (unsigned)(CF_RAW + ((wave * 2 + b) * 5 + nb) * 1024)) : "memory");
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(p), "s"(lds_base + (unsigned)(CF_RAW + ((wave * 2 + b) * 5 + nb) * 1024)) : "memory", "m0");
     };
     auto load_rows = [&](int tile) __attribute__((always_inline)) {
 #pragma unroll

@@ -66,7 +66,7 @@ __device__ __forceinline__ void cw_lds_barrier() { asm volatile("s_waitcnt lgkmc
 __device__ __forceinline__ void cw_dma_image(const char *g0, const char *g1, int voff, unsigned lds0, unsigned lds1)
 {
     asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt\n\t"
-                 "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2 nt" :: "v"(voff), "s"(g0), "s"(g1), "s"(lds0), "s"(lds1) : "memory");
+                 "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2 nt" :: "v"(voff), "s"(g0), "s"(g1), "s"(lds0), "s"(lds1) : "memory", "m0");
 }
 
 // Per-point table rows (layer 0's addend).  A lane (h, j) needs 16 consecutive floats of row j per column tile; fetched that way (four 16-B loads

@@ -523,13 +523,13 @@ __global__ __launch_bounds__(512, 1) void h2wgrad_kernel(H2WgradArgs a)
 // accumulator and the same blocks per workgroup as h2wgrad_kernel: bit-identical partials.
 __device__ __forceinline__ void h2_dma_row(const float *src, int voff, unsigned lds_dst)
 {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(src), "s"(lds_dst) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(src), "s"(lds_dst) : "memory", "m0");
 }
 __device__ __forceinline__ void h2_dma_row8(const float *src, int voff, unsigned lds_dst)      // lanes 0..7 only (the 32 columns past the 256th)
 {
     unsigned long long keep;
     asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 0xff\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b64 exec, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(src), "s"(lds_dst) : "memory");
+                 : "=&s"(keep) : "v"(voff), "s"(src), "s"(lds_dst) : "memory", "m0");
 }
 __global__ __launch_bounds__(512, 1) void h2wgrad_dma_kernel(H2WgradArgs a)
 {

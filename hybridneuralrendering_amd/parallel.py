@@ -308,11 +308,13 @@ class PointGradExchange:
         idc = ids[:cap].to(torch.int64) if ids.numel() >= cap else torch.cat([ids.to(torch.int64), torch.zeros((cap - ids.numel(),), dtype=torch.int64, device=dev)])
         idc = torch.where(live, idc, slot % N)                            # padded slots read distinct rows (their values are masked below)
         rec = torch.zeros((cap + 2, self.W), dtype=flat[0].dtype, device=dev)
-        body = torch.cat([f.index_select(0, idc) for f in flat], dim=1) * live[:, None].to(flat[0].dtype)
+        body = torch.cat([f.index_select(0, idc) for f in flat], dim=1)
+        body = torch.where(live[:, None], body, torch.zeros_like(body))     # (+0.0 in the unused slots: x * 0 would keep the sign of x)
         rec[1:cap + 1, 1:] = body
         rec[1:cap + 1, 0] = torch.where(live, idc, torch.full_like(idc, -1)).to(torch.int32).view(torch.float32)
         zero_in = (n > 0) & (idc[:1] == 0)                                  # ascending ids: point 0 is touched iff it comes first
-        rec[cap + 1, 1:] = torch.cat([f[0] for f in flat]) * (~zero_in).to(flat[0].dtype)
+        row0 = torch.cat([f[0] for f in flat])
+        rec[cap + 1, 1:] = torch.where(zero_in, torch.zeros_like(row0), row0)
         rec[cap + 1, 0] = torch.where(zero_in, torch.full((1,), -1, dtype=torch.int32, device=dev), torch.zeros((1,), dtype=torch.int32, device=dev)).view(torch.float32)[0]
         rec[0, 0] = n.to(flat[0].dtype)[0]
         rec[0, 1] = n_valid.reshape(-1)[0].to(flat[0].dtype)

@@ -190,3 +190,37 @@ def test_segmented_rows_equal_the_packed_layout():
     for dW, db in res:
         assert (np.abs(dW - ref) / mag).max() < 4e-7
         assert (np.abs(db - Z64.sum(0)) / np.abs(Z64).sum(0)).max() < 4e-7
+
+
+_WGRAD_AB = r'''
+import sys, hashlib, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from hybridneuralrendering_amd import _lib
+L = _lib.lib()
+dev = torch.device("cuda:0")
+M, N, K = 40000, 256, 256
+g = torch.Generator(device="cpu").manual_seed(12)
+Z, X = (torch.randn((M, N), generator=g) * 0.1).to(dev), torch.randn((M, K), generator=g).to(dev)
+one = torch.tensor([np.float32(1.0).view(np.int32)], dtype=torch.int32, device=dev)
+big = torch.tensor([np.float32(8.0).view(np.int32)], dtype=torch.int32, device=dev)
+scratch = torch.empty((int(L.hnr_h2wgrad_scratch_bytes(N, K)),), dtype=torch.uint8, device=dev)
+dW, db = torch.empty((N, K), device=dev), torch.empty((N,), device=dev)
+_lib.check(L.hnr_h2wgrad(_lib.ptr(Z), N, _lib.ptr(X), K, M, None, 1, 0, N, K, _lib.ptr(one), _lib.ptr(big), _lib.ptr(dW), K, _lib.ptr(db), 0, _lib.ptr(scratch), _lib.stream()), "hnr_h2wgrad")
+h = hashlib.sha1(); h.update(dW.cpu().numpy().tobytes()); h.update(db.cpu().numpy().tobytes())
+print("WGRAD_SHA", h.hexdigest())
+'''
+
+
+def test_dma_staged_weight_gradient_equals_the_register_staged_kernel_bit_for_bit(tmp_path):
+    """h2wgrad_dma_kernel (fp32 rows global -> LDS by DMA; the default for 256-wide layers) against h2wgrad_kernel<8,9,1,0,1> (HNR_WGRAD_DMA=0) on the
+    same seeded operands, in two processes (the choice is read once per process): identical dW and db (round-4 advice: the claim had no test)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "w.py"
+    script.write_text(_WGRAD_AB)
+    sha = []
+    for v in ("1", "0"):
+        p = subprocess.run([sys.executable, str(script), root], capture_output=True, text=True, timeout=600, env=dict(os.environ, HNR_WGRAD_DMA=v))
+        assert p.returncode == 0, p.stderr[-2000:]
+        sha.append([l for l in p.stdout.splitlines() if l.startswith("WGRAD_SHA")][0])
+    assert sha[0] == sha[1], sha
