@@ -527,7 +527,11 @@ __global__ __launch_bounds__(256) void conv3x3_bwd_tile_kernel(ConvTileArgs a)
     }
     // ---- load
     constexpr int D0 = (S == 1) ? 1 : 0;
-    for (int i = t; i < COUT * DR * DR; i += 256) {
+    // (hnr_opaque: the tile indices are small enough for the compiler to do this arithmetic in PACKED 16-bit instructions -- v_pk_mad_u16 and friends, 20 of
+    // them in the <24,24,1,8> instance.  Nothing is known against them, but the failure of the packed fp32 ones beside other waves' MFMAs (DESIGN.md
+    // section 2) was never explained either, so the library carries NO v_pk_* instruction at all: tests/test_abi_and_host.py checks the disassembly.)
+    for (int i0 = t; i0 < COUT * DR * DR; i0 += 256) {
+        const int i = hnr_opaque(i0);
         const int c = i / (DR * DR), r = i % (DR * DR), oy = oy0 - D0 + r / DR, ox = ox0 - D0 + r % DR;
         float dz = 0.f;
         if (oy >= 0 && oy < a.Hout && ox >= 0 && ox < a.Wout) {
@@ -536,7 +540,8 @@ __global__ __launch_bounds__(256) void conv3x3_bwd_tile_kernel(ConvTileArgs a)
         }
         s_dz[c * DSTR + r] = dz;
     }
-    for (int i = t; i < CIN * IR * IR; i += 256) {
+    for (int i0 = t; i0 < CIN * IR * IR; i0 += 256) {
+        const int i = hnr_opaque(i0);
         const int c = i / (IR * IR), r = i % (IR * IR), iy = S * oy0 - 1 + r / IR, ix = S * ox0 - 1 + r % IR;
         float x = 0.f;
         if (iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win)
@@ -544,7 +549,8 @@ __global__ __launch_bounds__(256) void conv3x3_bwd_tile_kernel(ConvTileArgs a)
         s_in[c * ISTR + r] = x;
     }
     if (DGRAD)
-        for (int i = t; i < 9 * COUT * CIN; i += 256) {             // w[co][ci][k] -> s_w[k][co][ci]
+        for (int i0 = t; i0 < 9 * COUT * CIN; i0 += 256) {          // w[co][ci][k] -> s_w[k][co][ci]
+            const int i = hnr_opaque(i0);
             const int k = i % 9, ci = (i / 9) % CIN, co = i / (9 * CIN);
             s_w[(k * COUT + co) * CIN + ci] = a.w[i];
         }

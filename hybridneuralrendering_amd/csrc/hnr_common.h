@@ -156,6 +156,9 @@ __device__ __forceinline__ float hnr_div_cell(float n, float d)
     return fmaf(fmaf(-d, q, n), r, q);
 }
 
+// An integer the compiler knows nothing about (no range, no relation to other values): keeps index arithmetic on small values in 32-bit instructions.
+__device__ __forceinline__ int hnr_opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+
 __device__ __forceinline__ int cell_coord(float p, float o, float c)
 {
     float d = __fsub_rn(p, o);

@@ -437,7 +437,7 @@ def test_ctypes_structs_have_the_layout_of_the_c_header(tmp_path):
         for fname, _ in cls._fields_:
             assert got[(cname, fname)] == getattr(cls, fname).offset, (cname, fname)
 
-def test_library_has_no_packed_fp32_arithmetic(tmp_path):
+def test_library_has_no_packed_instructions(tmp_path):
     """v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 give wrong results in lanes 48..63 of a wave on gfx950 while another wave of the same SIMD runs MFMAs
     (another stream's GEMM, another process): tools/featmap_contention.py, profiles/README.md round 4.  The library is built without them
     (csrc/Makefile: -fno-slp-vectorize; hnr_h2.h: f32x2 is a struct); this disassembles the device code of the built library and checks."""
@@ -454,7 +454,10 @@ def test_library_has_no_packed_fp32_arithmetic(tmp_path):
     for f in objs:
         dis = subprocess.run([objdump, "-d", f], cwd=tmp_path, check=True, capture_output=True, text=True).stdout
         n_mfma += dis.count("v_mfma_")
-        bad += [l.strip() for l in dis.splitlines() if "v_pk_mul_f32" in l or "v_pk_add_f32" in l or "v_pk_fma_f32" in l][:5]
+        # round 5: EVERY packed opcode, not only the three fp32 ones the experiment convicted -- the mechanism was never found (no reproducer smaller than
+        # featmap_kernel), so nothing says the integer ones (20 v_pk_*_u16 / _i16 sat in conv3x3_bwd_tile_kernel<24,24,1,8>'s index arithmetic) or
+        # v_pk_mov_b32 are safe beside another wave's MFMAs; the library simply contains none (csrc/hnr_common.h: hnr_opaque)
+        bad += [l.strip() for l in dis.splitlines() if "v_pk_" in l][:5]
     assert n_mfma > 1000, "the disassembly does not look like the library's device code"
     assert not bad, bad
 
@@ -467,6 +470,6 @@ def test_committed_pmc_files_hold_the_kernels_bench_looks_up():
     tr = json.load(open(newest("train_traffic.json")))["kernels"]
     assert any("h2wgrad_dma_kernel" in k for k in tr), list(tr)
     fr = json.load(open(newest("traffic.json")))["kernels"]
-    assert any("chain_ws_kernel<0>" in k for k in fr) and any("march_kernel" in k for k in fr) and any("knn3_kernel<8, 1>" in k for k in fr), list(fr)
+    assert any("chain_ws_kernel<0>" in k for k in fr) and any("march_kernel" in k for k in fr) and any("knn_quad_kernel" in k for k in fr), list(fr)
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert '"h2wgrad_dma_kernel" in k' in src and "chain_ws_kernel<0>" in src

@@ -77,6 +77,11 @@ def test_bench_gpus_2_spawns_two_ranks_and_reassembles_the_same_frame(tmp_path):
     d3 = _run(["--gpus", "2", "--shard", "blocks", "--dump-colors", c], env={"HNR_BENCH_REHEARSAL": "1"})
     assert d1["n_gpus"] == 1 and d2["n_gpus"] == 2 and d2["scaling"] == "strong"
     assert "round-robin" in d2["config"]["parallelism"] and "contiguous" in d3["config"]["parallelism"]
+    # both ways of dealing the rays are timed in the same run (the first N-GPU record settles SURVEY 8e's choice)
+    for dd in (d2, d3):
+        ab = dd["shard_ab"]
+        assert ab["lines"]["ms_per_step_max_rank"] > 0 and ab["blocks"]["ms_per_step_max_rank"] > 0 and len(ab["lines"]["per_rank_ms"]) == 2
+    assert d1["shard_ab"] is None and d1["rccl_ranks"] == 0
     assert np.array_equal(np.load(a), np.load(c))
     assert d2["config"]["rays_per_step"] == d1["config"]["rays_per_step"] and d2["config"]["rays_per_gpu"] * 2 == d1["config"]["rays_per_gpu"]
     assert "REHEARSAL" in d2["data"]
@@ -96,7 +101,7 @@ def test_bench_weak_scaling_flag_and_world_size_mismatch():
 
 
 def test_feature_map_repeats_bit_for_bit_beside_another_process():
-    """The behaviour behind tests/test_abi_and_host.py::test_library_has_no_packed_fp32_arithmetic: hnr_image_features repeated while another process
+    """The behaviour behind tests/test_abi_and_host.py::test_library_has_no_packed_instructions: hnr_image_features repeated while another process
     renders frames on the same GPU.  With packed fp32 instructions in featmap_kernel 38 % of such launches came out wrong in lanes 48..63
     (profiles/r04_contention.txt); 500 launches must all repeat the quiet result."""
     e = dict(os.environ, FM_ITERS="500", FM_HOG_WAIT="25")

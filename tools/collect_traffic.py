@@ -12,7 +12,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 root = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "traffic5")
-KERNELS = ("chain_ws_kernel", "chain_kernel", "chain_gather_kernel", "chain_sigma_kernel", "mlp3_kernel", "knn3_kernel", "knn_set_kernel", "march_kernel", "proj_rows_kernel", "merge_kernel", "final_color_kernel",
+KERNELS = ("chain_ws_kernel", "chain_kernel", "chain_gather_kernel", "chain_sigma_kernel", "mlp3_kernel", "knn3_kernel", "knn_quad_kernel", "knn_nb_kernel", "knn_set_kernel", "march_kernel", "proj_rows_kernel", "merge_kernel", "final_color_kernel",
            "composite_kernel", "linear_s3w_kernel", "linear_f32_kernel<2, 2, 1, 0, 4", "gather_rows", "ksum_kernel")
 out = {}
 for name in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -39,4 +39,4 @@ note = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `
         "(gfx950 tallies 128-B requests as 64 B on wide coalesced reads; calibrated in round 1 on ksum_kernel: 12.4 GB raw vs 24.3 GB of rows actually read). "
         "chain_ws_kernel<0> = the fused per-neighbour chain (one launch per frame); its weight image (848 KiB) is re-read by every workgroup tile from L2, "
         "which these memory-side counters do not see.")
-json.dump(dict(note=note, kernels=kern), open(os.path.join(ROOT, "profiles", (sys.argv[2] if len(sys.argv) > 2 else "r04") + "_traffic.json"), "w"), indent=1)
+json.dump(dict(note=note, kernels=kern), open(os.path.join(ROOT, "profiles", (sys.argv[2] if len(sys.argv) > 2 else "r05") + "_traffic.json"), "w"), indent=1)
