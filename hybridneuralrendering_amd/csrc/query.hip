@@ -562,8 +562,11 @@ __global__ __launch_bounds__(256) void knn3_kernel(GridView g, const int32_t *__
 // in LDS by the number of loop trips they need (4 candidates per trip, the two shells separately) and deals them to its lanes in that order: the
 // samples of a wave need the same number of trips up to +-1.  (Round 4 tried the same re-dealing over the 27-cell walk and gained nothing: there the
 // list length cost 54 lookups per sample.)  The order samples are taken in changes nothing a sample computes; the counters are integer sums.
-constexpr int NB_CHUNK = 1024;        // samples sorted per workgroup and round (4 per thread)
-constexpr int NB_BINS = 32;
+constexpr int NB_CHUNK = 1024;        // most samples sorted per workgroup and round (4 per thread)
+// (Round 5 also tried to size the rounds on the device so that the last round of residency is full -- 832 samples per round on 2048 workgroups, 768 on the
+// 1536 the LDS lets the chip hold: 0.645 / 0.69 ms for the query against 0.60 with fixed rounds of 1024.  Fewer, larger rounds win: a round's cost is its
+// chain of dependent lookups + three barriers, and the workgroups that wait for a slot fill the first ones' tail.)
+__device__ __forceinline__ int nb_chunk_size(int, int) { return NB_CHUNK; }
 template <int K, int SORTED, int BIN>
 __global__ __launch_bounds__(256) void knn_nb_kernel(GridView g, const int32_t *__restrict__ work, const float *__restrict__ loc,
                                                      int SR, float radius2, int layers, int32_t *__restrict__ pidx, int8_t *__restrict__ ray_mask,
@@ -572,7 +575,7 @@ __global__ __launch_bounds__(256) void knn_nb_kernel(GridView g, const int32_t *
     __shared__ unsigned long long s_st[4][4];
     __shared__ int32_t s_item[BIN ? NB_CHUNK : 1];
     __shared__ uint2 s_rg[BIN ? NB_CHUNK : 1];
-    __shared__ int s_hist[NB_BINS], s_base[NB_BINS];
+    __shared__ int s_hist[BIN == 2 ? NB_BINS * 32 : NB_BINS], s_base[BIN == 2 ? NB_BINS * 32 : NB_BINS], s_wsum[4];
     const int n = (int)counts[HNR_CNT_SAMPLES];
     unsigned n_cells = 0, n_cand = 0, n_nb = 0, n_sv = 0;
     auto lookup = [&](int item) -> uint2 {
@@ -637,15 +640,19 @@ __global__ __launch_bounds__(256) void knn_nb_kernel(GridView g, const int32_t *
         }
     };
     if constexpr (BIN != 0) {
-        for (int w0 = blockIdx.x * NB_CHUNK; w0 < n; w0 += gridDim.x * NB_CHUNK) {
-            if (threadIdx.x < NB_BINS) s_hist[threadIdx.x] = 0;
+        // BIN == 2: buckets = (loop trips, 5 bits of the cell's run address): samples of one cell share a bucket and end up in neighbouring lanes, so the
+        // four lanes of a quad mostly read the SAME record with a load instruction (one cache line per quad instead of four)
+        constexpr int NBK = BIN == 2 ? NB_BINS * 32 : NB_BINS;
+        const int chunk = nb_chunk_size(n, (int)gridDim.x);
+        for (int w0 = blockIdx.x * chunk; w0 < n; w0 += gridDim.x * chunk) {
+            for (int i = threadIdx.x; i < NBK; i += 256) s_hist[i] = 0;
             __syncthreads();
             int item[4], key[4], rank[4];
             uint2 rg[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {                          // (all four lookups in flight)
-                const int w = w0 + q * 256 + (int)threadIdx.x;
-                item[q] = w < n ? work[w] : -1;
+                const int wi = q * 256 + (int)threadIdx.x, w = w0 + wi;
+                item[q] = (wi < chunk && w < n) ? work[w] : -1;
                 rg[q] = item[q] >= 0 ? lookup(item[q]) : make_uint2(0u, 0u);
             }
 #pragma unroll
@@ -653,21 +660,32 @@ __global__ __launch_bounds__(256) void knn_nb_kernel(GridView g, const int32_t *
                 const int c0 = (int)(rg[q].y & 63u), tot = (int)((rg[q].y >> 6) & 2047u);
                 const int trips = ((c0 + 3) >> 2) + ((tot - c0 + 3) >> 2);
                 key[q] = trips < NB_BINS - 1 ? trips : NB_BINS - 1;
+                key[q] = NB_BINS - 1 - key[q];                     // longest lists first
+                if constexpr (BIN == 2) key[q] = key[q] * 32 + (int)((rg[q].x >> 2) & 31u);
                 rank[q] = item[q] >= 0 ? atomicAdd(&s_hist[key[q]], 1) : 0;
             }
             __syncthreads();
-            if (threadIdx.x < 64) {                                // exclusive scan of the 32 bin counts, longest lists first
-                const int t = threadIdx.x;
-                int v = t < NB_BINS ? s_hist[NB_BINS - 1 - t] : 0, inc = v;
-                for (int o = 1; o < NB_BINS; o <<= 1) { const int u = __shfl_up(inc, o); if (t >= o) inc += u; }
-                if (t < NB_BINS) s_base[NB_BINS - 1 - t] = inc - v;
+            {   // exclusive scan of the bucket counts: 4 (or 1/8) per thread, wave scan, wave totals through LDS
+                constexpr int PER = (NBK + 255) / 256;
+                int v[PER], sum = 0;
+#pragma unroll
+                for (int i = 0; i < PER; ++i) { const int b = (int)threadIdx.x * PER + i; v[i] = b < NBK ? s_hist[b] : 0; sum += v[i]; }
+                int inc = sum;
+                const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+                for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o); if (lane >= o) inc += u; }
+                if (lane == 63) s_wsum[wv] = inc;
+                __syncthreads();
+                int base = inc - sum;
+                for (int k = 0; k < wv; ++k) base += s_wsum[k];
+#pragma unroll
+                for (int i = 0; i < PER; ++i) { const int b = (int)threadIdx.x * PER + i; if (b < NBK) s_base[b] = base; base += v[i]; }
             }
             __syncthreads();
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 if (item[q] >= 0) { const int pos = s_base[key[q]] + rank[q]; s_item[pos] = item[q]; s_rg[pos] = rg[q]; }
             __syncthreads();
-            const int m = min(NB_CHUNK, n - w0);
+            const int m = min(chunk, n - w0);
             for (int t = threadIdx.x; t < m; t += 256) one(s_item[t], s_rg[t]);
             __syncthreads();
         }
@@ -771,8 +789,9 @@ __global__ __launch_bounds__(256) void knn_quad_kernel(GridView g, const int32_t
         const uint2 rg = g.nb_rng[have ? rec.z + (uint32_t)__popcll(bb & ((1ull << b) - 1ull)) : 0u];
         return have ? rg : make_uint2(0u, 0u);
     };
-    for (int w0 = blockIdx.x * NB_CHUNK; w0 < n; w0 += gridDim.x * NB_CHUNK) {
-        const int m = min(NB_CHUNK, n - w0);
+    const int chunk = nb_chunk_size(n, (int)gridDim.x);
+    for (int w0 = blockIdx.x * chunk; w0 < n; w0 += gridDim.x * chunk) {
+        const int m = min(chunk, n - w0);
         // ---- phase A: the chunk's samples with their positions and run records into LDS, in the order they will be processed
         if (threadIdx.x < NB_BINS) s_hist[threadIdx.x] = 0;
         if (threadIdx.x < 64) { s_loc[m + threadIdx.x] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1)); s_rg[m + threadIdx.x] = make_uint2(0u, 0u); }
@@ -783,8 +802,8 @@ __global__ __launch_bounds__(256) void knn_quad_kernel(GridView g, const int32_t
             uint2 rg[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int w = w0 + u * 256 + (int)threadIdx.x;
-                item[u] = w < n ? work[w] : -1;
+                const int wi = u * 256 + (int)threadIdx.x, w = w0 + wi;
+                item[u] = (wi < chunk && w < n) ? work[w] : -1;
                 const size_t o = 3 * (size_t)(item[u] < 0 ? 0 : item[u]);
                 lc[u] = make_float4(loc[o], loc[o + 1], loc[o + 2], __int_as_float(item[u]));
             }
@@ -1074,15 +1093,24 @@ extern "C" int hnr_march_query(const hnr_grid *g, const float *d_campos, const f
     }
     if (q->K == 8 && layers <= 2 && v.nb_pts && knn_sel != 1 && knn_sel != 3) {
         // the grid carries 3x3x3 neighbourhood lists (P <= 63): two lookups per sample, contiguous candidates (HNR_KNN=3: the 27-cell walk below)
-        const int blocks = knn_blocks(max_items);
-        const bool bin = knn_sel != 5;                             // HNR_KNN=5: work-list order (no in-block sort by list length)
+        int blocks = knn_blocks(max_items);
+        const int bin = knn_sel == 5 ? 0 : (knn_sel == 8 ? 2 : 1);
+        {   // workgroups per CU of the persistent k-NN kernels (HNR_KNN_WG_PER_CU; 8 = what knn_blocks caps at).  Measured for the quad kernel: 6 (what its
+            // 26 KB of LDS let a CU hold at once) 0.423 ms, 8 0.35 ms -- the workgroups that wait for a slot fill the tail of the first ones
+            static int wg_per_cu = -1;
+            if (wg_per_cu < 0) { const char *e = getenv("HNR_KNN_WG_PER_CU"); wg_per_cu = e ? atoi(e) : 8; if (wg_per_cu < 1) wg_per_cu = 1; }
+            const int cap = device_num_cus() * wg_per_cu;
+            if (knn_sel != 5) blocks = cdiv(max_items, 256) < cap ? cdiv(max_items, 256) : cap;
+            if (blocks > knn_blocks(max_items)) blocks = knn_blocks(max_items);          // (the per-workgroup counters' scratch is sized for that many)
+            if (blocks < 1) blocks = 1;
+        }  // HNR_KNN=5: work-list order; 7: sorted by list length; 8: ... and by cell
 #define HNR_NB_LAUNCH(S_, B_) knn_nb_kernel<8, S_, B_><<<blocks, 256, 0, st>>>(v, d_work, d_sample_loc_w, q->SR, q->radius2, layers, d_sample_pidx, d_ray_mask, cnt, block_stats)
         // HNR_KNN: 4 (default) quad-per-sample kernel for the set-exact order; 6 the same in work-list order; 7 / 5 one lane per sample, sorted by list length / not
         if (q->knn_order == 1 && (knn_sel == 4 || knn_sel == 6)) {
             if (knn_sel == 4) knn_quad_kernel<1><<<blocks, 256, 0, st>>>(v, d_work, d_sample_loc_w, q->SR, q->radius2, layers, d_sample_pidx, d_ray_mask, cnt, block_stats);
             else knn_quad_kernel<0><<<blocks, 256, 0, st>>>(v, d_work, d_sample_loc_w, q->SR, q->radius2, layers, d_sample_pidx, d_ray_mask, cnt, block_stats);
-        } else if (q->knn_order == 1) { if (bin) HNR_NB_LAUNCH(1, 1); else HNR_NB_LAUNCH(1, 0); }
-        else { if (bin) HNR_NB_LAUNCH(0, 1); else HNR_NB_LAUNCH(0, 0); }
+        } else if (q->knn_order == 1) { if (bin == 2) HNR_NB_LAUNCH(1, 2); else if (bin) HNR_NB_LAUNCH(1, 1); else HNR_NB_LAUNCH(1, 0); }
+        else { if (bin == 2) HNR_NB_LAUNCH(0, 2); else if (bin) HNR_NB_LAUNCH(0, 1); else HNR_NB_LAUNCH(0, 0); }
 #undef HNR_NB_LAUNCH
         knn_finalize_kernel<<<1, 256, 0, st>>>(block_stats, blocks, cnt);
         HNR_LAUNCH_CHECK();
