@@ -566,6 +566,7 @@ constexpr int NB_CHUNK = 1024;        // most samples sorted per workgroup and r
 // (Round 5 also tried to size the rounds on the device so that the last round of residency is full -- 832 samples per round on 2048 workgroups, 768 on the
 // 1536 the LDS lets the chip hold: 0.645 / 0.69 ms for the query against 0.60 with fixed rounds of 1024.  Fewer, larger rounds win: a round's cost is its
 // chain of dependent lookups + three barriers, and the workgroups that wait for a slot fill the first ones' tail.)
+constexpr int NB_BINS = 32;
 __device__ __forceinline__ int nb_chunk_size(int, int) { return NB_CHUNK; }
 template <int K, int SORTED, int BIN>
 __global__ __launch_bounds__(256) void knn_nb_kernel(GridView g, const int32_t *__restrict__ work, const float *__restrict__ loc,
