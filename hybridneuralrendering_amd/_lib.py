@@ -128,6 +128,7 @@ SIGNATURES = {
     "hnr_proj_rows": (_I, [_P] * 8 + [_I, _I, _I, _P, _I, _I, _P, _I, _P, _P, _P]),
     "hnr_proj_pixels": (_I, [_P] * 5 + [_I, _I, _I, _I, _P, _P]),
     "hnr_div_probe": (_I, [_P, _P, _I, _P, _P, _P]),
+    "hnr_div_probe2": (_I, [_P, _P, _F, _I, _P, _P, _P, _P, _P]),
     "hnr_merge": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _P, _I, _P, _P, _I, _P]),
     "hnr_chain_packed_bytes": (ctypes.c_int64, []),
     "hnr_chain_workspace_bytes": (ctypes.c_int64, [_I]),

@@ -1118,6 +1118,29 @@ extern "C" int hnr_div_probe(const float *d_num, const float *d_den, int n, floa
     return HNR_OK;
 }
 
+// ... the other two members of the family (round-4 advice): the cell index floor((p - o) / c) of the query kernels (hnr_div_cell inside cell_coord) beside the
+// same expression with the compiler's division, and hnr_div64 (the loss kernels' scalar means) beside the compiler's fp64 division
+__global__ void div_probe2_kernel(const float *__restrict__ p, const float *__restrict__ c, float o, int count, int32_t *__restrict__ cell_hnr, int32_t *__restrict__ cell_ieee,
+                                  double *__restrict__ q64_hnr, double *__restrict__ q64_ieee)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    cell_hnr[i] = hnr::cell_coord(p[i], o, c[i]);
+    const float q = __fsub_rn(p[i], o) / c[i];
+    cell_ieee[i] = (q > -2.0e9f && q < 2.0e9f) ? (int)floorf(q) : INT32_MIN;
+    const double n = (double)p[i] * 1.0000001192092896, d = (double)c[i] * 3.0000000000000004;      // (operands that are not fp32 values)
+    q64_hnr[i] = hnr::hnr_div64(n, d); q64_ieee[i] = n / d;
+}
+extern "C" int hnr_div_probe2(const float *d_p, const float *d_c, float origin, int n, int32_t *d_cell_hnr, int32_t *d_cell_ieee, double *d_q64_hnr, double *d_q64_ieee,
+                              void *stream)
+{
+    if (n < 0 || (n > 0 && (!d_p || !d_c || !d_cell_hnr || !d_cell_ieee || !d_q64_hnr || !d_q64_ieee))) { set_error("hnr_div_probe2: bad argument"); return HNR_ERR_BADARG; }
+    if (n == 0) return HNR_OK;
+    div_probe2_kernel<<<cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(d_p, d_c, origin, n, d_cell_hnr, d_cell_ieee, d_q64_hnr, d_q64_ieee);
+    HNR_LAUNCH_CHECK();
+    return HNR_OK;
+}
+
 extern "C" int hnr_proj_pixels(const float *d_sample_loc_w, const int32_t *d_vs_item, const int64_t *d_counts, const float *d_w2c,
                                const float *d_intrinsic, int V, int H, int W, int cap_samples, int32_t *d_pix, void *stream)
 {

@@ -563,11 +563,18 @@ __global__ __launch_bounds__(256) void knn3_kernel(GridView g, const int32_t *__
 // samples of a wave need the same number of trips up to +-1.  (Round 4 tried the same re-dealing over the 27-cell walk and gained nothing: there the
 // list length cost 54 lookups per sample.)  The order samples are taken in changes nothing a sample computes; the counters are integer sums.
 constexpr int NB_CHUNK = 1024;        // most samples sorted per workgroup and round (4 per thread)
-// (Round 5 also tried to size the rounds on the device so that the last round of residency is full -- 832 samples per round on 2048 workgroups, 768 on the
-// 1536 the LDS lets the chip hold: 0.645 / 0.69 ms for the query against 0.60 with fixed rounds of 1024.  Fewer, larger rounds win: a round's cost is its
-// chain of dependent lookups + three barriers, and the workgroups that wait for a slot fill the first ones' tail.)
+// Samples per workgroup round: 1024 when there is enough work for every workgroup of the launch, fewer for small batches (a training batch has ~38 k
+// samples: 38 rounds of 1024 would keep 38 of 2048 workgroups busy).  (Round 5 also tried to size the rounds so that the LAST round of residency is
+// full on a whole frame -- 832 samples per round on 2048 workgroups, 768 on the 1536 the LDS lets the chip hold: 0.645 / 0.69 ms for the query against
+// 0.60 with rounds of 1024.  Fewer, larger rounds win: a round's cost is its chain of dependent lookups + three barriers, and the workgroups that wait
+// for a slot fill the first ones' tail.)
+__device__ __forceinline__ int nb_chunk_size(int n, int n_groups)
+{
+    int c = (n + n_groups - 1) / n_groups;
+    c = (c + 63) & ~63;
+    return c < 64 ? 64 : (c > NB_CHUNK ? NB_CHUNK : c);
+}
 constexpr int NB_BINS = 32;
-__device__ __forceinline__ int nb_chunk_size(int, int) { return NB_CHUNK; }
 template <int K, int SORTED, int BIN>
 __global__ __launch_bounds__(256) void knn_nb_kernel(GridView g, const int32_t *__restrict__ work, const float *__restrict__ loc,
                                                      int SR, float radius2, int layers, int32_t *__restrict__ pidx, int8_t *__restrict__ ray_mask,
@@ -1060,7 +1067,10 @@ extern "C" int hnr_march_query(const hnr_grid *g, const float *d_campos, const f
     // workgroups that the last, partial round of residency is a few per cent of the launch (ONE workgroup per resident slot left a third of the CUs idle in a second round)
     static int rays_per_wave = -1;
     if (rays_per_wave < 0) { const char *e = getenv("HNR_MARCH_RAYS_PER_WAVE"); rays_per_wave = e ? atoi(e) : 8; if (rays_per_wave < 1) rays_per_wave = 1; }
-    int march_blocks = cdiv((int64_t)cdiv(q->R, rays_per_wave) * 64, 256);
+    // (small batches: one ray per wave until there are ~32 waves per CU)
+    int rpw = q->R / (device_num_cus() * 32);
+    rpw = rpw < 1 ? 1 : (rpw > rays_per_wave ? rays_per_wave : rpw);
+    int march_blocks = cdiv((int64_t)cdiv(q->R, rpw) * 64, 256);
     if (march_blocks < 1) march_blocks = 1;
     march_kernel<<<march_blocks, 256, 0, st>>>(v, d_campos, d_raydir, d_tmid, q->R, q->D, q->SR, q->K,
                                                                 q->tmid_stride, q->pad_outputs, d_sample_pidx, d_sample_loc_w,

@@ -285,6 +285,11 @@ int hnr_proj_rows(const float *d_sample_loc_w, const int32_t *d_vs_item, const i
 /* Probe (parity evidence): q_hnr[i] = the library's divide-free correctly rounded quotient (hnr_div, csrc/hnr_common.h: what chain_gather_kernel and
  * train_ksum_bwd_kernel divide with instead of the v_div_scale / v_div_fmas expansion), q_ieee[i] = num[i] / den[i] as the compiler expands it. */
 int hnr_div_probe(const float *d_num, const float *d_den, int n, float *d_q_hnr, float *d_q_ieee, void *stream);
+/* ... and for the other two divisions of the device code: cell_hnr[i] = the query kernels' cell index floor((p[i] - origin) / c[i]) (hnr_div_cell inside
+ * cell_coord; INT32_MIN beyond +-2e9 / NaN), cell_ieee[i] = the same expression with the compiler's division; q64_* = hnr_div64 (the loss kernels' means)
+ * beside the compiler's fp64 division on operands derived from p, c. */
+int hnr_div_probe2(const float *d_p, const float *d_c, float origin, int n, int32_t *d_cell_hnr, int32_t *d_cell_ieee, double *d_q64_hnr, double *d_q64_ieee,
+                   void *stream);
 
 /* Probe (parity evidence, not on the render path): the integer pixel every (view v, valid sample s) row of the merge stage gathers,
  * d_pix[(v * cap_samples + s) * 2 + {0,1}] = (px, py), or (-1, -1) where the reference's bounds rule masks the row -- computed by the one

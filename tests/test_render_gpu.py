@@ -240,3 +240,36 @@ def test_divide_free_quotient_is_the_correctly_rounded_one():
     same = lambda x, y: (x.view(np.uint32) == y.view(np.uint32)) | (np.isnan(x) & np.isnan(y))
     assert same(b, want).all(), "the compiler's division is not IEEE on %d pairs" % int((~same(b, want)).sum())
     assert same(a, want).all(), int((~same(a, want)).sum())
+
+
+def test_cell_index_and_fp64_quotients_equal_the_compiler_divisions():
+    """The other two members of hnr_div's family (round-4 advice: they had no test): the query kernels' cell index floor((p - o) / c) through hnr_div_cell
+    (grid build, march, k-NN: a wrong cell at a voxel border changes index sets) and hnr_div64 (the loss kernels' scalar means), each beside the
+    compiler's division of the same operands on the device: identical cell indices -- also for quotients beyond +-2e9, NaN / inf positions and the
+    exponent-range ends hnr_div_cell's comment argues about -- and bit-identical fp64 quotients."""
+    from hybridneuralrendering_amd import _lib
+    L, p = _lib.lib(), _lib.ptr
+    rng = np.random.default_rng(1)
+    n = 1 << 21
+    pos = np.concatenate([rng.uniform(-12, 12, n), rng.standard_normal(n // 4) * np.exp2(rng.integers(-120, 120, n // 4)),
+                          np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1e-45, -1e-45, 3e38, -3e38, 0.016, 0.032, 0.048])]).astype(np.float32)
+    cell = np.concatenate([rng.choice(np.array([0.004, 0.008, 0.016, 0.032, 0.05, 1.0], np.float32), n), np.exp2(rng.uniform(-20, 20, n // 4)).astype(np.float32),
+                           np.full(12, 0.016, np.float32)]).astype(np.float32)
+    # positions ON cell borders (p = o + k c up to rounding): where a last-bit difference of the quotient would change the floor
+    k = rng.integers(-700, 700, 1 << 18).astype(np.float32)
+    cb = rng.choice(np.array([0.004, 0.008, 0.016, 0.032], np.float32), 1 << 18)
+    origin = np.float32(-2.735034)
+    pos = np.concatenate([pos, (origin + k * cb).astype(np.float32)]); cell = np.concatenate([cell, cb])
+    dp, dc = torch.from_numpy(pos).cuda(), torch.from_numpy(cell).cuda()
+    ch, ci = torch.empty(pos.shape, dtype=torch.int32, device="cuda"), torch.empty(pos.shape, dtype=torch.int32, device="cuda")
+    qh, qi = torch.empty(pos.shape, dtype=torch.float64, device="cuda"), torch.empty(pos.shape, dtype=torch.float64, device="cuda")
+    _lib.check(L.hnr_div_probe2(p(dp), p(dc), float(origin), int(pos.size), p(ch), p(ci), p(qh), p(qi), _lib.stream()), "hnr_div_probe2")
+    a, b = ch.cpu().numpy(), ci.cpu().numpy()
+    assert (a == b).all(), "%d of %d cell indices differ (first: p=%r c=%r -> %d vs %d)" % (
+        int((a != b).sum()), a.size, pos[np.argmax(a != b)], cell[np.argmax(a != b)], a[np.argmax(a != b)], b[np.argmax(a != b)])
+    with np.errstate(all="ignore"):
+        want = np.floor((pos - origin).astype(np.float32) / cell)
+    fin = np.isfinite(want) & (np.abs(want) < 2e9)
+    assert (a[fin] == want[fin].astype(np.int64)).all() and (a[~fin] == np.iinfo(np.int32).min).all()
+    x, y = qh.cpu().numpy(), qi.cpu().numpy()
+    assert ((x.view(np.uint64) == y.view(np.uint64)) | (np.isnan(x) & np.isnan(y))).all()
