@@ -90,6 +90,7 @@ __global__ __launch_bounds__(256) void segment_sum_rows_det_kernel(const float *
 // minimum search, took 229 us on the C3 batch: 8 145 touched points with 27 rows at the median and up to 171 -- the chip waited for the few
 // waves with the long segments.)  Segments of more than SEG_LDS_ROWS rows: wave 0 alone, by repeated minimum search.
 constexpr int SEG_LDS_ROWS = 2048;
+constexpr int SEG_WAVE_ROWS = 16;       // segments up to this many rows: one wave, no barrier
 __global__ __launch_bounds__(256) void segment_sum_rows_csr_kernel(const float *__restrict__ A, int lda, const int32_t *__restrict__ row_list,
                                                                    const int32_t *__restrict__ seg_start, const int32_t *__restrict__ seg_count, int n_cols,
                                                                    int n_keys, const long long *__restrict__ d_nkeys, float *__restrict__ dst, int64_t dst_stride,
@@ -106,7 +107,49 @@ __global__ __launch_bounds__(256) void segment_sum_rows_csr_kernel(const float *
     const bool on = 4 * lane < n_cols, on2 = A2 && 4 * lane < n_cols2;
     const float *base = A + 4 * lane, *base2 = A2 + 4 * lane;
     auto add = [&](float4 &a, const float4 &v) { a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; };
-    for (int key = blockIdx.x; key < n_keys; key += gridDim.x) {
+    // Keys are taken four at a time, one per wave.  SHORT segments (<= SEG_WAVE_ROWS rows: what a batch of scattered patches produces -- config 5 touches
+    // 66 k points with ~5 rows each, where the workgroup-per-key form below spent its time in three barriers and an LDS sort per key: 458 us) are summed
+    // by their wave alone: ids in lanes, rank by comparison, rows added one after the other in ascending row order (a fixed order; for such a segment the
+    // sum is a plain left-to-right one instead of four quarter sums).  The longer ones of the four follow, each by the whole workgroup.
+    __shared__ int s_long[4];
+    for (int g = blockIdx.x * 4; g < n_keys; g += gridDim.x * 4) {
+        {
+            const int key = g + wave;
+            const int cnt = key < n_keys ? seg_count[key] : 0;
+            if (cnt > 0 && cnt <= SEG_WAVE_ROWS) {
+                const int lo = seg_start[key];
+                const int mine = lane < cnt ? row_list[lo + lane] : 0x7fffffff;
+                int rank = 0;
+                for (int j = 0; j < cnt; ++j) rank += __shfl(mine, j) < mine ? 1 : 0;
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), acc2 = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int e0 = 0; e0 < cnt; e0 += 4) {                      // four rows' loads in flight
+                    int r[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const unsigned long long b = __ballot(lane < cnt && rank == e0 + i);
+                        r[i] = b ? __shfl(mine, __ffsll((long long)b) - 1) : -1;
+                    }
+                    float4 v[4], v2[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        v[i] = (on && r[i] >= 0) ? *reinterpret_cast<const float4 *>(base + (size_t)r[i] * lda) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        v2[i] = (on2 && r[i] >= 0) ? *reinterpret_cast<const float4 *>(base2 + (size_t)r[i] * lda2) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) if (r[i] >= 0) { add(acc, v[i]); add(acc2, v2[i]); }
+                }
+                if (on) {
+                    reinterpret_cast<float4 *>(dst + (size_t)key * dst_stride)[lane] = acc;
+                    mx = fmaxf(fmaxf(mx, fmaxf(fabsf(acc.x), fabsf(acc.y))), fmaxf(fabsf(acc.z), fabsf(acc.w)));
+                }
+                if (on2) reinterpret_cast<float4 *>(dst2 + (size_t)key * dst_stride2)[lane] = acc2;
+            }
+            if (lane == 0) s_long[wave] = (cnt > SEG_WAVE_ROWS || (cnt == 0 && key < n_keys)) ? key : -1;
+        }
+        __syncthreads();
+      for (int kk = 0; kk < 4; ++kk) {
+        const int key = s_long[kk];
+        if (key < 0) continue;                                             // (uniform over the workgroup: read from LDS)
         const int lo = seg_start[key], cnt = seg_count[key];
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), acc2 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (cnt <= SEG_LDS_ROWS) {
@@ -171,10 +214,15 @@ __global__ __launch_bounds__(256) void segment_sum_rows_csr_kernel(const float *
             if (on2) reinterpret_cast<float4 *>(dst2 + (size_t)key * dst_stride2)[lane] = t2;
         }
         __syncthreads();                                 // the LDS lists and partials are reused by the block's next key
+      }
+        __syncthreads();                                 // (s_long is rewritten by the next group)
     }
-    if (absmax && wave == 0) {
+    if (absmax) {                                         // (every wave may hold a maximum now)
+        __shared__ float s_mx[4];
         for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-        if (lane == 0) absmax_publish(absmax, mx);
+        if (lane == 0) s_mx[wave] = mx;
+        __syncthreads();
+        if (tid == 0) absmax_publish(absmax, fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3])));
     }
 }
 
@@ -297,7 +345,7 @@ int segment_sum_rows_csr_dc(const float *d_A, int lda, const int32_t *d_row_list
 {
     if (keys_cap <= 0) return HNR_OK;
     if (d_A2 && (n_cols2 <= 0 || n_cols2 > 256 || (n_cols2 & 3))) { set_error("segment_sum_rows_csr: bad second matrix"); return HNR_ERR_BADARG; }
-    int64_t blocks = keys_cap;                       // one workgroup per key, a fixed grid striding over the keys the device count leaves
+    int64_t blocks = (keys_cap + 3) / 4;             // four keys per workgroup round, a fixed grid striding over the keys the device count leaves
     if (blocks > 4096) blocks = 4096;
     segment_sum_rows_csr_kernel<<<(int)blocks, 256, 0, st>>>(d_A, lda, d_row_list, d_seg_start, d_seg_count, n_cols, keys_cap, d_nkeys, d_dst, dst_stride,
                                                                                    d_A2, lda2, d_A2 ? n_cols2 : 0, d_dst2, dst_stride2, d_absmax);
