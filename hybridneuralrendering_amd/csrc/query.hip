@@ -575,7 +575,15 @@ __device__ __forceinline__ int nb_chunk_size(int n, int n_groups)
     return c < 64 ? 64 : (c > NB_CHUNK ? NB_CHUNK : c);
 }
 constexpr int NB_BINS = 32;
-template <int K, int SORTED, int BIN>
+// values of the other lanes of a quad (quad_perm DPP; CTRL = sel0 | sel1 << 2 | sel2 << 4 | sel3 << 6)
+template <int CTRL>
+__device__ __forceinline__ float quad_f(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true)); }
+template <int CTRL>
+__device__ __forceinline__ int quad_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+// XP: the four lanes of a quad FETCH each other's candidates -- with instruction k every lane of the quad reads one record of quad-lane k's run (one 64-byte
+// line per quad and instruction instead of four) -- and the records change hands through a per-wave LDS staging area (row stride 80 bytes): the address unit
+// sees a quarter of the lines, and every lane still keeps its own list (31 instructions per candidate and LANE, not 14 per candidate and QUAD).
+template <int K, int SORTED, int BIN, int XP = 0>
 __global__ __launch_bounds__(256) void knn_nb_kernel(GridView g, const int32_t *__restrict__ work, const float *__restrict__ loc,
                                                      int SR, float radius2, int layers, int32_t *__restrict__ pidx, int8_t *__restrict__ ray_mask,
                                                      const unsigned long long *__restrict__ counts, unsigned long long *__restrict__ block_stats)
@@ -584,6 +592,7 @@ __global__ __launch_bounds__(256) void knn_nb_kernel(GridView g, const int32_t *
     __shared__ int32_t s_item[BIN ? NB_CHUNK : 1];
     __shared__ uint2 s_rg[BIN ? NB_CHUNK : 1];
     __shared__ int s_hist[BIN == 2 ? NB_BINS * 32 : NB_BINS], s_base[BIN == 2 ? NB_BINS * 32 : NB_BINS], s_wsum[4];
+    __shared__ float4 s_stage[XP ? 256 * 5 : 1];
     const int n = (int)counts[HNR_CNT_SAMPLES];
     unsigned n_cells = 0, n_cand = 0, n_nb = 0, n_sv = 0;
     auto lookup = [&](int item) -> uint2 {
@@ -598,8 +607,9 @@ __global__ __launch_bounds__(256) void knn_nb_kernel(GridView g, const int32_t *
         const uint2 rg = g.nb_rng[have ? rec.z + (uint32_t)__popcll(bb & ((1ull << b) - 1ull)) : 0u];
         return have ? rg : make_uint2(0u, 0u);
     };
-    auto one = [&](int item, uint2 rg) {
-        const float cx = loc[3 * (size_t)item], cy = loc[3 * (size_t)item + 1], cz = loc[3 * (size_t)item + 2];
+    auto one = [&](int item, uint2 rg) {                          // XP: item < 0 = an idle lane that only helps its quad fetch (rg = {0, 0})
+        const size_t lo3 = 3 * (size_t)(item < 0 ? 0 : item);
+        const float cx = loc[lo3], cy = loc[lo3 + 1], cz = loc[lo3 + 2];
         const int start = (int)rg.x;
         const int c0 = (int)(rg.y & 63u), tot = (int)((rg.y >> 6) & 2047u);
         typename std::conditional<SORTED != 0, KSorted<K>, KBuf<K>>::type kb;
@@ -612,6 +622,34 @@ __global__ __launch_bounds__(256) void knn_nb_kernel(GridView g, const int32_t *
                 const float v = __fadd_rn(__fadd_rn(__fmul_rn(xv, xv), __fmul_rn(yv, yv)), __fmul_rn(zv, zv));
                 kb.offer_sel(v, __float_as_int(p.w), ok && (radius2 == 0.f || v <= radius2));
             };
+            if constexpr (XP != 0) {
+                // lo is a multiple of 4 (runs and both of their parts start on a line); a lane that has nothing left keeps fetching its first line
+                const int q = threadIdx.x & 3;
+                float4 *wr = s_stage + (size_t)(threadIdx.x & ~3) * 5 + q, *rd = s_stage + (size_t)threadIdx.x * 5;
+                auto fetch = [&](int jj, float4 (&rec)[4]) {
+                    rec[0] = g.nb_pts[quad_i<0x00>(jj) + q]; rec[1] = g.nb_pts[quad_i<0x55>(jj) + q];
+                    rec[2] = g.nb_pts[quad_i<0xaa>(jj) + q]; rec[3] = g.nb_pts[quad_i<0xff>(jj) + q];
+                };
+                bool live = j < hi;
+                float4 rec[4];
+                fetch(live ? j : lo, rec);
+                while (__builtin_amdgcn_ballot_w64(live) != 0ull) {
+                    float4 p[4];
+                    wr[0] = rec[0]; wr[5] = rec[1]; wr[10] = rec[2]; wr[15] = rec[3];      // record q of quad-lane k's line -> row of lane k, slot q
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    p[0] = rd[0]; p[1] = rd[1]; p[2] = rd[2]; p[3] = rd[3];
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();                                        // (the rows are rewritten by the next trip)
+                    const int jn = j + 4;
+                    const bool ln = live && jn < hi;
+                    fetch(ln ? jn : lo, rec);
+                    consume(p[0], live); consume(p[1], live && j + 1 < hi); consume(p[2], live && j + 2 < hi); consume(p[3], live && j + 3 < hi);
+                    j = jn; live = ln;
+                }
+                return;
+            }
             // unconditional loads (an exhausted lane re-reads record 0): four requests stay in flight across the insertion code
             int a0 = gen(), a1 = gen(), a2 = gen(), a3 = gen();
             float4 p0 = g.nb_pts[a0 < 0 ? 0 : a0], p1 = g.nb_pts[a1 < 0 ? 0 : a1], p2 = g.nb_pts[a2 < 0 ? 0 : a2], p3 = g.nb_pts[a3 < 0 ? 0 : a3];
@@ -628,13 +666,17 @@ __global__ __launch_bounds__(256) void knn_nb_kernel(GridView g, const int32_t *
         kb.sync_kid();
         n_cells += (rg.y >> 22) & 1u;
         n_cand += (unsigned)c0;
-        if (layers > 1 && kb.kid < K) {                          // reference: `if (kid >= K) break;` after a layer
+        const bool shell1 = layers > 1 && kb.kid < K;             // reference: `if (kid >= K) break;` after a layer
+        if (XP != 0 || shell1) {                                 // (XP: every lane takes part in its quad's fetches, with an empty range if it is done)
             const int s1 = start + ((c0 + 3) & ~3);              // (the own-cell part of a run is padded to a multiple of 4 entries)
-            run(s1, s1 + tot - c0);
+            run(s1, shell1 ? s1 + tot - c0 : s1);
+        }
+        if (shell1) {
             kb.sync_kid();
             n_cells += (rg.y >> 17) & 31u;
             n_cand += (unsigned)(tot - c0);
         }
+        if (item < 0) return;
         {
             int32_t *o = pidx + (size_t)item * K;
 #pragma unroll
@@ -694,7 +736,11 @@ __global__ __launch_bounds__(256) void knn_nb_kernel(GridView g, const int32_t *
                 if (item[q] >= 0) { const int pos = s_base[key[q]] + rank[q]; s_item[pos] = item[q]; s_rg[pos] = rg[q]; }
             __syncthreads();
             const int m = min(chunk, n - w0);
-            for (int t = threadIdx.x; t < m; t += 256) one(s_item[t], s_rg[t]);
+            if constexpr (XP != 0) {
+                for (int t0 = 0; t0 < m; t0 += 256) { const int t = t0 + (int)threadIdx.x; const bool ok = t < m; one(ok ? s_item[t] : -1, ok ? s_rg[t] : make_uint2(0u, 0u)); }
+            } else {
+                for (int t = threadIdx.x; t < m; t += 256) one(s_item[t], s_rg[t]);
+            }
             __syncthreads();
         }
     } else {
@@ -730,10 +776,6 @@ __global__ __launch_bounds__(256) void knn_nb_kernel(GridView g, const int32_t *
 // list itself spread over the quad (lane i holds entries 2 i and 2 i + 1) with the neighbours' entries and the broadcast candidate moving through
 // quad_perm DPP -- 14 instructions per candidate and quad instead of 31 per candidate and lane.  Ascending (d2, enumeration order) exactly as KSorted:
 // a candidate is placed before the entries it is STRICTLY smaller than.
-template <int CTRL>
-__device__ __forceinline__ float quad_f(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true)); }
-template <int CTRL>
-__device__ __forceinline__ int quad_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
 
 struct QuadList {
     float a, b;           // entries 2 q and 2 q + 1 of the quad's ascending list (q = lane & 3)
@@ -1116,6 +1158,10 @@ extern "C" int hnr_march_query(const hnr_grid *g, const float *d_campos, const f
             if (blocks < 1) blocks = 1;
         }  // HNR_KNN=5: work-list order; 7: sorted by list length; 8: ... and by cell
 #define HNR_NB_LAUNCH(S_, B_) knn_nb_kernel<8, S_, B_><<<blocks, 256, 0, st>>>(v, d_work, d_sample_loc_w, q->SR, q->radius2, layers, d_sample_pidx, d_ray_mask, cnt, block_stats)
+        if (knn_sel == 9) {                                       // one lane per sample, sorted by list length, candidates fetched quad-cooperatively
+            if (q->knn_order == 1) knn_nb_kernel<8, 1, 1, 1><<<blocks, 256, 0, st>>>(v, d_work, d_sample_loc_w, q->SR, q->radius2, layers, d_sample_pidx, d_ray_mask, cnt, block_stats);
+            else knn_nb_kernel<8, 0, 1, 1><<<blocks, 256, 0, st>>>(v, d_work, d_sample_loc_w, q->SR, q->radius2, layers, d_sample_pidx, d_ray_mask, cnt, block_stats);
+        } else
         // HNR_KNN: 4 (default) quad-per-sample kernel for the set-exact order; 6 the same in work-list order; 7 / 5 one lane per sample, sorted by list length / not
         if (q->knn_order == 1 && (knn_sel == 4 || knn_sel == 6)) {
             if (knn_sel == 4) knn_quad_kernel<1><<<blocks, 256, 0, st>>>(v, d_work, d_sample_loc_w, q->SR, q->radius2, layers, d_sample_pidx, d_ray_mask, cnt, block_stats);
