@@ -72,16 +72,31 @@ def spawn_ranks(args):
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
+    import tempfile
     procs = []
-    for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].communicate()[0]
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0.decode("utf-8", "replace"))
-    sys.stdout.flush()
+    with tempfile.TemporaryFile() as out0:
+        for r in range(args.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=out0 if r == 0 else subprocess.DEVNULL))
+        # a rank that dies (an exception in a timed step) must not leave the others waiting in a collective until RCCL's watchdog gives up
+        # (round-4 advice): the parent watches all of them and ends the survivors -- its own children, by PID -- as soon as one has failed
+        while True:
+            rcs = [p.poll() for p in procs]
+            if all(rc is not None for rc in rcs):
+                break
+            if any(rc not in (None, 0) for rc in rcs):
+                time.sleep(2.0)                                # (let the failing rank's neighbours fail by themselves first: their messages are the useful ones)
+                for p in procs:
+                    if p.poll() is None:
+                        p.kill()
+                rcs = [p.wait() for p in procs]
+                break
+            time.sleep(0.2)
+        out0.seek(0)
+        sys.stdout.write(out0.read().decode("utf-8", "replace"))
+        sys.stdout.flush()
     if any(rcs):
         raise SystemExit("bench.py: rank exit codes %s" % rcs)
 

@@ -473,3 +473,28 @@ def test_committed_pmc_files_hold_the_kernels_bench_looks_up():
     assert any("chain_ws_kernel<0>" in k for k in fr) and any("march_kernel" in k for k in fr) and any("knn_quad_kernel" in k for k in fr), list(fr)
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert '"h2wgrad_dma_kernel" in k' in src and "chain_ws_kernel<0>" in src
+
+
+def test_bench_parent_ends_all_ranks_when_one_fails():
+    """`python bench.py --gpus 2` without a launcher spawns the ranks itself.  A rank that dies must not leave the others waiting in a collective: the
+    parent watches its children and ends the survivors (round-4 advice).  Here (no GPU) rank 1 is made to outlive rank 0 by far; the parent must come back
+    promptly with the exit codes instead of waiting for it."""
+    import time
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU (both ranks fail at once on it: `bench.py needs a GPU`)")
+    # rank 1 is put to sleep before it runs a line of bench.py: a sitecustomize on its PYTHONPATH
+    hook = os.path.join(ROOT, "tests", "_sleepy_rank")
+    os.makedirs(hook, exist_ok=True)
+    with open(os.path.join(hook, "sitecustomize.py"), "w") as f:
+        f.write("import os, time\nif os.environ.get('RANK') == '1' and os.environ.get('HNR_TEST_SLEEPY_RANK') == '1':\n    time.sleep(600)\n")
+    try:
+        t0 = time.time()
+        env = dict(os.environ, PYTHONPATH=hook + os.pathsep + os.environ.get("PYTHONPATH", ""), HNR_TEST_SLEEPY_RANK="1")
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], cwd=ROOT, capture_output=True, text=True,
+                           timeout=300, env=env)
+        assert p.returncode != 0 and "rank exit codes" in (p.stderr + p.stdout), (p.returncode, p.stderr[-500:])
+        assert time.time() - t0 < 120, "the parent waited for the surviving rank"
+    finally:
+        import shutil
+        shutil.rmtree(hook, ignore_errors=True)
