@@ -789,8 +789,8 @@ def main():
         if lin:
             n = sum(v["launches"] for v in lin.values())
             t_lin = dict(hbm_bytes=sum(v["hbm_bytes"] * v["launches"] for v in lin.values()) / max(n, 1))
-        # (round 5: the k-NN over the grid's 3x3x3 neighbourhood lists -- knn_quad_kernel for the set-exact order, knn_nb_kernel<8,0,1> for the reference order)
-        knn_name = "knn_quad_kernel" if rnd.knn_order == "sorted" else "knn_nb_kernel<8, 0"
+        # (round 5: the k-NN over the grid's 3x3x3 neighbourhood lists: knn_nb_kernel<8, order, 2>)
+        knn_name = "knn_nb_kernel<8, 1" if rnd.knn_order == "sorted" else "knn_nb_kernel<8, 0"
         t_q = [v for k, v in pmc.items() if "march_kernel" in k or knn_name in k]
         if counts is not None:
             n_rows, n_valid = int(counts[CNT["NEIGHBOURS"]]), int(counts[CNT["SAMPLES_VALID"]])
@@ -890,14 +890,14 @@ def main():
                                   neighbour_order=("sorted: the reference's neighbour sets in ascending (d2, enumeration) order (hnr_query_params.knn_order = 1)"
                                                    if fo else "reference: slot for slot the reference's insertion history"),
                                   kernel="hnr_march_query: march_kernel + worklist scans + %s (k-NN over the grid's 3x3x3 neighbourhood lists)" % (
-                                      "knn_quad_kernel" if fo else "knn_nb_kernel<8,0,1>"),
+                                      "knn_nb_kernel<8,1,2>" if fo else "knn_nb_kernel<8,0,2>"),
                                   timing="HIP events around 5 back-to-back hnr_march_query launches on the bench frame (in the frame the query overlaps the "
                                          "feature-pyramid rebuild on a side stream: in_frame_ms)")
                     roof_q["sorted_neighbour_order"] = dict(avg_launch_ms=round(ms_o[1], 4), reference_order_ms_same_loop=round(ms_o[0], 4),
                                                             achieved=round(alg / (ms_o[1] * 1e-3) / 1e9, 1), frac=round(alg / (ms_o[1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                                            note="hnr_query_params.knn_order = 1: the reference's neighbour sets in ascending (d2, enumeration) order, a quad of lanes per "
-                                                                 "sample with the sorted list spread over the quad (csrc/query.hip knn_quad_kernel); reference order: one lane per sample "
-                                                                 "replaying the reference's farthest-first replacement; counters in profiles/r05_query_pmc.txt")
+                                                            note="hnr_query_params.knn_order = 1: the reference's neighbour sets in ascending (d2, enumeration) order (v_med3 insertion network); reference "
+                                                                 "order: the replay of the reference's farthest-first replacement; both one lane per sample over the grid's neighbourhood "
+                                                                 "lists, samples sorted by list length and cell inside a workgroup; counters in profiles/r05_query_pmc.txt")
         # one-off work that is amortised over frames (rebuilt only when the cloud / the weights change), timed once here
         amort = {}
         def _timed(fn):

@@ -593,6 +593,9 @@ __global__ __launch_bounds__(256) void knn_nb_kernel(GridView g, const int32_t *
     __shared__ uint2 s_rg[BIN ? NB_CHUNK : 1];
     __shared__ int s_hist[BIN == 2 ? NB_BINS * 32 : NB_BINS], s_base[BIN == 2 ? NB_BINS * 32 : NB_BINS], s_wsum[4];
     __shared__ float4 s_stage[XP ? 256 * 5 : 1];
+    constexpr int NBH = 1024;                                      // BIN == 3: hash slots, one per distinct cell of a round
+    __shared__ unsigned s_hkey[BIN == 3 ? NBH : 1];
+    __shared__ int s_hcnt[BIN == 3 ? NBH : 1], s_hpos[BIN == 3 ? NBH : 1];
     const int n = (int)counts[HNR_CNT_SAMPLES];
     unsigned n_cells = 0, n_cand = 0, n_nb = 0, n_sv = 0;
     auto lookup = [&](int item) -> uint2 {
@@ -689,7 +692,65 @@ __global__ __launch_bounds__(256) void knn_nb_kernel(GridView g, const int32_t *
             ++n_sv;
         }
     };
-    if constexpr (BIN != 0) {
+    if constexpr (BIN == 3) {
+        // BIN == 3: samples of one CELL next to each other, cells in the order of their list length (longest first).  The samples of a round find their cell
+        // in an LDS hash table keyed by the run address (one slot per distinct cell, the slot counts its samples and hands out ranks), the cells take their
+        // place inside their list-length bin with one atomic each, and a sample lands at bin base + cell base + rank.  Neighbouring lanes then read the SAME
+        // records: a load instruction of a wave touches fewer cache lines than with the cells interleaved (BIN == 2 groups by a 5-bit hash only: the bins of
+        // the common list lengths still interleave ~5 cells).
+        const int chunk = nb_chunk_size(n, (int)gridDim.x);
+        for (int w0 = blockIdx.x * chunk; w0 < n; w0 += gridDim.x * chunk) {
+            for (int i = threadIdx.x; i < NBH; i += 256) { s_hkey[i] = 0u; s_hcnt[i] = 0; }
+            if (threadIdx.x < NB_BINS) s_hist[threadIdx.x] = 0;
+            __syncthreads();
+            int item[4], slot[4], rank[4];
+            uint2 rg[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {                          // (all four lookups in flight)
+                const int wi = q * 256 + (int)threadIdx.x, w = w0 + wi;
+                item[q] = (wi < chunk && w < n) ? work[w] : -1;
+                rg[q] = item[q] >= 0 ? lookup(item[q]) : make_uint2(0u, 0u);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                slot[q] = 0; rank[q] = 0;
+                if (item[q] >= 0) {
+                    const int c0 = (int)(rg[q].y & 63u), tot = (int)((rg[q].y >> 6) & 2047u);
+                    const int trips = ((c0 + 3) >> 2) + ((tot - c0 + 3) >> 2);
+                    const int bin = NB_BINS - 1 - (trips < NB_BINS - 1 ? trips : NB_BINS - 1);      // longest lists first
+                    const unsigned key = rg[q].y ? rg[q].x + 1u : 0x7fffffffu;                      // (run addresses are unique per cell; no run: one slot for all)
+                    int sl = (int)((key * 2654435761u) >> 22) & (NBH - 1);
+                    for (;;) {
+                        const unsigned old = atomicCAS(&s_hkey[sl], 0u, key);
+                        if (old == 0u) { s_hpos[sl] = bin; break; }
+                        if (old == key) break;
+                        sl = (sl + 1) & (NBH - 1);
+                    }
+                    slot[q] = sl;
+                    rank[q] = atomicAdd(&s_hcnt[sl], 1);
+                }
+            }
+            __syncthreads();
+            for (int i = threadIdx.x; i < NBH; i += 256)
+                if (s_hkey[i] != 0u) { const int bin = s_hpos[i]; s_hpos[i] = atomicAdd(&s_hist[bin], s_hcnt[i]) | (bin << 16); }
+            __syncthreads();
+            if (threadIdx.x < 64) {                                // exclusive scan of the 32 bin totals
+                const int t = threadIdx.x;
+                const int v = t < NB_BINS ? s_hist[t] : 0;
+                int inc = v;
+                for (int o = 1; o < NB_BINS; o <<= 1) { const int u = __shfl_up(inc, o); if (t >= o) inc += u; }
+                if (t < NB_BINS) s_base[t] = inc - v;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (item[q] >= 0) { const int hp = s_hpos[slot[q]]; const int pos = s_base[hp >> 16] + (hp & 0xffff) + rank[q]; s_item[pos] = item[q]; s_rg[pos] = rg[q]; }
+            __syncthreads();
+            const int m = min(chunk, n - w0);
+            for (int t = threadIdx.x; t < m; t += 256) one(s_item[t], s_rg[t]);
+            __syncthreads();
+        }
+    } else if constexpr (BIN != 0) {
         // BIN == 2: buckets = (loop trips, 5 bits of the cell's run address): samples of one cell share a bucket and end up in neighbouring lanes, so the
         // four lanes of a quad mostly read the SAME record with a load instruction (one cache line per quad instead of four)
         constexpr int NBK = BIN == 2 ? NB_BINS * 32 : NB_BINS;
@@ -1130,7 +1191,7 @@ extern "C" int hnr_march_query(const hnr_grid *g, const float *d_campos, const f
     HNR_LAUNCH_CHECK();
     // K = 8 with a 3x3x3 neighbourhood (every shipped config): the pipelined kernel (HNR_KNN=1: the generic one-cell-at-a-time kernel)
     static int knn_sel = -1;
-    if (knn_sel < 0) { const char *e = getenv("HNR_KNN"); knn_sel = e ? atoi(e) : 4; }
+    if (knn_sel < 0) { const char *e = getenv("HNR_KNN"); knn_sel = e ? atoi(e) : 8; }
     if (q->knn_order == 1 && !(q->K == 8 && layers <= 2)) {
         set_error("hnr_march_query: knn_order = 1 (canonical neighbour order) is built for K = 8 with a 3x3x3 neighbourhood (K=%d)", q->K);
         return HNR_ERR_BADARG;
@@ -1147,7 +1208,7 @@ extern "C" int hnr_march_query(const hnr_grid *g, const float *d_campos, const f
     if (q->K == 8 && layers <= 2 && v.nb_pts && knn_sel != 1 && knn_sel != 3) {
         // the grid carries 3x3x3 neighbourhood lists (P <= 63): two lookups per sample, contiguous candidates (HNR_KNN=3: the 27-cell walk below)
         int blocks = knn_blocks(max_items);
-        const int bin = knn_sel == 5 ? 0 : (knn_sel == 8 ? 2 : 1);
+        const int bin = knn_sel == 5 ? 0 : (knn_sel == 8 ? 2 : (knn_sel == 10 ? 3 : 1));
         {   // workgroups per CU of the persistent k-NN kernels (HNR_KNN_WG_PER_CU; 8 = what knn_blocks caps at).  Measured for the quad kernel: 6 (what its
             // 26 KB of LDS let a CU hold at once) 0.423 ms, 8 0.35 ms -- the workgroups that wait for a slot fill the tail of the first ones
             static int wg_per_cu = -1;
@@ -1162,12 +1223,14 @@ extern "C" int hnr_march_query(const hnr_grid *g, const float *d_campos, const f
             if (q->knn_order == 1) knn_nb_kernel<8, 1, 1, 1><<<blocks, 256, 0, st>>>(v, d_work, d_sample_loc_w, q->SR, q->radius2, layers, d_sample_pidx, d_ray_mask, cnt, block_stats);
             else knn_nb_kernel<8, 0, 1, 1><<<blocks, 256, 0, st>>>(v, d_work, d_sample_loc_w, q->SR, q->radius2, layers, d_sample_pidx, d_ray_mask, cnt, block_stats);
         } else
-        // HNR_KNN: 4 (default) quad-per-sample kernel for the set-exact order; 6 the same in work-list order; 7 / 5 one lane per sample, sorted by list length / not
+        // HNR_KNN: 8 (default) one lane per sample, samples sorted by list length and by a hash of their cell; 10 ... exactly by cell; 7 by list length only; 5 work-list
+        // order; 9 candidates fetched quad-cooperatively through LDS; 4 quad-per-sample kernel (set-exact order only), 6 the same in work-list order; 3 / 1 the 27-cell walks.
+        // Same-run query times on the bench frame (ms): 8 0.586 - 0.606 | 4 0.603 - 0.623 | 10 0.609 | 7 0.614 - 0.640 | 5 0.625 | 9 1.18 | 3 0.72 - 0.75
         if (q->knn_order == 1 && (knn_sel == 4 || knn_sel == 6)) {
             if (knn_sel == 4) knn_quad_kernel<1><<<blocks, 256, 0, st>>>(v, d_work, d_sample_loc_w, q->SR, q->radius2, layers, d_sample_pidx, d_ray_mask, cnt, block_stats);
             else knn_quad_kernel<0><<<blocks, 256, 0, st>>>(v, d_work, d_sample_loc_w, q->SR, q->radius2, layers, d_sample_pidx, d_ray_mask, cnt, block_stats);
-        } else if (q->knn_order == 1) { if (bin == 2) HNR_NB_LAUNCH(1, 2); else if (bin) HNR_NB_LAUNCH(1, 1); else HNR_NB_LAUNCH(1, 0); }
-        else { if (bin == 2) HNR_NB_LAUNCH(0, 2); else if (bin) HNR_NB_LAUNCH(0, 1); else HNR_NB_LAUNCH(0, 0); }
+        } else if (q->knn_order == 1) { if (bin == 3) HNR_NB_LAUNCH(1, 3); else if (bin == 2) HNR_NB_LAUNCH(1, 2); else if (bin) HNR_NB_LAUNCH(1, 1); else HNR_NB_LAUNCH(1, 0); }
+        else { if (bin == 3) HNR_NB_LAUNCH(0, 3); else if (bin == 2) HNR_NB_LAUNCH(0, 2); else if (bin) HNR_NB_LAUNCH(0, 1); else HNR_NB_LAUNCH(0, 0); }
 #undef HNR_NB_LAUNCH
         knn_finalize_kernel<<<1, 256, 0, st>>>(block_stats, blocks, cnt);
         HNR_LAUNCH_CHECK();

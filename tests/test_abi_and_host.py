@@ -470,7 +470,7 @@ def test_committed_pmc_files_hold_the_kernels_bench_looks_up():
     tr = json.load(open(newest("train_traffic.json")))["kernels"]
     assert any("h2wgrad_dma_kernel" in k for k in tr), list(tr)
     fr = json.load(open(newest("traffic.json")))["kernels"]
-    assert any("chain_ws_kernel<0>" in k for k in fr) and any("march_kernel" in k for k in fr) and any("knn_quad_kernel" in k for k in fr), list(fr)
+    assert any("chain_ws_kernel<0>" in k for k in fr) and any("march_kernel" in k for k in fr) and any("knn_nb_kernel<8, 1" in k for k in fr), list(fr)
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert '"h2wgrad_dma_kernel" in k' in src and "chain_ws_kernel<0>" in src
 

@@ -348,7 +348,7 @@ def test_every_knn_kernel_variant_returns_the_same_bits(tmp_path):
         assert p.returncode == 0, p.stderr[-2000:]
         return [l for l in p.stdout.splitlines() if l.startswith("VARIANT")][0].split()[1:]
     base = run()
-    for env in (dict(HNR_KNN="3"), dict(HNR_KNN="5"), dict(HNR_KNN="6"), dict(HNR_KNN="7"), dict(HNR_KNN="8"), dict(HNR_KNN="9"), dict(HNR_NB_LISTS="0"), dict(HNR_MARCH_PROBE="2"),
+    for env in (dict(HNR_KNN="3"), dict(HNR_KNN="4"), dict(HNR_KNN="5"), dict(HNR_KNN="6"), dict(HNR_KNN="7"), dict(HNR_KNN="9"), dict(HNR_KNN="10"), dict(HNR_NB_LISTS="0"), dict(HNR_MARCH_PROBE="2"),
                 dict(HNR_MARCH_RAYS_PER_WAVE="1"), dict(HNR_MARCH_RAYS_PER_WAVE="64")):
         got = run(**env)
         assert got[:2] == base[:2], (env, got, base)
