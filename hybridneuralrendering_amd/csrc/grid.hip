@@ -310,6 +310,20 @@ __global__ __launch_bounds__(256) void nb_lists_kernel(GridView g, const unsigne
     else nb_cnt[slot] = c0p + ((total - c0 + 3u) & ~3u);
 }
 
+// brick_near (GridView): one thread per brick, OR over the 5x5x5 bricks around it of "the dilated mask has a cell here"
+__global__ void brick_near_kernel(GridView g, const unsigned long long *__restrict__ dil, int bx, uint32_t n_words, uint8_t *__restrict__ near)
+{
+    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_words) return;
+    const int wz = (int)(w % (uint32_t)g.bz), wy = (int)((w / (uint32_t)g.bz) % (uint32_t)g.by), wx = (int)(w / ((uint32_t)g.bz * (uint32_t)g.by));
+    bool any = false;
+    for (int x = max(0, wx - 2); x <= min(bx - 1, wx + 2) && !any; ++x)
+        for (int y = max(0, wy - 2); y <= min(g.by - 1, wy + 2) && !any; ++y)
+            for (int z = max(0, wz - 2); z <= min(g.bz - 1, wz + 2); ++z)
+                if (dil[((size_t)x * g.by + y) * g.bz + z] != 0ull) { any = true; break; }
+    near[w] = any ? 1 : 0;
+}
+
 __global__ void pack_dil_rec_kernel(const unsigned long long *__restrict__ dil, const uint32_t *__restrict__ dprefix, uint32_t n_words, uint4 *rec)
 {
     uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
@@ -456,6 +470,17 @@ static int build_impl(hnr_grid *g, const float *d_xyz, int n, hipStream_t st)
     g->dil = dil.release();
     g->cell_rng = cell_rng.release();
     g->pts = pts.release();
+    // ---- brick-level "anything near" mask for the march's coarse level (GridView::brick_near).  Only with HNR_MARCH_TWO_LEVEL=1: the two-level march
+    //      returns the same samples (tests/test_query_gpu.py runs it) and is NOT faster on the bench frame (0.242 vs 0.233 ms: a coarse probe costs what
+    //      a fine one does -- the three exact divisions -- and too many groups of a cluttered room lie within two bricks of the mask)
+    if (const char *e2 = getenv("HNR_MARCH_TWO_LEVEL"); e2 && atoi(e2) != 0) {
+        DevBuf<uint8_t> nearb;
+        GB_CHECK(nearb.alloc(n_words));
+        const GridView v1 = g->view();
+        brick_near_kernel<<<cdiv(n_words, TB), TB, 0, st>>>(v1, g->dil, g->bd[0], n_words, nearb.p);
+        GB_CHECK(hipGetLastError());
+        g->brick_near = nearb.release();
+    }
     // ---- 3x3x3 neighbourhood lists for the k-NN (hnr_common.h, GridView::nb_*): count, scan, fill.  Needs P <= 63 (the packed record) and the lists to
     //      fit 32-bit indices; HNR_NB_LISTS=0 skips them (the k-NN then walks the 27 cells itself: knn3_kernel).
     int64_t nb_bytes = 0;
@@ -501,7 +526,7 @@ static int build_impl(hnr_grid *g, const float *d_xyz, int n, hipStream_t st)
     g->st.n_cells_over_P = (int64_t)h_scal[1];
     g->st.n_dilated = (int64_t)h_scal[2];
     g->st.n_words = n_words;
-    g->st.bytes = (int64_t)n_words * (16 + 8) + (int64_t)n_occ * 8 + (int64_t)n_listed * 16 + nb_bytes;
+    g->st.bytes = (int64_t)n_words * (16 + 8 + 1) + (int64_t)n_occ * 8 + (int64_t)n_listed * 16 + nb_bytes;
     return HNR_OK;
 }
 
@@ -533,6 +558,7 @@ extern "C" int hnr_grid_free(hnr_grid *g)
     if (g->dil_rec) (void)hipFree(g->dil_rec);
     if (g->nb_rng) (void)hipFree(g->nb_rng);
     if (g->nb_pts) (void)hipFree(g->nb_pts);
+    if (g->brick_near) (void)hipFree(g->brick_near);
     delete g;
     return HNR_OK;
 }

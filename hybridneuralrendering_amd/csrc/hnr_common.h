@@ -51,6 +51,9 @@ struct GridView {
     const uint4 *dil_rec;
     const uint2 *nb_rng;
     const float4 *nb_pts;
+    // brick_near[w] != 0: some cell of the dilated mask lies in brick w or within TWO bricks of it (5x5x5 bricks).  The march probes one depth in four
+    // and skips the other three when the probed one sits in a brick with brick_near == 0 and the ray cannot leave the 5x5x5 block within three steps.
+    const uint8_t *brick_near;
 };
 
 // floor((p - shift) / size) with fp32 subtract and IEEE fp32 divide, exactly as the reference
@@ -219,6 +222,7 @@ struct hnr_grid {
     uint4 *dil_rec;
     uint2 *nb_rng;
     float4 *nb_pts;
+    uint8_t *brick_near;
     hnr::GridView view() const
     {
         hnr::GridView v;
@@ -227,7 +231,7 @@ struct hnr_grid {
         v.dx = p.dims[0]; v.dy = p.dims[1]; v.dz = p.dims[2];
         v.by = bd[1]; v.bz = bd[2];
         v.occ_rec = occ_rec; v.dil = dil; v.cell_rng = cell_rng; v.pts = pts;
-        v.dil_rec = dil_rec; v.nb_rng = nb_rng; v.nb_pts = nb_pts;
+        v.dil_rec = dil_rec; v.nb_rng = nb_rng; v.nb_pts = nb_pts; v.brick_near = brick_near;
         return v;
     }
 };

@@ -335,8 +335,8 @@ def test_every_knn_kernel_variant_returns_the_same_bits(tmp_path):
     """The k-NN has several forms (csrc/query.hip): over the grid's 3x3x3 neighbourhood lists with a quad of lanes per sample (HNR_KNN=4, the default for the
     set-exact order) or one lane per sample (7 / 5: with / without the in-workgroup sort by list length; 8: sorted by cell as well; 9: candidates fetched quad-cooperatively
     through LDS; 6: the quad form in work-list order), and the
-    27-cell walk without the lists (HNR_KNN=3, and what runs when the grid carries no lists: HNR_NB_LISTS=0); the march probes a ray's blocks together or
-    one after the other (HNR_MARCH_PROBE=2).  Every combination must return the bits the default does -- which the tests above pin to the oracle --
+    27-cell walk without the lists (HNR_KNN=3, and what runs when the grid carries no lists: HNR_NB_LISTS=0); the march probes a ray's blocks together or one after the other (HNR_MARCH_PROBE=2), or one depth in four with
+    the groups near the mask expanded (HNR_MARCH_TWO_LEVEL=1).  Every combination must return the bits the default does -- which the tests above pin to the oracle --
     in both neighbour orders, counters included."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -348,7 +348,7 @@ def test_every_knn_kernel_variant_returns_the_same_bits(tmp_path):
         assert p.returncode == 0, p.stderr[-2000:]
         return [l for l in p.stdout.splitlines() if l.startswith("VARIANT")][0].split()[1:]
     base = run()
-    for env in (dict(HNR_KNN="3"), dict(HNR_KNN="4"), dict(HNR_KNN="5"), dict(HNR_KNN="6"), dict(HNR_KNN="7"), dict(HNR_KNN="9"), dict(HNR_KNN="10"), dict(HNR_NB_LISTS="0"), dict(HNR_MARCH_PROBE="2"),
+    for env in (dict(HNR_KNN="3"), dict(HNR_KNN="4"), dict(HNR_KNN="5"), dict(HNR_KNN="6"), dict(HNR_KNN="7"), dict(HNR_KNN="9"), dict(HNR_KNN="10"), dict(HNR_NB_LISTS="0"), dict(HNR_MARCH_PROBE="2"), dict(HNR_MARCH_TWO_LEVEL="1"), dict(HNR_MARCH_TWO_LEVEL="1", HNR_MARCH_RAYS_PER_WAVE="1"),
                 dict(HNR_MARCH_RAYS_PER_WAVE="1"), dict(HNR_MARCH_RAYS_PER_WAVE="64")):
         got = run(**env)
         assert got[:2] == base[:2], (env, got, base)
