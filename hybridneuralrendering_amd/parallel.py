@@ -165,13 +165,23 @@ def allreduce_gradients(tensors, group=None, bucket_bytes=64 << 20):
         i = j
 
 
+def _with_point_zero(touched):
+    """Point 0 always travels (round-4 advice): the empty neighbour slots' share of d conf_coefficient lands on it through the reference's index clamp
+    (neural_points.py:711) whether or not the batch touched it, so a rank's gradient can be non-zero there outside `touched`."""
+    if touched.numel() and int(touched.min()) == 0:
+        return touched
+    return torch.cat([torch.zeros((1,), dtype=touched.dtype, device=touched.device), touched])
+
+
 def allreduce_point_gradients_sparse(grad, touched, group=None):
     """SUM over ranks of a point-buffer gradient [N, C] that is non-zero only on the rows `touched` (int64 ids, the points
     this rank's batch referenced -- at most ~600 k of N = 2-4 M): all-gather (id, row) pairs and scatter-add locally instead
-    of moving N x C floats around the ring.  Returns the summed dense gradient (new tensor)."""
+    of moving N x C floats around the ring.  Returns the summed dense gradient (new tensor).  (The host-synchronising form of round 4; the
+    training step uses PointGradExchange below.)"""
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return grad
     world = dist.get_world_size(group)
+    touched = _with_point_zero(touched)
     n_local = torch.tensor([touched.numel()], dtype=torch.int64, device=grad.device)
     counts = [torch.zeros_like(n_local) for _ in range(world)]
     dist.all_gather(counts, n_local, group=group)
@@ -206,6 +216,7 @@ def allreduce_point_buffers_sparse(grads, touched, group=None):
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return [g for g in grads]
     widths = [f.shape[1] for f in flat]
+    touched = _with_point_zero(touched)
     packed = torch.cat([f.index_select(0, touched) for f in flat], dim=1) if touched.numel() else torch.zeros((0, sum(widths)), dtype=flat[0].dtype, device=flat[0].device)
     world = dist.get_world_size(group)
     n_local = torch.tensor([touched.numel()], dtype=torch.int64, device=packed.device)
