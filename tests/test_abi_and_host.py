@@ -186,7 +186,7 @@ assert torch.allclose(s, pg(0)[0] + pg(1)[0], rtol=0, atol=1e-6)
 # ... and a gradient on point 0 that is NOT in `touched` (the empty slots' conf gradient, round-4 advice) travels too
 d0, ids0 = pg(rank)
 d0 = d0.clone(); d0[0] = 1.0 + rank
-assert 0 not in ids0.tolist()
+ids0 = ids0[ids0 != 0]
 s0 = parallel.allreduce_point_gradients_sparse(d0, ids0)
 assert torch.allclose(s0[0], torch.full((32,), 3.0)) and torch.allclose(s0[1:], (pg(0)[0] + pg(1)[0])[1:], rtol=0, atol=1e-6)
 # all four point buffers in one exchange (embeddings, conf, dir, colour: reference shapes with the leading 1)
