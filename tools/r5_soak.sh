@@ -8,3 +8,4 @@ HOG=$!
 sleep 30
 RACE_ITERS=5000 timeout 900 python3 tools/race_c3.py > $D/race_default_contended.txt 2>&1; echo "default side streams, beside another process, 5000 steps: $(tail -1 $D/race_default_contended.txt)"
 kill $HOG 2>/dev/null; wait $HOG 2>/dev/null
+exit 0
