@@ -10,7 +10,6 @@
 #include <stdlib.h>
 
 #include "hnr_h2.h"
-#include "cf_ws.h"
 
 namespace hnr {
 
@@ -1193,22 +1192,6 @@ static int mlp3_forward_impl(const float *d_A, int lda, int64_t M_cap, const int
         mlp3_probe_print(st, n_layers, K[0]);                                                                                          \
         HNR_LAUNCH_CHECK();                                                                                                             \
         return HNR_OK;                                                                                                                  \
-    }
-    // the colour-feature launch of the forward frame (280 -> 128 -> 128 -> 128 + tail 128 -> 64, plain rows): HNR_CF_WS=1 selects the weight-stationary
-    // kernel of csrc/cf_ws.hip (tools/ab_cf.py: A/B timing + SHA-1 of the outputs)
-    {
-        static int use_ws = -1;
-        if (use_ws < 0) { const char *e = getenv("HNR_CF_WS"); use_ws = e ? atoi(e) : 0; }          // opt-in: bit-identical to mlp3_kernel and as fast, not faster (profiles/README.md, round 4)
-        const long long big = (long long)M_cap * (ldc > ldc2 ? ldc : ldc2) * 4;
-        if (use_ws && n_layers == 4 && S[0] == 18 && S[1] == 8 && S[2] == 8 && S[3] == 8 && N[0] == 128 && N[1] == 128 && N[2] == 128 && N[3] == 64 &&
-            act[0] && act[1] && act[2] && !act[3] && K[0] > 256 && !d_R && !d_T0 && !d_T1 && !d_tmax && seg_stride == 0 && count_mult == 1 && big < 0x70000000ll) {
-            CfWsArgs c;
-            c.A = d_A; c.lda = lda; c.wimg = (const char *)d_packed;
-            for (int l = 0; l < 4; ++l) c.wbase[l] = a.wbase[l];
-            c.K0 = K[0]; c.slope = slope; c.counts = a.counts; c.count_index = count_index; c.M_cap = M_cap;
-            c.C = d_C; c.ldc = ldc; c.C2 = d_C2; c.ldc2 = ldc2;
-            return launch_cf_ws(c, st);
-        }
     }
     HNR_MLP3_CASE(18, 8, 8, 0, 2)     // color_feature_branch: 280 -> 128 -> 128 -> 128 (32-row tiles with 3 or 4 workgroups per CU: 2.63 / 2.61 vs 2.45 ms)
     HNR_MLP3_CASE(18, 8, 8, 8, 2)     // the same + tail 128 -> 64: the colour-feature columns of aux_merge_weight_block.0, once per sample
