@@ -411,7 +411,6 @@ __global__ __launch_bounds__(256) void chain_gather_kernel(ChainGatherArgs a)
 {
     __shared__ float s_d[128][7];                        // dists6 per row (odd stride: rows of consecutive lanes on distinct banks)
     const ChainClasses cls = chain_classes(a.counts, a.cap_samples);
-    const int n_valid = cls.n_valid;
     const int tid = threadIdx.x;
     for (int blk = blockIdx.x; blk < cls.n_tiles; blk += gridDim.x) {         // one 128-row tile = 4 groups per pass; the grid is sized from the capacity
     // first class: 16 samples x 8 slots; second class (hnr_chain_plan): 32 samples x 4 slots; third: 64 samples x 2 slots
