@@ -5,7 +5,7 @@ python tools/collect_pmc.py gpurun_out/r4_evidence [tag]"""
 import collections, csv, glob, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 root = sys.argv[1]; tag = sys.argv[2] if len(sys.argv) > 2 else "r04"
-KERN = ("march_kernel", "knn3_kernel", "chain_gather_kernel", "chain_ws_kernel", "chain_sigma_kernel", "mlp3_kernel", "merge_wp_kernel", "mixfinal_wp_kernel", "composite_kernel", "cf_ws_kernel")
+KERN = ("march_kernel", "knn3_kernel", "knn_nb_kernel", "knn_quad_kernel", "chain_gather_kernel", "chain_ws_kernel", "chain_sigma_kernel", "mlp3_kernel", "merge_wp_kernel", "mixfinal_wp_kernel", "composite_kernel", "cf_ws_kernel")
 per = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob(os.path.join(root, "pmc_g*.csv"))):
     if f.endswith("_trace.csv"): continue
