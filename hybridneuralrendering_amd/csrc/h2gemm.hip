@@ -595,20 +595,20 @@ __global__ __launch_bounds__(512, 1) void h2wgrad_dma_kernel(H2WgradArgs a)
             h2_dma_row8(a.X + (size_t)pm * a.ldx, vx8, raw + (unsigned)(RAWZ + row * WX * 4 + 1024));
         }
     };
+    auto convert_one = [&](const float4 v, char *base, long long blk, int it) __attribute__((always_inline)) {
+        const unsigned keep = (blk * RB + s_row[it] < M) ? s_keep[it] : (s_keep[it] & ~15u);
+        const float sc = (keep & 16u) ? sx : sz;
+        unsigned ph0, pm0, ph1, pm1;
+        split2h((keep & 1u) ? __fmul_rn(v.x, sc) : 0.f, (keep & 2u) ? __fmul_rn(v.y, sc) : 0.f, ph0, pm0);
+        split2h((keep & 4u) ? __fmul_rn(v.z, sc) : 0.f, (keep & 8u) ? __fmul_rn(v.w, sc) : 0.f, ph1, pm1);
+        ph0 = (keep & 0x100u) ? ((ph0 & 0xffff0000u) | 0x3c00u) : (keep & 0x200u) ? ((ph0 & 0x0000ffffu) | 0x3c000000u) : ph0;
+        ph1 = (keep & 0x400u) ? ((ph1 & 0xffff0000u) | 0x3c00u) : (keep & 0x800u) ? ((ph1 & 0x0000ffffu) | 0x3c000000u) : ph1;
+        *reinterpret_cast<uint2 *>(base + s_lds[it]) = make_uint2(ph0, ph1);
+        *reinterpret_cast<uint2 *>(base + s_lds[it] + ((keep & 16u) ? PX : PZ)) = make_uint2(pm0, pm1);
+    };
     auto convert = [&](const char *raw, char *base, long long blk) {
 #pragma unroll
-        for (int it = 0; it < NLD; ++it) {
-            const float4 v = *reinterpret_cast<const float4 *>(raw + s_raw[it]);
-            const unsigned keep = (blk * RB + s_row[it] < M) ? s_keep[it] : (s_keep[it] & ~15u);
-            const float sc = (keep & 16u) ? sx : sz;
-            unsigned ph0, pm0, ph1, pm1;
-            split2h((keep & 1u) ? __fmul_rn(v.x, sc) : 0.f, (keep & 2u) ? __fmul_rn(v.y, sc) : 0.f, ph0, pm0);
-            split2h((keep & 4u) ? __fmul_rn(v.z, sc) : 0.f, (keep & 8u) ? __fmul_rn(v.w, sc) : 0.f, ph1, pm1);
-            ph0 = (keep & 0x100u) ? ((ph0 & 0xffff0000u) | 0x3c00u) : (keep & 0x200u) ? ((ph0 & 0x0000ffffu) | 0x3c000000u) : ph0;
-            ph1 = (keep & 0x400u) ? ((ph1 & 0xffff0000u) | 0x3c00u) : (keep & 0x800u) ? ((ph1 & 0x0000ffffu) | 0x3c000000u) : ph1;
-            *reinterpret_cast<uint2 *>(base + s_lds[it]) = make_uint2(ph0, ph1);
-            *reinterpret_cast<uint2 *>(base + s_lds[it] + ((keep & 16u) ? PX : PZ)) = make_uint2(pm0, pm1);
-        }
+        for (int it = 0; it < NLD; ++it) convert_one(*reinterpret_cast<const float4 *>(raw + s_raw[it]), base, blk, it);
     };
     const long long step = gridDim.x;
     long long blk = blockIdx.x;
@@ -620,33 +620,56 @@ __global__ __launch_bounds__(512, 1) void h2wgrad_dma_kernel(H2WgradArgs a)
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     __syncthreads();
     convert(raw_p(0), planes(0), blk);
-    __syncthreads();
+    // One barrier per block: behind it block i's planes are complete, block i + 1's raw rows have landed, and nobody still reads what this
+    // iteration overwrites (raw(par): converted in iteration i - 1; planes(par ^ 1): multiplied in iteration i - 1).  Block i's MFMAs and block
+    // i + 1's conversion run in ONE phase, a conversion slot behind every pair of column tiles.  (Measured the same as two phases with a barrier
+    // between them, and as loads three blocks ahead through a ring of three raw blocks: profiles/r05_wgrad_ablation.txt -- the loop's terms add up.)
     int par = 0;
     for (; blk < n_blocks; blk += step, par ^= 1) {
-        dma_block(blk + 2 * step, raw_l(par));                                 // (block i's raw rows were converted before the last barrier)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // this wave's rows of block i + 1 have landed
+        __syncthreads();
+#ifdef HNR_WG_DBG
+        if (!(a.dbg & 4))
+#endif
+        dma_block(blk + 2 * step, raw_l(par));
         const char *zb = planes(par), *xb = planes(par) + 2 * PZ;
+        const char *rawn = raw_p(par ^ 1);
+        char *basen = planes(par ^ 1);
+        const long long blkn = blk + step;
         const f16x8 zh = h2_tr_frag(zb, RSZ, 32 * wn, 0, lane), zm = h2_tr_frag(zb + PZ, RSZ, 32 * wn, 0, lane);
+        f16x8 xh[2][2], xm[2][2];
+        xh[0][0] = h2_tr_frag(xb, RSX, 0, 0, lane); xm[0][0] = h2_tr_frag(xb + PX, RSX, 0, 0, lane);
+        xh[0][1] = h2_tr_frag(xb, RSX, 32, 0, lane); xm[0][1] = h2_tr_frag(xb + PX, RSX, 32, 0, lane);
 #pragma unroll
         for (int u0 = 0; u0 < KTW; u0 += 2) {
-            const f16x8 xh0 = h2_tr_frag(xb, RSX, 32 * u0, 0, lane), xm0 = h2_tr_frag(xb + PX, RSX, 32 * u0, 0, lane);
-            if (u0 + 1 < KTW) {
-                const f16x8 xh1 = h2_tr_frag(xb, RSX, 32 * (u0 + 1), 0, lane), xm1 = h2_tr_frag(xb + PX, RSX, 32 * (u0 + 1), 0, lane);
-                acc[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zm, xh0, acc[u0], 0, 0, 0);
-                acc[u0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zm, xh1, acc[u0 + 1], 0, 0, 0);
-                acc[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zh, xm0, acc[u0], 0, 0, 0);
-                acc[u0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zh, xm1, acc[u0 + 1], 0, 0, 0);
-                acc[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zh, xh0, acc[u0], 0, 0, 0);
-                acc[u0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zh, xh1, acc[u0 + 1], 0, 0, 0);
-            } else {
-                acc[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zm, xh0, acc[u0], 0, 0, 0);
-                acc[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zh, xm0, acc[u0], 0, 0, 0);
-                acc[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zh, xh0, acc[u0], 0, 0, 0);
+            const int cb = (u0 >> 1) & 1, it = u0 >> 1;
+            if (u0 + 2 < KTW) {                                                 // the next pair's fragments: in flight under this pair's MFMAs
+                xh[cb ^ 1][0] = h2_tr_frag(xb, RSX, 32 * (u0 + 2), 0, lane); xm[cb ^ 1][0] = h2_tr_frag(xb + PX, RSX, 32 * (u0 + 2), 0, lane);
+                if (u0 + 3 < KTW) { xh[cb ^ 1][1] = h2_tr_frag(xb, RSX, 32 * (u0 + 3), 0, lane); xm[cb ^ 1][1] = h2_tr_frag(xb + PX, RSX, 32 * (u0 + 3), 0, lane); }
             }
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (it < NLD) v = *reinterpret_cast<const float4 *>(rawn + s_raw[it]);
+#ifdef HNR_WG_DBG
+            if (!(a.dbg & 1))
+#endif
+            if (u0 + 1 < KTW) {
+                acc[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zm, xh[cb][0], acc[u0], 0, 0, 0);
+                acc[u0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zm, xh[cb][1], acc[u0 + 1], 0, 0, 0);
+                acc[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zh, xm[cb][0], acc[u0], 0, 0, 0);
+                acc[u0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zh, xm[cb][1], acc[u0 + 1], 0, 0, 0);
+                acc[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zh, xh[cb][0], acc[u0], 0, 0, 0);
+                acc[u0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zh, xh[cb][1], acc[u0 + 1], 0, 0, 0);
+            } else {
+                acc[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zm, xh[cb][0], acc[u0], 0, 0, 0);
+                acc[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zh, xm[cb][0], acc[u0], 0, 0, 0);
+                acc[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zh, xh[cb][0], acc[u0], 0, 0, 0);
+            }
+#ifdef HNR_WG_DBG
+            if (!(a.dbg & 2))
+#endif
+            if (it < NLD) convert_one(v, basen, blkn, it);
         }
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                        // this wave's rows of block i + 1 have landed (block i + 2's six requests may be in flight)
-        __syncthreads();                                                        // ... everybody's; and everybody is done with the planes block i + 1 goes into
-        convert(raw_p(par ^ 1), planes(par ^ 1), blk + step);
-        __syncthreads();
+        static_assert(NLD <= (KTW + 1) / 2, "a conversion slot behind every pair of column tiles");
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                            // no DMA into this workgroup's LDS may outlive it
     constexpr int NP = 32 * NT, KP = 32 * KT, LDP = KP;
@@ -812,6 +835,9 @@ extern "C" int hnr_h2wgrad(const float *d_dZ, int ldz, const float *d_X, int ldx
     a.dZ = d_dZ; a.ldz = ldz; a.X = d_X; a.ldx = ldx; a.d_m = reinterpret_cast<const long long *>(d_m); a.M_cap = M_cap; a.n_seg = n_seg; a.seg_stride = seg_stride;
     a.N = N; a.K = K;
     a.zmax = d_absmax_z; a.xmax = d_absmax_x; a.partial = (float *)d_scratch; a.dbg = 0;
+#ifdef HNR_WG_DBG
+    { const char *e = getenv("HNR_WG_DBG"); a.dbg = e ? atoi(e) : 0; }
+#endif
     const int64_t blocks = (M_cap * n_seg + 15) / 16;
     const int n_cu = h2_num_cus();
     int grid = (int)((blocks + 15) / 16 < n_cu ? (blocks + 15) / 16 : n_cu);           // at least 8 row blocks per workgroup: every workgroup writes (and the reduction reads) a whole partial
