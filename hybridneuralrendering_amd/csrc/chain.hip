@@ -856,7 +856,7 @@ extern "C" int hnr_chain_forward(const void *d_workspace, const float *d_point_t
     // default: the weight-stationary pipelined kernel (csrc/chain_ws.hip)
     static int rt_mode = 0;
     if (rt_mode == 0) { const char *e = getenv("HNR_CHAIN_RT"); rt_mode = (e && atoi(e) == 4) ? 4 : 16; }
-    a.skew = 0; a.uidx = nullptr; a.hmax = nullptr; a.x5max = nullptr;
+    a.skew = 0; a.uidx = nullptr; a.hmax = nullptr; a.x5max = nullptr; a.row_u = nullptr; a.ucap = 0;
     for (int l = 0; l < 4; ++l) { a.H[l] = nullptr; a.ldh[l] = 0; }
     static PerDeviceOnce attr_once;
     if (attr_once.first()) {
@@ -888,7 +888,8 @@ int chain_gather_train(const float *d_xyz, const float *d_conf, const float *d_d
 }
 
 int chain_forward_train(const void *d_workspace, const float *d_point_table, int ldt, const int32_t *d_uidx, const void *d_packed, const int64_t *d_counts,
-                        int cap_samples, float slope, float *d_X5, int ld5, float *d_sigma, float *const *d_H, const int *ldh, uint32_t *d_hmax, uint32_t *d_x5max, void *stream)
+                        int cap_samples, float slope, float *d_X5, int ld5, float *d_sigma, float *const *d_H, const int *ldh, uint32_t *d_hmax, uint32_t *d_x5max, void *stream,
+                        const int32_t *d_row_u, int ucap)
 {
     if (cap_samples <= 0) return HNR_OK;
     const int blocks = cdiv(cap_samples, 16) + 2;
@@ -898,9 +899,17 @@ int chain_forward_train(const void *d_workspace, const float *d_point_table, int
     a.counts = reinterpret_cast<const unsigned long long *>(d_counts);
     a.X5 = d_X5; a.ld5 = ld5; a.sigma = d_sigma; a.slope = slope; a.cap_samples = cap_samples; a.dbg = nullptr; a.dbg_layer = 0; a.skew = 0;
     for (int l = 0; l < 4; ++l) { a.H[l] = d_H[l]; a.ldh[l] = ldh[l]; }
-    a.uidx = d_uidx; a.hmax = d_hmax; a.x5max = d_x5max;
+    a.uidx = d_uidx; a.hmax = d_hmax; a.x5max = d_x5max; a.row_u = d_row_u; a.ucap = ucap;
     const int n_cu = chain_num_cus();
     const int tiles = cdiv(cap_samples, 16), grid = tiles < n_cu ? tiles : n_cu;
+    // The weight-stationary pipelined kernel in its activation-keeping form (csrc/chain_ws.hip, chain_ws_kernel<8>: the render path's kernel + eight
+    // 16-B stores per pass and lane; same arithmetic, same results bit for bit) when the row -> table-row map is there and every kept buffer's byte
+    // offsets fit 31 bits; HNR_TRAIN_CHAIN_WS=0: the layer-by-layer kernel below
+    static int use_ws = -1;
+    if (use_ws < 0) { const char *e = getenv("HNR_TRAIN_CHAIN_WS"); use_ws = e ? atoi(e) : 1; }
+    bool fits = d_row_u != nullptr && d_hmax != nullptr;
+    for (int l = 0; l < 4; ++l) fits = fits && d_H[l] != nullptr && (long long)blocks * 128 * ldh[l] * 4 < 0x7fffffffLL && (ldh[l] & 3) == 0;
+    if (use_ws && fits) return launch_chain_ws(a, grid, (hipStream_t)stream, 8);
     HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chain_kernel<4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, ch_lds_bytes(4)));
     chain_kernel<4, 3><<<grid, 256, ch_lds_bytes(4), (hipStream_t)stream>>>(a);
     HNR_LAUNCH_CHECK();

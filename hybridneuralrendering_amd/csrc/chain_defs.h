@@ -35,6 +35,7 @@ struct ChainArgs {
     // TRAINING forward (chain_kernel<4, 3>): every layer's post-activation output is kept for the backward pass
     float *H[4]; int ldh[4];           // [rows, ldh >= 256] block1.0 / block1.2 / block3.0 / block3.2 outputs; H[1] has ldh >= 264: columns 256..263 = block3's 7 extras + 0
     const int32_t *uidx;               // optional: point id -> row of ptab (the table holds the batch's touched points only)
+    const int32_t *row_u; int ucap;    // chain_ws_kernel<8>: row -> row of ptab directly (>= ucap: none, row 0 is used)
     unsigned *hmax;                    // [4] bit patterns of max |H[l]| (atomicMax; H[1]'s includes the extras): scales of the weight-gradient GEMMs
     unsigned *x5max;                   // optional: bit pattern of max |weighted feature sum| (the first 256 columns of X5), atomicMax
 };
@@ -72,7 +73,7 @@ __device__ __forceinline__ float chain_softplus_m1(float x)
 }
 
 // csrc/chain_ws.hip: weight-stationary, software-pipelined form of the chain kernel.  mode 0: product, 1: layer dump (a.dbg, a.dbg_layer),
-// 2: phase timing.
+// 2: phase timing, 8: training forward (a.H, a.hmax, a.x5max, a.row_u).
 int launch_chain_ws(const ChainArgs &a, int grid, hipStream_t st, int mode);
 
 }  // namespace hnr

@@ -30,12 +30,28 @@
 
 #include "chain_defs.h"
 
+#ifndef HNR_CW_X_NOROWU
+#define HNR_CW_X_NOROWU 0
+#endif
+#ifndef HNR_CW_X_NOHM
+#define HNR_CW_X_NOHM 0
+#endif
+#ifndef HNR_CW_X_NOX5
+#define HNR_CW_X_NOX5 0
+#endif
+#ifndef HNR_CW_X_NOHM3
+#define HNR_CW_X_NOHM3 0
+#endif
+#ifndef HNR_CW_X_NOEXT
+#define HNR_CW_X_NOEXT 0
+#endif
 namespace hnr {
 
 constexpr int CW_CST = ch_lds_exch(4) + 2048;          // LDS copy of bias[4][256], alpha_w[256], alpha_b, descale[4] (meta floats 0..1284)
 constexpr int CW_CST_FLOATS = CH_META_DESCALE + 4;
 constexpr int CW_DSUM = CW_CST + ((CW_CST_FLOATS * 4 + 15) & ~15);   // alpha-branch partial dot products of a tile: [4 row tiles][32 rows][4 waves]
-constexpr int cw_lds_bytes() { return CW_DSUM + 4 * 32 * 4 * 4; }
+constexpr int CW_HMAX = CW_DSUM + 4 * 32 * 4 * 4;        // training form: running maxima [4 layers + the stored sums][32 rows][4 waves] (ds_max_f32: no register carried through the tile loop)
+constexpr int cw_lds_bytes() { return CW_HMAX + 5 * 512; }
 
 // The resident weight fragments live in AGPRs that this file numbers itself: fragment (k step s, column tile c, plane p) = a[16 s + 8 c + 4 p .. +3].
 // Loads into them and the MFMAs that read them are inline asm with the register numbers in the text.  (Compiler-allocated fragments -- builtin
@@ -147,7 +163,27 @@ constexpr int CW_TILE_STAMPS = 16 * 128 * 4;
 // asm loads (weight fetches: 4 each; image DMAs behind the barriers of passes (3, 0..3): 2 each) with a time stamp in (t0, t1); stamps of the previous
 // tile are the same minus CW_TILE_STAMPS.  Only asm loads count: the compiler's loads and stores between them make the true number of operations
 // in flight larger, so a wait derived from this count is conservative.
-constexpr int cw_asm_between(int t0, int t1)
+// TRAINING form (chain_ws_kernel<8>): the first half of every epilogue stores the row tile's 16 x 2 post-activation values per lane as eight 16-B
+// buffer stores (one behind every second item).  They are counted by vmcnt like the loads (gfx9: one in-order counter for both), so the waits
+// below must allow for them exactly -- a wait that did not would drain the stores just issued.  cw_train_stores(P, sl): how many of them the
+// epilogue piece behind MFMA `sl` of pass P issues (the micro-stage arithmetic of epilogue_piece's first half).
+constexpr int cw_train_stores(int P, int sl)
+{
+    const int S = cw_steps(P >> 2), T = 6 * S, H = T / 2;
+    if (sl >= H) return 0;
+    const bool wide = S == 4;
+    const int MS = wide ? 17 : 33, m0 = sl * MS / H, m1 = (sl + 1) * MS / H;
+    int n = 0;
+    for (int ms = m0; ms < m1; ++ms) {
+        if (ms >= MS - 1) continue;
+        if (wide) { if (ms & 1) ++n; }                                        // items 2 (ms >> 1) and + 1 finish together
+        else if ((ms & 1) && ((ms >> 1) & 1)) ++n;                           // item ms >> 1 finishes; a store behind every odd item
+    }
+    return n;
+}
+constexpr int cw_train_stores_pass(int P) { int n = 0; for (int sl = 0; sl < 6 * cw_steps(P >> 2); ++sl) n += cw_train_stores(P, sl); return n; }
+static_assert(cw_train_stores_pass(0) == 8 && cw_train_stores_pass(5) == 8 && cw_train_stores_pass(9) == 8 && cw_train_stores_pass(15) == 8, "eight activation stores per pass");
+constexpr int cw_asm_between(int t0, int t1, bool trn = false)
 {
     int n = 0;
     for (int wrap = -1; wrap <= 0; ++wrap)
@@ -155,11 +191,12 @@ constexpr int cw_asm_between(int t0, int t1)
             for (int sl = 0; sl < 6 * cw_steps(Q >> 2); ++sl) {
                 if (cw_issue(Q, sl) >= 0) { const int t = cw_stamp(Q, sl, 2) + wrap * CW_TILE_STAMPS; if (t > t0 && t < t1) n += 4; }
                 if ((Q >> 2) == 3 && sl == 3 * cw_steps(3)) { const int t = cw_stamp(Q, sl, 0) + wrap * CW_TILE_STAMPS; if (t > t0 && t < t1) n += 2; }
+                if (trn && cw_train_stores(Q, sl) > 0) { const int t = cw_stamp(Q, sl, 3) + wrap * CW_TILE_STAMPS; if (t > t0 && t < t1) n += cw_train_stores(Q, sl); }
             }
     return n;
 }
 // what `s_waitcnt vmcnt` may leave in flight in front of the MFMA (P, slot) that needs block `blk`: the asm loads issued after the block's own
-constexpr int cw_need_count(int blk, int P, int slot)
+constexpr int cw_need_count(int blk, int P, int slot, bool trn = false)
 {
     const int t_need = cw_stamp(P, slot, 1);
     int t_blk = -2 * CW_TILE_STAMPS;
@@ -167,15 +204,15 @@ constexpr int cw_need_count(int blk, int P, int slot)
         for (int Q = 0; Q < 16; ++Q)
             for (int sl = 0; sl < 6 * cw_steps(Q >> 2); ++sl)
                 if (cw_issue(Q, sl) == blk) { const int t = cw_stamp(Q, sl, 2) + wrap * CW_TILE_STAMPS; if (t < t_need && t > t_blk) t_blk = t; }
-    return cw_asm_between(t_blk, t_need);
+    return cw_asm_between(t_blk, t_need, trn);
 }
 // ... in front of the barrier of pass Pw, for the image DMA issued behind the barrier of pass (3, rt)
-constexpr int cw_dma_count(int rt, int Pw)
+constexpr int cw_dma_count(int rt, int Pw, bool trn = false)
 {
     const int t1 = cw_stamp(Pw, 3 * cw_steps(Pw >> 2), 0);
     int t0 = cw_stamp(12 + rt, 48, 0);
     if (t0 >= t1) t0 -= CW_TILE_STAMPS;
-    return cw_asm_between(t0, t1);
+    return cw_asm_between(t0, t1, trn);
 }
 static_assert(cw_need_count(32 + 0, 4, 48) == 28 && cw_need_count(32 + 7, 4, 90) == 0, "block1.2's k steps 0..7 are fetched behind the first eight iterations of pass (1,0)");
 static_assert(cw_need_count(3, 0, 18) == 22 && cw_need_count(0, 0, 0) == 30, "layer 0 fetches: followed by the image DMA of row tile 3, block1.2's 8..11, then by the first fetch of pass (0,0)");
@@ -192,6 +229,8 @@ template <class T> using cw_lptr = __attribute__((address_space(3))) T *;      /
 template <int DBG>
 __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
 {
+    constexpr bool TR = DBG == 8;                                          // training form: every layer's output rows kept (a.H), maxima (a.hmax, a.x5max), table rows through a.row_u
+    constexpr int DB = TR ? 0 : DBG;                                      // 1: layer dump, 2: phase clocks, 3..7: timing probes
     constexpr int SLOT = ch_slot(4);
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5, j = lane & 31;   // wave in an SGPR: its tests are scalar branches
@@ -239,6 +278,7 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
     for (int i = tid; i < 2 * 4 * 32; i += 256)                            // extras k step: its k = 8..15 half stays zero
         CW_LDS(u32x4, 16 * SLOT + (i >> 5) * 1024 + (32 + (i & 31)) * 16) = u32x4{0u, 0u, 0u, 0u};
     for (int i = tid; i < CW_CST_FLOATS; i += 256) CW_LDS(float, CW_CST + 4 * i) = meta[i];
+    if constexpr (TR) { for (int i = tid; i < 5 * 128; i += 256) CW_LDS(float, CW_HMAX + 4 * i) = 0.f; }
 
     asm volatile("" ::: "a255");                                          // the kernel owns all 256 AGPRs (see above)
     u32x4 wx[2][2];                                                        // block3.0's 17th k step (VGPRs, once per tile)
@@ -248,7 +288,10 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
     int pid[4], pid_n[4] = {0, 0, 0, 0};
     float wq[4], wq_fin = 0.f;
     float4 e0 = make_float4(0.f, 0.f, 0.f, 0.f), e1 = e0;
-    float4 tv[2][2][4];                                                    // layer 0: rows of the per-point table, two row tiles in flight ([row tile & 1][column tile][16 B])
+    // layer 0: rows of the per-point table, two row tiles in flight ([row tile & 1][column tile][16 B]).  Training form: ONE set (32 registers that its kept
+    // maxima, offsets and store operands need): a row tile's rows are asked for at the barrier of its own pass, half a pass before their epilogue
+    float4 tv[TR ? 1 : 2][2][4];
+#define CW_TV(i_) tv[TR ? 0 : ((i_) & 1)]
 
     // weight fragments of (layer L, k step s) -> a[16 s ..]: four loads  (probe build -DHNR_CHAIN_WS_SAME_W=1: every k step reads the layer's
     // first one -- 64 KiB instead of 848 KiB of weights per tile from L2; results are garbage, the time shows what the weight stream costs)
@@ -264,7 +307,10 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
     auto load_ids = [&](int tile, int (&pd)[4]) __attribute__((always_inline)) {
         const char *aux = a.aux + (size_t)tile * 4 * CH_AUX_GROUP;
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) pd[rt] = reinterpret_cast<const int32_t *>(aux + rt * CH_AUX_GROUP)[j];
+        for (int rt = 0; rt < 4; ++rt) {
+            if constexpr (TR && !HNR_CW_X_NOROWU) { const int u = a.row_u[(size_t)tile * 128 + 32 * rt + j]; pd[rt] = (unsigned)u >= (unsigned)a.ucap ? 0 : u; }     // empty slots / rows past the end carry the sentinel: row 0, like chain_kernel<4, 3>
+            else pd[rt] = reinterpret_cast<const int32_t *>(aux + rt * CH_AUX_GROUP)[j];
+        }
     };
     auto load_rest = [&](int tile) __attribute__((always_inline)) {
         const char *aux = a.aux + (size_t)tile * 4 * CH_AUX_GROUP;
@@ -313,6 +359,18 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
         return o;
     };
 
+    // training: one descriptor per kept layer over the whole buffer (the launcher checks rows x row bytes < 2^31: a byte offset with bit 31 set is out
+    // of range, which is how the epilogue pieces of "no tile" drop their stores), running maxima of the layers' outputs and of the stored sums
+    __amdgpu_buffer_rsrc_t hrs[4];
+    float x5m = 0.f, x5_take = 0.f;                                        // (live inside a layer-3 epilogue's second half only)
+    int hv = 0;
+    if constexpr (TR) {
+#pragma unroll
+        for (int l = 0; l < 4; ++l) hrs[l] = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(a.H[l]), 0, 0x7fffffff, 0x00020000);
+    }
+    (void)hrs; (void)x5m; (void)x5_take; (void)hv;
+#define CW_HMAX_PUT(l_, v_) asm volatile("ds_max_f32 %0, %1 offset:%2" :: "v"(q_exw), "v"(v_), "n"(CW_HMAX - (int)ch_lds_exch(4) + (l_) * 512) : "memory")
+
     // ---- prologue: first tile's row scalars, its four layer-0 images (DMA), its first table rows, layer-0 weights + block1.2's k steps 8..11
     load_ids(t_first, pid);
     __syncthreads();                                                       // constants / zeroed extras visible; nobody DMAs into LDS before everybody is here
@@ -327,7 +385,7 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
     long long t_start = 0, w_start = 0, t_prev = 0, tm[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     int n_my = 0;
     long long tmf[4] = {0, 0, 0, 0}, tf_prev = 0;
-    if (DBG >= 2) { t_start = t_prev = clock64(); w_start = wall_clock64(); }
+    if (DB >= 2) { t_start = t_prev = clock64(); w_start = wall_clock64(); }
 
     // uniform scalars of the packed image (SGPRs)
     const float inv0 = __fmul_rn(pow2f(-14), meta[CH_META_DESCALE]), dw1 = meta[CH_META_DESCALE + 1], dw2 = meta[CH_META_DESCALE + 2], dw3 = meta[CH_META_DESCALE + 3],
@@ -348,7 +406,7 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
     float4 ex4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
     auto read_cst = [&](int L4, int k) __attribute__((always_inline)) {   // chunk k (items 2 k, 2 k + 1) of constants row L4 (0..3: biases, 4: alpha weights)
-        return (DBG == 5 || DBG == 7) ? make_float4(a.slope, 1.f, a.slope, 1.f) : CW_AT_F4(q_cst, L4 * 1024 + (k >> 2) * 128 + (k & 3) * 16);
+        return (DB == 5 || DB == 7) ? make_float4(a.slope, 1.f, a.slope, 1.f) : CW_AT_F4(q_cst, L4 * 1024 + (k >> 2) * 128 + (k & 3) * 16);
     };
     // ---- epilogue of pass PP = (PL, PR), accumulator set se, cut into MICRO-STAGES of 3..8 VALU instructions.  A wave issues in order, and a
     //      dependent VALU instruction issues 8 cycles after its producer, an independent one 4: so every micro-stage holds two independent
@@ -371,11 +429,23 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
                 // scalar fp32 VALU on purpose: packed fp32 instructions (v_pk_fma_f32 ...) do not overlap with this wave's MFMAs -- one
                 // of them behind an MFMA costs 18 cycles of matrix-pipe time, a v_fma_f32 none (tools/interleave_probe.hip)
                 if (it == 0) { amax = 0.f; ap = 0.f; }
+                if constexpr (TR) {
+                    if (it == 0) {                                              // this lane's byte offset of (row 32 PR + j of the tile, column col0) in H[PL]
+                        // (the lane's row and half are laundered: derived per-(layer, row tile) offsets hoisted out of the tile loop cost a register each)
+                        const int ld4 = a.ldh[PL] * 4;
+                        const int sb = to.t < 0 ? (int)0x80000000 : (to.t * 128 + 32 * PR) * ld4 + wave * 256;
+#ifdef HNR_CW_TR_COALESCED                                                       // timing probe (results are garbage): every store instruction writes 1 KiB of consecutive bytes
+                        hv = CW_KEEP(lane) * 16 + ((to.t < 0 ? (int)0x80000000 : (to.t * 128 + 32 * PR) * ld4) + wave * 256 * 32);
+#else
+                        hv = CW_KEEP(j) * ld4 + (CW_KEEP(h) * 64 + sb);
+#endif
+                    }
+                }
                 if ((it & 1) == 0 && k >= 1 && k + 1 < 8) { bq[(k + 1) & 1] = read_cst(PL, k + 1); if (PL == 3) aq[(k + 1) & 1] = read_cst(4, k + 1); }
                 float ax = (it & 1) ? bq[k & 1].z : bq[k & 1].x, ay = (it & 1) ? bq[k & 1].w : bq[k & 1].y;
                 if (PL == 0) {
-                    if (q == 0) cw_table_swap(tv[PR & 1][c][0], tv[PR & 1][c][1], tv[PR & 1][c][2], tv[PR & 1][c][3]);
-                    const float4 t4 = tv[PR & 1][c][q >> 1];
+                    if (q == 0) cw_table_swap(CW_TV(PR)[c][0], CW_TV(PR)[c][1], CW_TV(PR)[c][2], CW_TV(PR)[c][3]);
+                    const float4 t4 = CW_TV(PR)[c][q >> 1];
                     if ((q >> 1) == 0) { ax = cw_table_add<0>((q & 1) ? t4.z : t4.x, ax); ay = cw_table_add<0>((q & 1) ? t4.w : t4.y, ay); }
                     else if ((q >> 1) == 1) { ax = cw_table_add<1>((q & 1) ? t4.z : t4.x, ax); ay = cw_table_add<1>((q & 1) ? t4.w : t4.y, ay); }
                     else if ((q >> 1) == 2) { ax = cw_table_add<2>((q & 1) ? t4.z : t4.x, ax); ay = cw_table_add<2>((q & 1) ? t4.w : t4.y, ay); }
@@ -390,7 +460,21 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
                 acc[se][c][2 * q] = vx; acc[se][c][2 * q + 1] = vy;
                 if (PL == 3) { ap = fmaf(vx, (it & 1) ? aq[k & 1].z : aq[k & 1].x, ap); ap = fmaf(vy, (it & 1) ? aq[k & 1].w : aq[k & 1].y, ap); }
                 else amax = fmaxf(fmaxf(amax, fabsf(vx)), fabsf(vy));
-                if (DBG == 1) {
+                if constexpr (TR) {
+                    if (PL == 3) amax = fmaxf(fmaxf(amax, fabsf(vx)), fabsf(vy));
+#ifndef HNR_CW_TR_NOSTORE
+                    if (it & 1)                                                 // columns col0 + 32 c + 2 (q - 1) .. + 3 of the row: items it - 1, it
+#else
+                    if (false)
+#endif
+                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(acc[se][c][2 * q - 2]), __float_as_uint(acc[se][c][2 * q - 1]), __float_as_uint(vx), __float_as_uint(vy)},
+#ifdef HNR_CW_TR_COALESCED
+                                                               hrs[PL], hv + (8 * c + 2 * (q - 1)) * 512, 0, 0);
+#else
+                                                               hrs[PL], hv + (32 * c + 2 * (q - 1)) * 4, 0, 0);
+#endif
+                }
+                if (DB == 1) {
                     if (a.dbg && a.dbg_layer == PL && to.t >= 0) {
                         int te = to.t;                                          // laundered: no 64-bit induction variable
                         asm volatile("" : "+s"(te));
@@ -416,14 +500,18 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
                     // the two half-waves' partial results meet through v_permlane32_swap (one VALU instruction; a ds_bpermute's wait also drained the
                     // operand reads in flight); both halves then hold the same value and both store it (same address: no exec-masked branch)
                     float v_lo, v_hi;
-                    if (PL == 3) { cw_halves(ap, v_lo, v_hi); m = __fadd_rn(v_lo, v_hi); CW_AT(float, q_dsw, PR * 512) = m; }
+                    if (PL == 3) {
+                        cw_halves(ap, v_lo, v_hi); m = __fadd_rn(v_lo, v_hi); CW_AT(float, q_dsw, PR * 512) = m;
+                        if constexpr (TR && !HNR_CW_X_NOHM3) { const float am = __fmul_rn(amax, to.t >= 0 ? 1.f : 0.f); CW_HMAX_PUT(3, am); }     // (no tile: garbage times 0; a NaN loses the comparison)
+                    }
                     else {
                         cw_halves(amax, v_lo, v_hi);
                         m = fmaxf(v_lo, v_hi);
                         if (PL == 1 && PR == wave)
                             m = fmaxf(m, fmaxf(fmaxf(fmaxf(fabsf(e0.x), fabsf(e0.y)), fmaxf(fabsf(e0.z), fabsf(e0.w))), fmaxf(fmaxf(fabsf(e1.x), fabsf(e1.y)), fabsf(e1.z))));
                     }
-                    if (PL != 3 && DBG != 6 && DBG != 7) CW_AT(float, q_exw, exb) = m;
+                    if (PL != 3 && DB != 6 && DB != 7) CW_AT(float, q_exw, exb) = m;
+                    if constexpr (TR && !HNR_CW_X_NOHM) { if (PL != 3) CW_HMAX_PUT(PL, m); }
                 }
             }
             return;
@@ -441,7 +529,7 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
             const int MS = 21, m0 = k2 * MS / N2, m1 = (k2 + 1) * MS / N2;
 #pragma unroll
             for (int ms = m0; ms < m1; ++ms) {
-                if (ms == 0) ex4 = (DBG == 5 || DBG == 7) ? make_float4(amax, 1.f, 2.f, 3.f) : CW_AT_F4(q_exr, exb);
+                if (ms == 0) ex4 = (DB == 5 || DB == 7) ? make_float4(amax, 1.f, 2.f, 3.f) : CW_AT_F4(q_exr, exb);
                 else if (ms == 1) {
                     const int k = row_scale_exp(fmaxf(fmaxf(ex4.x, ex4.y), fmaxf(ex4.z, ex4.w)));
                     sc_run = pow2f(k);
@@ -468,13 +556,13 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
                     }
                     // operand-plane stores, ONE per stage (two 16-B stores behind one MFMA do not fit its shadow: 13 cycles of data transfer each): the
                     // high parts of items q - 3 .. q are complete after stage q, their low parts one stage later
-                    if (it < 16 && ((it & 3) == 3) && !(DBG == 6 || DBG == 7)) {
+                    if (it < 16 && ((it & 3) == 3) && !(DB == 6 || DB == 7)) {
                         const int c = it >> 3, q = it & 7;
                         CW_AT(u32x4, q_pub, c * 2 * SLOT + PR * 2048 + (q == 7 ? 512 : 0)) = u32x4{ph[q - 3], ph[q - 2], ph[q - 1], ph[q]};
                     }
                     if (ip >= 0) {
                         const int cp = ip >> 3, qp = ip & 7;
-                        if ((qp == 3 || qp == 7) && (DBG == 6 || DBG == 7)) { asm volatile("" :: "v"(ph[qp]), "v"(pm[qp]), "v"(ph[qp - 1]), "v"(pm[qp - 1]), "v"(ph[qp - 2]), "v"(pm[qp - 2]), "v"(ph[qp - 3]), "v"(pm[qp - 3])); }
+                        if ((qp == 3 || qp == 7) && (DB == 6 || DB == 7)) { asm volatile("" :: "v"(ph[qp]), "v"(pm[qp]), "v"(ph[qp - 1]), "v"(pm[qp - 1]), "v"(ph[qp - 2]), "v"(pm[qp - 2]), "v"(ph[qp - 3]), "v"(pm[qp - 3])); }
                         else if (qp == 3 || qp == 7)
                             CW_AT(u32x4, q_pub, cp * 2 * SLOT + PR * 2048 + (qp == 7 ? 512 : 0) + 1024) = u32x4{pm[qp - 3], pm[qp - 2], pm[qp - 1], pm[qp]};
                     }
@@ -487,6 +575,11 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
                         split2h(__fmul_rn(e1.z, sc_run), 0.f, xh[3], xm[3]);
                         CW_AT(u32x4, q_ext, PR * 2048) = u32x4{xh[0], xh[1], xh[2], xh[3]};
                         CW_AT(u32x4, q_ext, PR * 2048 + 1024) = u32x4{xm[0], xm[1], xm[2], xm[3]};
+                        if constexpr (TR && !HNR_CW_X_NOEXT) {                                     // X3 = [H2 | colour3 | dir - viewdir | dir . viewdir | 0]  (not in the wait counts: not every wave issues them)
+                            const int ev = ((to.t * 128 + 32 * PR + CW_KEEP(j)) * a.ldh[1] + 256) * 4;
+                            __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(e0.x), __float_as_uint(e0.y), __float_as_uint(e0.z), __float_as_uint(e0.w)}, hrs[1], ev, 0, 0);
+                            __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(e1.x), __float_as_uint(e1.y), __float_as_uint(e1.z), 0u}, hrs[1], ev + 16, 0, 0);
+                        }
                     }
                 } else prefetch_next();
             }
@@ -510,6 +603,8 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
                 x5_voff = st ? (ls * a.ld5 + col0) * 4 : 0x40000000;
                 x5_flag = kc_e > 0 ? 0.f : 1.f;
                 x5_flag2 = kc_e > 1 ? 0.f : 1.f;
+                if constexpr (TR && !HNR_CW_X_NOX5) x5m = 0.f;
+                if constexpr (TR && !HNR_CW_X_NOX5) x5_take = (st && to.first + CW_KEEP(ls) < to.end) ? 1.f : 0.f;
             } else if (ms < 33) {
                 // the sum over a sample's 8 (4, 2) row slots = 8 (4, 2) adjacent lanes: pair swap, quad-pair swap, half-row mirror; the second and
                 // third step as f += dpp(f) * flag (exactly f + dpp(f) or f).  Four values per step and one asm block per step: a DPP read sits four
@@ -534,8 +629,13 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
                                  : "+v"(kf[kb][0]), "+v"(kf[kb][1]), "+v"(kf[kb][2]), "+v"(kf[kb][3]) : "v"(x5_flag));
                     __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(kf[kb][0]), __float_as_uint(kf[kb][1]), __float_as_uint(kf[kb][2]), __float_as_uint(kf[kb][3])}, to.rs,
                                                            x5_voff + (32 * c + e0i) * 4, 0, 0);
+                    if constexpr (TR && !HNR_CW_X_NOX5) {
+                        const float m4 = fmaxf(fmaxf(fabsf(kf[kb][0]), fabsf(kf[kb][1])), fmaxf(fabsf(kf[kb][2]), fabsf(kf[kb][3])));
+                        x5m = fmaxf(x5m, __fmul_rn(m4, x5_take));                // lanes that store nothing hold partial sums: times 0 (a NaN from garbage loses the maximum)
+                    }
                 }
             } else if (ms == 33) {
+                if constexpr (TR && !HNR_CW_X_NOX5) CW_HMAX_PUT(4, x5m);
                 // the tile's density inputs (the alpha dot of every row = the four waves' partial sums): wave w stores row tile w's 32 values into the
                 // tile's row scalars; softplus, the rows' weights and the K-sum are chain_sigma_kernel's (~160 instructions per wave and tile that
                 // no MFMA of this kernel could hide: they ran in the 24-MFMA pass (0,0))
@@ -569,7 +669,7 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
             constexpr int PP = (P + 15) & 15, PL = PP >> 2, PR = PP & 3, sm = rt & 1;
             constexpr int T = 6 * S, H = T / 2;
             const TileOut &to_e = P == 0 ? to_fin : to_cur;                // tile of the row tile whose epilogue runs here
-            if (DBG >= 2) { const long long t_ = clock64(); tm[(P + 15) & 15] += t_ - t_prev; t_prev = t_; if (P == 2) tmf[3] += t_ - tf_prev; if (P == 1) tf_prev = t_; }
+            if (DB >= 2) { const long long t_ = clock64(); tm[(P + 15) & 15] += t_ - t_prev; t_prev = t_; if (P == 2) tmf[3] += t_ - tf_prev; if (P == 1) tf_prev = t_; }
             if constexpr (P != 0) CW_REFRESH(P);
             // ---- pass start: loads that ride ahead (each placed where no wait of the following passes lands right behind it)
             if (P == 6) {                                                  // block3.0's 17th k step: used by the last MFMAs of passes (2, 0..3)
@@ -589,18 +689,20 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
                     // DMA'd layer-0 images: row tile 0's must have landed before the barrier of (3,3) (read from that pass's last iterations on), row
                     // tile 3's before the barrier of (0,2); row tiles 1, 2: covered by the wait at the head of (0,0).  Counted in the asm loads this wave
                     // has issued since (cw_dma_count)
-                    if constexpr (P == 15) cw_wait_vm<cw_dma_count(0, 15)>();
-                    if constexpr (P == 2) cw_wait_vm<cw_dma_count(3, 2)>();
-                    if (DBG >= 2 && P == 1) { const long long t_ = clock64(); tmf[0] += t_ - tf_prev; tf_prev = t_; }
+                    // (more than 63 operations issued since: the counter cannot hold that many, the DMA has landed)
+                    if constexpr (P == 15) { constexpr int d_ = cw_dma_count(0, 15, TR); if constexpr (d_ <= 63) cw_wait_vm<d_>(); }
+                    if constexpr (P == 2) { constexpr int d_ = cw_dma_count(3, 2, TR); if constexpr (d_ <= 63) cw_wait_vm<d_>(); }
+                    if (DB >= 2 && P == 1) { const long long t_ = clock64(); tmf[0] += t_ - tf_prev; tf_prev = t_; }
                     cw_lds_barrier();
-                    if (DBG >= 2 && P == 1) { const long long t_ = clock64(); tmf[1] += t_ - tf_prev; tf_prev = t_; }
+                    if (DB >= 2 && P == 1) { const long long t_ = clock64(); tmf[1] += t_ - tf_prev; tf_prev = t_; }
                     // every wave is past the first k steps of pass (3, rt): the next tile's image of row tile rt may overwrite their operand planes
                     if constexpr (L == 3) dma_image(tile_nx, rt);
                     // layer 0's table rows are asked for one and a half passes before their epilogue: row tile rt + 1 at the barrier of pass
                     // (0, rt) -- the set it goes into was consumed in this pass's first half --, the next tile's row tile 0 at the barrier of (3, 2)
-                    if constexpr (L == 0 && rt < 3) load_table(pid[rt + 1], tv[(rt + 1) & 1]);
+                    if constexpr (!TR && L == 0 && rt < 3) load_table(pid[rt + 1], tv[TR ? 0 : (rt + 1) & 1]);
+                    if constexpr (TR && L == 0 && rt >= 1) load_table(pid[rt], tv[0]);
                     if constexpr (P == 14) load_table(pid_n[0], tv[0]);
-                    if (DBG >= 2 && P == 1) { const long long t_ = clock64(); tmf[2] += t_ - tf_prev; tf_prev = t_; }
+                    if (DB >= 2 && P == 1) { const long long t_ = clock64(); tmf[2] += t_ - tf_prev; tf_prev = t_; }
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 constexpr int wp = g == 0 ? 1 : 0, xp_ = g == 1 ? 1 : 0;   // wm*xh, wh*xm, wh*xh: smallest terms first
@@ -608,11 +710,11 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
                 // first pass of a layer: wait for the k step's fragments, counted in the asm loads issued after them (cw_need_count).  Pass (0,0):
                 // the eight X5 stores of (3,2)'s epilogue also follow layer 0's fetches (a wait that did not allow for them would drain them)
                 if constexpr (rt == 0 && g == 0 && c == 0 && s < 16) {
-                    constexpr int n_ = cw_need_count(32 * L + s, P, slot) + (P == 0 ? 8 : 0);
-                    if constexpr (n_ <= 56) cw_wait_vm<n_>();
+                    constexpr int n_ = cw_need_count(32 * L + s, P, slot, TR) + (P == 0 ? 8 : 0);
+                    if constexpr (n_ <= (TR ? 63 : 56)) cw_wait_vm<n_>();
                 }
                 constexpr int A0 = 16 * (s < 16 ? s : 0) + 4 * wp + 8 * c;
-                if constexpr (DBG == 4) { if (slot < 2) { acc[sm][c] = f32x16{} + bf[ring][xp_][0]; } }
+                if constexpr (DB == 4) { if (slot < 2) { acc[sm][c] = f32x16{} + bf[ring][xp_][0]; } }
                 else if constexpr (L == 2 && s == 16) cw_mfma_vw(acc[sm][c], wx[c][wp], bf[ring][xp_]);
                 else if constexpr (slot < 2) cw_mfma_first<A0>(acc[sm][c], bf[ring][xp_]);
                 else cw_mfma<A0>(acc[sm][c], bf[ring][xp_]);
@@ -625,7 +727,7 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
                 if constexpr (g < 2 && c == 0 && P == 15 && it == 15) bf[0][g] = b_read(0, 0, g);
                 // the weight stream (cw_issue)
                 { constexpr int blk = cw_issue(P, slot); if constexpr (blk >= 0) CW_LOAD_W(blk >> 5, blk & 31); }
-                if (DBG != 3) epilogue_piece(PL, PR, S, slot, to_e);
+                if (DB != 3) epilogue_piece(PL, PR, S, slot, to_e);
                 __builtin_amdgcn_sched_barrier(0);
             });
         });
@@ -642,12 +744,29 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
         epilogue_piece(3, 3, CH_S0, slot, to_fin);
     });
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // the last tile's fetch-ahead (DMA into this workgroup's LDS) must not outlive the workgroup
-    if (DBG >= 2 && blockIdx.x == 0 && lane == 0 && a.dbg) {               // block 0: cycles per pass [wave][16]
+    if constexpr (TR) {
+        // one atomic per workgroup and layer (as chain_kernel<4, 3>)
+        __syncthreads();
+        float *exch = reinterpret_cast<float *>(lds + ch_lds_exch(4));
+#pragma unroll
+        for (int l = 0; l < 5; ++l) {
+            float m = tid < 128 ? CW_LDS(float, CW_HMAX + l * 512 + 4 * tid) : 0.f;
+            for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+            if (lane == 0) exch[4 * l + wave] = m;
+        }
+        __syncthreads();
+        if (tid < 5) {
+            const float m = fmaxf(fmaxf(exch[4 * tid], exch[4 * tid + 1]), fmaxf(exch[4 * tid + 2], exch[4 * tid + 3]));
+            unsigned *dst = tid < 4 ? (a.hmax ? a.hmax + tid : nullptr) : a.x5max;
+            if (dst && m > 0.f) atomicMax(dst, __float_as_uint(m));
+        }
+    }
+    if (DB >= 2 && blockIdx.x == 0 && lane == 0 && a.dbg) {               // block 0: cycles per pass [wave][16]
         long long *o = reinterpret_cast<long long *>(a.dbg) + 4 * 1024 + wave * 16;
         for (int i = 0; i < 16; ++i) o[i] = tm[i];
         if (wave == 0) { long long *o2 = reinterpret_cast<long long *>(a.dbg) + 4 * 1024 + 64; for (int i = 0; i < 4; ++i) o2[i] = tmf[i]; }
     }
-    if (DBG >= 2 && tid == 0 && a.dbg) {                                   // every block: {cycles, wall ticks, tiles}
+    if (DB >= 2 && tid == 0 && a.dbg) {                                   // every block: {cycles, wall ticks, tiles}
         long long *o = reinterpret_cast<long long *>(a.dbg) + 4 * (size_t)blockIdx.x;
         o[0] = clock64() - t_start; o[1] = wall_clock64() - w_start; o[2] = n_my; o[3] = 0;
     }
@@ -677,10 +796,15 @@ __global__ __launch_bounds__(128) void chain_sigma_kernel(ChainArgs a)
 int launch_chain_ws(const ChainArgs &a, int grid, hipStream_t st, int mode)
 {
     static PerDeviceOnce attr_once;
+#ifdef HNR_CW_ONLY8                                                              // register-pressure experiments: compile the training form alone
+    chain_ws_kernel<8><<<grid, 256, cw_lds_bytes(), st>>>(a);
+    return HNR_OK;
+#endif
     if (attr_once.first()) {
         HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chain_ws_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, cw_lds_bytes()));
         HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chain_ws_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, cw_lds_bytes()));
         HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chain_ws_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, cw_lds_bytes()));
+        HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chain_ws_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, cw_lds_bytes()));
 #ifdef HNR_CHAIN_WS_PROBES
         HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chain_ws_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, cw_lds_bytes()));
         HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chain_ws_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, cw_lds_bytes()));
@@ -697,7 +821,8 @@ int launch_chain_ws(const ChainArgs &a, int grid, hipStream_t st, int mode)
     else if (mode == 4) chain_ws_kernel<4><<<grid, 256, cw_lds_bytes(), st>>>(a);      // no MFMAs
     else
 #endif
-    if (mode == 2) chain_ws_kernel<2><<<grid, 256, cw_lds_bytes(), st>>>(a);
+    if (mode == 8) chain_ws_kernel<8><<<grid, 256, cw_lds_bytes(), st>>>(a);
+    else if (mode == 2) chain_ws_kernel<2><<<grid, 256, cw_lds_bytes(), st>>>(a);
     else if (mode == 1) chain_ws_kernel<1><<<grid, 256, cw_lds_bytes(), st>>>(a);
     else chain_ws_kernel<0><<<grid, 256, cw_lds_bytes(), st>>>(a);
     HNR_LAUNCH_CHECK();

@@ -599,7 +599,7 @@ extern "C" int hnr_render_train_forward(const hnr_grid *grid, const hnr_train_pa
     TR(mark());
     {
         float *H[4] = {L.H1, L.X3, L.H3, L.H4}; const int ldh[4] = {256, 264, 256, 256};
-        TR(chain_forward_train(L.chain_ws, L.Tu, 256, L.uidx, L.img_chain, o->d_counts, cap, sl, L.X5, 280, L.sigma, H, ldh, L.amax + AM_H1, L.amax + AM_X5, stream));     // (AM_X5 starts at 1: the direction encoding's columns)
+        TR(chain_forward_train(L.chain_ws, L.Tu, 256, L.uidx, L.img_chain, o->d_counts, cap, sl, L.X5, 280, L.sigma, H, ldh, L.amax + AM_H1, L.amax + AM_X5, stream, L.row_u, (int)L.ucap));     // (AM_X5 starts at 1: the direction encoding's columns)
     }
     TR(mark());
     // maxima that only the backward call's weight gradients read (per-tensor scales of X6, X7): on the side stream once the image branch is done with it

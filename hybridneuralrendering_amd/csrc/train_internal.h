@@ -11,7 +11,8 @@ int chain_gather_train(const float *d_xyz, const float *d_conf, const float *d_d
                        const int64_t *d_counts, int SR, int K, int cap_samples, void *d_workspace, float *d_X5, int ld5, float *d_weight_out,
                        float *d_conf_out, float *d_Xd, int32_t *d_row_pid, void *stream);
 int chain_forward_train(const void *d_workspace, const float *d_point_table, int ldt, const int32_t *d_uidx, const void *d_packed, const int64_t *d_counts,
-                        int cap_samples, float slope, float *d_X5, int ld5, float *d_sigma, float *const *d_H, const int *ldh, uint32_t *d_hmax, uint32_t *d_x5max, void *stream);
+                        int cap_samples, float slope, float *d_X5, int ld5, float *d_sigma, float *const *d_H, const int *ldh, uint32_t *d_hmax, uint32_t *d_x5max, void *stream,
+                        const int32_t *d_row_u = nullptr, int ucap = 0);
 // csrc/mlp.hip
 int mlp3_forward_train(const float *d_A, int lda, int64_t M_cap, const int64_t *d_counts, int count_index, int count_mult, int seg_stride,
                        const void *d_packed, int n_layers, const int *N, const int *K, const int *act, float slope, const float *d_R,
