@@ -30,21 +30,6 @@
 
 #include "chain_defs.h"
 
-#ifndef HNR_CW_X_NOROWU
-#define HNR_CW_X_NOROWU 0
-#endif
-#ifndef HNR_CW_X_NOHM
-#define HNR_CW_X_NOHM 0
-#endif
-#ifndef HNR_CW_X_NOX5
-#define HNR_CW_X_NOX5 0
-#endif
-#ifndef HNR_CW_X_NOHM3
-#define HNR_CW_X_NOHM3 0
-#endif
-#ifndef HNR_CW_X_NOEXT
-#define HNR_CW_X_NOEXT 0
-#endif
 namespace hnr {
 
 constexpr int CW_CST = ch_lds_exch(4) + 2048;          // LDS copy of bias[4][256], alpha_w[256], alpha_b, descale[4] (meta floats 0..1284)
@@ -163,21 +148,26 @@ constexpr int CW_TILE_STAMPS = 16 * 128 * 4;
 // asm loads (weight fetches: 4 each; image DMAs behind the barriers of passes (3, 0..3): 2 each) with a time stamp in (t0, t1); stamps of the previous
 // tile are the same minus CW_TILE_STAMPS.  Only asm loads count: the compiler's loads and stores between them make the true number of operations
 // in flight larger, so a wait derived from this count is conservative.
-// TRAINING form (chain_ws_kernel<8>): the first half of every epilogue stores the row tile's 16 x 2 post-activation values per lane as eight 16-B
-// buffer stores (one behind every second item).  They are counted by vmcnt like the loads (gfx9: one in-order counter for both), so the waits
+// TRAINING form (chain_ws_kernel<8>): every epilogue stores the row tile's 16 x 2 post-activation values per lane as eight 16-B buffer stores, four
+// per column tile once the tile's sixteen values are final (tr_group in the kernel: a 4 x 4 transpose inside each quad first, so that a store
+// instruction writes 64 consecutive bytes per quad).  They are counted by vmcnt like the loads (gfx9: one in-order counter for both), so the waits
 // below must allow for them exactly -- a wait that did not would drain the stores just issued.  cw_train_stores(P, sl): how many of them the
-// epilogue piece behind MFMA `sl` of pass P issues (the micro-stage arithmetic of epilogue_piece's first half).
+// epilogue piece behind MFMA `sl` of pass P issues (the micro-stage arithmetic of epilogue_piece).
 constexpr int cw_train_stores(int P, int sl)
 {
     const int S = cw_steps(P >> 2), T = 6 * S, H = T / 2;
-    if (sl >= H) return 0;
     const bool wide = S == 4;
-    const int MS = wide ? 17 : 33, m0 = sl * MS / H, m1 = (sl + 1) * MS / H;
     int n = 0;
-    for (int ms = m0; ms < m1; ++ms) {
-        if (ms >= MS - 1) continue;
-        if (wide) { if (ms & 1) ++n; }                                        // items 2 (ms >> 1) and + 1 finish together
-        else if ((ms & 1) && ((ms >> 1) & 1)) ++n;                           // item ms >> 1 finishes; a store behind every odd item
+    if (sl < H) {                                                             // column tile 0's group: sub-steps 3, 4 (two stores each)
+        const int MS = wide ? 17 : 33;
+        for (int ms = sl * MS / H; ms < (sl + 1) * MS / H; ++ms) {
+            if (wide) { if (ms == 15) n += 4; }
+            else if (ms == 23 || ms == 25) n += 2;
+        }
+    } else {                                                                  // column tile 1's group: micro-stages 1..5 of the second half
+        const int PLe = ((P + 15) & 15) >> 2, MS2 = PLe != 3 ? 21 : 35, k2 = sl - H, N2 = T - H;
+        for (int ms = k2 * MS2 / N2; ms < (k2 + 1) * MS2 / N2; ++ms)
+            if (ms == 4 || ms == 5) n += 2;
     }
     return n;
 }
@@ -308,7 +298,7 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
         const char *aux = a.aux + (size_t)tile * 4 * CH_AUX_GROUP;
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) {
-            if constexpr (TR && !HNR_CW_X_NOROWU) { const int u = a.row_u[(size_t)tile * 128 + 32 * rt + j]; pd[rt] = (unsigned)u >= (unsigned)a.ucap ? 0 : u; }     // empty slots / rows past the end carry the sentinel: row 0, like chain_kernel<4, 3>
+            if constexpr (TR) { const int u = a.row_u[(size_t)tile * 128 + 32 * rt + j]; pd[rt] = (unsigned)u >= (unsigned)a.ucap ? 0 : u; }     // empty slots / rows past the end carry the sentinel: row 0, like chain_kernel<4, 3>
             else pd[rt] = reinterpret_cast<const int32_t *>(aux + rt * CH_AUX_GROUP)[j];
         }
     };
@@ -363,12 +353,12 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
     // of range, which is how the epilogue pieces of "no tile" drop their stores), running maxima of the layers' outputs and of the stored sums
     __amdgpu_buffer_rsrc_t hrs[4];
     float x5m = 0.f, x5_take = 0.f;                                        // (live inside a layer-3 epilogue's second half only)
-    int hv = 0;
+    float4 tb[4];                                                          // a column tile's sixteen values on their way out (tr_group)
     if constexpr (TR) {
 #pragma unroll
         for (int l = 0; l < 4; ++l) hrs[l] = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(a.H[l]), 0, 0x7fffffff, 0x00020000);
     }
-    (void)hrs; (void)x5m; (void)x5_take; (void)hv;
+    (void)hrs; (void)x5m; (void)x5_take; (void)tb;
 #define CW_HMAX_PUT(l_, v_) asm volatile("ds_max_f32 %0, %1 offset:%2" :: "v"(q_exw), "v"(v_), "n"(CW_HMAX - (int)ch_lds_exch(4) + (l_) * 512) : "memory")
 
     // ---- prologue: first tile's row scalars, its four layer-0 images (DMA), its first table rows, layer-0 weights + block1.2's k steps 8..11
@@ -413,6 +403,39 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
     //      chains (the x and the y value of an item), an item's chain is cut in two stages that land behind different MFMAs, and LDS reads
     //      are issued well before their first use.  `slot` counts the 6 S MFMAs of the RUNNING pass, H = first slot of its second
     //      half; micro-stages [slot * MS / H, (slot + 1) * MS / H) run behind MFMA `slot`.  All arguments are constants after unrolling.
+    // Training form: the sixteen values of (row tile PR, column tile c) leave as four 16-B stores.  Stored straight from the accumulator layout a quad's
+    // four lanes would write to four different rows -- one address-unit cycle per (quad, cache line), 64 per instruction, and the kernel ran 0.60 ms
+    // against 0.455 with (meaningless) consecutive addresses.  So the quad transposes first, the way cw_table_swap's loads do in reverse: piece x of
+    // lane t ^ x by DPP (sub-steps 0, 1), slot r <- piece r ^ t inside each lane (2), then store r writes row (j & ~3) + r for the whole quad, lane t
+    // its piece r ^ t: 64 consecutive bytes per quad (3, 4).  All arguments are constants after unrolling.
+    auto tr_group = [&](int PL, int PR, int c, int sub, const TileOut &to) __attribute__((always_inline)) {
+        const int se = PR & 1;
+        auto dppx = [&](float v, int x) __attribute__((always_inline)) -> float {      // the value of lane t ^ x of the quad (bit pattern moved: the builtin on ints)
+            const int i = __builtin_bit_cast(int, v);
+            const int r = x == 1 ? __builtin_amdgcn_update_dpp(0, i, 0xB1, 0xf, 0xf, false) : x == 2 ? __builtin_amdgcn_update_dpp(0, i, 0x4E, 0xf, 0xf, false)
+                                                                                             : __builtin_amdgcn_update_dpp(0, i, 0x1B, 0xf, 0xf, false);
+            return __builtin_bit_cast(float, r);
+        };
+        if (sub == 0) {
+            tb[0] = make_float4(acc[se][c][0], acc[se][c][1], acc[se][c][2], acc[se][c][3]);
+            tb[1] = make_float4(dppx(acc[se][c][4], 1), dppx(acc[se][c][5], 1), dppx(acc[se][c][6], 1), dppx(acc[se][c][7], 1));
+        } else if (sub == 1) {
+            tb[2] = make_float4(dppx(acc[se][c][8], 2), dppx(acc[se][c][9], 2), dppx(acc[se][c][10], 2), dppx(acc[se][c][11], 2));
+            tb[3] = make_float4(dppx(acc[se][c][12], 3), dppx(acc[se][c][13], 3), dppx(acc[se][c][14], 3), dppx(acc[se][c][15], 3));
+        } else if (sub == 2) cw_table_swap(tb[0], tb[1], tb[2], tb[3]);
+        else {
+            // byte offset of (row (j & ~3) of row tile PR, this half's 64 bytes of column tile c) in H[PL]; the lane's row and half are laundered
+            // (derived offsets hoisted out of the tile loop cost a register each); "no tile": bit 31 set = out of the descriptor's range
+            const int ld4 = a.ldh[PL] * 4;
+            const int sb = (to.t < 0 ? (int)0x80000000 : (to.t * 128 + 32 * PR) * ld4 + wave * 256) + 128 * c;
+            const int jj = CW_KEEP(j);
+            const int hvq = (jj & ~3) * ld4 + (CW_KEEP(h) * 64 + sb), t16 = (jj & 3) * 16;
+#pragma unroll
+            for (int r = 2 * (sub - 3); r < 2 * (sub - 3) + 2; ++r)
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(tb[r].x), __float_as_uint(tb[r].y), __float_as_uint(tb[r].z), __float_as_uint(tb[r].w)}, hrs[PL],
+                                                       hvq + r * ld4 + ((16 * r) ^ t16), 0, 0);
+        }
+    };
     auto epilogue_piece = [&](int PL, int PR, int S, int slot, const TileOut &to) __attribute__((always_inline)) {
         const int T = 6 * S, H = T / 2, se = PR & 1;
         const int exb = (PR & 1) * 512;
@@ -429,18 +452,6 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
                 // scalar fp32 VALU on purpose: packed fp32 instructions (v_pk_fma_f32 ...) do not overlap with this wave's MFMAs -- one
                 // of them behind an MFMA costs 18 cycles of matrix-pipe time, a v_fma_f32 none (tools/interleave_probe.hip)
                 if (it == 0) { amax = 0.f; ap = 0.f; }
-                if constexpr (TR) {
-                    if (it == 0) {                                              // this lane's byte offset of (row 32 PR + j of the tile, column col0) in H[PL]
-                        // (the lane's row and half are laundered: derived per-(layer, row tile) offsets hoisted out of the tile loop cost a register each)
-                        const int ld4 = a.ldh[PL] * 4;
-                        const int sb = to.t < 0 ? (int)0x80000000 : (to.t * 128 + 32 * PR) * ld4 + wave * 256;
-#ifdef HNR_CW_TR_COALESCED                                                       // timing probe (results are garbage): every store instruction writes 1 KiB of consecutive bytes
-                        hv = CW_KEEP(lane) * 16 + ((to.t < 0 ? (int)0x80000000 : (to.t * 128 + 32 * PR) * ld4) + wave * 256 * 32);
-#else
-                        hv = CW_KEEP(j) * ld4 + (CW_KEEP(h) * 64 + sb);
-#endif
-                    }
-                }
                 if ((it & 1) == 0 && k >= 1 && k + 1 < 8) { bq[(k + 1) & 1] = read_cst(PL, k + 1); if (PL == 3) aq[(k + 1) & 1] = read_cst(4, k + 1); }
                 float ax = (it & 1) ? bq[k & 1].z : bq[k & 1].x, ay = (it & 1) ? bq[k & 1].w : bq[k & 1].y;
                 if (PL == 0) {
@@ -462,17 +473,6 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
                 else amax = fmaxf(fmaxf(amax, fabsf(vx)), fabsf(vy));
                 if constexpr (TR) {
                     if (PL == 3) amax = fmaxf(fmaxf(amax, fabsf(vx)), fabsf(vy));
-#ifndef HNR_CW_TR_NOSTORE
-                    if (it & 1)                                                 // columns col0 + 32 c + 2 (q - 1) .. + 3 of the row: items it - 1, it
-#else
-                    if (false)
-#endif
-                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(acc[se][c][2 * q - 2]), __float_as_uint(acc[se][c][2 * q - 1]), __float_as_uint(vx), __float_as_uint(vy)},
-#ifdef HNR_CW_TR_COALESCED
-                                                               hrs[PL], hv + (8 * c + 2 * (q - 1)) * 512, 0, 0);
-#else
-                                                               hrs[PL], hv + (32 * c + 2 * (q - 1)) * 4, 0, 0);
-#endif
                 }
                 if (DB == 1) {
                     if (a.dbg && a.dbg_layer == PL && to.t >= 0) {
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
                     float v_lo, v_hi;
                     if (PL == 3) {
                         cw_halves(ap, v_lo, v_hi); m = __fadd_rn(v_lo, v_hi); CW_AT(float, q_dsw, PR * 512) = m;
-                        if constexpr (TR && !HNR_CW_X_NOHM3) { const float am = __fmul_rn(amax, to.t >= 0 ? 1.f : 0.f); CW_HMAX_PUT(3, am); }     // (no tile: garbage times 0; a NaN loses the comparison)
+                        if constexpr (TR) { const float am = __fmul_rn(amax, to.t >= 0 ? 1.f : 0.f); CW_HMAX_PUT(3, am); }     // (no tile: garbage times 0; a NaN loses the comparison)
                     }
                     else {
                         cw_halves(amax, v_lo, v_hi);
@@ -511,7 +511,15 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
                             m = fmaxf(m, fmaxf(fmaxf(fmaxf(fabsf(e0.x), fabsf(e0.y)), fmaxf(fabsf(e0.z), fabsf(e0.w))), fmaxf(fmaxf(fabsf(e1.x), fabsf(e1.y)), fabsf(e1.z))));
                     }
                     if (PL != 3 && DB != 6 && DB != 7) CW_AT(float, q_exw, exb) = m;
-                    if constexpr (TR && !HNR_CW_X_NOHM) { if (PL != 3) CW_HMAX_PUT(PL, m); }
+                    if constexpr (TR) { if (PL != 3) CW_HMAX_PUT(PL, m); }
+                }
+                if constexpr (TR) {                                             // column tile 0 is final after item 7 (micro-stage 15; wide: 7)
+                    if (wide) {
+                        if (ms == 9) tr_group(PL, PR, 0, 0, to);
+                        if (ms == 11) tr_group(PL, PR, 0, 1, to);
+                        if (ms == 13) tr_group(PL, PR, 0, 2, to);
+                        if (ms == 15) { tr_group(PL, PR, 0, 3, to); tr_group(PL, PR, 0, 4, to); }
+                    } else if (ms >= 17 && ms <= 25 && (ms & 1)) tr_group(PL, PR, 0, (ms - 17) >> 1, to);
                 }
             }
             return;
@@ -529,6 +537,7 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
             const int MS = 21, m0 = k2 * MS / N2, m1 = (k2 + 1) * MS / N2;
 #pragma unroll
             for (int ms = m0; ms < m1; ++ms) {
+                if constexpr (TR) { if (ms >= 1 && ms <= 5) tr_group(PL, PR, 1, ms - 1, to); }       // column tile 1's values leave
                 if (ms == 0) ex4 = (DB == 5 || DB == 7) ? make_float4(amax, 1.f, 2.f, 3.f) : CW_AT_F4(q_exr, exb);
                 else if (ms == 1) {
                     const int k = row_scale_exp(fmaxf(fmaxf(ex4.x, ex4.y), fmaxf(ex4.z, ex4.w)));
@@ -575,7 +584,7 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
                         split2h(__fmul_rn(e1.z, sc_run), 0.f, xh[3], xm[3]);
                         CW_AT(u32x4, q_ext, PR * 2048) = u32x4{xh[0], xh[1], xh[2], xh[3]};
                         CW_AT(u32x4, q_ext, PR * 2048 + 1024) = u32x4{xm[0], xm[1], xm[2], xm[3]};
-                        if constexpr (TR && !HNR_CW_X_NOEXT) {                                     // X3 = [H2 | colour3 | dir - viewdir | dir . viewdir | 0]  (not in the wait counts: not every wave issues them)
+                        if constexpr (TR) {                                     // X3 = [H2 | colour3 | dir - viewdir | dir . viewdir | 0]  (not in the wait counts: not every wave issues them)
                             const int ev = ((to.t * 128 + 32 * PR + CW_KEEP(j)) * a.ldh[1] + 256) * 4;
                             __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(e0.x), __float_as_uint(e0.y), __float_as_uint(e0.z), __float_as_uint(e0.w)}, hrs[1], ev, 0, 0);
                             __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(e1.x), __float_as_uint(e1.y), __float_as_uint(e1.z), 0u}, hrs[1], ev + 16, 0, 0);
@@ -595,6 +604,7 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
         const int MS = 35, m0 = k2 * MS / N2, m1 = (k2 + 1) * MS / N2;
 #pragma unroll
         for (int ms = m0; ms < m1; ++ms) {
+            if constexpr (TR) { if (ms >= 1 && ms <= 5) tr_group(PL, PR, 1, ms - 1, to); }
             if (ms == 0) {
                 if (PR == 3) ex4 = CW_AT_F4(q_dsr, 0);
                 // this row tile's samples: (4 << kc) of them from sample PR (4 << kc) of the tile; lanes past the tile's / class's end are out of the descriptor's range
@@ -603,8 +613,8 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
                 x5_voff = st ? (ls * a.ld5 + col0) * 4 : 0x40000000;
                 x5_flag = kc_e > 0 ? 0.f : 1.f;
                 x5_flag2 = kc_e > 1 ? 0.f : 1.f;
-                if constexpr (TR && !HNR_CW_X_NOX5) x5m = 0.f;
-                if constexpr (TR && !HNR_CW_X_NOX5) x5_take = (st && to.first + CW_KEEP(ls) < to.end) ? 1.f : 0.f;
+                if constexpr (TR) x5m = 0.f;
+                if constexpr (TR) x5_take = (st && to.first + CW_KEEP(ls) < to.end) ? 1.f : 0.f;
             } else if (ms < 33) {
                 // the sum over a sample's 8 (4, 2) row slots = 8 (4, 2) adjacent lanes: pair swap, quad-pair swap, half-row mirror; the second and
                 // third step as f += dpp(f) * flag (exactly f + dpp(f) or f).  Four values per step and one asm block per step: a DPP read sits four
@@ -629,13 +639,13 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
                                  : "+v"(kf[kb][0]), "+v"(kf[kb][1]), "+v"(kf[kb][2]), "+v"(kf[kb][3]) : "v"(x5_flag));
                     __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(kf[kb][0]), __float_as_uint(kf[kb][1]), __float_as_uint(kf[kb][2]), __float_as_uint(kf[kb][3])}, to.rs,
                                                            x5_voff + (32 * c + e0i) * 4, 0, 0);
-                    if constexpr (TR && !HNR_CW_X_NOX5) {
+                    if constexpr (TR) {
                         const float m4 = fmaxf(fmaxf(fabsf(kf[kb][0]), fabsf(kf[kb][1])), fmaxf(fabsf(kf[kb][2]), fabsf(kf[kb][3])));
                         x5m = fmaxf(x5m, __fmul_rn(m4, x5_take));                // lanes that store nothing hold partial sums: times 0 (a NaN from garbage loses the maximum)
                     }
                 }
             } else if (ms == 33) {
-                if constexpr (TR && !HNR_CW_X_NOX5) CW_HMAX_PUT(4, x5m);
+                if constexpr (TR) CW_HMAX_PUT(4, x5m);
                 // the tile's density inputs (the alpha dot of every row = the four waves' partial sums): wave w stores row tile w's 32 values into the
                 // tile's row scalars; softplus, the rows' weights and the K-sum are chain_sigma_kernel's (~160 instructions per wave and tile that
                 // no MFMA of this kernel could hide: they ran in the 24-MFMA pass (0,0))
@@ -796,10 +806,6 @@ __global__ __launch_bounds__(128) void chain_sigma_kernel(ChainArgs a)
 int launch_chain_ws(const ChainArgs &a, int grid, hipStream_t st, int mode)
 {
     static PerDeviceOnce attr_once;
-#ifdef HNR_CW_ONLY8                                                              // register-pressure experiments: compile the training form alone
-    chain_ws_kernel<8><<<grid, 256, cw_lds_bytes(), st>>>(a);
-    return HNR_OK;
-#endif
     if (attr_once.first()) {
         HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chain_ws_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, cw_lds_bytes()));
         HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chain_ws_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, cw_lds_bytes()));
