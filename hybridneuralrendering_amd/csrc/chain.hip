@@ -166,6 +166,14 @@ __global__ __launch_bounds__(256, RT >= 4 ? 1 : 2) void chain_kernel(ChainArgs a
                         for (int q = 0; q < 4; ++q)
                             *reinterpret_cast<float4 *>(o + 32 * c + 4 * q) = make_float4(acc[rt][c][4 * q], acc[rt][c][4 * q + 1], acc[rt][c][4 * q + 2], acc[rt][c][4 * q + 3]);
                     hmax_run[layer] = fmaxf(hmax_run[layer], m);
+                    if (a.hbits && layer < 3) {                                 // the signs of the lane's 32 values (chain_defs.h)
+                        unsigned mb = 0u;
+#pragma unroll
+                        for (int c = 0; c < 2; ++c)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) mb = (mb << 1) | (acc[rt][c][r] > 0.f ? 1u : 0u);
+                        a.hbits[(size_t)layer * a.hbits_stride + (((size_t)tile * RT + rt) * 4 + wave) * 64 + lane] = mb;
+                    }
                 }
             }
         };
@@ -856,7 +864,7 @@ extern "C" int hnr_chain_forward(const void *d_workspace, const float *d_point_t
     // default: the weight-stationary pipelined kernel (csrc/chain_ws.hip)
     static int rt_mode = 0;
     if (rt_mode == 0) { const char *e = getenv("HNR_CHAIN_RT"); rt_mode = (e && atoi(e) == 4) ? 4 : 16; }
-    a.skew = 0; a.uidx = nullptr; a.hmax = nullptr; a.x5max = nullptr; a.row_u = nullptr; a.ucap = 0;
+    a.skew = 0; a.uidx = nullptr; a.hmax = nullptr; a.x5max = nullptr; a.row_u = nullptr; a.ucap = 0; a.hbits = nullptr; a.hbits_stride = 0;
     for (int l = 0; l < 4; ++l) { a.H[l] = nullptr; a.ldh[l] = 0; }
     static PerDeviceOnce attr_once;
     if (attr_once.first()) {
@@ -889,7 +897,7 @@ int chain_gather_train(const float *d_xyz, const float *d_conf, const float *d_d
 
 int chain_forward_train(const void *d_workspace, const float *d_point_table, int ldt, const int32_t *d_uidx, const void *d_packed, const int64_t *d_counts,
                         int cap_samples, float slope, float *d_X5, int ld5, float *d_sigma, float *const *d_H, const int *ldh, uint32_t *d_hmax, uint32_t *d_x5max, void *stream,
-                        const int32_t *d_row_u, int ucap)
+                        const int32_t *d_row_u, int ucap, uint32_t *d_hbits, long long hbits_stride)
 {
     if (cap_samples <= 0) return HNR_OK;
     const int blocks = cdiv(cap_samples, 16) + 2;
@@ -899,7 +907,7 @@ int chain_forward_train(const void *d_workspace, const float *d_point_table, int
     a.counts = reinterpret_cast<const unsigned long long *>(d_counts);
     a.X5 = d_X5; a.ld5 = ld5; a.sigma = d_sigma; a.slope = slope; a.cap_samples = cap_samples; a.dbg = nullptr; a.dbg_layer = 0; a.skew = 0;
     for (int l = 0; l < 4; ++l) { a.H[l] = d_H[l]; a.ldh[l] = ldh[l]; }
-    a.uidx = d_uidx; a.hmax = d_hmax; a.x5max = d_x5max; a.row_u = d_row_u; a.ucap = ucap;
+    a.uidx = d_uidx; a.hmax = d_hmax; a.x5max = d_x5max; a.row_u = d_row_u; a.ucap = ucap; a.hbits = d_hbits; a.hbits_stride = hbits_stride;
     const int n_cu = chain_num_cus();
     const int tiles = cdiv(cap_samples, 16), grid = tiles < n_cu ? tiles : n_cu;
     // The weight-stationary pipelined kernel in its activation-keeping form (csrc/chain_ws.hip, chain_ws_kernel<8>: the render path's kernel + eight

@@ -36,6 +36,8 @@ struct ChainArgs {
     float *H[4]; int ldh[4];           // [rows, ldh >= 256] block1.0 / block1.2 / block3.0 / block3.2 outputs; H[1] has ldh >= 264: columns 256..263 = block3's 7 extras + 0
     const int32_t *uidx;               // optional: point id -> row of ptab (the table holds the batch's touched points only)
     const int32_t *row_u; int ucap;    // chain_ws_kernel<8>: row -> row of ptab directly (>= ucap: none, row 0 is used)
+    uint32_t *hbits; long long hbits_stride;   // training, optional: the signs of H[0..2] as one word per (32-row tile, wave, lane): bit 31 - i = (value i of the lane's 32 columns > 0);
+                                               // layer l at hbits + l * hbits_stride words, word (((row >> 5) * 4 + wave) * 64 + lane).  The input gradients' LeakyReLU' reads these.
     unsigned *hmax;                    // [4] bit patterns of max |H[l]| (atomicMax; H[1]'s includes the extras): scales of the weight-gradient GEMMs
     unsigned *x5max;                   // optional: bit pattern of max |weighted feature sum| (the first 256 columns of X5), atomicMax
 };

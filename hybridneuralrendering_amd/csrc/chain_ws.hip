@@ -159,10 +159,11 @@ constexpr int cw_train_stores(int P, int sl)
     const bool wide = S == 4;
     int n = 0;
     if (sl < H) {                                                             // column tile 0's group: sub-steps 3, 4 (two stores each)
-        const int MS = wide ? 17 : 33;
+        const int MS = wide ? 17 : 33, PLe = ((P + 15) & 15) >> 2;
         for (int ms = sl * MS / H; ms < (sl + 1) * MS / H; ++ms) {
             if (wide) { if (ms == 15) n += 4; }
             else if (ms == 23 || ms == 25) n += 2;
+            if (ms == MS - 1 && PLe != 3) n += 1;                             // the sign words of H[0..2]
         }
     } else {                                                                  // column tile 1's group: micro-stages 1..5 of the second half
         const int PLe = ((P + 15) & 15) >> 2, MS2 = PLe != 3 ? 21 : 35, k2 = sl - H, N2 = T - H;
@@ -172,7 +173,7 @@ constexpr int cw_train_stores(int P, int sl)
     return n;
 }
 constexpr int cw_train_stores_pass(int P) { int n = 0; for (int sl = 0; sl < 6 * cw_steps(P >> 2); ++sl) n += cw_train_stores(P, sl); return n; }
-static_assert(cw_train_stores_pass(0) == 8 && cw_train_stores_pass(5) == 8 && cw_train_stores_pass(9) == 8 && cw_train_stores_pass(15) == 8, "eight activation stores per pass");
+static_assert(cw_train_stores_pass(0) == 8 && cw_train_stores_pass(4) == 9 && cw_train_stores_pass(5) == 9 && cw_train_stores_pass(9) == 9 && cw_train_stores_pass(15) == 8, "eight activation stores per pass (+ the sign word of a hidden layer's row tile)");
 constexpr int cw_asm_between(int t0, int t1, bool trn = false)
 {
     int n = 0;
@@ -354,11 +355,14 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
     __amdgpu_buffer_rsrc_t hrs[4];
     float x5m = 0.f, x5_take = 0.f;                                        // (live inside a layer-3 epilogue's second half only)
     float4 tb[4];                                                          // a column tile's sixteen values on their way out (tr_group)
+    unsigned mbits = 0u;                                                   // signs of the running epilogue's 32 values (bit 31 - i: value i > 0)
+    __amdgpu_buffer_rsrc_t brs;
     if constexpr (TR) {
 #pragma unroll
         for (int l = 0; l < 4; ++l) hrs[l] = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(a.H[l]), 0, 0x7fffffff, 0x00020000);
     }
-    (void)hrs; (void)x5m; (void)x5_take; (void)tb;
+    if constexpr (TR) brs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(a.hbits), 0, a.hbits ? 0x7fffffff : 0, 0x00020000);
+    (void)hrs; (void)x5m; (void)x5_take; (void)tb; (void)mbits; (void)brs;
 #define CW_HMAX_PUT(l_, v_) asm volatile("ds_max_f32 %0, %1 offset:%2" :: "v"(q_exw), "v"(v_), "n"(CW_HMAX - (int)ch_lds_exch(4) + (l_) * 512) : "memory")
 
     // ---- prologue: first tile's row scalars, its four layer-0 images (DMA), its first table rows, layer-0 weights + block1.2's k steps 8..11
@@ -473,6 +477,11 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
                 else amax = fmaxf(fmaxf(amax, fabsf(vx)), fabsf(vy));
                 if constexpr (TR) {
                     if (PL == 3) amax = fmaxf(fmaxf(amax, fabsf(vx)), fabsf(vy));
+                    else {                                                      // mbits = mbits * 2 + (v > 0), twice: thirty-two of these push the previous row tile's bits out
+                        unsigned long long cy;
+                        asm volatile("v_cmp_gt_f32 vcc, %2, 0\n\tv_cmp_gt_f32_e64 %1, %3, 0\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\tv_addc_co_u32_e64 %0, %1, %0, %0, %1"
+                                     : "+v"(mbits), "=&s"(cy) : "v"(vx), "v"(vy) : "vcc");
+                    }
                 }
                 if (DB == 1) {
                     if (a.dbg && a.dbg_layer == PL && to.t >= 0) {
@@ -512,6 +521,10 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
                     }
                     if (PL != 3 && DB != 6 && DB != 7) CW_AT(float, q_exw, exb) = m;
                     if constexpr (TR) { if (PL != 3) CW_HMAX_PUT(PL, m); }
+                    if constexpr (TR) {
+                        if (PL != 3)                                            // (counted in cw_train_stores; a NULL a.hbits has an empty descriptor: dropped)
+                            __builtin_amdgcn_raw_buffer_store_b32(mbits, brs, CW_KEEP(lane) * 4, (int)(PL * a.hbits_stride * 4) + ((to.t * 4 + PR) * 4 + wave) * 256, 0);
+                    }
                 }
                 if constexpr (TR) {                                             // column tile 0 is final after item 7 (micro-stage 15; wide: 7)
                     if (wide) {

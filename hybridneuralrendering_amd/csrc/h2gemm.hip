@@ -92,6 +92,8 @@ struct H2LinArgs {
     int act;                                   // mode 0: LeakyReLU after the bias
     float slope;
     const float *side; int lds_;               // mode 1: stored forward activation [M, lds_]
+    const uint32_t *side_bits;                 // mode 1, optional: its signs instead -- one word per (32-row tile, wave, lane) of the chain kernels' layout, bit 31 - i = (value i of the
+                                               // lane's 32 columns col0 + 32 c + 0..15 is > 0); 1/32 of the bytes and one load per row tile and lane instead of eight
     float *C; int ldc;
     unsigned *absmax;                          // optional: max |C| (bit pattern, atomicMax)
 };
@@ -196,7 +198,10 @@ __global__ __launch_bounds__(256, 2) void h2lin_kernel(H2LinArgs a)
             h2_mfma_layer<RT, 2, S, 0, CH_WSTEP, SLOT>(wsrd, 0, woff, lds, lane, acc, []() {});
             // mode 1: the rows' stored activations, one row tile ahead of its use (the weight fragments' registers are free by now)
             float4 sd[2][2][4];
+            unsigned sbits[2] = {0u, 0u};
+            const bool use_bits = a.side_bits != nullptr;
             auto load_side = [&](int rt) {
+                if (use_bits) { sbits[rt & 1] = a.side_bits[(((row_base + 32 * rt) >> 5) * 4 + wave) * 64 + lane]; return; }
                 long long row = row_base + 32 * rt + j;
                 if (row >= M) row = M - 1;
                 const float *srow = a.side + (size_t)phys(row) * a.lds_ + col0;
@@ -222,6 +227,7 @@ __global__ __launch_bounds__(256, 2) void h2lin_kernel(H2LinArgs a)
                         for (int e = 0; e < 4; ++e) {
                             float v = fmaf(acc[rt][c][4 * q + e], inv[rt], bq[e]);
                             if (a.mode == 0) { if (a.act) v = fmaxf(v, __fmul_rn(v, a.slope)); }
+                            else if (use_bits) v = __fmul_rn(v, ((sbits[rt & 1] >> (31 - (16 * c + 4 * q + e))) & 1u) ? 1.f : a.slope);
                             else v = __fmul_rn(v, sq[e] > 0.f ? 1.f : a.slope);
                             o[4 * q + e] = v;
                             gmax = fmaxf(gmax, fabsf(v));
@@ -757,12 +763,30 @@ extern "C" int hnr_h2lin_pack(int n_jobs, const float *const *d_W, const int64_t
     return HNR_OK;
 }
 
+namespace hnr {
+int h2lin_launch(const float *d_A, int lda, int64_t M_cap, const int64_t *d_m, int n_seg, int64_t seg_stride, const void *d_packed, int N, int K, int mode,
+                 int act, float slope, const float *d_side, int ld_side, const uint32_t *d_side_bits, float *d_C, int ldc, uint32_t *d_absmax, void *stream);
+// dX = (dZ W) * LeakyReLU'(forward activation) with the activation's signs as the chain kernels' bit words (csrc/chain_ws.hip, training form)
+int h2lin_dgrad_bits(const float *d_dZ, int ldz, int64_t M_cap, const int64_t *d_m, const void *d_packed, int N, int K, float slope, const uint32_t *d_side_bits,
+                     float *d_C, int ldc, uint32_t *d_absmax, void *stream)
+{
+    if (!d_side_bits || N != 256 || (M_cap & 31)) { set_error("h2lin_dgrad_bits: needs the bit words, N = 256 and whole 32-row tiles"); return HNR_ERR_BADARG; }
+    return h2lin_launch(d_dZ, ldz, M_cap, d_m, 1, 0, d_packed, N, K, 1, 0, slope, nullptr, 0, d_side_bits, d_C, ldc, d_absmax, stream);
+}
+}  // namespace hnr
+
 extern "C" int hnr_h2lin(const float *d_A, int lda, int64_t M_cap, const int64_t *d_m, int n_seg, int64_t seg_stride, const void *d_packed, int N, int K, int mode,
                          int act, float slope, const float *d_side, int ld_side, float *d_C, int ldc, uint32_t *d_absmax, void *stream)
 {
+    return hnr::h2lin_launch(d_A, lda, M_cap, d_m, n_seg, seg_stride, d_packed, N, K, mode, act, slope, d_side, ld_side, nullptr, d_C, ldc, d_absmax, stream);
+}
+
+int hnr::h2lin_launch(const float *d_A, int lda, int64_t M_cap, const int64_t *d_m, int n_seg, int64_t seg_stride, const void *d_packed, int N, int K, int mode,
+                      int act, float slope, const float *d_side, int ld_side, const uint32_t *d_side_bits, float *d_C, int ldc, uint32_t *d_absmax, void *stream)
+{
     if (n_seg < 1 || n_seg > 8 || (n_seg > 1 && seg_stride <= 0)) { set_error("hnr_h2lin: n_seg must be 1..8 (got %d) with a positive seg_stride", n_seg); return HNR_ERR_BADARG; }
     if (M_cap < 0 || N <= 0 || N > 256 || K <= 0 || K > 288 || lda < K || (lda & 3) || ldc < N || (ldc & 3) || (mode != 0 && mode != 1) ||
-        (mode == 1 && (!d_side || ld_side < N || (ld_side & 3) || ((uintptr_t)d_side & 15))) || !(slope > 0.f && slope < 1.f)) {
+        (mode == 1 && !d_side_bits && (!d_side || ld_side < N || (ld_side & 3) || ((uintptr_t)d_side & 15))) || !(slope > 0.f && slope < 1.f)) {
         set_error("hnr_h2lin: bad sizes (N=%d K=%d lda=%d ldc=%d mode=%d ld_side=%d slope=%g)", N, K, lda, ldc, mode, ld_side, (double)slope);
         return HNR_ERR_BADARG;
     }
@@ -771,7 +795,7 @@ extern "C" int hnr_h2lin(const float *d_A, int lda, int64_t M_cap, const int64_t
     H2LinArgs a;
     a.A = d_A; a.lda = lda; a.d_m = reinterpret_cast<const long long *>(d_m); a.M_cap = M_cap; a.n_seg = n_seg; a.seg_stride = seg_stride;
     a.wimg = (const char *)d_packed; a.N = N; a.K = K;
-    a.mode = mode; a.act = act; a.slope = slope; a.side = d_side; a.lds_ = ld_side; a.C = d_C; a.ldc = ldc; a.absmax = d_absmax;
+    a.mode = mode; a.act = act; a.slope = slope; a.side = d_side; a.lds_ = ld_side; a.side_bits = d_side_bits; a.C = d_C; a.ldc = ldc; a.absmax = d_absmax;
     const int S = (K + 15) / 16;
     const int64_t tiles = (M_cap * n_seg + 63) / 64;
     const int wgs = 2 * h2_num_cus(), grid = (int)(tiles < wgs ? tiles : wgs);

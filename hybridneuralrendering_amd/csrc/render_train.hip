@@ -55,6 +55,7 @@ struct Layout {
     long long *tc;
     uint32_t *amax;
     char *chain_ws, *img_chain, *img_cf, *img_mw, *img_mx, *img[IM_N];
+    uint32_t *hbits;
     float *W0fd, *Xd, *H1, *X3, *H3, *H4, *E, *Tu, *X5, *sigma, *T1, *T2, *CF, *pre, *X6, *vmask, *M1, *M2, *M3, *X7, *Y1, *Y2, *Y3, *fm, *fm_scratch;
     // backward temporaries
     float *g_dec, *gY3, *gCF, *g_sigma, *dY2, *dY1, *gX7, *gF, *gZ3m, *dM2, *dM1, *gX6, *gpre, *tmpCF, *tmpWfd, *g_pyr, *g_fm, *dT2, *dT1, *gX5, *gZ4, *g_wagg,
@@ -95,6 +96,7 @@ Layout carve(void *ws, size_t ws_bytes, const hnr_train_params *p, bool *ok)
     L.W0fd = c.take<float>(64 * 48);
     L.Xd = c.take<float>(rows * 64);
     L.H1 = c.take<float>(rows * 256); L.X3 = c.take<float>(rows * 264); L.H3 = c.take<float>(rows * 256); L.H4 = c.take<float>(rows * 256);
+    L.hbits = c.take<uint32_t>(3 * rows * 8);                           // signs of H1 / X3[:, :256] / H3: 256 bits per row (ChainArgs::hbits)
     L.E = c.take<float>(ucap * 224); L.Tu = c.take<float>(ucap * 256);
     L.X5 = c.take<float>(cap * 280); L.sigma = c.take<float>(cap + 1);
     L.T1 = c.take<float>(cap * 128); L.T2 = c.take<float>(cap * 128); L.CF = c.take<float>(cap * 128); L.pre = c.take<float>(cap * 64);
@@ -599,7 +601,7 @@ extern "C" int hnr_render_train_forward(const hnr_grid *grid, const hnr_train_pa
     TR(mark());
     {
         float *H[4] = {L.H1, L.X3, L.H3, L.H4}; const int ldh[4] = {256, 264, 256, 256};
-        TR(chain_forward_train(L.chain_ws, L.Tu, 256, L.uidx, L.img_chain, o->d_counts, cap, sl, L.X5, 280, L.sigma, H, ldh, L.amax + AM_H1, L.amax + AM_X5, stream, L.row_u, (int)L.ucap));     // (AM_X5 starts at 1: the direction encoding's columns)
+        TR(chain_forward_train(L.chain_ws, L.Tu, 256, L.uidx, L.img_chain, o->d_counts, cap, sl, L.X5, 280, L.sigma, H, ldh, L.amax + AM_H1, L.amax + AM_X5, stream, L.row_u, (int)L.ucap, L.hbits, (long long)L.rows_cap * 8));     // (AM_X5 starts at 1: the direction encoding's columns)
     }
     TR(mark());
     // maxima that only the backward call's weight gradients read (per-tensor scales of X6, X7): on the side stream once the image branch is done with it
@@ -803,9 +805,11 @@ extern "C" int hnr_render_train_backward(const hnr_train_params *p, const hnr_tr
     TR(mark());
     // ---- 9. block3
     TR(wgrad_n(L.gZ4, 256, L.H3, 256, rows, dM, 1, 0, 256, 256, AM_gZ4, AM_H3, g.block3_2_w, 256, g.block3_2_b));
-    TR(dgrad(L.gZ4, 256, rows, dM, 1, 0, IM_B32T, 256, 256, L.H3, 256, L.dZ3, 256, AM_dZ3));
+    // (the three input gradients of the per-neighbour chain read their LeakyReLU' from the forward's sign words: 32 B per row instead of 1 KiB)
+    const long long hb = (long long)L.rows_cap * 8;
+    TR(h2lin_dgrad_bits(L.gZ4, 256, rows, dM, L.img[IM_B32T], 256, 256, sl, L.hbits + 2 * hb, L.dZ3, 256, am + AM_dZ3, stream));
     TR(wgrad_n(L.dZ3, 256, L.X3, 264, rows, dM, 1, 0, 256, 263, AM_dZ3, AM_X3, g.block3_0_w, 263, g.block3_0_b));
-    TR(dgrad(L.dZ3, 256, rows, dM, 1, 0, IM_B30T, 256, 256, L.X3, 264, L.gX3, 264, AM_dZ2));
+    TR(h2lin_dgrad_bits(L.dZ3, 256, rows, dM, L.img[IM_B30T], 256, 256, sl, L.hbits + hb, L.gX3, 264, am + AM_dZ2, stream));
     {
         int nb = cdiv(rows, 16); if (nb > 2048) nb = 2048;
         train_extras_dgrad_kernel<<<nb, 256, 0, st>>>(L.dZ3, w->block3_0_w, L.tc + TC_M8, L.gX3);
@@ -825,7 +829,7 @@ extern "C" int hnr_render_train_backward(const hnr_train_params *p, const hnr_tr
     TR(mark());                                                      // (the rows' small gradients G8 are summed per point together with block1's rows below)
     // ---- 11. block1 (first layer split: 60 distance columns per row + the per-point table)
     TR(wgrad_n(L.gX3, 264, L.H1, 256, rows, dM, 1, 0, 256, 256, AM_dZ2, AM_H1, g.block1_2_w, 256, g.block1_2_b));
-    TR(dgrad(L.gX3, 264, rows, dM, 1, 0, IM_B12T, 256, 256, L.H1, 256, L.dZ1, 256, AM_dZ1));
+    TR(h2lin_dgrad_bits(L.gX3, 264, rows, dM, L.img[IM_B12T], 256, 256, sl, L.hbits, L.dZ1, 256, am + AM_dZ1, stream));
     TR(wgrad_n(L.dZ1, 256, L.Xd, 64, rows, dM, 1, 0, 256, 60, AM_dZ1, AM_ONE, g.block1_0_w + 224, 284, g.block1_0_b));
     TR(segment_sum_rows_csr_dc(L.dZ1, 256, L.row_list, L.seg_start, L.seg_cnt, 256, (int)ucap, L.tc + TC_U, L.gTu, 256, L.G8, 8, 8, L.P8, 8, am + AM_gTu, st));
     TR(point_small_grads_dc(L.P8, L.ulist, (int)ucap, L.tc + TC_U, gc->d_conf, gc->d_dir, gc->d_color, st));

@@ -12,7 +12,10 @@ int chain_gather_train(const float *d_xyz, const float *d_conf, const float *d_d
                        float *d_conf_out, float *d_Xd, int32_t *d_row_pid, void *stream);
 int chain_forward_train(const void *d_workspace, const float *d_point_table, int ldt, const int32_t *d_uidx, const void *d_packed, const int64_t *d_counts,
                         int cap_samples, float slope, float *d_X5, int ld5, float *d_sigma, float *const *d_H, const int *ldh, uint32_t *d_hmax, uint32_t *d_x5max, void *stream,
-                        const int32_t *d_row_u = nullptr, int ucap = 0);
+                        const int32_t *d_row_u = nullptr, int ucap = 0, uint32_t *d_hbits = nullptr, long long hbits_stride = 0);
+// csrc/h2gemm.hip: dX = (dZ W) * LeakyReLU'(forward activation), the activation's signs as the chain kernels' bit words (ChainArgs::hbits)
+int h2lin_dgrad_bits(const float *d_dZ, int ldz, int64_t M_cap, const int64_t *d_m, const void *d_packed, int N, int K, float slope, const uint32_t *d_side_bits,
+                     float *d_C, int ldc, uint32_t *d_absmax, void *stream);
 // csrc/mlp.hip
 int mlp3_forward_train(const float *d_A, int lda, int64_t M_cap, const int64_t *d_counts, int count_index, int count_mult, int seg_stride,
                        const void *d_packed, int n_layers, const int *N, const int *K, const int *act, float slope, const float *d_R,
