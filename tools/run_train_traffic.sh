@@ -7,4 +7,4 @@ for c in FETCH_SIZE WRITE_SIZE; do
   echo "$c rc=$?"
   mkdir -p $OUT/pmc_$c/x; cp /tmp/pmct_$c/*counter_collection.csv $OUT/pmc_$c/x/ 2>/dev/null
 done
-cd $GRAFT_REPO_ROOT && python tools/collect_train_traffic.py gpurun_out/train_traffic
+cd $GRAFT_REPO_ROOT && python tools/collect_train_traffic.py gpurun_out/train_traffic ${1:-r05}
