@@ -16,6 +16,7 @@
 // Every row count is read on the device (*d_m), so the training step needs no host synchronisation (the reference's torch autograd
 // sizes every gradient tensor from host-side shapes).
 #include <stdlib.h>
+#include <type_traits>
 
 #include "chain_defs.h"
 
@@ -96,6 +97,7 @@ struct H2LinArgs {
                                                // lane's 32 columns col0 + 32 c + 0..15 is > 0); 1/32 of the bytes and one load per row tile and lane instead of eight
     float *C; int ldc;
     unsigned *absmax;                          // optional: max |C| (bit pattern, atomicMax)
+    int spread;                                // narrow layers: the (row tile, column tile) pairs dealt to all four waves (HNR_H2LIN_SPREAD=0: wave w = columns 64 w .. only)
 };
 
 // 64-row tiles, two workgroups per CU (one's row loads / split / epilogue under the other's MFMAs); wave w owns output columns 64 w .. + 63.
@@ -119,9 +121,6 @@ __global__ __launch_bounds__(256, 2) void h2lin_kernel(H2LinArgs a)
     const float *meta = reinterpret_cast<const float *>(a.wimg + (size_t)S * CH_WSTEP);
     const __amdgpu_buffer_rsrc_t wsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(a.wimg), 0, S * CH_WSTEP, 0x00020000);
     float *rowinv = reinterpret_cast<float *>(lds + S * SLOT);                 // [ROWS]
-    const int col0 = 64 * wave + 16 * h;
-    const unsigned woff = (unsigned)(2 * wave) * 2048u + (unsigned)lane * 16u;
-    const bool active = 64 * wave < a.N;
     const float dw = meta[HL_DESC];
     float gmax = 0.f;
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -184,44 +183,51 @@ __global__ __launch_bounds__(256, 2) void h2lin_kernel(H2LinArgs a)
             }
         }
         __syncthreads();
-        if (active) {
-            float inv[RT];
+        // Which (row tile, column tile) pairs a wave multiplies.  Wide layers (N > 128): wave w = the 64 columns 64 w .. of both row tiles.  Narrower ones
+        // left waves idle through the MFMA loop AND the epilogue (N <= 64: three of four) -- the narrow layers' input gradients of a training step are
+        // ~15 launches of 20 - 65 us on the main queue, 2.5 - 3x their bytes' time --: N <= 128: wave w = column tile w of both row tiles; N <= 64:
+        // wave w = column tile w & 1 of row tile w >> 1.  Same arithmetic per element.
+        auto compute = [&](auto rtw_c, auto nct_c, int rt0, int ct0) __attribute__((always_inline)) {
+            constexpr int RTW = decltype(rtw_c)::value, NCT = decltype(nct_c)::value;
+            const int colb = 32 * ct0 + 16 * h;                                // this lane's columns of the wave's column tile c: colb + 32 c + 0..15
+            const unsigned wo = (unsigned)ct0 * 2048u + (unsigned)lane * 16u;
+            float inv[RTW];
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) inv[rt] = __fmul_rn(rowinv[32 * rt + j], dw);
-            f32x16 acc[RT][2];
+            for (int rt = 0; rt < RTW; ++rt) inv[rt] = __fmul_rn(rowinv[32 * (rt0 + rt) + j], dw);
+            f32x16 acc[RTW][NCT];
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
+            for (int rt = 0; rt < RTW; ++rt)
 #pragma unroll
-                for (int c = 0; c < 2; ++c)
+                for (int c = 0; c < NCT; ++c)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[rt][c][r] = 0.f;
-            h2_mfma_layer<RT, 2, S, 0, CH_WSTEP, SLOT>(wsrd, 0, woff, lds, lane, acc, []() {});
+            h2_mfma_layer<RTW, NCT, S, 0, CH_WSTEP, SLOT>(wsrd, 0, wo, lds + rt0 * 2048, lane, acc, []() {});
             // mode 1: the rows' stored activations, one row tile ahead of its use (the weight fragments' registers are free by now)
-            float4 sd[2][2][4];
+            float4 sd[2][NCT][4];
             unsigned sbits[2] = {0u, 0u};
-            const bool use_bits = a.side_bits != nullptr;
+            const bool use_bits = a.side_bits != nullptr;                      // (N = 256 only: the wave owns the chain kernels' 64 columns)
             auto load_side = [&](int rt) {
-                if (use_bits) { sbits[rt & 1] = a.side_bits[(((row_base + 32 * rt) >> 5) * 4 + wave) * 64 + lane]; return; }
-                long long row = row_base + 32 * rt + j;
+                if (use_bits) { sbits[rt & 1] = a.side_bits[(((row_base + 32 * (rt0 + rt)) >> 5) * 4 + wave) * 64 + lane]; return; }
+                long long row = row_base + 32 * (rt0 + rt) + j;
                 if (row >= M) row = M - 1;
-                const float *srow = a.side + (size_t)phys(row) * a.lds_ + col0;
+                const float *srow = a.side + (size_t)phys(row) * a.lds_ + colb;
 #pragma unroll
-                for (int c = 0; c < 2; ++c)
+                for (int c = 0; c < NCT; ++c)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) sd[rt & 1][c][q] = (col0 + 32 * c + 4 * q + 4 <= a.lds_) ? *reinterpret_cast<const float4 *>(srow + 32 * c + 4 * q) : make_float4(1.f, 1.f, 1.f, 1.f);
+                    for (int q = 0; q < 4; ++q) sd[rt & 1][c][q] = (colb + 32 * c + 4 * q + 4 <= a.lds_) ? *reinterpret_cast<const float4 *>(srow + 32 * c + 4 * q) : make_float4(1.f, 1.f, 1.f, 1.f);
             };
             if (a.mode == 1) load_side(0);
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
-                const long long row = row_base + 32 * rt + j;
-                if (a.mode == 1 && rt + 1 < RT) load_side(rt + 1);
+            for (int rt = 0; rt < RTW; ++rt) {
+                const long long row = row_base + 32 * (rt0 + rt) + j;
+                if (a.mode == 1 && rt + 1 < RTW) load_side(rt + 1);
 #pragma unroll
-                for (int c = 0; c < 2; ++c) {
+                for (int c = 0; c < NCT; ++c) {
                     float o[16];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         float bq[4] = {0.f, 0.f, 0.f, 0.f};
-                        if (a.mode == 0) { const float4 b4 = *reinterpret_cast<const float4 *>(meta + col0 + 32 * c + 4 * q); bq[0] = b4.x; bq[1] = b4.y; bq[2] = b4.z; bq[3] = b4.w; }
+                        if (a.mode == 0) { const float4 b4 = *reinterpret_cast<const float4 *>(meta + colb + 32 * c + 4 * q); bq[0] = b4.x; bq[1] = b4.y; bq[2] = b4.z; bq[3] = b4.w; }
                         const float *sq = reinterpret_cast<const float *>(&sd[rt & 1][c][q]);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -234,15 +240,18 @@ __global__ __launch_bounds__(256, 2) void h2lin_kernel(H2LinArgs a)
                         }
                     }
                     if (row < M) {
-                        float *dst = a.C + (size_t)phys(row) * a.ldc + col0 + 32 * c;
+                        float *dst = a.C + (size_t)phys(row) * a.ldc + colb + 32 * c;
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
-                            if (col0 + 32 * c + 4 * q + 4 <= a.ldc && col0 + 32 * c + 4 * q < ((a.N + 3) & ~3))
+                            if (colb + 32 * c + 4 * q + 4 <= a.ldc && colb + 32 * c + 4 * q < ((a.N + 3) & ~3))
                                 *reinterpret_cast<float4 *>(dst + 4 * q) = make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
                     }
                 }
             }
-        }
+        };
+        if (a.N > 128 || !a.spread) { if (64 * wave < a.N) compute(std::integral_constant<int, RT>{}, std::integral_constant<int, 2>{}, 0, 2 * wave); }
+        else if (a.N > 64) { if (32 * wave < a.N) compute(std::integral_constant<int, RT>{}, std::integral_constant<int, 1>{}, 0, wave); }
+        else if (32 * (wave & 1) < a.N) compute(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, wave >> 1, wave & 1);
         __syncthreads();                                                       // the planes are rewritten by the next tile's prologue
     }
     if (a.absmax) {
@@ -796,6 +805,9 @@ int hnr::h2lin_launch(const float *d_A, int lda, int64_t M_cap, const int64_t *d
     a.A = d_A; a.lda = lda; a.d_m = reinterpret_cast<const long long *>(d_m); a.M_cap = M_cap; a.n_seg = n_seg; a.seg_stride = seg_stride;
     a.wimg = (const char *)d_packed; a.N = N; a.K = K;
     a.mode = mode; a.act = act; a.slope = slope; a.side = d_side; a.lds_ = ld_side; a.side_bits = d_side_bits; a.C = d_C; a.ldc = ldc; a.absmax = d_absmax;
+    static int spread = -1;
+    if (spread < 0) { const char *e = getenv("HNR_H2LIN_SPREAD"); spread = e ? atoi(e) : 1; }
+    a.spread = spread;
     const int S = (K + 15) / 16;
     const int64_t tiles = (M_cap * n_seg + 63) / 64;
     const int wgs = 2 * h2_num_cus(), grid = (int)(tiles < wgs ? tiles : wgs);
