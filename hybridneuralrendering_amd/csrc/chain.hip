@@ -702,7 +702,7 @@ extern "C" int64_t hnr_chain_workspace_bytes(int cap_samples)
 {
     if (cap_samples < 0) return -1;
     const int64_t groups = 4 * (((int64_t)cap_samples + 15) / 16 + 2);            // whole 4-group blocks of the gather kernel (+ 2: each of the three slot classes ends in a partial block)
-    return groups * (CH_XP_GROUP + CH_AUX_GROUP);
+    return groups * (CH_XP_GROUP + CH_AUX_GROUP + 32 * 4);                        // operand images, row scalars, density inputs (ChainArgs::dsig)
 }
 
 extern "C" int hnr_chain_pack(const float *d_w_b1_0_dist, int ldw0, const float *d_b_b1_0, const float *d_w_b1_2, const float *d_b_b1_2,
@@ -854,6 +854,7 @@ extern "C" int hnr_chain_forward(const void *d_workspace, const float *d_point_t
     const int blocks = cdiv(cap_samples, 16) + 2;
     ChainArgs a;
     a.xp = (const char *)d_workspace; a.aux = (const char *)d_workspace + (size_t)blocks * 4 * CH_XP_GROUP;
+    a.dsig = reinterpret_cast<float *>((char *)d_workspace + (size_t)blocks * 4 * (CH_XP_GROUP + CH_AUX_GROUP));
     a.ptab = d_point_table; a.ldt = ldt; a.wimg = (const char *)d_packed;
     { static int tab0 = -1; if (tab0 < 0) { const char *e = getenv("HNR_CHAIN_PROBE_TAB0"); tab0 = e ? atoi(e) : 0; } if (tab0) a.ldt = 0; }      // probe: every row reads table row 0 (what the gather's latency costs; results are garbage)
     a.counts = reinterpret_cast<const unsigned long long *>(d_counts);
@@ -903,6 +904,7 @@ int chain_forward_train(const void *d_workspace, const float *d_point_table, int
     const int blocks = cdiv(cap_samples, 16) + 2;
     ChainArgs a;
     a.xp = (const char *)d_workspace; a.aux = (const char *)d_workspace + (size_t)blocks * 4 * CH_XP_GROUP;
+    a.dsig = reinterpret_cast<float *>((char *)d_workspace + (size_t)blocks * 4 * (CH_XP_GROUP + CH_AUX_GROUP));
     a.ptab = d_point_table; a.ldt = ldt; a.wimg = (const char *)d_packed;
     a.counts = reinterpret_cast<const unsigned long long *>(d_counts);
     a.X5 = d_X5; a.ld5 = ld5; a.sigma = d_sigma; a.slope = slope; a.cap_samples = cap_samples; a.dbg = nullptr; a.dbg_layer = 0; a.skew = 0;

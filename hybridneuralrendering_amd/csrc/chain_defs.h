@@ -23,6 +23,8 @@ constexpr int ch_lds_bytes(int RT) { return ch_lds_exch(RT) + 32 * RT * 4 * 4; }
 struct ChainArgs {
     const char *xp;                    // [groups][CH_XP_GROUP] layer-0 operand image (chain_gather_kernel)
     const char *aux;                   // [groups][CH_AUX_GROUP]
+    float *dsig;                       // [groups][32] the rows' density inputs (alpha dot of block3's output), one float per row: chain_ws_kernel -> chain_sigma_kernel.  (They were
+                                       // parked in the eighth float of the rows' 32-byte `ext` records: 4-byte accesses 32 bytes apart move whole sectors -- 1.1 GB per frame for 0.1 GB of values.)
     const float *ptab; int ldt;        // per-point addend of block1.0: [N, ldt >= 256]
     const char *wimg;                  // packed weights (hnr_chain_pack)
     const unsigned long long *counts;  // device counters of the query (n_valid samples)

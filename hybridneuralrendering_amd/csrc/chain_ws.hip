@@ -345,8 +345,8 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
         if (t < 0) { o.first = n_valid; o.end = 0; }
         int n = o.end - o.first; n = n < 0 ? 0 : (n > (16 << o.kc) ? (16 << o.kc) : n);
         o.rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(a.X5) + (size_t)o.first * a.ld5 * 4, 0, n * a.ld5 * 4, 0x00020000);
-        // the tile's own row scalars: the rows' density inputs go to the unused eighth `ext` float (chain_sigma_kernel reads them)
-        o.rs_aux = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(a.aux) + (size_t)tt * 4 * CH_AUX_GROUP, 0, t < 0 ? 0 : 4 * CH_AUX_GROUP, 0x00020000);
+        // the tile's 128 density inputs (ChainArgs::dsig; chain_sigma_kernel reads them)
+        o.rs_aux = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(a.dsig) + (size_t)tt * 128 * 4, 0, t < 0 ? 0 : 128 * 4, 0x00020000);
         return o;
     };
 
@@ -660,11 +660,11 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
             } else if (ms == 33) {
                 if constexpr (TR) CW_HMAX_PUT(4, x5m);
                 // the tile's density inputs (the alpha dot of every row = the four waves' partial sums): wave w stores row tile w's 32 values into the
-                // tile's row scalars; softplus, the rows' weights and the K-sum are chain_sigma_kernel's (~160 instructions per wave and tile that
+                // tile's slice of ChainArgs::dsig; softplus, the rows' weights and the K-sum are chain_sigma_kernel's (~160 instructions per wave and tile that
                 // no MFMA of this kernel could hide: they ran in the 24-MFMA pass (0,0))
                 if (PR == 3) {
                     const float d = __fadd_rn(__fadd_rn(ex4.x, ex4.y), __fadd_rn(ex4.z, ex4.w));
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d), to.rs_aux, h == 0 ? wave * CH_AUX_GROUP + 256 + j * 32 + 28 : 0x40000000, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d), to.rs_aux, h == 0 ? (wave * 32 + j) * 4 : 0x40000000, 0, 0);
                 }
             } else prefetch_next();
         }
@@ -795,7 +795,7 @@ __global__ __launch_bounds__(256, 1) void chain_ws_kernel(ChainArgs a)
     }
 }
 
-// The samples' densities from the row tiles' density inputs chain_ws_kernel left in the row scalars (ext[.][7]): sigma = sum over the sample's row
+// The samples' densities from the row tiles' density inputs chain_ws_kernel left (ChainArgs::dsig, one float per row): sigma = sum over the sample's row
 // slots of softplus(d + alpha_b - 1) x aggregation weight, added in the order of the lane steps the chain kernels use (pairs, quad pairs, halves).
 // One 128-thread block per tile, thread = row; raw2out_density: models/aggregators/point_aggregators.py:471-476.
 __global__ __launch_bounds__(128) void chain_sigma_kernel(ChainArgs a)
@@ -805,7 +805,7 @@ __global__ __launch_bounds__(128) void chain_sigma_kernel(ChainArgs a)
     if (tile >= cls.n_tiles) return;
     const int lane = threadIdx.x & 63, rt = threadIdx.x >> 5, j = lane & 31;
     const char *aux = a.aux + ((size_t)tile * 4 + rt) * CH_AUX_GROUP;
-    const float d = reinterpret_cast<const float *>(aux + 256 + j * 32)[7], wq = reinterpret_cast<const float *>(aux + 128)[j];
+    const float d = a.dsig[(size_t)tile * 128 + threadIdx.x], wq = reinterpret_cast<const float *>(aux + 128)[j];
     const float alpha_b = reinterpret_cast<const float *>(a.wimg + CH_META)[4 * 256 + 256];
     const int kc = chain_tile_class(cls, tile);
     float sg = __fmul_rn(chain_softplus_m1(__fadd_rn(d, alpha_b)), wq);

@@ -315,4 +315,4 @@ def test_chain_capacity_bounds_and_bad_arguments():
     with pytest.raises(HnrError):
         _lib.check(L.hnr_chain_forward(None, None, 256, None, None, 16, ctypes.c_float(1.5), None, 280, None, None, 0, None), "hnr_chain_forward")
     # whole 16-sample blocks, plus two: each of the three slot classes may end in a partial block
-    assert L.hnr_chain_workspace_bytes(0) == 8 * (8192 + 1280) and L.hnr_chain_workspace_bytes(17) == 16 * (8192 + 1280)
+    assert L.hnr_chain_workspace_bytes(0) == 8 * (8192 + 1280 + 128) and L.hnr_chain_workspace_bytes(17) == 16 * (8192 + 1280 + 128)
