@@ -510,13 +510,15 @@ static int build_impl(hnr_grid *g, const float *d_xyz, int n, hipStream_t st)
             uint32_t nb_total = 0;
             GB_CHECK(hipMemcpyAsync(&nb_total, nb_start.p + n_dil, 4, hipMemcpyDeviceToHost, st));
             GB_CHECK(hipStreamSynchronize(st));
-            GB_CHECK(nbp.alloc((size_t)nb_total + 1));
+            // + 4 zeroed records: the quad / XP k-NN forms read four records from a run's shell-1 start, which is nb_total for an empty last run
+            GB_CHECK(nbp.alloc((size_t)nb_total + 4));
+            GB_CHECK(hipMemsetAsync(nbp.p + nb_total, 0, 4 * sizeof(float4), st));
             nb_lists_kernel<true><<<nb_blocks, 256, 0, st>>>(v2, g->dil, dprefix.p, n_words, nb_start.p, nullptr, nbr.p, nbp.p);
             pack_dil_rec_kernel<<<cdiv(n_words, TB), TB, 0, st>>>(g->dil, dprefix.p, n_words, drec.p);
             GB_CHECK(hipGetLastError());
             GB_CHECK(hipStreamSynchronize(st));                             // (the scratch buffers above die with this scope)
             g->dil_rec = drec.release(); g->nb_rng = nbr.release(); g->nb_pts = nbp.release();
-            nb_bytes = (int64_t)n_words * 16 + n_dil * 8 + ((int64_t)nb_total + 1) * 16;
+            nb_bytes = (int64_t)n_words * 16 + n_dil * 8 + ((int64_t)nb_total + 4) * 16;
         }
     }
     g->st.n_points = n;

@@ -6,7 +6,8 @@ host syncs -- 124 times per 620x460 frame) and scatters every chunk into an [H,W
 Here a frame is ONE launch of the fused path over all its rays (the grid and the reference-view pyramid are built once),
 the [H,W,3] image is assembled on the device by pixel index, and with torch.distributed the rays are sharded over the ranks
 and reassembled on rank 0 with one gather (parallel.render_sharded).  Chunking is still available (`chunk_rays`) and gives
-the same pixels at jitter 0 (tests/test_render_gpu.py::test_whole_frame_equals_chunked_render).
+the same pixels at jitter 0 (tests/test_render_gpu.py::test_whole_frame_equals_the_reference_chunk_loop, against a frame the imported
+reference rendered chunk by chunk).
 """
 import torch
 import torch.distributed as dist
@@ -19,8 +20,8 @@ def render_image(renderer, cloud, frame, chunk_rays=0, sharded=None, group=None)
     """frame: dict with the dataset item of the reference (data/scannet_ft_dataset.py:855-976), batch dim optional:
     raydir [R,3], pixel_idx [R,2] (x, y), campos [3], camrotc2w [3,3], bg_color [3], near, far, h, w, c2w_nearest [V,4,4],
     campos_nearest [V,3], intrinsic_nearest [3,3], images_nearest [V,H,W,3] (+ optional frame_weight_nearest [V]).
-    Returns dict(image [h,w,3] (bg colour where no ray was cast), ray_mask [R] i8, coarse_raycolor [R,3]) -- on rank 0 when
-    sharded, None on the other ranks."""
+    Returns dict(image [h,w,3] (zero where no ray was cast: run/test_ft.py:191 scatters into np.zeros), ray_mask [R] i8, coarse_raycolor [R,3]) --
+    on rank 0 when sharded, None on the other ranks."""
     sq = lambda t, nd: t.reshape(t.shape[-nd:]) if isinstance(t, torch.Tensor) else t
     raydir = sq(frame["raydir"], 2)
     pix = sq(frame["pixel_idx"], 2)
@@ -66,7 +67,7 @@ def render_image(renderer, cloud, frame, chunk_rays=0, sharded=None, group=None)
     if rows is None:
         return None
     col, mask = rows[:, :3].contiguous(), rows[:, 3].to(torch.int8)
-    img = sq(frame["bg_color"], 1).to(col.device, torch.float32).expand(h, w, 3).clone()
+    img = torch.zeros((h, w, 3), dtype=torch.float32, device=col.device)        # test_ft.py:191 `np.zeros((height, width, 3))`: the margin stays zero
     px, py = pix[:, 0].to(col.device, torch.long), pix[:, 1].to(col.device, torch.long)
     img[py, px] = col                                            # test_ft.py:193 `visuals[key][y, x, :] = chunk`, on the device
     return dict(image=img, ray_mask=mask, coarse_raycolor=col)

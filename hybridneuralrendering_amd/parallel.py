@@ -283,7 +283,7 @@ class PointGradExchange:
         if self.W < 3:
             raise ValueError("PointGradExchange: needs at least two gradient columns (the header holds three values)")
 
-    def _hip(self, flat, ids=None, count=None):
+    def _hip(self, flat, ids=None, count=None, n_valid=None):
         """the HIP kernels serve the training step's own layout: fp32 [N,32] [N,1] [N,3] [N,3] on the GPU, int32 ids, an int64 count (HNR_EXCHANGE_TORCH=1: torch ops)"""
         import os
         if os.environ.get("HNR_EXCHANGE_TORCH") == "1" or self.widths != (32, 1, 3, 3):
@@ -291,6 +291,8 @@ class PointGradExchange:
         ok = all(f.is_cuda and f.dtype == torch.float32 and f.is_contiguous() for f in flat)
         if ids is not None:
             ok = ok and ids.is_cuda and ids.dtype == torch.int32 and ids.is_contiguous() and count.is_cuda and count.dtype == torch.int64 and ids.numel() >= 1
+        if n_valid is not None:
+            ok = ok and n_valid.is_cuda
         return ok
 
     def _flat(self, grads):
@@ -303,7 +305,7 @@ class PointGradExchange:
         flat, N = self._flat(grads)
         dev = flat[0].device
         cap = self.cap
-        if self._hip(flat, ids, count):
+        if self._hip(flat, ids, count, n_valid):
             # one launch of libhnr_hip.so (csrc/exchange.hip) instead of ~25 tiny torch kernels; same bits (tests/test_train_gpu.py)
             from . import _lib
             rec = torch.empty((cap + 2, self.W), dtype=torch.float32, device=dev)
@@ -332,6 +334,13 @@ class PointGradExchange:
         rec[0, 2] = (cnt > cap).to(flat[0].dtype)[0]
         return rec
 
+    def raise_on_overflow(self, flag):
+        """Reads the (running maximum of the) overflow flag `apply` returns -- a host synchronisation -- and raises when it is set."""
+        if float(flag) != 0.0:
+            from ._lib import HnrError
+            raise HnrError("PointGradExchange: a rank touched more than the %d points the exchange was sized for; its extra gradient rows were not "
+                           "exchanged (replicas diverge) -- rebuild with a larger capacity" % self.cap)
+
     def exchange(self, rec):
         """[world, capacity + 2, W]: every rank's records.  ONE collective (none at world size 1)."""
         if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(self.group) == 1:
@@ -347,8 +356,11 @@ class PointGradExchange:
         return out
 
     def apply(self, all_rec, grads, own_rank):
-        """In place: every dense gradient becomes sum_r (n_r / n) g_r.  Returns (global number of valid rays, overflow flag) as device tensors --
-        check the flag once after the timed loop (a rank touched more points than `capacity`: its extra rows were dropped)."""
+        """In place: every dense gradient becomes sum_r (n_r / n) g_r.  Returns (global number of valid rays, overflow flag) as device tensors.
+        OVERFLOW (flag != 0: some rank touched more points than `capacity`) is an error the caller must act on: that rank's extra rows were not sent
+        and stay in ITS dense gradient as local, unscaled values, so the replicated point buffers would diverge if the optimiser stepped on them.
+        Keep the running maximum of the flag on the device and pass it to `raise_on_overflow` at a point where a host read is acceptable (once per
+        logging interval), then rebuild the exchange with a larger capacity and redo the affected steps."""
         flat, N = self._flat(grads)
         cap = self.cap
         if self._hip(flat) and all_rec.is_cuda and all_rec.is_contiguous():

@@ -401,11 +401,23 @@ def _blur_arg(blur_kernels, patch_num, patch_size, patch_layout):
     return (blur_kernels, -int(patch_num) if patch_layout == "patch_major" else int(patch_num), int(patch_size))
 
 
-def _assign_grads(aggregator, emb, conf, pdir, color, pg, ag, accumulate=True):
+def _assign_grads(aggregator, emb, conf, pdir, color, pg, ag, accumulate=True, cached=False):
+    """Sets / adds to the .grad fields as autograd would.  `cached`: pg / ag are buffers the NEXT step overwrites in place (TrainPath.reuse_outputs,
+    CapturedTrainStep): with accumulate a .grad never aliases them (first assignment clones, later ones add in place into the clone), so
+    optimizer.zero_grad(set_to_none=False) and gradient accumulation see autograd's semantics; accumulate=False hands out the buffers themselves."""
     def put(t, g):
-        if isinstance(t, torch.Tensor) and t.requires_grad:
-            g = g.reshape(t.shape)
-            t.grad = g if (t.grad is None or not accumulate) else t.grad + g
+        if not (isinstance(t, torch.Tensor) and t.requires_grad):
+            return
+        g = g.reshape(t.shape)
+        if not accumulate:
+            t.grad = g
+        elif t.grad is None:
+            t.grad = g.clone() if cached else g
+        elif t.grad.data_ptr() == g.data_ptr():
+            raise HnrError("train_step: .grad of a parameter IS the step's own gradient buffer (an earlier step assigned it with accumulate_grads=False), "
+                           "so its previous value is already overwritten; set the gradients to None or keep accumulate_grads=False")
+        else:
+            t.grad.add_(g)
     put(emb, pg["points_embeding"]); put(conf, pg["points_conf"]); put(pdir, pg["points_dir"]); put(color, pg["points_color"])
     for n, q in aggregator.named_parameters():
         if n in ag:
@@ -415,7 +427,7 @@ def _assign_grads(aggregator, emb, conf, pdir, color, pg, ag, accumulate=True):
 def train_step(path, aggregator, xyz, emb, conf, pdir, color, raydir, campos, camrot, bg_color, near, far, c2w_nearest, campos_nearest,
                intrinsic_nearest, images_nearest, gt_image, zero_epsilon=1e-3, w_color=1.0, w_zero_one=1e-4, frame_weight=None, tmid=None,
                ray_drop=None, assign_grads=True, frame_weight_nearest=None, blur_kernels=None, patch_num=None, patch_size=None, patch_layout="grid",
-               w2c_nearest=None):
+               w2c_nearest=None, accumulate_grads=True):
     """forward -> [blur module] -> shipped loss terms -> backward of one ray batch as groups of library launches queued back to back: no autograd
     graph, no masked copies, nothing read back to the host -- the body of the reference's optimize_parameters before its optimizer steps
     (models/neural_points_volumetric_model.py:202-214: self.forward(); loss_total.backward(), with compute_losses of
@@ -432,7 +444,8 @@ def train_step(path, aggregator, xyz, emb, conf, pdir, color, raydir, campos, ca
     (models/aggregators/point_aggregators.py:1203), a device tensor that only the forward / backward calls read.
 
     emb/conf/pdir/color and the aggregator's parameters are read as they are; with assign_grads their .grad fields are set (or added to,
-    as autograd does).  Returns (outputs dict with `loss` = {total, colour MSE, zero-one mean, valid rays} on the device and `_saved` = the step's
+    as autograd does -- also under TrainPath.reuse_outputs, where a .grad is then a private copy of the step's buffer, never the buffer the next
+    step overwrites; accumulate_grads=False assigns the step's own buffers instead: no copy, valid until the next step).  Returns (outputs dict with `loss` = {total, colour MSE, zero-one mean, valid rays} on the device and `_saved` = the step's
     state for TrainPath.touched_points / the flat weight-gradient buffer, point grads dict, aggregator grads dict keyed by parameter name)."""
     cloud = PointCloud(xyz, emb.detach(), conf.detach(), pdir.detach(), color.detach())
     out, S, pg, ag = _queue_step(path, cloud, raydir, campos, camrot, bg_color, near, far, c2w_nearest, campos_nearest, intrinsic_nearest, images_nearest,
@@ -440,7 +453,7 @@ def train_step(path, aggregator, xyz, emb, conf, pdir, color, raydir, campos, ca
                                  _blur_arg(blur_kernels, patch_num, patch_size, patch_layout), w2c_nearest)
     out["_saved"] = S
     if assign_grads:
-        _assign_grads(aggregator, emb, conf, pdir, color, pg, ag)
+        _assign_grads(aggregator, emb, conf, pdir, color, pg, ag, accumulate=bool(accumulate_grads), cached=bool(path.reuse_outputs))
     return out, pg, ag
 
 
@@ -470,11 +483,12 @@ class CapturedTrainStep:
         for k in req:
             if k not in sample:
                 raise HnrError("CapturedTrainStep: sample input %r is missing" % k)
-        st = {k: _lib.require_gpu(v, k).clone() for k, v in sample.items() if isinstance(v, torch.Tensor)}
+        st = {k: _lib.require_gpu(v, k).clone() for k, v in sample.items() if isinstance(v, torch.Tensor) and k != "frame_weight"}
         if "w2c_nearest" not in st:
             st["w2c_nearest"] = torch.inverse(st["c2w_nearest"].reshape(-1, 4, 4)).contiguous()
-        st["frame_weight"] = torch.full((1,), float(sample.get("frame_weight", 1.0) if not isinstance(sample.get("frame_weight"), torch.Tensor) else 1.0),
-                                        dtype=torch.float32, device=dev)
+        fw0 = sample.get("frame_weight")
+        fw0 = 1.0 if fw0 is None else (float(fw0.reshape(-1)[0].item()) if isinstance(fw0, torch.Tensor) else float(fw0))   # (construction time: a host read is fine)
+        st["frame_weight"] = torch.full((1,), fw0, dtype=torch.float32, device=dev)
         self.inputs = st
         blur = _blur_arg(st.get("blur_kernels"), patch_num, patch_size, patch_layout)
         cloud = PointCloud(xyz, emb.detach(), conf.detach(), pdir.detach(), color.detach())

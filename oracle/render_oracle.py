@@ -322,8 +322,9 @@ def shipped_loss(full_raycolor, ray_mask, conf_coefficient, gt, zero_epsilon, w_
 
 def train_step(xyz, emb, conf, pdir, color, sd, q, campos, camrotc2w, raydir_all, bg_color, c2w_nearest, campos_nearest,
                intrinsic_nearest, images_nearest, vsize, gt, zero_epsilon, drop_ray_rows, raydist_mode_unit=1, dtype=None, use_nearest=4,
-               frame_weight=None, frame_weight_n=None):
-    """Forward in train mode + autograd of shipped_loss.  frame_weight: the item's scalar on loss_total (models/base_rendering_model.py:1204-1205);
+               frame_weight=None, frame_weight_n=None, blur=None):
+    """Forward in train mode + autograd of shipped_loss.  blur = (kernels [N,ks,ks], patch_num, patch_size): the blur-handling module between the
+    render and the losses (models/mvs_points_volumetric_model.py:145-146: blur_update_output replaces output["coarse_raycolor"]).  frame_weight: the item's scalar on loss_total (models/base_rendering_model.py:1204-1205);
     frame_weight_n [1,V]: the per-view weights of the image-feature merge (models/aggregators/point_aggregators.py:1202-1203).  Returns (outputs, loss triple, grads dict) with grads keyed
     `neural_points.points_*` and `aggregator.<param>` like the reference's named parameters.
     dtype=torch.float64 re-runs the same graph in double precision (the query result q is kept): the yardstick for how much
@@ -337,7 +338,7 @@ def train_step(xyz, emb, conf, pdir, color, sd, q, campos, camrotc2w, raydir_all
             return train_step(c(xyz), c(emb), c(conf), c(pdir), c(color), {k: c(v) for k, v in sd.items()}, q, c(campos), c(camrotc2w),
                               c(raydir_all), c(bg_color), c(c2w_nearest), c(campos_nearest), c(intrinsic_nearest), c(images_nearest),
                               vsize, c(gt), zero_epsilon, drop_ray_rows, raydist_mode_unit, use_nearest=use_nearest, frame_weight=frame_weight,
-                              frame_weight_n=c(frame_weight_n))
+                              frame_weight_n=c(frame_weight_n), blur=None if blur is None else (c(blur[0]), blur[1], blur[2]))
         finally:
             torch.set_default_dtype(old)
     leaves = dict(emb=emb.clone().requires_grad_(True), conf=conf.clone().requires_grad_(True),
@@ -346,7 +347,11 @@ def train_step(xyz, emb, conf, pdir, color, sd, q, campos, camrotc2w, raydir_all
     out = render(xyz, leaves["emb"], leaves["conf"], leaves["pdir"], leaves["color"], sdl, q, campos, camrotc2w, raydir_all,
                  bg_color, c2w_nearest, campos_nearest, intrinsic_nearest, images_nearest, vsize, raydist_mode_unit,
                  is_train=True, drop_ray_rows=drop_ray_rows, use_nearest=use_nearest, frame_weight_n=frame_weight_n)
-    loss, lc, lz = shipped_loss(out["full_coarse_raycolor"], out["ray_mask"], out["conf_coefficient"], gt, zero_epsilon, frame_weight=frame_weight)
+    col = out["full_coarse_raycolor"]
+    if blur is not None:
+        col, out["blur_select"] = blur_update_output(col, gt, blur[0], blur[1], blur[2])
+        out["blurred_raycolor"] = col
+    loss, lc, lz = shipped_loss(col, out["ray_mask"], out["conf_coefficient"], gt, zero_epsilon, frame_weight=frame_weight)
     loss.backward()
     grads = {"neural_points.points_embeding": leaves["emb"].grad, "neural_points.points_conf": leaves["conf"].grad,
              "neural_points.points_dir": leaves["pdir"].grad, "neural_points.points_color": leaves["color"].grad}

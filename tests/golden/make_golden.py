@@ -10,6 +10,8 @@ What is pinned by the reference itself (runs on CPU with torch):
   * train_*.npz         <- the same forward in train mode (jittered depths, patch drop) + torch autograd of the
                            shipped loss terms: gradients w.r.t. every aggregator parameter and the point buffers
   * aggregator_param_keys.json <- PointAggregator(opt).state_dict() names/shapes for the shipped option sets
+  * render_frame_chunked.npz <- the eval driver's 2304-ray chunk loop (run/test_ft.py:146-198) over a whole small frame
+  * train_c5_small.npz  <- the CHAINED C5 step: train-mode forward -> blur_update_output -> compute_losses with the frame weight -> autograd
   * blur_select.npz     <- BaseRenderingModel.blur_update_output (models/base_rendering_model.py:677-745) + autograd
   * render_scannet_small_prob.npz <- the same forward with opt.prob = 1: the hole-probing outputs (:392-416)
   * render_*.npz        <- NeuralPointsRayMarching.forward (models/neural_points_volumetric_model.py:257-427)
@@ -566,6 +568,158 @@ def gen_train(ref, tag, scene_name, n_points, seed, w, h, patch, opt_over=None, 
     opt.is_train = 0
 
 
+def _reference_net(ref, sc, opt, n_points, train):
+    """NeuralPoints + PointAggregator + NeuralPointsRayMarching of the reference on CPU around the oracle querier, weights seeded by the
+    caller's torch.manual_seed (the construction order of gen_render / gen_train, so the same seed gives the same weights)."""
+    opt.checkpoints_dir, opt.name, opt.resume_iter = "/nonexistent", "golden", "latest"
+    ref.npts.lighting_fast_querier_w = make_oracle_querier(ref)
+    ckpt = {"neural_points.xyz": torch.from_numpy(sc.xyz), "neural_points.points_embeding": torch.from_numpy(sc.emb),
+            "neural_points.points_conf": torch.from_numpy(sc.conf), "neural_points.points_dir": torch.from_numpy(sc.dir),
+            "neural_points.points_color": torch.from_numpy(sc.color)}
+    with tempfile.NamedTemporaryFile(suffix=".pth", delete=False) as f:
+        torch.save(ckpt, f.name)
+        ckpt_path = f.name
+    neural_points = ref.npts.NeuralPoints(opt.point_features_dim, n_points, opt, torch.device("cpu"), checkpoint=ckpt_path,
+                                          feature_init_method="rand", reg_weight=0.)
+    os.unlink(ckpt_path)
+    aggregator = ref.agg.PointAggregator(opt)
+    with torch.no_grad():
+        aggregator.alpha_branch[0].weight.mul_(30.0)
+        aggregator.alpha_branch[0].bias.fill_(30.0)
+    net = ref.vol.NeuralPointsRayMarching(
+        tonemap_func=ref.drf.find_tone_map(opt.which_tonemap_func), render_func=ref.drf.find_render_function(opt.which_render_func),
+        blend_func=ref.drf.find_blend_function(opt.which_blend_func), aggregator=aggregator, is_compute_depth=False,
+        neural_points=neural_points, opt=opt, num_pos_freqs=opt.num_pos_freqs, num_viewdir_freqs=opt.num_viewdir_freqs)
+    net.train() if train else net.eval()
+    return neural_points, aggregator, net
+
+
+def _net_inputs(sc, pix, raydir):
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    return dict(
+        campos=t(sc.c2w[:3, 3])[None], raydir=t(raydir)[None], bg_color=t(sc.bg_color)[None],
+        camrotc2w=t(sc.c2w[:3, :3])[None], pixel_idx=t(pix.astype(np.float32))[None],
+        near=torch.tensor([[[sc.near]]]), far=torch.tensor([[[sc.far]]]), h=torch.tensor([sc.h]), w=torch.tensor([sc.w]),
+        intrinsic=t(sc.intrinsic)[None], c2w=t(sc.c2w)[None], c2w_nearest=t(sc.c2w_nearest)[None],
+        images_nearest=t(sc.images_nearest)[None], campos_nearest=t(sc.c2w_nearest[:, :3, 3])[None],
+        intrinsic_nearest=t(sc.intrinsic)[None], vid_angle_nearest=torch.zeros(1, 4), frame_weight_nearest=torch.ones(1, 4))
+
+
+def gen_train_c5(ref, tag="c5_small", twin="scannet_small", scene_name="scene0241", n_points=12000, seed=11, w=64, h=48,
+                 size=(1.0, 0.8, 0.6), dilation_setup="7_4_1_3", frame_weight=0.7):
+    """The CHAINED C5 step of the reference on CPU (models/mvs_points_volumetric_model.py:135-152 + :111-118): forward in train mode on a
+    `random_sample='dilated'` batch -> fill_invalid -> BaseRenderingModel.blur_update_output (models/base_rendering_model.py:677-745, pre-defined
+    kernels) -> BaseRenderingModel.compute_losses with the shipped items and the item's frame weight (:1022-1262, :1205-1206) -> loss_total.backward().
+    Every step after the query is the reference's own code; stored: the batch, the drawn depth tables, the blurred colours, loss_total and all
+    gradients.  Scene and weights are those of render_<twin>.npz (same seed; asserted)."""
+    import models.base_rendering_model as brm
+    torch.manual_seed(seed)
+    sc = scenes.make_scene(scene_name, n_points, seed, w=w, h=h, size=size)
+    opt = sc.opt
+    opt.agg_axis_weight, opt.dilation_setup, opt.is_train = None, dilation_setup, 1
+    neural_points, aggregator, net = _reference_net(ref, sc, opt, n_points, train=True)
+    pix, pn, ps = scenes.dilated_patch_batch(sc.w, sc.h, 2, dilation_setup, seed=seed + 30)
+    raydir = scenes.camera_rays(pix, sc.intrinsic, sc.c2w)
+    rng = np.random.default_rng(seed + 31)
+    gt = rng.uniform(0, 1, size=(1, pix.shape[0], 3)).astype(np.float32)
+    kernels = scenes.blur_kernels_v2(k_size=5, dists=(1, 2), n_dirs=8)                # 8 symmetric 5x5 line kernels (4x4 patches)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    inputs = _net_inputs(sc, pix, raydir)
+    out = net(**inputs)
+    Q = ref.npts.lighting_fast_querier_w
+    q, ts = Q.last, Q.last_ts
+    shell = SimpleNamespace(input={}, opt=opt, tonemap_func=ref.drf.find_tone_map(opt.which_tonemap_func))
+    out_full = ref.vol.NeuralPointsVolumetricModel.fill_invalid(shell, dict(out), inputs)
+    eps = float(getattr(opt, "zero_epsilon", 1e-3))
+    lopt = SimpleNamespace(color_loss_items=["ray_masked_coarse_raycolor", "ray_miss_coarse_raycolor", "coarse_raycolor"],
+                           color_loss_weights=[1.0, 0.0, 0.0], depth_loss_items=[], depth_loss_weights=[], bg_loss_items=[], bg_loss_weights=[],
+                           zero_one_loss_items=["conf_coefficient"], zero_one_loss_weights=[1e-4], zero_epsilon=eps, l2_size_loss_items=[],
+                           l2_size_loss_weights=[], sparse_loss_weight=0, use_frame_weight=1)
+    # the model object as set_input leaves it (:434-445): the blur module and compute_losses read these attributes
+    model = SimpleNamespace(opt=lopt, output=dict(coarse_raycolor=out_full["coarse_raycolor"], ray_mask=out["ray_mask"],
+                                                  conf_coefficient=out["conf_coefficient"]),
+                            gt_image=t(gt), l2loss=torch.nn.MSELoss(), is_train=True, dilation_PatchNum=pn, dilation_PatchSize=ps, input={},
+                            frame_weight=np.float32(frame_weight), blur_kernels=t(kernels)[None], xv_patches=[], yv_patches=[])
+    orig_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self             # blur_update_output moves the kernels with .cuda(); no GPU here
+    try:
+        brm.BaseRenderingModel.blur_update_output(model)
+    finally:
+        torch.Tensor.cuda = orig_cuda
+    blurred = model.output["coarse_raycolor"]
+    brm.BaseRenderingModel.compute_losses(model)
+    model.loss_total.backward()
+    twin_z = np.load(os.path.join(HERE, "render_%s.npz" % twin))
+    for k, v in aggregator.state_dict().items():
+        assert np.array_equal(twin_z["sd." + k], v.detach().numpy()), k
+    for k, v in (("xyz", sc.xyz), ("emb", sc.emb), ("conf", sc.conf), ("pdir", sc.dir), ("color", sc.color), ("c2w_nearest", sc.c2w_nearest)):
+        assert np.array_equal(twin_z[k], v), k
+    save = dict(
+        scene_from=np.array("render_%s" % twin),
+        opt_json=np.array(json.dumps({k: v for k, v in vars(opt).items() if isinstance(v, (int, float, str, list, tuple, type(None)))})),
+        pix=pix, raydir=raydir, c2w=sc.c2w, intrinsic=sc.intrinsic, bg_color=sc.bg_color, near_far=np.array([sc.near, sc.far], np.float64),
+        tmid=ts.astype(np.float32), gt=gt, zero_epsilon=np.float64(eps), blur_kernels=kernels, frame_weight=np.float64(frame_weight),
+        patch=np.array([pn, ps]),
+        q_sample_pidx=q["sample_pidx"], q_sample_loc_w=q["sample_loc_w"], q_ray_mask=q["ray_mask"],
+        coarse_raycolor=out["coarse_raycolor"].detach().numpy(), conf_coefficient=out["conf_coefficient"].detach().numpy(),
+        full_coarse_raycolor=out_full["coarse_raycolor"].detach().numpy(), blurred_raycolor=blurred.detach().numpy(),
+        loss=np.array([float(model.loss_total), float(model.loss_ray_masked_coarse_raycolor), float(model.loss_conf_coefficient)], np.float64),
+        loss_compute_losses=np.float64(float(model.loss_total)),
+    )
+    for k, prm in aggregator.named_parameters():
+        if prm.grad is not None:
+            save["grad.aggregator." + k] = prm.grad.numpy()
+    for k in ("points_embeding", "points_conf", "points_dir", "points_color"):
+        save["grad.neural_points." + k] = getattr(neural_points, k).grad.numpy()
+    path = os.path.join(HERE, "train_%s.npz" % tag)
+    np.savez_compressed(path, **save)
+    changed = int((np.abs(save["blurred_raycolor"] - save["full_coarse_raycolor"]).reshape(pn, ps, pn, ps, 3).max(axis=(1, 3, 4)) > 0).sum())
+    print("%s: %d rays (%d patches of %dx%d), %d valid, %d patches replaced by a blurred candidate, loss_total %.6f, %.1f MB" % (
+        os.path.basename(path), raydir.shape[0], pn * pn, ps, ps, int(q["ray_mask"].sum()), changed, float(model.loss_total), os.path.getsize(path) / 1e6))
+    opt.is_train = 0
+
+
+def gen_frame_chunked(ref, twin="scannet_small", scene_name="scene0241", n_points=12000, seed=11, w=64, h=48, size=(1.0, 0.8, 0.6), margin=2, chunk=2304):
+    """The eval driver's chunk loop (run/test_ft.py:146-198) over a whole small frame through the imported reference: the frame's rays in chunks of
+    `chunk` = random_sample_size^2 = 2304, per chunk model.test() = NeuralPointsRayMarching.forward (eval) + fill_invalid (:84-126), every chunk scattered
+    into an np.zeros([H,W,3]) image by pixel index (:185-198).  Scene and weights are render_<twin>.npz's (asserted).  Also renders with chunk 1024 and
+    records the largest difference between the two chunkings (chunking must not change results at jitter 0)."""
+    torch.manual_seed(seed)
+    sc = scenes.make_scene(scene_name, n_points, seed, w=w, h=h, size=size)
+    opt = sc.opt
+    opt.agg_axis_weight = None
+    neural_points, aggregator, net = _reference_net(ref, sc, opt, n_points, train=False)
+    twin_z = np.load(os.path.join(HERE, "render_%s.npz" % twin))
+    for k, v in aggregator.state_dict().items():
+        assert np.array_equal(twin_z["sd." + k], v.detach().numpy()), k
+    assert np.array_equal(twin_z["xyz"], sc.xyz) and np.array_equal(twin_z["c2w_nearest"], sc.c2w_nearest)
+    pix = scenes.pixel_grid(sc.w, sc.h, margin)
+    raydir = scenes.camera_rays(pix, sc.intrinsic, sc.c2w)
+    shell = SimpleNamespace(input={}, opt=opt, tonemap_func=ref.drf.find_tone_map(opt.which_tonemap_func))
+
+    def loop(chunk_size):
+        image = np.zeros((sc.h, sc.w, 3), np.float32)                 # test_ft.py:191
+        masks = []
+        for k in range(0, pix.shape[0], chunk_size):                   # :165-167
+            inputs = _net_inputs(sc, pix[k:k + chunk_size], raydir[k:k + chunk_size])
+            with torch.no_grad():
+                out = net(**inputs)
+                full = ref.vol.NeuralPointsVolumetricModel.fill_invalid(shell, dict(out), inputs)
+            cp = inputs["pixel_idx"].numpy().astype(np.int32)          # :186
+            image[cp[0, ..., 1], cp[0, ..., 0], :] = full["coarse_raycolor"][0].numpy()      # :193
+            masks.append(out["ray_mask"][0].numpy())
+        return image, np.concatenate(masks)
+    image, mask = loop(chunk)
+    image2, mask2 = loop(1024)
+    assert np.array_equal(mask, mask2)
+    diff = float(np.abs(image - image2).max())
+    np.savez_compressed(os.path.join(HERE, "render_frame_chunked.npz"), scene_from=np.array("render_%s" % twin), pix=pix, raydir=raydir,
+                        c2w=sc.c2w, intrinsic=sc.intrinsic, bg_color=sc.bg_color, near_far=np.array([sc.near, sc.far], np.float64),
+                        hw=np.array([sc.h, sc.w]), chunk=np.array(chunk), image=image, ray_mask=mask, max_abs_between_chunkings=np.float64(diff))
+    print("render_frame_chunked.npz: %dx%d frame, %d rays in %d chunks of %d, %d valid; max |chunk %d - chunk 1024| = %.2e" % (
+        sc.w, sc.h, pix.shape[0], -(-pix.shape[0] // chunk), chunk, int(mask.sum()), chunk, diff))
+
+
 def gen_param_keys(ref):
     """Parameter names and shapes of the reference's PointAggregator for the option sets of the shipped scripts
     (default hybrid; *_learnable.sh: learnable_blur_kernel=1; plus the conv front-end switch)."""
@@ -746,6 +900,8 @@ def main():
               keep=("alpha_branch", "color_final_block", "color_mixup_block", "block3.2.bias", "block1.0.bias"))
     # object scene: most rays miss (R' << R), SR = 40
     gen_train(ref, "synth_small", "lego", 9000, 12, 40, 40, 20, opt_over=dict(agg_axis_weight=None, SR=40, dilation_setup="5_4_1_8"), margin=8)
+    gen_train_c5(ref)
+    gen_frame_chunked(ref)
 
 
 if __name__ == "__main__":

@@ -30,7 +30,11 @@ def load_train(tag):
         d["grad"] = {k[5:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("grad.")}
         d["grad_names"] = [str(n) for n in z["grad_names"]]
         return d
-    d = load_render(tag)
+    # `scene_from` (train_c5_small.npz): scene and weights of another render fixture, its own ray batch and extra inputs
+    d = load_render(str(z["scene_from"])[len("render_"):] if "scene_from" in z.files else tag)
+    for k in ("blur_kernels", "frame_weight", "patch", "blurred_raycolor"):
+        if k in z.files:
+            d[k] = z[k]
     for k in ("coarse_raycolor", "conf_coefficient", "full_coarse_raycolor", "q_sample_pidx", "q_sample_loc_w", "q_ray_mask",
               "pix", "raydir", "c2w", "intrinsic", "bg_color", "near_far", "tmid", "gt", "loss", "zero_epsilon", "loss_compute_losses"):
         d[k] = z[k]

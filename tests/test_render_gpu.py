@@ -131,30 +131,47 @@ def test_image_feature_map_matches_oracle():
     assert torch.all(got[:, :, 0, 0] == 0)
 
 
-def test_whole_frame_equals_chunked_render():
-    """driver.render_image: one launch over the frame vs the reference's 2304-ray chunk loop (run/test_ft.py:165-198) --
-    the query is bit-identical and the colours agree to fp32 summation-order noise; the image is assembled by pixel index."""
-    from hybridneuralrendering_amd import scenes
-    from hybridneuralrendering_amd.driver import render_image
-    d, ti, opt, cloud, rnd = _setup("scannet_small")
-    sc_w, sc_h = int(d["scene"][3]), int(d["scene"][4])
-    pix = scenes.pixel_grid(sc_w, sc_h, 2)
-    rays = scenes.camera_rays(pix, d["intrinsic"], d["c2w"])
-    dev = ti["raydir"].device
-    near, far = d["near_far"]
-    frame = dict(raydir=torch.from_numpy(rays).to(dev)[None], pixel_idx=torch.from_numpy(pix.astype(np.float32)).to(dev)[None], campos=ti["campos"],
-                 camrotc2w=ti["camrotc2w"], bg_color=ti["bg_color"], near=torch.tensor([[[near]]]), far=torch.tensor([[[far]]]), h=sc_h, w=sc_w,
+def _chunk_loop_frame(dev):
+    """tests/golden/render_frame_chunked.npz: a 64x48 frame (2640 rays) the imported reference rendered with its eval driver's 2304-ray chunk loop
+    (run/test_ft.py:146-198; make_golden.py::gen_frame_chunked).  Returns (fixture, frame dict for driver.render_image, cloud, renderer)."""
+    import os
+    from tests.golden_io import GOLD
+    z = np.load(os.path.join(GOLD, "render_frame_chunked.npz"))
+    d, ti, opt, cloud, rnd = _setup(str(z["scene_from"])[len("render_"):])
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    near, far = z["near_far"]
+    h, w = (int(v) for v in z["hw"])
+    frame = dict(raydir=t(z["raydir"])[None], pixel_idx=t(z["pix"].astype(np.float32))[None], campos=t(z["c2w"][:3, 3])[None],
+                 camrotc2w=t(z["c2w"][:3, :3])[None], bg_color=t(z["bg_color"])[None], near=torch.tensor([[[near]]]), far=torch.tensor([[[far]]]), h=h, w=w,
                  c2w_nearest=ti["c2w_nearest"], campos_nearest=ti["campos_nearest"], intrinsic_nearest=ti["intrinsic_nearest"],
                  images_nearest=ti["images_nearest"])
+    return z, frame, cloud, rnd
+
+
+def test_whole_frame_equals_the_reference_chunk_loop():
+    """driver.render_image -- ONE launch over the frame, image assembled on the device by pixel index -- against the [H,W,3] image the imported
+    reference produced with its 2304-ray chunk loop (run/test_ft.py:165-198): same valid rays, colours within the fp32 tolerance of the goldens,
+    uncast margin pixels zero like the reference's np.zeros image (:191).  Our own chunked form (chunk_rays) is held to the same fixture."""
+    from hybridneuralrendering_amd.driver import render_image
+    dev = torch.device("cuda:0")
+    z, frame, cloud, rnd = _chunk_loop_frame(dev)
     whole = render_image(rnd, cloud, frame)
-    chunked = render_image(rnd, cloud, frame, chunk_rays=48 * 48 // 9)
-    assert whole["image"].shape == (sc_h, sc_w, 3)
-    assert torch.equal(whole["ray_mask"], chunked["ray_mask"])
-    assert float((whole["image"] - chunked["image"]).abs().max()) < 2e-5
-    # margin pixels were never cast: background colour
-    assert bool((whole["image"][0, 0] == ti["bg_color"][0]).all())
+    chunked = render_image(rnd, cloud, frame, chunk_rays=int(z["chunk"]))
+    small = render_image(rnd, cloud, frame, chunk_rays=48 * 48 // 9)
+    ref = z["image"]
+    for name, got in (("whole frame", whole), ("2304-ray chunks", chunked), ("256-ray chunks", small)):
+        assert got["image"].shape == ref.shape
+        np.testing.assert_array_equal(got["ray_mask"].cpu().numpy(), z["ray_mask"], err_msg=name)
+        img = got["image"].cpu().numpy()
+        err = float(np.abs(img - ref).max())
+        assert err < TOL_RAYCOLOR, (name, err)
+        assert _psnr(img, ref) > 70.0, name
+    assert torch.equal(whole["ray_mask"], small["ray_mask"])
+    assert float((whole["image"] - small["image"]).abs().max()) < 2e-5           # chunking changes fp32 summation order at most
     img = whole["image"].cpu().numpy()
+    pix = z["pix"]
     np.testing.assert_array_equal(img[pix[:, 1], pix[:, 0]], whole["coarse_raycolor"].cpu().numpy())
+    assert float(np.abs(img[0]).max()) == 0.0 and float(np.abs(ref[0]).max()) == 0.0   # margin rows: never cast, zero in both
     assert int(whole["ray_mask"].sum()) > 100 and img.std() > 0.01
 
 

@@ -86,6 +86,29 @@ def test_render_oracle_matches_reference(tag):
     assert d["coarse_raycolor"].std() > 0.01 and (d["coarse_point_opacity"] > 0.05).sum() > 20
 
 
+def test_oracle_whole_frame_matches_the_reference_chunk_loop():
+    """tests/golden/render_frame_chunked.npz: the imported reference's eval chunk loop (run/test_ft.py:146-198, 2304-ray chunks) over a 64x48 frame.
+    The oracle renders the same frame in ONE pass (query oracle over all rays + render): chunking does not change pixels at jitter 0."""
+    z = np.load(os.path.join(GOLD, "render_frame_chunked.npz"))
+    d = load_render(str(z["scene_from"])[len("render_"):])
+    ti = torch_inputs(d)
+    o = d["opt"]
+    hp = qo.hyperparameters(d["xyz"], o["vsize"], o["vscale"], o["kernel_size"], o["ranges"], o["radius_limit_scale"])
+    g = qo.OracleGrid(d["xyz"], hp["origin"], hp["cell"], hp["dims"], o["query_size"], o["P"], o["max_o"])
+    near, far = z["near_far"]
+    q = g.query(z["c2w"][:3, 3], z["raydir"], qo.tmid_table(float(near), float(far), o["z_depth_dim"]), o["SR"], o["K"], hp["radius2"], o["kernel_size"])
+    np.testing.assert_array_equal(q["ray_mask"], z["ray_mask"])
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    with torch.no_grad():
+        out = ro.render(ti["xyz"], ti["emb"], ti["conf"], ti["pdir"], ti["color"], d["sd"], q, t(z["c2w"][:3, 3])[None], t(z["c2w"][:3, :3])[None],
+                        t(z["raydir"])[None], t(z["bg_color"])[None], ti["c2w_nearest"], ti["campos_nearest"], ti["intrinsic_nearest"],
+                        ti["images_nearest"], o["vsize"])
+    img = np.zeros_like(z["image"])
+    img[z["pix"][:, 1], z["pix"][:, 0]] = out["full_coarse_raycolor"][0].numpy()
+    np.testing.assert_allclose(img, z["image"], rtol=0, atol=2e-6)
+    assert float(z["max_abs_between_chunkings"]) <= 1e-6 and int(z["ray_mask"].sum()) > 2000
+
+
 def test_query_fixture_is_reproduced_by_the_query_oracle():
     """The sample_pidx stored in the render fixture came from the C oracle; re-derive it from the inputs."""
     d = load_render("scannet_small")
@@ -125,6 +148,34 @@ def test_train_step_oracle_matches_reference_gradients(tag):
     if "loss_compute_losses" in d and tag == "scannet_small":
         assert abs(float(d["loss_compute_losses"]) - (losses[0] + 3e-6)) < 3e-7
     # the set of parameters that receive a gradient (use_nearest = 0: none for the image branch) + the stored subset of values
+    assert sorted(k for k in grads if k.startswith("aggregator.")) == d["grad_names"]
+    for k, g in d["grad"].items():
+        ref = g.numpy()
+        scale = np.abs(ref).max()
+        assert scale > 0, k
+        np.testing.assert_allclose(grads[k].numpy(), ref, rtol=1e-4, atol=2e-5 * scale, err_msg=k)
+
+
+def test_chained_c5_step_oracle_matches_reference_gradients():
+    """BASELINE config C5 end to end as the reference chains it (models/mvs_points_volumetric_model.py:135-152): train-mode forward on a dilated
+    patch batch -> blur_update_output -> compute_losses with the item's frame weight -> backward.  tests/golden/train_c5_small.npz holds the imported
+    reference's blurred colours, loss_total and every gradient (make_golden.py::gen_train_c5); the oracle's chained step reproduces them."""
+    d = load_train("c5_small")
+    ti = torch_inputs(d)
+    q = dict(sample_pidx=d["q_sample_pidx"], sample_loc_w=d["q_sample_loc_w"], ray_mask=d["q_ray_mask"])
+    pn, ps = (int(v) for v in d["patch"])
+    fw = float(d["frame_weight"])
+    out, losses, grads = ro.train_step(ti["xyz"], ti["emb"], ti["conf"], ti["pdir"], ti["color"], d["sd"], q, ti["campos"],
+                                       ti["camrotc2w"], ti["raydir"], ti["bg_color"], ti["c2w_nearest"], ti["campos_nearest"],
+                                       ti["intrinsic_nearest"], ti["images_nearest"], d["opt"]["vsize"],
+                                       torch.from_numpy(d["gt"]), float(d["zero_epsilon"]), _drop_rows(d["opt"]), frame_weight=fw,
+                                       blur=(torch.from_numpy(d["blur_kernels"]), pn, ps))
+    np.testing.assert_allclose(out["full_coarse_raycolor"].detach().numpy(), d["full_coarse_raycolor"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(out["blurred_raycolor"].detach().numpy(), d["blurred_raycolor"], rtol=0, atol=2e-6)
+    assert not np.array_equal(d["blurred_raycolor"], d["full_coarse_raycolor"])               # some patch took a blurred candidate
+    # compute_losses adds 1e-6 per colour item before the frame weight multiplies loss_total (:1198, :1205-1206)
+    assert abs(float(d["loss_compute_losses"]) - (losses[0] + 3e-6 * fw)) < 3e-7
+    np.testing.assert_allclose(np.array(losses[1:]), d["loss"][1:], rtol=1e-6)
     assert sorted(k for k in grads if k.startswith("aggregator.")) == d["grad_names"]
     for k, g in d["grad"].items():
         ref = g.numpy()

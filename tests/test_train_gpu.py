@@ -428,6 +428,97 @@ def test_graph_free_step_with_the_blur_module_equals_the_autograd_form():
     assert n == want.numel() and torch.equal(ids[:n].long(), want.long())
 
 
+def test_chained_c5_step_matches_reference_gradients():
+    """BASELINE config C5 as the reference chains it (models/mvs_points_volumetric_model.py:135-152): train-mode forward on a dilated patch batch ->
+    blur_update_output (models/base_rendering_model.py:677-745) -> compute_losses with the item's frame weight (:1205-1206) -> backward.
+    tests/golden/train_c5_small.npz = the imported reference's blurred colours, loss_total and all 48 + 4 gradients of that chain
+    (make_golden.py::gen_train_c5); train.train_step(blur_kernels=..., frame_weight=...) -- the production step bench.py times -- against them."""
+    from hybridneuralrendering_amd.train import train_step
+    d, ti, opt, agg, path = _setup("c5_small")
+    dev = ti["emb"].device
+    emb, conf, pdir, color = _leaves(ti)
+    near, far = d["near_far"]
+    tmid = torch.from_numpy(d["tmid"]).to(dev)
+    gt = torch.from_numpy(d["gt"][0]).to(dev)
+    pn, ps = (int(v) for v in d["patch"])
+    fw = float(d["frame_weight"])
+    kern = torch.from_numpy(d["blur_kernels"]).to(dev)[None]
+    agg.zero_grad(set_to_none=True)
+    out, pg, ag = train_step(path, agg, ti["xyz"], emb, conf, pdir, color, ti["raydir"][0], ti["campos"][0], ti["camrotc2w"][0], ti["bg_color"][0],
+                             near, far, ti["c2w_nearest"][0], ti["campos_nearest"][0], ti["intrinsic_nearest"][0], ti["images_nearest"][0], gt,
+                             zero_epsilon=float(d["zero_epsilon"]), w_color=1.0, w_zero_one=1e-4, frame_weight=fw, tmid=tmid,
+                             blur_kernels=kern, patch_num=pn, patch_size=ps)
+    np.testing.assert_array_equal(out["ray_mask"].cpu().numpy(), d["q_ray_mask"])
+    np.testing.assert_allclose(out["coarse_raycolor"].cpu().numpy(), d["full_coarse_raycolor"][0], rtol=0, atol=2e-4)
+    # the blur module's choice per patch and its colours are the reference's
+    np.testing.assert_allclose(out["blurred_raycolor"].reshape(-1, 3).cpu().numpy(), d["blurred_raycolor"][0], rtol=0, atol=2e-4)
+    assert not np.array_equal(d["blurred_raycolor"], d["full_coarse_raycolor"])
+    parts = out["loss"].cpu().numpy()
+    np.testing.assert_allclose([parts[1], parts[2]], d["loss"][1:], rtol=2e-5)
+    assert abs(float(parts[0]) - float(d["loss_compute_losses"])) < 5e-6                       # (compute_losses' constant 1e-6 per colour item, :1198)
+    assert int(parts[3]) == int(d["q_ray_mask"].sum())
+    got = {"neural_points.points_embeding": emb.grad, "neural_points.points_conf": conf.grad,
+           "neural_points.points_dir": pdir.grad, "neural_points.points_color": color.grad}
+    for k, prm in agg.named_parameters():
+        if prm.grad is not None:
+            got["aggregator." + k] = prm.grad
+    assert sorted(k for k in got if k.startswith("aggregator.")) == d["grad_names"], set(got) ^ set(d["grad_names"])
+    _check_grads(got, d["grad"], "chained C5 step vs reference")
+
+
+def test_reused_output_buffers_keep_autograd_grad_semantics():
+    """TrainPath.reuse_outputs: every step overwrites the same gradient buffers.  .grad must never alias them (round-5 advice): after
+    optimizer.zero_grad(set_to_none=False) a second step leaves g2 (not 2 x g2), and without zeroing it leaves g1 + g2; accumulate_grads=False hands
+    out the buffers themselves and a later accumulating step refuses to add into them."""
+    from hybridneuralrendering_amd.train import train_step
+    from hybridneuralrendering_amd import HnrError
+    d, ti, opt, agg, path = _setup()
+    path.reuse_outputs = True
+    dev = ti["emb"].device
+    near, far = d["near_far"]
+    tmid = torch.from_numpy(d["tmid"]).to(dev)
+    gt = torch.from_numpy(d["gt"][0]).to(dev)
+    gt2 = torch.rand_like(gt)
+    emb, conf, pdir, color = _leaves(ti)
+    leaves = dict(points_embeding=emb, points_conf=conf, points_dir=pdir, points_color=color)
+
+    def step(g, **kw):
+        return train_step(path, agg, ti["xyz"], emb, conf, pdir, color, ti["raydir"][0], ti["campos"][0], ti["camrotc2w"][0], ti["bg_color"][0], near, far,
+                          ti["c2w_nearest"][0], ti["campos_nearest"][0], ti["intrinsic_nearest"][0], ti["images_nearest"][0], g,
+                          zero_epsilon=float(d["zero_epsilon"]), tmid=tmid, **kw)
+
+    def grads():
+        out = {k: t.grad.clone() for k, t in leaves.items()}
+        out.update({n: q.grad.clone() for n, q in agg.named_parameters() if q.grad is not None})
+        return out
+    _o, pg, ag = step(gt)
+    g1 = grads()
+    assert emb.grad.data_ptr() != pg["points_embeding"].data_ptr()
+    assert all(q.grad.data_ptr() != ag[n].data_ptr() for n, q in agg.named_parameters() if n in ag)
+    # accumulation without zeroing: g1 + g2
+    step(gt2)
+    acc = grads()
+    # zero in place (the torch < 2.0 default and a common explicit choice), second step again: exactly g2
+    for t in leaves.values():
+        t.grad.zero_()
+    agg.zero_grad(set_to_none=False)
+    step(gt2)
+    g2 = grads()
+    for k in g1:
+        assert torch.equal(acc[k], g1[k] + g2[k]), k
+        assert not torch.equal(g2[k], 2 * g2[k]) or float(g2[k].abs().max()) == 0.0
+    assert float((g2["points_embeding"] - g1["points_embeding"]).abs().max()) > 0          # another target: another gradient
+    # accumulate_grads=False: the step's own buffers, and an accumulating step afterwards refuses to add into them
+    for t in leaves.values():
+        t.grad = None
+    agg.zero_grad(set_to_none=True)
+    _o, pg, ag = step(gt2, accumulate_grads=False)
+    assert emb.grad.data_ptr() == pg["points_embeding"].data_ptr()
+    assert torch.equal(emb.grad.reshape(-1), g2["points_embeding"].reshape(-1))
+    with pytest.raises(HnrError):
+        step(gt)
+
+
 def test_captured_train_step_replays_bit_identically_and_follows_its_inputs():
     """train.CapturedTrainStep: the step (forward, blur module, loss kernels, backward: ~150 launches on three queues) captured once in a hipGraph;
     a replay with the same inputs equals the eager train_step bit for bit, a replay with another ray batch / ground truth / frame weight equals the
