@@ -504,3 +504,19 @@ def test_bench_parent_ends_all_ranks_when_one_fails():
     finally:
         import shutil
         shutil.rmtree(hook, ignore_errors=True)
+
+
+def test_torch_library_ops_load_and_carry_schemas():
+    """TORCH_LIBRARY(hnr) (csrc/torch_ops/hnr_torch.cpp): the second op layer of SURVEY 8b loads next to libhnr_hip.so and registers the five ops with
+    their schemas; without a GPU the dispatcher has no kernel for a CPU tensor and says so (nothing falls back to a CPU computation)."""
+    import torch
+    from hybridneuralrendering_amd import torch_ops
+    ops = torch_ops.load()
+    want = {"grid_build": "-> int", "grid_free": "-> ()", "march_query": "-> (Tensor, Tensor, Tensor, Tensor, Tensor)", "render_forward": "-> Tensor[]",
+            "render_train": "-> Tensor[]"}
+    for name, ret in want.items():
+        schema = str(getattr(ops, name).default._schema)
+        assert schema.startswith("hnr::" + name + "(") and schema.endswith(ret), schema
+    with pytest.raises((RuntimeError, NotImplementedError)):
+        ops.grid_build(torch.zeros(4, 3), [0., 0., 0.], [1., 1., 1.], [2, 2, 2], [3, 3, 3], 4, 10)
+    assert len(torch_ops.TRAIN_WEIGHT_NAMES) == 44 and len(set(torch_ops.TRAIN_WEIGHT_NAMES)) == 44

@@ -505,8 +505,12 @@ def test_reused_output_buffers_keep_autograd_grad_semantics():
     step(gt2)
     g2 = grads()
     for k in g1:
-        assert torch.equal(acc[k], g1[k] + g2[k]), k
-        assert not torch.equal(g2[k], 2 * g2[k]) or float(g2[k].abs().max()) == 0.0
+        # point gradients are fixed-order sums: exact; a few narrow weight gradients are float-atomic sums, equal up to the order of their additions
+        want = g1[k] + g2[k]
+        if k in leaves:
+            assert torch.equal(acc[k], want), k
+        else:
+            assert float((acc[k] - want).abs().max()) <= 4e-6 * max(float(want.abs().max()), 1e-30), k
     assert float((g2["points_embeding"] - g1["points_embeding"]).abs().max()) > 0          # another target: another gradient
     # accumulate_grads=False: the step's own buffers, and an accumulating step afterwards refuses to add into them
     for t in leaves.values():
