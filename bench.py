@@ -145,7 +145,7 @@ def render_frame(rnd, cloud, cam, sc, chunk, timers=None, statuses=None):
 
 
 def _newest_profile(suffix):
-    """profiles/rNN_<suffix> of the latest round that has one (the PMC passes are re-collected when the kernels change: tools/run_r4_evidence.sh)"""
+    """profiles/rNN_<suffix> of the latest round that has one (the PMC passes are re-collected when the kernels change: tools/gpu_job.sh)"""
     for tag in ("r05", "r04", "r03"):
         if os.path.exists(os.path.join(ROOT, "profiles", "%s_%s" % (tag, suffix))):
             return "%s_%s" % (tag, suffix)

@@ -1,7 +1,7 @@
-"""Summarise SQ / GRBM counter passes of the bench frame (tools/run_r4_evidence.sh: pmc_g1.csv, pmc_g2.csv, pmc_g3.csv = rocprofv3 --pmc
+"""Summarise SQ / GRBM counter passes of the bench frame (tools/gpu_job.sh: pmc_g1.csv, pmc_g2.csv, pmc_g3.csv = rocprofv3 --pmc
 counter_collection CSVs of separate passes) into profiles/<tag>_chain_pmc.json: per kernel the largest launch of every counter, MFMA-busy fraction
 = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles), kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs.
-python tools/collect_pmc.py gpurun_out/r4_evidence [tag]"""
+python tools/collect_pmc.py gpurun_out/<tag> [rNN]"""
 import collections, csv, glob, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 root = sys.argv[1]; tag = sys.argv[2] if len(sys.argv) > 2 else "r04"
@@ -26,7 +26,7 @@ for k, cs in per.items():
         e["wait_inst_any_frac"] = round(c.get("SQ_WAIT_INST_ANY", 0.0) / c["SQ_WAVE_CYCLES"], 4)
     out["chain_ws_kernel" if "chain_ws_kernel" in k else k] = e
     print("%-50s cycles %.0f mfma_busy %s valu/mfma %s" % (k[:50], cyc, e.get("mfma_busy_fraction"), e.get("valu_per_mfma")))
-note = ("rocprofv3 --kernel-trace --pmc, separate passes of `bench.py --no-cpu-baseline --no-train-leg --no-f32-anchor --steps 2 --warmup 1` (tools/run_r4_evidence.sh); "
+note = ("rocprofv3 --kernel-trace --pmc, separate passes of `bench.py --no-cpu-baseline --no-train-leg --no-f32-anchor --steps 2 --warmup 1` (tools/gpu_job.sh); "
         "per kernel the LARGEST launch of each counter (the frame launches). SQ_VALU_MFMA_BUSY_CYCLES is summed over the 1024 SIMDs (= 32 x SQ_INSTS_MFMA for "
         "v_mfma_f32_32x32x16_f16); GRBM_GUI_ACTIVE is summed over the 8 XCDs; mfma_busy_fraction = busy cycles per SIMD / kernel cycles.")
 json.dump(dict(note=note, kernels=out, **{k: v for k, v in out.items() if k == "chain_ws_kernel"}), open(os.path.join(ROOT, "profiles", tag + "_chain_pmc.json"), "w"), indent=1)

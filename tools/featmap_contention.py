@@ -1,5 +1,5 @@
 """The reference-view feature pyramid alone (hnr_image_features: six conv launches + featmap_kernel), repeated on fixed buffers; every output is
-compared with the first one.  Run it beside another process that keeps the GPU busy (tools/r4_featmap.sh).  FM_ITERS launches (default 2000);
+compared with the first one.  Run it beside another process that keeps the GPU busy (another bench.py loop).  FM_ITERS launches (default 2000);
 FM_ONLY=1: the six convolutions once, then only featmap_kernel is repeated (needs the probe entry: not available -> runs everything)."""
 import ctypes, os, sys, time
 import numpy as np, torch
