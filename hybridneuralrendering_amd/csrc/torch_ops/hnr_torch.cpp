@@ -205,7 +205,7 @@ c10::intrusive_ptr<TrainCall> train_forward(int64_t grid, c10::ArrayRef<Tensor> 
     hnr_render_camera cam{fptr(in[I_CAMPOS], "campos"), fptr(in[I_CAMROT], "camrot"), fptr(raydir, "raydir"), fptr(tmid, "tmid"), fptr(in[I_BG], "bg_color")};
     hnr_train_views vw{nullptr, nullptr, nullptr, nullptr, nullptr};
     if (views) vw = hnr_train_views{fptr(in[I_W2C], "w2c"), fptr(in[I_INTR], "intrinsic"), fptr(in[I_CAMN], "campos_nearest"), fptr(img, "images"),
-                                    in[I_FW].defined() ? fptr(in[I_FW], "frame_w") : nullptr};
+                                    in[I_FW].numel() > 0 ? fptr(in[I_FW], "frame_w") : nullptr};
     auto oi = raydir.options().dtype(at::kInt);
     c.outs = {new_f32({R, 3}, raydir), new_f32({R, SR}, raydir), new_f32({R}, raydir), new_f32({R, SR}, raydir), at::empty({R}, raydir.options().dtype(at::kChar)),
               new_f32({R, SR, 4}, raydir), at::empty({R, SR, K}, oi), new_f32({R, SR, 3}, raydir), at::empty({R}, oi),
@@ -238,7 +238,7 @@ std::vector<Tensor> train_backward(const TrainCall &c, c10::ArrayRef<Tensor> in,
     hnr_render_camera cam{fptr(in[I_CAMPOS], "campos"), fptr(in[I_CAMROT], "camrot"), fptr(in[I_RAYDIR], "raydir"), fptr(in[I_TMID], "tmid"), fptr(in[I_BG], "bg_color")};
     hnr_train_views vw{nullptr, nullptr, nullptr, nullptr, nullptr};
     if (views) vw = hnr_train_views{fptr(in[I_W2C], "w2c"), fptr(in[I_INTR], "intrinsic"), fptr(in[I_CAMN], "campos_nearest"), fptr(in[I_IMG], "images"),
-                                    in[I_FW].defined() ? fptr(in[I_FW], "frame_w") : nullptr};
+                                    in[I_FW].numel() > 0 ? fptr(in[I_FW], "frame_w") : nullptr};
     hnr_render_outputs out = outputs_of(c.outs);
     hnr_train_cloud_grads cg{g[0].data_ptr<float>(), g[1].data_ptr<float>(), g[2].data_ptr<float>(), g[3].data_ptr<float>()};
     const Tensor gc = g_col.contiguous();
@@ -308,6 +308,9 @@ std::vector<Tensor> unpack(const c10::List<std::optional<Tensor>> &l)
 {
     std::vector<Tensor> v;
     for (size_t i = 0; i < l.size(); ++i) { std::optional<Tensor> t = l.get(i); v.push_back(t.has_value() ? *t : Tensor()); }
+    // an absent optional input travels as an EMPTY tensor on the rays' device (the autograd node's input list must hold defined tensors)
+    TORCH_CHECK(v.size() == N_IN && v[I_RAYDIR].defined(), "hnr::render_train: 15 inputs expected, raydir among them");
+    for (auto &t : v) if (!t.defined()) t = at::empty({0}, v[I_RAYDIR].options().dtype(at::kFloat));
     return v;
 }
 std::vector<Tensor> render_train_autograd(int64_t grid, const c10::List<std::optional<Tensor>> &in_l, c10::ArrayRef<Tensor> weights, const OptT &drop_lut, const OptT &ray_drop, int64_t SR,
