@@ -476,9 +476,26 @@ def test_committed_pmc_files_hold_the_kernels_bench_looks_up():
     tr = json.load(open(newest("train_traffic.json")))["kernels"]
     assert any("h2wgrad_dma_kernel" in k for k in tr), list(tr)
     fr = json.load(open(newest("traffic.json")))["kernels"]
-    assert any("chain_ws_kernel<0>" in k for k in fr) and any("march_kernel" in k for k in fr) and any("knn_nb_kernel<8, 1" in k for k in fr), list(fr)
-    src = open(os.path.join(ROOT, "bench.py")).read()
-    assert '"h2wgrad_dma_kernel" in k' in src and "chain_ws_kernel<0>" in src
+    assert any("chain_ws_kernel<0>" in k for k in fr) and any("march_kernel" in k for k in fr) and any("knn_nb_kernel<8, 0" in k for k in fr), list(fr)
+    src = "".join(open(f).read() for f in glob.glob(os.path.join(ROOT, "hnr_bench", "*.py")))
+    assert '"h2wgrad_dma_kernel" in k' in src and '"chain_ws_kernel" in k' in src and '"march_kernel" in k' in src
+
+
+def test_bench_refuses_a_stale_chain_pmc_file(tmp_path, monkeypatch):
+    """roofline.mfma_busy comes from a committed PMC summary; the summary records the sha256 of the kernel source it was collected from
+    (tools/collect_pmc.py) and the bench refuses it -- mfma_busy = None and a note -- when csrc/chain_ws.hip has changed since (round-5 verdict:
+    the r04 file was quoted after five changes of the kernel)."""
+    import json
+    import hnr_bench.rooflines as R_
+    busy, src = R_.chain_mfma_busy()
+    pm = json.load(open(os.path.join(ROOT, "profiles", R_.CHAIN_PMC_JSON)))
+    if (pm.get("source_sha256") or {}).get("chain_ws.hip") == R_.source_sha256("chain_ws.hip"):
+        assert busy == pm["chain_ws_kernel"]["mfma_busy_fraction"] and "SQ_VALU_MFMA_BUSY_CYCLES" in src
+    else:
+        assert busy is None and "another build" in src
+    monkeypatch.setattr(R_, "source_sha256", lambda name: "0" * 64)
+    busy, src = R_.chain_mfma_busy()
+    assert busy is None and "another build" in src
 
 
 def test_bench_parent_ends_all_ranks_when_one_fails():

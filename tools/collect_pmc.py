@@ -29,4 +29,8 @@ for k, cs in per.items():
 note = ("rocprofv3 --kernel-trace --pmc, separate passes of `bench.py --no-cpu-baseline --no-train-leg --no-f32-anchor --steps 2 --warmup 1` (tools/gpu_job.sh); "
         "per kernel the LARGEST launch of each counter (the frame launches). SQ_VALU_MFMA_BUSY_CYCLES is summed over the 1024 SIMDs (= 32 x SQ_INSTS_MFMA for "
         "v_mfma_f32_32x32x16_f16); GRBM_GUI_ACTIVE is summed over the 8 XCDs; mfma_busy_fraction = busy cycles per SIMD / kernel cycles.")
-json.dump(dict(note=note, kernels=out, **{k: v for k, v in out.items() if k == "chain_ws_kernel"}), open(os.path.join(ROOT, "profiles", tag + "_chain_pmc.json"), "w"), indent=1)
+import hashlib
+sha = {}
+for f in ("chain_ws.hip", "chain_defs.h", "query.hip", "mlp.hip"):
+    sha[f] = hashlib.sha256(open(os.path.join(ROOT, "hybridneuralrendering_amd", "csrc", f), "rb").read()).hexdigest()
+json.dump(dict(note=note, source_sha256=sha, kernels=out, **{k: v for k, v in out.items() if k == "chain_ws_kernel"}), open(os.path.join(ROOT, "profiles", tag + "_chain_pmc.json"), "w"), indent=1)
