@@ -109,6 +109,8 @@ SIGNATURES = {
     "hnr_grid_get_stats": (_I, [_P, ctypes.POINTER(GridStats)]),
     "hnr_grid_get_params": (_I, [_P, ctypes.POINTER(GridParams)]),
     "hnr_grid_export_dense": (_I, [_P, _P, _P, _P, _P]),
+    "hnr_grid_grow": (_I, [_P, _P, _I, _P]),
+    "hnr_grid_export_runs": (_I, [_P, _P, _P, _P]),
     "hnr_query_work_elems": (ctypes.c_int64, [_I, _I]),
     "hnr_march_query": (_I, [_P, _P, _P, _P, ctypes.POINTER(QueryParams), _P, _P, _P, _P, _P, _P, _P]),
     "hnr_ray_compact_plan": (_I, [_P, _I, _P, _P, _P, _P]),

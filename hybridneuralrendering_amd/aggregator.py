@@ -203,7 +203,7 @@ class PointAggregator(nn.Module):
                 mx=FusedMlp3([mx[0].weight, mx[2].weight, mx[4].weight], [mx[0].bias, mx[2].bias, mx[4].bias], [1, 1, 0]))
         return self._packed_mlp3
 
-    def point_table(self, emb, ids=None, n_ids=None, want_rows=False):
+    def point_table(self, emb, ids=None, n_ids=None, want_rows=False, out=None):
         """[N,256] = [emb | PE3(emb)] @ block1.0.weight[:, :224]^T -- the point-only part of block1's first layer
         (exact split of the dot product; the bias and the 60 distance columns are added per (sample, neighbour) row).
         ids: int32 list of point ids -> only those rows (training: the points a batch touches)."""
@@ -217,7 +217,7 @@ class PointAggregator(nn.Module):
         with torch.cuda.device(emb.device):
             _lib.check(L.hnr_point_rows(_lib.ptr(emb), _lib.ptr(ids) if ids is not None else None, n, F, _lib.ptr(E), 224,
                                         _lib.stream()), "hnr_point_rows")
-        T = pk["b1_point"](E, act=False)
+        T = pk["b1_point"](E, act=False) if out is None else pk["b1_point"](E, out=out, act=False)      # out: [n, >= 256] rows of a caller-owned table
         return (T, E) if want_rows else T
 
     def image_features(self, images_nearest):

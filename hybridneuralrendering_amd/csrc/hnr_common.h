@@ -210,6 +210,7 @@ __device__ __forceinline__ bool hnr_project_pixel(float x, float y, float z, con
 
 }  // namespace hnr
 
+struct hnr_grid_upd;             // scratch + spare tables of hnr_grid_grow (csrc/grid.hip), allocated by its first call
 struct hnr_grid {
     hnr_grid_params p;
     hnr_grid_stats st;
@@ -223,6 +224,13 @@ struct hnr_grid {
     uint2 *nb_rng;
     float4 *nb_pts;
     uint8_t *brick_near;
+    // what hnr_grid_grow needs to extend the tables in place: entries in use / allocated (the build leaves slack behind pts, nb_pts, cell_rng, nb_rng),
+    // the unclamped number of points of every occupied cell, and the cell of the first in-bounds point (the `voxel_idx > 0` rule: it never lists points)
+    uint32_t n_occ, n_dil, pts_used, pts_cap, nb_used, nb_cap, occ_cap, dil_cap;
+    uint32_t *cell_total;
+    int first_inb;               // id of the first in-bounds point, INT_MAX: none
+    int slot0_word, slot0_bit;   // its cell (brick word, bit); -1: none
+    hnr_grid_upd *upd;
     hnr::GridView view() const
     {
         hnr::GridView v;

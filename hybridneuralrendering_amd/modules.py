@@ -144,9 +144,9 @@ class NeuralPoints(nn.Module):
             self._points_changed()
 
     def _points_changed(self):
-        """The voxel grid is cached per cloud (the reference rebuilds it per chunk, so it never has this problem): any change
-        of the point set drops it; the next query rebuilds it (3.5 ms for 2 M points -- cheap enough that an incremental CSR
-        update, SURVEY 8f-3, buys nothing)."""
+        """The voxel grid is cached per cloud (the reference rebuilds it per chunk, so it never has this problem): a change of
+        the point set other than appending (prune, set_points: point ids shift) drops it and the next query rebuilds it;
+        grow_points extends it in place (querier.grow)."""
         if getattr(self, "querier", None) is not None:
             self.querier.clean_up()
 
@@ -161,7 +161,12 @@ class NeuralPoints(nn.Module):
         print("@@@@@@@@@  pruned {}/{}".format(torch.sum(mask == 0), mask.shape[0]))
 
     def grow_points(self, add_xyz, add_embedding, add_color, add_dir, add_conf, add_eulers=None, add_Rw2c=None):   # :376-402
-        self._set("xyz", torch.cat([self.xyz, add_xyz], dim=0), self.opt.xyz_grad)
+        n_old = int(self.xyz.shape[0])
+        self.xyz = nn.Parameter(torch.cat([self.xyz, add_xyz], dim=0), requires_grad=self.opt.xyz_grad > 0)
+        # points were APPENDED: the cached voxel grid is extended in place when the grown cloud keeps the grid geometry (SURVEY 8f-3;
+        # querier.grow -> hnr_grid_grow), dropped and rebuilt by the next query otherwise
+        if getattr(self, "querier", None) is not None:
+            self.querier.grow(self.xyz, n_old)
         for name, add, flag in (("points_embeding", add_embedding, self.opt.feat_grad), ("points_conf", add_conf, self.opt.conf_grad),
                                 ("points_dir", add_dir, self.opt.dir_grad), ("points_color", add_color, self.opt.color_grad)):
             t = getattr(self, name)

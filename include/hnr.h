@@ -43,6 +43,7 @@ extern "C" {
 #define HNR_ERR_HIP      -2   /* a HIP runtime call failed (hnr_last_error() has the string)     */
 #define HNR_ERR_TOOBIG   -3   /* grid volume or an index would overflow 32 bits                 */
 #define HNR_ERR_NOMEM    -4   /* device allocation failed                                       */
+#define HNR_NEED_REBUILD  1   /* hnr_grid_grow: not an error -- the update cannot be done in place, nothing was changed; call hnr_grid_build */
 
 #define HNR_MAX_K        32   /* neighbours per shading sample (reference scripts: 8)           */
 
@@ -92,6 +93,20 @@ int hnr_grid_build(const float *d_xyz, int n_points, const hnr_grid_params *p, v
 int hnr_grid_free(hnr_grid *g);
 int hnr_grid_get_stats(const hnr_grid *g, hnr_grid_stats *out);
 int hnr_grid_get_params(const hnr_grid *g, hnr_grid_params *out);
+
+/* After grow_points (models/neural_points/neural_points.py:376-402: new points are APPENDED to the cloud): extends the tables of a grid in place instead of
+ * rebuilding them.  d_xyz [n_points,3] is the grown cloud; its first hnr_grid_get_stats().n_points rows must be the points the grid describes, unchanged,
+ * and the grid parameters (origin / cell / dims, i.e. the cloud's bounding box and opt) must still apply -- the caller checks both
+ * (querier.lighting_fast_querier.grow).  On HNR_OK the grid is logically what hnr_grid_build(d_xyz, n_points, same parameters) returns: same dilated
+ * mask, same per-cell lists and 3x3x3 neighbourhood runs in the same order, same counters; physically the changed lists / runs were appended in the
+ * slack the build leaves behind its tables (HNR_GRID_SLACK percent, default 25) and the superseded ones stay as holes.  Returns HNR_NEED_REBUILD (> 0,
+ * nothing changed) when that slack is used up, when max_o would be exceeded or was, or for grids without neighbourhood lists (P > 63).  Synchronises the
+ * host twice (sizes); launches already queued keep reading the old tables.  The reference has no counterpart: it rebuilds its tables for every
+ * 2304-ray chunk and leaves the process after growing (run/train_ft.py:926-952). */
+int hnr_grid_grow(hnr_grid *g, const float *d_xyz, int n_points, void *stream);
+/* Test hook: per cell of dims, the length of its 3x3x3 neighbourhood run (-1: the cell is not in the dilated mask) and an order-dependent hash of the
+ * run's records -- two grids with equal hnr_grid_export_dense and hnr_grid_export_runs outputs answer every query identically. */
+int hnr_grid_export_runs(const hnr_grid *g, int32_t *d_run_len, uint64_t *d_run_hash, void *stream);
 
 /* Test hook: expands the device tables into the reference's dense layout so they can be compared
  * with the oracle: d_coor_occ [X*Y*Z] u8 (dilated mask), d_cell_count [X*Y*Z] i32 (-1 = voxel not

@@ -1,0 +1,153 @@
+"""hnr_grid_grow (incremental grid update after grow_points, /root/reference/models/neural_points/neural_points.py:376-402): the tables
+extended in place must be LOGICALLY what hnr_grid_build returns for the grown cloud -- same dilated mask, same per-cell lists (count, first point),
+same 3x3x3 neighbourhood runs in the same order, same counters -- and answer every query with the same bits."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _params(xyz, vsize=0.02, P=6, max_o=200000, query=(3, 3, 3)):
+    lo, hi = xyz.min(0) - 0.05, xyz.max(0) + 0.05
+    dims = np.ceil((hi - lo) / vsize).astype(np.int32)
+    return dict(origin=lo.astype(np.float32), cell=np.full(3, vsize, np.float32), dims=dims, query_size=list(query), P=P, max_o=max_o)
+
+
+def _grid(xyz_t, prm):
+    from hybridneuralrendering_amd.querier import VoxelGrid
+    return VoxelGrid(xyz_t, prm["origin"], prm["cell"], prm["dims"], prm["query_size"], prm["P"], prm["max_o"])
+
+
+def _same_tables(a, b):
+    for x, y, name in zip(a.export_dense(), b.export_dense(), ("coor_occ", "cell_count", "cell_first")):
+        assert torch.equal(x, y), name
+    for x, y, name in zip(a.export_runs(), b.export_runs(), ("run_len", "run_hash")):
+        assert torch.equal(x, y), name
+    for k in ("n_points", "n_inbounds", "n_occ", "n_dropped_voxels", "n_cells_over_P", "n_dilated", "n_words"):
+        assert a.stats[k] == b.stats[k], (k, a.stats[k], b.stats[k])
+
+
+def _same_queries(a, b, xyz, seed):
+    from hybridneuralrendering_amd import querier as Q
+    g = torch.Generator().manual_seed(seed)
+    R = 3000
+    c = torch.from_numpy(xyz.mean(0))
+    campos = (c + torch.tensor([0.0, 0.0, -1.5])).to(DEV)
+    tgt = c[None] + (torch.rand((R, 3), generator=g) - 0.5) * torch.from_numpy(xyz.max(0) - xyz.min(0))[None]
+    raydir = (tgt.to(DEV) - campos[None]).contiguous()
+    raydir = raydir / raydir[:, 2:3].abs().clamp(min=1e-3)
+    tmid = Q.tmid_table(0.1, 3.0, 256, device=DEV)
+    for order in (0, 1):
+        ra = Q.march_query(a, campos, raydir.float(), tmid, 16, 8, np.float32(0.04 ** 2), [3, 3, 3], pad=True, knn_order=order)
+        rb = Q.march_query(b, campos, raydir.float(), tmid, 16, 8, np.float32(0.04 ** 2), [3, 3, 3], pad=True, knn_order=order)
+        for k in ("sample_pidx", "sample_loc_w", "ray_nsamp", "ray_mask"):
+            assert torch.equal(ra[k], rb[k]), (order, k)
+        assert int((ra["sample_pidx"] >= 0).sum()) > 1000
+
+
+def _cloud(seed, n, spread=(1.0, 0.8, 0.05)):
+    rng = np.random.default_rng(seed)
+    # a wavy sheet: many cells with several points (P = 6 overflows in places), empty space around it
+    u = rng.uniform(-0.5, 0.5, size=(n, 2))
+    z = 0.1 * np.sin(6 * u[:, 0]) + rng.normal(0, spread[2] * 0.2, size=n)
+    return np.stack([u[:, 0] * spread[0] * 2, u[:, 1] * spread[1] * 2, z], axis=1).astype(np.float32)
+
+
+@pytest.mark.parametrize("seed,n_old,n_new", [(1, 40000, 400), (2, 40000, 4000), (3, 5000, 50), (4, 60000, 1)])
+def test_grown_grid_equals_a_rebuild(seed, n_old, n_new):
+    rng = np.random.default_rng(100 + seed)
+    base = _cloud(seed, n_old)
+    # new points: some in fresh cells (a patch beside the sheet), some inside existing (partly full) cells, some in the cell of point 0 (the slot-0
+    # cell never lists points), some outside the grid
+    k = max(n_new // 4, 1)
+    fresh = _cloud(seed + 50, k) * np.float32(0.2) + np.array([0.3, 0.3, 0.25], np.float32)
+    dup = base[rng.integers(0, n_old, size=k)] + rng.normal(0, 0.003, size=(k, 3)).astype(np.float32)
+    first = base[:1] + rng.normal(0, 0.002, size=(max(n_new - 3 * k, 0) + 1, 3)).astype(np.float32)
+    out = base[rng.integers(0, n_old, size=k)] + np.array([5.0, 0, 0], np.float32)
+    new = np.concatenate([fresh, dup, first, out])[:n_new]
+    full = np.concatenate([base, new])
+    prm = _params(np.concatenate([base, fresh]))                       # the box both clouds are built in (the out-of-bounds points stay outside)
+    t_full = torch.from_numpy(full).to(DEV)
+    g_inc = _grid(t_full[:n_old].contiguous(), prm)
+    assert g_inc.grow(t_full) is True
+    g_ref = _grid(t_full, prm)
+    _same_tables(g_inc, g_ref)
+    _same_queries(g_inc, g_ref, full[:n_old], seed)
+
+
+def test_repeated_grows_then_the_slack_runs_out_and_nothing_changes(monkeypatch):
+    """Three grows in a row stay equal to rebuilds; with a tiny slack (HNR_GRID_SLACK=1) a large grow is refused (False), the grid still answers for
+    the OLD cloud, and a rebuild takes over."""
+    rng = np.random.default_rng(7)
+    base = _cloud(11, 30000)
+    adds = [base[rng.integers(0, 30000, size=600)] + rng.normal(0, 0.01, size=(600, 3)).astype(np.float32) for _ in range(3)]
+    prm = _params(base)
+    cur = base
+    g = _grid(torch.from_numpy(base).to(DEV), prm)
+    for a in adds:
+        cur = np.concatenate([cur, np.clip(a, base.min(0), base.max(0))])
+        t = torch.from_numpy(cur).to(DEV)
+        assert g.grow(t) is True
+        _same_tables(g, _grid(t, prm))
+    monkeypatch.setenv("HNR_GRID_SLACK", "1")
+    g2 = _grid(torch.from_numpy(base).to(DEV), prm)
+    before = [x.clone() for x in g2.export_dense()] + [x.clone() for x in g2.export_runs()]
+    big = np.concatenate([base, np.clip(base[:20000] + np.float32(0.013), base.min(0), base.max(0))])
+    assert g2.grow(torch.from_numpy(big).to(DEV)) is False
+    after = list(g2.export_dense()) + list(g2.export_runs())
+    assert all(torch.equal(x, y) for x, y in zip(before, after)) and g2.n_points == 30000
+
+
+def test_grow_points_extends_the_cached_grid_and_the_point_table_in_place():
+    """NeuralPoints.grow_points -> querier.grow: same grid handle afterwards when the grown cloud keeps the grid geometry, a rebuild when its bounding
+    box changes; HybridRenderer.point_table computes only the new rows.  Timing at the bench size (2 M points + 1 %) is printed."""
+    import time
+    from hybridneuralrendering_amd import scenes
+    from hybridneuralrendering_amd.aggregator import PointAggregator
+    from hybridneuralrendering_amd.render import HybridRenderer, PointCloud
+    from hybridneuralrendering_amd.querier import lighting_fast_querier
+    sc = scenes.make_scene("scene0241", 2000000, 2)
+    opt = sc.opt
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    xyz, emb = t(sc.xyz), t(sc.emb)
+    q = lighting_fast_querier(torch.device(DEV), opt)
+    grid, hp = q._grid_for(xyz[None])
+    handle = grid.handle.value
+    rng = np.random.default_rng(3)
+    add = 20000
+    new = sc.xyz[rng.integers(0, sc.xyz.shape[0], size=add)] + rng.normal(0, 0.01, size=(add, 3)).astype(np.float32)
+    new = np.clip(new, sc.xyz.min(0), sc.xyz.max(0))                           # inside the old bounding box: same origin / dims
+    xyz2 = torch.cat([xyz, t(new)])
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    assert q.grow(xyz2, xyz.shape[0]) is True
+    torch.cuda.synchronize(); ms_grow = (time.perf_counter() - t0) * 1e3
+    grid2, hp2 = q._grid_for(xyz2[None])
+    assert grid2.handle.value == handle and grid2.n_points == xyz2.shape[0]
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    ref = _grid(xyz2, dict(origin=hp2[2][:3], cell=hp2[5], dims=hp2[6], query_size=opt.query_size, P=opt.P, max_o=opt.max_o))
+    torch.cuda.synchronize(); ms_build = (time.perf_counter() - t0) * 1e3
+    _same_tables(grid2, ref)
+    # the per-point table: only the new rows are computed
+    torch.manual_seed(0)
+    agg = PointAggregator(opt).to(DEV)
+    rnd = HybridRenderer(opt, agg, torch.device(DEV))
+    conf, pdir, col = t(sc.conf), t(sc.dir), t(sc.color)
+    c1 = PointCloud(xyz, emb, conf, pdir, col)
+    pt1 = rnd.point_table(c1).clone()
+    emb2 = torch.cat([emb.reshape(-1, 32), torch.randn((add, 32), device=DEV) * 0.3])
+    c2 = PointCloud(xyz2, emb2, torch.cat([conf.reshape(-1), torch.ones(add, device=DEV)]), torch.cat([pdir.reshape(-1, 3), torch.zeros((add, 3), device=DEV)]),
+                    torch.cat([col.reshape(-1, 3), torch.zeros((add, 3), device=DEV)]))
+    store = rnd._pt_store
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    pt2 = rnd.point_table(c2)
+    torch.cuda.synchronize(); ms_tab = (time.perf_counter() - t0) * 1e3
+    assert rnd._pt_store is store and pt2.shape[0] == xyz2.shape[0]
+    assert torch.equal(pt2[:xyz.shape[0]], pt1) and torch.equal(pt2, agg.point_table(emb2))
+    print("GRID_GROW 2 M points + %d: hnr_grid_grow (incl. bounds + host checks) %.2f ms, full hnr_grid_build %.2f ms, point table rows %.2f ms" % (
+        add, ms_grow, ms_build, ms_tab))
+    assert ms_grow < 0.5 * ms_build
+    # a point outside the old bounding box changes origin / dims: the cache is dropped, the next query rebuilds
+    far = torch.cat([xyz2, (xyz2.max(0).values + 0.5)[None]])
+    assert q.grow(far, xyz2.shape[0]) is False and q._grid is None

@@ -19,7 +19,7 @@ for job in "$@"; do
   name=${job%%:*}; arg=""; [ "$job" != "$name" ] && arg=${job#*:}
   case $name in
     tests)
-      timeout 3000 python3 -m pytest tests -x -q -m gpu $arg > "$O/pytest_gpu.txt" 2>&1; echo "pytest rc=$?" >> "$O/pytest_gpu.txt"; tail -5 "$O/pytest_gpu.txt";;
+      timeout 3000 python3 -m pytest ${arg:-tests} -x -q -m gpu > "$O/pytest_gpu.txt" 2>&1; echo "pytest rc=$?" >> "$O/pytest_gpu.txt"; tail -5 "$O/pytest_gpu.txt";;
     smoke)
       timeout 600 python3 -c "import __graft_entry__ as g; g.smoke()" > "$O/smoke.txt" 2>&1; echo "smoke rc=$?"; tail -2 "$O/smoke.txt";;
     bench)
