@@ -791,7 +791,8 @@ __device__ __forceinline__ bool upd_nb_cell(const GridView &g, const unsigned lo
     return true;
 }
 
-// new run table: clean runs keep their place; dirty ones are measured (FILL = false) or written behind the used part of nb_pts (FILL = true)
+// new run table: clean runs keep their place; dirty ones are measured (FILL = false) and then written (FILL = true) -- over their old run when the new
+// one fits its two padded parts (a point or two added to a neighbourhood usually do), behind the used part of nb_pts otherwise
 template <bool FILL>
 __global__ void upd_runs_kernel(GridView g, const unsigned long long *__restrict__ dil_old, const uint4 *__restrict__ drec_old, const unsigned long long *__restrict__ dil,
                                 const uint32_t *__restrict__ dprefix, const unsigned long long *__restrict__ ddirty, uint32_t n_words, const unsigned long long *__restrict__ bits,
@@ -814,7 +815,9 @@ __global__ void upd_runs_kernel(GridView g, const unsigned long long *__restrict
     const int wz = (int)(w % (uint32_t)g.bz), wy = (int)((w / (uint32_t)g.bz) % (uint32_t)g.by), wx = (int)(w / ((uint32_t)g.bz * (uint32_t)g.by));
     const int x = wx * 4 + (b >> 4), y = wy * 4 + ((b >> 2) & 3), z = wz * 4 + (b & 3);
     uint32_t c0 = 0, total = 0, cells1 = 0, cell0 = 0;
-    const uint32_t start = FILL ? nb_used + run_off[ds] : 0u;
+    // FILL: run_len[ds] > 0: appended at nb_used + run_off[ds]; == 0: in place (the measuring pass left the old start in nb_rng[ds].x)
+    // (an empty new run has no old place either: it points at the append position -- readers fetch the first records of a run before they test its length)
+    const uint32_t start = FILL ? ((run_len[ds] || nb_rng[ds].x == 0xFFFFFFFFu) ? nb_used + run_off[ds] : nb_rng[ds].x) : 0u;
     uint32_t out = start;
     int2 rg;
     if (upd_nb_cell(g, bits, prefix, rng, x, y, z, rg)) {
@@ -832,7 +835,17 @@ __global__ void upd_runs_kernel(GridView g, const unsigned long long *__restrict
                 if (FILL) for (int j = 0; j < rg.y; ++j) nb_pts[out++] = pts[rg.x + j];
             }
     if (FILL) nb_rng[ds] = make_uint2(start, c0 | (total << 6) | (cells1 << 17) | (cell0 << 22));
-    else run_len[ds] = c0p + ((total - c0 + 3u) & ~3u);
+    else {
+        const uint32_t len = c0p + ((total - c0 + 3u) & ~3u);
+        uint32_t keep = 0xFFFFFFFFu;                                           // old start when the new run fits the old one's padded parts
+        if ((bo >> b) & 1ull) {
+            const uint2 ro = nb_rng_old[drec_old[w].z + (uint32_t)__popcll(bo & ((1ull << b) - 1ull))];
+            const uint32_t c0o = ro.y & 63u, toto = (ro.y >> 6) & 2047u;
+            if (c0p == ((c0o + 3u) & ~3u) && ((total - c0 + 3u) & ~3u) <= ((toto - c0o + 3u) & ~3u)) keep = ro.x;
+        }
+        run_len[ds] = keep != 0xFFFFFFFFu ? 0u : len;
+        nb_rng[ds] = make_uint2(keep, 0u);
+    }
 }
 
 // totals the host needs before anything visible is written: cells, dilated cells, appended entries
@@ -914,7 +927,11 @@ static int grow_impl(hnr_grid *g, const float *d_xyz, int n, hipStream_t st)
     GU_CHECK(hipMemcpyAsync(h, u.scal, sizeof(h), hipMemcpyDeviceToHost, st));
     GU_CHECK(hipStreamSynchronize(st));
     const uint64_t n_occ = h[US_NOCC], n_dil = h[US_NDIL];
-    if (n_occ > g->occ_cap || n_dil > g->dil_cap || n_occ > (uint64_t)g->p.max_o) return HNR_NEED_REBUILD;
+    if (n_occ > g->occ_cap || n_dil > g->dil_cap || n_occ > (uint64_t)g->p.max_o) {
+        set_error("hnr_grid_grow: rebuild needed (%llu cells / capacity %u, %llu dilated cells / capacity %u, max_o %d)", (unsigned long long)n_occ, g->occ_cap,
+                  (unsigned long long)n_dil, g->dil_cap, g->p.max_o);
+        return HNR_NEED_REBUILD;
+    }
     upd_rng_kernel<<<cdiv(n_occ, TB), TB, 0, st>>>(u.old_of_new, g->cell_rng, u.cell_total, (uint32_t)n_occ, g->occ_cap, P, g->slot0_word, g->slot0_bit, u.bits, u.prefix,
                                                   u.cell_rng, u.add_len, u.scal);
     { size_t sz = u.tmp_bytes; GU_CHECK(rocprim::exclusive_scan((void *)u.tmp, sz, u.add_len, u.add_off, 0u, (size_t)n_occ, rocprim::plus<uint32_t>(), st)); }
@@ -929,7 +946,11 @@ static int grow_impl(hnr_grid *g, const float *d_xyz, int n, hipStream_t st)
     GU_CHECK(hipMemcpyAsync(h, u.scal, sizeof(h), hipMemcpyDeviceToHost, st));
     GU_CHECK(hipStreamSynchronize(st));
     const uint64_t pts_add = h[US_PTS_ADD], nb_add = h[US_NB_ADD];
-    if ((uint64_t)g->pts_used + pts_add > g->pts_cap || (uint64_t)g->nb_used + nb_add + 4 > g->nb_cap) return HNR_NEED_REBUILD;
+    if ((uint64_t)g->pts_used + pts_add > g->pts_cap || (uint64_t)g->nb_used + nb_add + 4 > g->nb_cap) {
+        set_error("hnr_grid_grow: rebuild needed (list entries %u + %llu of %u, run entries %u + %llu of %u: the slack of the build is used up)", g->pts_used,
+                  (unsigned long long)pts_add, g->pts_cap, g->nb_used, (unsigned long long)nb_add, g->nb_cap);
+        return HNR_NEED_REBUILD;
+    }
     // ---- from here on the live arrays are written: the appended parts of pts / nb_pts first (no reader sees them yet), then the small tables are swapped in
     upd_place_kernel<<<cdiv(n_occ, TB), TB, 0, st>>>(u.old_of_new, g->cell_rng, u.add_len, u.add_off, (uint32_t)n_occ, g->pts_used, u.cell_rng, g->pts);
     upd_append_kernel<<<cdiv(n_new, TB), TB, 0, st>>>(d_xyz, u.keys2, u.vals2, u.rank, n_new, u.old_of_new, g->cell_rng, u.cell_rng, u.add_len, g->pts);

@@ -55,8 +55,10 @@ def _cloud(seed, n, spread=(1.0, 0.8, 0.05)):
     return np.stack([u[:, 0] * spread[0] * 2, u[:, 1] * spread[1] * 2, z], axis=1).astype(np.float32)
 
 
-@pytest.mark.parametrize("seed,n_old,n_new", [(1, 40000, 400), (2, 40000, 4000), (3, 5000, 50), (4, 60000, 1)])
-def test_grown_grid_equals_a_rebuild(seed, n_old, n_new):
+@pytest.mark.parametrize("seed,n_old,n_new,slack", [(1, 40000, 400, None), (2, 40000, 4000, "300"), (3, 5000, 50, None), (4, 60000, 1, None)])
+def test_grown_grid_equals_a_rebuild(seed, n_old, n_new, slack, monkeypatch):
+    if slack:                                   # 10 % new points rewrite more runs than the default 25 % of slack holds (then: a rebuild, tested below)
+        monkeypatch.setenv("HNR_GRID_SLACK", slack)
     rng = np.random.default_rng(100 + seed)
     base = _cloud(seed, n_old)
     # new points: some in fresh cells (a patch beside the sheet), some inside existing (partly full) cells, some in the cell of point 0 (the slot-0
@@ -71,7 +73,8 @@ def test_grown_grid_equals_a_rebuild(seed, n_old, n_new):
     prm = _params(np.concatenate([base, fresh]))                       # the box both clouds are built in (the out-of-bounds points stay outside)
     t_full = torch.from_numpy(full).to(DEV)
     g_inc = _grid(t_full[:n_old].contiguous(), prm)
-    assert g_inc.grow(t_full) is True
+    from hybridneuralrendering_amd import _lib
+    assert g_inc.grow(t_full) is True, _lib.lib().hnr_last_error()
     g_ref = _grid(t_full, prm)
     _same_tables(g_inc, g_ref)
     _same_queries(g_inc, g_ref, full[:n_old], seed)
@@ -86,11 +89,15 @@ def test_repeated_grows_then_the_slack_runs_out_and_nothing_changes(monkeypatch)
     prm = _params(base)
     cur = base
     g = _grid(torch.from_numpy(base).to(DEV), prm)
+    monkeypatch.setenv("HNR_GRID_SLACK", "150")
+    g = _grid(torch.from_numpy(base).to(DEV), prm)
+    from hybridneuralrendering_amd import _lib
     for a in adds:
         cur = np.concatenate([cur, np.clip(a, base.min(0), base.max(0))])
         t = torch.from_numpy(cur).to(DEV)
-        assert g.grow(t) is True
+        assert g.grow(t) is True, _lib.lib().hnr_last_error()
         _same_tables(g, _grid(t, prm))
+    _same_queries(g, _grid(t, prm), cur, 5)
     monkeypatch.setenv("HNR_GRID_SLACK", "1")
     g2 = _grid(torch.from_numpy(base).to(DEV), prm)
     before = [x.clone() for x in g2.export_dense()] + [x.clone() for x in g2.export_runs()]
