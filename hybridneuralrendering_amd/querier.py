@@ -249,11 +249,13 @@ class lighting_fast_querier:
     def clean_up(self):
         if self._grid is not None:
             self._grid.free()
-        self._grid, self._grid_key, self._hp, self._grid_src = None, None, None, None
+        self._grid, self._grid_key, self._hp, self._grid_src, self._grid_bounds = None, None, None, None, None
 
     # -- hyper-parameters (:46-77) -------------------------------------------------------------
-    def get_hyperparameters(self, vsize_np, point_xyz_w_tensor, ranges=None):
-        mn, mx = points_bounds(point_xyz_w_tensor)
+    def get_hyperparameters(self, vsize_np, point_xyz_w_tensor, ranges=None, bounds=None):
+        """bounds: (min, max) of the cloud when the caller knows them already (grow: old bounds combined with the new points')."""
+        mn, mx = points_bounds(point_xyz_w_tensor) if bounds is None else bounds
+        self._last_bounds = (np.asarray(mn, np.float32).copy(), np.asarray(mx, np.float32).copy())
         radius_limit_np, ranges_np, scaled_vsize_np, scaled_vdim_np, vdim_np = compute_hyperparameters(
             mn, mx, vsize_np, self.opt.vscale, self.opt.kernel_size, ranges, self.opt.radius_limit_scale)
         depth_limit_np = np.asarray(getattr(self.opt, "depth_limit_scale", 0.0) * vsize_np[2]).astype(np.float32)
@@ -271,6 +273,7 @@ class lighting_fast_querier:
             return self._grid, self._hp
         self.clean_up()
         hp = self.get_hyperparameters(self.opt.vsize, point_xyz_w_tensor, ranges=self.opt.ranges)
+        self._grid_bounds = self._last_bounds
         radius_limit_np, _, ranges_np, _, _, scaled_vsize_np, scaled_vdim_np = hp[:7]
         self._grid = VoxelGrid(xyz.reshape(-1, 3), ranges_np[:3], scaled_vsize_np, scaled_vdim_np, self.opt.query_size,
                                self.opt.P, self.opt.max_o)
@@ -287,18 +290,27 @@ class lighting_fast_querier:
     def grow(self, point_xyz_w_tensor, n_old):
         """After NeuralPoints.grow_points (neural_points.py:376-402): `point_xyz_w_tensor` [1,N,3] / [N,3] is the grown cloud whose first n_old rows
         are the cloud the cached grid was built from.  When the grown cloud gives the SAME grid geometry (get_hyperparameters: its bounding box
-        decides origin and dims) the tables are extended in place (hnr_grid_grow, ~0.3 ms for 1 % new points instead of a ~6 ms rebuild) and
+        decides origin and dims) the tables are extended in place (hnr_grid_grow: 0.85 - 0.9 ms for 1 % new points at 2 M against a 4.7 ms rebuild) and
         True is returned; otherwise the cache is dropped and the next query rebuilds.  Logically identical to a rebuild either way."""
         xyz = point_xyz_w_tensor.detach()
         if self._grid is None or self._hp is None or self._grid.n_points != int(n_old):
             self.clean_up()
             return False
-        hp = self.get_hyperparameters(self.opt.vsize, xyz if xyz.dim() == 3 else xyz[None], ranges=self.opt.ranges)
+        # the grown cloud's bounds = the old cloud's combined with the NEW points' (min / max are exact: the same values as a pass over all N points)
+        old_b = getattr(self, "_grid_bounds", None)                    # bounds of the cloud the cached grid describes (_grid_for / grow)
+        flat = xyz.reshape(-1, 3)
+        if old_b is None or flat.shape[0] <= int(n_old):
+            self.clean_up()
+            return False
+        mn2, mx2 = points_bounds(flat[int(n_old):])
+        hp = self.get_hyperparameters(self.opt.vsize, xyz if xyz.dim() == 3 else xyz[None], ranges=self.opt.ranges,
+                                      bounds=(np.minimum(old_b[0], mn2), np.maximum(old_b[1], mx2)))
         same = all(np.array_equal(np.asarray(hp[i]), np.asarray(self._hp[i])) for i in (0, 2, 5, 6))
         if not same or not self._grid.grow(xyz.reshape(-1, 3)):
             self.clean_up()
             return False
         self._grid_key, self._hp, self._grid_src = self._key_of(xyz if xyz.dim() == 3 else xyz[None]), hp, xyz
+        self._grid_bounds = self._last_bounds
         self.last_grid_stats = self._grid.stats
         return True
 
