@@ -335,29 +335,6 @@ __global__ void brick_near_kernel(GridView g, const unsigned long long *__restri
     near[w] = any ? 1 : 0;
 }
 
-// GridView::coarse: every brick with a dilated cell marks the coarse cells its extent, widened by one cell, overlaps
-__global__ void coarse_mark_kernel(GridView g, const unsigned long long *__restrict__ dil, uint32_t n_words, int ncy, int ncz, uint8_t *__restrict__ coarse)
-{
-    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= n_words || dil[w] == 0ull) return;
-    const int wz = (int)(w % (uint32_t)g.bz), wy = (int)((w / (uint32_t)g.bz) % (uint32_t)g.by), wx = (int)(w / ((uint32_t)g.bz * (uint32_t)g.by));
-    const int x0 = max(4 * wx - 1, 0) >> 4, x1 = min(4 * wx + 4, g.dx - 1) >> 4, y0 = max(4 * wy - 1, 0) >> 4, y1 = min(4 * wy + 4, g.dy - 1) >> 4;
-    const int z0 = max(4 * wz - 1, 0) >> 4, z1 = min(4 * wz + 4, g.dz - 1) >> 4;
-    for (int x = x0; x <= x1; ++x)
-        for (int y = y0; y <= y1; ++y)
-            for (int z = z0; z <= z1; ++z) coarse[((size_t)x * ncy + y) * ncz + z] = 1;
-}
-
-static hipError_t coarse_build(hnr_grid *g, const unsigned long long *dil, hipStream_t st)
-{
-    if (!g->coarse) return hipSuccess;
-    const size_t n = (size_t)g->nc[0] * g->nc[1] * g->nc[2];
-    hipError_t e = hipMemsetAsync(g->coarse, 0, n, st);
-    if (e != hipSuccess) return e;
-    coarse_mark_kernel<<<cdiv(g->n_words, 256), 256, 0, st>>>(g->view(), dil, g->n_words, g->nc[1], g->nc[2], g->coarse);
-    return hipGetLastError();
-}
-
 __global__ void pack_dil_rec_kernel(const unsigned long long *__restrict__ dil, const uint32_t *__restrict__ dprefix, uint32_t n_words, uint4 *rec)
 {
     uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
@@ -509,23 +486,6 @@ static int build_impl(hnr_grid *g, const float *d_xyz, int n, hipStream_t st)
 
     g->occ_rec = rec.release();
     g->dil = dil.release();
-    // ---- coarse empty-space mask for the march (GridView::coarse).  The march's approximate coordinates are good to ~8 ulps of the largest coordinate
-    //      in cell units; the mask's margin is one cell: built only when that is at least 2^-6 of a cell away (coordinates below 2^17 cells), HNR_MARCH_COARSE=0: never
-    {
-        float big = 0.f;
-        for (int a = 0; a < 3; ++a) {
-            const float ext = fabsf(p->origin[a]) + (float)p->dims[a] * p->cell[a];
-            big = fmaxf(big, ext / p->cell[a]);
-        }
-        const char *ec = getenv("HNR_MARCH_COARSE");
-        if (!(ec && atoi(ec) == 0) && big < 131072.f) {
-            for (int a = 0; a < 3; ++a) g->nc[a] = (p->dims[a] + 15) / 16;
-            DevBuf<uint8_t> cm;
-            GB_CHECK(cm.alloc((size_t)g->nc[0] * g->nc[1] * g->nc[2]));
-            g->coarse = cm.release();
-            GB_CHECK(coarse_build(g, g->dil, st));
-        }
-    }
     g->cell_rng = cell_rng.release();
     g->pts = pts.release();
     g->cell_total = cell_total.release();
@@ -1000,7 +960,6 @@ static int grow_impl(hnr_grid *g, const float *d_xyz, int n, hipStream_t st)
     pack_rec_kernel<<<cdiv(n_words, TB), TB, 0, st>>>(u.bits, u.prefix, n_words, u.occ_rec);
     pack_dil_rec_kernel<<<cdiv(n_words, TB), TB, 0, st>>>(u.dil, u.dprefix, n_words, u.dil_rec);
     GU_CHECK(hipGetLastError());
-    GU_CHECK(coarse_build(g, u.dil, st));                                    // (the mask only gains entries: marches already queued stay conservative)
     // (kernels already queued on `st` keep reading the old tables: the swap below only changes what LATER launches are handed; the old arrays become the
     //  next update's spares and are not written before that update's kernels, which run behind everything queued now)
     std::swap(g->occ_rec, u.occ_rec); std::swap(g->dil_rec, u.dil_rec); std::swap(g->dil, u.dil); std::swap(g->cell_rng, u.cell_rng);
@@ -1041,7 +1000,6 @@ extern "C" int hnr_grid_free(hnr_grid *g)
     if (g->nb_pts) (void)hipFree(g->nb_pts);
     if (g->brick_near) (void)hipFree(g->brick_near);
     if (g->cell_total) (void)hipFree(g->cell_total);
-    if (g->coarse) (void)hipFree(g->coarse);
     grid_upd_free(g->upd);
     delete g;
     return HNR_OK;

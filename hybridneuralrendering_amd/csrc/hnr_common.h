@@ -54,12 +54,6 @@ struct GridView {
     // brick_near[w] != 0: some cell of the dilated mask lies in brick w or within TWO bricks of it (5x5x5 bricks).  The march probes one depth in four
     // and skips the other three when the probed one sits in a brick with brick_near == 0 and the ray cannot leave the 5x5x5 block within three steps.
     const uint8_t *brick_near;
-    // coarse[c] != 0: the coarse cell c = 16^3 cells (4^3 bricks) holds a cell of the dilated mask, or lies within ONE cell of one.  The march tests a
-    // block of 64 depths against it with approximate coordinates (one fma per axis) and skips the exact probe of the block when no lane's coarse cell
-    // is marked: the one-cell margin covers the approximation by three orders of magnitude, so the kept samples are the same by construction.
-    // NULL: no skip (grids whose coordinates are too large for the margin, HNR_MARCH_COARSE=0).
-    const uint8_t *coarse;
-    int ncx, ncy, ncz;
 };
 
 // floor((p - shift) / size) with fp32 subtract and IEEE fp32 divide, exactly as the reference
@@ -230,8 +224,6 @@ struct hnr_grid {
     uint2 *nb_rng;
     float4 *nb_pts;
     uint8_t *brick_near;
-    uint8_t *coarse;             // GridView::coarse, [nc[0] * nc[1] * nc[2]]
-    int nc[3];
     // what hnr_grid_grow needs to extend the tables in place: entries in use / allocated (the build leaves slack behind pts, nb_pts, cell_rng, nb_rng),
     // the unclamped number of points of every occupied cell, and the cell of the first in-bounds point (the `voxel_idx > 0` rule: it never lists points)
     uint32_t n_occ, n_dil, pts_used, pts_cap, nb_used, nb_cap, occ_cap, dil_cap;
@@ -248,7 +240,6 @@ struct hnr_grid {
         v.by = bd[1]; v.bz = bd[2];
         v.occ_rec = occ_rec; v.dil = dil; v.cell_rng = cell_rng; v.pts = pts;
         v.dil_rec = dil_rec; v.nb_rng = nb_rng; v.nb_pts = nb_pts; v.brick_near = brick_near;
-        v.coarse = coarse; v.ncx = nc[0]; v.ncy = nc[1]; v.ncz = nc[2];
         return v;
     }
 };

@@ -163,38 +163,10 @@ __global__ __launch_bounds__(256) void march_kernel(GridView g, const float *__r
             unsigned long long wd[8];
             int bt[8];
             bool in[8];
-            // Round 6: most blocks of 64 depths inside the grid's box lie in the room's air.  Every lane looks its depth's COARSE cell (16^3 cells) up
-            // with approximate coordinates -- q ~ a + b t per axis, one fma; the exact chain costs ~25 instructions -- and the block is probed exactly only
-            // when some lane's coarse cell is marked.  The mask is widened by one cell and the approximation is good to ~1e-3 cells, so a lane whose exact
-            // cell is in the dilated mask always sees a marked coarse cell: the kept samples are the same bits (every oracle comparison runs this path).
-            unsigned near_mask = 0xffu;
-            if (g.coarse && !(probe_mode & 8)) {
-                const float rcx = __builtin_amdgcn_rcpf(g.cx), rcy = __builtin_amdgcn_rcpf(g.cy), rcz = __builtin_amdgcn_rcpf(g.cz);
-                const float ax = (px - g.ox) * rcx, ay = (py - g.oy) * rcy, az = (pz - g.oz) * rcz, bx = dx * rcx, by = dy * rcy, bz = dz * rcz;
-                const float hx = (float)(g.ncx - 1), hy = (float)(g.ncy - 1), hz = (float)(g.ncz - 1);
-                uint8_t cm[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    cm[k] = 0;
-                    if (k < nblk) {
-                        const float t = tv[k];
-                        // coarse coordinates, clamped into the mask (lanes outside the slab interval do not vote; NaN -> 0 through the clamp's fmaxf / fminf)
-                        const float cxf = fminf(fmaxf(floorf(fmaf(t, bx, ax) * 0.0625f), 0.f), hx), cyf = fminf(fmaxf(floorf(fmaf(t, by, ay) * 0.0625f), 0.f), hy);
-                        const float czf = fminf(fmaxf(floorf(fmaf(t, bz, az) * 0.0625f), 0.f), hz);
-                        cm[k] = g.coarse[((int)cxf * g.ncy + (int)cyf) * g.ncz + (int)czf];
-                    }
-                }
-                near_mask = 0u;
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    if (k < nblk && __builtin_amdgcn_ballot_w64(tv[k] >= t_in && tv[k] <= t_out && cm[k] != 0) != 0ull) near_mask |= 1u << k;
-                if (!(dx == dx && dy == dy && dz == dz) || !(t_in > -INFINITY)) near_mask = 0xffu;      // (NaN directions / no slab interval: the exact path decides)
-            }
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 in[k] = false; wd[k] = 0ull; bt[k] = 0; sx[k] = sy[k] = sz[k] = 0.f;
-                if (k < nblk && ((near_mask >> k) & 1u) && __builtin_amdgcn_ballot_w64(tv[k] >= t_in && tv[k] <= t_out) != 0ull)
-                    in[k] = probe(tv[k], sx[k], sy[k], sz[k], wd[k], bt[k]);
+                if (k < nblk && __builtin_amdgcn_ballot_w64(tv[k] >= t_in && tv[k] <= t_out) != 0ull) in[k] = probe(tv[k], sx[k], sy[k], sz[k], wd[k], bt[k]);
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k)

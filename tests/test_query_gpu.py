@@ -351,9 +351,7 @@ def test_every_knn_kernel_variant_returns_the_same_bits(tmp_path):
         return [l for l in p.stdout.splitlines() if l.startswith("VARIANT")][0].split()[1:]
     base = run()
     for env in (dict(HNR_KNN="3"), dict(HNR_KNN="4"), dict(HNR_KNN="5"), dict(HNR_KNN="6"), dict(HNR_KNN="7"), dict(HNR_KNN="9"), dict(HNR_KNN="10"), dict(HNR_NB_LISTS="0"), dict(HNR_MARCH_PROBE="2"), dict(HNR_MARCH_TWO_LEVEL="1"), dict(HNR_MARCH_TWO_LEVEL="1", HNR_MARCH_RAYS_PER_WAVE="1"),
-                dict(HNR_MARCH_RAYS_PER_WAVE="1"), dict(HNR_MARCH_RAYS_PER_WAVE="64"),
-                # round 6: the march skips blocks of 64 depths whose coarse cells (16^3) are all empty; without the coarse mask / with the skip switched off
-                dict(HNR_MARCH_COARSE="0"), dict(HNR_MARCH_PROBE="8")):
+                dict(HNR_MARCH_RAYS_PER_WAVE="1"), dict(HNR_MARCH_RAYS_PER_WAVE="64")):
         got = run(**env)
         assert got[:2] == base[:2], (env, got, base)
         if "HNR_NB_LISTS" in env:
