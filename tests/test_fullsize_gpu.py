@@ -208,6 +208,24 @@ def test_c3_scene0241_train_step_full_size():
             tol_e, tol_l2 = (8e-3, 3e-3) if "aux_merge_weight_block" in k else (2e-3, 1.5e-3)
             assert e < tol_e and l2 < tol_l2, (k, e, l2)
     print("C3 full size: %d rows; worst gradient error: weights %.1e, points %.1e of max" % (int(o["counts"][3]), worst_w, worst_p))
+    # fp64 yardstick for the widest tolerances above (round-5 verdict: "would not notice a 0.3 % systematic error in a merge-weight gradient"): the same
+    # graph in double precision on the CPU; the HIP gradients must be as close to it as the reference's own fp32 evaluation is (x 3), i.e. what the
+    # tolerances absorb is fp32 rounding of the reference arithmetic, not an error of the kernels
+    _, _, g64 = ro.train_step(c(sc.xyz), c(sc.emb), c(sc.conf), c(sc.dir), c(sc.color), sd, q, c(sc.c2w[:3, 3])[None], c(sc.c2w[:3, :3])[None],
+                              c(rays)[None], c(sc.bg_color)[None], c(sc.c2w_nearest)[None], c(sc.c2w_nearest[:, :3, 3])[None],
+                              c(sc.intrinsic)[None], c(sc.images_nearest)[None], opt.vsize, c(gt), 1e-3, ro.drop_patch_rays(8, 7, opt.drop_ratio),
+                              dtype=torch.float64)
+    report = []
+    for k, r64 in g64.items():
+        r64 = r64.numpy().astype(np.float64)
+        if r64.size == 1 or not ("aux_merge_weight_block" in k or k.startswith("neural_points.")):
+            continue
+        nrm = np.linalg.norm(r64)
+        e_gpu = float(np.linalg.norm(got[k].detach().cpu().numpy().astype(np.float64).reshape(r64.shape) - r64) / nrm)
+        e_ref = float(np.linalg.norm(gref[k].numpy().astype(np.float64) - r64) / nrm)
+        report.append((k, e_gpu, e_ref))
+        assert e_gpu <= max(3.0 * e_ref, 2e-4), (k, e_gpu, e_ref)
+    print("C3 full size, relative l2 vs the fp64 graph (HIP | reference arithmetic in fp32): " + "; ".join("%s %.1e | %.1e" % (k.split(".", 1)[1], a_, b_) for k, a_, b_ in report))
 
 
 def test_c4_scene0101_full_forward_render_and_8_way_shards():
