@@ -580,6 +580,7 @@ struct hnr_grid_upd_t {
     uint2 *nb_rng = nullptr; uint32_t *run_len = nullptr, *run_off = nullptr;                       // [dil_cap]
     uint32_t *keys = nullptr, *vals = nullptr, *keys2 = nullptr, *vals2 = nullptr, *rank = nullptr; // [new_cap]
     char *tmp = nullptr; size_t tmp_bytes = 0;
+    char *arena = nullptr;                                                                          // one allocation behind the scratch arrays (not the spare tables)
     unsigned long long *scal = nullptr;                                                             // device scalars [8]
     int new_cap = 0;
 };
@@ -590,8 +591,7 @@ namespace hnr {
 void grid_upd_free(hnr_grid_upd *u)
 {
     if (!u) return;
-    void *all[] = {u->bits, u->dil, u->touched, u->ddirty, u->cnt, u->prefix, u->dcnt, u->dprefix, u->occ_rec, u->dil_rec, u->cell_rng, u->cell_total, u->add_len,
-                   u->add_off, u->old_of_new, u->nb_rng, u->run_len, u->run_off, u->keys, u->vals, u->keys2, u->vals2, u->rank, u->tmp, u->scal};
+    void *all[] = {u->arena, u->dil, u->occ_rec, u->dil_rec, u->cell_rng, u->cell_total, u->nb_rng, u->keys, u->vals, u->keys2, u->vals2, u->rank, u->tmp};
     for (void *q : all) if (q) (void)hipFree(q);
     delete u;
 }
@@ -882,13 +882,23 @@ static int grow_impl(hnr_grid *g, const float *d_xyz, int n, hipStream_t st)
     const int n_old = (int)g->st.n_points, n_new = n - n_old, P = g->p.P;
     if (!g->upd) g->upd = new hnr_grid_upd();
     hnr_grid_upd &u = *g->upd;
-    GU_CHECK(upd_alloc(u.bits, n_words)); GU_CHECK(upd_alloc(u.dil, n_words)); GU_CHECK(upd_alloc(u.touched, n_words)); GU_CHECK(upd_alloc(u.ddirty, n_words));
-    GU_CHECK(upd_alloc(u.cnt, n_words)); GU_CHECK(upd_alloc(u.prefix, n_words)); GU_CHECK(upd_alloc(u.dcnt, n_words)); GU_CHECK(upd_alloc(u.dprefix, n_words));
-    GU_CHECK(upd_alloc(u.occ_rec, n_words)); GU_CHECK(upd_alloc(u.dil_rec, n_words));
-    GU_CHECK(upd_alloc(u.cell_rng, g->occ_cap)); GU_CHECK(upd_alloc(u.cell_total, g->occ_cap)); GU_CHECK(upd_alloc(u.add_len, g->occ_cap));
-    GU_CHECK(upd_alloc(u.add_off, g->occ_cap)); GU_CHECK(upd_alloc(u.old_of_new, g->occ_cap));
-    GU_CHECK(upd_alloc(u.nb_rng, g->dil_cap)); GU_CHECK(upd_alloc(u.run_len, g->dil_cap)); GU_CHECK(upd_alloc(u.run_off, g->dil_cap));
-    GU_CHECK(upd_alloc(u.scal, US_N));
+    if (!u.arena) {
+        // the table-sized scratch arrays from ONE allocation (two dozen hipMallocs cost 0.3 ms on the first call); the six SPARE tables that are swapped
+        // with the grid's own (and freed through it) stay individual allocations
+        const size_t nw = n_words, oc = g->occ_cap, dc = g->dil_cap;
+        auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+        const size_t total = 3 * up(nw * 8) + 4 * up(nw * 4) + 3 * up(oc * 4) + 2 * up(dc * 4) + up(US_N * 8);
+        GU_CHECK(hipMalloc((void **)&u.arena, total));
+        char *base = u.arena;
+        auto take = [&](size_t b) { char *q = base; base += up(b); return q; };
+        u.bits = (unsigned long long *)take(nw * 8); u.touched = (unsigned long long *)take(nw * 8); u.ddirty = (unsigned long long *)take(nw * 8);
+        u.cnt = (uint32_t *)take(nw * 4); u.prefix = (uint32_t *)take(nw * 4); u.dcnt = (uint32_t *)take(nw * 4); u.dprefix = (uint32_t *)take(nw * 4);
+        u.add_len = (uint32_t *)take(oc * 4); u.add_off = (uint32_t *)take(oc * 4); u.old_of_new = (int32_t *)take(oc * 4);
+        u.run_len = (uint32_t *)take(dc * 4); u.run_off = (uint32_t *)take(dc * 4);
+        u.scal = (unsigned long long *)take(US_N * 8);
+        GU_CHECK(upd_alloc(u.dil, nw)); GU_CHECK(upd_alloc(u.occ_rec, nw)); GU_CHECK(upd_alloc(u.dil_rec, nw));
+        GU_CHECK(upd_alloc(u.cell_rng, oc)); GU_CHECK(upd_alloc(u.cell_total, oc)); GU_CHECK(upd_alloc(u.nb_rng, dc));
+    }
     if (n_new > u.new_cap) {
         for (uint32_t **q : {&u.keys, &u.vals, &u.keys2, &u.vals2, &u.rank}) { if (*q) (void)hipFree(*q); *q = nullptr; }
         u.new_cap = n_new + n_new / 2 + 1024;

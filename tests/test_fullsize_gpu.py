@@ -225,6 +225,10 @@ def test_c3_scene0241_train_step_full_size():
         e_ref = float(np.linalg.norm(gref[k].numpy().astype(np.float64) - r64) / nrm)
         report.append((k, e_gpu, e_ref))
         assert e_gpu <= max(3.0 * e_ref, 2e-4), (k, e_gpu, e_ref)
+        if "aux_merge_weight_block" in k:
+            # measured: HIP 8e-7 .. 2.1e-5, the reference's fp32 arithmetic 8e-6 .. 1.2e-3 -- the 8e-3 / 3e-3 allowed above against the fp32 oracle is the
+            # ORACLE's rounding; against fp64 a 0.3 % systematic error of a merge-weight gradient would fail here by a factor of 30
+            assert e_gpu < 1e-4, (k, e_gpu)
     print("C3 full size, relative l2 vs the fp64 graph (HIP | reference arithmetic in fp32): " + "; ".join("%s %.1e | %.1e" % (k.split(".", 1)[1], a_, b_) for k, a_, b_ in report))
 
 
