@@ -896,14 +896,17 @@ static int grow_impl(hnr_grid *g, const float *d_xyz, int n, hipStream_t st)
         u.add_len = (uint32_t *)take(oc * 4); u.add_off = (uint32_t *)take(oc * 4); u.old_of_new = (int32_t *)take(oc * 4);
         u.run_len = (uint32_t *)take(dc * 4); u.run_off = (uint32_t *)take(dc * 4);
         u.scal = (unsigned long long *)take(US_N * 8);
-        GU_CHECK(upd_alloc(u.dil, nw)); GU_CHECK(upd_alloc(u.occ_rec, nw)); GU_CHECK(upd_alloc(u.dil_rec, nw));
-        GU_CHECK(upd_alloc(u.cell_rng, oc)); GU_CHECK(upd_alloc(u.cell_total, oc)); GU_CHECK(upd_alloc(u.nb_rng, dc));
     }
+    // (no-ops once allocated; a call that failed half-way leaves the rest for the next one)
+    GU_CHECK(upd_alloc(u.dil, n_words)); GU_CHECK(upd_alloc(u.occ_rec, n_words)); GU_CHECK(upd_alloc(u.dil_rec, n_words));
+    GU_CHECK(upd_alloc(u.cell_rng, g->occ_cap)); GU_CHECK(upd_alloc(u.cell_total, g->occ_cap)); GU_CHECK(upd_alloc(u.nb_rng, g->dil_cap));
     if (n_new > u.new_cap) {
         for (uint32_t **q : {&u.keys, &u.vals, &u.keys2, &u.vals2, &u.rank}) { if (*q) (void)hipFree(*q); *q = nullptr; }
-        u.new_cap = n_new + n_new / 2 + 1024;
-        GU_CHECK(upd_alloc(u.keys, u.new_cap)); GU_CHECK(upd_alloc(u.vals, u.new_cap)); GU_CHECK(upd_alloc(u.keys2, u.new_cap)); GU_CHECK(upd_alloc(u.vals2, u.new_cap));
-        GU_CHECK(upd_alloc(u.rank, u.new_cap));
+        u.new_cap = 0;
+        const int cap = n_new + n_new / 2 + 1024;
+        GU_CHECK(upd_alloc(u.keys, cap)); GU_CHECK(upd_alloc(u.vals, cap)); GU_CHECK(upd_alloc(u.keys2, cap)); GU_CHECK(upd_alloc(u.vals2, cap));
+        GU_CHECK(upd_alloc(u.rank, cap));
+        u.new_cap = cap;
     }
     size_t s1 = 0, s2 = 0, s3 = 0, s4 = 0;
     GU_CHECK(rocprim::exclusive_scan(nullptr, s1, u.cnt, u.prefix, 0u, (size_t)n_words, rocprim::plus<uint32_t>(), st));
