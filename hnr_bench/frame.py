@@ -193,6 +193,18 @@ def main():
     train_sharded = None
     if not args.no_train_leg:
         train_sharded = train_leg_sharded(args, sc, opt, agg, cloud, rnd, cam, dev, world, rank, rehearsal, emulate)
+        if world == 1 and not emulate and train_sharded and not train_sharded.get("error"):
+            # what sharding this batch over 8 GPUs could buy (round-5 verdict): rank 0's 1/8 share alone on this GPU, the
+            # collectives' local parts included; per-GPU efficiency = whole batch / (8 x share).  C5 is too small a
+            # batch to shard efficiently and the line says so.
+            share = train_leg_sharded(args, sc, opt, agg, cloud, rnd, cam, dev, world, rank, rehearsal, "0/8", steps=10)
+            if share and not share.get("error") and share.get("ms_per_step"):
+                eff = train_sharded["ms_per_step"] / (8.0 * share["ms_per_step"])
+                train_sharded["share_1_of_8"] = dict(
+                    ms_per_step=share["ms_per_step"], compute_ms=share.get("compute_ms"),
+                    predicted_per_gpu_efficiency_at_8=round(eff, 3),
+                    note="emulated on ONE GPU (no RCCL): one rank's 6-7 patches alone; a share is a chain of ~190 "
+                         "launches whose fixed part does not shrink with the batch")
 
     if rank == 0:
         counts = out["counts"].cpu().numpy() if args.chunk <= 0 or args.chunk >= R else None
