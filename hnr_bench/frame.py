@@ -194,8 +194,8 @@ def main():
     if not args.no_train_leg:
         train_sharded = train_leg_sharded(args, sc, opt, agg, cloud, rnd, cam, dev, world, rank, rehearsal, emulate)
         if world == 1 and not emulate and train_sharded and not train_sharded.get("error"):
-            # what sharding this batch over 8 GPUs could buy (round-5 verdict): rank 0's 1/8 share alone on this GPU, the
-            # collectives' local parts included; per-GPU efficiency = whole batch / (8 x share).  C5 is too small a
+            # what sharding this batch over 8 GPUs could buy (round-5 verdict): rank 0's 1/8 share alone on this GPU,
+            # the collectives' local parts included; per-GPU efficiency = whole batch / (8 x share).  C5 is too small a
             # batch to shard efficiently and the line says so.
             share = train_leg_sharded(args, sc, opt, agg, cloud, rnd, cam, dev, world, rank, rehearsal, "0/8", steps=10)
             if share and not share.get("error") and share.get("ms_per_step"):

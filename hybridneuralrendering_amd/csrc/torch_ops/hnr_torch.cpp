@@ -14,8 +14,8 @@
 #include <ATen/ATen.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/library.h>
+#include <ATen/core/dispatch/Dispatcher.h>
 #include <torch/csrc/autograd/custom_function.h>
-#include <torch/custom_class.h>
 
 #include <cstring>
 #include <vector>
@@ -147,22 +147,23 @@ std::vector<Tensor> render_forward(int64_t grid, const Tensor &xyz, const Tensor
 }
 
 // ---- hnr::render_train: forward in train mode; backward through the registered autograd formula.
+// Three ops: hnr::render_train_fwd / hnr::render_train_bwd are the two library calls (CUDA kernels + shape functions registered from Python), and
+// hnr::render_train is the differentiable op whose Autograd kernel is a C++ autograd::Function that REDISPATCHES to those two -- so tracing
+// (FakeTensorMode, torch.compile, export) sees ops with shape functions on both sides of the tape and never runs a kernel.
 // weights: the 44 tensors of hnr_train_weights in struct order (block1.0 w, b, block1.2 w, b, block3.0 w, b, block3.2 w, b, alpha w, b, cf w x3, cf b x3,
-// mw w x4, mw b x4, mx w x3, mx b x3, fin w, b, conv w x6, conv b x6); with V = 0 the image-branch entries may be undefined tensors.
-constexpr int N_TW = 44;
+// mw w x4, mw b x4, mx w x3, mx b x3, fin w, b, conv w x6, conv b x6).
+constexpr int N_TW = 44, N_OUT = 13;
+// inputs: [xyz, emb, conf, dir, color, campos, camrot, raydir, tmid, bg_color, w2c, intrinsic, campos_nearest, images, frame_w]; the last five are optional
+enum { I_XYZ, I_EMB, I_CONF, I_DIR, I_COLOR, I_CAMPOS, I_CAMROT, I_RAYDIR, I_TMID, I_BG, I_W2C, I_INTR, I_CAMN, I_IMG, I_FW, N_IN };
+using OptList = c10::List<std::optional<Tensor>>;
+
 void fill_train_weights(hnr_train_weights &w, c10::ArrayRef<Tensor> t)
 {
     const float **slot = reinterpret_cast<const float **>(&w);
     static_assert(sizeof(hnr_train_weights) == N_TW * sizeof(void *), "hnr_train_weights is 44 pointers");
     for (int i = 0; i < N_TW; ++i) slot[i] = t[i].defined() ? fptr(t[i], "train weight") : nullptr;
 }
-struct TrainCall : torch::CustomClassHolder {
-    hnr_train_params p;
-    std::vector<Tensor> keep;        // inputs the backward call reads again
-    Tensor ws; char *wsp; int64_t nbytes;
-    std::vector<Tensor> outs;        // raycolor, opacity, is_background, blend_weight, ray_mask, decoded, sample_pidx, sample_loc_w, ray_nsamp, counts, status, weight, conf_coefficient
-};
-hnr_render_outputs outputs_of(const std::vector<Tensor> &o)
+hnr_render_outputs outputs_of(c10::ArrayRef<Tensor> o)
 {
     hnr_render_outputs out;
     std::memset(&out, 0, sizeof(out));
@@ -172,164 +173,209 @@ hnr_render_outputs outputs_of(const std::vector<Tensor> &o)
     out.d_conf_coefficient = o[12].data_ptr<float>();
     return out;
 }
-
-// inputs in one flat list so that the autograd node can save them: [xyz, emb, conf, dir, color, campos, camrot, raydir, tmid, bg_color, w2c, intrinsic, campos_nearest, images, frame_w]
-enum { I_XYZ, I_EMB, I_CONF, I_DIR, I_COLOR, I_CAMPOS, I_CAMROT, I_RAYDIR, I_TMID, I_BG, I_W2C, I_INTR, I_CAMN, I_IMG, I_FW, N_IN };
-
-c10::intrusive_ptr<TrainCall> train_forward(int64_t grid, c10::ArrayRef<Tensor> in, c10::ArrayRef<Tensor> weights, const OptT &drop_lut, const OptT &ray_drop, int64_t SR,
-                        at::IntArrayRef kernel_size, double radius2, double vsize_z, int64_t raydist_mode_unit, int64_t knn_order, double slope, int64_t cap_samples)
+// None -> undefined; the point buffers in the library's flat shapes (the reference's are [1,N,32], [1,N,1], ...)
+std::vector<Tensor> unpack(const OptList &l)
 {
-    TORCH_CHECK(in.size() == N_IN && weights.size() == N_TW, "hnr::render_train: 15 inputs and 44 weights expected");
-    const Tensor &raydir = in[I_RAYDIR], &tmid = in[I_TMID], &img = in[I_IMG];
-    const int64_t R = raydir.size(0), K = 8;
-    auto cp = c10::make_intrusive<TrainCall>();
-    TrainCall &c = *cp;
-    std::memset(&c.p, 0, sizeof(c.p));
-    c.p.R = (int)R; c.p.SR = (int)SR; c.p.K = (int)K; c.p.D = (int)tmid.size(-1);
-    c.p.tmid_stride = tmid.dim() == 1 ? 0 : (int)tmid.size(1);
-    for (int i = 0; i < 3; ++i) c.p.kernel_size[i] = (int)kernel_size[i];
-    c.p.radius2 = (float)radius2; c.p.vsize_z = (float)vsize_z; c.p.raydist_mode_unit = (int)raydist_mode_unit;
-    const bool views = img.defined() && img.numel() > 0;
-    c.p.V = views ? (int)img.size(0) : 0; c.p.H = views ? (int)img.size(1) : 0; c.p.W = views ? (int)img.size(2) : 0;
-    c.p.n_points = (int)in[I_XYZ].size(0);
-    c.p.cap_samples = (int)(cap_samples > 0 ? cap_samples : R * SR);
-    c.p.knn_order = (int)knn_order; c.p.slope = (float)slope;
-    c.nbytes = hnr_render_train_workspace_bytes(&c.p);
-    TORCH_CHECK(c.nbytes >= 0, "hnr_render_train_workspace_bytes: ", hnr_last_error());
-    c.ws = at::empty({c.nbytes + 256}, raydir.options().dtype(at::kByte));
-    c.wsp = reinterpret_cast<char *>(c.ws.data_ptr());
-    c.wsp += (256 - (reinterpret_cast<uintptr_t>(c.wsp) & 255)) & 255;
-    hnr_train_cloud cl{fptr(in[I_XYZ], "xyz"), fptr(in[I_EMB], "emb"), fptr(in[I_CONF], "conf"), fptr(in[I_DIR], "dir"), fptr(in[I_COLOR], "color")};
+    TORCH_CHECK(l.size() == N_IN, "hnr::render_train: 15 inputs expected");
+    std::vector<Tensor> v;
+    for (size_t i = 0; i < l.size(); ++i) { std::optional<Tensor> t = l.get(i); v.push_back(t.has_value() ? *t : Tensor()); }
+    TORCH_CHECK(v[I_XYZ].defined() && v[I_RAYDIR].defined(), "hnr::render_train: xyz and raydir are required");
+    const int64_t N = v[I_XYZ].size(-2);
+    v[I_XYZ] = v[I_XYZ].reshape({N, 3}); v[I_EMB] = v[I_EMB].reshape({N, 32}); v[I_CONF] = v[I_CONF].reshape({N});
+    v[I_DIR] = v[I_DIR].reshape({N, 3}); v[I_COLOR] = v[I_COLOR].reshape({N, 3});
+    return v;
+}
+struct TrainStructs {
+    hnr_train_params p;
+    hnr_train_cloud cl;
     hnr_train_weights w;
-    fill_train_weights(w, weights);
-    hnr_render_camera cam{fptr(in[I_CAMPOS], "campos"), fptr(in[I_CAMROT], "camrot"), fptr(raydir, "raydir"), fptr(tmid, "tmid"), fptr(in[I_BG], "bg_color")};
-    hnr_train_views vw{nullptr, nullptr, nullptr, nullptr, nullptr};
-    if (views) vw = hnr_train_views{fptr(in[I_W2C], "w2c"), fptr(in[I_INTR], "intrinsic"), fptr(in[I_CAMN], "campos_nearest"), fptr(img, "images"),
-                                    in[I_FW].numel() > 0 ? fptr(in[I_FW], "frame_w") : nullptr};
-    auto oi = raydir.options().dtype(at::kInt);
-    c.outs = {new_f32({R, 3}, raydir), new_f32({R, SR}, raydir), new_f32({R}, raydir), new_f32({R, SR}, raydir), at::empty({R}, raydir.options().dtype(at::kChar)),
-              new_f32({R, SR, 4}, raydir), at::empty({R, SR, K}, oi), new_f32({R, SR, 3}, raydir), at::empty({R}, oi),
-              at::empty({HNR_NCOUNTS}, raydir.options().dtype(at::kLong)), at::empty({2}, oi), new_f32({R, SR, K}, raydir), new_f32({R, SR, K}, raydir)};
-    hnr_render_outputs out = outputs_of(c.outs);
-    const uint8_t *lut = (drop_lut.has_value() && drop_lut->defined()) ? cptr<uint8_t>(*drop_lut, "drop_lut", at::kByte) : nullptr;
-    const uint8_t *rd = (ray_drop.has_value() && ray_drop->defined()) ? cptr<uint8_t>(*ray_drop, "ray_drop", at::kByte) : nullptr;
-    hnr_check(hnr_render_train_forward(reinterpret_cast<const hnr_grid *>((intptr_t)grid), &c.p, &cl, &w, &cam, views ? &vw : nullptr, lut, rd, c.wsp, c.nbytes, &out,
-                                       cur_stream(raydir)),
-              "hnr_render_train_forward");
-    return cp;
+    hnr_render_camera cam;
+    hnr_train_views vw;
+    bool views;
+};
+TrainStructs train_structs(const std::vector<Tensor> &in, c10::ArrayRef<Tensor> weights, int64_t SR, at::IntArrayRef kernel_size, double radius2, double vsize_z,
+                           int64_t raydist_mode_unit, int64_t knn_order, double slope, int64_t cap_samples)
+{
+    TORCH_CHECK(weights.size() == N_TW && kernel_size.size() == 3, "hnr::render_train: 44 weights, kernel_size [3]");
+    const Tensor &raydir = in[I_RAYDIR], &tmid = in[I_TMID], &img = in[I_IMG];
+    const int64_t R = raydir.size(0);
+    TrainStructs t;
+    std::memset(&t.p, 0, sizeof(t.p));
+    t.p.R = (int)R; t.p.SR = (int)SR; t.p.K = 8; t.p.D = (int)tmid.size(-1);
+    t.p.tmid_stride = tmid.dim() == 1 ? 0 : (int)tmid.size(1);
+    for (int i = 0; i < 3; ++i) t.p.kernel_size[i] = (int)kernel_size[i];
+    t.p.radius2 = (float)radius2; t.p.vsize_z = (float)vsize_z; t.p.raydist_mode_unit = (int)raydist_mode_unit;
+    t.views = img.defined() && img.numel() > 0;
+    t.p.V = t.views ? (int)img.size(0) : 0; t.p.H = t.views ? (int)img.size(1) : 0; t.p.W = t.views ? (int)img.size(2) : 0;
+    t.p.n_points = (int)in[I_XYZ].size(0);
+    t.p.cap_samples = (int)(cap_samples > 0 ? cap_samples : R * SR);
+    t.p.knn_order = (int)knn_order; t.p.slope = (float)slope;
+    t.cl = hnr_train_cloud{fptr(in[I_XYZ], "xyz"), fptr(in[I_EMB], "emb"), fptr(in[I_CONF], "conf"), fptr(in[I_DIR], "dir"), fptr(in[I_COLOR], "color")};
+    fill_train_weights(t.w, weights);
+    t.cam = hnr_render_camera{fptr(in[I_CAMPOS], "campos"), fptr(in[I_CAMROT], "camrot"), fptr(raydir, "raydir"), fptr(tmid, "tmid"), fptr(in[I_BG], "bg_color")};
+    t.vw = hnr_train_views{nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (t.views) t.vw = hnr_train_views{fptr(in[I_W2C], "w2c"), fptr(in[I_INTR], "intrinsic"), fptr(in[I_CAMN], "campos_nearest"), fptr(img, "images"),
+                                        in[I_FW].defined() && in[I_FW].numel() > 0 ? fptr(in[I_FW], "frame_w") : nullptr};
+    return t;
+}
+char *aligned(const Tensor &ws)
+{
+    char *q = reinterpret_cast<char *>(ws.data_ptr());
+    return q + ((256 - (reinterpret_cast<uintptr_t>(q) & 255)) & 255);
 }
 
-// gradients: [d emb [N,32], d conf [N], d dir [N,3], d color [N,3]] + 44 weight gradients (undefined where the forward had none)
-std::vector<Tensor> train_backward(const TrainCall &c, c10::ArrayRef<Tensor> in, c10::ArrayRef<Tensor> weights, const Tensor &g_col, const OptT &g_cc)
+// hnr::render_train_fwd -> the 13 outputs (raycolor, opacity, is_background, blend_weight, ray_mask, decoded, sample_pidx, sample_loc_w, ray_nsamp, counts,
+// status, weight, conf_coefficient) + the step's workspace (uint8), which hnr::render_train_bwd needs
+std::vector<Tensor> render_train_fwd(int64_t grid, const OptList &in_l, c10::ArrayRef<Tensor> weights, const OptT &drop_lut, const OptT &ray_drop, int64_t SR,
+                                     at::IntArrayRef kernel_size, double radius2, double vsize_z, int64_t raydist_mode_unit, int64_t knn_order, double slope, int64_t cap_samples)
 {
+    const std::vector<Tensor> in = unpack(in_l);
+    TrainStructs t = train_structs(in, weights, SR, kernel_size, radius2, vsize_z, raydist_mode_unit, knn_order, slope, cap_samples);
+    const Tensor &raydir = in[I_RAYDIR];
+    const int64_t R = raydir.size(0), K = 8;
+    const int64_t nbytes = hnr_render_train_workspace_bytes(&t.p);
+    TORCH_CHECK(nbytes >= 0, "hnr_render_train_workspace_bytes: ", hnr_last_error());
+    Tensor ws = at::empty({nbytes + 256}, raydir.options().dtype(at::kByte));
+    auto oi = raydir.options().dtype(at::kInt);
+    std::vector<Tensor> outs = {new_f32({R, 3}, raydir), new_f32({R, SR}, raydir), new_f32({R}, raydir), new_f32({R, SR}, raydir),
+                                at::empty({R}, raydir.options().dtype(at::kChar)), new_f32({R, SR, 4}, raydir), at::empty({R, SR, K}, oi), new_f32({R, SR, 3}, raydir),
+                                at::empty({R}, oi), at::empty({HNR_NCOUNTS}, raydir.options().dtype(at::kLong)), at::empty({2}, oi), new_f32({R, SR, K}, raydir),
+                                new_f32({R, SR, K}, raydir)};
+    hnr_render_outputs out = outputs_of(outs);
+    const uint8_t *lut = (drop_lut.has_value() && drop_lut->defined()) ? cptr<uint8_t>(*drop_lut, "drop_lut", at::kByte) : nullptr;
+    const uint8_t *rd = (ray_drop.has_value() && ray_drop->defined()) ? cptr<uint8_t>(*ray_drop, "ray_drop", at::kByte) : nullptr;
+    hnr_check(hnr_render_train_forward(reinterpret_cast<const hnr_grid *>((intptr_t)grid), &t.p, &t.cl, &t.w, &t.cam, t.views ? &t.vw : nullptr, lut, rd, aligned(ws), nbytes,
+                                       &out, cur_stream(raydir)),
+              "hnr_render_train_forward");
+    outs.push_back(ws);
+    return outs;
+}
+
+// hnr::render_train_bwd -> [d emb [N,32], d conf [N], d dir [N,3], d color [N,3]] + 44 weight gradients (zero-size where the forward had no views)
+std::vector<Tensor> render_train_bwd(const OptList &in_l, c10::ArrayRef<Tensor> weights, c10::ArrayRef<Tensor> fwd, const Tensor &g_col, const OptT &g_cc, int64_t SR,
+                                     at::IntArrayRef kernel_size, double radius2, double vsize_z, int64_t raydist_mode_unit, int64_t knn_order, double slope, int64_t cap_samples)
+{
+    TORCH_CHECK(fwd.size() == N_OUT + 1, "hnr::render_train_bwd: the 14 tensors hnr::render_train_fwd returned");
+    const std::vector<Tensor> in = unpack(in_l);
+    TrainStructs t = train_structs(in, weights, SR, kernel_size, radius2, vsize_z, raydist_mode_unit, knn_order, slope, cap_samples);
     const int64_t N = in[I_XYZ].size(0);
-    const Tensor &like = in[I_RAYDIR];
+    const Tensor &like = in[I_RAYDIR], &ws = fwd[N_OUT];
     std::vector<Tensor> g = {new_f32({N, 32}, like), new_f32({N}, like), new_f32({N, 3}, like), new_f32({N, 3}, like)};
-    std::vector<Tensor> gw(N_TW);
-    const bool views = c.p.V > 0;
+    std::vector<Tensor> gw(N_TW), gw_ptr(N_TW);
     for (int i = 0; i < N_TW; ++i) {
         const bool image_branch = (i >= 16 && i < 24) || i >= 32;             // mw_w/b (aux_merge_weight_block), conv_w/b (aux_block_s*)
-        if (weights[i].defined() && (views || !image_branch)) gw[i] = at::empty_like(weights[i]);
+        const bool have = t.views || !image_branch;
+        gw[i] = have ? at::empty_like(weights[i]) : at::empty({0}, weights[i].options());
+        if (have) gw_ptr[i] = gw[i];
     }
-    hnr_train_cloud cl{fptr(in[I_XYZ], "xyz"), fptr(in[I_EMB], "emb"), fptr(in[I_CONF], "conf"), fptr(in[I_DIR], "dir"), fptr(in[I_COLOR], "color")};
-    hnr_train_weights w, wg;
-    fill_train_weights(w, weights);
-    fill_train_weights(wg, gw);
-    hnr_render_camera cam{fptr(in[I_CAMPOS], "campos"), fptr(in[I_CAMROT], "camrot"), fptr(in[I_RAYDIR], "raydir"), fptr(in[I_TMID], "tmid"), fptr(in[I_BG], "bg_color")};
-    hnr_train_views vw{nullptr, nullptr, nullptr, nullptr, nullptr};
-    if (views) vw = hnr_train_views{fptr(in[I_W2C], "w2c"), fptr(in[I_INTR], "intrinsic"), fptr(in[I_CAMN], "campos_nearest"), fptr(in[I_IMG], "images"),
-                                    in[I_FW].numel() > 0 ? fptr(in[I_FW], "frame_w") : nullptr};
-    hnr_render_outputs out = outputs_of(c.outs);
+    hnr_train_weights wg;
+    fill_train_weights(wg, gw_ptr);
+    hnr_render_outputs out = outputs_of(fwd.slice(0, N_OUT));
     hnr_train_cloud_grads cg{g[0].data_ptr<float>(), g[1].data_ptr<float>(), g[2].data_ptr<float>(), g[3].data_ptr<float>()};
     const Tensor gc = g_col.contiguous();
     Tensor gcc;
     if (g_cc.has_value() && g_cc->defined()) gcc = g_cc->contiguous();
-    hnr_check(hnr_render_train_backward(&c.p, &cl, &w, &cam, views ? &vw : nullptr, c.wsp, c.nbytes, &out, fptr(gc, "grad coarse_raycolor"),
+    const int64_t nbytes = hnr_render_train_workspace_bytes(&t.p);
+    hnr_check(hnr_render_train_backward(&t.p, &t.cl, &t.w, &t.cam, t.views ? &t.vw : nullptr, aligned(ws), nbytes, &out, fptr(gc, "grad coarse_raycolor"),
                                         gcc.defined() ? fptr(gcc, "grad conf_coefficient") : nullptr, &cg, &wg, cur_stream(like)),
               "hnr_render_train_backward");
     g.insert(g.end(), gw.begin(), gw.end());
     return g;
 }
 
+std::vector<Tensor> call_fwd(int64_t grid, const OptList &in, at::TensorList weights, const OptT &drop_lut, const OptT &ray_drop, int64_t SR, at::IntArrayRef ks, double r2,
+                             double vz, int64_t rmu, int64_t order, double slope, int64_t cap)
+{
+    static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("hnr::render_train_fwd", "")
+                         .typed<std::vector<Tensor>(int64_t, const OptList &, at::TensorList, const OptT &, const OptT &, int64_t, at::IntArrayRef, double, double, int64_t,
+                                                    int64_t, double, int64_t)>();
+    return op.call(grid, in, weights, drop_lut, ray_drop, SR, ks, r2, vz, rmu, order, slope, cap);
+}
+std::vector<Tensor> call_bwd(const OptList &in, at::TensorList weights, at::TensorList fwd, const Tensor &g_col, const OptT &g_cc, int64_t SR, at::IntArrayRef ks, double r2,
+                             double vz, int64_t rmu, int64_t order, double slope, int64_t cap)
+{
+    static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("hnr::render_train_bwd", "")
+                         .typed<std::vector<Tensor>(const OptList &, at::TensorList, at::TensorList, const Tensor &, const OptT &, int64_t, at::IntArrayRef, double, double,
+                                                    int64_t, int64_t, double, int64_t)>();
+    return op.call(in, weights, fwd, g_col, g_cc, SR, ks, r2, vz, rmu, order, slope, cap);
+}
+
 struct RenderTrainFn : public torch::autograd::Function<RenderTrainFn> {
-    // args: grid, inputs (15), weights (44), drop_lut, ray_drop, scalars.  Differentiable outputs: coarse_raycolor [R,3], conf_coefficient [R,SR,K].
-    static torch::autograd::variable_list forward(torch::autograd::AutogradContext *ctx, int64_t grid, at::TensorList in, at::TensorList weights,
-                                                  OptT drop_lut, OptT ray_drop, int64_t SR, std::vector<int64_t> kernel_size, double radius2, double vsize_z,
-                                                  int64_t raydist_mode_unit, int64_t knn_order, double slope, int64_t cap_samples)
+    // tensor arguments first (15 inputs, 44 weights: the flat order backward() returns gradients in), then the rest
+    static torch::autograd::variable_list forward(torch::autograd::AutogradContext *ctx, at::TensorList in, at::TensorList weights, int64_t grid, OptT drop_lut, OptT ray_drop,
+                                                  int64_t SR, std::vector<int64_t> ks, double r2, double vz, int64_t rmu, int64_t order, double slope, int64_t cap)
     {
         at::AutoDispatchBelowADInplaceOrView guard;
-        std::vector<Tensor> ind(in.begin(), in.end()), wd(weights.begin(), weights.end());
-        for (auto &t : ind) if (t.defined()) t = t.detach();
-        for (auto &t : wd) if (t.defined()) t = t.detach();
-        // reference shapes ([1,N,32], [1,N,1], ...) -> the library's flat ones
-        const int64_t N = ind[I_XYZ].size(-2);
-        ind[I_XYZ] = ind[I_XYZ].reshape({N, 3}); ind[I_EMB] = ind[I_EMB].reshape({N, 32}); ind[I_CONF] = ind[I_CONF].reshape({N});
-        ind[I_DIR] = ind[I_DIR].reshape({N, 3}); ind[I_COLOR] = ind[I_COLOR].reshape({N, 3});
-        auto call = train_forward(grid, ind, wd, drop_lut, ray_drop, SR, kernel_size, radius2, vsize_z, raydist_mode_unit, knn_order, slope, cap_samples);
-        ctx->saved_data["call"] = c10::IValue::make_capsule(call);          // the step's workspace + outputs live until backward ran or the graph is freed
-        call->keep = ind;
-        call->keep.insert(call->keep.end(), wd.begin(), wd.end());
+        OptList in_l;
+        for (const Tensor &t : in) in_l.push_back((t.defined() && t.numel() > 0) ? std::optional<Tensor>(t.detach()) : std::optional<Tensor>());
+        std::vector<Tensor> wd;
+        for (const Tensor &t : weights) wd.push_back(t.detach());
+        std::vector<Tensor> outs = call_fwd(grid, in_l, wd, drop_lut, ray_drop, SR, ks, r2, vz, rmu, order, slope, cap);
+        std::vector<Tensor> save;
+        for (const Tensor &t : in) save.push_back(t);
+        for (const Tensor &t : weights) save.push_back(t);
+        for (const Tensor &t : outs) save.push_back(t);
+        ctx->save_for_backward(save);
+        ctx->saved_data["ks"] = ks; ctx->saved_data["SR"] = SR; ctx->saved_data["r2"] = r2; ctx->saved_data["vz"] = vz; ctx->saved_data["rmu"] = rmu;
+        ctx->saved_data["order"] = order; ctx->saved_data["slope"] = slope; ctx->saved_data["cap"] = cap;
         std::vector<int64_t> shp;
-        for (int i : {I_EMB, I_CONF, I_DIR, I_COLOR}) { auto s = in[i].sizes(); shp.push_back((int64_t)s.size()); shp.insert(shp.end(), s.begin(), s.end()); }
+        for (int i : {I_EMB, I_CONF, I_DIR, I_COLOR}) { auto sz = in[i].sizes(); shp.push_back((int64_t)sz.size()); shp.insert(shp.end(), sz.begin(), sz.end()); }
         ctx->saved_data["leaf_shapes"] = shp;
-        torch::autograd::variable_list out(call->outs.begin(), call->outs.end());
-        std::vector<Tensor> nd;
-        for (size_t i = 1; i < 12; ++i) nd.push_back(out[i]);                  // everything but raycolor (0) and conf_coefficient (12) is returned detached
+        torch::autograd::variable_list out(outs.begin(), outs.begin() + N_OUT);
+        std::vector<Tensor> nd(out.begin() + 1, out.begin() + 12);            // everything but raycolor (0) and conf_coefficient (12) is returned detached
         ctx->mark_non_differentiable(nd);
         return out;
     }
     static torch::autograd::variable_list backward(torch::autograd::AutogradContext *ctx, torch::autograd::variable_list go)
     {
-        TORCH_CHECK(ctx->saved_data["call"].isCapsule(), "hnr::render_train: backward called twice (the step's workspace is released after the first backward)");
-        auto call = c10::static_intrusive_pointer_cast<TrainCall>(ctx->saved_data["call"].toCapsule());
-        std::vector<Tensor> ind(call->keep.begin(), call->keep.begin() + N_IN), wd(call->keep.begin() + N_IN, call->keep.end());
-        Tensor g_col = go[0].defined() ? go[0] : at::zeros_like(call->outs[0]);
-        OptT g_cc = go[12].defined() ? OptT(go[12]) : OptT();
-        std::vector<Tensor> g = train_backward(*call, ind, wd, g_col, g_cc);
-        ctx->saved_data["call"] = (int64_t)0;                                  // releases the workspace
+        const auto saved = ctx->get_saved_variables();
+        TORCH_CHECK(saved.size() == N_IN + N_TW + N_OUT + 1, "hnr::render_train: saved state missing");
+        OptList in_l;
+        for (int i = 0; i < N_IN; ++i) in_l.push_back((saved[i].defined() && saved[i].numel() > 0) ? std::optional<Tensor>(saved[i].detach()) : std::optional<Tensor>());
+        std::vector<Tensor> wd, fwd;
+        for (int i = 0; i < N_TW; ++i) wd.push_back(saved[N_IN + i].detach());
+        for (int i = 0; i <= N_OUT; ++i) fwd.push_back(saved[N_IN + N_TW + i]);
+        at::AutoDispatchBelowADInplaceOrView guard;
+        const Tensor g_col = go[0].defined() ? go[0] : at::zeros_like(fwd[0]);
+        const OptT g_cc = go[12].defined() ? OptT(go[12]) : OptT();
+        std::vector<Tensor> g = call_bwd(in_l, wd, fwd, g_col, g_cc, ctx->saved_data["SR"].toInt(), ctx->saved_data["ks"].toIntVector(), ctx->saved_data["r2"].toDouble(),
+                                         ctx->saved_data["vz"].toDouble(), ctx->saved_data["rmu"].toInt(), ctx->saved_data["order"].toInt(), ctx->saved_data["slope"].toDouble(),
+                                         ctx->saved_data["cap"].toInt());
         auto shp = ctx->saved_data["leaf_shapes"].toIntVector();
         torch::autograd::variable_list res;
-        res.emplace_back();                                                     // grid
         size_t pos = 0;
         for (int i = 0; i < N_IN; ++i) {
             if (i >= I_EMB && i <= I_COLOR) {
                 const int64_t nd = shp[pos++];
-                std::vector<int64_t> s(shp.begin() + pos, shp.begin() + pos + nd); pos += nd;
-                res.push_back(g[i - I_EMB].reshape(s));
+                std::vector<int64_t> sz(shp.begin() + pos, shp.begin() + pos + nd); pos += nd;
+                res.push_back(g[i - I_EMB].reshape(sz));
             } else res.emplace_back();
         }
-        for (int i = 0; i < N_TW; ++i) res.push_back(g[4 + i]);
-        for (int i = 0; i < 10; ++i) res.emplace_back();                        // drop_lut, ray_drop, scalars
+        for (int i = 0; i < N_TW; ++i) res.push_back(g[4 + i].numel() > 0 ? g[4 + i] : Tensor());
+        for (int i = 0; i < 11; ++i) res.emplace_back();                        // grid, drop_lut, ray_drop, the scalars
         return res;
     }
 };
 
-std::vector<Tensor> unpack(const c10::List<std::optional<Tensor>> &l)
-{
-    std::vector<Tensor> v;
-    for (size_t i = 0; i < l.size(); ++i) { std::optional<Tensor> t = l.get(i); v.push_back(t.has_value() ? *t : Tensor()); }
-    // an absent optional input travels as an EMPTY tensor on the rays' device (the autograd node's input list must hold defined tensors)
-    TORCH_CHECK(v.size() == N_IN && v[I_RAYDIR].defined(), "hnr::render_train: 15 inputs expected, raydir among them");
-    for (auto &t : v) if (!t.defined()) t = at::empty({0}, v[I_RAYDIR].options().dtype(at::kFloat));
-    return v;
-}
-std::vector<Tensor> render_train_autograd(int64_t grid, const c10::List<std::optional<Tensor>> &in_l, c10::ArrayRef<Tensor> weights, const OptT &drop_lut, const OptT &ray_drop, int64_t SR,
+// an absent optional input travels through the autograd node as an EMPTY tensor on the rays' device (its input list must hold defined tensors)
+std::vector<Tensor> render_train_autograd(int64_t grid, const OptList &in_l, c10::ArrayRef<Tensor> weights, const OptT &drop_lut, const OptT &ray_drop, int64_t SR,
                                           at::IntArrayRef kernel_size, double radius2, double vsize_z, int64_t raydist_mode_unit, int64_t knn_order, double slope,
                                           int64_t cap_samples)
 {
-    const std::vector<Tensor> in = unpack(in_l);
-    return RenderTrainFn::apply(grid, at::TensorList(in), at::TensorList(weights), drop_lut, ray_drop, SR, kernel_size.vec(), radius2, vsize_z, raydist_mode_unit, knn_order,
-                                slope, cap_samples);
+    TORCH_CHECK(in_l.size() == N_IN && weights.size() == N_TW, "hnr::render_train: 15 inputs and 44 weights expected");
+    std::vector<Tensor> in;
+    for (size_t i = 0; i < in_l.size(); ++i) { std::optional<Tensor> t = in_l.get(i); in.push_back(t.has_value() ? *t : Tensor()); }
+    TORCH_CHECK(in[I_RAYDIR].defined(), "hnr::render_train: raydir is required");
+    for (auto &t : in) if (!t.defined()) t = at::empty({0}, in[I_RAYDIR].options().dtype(at::kFloat));
+    return RenderTrainFn::apply(at::TensorList(in), weights, grid, drop_lut, ray_drop, SR, kernel_size.vec(), radius2, vsize_z, raydist_mode_unit, knn_order, slope, cap_samples);
 }
 // no-grad / inference dispatch of the same op: the forward call alone (the workspace dies with the call)
-std::vector<Tensor> render_train_cuda(int64_t grid, const c10::List<std::optional<Tensor>> &in_l, c10::ArrayRef<Tensor> weights, const OptT &drop_lut, const OptT &ray_drop, int64_t SR,
-                                      at::IntArrayRef kernel_size, double radius2, double vsize_z, int64_t raydist_mode_unit, int64_t knn_order, double slope, int64_t cap_samples)
+std::vector<Tensor> render_train_nograd(int64_t grid, const OptList &in_l, c10::ArrayRef<Tensor> weights, const OptT &drop_lut, const OptT &ray_drop, int64_t SR,
+                                        at::IntArrayRef kernel_size, double radius2, double vsize_z, int64_t raydist_mode_unit, int64_t knn_order, double slope, int64_t cap_samples)
 {
-    std::vector<Tensor> ind = unpack(in_l);
-    const int64_t N = ind[I_XYZ].size(-2);
-    ind[I_XYZ] = ind[I_XYZ].reshape({N, 3}); ind[I_EMB] = ind[I_EMB].reshape({N, 32}); ind[I_CONF] = ind[I_CONF].reshape({N});
-    ind[I_DIR] = ind[I_DIR].reshape({N, 3}); ind[I_COLOR] = ind[I_COLOR].reshape({N, 3});
-    return train_forward(grid, ind, weights, drop_lut, ray_drop, SR, kernel_size, radius2, vsize_z, raydist_mode_unit, knn_order, slope, cap_samples)->outs;
+    std::vector<Tensor> outs = call_fwd(grid, in_l, weights, drop_lut, ray_drop, SR, kernel_size, radius2, vsize_z, raydist_mode_unit, knn_order, slope, cap_samples);
+    outs.pop_back();
+    return outs;
 }
 
 }  // namespace
@@ -345,17 +391,23 @@ TORCH_LIBRARY(hnr, m)
           "int K, int[] kernel_size, float radius2, float vsize_z, int raydist_mode_unit, int knn_order, float slope, int cap_samples) -> Tensor[]");
     m.def("render_train(int grid, Tensor?[] inputs, Tensor[] weights, Tensor? drop_lut, Tensor? ray_drop, int SR, int[] kernel_size, float radius2, float vsize_z, "
           "int raydist_mode_unit, int knn_order, float slope, int cap_samples) -> Tensor[]");
+    m.def("render_train_fwd(int grid, Tensor?[] inputs, Tensor[] weights, Tensor? drop_lut, Tensor? ray_drop, int SR, int[] kernel_size, float radius2, float vsize_z, "
+          "int raydist_mode_unit, int knn_order, float slope, int cap_samples) -> Tensor[]");
+    m.def("render_train_bwd(Tensor?[] inputs, Tensor[] weights, Tensor[] fwd, Tensor g_raycolor, Tensor? g_conf_coefficient, int SR, int[] kernel_size, float radius2, "
+          "float vsize_z, int raydist_mode_unit, int knn_order, float slope, int cap_samples) -> Tensor[]");
 }
 TORCH_LIBRARY_IMPL(hnr, CompositeExplicitAutograd, m)
 {
     m.impl("grid_free", &grid_free);
+    m.impl("render_train", &render_train_nograd);       // below autograd: the forward op alone (redispatches: CUDA kernel or shape function)
 }
 TORCH_LIBRARY_IMPL(hnr, CUDA, m)
 {
     m.impl("grid_build", &grid_build);
     m.impl("march_query", &march_query);
     m.impl("render_forward", &render_forward);
-    m.impl("render_train", &render_train_cuda);
+    m.impl("render_train_fwd", &render_train_fwd);
+    m.impl("render_train_bwd", &render_train_bwd);
 }
 TORCH_LIBRARY_IMPL(hnr, Autograd, m)
 {

@@ -34,14 +34,75 @@ TRAIN_OUTPUTS = ("coarse_raycolor", "coarse_point_opacity", "coarse_is_backgroun
                  "ray_nsamp", "counts", "status", "weight", "conf_coefficient")
 
 
+NCOUNTS = _lib.NCOUNTS
+
+
+def _register_fakes():
+    """Shape functions ("fake" / meta kernels) of the tensor-returning ops: what torch.compile, torch.export and FakeTensorMode need to trace through
+    them without running a kernel.  Output shapes and dtypes are those of the C++ implementations (hnr_torch.cpp)."""
+    f32, i32 = torch.float32, torch.int32
+
+    @torch.library.register_fake("hnr::march_query")
+    def _(grid, campos, raydir, tmid, SR, K, radius2, kernel_size, pad, knn_order):
+        R, e = raydir.shape[0], raydir.new_empty
+        return (e((R, SR, K), dtype=i32), e((R, SR, 3), dtype=f32), e((R,), dtype=i32), e((R,), dtype=torch.int8), e((NCOUNTS,), dtype=torch.int64))
+
+    @torch.library.register_fake("hnr::render_forward")
+    def _(grid, xyz, conf, dir, color, point_table, point_records, packed, campos, camrot, raydir, tmid, bg_color, w2c, intrinsic, campos_nearest, featmap,
+          frame_w, SR, K, kernel_size, radius2, vsize_z, raydist_mode_unit, knn_order, slope, cap_samples):
+        R, e = raydir.shape[0], raydir.new_empty
+        return [e((R, 3), dtype=f32), e((R, SR), dtype=f32), e((R,), dtype=f32), e((R,), dtype=torch.int8), e((R, SR, 4), dtype=f32), e((R, SR, K), dtype=i32),
+                e((R, SR, 3), dtype=f32), e((R,), dtype=i32), e((NCOUNTS,), dtype=torch.int64), e((2,), dtype=i32)]
+
+    def train_outs(inputs, SR):
+        raydir = inputs[7]
+        R, K, e = raydir.shape[0], 8, raydir.new_empty
+        return [e((R, 3), dtype=f32), e((R, SR), dtype=f32), e((R,), dtype=f32), e((R, SR), dtype=f32), e((R,), dtype=torch.int8), e((R, SR, 4), dtype=f32),
+                e((R, SR, K), dtype=i32), e((R, SR, 3), dtype=f32), e((R,), dtype=i32), e((NCOUNTS,), dtype=torch.int64), e((2,), dtype=i32),
+                e((R, SR, K), dtype=f32), e((R, SR, K), dtype=f32)]
+
+    @torch.library.register_fake("hnr::render_train")
+    def _(grid, inputs, weights, drop_lut, ray_drop, SR, kernel_size, radius2, vsize_z, raydist_mode_unit, knn_order, slope, cap_samples):
+        return train_outs(inputs, SR)
+
+    @torch.library.register_fake("hnr::render_train_fwd")
+    def _(grid, inputs, weights, drop_lut, ray_drop, SR, kernel_size, radius2, vsize_z, raydist_mode_unit, knn_order, slope, cap_samples):
+        import ctypes
+        raydir, tmid, img = inputs[7], inputs[8], inputs[13]
+        prm = _lib.TrainParams()                                # the workspace size is a host-side function of the shapes (no kernel runs)
+        prm.R, prm.SR, prm.K, prm.D = int(raydir.shape[0]), int(SR), 8, int(tmid.shape[-1])
+        prm.tmid_stride = 0 if tmid.dim() == 1 else int(tmid.shape[1])
+        if img is not None and img.numel() > 0:
+            prm.V, prm.H, prm.W = int(img.shape[0]), int(img.shape[1]), int(img.shape[2])
+        for i in range(3):
+            prm.kernel_size[i] = int(kernel_size[i])
+        prm.radius2, prm.vsize_z, prm.raydist_mode_unit = float(radius2), float(vsize_z), int(raydist_mode_unit)
+        prm.knn_order, prm.slope = int(knn_order), float(slope)
+        prm.n_points = int(inputs[0].shape[-2])
+        prm.cap_samples = int(cap_samples) if cap_samples > 0 else prm.R * prm.SR
+        nbytes = int(_lib.lib().hnr_render_train_workspace_bytes(ctypes.byref(prm)))
+        if nbytes < 0:
+            raise HnrError("hnr_render_train_workspace_bytes: %s" % _lib.lib().hnr_last_error().decode("utf-8", "replace"))
+        return train_outs(inputs, SR) + [raydir.new_empty((nbytes + 256,), dtype=torch.uint8)]
+
+    @torch.library.register_fake("hnr::render_train_bwd")
+    def _(inputs, weights, fwd, g_raycolor, g_conf_coefficient, SR, kernel_size, radius2, vsize_z, raydist_mode_unit, knn_order, slope, cap_samples):
+        N, e, img = int(inputs[0].shape[-2]), inputs[7].new_empty, inputs[13]
+        views = img is not None and img.numel() > 0
+        image_branch = lambda i: (16 <= i < 24) or i >= 32
+        return [e((N, 32), dtype=f32), e((N,), dtype=f32), e((N, 3), dtype=f32), e((N, 3), dtype=f32)] + \
+               [torch.empty_like(w) if (views or not image_branch(i)) else w.new_empty((0,)) for i, w in enumerate(weights)]
+
+
 def load():
-    """Registers torch.ops.hnr (once).  libhnr_torch.so links libhnr_hip.so next to it."""
+    """Registers torch.ops.hnr (once), with shape functions for tracing.  libhnr_torch.so links libhnr_hip.so next to it."""
     global _loaded
     if not _loaded:
         if not os.path.exists(LIB_PATH):
             raise HnrError("%s is missing: build it with `make -C hybridneuralrendering_amd/csrc` (__graft_entry__.build())" % LIB_PATH)
         _lib.lib()                                         # the ctypes handle first: both bindings share ONE loaded libhnr_hip.so
         torch.ops.load_library(LIB_PATH)
+        _register_fakes()
         _loaded = True
     return torch.ops.hnr
 

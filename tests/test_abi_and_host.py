@@ -537,3 +537,33 @@ def test_torch_library_ops_load_and_carry_schemas():
     with pytest.raises((RuntimeError, NotImplementedError)):
         ops.grid_build(torch.zeros(4, 3), [0., 0., 0.], [1., 1., 1.], [2, 2, 2], [3, 3, 3], 4, 10)
     assert len(torch_ops.TRAIN_WEIGHT_NAMES) == 44 and len(set(torch_ops.TRAIN_WEIGHT_NAMES)) == 44
+    assert str(ops.render_train_fwd.default._schema).endswith("-> Tensor[]") and str(ops.render_train_bwd.default._schema).endswith("-> Tensor[]")
+
+
+def test_torch_library_ops_trace_with_fake_tensors():
+    """The tensor-returning ops carry shape functions (torch_ops._register_fakes): under FakeTensorMode -- what torch.compile / torch.export trace with --
+    they return tensors of the right shapes and dtypes without a kernel (or a GPU), and hnr::render_train's outputs are attached to the autograd graph
+    through the C++ autograd function, which redispatches to hnr::render_train_fwd instead of calling the library itself."""
+    import torch
+    from torch._subclasses import FakeTensorMode
+    from hybridneuralrendering_amd import torch_ops
+    ops = torch_ops.load()
+    with FakeTensorMode():
+        c = lambda *s, dt=torch.float32: torch.empty(s, device="cuda", dtype=dt)
+        R, SR, K, N = 100, 24, 8, 500
+        out = ops.march_query(0, c(3), c(R, 3), c(400), SR, K, 0.001, [3, 3, 3], True, 0)
+        assert [tuple(o.shape) for o in out] == [(R, SR, K), (R, SR, 3), (R,), (R,), (9,)] and out[0].dtype == torch.int32 and out[3].dtype == torch.int8
+        packed = [c(10, dt=torch.uint8)] * 4 + [c(64), c(1), c(3, 128), c(3)]
+        out = ops.render_forward(0, c(N, 3), c(N), c(N, 3), c(N, 3), c(N, 256), None, packed, c(3), c(3, 3), c(R, 3), c(400), c(3), None, None, None, None,
+                                 None, SR, K, [3, 3, 3], 0.001, 0.008, 1, 0, 0.01, 0)
+        assert [tuple(o.shape) for o in out] == [(R, 3), (R, SR), (R,), (R,), (R, SR, 4), (R, SR, K), (R, SR, 3), (R,), (9,), (2,)]
+        emb = c(1, N, 32).requires_grad_(True)
+        ins = [c(N, 3), emb, c(1, N, 1), c(1, N, 3), c(1, N, 3), c(3), c(3, 3), c(R, 3), c(R, 400), c(3), c(4, 4, 4), c(3, 3), c(4, 3), c(4, 48, 64, 3), None]
+        ws = [c(4, 4).requires_grad_(True) for _ in range(44)]
+        out = ops.render_train(0, ins, ws, None, None, SR, [3, 3, 3], 0.001, 0.008, 1, 0, 0.01, 0)
+        assert len(out) == 13 and tuple(out[0].shape) == (R, 3) and tuple(out[12].shape) == (R, SR, K)
+        assert out[0].requires_grad and out[12].requires_grad and not out[5].requires_grad and out[0].grad_fn is not None
+        fwd = ops.render_train_fwd(0, ins, ws, None, None, SR, [3, 3, 3], 0.001, 0.008, 1, 0, 0.01, 0)
+        assert len(fwd) == 14 and fwd[13].dtype == torch.uint8 and fwd[13].numel() > 1 << 20          # the step's workspace: sized by the library
+        g = ops.render_train_bwd(ins, ws, fwd, c(R, 3), None, SR, [3, 3, 3], 0.001, 0.008, 1, 0, 0.01, 0)
+        assert len(g) == 48 and tuple(g[0].shape) == (N, 32) and tuple(g[4].shape) == (4, 4)

@@ -129,3 +129,34 @@ def test_render_train_op_has_the_backward_registered_and_equals_the_ctypes_autog
     ref = d["grad"]["neural_points.points_embeding"].numpy()
     err = np.abs(l2[0].grad.cpu().numpy().reshape(ref.shape) - ref).max() / np.abs(ref).max()
     assert err < 1.5e-3, err
+
+
+def test_render_train_op_traces_forward_and_backward_without_running_a_kernel():
+    """FakeTensorMode through hnr::render_train and its backward: the autograd formula is made of dispatcher ops with shape functions
+    (render_train_fwd / render_train_bwd), so the whole step is traceable; torch.compile(backend="eager", fullgraph=True) captures a function
+    that calls the op without a graph break and returns the bits of the eager call."""
+    from torch._subclasses import FakeTensorMode
+    from hybridneuralrendering_amd import torch_ops
+    ops = torch_ops.load()
+    with FakeTensorMode():
+        c = lambda *s, dt=torch.float32: torch.empty(s, device="cuda", dtype=dt)
+        R, SR, N = 64, 24, 300
+        emb = c(1, N, 32).requires_grad_(True)
+        ins = [c(N, 3), emb, c(1, N, 1), c(1, N, 3), c(1, N, 3), c(3), c(3, 3), c(R, 3), c(R, 400), c(3), None, None, None, None, None]
+        ws = [c(4, 4).requires_grad_(True) for _ in range(44)]
+        out = ops.render_train(0, ins, ws, None, None, SR, [3, 3, 3], 0.001, 0.008, 1, 0, 0.01, 0)
+        (out[0].sum() + out[12].sum()).backward()
+        assert tuple(emb.grad.shape) == (1, N, 32) and ws[0].grad.shape == (4, 4) and ws[20].grad is None      # (no views: no image-branch gradient)
+    d, ti, opt, agg, cloud, rnd = _render_setup("scannet_small")
+    near, far = d["near_far"]
+    grid, hp = rnd.querier._grid_for(cloud.xyz[None])
+    tmid = rnd.querier._tmid_for(float(near), float(far), opt.z_depth_dim, ti["raydir"].shape[1], cloud.xyz.device)
+    h = torch_ops._handle(grid)
+    args = (ti["campos"][0].reshape(3), ti["raydir"][0], tmid, int(opt.SR), int(opt.K), float(np.float32(hp[0] ** 2)), [int(k) for k in opt.kernel_size], True, 0)
+
+    def f(campos, raydir, tm):
+        pidx, loc, nsamp, mask, counts = torch.ops.hnr.march_query(h, campos, raydir, tm, args[3], args[4], args[5], args[6], args[7], args[8])
+        return loc * 2.0, mask
+    want = f(args[0], args[1], args[2])
+    got = torch.compile(f, backend="eager", fullgraph=True)(args[0], args[1], args[2])
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
