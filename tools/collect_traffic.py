@@ -1,6 +1,6 @@
-"""Summarise the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py (tools/run_traffic.sh) into profiles/<tag>_traffic.json (tag = second argument, default r04).
+"""Summarise the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py (tools/gpu_job.sh <tag> traffic) into profiles/<tag>_traffic.json (tag = second argument, default r04).
 
-    bash tools/run_traffic.sh                      # on the GPU box: writes gpurun_out/traffic5/{pmc_FETCH_SIZE,pmc_WRITE_SIZE,stats}
+    bash tools/gpu_job.sh <tag> traffic      # on the GPU box: writes gpurun_out/<tag>/{pmc_FETCH_SIZE,pmc_WRITE_SIZE,stats}
     python tools/collect_traffic.py gpurun_out/traffic5
 """
 import collections
@@ -35,7 +35,7 @@ for k, fs in out["FETCH_SIZE"].items():
     kern[k] = dict(launches=len(f2), fetch_bytes_raw=raw, fetch_bytes_corrected=2 * raw, write_bytes=wr, hbm_bytes=2 * raw + wr)
     print("%-55s n=%2d fetch x2 %9.1f MB  write %9.1f MB" % (k[:55], len(f2), 2 * raw / 1e6, wr / 1e6))
 note = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-train-leg` on MI355X "
-        "(tools/run_traffic.sh); per-launch averages over the LARGE launches of each kernel name; FETCH_SIZE doubled per MI355X_MICROARCH.md "
+        "(tools/gpu_job.sh <tag> traffic); per-launch averages over the LARGE launches of each kernel name; FETCH_SIZE doubled per MI355X_MICROARCH.md "
         "(gfx950 tallies 128-B requests as 64 B on wide coalesced reads; calibrated in round 1 on ksum_kernel: 12.4 GB raw vs 24.3 GB of rows actually read). "
         "chain_ws_kernel<0> = the fused per-neighbour chain (one launch per frame); its weight image (848 KiB) is re-read by every workgroup tile from L2, "
         "which these memory-side counters do not see.")
