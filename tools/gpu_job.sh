@@ -7,6 +7,7 @@
 #   stats                  rocprofv3 --kernel-trace --stats of a 4-step frame-only bench  -> bench_kernel_stats.csv
 #   traffic                FETCH_SIZE / WRITE_SIZE passes (separate runs)                 -> tools/collect_traffic.py <tag>
 #   pmc                    SQ / GRBM counter groups (separate runs, no other tracing)     -> tools/collect_pmc.py <tag>
+#   train_traffic          FETCH_SIZE / WRITE_SIZE passes over tools/probe_train.py       -> tools/collect_train_traffic.py <tag>
 #   train_stats            kernel stats of tools/probe_train.py
 #   py:<script and args>   python3 <script ...> with stdout+stderr in <script>.txt
 # PMC passes never combine --pmc with sys/hip/hsa tracing (gpurun refuses that), and the profiled program is python3 itself.
@@ -44,6 +45,12 @@ for job in "$@"; do
         cp /tmp/pc$i/*counter_collection.csv "$O/pmc_g$i.csv" 2>/dev/null || tail -5 /tmp/pc$i.log
       done
       python3 tools/collect_pmc.py "gpurun_out/$TAG" "${TAG%%_*}";;
+    train_traffic)
+      for c in FETCH_SIZE WRITE_SIZE; do
+        (cd /tmp && rm -rf /tmp/pmct_$c && timeout 420 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmct_$c -o p -- python3 $G/tools/probe_train.py --steps 4 > /tmp/pmct_$c.log 2>&1); echo "train $c rc=$?"
+        mkdir -p "$O/train/pmc_$c/x"; cp /tmp/pmct_$c/*counter_collection.csv "$O/train/pmc_$c/x/" 2>/dev/null
+      done
+      python3 tools/collect_train_traffic.py "gpurun_out/$TAG/train" "${TAG%%_*}" | tail -8;;
     train_stats)
       (cd /tmp && rm -rf /tmp/stt && timeout 420 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/stt -o s -- python3 $G/tools/probe_train.py --steps 10 > "$O/probe_train.json" 2>/dev/null)
       cp /tmp/stt/*kernel_stats.csv "$O/train_kernel_stats.csv" 2>/dev/null;;
