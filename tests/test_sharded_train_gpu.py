@@ -187,7 +187,7 @@ def _run_c5(tmp_path, backend, port):
     script = tmp_path / "w5.py"
     # 2-rank gradients == 1-rank gradients: identical per-row arithmetic, different summation order of the per-point / per-weight sums and another
     # power-of-two operand scale in the weight-gradient GEMMs (one per batch) -- fp32-rounding class, far below the tolerance against the reference
-    script.write_text(_WORKER_C5.replace("WTOL", "2e-4").replace("PTOL", "2e-4"))
+    script.write_text(_WORKER_C5.replace("WTOL", "2e-5").replace("PTOL", "2e-5"))       # measured: weights 1.2e-6, points 3.1e-7 of max
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", HNR_TEST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
              for r in range(2)]
