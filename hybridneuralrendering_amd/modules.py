@@ -95,9 +95,11 @@ class NeuralPoints(nn.Module):
         if getattr(opt, "wcoord_query", 1) <= 0:
             raise HnrError("only the world-coordinate querier (wcoord_query=1) is implemented; no shipped script uses the other")
         if getattr(opt, "xyz_grad", 0) > 0:
-            # the reference differentiates through sampled_xyz / dists (neural_points.py:132-138); the HIP backward carries no
-            # position gradient, and an optimiser that silently never moves xyz would be a different training run
-            raise HnrError("xyz_grad > 0 is not implemented (no shipped script sets it): the HIP backward has no gradient w.r.t. point positions")
+            # the reference cannot run this either: with xyz requiring grad its query_points calls .cpu().numpy() on the
+            # point bounds (query_point_indices_worldcoords.py:67, reached from neural_points.py:568) and raises a
+            # RuntimeError on the first ray batch (reproduced with the imported reference).  Raise up front instead.
+            raise HnrError("xyz_grad > 0 is not supported: the reference's world-coordinate querier raises on the first query with it "
+                           "(numpy() on a tensor that requires grad), and the HIP backward carries no position gradient")
         fresh_conf = False
         if getattr(opt, "load_points", 0) == 1:
             saved = torch.load(checkpoint, map_location=device) if checkpoint else None

@@ -71,6 +71,12 @@ def test_unsupported_options_raise():
                  ("num_feat_freqs", 0), ("mixup_mode", "full"), ("act_type", "ReLU"), ("tradition_attention", 1)):
         with pytest.raises(HnrError):
             check_opt(scenes.default_opt(**{k: v}))
+    # position gradients: the reference's own querier raises on the first query (numpy() on a grad tensor), so ours
+    # refuses at construction; same for the perspective querier, which no shipped script selects
+    from hybridneuralrendering_amd.modules import NeuralPoints
+    for k, v in (("xyz_grad", 1), ("wcoord_query", 0)):
+        with pytest.raises(HnrError):
+            NeuralPoints(32, 8, scenes.default_opt(**{k: v}), "cpu")
     agg = PointAggregator(scenes.default_opt())
     names = {k: tuple(v.shape) for k, v in agg.state_dict().items()}
     # checkpoint compatibility: names and shapes of the reference's aggregator
