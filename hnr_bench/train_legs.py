@@ -263,6 +263,7 @@ def train_leg(args, sc, opt, agg, cloud, rnd, cam, dev, steps=20, warmup=3):
         t0 = time.perf_counter()
         for i in range(steps):
             out = one(evs[i])
+        host_dt = (time.perf_counter() - t0) / steps          # the host's share: Python + ctypes + ~200 launches, no wait
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
         gpu_ms = sum(e[0].elapsed_time(e[1]) for e in evs) / steps
@@ -355,7 +356,7 @@ def train_leg(args, sc, opt, agg, cloud, rnd, cam, dev, steps=20, warmup=3):
                            "%.3f ms at the 2.5 PFLOP/s peak, the operand stream %.3f ms at 8 TB/s: HBM is the nearer "
                            "roof" % (issued / 2.5e15 * 1e3, M8 * 2048.0 / 8e12 * 1e3)) if M8 > 0 else None
         return dict(workload="C3: 56x56 = %d rays, fwd (train mode) + bwd, shipped loss" % raydir.shape[0],
-                    ms_per_step=round(dt * 1e3, 3),
+                    ms_per_step=round(dt * 1e3, 3), host_ms_per_step=round(host_dt * 1e3, 3),
                     captured_ms_per_step=captured_ms, captured_form=graph_note, rays_per_s=round(raydir.shape[0] / dt,
                             1), fwd_ms=round(fwd, 3), loss_bwd_ms=round(bwd, 3),
                     neighbour_rows=int(c[3]), valid_samples=int(c[6]), steps=steps, entry="hnr_render_train_forward + "

@@ -184,6 +184,7 @@ SIGNATURES = {
                             ctypes.POINTER(_P), ctypes.POINTER(_P), _P]),
     "hnr_h2lin": (_I, [_P, _I, ctypes.c_int64, _P, _I, ctypes.c_int64, _P, _I, _I, _I, _I, _F, _P, _I, _P, _I, _P, _P]),
     "hnr_h2wgrad_scratch_bytes": (ctypes.c_int64, [_I, _I]),
+    "hnr_h2lin_dgrad_bits": (_I, [_P, _I, ctypes.c_int64, _P, _P, _I, _I, _F, _P, _P, _I, _P, _P]),
     "hnr_h2wgrad": (_I, [_P, _I, _P, _I, ctypes.c_int64, _P, _I, ctypes.c_int64, _I, _I, _P, _P, _P, _I, _P, _I, _P, _P]),
     "hnr_absmax": (_I, [_P, _I, ctypes.c_int64, _P, _I, ctypes.c_int64, _I, _P, _P]),
     "hnr_point_grad_pack": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P]),

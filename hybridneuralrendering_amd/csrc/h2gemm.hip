@@ -775,14 +775,28 @@ extern "C" int hnr_h2lin_pack(int n_jobs, const float *const *d_W, const int64_t
 namespace hnr {
 int h2lin_launch(const float *d_A, int lda, int64_t M_cap, const int64_t *d_m, int n_seg, int64_t seg_stride, const void *d_packed, int N, int K, int mode,
                  int act, float slope, const float *d_side, int ld_side, const uint32_t *d_side_bits, float *d_C, int ldc, uint32_t *d_absmax, void *stream);
+int launch_h2lin_ws(const float *d_dZ, int ldz, int64_t M_cap, const int64_t *d_m, const void *d_packed, float slope, const uint32_t *d_side_bits, float *d_C, int ldc,
+                    uint32_t *d_absmax, void *stream);                          // csrc/h2lin_ws.hip
 // dX = (dZ W) * LeakyReLU'(forward activation) with the activation's signs as the chain kernels' bit words (csrc/chain_ws.hip, training form)
 int h2lin_dgrad_bits(const float *d_dZ, int ldz, int64_t M_cap, const int64_t *d_m, const void *d_packed, int N, int K, float slope, const uint32_t *d_side_bits,
                      float *d_C, int ldc, uint32_t *d_absmax, void *stream)
 {
     if (!d_side_bits || N != 256 || (M_cap & 31)) { set_error("h2lin_dgrad_bits: needs the bit words, N = 256 and whole 32-row tiles"); return HNR_ERR_BADARG; }
+    // K = 256: the weight-stationary kernel (csrc/h2lin_ws.hip; bit-identical results).  HNR_H2LIN_WS=0: the streaming kernel below (A/B timing)
+    static int use_ws = -1;
+    if (use_ws < 0) { const char *e = getenv("HNR_H2LIN_WS"); use_ws = e ? atoi(e) : 1; }
+    if (use_ws && K == 256 && d_dZ && d_packed && d_C && ldz >= 256 && !(ldz & 3) && ldc >= 256 && !(ldc & 3) && !((uintptr_t)d_dZ & 15) && !((uintptr_t)d_C & 15) &&
+        !((uintptr_t)d_packed & 15) && slope > 0.f && slope < 1.f && (long long)M_cap * ldc * 4 < 0x7fffffffLL)
+        return launch_h2lin_ws(d_dZ, ldz, M_cap, d_m, d_packed, slope, d_side_bits, d_C, ldc, d_absmax, stream);
     return h2lin_launch(d_dZ, ldz, M_cap, d_m, 1, 0, d_packed, N, K, 1, 0, slope, nullptr, 0, d_side_bits, d_C, ldc, d_absmax, stream);
 }
 }  // namespace hnr
+
+extern "C" int hnr_h2lin_dgrad_bits(const float *d_dZ, int ldz, int64_t M_cap, const int64_t *d_m, const void *d_packed, int N, int K, float slope,
+                                    const uint32_t *d_side_bits, float *d_C, int ldc, uint32_t *d_absmax, void *stream)
+{
+    return hnr::h2lin_dgrad_bits(d_dZ, ldz, M_cap, d_m, d_packed, N, K, slope, d_side_bits, d_C, ldc, d_absmax, stream);
+}
 
 extern "C" int hnr_h2lin(const float *d_A, int lda, int64_t M_cap, const int64_t *d_m, int n_seg, int64_t seg_stride, const void *d_packed, int N, int K, int mode,
                          int act, float slope, const float *d_side, int ld_side, float *d_C, int ldc, uint32_t *d_absmax, void *stream)

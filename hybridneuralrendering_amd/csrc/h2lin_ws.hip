@@ -1,0 +1,301 @@
+// Weight-stationary input gradient of a 256 x 256 per-neighbour layer of the TRAINING step: dX = (dZ W) * LeakyReLU'(forward activation), the three
+// largest launches of hnr_render_train_backward (what torch autograd derives for block3.2 / block3.0 / block1.2 of PointAggregator.viewmlp,
+// /root/reference/models/aggregators/point_aggregators.py:948-975).  Same arithmetic as h2lin_kernel<16> (csrc/h2gemm.hip: per-row power-of-two scale, fp16
+// (h, m) planes, three v_mfma_f32_32x32x16_f16 per product in the order w_m x_h, w_h x_m, w_h x_h, k steps ascending, the same epilogue operations):
+// bit-identical results.  What differs is where the operands live and when things are issued:
+//   * h2lin_kernel streams the layer's 256 KiB of weight fragments from L2 for every 64-row tile -- its address unit is busy 0.61 of the time
+//     (profiles/README.md, round 5) and its phases (row loads + split | MFMA loop | epilogue) are serial per workgroup.  Here a wave loads its 64 output
+//     columns' fragments ONCE into 256 self-numbered AGPRs (as csrc/chain_ws.hip does per layer) and streams 32-row tiles past them;
+//   * the loop is software-pipelined by hand: iteration i multiplies tile i (96 MFMAs per wave) and, between those MFMAs, converts the rows of tile
+//     i + 1 (loaded two iterations earlier into one of two register sets), reloads that set with tile i + 3, and runs the epilogue of tile i - 1 out of
+//     the other accumulator set.  One workgroup barrier per tile.
+// The compiler must not touch AGPRs or scratch in this file (Makefile: build/h2lin_ws.checked).
+#include <stdio.h>
+#include <stdlib.h>
+#include <utility>
+
+#include "chain_defs.h"
+
+namespace hnr {
+
+constexpr int HW_S = 16;                                   // k steps (K = 256)
+constexpr int HW_SLOT = 2048 + 32;                         // LDS bytes of one k step of a tile's operand planes: [plane 2][64 lanes][16 B] + pad (as h2lin_kernel)
+constexpr int HW_BUF = HW_S * HW_SLOT;
+constexpr int HW_RINV = 2 * HW_BUF;                        // float [4][32]: 2^-k of the rows of tiles i - 1 .. i + 1 (index tile & 3)
+constexpr int HW_DUMP = HW_RINV + 4 * 32 * 4;              // float [4 waves][64]: where lanes 1..63 put the value lane 0 publishes
+constexpr int HW_LDS = HW_DUMP + 4 * 64 * 4 + 16;
+constexpr int HW_DESC = 256;                               // meta float: the layer's descale (HL_DESC of h2gemm.hip)
+
+struct H2LinWsArgs {
+    const float *A; int lda;
+    const long long *d_m; long long M_cap;
+    const char *wimg;
+    float slope;
+    const uint32_t *side_bits;
+    float *C; int ldc;
+    unsigned *absmax;
+};
+
+#ifdef HNR_WS_PROBE
+__device__ long long g_hw_probe[40];      // probe build (make EXTRA=-DHNR_WS_PROBE): cycles per k step of wave 0 of workgroup 0, [17] = iterations
+#define HW_STAMP(k_) do { const long long t_ = clock64(); tm_[k_] += t_ - tp_; tp_ = t_; } while (0)
+#else
+#define HW_STAMP(k_) do { } while (0)
+#endif
+
+namespace {
+
+#define HW_LOAD_FRAG(N_, rsrc_, voff_, soff_, IMM_) asm volatile("buffer_load_dwordx4 a[%2:%3], %0, %1, %4 offen offset:%5" :: "v"(voff_), "s"(rsrc_), "n"(N_), "n"((N_) + 3), "s"(soff_), "n"(IMM_))
+template <int N> __device__ __forceinline__ void hw_mfma(f32x16 &acc, const u32x4 &x)
+{
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, a[%2:%3], %1, %0" : "+v"(acc) : "v"(x), "n"(N), "n"(N + 3));
+}
+template <int N> __device__ __forceinline__ void hw_mfma_first(f32x16 &acc, const u32x4 &x)
+{
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, a[%2:%3], %1, 0" : "=&v"(acc) : "v"(x), "n"(N), "n"(N + 3));
+}
+template <int s> __device__ __forceinline__ void hw_load_step(__amdgpu_buffer_rsrc_t wsrd, int voff)
+{
+    int soff = s * CH_WSTEP;
+    HW_LOAD_FRAG(16 * s + 0, wsrd, voff, soff, 0);
+    HW_LOAD_FRAG(16 * s + 4, wsrd, voff, soff, 1024);
+    HW_LOAD_FRAG(16 * s + 8, wsrd, voff, soff, 2048);
+    HW_LOAD_FRAG(16 * s + 12, wsrd, voff, soff, 3072);
+}
+template <int... Ss> __device__ __forceinline__ void hw_load_all(__amdgpu_buffer_rsrc_t wsrd, int voff, std::integer_sequence<int, Ss...>) { (hw_load_step<Ss>(wsrd, voff), ...); }
+// In-lane half of the quad's 4 x 4 transpose of 16-byte pieces (cw_table_swap of csrc/chain_ws.hip): slot d <- register t ^ d, t = lane & 3 --
+// two rounds of exec-masked v_swap_b32.
+__device__ __forceinline__ void hw_quad_swap(float4 &r0, float4 &r1, float4 &r2, float4 &r3)
+{
+    unsigned long long keep;
+    asm volatile("s_mov_b64 %16, exec\n\ts_mov_b32 exec_lo, 0xaaaaaaaa\n\ts_mov_b32 exec_hi, 0xaaaaaaaa\n\t"
+                 "v_swap_b32 %0, %4\n\tv_swap_b32 %1, %5\n\tv_swap_b32 %2, %6\n\tv_swap_b32 %3, %7\n\t"
+                 "v_swap_b32 %8, %12\n\tv_swap_b32 %9, %13\n\tv_swap_b32 %10, %14\n\tv_swap_b32 %11, %15\n\t"
+                 "s_mov_b32 exec_lo, 0xcccccccc\n\ts_mov_b32 exec_hi, 0xcccccccc\n\t"
+                 "v_swap_b32 %0, %8\n\tv_swap_b32 %1, %9\n\tv_swap_b32 %2, %10\n\tv_swap_b32 %3, %11\n\t"
+                 "v_swap_b32 %4, %12\n\tv_swap_b32 %5, %13\n\tv_swap_b32 %6, %14\n\tv_swap_b32 %7, %15\n\t"
+                 "s_mov_b64 exec, %16\n\ts_nop 1"
+                 : "+v"(r0.x), "+v"(r0.y), "+v"(r0.z), "+v"(r0.w), "+v"(r1.x), "+v"(r1.y), "+v"(r1.z), "+v"(r1.w),
+                   "+v"(r2.x), "+v"(r2.y), "+v"(r2.z), "+v"(r2.w), "+v"(r3.x), "+v"(r3.y), "+v"(r3.z), "+v"(r3.w), "=&s"(keep));
+}
+template <class F, int... Is> __device__ __forceinline__ void hw_static_seq(F &&f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F> __device__ __forceinline__ void hw_static_for(F &&f) { hw_static_seq(f, std::make_integer_sequence<int, N>{}); }
+
+}  // namespace
+
+__global__ __launch_bounds__(256, 1) void h2lin_ws_kernel(H2LinWsArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5, j = lane & 31;
+    long long M = a.M_cap;
+    if (a.d_m) { const long long c = *a.d_m; if (c < M) M = c; }
+    const int n_tiles = (int)((M + 31) >> 5);
+    if ((int)blockIdx.x >= n_tiles) return;
+    const int n_my = (n_tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1;
+    const int last_tile = (int)blockIdx.x + (n_my - 1) * (int)gridDim.x;
+    asm volatile("" ::: "a255");                                           // the kernel owns all 256 AGPRs
+    // ---- this wave's weight fragments: (k step s, column tile c of the wave, plane p) -> a[16 s + 8 c + 4 p .. + 3]
+    {
+        const __amdgpu_buffer_rsrc_t wsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(a.wimg), 0, HW_S * CH_WSTEP, 0x00020000);
+        hw_load_all(wsrd, wave * 4096 + lane * 16, std::make_integer_sequence<int, HW_S>{});
+    }
+    const float dw = reinterpret_cast<const float *>(a.wimg + (size_t)HW_S * CH_WSTEP)[HW_DESC];
+    float *rinv_all = reinterpret_cast<float *>(lds + HW_RINV), *rinv_dump = reinterpret_cast<float *>(lds + HW_DUMP) + 64 * wave;
+    // tile of this workgroup's i-th iteration; past the end: the last one again (its results are not stored a second time)
+    auto tile_of = [&](int i) { const int t = (int)blockIdx.x + i * (int)gridDim.x; return t < n_tiles ? t : last_tile; };
+    // rows 8 wave .. + 7 of a tile, one row per instruction: lane l holds columns 4 l .. 4 l + 3.  Rows past M inside the last tile are read as they
+    // are (the operand has M_cap rows, a multiple of 32): every row of this product is independent of the others, theirs are neither stored nor counted
+    auto load_row = [&](int i, int r) -> float4 {
+        const float *base = a.A + ((size_t)tile_of(i) * 32 + 8 * wave + r) * (size_t)a.lda;      // uniform: scalar arithmetic
+        return *reinterpret_cast<const float4 *>(base + 4 * lane);
+    };
+    // lane-constant part of a row's plane addresses: k step lane >> 2, lane half (lane >> 1) & 1, elements 4 (lane & 1) ..
+    char *cv_base = lds + (lane >> 2) * HW_SLOT + ((lane >> 1) & 1) * 512 + (lane & 1) * 8 + wave * 128;
+    // A row's conversion in two STAGES of six pieces each (a piece = what is issued behind one MFMA): stage A: the row's maximum (butterfly over
+    // the 64 lanes as in h2lin_kernel with LPR = 64) -> its power-of-two scale; stage B: scale, fp16 split, the two plane stores, the reload of the
+    // register with the row of the tile two further on.  Stage B of row r runs one k step behind stage A: two independent dependency chains per piece.
+    float cm[2] = {0.f, 0.f}, csc[2] = {0.f, 0.f};
+    unsigned cph[2] = {0u, 0u}, cpm[2] = {0u, 0u};
+    auto conv_a = [&](const float4 &v, int r, int piece, int tile_i) __attribute__((always_inline)) {
+        float &m = cm[r & 1];
+        // m = max(m, m of the DPP source lane) as ONE instruction (the builtin form compiles to mov_dpp + canonicalise + max + a copy); lanes without a
+        // source / outside the row mask keep m.  s_nop 1: a DPP operand written by the previous VALU instruction needs two wait states.
+#define HW_MAX_DPP(ctrl_) asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 " ctrl_ : "+v"(m))
+        if (piece == 0) m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+        else if (piece == 1) { HW_MAX_DPP("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"); HW_MAX_DPP("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"); }
+        else if (piece == 2) { HW_MAX_DPP("row_half_mirror row_mask:0xf bank_mask:0xf"); HW_MAX_DPP("row_mirror row_mask:0xf bank_mask:0xf"); }
+        else if (piece == 3) { HW_MAX_DPP("row_bcast:15 row_mask:0xa bank_mask:0xf"); HW_MAX_DPP("row_bcast:31 row_mask:0xc bank_mask:0xf"); }
+#undef HW_MAX_DPP
+        else if (piece == 4) {
+            const int k = row_scale_exp(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 63)));
+            csc[r & 1] = pow2f(k);
+            m = pow2f(-k);
+        } else {
+            // lane 0 publishes the row's 2^-k; the other lanes write a dump word each (no exec-masked branch in the MFMA stream)
+            float *dst = lane == 0 ? rinv_all + (tile_i & 3) * 32 + 8 * wave + r : rinv_dump + lane;
+            *dst = m;
+        }
+    };
+    auto conv_b = [&](float4 &v, int r, int piece, int buf, int i_next) __attribute__((always_inline)) {
+        const float sc = csc[r & 1];
+        if (piece == 0) { v.x = __fmul_rn(v.x, sc); v.y = __fmul_rn(v.y, sc); v.z = __fmul_rn(v.z, sc); v.w = __fmul_rn(v.w, sc); }
+        else if (piece == 1) split2h(v.x, v.y, cph[0], cpm[0]);
+        else if (piece == 2) split2h(v.z, v.w, cph[1], cpm[1]);
+        else if (piece == 3) {
+            char *dst = cv_base + buf * HW_BUF + r * 16;
+            *reinterpret_cast<uint2 *>(dst) = make_uint2(cph[0], cph[1]);
+            *reinterpret_cast<uint2 *>(dst + 1024) = make_uint2(cpm[0], cpm[1]);
+        } else if (piece == 4) v = load_row(i_next, r);
+    };
+    float4 rows[2][8];
+    f32x16 acc[2][2];
+    float gmax = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { rows[0][r] = load_row(0, r); rows[1][r] = load_row(1, r); }
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[1][c][r] = 0.f;                    // (iteration 0 runs an epilogue over these)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // the weight fragments (loads the compiler does not know of) and the first rows
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+#pragma unroll
+        for (int pc = 0; pc < 6; ++pc) conv_a(rows[0][r], r, pc, 0);
+#pragma unroll
+        for (int pc = 0; pc < 6; ++pc) conv_b(rows[0][r], r, pc, 0, 2);
+    }
+    __syncthreads();
+
+    const int colb = 64 * wave + 16 * h;
+    const char *fr_base = lds + lane * 16;
+#ifdef HNR_WS_PROBE
+    long long tm_[18] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tp_ = clock64();
+#endif
+    unsigned bits_carry = a.side_bits[((size_t)tile_of(0) * 4 + wave) * 64 + lane];
+    float4 tb[4];
+    // the output rows through a buffer descriptor that ends with row M - 1: rows past M (and everything in iteration 0) fall outside and are dropped
+    const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(a.C, 0, (int)(M * a.ldc * 4), 0x00020000);
+    // Iteration i (PAR = i & 1): MFMAs of tile i from buffer PAR into acc[PAR]; between them: rows of tile i + 1 (register set PAR ^ 1) -> buffer PAR ^ 1,
+    // the set reloaded with tile i + 3, epilogue of tile i - 1 out of acc[PAR ^ 1].  i = n_my multiplies the last tile once more (nothing of it is stored).
+    auto body = [&](auto par_c, int i) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(par_c)::value, OTH = PAR ^ 1;
+        const char *fb = fr_base + PAR * HW_BUF;
+        // ---- the epilogue that runs in this iteration: tile i - 1, out of acc[OTH] (in place).  Its sign words were loaded one iteration ago.
+        const int tp = tile_of(i - 1 < 0 ? 0 : i - 1);
+        const bool live = i >= 1 && (long long)tp * 32 + j < M;             // rows past M (and iteration 0): scaled by 0 -- never the maximum -- and out of the store range
+        const unsigned bits = bits_carry;
+        bits_carry = a.side_bits[((size_t)tile_of(i) * 4 + wave) * 64 + lane];
+        const float inv = live ? __fmul_rn(rinv_all[((i - 1) & 3) * 32 + j], dw) : 0.f;
+        // byte offset of (row (j & ~3) of the tile, this lane half's 64 bytes of the wave's first column tile); iteration 0: out of the descriptor's range
+        const int st_base = i >= 1 ? ((tp * 32 + (j & ~3)) * a.ldc + colb) * 4 : (int)0x80000000;
+        const int t16 = (j & 3) * 16, ld4 = a.ldc * 4;
+        auto value = [&](int c, int vi) __attribute__((always_inline)) {
+            float v = fmaf(acc[OTH][c][vi], inv, 0.f);
+            v = __fmul_rn(v, ((bits >> (31 - (16 * c + vi))) & 1u) ? 1.f : a.slope);
+            acc[OTH][c][vi] = v;
+            gmax = fmaxf(gmax, fabsf(v));
+        };
+        // the sixteen values of (row j, column tile c) leave as four 16-B stores of 64 consecutive bytes per quad (csrc/chain_ws.hip, tr_group): straight
+        // from the accumulator layout a quad's lanes write four different rows -- one address-unit cycle per (quad, cache line), 64 per instruction
+        auto dppx = [&](float v, int x) __attribute__((always_inline)) -> float {      // the value of lane t ^ x of the quad (bit pattern moved: the builtin on ints)
+            const int b = __builtin_bit_cast(int, v);
+            const int r = x == 1 ? __builtin_amdgcn_update_dpp(0, b, 0xB1, 0xf, 0xf, false) : x == 2 ? __builtin_amdgcn_update_dpp(0, b, 0x4E, 0xf, 0xf, false)
+                                                                                             : __builtin_amdgcn_update_dpp(0, b, 0x1B, 0xf, 0xf, false);
+            return __builtin_bit_cast(float, r);
+        };
+        auto transpose = [&](int c, int sub) __attribute__((always_inline)) {
+            const f32x16 &o = acc[OTH][c];
+            if (sub == 0) { tb[0] = make_float4(o[0], o[1], o[2], o[3]); tb[1] = make_float4(dppx(o[4], 1), dppx(o[5], 1), dppx(o[6], 1), dppx(o[7], 1)); }
+            else if (sub == 1) { tb[2] = make_float4(dppx(o[8], 2), dppx(o[9], 2), dppx(o[10], 2), dppx(o[11], 2)); tb[3] = make_float4(dppx(o[12], 3), dppx(o[13], 3), dppx(o[14], 3), dppx(o[15], 3)); }
+            else if (sub == 2) hw_quad_swap(tb[0], tb[1], tb[2], tb[3]);
+            else {
+#pragma unroll
+                for (int r = 2 * (sub - 3); r < 2 * (sub - 3) + 2; ++r)
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(tb[r].x), __float_as_uint(tb[r].y), __float_as_uint(tb[r].z), __float_as_uint(tb[r].w)}, crs,
+                                                           st_base + r * ld4 + 128 * c + ((16 * r) ^ t16), 0, 0);
+            }
+        };
+        u32x4 xf[2][2];
+        xf[0][0] = *reinterpret_cast<const u32x4 *>(fb);
+        xf[0][1] = *reinterpret_cast<const u32x4 *>(fb + 1024);
+        hw_static_for<HW_S>([&](auto s_c) {
+            constexpr int s = decltype(s_c)::value, cur = s & 1, nxt = cur ^ 1;
+            if constexpr (s + 1 < HW_S) {
+                xf[nxt][0] = *reinterpret_cast<const u32x4 *>(fb + (s + 1) * HW_SLOT);
+                xf[nxt][1] = *reinterpret_cast<const u32x4 *>(fb + (s + 1) * HW_SLOT + 1024);
+            }
+            hw_static_for<6>([&](auto pc_c) {
+                constexpr int pc = decltype(pc_c)::value;
+                // smallest terms first (w_m x_h, w_h x_m, w_h x_h), the two accumulators alternating
+                constexpr int cc = pc & 1, term = pc >> 1, wp = term == 0 ? 1 : 0, xp = term == 1 ? 1 : 0;
+                if constexpr (s == 0 && term == 0) hw_mfma_first<16 * s + 8 * cc + 4 * wp>(acc[PAR][cc], xf[cur][xp]);
+                else hw_mfma<16 * s + 8 * cc + 4 * wp>(acc[PAR][cc], xf[cur][xp]);
+                // pieces behind this MFMA.  Conversion of tile i + 1: row s stage A, row s - 1 stage B (k steps 0..8).  Epilogue of tile i - 1: column tile 0's
+                // values two per k step (0..7, behind MFMAs 4, 5), column tile 1's four per k step (8..11); transposes + stores of tile 0 in k steps 8..10,
+                // of tile 1 in k step 12
+                if constexpr (s < 8) conv_a(rows[OTH][s], s, pc, i + 1);
+                if constexpr (s >= 1 && s <= 8) conv_b(rows[OTH][s - 1], s - 1, pc, OTH, i + 3);
+                if constexpr (s < 8 && pc >= 4) value(0, 2 * s + pc - 4);
+                if constexpr (s >= 8 && s < 12 && pc < 4) value(1, 4 * (s - 8) + pc);
+                if constexpr (s == 8 && pc >= 4) transpose(0, pc - 4);
+                if constexpr (s == 9 && pc >= 4) transpose(0, pc - 2);
+                if constexpr (s == 10 && pc == 4) transpose(0, 4);
+                if constexpr (s == 12 && pc < 5) transpose(1, pc);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            HW_STAMP(s);
+        });
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        HW_STAMP(16);
+#ifdef HNR_WS_PROBE
+        tm_[17] += 1;
+#endif
+    };
+    {
+        int i = 0;
+        for (; i + 1 <= n_my; i += 2) { body(std::integral_constant<int, 0>{}, i); body(std::integral_constant<int, 1>{}, i + 1); }
+        if (i <= n_my) body(std::integral_constant<int, 0>{}, i);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef HNR_WS_PROBE
+    if (blockIdx.x == 0 && tid == 0) for (int k = 0; k < 18; ++k) g_hw_probe[k] = tm_[k];
+#endif
+    if (a.absmax) {
+        for (int o = 32; o > 0; o >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, o));
+        float *s_m = reinterpret_cast<float *>(lds + HW_DUMP + 4 * 64 * 4);
+        if (lane == 0) s_m[wave] = gmax;
+        __syncthreads();
+        if (tid == 0) { gmax = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3])); if (gmax > 0.f) atomicMax(a.absmax, __float_as_uint(gmax)); }
+    }
+}
+
+// csrc/h2gemm.hip (h2lin_dgrad_bits) calls this for N = K = 256 when HNR_H2LIN_WS != 0
+int launch_h2lin_ws(const float *d_dZ, int ldz, int64_t M_cap, const int64_t *d_m, const void *d_packed, float slope, const uint32_t *d_side_bits, float *d_C, int ldc,
+                    uint32_t *d_absmax, void *stream)
+{
+    if (M_cap <= 0) return HNR_OK;
+    if ((long long)M_cap * ldc * 4 >= 0x7fffffffLL) { set_error("h2lin_ws: more than 2 GiB of output rows (32-bit store offsets)"); return HNR_ERR_BADARG; }
+    H2LinWsArgs a;
+    a.A = d_dZ; a.lda = ldz; a.d_m = reinterpret_cast<const long long *>(d_m); a.M_cap = M_cap; a.wimg = (const char *)d_packed; a.slope = slope;
+    a.side_bits = d_side_bits; a.C = d_C; a.ldc = ldc; a.absmax = d_absmax;
+    static PerDeviceOnce once;
+    if (once.first()) HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(h2lin_ws_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, HW_LDS));
+    const int64_t tiles = (M_cap + 31) / 32;
+    const int n_cu = device_num_cus(), grid = (int)(tiles < n_cu ? tiles : n_cu);
+    h2lin_ws_kernel<<<grid, 256, HW_LDS, (hipStream_t)stream>>>(a);
+    HNR_LAUNCH_CHECK();
+#ifdef HNR_WS_PROBE
+    if (getenv("HNR_WS_PROBE_PRINT")) {
+        long long hp[40];
+        if (hipDeviceSynchronize() == hipSuccess && hipMemcpyFromSymbol(hp, HIP_SYMBOL(g_hw_probe), sizeof(hp)) == hipSuccess && hp[17] > 0) {
+            fprintf(stderr, "h2lin_ws probe: %lld iterations; cycles per k step:", hp[17]);
+            long long tot = 0;
+            for (int k = 0; k < 17; ++k) { fprintf(stderr, " %lld", hp[k] / hp[17]); tot += hp[k]; }
+            fprintf(stderr, "  = %lld per tile\n", tot / hp[17]);
+        }
+    }
+#endif
+    return HNR_OK;
+}
+
+}  // namespace hnr

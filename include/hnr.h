@@ -542,6 +542,10 @@ int hnr_segment_sum_rows_csr(const float *d_A, int lda, const int32_t *d_row_lis
  *                    mode 1: C = (A W^T) * (side > 0 ? 1 : slope)   -- side [M, ld_side] is the stored forward activation: the input
  *                    gradient through a LeakyReLU.  K in {<= 48, <= 64, <= 128, <= 224, <= 256}.  d_absmax (optional): max |C| is
  *                    atomically max-ed into it as a bit pattern (the scale of a later hnr_h2wgrad).
+ *   hnr_h2lin_dgrad_bits   mode 1 of hnr_h2lin for the per-neighbour chain (N = 256, whole 32-row tiles: M_cap % 32 == 0): LeakyReLU' comes from the
+ *                    SIGN WORDS the training forward leaves (one word per (32-row tile, wave = 64-column group, lane): bit 31 - i = (value i of
+ *                    the lane's 32 columns 64 wave + 16 (lane >> 5) + {0..15, 32..47} of row (lane & 31) is > 0)) instead of the stored
+ *                    activation.  K = 256 runs the weight-stationary kernel (csrc/h2lin_ws.hip); results equal hnr_h2lin's bit for bit.
  *   hnr_h2wgrad      dW[N, K] (row stride lddw) = dZ[M, N]^T X[M, K], db[N] = column sums of dZ (d_db may be NULL); accumulate != 0 adds.
  *                    d_absmax_z / d_absmax_x: bit patterns of (an upper bound of) max |dZ|, max |X| (hnr_absmax or a producer's output).
  *                    N <= 256, K <= 287.  Deterministic (fixed-order partials, no atomics); d_scratch: hnr_h2wgrad_scratch_bytes(N, K).
@@ -551,6 +555,8 @@ int hnr_h2lin_pack(int n_jobs, const float *const *d_W, const int64_t *rs, const
                    const float *const *d_bias /*may be NULL*/, void *const *d_packed, void *stream);
 int hnr_h2lin(const float *d_A, int lda, int64_t M_cap, const int64_t *d_m, int n_seg, int64_t seg_stride, const void *d_packed, int N, int K, int mode,
               int act, float slope, const float *d_side, int ld_side, float *d_C, int ldc, uint32_t *d_absmax, void *stream);
+int hnr_h2lin_dgrad_bits(const float *d_dZ, int ldz, int64_t M_cap, const int64_t *d_m, const void *d_packed, int N, int K, float slope,
+                         const uint32_t *d_side_bits, float *d_C, int ldc, uint32_t *d_absmax, void *stream);
 int64_t hnr_h2wgrad_scratch_bytes(int N, int K);
 int hnr_h2wgrad(const float *d_dZ, int ldz, const float *d_X, int ldx, int64_t M_cap, const int64_t *d_m, int n_seg, int64_t seg_stride, int N, int K,
                 const uint32_t *d_absmax_z, const uint32_t *d_absmax_x, float *d_dW, int lddw, float *d_db, int accumulate,

@@ -79,6 +79,54 @@ def test_h2lin_matches_fp64(M, N, K, mode):
         assert gmax >= np.abs(got[:M, :N]).max() * (1 - 1e-6) and gmax <= np.abs(got[:M, :N]).max() * 1.0001 + 1e-30
 
 
+def _sign_words(side, M_cap):
+    """The chain kernels' sign words of an activation [M_cap, 256] (ChainArgs::hbits): word ((tile * 4 + wave) * 64 + lane), bit 31 - i = (value i of the
+    lane's 32 columns 64 wave + 16 (lane >> 5) + {0..15, 32..47} of row 32 tile + (lane & 31) is > 0)."""
+    pos = (side[:, :256] > 0).reshape(M_cap // 32, 32, 4, 2, 2, 16)           # tile, row j, wave, column tile c, lane half h, r
+    bits = np.zeros((M_cap // 32, 4, 2, 32), dtype=np.uint32)                  # tile, wave, h, j
+    for c in range(2):
+        for r in range(16):
+            bits |= np.transpose(pos[:, :, :, c, :, r], (0, 2, 3, 1)).astype(np.uint32) << np.uint32(31 - (16 * c + r))
+    return bits.reshape(-1).view(np.int32)
+
+
+@pytest.mark.parametrize("M_cap,M,K,lda,ldc", [(4096, 4001, 256, 256, 256), (8192, 8192, 256, 264, 264), (64, 33, 256, 256, 264), (32, 1, 256, 256, 256),
+                                               (2048, 2000, 224, 224, 256), (96, 96, 256, 256, 256)])
+def test_h2lin_dgrad_bits_matches_fp64_and_the_float_side_form(M_cap, M, K, lda, ldc):
+    """hnr_h2lin_dgrad_bits (K = 256: the weight-stationary kernel csrc/h2lin_ws.hip; other K: the streaming kernel reading sign words) = what torch autograd
+    computes for dX of a Linear behind a LeakyReLU whose output is known by its signs; equal BIT FOR BIT to hnr_h2lin mode 1 with the activation itself."""
+    dev = _dev()
+    L = _lib.lib()
+    g = torch.Generator(device="cpu").manual_seed(M_cap + M + K)
+    N = 256
+    A = torch.zeros((M_cap, lda))
+    A[:, :K] = torch.randn((M_cap, K), generator=g) * torch.exp(2.0 * torch.randn((M_cap, 1), generator=g))
+    W = torch.randn((K, N), generator=g) / np.sqrt(K)                          # the forward layer's weight [K outputs of the forward = our K inputs, N]
+    side = torch.randn((M_cap, ldc), generator=g)
+    Ad, sd = A.to(dev), side.to(dev)
+    img = pack([W.to(dev)], transposed=[True])[0]
+    bits = torch.from_numpy(_sign_words(side.numpy(), M_cap)).to(dev)
+    dm = torch.tensor([M], dtype=torch.int64, device=dev)
+    slope = 0.01
+    C1, C2 = torch.full((M_cap, ldc), 7.0, device=dev), torch.full((M_cap, ldc), 7.0, device=dev)
+    m1, m2 = torch.zeros(1, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
+    for _ in range(2):                                                         # (twice: the maximum word is a running maximum, the rows are rewritten)
+        _lib.check(L.hnr_h2lin_dgrad_bits(_lib.ptr(Ad), lda, M_cap, _lib.ptr(dm), _lib.ptr(img), N, K, slope, _lib.ptr(bits), _lib.ptr(C1), ldc, _lib.ptr(m1),
+                                          _lib.stream()), "hnr_h2lin_dgrad_bits")
+    _lib.check(L.hnr_h2lin(_lib.ptr(Ad), lda, M_cap, _lib.ptr(dm), 1, 0, _lib.ptr(img), N, K, 1, 0, slope, _lib.ptr(sd), ldc, _lib.ptr(C2), ldc, _lib.ptr(m2),
+                           _lib.stream()), "hnr_h2lin")
+    got = C1.cpu().numpy()
+    assert got.tobytes() == C2.cpu().numpy().tobytes() and m1.item() == m2.item()
+    assert (got[M:] == 7.0).all() and (got[:, N:] == 7.0).all(), "rows past *d_m / padding columns were written"
+    A64, W64 = A[:M, :K].numpy().astype(np.float64), W.numpy().astype(np.float64)
+    ref = (A64 @ W64) * np.where(side[:M, :N].numpy() > 0, 1.0, slope)
+    mag = np.abs(A64) @ np.abs(W64)
+    err = np.abs(got[:M, :N].astype(np.float64) - ref) / (mag + 1e-30)
+    assert err.max() < 4e-7, err.max()
+    gmax = float(np.frombuffer(np.int32(m1.item()).tobytes(), dtype=np.float32)[0])
+    assert gmax == np.abs(got[:M, :N]).max()
+
+
 @pytest.mark.parametrize("M,N,K", [(20000, 256, 256), (777, 256, 263), (3001, 256, 60), (999, 256, 224), (4096, 128, 280), (5000, 128, 128),
                                    (3333, 64, 48), (2500, 64, 64), (1200, 64, 128), (900, 45, 90), (31, 45, 45), (1, 256, 256)])
 def test_h2wgrad_matches_fp64(M, N, K):

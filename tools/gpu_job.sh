@@ -9,6 +9,7 @@
 #   pmc                    SQ / GRBM counter groups (separate runs, no other tracing)     -> tools/collect_pmc.py <tag>
 #   train_traffic          FETCH_SIZE / WRITE_SIZE passes over tools/probe_train.py       -> tools/collect_train_traffic.py <tag>
 #   train_stats            kernel stats of tools/probe_train.py
+#   train_timeline[:args]  per-launch timeline of the last step of tools/probe_train.py             -> train_timeline.txt
 #   py:<script and args>   python3 <script ...> with stdout+stderr in <script>.txt
 # PMC passes never combine --pmc with sys/hip/hsa tracing (gpurun refuses that), and the profiled program is python3 itself.
 cd "$GRAFT_REPO_ROOT" || exit 1
@@ -54,6 +55,9 @@ for job in "$@"; do
     train_stats)
       (cd /tmp && rm -rf /tmp/stt && timeout 420 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/stt -o s -- python3 $G/tools/probe_train.py --steps 10 > "$O/probe_train.json" 2>/dev/null)
       cp /tmp/stt/*kernel_stats.csv "$O/train_kernel_stats.csv" 2>/dev/null;;
+    train_timeline)
+      (cd /tmp && rm -rf /tmp/stl && timeout 420 rocprofv3 --kernel-trace --output-format csv -d /tmp/stl -o s -- python3 $G/tools/probe_train.py --steps 6 ${arg} > "$O/probe_train_tl.json" 2>/dev/null)
+      python3 tools/timeline.py /tmp/stl/*kernel_trace.csv "$O/train_timeline.txt" march_kernel 12 | tail -3;;
     py)
       f=$(echo "$arg" | awk '{print $1}'); timeout 1500 python3 $arg > "$O/$(basename "$f" .py).txt" 2>&1; echo "$f rc=$?"; tail -12 "$O/$(basename "$f" .py).txt";;
     *) echo "unknown job $job";;
