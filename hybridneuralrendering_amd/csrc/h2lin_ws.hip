@@ -21,10 +21,24 @@ namespace hnr {
 constexpr int HW_S = 16;                                   // k steps (K = 256)
 constexpr int HW_SLOT = 2048 + 32;                         // LDS bytes of one k step of a tile's operand planes: [plane 2][64 lanes][16 B] + pad (as h2lin_kernel)
 constexpr int HW_BUF = HW_S * HW_SLOT;
-constexpr int HW_RINV = 2 * HW_BUF;                        // float [4][32]: 2^-k of the rows of tiles i - 1 .. i + 1 (index tile & 3)
+constexpr int HW_RINV = 3 * HW_BUF;                        // (three plane buffers) float [4][32]: 2^-k of the rows of tiles i - 1 .. i + 1 (index tile & 3)
 constexpr int HW_DUMP = HW_RINV + 4 * 32 * 4;              // float [4 waves][64]: where lanes 1..63 put the value lane 0 publishes
 constexpr int HW_LDS = HW_DUMP + 4 * 64 * 4 + 16;
 constexpr int HW_DESC = 256;                               // meta float: the layer's descale (HL_DESC of h2gemm.hip)
+
+// Which pieces run behind MFMA `slot` = 6 (k step) + (MFMA of the k step), 96 slots per tile; every piece is 4 - 7 instructions, so that the wave's VALU
+// work is spread evenly under its MFMAs (32 cycles of matrix pipe each: room for ~6 VALU instructions).
+//   conversion: 36 ops (2 groups x 18, alternating) on the even slots before the barrier (end of k step 11);
+//   epilogue: 52 ops -- column tile 0's sixteen values, its transpose + stores (9), column tile 1's values and stores, 2 ops that prepare the next
+//   iteration's epilogue -- on the odd slots before the barrier and two of every three slots after it.
+constexpr int HW_BAR_STEP = 11;
+constexpr int hw_conv_at(int slot) { return (slot < 72 && !(slot & 1)) ? slot / 2 : -1; }
+constexpr int hw_epi_at(int slot)
+{
+    if (slot < 72) return (slot & 1) ? (slot - 1) / 2 : -1;
+    for (int k = 0; k < 16; ++k) if (72 + (k * 24) / 16 == slot) return 36 + k;
+    return -1;
+}
 
 struct H2LinWsArgs {
     const float *A; int lda;
@@ -64,14 +78,21 @@ template <int s> __device__ __forceinline__ void hw_load_step(__amdgpu_buffer_rs
 }
 template <int... Ss> __device__ __forceinline__ void hw_load_all(__amdgpu_buffer_rsrc_t wsrd, int voff, std::integer_sequence<int, Ss...>) { (hw_load_step<Ss>(wsrd, voff), ...); }
 // In-lane half of the quad's 4 x 4 transpose of 16-byte pieces (cw_table_swap of csrc/chain_ws.hip): slot d <- register t ^ d, t = lane & 3 --
-// two rounds of exec-masked v_swap_b32.
-__device__ __forceinline__ void hw_quad_swap(float4 &r0, float4 &r1, float4 &r2, float4 &r3)
+// two rounds of exec-masked v_swap_b32 (a: lanes with t & 1 swap slots 0 <-> 1, 2 <-> 3; b: lanes with t & 2 swap 0 <-> 2, 1 <-> 3).
+__device__ __forceinline__ void hw_quad_swap_a(float4 &r0, float4 &r1, float4 &r2, float4 &r3)
 {
     unsigned long long keep;
     asm volatile("s_mov_b64 %16, exec\n\ts_mov_b32 exec_lo, 0xaaaaaaaa\n\ts_mov_b32 exec_hi, 0xaaaaaaaa\n\t"
                  "v_swap_b32 %0, %4\n\tv_swap_b32 %1, %5\n\tv_swap_b32 %2, %6\n\tv_swap_b32 %3, %7\n\t"
                  "v_swap_b32 %8, %12\n\tv_swap_b32 %9, %13\n\tv_swap_b32 %10, %14\n\tv_swap_b32 %11, %15\n\t"
-                 "s_mov_b32 exec_lo, 0xcccccccc\n\ts_mov_b32 exec_hi, 0xcccccccc\n\t"
+                 "s_mov_b64 exec, %16\n\ts_nop 1"
+                 : "+v"(r0.x), "+v"(r0.y), "+v"(r0.z), "+v"(r0.w), "+v"(r1.x), "+v"(r1.y), "+v"(r1.z), "+v"(r1.w),
+                   "+v"(r2.x), "+v"(r2.y), "+v"(r2.z), "+v"(r2.w), "+v"(r3.x), "+v"(r3.y), "+v"(r3.z), "+v"(r3.w), "=&s"(keep));
+}
+__device__ __forceinline__ void hw_quad_swap_b(float4 &r0, float4 &r1, float4 &r2, float4 &r3)
+{
+    unsigned long long keep;
+    asm volatile("s_mov_b64 %16, exec\n\ts_mov_b32 exec_lo, 0xcccccccc\n\ts_mov_b32 exec_hi, 0xcccccccc\n\t"
                  "v_swap_b32 %0, %8\n\tv_swap_b32 %1, %9\n\tv_swap_b32 %2, %10\n\tv_swap_b32 %3, %11\n\t"
                  "v_swap_b32 %4, %12\n\tv_swap_b32 %5, %13\n\tv_swap_b32 %6, %14\n\tv_swap_b32 %7, %15\n\t"
                  "s_mov_b64 exec, %16\n\ts_nop 1"
@@ -103,67 +124,82 @@ __global__ __launch_bounds__(256, 1) void h2lin_ws_kernel(H2LinWsArgs a)
     float *rinv_all = reinterpret_cast<float *>(lds + HW_RINV), *rinv_dump = reinterpret_cast<float *>(lds + HW_DUMP) + 64 * wave;
     // tile of this workgroup's i-th iteration; past the end: the last one again (its results are not stored a second time)
     auto tile_of = [&](int i) { const int t = (int)blockIdx.x + i * (int)gridDim.x; return t < n_tiles ? t : last_tile; };
-    // rows 8 wave .. + 7 of a tile, one row per instruction: lane l holds columns 4 l .. 4 l + 3.  Rows past M inside the last tile are read as they
-    // are (the operand has M_cap rows, a multiple of 32): every row of this product is independent of the others, theirs are neither stored nor counted
-    auto load_row = [&](int i, int r) -> float4 {
-        const float *base = a.A + ((size_t)tile_of(i) * 32 + 8 * wave + r) * (size_t)a.lda;      // uniform: scalar arithmetic
-        return *reinterpret_cast<const float4 *>(base + 4 * lane);
+    // Rows 8 wave .. + 7 of a tile as two groups g of four rows: lane (sub = lane >> 4, lr = lane & 15) holds columns 4 (lr + 16 nb) .. + 3, nb = 0..3, of row
+    // 8 wave + 4 g + sub -- sixteen lanes per row, so that a row's maximum is 4 DPP steps for FOUR rows at once (one lane group per row: 6 steps per row).
+    // Rows past M inside the last tile are read as they are (the operand has M_cap rows, a multiple of 32): every row of this product is independent of
+    // the others, theirs are neither stored nor counted.
+    const int sub = lane >> 4, lr = lane & 15;
+    const int ld_off = sub * a.lda + 4 * lr;
+    auto load_q = [&](int i, int g, int nb) -> float4 {
+        const float *base = a.A + ((size_t)tile_of(i) * 32 + 8 * wave + 4 * g) * (size_t)a.lda;      // uniform: scalar arithmetic
+        return *reinterpret_cast<const float4 *>(base + ld_off + 64 * nb);
     };
-    // lane-constant part of a row's plane addresses: k step lane >> 2, lane half (lane >> 1) & 1, elements 4 (lane & 1) ..
-    char *cv_base = lds + (lane >> 2) * HW_SLOT + ((lane >> 1) & 1) * 512 + (lane & 1) * 8 + wave * 128;
-    // A row's conversion in two STAGES of six pieces each (a piece = what is issued behind one MFMA): stage A: the row's maximum (butterfly over
-    // the 64 lanes as in h2lin_kernel with LPR = 64) -> its power-of-two scale; stage B: scale, fp16 split, the two plane stores, the reload of the
-    // register with the row of the tile two further on.  Stage B of row r runs one k step behind stage A: two independent dependency chains per piece.
-    float cm[2] = {0.f, 0.f}, csc[2] = {0.f, 0.f};
-    unsigned cph[2] = {0u, 0u}, cpm[2] = {0u, 0u};
-    auto conv_a = [&](const float4 &v, int r, int piece, int tile_i) __attribute__((always_inline)) {
-        float &m = cm[r & 1];
-        // m = max(m, m of the DPP source lane) as ONE instruction (the builtin form compiles to mov_dpp + canonicalise + max + a copy); lanes without a
-        // source / outside the row mask keep m.  s_nop 1: a DPP operand written by the previous VALU instruction needs two wait states.
+    // lane-constant part of the plane addresses of the lane's values: k step (lr >> 2) + 4 nb, lane half (lr >> 1) & 1, elements 4 (lr & 1) .., row 8 wave + 4 g + sub
+    char *cv_base = lds + (lr >> 2) * HW_SLOT + ((lr >> 1) & 1) * 512 + (lr & 1) * 8 + (8 * wave + sub) * 16;
+    // The conversion of a group in eighteen OPS (an op = what is issued behind one MFMA): 0, 1: the lane's maximum; 2, 3: the row's (DPP butterfly over its
+    // sixteen lanes); 4: power-of-two scale; 5: lane lr = 0 publishes 2^-k; 6 + 3 nb + {0, 1, 2}: column block nb: scale + fp16 split of its first / second
+    // pair, then the plane stores and the reload of the register with the block of the tile two further on.  The two groups' ops alternate: two
+    // independent dependency chains.
+    float cm[2] = {0.f, 0.f}, cmb[2] = {0.f, 0.f}, csc[2] = {0.f, 0.f};
+    unsigned cph[2][2] = {{0u, 0u}, {0u, 0u}}, cpm[2][2] = {{0u, 0u}, {0u, 0u}};
+    auto conv_op = [&](float4 (&v)[4], int g, int op, int tile_i, int wb, int i_next) __attribute__((always_inline)) {
+        float &m = cm[g];
+        // m = max(m, m of the DPP source lane) as ONE instruction (the builtin form compiles to mov_dpp + canonicalise + max + a copy).
+        // s_nop 1: a DPP operand written by the previous VALU instruction needs two wait states.
 #define HW_MAX_DPP(ctrl_) asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 " ctrl_ : "+v"(m))
-        if (piece == 0) m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
-        else if (piece == 1) { HW_MAX_DPP("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"); HW_MAX_DPP("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"); }
-        else if (piece == 2) { HW_MAX_DPP("row_half_mirror row_mask:0xf bank_mask:0xf"); HW_MAX_DPP("row_mirror row_mask:0xf bank_mask:0xf"); }
-        else if (piece == 3) { HW_MAX_DPP("row_bcast:15 row_mask:0xa bank_mask:0xf"); HW_MAX_DPP("row_bcast:31 row_mask:0xc bank_mask:0xf"); }
+        // (v_max3_f32 with |.| on its sources: two values per instruction, two independent chains; written as fmaxf(fabsf()) the compiler canonicalises every
+        // operand first -- 16 instructions for 16 values)
+#define HW_MAX3(d_, a_, b_, c_) asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(d_) : "v"(a_), "v"(b_), "v"(c_))
+        if (op == 0) {
+            float ma, mb;
+            HW_MAX3(ma, v[0].x, v[0].y, v[0].z); HW_MAX3(mb, v[0].w, v[1].x, v[1].y); HW_MAX3(ma, v[1].z, v[1].w, ma); HW_MAX3(mb, v[2].x, v[2].y, mb);
+            m = ma; cmb[g] = mb;
+        } else if (op == 1) {
+            float ma = m, mb = cmb[g];
+            HW_MAX3(ma, v[2].z, v[2].w, ma); HW_MAX3(mb, v[3].x, v[3].y, mb); HW_MAX3(ma, v[3].z, v[3].w, ma);
+            m = fmaxf(ma, mb);
+        }
+#undef HW_MAX3
+        else if (op == 2) { HW_MAX_DPP("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"); HW_MAX_DPP("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"); }
+        else if (op == 3) { HW_MAX_DPP("row_half_mirror row_mask:0xf bank_mask:0xf"); HW_MAX_DPP("row_mirror row_mask:0xf bank_mask:0xf"); }
 #undef HW_MAX_DPP
-        else if (piece == 4) {
-            const int k = row_scale_exp(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 63)));
-            csc[r & 1] = pow2f(k);
+        else if (op == 4) {
+            const int k = row_scale_exp(m);
+            csc[g] = pow2f(k);
             m = pow2f(-k);
-        } else {
-            // lane 0 publishes the row's 2^-k; the other lanes write a dump word each (no exec-masked branch in the MFMA stream)
-            float *dst = lane == 0 ? rinv_all + (tile_i & 3) * 32 + 8 * wave + r : rinv_dump + lane;
+        } else if (op == 5) {
+            // (the other lanes write a dump word each: no exec-masked branch in the MFMA stream)
+            float *dst = lr == 0 ? rinv_all + (tile_i & 3) * 32 + 8 * wave + 4 * g + sub : rinv_dump + lane;
             *dst = m;
+        } else {
+            const int nb = (op - 6) / 3, part = (op - 6) % 3;
+            const float sc = csc[g];
+            if (part == 0) split2h(__fmul_rn(v[nb].x, sc), __fmul_rn(v[nb].y, sc), cph[g][0], cpm[g][0]);
+            else if (part == 1) split2h(__fmul_rn(v[nb].z, sc), __fmul_rn(v[nb].w, sc), cph[g][1], cpm[g][1]);
+            else {
+                char *dst = cv_base + wb + g * 64 + nb * 4 * HW_SLOT;
+                *reinterpret_cast<uint2 *>(dst) = make_uint2(cph[g][0], cph[g][1]);
+                *reinterpret_cast<uint2 *>(dst + 1024) = make_uint2(cpm[g][0], cpm[g][1]);
+                v[nb] = load_q(i_next, g, nb);
+            }
         }
     };
-    auto conv_b = [&](float4 &v, int r, int piece, int buf, int i_next) __attribute__((always_inline)) {
-        const float sc = csc[r & 1];
-        if (piece == 0) { v.x = __fmul_rn(v.x, sc); v.y = __fmul_rn(v.y, sc); v.z = __fmul_rn(v.z, sc); v.w = __fmul_rn(v.w, sc); }
-        else if (piece == 1) split2h(v.x, v.y, cph[0], cpm[0]);
-        else if (piece == 2) split2h(v.z, v.w, cph[1], cpm[1]);
-        else if (piece == 3) {
-            char *dst = cv_base + buf * HW_BUF + r * 16;
-            *reinterpret_cast<uint2 *>(dst) = make_uint2(cph[0], cph[1]);
-            *reinterpret_cast<uint2 *>(dst + 1024) = make_uint2(cpm[0], cpm[1]);
-        } else if (piece == 4) v = load_row(i_next, r);
-    };
-    float4 rows[2][8];
+    float4 rows[2][2][4];
     f32x16 acc[2][2];
     float gmax = 0.f;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) { rows[0][r] = load_row(0, r); rows[1][r] = load_row(1, r); }
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) { rows[0][g][nb] = load_q(0, g, nb); rows[1][g][nb] = load_q(1, g, nb); }
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[1][c][r] = 0.f;                    // (iteration 0 runs an epilogue over these)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // the weight fragments (loads the compiler does not know of) and the first rows
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
+    for (int g = 0; g < 2; ++g)
 #pragma unroll
-        for (int pc = 0; pc < 6; ++pc) conv_a(rows[0][r], r, pc, 0);
-#pragma unroll
-        for (int pc = 0; pc < 6; ++pc) conv_b(rows[0][r], r, pc, 0, 2);
-    }
+        for (int op = 0; op < 18; ++op) conv_op(rows[0][g], g, op, 0, 0, 2);
     __syncthreads();
 
     const int colb = 64 * wave + 16 * h;
@@ -171,27 +207,38 @@ __global__ __launch_bounds__(256, 1) void h2lin_ws_kernel(H2LinWsArgs a)
 #ifdef HNR_WS_PROBE
     long long tm_[18] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tp_ = clock64();
 #endif
-    unsigned bits_carry = a.side_bits[((size_t)tile_of(0) * 4 + wave) * 64 + lane];
+    unsigned bits_carry = 0u;
+    float rinv_carry = 0.f, inv = 0.f;                                      // inv: 2^-k of row j of the tile whose epilogue runs x the layer's descale (0: a dead row)
+    int st_base = (int)0x80000000;                                          // byte offset of (row (j & ~3) of that tile, this lane half's 64 bytes of the wave's first column tile); iteration 0: out of range
     float4 tb[4];
+    u32x4 xf[2][2];
+    xf[0][0] = *reinterpret_cast<const u32x4 *>(fr_base);
+    xf[0][1] = *reinterpret_cast<const u32x4 *>(fr_base + 1024);
+    int rb = 0, wb = HW_BUF;                                                // byte offsets of the buffer read by this iteration's MFMAs / written by its conversion
+    const int t16 = (j & 3) * 16, ld4 = a.ldc * 4;
+    const unsigned slope_bits = __float_as_uint(a.slope);
     // the output rows through a buffer descriptor that ends with row M - 1: rows past M (and everything in iteration 0) fall outside and are dropped
     const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(a.C, 0, (int)(M * a.ldc * 4), 0x00020000);
-    // Iteration i (PAR = i & 1): MFMAs of tile i from buffer PAR into acc[PAR]; between them: rows of tile i + 1 (register set PAR ^ 1) -> buffer PAR ^ 1,
-    // the set reloaded with tile i + 3, epilogue of tile i - 1 out of acc[PAR ^ 1].  i = n_my multiplies the last tile once more (nothing of it is stored).
+    // Iteration i (PAR = i & 1): MFMAs of tile i from buffer i % 3 into acc[PAR]; behind them, one small piece per MFMA ("slot" 6 s + pc):
+    //   * k steps 0..11: rows of tile i + 1 (register set PAR ^ 1) -> buffer (i + 1) % 3, the set reloaded with tile i + 3; then the iteration's ONE barrier.
+    //     Three buffers: the buffer written here was last read in iteration i - 1, which every wave has left before it passes iteration i's barrier, and the
+    //     next iteration's first fragments can be fetched at the end of this one (no LDS latency at the head of an iteration);
+    //   * all k steps: epilogue of tile i - 1 out of acc[PAR ^ 1], in place, then the transposed stores; last, what the next iteration's epilogue needs.
+    // i = n_my multiplies the last tile once more (nothing of it is stored).
     auto body = [&](auto par_c, int i) __attribute__((always_inline)) {
         constexpr int PAR = decltype(par_c)::value, OTH = PAR ^ 1;
-        const char *fb = fr_base + PAR * HW_BUF;
-        // ---- the epilogue that runs in this iteration: tile i - 1, out of acc[OTH] (in place).  Its sign words were loaded one iteration ago.
-        const int tp = tile_of(i - 1 < 0 ? 0 : i - 1);
-        const bool live = i >= 1 && (long long)tp * 32 + j < M;             // rows past M (and iteration 0): scaled by 0 -- never the maximum -- and out of the store range
-        const unsigned bits = bits_carry;
+        const char *fb = fr_base + rb;
+        const unsigned bits = bits_carry;                                   // sign words of tile i - 1 (loaded one iteration ago)
         bits_carry = a.side_bits[((size_t)tile_of(i) * 4 + wave) * 64 + lane];
-        const float inv = live ? __fmul_rn(rinv_all[((i - 1) & 3) * 32 + j], dw) : 0.f;
-        // byte offset of (row (j & ~3) of the tile, this lane half's 64 bytes of the wave's first column tile); iteration 0: out of the descriptor's range
-        const int st_base = i >= 1 ? ((tp * 32 + (j & ~3)) * a.ldc + colb) * 4 : (int)0x80000000;
-        const int t16 = (j & 3) * 16, ld4 = a.ldc * 4;
         auto value = [&](int c, int vi) __attribute__((always_inline)) {
             float v = fmaf(acc[OTH][c][vi], inv, 0.f);
-            v = __fmul_rn(v, ((bits >> (31 - (16 * c + vi))) & 1u) ? 1.f : a.slope);
+            // x (bit ? 1 : slope) without a compare: the bit spread over a word (v_bfe_i32), then a bit-field select between the two constants -- no SGPR
+            // pair written by a VALU instruction and read by the next (a hazard nop behind every v_cmp / v_cndmask pair)
+            int sel;
+            asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(sel) : "v"(bits), "n"(31 - (16 * c + vi)));
+            unsigned fac;
+            asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(fac) : "v"(sel), "v"(0x3f800000u), "v"(slope_bits));
+            v = __fmul_rn(v, __uint_as_float(fac));
             acc[OTH][c][vi] = v;
             gmax = fmaxf(gmax, fabsf(v));
         };
@@ -203,50 +250,58 @@ __global__ __launch_bounds__(256, 1) void h2lin_ws_kernel(H2LinWsArgs a)
                                                                                              : __builtin_amdgcn_update_dpp(0, b, 0x1B, 0xf, 0xf, false);
             return __builtin_bit_cast(float, r);
         };
-        auto transpose = [&](int c, int sub) __attribute__((always_inline)) {
+        auto transpose = [&](int c, int sub_) __attribute__((always_inline)) {
             const f32x16 &o = acc[OTH][c];
-            if (sub == 0) { tb[0] = make_float4(o[0], o[1], o[2], o[3]); tb[1] = make_float4(dppx(o[4], 1), dppx(o[5], 1), dppx(o[6], 1), dppx(o[7], 1)); }
-            else if (sub == 1) { tb[2] = make_float4(dppx(o[8], 2), dppx(o[9], 2), dppx(o[10], 2), dppx(o[11], 2)); tb[3] = make_float4(dppx(o[12], 3), dppx(o[13], 3), dppx(o[14], 3), dppx(o[15], 3)); }
-            else if (sub == 2) hw_quad_swap(tb[0], tb[1], tb[2], tb[3]);
+            if (sub_ == 0) { tb[0] = make_float4(o[0], o[1], o[2], o[3]); tb[1] = make_float4(dppx(o[4], 1), dppx(o[5], 1), dppx(o[6], 1), dppx(o[7], 1)); }
+            else if (sub_ == 1) tb[2] = make_float4(dppx(o[8], 2), dppx(o[9], 2), dppx(o[10], 2), dppx(o[11], 2));
+            else if (sub_ == 2) tb[3] = make_float4(dppx(o[12], 3), dppx(o[13], 3), dppx(o[14], 3), dppx(o[15], 3));
+            else if (sub_ == 3) hw_quad_swap_a(tb[0], tb[1], tb[2], tb[3]);
+            else if (sub_ == 4) hw_quad_swap_b(tb[0], tb[1], tb[2], tb[3]);
             else {
-#pragma unroll
-                for (int r = 2 * (sub - 3); r < 2 * (sub - 3) + 2; ++r)
-                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(tb[r].x), __float_as_uint(tb[r].y), __float_as_uint(tb[r].z), __float_as_uint(tb[r].w)}, crs,
-                                                           st_base + r * ld4 + 128 * c + ((16 * r) ^ t16), 0, 0);
+                const int r = sub_ - 5;
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(tb[r].x), __float_as_uint(tb[r].y), __float_as_uint(tb[r].z), __float_as_uint(tb[r].w)}, crs,
+                                                       st_base + r * ld4 + 128 * c + ((16 * r) ^ t16), 0, 0);
             }
         };
-        u32x4 xf[2][2];
-        xf[0][0] = *reinterpret_cast<const u32x4 *>(fb);
-        xf[0][1] = *reinterpret_cast<const u32x4 *>(fb + 1024);
+        // what the NEXT iteration's epilogue (tile i) needs; the stores of this one have been issued
+        auto prepare = [&](int part) __attribute__((always_inline)) {
+            const int tn = tile_of(i);
+            if (part == 0) st_base = ((tn * 32 + (j & ~3)) * a.ldc + colb) * 4;
+            else inv = ((long long)tn * 32 + j < M) ? __fmul_rn(rinv_carry, dw) : 0.f;      // rows past M: scaled by 0 -- never the maximum -- and out of the store range
+        };
         hw_static_for<HW_S>([&](auto s_c) {
             constexpr int s = decltype(s_c)::value, cur = s & 1, nxt = cur ^ 1;
             if constexpr (s + 1 < HW_S) {
                 xf[nxt][0] = *reinterpret_cast<const u32x4 *>(fb + (s + 1) * HW_SLOT);
                 xf[nxt][1] = *reinterpret_cast<const u32x4 *>(fb + (s + 1) * HW_SLOT + 1024);
+            } else {
+                // the next iteration's first fragments (its buffer is complete since this iteration's barrier) and its epilogue's row scales
+                xf[nxt][0] = *reinterpret_cast<const u32x4 *>(fr_base + wb);
+                xf[nxt][1] = *reinterpret_cast<const u32x4 *>(fr_base + wb + 1024);
+                rinv_carry = rinv_all[(i & 3) * 32 + j];
             }
             hw_static_for<6>([&](auto pc_c) {
-                constexpr int pc = decltype(pc_c)::value;
+                constexpr int pc = decltype(pc_c)::value, slot = 6 * s + pc;
                 // smallest terms first (w_m x_h, w_h x_m, w_h x_h), the two accumulators alternating
                 constexpr int cc = pc & 1, term = pc >> 1, wp = term == 0 ? 1 : 0, xp = term == 1 ? 1 : 0;
                 if constexpr (s == 0 && term == 0) hw_mfma_first<16 * s + 8 * cc + 4 * wp>(acc[PAR][cc], xf[cur][xp]);
                 else hw_mfma<16 * s + 8 * cc + 4 * wp>(acc[PAR][cc], xf[cur][xp]);
-                // pieces behind this MFMA.  Conversion of tile i + 1: row s stage A, row s - 1 stage B (k steps 0..8).  Epilogue of tile i - 1: column tile 0's
-                // values two per k step (0..7, behind MFMAs 4, 5), column tile 1's four per k step (8..11); transposes + stores of tile 0 in k steps 8..10,
-                // of tile 1 in k step 12
-                if constexpr (s < 8) conv_a(rows[OTH][s], s, pc, i + 1);
-                if constexpr (s >= 1 && s <= 8) conv_b(rows[OTH][s - 1], s - 1, pc, OTH, i + 3);
-                if constexpr (s < 8 && pc >= 4) value(0, 2 * s + pc - 4);
-                if constexpr (s >= 8 && s < 12 && pc < 4) value(1, 4 * (s - 8) + pc);
-                if constexpr (s == 8 && pc >= 4) transpose(0, pc - 4);
-                if constexpr (s == 9 && pc >= 4) transpose(0, pc - 2);
-                if constexpr (s == 10 && pc == 4) transpose(0, 4);
-                if constexpr (s == 12 && pc < 5) transpose(1, pc);
+                // the pieces behind this MFMA
+                constexpr int cn = hw_conv_at(slot);
+                if constexpr (cn >= 0) conv_op(rows[OTH][cn & 1], cn & 1, cn >> 1, i + 1, wb, i + 3);
+                constexpr int en = hw_epi_at(slot);
+                if constexpr (en >= 0 && en < 16) value(0, en);
+                else if constexpr (en >= 16 && en < 25) transpose(0, en - 16);
+                else if constexpr (en >= 25 && en < 41) value(1, en - 25);
+                else if constexpr (en >= 41 && en < 50) transpose(1, en - 41);
+                else if constexpr (en >= 50) prepare(en - 50);
                 __builtin_amdgcn_sched_barrier(0);
             });
+            if constexpr (s == HW_BAR_STEP) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
             HW_STAMP(s);
         });
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        HW_STAMP(16);
+        rb = wb;
+        wb = wb + HW_BUF < 3 * HW_BUF ? wb + HW_BUF : 0;
 #ifdef HNR_WS_PROBE
         tm_[17] += 1;
 #endif
