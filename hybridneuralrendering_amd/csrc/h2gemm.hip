@@ -702,6 +702,189 @@ __global__ __launch_bounds__(512, 1) void h2wgrad_dma_kernel(H2WgradArgs a)
     }
 }
 
+// The same kernel for its shape in the training step -- N = 256 output columns, K = 256 .. 287 inputs, plain rows (n_seg = 1): the three 256-wide layers
+// of the per-neighbour chain, 306 k rows each.  h2wgrad_dma_kernel spends ~370 instructions per 16-row block and wave for 27 MFMAs: segment arithmetic in
+// 64-bit compares for every DMA'd row, a mask select per converted value, exec-masked fix-ups for the bias column in every conversion slot -- 14
+// instructions per MFMA where the matrix pipe hides ~6.  Here
+//   * the 512 real columns of a block (256 of dZ + 256 of X) are exactly four conversion slots per thread, a thread keeping its operand, its four
+//     columns and its scale: LDS read, four products, two splits, one paired LDS write -- no masks (rows past the end: the dZ scale is 0);
+//   * the ninth X tile (columns 256 .. 287: the inputs past the 256th, then the bias column of ones, then zeros) is constant for K = 256 -- written once
+//     into both plane stages -- and one extra slot of the first 128 threads otherwise (NINTH);
+//   * a DMA'd row costs scalar arithmetic only.
+// Same staging values, same MFMA order per accumulator, same blocks per workgroup: partials bit-identical to h2wgrad_dma_kernel's.
+template <bool NINTH>
+__global__ __launch_bounds__(512, 1) void h2wgrad_dma256_kernel(H2WgradArgs a)
+{
+    constexpr int NT = 8, KT = 9, KTW = KT;
+    constexpr int WZ = 32 * NT, WX = 32 * KT;
+    constexpr int RSZ = ((WZ * 2 - 64 + 255) & ~255) + 64, RSX = ((WX * 2 - 64 + 255) & ~255) + 64;
+    constexpr int RB = 16;
+    constexpr int PZ = RB * RSZ, PX = RB * RSX, STAGE = 2 * PZ + 2 * PX;
+    constexpr int RAWZ = RB * WZ * 4, RAWX = RB * WX * 4, RAW = RAWZ + RAWX;   // raw fp32 rows of a block: [16][256] dZ, then [16][288] X
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wn = wave;
+    long long M = a.M_cap;
+    if (a.d_m) { const long long c = *a.d_m; if (c < M) M = c; }
+    const long long n_blocks = (M + RB - 1) / RB;
+    if (n_blocks == 0 && blockIdx.x > 0) return;
+    const int kz = row_scale_exp(__uint_as_float(*a.zmax)), kx = row_scale_exp(__uint_as_float(*a.xmax));
+    const float sz = pow2f(kz), sx = pow2f(kx);
+    f32x16 acc[KTW];
+#pragma unroll
+    for (int u = 0; u < KTW; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
+    // main conversion slots of this thread: operand (tid & 64 ? X : dZ), columns 4 (tid & 63) .. + 3, rows (tid >> 7) + 4 it, it = 0..3
+    const bool isx = (tid & 64) != 0;
+    const int c0 = 4 * (tid & 63), r0 = tid >> 7;
+    const int raw0 = isx ? RAWZ + (r0 * WX + c0) * 4 : (r0 * WZ + c0) * 4, raw_step = 4 * (isx ? WX : WZ) * 4;
+    const int pl0 = (isx ? 2 * PZ : 0) + r0 * (isx ? RSX : RSZ) + c0 * 2, pl_step = 4 * (isx ? RSX : RSZ), pl_m = isx ? PX : PZ;
+    const float sc_main = isx ? sx : sz;
+    // the ninth X tile's slot (threads 0 .. 127): row tid >> 3, columns 256 + 4 (tid & 7) ..
+    const int r9 = tid >> 3, c9 = 256 + 4 * (tid & 7);
+    unsigned keep9 = 0;
+    if (NINTH) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) keep9 |= (c9 + 4 <= a.ldx && c9 + e < a.K) ? (1u << e) : 0u;
+        if ((a.K >> 2) == (c9 >> 2)) keep9 |= 256u << (a.K & 3);
+    }
+    const unsigned lds_base = (unsigned)reinterpret_cast<uintptr_t>(lds);
+    const int vx8 = (lane < 8 && 256 + 4 * lane + 4 <= a.ldx) ? (256 + 4 * lane) * 4 : 0;
+    // (32-bit block / row numbers: M < 2^31 rows; a DMA'd row costs a scalar min, one 64-bit product and two adds per operand)
+    const int M32 = (int)M, last_row = M32 > 0 ? M32 - 1 : 0;
+    auto dma_block = [&](int blk, unsigned raw) {
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int row = 2 * wave + rr;
+            int m = blk * RB + row;                                             // (uniform: scalar arithmetic)
+            m = m < last_row ? m : last_row;                                    // rows past the end re-read the last row (their dZ is scaled by 0)
+            h2_dma_row(a.dZ + (size_t)(unsigned)m * (unsigned)a.ldz, lane * 16, raw + (unsigned)(row * WZ * 4));
+            h2_dma_row(a.X + (size_t)(unsigned)m * (unsigned)a.ldx, lane * 16, raw + (unsigned)(RAWZ + row * WX * 4));
+            if (NINTH) h2_dma_row8(a.X + (size_t)(unsigned)m * (unsigned)a.ldx, vx8, raw + (unsigned)(RAWZ + row * WX * 4 + 1024));
+        }
+    };
+    auto convert_main = [&](const float4 v, char *base, int blk, int it) __attribute__((always_inline)) {
+        const float sc = (isx || blk * RB + r0 + 4 * it < M32) ? sc_main : 0.f;
+        unsigned ph0, pm0, ph1, pm1;
+        split2h(__fmul_rn(v.x, sc), __fmul_rn(v.y, sc), ph0, pm0);
+        split2h(__fmul_rn(v.z, sc), __fmul_rn(v.w, sc), ph1, pm1);
+        char *dst = base + pl0 + it * pl_step;
+        *reinterpret_cast<uint2 *>(dst) = make_uint2(ph0, ph1);
+        *reinterpret_cast<uint2 *>(dst + pl_m) = make_uint2(pm0, pm1);
+    };
+    auto convert_ninth = [&](const float4 v, char *base) __attribute__((always_inline)) {      // (as h2wgrad_dma_kernel's slot; X rows past the end meet dZ = 0)
+        const unsigned keep = keep9;
+        unsigned ph0, pm0, ph1, pm1;
+        split2h((keep & 1u) ? __fmul_rn(v.x, sx) : 0.f, (keep & 2u) ? __fmul_rn(v.y, sx) : 0.f, ph0, pm0);
+        split2h((keep & 4u) ? __fmul_rn(v.z, sx) : 0.f, (keep & 8u) ? __fmul_rn(v.w, sx) : 0.f, ph1, pm1);
+        ph0 = (keep & 0x100u) ? ((ph0 & 0xffff0000u) | 0x3c00u) : (keep & 0x200u) ? ((ph0 & 0x0000ffffu) | 0x3c000000u) : ph0;
+        ph1 = (keep & 0x400u) ? ((ph1 & 0xffff0000u) | 0x3c00u) : (keep & 0x800u) ? ((ph1 & 0x0000ffffu) | 0x3c000000u) : ph1;
+        char *dst = base + 2 * PZ + r9 * RSX + c9 * 2;
+        *reinterpret_cast<uint2 *>(dst) = make_uint2(ph0, ph1);
+        *reinterpret_cast<uint2 *>(dst + PX) = make_uint2(pm0, pm1);
+    };
+    const int step = gridDim.x, n_blk = (int)n_blocks;
+    int blk = blockIdx.x;
+    auto planes = [&](int p_) { return lds + p_ * STAGE; };
+    auto raw_p = [&](int p_) { return lds + 2 * STAGE + p_ * RAW; };
+    auto raw_l = [&](int p_) { return lds_base + (unsigned)(2 * STAGE + p_ * RAW); };
+    if (!NINTH && tid < 128) {
+        // K = 256: the ninth tile of every block = [1 (the bias column: fp16 1.0 in the high plane), 0, 0, ...]
+#pragma unroll
+        for (int p_ = 0; p_ < 2; ++p_) {
+            char *dst = planes(p_) + 2 * PZ + r9 * RSX + c9 * 2;
+            *reinterpret_cast<uint2 *>(dst) = make_uint2(c9 == 256 ? 0x3c00u : 0u, 0u);
+            *reinterpret_cast<uint2 *>(dst + PX) = make_uint2(0u, 0u);
+        }
+    }
+    dma_block(blk, raw_l(0));
+    dma_block(blk + step, raw_l(1));
+    if (NINTH) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) convert_main(*reinterpret_cast<const float4 *>(raw_p(0) + raw0 + it * raw_step), planes(0), blk, it);
+    if (NINTH && tid < 128) convert_ninth(*reinterpret_cast<const float4 *>(raw_p(0) + RAWZ + (r9 * WX + c9) * 4), planes(0));
+    // The loop body is FLAT: 27 MFMAs with everything else dealt out between them, a few instructions behind each (fragment reads of the next pair of X
+    // tiles, a piece of the next block's conversion, the DMA of the block after), fenced so that the compiler keeps the order.  Two waves share a SIMD's
+    // matrix pipe: six MFMAs back to back in both meant twelve serialised, and a wave waiting to issue an MFMA holds the SIMD's VALU port -- nothing else
+    // of either wave ran meanwhile (the kernel's terms added up: profiles/r05_wgrad_ablation.txt); with an MFMA every ~8 instructions the other wave's
+    // VALU work runs in the gaps.
+    int par = 0;
+    for (; blk < n_blk; blk += step, par ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // this wave's rows of block i + 1 have landed
+        __syncthreads();
+        const char *zb = planes(par), *xb = planes(par) + 2 * PZ;
+        const char *rawn = raw_p(par ^ 1);
+        char *basen = planes(par ^ 1);
+        const int blkn = blk + step;
+        const f16x8 zh = h2_tr_frag(zb, RSZ, 32 * wn, 0, lane), zm = h2_tr_frag(zb + PZ, RSZ, 32 * wn, 0, lane);
+        f16x8 xh[2][2], xm[2][2];
+        xh[0][0] = h2_tr_frag(xb, RSX, 0, 0, lane); xh[0][1] = h2_tr_frag(xb, RSX, 32, 0, lane);
+        xm[0][0] = h2_tr_frag(xb + PX, RSX, 0, 0, lane); xm[0][1] = h2_tr_frag(xb + PX, RSX, 32, 0, lane);
+        dma_block(blk + 2 * step, raw_l(par));
+        __builtin_amdgcn_sched_barrier(0);
+        float4 v = *reinterpret_cast<const float4 *>(rawn + raw0);
+        float sc = 0.f;
+        unsigned ph0 = 0, pm0 = 0, ph1 = 0, pm1 = 0;
+#pragma unroll
+        for (int u0 = 0; u0 < KTW; u0 += 2) {
+            const int cb = (u0 >> 1) & 1, it = u0 >> 1;
+            const bool pair = u0 + 1 < KTW;
+            // conversion slot `it` of the next block in six pieces (it = 4: the ninth tile's slot / nothing)
+            auto piece = [&](int pc) __attribute__((always_inline)) {
+                if (it < 4) {
+                    if (pc == 0) { sc = (isx || blkn * RB + r0 + 4 * it < M32) ? sc_main : 0.f; v.x = __fmul_rn(v.x, sc); v.y = __fmul_rn(v.y, sc); }
+                    else if (pc == 1) { v.z = __fmul_rn(v.z, sc); v.w = __fmul_rn(v.w, sc); }
+                    else if (pc == 2) split2h(v.x, v.y, ph0, pm0);
+                    else if (pc == 3) split2h(v.z, v.w, ph1, pm1);
+                    else if (pc == 4) {
+                        char *dst = basen + pl0 + it * pl_step;
+                        *reinterpret_cast<uint2 *>(dst) = make_uint2(ph0, ph1);
+                        *reinterpret_cast<uint2 *>(dst + pl_m) = make_uint2(pm0, pm1);
+                    } else if (it + 1 < 4) v = *reinterpret_cast<const float4 *>(rawn + raw0 + (it + 1) * raw_step);
+                    else if (NINTH) v = *reinterpret_cast<const float4 *>(rawn + RAWZ + ((r9 & 15) * WX + c9) * 4);
+                } else if (NINTH && pc == 0 && tid < 128) convert_ninth(v, basen);
+            };
+            // the next pair's fragments (two transposing reads each), one behind each of the first four MFMAs
+            auto frag = [&](int pc) __attribute__((always_inline)) {
+                if (u0 + 2 >= KTW) return;
+                if (pc == 0) xh[cb ^ 1][0] = h2_tr_frag(xb, RSX, 32 * (u0 + 2), 0, lane);
+                else if (pc == 1) xm[cb ^ 1][0] = h2_tr_frag(xb + PX, RSX, 32 * (u0 + 2), 0, lane);
+                else if (u0 + 3 < KTW && pc == 2) xh[cb ^ 1][1] = h2_tr_frag(xb, RSX, 32 * (u0 + 3), 0, lane);
+                else if (u0 + 3 < KTW && pc == 3) xm[cb ^ 1][1] = h2_tr_frag(xb + PX, RSX, 32 * (u0 + 3), 0, lane);
+            };
+#define HNR_WG_SLOT(pc_, stmt_) do { stmt_; frag(pc_); piece(pc_); __builtin_amdgcn_sched_barrier(0); } while (0)
+            if (pair) {
+                HNR_WG_SLOT(0, acc[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zm, xh[cb][0], acc[u0], 0, 0, 0));
+                HNR_WG_SLOT(1, acc[u0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zm, xh[cb][1], acc[u0 + 1], 0, 0, 0));
+                HNR_WG_SLOT(2, acc[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zh, xm[cb][0], acc[u0], 0, 0, 0));
+                HNR_WG_SLOT(3, acc[u0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zh, xm[cb][1], acc[u0 + 1], 0, 0, 0));
+                HNR_WG_SLOT(4, acc[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zh, xh[cb][0], acc[u0], 0, 0, 0));
+                HNR_WG_SLOT(5, acc[u0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zh, xh[cb][1], acc[u0 + 1], 0, 0, 0));
+            } else {
+                HNR_WG_SLOT(0, acc[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zm, xh[cb][0], acc[u0], 0, 0, 0));
+                HNR_WG_SLOT(1, acc[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zh, xm[cb][0], acc[u0], 0, 0, 0));
+                HNR_WG_SLOT(2, acc[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zh, xh[cb][0], acc[u0], 0, 0, 0));
+            }
+#undef HNR_WG_SLOT
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                            // no DMA into this workgroup's LDS may outlive it
+    constexpr int NP = 32 * NT, KP = 32 * KT, LDP = KP;
+    float *out = a.partial + (size_t)blockIdx.x * NP * LDP;
+    const float dsz = pow2f(-kz), dsx = pow2f(-kx);
+#pragma unroll
+    for (int u = 0; u < KTW; ++u) {
+        const int kc = 32 * u + (lane & 31);
+        const float d2 = kc == a.K ? 1.0f : dsx;                               // the bias column was staged unscaled
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = 32 * wn + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            out[(size_t)n * LDP + kc] = __fmul_rn(__fmul_rn(acc[u][r], dsz), d2);
+        }
+    }
+}
+
 // dW[n, k] (+)= sum over the workgroups that had rows, in a FIXED order; db[n] likewise (column KP of the partials).  64 outputs per block
 // (coalesced along k), the partials dealt to the block's four waves (wave w takes partials w, w + 4, ...: eight interleaved running sums each),
 // the four results added in wave order -- a single chain of `used` dependent loads per output was 13 us of latency per launch, fifteen times
@@ -911,8 +1094,14 @@ extern "C" int hnr_h2wgrad(const float *d_dZ, int ldz, const float *d_X, int ldx
         if (once89.first()) {
             HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(h2wgrad_kernel<8, 9, 1, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb));
             HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(h2wgrad_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_dma));
+            HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(h2wgrad_dma256_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_dma));
+            HNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(h2wgrad_dma256_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_dma));
         }
-        if (use_dma) h2wgrad_dma_kernel<<<grid, 512, lds_dma, st>>>(a);
+        // N = 256, plain rows: the kernel specialised for the training step's 256-wide layers (HNR_WGRAD_DMA=2: the general DMA kernel instead, A/B timing)
+        const bool fast = use_dma == 1 && N == 256 && n_seg == 1 && ldz >= 256 && ldx >= 256 && M_cap < 0x7ffff000LL;
+        if (fast && K == 256) h2wgrad_dma256_kernel<false><<<grid, 512, lds_dma, st>>>(a);
+        else if (fast) h2wgrad_dma256_kernel<true><<<grid, 512, lds_dma, st>>>(a);
+        else if (use_dma) h2wgrad_dma_kernel<<<grid, 512, lds_dma, st>>>(a);
         else h2wgrad_kernel<8, 9, 1, 0, 1><<<grid, 512, ldsb, st>>>(a);
     }
     HNR_H2WG_CASE(8, 9) HNR_H2WG_CASE(8, 8) HNR_H2WG_CASE(8, 2) HNR_H2WG_CASE(4, 9) HNR_H2WG_CASE(4, 5) HNR_H2WG_CASE(2, 9) HNR_H2WG_CASE(2, 5) HNR_H2WG_CASE(2, 3) HNR_H2WG_CASE(2, 2)
