@@ -336,10 +336,9 @@ def train_leg(args, sc, opt, agg, cloud, rnd, cam, dev, steps=20, warmup=3):
         # C3 batch: 307 120 row slots) PMC bytes of the 256-wide weight gradient (its launches inside the training step,
         # profiles/<TRAIN_TRAFFIC_JSON>), selected by kernel name; the batch behind that file is this one up to the
         # depth jitter (row slots within 1 %: `traffic_rows` beside it)
-        # (the DMA-staged kernel is the default since round 4)
-        t_wg = [v for k, v in pmc_traffic(TRAIN_TRAFFIC_JSON).items() if "h2wgrad_dma_kernel" in k
-                or "h2wgrad_kernel<8, 9" in k]
-        roof_t = dict(kernel="h2wgrad_dma_kernel + reduce (hnr_h2wgrad: dW = dZ^T X, db of one 256 x 256 per-neighbour "
+        # (the DMA-staged kernel specialised for the 256-wide layers: the default since round 6)
+        t_wg = [v for k, v in pmc_traffic(TRAIN_TRAFFIC_JSON).items() if "h2wgrad_dma256_kernel<false>" in k]
+        roof_t = dict(kernel="h2wgrad_dma256_kernel<false> + reduce (hnr_h2wgrad: dW = dZ^T X, db of one 256 x 256 per-neighbour "
                              "layer; M = %d row slots)" % M8, bound="hbm",
                       achieved=round(M8 * 2048.0 / (ms_w * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                       frac=round(M8 * 2048.0 / (ms_w * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),

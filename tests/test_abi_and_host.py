@@ -480,11 +480,11 @@ def test_committed_pmc_files_hold_the_kernels_bench_looks_up():
     import glob, json
     newest = lambda suf: sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r0*_" + suf)) if suf.startswith("train") or "train_" not in os.path.basename(f))[-1]
     tr = json.load(open(newest("train_traffic.json")))["kernels"]
-    assert any("h2wgrad_dma_kernel" in k for k in tr), list(tr)
+    assert any("h2wgrad_dma256_kernel<false>" in k for k in tr), list(tr)
     fr = json.load(open(newest("traffic.json")))["kernels"]
     assert any("chain_ws_kernel<0>" in k for k in fr) and any("march_kernel" in k for k in fr) and any("knn_nb_kernel<8, 0" in k for k in fr), list(fr)
     src = "".join(open(f).read() for f in glob.glob(os.path.join(ROOT, "hnr_bench", "*.py")))
-    assert '"h2wgrad_dma_kernel" in k' in src and '"chain_ws_kernel" in k' in src and '"march_kernel" in k' in src
+    assert '"h2wgrad_dma256_kernel<false>" in k' in src and '"chain_ws_kernel" in k' in src and '"march_kernel" in k' in src
 
 
 def test_bench_refuses_a_stale_chain_pmc_file(tmp_path, monkeypatch):

@@ -9,7 +9,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 root = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "train_traffic")
-KERNELS = ("h2wgrad_dma_kernel", "h2wgrad_kernel<8, 9", "h2wgrad_kernel<8, 2", "h2lin_kernel<16>", "chain_kernel<4, 3>", "chain_ws_kernel<8>", "train_ksum_bwd_kernel", "segment_sum_rows_csr_kernel", "train_extras_dgrad_kernel",
+KERNELS = ("h2wgrad_dma256_kernel<false>", "h2wgrad_dma256_kernel<true>", "h2wgrad_dma_kernel", "h2wgrad_kernel<8, 9", "h2wgrad_kernel<8, 2", "h2lin_ws_kernel", "h2lin_kernel<16>", "chain_kernel<4, 3>", "chain_ws_kernel<8>", "train_ksum_bwd_kernel", "segment_sum_rows_csr_kernel", "train_extras_dgrad_kernel",
            "chain_gather_kernel", "merge_bwd_kernel", "mlp3_kernel<18")
 out = {}
 for name in ("FETCH_SIZE", "WRITE_SIZE"):
