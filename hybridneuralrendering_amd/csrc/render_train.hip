@@ -275,15 +275,40 @@ __global__ __launch_bounds__(1024) void train_ksum_bwd_kernel(KsumPadArgs a)
             wv[k] = reinterpret_cast<const float *>(ax + 128)[j0 + k];
             hv[k] = reinterpret_cast<const float4 *>(a.H4 + (row0 + k) * 256)[lane];
         }
+        // The sample's sixteen wave sums (per row: h . alpha_w and h . gX5) in ONE butterfly: every step halves the number of values a lane carries (the
+        // lanes of one half keep the first half of the values and hand the others over), 8 + 4 + 2 + 1 + 1 + 1 exchanges instead of 16 x 6 in series --
+        // the kernel was bound by that latency.  Each sum is formed by the same pairwise additions as a plain xor butterfly: same bits.
+        float r8[8], r4[4], r2[2], r1;
+        {
+            float v[16];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float4 h = hv[k];
+                v[2 * k] = h.x * aw.x + h.y * aw.y + h.z * aw.z + h.w * aw.w;
+                v[2 * k + 1] = h.x * gf.x + h.y * gf.y + h.z * gf.z + h.w * gf.w;
+            }
+            const bool b5 = (lane & 32) != 0, b4 = (lane & 16) != 0, b3 = (lane & 8) != 0, b2 = (lane & 4) != 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) r8[i] = (b5 ? v[i + 8] : v[i]) + __shfl_xor(b5 ? v[i] : v[i + 8], 32);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) r4[i] = (b4 ? r8[i + 4] : r8[i]) + __shfl_xor(b4 ? r8[i] : r8[i + 4], 16);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) r2[i] = (b3 ? r4[i + 2] : r4[i]) + __shfl_xor(b3 ? r4[i] : r4[i + 2], 8);
+            r1 = (b2 ? r2[1] : r2[0]) + __shfl_xor(b2 ? r2[0] : r2[1], 4);
+            r1 += __shfl_xor(r1, 2);
+            r1 += __shfl_xor(r1, 1);
+        }
+        // value index i = 2 k (+ 1) sits in the lanes 4 i .. 4 i + 3
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const size_t row = row0 + k;
             float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
             float gw = 0.f;
+            const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r1), 8 * k));
+            const float hf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r1), 8 * k + 4));
             if (pid[k] >= 0) {
                 const float w = wv[k];
                 const float4 h = hv[k];
-                const float d = train_wave_sum(h.x * aw.x + h.y * aw.y + h.z * aw.z + h.w * aw.w);
                 const float yv = __fsub_rn(d + ab, 1.0f);
                 const float ez = expf(yv);
                 const float sp = yv > 20.f ? yv : log1pf(ez);
@@ -293,7 +318,6 @@ __global__ __launch_bounds__(1024) void train_ksum_bwd_kernel(KsumPadArgs a)
                 o.y = (w * gf.y + da * aw.y) * (h.y > 0.f ? 1.f : a.slope);
                 o.z = (w * gf.z + da * aw.z) * (h.z > 0.f ? 1.f : a.slope);
                 o.w = (w * gf.w + da * aw.w) * (h.w > 0.f ? 1.f : a.slope);
-                const float hf = train_wave_sum(h.x * gf.x + h.y * gf.y + h.z * gf.z + h.w * gf.w);
                 gw = sp * gs + hf;
                 acc.x += da * h.x; acc.y += da * h.y; acc.z += da * h.z; acc.w += da * h.w;
                 acc_b += da;
