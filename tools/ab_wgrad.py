@@ -20,7 +20,7 @@ from hybridneuralrendering_amd import _lib
 L = _lib.lib(); dev = torch.device("cuda:0")
 torch.manual_seed(0)                 # seeded operands: the checksums of the two runs are comparable (tests/test_h2gemm_gpu.py holds the bit-for-bit test)
 res = {}
-for (M, N, K) in ((306832, 256, 256), (306832, 256, 263), (306821, 256, 256), (1000, 256, 287)):
+for (M, N, K) in ((306832, 256, 256), (306832, 256, 263), (306821, 256, 256), (1000, 256, 287), (306832, 256, 60), (306821, 256, 60), (37, 256, 63)):
     Z, X = torch.randn((M, N), device=dev), torch.randn((M, K + (4 - K % 4) % 4), device=dev)
     mz = torch.tensor([np.float32(8.0).view(np.int32)], dtype=torch.int32, device=dev)
     scratch = torch.empty((int(L.hnr_h2wgrad_scratch_bytes(N, K)),), dtype=torch.uint8, device=dev)
