@@ -7,8 +7,9 @@
 //     (profiles/README.md, round 5) and its phases (row loads + split | MFMA loop | epilogue) are serial per workgroup.  Here a wave loads its 64 output
 //     columns' fragments ONCE into 256 self-numbered AGPRs (as csrc/chain_ws.hip does per layer) and streams 32-row tiles past them;
 //   * the loop is software-pipelined by hand: iteration i multiplies tile i (96 MFMAs per wave) and, between those MFMAs, converts the rows of tile
-//     i + 1 (loaded two iterations earlier into one of two register sets), reloads that set with tile i + 3, and runs the epilogue of tile i - 1 out of
-//     the other accumulator set.  One workgroup barrier per tile.
+//     i + 1 (loaded two iterations earlier into one of two register sets) into the next of THREE LDS plane buffers, reloads that set with tile i + 3, and
+//     runs the epilogue of tile i - 1 out of the other accumulator set (values in place, then quad-transposed 64-byte stores).  One workgroup barrier per
+//     tile, in mid-iteration; every piece behind an MFMA is 4 - 7 instructions (the slot tables below).  Measured: profiles/r06_train_gemms.txt.
 // The compiler must not touch AGPRs or scratch in this file (Makefile: build/h2lin_ws.checked).
 #include <stdio.h>
 #include <stdlib.h>
