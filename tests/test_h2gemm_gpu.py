@@ -91,7 +91,7 @@ def _sign_words(side, M_cap):
 
 
 @pytest.mark.parametrize("M_cap,M,K,lda,ldc", [(4096, 4001, 256, 256, 256), (8192, 8192, 256, 264, 264), (64, 33, 256, 256, 264), (32, 1, 256, 256, 256),
-                                               (2048, 2000, 224, 224, 256), (96, 96, 256, 256, 256)])
+                                               (2048, 2000, 224, 224, 256), (96, 96, 256, 256, 256), (64, 0, 256, 256, 256)])
 def test_h2lin_dgrad_bits_matches_fp64_and_the_float_side_form(M_cap, M, K, lda, ldc):
     """hnr_h2lin_dgrad_bits (K = 256: the weight-stationary kernel csrc/h2lin_ws.hip; other K: the streaming kernel reading sign words) = what torch autograd
     computes for dX of a Linear behind a LeakyReLU whose output is known by its signs; equal BIT FOR BIT to hnr_h2lin mode 1 with the activation itself."""
@@ -118,6 +118,9 @@ def test_h2lin_dgrad_bits_matches_fp64_and_the_float_side_form(M_cap, M, K, lda,
     got = C1.cpu().numpy()
     assert got.tobytes() == C2.cpu().numpy().tobytes() and m1.item() == m2.item()
     assert (got[M:] == 7.0).all() and (got[:, N:] == 7.0).all(), "rows past *d_m / padding columns were written"
+    if M == 0:                                                                 # no rows: nothing written, the maximum word untouched
+        assert m1.item() == 0
+        return
     A64, W64 = A[:M, :K].numpy().astype(np.float64), W.numpy().astype(np.float64)
     ref = (A64 @ W64) * np.where(side[:M, :N].numpy() > 0, 1.0, slope)
     mag = np.abs(A64) @ np.abs(W64)
