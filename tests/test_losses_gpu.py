@@ -37,6 +37,7 @@ def test_shipped_loss_matches_oracle(R, frac_valid, fw):
     (total * 1.0).backward()
     p = parts.cpu().numpy()
     rt = float(ref_total.detach())
+    lc, lz = lc.detach(), lz.detach()
     assert abs(p[0] - rt) <= 2e-6 * max(1.0, abs(rt))
     assert abs(p[1] - float(lc)) <= 2e-6 * max(1e-3, float(lc)) and abs(p[2] - float(lz)) <= 2e-6 * abs(float(lz))
     assert int(p[3]) == int(mask.sum())
