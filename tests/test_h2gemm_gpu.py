@@ -247,31 +247,48 @@ _WGRAD_AB = r'''
 import sys, hashlib, numpy as np, torch
 sys.path.insert(0, sys.argv[1])
 from hybridneuralrendering_amd import _lib
+from tests.test_h2gemm_gpu import pack, _sign_words
 L = _lib.lib()
 dev = torch.device("cuda:0")
-M, N, K = 40000, 256, 256
-g = torch.Generator(device="cpu").manual_seed(12)
-Z, X = (torch.randn((M, N), generator=g) * 0.1).to(dev), torch.randn((M, K), generator=g).to(dev)
+h = hashlib.sha1()
 one = torch.tensor([np.float32(1.0).view(np.int32)], dtype=torch.int32, device=dev)
 big = torch.tensor([np.float32(8.0).view(np.int32)], dtype=torch.int32, device=dev)
-scratch = torch.empty((int(L.hnr_h2wgrad_scratch_bytes(N, K)),), dtype=torch.uint8, device=dev)
-dW, db = torch.empty((N, K), device=dev), torch.empty((N,), device=dev)
-_lib.check(L.hnr_h2wgrad(_lib.ptr(Z), N, _lib.ptr(X), K, M, None, 1, 0, N, K, _lib.ptr(one), _lib.ptr(big), _lib.ptr(dW), K, _lib.ptr(db), 0, _lib.ptr(scratch), _lib.stream()), "hnr_h2wgrad")
-h = hashlib.sha1(); h.update(dW.cpu().numpy().tobytes()); h.update(db.cpu().numpy().tobytes())
+# weight gradients of the 256-wide shapes (ragged row counts, the ninth tile empty / partly full / full, padded row strides)
+for M, N, K, ldz, ldx in ((40000, 256, 256, 256, 256), (33333, 256, 263, 264, 264), (777, 256, 287, 256, 288), (5, 256, 256, 264, 256)):
+    g = torch.Generator(device="cpu").manual_seed(12 + M)
+    Z, X = (torch.randn((M, ldz), generator=g) * 0.1).to(dev), torch.randn((M, ldx), generator=g).to(dev)
+    scratch = torch.empty((int(L.hnr_h2wgrad_scratch_bytes(N, K)),), dtype=torch.uint8, device=dev)
+    dW, db = torch.empty((N, K), device=dev), torch.empty((N,), device=dev)
+    _lib.check(L.hnr_h2wgrad(_lib.ptr(Z), ldz, _lib.ptr(X), ldx, M, None, 1, 0, N, K, _lib.ptr(one), _lib.ptr(big), _lib.ptr(dW), K, _lib.ptr(db), 0, _lib.ptr(scratch), _lib.stream()), "hnr_h2wgrad")
+    h.update(dW.cpu().numpy().tobytes()); h.update(db.cpu().numpy().tobytes())
+# input gradients through the sign words (HNR_H2LIN_WS: weight-stationary / streaming kernel)
+for M_cap, M, lda, ldc in ((20000 // 32 * 32, 19990, 256, 256), (4096, 4096, 264, 264), (64, 3, 256, 264)):
+    g = torch.Generator(device="cpu").manual_seed(7 + M)
+    A = (torch.randn((M_cap, lda), generator=g) * torch.exp(2.0 * torch.randn((M_cap, 1), generator=g))).to(dev)
+    W = (torch.randn((256, 256), generator=g) / 16).to(dev)
+    side = torch.randn((M_cap, 256), generator=g)
+    img = pack([W], transposed=[True])[0]
+    bits = torch.from_numpy(_sign_words(side.numpy(), M_cap)).to(dev)
+    C = torch.full((M_cap, ldc), 7.0, device=dev)
+    mx = torch.zeros(1, dtype=torch.int32, device=dev)
+    dm = torch.tensor([M], dtype=torch.int64, device=dev)
+    _lib.check(L.hnr_h2lin_dgrad_bits(_lib.ptr(A), lda, M_cap, _lib.ptr(dm), _lib.ptr(img), 256, 256, 0.01, _lib.ptr(bits), _lib.ptr(C), ldc, _lib.ptr(mx), _lib.stream()), "dgrad_bits")
+    h.update(C.cpu().numpy().tobytes()); h.update(mx.cpu().numpy().tobytes())
 print("WGRAD_SHA", h.hexdigest())
 '''
 
 
-def test_dma_staged_weight_gradient_equals_the_register_staged_kernel_bit_for_bit(tmp_path):
-    """h2wgrad_dma_kernel (fp32 rows global -> LDS by DMA; the default for 256-wide layers) against h2wgrad_kernel<8,9,1,0,1> (HNR_WGRAD_DMA=0) on the
-    same seeded operands, in two processes (the choice is read once per process): identical dW and db (round-4 advice: the claim had no test)."""
+def test_kernel_forms_of_the_256_wide_layers_agree_bit_for_bit(tmp_path):
+    """The forms a 256-wide layer's gradients can run in give the same bits on the same seeded operands (the choices are read once per process: one
+    process per form): weight gradient specialised for N = 256 / plain rows (HNR_WGRAD_DMA=1, the default) = the general DMA-staged kernel (=2) = the
+    register-staged one (=0); input gradient weight-stationary (HNR_H2LIN_WS=1, the default) = streaming (=0)."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "w.py"
     script.write_text(_WGRAD_AB)
     sha = []
-    for v in ("1", "0"):
-        p = subprocess.run([sys.executable, str(script), root], capture_output=True, text=True, timeout=600, env=dict(os.environ, HNR_WGRAD_DMA=v))
+    for dma, ws in (("1", "1"), ("2", "0"), ("0", "1")):
+        p = subprocess.run([sys.executable, str(script), root], capture_output=True, text=True, timeout=600, env=dict(os.environ, HNR_WGRAD_DMA=dma, HNR_H2LIN_WS=ws))
         assert p.returncode == 0, p.stderr[-2000:]
         sha.append([l for l in p.stdout.splitlines() if l.startswith("WGRAD_SHA")][0])
-    assert sha[0] == sha[1], sha
+    assert sha[0] == sha[1] == sha[2], sha
