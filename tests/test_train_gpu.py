@@ -187,6 +187,30 @@ def test_train_step_matches_oracle_on_a_fresh_batch():
     _check_grads(got, ref64, "vs fp64", tol_weights=TOL_POINTS)
 
 
+def test_train_step_on_a_batch_that_hits_nothing():
+    """The camera stands far outside the cloud: zero valid samples run through every kernel of the step (device-side row counts of 0 -- the
+    weight-stationary input gradient and the weight-gradient kernels among them).  The reference's loss for such a batch is the regulariser alone
+    (colour loss set to 0, base_rendering_model.py:1144); all gradients are exact zeros and nothing hangs or reads out of bounds."""
+    from hybridneuralrendering_amd.train import train_step
+    d, ti, opt, agg, path = _setup()
+    dev = ti["emb"].device
+    near, far = d["near_far"]
+    raydir = ti["raydir"][0]
+    campos = (ti["campos"][0] + 1000.0).contiguous()                       # a kilometre away: no ray meets the grid between near and far
+    gt = torch.rand((raydir.shape[0], 3), device=dev)
+    emb, conf, pdir, color = _leaves(ti)
+    for _ in range(2):                                                     # twice: the second step reuses the buffers of the first
+        out, pg, ag = train_step(path, agg, ti["xyz"], emb, conf, pdir, color, raydir.contiguous(), campos, ti["camrotc2w"][0], ti["bg_color"][0], near, far,
+                                 ti["c2w_nearest"][0], ti["campos_nearest"][0], ti["intrinsic_nearest"][0], ti["images_nearest"][0], gt,
+                                 zero_epsilon=float(d["zero_epsilon"]), assign_grads=False)
+        torch.cuda.synchronize()
+        path.check_status(out)
+        assert int(out["ray_mask"].sum()) == 0 and int(out["counts"][6]) == 0
+        assert torch.isfinite(out["loss"]).all()
+        for k, g in list(pg.items()) + list(ag.items()):
+            assert torch.isfinite(g).all() and float(g.abs().max()) == 0.0, k
+
+
 def test_train_step_keeps_the_two_frame_weights_apart():
     """The item's scalar `frame_weight` multiplies loss_total (models/base_rendering_model.py:1204-1205); `frame_weight_nearest` [1,V] scales the
     per-view merge weights (models/aggregators/point_aggregators.py:1202-1203).  train_step takes them as two arguments (one
