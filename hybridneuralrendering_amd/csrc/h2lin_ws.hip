@@ -235,10 +235,8 @@ __global__ __launch_bounds__(256, 1) void h2lin_ws_kernel(H2LinWsArgs a)
             float v = fmaf(acc[OTH][c][vi], inv, 0.f);
             // x (bit ? 1 : slope) without a compare: the bit spread over a word (v_bfe_i32), then a bit-field select between the two constants -- no SGPR
             // pair written by a VALU instruction and read by the next (a hazard nop behind every v_cmp / v_cndmask pair)
-            int sel;
-            asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(sel) : "v"(bits), "n"(31 - (16 * c + vi)));
-            unsigned fac;
-            asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(fac) : "v"(sel), "v"(0x3f800000u), "v"(slope_bits));
+            unsigned fac;                                                  // (one asm statement: the compiler pads every asm whose result is used next with a nop)
+            asm("v_bfe_i32 %0, %1, %2, 1\n\tv_bfi_b32 %0, %0, %3, %4" : "=&v"(fac) : "v"(bits), "n"(31 - (16 * c + vi)), "v"(0x3f800000u), "v"(slope_bits));
             v = __fmul_rn(v, __uint_as_float(fac));
             acc[OTH][c][vi] = v;
             gmax = fmaxf(gmax, fabsf(v));
